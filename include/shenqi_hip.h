@@ -1,0 +1,232 @@
+/* shenqi_hip.h — C-ABI of the MI355X (gfx950) TreePM + SPH force engine.
+ *
+ * This is the drop-in boundary for shenqi's device seam: the four free functions the
+ * reference calls when `UseGPU` is set,
+ *     grav_short_tree_cuda   (libgadget/gravshort2.hpp:440-443, caller gravshort-tree2.cpp:151-154)
+ *     density_cuda           (libgadget/densitytree2.hpp:437-439, caller density2.cpp:116-119)
+ *     hydro_force_cuda       (libgadget/hydratree2.hpp:391-393,  caller hydra2.cpp:89-91)
+ *     petapm_fft_r2c/_c2r + the host PM deposit/transfer/readout loops
+ *                            (libgadget/petapm.h:136,143-144; petapm.cpp:392-465)
+ * All entry points are extern "C", take plain pointers / sizes / POD structs and return an int
+ * status (0 = ok).  On failure shq_last_error() returns a message; the shenqi-side shim turns
+ * a non-zero status into endrun() (reference error convention: libgadget/utils/endrun.h:6,
+ * device-launch check treewalk2.cuh:326-328).
+ *
+ * Ownership: the caller owns every host array; the library owns all device memory (its own
+ * pools, never the caller's allocator: reference arena is LIFO, utils/memory.c).
+ * Threading: one context per rank/GPU, calls come from the rank's main thread
+ * (MPI_THREAD_FUNNELED, gadget/main.cpp:35).  Calls are synchronous unless stated.
+ *
+ * Two levels are offered:
+ *   one-shot  (shq_grav_short_tree, shq_pm_force, shq_density, shq_hydro_force):
+ *             host pointers in, host pointers out — what the reference call sites need;
+ *   resident  (shq_particles_upload / shq_tree_upload / *_run / *_download):
+ *             data stays in HBM between calls; used by time-step loops that keep particles
+ *             on the device and by bench.py (timed region starts with inputs in HBM).
+ */
+#ifndef SHENQI_HIP_H
+#define SHENQI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHQ_OK 0
+#define SHQ_ERR_INVALID 1   /* bad argument / inconsistent view */
+#define SHQ_ERR_DEVICE 2    /* HIP runtime / launch failure */
+#define SHQ_ERR_NOMEM 3     /* device allocation failed */
+#define SHQ_ERR_STATE 4     /* call order violated (e.g. run before upload) */
+#define SHQ_ERR_NOCONV 5    /* Hsml iteration did not converge within MAXITER */
+
+#define SHQ_NGRAVTAB 512    /* NGRAVTAB, libgadget/gravity.h:35 */
+#define SHQ_NMAXCHILD 8     /* NMAXCHILD, libgadget/forcetree.h:13 */
+#define SHQ_NODELISTLENGTH 4 /* NODELISTLENGTH, libgadget/localtreewalk2.h */
+#define SHQ_TIMEBINS 46     /* TIMEBINS, libgadget/timebinmgr.h */
+
+typedef struct shq_context shq_context;
+
+/* ---- context ------------------------------------------------------------------------- */
+
+/* Create a context on HIP device `device`.  `stream` is a hipStream_t to launch on (e.g.
+ * torch's current stream) or NULL for a library-owned stream. */
+int shq_init(int device, void *stream, shq_context **out);
+void shq_shutdown(shq_context *ctx);
+/* Last error message of the calling thread ("" if none). */
+const char *shq_last_error(void);
+/* Block until all work queued on the context's stream has finished. */
+int shq_synchronize(shq_context *ctx);
+/* The hipStream_t the context launches on (for event timing by the caller). */
+void *shq_stream(shq_context *ctx);
+/* HIP-event timer on the context's stream: begin/end bracket; elapsed returns ms of slot. */
+int shq_timer_begin(shq_context *ctx, int slot);
+int shq_timer_end(shq_context *ctx, int slot);
+int shq_timer_elapsed_ms(shq_context *ctx, int slot, double *ms);
+/* Library version string. */
+const char *shq_version(void);
+
+/* ---- data views (reference layouts, no copies on the host side) ---------------------- */
+
+/* Strided AoS view of `struct particle_data` (libgadget/partmanager.h:9-71), in the spirit of
+ * PetaPMParticleStruct (libgadget/petapm.h:62-72): base pointer + element size + byte offsets.
+ * An offset of SHQ_NOFIELD means "field not supplied". */
+#define SHQ_NOFIELD ((size_t)-1)
+typedef struct shq_part_view {
+    void *base;             /* PartManager->Base */
+    size_t elsize;          /* sizeof(struct particle_data) = 160 */
+    int64_t numpart;        /* PartManager->NumPart */
+    size_t off_pos;         /* double Pos[3] */
+    size_t off_mass;        /* float  Mass */
+    size_t off_type;        /* unsigned char Type */
+    size_t off_flags;       /* unsigned int bitfield word: bit0 IsGarbage, bit1 Swallowed */
+    size_t off_pi;          /* int PI (slot index) */
+    size_t off_vel;         /* double Vel[3] */
+    size_t off_treeacc;     /* double FullTreeGravAccel[3] */
+    size_t off_gravpm;      /* double GravPM[3] */
+    size_t off_potential;   /* double Potential */
+    size_t off_hsml;        /* double Hsml */
+    size_t off_dthsml;      /* double DtHsml */
+    size_t off_timebin_hydro;   /* unsigned char TimeBinHydro */
+    size_t off_timebin_gravity; /* unsigned char TimeBinGravity */
+} shq_part_view;
+
+/* Strided view of `struct sph_particle_data` (libgadget/slotsmanager.h:97-131), indexed by PI. */
+typedef struct shq_sph_view {
+    void *base;
+    size_t elsize;          /* 176 */
+    int64_t numslots;
+    size_t off_density, off_egywtdensity, off_entropy, off_dtentropy, off_maxsignalvel;
+    size_t off_hydroaccel;  /* double[3] */
+    size_t off_dhsmlegydensityfactor, off_divvel, off_curlvel, off_delaytime;
+} shq_sph_view;
+
+/* Binary mirror of `struct NODE` (libgadget/forcetree.h:38-66), 120 bytes, so the host tree
+ * (forcetree.cpp keeps ownership) is passed as-is. */
+typedef struct shq_node {
+    int32_t sibling;
+    int32_t father;
+    double len;
+    double center[3];
+    double cofm[3];     /* mom.cofm */
+    double mass;        /* mom.mass */
+    double hmax;        /* mom.hmax */
+    int32_t suns[SHQ_NMAXCHILD];
+    int32_t noccupied;
+    uint32_t flags;     /* bit0 InternalTopLevel, bit1 TopLevel, bit2 DependsOnLocalMass, bits3-4 ChildType */
+} shq_node;
+#define SHQ_NODE_INTERNALTOPLEVEL(f) ((f) & 1u)
+#define SHQ_NODE_TOPLEVEL(f) (((f) >> 1) & 1u)
+#define SHQ_NODE_CHILDTYPE(f) (((f) >> 3) & 3u)
+#define SHQ_PARTICLE_NODE_TYPE 0
+#define SHQ_NODE_NODE_TYPE 1
+#define SHQ_PSEUDO_NODE_TYPE 2
+
+/* View of `ForceTree` (libgadget/forcetree.h:75-112). Index space as in the reference:
+ * [0,firstnode) particles, [firstnode,firstnode+numnodes) nodes, >= lastnode pseudo. */
+typedef struct shq_tree_view {
+    const shq_node *nodes_base;  /* ForceTree.Nodes_base (Nodes = nodes_base - firstnode) */
+    int64_t firstnode;
+    int64_t lastnode;
+    int64_t numnodes;
+    int32_t rootnode;            /* node the primary walk starts from (== firstnode) */
+    int32_t full_particle_tree_flag;
+    double BoxSize;
+} shq_tree_view;
+
+/* ---- short-range gravity -------------------------------------------------------------- */
+
+/* POD mirror of GravTreeParams (libgadget/gravshort2.hpp:21-55) incl. GravShortTable
+ * (libgadget/gravity.h:32-61) held by value exactly as the reference does. */
+typedef struct shq_grav_params {
+    double BoxSize;
+    double cellsize;        /* BoxSize / Nmesh */
+    double Rcut;            /* TreeParams.Rcut * Asmth * cellsize */
+    double G;
+    double cbrtrho0;
+    double ForceSoftening;  /* FORCE_SOFTENING() = 2.8 * GravitySoftening */
+    double ErrTolForceAcc;
+    double BHOpeningAngle2; /* already squared; = MaxBHOpeningAngle^2 when TreeUseBH == 0 */
+    int32_t TreeUseBH;
+    int32_t pad_;
+    float shortrange_table[SHQ_NGRAVTAB];
+    float shortrange_table_potential[SHQ_NGRAVTAB];
+    double dx;              /* table spacing in mesh cells */
+} shq_grav_params;
+
+typedef struct shq_walk_stats {
+    int64_t ntargets;
+    int64_t ninteractions;      /* sum over targets of the reference's visit() return value */
+    int64_t min_interactions;
+    int64_t max_interactions;
+    int64_t nnodes_visited;     /* node tests executed by wavefronts (union walk) */
+    double kernel_ms;           /* HIP-event time of the walk kernel(s) */
+} shq_walk_stats;
+
+/* Walk flavours. EXACT reproduces the reference's per-target opening decisions and
+ * interaction set (parity bar runtests.cpp:441-443). */
+#define SHQ_WALK_EXACT 0
+#define SHQ_WALK_GROUP 1
+
+/* One-shot replacement of grav_short_tree_cuda(): walks the local tree for the `nactive`
+ * targets in `active` (NULL => all particles, as ActiveParticles with a NULL list), writes
+ * Accel[target][0..2] (already multiplied by G: GravTreeOutput::postprocess,
+ * gravshort2.hpp:88-107) and, when update_potential, also FullTreeGravAccel and Potential
+ * inside the particle view. `accel` is indexed by particle index, numpart rows. */
+int shq_grav_short_tree(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts,
+                        const int32_t *active, int64_t nactive, const shq_grav_params *params,
+                        double (*accel)[3], int update_potential, int walk_mode,
+                        shq_walk_stats *stats);
+
+/* Resident API. */
+int shq_particles_upload(shq_context *ctx, const shq_part_view *parts);
+int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree);
+/* active: host int32 list or NULL. The walk and postprocess are queued on the stream. */
+int shq_grav_short_run(shq_context *ctx, const shq_grav_params *params, const int32_t *active,
+                       int64_t nactive, int update_potential, int walk_mode);
+/* Copy results back: accel[numpart][3] (may be NULL), potential[numpart] (may be NULL),
+ * ninteractions[numpart] (may be NULL). Synchronises. */
+int shq_grav_short_download(shq_context *ctx, double (*accel)[3], double *potential,
+                            int64_t *ninteractions, shq_walk_stats *stats);
+/* Set the per-particle OldAcc inputs on the device from the device-resident
+ * FullTreeGravAccel + GravPM of the last shq_grav_short_run / shq_pm_run
+ * (grav_get_abs_accel, gravshort2.hpp:111-121). */
+int shq_grav_refresh_oldacc(shq_context *ctx, double G);
+
+/* ---- long-range PM --------------------------------------------------------------------- */
+
+/* Mirror of the PetaPM fields gravpm.cpp reads (libgadget/petapm.h:87-112). */
+typedef struct shq_pm_params {
+    int32_t Nmesh;
+    int32_t pad_;
+    double BoxSize;
+    double Asmth;
+    double G;
+} shq_pm_params;
+
+/* One-shot replacement of gravpm_force()'s compute (gravpm.cpp:60-119 minus tree/regions/P(k)):
+ * zero GravPM, CIC deposit, r2c, potential_transfer, c2r, readout.  Writes
+ * gravpm[numpart][3] and ADDS the PM potential into potential[numpart] (readout_potential,
+ * gravpm.cpp:489-491) when potential != NULL.  Particles with the Swallowed flag are skipped
+ * (RegionInd = -2, gravpm.cpp:176-178). */
+int shq_pm_force(shq_context *ctx, const shq_pm_params *pm, const shq_part_view *parts,
+                 double (*gravpm)[3], double *potential);
+/* Resident: uses the uploaded particles. */
+int shq_pm_run(shq_context *ctx, const shq_pm_params *pm);
+int shq_pm_download(shq_context *ctx, double (*gravpm)[3], double *pm_potential);
+/* Debug / parity taps: copy the mesh after deposit (Nmesh^3 doubles, [x][y][z]) and the
+ * potential mesh after c2r. Valid after shq_pm_run with keep_meshes set. */
+int shq_pm_set_debug(shq_context *ctx, int keep_meshes);
+int shq_pm_download_mesh(shq_context *ctx, int which /*0 density,1 potential*/, double *mesh);
+
+/* Drop-ins for petapm_fft_r2c / petapm_fft_c2r (libgadget/petapm.cpp:49-71): unscaled
+ * single-rank 3-D transforms of an Nmesh^3 real array ([x][y][z], z fastest) to/from its
+ * half-spectrum ([x][y][z'], z' <= Nmesh/2). Host pointers. */
+int shq_fft_r2c(shq_context *ctx, int Nmesh, const double *real, double *complx);
+int shq_fft_c2r(shq_context *ctx, int Nmesh, const double *complx, double *real);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHENQI_HIP_H */

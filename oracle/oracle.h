@@ -1,0 +1,75 @@
+/* oracle.h — CPU restatement of the reference algorithms on the TreePM+SPH force path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under shenqi_amd/ may include, link or call this.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ *
+ * Every function cites the reference file:line (relative to /root/reference) it restates.
+ * Pinning: see oracle/README.md (reference golden values of tests/test_densitykernel.cpp, the
+ * reference's own accuracy gates of tests/test_gravity.cpp / tests/test_density.cpp /
+ * runtests.cpp, and the short-range table compiled from the reference's own data file into
+ * oracle/_ref/).
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#include "../include/shenqi_hip.h" /* POD layouts only (shq_node, shq_grav_params, ...) */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* libgadget/partmanager.h:99 */
+static inline double orc_nearest(double x, double BoxSize)
+{
+    return (x > 0.5 * BoxSize) ? (x - BoxSize) : ((x < -0.5 * BoxSize) ? (x + BoxSize) : x);
+}
+
+/* ---- tree (libgadget/forcetree.cpp) ---- */
+/* Build the oct-tree by sequential insertion of particles idx[0..n) (NULL => 0..n-1), then
+ * compute moments, sibling threading and remove empty leaves.  nodes must hold maxnodes
+ * entries.  Node index space: firstnode == numpart_total.  hsml may be NULL (hmax = 0).
+ * Returns number of nodes used, or -1 if maxnodes is too small. */
+int64_t orc_tree_build(const double *pos, const float *mass, const double *hsml,
+                       const int32_t *idx, int64_t n, int64_t numpart_total, double BoxSize,
+                       shq_node *nodes, int64_t maxnodes, int32_t *father);
+
+/* ---- short-range gravity (libgadget/gravshort2.hpp) ---- */
+/* Per-target stackless primary walk; acc_out[n][3], pot_out[n] raw (before postprocess),
+ * nint_out[n].  oldacc = |FullTreeGravAccel+GravPM|/G per particle. targets NULL => all. */
+void orc_grav_walk(const shq_node *nodes, int64_t firstnode, const double *pos,
+                   const float *mass, const double *oldacc, const int32_t *targets,
+                   int64_t ntargets, const shq_grav_params *p, double *acc_out,
+                   double *pot_out, int64_t *nint_out);
+/* GravTreeOutput::postprocess (gravshort2.hpp:88-107): in place on acc/pot for target list. */
+void orc_grav_postprocess(const float *mass, const int32_t *targets, int64_t ntargets,
+                          const shq_grav_params *p, int update_potential, double *acc,
+                          double *pot);
+/* Single interaction (apply_accn, gravshort2.hpp:326-358); returns 1 if applied. */
+int orc_apply_accn(const double dx[3], double r2, double mass, const shq_grav_params *p,
+                   double acc[3], double *pot);
+/* Direct summation with +-repeat periodic images and the spline softening, as
+ * tests/test_gravity.cpp:41-76,121-143 (force_direct / grav_force). */
+void orc_force_direct(const double *pos, const float *mass, int64_t n, double BoxSize, double G,
+                      double h, int repeat, double *accn);
+
+/* ---- PM (libgadget/petapm.cpp, gravpm.cpp) ---- */
+/* Full PM force: CIC deposit, r2c, potential_transfer, 4x (transfer + c2r), CIC readout.
+ * fixed_point_log2scale < 0: plain f64 deposit; >= 0: deposit rounds each contribution to a
+ * multiple of 2^-scale (the device's order-independent integer deposit). mesh_rho / mesh_pot
+ * (Nmesh^3, may be NULL) receive the deposited mass mesh and the potential mesh.
+ * use_stencil: 0 = four k-space transfers + c2r as the reference; 1 = one c2r + real-space
+ * 4-point differencing (mathematically identical symbol). */
+void orc_pm_force(const double *pos, const float *mass, const uint8_t *skip, int64_t n,
+                  const shq_pm_params *pm, int fixed_point_log2scale, int use_stencil,
+                  double *gravpm, double *potential, double *mesh_rho, double *mesh_pot);
+/* Unscaled 3-D r2c / c2r on an N^3 mesh, layouts [x][y][z] <-> [x][y][z'<=N/2] complex. */
+void orc_fft_r2c(int N, const double *real, double *complx);
+void orc_fft_c2r(int N, const double *complx, double *real);
+
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

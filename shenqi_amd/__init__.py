@@ -1,0 +1,171 @@
+"""shenqi_amd — MI355X-native TreePM + SPH force engine behind shenqi's operator API.
+
+Thin Python driver over two native libraries:
+  lib/libshenqi_hip.so   hand-written HIP (gfx950) kernels + the C-ABI (include/shenqi_hip.h)
+  lib/libshenqi_host.so  C++ host mirror of the reference operator interface
+                         (force_tree_full, grav_short_tree, gravpm_force, ...)
+Names follow the reference (libgadget/gravity.h, forcetree.h, partmanager.h).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import (PARTICLE_DTYPE, SPH_DTYPE, NODE_DTYPE, WALK_EXACT, WALK_GROUP, GravParams, PMParams,
+                   WalkStats, ShqError)
+
+GASMASK, DMMASK, NUMASK, STARMASK, BHMASK = 1, 2, 4, 16, 32
+ALLMASK = (1 << 6) - 1
+SHORTRANGE_FORCE_WINDOW_TYPE_EXACT = 1
+SHORTRANGE_FORCE_WINDOW_TYPE_ERFC = 2
+
+
+class Context:
+    """One library context per rank / GPU (shq_init)."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        capi.check(capi.hip.shq_init(device, stream, C.byref(h)), "shq_init")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            capi.hip.shq_shutdown(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def synchronize(self):
+        capi.check(capi.hip.shq_synchronize(self.h), "shq_synchronize")
+
+    def timer_begin(self, slot):
+        capi.check(capi.hip.shq_timer_begin(self.h, slot))
+
+    def timer_end(self, slot):
+        capi.check(capi.hip.shq_timer_end(self.h, slot))
+
+    def timer_ms(self, slot):
+        ms = C.c_double()
+        capi.check(capi.hip.shq_timer_elapsed_ms(self.h, slot, C.byref(ms)))
+        return ms.value
+
+
+class PartManager:
+    """PartManager[1] of the reference: a particle_data array plus NumPart / BoxSize."""
+
+    def __init__(self, numpart, BoxSize):
+        self.Base = np.zeros(int(numpart), dtype=PARTICLE_DTYPE)
+        self.NumPart = int(numpart)
+        self.BoxSize = float(BoxSize)
+        self._h = capi.host.shqh_partmanager_create(capi.ptr(self.Base), self.NumPart, self.BoxSize)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            capi.host.shqh_partmanager_free(self._h)
+            self._h = None
+
+    def view(self):
+        v = capi.PartView()
+        capi.host.shqh_part_view(self._h, C.byref(v))
+        return v
+
+
+class ForceTree:
+    def __init__(self, handle, pman):
+        self._h = handle
+        self._pman = pman  # keep the particles alive
+        info = (C.c_int64 * 5)()
+        capi.host.shqh_tree_info(handle, C.byref(info))
+        self.firstnode, self.lastnode, self.numnodes, self.NumParticles, self.full_particle_tree_flag = [int(x) for x in info]
+        self.BoxSize = pman.BoxSize
+
+    @property
+    def Nodes_base(self):
+        p = capi.host.shqh_tree_nodes(self._h)
+        buf = (C.c_char * (self.numnodes * 120)).from_address(p)
+        return np.frombuffer(buf, dtype=NODE_DTYPE)
+
+    def view(self):
+        v = capi.TreeView()
+        capi.host.shqh_tree_view(self._h, C.byref(v))
+        return v
+
+    def free(self):
+        if self._h:
+            capi.host.shqh_force_tree_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.free()
+
+
+def force_tree_rebuild_mask(pman, mask, active=None, full=False):
+    act = None if active is None else np.ascontiguousarray(active, dtype=np.int32)
+    h = capi.host.shqh_force_tree_rebuild_mask(pman._h, mask, capi.ptr(act), 0 if act is None else len(act), int(full))
+    if not h:
+        raise ShqError(capi.host.shqh_last_error().decode())
+    return ForceTree(h, pman)
+
+
+def force_tree_full(pman):
+    return force_tree_rebuild_mask(pman, ALLMASK, None, full=True)
+
+
+def set_gravshort_treepar(ErrTolForceAcc=0.002, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=2, Rcut=6.0,
+                          FractionalGravitySoftening=1.0 / 30.0, ShortRangeForceWindowType=SHORTRANGE_FORCE_WINDOW_TYPE_EXACT):
+    capi.host.shqh_set_gravshort_treepar(ErrTolForceAcc, BHOpeningAngle, MaxBHOpeningAngle, TreeUseBH, Rcut,
+                                         FractionalGravitySoftening, ShortRangeForceWindowType)
+
+
+def get_TreeUseBH():
+    return capi.host.shqh_get_TreeUseBH()
+
+
+def gravshort_set_softenings(MeanSeparation):
+    capi.host.shqh_gravshort_set_softenings(MeanSeparation)
+
+
+def FORCE_SOFTENING():
+    return capi.host.shqh_FORCE_SOFTENING()
+
+
+def make_grav_params(BoxSize, Asmth, Nmesh, G, rho0):
+    gp = GravParams()
+    capi.check_host(capi.host.shqh_make_grav_params(BoxSize, Asmth, Nmesh, G, rho0, C.byref(gp)), "make_grav_params")
+    return gp
+
+
+def grav_short_tree(ctx, act, pm, tree, AccelStore, rho0, Ti_Current=0, UseGPU=True, walk_mode=WALK_EXACT, pman=None):
+    """grav_short_tree(act, pm, tree, AccelStore, rho0, Ti_Current, UseGPU), libgadget/gravity.h:89.
+    act: int32 index array or None (all). pm: dict(Asmth, Nmesh, G). Returns WalkStats."""
+    pman = pman or tree._pman
+    stats = WalkStats()
+    a = None if act is None else np.ascontiguousarray(act, dtype=np.int32)
+    rc = capi.host.shqh_grav_short_tree(ctx.h, pman._h, tree._h, pm["Asmth"], pm["Nmesh"], pm["G"], capi.ptr(a),
+                                        0 if a is None else len(a), capi.ptr(AccelStore), rho0, int(UseGPU), walk_mode,
+                                        C.byref(stats))
+    capi.check_host(rc, "grav_short_tree")
+    return stats
+
+
+def gravpm_force(ctx, pm, pman, UseGPU=True):
+    capi.check_host(capi.host.shqh_gravpm_force(ctx.h, pman._h, pm["Asmth"], pm["Nmesh"], pm["G"], int(UseGPU)), "gravpm_force")
+
+
+def synth_positions(kind, n, seed=20240601, L=1.0):
+    """SURVEY §8(d) synthetic inputs: kind 'grid' | 'uniform' | 'cluster'."""
+    k = {"grid": 0, "uniform": 1, "cluster": 2}[kind]
+    pos = np.empty((int(n), 3), dtype=np.float64)
+    capi.host.shqh_synth_positions(k, int(n), seed, L, capi.ptr(pos))
+    return pos
+
+
+def morton_order(pos, L):
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    order = np.empty(len(pos), dtype=np.int32)
+    capi.host.shqh_morton_order(capi.ptr(pos), len(pos), L, capi.ptr(order))
+    return order

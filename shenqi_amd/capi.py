@@ -1,0 +1,219 @@
+"""ctypes bindings of the C-ABI (include/shenqi_hip.h) and of the host mirror library.
+
+The compute lives in shenqi_amd/lib/libshenqi_hip.so (hand-written HIP for gfx950).  There is
+no Python or CPU fallback: if the library is missing, importing this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBDIR = os.path.join(_HERE, "lib")
+DATADIR = os.path.join(_HERE, "data")
+
+NGRAVTAB = 512
+NMAXCHILD = 8
+NOFIELD = C.c_size_t(-1).value
+
+WALK_EXACT = 0
+WALK_GROUP = 1
+
+
+class ShqError(RuntimeError):
+    """Non-zero status from the library (the shim's endrun() equivalent)."""
+
+
+def _load(name):
+    path = os.path.join(LIBDIR, name)
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). shenqi_amd has no fallback path."
+        )
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+hip = _load("libshenqi_hip.so")
+host = _load("libshenqi_host.so")
+
+
+# ---- POD mirrors ---------------------------------------------------------------------------
+class PartView(C.Structure):
+    _fields_ = [
+        ("base", C.c_void_p), ("elsize", C.c_size_t), ("numpart", C.c_int64),
+        ("off_pos", C.c_size_t), ("off_mass", C.c_size_t), ("off_type", C.c_size_t),
+        ("off_flags", C.c_size_t), ("off_pi", C.c_size_t), ("off_vel", C.c_size_t),
+        ("off_treeacc", C.c_size_t), ("off_gravpm", C.c_size_t), ("off_potential", C.c_size_t),
+        ("off_hsml", C.c_size_t), ("off_dthsml", C.c_size_t),
+        ("off_timebin_hydro", C.c_size_t), ("off_timebin_gravity", C.c_size_t),
+    ]
+
+
+class Node(C.Structure):
+    _fields_ = [
+        ("sibling", C.c_int32), ("father", C.c_int32), ("len", C.c_double),
+        ("center", C.c_double * 3), ("cofm", C.c_double * 3), ("mass", C.c_double),
+        ("hmax", C.c_double), ("suns", C.c_int32 * NMAXCHILD), ("noccupied", C.c_int32),
+        ("flags", C.c_uint32),
+    ]
+
+
+NODE_DTYPE = np.dtype(
+    {
+        "names": ["sibling", "father", "len", "center", "cofm", "mass", "hmax", "suns", "noccupied", "flags"],
+        "formats": ["<i4", "<i4", "<f8", ("<f8", 3), ("<f8", 3), "<f8", "<f8", ("<i4", 8), "<i4", "<u4"],
+        "offsets": [0, 4, 8, 16, 40, 64, 72, 80, 112, 116],
+        "itemsize": 120,
+    }
+)
+assert C.sizeof(Node) == 120
+
+# struct particle_data, libgadget/partmanager.h:9-71 (160 B)
+PARTICLE_DTYPE = np.dtype(
+    {
+        "names": ["Pos", "TopLeaf", "Mass", "PI", "Flags", "TimeBinHydro", "TimeBinGravity", "Type", "Vel",
+                  "FullTreeGravAccel", "GravPM", "Ti_drift", "Hsml", "DtHsml", "ID", "GrNr", "Potential"],
+        "formats": [("<f8", 3), "<i4", "<f4", "<i4", "u1", "u1", "u1", "u1", ("<f8", 3), ("<f8", 3), ("<f8", 3),
+                    "<i8", "<f8", "<f8", "<u8", "<i8", "<f8"],
+        "offsets": [0, 24, 28, 32, 36, 37, 38, 39, 40, 64, 88, 112, 120, 128, 136, 144, 152],
+        "itemsize": 160,
+    }
+)
+
+# struct sph_particle_data, libgadget/slotsmanager.h:97-131 (176 B)
+SPH_DTYPE = np.dtype(
+    {
+        "names": ["ReverseLink", "Density", "EgyWtDensity", "Entropy", "DtEntropy", "MaxSignalVel", "HydroAccel",
+                  "DhsmlEgyDensityFactor", "DivVel", "CurlVel", "Sfr", "Ne", "VDisp", "DelayTime", "Metallicity", "Metals"],
+        "formats": ["<i4", "<f8", "<f8", "<f8", "<f8", "<f8", ("<f8", 3), "<f8", "<f8", "<f8", "<f8", "<f8", "<f8",
+                    "<f8", "<f8", ("<f4", 9)],
+        "offsets": [0, 8, 16, 24, 32, 40, 48, 72, 80, 88, 96, 104, 112, 120, 128, 136],
+        "itemsize": 176,
+    }
+)
+
+
+class TreeView(C.Structure):
+    _fields_ = [
+        ("nodes_base", C.c_void_p), ("firstnode", C.c_int64), ("lastnode", C.c_int64),
+        ("numnodes", C.c_int64), ("rootnode", C.c_int32), ("full_particle_tree_flag", C.c_int32),
+        ("BoxSize", C.c_double),
+    ]
+
+
+class GravParams(C.Structure):
+    _fields_ = [
+        ("BoxSize", C.c_double), ("cellsize", C.c_double), ("Rcut", C.c_double), ("G", C.c_double),
+        ("cbrtrho0", C.c_double), ("ForceSoftening", C.c_double), ("ErrTolForceAcc", C.c_double),
+        ("BHOpeningAngle2", C.c_double), ("TreeUseBH", C.c_int32), ("pad_", C.c_int32),
+        ("shortrange_table", C.c_float * NGRAVTAB), ("shortrange_table_potential", C.c_float * NGRAVTAB),
+        ("dx", C.c_double),
+    ]
+
+
+class WalkStats(C.Structure):
+    _fields_ = [
+        ("ntargets", C.c_int64), ("ninteractions", C.c_int64), ("min_interactions", C.c_int64),
+        ("max_interactions", C.c_int64), ("nnodes_visited", C.c_int64), ("kernel_ms", C.c_double),
+    ]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class PMParams(C.Structure):
+    _fields_ = [("Nmesh", C.c_int32), ("pad_", C.c_int32), ("BoxSize", C.c_double), ("Asmth", C.c_double),
+                ("G", C.c_double)]
+
+
+# ---- prototypes ------------------------------------------------------------------------------
+_vp = C.c_void_p
+hip.shq_last_error.restype = C.c_char_p
+hip.shq_version.restype = C.c_char_p
+hip.shq_init.argtypes = [C.c_int, _vp, C.POINTER(_vp)]
+hip.shq_shutdown.argtypes = [_vp]
+hip.shq_shutdown.restype = None
+hip.shq_synchronize.argtypes = [_vp]
+hip.shq_stream.argtypes = [_vp]
+hip.shq_stream.restype = _vp
+hip.shq_timer_begin.argtypes = [_vp, C.c_int]
+hip.shq_timer_end.argtypes = [_vp, C.c_int]
+hip.shq_timer_elapsed_ms.argtypes = [_vp, C.c_int, C.POINTER(C.c_double)]
+hip.shq_particles_upload.argtypes = [_vp, C.POINTER(PartView)]
+hip.shq_tree_upload.argtypes = [_vp, C.POINTER(TreeView)]
+hip.shq_grav_short_run.argtypes = [_vp, C.POINTER(GravParams), _vp, C.c_int64, C.c_int, C.c_int]
+hip.shq_grav_short_download.argtypes = [_vp, _vp, _vp, _vp, C.POINTER(WalkStats)]
+hip.shq_grav_refresh_oldacc.argtypes = [_vp, C.c_double]
+hip.shq_grav_short_tree.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), _vp, C.c_int64,
+                                    C.POINTER(GravParams), _vp, C.c_int, C.c_int, C.POINTER(WalkStats)]
+hip.shq_pm_force.argtypes = [_vp, C.POINTER(PMParams), C.POINTER(PartView), _vp, _vp]
+hip.shq_pm_run.argtypes = [_vp, C.POINTER(PMParams)]
+hip.shq_pm_download.argtypes = [_vp, _vp, _vp]
+hip.shq_pm_set_debug.argtypes = [_vp, C.c_int]
+hip.shq_pm_download_mesh.argtypes = [_vp, C.c_int, _vp]
+hip.shq_fft_r2c.argtypes = [_vp, C.c_int, _vp, _vp]
+hip.shq_fft_c2r.argtypes = [_vp, C.c_int, _vp, _vp]
+
+host.shqh_last_error.restype = C.c_char_p
+host.shqh_partmanager_create.argtypes = [_vp, C.c_int64, C.c_double]
+host.shqh_partmanager_create.restype = _vp
+host.shqh_partmanager_free.argtypes = [_vp]
+host.shqh_partmanager_free.restype = None
+host.shqh_force_tree_rebuild_mask.argtypes = [_vp, C.c_int, _vp, C.c_int64, C.c_int]
+host.shqh_force_tree_rebuild_mask.restype = _vp
+host.shqh_force_tree_free.argtypes = [_vp]
+host.shqh_force_tree_free.restype = None
+host.shqh_tree_info.argtypes = [_vp, C.POINTER(C.c_int64 * 5)]
+host.shqh_tree_info.restype = None
+host.shqh_tree_nodes.argtypes = [_vp]
+host.shqh_tree_nodes.restype = _vp
+host.shqh_tree_father.argtypes = [_vp]
+host.shqh_tree_father.restype = _vp
+host.shqh_tree_view.argtypes = [_vp, C.POINTER(TreeView)]
+host.shqh_tree_view.restype = None
+host.shqh_part_view.argtypes = [_vp, C.POINTER(PartView)]
+host.shqh_part_view.restype = None
+host.shqh_set_kernel_table.argtypes = [_vp]
+host.shqh_set_gravshort_treepar.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int]
+host.shqh_set_gravshort_treepar.restype = None
+host.shqh_gravshort_set_softenings.argtypes = [C.c_double]
+host.shqh_gravshort_set_softenings.restype = None
+host.shqh_FORCE_SOFTENING.restype = C.c_double
+host.shqh_make_grav_params.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.POINTER(GravParams)]
+host.shqh_grav_short_tree.argtypes = [_vp, _vp, _vp, C.c_double, C.c_int, C.c_double, _vp, C.c_int64, _vp,
+                                      C.c_double, C.c_int, C.c_int, C.POINTER(WalkStats)]
+host.shqh_gravpm_force.argtypes = [_vp, _vp, C.c_double, C.c_int, C.c_double, C.c_int]
+host.shqh_synth_positions.argtypes = [C.c_int, C.c_int64, C.c_uint64, C.c_double, _vp]
+host.shqh_synth_positions.restype = None
+host.shqh_morton_order.argtypes = [_vp, C.c_int64, C.c_double, _vp]
+host.shqh_morton_order.restype = None
+
+
+def check(rc, where="shq"):
+    if rc != 0:
+        msg = hip.shq_last_error().decode() or host.shqh_last_error().decode()
+        raise ShqError(f"{where} failed with status {rc}: {msg}")
+
+
+def check_host(rc, where="shqh"):
+    if rc != 0:
+        msg = host.shqh_last_error().decode() or hip.shq_last_error().decode()
+        raise ShqError(f"{where} failed with status {rc}: {msg}")
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def load_kernel_table():
+    tab = np.fromfile(os.path.join(DATADIR, "shortrange_force_kernels.f64"), dtype="<f8").reshape(NGRAVTAB, 5)
+    return np.ascontiguousarray(tab)
+
+
+_KERNELS = load_kernel_table()
+host.shqh_set_kernel_table(ptr(_KERNELS))

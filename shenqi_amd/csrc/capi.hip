@@ -1,0 +1,501 @@
+/* capi.hip — the extern "C" boundary of libshenqi_hip (see include/shenqi_hip.h). */
+#include "common.hpp"
+#include <stdarg.h>
+#include <string.h>
+#include <math.h>
+#include <thread>
+#include <atomic>
+#include <algorithm>
+
+static thread_local char g_err[1024] = "";
+
+void shq_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *shq_last_error(void) { return g_err; }
+extern "C" const char *shq_version(void) { return "shenqi_hip 0.1 (gfx950)"; }
+
+namespace {
+
+/* simple host parallel-for (the host side packs views into the device layout) */
+template <typename F> void parallel_for(int64_t n, F f)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if(nt == 0)
+        nt = 1;
+    if(nt > 32)
+        nt = 32;
+    if(n < 65536 || nt == 1) {
+        f((int64_t) 0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const int64_t chunk = (n + nt - 1) / nt;
+    for(unsigned t = 0; t < nt; t++) {
+        const int64_t lo = (int64_t) t * chunk, hi = std::min(n, lo + chunk);
+        if(lo >= hi)
+            break;
+        th.emplace_back([=]() { f(lo, hi); });
+    }
+    for(auto &x : th)
+        x.join();
+}
+
+template <typename T> inline const T *field(const shq_part_view *v, int64_t i, size_t off)
+{
+    return reinterpret_cast<const T *>(static_cast<const char *>(v->base) + (size_t) i * v->elsize + off);
+}
+template <typename T> inline T *field_w(const shq_part_view *v, int64_t i, size_t off)
+{
+    return reinterpret_cast<T *>(static_cast<char *>(v->base) + (size_t) i * v->elsize + off);
+}
+
+__global__ void gather_leaf_kernel(const double4 *posm, const int32_t *pidx, double4 *out, long long n)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+        out[i] = posm[pidx[i]];
+}
+
+int upload_active(shq_context *ctx, const int32_t *active, int64_t nactive, const int32_t **d_active)
+{
+    *d_active = nullptr;
+    if(!active)
+        return SHQ_OK;
+    for(int64_t k = 0; k < nactive; k++)
+        SHQ_CHECK(active[k] >= 0 && active[k] < ctx->numpart, SHQ_ERR_INVALID, "active[%ld] = %d out of range", (long) k, active[k]);
+    SHQ_TRY(ctx->active.reserve((size_t) std::max<int64_t>(nactive, 1)));
+    if(nactive > 0)
+        SHQ_HIP(hipMemcpyAsync(ctx->active.ptr, active, sizeof(int32_t) * nactive, hipMemcpyHostToDevice, ctx->stream));
+    *d_active = ctx->active.ptr;
+    return SHQ_OK;
+}
+
+} // namespace
+
+extern "C" int shq_init(int device, void *stream, shq_context **out)
+{
+    SHQ_CHECK(out != nullptr, SHQ_ERR_INVALID, "shq_init: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    SHQ_HIP(hipGetDeviceCount(&ndev));
+    SHQ_CHECK(ndev > 0, SHQ_ERR_DEVICE, "shq_init: no HIP device visible");
+    SHQ_CHECK(device >= 0 && device < ndev, SHQ_ERR_INVALID, "shq_init: device %d out of range (%d devices)", device, ndev);
+    SHQ_HIP(hipSetDevice(device));
+    shq_context *ctx = new shq_context();
+    ctx->device = device;
+    if(stream) {
+        ctx->stream = (hipStream_t) stream;
+        ctx->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if(e != hipSuccess) {
+            shq_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            delete ctx;
+            return SHQ_ERR_DEVICE;
+        }
+        ctx->own_stream = true;
+    }
+    for(int i = 0; i < SHQ_NTIMERS; i++) {
+        (void) hipEventCreate(&ctx->ev_begin[i]);
+        (void) hipEventCreate(&ctx->ev_end[i]);
+    }
+    *out = ctx;
+    return SHQ_OK;
+}
+
+extern "C" void shq_shutdown(shq_context *ctx)
+{
+    if(!ctx)
+        return;
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->stream);
+    shq_pm_destroy_plans(ctx);
+    ctx->posm.release(); ctx->oldacc.release(); ctx->treeacc.release(); ctx->gravpm.release();
+    ctx->pmpot.release(); ctx->acc.release(); ctx->pot.release(); ctx->nint.release();
+    ctx->pflags.release(); ctx->active.release(); ctx->gstats.release();
+    ctx->nodeA.release(); ctx->nodeB.release(); ctx->nodeC.release();
+    ctx->posm_leaf.release(); ctx->leaf_pidx.release();
+    ctx->mesh.release(); ctx->sinctab.release(); ctx->dbg_rho.release(); ctx->dbg_pot.release();
+    ctx->gravtab.release(); ctx->stage.release();
+    for(int i = 0; i < SHQ_NTIMERS; i++) {
+        (void) hipEventDestroy(ctx->ev_begin[i]);
+        (void) hipEventDestroy(ctx->ev_end[i]);
+    }
+    if(ctx->own_stream)
+        (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int shq_synchronize(shq_context *ctx)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    return SHQ_OK;
+}
+
+extern "C" void *shq_stream(shq_context *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
+
+extern "C" int shq_timer_begin(shq_context *ctx, int slot)
+{
+    SHQ_CHECK(ctx && slot >= 0 && slot < SHQ_NTIMERS - 1, SHQ_ERR_INVALID, "bad timer slot %d", slot);
+    SHQ_HIP(hipEventRecord(ctx->ev_begin[slot], ctx->stream));
+    return SHQ_OK;
+}
+extern "C" int shq_timer_end(shq_context *ctx, int slot)
+{
+    SHQ_CHECK(ctx && slot >= 0 && slot < SHQ_NTIMERS - 1, SHQ_ERR_INVALID, "bad timer slot %d", slot);
+    SHQ_HIP(hipEventRecord(ctx->ev_end[slot], ctx->stream));
+    return SHQ_OK;
+}
+extern "C" int shq_timer_elapsed_ms(shq_context *ctx, int slot, double *ms)
+{
+    SHQ_CHECK(ctx && ms && slot >= 0 && slot < SHQ_NTIMERS, SHQ_ERR_INVALID, "bad timer slot %d", slot);
+    SHQ_HIP(hipEventSynchronize(ctx->ev_end[slot]));
+    float f = 0;
+    SHQ_HIP(hipEventElapsedTime(&f, ctx->ev_begin[slot], ctx->ev_end[slot]));
+    *ms = f;
+    return SHQ_OK;
+}
+
+/* ---- uploads --------------------------------------------------------------------------- */
+
+extern "C" int shq_particles_upload(shq_context *ctx, const shq_part_view *parts)
+{
+    SHQ_CHECK(ctx && parts, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(parts->numpart >= 0 && parts->numpart < (1ll << 31), SHQ_ERR_INVALID, "numpart %ld out of range (int32 particle indices, treewalk2.h:599-615)", (long) parts->numpart);
+    SHQ_CHECK(parts->numpart == 0 || parts->base, SHQ_ERR_INVALID, "particle base is NULL");
+    SHQ_CHECK(parts->off_pos != SHQ_NOFIELD && parts->off_mass != SHQ_NOFIELD, SHQ_ERR_INVALID, "particle view needs Pos and Mass");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t n = parts->numpart;
+    const size_t cap = (size_t) std::max<int64_t>(n, 1);
+    SHQ_TRY(ctx->posm.reserve(cap));
+    SHQ_TRY(ctx->oldacc.reserve(cap));
+    SHQ_TRY(ctx->treeacc.reserve(3 * cap));
+    SHQ_TRY(ctx->gravpm.reserve(3 * cap));
+    SHQ_TRY(ctx->pmpot.reserve(cap));
+    SHQ_TRY(ctx->acc.reserve(3 * cap));
+    SHQ_TRY(ctx->pot.reserve(cap));
+    SHQ_TRY(ctx->nint.reserve(cap));
+    SHQ_TRY(ctx->pflags.reserve(cap));
+
+    std::vector<double4> h_posm(cap);
+    std::vector<double> h_tree(3 * cap, 0.0), h_pm(3 * cap, 0.0);
+    std::vector<uint8_t> h_flags(cap, 0);
+    std::vector<double> partial_mass(64, 0.0);
+    std::atomic<int> bad(0);
+    parallel_for(n, [&](int64_t lo, int64_t hi) {
+        for(int64_t i = lo; i < hi; i++) {
+            const double *pos = field<double>(parts, i, parts->off_pos);
+            const float m = *field<float>(parts, i, parts->off_mass);
+            h_posm[i] = make_double4(pos[0], pos[1], pos[2], (double) m);
+            if(!(isfinite(pos[0]) && isfinite(pos[1]) && isfinite(pos[2]) && isfinite(m)))
+                bad.store(1);
+            if(parts->off_treeacc != SHQ_NOFIELD) {
+                const double *a = field<double>(parts, i, parts->off_treeacc);
+                h_tree[3 * i] = a[0]; h_tree[3 * i + 1] = a[1]; h_tree[3 * i + 2] = a[2];
+            }
+            if(parts->off_gravpm != SHQ_NOFIELD) {
+                const double *a = field<double>(parts, i, parts->off_gravpm);
+                h_pm[3 * i] = a[0]; h_pm[3 * i + 1] = a[1]; h_pm[3 * i + 2] = a[2];
+            }
+            uint8_t fl = 0;
+            if(parts->off_flags != SHQ_NOFIELD)
+                fl |= (uint8_t) (*field<uint32_t>(parts, i, parts->off_flags) & 3u);
+            if(parts->off_type != SHQ_NOFIELD)
+                fl |= (uint8_t) ((*field<uint8_t>(parts, i, parts->off_type) & 0xf) << 4);
+            h_flags[i] = fl;
+        }
+    });
+    SHQ_CHECK(bad.load() == 0, SHQ_ERR_INVALID, "non-finite particle position or mass");
+    double msum = 0;
+    for(int64_t i = 0; i < n; i++)
+        msum += fabs(h_posm[i].w);
+    ctx->mass_sum = msum;
+    if(ctx->pm_log2scale_user >= 0)
+        ctx->pm_log2scale = ctx->pm_log2scale_user;
+    else {
+        int ex = 0;
+        (void) frexp(msum > 0 ? msum : 1.0, &ex); /* msum < 2^ex */
+        ctx->pm_log2scale = 61 - ex;
+    }
+    if(n > 0) {
+        SHQ_HIP(hipMemcpyAsync(ctx->posm.ptr, h_posm.data(), sizeof(double4) * n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(ctx->treeacc.ptr, h_tree.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(ctx->gravpm.ptr, h_pm.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(ctx->pflags.ptr, h_flags.data(), n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemsetAsync(ctx->oldacc.ptr, 0, sizeof(double) * n, ctx->stream));
+        SHQ_HIP(hipMemsetAsync(ctx->pmpot.ptr, 0, sizeof(double) * n, ctx->stream));
+        SHQ_HIP(hipMemsetAsync(ctx->acc.ptr, 0, sizeof(double) * 3 * n, ctx->stream));
+        SHQ_HIP(hipMemsetAsync(ctx->pot.ptr, 0, sizeof(double) * n, ctx->stream));
+        SHQ_HIP(hipMemsetAsync(ctx->nint.ptr, 0, sizeof(int32_t) * n, ctx->stream));
+    }
+    SHQ_HIP(hipStreamSynchronize(ctx->stream)); /* host vectors die here */
+    ctx->numpart = n;
+    ctx->have_parts = true;
+    ctx->have_tree = false; /* leaf copy refers to the old particles */
+    ctx->have_pm_result = false;
+    return SHQ_OK;
+}
+
+extern "C" int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree)
+{
+    SHQ_CHECK(ctx && tree, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "tree_upload: upload particles first");
+    SHQ_CHECK(tree->nodes_base && tree->numnodes > 0, SHQ_ERR_INVALID, "tree has no nodes");
+    SHQ_CHECK(tree->numnodes < (1ll << 31), SHQ_ERR_INVALID, "too many nodes");
+    SHQ_CHECK(tree->rootnode >= tree->firstnode && tree->rootnode < tree->firstnode + tree->numnodes, SHQ_ERR_INVALID, "root node %d outside [%ld, %ld)", tree->rootnode, (long) tree->firstnode, (long) (tree->firstnode + tree->numnodes));
+    SHQ_CHECK(tree->BoxSize > 0, SHQ_ERR_INVALID, "tree BoxSize must be > 0");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t nn = tree->numnodes, fn = tree->firstnode;
+    const shq_node *src = tree->nodes_base;
+    std::vector<NodeA> hA(nn);
+    std::vector<NodeB> hB(nn);
+    std::vector<NodeC> hC(nn);
+    /* leaf slot offsets: exclusive prefix sum of noccupied over leaf nodes in node-index order */
+    std::vector<int64_t> pstart(nn + 1, 0);
+    for(int64_t i = 0; i < nn; i++) {
+        int cnt = 0;
+        if(SHQ_NODE_CHILDTYPE(src[i].flags) == SHQ_PARTICLE_NODE_TYPE) {
+            cnt = src[i].noccupied;
+            if(cnt < 0 || cnt > SHQ_NMAXCHILD)
+                cnt = 0; /* unreachable scratch node */
+        }
+        pstart[i + 1] = pstart[i] + cnt;
+    }
+    const int64_t nleafparts = pstart[nn];
+    SHQ_CHECK(nleafparts < (1ll << 31), SHQ_ERR_INVALID, "too many leaf particles");
+    std::vector<int32_t> pidx((size_t) std::max<int64_t>(nleafparts, 1));
+    std::atomic<int> bad(0);
+    const int64_t np = ctx->numpart;
+    parallel_for(nn, [&](int64_t lo, int64_t hi) {
+        for(int64_t i = lo; i < hi; i++) {
+            const shq_node &s = src[i];
+            NodeA a; NodeB b; NodeC c;
+            a.cofm[0] = s.cofm[0]; a.cofm[1] = s.cofm[1]; a.cofm[2] = s.cofm[2]; a.mass = s.mass;
+            b.center[0] = s.center[0]; b.center[1] = s.center[1]; b.center[2] = s.center[2]; b.len = s.len;
+            const int64_t sib = s.sibling;
+            c.sibling = (sib >= fn && sib < fn + nn) ? (int32_t) (sib - fn) : -1;
+            c.type = (int32_t) SHQ_NODE_CHILDTYPE(s.flags);
+            c.count = 0;
+            c.child = -1;
+            if(c.type == SHQ_PARTICLE_NODE_TYPE) {
+                const int cnt = (int) (pstart[i + 1] - pstart[i]);
+                c.count = cnt;
+                c.child = (int32_t) pstart[i];
+                for(int k = 0; k < cnt; k++) {
+                    const int32_t p = s.suns[k];
+                    if(p < 0 || p >= np) {
+                        /* only an error if the node is reachable; mark and neutralise */
+                        c.count = 0;
+                        if(s.father >= -1)
+                            bad.store(1);
+                        break;
+                    }
+                    pidx[pstart[i] + k] = p;
+                }
+                if(c.count == 0)
+                    for(int k = 0; k < cnt; k++)
+                        pidx[pstart[i] + k] = 0;
+            } else if(c.type == SHQ_NODE_NODE_TYPE) {
+                const int64_t ch = s.suns[0];
+                c.child = (ch >= fn && ch < fn + nn) ? (int32_t) (ch - fn) : -1;
+                if(c.child < 0)
+                    c.type = SHQ_PSEUDO_NODE_TYPE; /* never descend into an invalid link */
+            }
+            hA[i] = a; hB[i] = b; hC[i] = c;
+        }
+    });
+    SHQ_CHECK(bad.load() == 0, SHQ_ERR_INVALID, "tree leaf refers to a particle index outside [0, numpart)");
+    SHQ_TRY(ctx->nodeA.reserve(nn));
+    SHQ_TRY(ctx->nodeB.reserve(nn));
+    SHQ_TRY(ctx->nodeC.reserve(nn));
+    SHQ_TRY(ctx->leaf_pidx.reserve(pidx.size()));
+    SHQ_TRY(ctx->posm_leaf.reserve(pidx.size()));
+    SHQ_HIP(hipMemcpyAsync(ctx->nodeA.ptr, hA.data(), sizeof(NodeA) * nn, hipMemcpyHostToDevice, ctx->stream));
+    SHQ_HIP(hipMemcpyAsync(ctx->nodeB.ptr, hB.data(), sizeof(NodeB) * nn, hipMemcpyHostToDevice, ctx->stream));
+    SHQ_HIP(hipMemcpyAsync(ctx->nodeC.ptr, hC.data(), sizeof(NodeC) * nn, hipMemcpyHostToDevice, ctx->stream));
+    if(nleafparts > 0) {
+        SHQ_HIP(hipMemcpyAsync(ctx->leaf_pidx.ptr, pidx.data(), sizeof(int32_t) * nleafparts, hipMemcpyHostToDevice, ctx->stream));
+        const int threads = 256;
+        gather_leaf_kernel<<<dim3((unsigned) ((nleafparts + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+            ctx->posm.ptr, ctx->leaf_pidx.ptr, ctx->posm_leaf.ptr, nleafparts);
+        SHQ_HIP(hipGetLastError());
+    }
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->numnodes = nn;
+    ctx->firstnode = fn;
+    ctx->root = (int32_t) (tree->rootnode - fn);
+    ctx->ntreeparts = nleafparts;
+    ctx->treeBox = tree->BoxSize;
+    ctx->have_tree = true;
+    return SHQ_OK;
+}
+
+/* ---- gravity ---------------------------------------------------------------------------- */
+
+extern "C" int shq_grav_short_run(shq_context *ctx, const shq_grav_params *params, const int32_t *active,
+                                  int64_t nactive, int update_potential, int walk_mode)
+{
+    SHQ_CHECK(ctx && params, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "grav_short_run: upload particles and tree first");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int32_t *d_active = nullptr;
+    int64_t nt = active ? nactive : ctx->numpart;
+    SHQ_TRY(upload_active(ctx, active, nt, &d_active));
+    SHQ_TRY(shq_launch_grav_walk(ctx, params, d_active, nt, update_potential, walk_mode));
+    SHQ_TRY(shq_launch_grav_postprocess(ctx, params, d_active, nt, update_potential));
+    ctx->last_stats.ntargets = nt;
+    return SHQ_OK;
+}
+
+extern "C" int shq_grav_short_download(shq_context *ctx, double (*accel)[3], double *potential,
+                                       int64_t *ninteractions, shq_walk_stats *stats)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "nothing to download");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t n = ctx->numpart;
+    if(accel && n > 0)
+        SHQ_HIP(hipMemcpyAsync(accel, ctx->acc.ptr, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
+    if(potential && n > 0)
+        SHQ_HIP(hipMemcpyAsync(potential, ctx->pot.ptr, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<int32_t> h_nint;
+    if(ninteractions && n > 0) {
+        h_nint.resize(n);
+        SHQ_HIP(hipMemcpyAsync(h_nint.data(), ctx->nint.ptr, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    GravStatsDev gs = {};
+    if(stats && ctx->gstats.ptr)
+        SHQ_HIP(hipMemcpyAsync(&gs, ctx->gstats.ptr, sizeof(gs), hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    if(ninteractions)
+        for(int64_t i = 0; i < n; i++)
+            ninteractions[i] = h_nint[i];
+    if(stats) {
+        stats->ntargets = ctx->last_stats.ntargets;
+        stats->ninteractions = (int64_t) gs.ninteractions;
+        stats->nnodes_visited = (int64_t) gs.nvisited;
+        stats->min_interactions = stats->ntargets > 0 ? gs.min_int : 0;
+        stats->max_interactions = gs.max_int;
+        float ms = 0;
+        if(stats->ntargets > 0 && hipEventElapsedTime(&ms, ctx->ev_begin[SHQ_NTIMERS - 1], ctx->ev_end[SHQ_NTIMERS - 1]) == hipSuccess)
+            stats->kernel_ms = ms;
+        else
+            stats->kernel_ms = 0;
+    }
+    return SHQ_OK;
+}
+
+extern "C" int shq_grav_refresh_oldacc(shq_context *ctx, double G)
+{
+    SHQ_CHECK(ctx && G > 0, SHQ_ERR_INVALID, "bad argument");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    return shq_launch_oldacc(ctx, G);
+}
+
+extern "C" int shq_grav_short_tree(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts,
+                                   const int32_t *active, int64_t nactive, const shq_grav_params *params,
+                                   double (*accel)[3], int update_potential, int walk_mode, shq_walk_stats *stats)
+{
+    SHQ_CHECK(ctx && tree && parts && params && accel, SHQ_ERR_INVALID, "null argument");
+    SHQ_TRY(shq_particles_upload(ctx, parts));
+    SHQ_TRY(shq_tree_upload(ctx, tree));
+    SHQ_TRY(shq_grav_refresh_oldacc(ctx, params->G));
+    SHQ_TRY(shq_grav_short_run(ctx, params, active, nactive, update_potential, walk_mode));
+    const int64_t n = parts->numpart;
+    std::vector<double> h_acc((size_t) std::max<int64_t>(3 * n, 1)), h_pot((size_t) std::max<int64_t>(n, 1));
+    SHQ_TRY(shq_grav_short_download(ctx, (double (*)[3]) h_acc.data(), update_potential ? h_pot.data() : nullptr, nullptr, stats));
+    /* reduce<PRIMARY> assigns only the walked targets (localtreewalk2.h:39) */
+    const int64_t nt = active ? nactive : n;
+    for(int64_t t = 0; t < nt; t++) {
+        const int64_t i = active ? active[t] : t;
+        accel[i][0] = h_acc[3 * i];
+        accel[i][1] = h_acc[3 * i + 1];
+        accel[i][2] = h_acc[3 * i + 2];
+        if(update_potential) {
+            if(parts->off_treeacc != SHQ_NOFIELD) {
+                double *a = field_w<double>(parts, i, parts->off_treeacc);
+                a[0] = h_acc[3 * i]; a[1] = h_acc[3 * i + 1]; a[2] = h_acc[3 * i + 2];
+            }
+            if(parts->off_potential != SHQ_NOFIELD)
+                *field_w<double>(parts, i, parts->off_potential) = h_pot[i];
+        }
+    }
+    return SHQ_OK;
+}
+
+/* ---- PM ----------------------------------------------------------------------------------- */
+
+extern "C" int shq_pm_run(shq_context *ctx, const shq_pm_params *pm)
+{
+    SHQ_CHECK(ctx && pm, SHQ_ERR_INVALID, "null argument");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    return shq_pm_execute(ctx, pm);
+}
+
+extern "C" int shq_pm_download(shq_context *ctx, double (*gravpm)[3], double *pm_potential)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_CHECK(ctx->have_pm_result, SHQ_ERR_STATE, "pm_download before pm_run");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t n = ctx->numpart;
+    if(gravpm && n > 0)
+        SHQ_HIP(hipMemcpyAsync(gravpm, ctx->gravpm.ptr, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
+    if(pm_potential && n > 0)
+        SHQ_HIP(hipMemcpyAsync(pm_potential, ctx->pmpot.ptr, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    return SHQ_OK;
+}
+
+extern "C" int shq_pm_force(shq_context *ctx, const shq_pm_params *pm, const shq_part_view *parts,
+                            double (*gravpm)[3], double *potential)
+{
+    SHQ_CHECK(ctx && pm && parts && gravpm, SHQ_ERR_INVALID, "null argument");
+    SHQ_TRY(shq_particles_upload(ctx, parts));
+    SHQ_TRY(shq_pm_run(ctx, pm));
+    const int64_t n = parts->numpart;
+    std::vector<double> h_pot((size_t) std::max<int64_t>(n, 1));
+    SHQ_TRY(shq_pm_download(ctx, gravpm, potential ? h_pot.data() : nullptr));
+    if(potential)
+        for(int64_t i = 0; i < n; i++)
+            potential[i] += h_pot[i]; /* readout_potential adds, gravpm.cpp:489-491 */
+    return SHQ_OK;
+}
+
+extern "C" int shq_pm_set_debug(shq_context *ctx, int keep_meshes)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    ctx->pm_keep = keep_meshes;
+    return SHQ_OK;
+}
+
+extern "C" int shq_pm_download_mesh(shq_context *ctx, int which, double *mesh)
+{
+    SHQ_CHECK(ctx && mesh, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_pm_result && ctx->pm_keep, SHQ_ERR_STATE, "pm_download_mesh needs shq_pm_set_debug(1) before shq_pm_run");
+    SHQ_CHECK(which == 0 || which == 1, SHQ_ERR_INVALID, "which must be 0 or 1");
+    const size_t tot = (size_t) ctx->pm_nmesh * ctx->pm_nmesh * ctx->pm_nmesh;
+    SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_HIP(hipMemcpyAsync(mesh, which == 0 ? ctx->dbg_rho.ptr : ctx->dbg_pot.ptr, tot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    return SHQ_OK;
+}
+
+extern "C" int shq_fft_r2c(shq_context *ctx, int Nmesh, const double *real, double *complx)
+{
+    SHQ_CHECK(ctx && real && complx, SHQ_ERR_INVALID, "null argument");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    return shq_fft_roundtrip_r2c(ctx, Nmesh, real, complx);
+}
+extern "C" int shq_fft_c2r(shq_context *ctx, int Nmesh, const double *complx, double *real)
+{
+    SHQ_CHECK(ctx && real && complx, SHQ_ERR_INVALID, "null argument");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    return shq_fft_roundtrip_c2r(ctx, Nmesh, complx, real);
+}

@@ -1,0 +1,183 @@
+/* common.hpp — context, error plumbing and device buffers of libshenqi_hip (gfx950 only). */
+#ifndef SHQ_COMMON_HPP
+#define SHQ_COMMON_HPP
+
+#include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "../../include/shenqi_hip.h"
+
+void shq_set_error(const char *fmt, ...);
+
+#define SHQ_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if(e_ != hipSuccess) {                                                                 \
+            shq_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return (e_ == hipErrorOutOfMemory) ? SHQ_ERR_NOMEM : SHQ_ERR_DEVICE;               \
+        }                                                                                      \
+    } while(0)
+
+#define SHQ_CHECK(cond, code, ...)                                                             \
+    do {                                                                                       \
+        if(!(cond)) {                                                                          \
+            shq_set_error(__VA_ARGS__);                                                        \
+            return (code);                                                                     \
+        }                                                                                      \
+    } while(0)
+
+#define SHQ_TRY(call)                                                                          \
+    do {                                                                                       \
+        int rc_ = (call);                                                                      \
+        if(rc_ != SHQ_OK)                                                                      \
+            return rc_;                                                                        \
+    } while(0)
+
+/* Grow-only device buffer from the library's own pool (never the caller's arena). */
+template <typename T> struct DevBuf {
+    T *ptr = nullptr;
+    size_t cap = 0; /* elements */
+    int reserve(size_t n)
+    {
+        if(n <= cap)
+            return SHQ_OK;
+        if(ptr)
+            (void) hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc((void **) &ptr, n * sizeof(T));
+        if(e != hipSuccess) {
+            shq_set_error("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+            ptr = nullptr;
+            return SHQ_ERR_NOMEM;
+        }
+        cap = n;
+        return SHQ_OK;
+    }
+    void release()
+    {
+        if(ptr)
+            (void) hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+/* Pinned host staging buffer. */
+template <typename T> struct PinBuf {
+    T *ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if(n <= cap)
+            return SHQ_OK;
+        if(ptr)
+            (void) hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t e = hipHostMalloc((void **) &ptr, n * sizeof(T), hipHostMallocDefault);
+        if(e != hipSuccess) {
+            shq_set_error("hipHostMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+            ptr = nullptr;
+            return SHQ_ERR_NOMEM;
+        }
+        cap = n;
+        return SHQ_OK;
+    }
+    void release()
+    {
+        if(ptr)
+            (void) hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+/* Walk-time node pool record split in three 16/32-byte streams (wave-uniform scalar loads). */
+struct NodeA { double cofm[3]; double mass; };   /* 32 B */
+struct NodeB { double center[3]; double len; };  /* 32 B */
+struct NodeC { int32_t sibling; int32_t child; int32_t type; int32_t count; }; /* 16 B: child = first
+    child node (NODE) or first leaf-order particle slot (PARTICLE); count = noccupied for leaves */
+struct NodeH { double hmax; };                    /* SPH only */
+
+struct GravStatsDev {
+    unsigned long long ninteractions;
+    unsigned long long nvisited;
+    long long min_int;
+    long long max_int;
+};
+
+#define SHQ_NTIMERS 16
+
+struct shq_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev_begin[SHQ_NTIMERS] = {};
+    hipEvent_t ev_end[SHQ_NTIMERS] = {};
+
+    /* ---- particle store, by particle index (sorted SoA, Peano order as the host keeps it) */
+    int64_t numpart = 0;
+    DevBuf<double4> posm;      /* x,y,z,mass */
+    DevBuf<double> oldacc;     /* |FullTreeGravAccel + GravPM| / G */
+    DevBuf<double> treeacc;    /* [N][3] FullTreeGravAccel */
+    DevBuf<double> gravpm;     /* [N][3] */
+    DevBuf<double> pmpot;      /* [N] PM potential contribution */
+    DevBuf<double> acc;        /* [N][3] walk output (Accel) */
+    DevBuf<double> pot;        /* [N] tree potential */
+    DevBuf<int32_t> nint;      /* [N] interactions */
+    DevBuf<uint8_t> pflags;    /* bit0 garbage, bit1 swallowed; bits 4-7 type */
+    DevBuf<int32_t> active;    /* uploaded active list */
+    DevBuf<GravStatsDev> gstats;
+    bool have_parts = false;
+
+    /* ---- node pool */
+    int64_t numnodes = 0;
+    int64_t firstnode = 0;
+    int32_t root = 0;          /* packed index of the root */
+    int64_t ntreeparts = 0;    /* particles referenced by leaves */
+    DevBuf<NodeA> nodeA;
+    DevBuf<NodeB> nodeB;
+    DevBuf<NodeC> nodeC;
+    DevBuf<double4> posm_leaf; /* leaf-ordered copy of (x,y,z,m) */
+    DevBuf<int32_t> leaf_pidx; /* leaf slot -> particle index */
+    bool have_tree = false;
+    double treeBox = 0;
+
+    /* ---- PM */
+    int pm_nmesh = 0;
+    hipfftHandle plan_r2c = 0, plan_c2r = 0;
+    bool have_plans = false;
+    DevBuf<double> mesh;       /* padded in-place real/complex mesh: N*N*(N+2) doubles */
+    DevBuf<double> sinctab;    /* 1/sinc^2 per mesh index */
+    DevBuf<double> dbg_rho, dbg_pot;
+    int pm_keep = 0;
+    int pm_log2scale = 30;     /* fixed-point deposit scale 2^e, set at particle upload */
+    int pm_log2scale_user = -1; /* >=0: forced by the caller (multi-rank consistency) */
+    double mass_sum = 0;
+    DevBuf<float> gravtab;     /* [2][512] window table */
+    bool have_pm_result = false;
+
+    shq_walk_stats last_stats = {};
+    float last_walk_ms = 0;
+
+    /* host staging */
+    PinBuf<char> stage;
+};
+
+/* grav_walk.hip */
+int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active,
+                         int64_t ntargets, int update_potential, int walk_mode);
+int shq_launch_grav_postprocess(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active,
+                                int64_t ntargets, int update_potential);
+int shq_launch_oldacc(shq_context *ctx, double G);
+/* pm.hip */
+int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm);
+void shq_pm_destroy_plans(shq_context *ctx);
+int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *complx);
+int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double *real);
+
+#endif

@@ -1,0 +1,344 @@
+/* grav_walk.hip — short-range Barnes-Hut / relative-criterion tree walk for gfx950.
+ *
+ * Replaces treewalk_primary_kernel<GravTreeWalk> (libgadget/treewalk2.cuh:104-134, one thread
+ * per particle, AoS managed memory) + GravLocalTreeWalk::visit (libgadget/gravshort2.hpp:227-322)
+ * with a wavefront-collective walk:
+ *
+ *   - one 64-lane wavefront owns 64 consecutive targets (Peano-ordered => spatially compact);
+ *   - the wavefront walks the UNION of its lanes' reference walks.  `cur` (the node being
+ *     tested) is wave-uniform, so the node pool is read with scalar loads; every lane keeps
+ *     `mynext`, the node its own reference walk would visit next, and takes part in a node test
+ *     only while mynext == cur.  A lane that discards or accepts a node sets mynext = sibling
+ *     and sleeps until the union walk reaches that sibling; the union opens a node when any
+ *     awake lane opens it.  Per target this yields exactly the reference's opening decisions,
+ *     interaction set and summation order (depth-first), i.e. the EXACT flavour;
+ *   - leaf particles come from a leaf-ordered (x,y,z,m) copy: one 32-byte uniform load each;
+ *   - the 2x512-float TreePM window table (gravity.h:32-61) is staged in LDS as
+ *     {f[i], f[i+1], p[i], p[i+1]} so an interaction needs one ds_read_b128.
+ *
+ * All arithmetic is f64 as in the reference (LOW_PRECISION=double).
+ */
+#include "common.hpp"
+
+namespace {
+
+struct WalkArgs {
+    const NodeA *nodeA;
+    const NodeB *nodeB;
+    const NodeC *nodeC;
+    const double4 *posm;       /* by particle index */
+    const double4 *posm_leaf;  /* leaf order */
+    const double *oldacc;
+    const int32_t *targets;    /* may be null */
+    double *acc;               /* [N][3] by particle index */
+    double *pot;
+    int32_t *nint;
+    GravStatsDev *stats;
+    long long ntargets;
+    int root;
+    double Box, halfBox;
+    double rcut, rcut2;
+    double h, h2, h_inv, h3_inv;
+    double inv_celldx;         /* 1 / (cellsize * dx) */
+    double errtol, bh2;
+    int useBH;
+    const float *tab_f;
+    const float *tab_p;
+};
+
+__device__ __forceinline__ double nearest(double x, double box, double half)
+{
+    return (x > half) ? (x - box) : ((x < -half) ? (x + box) : x);
+}
+
+/* apply_accn (gravshort2.hpp:326-358) + apply_short_range_window (gravity.h:48-60) */
+template <bool POT>
+__device__ __forceinline__ void apply_accn(const float4 *__restrict__ tab, double dx, double dy, double dz, double r2,
+                                           double mass, const WalkArgs &a, double &ax, double &ay, double &az,
+                                           double &pot)
+{
+    const double r = sqrt(r2);
+    double fac = mass / (r2 * r);
+    double facpot = -mass / r;
+    if(r2 < a.h2) {
+        const double u = r * a.h_inv;
+        double wp;
+        if(u < 0.5) {
+            fac = mass * a.h3_inv * (10.666666666667 + u * u * (32.0 * u - 38.4));
+            wp = -2.8 + u * u * (5.333333333333 + u * u * (6.4 * u - 9.6));
+        } else {
+            fac = mass * a.h3_inv *
+                  (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u -
+                   0.066666666667 / (u * u * u));
+            wp = -3.2 + 0.066666666667 / u + u * u * (10.666666666667 + u * (-16.0 + u * (9.6 - 2.133333333333 * u)));
+        }
+        facpot = mass * a.h_inv * wp;
+    }
+    const double fi = r * a.inv_celldx;
+    const double fl = floor(fi);
+    if(fl < (double) (SHQ_NGRAVTAB - 1)) {
+        const int ti = (int) fl;
+        const float4 t = tab[ti];
+        const double w1 = fi - fl, w0 = 1.0 - w1;
+        fac *= w0 * (double) t.x + w1 * (double) t.y;
+        ax += dx * fac;
+        ay += dy * fac;
+        az += dz * fac;
+        if(POT) {
+            facpot *= w0 * (double) t.z + w1 * (double) t.w;
+            pot += facpot;
+        }
+    }
+}
+
+template <bool POT> __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
+{
+    __shared__ float4 tab[SHQ_NGRAVTAB];
+    for(int i = threadIdx.x; i < SHQ_NGRAVTAB; i += blockDim.x) {
+        const int j = (i + 1 < SHQ_NGRAVTAB) ? i + 1 : i;
+        tab[i] = make_float4(a.tab_f[i], a.tab_f[j], a.tab_p[i], a.tab_p[j]);
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long t = wave * 64 + lane;
+    const bool valid = t < a.ntargets;
+    long long pi = 0;
+    double px = 0, py = 0, pz = 0, aold = 0;
+    if(valid) {
+        pi = a.targets ? (long long) a.targets[t] : t;
+        const double4 p = a.posm[pi];
+        px = p.x;
+        py = p.y;
+        pz = p.z;
+        aold = a.errtol * a.oldacc[pi];
+    }
+    double ax = 0, ay = 0, az = 0, pot = 0;
+    int nint = 0;
+    int mynext = valid ? a.root : -2;
+    int cur = a.root;
+    unsigned long long visited = 0;
+
+    while(cur >= 0) {
+        cur = __builtin_amdgcn_readfirstlane(cur);
+        const NodeA A = a.nodeA[cur];
+        const NodeB B = a.nodeB[cur];
+        const NodeC C = a.nodeC[cur];
+        visited++;
+        const bool act = (mynext == cur);
+
+        /* gravshort2.hpp:262-265 */
+        double dx = nearest(A.cofm[0] - px, a.Box, a.halfBox);
+        double dy = nearest(A.cofm[1] - py, a.Box, a.halfBox);
+        double dz = nearest(A.cofm[2] - pz, a.Box, a.halfBox);
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        const double cx = fabs(nearest(B.center[0] - px, a.Box, a.halfBox));
+        const double cy = fabs(nearest(B.center[1] - py, a.Box, a.halfBox));
+        const double cz = fabs(nearest(B.center[2] - pz, a.Box, a.halfBox));
+        const double len = B.len;
+        /* shall_we_discard_node, gravshort2.hpp:152-167 */
+        const double eff = a.rcut + 0.5 * len;
+        const bool discard = (r2 > a.rcut2) && (cx > eff || cy > eff || cz > eff);
+        /* shall_we_open_node, gravshort2.hpp:172-193 (len*len/r2 > theta2 written without the divide) */
+        const double len2 = len * len;
+        const double inside = 0.6 * len;
+        const bool open = ((a.useBH == 0) && (A.mass * len2 > r2 * r2 * aold)) || (len2 > r2 * a.bh2) ||
+                          (cx < inside && cy < inside && cz < inside);
+        const bool accept = act && !discard && !open;
+        const bool doopen = act && !discard && open;
+
+        if(accept) {
+            apply_accn<POT>(tab, dx, dy, dz, r2, A.mass, a, ax, ay, az, pot);
+            nint++;
+        }
+        if(C.type == SHQ_PARTICLE_NODE_TYPE) {
+            /* gravshort2.hpp:290-304: every particle of an opened leaf is evaluated */
+            if(__ballot(doopen) != 0ull) {
+                for(int k = 0; k < C.count; k++) {
+                    const double4 q = a.posm_leaf[C.child + k];
+                    if(doopen) {
+                        const double ex = nearest(q.x - px, a.Box, a.halfBox);
+                        const double ey = nearest(q.y - py, a.Box, a.halfBox);
+                        const double ez = nearest(q.z - pz, a.Box, a.halfBox);
+                        const double rr2 = ex * ex + ey * ey + ez * ez;
+                        apply_accn<POT>(tab, ex, ey, ez, rr2, q.w, a, ax, ay, az, pot);
+                        nint++;
+                    }
+                }
+            }
+            if(act)
+                mynext = C.sibling;
+            cur = C.sibling;
+        } else if(C.type == SHQ_PSEUDO_NODE_TYPE) {
+            /* gravshort2.hpp:305-315: pseudo nodes are skipped by the local walk */
+            if(act)
+                mynext = C.sibling;
+            cur = C.sibling;
+        } else {
+            const bool anyopen = __ballot(doopen) != 0ull;
+            if(act)
+                mynext = doopen ? C.child : C.sibling;
+            cur = anyopen ? C.child : C.sibling;
+        }
+    }
+
+    if(valid) {
+        a.acc[3 * pi + 0] = ax;
+        a.acc[3 * pi + 1] = ay;
+        a.acc[3 * pi + 2] = az;
+        if(POT)
+            a.pot[pi] = pot;
+        a.nint[pi] = nint;
+    }
+    /* statistics (treewalk2.h:446-448 interaction min/max) */
+    long long mn = valid ? nint : 0x7fffffffffffll, mx = valid ? nint : 0, sm = valid ? nint : 0;
+    for(int off = 32; off > 0; off >>= 1) {
+        long long o1 = __shfl_xor(mn, off), o2 = __shfl_xor(mx, off), o3 = __shfl_xor(sm, off);
+        mn = o1 < mn ? o1 : mn;
+        mx = o2 > mx ? o2 : mx;
+        sm += o3;
+    }
+    if(lane == 0 && a.stats) {
+        atomicAdd(&a.stats->ninteractions, (unsigned long long) sm);
+        atomicAdd(&a.stats->nvisited, visited);
+        atomicMin(&a.stats->min_int, mn);
+        atomicMax(&a.stats->max_int, mx);
+    }
+}
+
+/* GravTreeOutput::postprocess, gravshort2.hpp:88-107 */
+__global__ void grav_postprocess_kernel(const int32_t *targets, long long ntargets, const double4 *posm, double *acc,
+                                        double *pot, double *treeacc, double G, double h, double cbrtrho0,
+                                        int update_potential)
+{
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= ntargets)
+        return;
+    const long long i = targets ? (long long) targets[t] : t;
+    const double a0 = acc[3 * i + 0] * G, a1 = acc[3 * i + 1] * G, a2 = acc[3 * i + 2] * G;
+    acc[3 * i + 0] = a0;
+    acc[3 * i + 1] = a1;
+    acc[3 * i + 2] = a2;
+    if(update_potential) {
+        treeacc[3 * i + 0] = a0;
+        treeacc[3 * i + 1] = a1;
+        treeacc[3 * i + 2] = a2;
+        const double m = posm[i].w;
+        double p = pot[i];
+        p += m / (h / 2.8);
+        p -= 2.8372975 * pow(m, 2.0 / 3) * cbrtrho0;
+        p *= G;
+        pot[i] = p;
+    }
+}
+
+/* grav_get_abs_accel, gravshort2.hpp:111-121 */
+__global__ void oldacc_kernel(long long n, const double *treeacc, const double *gravpm, double *oldacc, double G)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    double s = 0;
+    for(int j = 0; j < 3; j++) {
+        const double ax = treeacc[3 * i + j] + gravpm[3 * i + j];
+        s += ax * ax;
+    }
+    oldacc[i] = sqrt(s) / G;
+}
+
+__global__ void stats_init_kernel(GravStatsDev *s)
+{
+    s->ninteractions = 0;
+    s->nvisited = 0;
+    s->min_int = 0x7fffffffffffll;
+    s->max_int = 0;
+}
+
+} // namespace
+
+int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets,
+                         int update_potential, int walk_mode)
+{
+    SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "grav walk: particles and tree must be uploaded first");
+    SHQ_CHECK(walk_mode == SHQ_WALK_EXACT || walk_mode == SHQ_WALK_GROUP, SHQ_ERR_INVALID, "unknown walk_mode %d", walk_mode);
+    SHQ_CHECK(p->ForceSoftening > 0 && p->cellsize > 0 && p->dx > 0, SHQ_ERR_INVALID, "grav params: softening/cellsize/dx must be > 0");
+    SHQ_CHECK(ntargets >= 0 && ntargets <= ctx->numpart, SHQ_ERR_INVALID, "grav walk: ntargets %ld out of range", (long) ntargets);
+    SHQ_TRY(ctx->gravtab.reserve(2 * SHQ_NGRAVTAB));
+    SHQ_TRY(ctx->gstats.reserve(1));
+    SHQ_HIP(hipMemcpyAsync(ctx->gravtab.ptr, p->shortrange_table, sizeof(float) * SHQ_NGRAVTAB, hipMemcpyHostToDevice, ctx->stream));
+    SHQ_HIP(hipMemcpyAsync(ctx->gravtab.ptr + SHQ_NGRAVTAB, p->shortrange_table_potential, sizeof(float) * SHQ_NGRAVTAB,
+                           hipMemcpyHostToDevice, ctx->stream));
+    stats_init_kernel<<<1, 1, 0, ctx->stream>>>(ctx->gstats.ptr);
+    if(ntargets == 0)
+        return SHQ_OK;
+
+    WalkArgs a;
+    a.nodeA = ctx->nodeA.ptr;
+    a.nodeB = ctx->nodeB.ptr;
+    a.nodeC = ctx->nodeC.ptr;
+    a.posm = ctx->posm.ptr;
+    a.posm_leaf = ctx->posm_leaf.ptr;
+    a.oldacc = ctx->oldacc.ptr;
+    a.targets = d_active;
+    a.acc = ctx->acc.ptr;
+    a.pot = ctx->pot.ptr;
+    a.nint = ctx->nint.ptr;
+    a.stats = ctx->gstats.ptr;
+    a.ntargets = ntargets;
+    a.root = ctx->root;
+    a.Box = p->BoxSize;
+    a.halfBox = 0.5 * p->BoxSize;
+    a.rcut = p->Rcut;
+    a.rcut2 = p->Rcut * p->Rcut;
+    a.h = p->ForceSoftening;
+    a.h2 = a.h * a.h;
+    a.h_inv = 1.0 / a.h;
+    a.h3_inv = 1.0 / a.h / a.h / a.h;
+    a.inv_celldx = 1.0 / (p->cellsize * p->dx);
+    a.errtol = p->ErrTolForceAcc;
+    a.bh2 = p->BHOpeningAngle2;
+    a.useBH = p->TreeUseBH;
+    a.tab_f = ctx->gravtab.ptr;
+    a.tab_p = ctx->gravtab.ptr + SHQ_NGRAVTAB;
+
+    const int threads = 256;
+    const long long nwaves = (ntargets + 63) / 64;
+    const long long blocks = (nwaves + (threads / 64) - 1) / (threads / 64);
+    SHQ_CHECK(blocks < (1ll << 31), SHQ_ERR_INVALID, "grav walk: too many targets for one launch");
+    SHQ_HIP(hipEventRecord(ctx->ev_begin[SHQ_NTIMERS - 1], ctx->stream));
+    if(update_potential)
+        grav_walk_exact_kernel<true><<<dim3((unsigned) blocks), dim3(threads), 0, ctx->stream>>>(a);
+    else
+        grav_walk_exact_kernel<false><<<dim3((unsigned) blocks), dim3(threads), 0, ctx->stream>>>(a);
+    SHQ_HIP(hipGetLastError());
+    SHQ_HIP(hipEventRecord(ctx->ev_end[SHQ_NTIMERS - 1], ctx->stream));
+    return SHQ_OK;
+}
+
+int shq_launch_grav_postprocess(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets,
+                                int update_potential)
+{
+    if(ntargets == 0)
+        return SHQ_OK;
+    const int threads = 256;
+    const long long blocks = (ntargets + threads - 1) / threads;
+    grav_postprocess_kernel<<<dim3((unsigned) blocks), dim3(threads), 0, ctx->stream>>>(
+        d_active, ntargets, ctx->posm.ptr, ctx->acc.ptr, ctx->pot.ptr, ctx->treeacc.ptr, p->G, p->ForceSoftening,
+        p->cbrtrho0, update_potential);
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}
+
+int shq_launch_oldacc(shq_context *ctx, double G)
+{
+    SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "refresh_oldacc: no particles uploaded");
+    if(ctx->numpart == 0)
+        return SHQ_OK;
+    const int threads = 256;
+    const long long blocks = (ctx->numpart + threads - 1) / threads;
+    oldacc_kernel<<<dim3((unsigned) blocks), dim3(threads), 0, ctx->stream>>>(ctx->numpart, ctx->treeacc.ptr,
+                                                                              ctx->gravpm.ptr, ctx->oldacc.ptr, G);
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}

@@ -1,0 +1,326 @@
+/* pm.hip — long-range particle-mesh force entirely on the device (gfx950).
+ *
+ * Replaces, for a single rank, the host loops of libgadget/petapm.cpp that stay on the CPU even
+ * with UseGPU (petapm.cpp:21-28): CIC deposit (pm_iterate/put_particle_to_mesh :1132-1197,
+ * :1304-1310), the transfer-function sweeps (pm_apply_transfer_function :1258-1298 with
+ * potential_transfer gravpm.cpp:378-444) and the CIC readout (gravpm.cpp:489-500), plus the
+ * heffte/cuFFT r2c/c2r (petapm.cpp:49-71).
+ *
+ * MI355X-first choices:
+ *  - no regions/pencil exchange on one GPU: particles deposit straight into the global mesh;
+ *  - the deposit accumulates in 64-bit fixed point with integer atomics: integer addition is
+ *    associative, so the mesh is bit-identical for any particle order / GPU count (the
+ *    reference's `omp atomic` f64 adds are order dependent);
+ *  - one in-place r2c and ONE in-place c2r (the potential).  The reference does three more
+ *    c2r's after multiplying by i*K(w), K = (8 sin w - sin 2w)/6 (gravpm.cpp:448-478); that
+ *    symbol is exactly the Fourier image of the 4-point difference
+ *        -(N/L) [ 2/3 (f(+1)-f(-1)) - 1/12 (f(+2)-f(-2)) ],
+ *    which the readout kernel applies in real space while gathering: 2 FFTs instead of 5.
+ * All arithmetic is f64.
+ */
+#include "common.hpp"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ int wrapi(int i, int N) { return i >= N ? i - N : (i < 0 ? i + N : i); }
+
+/* CIC cell + residual: petapm.cpp:1147-1160 */
+__device__ __forceinline__ void cic_setup(double p, double inv_cell, int N, int &ic, double &res)
+{
+    const double tmp = p * inv_cell;
+    const double fl = floor(tmp);
+    res = tmp - fl;
+    int i = (int) fl;
+    i %= N;
+    if(i < 0)
+        i += N;
+    ic = i;
+}
+
+__global__ void pm_zero_kernel(unsigned long long *mesh, size_t n)
+{
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    for(; i < n; i += stride)
+        mesh[i] = 0ull;
+}
+
+/* put_particle_to_mesh, petapm.cpp:1304-1310, fixed-point accumulate */
+__global__ __launch_bounds__(256) void pm_deposit_kernel(const double4 *__restrict__ posm, const uint8_t *__restrict__ pflags,
+                                                         long long n, unsigned long long *mesh, int N, double inv_cell,
+                                                         double scale)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    if(pflags && (pflags[i] & 2)) /* Swallowed: RegionInd = -2, gravpm.cpp:176-178 */
+        return;
+    const double4 p = posm[i];
+    int ic[3];
+    double res[3];
+    cic_setup(p.x, inv_cell, N, ic[0], res[0]);
+    cic_setup(p.y, inv_cell, N, ic[1], res[1]);
+    cic_setup(p.z, inv_cell, N, ic[2], res[2]);
+    const size_t sy = (size_t) (N + 2), sx = (size_t) N * (N + 2);
+#pragma unroll
+    for(int c = 0; c < 8; c++) {
+        double w = 1.0;
+        size_t lin = 0;
+#pragma unroll
+        for(int k = 0; k < 3; k++) {
+            const int off = (c >> k) & 1;
+            const int t = wrapi(ic[k] + off, N);
+            lin += (size_t) t * (k == 0 ? sx : (k == 1 ? sy : 1));
+            w *= off ? res[k] : (1 - res[k]);
+        }
+        const long long q = __double2ll_rn(w * p.w * scale);
+        atomicAdd(&mesh[lin], (unsigned long long) q);
+    }
+}
+
+__global__ void pm_convert_kernel(double *mesh, size_t n, double inv_scale)
+{
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    long long *im = reinterpret_cast<long long *>(mesh);
+    for(; i < n; i += stride)
+        mesh[i] = (double) im[i] * inv_scale;
+}
+
+/* potential_transfer, gravpm.cpp:378-444, on the [x][y][z'] half spectrum */
+__global__ __launch_bounds__(256) void pm_green_kernel(double2 *cmesh, int N, int Nc, const double *__restrict__ sinctab,
+                                                       double asmth2, double pot_factor)
+{
+    const size_t total = (size_t) N * N * Nc;
+    size_t ip = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if(ip >= total)
+        return;
+    const int z = (int) (ip % Nc);
+    const size_t xy = ip / Nc;
+    const int y = (int) (xy % N);
+    const int x = (int) (xy / N);
+    const int kx = x <= N / 2 ? x : x - N; /* petapm_mesh_to_k, petapm.cpp:159-162 */
+    const int ky = y <= N / 2 ? y : y - N;
+    const int kz = z;
+    const long long k2 = (long long) kx * kx + (long long) ky * ky + (long long) kz * kz;
+    double2 v = cmesh[ip];
+    if(k2 == 0) {
+        v.x = 0;
+        v.y = 0;
+    } else {
+        double f = 1.0;
+        const double smth = exp(-(double) k2 * asmth2) / (double) k2;
+        f *= sinctab[x];
+        f *= sinctab[y];
+        f *= sinctab[z];
+        const double fac = pot_factor * smth * f * f;
+        v.x *= fac;
+        v.y *= fac;
+    }
+    cmesh[ip] = v;
+}
+
+/* readout_potential / readout_force_{x,y,z}, gravpm.cpp:489-500, with the force obtained by
+ * 4-point differencing of the potential mesh (see file header). */
+__global__ __launch_bounds__(256) void pm_readout_kernel(const double4 *__restrict__ posm, const uint8_t *__restrict__ pflags,
+                                                         long long n, const double *__restrict__ mesh, int N,
+                                                         double inv_cell, double ffac, double *gravpm, double *pmpot)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    double g0 = 0, g1 = 0, g2 = 0, gp = 0;
+    if(!(pflags && (pflags[i] & 2))) {
+        const double4 p = posm[i];
+        int ic[3];
+        double res[3];
+        cic_setup(p.x, inv_cell, N, ic[0], res[0]);
+        cic_setup(p.y, inv_cell, N, ic[1], res[1]);
+        cic_setup(p.z, inv_cell, N, ic[2], res[2]);
+        const size_t sy = (size_t) (N + 2), sx = (size_t) N * (N + 2);
+        /* wrapped indices for offsets -2..3 along every axis */
+        size_t ox[6], oy[6], oz[6];
+#pragma unroll
+        for(int d = 0; d < 6; d++) {
+            ox[d] = (size_t) wrapi(ic[0] + d - 2, N) * sx;
+            oy[d] = (size_t) wrapi(ic[1] + d - 2, N) * sy;
+            oz[d] = (size_t) wrapi(ic[2] + d - 2, N);
+        }
+        const double c1 = 2.0 / 3.0, c2 = 1.0 / 12.0;
+#pragma unroll
+        for(int c = 0; c < 8; c++) {
+            const int a = c & 1, b = (c >> 1) & 1, e = (c >> 2) & 1;
+            const double w = (a ? res[0] : 1 - res[0]) * (b ? res[1] : 1 - res[1]) * (e ? res[2] : 1 - res[2]);
+            const int X = 2 + a, Y = 2 + b, Z = 2 + e;
+            const double phi = mesh[ox[X] + oy[Y] + oz[Z]];
+            const double fx = ffac * (c1 * (mesh[ox[X + 1] + oy[Y] + oz[Z]] - mesh[ox[X - 1] + oy[Y] + oz[Z]]) -
+                                      c2 * (mesh[ox[X + 2] + oy[Y] + oz[Z]] - mesh[ox[X - 2] + oy[Y] + oz[Z]]));
+            const double fy = ffac * (c1 * (mesh[ox[X] + oy[Y + 1] + oz[Z]] - mesh[ox[X] + oy[Y - 1] + oz[Z]]) -
+                                      c2 * (mesh[ox[X] + oy[Y + 2] + oz[Z]] - mesh[ox[X] + oy[Y - 2] + oz[Z]]));
+            const double fz = ffac * (c1 * (mesh[ox[X] + oy[Y] + oz[Z + 1]] - mesh[ox[X] + oy[Y] + oz[Z - 1]]) -
+                                      c2 * (mesh[ox[X] + oy[Y] + oz[Z + 2]] - mesh[ox[X] + oy[Y] + oz[Z - 2]]));
+            gp += w * phi;
+            g0 += w * fx;
+            g1 += w * fy;
+            g2 += w * fz;
+        }
+    }
+    gravpm[3 * i + 0] = g0;
+    gravpm[3 * i + 1] = g1;
+    gravpm[3 * i + 2] = g2;
+    pmpot[i] = gp;
+}
+
+__global__ void pm_unpad_kernel(const double *mesh, double *dense, int N)
+{
+    const size_t total = (size_t) N * N * N;
+    size_t ip = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if(ip >= total)
+        return;
+    const int z = (int) (ip % N);
+    const size_t xy = ip / N;
+    dense[ip] = mesh[xy * (N + 2) + z];
+}
+__global__ void pm_pad_kernel(const double *dense, double *mesh, int N)
+{
+    const size_t total = (size_t) N * N * N;
+    size_t ip = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if(ip >= total)
+        return;
+    const int z = (int) (ip % N);
+    const size_t xy = ip / N;
+    mesh[xy * (N + 2) + z] = dense[ip];
+}
+
+} // namespace
+
+void shq_pm_destroy_plans(shq_context *ctx)
+{
+    if(ctx->have_plans) {
+        hipfftDestroy(ctx->plan_r2c);
+        hipfftDestroy(ctx->plan_c2r);
+        ctx->have_plans = false;
+        ctx->pm_nmesh = 0;
+    }
+}
+
+static int pm_prepare(shq_context *ctx, int N)
+{
+    SHQ_CHECK(N >= 4 && N % 2 == 0, SHQ_ERR_INVALID, "Nmesh must be even and >= 4 (got %d)", N);
+    if(ctx->have_plans && ctx->pm_nmesh == N)
+        return SHQ_OK;
+    shq_pm_destroy_plans(ctx);
+    const size_t padded = (size_t) N * N * (N + 2);
+    SHQ_TRY(ctx->mesh.reserve(padded));
+    SHQ_TRY(ctx->sinctab.reserve(N));
+    /* 1/sinc^2(pi k/N) per mesh index: gravpm.cpp:294-302, :398-402 */
+    std::vector<double> tab(N);
+    for(int i = 0; i < N; i++) {
+        const int k = i <= N / 2 ? i : i - N;
+        double tmp = (k * M_PI) / N;
+        double s;
+        if(tmp < 1e-5 && tmp > -1e-5) {
+            double x2 = tmp * tmp;
+            s = 1.0 - x2 / 6. + x2 * x2 / 120.;
+        } else
+            s = sin(tmp) / tmp;
+        tab[i] = 1. / (s * s);
+    }
+    SHQ_HIP(hipMemcpy(ctx->sinctab.ptr, tab.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    hipfftResult r = hipfftPlan3d(&ctx->plan_r2c, N, N, N, HIPFFT_D2Z);
+    SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftPlan3d(D2Z, %d) failed: %d", N, (int) r);
+    r = hipfftPlan3d(&ctx->plan_c2r, N, N, N, HIPFFT_Z2D);
+    SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftPlan3d(Z2D, %d) failed: %d", N, (int) r);
+    hipfftSetStream(ctx->plan_r2c, ctx->stream);
+    hipfftSetStream(ctx->plan_c2r, ctx->stream);
+    ctx->have_plans = true;
+    ctx->pm_nmesh = N;
+    return SHQ_OK;
+}
+
+int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
+{
+    SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "pm: particles must be uploaded first");
+    SHQ_CHECK(pm->BoxSize > 0 && pm->Asmth > 0, SHQ_ERR_INVALID, "pm params: BoxSize and Asmth must be > 0");
+    const int N = pm->Nmesh;
+    SHQ_TRY(pm_prepare(ctx, N));
+    const size_t padded = (size_t) N * N * (N + 2);
+    const int Nc = N / 2 + 1;
+    const double inv_cell = N / pm->BoxSize; /* 1/CellSize */
+    const long long n = ctx->numpart;
+    /* fixed-point scale: 2^e with e chosen so that the whole mass in one cell cannot overflow */
+    int e = ctx->pm_log2scale;
+    const double scale = ldexp(1.0, e);
+    const int threads = 256;
+
+    pm_zero_kernel<<<dim3(2048), dim3(threads), 0, ctx->stream>>>((unsigned long long *) ctx->mesh.ptr, padded);
+    if(n > 0)
+        pm_deposit_kernel<<<dim3((unsigned) ((n + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+            ctx->posm.ptr, ctx->pflags.ptr, n, (unsigned long long *) ctx->mesh.ptr, N, inv_cell, scale);
+    pm_convert_kernel<<<dim3(2048), dim3(threads), 0, ctx->stream>>>(ctx->mesh.ptr, padded, 1.0 / scale);
+    SHQ_HIP(hipGetLastError());
+    if(ctx->pm_keep) {
+        SHQ_TRY(ctx->dbg_rho.reserve((size_t) N * N * N));
+        const size_t tot = (size_t) N * N * N;
+        pm_unpad_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(ctx->mesh.ptr, ctx->dbg_rho.ptr, N);
+    }
+    hipfftResult r = hipfftExecD2Z(ctx->plan_r2c, (hipfftDoubleReal *) ctx->mesh.ptr, (hipfftDoubleComplex *) ctx->mesh.ptr);
+    SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecD2Z failed: %d", (int) r);
+    {
+        const size_t tot = (size_t) N * N * Nc;
+        const double asmth2 = pow((2 * M_PI) * pm->Asmth / N, 2);
+        const double pot_factor = -pm->G / (M_PI * pm->BoxSize);
+        pm_green_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+            (double2 *) ctx->mesh.ptr, N, Nc, ctx->sinctab.ptr, asmth2, pot_factor);
+    }
+    r = hipfftExecZ2D(ctx->plan_c2r, (hipfftDoubleComplex *) ctx->mesh.ptr, (hipfftDoubleReal *) ctx->mesh.ptr);
+    SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecZ2D failed: %d", (int) r);
+    if(ctx->pm_keep) {
+        SHQ_TRY(ctx->dbg_pot.reserve((size_t) N * N * N));
+        const size_t tot = (size_t) N * N * N;
+        pm_unpad_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(ctx->mesh.ptr, ctx->dbg_pot.ptr, N);
+    }
+    if(n > 0) {
+        const double ffac = -(N / pm->BoxSize);
+        pm_readout_kernel<<<dim3((unsigned) ((n + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+            ctx->posm.ptr, ctx->pflags.ptr, n, ctx->mesh.ptr, N, inv_cell, ffac, ctx->gravpm.ptr, ctx->pmpot.ptr);
+    }
+    SHQ_HIP(hipGetLastError());
+    ctx->have_pm_result = true;
+    return SHQ_OK;
+}
+
+int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *complx)
+{
+    SHQ_TRY(pm_prepare(ctx, N));
+    const size_t tot = (size_t) N * N * N;
+    DevBuf<double> dense;
+    SHQ_TRY(dense.reserve(tot));
+    SHQ_HIP(hipMemcpyAsync(dense.ptr, real, tot * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const int threads = 256;
+    pm_pad_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(dense.ptr, ctx->mesh.ptr, N);
+    hipfftResult r = hipfftExecD2Z(ctx->plan_r2c, (hipfftDoubleReal *) ctx->mesh.ptr, (hipfftDoubleComplex *) ctx->mesh.ptr);
+    SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecD2Z failed: %d", (int) r);
+    SHQ_HIP(hipMemcpyAsync(complx, ctx->mesh.ptr, (size_t) N * N * (N + 2) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    dense.release();
+    return SHQ_OK;
+}
+
+int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double *real)
+{
+    SHQ_TRY(pm_prepare(ctx, N));
+    const size_t tot = (size_t) N * N * N;
+    DevBuf<double> dense;
+    SHQ_TRY(dense.reserve(tot));
+    SHQ_HIP(hipMemcpyAsync(ctx->mesh.ptr, complx, (size_t) N * N * (N + 2) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipfftResult r = hipfftExecZ2D(ctx->plan_c2r, (hipfftDoubleComplex *) ctx->mesh.ptr, (hipfftDoubleReal *) ctx->mesh.ptr);
+    SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecZ2D failed: %d", (int) r);
+    const int threads = 256;
+    pm_unpad_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(ctx->mesh.ptr, dense.ptr, N);
+    SHQ_HIP(hipMemcpyAsync(real, dense.ptr, tot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    dense.release();
+    return SHQ_OK;
+}

@@ -1,0 +1,183 @@
+/* hostapi.cpp — flat C test/driver API over the host mirror (ctypes-friendly). */
+#include "gravity.hpp"
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <random>
+#include <string>
+
+static thread_local std::string g_err;
+extern "C" void shqh_set_error(const char *msg) { g_err = msg ? msg : ""; }
+extern "C" const char *shqh_last_error(void) { return g_err.c_str(); }
+
+static double g_kernels[SHQ_NGRAVTAB][5];
+
+extern "C" {
+
+part_manager_type *shqh_partmanager_create(particle_data *base, int64_t n, double BoxSize)
+{
+    part_manager_type *pm = (part_manager_type *) calloc(1, sizeof(part_manager_type));
+    pm->Base = base;
+    pm->NumPart = n;
+    pm->MaxPart = n;
+    pm->BoxSize = BoxSize;
+    return pm;
+}
+void shqh_partmanager_free(part_manager_type *pm) { free(pm); }
+
+ForceTree *shqh_force_tree_rebuild_mask(part_manager_type *pm, int mask, const int *active, int64_t nactive, int full)
+{
+    ForceTree *t = (ForceTree *) calloc(1, sizeof(ForceTree));
+    ActiveParticles act;
+    memset(&act, 0, sizeof(act));
+    act.ActiveParticle = (int *) active;
+    act.NumActiveParticle = nactive;
+    int rc = force_tree_rebuild_mask(t, pm, mask, active ? &act : nullptr, 1);
+    if(rc != 0) {
+        char buf[128];
+        snprintf(buf, sizeof(buf), "force_tree_rebuild_mask failed with code %d%s", rc,
+                 rc == 2 ? " (more than NMAXCHILD particles at one position)" : "");
+        shqh_set_error(buf);
+        free(t);
+        return nullptr;
+    }
+    if(full)
+        t->full_particle_tree_flag = 1;
+    return t;
+}
+void shqh_force_tree_free(ForceTree *t)
+{
+    if(!t)
+        return;
+    force_tree_free(t);
+    free(t);
+}
+void shqh_tree_info(const ForceTree *t, int64_t out[5])
+{
+    out[0] = t->firstnode;
+    out[1] = t->lastnode;
+    out[2] = t->numnodes;
+    out[3] = t->NumParticles;
+    out[4] = t->full_particle_tree_flag;
+}
+const NODE *shqh_tree_nodes(const ForceTree *t) { return t->Nodes_base; }
+const int *shqh_tree_father(const ForceTree *t) { return t->Father; }
+void shqh_tree_view(const ForceTree *t, shq_tree_view *out) { *out = force_tree_view(t); }
+void shqh_part_view(part_manager_type *pm, shq_part_view *out) { *out = make_part_view(pm->Base, pm->NumPart); }
+
+int shqh_set_kernel_table(const double *table)
+{
+    memcpy(g_kernels, table, sizeof(g_kernels));
+    return gravshort_set_kernel_table(g_kernels);
+}
+void shqh_set_gravshort_treepar(double ErrTolForceAcc, double BHOpeningAngle, double MaxBHOpeningAngle, int TreeUseBH,
+                                double Rcut, double FractionalGravitySoftening, int windowtype)
+{
+    struct gravshort_tree_params p;
+    memset(&p, 0, sizeof(p));
+    p.ErrTolForceAcc = ErrTolForceAcc;
+    p.BHOpeningAngle = BHOpeningAngle;
+    p.MaxBHOpeningAngle = MaxBHOpeningAngle;
+    p.TreeUseBH = TreeUseBH;
+    p.Rcut = Rcut;
+    p.FractionalGravitySoftening = FractionalGravitySoftening;
+    p.MaxExportBufferBytes = 3584 * 1024 * 1024L;
+    p.ShortRangeForceWindowType = (enum ShortRangeForceWindowType) windowtype;
+    set_gravshort_treepar(p);
+}
+int shqh_get_TreeUseBH(void) { return get_gravshort_treepar().TreeUseBH; }
+void shqh_gravshort_set_softenings(double MeanSeparation) { gravshort_set_softenings(MeanSeparation); }
+double shqh_FORCE_SOFTENING(void) { return FORCE_SOFTENING(); }
+
+int shqh_make_grav_params(double BoxSize, double Asmth, int Nmesh, double G, double rho0, shq_grav_params *out)
+{
+    PetaPM pm;
+    gravpm_init_periodic(&pm, BoxSize, Asmth, Nmesh, G);
+    return make_grav_params(&pm, BoxSize, rho0, out);
+}
+
+int shqh_grav_short_tree(shq_context *ctx, part_manager_type *pmgr, ForceTree *tree, double Asmth, int Nmesh, double G,
+                         const int *active, int64_t nactive, double *AccelStore, double rho0, int UseGPU, int walk_mode,
+                         shq_walk_stats *stats)
+{
+    PetaPM pm;
+    gravpm_init_periodic(&pm, pmgr->BoxSize, Asmth, Nmesh, G);
+    ActiveParticles act;
+    memset(&act, 0, sizeof(act));
+    act.ActiveParticle = (int *) active;
+    act.NumActiveParticle = active ? nactive : pmgr->NumPart;
+    return grav_short_tree(ctx, &act, &pm, tree, pmgr, (MyFloat (*)[3]) AccelStore, rho0, 0, UseGPU != 0, walk_mode, stats);
+}
+
+int shqh_gravpm_force(shq_context *ctx, part_manager_type *pmgr, double Asmth, int Nmesh, double G, int UseGPU)
+{
+    PetaPM pm;
+    gravpm_init_periodic(&pm, pmgr->BoxSize, Asmth, Nmesh, G);
+    return gravpm_force(ctx, &pm, pmgr, UseGPU != 0);
+}
+
+/* Synthetic inputs of SURVEY.md §8(d): kind 0 S-grid, 1 S-uniform, 2 S-cluster
+ * (mirrors tests/test_gravity.cpp:316-341 with a 64-bit engine). n3 = particles per dimension
+ * for the grid; n = total particles otherwise. */
+void shqh_synth_positions(int kind, int64_t n, uint64_t seed, double L, double *pos)
+{
+    if(kind == 0) {
+        const int64_t nc = (int64_t) llround(cbrt((double) n));
+        for(int64_t i = 0; i < n; i++) {
+            pos[3 * i] = (L / nc) * (i / nc / nc);
+            pos[3 * i + 1] = (L / nc) * ((i / nc) % nc);
+            pos[3 * i + 2] = (L / nc) * (i % nc);
+        }
+        return;
+    }
+    std::mt19937_64 gen(seed);
+    auto u01 = [&]() { return (double) (gen() >> 11) * (1.0 / 9007199254740992.0); };
+    for(int64_t i = 0; i < n; i++) {
+        for(int j = 0; j < 3; j++) {
+            double v;
+            if(kind == 1 || i < n / 4)
+                v = L * u01();
+            else if(i < 3 * n / 4)
+                v = L / 2 + L / 8 * exp(pow(u01() - 0.5, 2));
+            else
+                v = L * 0.1 + L / 32 * exp(pow(u01() - 0.5, 2));
+            pos[3 * i + j] = v;
+        }
+    }
+}
+
+/* Sort particle indices along a Morton (Z-order) key of `bits` bits per dimension so that
+ * consecutive particles are spatially close (the reference keeps particles in Peano-Hilbert
+ * order, domain.cpp:268; any space-filling order gives compact target groups). */
+void shqh_morton_order(const double *pos, int64_t n, double L, int32_t *order)
+{
+    struct KV { uint64_t k; int32_t i; };
+    KV *kv = (KV *) malloc(sizeof(KV) * (size_t) (n > 0 ? n : 1));
+    const double scale = (double) (1 << 21) / (L * 1.001);
+#pragma omp parallel for
+    for(int64_t i = 0; i < n; i++) {
+        uint64_t key = 0;
+        uint64_t c[3];
+        for(int j = 0; j < 3; j++) {
+            double v = (pos[3 * i + j] + L / 2000.) * scale;
+            if(v < 0) v = 0;
+            if(v > (double) ((1 << 21) - 1)) v = (double) ((1 << 21) - 1);
+            c[j] = (uint64_t) v;
+        }
+        for(int b = 20; b >= 0; b--)
+            key = (key << 3) | (((c[2] >> b) & 1) << 2) | (((c[1] >> b) & 1) << 1) | ((c[0] >> b) & 1);
+        kv[i].k = key;
+        kv[i].i = (int32_t) i;
+    }
+    qsort(kv, (size_t) n, sizeof(KV), [](const void *a, const void *b) {
+        const KV *x = (const KV *) a, *y = (const KV *) b;
+        if(x->k != y->k) return x->k < y->k ? -1 : 1;
+        return x->i < y->i ? -1 : (x->i > y->i ? 1 : 0);
+    });
+    for(int64_t i = 0; i < n; i++)
+        order[i] = kv[i].i;
+    free(kv);
+}
+
+} /* extern "C" */

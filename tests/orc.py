@@ -1,0 +1,129 @@
+"""ctypes wrapper of the CPU oracle (oracle/liboracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from shenqi_amd.capi import GravParams, PMParams, NODE_DTYPE, ptr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_path = os.path.join(ROOT, "oracle", "liboracle.so")
+if not os.path.exists(_path):
+    raise ImportError(f"{_path} missing: run `make -C oracle` (or __graft_entry__.build())")
+lib = C.CDLL(_path)
+_vp = C.c_void_p
+lib.orc_tree_build.argtypes = [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_double, _vp, C.c_int64, _vp]
+lib.orc_tree_build.restype = C.c_int64
+lib.orc_grav_walk.argtypes = [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int64, C.POINTER(GravParams), _vp, _vp, _vp]
+lib.orc_grav_walk.restype = None
+lib.orc_grav_postprocess.argtypes = [_vp, _vp, C.c_int64, C.POINTER(GravParams), C.c_int, _vp, _vp]
+lib.orc_grav_postprocess.restype = None
+lib.orc_apply_accn.argtypes = [_vp, C.c_double, C.c_double, C.POINTER(GravParams), _vp, _vp]
+lib.orc_force_direct.argtypes = [_vp, _vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int, _vp]
+lib.orc_force_direct.restype = None
+lib.orc_pm_force.argtypes = [_vp, _vp, _vp, C.c_int64, C.POINTER(PMParams), C.c_int, C.c_int, _vp, _vp, _vp, _vp]
+lib.orc_pm_force.restype = None
+lib.orc_fft_r2c.argtypes = [C.c_int, _vp, _vp]
+lib.orc_fft_r2c.restype = None
+lib.orc_fft_c2r.argtypes = [C.c_int, _vp, _vp]
+lib.orc_fft_c2r.restype = None
+lib.orc_density_kernel.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, _vp]
+lib.orc_num_threads.restype = C.c_int
+
+
+def tree_build(pos, mass, BoxSize, hsml=None, idx=None, numpart_total=None):
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    mass = np.ascontiguousarray(mass, dtype=np.float32)
+    n = len(pos) if idx is None else len(idx)
+    ntot = len(pos) if numpart_total is None else numpart_total
+    maxnodes = int(2.0 * n) + 4096
+    while True:
+        nodes = np.zeros(maxnodes, dtype=NODE_DTYPE)
+        father = np.full(ntot, -1, dtype=np.int32)
+        nn = lib.orc_tree_build(ptr(pos), ptr(mass), ptr(hsml), ptr(idx), n, ntot, BoxSize, ptr(nodes), maxnodes, ptr(father))
+        if nn >= 0:
+            return nodes[:nn].copy(), ntot, father
+        maxnodes *= 2
+
+
+def grav_walk(nodes, firstnode, pos, mass, oldacc, gp, targets=None):
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    mass = np.ascontiguousarray(mass, dtype=np.float32)
+    oldacc = np.ascontiguousarray(oldacc, dtype=np.float64)
+    nt = len(pos) if targets is None else len(targets)
+    acc = np.zeros((nt, 3))
+    pot = np.zeros(nt)
+    nint = np.zeros(nt, dtype=np.int64)
+    lib.orc_grav_walk(ptr(nodes), firstnode, ptr(pos), ptr(mass), ptr(oldacc), ptr(targets), nt, C.byref(gp), ptr(acc), ptr(pot), ptr(nint))
+    return acc, pot, nint
+
+
+def grav_postprocess(mass, gp, acc, pot, update_potential, targets=None):
+    mass = np.ascontiguousarray(mass, dtype=np.float32)
+    lib.orc_grav_postprocess(ptr(mass), ptr(targets), len(acc), C.byref(gp), int(update_potential), ptr(acc), ptr(pot))
+
+
+def apply_accn(dx, r2, mass, gp):
+    dx = np.ascontiguousarray(dx, dtype=np.float64)
+    acc = np.zeros(3)
+    pot = np.zeros(1)
+    applied = lib.orc_apply_accn(ptr(dx), r2, mass, C.byref(gp), ptr(acc), ptr(pot))
+    return applied, acc, pot[0]
+
+
+def force_direct(pos, mass, BoxSize, G, h, repeat=1):
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    mass = np.ascontiguousarray(mass, dtype=np.float32)
+    acc = np.zeros((len(pos), 3))
+    lib.orc_force_direct(ptr(pos), ptr(mass), len(pos), BoxSize, G, h, repeat, ptr(acc))
+    return acc
+
+
+def pm_force(pos, mass, Nmesh, BoxSize, Asmth, G, skip=None, fixed_point_log2scale=-1, use_stencil=0, want_mesh=False):
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    mass = np.ascontiguousarray(mass, dtype=np.float32)
+    pm = PMParams(Nmesh, 0, BoxSize, Asmth, G)
+    g = np.zeros((len(pos), 3))
+    pot = np.zeros(len(pos))
+    rho = np.zeros((Nmesh, Nmesh, Nmesh)) if want_mesh else None
+    phi = np.zeros((Nmesh, Nmesh, Nmesh)) if want_mesh else None
+    lib.orc_pm_force(ptr(pos), ptr(mass), ptr(skip), len(pos), C.byref(pm), fixed_point_log2scale, use_stencil,
+                     ptr(g), ptr(pot), ptr(rho), ptr(phi))
+    return g, pot, rho, phi
+
+
+def fft_r2c(real):
+    N = real.shape[0]
+    real = np.ascontiguousarray(real, dtype=np.float64)
+    out = np.zeros((N, N, N // 2 + 1), dtype=np.complex128)
+    lib.orc_fft_r2c(N, ptr(real), ptr(out))
+    return out
+
+
+def fft_c2r(cplx):
+    N = cplx.shape[0]
+    cplx = np.ascontiguousarray(cplx, dtype=np.complex128)
+    out = np.zeros((N, N, N))
+    lib.orc_fft_c2r(N, ptr(cplx), ptr(out))
+    return out
+
+
+def density_kernel(ktype, H, u, eta=1.0):
+    out = np.zeros(5)
+    rc = lib.orc_density_kernel(ktype, H, u, eta, ptr(out))
+    assert rc == 0
+    return dict(desnumngb=out[0], volume=out[1], wk=out[2], dwk=out[3], dW=out[4])
+
+
+def boost_mt19937_uniform(seed, n, skip=0):
+    """boost::random::mt19937(seed) through boost::random::uniform_real_distribution<double>(0,1):
+    one 32-bit draw per variate, value = draw / 2^32 (tests/test_gravity.cpp:318, test_density.cpp:273)."""
+    rs = np.random.RandomState()
+    # init_genrand(seed), identical to boost/std mt19937(seed)
+    mt = np.zeros(624, dtype=np.uint64)
+    mt[0] = seed & 0xFFFFFFFF
+    for i in range(1, 624):
+        mt[i] = (1812433253 * (int(mt[i - 1]) ^ (int(mt[i - 1]) >> 30)) + i) & 0xFFFFFFFF
+    rs.set_state(("MT19937", mt.astype(np.uint32), 624))
+    raw = rs.randint(0, 2**32, size=skip + n, dtype=np.uint64)  # one tempered 32-bit output each
+    return raw[skip:].astype(np.float64) / 4294967296.0

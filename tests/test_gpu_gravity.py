@@ -1,0 +1,250 @@
+"""GPU parity tests of the short-range tree walk and the PM force, through the C-ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import shenqi_amd as sq
+from shenqi_amd import capi
+import orc
+import common as cm
+
+pytestmark = pytest.mark.gpu
+
+
+def _positions(kind, n=16**3):
+    if kind == "grid":
+        return cm.grid_positions(round(n ** (1 / 3)))
+    if kind == "close":
+        return cm.close_positions(round(n ** (1 / 3)))
+    if kind == "random":
+        return cm.random_positions(orc.boost_mt19937_uniform(0, 3 * n), n)
+    if kind == "cluster":
+        return sq.synth_positions("cluster", n, L=cm.BOX)
+    raise ValueError(kind)
+
+
+def _gpu_walk(ctx, pman, tree, gp, oldacc_from, active=None, update_potential=True, mode=sq.WALK_EXACT):
+    """resident API: upload, set OldAcc inputs, run, download"""
+    P = pman.Base
+    P["FullTreeGravAccel"] = oldacc_from[0]
+    P["GravPM"] = oldacc_from[1]
+    pv, tv = pman.view(), tree.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    capi.check(capi.hip.shq_tree_upload(ctx.h, C.byref(tv)))
+    capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, gp.G))
+    a = None if active is None else np.ascontiguousarray(active, dtype=np.int32)
+    capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), capi.ptr(a), 0 if a is None else len(a), int(update_potential), mode))
+    n = pman.NumPart
+    acc = np.zeros((n, 3)); pot = np.zeros(n); nint = np.zeros(n, dtype=np.int64)
+    st = sq.WalkStats()
+    capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), capi.ptr(pot), capi.ptr(nint), C.byref(st)))
+    return acc, pot, nint, st
+
+
+@pytest.mark.parametrize("kind", ["grid", "close", "random"])
+@pytest.mark.parametrize("usebh", [1, 0])
+def test_walk_exact_parity_16(ctx, kind, usebh):
+    """L1 ladder: identical opening decisions => identical interaction counts (integers, exact)
+    and forces within the reference's CPU<->GPU bar (runtests.cpp:441-443: max < 1e-5)."""
+    pos = _positions(kind)
+    n = len(pos)
+    pman = cm.make_partmanager(pos)
+    tree = sq.force_tree_full(pman)
+    cm.reference_treepar(ErrTolForceAcc=0.002, MaxBHOpeningAngle=0.9, TreeUseBH=usebh)
+    sq.gravshort_set_softenings(cm.BOX / np.cbrt(n))
+    gp = sq.make_grav_params(cm.BOX, 1.5, 48, cm.G, cm.RHO0)
+    rng = np.random.default_rng(5)
+    told = rng.normal(size=(n, 3)) * 500.0      # arbitrary previous-step accelerations
+    pold = rng.normal(size=(n, 3)) * 50.0
+    acc, pot, nint, st = _gpu_walk(ctx, pman, tree, gp, (told, pold))
+    oldacc = np.linalg.norm(told + pold, axis=1) / cm.G
+    mass = pman.Base["Mass"]
+    oacc, opot, onint = orc.grav_walk(tree.Nodes_base, tree.firstnode, pos, mass, oldacc, gp)
+    orc.grav_postprocess(mass, gp, oacc, opot, True)
+    assert np.array_equal(nint, onint)
+    assert st.ninteractions == onint.sum() and st.min_interactions == onint.min() and st.max_interactions == onint.max()
+    scale = np.abs(oacc).max()
+    assert np.abs(acc - oacc).max() < 1e-11 * scale
+    if kind != "grid":
+        assert cm.force_err(acc, oacc).max() < 1e-5
+    assert np.allclose(pot, opot, rtol=1e-10, atol=1e-10 * np.abs(opot).max())
+
+
+def test_walk_exact_parity_64_cluster(ctx):
+    """S-cluster 64^3, Nmesh 192, relative criterion at ErrTolForceAcc 0.005 (north-star setting)."""
+    n = 64**3
+    L = 1.0
+    pos = sq.synth_positions("cluster", n, L=L)
+    pos = pos[sq.morton_order(pos, L)]
+    pman = cm.make_partmanager(pos, box=L)
+    tree = sq.force_tree_full(pman)
+    sq.set_gravshort_treepar(ErrTolForceAcc=0.005, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=1, Rcut=6.0)
+    sq.gravshort_set_softenings(L / 64)
+    gp = sq.make_grav_params(L, 1.5, 192, cm.G, cm.RHO0)
+    mass = pman.Base["Mass"]
+    z = np.zeros((n, 3))
+    acc1, _, nint1, st1 = _gpu_walk(ctx, pman, tree, gp, (z, z))                    # BH seeding pass
+    o1, op1, on1 = orc.grav_walk(tree.Nodes_base, tree.firstnode, pos, mass, np.zeros(n), gp)
+    orc.grav_postprocess(mass, gp, o1, op1, True)
+    assert np.array_equal(nint1, on1)
+    sq.set_gravshort_treepar(ErrTolForceAcc=0.005, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=0, Rcut=6.0)
+    gp = sq.make_grav_params(L, 1.5, 192, cm.G, cm.RHO0)
+    acc2, pot2, nint2, st2 = _gpu_walk(ctx, pman, tree, gp, (o1, z))
+    o2, op2, on2 = orc.grav_walk(tree.Nodes_base, tree.firstnode, pos, mass, np.linalg.norm(o1, axis=1) / cm.G, gp)
+    orc.grav_postprocess(mass, gp, o2, op2, True)
+    assert np.array_equal(nint2, on2)
+    err = cm.force_err(acc2, o2)
+    assert err.max() < 1e-5
+    rms = np.sqrt(np.mean(np.sum((acc2 - o2) ** 2, axis=1) / np.sum(o2 ** 2, axis=1)))
+    assert rms < 1e-3          # north-star tolerance (BASELINE.json); in practice ~1e-14
+    print("64^3 cluster: interactions/target mean %.1f min %d max %d, visited/wave %.0f, kernel %.2f ms, rms %.2e"
+          % (on2.mean(), on2.min(), on2.max(), st2.nnodes_visited / (n / 64), st2.kernel_ms, rms))
+
+
+def test_walk_active_subset_and_edges(ctx):
+    """ragged / empty active lists; accel rows of inactive particles untouched (reduce<PRIMARY>
+    assigns only walked targets, localtreewalk2.h:39)."""
+    pos = _positions("random")
+    n = len(pos)
+    pman = cm.make_partmanager(pos)
+    tree = sq.force_tree_full(pman)
+    cm.reference_treepar(MaxBHOpeningAngle=0.9, TreeUseBH=1)
+    sq.gravshort_set_softenings(cm.BOX / np.cbrt(n))
+    pm = dict(Asmth=1.5, Nmesh=48, G=cm.G)
+    gp = sq.make_grav_params(cm.BOX, 1.5, 48, cm.G, cm.RHO0)
+    mass = pman.Base["Mass"]
+    full, _, _ = orc.grav_walk(tree.Nodes_base, tree.firstnode, pos, mass, np.zeros(n), gp)
+    full *= cm.G
+    for act in (np.arange(0, n, 7, dtype=np.int32), np.array([n - 1], dtype=np.int32), np.array([], dtype=np.int32),
+                np.arange(0, 65, dtype=np.int32)):
+        store = np.full((n, 3), 777.0)
+        tree.full_particle_tree_flag = 1
+        st = sq.grav_short_tree(ctx, act, pm, tree, store, cm.RHO0)
+        assert st.ntargets == len(act)
+        mask = np.zeros(n, dtype=bool)
+        mask[act] = True
+        assert np.all(store[~mask] == 777.0)
+        if len(act):
+            assert np.abs(store[mask] - full[mask]).max() < 1e-11 * np.abs(full).max()
+        cm.reference_treepar(MaxBHOpeningAngle=0.9, TreeUseBH=1)
+
+
+def test_error_behaviour(ctx):
+    pos = _positions("grid")
+    pman = cm.make_partmanager(pos)
+    tree = sq.force_tree_full(pman)
+    cm.reference_treepar()
+    sq.gravshort_set_softenings(0.5)
+    pm = dict(Asmth=1.5, Nmesh=48, G=cm.G)
+    with pytest.raises(sq.ShqError):           # no CPU fallback in the product
+        sq.grav_short_tree(ctx, None, pm, tree, None, cm.RHO0, UseGPU=False)
+    with pytest.raises(sq.ShqError):
+        sq.gravpm_force(ctx, pm, pman, UseGPU=False)
+    with pytest.raises(sq.ShqError):           # exact window needs Asmth 1.5
+        sq.grav_short_tree(ctx, None, dict(Asmth=1.25, Nmesh=48, G=cm.G), tree, None, cm.RHO0)
+    gas_tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+    with pytest.raises(sq.ShqError):           # gravshort2.hpp:208-210 mask check
+        sq.grav_short_tree(ctx, None, pm, gas_tree, None, cm.RHO0)
+    c2 = sq.Context(0)
+    gp = sq.make_grav_params(cm.BOX, 1.5, 48, cm.G, cm.RHO0)
+    rc = capi.hip.shq_grav_short_run(c2.h, C.byref(gp), None, 0, 1, 0)
+    assert rc == 4 and b"upload" in capi.hip.shq_last_error()      # SHQ_ERR_STATE
+    c2.close()
+
+
+@pytest.mark.parametrize("kind", ["random", "close"])
+def test_pm_parity_16(ctx, kind):
+    """PM ladder: deposit mesh bit-exact against the fixed-point oracle, GravPM / potential
+    within FFT-library rounding of the reference-structure oracle (5 FFTs, k-space differencing)."""
+    pos = _positions(kind)
+    n = len(pos)
+    pman = cm.make_partmanager(pos)
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    capi.check(capi.hip.shq_pm_set_debug(ctx.h, 1))
+    pmp = sq.PMParams(48, 0, cm.BOX, 1.5, cm.G)
+    capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
+    g = np.zeros((n, 3)); ppot = np.zeros(n)
+    capi.check(capi.hip.shq_pm_download(ctx.h, capi.ptr(g), capi.ptr(ppot)))
+    rho = np.zeros((48, 48, 48)); phi = np.zeros((48, 48, 48))
+    capi.check(capi.hip.shq_pm_download_mesh(ctx.h, 0, capi.ptr(rho)))
+    capi.check(capi.hip.shq_pm_download_mesh(ctx.h, 1, capi.ptr(phi)))
+    capi.check(capi.hip.shq_pm_set_debug(ctx.h, 0))
+    mass = pman.Base["Mass"]
+    e = 61 - int(np.frexp(float(n))[1])       # the library's scale rule: 2^(61 - ex), msum < 2^ex
+    og, opot, orho, ophi = orc.pm_force(pos, mass, 48, cm.BOX, 1.5, cm.G, fixed_point_log2scale=e, use_stencil=0, want_mesh=True)
+    assert np.array_equal(rho, orho)                                  # integer deposit: bit-exact
+    assert abs(rho.sum() - n) < 1e-6
+    assert np.abs(phi - ophi).max() < 1e-11 * np.abs(ophi).max()
+    assert np.abs(g - og).max() < 1e-10 * np.abs(og).max()
+    assert np.abs(ppot - opot).max() < 1e-10 * np.abs(opot).max()
+    # against the plain-f64 reference-structure oracle the only extra difference is the 2^-e quantum
+    og2, _, _, _ = orc.pm_force(pos, mass, 48, cm.BOX, 1.5, cm.G)
+    assert np.abs(g - og2).max() < 1e-9 * np.abs(og2).max()
+    # bit-pattern reproducibility per FFT plan: same inputs, same plan => identical bits
+    capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
+    g2 = np.zeros((n, 3)); p2 = np.zeros(n)
+    capi.check(capi.hip.shq_pm_download(ctx.h, capi.ptr(g2), capi.ptr(p2)))
+    assert np.array_equal(g, g2) and np.array_equal(ppot, p2)
+    # ... and for any particle order (order-independent integer deposit)
+    perm = np.random.default_rng(1).permutation(n)
+    pman2 = cm.make_partmanager(pos[perm])
+    pv2 = pman2.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv2)))
+    capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
+    g3 = np.zeros((n, 3)); p3 = np.zeros(n)
+    capi.check(capi.hip.shq_pm_download(ctx.h, capi.ptr(g3), capi.ptr(p3)))
+    assert np.array_equal(g3, g[perm]) and np.array_equal(p3, ppot[perm])
+
+
+def test_fft_dropins(ctx):
+    """petapm_fft_r2c / petapm_fft_c2r drop-ins: unscaled, round trip = N^3 * identity."""
+    N = 24
+    a = np.random.default_rng(2).normal(size=(N, N, N))
+    out = np.zeros((N, N, N // 2 + 1), dtype=np.complex128)
+    capi.check(capi.hip.shq_fft_r2c(ctx.h, N, capi.ptr(a), capi.ptr(out)))
+    ref = orc.fft_r2c(a)
+    assert np.abs(out - ref).max() < 1e-12 * np.abs(ref).max()
+    back = np.zeros((N, N, N))
+    capi.check(capi.hip.shq_fft_c2r(ctx.h, N, capi.ptr(out), capi.ptr(back)))
+    assert np.abs(back - a * N**3).max() < 1e-11 * N**3
+
+
+def _do_force_test(ctx, pos, Nmesh=48, ErrTol=0.002, direct=True):
+    """do_force_test, tests/test_gravity.cpp:197-247, through the host mirror of the reference API."""
+    n = len(pos)
+    pman = cm.make_partmanager(pos)
+    pm = dict(Asmth=1.5, Nmesh=Nmesh, G=cm.G)
+    sq.gravpm_force(ctx, pm, pman)
+    tree = sq.force_tree_full(pman)
+    cm.reference_treepar(ErrTolForceAcc=ErrTol)                 # TreeUseBH = 2, MaxBHOpeningAngle = 0
+    sq.gravshort_set_softenings(cm.BOX / np.cbrt(n))
+    sq.grav_short_tree(ctx, None, pm, tree, None, cm.RHO0)
+    assert sq.get_TreeUseBH() == 0                              # gravshort-tree2.cpp:168-171
+    st = sq.grav_short_tree(ctx, None, pm, tree, None, cm.RHO0)
+    P = pman.Base
+    total = P["GravPM"] + P["FullTreeGravAccel"]
+    if not direct:
+        return total, st
+    pair = orc.force_direct(pos, P["Mass"], cm.BOX, cm.G, sq.FORCE_SOFTENING(), 1)
+    return cm.check_accns(pair, total), st
+
+
+def test_reference_gate_force_flat_gpu(ctx):
+    total, st = _do_force_test(ctx, cm.grid_positions(16), direct=False)
+    assert np.abs(total).max() < 0.015          # tests/test_gravity.cpp:288-289
+    assert np.abs(total).mean() < 0.005
+
+
+@pytest.mark.parametrize("kind", ["close", "random0", "random1"])
+def test_reference_gate_force_vs_direct_gpu(ctx, kind):
+    n = 16**3
+    if kind == "close":
+        pos = cm.close_positions(16)
+    else:
+        k = int(kind[-1])
+        pos = cm.random_positions(orc.boost_mt19937_uniform(0, 3 * n, skip=3 * n * k), n)
+    (meanerr, maxerr), st = _do_force_test(ctx, pos)
+    assert maxerr < 3 * 0.002                   # tests/test_gravity.cpp:165-166
+    assert meanerr < 0.8 * 0.002

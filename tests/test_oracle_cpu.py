@@ -1,0 +1,263 @@
+"""CPU tests pinning the oracle: reference golden values, reference-built pieces (oracle/_ref),
+and the reference's own accuracy gates, plus host-logic checks (tree builder, params)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import shenqi_amd as sq
+from shenqi_amd import capi
+import orc
+import common as cm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+
+# tests/test_densitykernel.cpp:13-36 (exact golden values)
+KERNEL_GOLDEN = {
+    1: dict(desnumngb=33.510321638291124, wk=0.079577471545947673, dwk=-0.238732414637843),
+    4: dict(desnumngb=65.449846949787357, wk=0.075283862851696096, dwk=-0.29142140458721072),
+    2: dict(desnumngb=113.09733552923254, wk=0.066304197971682174, dwk=-0.3147351169541876),
+}
+
+
+@pytest.mark.parametrize("ktype", [1, 2, 4])
+def test_density_kernel_golden(ktype):
+    k = orc.density_kernel(ktype, 2.0, 0.5, 1.0)
+    g = KERNEL_GOLDEN[ktype]
+    assert abs(k["desnumngb"] - g["desnumngb"]) < 1e-9 * g["desnumngb"]
+    assert k["volume"] == 4.0 / 3.0 * np.pi * 2.0**3
+    assert k["wk"] == g["wk"]
+    assert k["dwk"] == g["dwk"]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "libdensitykernel_ref.so")), reason="oracle/_ref not built")
+def test_density_kernel_vs_reference_build():
+    ref = C.CDLL(os.path.join(REFDIR, "libdensitykernel_ref.so"))
+    ref.ref_density_kernel.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]
+    rng = np.random.default_rng(7)
+    for ktype in (1, 2, 4):
+        for _ in range(200):
+            H, u, eta = rng.uniform(0.01, 5), rng.uniform(0, 1.05), rng.uniform(0.5, 2)
+            out = np.zeros(5)
+            assert ref.ref_density_kernel(ktype, H, u, eta, capi.ptr(out)) == 0
+            k = orc.density_kernel(ktype, H, u, eta)
+            got = np.array([k["desnumngb"], k["volume"], k["wk"], k["dwk"], k["dW"]])
+            assert np.array_equal(got, out), (ktype, H, u, got, out)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "libshortrange_ref.so")), reason="oracle/_ref not built")
+def test_shortrange_table_fixture_matches_reference_data():
+    ref = C.CDLL(os.path.join(REFDIR, "libshortrange_ref.so"))
+    arr = (C.c_double * (512 * 5)).in_dll(ref, "shortrange_force_kernels")
+    tab = np.frombuffer(arr, dtype=np.float64).reshape(512, 5)
+    assert np.array_equal(tab, capi.load_kernel_table())
+
+
+def test_shortrange_table_properties():
+    tab = capi.load_kernel_table()
+    assert tab.shape == (512, 5)
+    assert tab[1, 0] == 0.029354207436397859 or abs(tab[1, 0] - 0.029354207436397859) < 1e-15
+    assert abs(tab[-1, 0] - 15.0) < 1e-12
+    # GravShortTable (gravity.h:32-61): exact window = columns 2 (force) and 1 (potential)
+    cm.reference_treepar()
+    gp = sq.make_grav_params(8.0, 1.5, 48, cm.G, cm.RHO0)
+    assert np.array_equal(np.array(gp.shortrange_table), tab[:, 2].astype(np.float32))
+    assert np.array_equal(np.array(gp.shortrange_table_potential), tab[:, 1].astype(np.float32))
+    assert gp.dx == tab[1, 0]
+    # Asmth != 1.5 with the exact window is an error (gravshort-tree2.cpp:42-46)
+    with pytest.raises(sq.ShqError):
+        sq.make_grav_params(8.0, 1.25, 48, cm.G, cm.RHO0)
+
+
+def test_grav_params_mirror_reference_ctor():
+    """GravTreeParams ctor, gravshort2.hpp:45-54."""
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=0)
+    sq.gravshort_set_softenings(8.0 / 16)
+    gp = sq.make_grav_params(8.0, 1.5, 48, cm.G, cm.RHO0)
+    assert gp.cellsize == 8.0 / 48
+    assert gp.Rcut == 6.0 * 1.5 * (8.0 / 48)
+    assert gp.ForceSoftening == 2.8 * (1.0 / 30.0) * (8.0 / 16)
+    assert gp.BHOpeningAngle2 == 0.9 * 0.9      # TreeUseBH == 0 -> MaxBHOpeningAngle
+    cm.reference_treepar(TreeUseBH=1)
+    gp = sq.make_grav_params(8.0, 1.5, 48, cm.G, cm.RHO0)
+    assert gp.BHOpeningAngle2 == 0.175 * 0.175
+
+
+def _apply_accn_numpy(dx, mass, gp):
+    """independent float64 restatement for the L0 check"""
+    r2 = float(np.dot(dx, dx))
+    r = np.sqrt(r2)
+    h = gp.ForceSoftening
+    fac = mass / (r2 * r)
+    if r2 < h * h:
+        u = r / h
+        if u < 0.5:
+            fac = mass / h**3 * (10.666666666667 + u * u * (32.0 * u - 38.4))
+        else:
+            fac = mass / h**3 * (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u**3 - 0.066666666667 / u**3)
+    i = r / gp.cellsize / gp.dx
+    ti = int(np.floor(i))
+    if ti >= 511:
+        return np.zeros(3)
+    t = np.array(gp.shortrange_table, dtype=np.float64)
+    fac *= (ti + 1 - i) * t[ti] + (i - ti) * t[ti + 1]
+    return dx * fac
+
+
+def test_apply_accn_l0():
+    cm.reference_treepar()
+    sq.gravshort_set_softenings(8.0 / 16)
+    gp = sq.make_grav_params(8.0, 1.5, 48, cm.G, cm.RHO0)
+    rng = np.random.default_rng(3)
+    for _ in range(500):
+        dx = rng.normal(size=3) * 10 ** rng.uniform(-3, 0.5)
+        applied, acc, pot = orc.apply_accn(dx, float(np.dot(dx, dx)), 1.5, gp)
+        want = _apply_accn_numpy(dx, 1.5, gp)
+        assert np.allclose(acc, want, rtol=1e-13, atol=0)
+        assert applied == (1 if np.linalg.norm(dx) / gp.cellsize / gp.dx < 511 else 0)
+    # beyond the table (15 cells) nothing is added: gravity.h:52-54
+    applied, acc, pot = orc.apply_accn(np.array([15.1 * gp.cellsize, 0, 0]), (15.1 * gp.cellsize) ** 2, 1.0, gp)
+    assert applied == 0 and np.all(acc == 0) and pot == 0
+
+
+def _canon(nodes, firstnode, no):
+    """canonical recursive description of a tree: (len, center, sorted particle list | children)"""
+    nd = nodes[no - firstnode]
+    ct = (nd["flags"] >> 3) & 3
+    if ct == 0:
+        return ("L", float(nd["len"]), tuple(nd["center"]), tuple(sorted(nd["suns"][: nd["noccupied"]])))
+    kids = [c for c in nd["suns"] if c >= 0]
+    return ("N", float(nd["len"]), tuple(nd["center"]), tuple(_canon(nodes, firstnode, c) for c in kids))
+
+
+def _walk_order(nodes, firstnode):
+    """follow the threaded walk opening every node; returns visited node list"""
+    out = []
+    no = firstnode
+    while no >= 0:
+        nd = nodes[no - firstnode]
+        out.append(no)
+        ct = (nd["flags"] >> 3) & 3
+        no = nd["suns"][0] if ct == 1 else nd["sibling"]
+    return out
+
+
+@pytest.mark.parametrize("kind", ["grid", "random", "close"])
+def test_host_tree_equals_reference_insertion_tree(kind):
+    """The product's top-down builder must yield the tree the reference's insertion algorithm
+    yields (restated in oracle/grav.cpp from forcetree.cpp)."""
+    n = 16**3
+    if kind == "grid":
+        pos = cm.grid_positions(16)
+    elif kind == "close":
+        pos = cm.close_positions(16)
+    else:
+        pos = cm.random_positions(orc.boost_mt19937_uniform(0, 3 * n), n)
+    pman = cm.make_partmanager(pos)
+    tree = sq.force_tree_full(pman)
+    hn = tree.Nodes_base
+    on, ofirst, ofather = orc.tree_build(pos, pman.Base["Mass"], cm.BOX)
+    assert tree.firstnode == ofirst == n
+    assert _canon(hn, n, n) == _canon(on, n, n)
+    # threaded traversal visits the same sequence of cells
+    ho = [(_c["len"], tuple(_c["center"])) for _c in (hn[i - n] for i in _walk_order(hn, n))]
+    oo = [(_c["len"], tuple(_c["center"])) for _c in (on[i - n] for i in _walk_order(on, n))]
+    assert ho == oo
+    # moments: mass conservation and matching centre of mass (tests/test_forcetree.cpp:117-169)
+    assert hn[0]["mass"] == n
+    hm = {(_c["len"], tuple(_c["center"])): (_c["mass"], tuple(_c["cofm"])) for _c in hn[: tree.numnodes] if _c["father"] >= -1 and _c["mass"] > 0}
+    for _c in on:
+        if _c["mass"] > 0 and (_c["len"], tuple(_c["center"])) in hm:
+            m, cofm = hm[(_c["len"], tuple(_c["center"]))]
+            assert m == _c["mass"]
+            assert np.allclose(cofm, _c["cofm"], rtol=1e-14, atol=1e-14)
+
+
+def _oracle_treepm(pos, ErrTol=0.002, Nmesh=48, Rcut=7.0, MaxBH=0.0, nodes=None):
+    """do_force_test, tests/test_gravity.cpp:197-247, with the oracle."""
+    n = len(pos)
+    mass = np.ones(n, dtype=np.float32)
+    gpm, pot, _, _ = orc.pm_force(pos, mass, Nmesh, cm.BOX, 1.5, cm.G)
+    if nodes is None:
+        nodes, first, _ = orc.tree_build(pos, mass, cm.BOX)
+    first = n
+    cm.reference_treepar(ErrTolForceAcc=ErrTol, MaxBHOpeningAngle=MaxBH, Rcut=Rcut)
+    sq.gravshort_set_softenings(cm.BOX / np.cbrt(n))
+    gp = sq.make_grav_params(cm.BOX, 1.5, Nmesh, cm.G, cm.RHO0)          # TreeUseBH = 2: BH pass
+    oldacc = np.linalg.norm(gpm, axis=1) / cm.G                        # FullTreeGravAccel = 0 initially
+    acc, tpot, nint1 = orc.grav_walk(nodes, first, pos, mass, oldacc, gp)
+    orc.grav_postprocess(mass, gp, acc, tpot, True)
+    cm.reference_treepar(ErrTolForceAcc=ErrTol, MaxBHOpeningAngle=MaxBH, Rcut=Rcut, TreeUseBH=0)   # gravshort-tree2.cpp:170-171
+    gp = sq.make_grav_params(cm.BOX, 1.5, Nmesh, cm.G, cm.RHO0)
+    oldacc = np.linalg.norm(acc + gpm, axis=1) / cm.G
+    acc2, tpot2, nint2 = orc.grav_walk(nodes, first, pos, mass, oldacc, gp)
+    orc.grav_postprocess(mass, gp, acc2, tpot2, True)
+    return gpm, acc2, (nint1, nint2)
+
+
+def test_reference_gate_force_flat():
+    """tests/test_gravity.cpp:249-292: homogeneous grid => total force ~ 0."""
+    pos = cm.grid_positions(16)
+    gpm, acc, _ = _oracle_treepm(pos)
+    tot = np.abs(gpm + acc)
+    assert tot.max() < 0.015
+    assert tot.mean() < 0.005
+
+
+@pytest.mark.parametrize("kind", ["close", "random0", "random1"])
+def test_reference_gate_force_vs_direct(kind):
+    """tests/test_gravity.cpp:294-355 with check_against_force_direct (:145-169)."""
+    n = 16**3
+    if kind == "close":
+        pos = cm.close_positions(16)
+    else:
+        k = int(kind[-1])
+        u = orc.boost_mt19937_uniform(0, 3 * n, skip=3 * n * k)   # the engine is shared by both iterations (:349-353)
+        pos = cm.random_positions(u, n)
+    gpm, acc, nint = _oracle_treepm(pos)
+    sq.gravshort_set_softenings(cm.BOX / np.cbrt(n))
+    direct = orc.force_direct(pos, np.ones(n, dtype=np.float32), cm.BOX, cm.G, sq.FORCE_SOFTENING(), 1)
+    meanerr, maxerr = cm.check_accns(direct, gpm + acc)
+    assert maxerr < 3 * 0.002, (meanerr, maxerr)
+    assert meanerr < 0.8 * 0.002, (meanerr, maxerr)
+
+
+def test_oracle_walk_relative_criterion_vs_open_tree():
+    """runtests.cpp:304-315: tree (relative criterion, MaxBHOpeningAngle 0.9) vs fully open tree:
+    mean error <= 1.2 ErrTolForceAcc."""
+    n = 16**3
+    pos = cm.random_positions(orc.boost_mt19937_uniform(0, 3 * n), n)
+    gpm, acc_open, _ = _oracle_treepm(pos, MaxBH=0.0)
+    gpm, acc_rel, (n1, n2) = _oracle_treepm(pos, MaxBH=0.9)
+    err = cm.force_err(acc_rel, acc_open)
+    assert err.mean() <= 1.2 * 0.002
+    assert n2.max() < n  # not fully open
+
+
+def test_oracle_fft_matches_numpy():
+    rng = np.random.default_rng(11)
+    for N in (12, 48):
+        a = rng.normal(size=(N, N, N))
+        f = orc.fft_r2c(a)
+        ref = np.fft.rfftn(a)
+        assert np.abs(f - ref).max() < 1e-12 * np.abs(ref).max()
+        back = orc.fft_c2r(f)
+        assert np.abs(back - a * N**3).max() < 1e-12 * N**3
+
+
+def test_oracle_pm_stencil_equals_kspace_difference():
+    """one c2r + 4-point real-space difference == three extra c2r with i*K(w) (gravpm.cpp:448-488)."""
+    n = 16**3
+    pos = cm.random_positions(orc.boost_mt19937_uniform(0, 3 * n), n)
+    m = np.ones(n, dtype=np.float32)
+    g0, p0, rho, phi = orc.pm_force(pos, m, 48, cm.BOX, 1.5, cm.G, use_stencil=0, want_mesh=True)
+    g1, p1, _, _ = orc.pm_force(pos, m, 48, cm.BOX, 1.5, cm.G, use_stencil=1)
+    assert abs(rho.sum() - n) < 1e-9        # mass conservation, petapm.cpp:1225-1255
+    assert np.abs(g0 - g1).max() < 1e-12 * np.abs(g0).max()
+    assert np.allclose(p0, p1, rtol=1e-12, atol=0)   # deposit order (omp atomic) is not fixed
+    # fixed-point deposit: quantised at 2^-e, force agrees to ~1e-11
+    g2, _, rho2, _ = orc.pm_force(pos, m, 48, cm.BOX, 1.5, cm.G, fixed_point_log2scale=48, use_stencil=1, want_mesh=True)
+    assert np.abs(rho2 - rho).max() < 8 * 2.0**-48 * 64
+    assert np.abs(g2 - g1).max() < 1e-10 * np.abs(g1).max()
