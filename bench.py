@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py — particle-steps/s of one TreePM force evaluation (PM + short-range tree walk).
+
+Contract: python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over the resident particle set: shq_pm_run (CIC deposit,
+r2c, potential transfer, c2r, readout) + shq_grav_short_run (relative-criterion walk for every
+particle) + OldAcc refresh.  Inputs are resident in HBM when the timed region starts; tree
+build and host packing are outside it.
+
+Workload at N=1: BASELINE.json configs[1] — dm-only 256^3, Nmesh 768, S-cluster positions,
+Asmth 1.5, TreeRcut 6, softening 2.8 L/(30 n), exact window, ErrTolForceAcc 0.005, after a
+theta=0.175 Barnes-Hut seeding walk.  For N>1 every rank runs the same workload on its own GPU
+(independent replicas; the sharded multi-GPU exchange path is not built yet) => "scaling": "weak".
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+# host-side OpenMP (tree build, CPU baseline) uses the cores this process may run on
+os.environ.setdefault("OMP_NUM_THREADS", str(len(os.sched_getaffinity(0))))
+
+G = 43.0071
+RHO0 = 0.3 * 3 * 0.1 * 0.1 / (8 * np.pi * G)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VECTOR_PEAK_TF = 78.6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=256, help="particles per dimension (default 256 = configs[1])")
+    ap.add_argument("--errtol", type=float, default=0.005)
+    ap.add_argument("--kind", default="cluster", choices=["cluster", "uniform", "grid"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--walk-mode", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(pos, mass, tree, gp_rel, oldacc, L):
+    """Oracle (CPU port of the reference algorithm) on a bounded 1/64 sample of the workload:
+    the tree walk of every 64th 64-target group on the SAME tree, plus a full PM step of a
+    64^3-particle / 192^3-mesh sub-problem (1/64 of the particles and of the mesh)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc  # noqa: E402  (oracle = checker / reported baseline only)
+
+    n = len(pos)
+    groups = np.arange(0, n // 64, 64)
+    targets = (groups[:, None] * 64 + np.arange(64)[None, :]).ravel().astype(np.int32)
+    if len(targets) == 0:
+        targets = np.arange(n, dtype=np.int32)
+    t0 = time.perf_counter()
+    orc.grav_walk(tree.Nodes_base, tree.firstnode, pos, mass, oldacc, gp_rel, targets=targets)
+    t_tree = time.perf_counter() - t0
+    nsub = min(n, 64**3)
+    sub = pos[:: max(1, n // nsub)][:nsub]
+    t0 = time.perf_counter()
+    orc.pm_force(sub, np.ones(len(sub), dtype=np.float32), 192, L, 1.5, G)
+    t_pm = time.perf_counter() - t0
+    frac_tree = len(targets) / n
+    frac_pm = len(sub) / n
+    est_full = t_tree / frac_tree + t_pm / frac_pm
+    return {
+        "value": n / est_full, "unit": "particle-steps/s", "cores": orc.lib.orc_num_threads(), "kind": "port",
+        "sample": "oracle tree walk of %d of %d targets (every 64th 64-target group, same tree) in %.2f s + oracle PM step "
+                  "(reference structure, 5 FFTs) on a %d-particle/192^3-mesh sub-problem in %.2f s; each scaled by its "
+                  "fraction of the full job" % (len(targets), n, t_tree, len(sub), t_pm),
+        "tree_s_sample": t_tree, "pm_s_sample": t_pm,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    import shenqi_amd as sq
+    from shenqi_amd import capi
+
+    n1 = args.n
+    n = n1**3
+    L = 1.0
+    nmesh = 3 * n1 if n1 != 512 else 1024
+    t_setup = time.perf_counter()
+    pos = sq.synth_positions(args.kind, n, seed=20240601 + rank, L=L)
+    pos = pos[sq.morton_order(pos, L)]
+    pman = sq.PartManager(n, L)
+    P = pman.Base
+    P["Pos"] = pos
+    P["Type"] = 1
+    P["Mass"] = 1.0
+    tree = sq.force_tree_full(pman)
+    t_tree_build = time.perf_counter() - t_setup
+
+    ctx = sq.Context(local_rank if world > 1 else 0)
+    sq.set_gravshort_treepar(ErrTolForceAcc=args.errtol, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=1, Rcut=6.0)
+    sq.gravshort_set_softenings(L / n1)
+    gp_bh = sq.make_grav_params(L, 1.5, nmesh, G, RHO0)
+    sq.set_gravshort_treepar(ErrTolForceAcc=args.errtol, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=0, Rcut=6.0)
+    gp_rel = sq.make_grav_params(L, 1.5, nmesh, G, RHO0)
+    pmp = sq.PMParams(nmesh, 0, L, 1.5, G)
+
+    pv, tv = pman.view(), tree.view()
+    t0 = time.perf_counter()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    capi.check(capi.hip.shq_tree_upload(ctx.h, C.byref(tv)))
+    t_upload = time.perf_counter() - t0
+
+    def step(gp):
+        capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
+        capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, args.walk_mode))
+        capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, G))
+
+    # seeding: PM + Barnes-Hut walk (theta = 0.175) so that the timed walks use the relative criterion
+    t0 = time.perf_counter()
+    step(gp_bh)
+    ctx.synchronize()
+    t_seed = time.perf_counter() - t0
+    for _ in range(args.warmup):
+        step(gp_rel)
+    ctx.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    walk_ms, pm_ms = [], []
+    barrier()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.timer_begin(0)
+    for _ in range(args.steps):
+        step(gp_rel)
+    ctx.timer_end(0)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    ev_ms = ctx.timer_ms(0)
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-kernel durations of the last step (HIP events recorded on the launch stream)
+    st = sq.WalkStats()
+    capi.check(capi.hip.shq_grav_short_download(ctx.h, None, None, None, C.byref(st)))
+    ph = (C.c_double * 6)()
+    capi.check(capi.hip.shq_pm_phase_ms(ctx.h, C.byref(ph)))
+    ph = list(ph)
+
+    ncells = float(nmesh) ** 3
+    # algorithmic bytes
+    tree_bytes = 68.0 * n + 76.0 * tree.numnodes          # compulsory: targets in/out + node pool once
+    pm_bytes = 468.0 * n + 240.0 * ncells                  # fused minimum of the reference structure
+    walk_s = st.kernel_ms * 1e-3
+    pm_s = ph[5] * 1e-3
+    dominant = "grav_walk_exact_kernel" if walk_s >= pm_s else "pm (deposit+r2c+transfer+c2r+readout)"
+    if walk_s >= pm_s:
+        ach = tree_bytes / walk_s / 1e9
+    else:
+        ach = pm_bytes / pm_s / 1e9
+    out = {
+        "metric": "particle-steps/sec (grav+PM+SPH) at 256^3; rms force error vs ref",
+        "value": n * world * args.steps / elapsed,
+        "unit": "particle-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "dm-only %d^3 TreePM (S-%s, Nmesh %d, Asmth 1.5, Rcut 6, ErrTolForceAcc %g, exact window)"
+                               % (n1, args.kind, nmesh, args.errtol),
+                   "particles_per_gpu": n, "nmesh": nmesh, "parallelism": "replicas x%d" % world if world > 1 else "1 GPU",
+                   "walk": "exact (per-target reference opening decisions)"},
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": None},
+        "kernels": {
+            "tree_walk_ms": st.kernel_ms, "tree_interactions_per_target": st.ninteractions / max(1, st.ntargets),
+            "tree_interactions_per_s": st.ninteractions / max(walk_s, 1e-12),
+            "tree_fp64_frac_of_vector_peak": 45.0 * st.ninteractions / max(walk_s, 1e-12) / 1e12 / FP64_VECTOR_PEAK_TF,
+            "tree_nodes_visited_per_wave": st.nnodes_visited / max(1.0, st.ntargets / 64.0),
+            "tree_lane_efficiency": st.ninteractions / max(1.0, 64.0 * st.nwave_interactions),
+            "tree_algorithmic_GBs": tree_bytes / max(walk_s, 1e-12) / 1e9,
+            "pm_ms": {"deposit": ph[0], "r2c": ph[1], "transfer": ph[2], "c2r": ph[3], "readout": ph[4], "total": ph[5]},
+            "pm_algorithmic_GBs": pm_bytes / max(pm_s, 1e-12) / 1e9,
+            "pm_frac_of_hbm_peak": pm_bytes / max(pm_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
+            "event_ms_per_step": ev_ms / args.steps,
+        },
+        "setup_s": {"tree_build": t_tree_build, "upload": t_upload, "seed_step": t_seed},
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        oldacc = np.zeros(n)
+        acc = np.zeros((n, 3))
+        gpm = np.zeros((n, 3))
+        capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), None, None, None))
+        capi.check(capi.hip.shq_pm_download(ctx.h, capi.ptr(gpm), None))
+        oldacc = np.linalg.norm(acc + gpm, axis=1) / G
+        out["cpu_baseline"] = cpu_baseline(pos, P["Mass"], tree, gp_rel, oldacc, L)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -161,6 +161,7 @@ typedef struct shq_walk_stats {
     int64_t min_interactions;
     int64_t max_interactions;
     int64_t nnodes_visited;     /* node tests executed by wavefronts (union walk) */
+    int64_t nwave_interactions; /* interaction evaluations issued by wavefronts (x64 lanes each) */
     double kernel_ms;           /* HIP-event time of the walk kernel(s) */
 } shq_walk_stats;
 
@@ -217,6 +218,9 @@ int shq_pm_run(shq_context *ctx, const shq_pm_params *pm);
 int shq_pm_download(shq_context *ctx, double (*gravpm)[3], double *pm_potential);
 /* Debug / parity taps: copy the mesh after deposit (Nmesh^3 doubles, [x][y][z]) and the
  * potential mesh after c2r. Valid after shq_pm_run with keep_meshes set. */
+/* HIP-event durations (ms) of the last shq_pm_run's phases: [0] zero+deposit+convert, [1] r2c,
+ * [2] potential transfer, [3] c2r, [4] readout, [5] total. Synchronises. */
+int shq_pm_phase_ms(shq_context *ctx, double ms[6]);
 int shq_pm_set_debug(shq_context *ctx, int keep_meshes);
 int shq_pm_download_mesh(shq_context *ctx, int which /*0 density,1 potential*/, double *mesh);
 

@@ -205,6 +205,8 @@ extern "C" void orc_pm_force(const double *pos, const float *mass, const uint8_t
     const double CellSize = pm->BoxSize / N;
     std::vector<double> real(N3, 0.0);
     const double scale = fixed_point_log2scale >= 0 ? ldexp(1.0, fixed_point_log2scale) : 0;
+    /* fixed-point mode sums in 64-bit integers (exact, order independent) like the device */
+    std::vector<long long> ireal(fixed_point_log2scale >= 0 ? N3 : 0, 0);
 
     /* deposit: put_particle_to_mesh, petapm.cpp:1304-1310 */
 #pragma omp parallel for
@@ -224,12 +226,19 @@ extern "C" void orc_pm_force(const double *pos, const float *mass, const uint8_t
                 weight *= offset ? Res[k] : (1 - Res[k]);
             }
             double v = weight * mass[i];
-            if(fixed_point_log2scale >= 0)
-                v = (double) llrint(v * scale) / scale;
+            if(fixed_point_log2scale >= 0) {
+                const long long q = llrint(v * scale);
 #pragma omp atomic update
-            real[linear] += v;
+                ireal[linear] += q;
+            } else {
+#pragma omp atomic update
+                real[linear] += v;
+            }
         }
     }
+    if(fixed_point_log2scale >= 0)
+        for(size_t c = 0; c < N3; c++)
+            real[c] = (double) ireal[c] * (1.0 / scale);
     if(mesh_rho)
         memcpy(mesh_rho, real.data(), sizeof(double) * N3);
 

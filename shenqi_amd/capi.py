@@ -115,7 +115,8 @@ class GravParams(C.Structure):
 class WalkStats(C.Structure):
     _fields_ = [
         ("ntargets", C.c_int64), ("ninteractions", C.c_int64), ("min_interactions", C.c_int64),
-        ("max_interactions", C.c_int64), ("nnodes_visited", C.c_int64), ("kernel_ms", C.c_double),
+        ("max_interactions", C.c_int64), ("nnodes_visited", C.c_int64), ("nwave_interactions", C.c_int64),
+        ("kernel_ms", C.c_double),
     ]
 
     def asdict(self):
@@ -150,6 +151,7 @@ hip.shq_grav_short_tree.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView
 hip.shq_pm_force.argtypes = [_vp, C.POINTER(PMParams), C.POINTER(PartView), _vp, _vp]
 hip.shq_pm_run.argtypes = [_vp, C.POINTER(PMParams)]
 hip.shq_pm_download.argtypes = [_vp, _vp, _vp]
+hip.shq_pm_phase_ms.argtypes = [_vp, C.POINTER(C.c_double * 6)]
 hip.shq_pm_set_debug.argtypes = [_vp, C.c_int]
 hip.shq_pm_download_mesh.argtypes = [_vp, C.c_int, _vp]
 hip.shq_fft_r2c.argtypes = [_vp, C.c_int, _vp, _vp]

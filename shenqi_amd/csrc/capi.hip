@@ -143,13 +143,13 @@ extern "C" void *shq_stream(shq_context *ctx) { return ctx ? (void *) ctx->strea
 
 extern "C" int shq_timer_begin(shq_context *ctx, int slot)
 {
-    SHQ_CHECK(ctx && slot >= 0 && slot < SHQ_NTIMERS - 1, SHQ_ERR_INVALID, "bad timer slot %d", slot);
+    SHQ_CHECK(ctx && slot >= 0 && slot < 8, SHQ_ERR_INVALID, "bad timer slot %d", slot);
     SHQ_HIP(hipEventRecord(ctx->ev_begin[slot], ctx->stream));
     return SHQ_OK;
 }
 extern "C" int shq_timer_end(shq_context *ctx, int slot)
 {
-    SHQ_CHECK(ctx && slot >= 0 && slot < SHQ_NTIMERS - 1, SHQ_ERR_INVALID, "bad timer slot %d", slot);
+    SHQ_CHECK(ctx && slot >= 0 && slot < 8, SHQ_ERR_INVALID, "bad timer slot %d", slot);
     SHQ_HIP(hipEventRecord(ctx->ev_end[slot], ctx->stream));
     return SHQ_OK;
 }
@@ -252,85 +252,109 @@ extern "C" int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree)
     SHQ_CHECK(tree->rootnode >= tree->firstnode && tree->rootnode < tree->firstnode + tree->numnodes, SHQ_ERR_INVALID, "root node %d outside [%ld, %ld)", tree->rootnode, (long) tree->firstnode, (long) (tree->firstnode + tree->numnodes));
     SHQ_CHECK(tree->BoxSize > 0, SHQ_ERR_INVALID, "tree BoxSize must be > 0");
     SHQ_HIP(hipSetDevice(ctx->device));
-    const int64_t nn = tree->numnodes, fn = tree->firstnode;
+    const int64_t nall = tree->numnodes, fn = tree->firstnode;
     const shq_node *src = tree->nodes_base;
-    std::vector<NodeA> hA(nn);
-    std::vector<NodeB> hB(nn);
-    std::vector<NodeC> hC(nn);
-    /* leaf slot offsets: exclusive prefix sum of noccupied over leaf nodes in node-index order */
-    std::vector<int64_t> pstart(nn + 1, 0);
-    for(int64_t i = 0; i < nn; i++) {
-        int cnt = 0;
-        if(SHQ_NODE_CHILDTYPE(src[i].flags) == SHQ_PARTICLE_NODE_TYPE) {
-            cnt = src[i].noccupied;
-            if(cnt < 0 || cnt > SHQ_NMAXCHILD)
-                cnt = 0; /* unreachable scratch node */
+    /* Depth-first pre-order of the reachable nodes = the threaded walk with every node opened
+     * (open -> suns[0], otherwise -> sibling; forcetree.cpp:1016-1103 sets both).  The device
+     * pool is stored in this order so that the record after the current one is almost always
+     * the next one visited. */
+    std::vector<int32_t> order;
+    order.reserve((size_t) nall);
+    std::vector<int32_t> newidx((size_t) nall, -1);
+    {
+        int64_t no = tree->rootnode;
+        while(no >= fn && no < fn + nall) {
+            const int64_t i = no - fn;
+            SHQ_CHECK(newidx[i] < 0, SHQ_ERR_INVALID, "tree threading revisits node %ld (cycle)", (long) no);
+            newidx[i] = (int32_t) order.size();
+            order.push_back((int32_t) i);
+            const shq_node &s = src[i];
+            if(SHQ_NODE_CHILDTYPE(s.flags) == SHQ_NODE_NODE_TYPE && s.suns[0] >= fn && s.suns[0] < fn + nall)
+                no = s.suns[0];
+            else
+                no = s.sibling;
         }
-        pstart[i + 1] = pstart[i] + cnt;
+    }
+    const int64_t nn = (int64_t) order.size();
+    std::vector<NodeA> hA(nn + 1);
+    std::vector<NodeB> hB(nn + 1);
+    std::vector<NodeC> hC(nn + 1);
+    /* leaf slot offsets: exclusive prefix sum of noccupied over leaves in pre-order */
+    std::vector<int64_t> pstart(nn + 1, 0);
+    for(int64_t j = 0; j < nn; j++) {
+        const shq_node &s = src[order[j]];
+        int cnt = 0;
+        if(SHQ_NODE_CHILDTYPE(s.flags) == SHQ_PARTICLE_NODE_TYPE) {
+            cnt = s.noccupied;
+            SHQ_CHECK(cnt >= 0 && cnt <= SHQ_NMAXCHILD, SHQ_ERR_INVALID, "leaf node %ld has noccupied = %d", (long) (order[j] + fn), cnt);
+        }
+        pstart[j + 1] = pstart[j] + cnt;
     }
     const int64_t nleafparts = pstart[nn];
-    SHQ_CHECK(nleafparts < (1ll << 31), SHQ_ERR_INVALID, "too many leaf particles");
-    std::vector<int32_t> pidx((size_t) std::max<int64_t>(nleafparts, 1));
+    SHQ_CHECK(nleafparts < (1ll << 31) - 16, SHQ_ERR_INVALID, "too many leaf particles");
+    std::vector<int32_t> pidx((size_t) nleafparts + SHQ_NMAXCHILD, 0); /* padded: the walk fetches 4 slots at a time */
     std::atomic<int> bad(0);
     const int64_t np = ctx->numpart;
     parallel_for(nn, [&](int64_t lo, int64_t hi) {
-        for(int64_t i = lo; i < hi; i++) {
-            const shq_node &s = src[i];
+        for(int64_t j = lo; j < hi; j++) {
+            const shq_node &s = src[order[j]];
             NodeA a; NodeB b; NodeC c;
             a.cofm[0] = s.cofm[0]; a.cofm[1] = s.cofm[1]; a.cofm[2] = s.cofm[2]; a.mass = s.mass;
             b.center[0] = s.center[0]; b.center[1] = s.center[1]; b.center[2] = s.center[2]; b.len = s.len;
             const int64_t sib = s.sibling;
-            c.sibling = (sib >= fn && sib < fn + nn) ? (int32_t) (sib - fn) : -1;
+            c.sibling = (sib >= fn && sib < fn + nall) ? newidx[sib - fn] : -1;
             c.type = (int32_t) SHQ_NODE_CHILDTYPE(s.flags);
             c.count = 0;
             c.child = -1;
             if(c.type == SHQ_PARTICLE_NODE_TYPE) {
-                const int cnt = (int) (pstart[i + 1] - pstart[i]);
+                const int cnt = (int) (pstart[j + 1] - pstart[j]);
                 c.count = cnt;
-                c.child = (int32_t) pstart[i];
+                c.child = (int32_t) pstart[j];
                 for(int k = 0; k < cnt; k++) {
                     const int32_t p = s.suns[k];
                     if(p < 0 || p >= np) {
-                        /* only an error if the node is reachable; mark and neutralise */
-                        c.count = 0;
-                        if(s.father >= -1)
-                            bad.store(1);
+                        bad.store(1);
                         break;
                     }
-                    pidx[pstart[i] + k] = p;
+                    pidx[pstart[j] + k] = p;
                 }
-                if(c.count == 0)
-                    for(int k = 0; k < cnt; k++)
-                        pidx[pstart[i] + k] = 0;
             } else if(c.type == SHQ_NODE_NODE_TYPE) {
                 const int64_t ch = s.suns[0];
-                c.child = (ch >= fn && ch < fn + nn) ? (int32_t) (ch - fn) : -1;
+                c.child = (ch >= fn && ch < fn + nall) ? newidx[ch - fn] : -1;
                 if(c.child < 0)
                     c.type = SHQ_PSEUDO_NODE_TYPE; /* never descend into an invalid link */
             }
-            hA[i] = a; hB[i] = b; hC[i] = c;
+            hA[j] = a; hB[j] = b; hC[j] = c;
         }
     });
     SHQ_CHECK(bad.load() == 0, SHQ_ERR_INVALID, "tree leaf refers to a particle index outside [0, numpart)");
-    SHQ_TRY(ctx->nodeA.reserve(nn));
-    SHQ_TRY(ctx->nodeB.reserve(nn));
-    SHQ_TRY(ctx->nodeC.reserve(nn));
+    /* pad record: speculative fetch of pool[cur + 1] at the last node */
+    memset(&hA[nn], 0, sizeof(NodeA));
+    memset(&hB[nn], 0, sizeof(NodeB));
+    hC[nn].sibling = -1; hC[nn].child = -1; hC[nn].type = SHQ_PSEUDO_NODE_TYPE; hC[nn].count = 0;
+    SHQ_TRY(ctx->nodeA.reserve(nn + 1));
+    SHQ_TRY(ctx->nodeB.reserve(nn + 1));
+    SHQ_TRY(ctx->nodeC.reserve(nn + 1));
     SHQ_TRY(ctx->leaf_pidx.reserve(pidx.size()));
     SHQ_TRY(ctx->posm_leaf.reserve(pidx.size()));
-    SHQ_HIP(hipMemcpyAsync(ctx->nodeA.ptr, hA.data(), sizeof(NodeA) * nn, hipMemcpyHostToDevice, ctx->stream));
-    SHQ_HIP(hipMemcpyAsync(ctx->nodeB.ptr, hB.data(), sizeof(NodeB) * nn, hipMemcpyHostToDevice, ctx->stream));
-    SHQ_HIP(hipMemcpyAsync(ctx->nodeC.ptr, hC.data(), sizeof(NodeC) * nn, hipMemcpyHostToDevice, ctx->stream));
-    if(nleafparts > 0) {
-        SHQ_HIP(hipMemcpyAsync(ctx->leaf_pidx.ptr, pidx.data(), sizeof(int32_t) * nleafparts, hipMemcpyHostToDevice, ctx->stream));
-        const int threads = 256;
-        gather_leaf_kernel<<<dim3((unsigned) ((nleafparts + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-            ctx->posm.ptr, ctx->leaf_pidx.ptr, ctx->posm_leaf.ptr, nleafparts);
-        SHQ_HIP(hipGetLastError());
+    SHQ_HIP(hipMemcpyAsync(ctx->nodeA.ptr, hA.data(), sizeof(NodeA) * (nn + 1), hipMemcpyHostToDevice, ctx->stream));
+    SHQ_HIP(hipMemcpyAsync(ctx->nodeB.ptr, hB.data(), sizeof(NodeB) * (nn + 1), hipMemcpyHostToDevice, ctx->stream));
+    SHQ_HIP(hipMemcpyAsync(ctx->nodeC.ptr, hC.data(), sizeof(NodeC) * (nn + 1), hipMemcpyHostToDevice, ctx->stream));
+    {
+        const int64_t npad = (int64_t) pidx.size();
+        SHQ_HIP(hipMemcpyAsync(ctx->leaf_pidx.ptr, pidx.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice, ctx->stream));
+        if(np > 0) {
+            const int threads = 256;
+            gather_leaf_kernel<<<dim3((unsigned) ((npad + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+                ctx->posm.ptr, ctx->leaf_pidx.ptr, ctx->posm_leaf.ptr, npad);
+            SHQ_HIP(hipGetLastError());
+        } else
+            SHQ_HIP(hipMemsetAsync(ctx->posm_leaf.ptr, 0, sizeof(double4) * npad, ctx->stream));
     }
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     ctx->numnodes = nn;
     ctx->firstnode = fn;
-    ctx->root = (int32_t) (tree->rootnode - fn);
+    ctx->root = 0; /* pre-order: the root is record 0 */
     ctx->ntreeparts = nleafparts;
     ctx->treeBox = tree->BoxSize;
     ctx->have_tree = true;
@@ -381,6 +405,7 @@ extern "C" int shq_grav_short_download(shq_context *ctx, double (*accel)[3], dou
         stats->ntargets = ctx->last_stats.ntargets;
         stats->ninteractions = (int64_t) gs.ninteractions;
         stats->nnodes_visited = (int64_t) gs.nvisited;
+        stats->nwave_interactions = (int64_t) gs.nwave_applies;
         stats->min_interactions = stats->ntargets > 0 ? gs.min_int : 0;
         stats->max_interactions = gs.max_int;
         float ms = 0;
@@ -465,6 +490,23 @@ extern "C" int shq_pm_force(shq_context *ctx, const shq_pm_params *pm, const shq
     if(potential)
         for(int64_t i = 0; i < n; i++)
             potential[i] += h_pot[i]; /* readout_potential adds, gravpm.cpp:489-491 */
+    return SHQ_OK;
+}
+
+extern "C" int shq_pm_phase_ms(shq_context *ctx, double ms[6])
+{
+    SHQ_CHECK(ctx && ms, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_pm_result, SHQ_ERR_STATE, "pm_phase_ms before pm_run");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_HIP(hipEventSynchronize(ctx->ev_begin[13]));
+    for(int i = 0; i < 5; i++) {
+        float f = 0;
+        SHQ_HIP(hipEventElapsedTime(&f, ctx->ev_begin[8 + i], ctx->ev_begin[9 + i]));
+        ms[i] = f;
+    }
+    float f = 0;
+    SHQ_HIP(hipEventElapsedTime(&f, ctx->ev_begin[8], ctx->ev_begin[13]));
+    ms[5] = f;
     return SHQ_OK;
 }
 

@@ -106,6 +106,7 @@ struct NodeH { double hmax; };                    /* SPH only */
 struct GravStatsDev {
     unsigned long long ninteractions;
     unsigned long long nvisited;
+    unsigned long long nwave_applies;
     long long min_int;
     long long max_int;
 };

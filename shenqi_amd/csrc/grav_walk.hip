@@ -36,7 +36,7 @@ struct WalkArgs {
     GravStatsDev *stats;
     long long ntargets;
     int root;
-    double Box, halfBox;
+    double Box, invBox;
     double rcut, rcut2;
     double h, h2, h_inv, h3_inv;
     double inv_celldx;         /* 1 / (cellsize * dx) */
@@ -46,20 +46,26 @@ struct WalkArgs {
     const float *tab_p;
 };
 
-__device__ __forceinline__ double nearest(double x, double box, double half)
+/* NEAREST (partmanager.h:99) as d - L*rint(d/L): one multiply, one round, one fma. For
+ * |d| < L (always true for positions inside the box) this equals the reference's one-shot wrap
+ * except within an ulp of |d| = L/2, where both images are equally valid. */
+__device__ __forceinline__ double wrapd(double d, double L, double invL)
 {
-    return (x > half) ? (x - box) : ((x < -half) ? (x + box) : x);
+    return fma(-L, rint(d * invL), d);
 }
 
-/* apply_accn (gravshort2.hpp:326-358) + apply_short_range_window (gravity.h:48-60) */
+/* apply_accn (gravshort2.hpp:326-358) + apply_short_range_window (gravity.h:48-60).
+ * 1/r comes from rsqrt (v_rsq_f64 + refinement) instead of sqrt and two divides: mass/r^3 =
+ * mass*rinv^3 agrees with mass/(r2*r) to a few ulp. */
 template <bool POT>
 __device__ __forceinline__ void apply_accn(const float4 *__restrict__ tab, double dx, double dy, double dz, double r2,
                                            double mass, const WalkArgs &a, double &ax, double &ay, double &az,
                                            double &pot)
 {
-    const double r = sqrt(r2);
-    double fac = mass / (r2 * r);
-    double facpot = -mass / r;
+    const double rinv = rsqrt(r2);
+    const double r = (r2 > 0) ? r2 * rinv : 0.0;
+    double fac = mass * rinv * rinv * rinv;
+    double facpot = -mass * rinv;
     if(r2 < a.h2) {
         const double u = r * a.h_inv;
         double wp;
@@ -91,6 +97,22 @@ __device__ __forceinline__ void apply_accn(const float4 *__restrict__ tab, doubl
     }
 }
 
+template <bool POT>
+__device__ __forceinline__ void leaf_particle(const float4 *__restrict__ tab, const double4 q, double px, double py,
+                                              double pz, const WalkArgs &a, double &ax, double &ay, double &az,
+                                              double &pot)
+{
+    const double ex = wrapd(q.x - px, a.Box, a.invBox);
+    const double ey = wrapd(q.y - py, a.Box, a.invBox);
+    const double ez = wrapd(q.z - pz, a.Box, a.invBox);
+    const double rr2 = ex * ex + ey * ey + ez * ez;
+    apply_accn<POT>(tab, ex, ey, ez, rr2, q.w, a, ax, ay, az, pot);
+}
+
+/* The node pool is in depth-first pre-order (packed at upload): the first child of node i is
+ * i+1, and the `sibling` of a leaf is i+1 as well, so the record after the current one is the
+ * next to be visited unless a whole subtree is skipped.  It is fetched speculatively at the top
+ * of each visit so its latency hides behind the arithmetic of the current node. */
 template <bool POT> __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
 {
     __shared__ float4 tab[SHQ_NGRAVTAB];
@@ -118,24 +140,28 @@ template <bool POT> __global__ __launch_bounds__(256) void grav_walk_exact_kerne
     int nint = 0;
     int mynext = valid ? a.root : -2;
     int cur = a.root;
-    unsigned long long visited = 0;
+    unsigned int visited = 0, wave_applies = 0;
+
+    NodeA A = a.nodeA[cur];
+    NodeB B = a.nodeB[cur];
+    NodeC C = a.nodeC[cur];
 
     while(cur >= 0) {
-        cur = __builtin_amdgcn_readfirstlane(cur);
-        const NodeA A = a.nodeA[cur];
-        const NodeB B = a.nodeB[cur];
-        const NodeC C = a.nodeC[cur];
+        /* speculative fetch of the next pre-order record (pool is padded by one record) */
+        const NodeA A1 = a.nodeA[cur + 1];
+        const NodeB B1 = a.nodeB[cur + 1];
+        const NodeC C1 = a.nodeC[cur + 1];
         visited++;
         const bool act = (mynext == cur);
 
         /* gravshort2.hpp:262-265 */
-        double dx = nearest(A.cofm[0] - px, a.Box, a.halfBox);
-        double dy = nearest(A.cofm[1] - py, a.Box, a.halfBox);
-        double dz = nearest(A.cofm[2] - pz, a.Box, a.halfBox);
+        const double dx = wrapd(A.cofm[0] - px, a.Box, a.invBox);
+        const double dy = wrapd(A.cofm[1] - py, a.Box, a.invBox);
+        const double dz = wrapd(A.cofm[2] - pz, a.Box, a.invBox);
         const double r2 = dx * dx + dy * dy + dz * dz;
-        const double cx = fabs(nearest(B.center[0] - px, a.Box, a.halfBox));
-        const double cy = fabs(nearest(B.center[1] - py, a.Box, a.halfBox));
-        const double cz = fabs(nearest(B.center[2] - pz, a.Box, a.halfBox));
+        const double cx = fabs(wrapd(B.center[0] - px, a.Box, a.invBox));
+        const double cy = fabs(wrapd(B.center[1] - py, a.Box, a.invBox));
+        const double cz = fabs(wrapd(B.center[2] - pz, a.Box, a.invBox));
         const double len = B.len;
         /* shall_we_discard_node, gravshort2.hpp:152-167 */
         const double eff = a.rcut + 0.5 * len;
@@ -148,39 +174,65 @@ template <bool POT> __global__ __launch_bounds__(256) void grav_walk_exact_kerne
         const bool accept = act && !discard && !open;
         const bool doopen = act && !discard && open;
 
-        if(accept) {
-            apply_accn<POT>(tab, dx, dy, dz, r2, A.mass, a, ax, ay, az, pot);
-            nint++;
+        if(__ballot(accept) != 0ull) {
+            wave_applies++;
+            if(accept) {
+                apply_accn<POT>(tab, dx, dy, dz, r2, A.mass, a, ax, ay, az, pot);
+                nint++;
+            }
         }
+        int next;
         if(C.type == SHQ_PARTICLE_NODE_TYPE) {
             /* gravshort2.hpp:290-304: every particle of an opened leaf is evaluated */
             if(__ballot(doopen) != 0ull) {
-                for(int k = 0; k < C.count; k++) {
-                    const double4 q = a.posm_leaf[C.child + k];
+                const double4 *__restrict__ lp = a.posm_leaf + C.child;
+                const int cnt = C.count;
+                wave_applies += cnt;
+                /* leaf slots are contiguous and the array is padded: fetch four at a time */
+                const double4 q0 = lp[0], q1 = lp[1], q2 = lp[2], q3 = lp[3];
+                if(doopen) {
+                    if(cnt > 0) leaf_particle<POT>(tab, q0, px, py, pz, a, ax, ay, az, pot);
+                    if(cnt > 1) leaf_particle<POT>(tab, q1, px, py, pz, a, ax, ay, az, pot);
+                    if(cnt > 2) leaf_particle<POT>(tab, q2, px, py, pz, a, ax, ay, az, pot);
+                    if(cnt > 3) leaf_particle<POT>(tab, q3, px, py, pz, a, ax, ay, az, pot);
+                }
+                if(cnt > 4) {
+                    const double4 q4 = lp[4], q5 = lp[5], q6 = lp[6], q7 = lp[7];
                     if(doopen) {
-                        const double ex = nearest(q.x - px, a.Box, a.halfBox);
-                        const double ey = nearest(q.y - py, a.Box, a.halfBox);
-                        const double ez = nearest(q.z - pz, a.Box, a.halfBox);
-                        const double rr2 = ex * ex + ey * ey + ez * ez;
-                        apply_accn<POT>(tab, ex, ey, ez, rr2, q.w, a, ax, ay, az, pot);
-                        nint++;
+                        leaf_particle<POT>(tab, q4, px, py, pz, a, ax, ay, az, pot);
+                        if(cnt > 5) leaf_particle<POT>(tab, q5, px, py, pz, a, ax, ay, az, pot);
+                        if(cnt > 6) leaf_particle<POT>(tab, q6, px, py, pz, a, ax, ay, az, pot);
+                        if(cnt > 7) leaf_particle<POT>(tab, q7, px, py, pz, a, ax, ay, az, pot);
                     }
                 }
+                if(doopen)
+                    nint += cnt;
             }
             if(act)
                 mynext = C.sibling;
-            cur = C.sibling;
+            next = C.sibling;
         } else if(C.type == SHQ_PSEUDO_NODE_TYPE) {
             /* gravshort2.hpp:305-315: pseudo nodes are skipped by the local walk */
             if(act)
                 mynext = C.sibling;
-            cur = C.sibling;
+            next = C.sibling;
         } else {
             const bool anyopen = __ballot(doopen) != 0ull;
             if(act)
                 mynext = doopen ? C.child : C.sibling;
-            cur = anyopen ? C.child : C.sibling;
+            next = anyopen ? C.child : C.sibling;
         }
+        next = __builtin_amdgcn_readfirstlane(next);
+        if(next == cur + 1) {
+            A = A1;
+            B = B1;
+            C = C1;
+        } else if(next >= 0) {
+            A = a.nodeA[next];
+            B = a.nodeB[next];
+            C = a.nodeC[next];
+        }
+        cur = next;
     }
 
     if(valid) {
@@ -201,7 +253,8 @@ template <bool POT> __global__ __launch_bounds__(256) void grav_walk_exact_kerne
     }
     if(lane == 0 && a.stats) {
         atomicAdd(&a.stats->ninteractions, (unsigned long long) sm);
-        atomicAdd(&a.stats->nvisited, visited);
+        atomicAdd(&a.stats->nvisited, (unsigned long long) visited);
+        atomicAdd(&a.stats->nwave_applies, (unsigned long long) wave_applies);
         atomicMin(&a.stats->min_int, mn);
         atomicMax(&a.stats->max_int, mx);
     }
@@ -251,6 +304,7 @@ __global__ void stats_init_kernel(GravStatsDev *s)
 {
     s->ninteractions = 0;
     s->nvisited = 0;
+    s->nwave_applies = 0;
     s->min_int = 0x7fffffffffffll;
     s->max_int = 0;
 }
@@ -288,7 +342,7 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     a.ntargets = ntargets;
     a.root = ctx->root;
     a.Box = p->BoxSize;
-    a.halfBox = 0.5 * p->BoxSize;
+    a.invBox = 1.0 / p->BoxSize;
     a.rcut = p->Rcut;
     a.rcut2 = p->Rcut * p->Rcut;
     a.h = p->ForceSoftening;

@@ -26,9 +26,9 @@ namespace {
 __device__ __forceinline__ int wrapi(int i, int N) { return i >= N ? i - N : (i < 0 ? i + N : i); }
 
 /* CIC cell + residual: petapm.cpp:1147-1160 */
-__device__ __forceinline__ void cic_setup(double p, double inv_cell, int N, int &ic, double &res)
+__device__ __forceinline__ void cic_setup(double p, double cell, int N, int &ic, double &res)
 {
-    const double tmp = p * inv_cell;
+    const double tmp = p / cell; /* a true divide, as petapm.cpp:1148, so cells/weights match bit for bit */
     const double fl = floor(tmp);
     res = tmp - fl;
     int i = (int) fl;
@@ -46,36 +46,123 @@ __global__ void pm_zero_kernel(unsigned long long *mesh, size_t n)
         mesh[i] = 0ull;
 }
 
-/* put_particle_to_mesh, petapm.cpp:1304-1310, fixed-point accumulate */
+/* put_particle_to_mesh, petapm.cpp:1304-1310, fixed-point accumulate.
+ *
+ * One workgroup owns DEP_CHUNK consecutive particles.  Particles arrive in space-filling-curve
+ * order, so a chunk is spatially compact: when the bounding box of its CIC footprints fits a
+ * DEP_T^3 tile the contributions are first summed in LDS (64-bit integer ds atomics) and only
+ * the touched cells are flushed with one global atomic each.  In clustered regions (hundreds of
+ * particles per cell) this removes almost all global atomics and all same-address contention;
+ * sparse chunks whose footprint does not fit fall back to direct global atomics.  Integer adds
+ * commute, so both routes give bit-identical meshes. */
+#define DEP_T 16
+#define DEP_PPT 2
+#define DEP_CHUNK (256 * DEP_PPT)
+
 __global__ __launch_bounds__(256) void pm_deposit_kernel(const double4 *__restrict__ posm, const uint8_t *__restrict__ pflags,
-                                                         long long n, unsigned long long *mesh, int N, double inv_cell,
+                                                         long long n, unsigned long long *mesh, int N, double cell,
                                                          double scale)
 {
-    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if(i >= n)
-        return;
-    if(pflags && (pflags[i] & 2)) /* Swallowed: RegionInd = -2, gravpm.cpp:176-178 */
-        return;
-    const double4 p = posm[i];
-    int ic[3];
-    double res[3];
-    cic_setup(p.x, inv_cell, N, ic[0], res[0]);
-    cic_setup(p.y, inv_cell, N, ic[1], res[1]);
-    cic_setup(p.z, inv_cell, N, ic[2], res[2]);
-    const size_t sy = (size_t) (N + 2), sx = (size_t) N * (N + 2);
+    __shared__ unsigned long long tile[DEP_T * DEP_T * DEP_T];
+    __shared__ int s_min[3], s_max[3];
+    const int tid = threadIdx.x;
+    const long long base = (long long) blockIdx.x * DEP_CHUNK;
+    if(tid < 3) {
+        s_min[tid] = 0x7fffffff;
+        s_max[tid] = -0x7fffffff;
+    }
+    __syncthreads();
+    int ic[DEP_PPT][3];
+    double res[DEP_PPT][3];
+    double mass[DEP_PPT];
+    bool ok[DEP_PPT];
+    int lmin[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, lmax[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
 #pragma unroll
-    for(int c = 0; c < 8; c++) {
-        double w = 1.0;
-        size_t lin = 0;
+    for(int j = 0; j < DEP_PPT; j++) {
+        const long long i = base + (long long) j * 256 + tid;
+        ok[j] = (i < n) && !(pflags && (pflags[i] & 2)); /* Swallowed: RegionInd = -2, gravpm.cpp:176-178 */
+        mass[j] = 0;
+        if(ok[j]) {
+            const double4 p = posm[i];
+            cic_setup(p.x, cell, N, ic[j][0], res[j][0]);
+            cic_setup(p.y, cell, N, ic[j][1], res[j][1]);
+            cic_setup(p.z, cell, N, ic[j][2], res[j][2]);
+            mass[j] = p.w;
 #pragma unroll
-        for(int k = 0; k < 3; k++) {
-            const int off = (c >> k) & 1;
-            const int t = wrapi(ic[k] + off, N);
-            lin += (size_t) t * (k == 0 ? sx : (k == 1 ? sy : 1));
-            w *= off ? res[k] : (1 - res[k]);
+            for(int k = 0; k < 3; k++) {
+                lmin[k] = min(lmin[k], ic[j][k]);
+                lmax[k] = max(lmax[k], ic[j][k]);
+            }
         }
-        const long long q = __double2ll_rn(w * p.w * scale);
-        atomicAdd(&mesh[lin], (unsigned long long) q);
+    }
+#pragma unroll
+    for(int k = 0; k < 3; k++) {
+        int mn = lmin[k], mx = lmax[k];
+        for(int off = 32; off > 0; off >>= 1) {
+            mn = min(mn, __shfl_xor(mn, off));
+            mx = max(mx, __shfl_xor(mx, off));
+        }
+        if((tid & 63) == 0) {
+            atomicMin(&s_min[k], mn);
+            atomicMax(&s_max[k], mx);
+        }
+    }
+    __syncthreads();
+    const int m0 = s_min[0], m1 = s_min[1], m2 = s_min[2];
+    const bool fits = (s_max[0] - m0 + 2 <= DEP_T) && (s_max[1] - m1 + 2 <= DEP_T) && (s_max[2] - m2 + 2 <= DEP_T);
+    const size_t sy = (size_t) (N + 2), sx = (size_t) N * (N + 2);
+    if(fits) {
+        for(int c = tid; c < DEP_T * DEP_T * DEP_T; c += 256)
+            tile[c] = 0ull;
+        __syncthreads();
+#pragma unroll
+        for(int j = 0; j < DEP_PPT; j++) {
+            if(!ok[j])
+                continue;
+#pragma unroll
+            for(int c = 0; c < 8; c++) {
+                double w = 1.0;
+                int lin = 0;
+#pragma unroll
+                for(int k = 0; k < 3; k++) {
+                    const int off = (c >> k) & 1;
+                    const int t = ic[j][k] - (k == 0 ? m0 : (k == 1 ? m1 : m2)) + off;
+                    lin = lin * DEP_T + t;
+                    w *= off ? res[j][k] : (1 - res[j][k]);
+                }
+                const long long q = __double2ll_rn(w * mass[j] * scale);
+                atomicAdd(&tile[lin], (unsigned long long) q);
+            }
+        }
+        __syncthreads();
+        for(int c = tid; c < DEP_T * DEP_T * DEP_T; c += 256) {
+            const unsigned long long v = tile[c];
+            if(v != 0ull) {
+                const int tz = c % DEP_T, ty = (c / DEP_T) % DEP_T, tx = c / (DEP_T * DEP_T);
+                const size_t lin = (size_t) wrapi(m0 + tx, N) * sx + (size_t) wrapi(m1 + ty, N) * sy + (size_t) wrapi(m2 + tz, N);
+                atomicAdd(&mesh[lin], v);
+            }
+        }
+    } else {
+#pragma unroll
+        for(int j = 0; j < DEP_PPT; j++) {
+            if(!ok[j])
+                continue;
+#pragma unroll
+            for(int c = 0; c < 8; c++) {
+                double w = 1.0;
+                size_t lin = 0;
+#pragma unroll
+                for(int k = 0; k < 3; k++) {
+                    const int off = (c >> k) & 1;
+                    const int t = wrapi(ic[j][k] + off, N);
+                    lin += (size_t) t * (k == 0 ? sx : (k == 1 ? sy : 1));
+                    w *= off ? res[j][k] : (1 - res[j][k]);
+                }
+                const long long q = __double2ll_rn(w * mass[j] * scale);
+                atomicAdd(&mesh[lin], (unsigned long long) q);
+            }
+        }
     }
 }
 
@@ -125,7 +212,7 @@ __global__ __launch_bounds__(256) void pm_green_kernel(double2 *cmesh, int N, in
  * 4-point differencing of the potential mesh (see file header). */
 __global__ __launch_bounds__(256) void pm_readout_kernel(const double4 *__restrict__ posm, const uint8_t *__restrict__ pflags,
                                                          long long n, const double *__restrict__ mesh, int N,
-                                                         double inv_cell, double ffac, double *gravpm, double *pmpot)
+                                                         double cell, double ffac, double *gravpm, double *pmpot)
 {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= n)
@@ -135,9 +222,9 @@ __global__ __launch_bounds__(256) void pm_readout_kernel(const double4 *__restri
         const double4 p = posm[i];
         int ic[3];
         double res[3];
-        cic_setup(p.x, inv_cell, N, ic[0], res[0]);
-        cic_setup(p.y, inv_cell, N, ic[1], res[1]);
-        cic_setup(p.z, inv_cell, N, ic[2], res[2]);
+        cic_setup(p.x, cell, N, ic[0], res[0]);
+        cic_setup(p.y, cell, N, ic[1], res[1]);
+        cic_setup(p.z, cell, N, ic[2], res[2]);
         const size_t sy = (size_t) (N + 2), sx = (size_t) N * (N + 2);
         /* wrapped indices for offsets -2..3 along every axis */
         size_t ox[6], oy[6], oz[6];
@@ -247,17 +334,18 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
     SHQ_TRY(pm_prepare(ctx, N));
     const size_t padded = (size_t) N * N * (N + 2);
     const int Nc = N / 2 + 1;
-    const double inv_cell = N / pm->BoxSize; /* 1/CellSize */
+    const double cell = pm->BoxSize / N; /* CellSize */
     const long long n = ctx->numpart;
     /* fixed-point scale: 2^e with e chosen so that the whole mass in one cell cannot overflow */
     int e = ctx->pm_log2scale;
     const double scale = ldexp(1.0, e);
     const int threads = 256;
 
+    SHQ_HIP(hipEventRecord(ctx->ev_begin[8], ctx->stream));
     pm_zero_kernel<<<dim3(2048), dim3(threads), 0, ctx->stream>>>((unsigned long long *) ctx->mesh.ptr, padded);
     if(n > 0)
-        pm_deposit_kernel<<<dim3((unsigned) ((n + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-            ctx->posm.ptr, ctx->pflags.ptr, n, (unsigned long long *) ctx->mesh.ptr, N, inv_cell, scale);
+        pm_deposit_kernel<<<dim3((unsigned) ((n + DEP_CHUNK - 1) / DEP_CHUNK)), dim3(256), 0, ctx->stream>>>(
+            ctx->posm.ptr, ctx->pflags.ptr, n, (unsigned long long *) ctx->mesh.ptr, N, cell, scale);
     pm_convert_kernel<<<dim3(2048), dim3(threads), 0, ctx->stream>>>(ctx->mesh.ptr, padded, 1.0 / scale);
     SHQ_HIP(hipGetLastError());
     if(ctx->pm_keep) {
@@ -265,8 +353,10 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
         const size_t tot = (size_t) N * N * N;
         pm_unpad_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(ctx->mesh.ptr, ctx->dbg_rho.ptr, N);
     }
+    SHQ_HIP(hipEventRecord(ctx->ev_begin[9], ctx->stream));
     hipfftResult r = hipfftExecD2Z(ctx->plan_r2c, (hipfftDoubleReal *) ctx->mesh.ptr, (hipfftDoubleComplex *) ctx->mesh.ptr);
     SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecD2Z failed: %d", (int) r);
+    SHQ_HIP(hipEventRecord(ctx->ev_begin[10], ctx->stream));
     {
         const size_t tot = (size_t) N * N * Nc;
         const double asmth2 = pow((2 * M_PI) * pm->Asmth / N, 2);
@@ -274,8 +364,10 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
         pm_green_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
             (double2 *) ctx->mesh.ptr, N, Nc, ctx->sinctab.ptr, asmth2, pot_factor);
     }
+    SHQ_HIP(hipEventRecord(ctx->ev_begin[11], ctx->stream));
     r = hipfftExecZ2D(ctx->plan_c2r, (hipfftDoubleComplex *) ctx->mesh.ptr, (hipfftDoubleReal *) ctx->mesh.ptr);
     SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecZ2D failed: %d", (int) r);
+    SHQ_HIP(hipEventRecord(ctx->ev_begin[12], ctx->stream));
     if(ctx->pm_keep) {
         SHQ_TRY(ctx->dbg_pot.reserve((size_t) N * N * N));
         const size_t tot = (size_t) N * N * N;
@@ -284,9 +376,10 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
     if(n > 0) {
         const double ffac = -(N / pm->BoxSize);
         pm_readout_kernel<<<dim3((unsigned) ((n + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-            ctx->posm.ptr, ctx->pflags.ptr, n, ctx->mesh.ptr, N, inv_cell, ffac, ctx->gravpm.ptr, ctx->pmpot.ptr);
+            ctx->posm.ptr, ctx->pflags.ptr, n, ctx->mesh.ptr, N, cell, ffac, ctx->gravpm.ptr, ctx->pmpot.ptr);
     }
     SHQ_HIP(hipGetLastError());
+    SHQ_HIP(hipEventRecord(ctx->ev_begin[13], ctx->stream));
     ctx->have_pm_result = true;
     return SHQ_OK;
 }

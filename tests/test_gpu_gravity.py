@@ -174,7 +174,9 @@ def test_pm_parity_16(ctx, kind):
     mass = pman.Base["Mass"]
     e = 61 - int(np.frexp(float(n))[1])       # the library's scale rule: 2^(61 - ex), msum < 2^ex
     og, opot, orho, ophi = orc.pm_force(pos, mass, 48, cm.BOX, 1.5, cm.G, fixed_point_log2scale=e, use_stencil=0, want_mesh=True)
-    assert np.array_equal(rho, orho)                                  # integer deposit: bit-exact
+    nbad = int((rho != orho).sum())
+    assert nbad == 0, (nbad, float(np.abs(rho - orho).max()), float(rho.sum()), float(orho.sum()),
+                       np.argwhere(rho != orho)[:4].tolist())    # integer deposit: bit-exact
     assert abs(rho.sum() - n) < 1e-6
     assert np.abs(phi - ophi).max() < 1e-11 * np.abs(ophi).max()
     assert np.abs(g - og).max() < 1e-10 * np.abs(og).max()
