@@ -196,6 +196,9 @@ def main():
             "tree_fp64_frac_of_vector_peak": 45.0 * st.ninteractions / max(walk_s, 1e-12) / 1e12 / FP64_VECTOR_PEAK_TF,
             "tree_nodes_visited_per_wave": st.nnodes_visited / max(1.0, st.ntargets / 64.0),
             "tree_lane_efficiency": st.ninteractions / max(1.0, 64.0 * st.nwave_interactions),
+            "tree_node_rounds_per_wave": st.nwave_node_interactions / max(1.0, st.ntargets / 64.0),
+            "tree_particle_rounds_per_wave": (st.nwave_interactions - st.nwave_node_interactions) / max(1.0, st.ntargets / 64.0),
+            "tree_node_interactions_per_target": st.nnode_interactions / max(1, st.ntargets),
             "tree_algorithmic_GBs": tree_bytes / max(walk_s, 1e-12) / 1e9,
             "pm_ms": {"deposit": ph[0], "r2c": ph[1], "transfer": ph[2], "c2r": ph[3], "readout": ph[4], "total": ph[5]},
             "pm_algorithmic_GBs": pm_bytes / max(pm_s, 1e-12) / 1e9,

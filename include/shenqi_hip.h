@@ -162,6 +162,8 @@ typedef struct shq_walk_stats {
     int64_t max_interactions;
     int64_t nnodes_visited;     /* node tests executed by wavefronts (union walk) */
     int64_t nwave_interactions; /* interaction evaluations issued by wavefronts (x64 lanes each) */
+    int64_t nwave_node_interactions; /* ... of which monopole (node) evaluations */
+    int64_t nnode_interactions; /* per-target interactions that were node monopoles */
     double kernel_ms;           /* HIP-event time of the walk kernel(s) */
 } shq_walk_stats;
 

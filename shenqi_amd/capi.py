@@ -116,6 +116,7 @@ class WalkStats(C.Structure):
     _fields_ = [
         ("ntargets", C.c_int64), ("ninteractions", C.c_int64), ("min_interactions", C.c_int64),
         ("max_interactions", C.c_int64), ("nnodes_visited", C.c_int64), ("nwave_interactions", C.c_int64),
+        ("nwave_node_interactions", C.c_int64), ("nnode_interactions", C.c_int64),
         ("kernel_ms", C.c_double),
     ]
 

@@ -2,6 +2,7 @@
 #include "common.hpp"
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 #include <math.h>
 #include <thread>
 #include <atomic>
@@ -105,6 +106,10 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
         (void) hipEventCreate(&ctx->ev_begin[i]);
         (void) hipEventCreate(&ctx->ev_end[i]);
     }
+    if(const char *v = getenv("SHQ_WALK_VARIANT"))
+        ctx->walk_variant = atoi(v);
+    if(const char *v = getenv("SHQ_WALK_STATS"))
+        ctx->walk_stats = atoi(v);
     *out = ctx;
     return SHQ_OK;
 }
@@ -406,6 +411,8 @@ extern "C" int shq_grav_short_download(shq_context *ctx, double (*accel)[3], dou
         stats->ninteractions = (int64_t) gs.ninteractions;
         stats->nnodes_visited = (int64_t) gs.nvisited;
         stats->nwave_interactions = (int64_t) gs.nwave_applies;
+        stats->nwave_node_interactions = (int64_t) gs.nwave_node_applies;
+        stats->nnode_interactions = (int64_t) gs.nnode_interactions;
         stats->min_interactions = stats->ntargets > 0 ? gs.min_int : 0;
         stats->max_interactions = gs.max_int;
         float ms = 0;

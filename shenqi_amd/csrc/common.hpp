@@ -107,6 +107,8 @@ struct GravStatsDev {
     unsigned long long ninteractions;
     unsigned long long nvisited;
     unsigned long long nwave_applies;
+    unsigned long long nwave_node_applies;
+    unsigned long long nnode_interactions;
     long long min_int;
     long long max_int;
 };
@@ -163,6 +165,8 @@ struct shq_context {
     bool have_pm_result = false;
 
     shq_walk_stats last_stats = {};
+    int walk_variant = 3;      /* SHQ_WALK_VARIANT: 0 prefetch+leaf4, 1 prefetch+leaf2, 2 leaf4, 3 leaf2 (fastest: no SGPR spills) */
+    int walk_stats = 1;        /* SHQ_WALK_STATS: wave-level counters on/off */
     float last_walk_ms = 0;
 
     /* host staging */

@@ -12,13 +12,20 @@
  *     and sleeps until the union walk reaches that sibling; the union opens a node when any
  *     awake lane opens it.  Per target this yields exactly the reference's opening decisions,
  *     interaction set and summation order (depth-first), i.e. the EXACT flavour;
- *   - leaf particles come from a leaf-ordered (x,y,z,m) copy: one 32-byte uniform load each;
- *   - the 2x512-float TreePM window table (gravity.h:32-61) is staged in LDS as
- *     {f[i], f[i+1], p[i], p[i+1]} so an interaction needs one ds_read_b128.
+ *   - the node pool is in depth-first pre-order (packed at upload): the first child of node i is
+ *     i+1 and the `sibling` of a leaf is i+1 too, so the record after the current one is the
+ *     next to be visited unless a whole subtree is skipped; it is fetched speculatively;
+ *   - leaf particles come from a leaf-ordered (x,y,z,m) copy, fetched LEAFB at a time with
+ *     wave-uniform (scalar) loads;
+ *   - the 2x512-float TreePM window table (gravity.h:32-61) is staged in LDS as f64
+ *     {f[i], f[i+1]-f[i], p[i], p[i+1]-p[i]}: an interaction needs two ds_read_b128 and two fma.
  *
- * All arithmetic is f64 as in the reference (LOW_PRECISION=double).
+ * All arithmetic is f64 as in the reference (LOW_PRECISION=double).  The kernel is VALU-issue
+ * bound (f64 ops issue at 4 cycles per wave instruction), so the code below is written to keep
+ * the per-visit instruction count down.
  */
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -54,18 +61,30 @@ __device__ __forceinline__ double wrapd(double d, double L, double invL)
     return fma(-L, rint(d * invL), d);
 }
 
+/* 1/sqrt(x) to f64 accuracy: hardware estimate + one third-order Newton step (the form OCML
+ * uses), without the inf/zero special casing: callers clamp x away from zero. */
+__device__ __forceinline__ double rsqrt_fast(double x)
+{
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y0, y0, 1.0);
+    return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
+
 /* apply_accn (gravshort2.hpp:326-358) + apply_short_range_window (gravity.h:48-60).
- * 1/r comes from rsqrt (v_rsq_f64 + refinement) instead of sqrt and two divides: mass/r^3 =
- * mass*rinv^3 agrees with mass/(r2*r) to a few ulp. */
+ * mass/(r2*r) is formed as mass*rinv^3 (a few ulp from the reference's sqrt + divide); a
+ * coincident source (r2 == 0, the target itself) is clamped to a tiny r2 so that it falls in
+ * the softened branch and contributes dx*fac = 0 exactly as in the reference. */
 template <bool POT>
-__device__ __forceinline__ void apply_accn(const float4 *__restrict__ tab, double dx, double dy, double dz, double r2,
+__device__ __forceinline__ void apply_accn(const double4 *__restrict__ tab, double dx, double dy, double dz, double r2,
                                            double mass, const WalkArgs &a, double &ax, double &ay, double &az,
                                            double &pot)
 {
-    const double rinv = rsqrt(r2);
-    const double r = (r2 > 0) ? r2 * rinv : 0.0;
-    double fac = mass * rinv * rinv * rinv;
-    double facpot = -mass * rinv;
+    const double r2c = fmax(r2, 1e-280);
+    const double rinv = rsqrt_fast(r2c);
+    const double r = r2c * rinv;
+    const double mr = mass * rinv;
+    double fac = mr * rinv * rinv;
+    double facpot = -mr;
     if(r2 < a.h2) {
         const double u = r * a.h_inv;
         double wp;
@@ -81,24 +100,26 @@ __device__ __forceinline__ void apply_accn(const float4 *__restrict__ tab, doubl
         facpot = mass * a.h_inv * wp;
     }
     const double fi = r * a.inv_celldx;
-    const double fl = floor(fi);
-    if(fl < (double) (SHQ_NGRAVTAB - 1)) {
-        const int ti = (int) fl;
-        const float4 t = tab[ti];
-        const double w1 = fi - fl, w0 = 1.0 - w1;
-        fac *= w0 * (double) t.x + w1 * (double) t.y;
-        ax += dx * fac;
-        ay += dy * fac;
-        az += dz * fac;
+    if(fi < (double) (SHQ_NGRAVTAB - 1)) {
+        const int ti = (int) fi;                     /* fi >= 0: truncation == floor */
+        const double w1 = __builtin_amdgcn_fract(fi); /* fi - floor(fi) */
         if(POT) {
-            facpot *= w0 * (double) t.z + w1 * (double) t.w;
+            const double4 t = tab[ti];
+            fac *= fma(w1, t.y, t.x);
+            facpot *= fma(w1, t.w, t.z);
             pot += facpot;
+        } else {
+            const double2 t = *reinterpret_cast<const double2 *>(&tab[ti]);
+            fac *= fma(w1, t.y, t.x);
         }
+        ax = fma(dx, fac, ax);
+        ay = fma(dy, fac, ay);
+        az = fma(dz, fac, az);
     }
 }
 
 template <bool POT>
-__device__ __forceinline__ void leaf_particle(const float4 *__restrict__ tab, const double4 q, double px, double py,
+__device__ __forceinline__ void leaf_particle(const double4 *__restrict__ tab, const double4 q, double px, double py,
                                               double pz, const WalkArgs &a, double &ax, double &ay, double &az,
                                               double &pot)
 {
@@ -109,16 +130,16 @@ __device__ __forceinline__ void leaf_particle(const float4 *__restrict__ tab, co
     apply_accn<POT>(tab, ex, ey, ez, rr2, q.w, a, ax, ay, az, pot);
 }
 
-/* The node pool is in depth-first pre-order (packed at upload): the first child of node i is
- * i+1, and the `sibling` of a leaf is i+1 as well, so the record after the current one is the
- * next to be visited unless a whole subtree is skipped.  It is fetched speculatively at the top
- * of each visit so its latency hides behind the arithmetic of the current node. */
-template <bool POT> __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
+/* POT: accumulate the potential.  PREFETCH: speculative fetch of pool[cur+1].  LEAFB: leaf
+ * particles fetched per batch (2 or 4).  STATS: wave-level counters for the bench. */
+template <bool POT, bool PREFETCH, int LEAFB, bool STATS>
+__global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
 {
-    __shared__ float4 tab[SHQ_NGRAVTAB];
+    __shared__ double4 tab[SHQ_NGRAVTAB];
     for(int i = threadIdx.x; i < SHQ_NGRAVTAB; i += blockDim.x) {
         const int j = (i + 1 < SHQ_NGRAVTAB) ? i + 1 : i;
-        tab[i] = make_float4(a.tab_f[i], a.tab_f[j], a.tab_p[i], a.tab_p[j]);
+        const double f0 = a.tab_f[i], f1 = a.tab_f[j], p0 = a.tab_p[i], p1 = a.tab_p[j];
+        tab[i] = make_double4(f0, f1 - f0, p0, p1 - p0);
     }
     __syncthreads();
 
@@ -137,21 +158,26 @@ template <bool POT> __global__ __launch_bounds__(256) void grav_walk_exact_kerne
         aold = a.errtol * a.oldacc[pi];
     }
     double ax = 0, ay = 0, az = 0, pot = 0;
-    int nint = 0;
+    int nint = 0, nint_node = 0;
     int mynext = valid ? a.root : -2;
     int cur = a.root;
-    unsigned int visited = 0, wave_applies = 0;
+    unsigned int visited = 0, wave_applies = 0, wave_node_applies = 0;
 
     NodeA A = a.nodeA[cur];
     NodeB B = a.nodeB[cur];
     NodeC C = a.nodeC[cur];
 
     while(cur >= 0) {
-        /* speculative fetch of the next pre-order record (pool is padded by one record) */
-        const NodeA A1 = a.nodeA[cur + 1];
-        const NodeB B1 = a.nodeB[cur + 1];
-        const NodeC C1 = a.nodeC[cur + 1];
-        visited++;
+        NodeA A1;
+        NodeB B1;
+        NodeC C1;
+        if(PREFETCH) { /* pool is padded by one record */
+            A1 = a.nodeA[cur + 1];
+            B1 = a.nodeB[cur + 1];
+            C1 = a.nodeC[cur + 1];
+        }
+        if(STATS)
+            visited++;
         const bool act = (mynext == cur);
 
         /* gravshort2.hpp:262-265 */
@@ -165,20 +191,25 @@ template <bool POT> __global__ __launch_bounds__(256) void grav_walk_exact_kerne
         const double len = B.len;
         /* shall_we_discard_node, gravshort2.hpp:152-167 */
         const double eff = a.rcut + 0.5 * len;
-        const bool discard = (r2 > a.rcut2) && (cx > eff || cy > eff || cz > eff);
+        const bool discard = (r2 > a.rcut2) && (fmax(fmax(cx, cy), cz) > eff);
         /* shall_we_open_node, gravshort2.hpp:172-193 (len*len/r2 > theta2 written without the divide) */
         const double len2 = len * len;
         const double inside = 0.6 * len;
         const bool open = ((a.useBH == 0) && (A.mass * len2 > r2 * r2 * aold)) || (len2 > r2 * a.bh2) ||
-                          (cx < inside && cy < inside && cz < inside);
+                          (fmax(fmax(cx, cy), cz) < inside);
         const bool accept = act && !discard && !open;
         const bool doopen = act && !discard && open;
 
         if(__ballot(accept) != 0ull) {
-            wave_applies++;
+            if(STATS) {
+                wave_applies++;
+                wave_node_applies++;
+            }
             if(accept) {
                 apply_accn<POT>(tab, dx, dy, dz, r2, A.mass, a, ax, ay, az, pot);
                 nint++;
+                if(STATS)
+                    nint_node++;
             }
         }
         int next;
@@ -187,22 +218,22 @@ template <bool POT> __global__ __launch_bounds__(256) void grav_walk_exact_kerne
             if(__ballot(doopen) != 0ull) {
                 const double4 *__restrict__ lp = a.posm_leaf + C.child;
                 const int cnt = C.count;
-                wave_applies += cnt;
-                /* leaf slots are contiguous and the array is padded: fetch four at a time */
-                const double4 q0 = lp[0], q1 = lp[1], q2 = lp[2], q3 = lp[3];
-                if(doopen) {
-                    if(cnt > 0) leaf_particle<POT>(tab, q0, px, py, pz, a, ax, ay, az, pot);
-                    if(cnt > 1) leaf_particle<POT>(tab, q1, px, py, pz, a, ax, ay, az, pot);
-                    if(cnt > 2) leaf_particle<POT>(tab, q2, px, py, pz, a, ax, ay, az, pot);
-                    if(cnt > 3) leaf_particle<POT>(tab, q3, px, py, pz, a, ax, ay, az, pot);
-                }
-                if(cnt > 4) {
-                    const double4 q4 = lp[4], q5 = lp[5], q6 = lp[6], q7 = lp[7];
-                    if(doopen) {
-                        leaf_particle<POT>(tab, q4, px, py, pz, a, ax, ay, az, pot);
-                        if(cnt > 5) leaf_particle<POT>(tab, q5, px, py, pz, a, ax, ay, az, pot);
-                        if(cnt > 6) leaf_particle<POT>(tab, q6, px, py, pz, a, ax, ay, az, pot);
-                        if(cnt > 7) leaf_particle<POT>(tab, q7, px, py, pz, a, ax, ay, az, pot);
+                if(STATS)
+                    wave_applies += cnt;
+                /* leaf slots are contiguous and the array is padded by NMAXCHILD entries */
+#pragma unroll
+                for(int b = 0; b < SHQ_NMAXCHILD; b += LEAFB) {
+                    if(b < cnt) {
+                        double4 q[LEAFB];
+#pragma unroll
+                        for(int k = 0; k < LEAFB; k++)
+                            q[k] = lp[b + k];
+                        if(doopen) {
+#pragma unroll
+                            for(int k = 0; k < LEAFB; k++)
+                                if(b + k < cnt)
+                                    leaf_particle<POT>(tab, q[k], px, py, pz, a, ax, ay, az, pot);
+                        }
                     }
                 }
                 if(doopen)
@@ -223,7 +254,7 @@ template <bool POT> __global__ __launch_bounds__(256) void grav_walk_exact_kerne
             next = anyopen ? C.child : C.sibling;
         }
         next = __builtin_amdgcn_readfirstlane(next);
-        if(next == cur + 1) {
+        if(PREFETCH && next == cur + 1) {
             A = A1;
             B = B1;
             C = C1;
@@ -245,18 +276,25 @@ template <bool POT> __global__ __launch_bounds__(256) void grav_walk_exact_kerne
     }
     /* statistics (treewalk2.h:446-448 interaction min/max) */
     long long mn = valid ? nint : 0x7fffffffffffll, mx = valid ? nint : 0, sm = valid ? nint : 0;
+    int smn = valid ? nint_node : 0;
     for(int off = 32; off > 0; off >>= 1) {
         long long o1 = __shfl_xor(mn, off), o2 = __shfl_xor(mx, off), o3 = __shfl_xor(sm, off);
         mn = o1 < mn ? o1 : mn;
         mx = o2 > mx ? o2 : mx;
         sm += o3;
+        if(STATS)
+            smn += __shfl_xor(smn, off);
     }
     if(lane == 0 && a.stats) {
         atomicAdd(&a.stats->ninteractions, (unsigned long long) sm);
-        atomicAdd(&a.stats->nvisited, (unsigned long long) visited);
-        atomicAdd(&a.stats->nwave_applies, (unsigned long long) wave_applies);
         atomicMin(&a.stats->min_int, mn);
         atomicMax(&a.stats->max_int, mx);
+        if(STATS) {
+            atomicAdd(&a.stats->nvisited, (unsigned long long) visited);
+            atomicAdd(&a.stats->nwave_applies, (unsigned long long) wave_applies);
+            atomicAdd(&a.stats->nwave_node_applies, (unsigned long long) wave_node_applies);
+            atomicAdd(&a.stats->nnode_interactions, (unsigned long long) smn);
+        }
     }
 }
 
@@ -305,8 +343,19 @@ __global__ void stats_init_kernel(GravStatsDev *s)
     s->ninteractions = 0;
     s->nvisited = 0;
     s->nwave_applies = 0;
+    s->nwave_node_applies = 0;
+    s->nnode_interactions = 0;
     s->min_int = 0x7fffffffffffll;
     s->max_int = 0;
+}
+
+template <bool POT, bool PREFETCH, int LEAFB>
+void launch_variant(bool stats, dim3 grid, dim3 block, hipStream_t stream, const WalkArgs &a)
+{
+    if(stats)
+        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, true><<<grid, block, 0, stream>>>(a);
+    else
+        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, false><<<grid, block, 0, stream>>>(a);
 }
 
 } // namespace
@@ -360,11 +409,27 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     const long long nwaves = (ntargets + 63) / 64;
     const long long blocks = (nwaves + (threads / 64) - 1) / (threads / 64);
     SHQ_CHECK(blocks < (1ll << 31), SHQ_ERR_INVALID, "grav walk: too many targets for one launch");
+    const dim3 grid((unsigned) blocks), block(threads);
+    /* tuning knobs (diagnostic): SHQ_WALK_VARIANT = 0..3 selects prefetch/leaf-batch; the
+     * default is the measured-fastest one. */
+    const int variant = ctx->walk_variant;
+    const bool stats = ctx->walk_stats != 0;
     SHQ_HIP(hipEventRecord(ctx->ev_begin[SHQ_NTIMERS - 1], ctx->stream));
-    if(update_potential)
-        grav_walk_exact_kernel<true><<<dim3((unsigned) blocks), dim3(threads), 0, ctx->stream>>>(a);
-    else
-        grav_walk_exact_kernel<false><<<dim3((unsigned) blocks), dim3(threads), 0, ctx->stream>>>(a);
+    if(update_potential) {
+        switch(variant) {
+        case 0: launch_variant<true, true, 4>(stats, grid, block, ctx->stream, a); break;
+        case 1: launch_variant<true, true, 2>(stats, grid, block, ctx->stream, a); break;
+        case 2: launch_variant<true, false, 4>(stats, grid, block, ctx->stream, a); break;
+        default: launch_variant<true, false, 2>(stats, grid, block, ctx->stream, a); break;
+        }
+    } else {
+        switch(variant) {
+        case 0: launch_variant<false, true, 4>(stats, grid, block, ctx->stream, a); break;
+        case 1: launch_variant<false, true, 2>(stats, grid, block, ctx->stream, a); break;
+        case 2: launch_variant<false, false, 4>(stats, grid, block, ctx->stream, a); break;
+        default: launch_variant<false, false, 2>(stats, grid, block, ctx->stream, a); break;
+        }
+    }
     SHQ_HIP(hipGetLastError());
     SHQ_HIP(hipEventRecord(ctx->ev_end[SHQ_NTIMERS - 1], ctx->stream));
     return SHQ_OK;
