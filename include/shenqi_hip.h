@@ -133,6 +133,7 @@ typedef struct shq_tree_view {
     int32_t rootnode;            /* node the primary walk starts from (== firstnode) */
     int32_t full_particle_tree_flag;
     double BoxSize;
+    const int32_t *father;       /* ForceTree.Father (parent node of every particle) or NULL */
 } shq_tree_view;
 
 /* ---- short-range gravity -------------------------------------------------------------- */
@@ -196,6 +197,94 @@ int shq_grav_short_download(shq_context *ctx, double (*accel)[3], double *potent
  * FullTreeGravAccel + GravPM of the last shq_grav_short_run / shq_pm_run
  * (grav_get_abs_accel, gravshort2.hpp:111-121). */
 int shq_grav_refresh_oldacc(shq_context *ctx, double G);
+
+/* ---- SPH density and hydro force ------------------------------------------------------- */
+
+#define SHQ_DENSITY_KERNEL_CUBIC_SPLINE 1   /* enum DensityKernelType, libgadget/density2.h */
+#define SHQ_DENSITY_KERNEL_QUINTIC_SPLINE 2
+#define SHQ_DENSITY_KERNEL_QUARTIC_SPLINE 4
+
+/* POD mirror of KickFactorData (libgadget/density2.h:52-129): the host (timebinmgr) fills it. */
+typedef struct shq_kick_factors {
+    double FgravkickB;
+    double gravkicks[SHQ_TIMEBINS + 1];
+    double hydrokicks[SHQ_TIMEBINS + 1];
+    double dloga_kick[SHQ_TIMEBINS + 1];
+    double dloga_for_bin[SHQ_TIMEBINS + 1];
+} shq_kick_factors;
+
+/* POD mirror of DensityPriv + the density_params it reads (libgadget/densitytree2.hpp:10-52,
+ * density2.h:16-33). */
+typedef struct shq_density_params {
+    double BoxSize;
+    double DesNumNgb;           /* GetNumNgb(kernel) */
+    double DesNumNgbBH;         /* DesNumNgb * BlackHoleNgbFactor */
+    double MinGasHsml;
+    double MaxNumNgbDeviation;
+    int32_t update_hsml;
+    int32_t BlackHoleOn;
+    int32_t DoEgyDensity;
+    int32_t WindsDecouple;      /* winds_ever_decouple() */
+    int32_t DensityKernelType;
+    int32_t pad_;
+    shq_kick_factors kf;
+} shq_density_params;
+
+/* POD mirror of HydroPriv (libgadget/hydratree2.hpp:60-125). */
+typedef struct shq_hydro_params {
+    double BoxSize;
+    double atime;
+    double fac_mu;              /* pow(atime, 3(GAMMA-1)/2) / atime */
+    double fac_vsic_fix;        /* hubble * pow(atime, 3 GAMMA_MINUS1) */
+    double hubble_a2;           /* hubble * atime^2 */
+    double drifts[SHQ_TIMEBINS + 1];
+    double ArtBulkViscConst;
+    double DensityContrastLimit;
+    double WindSpeed;
+    double WindFreeTravelDensThresh;
+    int32_t DensityIndependentSphOn;
+    int32_t DensityKernelType;
+    shq_kick_factors kf;
+} shq_hydro_params;
+
+/* View of the BH slots density() writes for Type-5 targets (bh_particle_data.Density/.DivVel). */
+typedef struct shq_bh_view {
+    void *base;
+    size_t elsize;
+    int64_t numslots;
+    size_t off_density, off_divvel;
+} shq_bh_view;
+
+typedef struct shq_sph_stats {
+    int64_t ntargets;
+    int64_t ninteractions;   /* ngbiter calls summed over targets and iterations */
+    int32_t niterations;     /* Hsml iterations (do_hsml_loop, treewalk2.h:480-557) */
+    int32_t pad_;
+    double kernel_ms;        /* HIP-event time of the walk kernels */
+} shq_sph_stats;
+
+/* One-shot replacement of density_cuda() *including* the host Hsml loop the reference keeps on
+ * the CPU (do_hsml_loop + DensityOutput::postprocess + density_check_neighbours,
+ * treewalk2.h:480-557, densitytree2.hpp:117-257).  Targets: active particles of Type 0 / 5 that
+ * are neither garbage nor swallowed (DensityQuery::haswork).  Writes Part[].Hsml / DtHsml,
+ * SphP[].Density / EgyWtDensity / DhsmlEgyDensityFactor / DivVel / CurlVel, BhP[].Density /
+ * DivVel, and - as update_tree_hmax_father does (forcetree.cpp:1285-1313) - raises mom.hmax of
+ * the leaf holding each finished target in the caller's NODE array.  EntVarPred[numslots]
+ * (out, may be NULL) receives the predicted entropy variable handed to hydro
+ * (density2.cpp:147); GradRho_mag[numslots] (out, may be NULL) |grad rho| (density2.cpp:135-143).
+ * Returns SHQ_ERR_NOCONV if MAXITER (400) is exceeded. */
+int shq_density(shq_context *ctx, const shq_tree_view *tree, shq_node *nodes_rw,
+                const shq_part_view *parts, const shq_sph_view *sph, const shq_bh_view *bh,
+                const int32_t *active, int64_t nactive, const shq_density_params *params,
+                double *EntVarPred, double *GradRho_mag, shq_sph_stats *stats);
+
+/* One-shot replacement of hydro_force_cuda(): symmetric neighbour walk (cull radius
+ * max(hmax_node, Hsml_i)), HydroResult::reduce and HydroOutput::postprocess
+ * (hydratree2.hpp:127-149,201-379).  Writes SphP[].HydroAccel / DtEntropy / MaxSignalVel for
+ * the active Type-0 targets.  EntVarPred may be NULL (then computed per particle). */
+int shq_hydro_force(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts,
+                    const shq_sph_view *sph, const int32_t *active, int64_t nactive,
+                    const shq_hydro_params *params, const double *EntVarPred, shq_sph_stats *stats);
 
 /* ---- long-range PM --------------------------------------------------------------------- */
 

@@ -67,6 +67,44 @@ void orc_pm_force(const double *pos, const float *mass, const uint8_t *skip, int
 void orc_fft_r2c(int N, const double *real, double *complx);
 void orc_fft_c2r(int N, const double *complx, double *real);
 
+/* ---- SPH (libgadget/densitytree2.hpp, hydratree2.hpp, density2.h, densitykernel.hpp) ---- */
+/* Plain SoA inputs/outputs; slot arrays are indexed by pi[i] (the reference's PI). */
+typedef struct orc_sph_arrays {
+    int64_t n;     /* particles */
+    int64_t nsph;  /* gas slots */
+    const double *pos;      /* [n][3] */
+    const float *mass;      /* [n] */
+    const uint8_t *type;    /* [n] */
+    const uint8_t *flags;   /* [n] bit0 garbage, bit1 swallowed; may be NULL */
+    const int32_t *pi;      /* [n] */
+    double *hsml;           /* [n] in/out */
+    double *dthsml;         /* [n] out */
+    const double *vel;      /* [n][3] */
+    const double *treeacc;  /* [n][3] FullTreeGravAccel */
+    const double *gravpm;   /* [n][3] */
+    const uint8_t *bin_grav;  /* [n] */
+    const uint8_t *bin_hydro; /* [n] */
+    double *density, *egywtdensity;   /* [nsph] */
+    const double *entropy;            /* [nsph] */
+    double *dtentropy, *maxsignalvel; /* [nsph] */
+    double *hydroaccel;               /* [nsph][3] */
+    double *dhsmlegydensityfactor, *divvel, *curlvel; /* [nsph] */
+    const double *delaytime;          /* [nsph], may be NULL */
+    double *bh_density, *bh_divvel;   /* BH slots, may be NULL when there are no BHs */
+} orc_sph_arrays;
+
+int orc_density_kernel(int type, double H, double u, double eta, double out[5]);
+void orc_set_init_hsml(const shq_node *nodes, int64_t firstnode, const int32_t *father, orc_sph_arrays *a,
+                       double MeanGasSeparation, double DesNumNgb);
+/* Returns 0, or 1 if MAXITER was exceeded. EntVarPred: [nsph] out (NULL => no cache, values
+ * computed per neighbour as the reference does for few active particles). */
+int orc_density(shq_node *nodes, int64_t firstnode, const int32_t *father, orc_sph_arrays *a,
+                const int32_t *active, int64_t nactive, const shq_density_params *p, double *EntVarPred,
+                double *GradRho, int *niter_out, int64_t *nint_out);
+void orc_update_hmax(shq_node *nodes, int64_t firstnode, int64_t numnodes, const orc_sph_arrays *a);
+void orc_hydro(const shq_node *nodes, int64_t firstnode, orc_sph_arrays *a, const int32_t *active,
+               int64_t nactive, const shq_hydro_params *p, const double *EntVarPred, int64_t *nint_out);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

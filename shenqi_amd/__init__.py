@@ -169,3 +169,58 @@ def morton_order(pos, L):
     order = np.empty(len(pos), dtype=np.int32)
     capi.host.shqh_morton_order(capi.ptr(pos), len(pos), L, capi.ptr(order))
     return order
+
+
+# ---- SPH operators (libgadget/density2.h, hydra2.h) ---------------------------------------------
+from .capi import KickFactors, DensityParams, HydroParams, SphStats  # noqa: E402
+
+DENSITY_KERNEL_CUBIC_SPLINE, DENSITY_KERNEL_QUINTIC_SPLINE, DENSITY_KERNEL_QUARTIC_SPLINE = 1, 2, 4
+BH_SLOT_DTYPE = np.dtype([("Density", "<f8"), ("DivVel", "<f8")])
+
+
+def set_densitypar(DensityResolutionEta=1.0, MaxNumNgbDeviation=0.5, DensityKernelType=DENSITY_KERNEL_CUBIC_SPLINE,
+                   BlackHoleNgbFactor=2.0, MinGasHsml=0.006):
+    capi.host.shqh_set_densitypar(DensityResolutionEta, MaxNumNgbDeviation, DensityKernelType, BlackHoleNgbFactor, MinGasHsml)
+
+
+def GetNumNgb():
+    return capi.host.shqh_GetNumNgb()
+
+
+def set_hydropar(DensityIndependentSphOn=1, DensityContrastLimit=100.0, ArtBulkViscConst=0.75):
+    capi.host.shqh_set_hydropar(DensityIndependentSphOn, DensityContrastLimit, ArtBulkViscConst)
+
+
+def set_init_hsml(tree, MeanGasSeparation, pman):
+    capi.check_host(capi.host.shqh_set_init_hsml(tree._h, MeanGasSeparation, pman._h), "set_init_hsml")
+
+
+def force_tree_update_hmax(tree, pman):
+    capi.host.shqh_force_tree_update_hmax(tree._h, pman._h)
+
+
+def density(ctx, act, update_hsml, DoEgyDensity, BlackHoleOn, kick, tree, pman, SphP, BhP=None, GradRho_mag=None,
+            UseGPU=True):
+    """density(act, update_hsml, DoEgyDensity, BlackHoleOn, times..., &EntVarPred, GradRho_mag, tree, UseGPU),
+    libgadget/density2.h:42.  Returns (EntVarPred, SphStats)."""
+    a = None if act is None else np.ascontiguousarray(act, dtype=np.int32)
+    evp = np.zeros(max(len(SphP), 1))
+    st = SphStats()
+    kick = kick if kick is not None else KickFactors()
+    rc = capi.host.shqh_density(ctx.h, pman._h, tree._h, capi.ptr(SphP), len(SphP), capi.ptr(BhP), 0 if BhP is None else len(BhP),
+                                capi.ptr(a), 0 if a is None else len(a), int(update_hsml), int(DoEgyDensity), int(BlackHoleOn),
+                                C.byref(kick), capi.ptr(evp), capi.ptr(GradRho_mag), int(UseGPU), C.byref(st))
+    capi.check_host(rc, "density")
+    return evp, st
+
+
+def hydro_force(ctx, act, atime, hubble, EntVarPred, kick, tree, pman, SphP, drifts=None, UseGPU=True):
+    """hydro_force(act, atime, EntVarPred, times..., tree, UseGPU), libgadget/hydra2.h:9."""
+    a = None if act is None else np.ascontiguousarray(act, dtype=np.int32)
+    st = SphStats()
+    kick = kick if kick is not None else KickFactors()
+    d = None if drifts is None else np.ascontiguousarray(drifts, dtype=np.float64)
+    rc = capi.host.shqh_hydro_force(ctx.h, pman._h, tree._h, capi.ptr(SphP), len(SphP), capi.ptr(a), 0 if a is None else len(a),
+                                    atime, hubble, capi.ptr(EntVarPred), C.byref(kick), capi.ptr(d), int(UseGPU), C.byref(st))
+    capi.check_host(rc, "hydro_force")
+    return st

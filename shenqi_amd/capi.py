@@ -98,7 +98,7 @@ class TreeView(C.Structure):
     _fields_ = [
         ("nodes_base", C.c_void_p), ("firstnode", C.c_int64), ("lastnode", C.c_int64),
         ("numnodes", C.c_int64), ("rootnode", C.c_int32), ("full_particle_tree_flag", C.c_int32),
-        ("BoxSize", C.c_double),
+        ("BoxSize", C.c_double), ("father", C.c_void_p),
     ]
 
 
@@ -122,6 +122,47 @@ class WalkStats(C.Structure):
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+TIMEBINS = 46
+
+
+class KickFactors(C.Structure):
+    _fields_ = [("FgravkickB", C.c_double), ("gravkicks", C.c_double * (TIMEBINS + 1)),
+                ("hydrokicks", C.c_double * (TIMEBINS + 1)), ("dloga_kick", C.c_double * (TIMEBINS + 1)),
+                ("dloga_for_bin", C.c_double * (TIMEBINS + 1))]
+
+
+class DensityParams(C.Structure):
+    _fields_ = [("BoxSize", C.c_double), ("DesNumNgb", C.c_double), ("DesNumNgbBH", C.c_double),
+                ("MinGasHsml", C.c_double), ("MaxNumNgbDeviation", C.c_double), ("update_hsml", C.c_int32),
+                ("BlackHoleOn", C.c_int32), ("DoEgyDensity", C.c_int32), ("WindsDecouple", C.c_int32),
+                ("DensityKernelType", C.c_int32), ("pad_", C.c_int32), ("kf", KickFactors)]
+
+
+class HydroParams(C.Structure):
+    _fields_ = [("BoxSize", C.c_double), ("atime", C.c_double), ("fac_mu", C.c_double), ("fac_vsic_fix", C.c_double),
+                ("hubble_a2", C.c_double), ("drifts", C.c_double * (TIMEBINS + 1)), ("ArtBulkViscConst", C.c_double),
+                ("DensityContrastLimit", C.c_double), ("WindSpeed", C.c_double), ("WindFreeTravelDensThresh", C.c_double),
+                ("DensityIndependentSphOn", C.c_int32), ("DensityKernelType", C.c_int32), ("kf", KickFactors)]
+
+
+class SphView(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("elsize", C.c_size_t), ("numslots", C.c_int64),
+                ("off_density", C.c_size_t), ("off_egywtdensity", C.c_size_t), ("off_entropy", C.c_size_t),
+                ("off_dtentropy", C.c_size_t), ("off_maxsignalvel", C.c_size_t), ("off_hydroaccel", C.c_size_t),
+                ("off_dhsmlegydensityfactor", C.c_size_t), ("off_divvel", C.c_size_t), ("off_curlvel", C.c_size_t),
+                ("off_delaytime", C.c_size_t)]
+
+
+class BhView(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("elsize", C.c_size_t), ("numslots", C.c_int64),
+                ("off_density", C.c_size_t), ("off_divvel", C.c_size_t)]
+
+
+class SphStats(C.Structure):
+    _fields_ = [("ntargets", C.c_int64), ("ninteractions", C.c_int64), ("niterations", C.c_int32), ("pad_", C.c_int32),
+                ("kernel_ms", C.c_double)]
 
 
 class PMParams(C.Structure):
@@ -220,3 +261,21 @@ def load_kernel_table():
 
 _KERNELS = load_kernel_table()
 host.shqh_set_kernel_table(ptr(_KERNELS))
+
+# ---- SPH host-mirror prototypes --------------------------------------------------------------
+hip.shq_density.argtypes = [_vp, C.POINTER(TreeView), _vp, C.POINTER(PartView), C.POINTER(SphView), C.POINTER(BhView),
+                            _vp, C.c_int64, C.POINTER(DensityParams), _vp, _vp, C.POINTER(SphStats)]
+hip.shq_hydro_force.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(SphView), _vp, C.c_int64,
+                                C.POINTER(HydroParams), _vp, C.POINTER(SphStats)]
+host.shqh_set_densitypar.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]
+host.shqh_set_densitypar.restype = None
+host.shqh_GetNumNgb.restype = C.c_double
+host.shqh_set_hydropar.argtypes = [C.c_int, C.c_double, C.c_double]
+host.shqh_set_hydropar.restype = None
+host.shqh_set_init_hsml.argtypes = [_vp, C.c_double, _vp]
+host.shqh_force_tree_update_hmax.argtypes = [_vp, _vp]
+host.shqh_force_tree_update_hmax.restype = None
+host.shqh_density.argtypes = [_vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int, C.c_int, C.c_int,
+                              C.POINTER(KickFactors), _vp, _vp, C.c_int, C.POINTER(SphStats)]
+host.shqh_hydro_force.argtypes = [_vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_double, C.c_double, _vp,
+                                  C.POINTER(KickFactors), _vp, C.c_int, C.POINTER(SphStats)]

@@ -128,6 +128,16 @@ extern "C" void shq_shutdown(shq_context *ctx)
     ctx->posm_leaf.release(); ctx->leaf_pidx.release();
     ctx->mesh.release(); ctx->sinctab.release(); ctx->dbg_rho.release(); ctx->dbg_pot.release();
     ctx->gravtab.release(); ctx->stage.release();
+    ctx->node_hmax.release(); ctx->pfather.release();
+    ctx->hsml.release(); ctx->dthsml.release(); ctx->vel.release(); ctx->bin_grav.release(); ctx->bin_hydro.release();
+    ctx->g_entropy.release(); ctx->g_dtentropy.release(); ctx->g_hydroaccel.release(); ctx->g_delaytime.release();
+    ctx->g_density.release(); ctx->g_egywt.release(); ctx->g_dhsmlegy.release(); ctx->g_divvel.release(); ctx->g_curlvel.release();
+    ctx->g_hydroaccel_out.release(); ctx->g_dtentropy_out.release(); ctx->g_maxsignalvel.release();
+    ctx->velp.release(); ctx->hydC.release(); ctx->hydD.release(); ctx->velp_leaf.release(); ctx->hydC_leaf.release();
+    ctx->hydD_leaf.release(); ctx->hsml_leaf.release(); ctx->flag_leaf.release();
+    ctx->s_numngb.release(); ctx->s_dhsmldens.release(); ctx->s_left.release(); ctx->s_right.release(); ctx->s_rot.release();
+    ctx->s_gradrho.release(); ctx->s_evp_in.release(); ctx->s_todo.release(); ctx->s_queue2.release(); ctx->s_queue3.release();
+    ctx->s_blockcount.release(); ctx->s_counters.release();
     for(int i = 0; i < SHQ_NTIMERS; i++) {
         (void) hipEventDestroy(ctx->ev_begin[i]);
         (void) hipEventDestroy(ctx->ev_end[i]);
@@ -356,6 +366,29 @@ extern "C" int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree)
         } else
             SHQ_HIP(hipMemsetAsync(ctx->posm_leaf.ptr, 0, sizeof(double4) * npad, ctx->stream));
     }
+    /* SPH extras: mom.hmax per node and the leaf holding each particle (ForceTree.Father) */
+    {
+        std::vector<double> hH(nn + 1, 0.0);
+        for(int64_t j = 0; j < nn; j++)
+            hH[j] = src[order[j]].hmax;
+        SHQ_TRY(ctx->node_hmax.reserve(nn + 1));
+        SHQ_HIP(hipMemcpyAsync(ctx->node_hmax.ptr, hH.data(), sizeof(double) * (nn + 1), hipMemcpyHostToDevice, ctx->stream));
+        ctx->have_father = false;
+        if(tree->father && np > 0) {
+            std::vector<int32_t> pf((size_t) np, -1);
+            for(int64_t i = 0; i < np; i++) {
+                const int64_t f = tree->father[i];
+                if(f >= fn && f < fn + nall)
+                    pf[i] = newidx[f - fn];
+            }
+            SHQ_TRY(ctx->pfather.reserve((size_t) np));
+            SHQ_HIP(hipMemcpyAsync(ctx->pfather.ptr, pf.data(), sizeof(int32_t) * np, hipMemcpyHostToDevice, ctx->stream));
+            SHQ_HIP(hipStreamSynchronize(ctx->stream));
+            ctx->have_father = true;
+        }
+        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->node_order = order;
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     ctx->numnodes = nn;
     ctx->firstnode = fn;

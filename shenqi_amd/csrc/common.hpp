@@ -149,6 +149,24 @@ struct shq_context {
     DevBuf<int32_t> leaf_pidx; /* leaf slot -> particle index */
     bool have_tree = false;
     double treeBox = 0;
+    DevBuf<double> node_hmax;  /* mom.hmax per packed node (SPH symmetric cull) */
+    DevBuf<int32_t> pfather;   /* particle -> packed index of the leaf holding it, or -1 */
+    std::vector<int32_t> node_order; /* packed index -> index into the caller's nodes_base */
+    bool have_father = false;
+
+    /* ---- SPH state, by particle index (gas fields gathered from their slots at upload) */
+    bool have_sph = false;
+    DevBuf<double> hsml, dthsml, vel;
+    DevBuf<uint8_t> bin_grav, bin_hydro;
+    DevBuf<double> g_entropy, g_dtentropy, g_hydroaccel, g_delaytime;
+    DevBuf<double> g_density, g_egywt, g_dhsmlegy, g_divvel, g_curlvel;
+    DevBuf<double> g_hydroaccel_out, g_dtentropy_out, g_maxsignalvel;
+    DevBuf<double4> velp, hydC, hydD, velp_leaf, hydC_leaf, hydD_leaf;
+    DevBuf<double> hsml_leaf;
+    DevBuf<uint8_t> flag_leaf;
+    DevBuf<double> s_numngb, s_dhsmldens, s_left, s_right, s_rot, s_gradrho, s_evp_in;
+    DevBuf<int32_t> s_todo, s_queue2, s_queue3, s_blockcount;
+    DevBuf<long long> s_counters;
 
     /* ---- PM */
     int pm_nmesh = 0;
@@ -184,5 +202,11 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm);
 void shq_pm_destroy_plans(shq_context *ctx);
 int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *complx);
 int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double *real);
+/* sph.hip */
+int shq_sph_prepare(shq_context *ctx, const shq_kick_factors *kf, const shq_hydro_params *hp, const double *d_evp_in);
+int shq_sph_density_device(shq_context *ctx, const shq_density_params *p, const int32_t *d_queue, int64_t nq,
+                           int want_gradrho, shq_sph_stats *stats);
+int shq_sph_hydro_device(shq_context *ctx, const shq_hydro_params *p, const int32_t *d_queue, int64_t nq, shq_sph_stats *stats);
+int shq_sph_gradrho_mag(shq_context *ctx, double *d_out);
 
 #endif

@@ -1,0 +1,957 @@
+/* sph.hip — SPH density (with the smoothing-length iteration) and hydro force for gfx950.
+ *
+ * Replaces treewalk_primary_kernel<DensityTreeWalk*> / <HydroTreeWalk*> (treewalk2.cuh:104-134,
+ * densitycuda.cu, hydracuda.cu) AND the host-side Hsml loop the reference keeps on the CPU
+ * (TreeWalk::do_hsml_loop, treewalk2.h:480-557; DensityOutput::postprocess +
+ * density_check_neighbours, densitytree2.hpp:117-257; queue compaction).
+ *
+ * Structure (same wavefront-collective walk as grav_walk.hip):
+ *   - a wavefront owns 64 consecutive targets of the work queue; the union of the lanes'
+ *     neighbour walks is traversed with a wave-uniform `cur` and per-lane `mynext`; the cull
+ *     test (cull_node, localtreewalk2.h:154-182) is evaluated per lane, so every target sees
+ *     exactly the candidate set the reference's walk gives it, in the same order;
+ *   - per-neighbour quantities that the reference recomputes for every pair (SPH_VelPred,
+ *     SPH_EntVarPred, density/pressure prediction, sound speed, the Balsara factor f2 of j) are
+ *     pure functions of particle j, so a prepass evaluates them once per particle and stores them
+ *     in leaf order: a neighbour costs two (density) or four (hydro) 32-byte uniform loads;
+ *   - the Hsml iteration runs on the device: walk -> postprocess (bisection / Newton step,
+ *     Left/Right brackets) -> order-preserving compaction of the redo queue; the host only reads
+ *     back the queue length once per iteration.
+ * All arithmetic is f64.
+ */
+#include "common.hpp"
+#include <math.h>
+
+#define SPH_GAMMA (5.0 / 3.0)      /* physconst.h:35 */
+#define SPH_GAMMA_MINUS1 (SPH_GAMMA - 1)
+#define SPH_MAXITER 400            /* treewalk2.h:21 */
+
+namespace {
+
+__device__ __forceinline__ double wrapd(double d, double L, double invL) { return fma(-L, rint(d * invL), d); }
+
+/* Price (2012) kernels as libgadget/densitykernel.hpp:28-178 defines them (integer powers
+ * written as products). KT: 1 cubic, 2 quintic, 4 quartic. */
+template <int KT> struct Kern {
+    static constexpr double support = (KT == 1) ? 4.0 : ((KT == 2) ? 6.0 : 5.0);
+    double H, Wknorm, dnorm;
+    __device__ __forceinline__ explicit Kern(double H_) : H(H_)
+    {
+        const double sigma = (KT == 1) ? (1 / M_PI) : ((KT == 2) ? (1 / (120 * M_PI)) : (1 / (20 * M_PI)));
+        const double s = support / 2. / H;
+        Wknorm = sigma * (s * s * s);
+        dnorm = Wknorm * support / 2. / H;
+    }
+    static __device__ __forceinline__ double p3(double x) { return x * x * x; }
+    static __device__ __forceinline__ double p4(double x) { const double y = x * x; return y * y; }
+    static __device__ __forceinline__ double p5(double x) { const double y = x * x; return y * y * x; }
+    __device__ __forceinline__ double wk_int(double q) const
+    {
+        if(KT == 1) {
+            if(q < 1.0) return 0.25 * p3(2 - q) - p3(1 - q);
+            if(q < 2.0) return 0.25 * p3(2 - q);
+            return 0.0;
+        } else if(KT == 4) {
+            if(q < 0.5) return p4(2.5 - q) - 5 * p4(1.5 - q) + 10 * p4(0.5 - q);
+            if(q < 1.5) return p4(2.5 - q) - 5 * p4(1.5 - q);
+            if(q < 2.5) return p4(2.5 - q);
+            return 0.0;
+        } else {
+            if(q < 1.0) return p5(3 - q) - 6 * p5(2 - q) + 15 * p5(1 - q);
+            if(q < 2.0) return p5(3 - q) - 6 * p5(2 - q);
+            if(q < 3.0) return p5(3 - q);
+            return 0.0;
+        }
+    }
+    __device__ __forceinline__ double dwk_int(double q) const
+    {
+        if(KT == 1) {
+            if(q < 1.0) return -0.25 * 3 * (2 - q) * (2 - q) + 3 * (1 - q) * (1 - q);
+            if(q < 2.0) return -0.25 * 3 * (2 - q) * (2 - q);
+            return 0.0;
+        } else if(KT == 4) {
+            if(q < 0.5) return -4 * p3(2.5 - q) + 20 * p3(1.5 - q) - 40 * p3(0.5 - q);
+            if(q < 1.5) return -4 * p3(2.5 - q) + 20 * p3(1.5 - q);
+            if(q < 2.5) return -4 * p3(2.5 - q);
+            return 0.0;
+        } else {
+            if(q < 1.0) return -5 * p4(3 - q) + 30 * p4(2 - q) - 75 * p4(1 - q);
+            if(q < 2.0) return -5 * p4(3 - q) + 30 * p4(2 - q);
+            if(q < 3.0) return -5 * p4(3 - q);
+            return 0.0;
+        }
+    }
+    __device__ __forceinline__ double wk(double u) const { return Wknorm * wk_int(u * support / 2.); }
+    __device__ __forceinline__ double dwk(double u) const { return dnorm * dwk_int(u * support / 2.); }
+    __device__ __forceinline__ double volume() const { return (4.0 / 3 * M_PI) * (H * H * H); }
+};
+
+/* KickFactorData::SPH_EntVarPred, density2.h:115-128 */
+__device__ __forceinline__ double entvar_pred(double Entropy, double DtEntropy, double dloga)
+{
+    double e = Entropy + DtEntropy * dloga;
+    if(e < 0.05 * Entropy)
+        e = 0.05 * Entropy;
+    if(e <= 0)
+        return 0;
+    return exp(1. / SPH_GAMMA * log(e));
+}
+/* SPH_DensityPred, hydratree2.hpp:21-34 */
+__device__ __forceinline__ double density_pred(double Density, double DivVel, double dtdrift)
+{
+    const double d = Density - DivVel * Density * dtdrift;
+    return (d >= 1e-6 * Density) ? d : 1e-6 * Density;
+}
+/* PressurePredict, hydratree2.hpp:47-58 */
+__device__ __forceinline__ double pressure_predict(double eom, double evp)
+{
+    if(evp * eom <= 0)
+        return 0;
+    return exp(SPH_GAMMA * log(evp * eom));
+}
+
+struct SphDev {
+    /* node pool */
+    const NodeB *nodeB;
+    const NodeC *nodeC;
+    double *hmax;               /* per node */
+    const int32_t *pfather;     /* particle -> packed father leaf */
+    int root;
+    /* leaf-order neighbour data */
+    const double4 *posm_leaf;   /* x,y,z,m */
+    const double4 *velp_leaf;   /* predicted velocity, EntVarPred */
+    const double4 *hydC_leaf;   /* EntVarPred, density_j, soundspeed_j, p_over_rho2_j */
+    const double4 *hydD_leaf;   /* Dhsml_j, rr2_j, f2_j, dloga_for_bin_j */
+    const double *hsml_leaf;
+    const uint8_t *flag_leaf;   /* bit0 skip (garbage / not gas), bit1 wind-decoupled */
+    /* per particle */
+    const double4 *posm;
+    const uint8_t *pflags;
+    double *hsml;
+    double *dthsml;
+    const double4 *velp;
+    const double4 *hydC;
+    const double4 *hydD;
+    /* density scratch / outputs, by particle index */
+    double *numngb, *dhsmldens, *left, *right;
+    double *rho, *egyrho, *dhsmlegy, *div, *curl;
+    double *rot;      /* [N][3] */
+    double *gradrho;  /* [N][3] or null */
+    /* hydro outputs */
+    double *hacc;     /* [N][3] */
+    double *dtent, *maxsig;
+    double Box, invBox;
+};
+
+/* cull_node<symmetric>, localtreewalk2.h:154-182 */
+__device__ __forceinline__ bool cull_keep(const NodeB &B, double px, double py, double pz, double search, double Box,
+                                          double invBox)
+{
+    double dist = search + 0.5 * B.len;
+    const double dx = wrapd(B.center[0] - px, Box, invBox);
+    const double dy = wrapd(B.center[1] - py, Box, invBox);
+    const double dz = wrapd(B.center[2] - pz, Box, invBox);
+    if(fmax(fmax(fabs(dx), fabs(dy)), fabs(dz)) > dist)
+        return false;
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    dist += (0.5 * (1.7320508075688772 - 1.0)) * B.len;
+    return !(r2 > dist * dist);
+}
+
+/* ---- prepass: per-particle predicted quantities -------------------------------------------- */
+struct PredArgs {
+    long long n;
+    const uint8_t *pflags;
+    const double *vel, *treeacc, *gravpm, *hydroaccel; /* [N][3] by particle index */
+    const uint8_t *bin_grav, *bin_hydro;
+    const double *entropy, *dtentropy;
+    const double *hsml;
+    const double *density, *egywt, *dhsmlegy, *divvel, *curlvel;
+    double4 *velp, *hydC, *hydD;
+    const double *evp_in; /* caller-provided EntVarPred by particle index, or null */
+    shq_kick_factors kf;
+    double drifts[SHQ_TIMEBINS + 1];
+    int hydro;          /* also fill hydC/hydD */
+    int DISPH;
+    double fac_mu, contrast;
+};
+
+__global__ void sph_predict_kernel(const PredArgs a)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= a.n)
+        return;
+    const int type = a.pflags[i] >> 4;
+    if(type != 0) {
+        /* non-gas (BH targets use their own velocity: DensityQuery ctor, densitytree2.hpp:270-277) */
+        a.velp[i] = make_double4(a.vel[3 * i], a.vel[3 * i + 1], a.vel[3 * i + 2], 0.0);
+        return;
+    }
+    const int bg = a.bin_grav[i], bh = a.bin_hydro[i];
+    /* SPH_VelPred, density2.h:89-98 */
+    double v[3];
+    for(int j = 0; j < 3; j++)
+        v[j] = a.vel[3 * i + j] + a.kf.gravkicks[bg] * a.treeacc[3 * i + j] + a.gravpm[3 * i + j] * a.kf.FgravkickB +
+               a.kf.hydrokicks[bh] * a.hydroaccel[3 * i + j];
+    const double evp = a.evp_in ? a.evp_in[i] : entvar_pred(a.entropy[i], a.dtentropy[i], a.kf.dloga_kick[bh]);
+    a.velp[i] = make_double4(v[0], v[1], v[2], evp);
+    if(a.hydro) {
+        /* ngbiter's j-side quantities, hydratree2.hpp:283-300,325-326,357-364 */
+        const double density_j = density_pred(a.density[i], a.divvel[i], a.drifts[bh]);
+        const double eom_j = density_pred(a.DISPH ? a.egywt[i] : a.density[i], a.divvel[i], a.drifts[bh]);
+        const double P = pressure_predict(eom_j, evp);
+        const double cs = sqrt(SPH_GAMMA * P / eom_j);
+        a.hydC[i] = make_double4(evp, density_j, cs, P / (eom_j * eom_j));
+        const double f2 = fabs(a.divvel[i]) / (fabs(a.divvel[i]) + a.curlvel[i] + 0.0001 * cs / a.fac_mu / a.hsml[i]);
+        double rr2 = 1;
+        if(a.DISPH) {
+            rr2 = 0;
+            if(a.contrast >= 0) {
+                rr2 = eom_j / density_j;
+                if(a.contrast > 0)
+                    rr2 = fmin(rr2, a.contrast);
+            }
+        }
+        a.hydD[i] = make_double4(a.dhsmlegy[i], rr2, f2, a.kf.dloga_for_bin[bh]);
+    }
+}
+
+__global__ void sph_gather_leaf_kernel(long long nleaf, const int32_t *pidx, const double4 *velp, const double4 *hydC,
+                                       const double4 *hydD, const double *hsml, const uint8_t *pflags, const double *delay,
+                                       double4 *velp_leaf, double4 *hydC_leaf, double4 *hydD_leaf, double *hsml_leaf,
+                                       uint8_t *flag_leaf)
+{
+    const long long s = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(s >= nleaf)
+        return;
+    const int p = pidx[s];
+    velp_leaf[s] = velp[p];
+    if(hydC_leaf) {
+        hydC_leaf[s] = hydC[p];
+        hydD_leaf[s] = hydD[p];
+    }
+    hsml_leaf[s] = hsml[p];
+    const uint8_t f = pflags[p];
+    uint8_t o = 0;
+    if((f & 1) || (f >> 4) != 0) /* IsGarbage, or type changed since the tree was built (GASMASK) */
+        o |= 1;
+    if(delay && delay[p] > 0)
+        o |= 2;
+    flag_leaf[s] = o;
+}
+
+/* ---- density walk ------------------------------------------------------------------------------ */
+template <int KT> __global__ __launch_bounds__(256) void sph_density_kernel(const SphDev a, const int32_t *queue, long long nq,
+                                                                           int WindsDecouple, unsigned long long *nint_total)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long t = wave * 64 + lane;
+    const bool valid = t < nq;
+    long long pi = 0;
+    double px = 0, py = 0, pz = 0, h = 0, vx = 0, vy = 0, vz = 0;
+    int type = 0;
+    if(valid) {
+        pi = queue ? (long long) queue[t] : t;
+        const double4 p = a.posm[pi];
+        px = p.x; py = p.y; pz = p.z;
+        h = a.hsml[pi];
+        const double4 v = a.velp[pi];
+        vx = v.x; vy = v.y; vz = v.z;
+        type = a.pflags[pi] >> 4;
+    }
+    const Kern<KT> kernel(valid ? h : 1.0);
+    const double h2 = h * h, Hinv = 1.0 / kernel.H, vol = kernel.volume();
+    double Ngb = 0, Rho = 0, DhsmlDensity = 0, EgyRho = 0, DhsmlEgy = 0, Div = 0;
+    double R0 = 0, R1 = 0, R2 = 0, G0 = 0, G1 = 0, G2 = 0;
+    unsigned int nint = 0;
+    int mynext = valid ? a.root : -2;
+    int cur = a.root;
+    while(cur >= 0) {
+        cur = __builtin_amdgcn_readfirstlane(cur);
+        const NodeB B = a.nodeB[cur];
+        const NodeC C = a.nodeC[cur];
+        const bool act = (mynext == cur);
+        const bool keep = act && cull_keep(B, px, py, pz, h, a.Box, a.invBox);
+        int next;
+        if(C.type == SHQ_PARTICLE_NODE_TYPE) {
+            if(__ballot(keep) != 0ull) {
+                for(int k = 0; k < C.count; k++) {
+                    const int s = C.child + k;
+                    const uint8_t fl = a.flag_leaf[s];
+                    if(fl & 1)
+                        continue;
+                    const double4 q = a.posm_leaf[s];
+                    const double4 w = a.velp_leaf[s];
+                    if(keep) {
+                        nint++;
+                        /* ngbiter, densitytree2.hpp:362-423; dist points from the neighbour to the target */
+                        const double d0 = wrapd(px - q.x, a.Box, a.invBox);
+                        const double d1 = wrapd(py - q.y, a.Box, a.invBox);
+                        const double d2 = wrapd(pz - q.z, a.Box, a.invBox);
+                        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+                        if(r2 < h2 && !(WindsDecouple && type == 5 && (fl & 2))) {
+                            const double r = sqrt(r2);
+                            const double u = r * Hinv;
+                            const double wk = kernel.wk(u);
+                            const double dwk = kernel.dwk(u);
+                            Ngb += wk * vol;
+                            const double mj = q.w;
+                            Rho += mj * wk;
+                            const double dW = -(3 * wk * Hinv + u * dwk); /* DensityKrnl::dW, densitykernel.hpp:58-61 */
+                            DhsmlDensity += mj * dW;
+                            EgyRho += mj * w.w * wk;
+                            DhsmlEgy += mj * w.w * dW;
+                            if(r > 0) {
+                                const double fac = mj * dwk / r;
+                                const double e0 = vx - w.x, e1 = vy - w.y, e2 = vz - w.z;
+                                Div += -fac * (d0 * e0 + d1 * e1 + d2 * e2);
+                                R0 += fac * (e1 * d2 - e2 * d1);
+                                R1 += fac * (e2 * d0 - e0 * d2);
+                                R2 += fac * (e0 * d1 - e1 * d0);
+                                G0 += fac * d0;
+                                G1 += fac * d1;
+                                G2 += fac * d2;
+                            }
+                        }
+                    }
+                }
+            }
+            if(act)
+                mynext = C.sibling;
+            next = C.sibling;
+        } else if(C.type == SHQ_PSEUDO_NODE_TYPE) {
+            if(act)
+                mynext = C.sibling;
+            next = C.sibling;
+        } else {
+            const bool any = __ballot(keep) != 0ull;
+            if(act)
+                mynext = keep ? C.child : C.sibling;
+            next = any ? C.child : C.sibling;
+        }
+        cur = next;
+    }
+    if(valid) {
+        /* DensityResult::reduce<PRIMARY>, densitytree2.hpp:308-343 */
+        a.numngb[pi] = Ngb;
+        a.dhsmldens[pi] = DhsmlDensity;
+        a.rho[pi] = Rho;
+        a.div[pi] = Div;
+        if(type == 0) {
+            a.rot[3 * pi] = R0;
+            a.rot[3 * pi + 1] = R1;
+            a.rot[3 * pi + 2] = R2;
+            if(a.gradrho) {
+                a.gradrho[3 * pi] = G0;
+                a.gradrho[3 * pi + 1] = G1;
+                a.gradrho[3 * pi + 2] = G2;
+            }
+            a.egyrho[pi] = EgyRho;
+            a.dhsmlegy[pi] = DhsmlEgy;
+        }
+    }
+    unsigned int s = nint;
+    for(int off = 32; off > 0; off >>= 1)
+        s += __shfl_xor(s, off);
+    if(lane == 0 && nint_total)
+        atomicAdd(nint_total, (unsigned long long) s);
+}
+
+/* ---- density postprocess + Hsml update (DensityOutput::postprocess, density_check_neighbours) -- */
+struct PostArgs {
+    double Box, DesNumNgb, DesNumNgbBH, MinGasHsml, MaxDev;
+    int update_hsml, BlackHoleOn, DoEgyDensity;
+};
+
+__global__ void sph_density_post_kernel(const SphDev a, const int32_t *queue, long long nq, const PostArgs p, int32_t *todo)
+{
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= nq)
+        return;
+    const long long i = queue ? (long long) queue[t] : t;
+    const int type = a.pflags[i] >> 4;
+    int done = 0;
+    const double density = a.rho[i];
+    double hs = a.hsml[i];
+    double DhsmlDens = a.dhsmldens[i];
+    DhsmlDens *= hs / (3 * density);
+    DhsmlDens = 1 / (1 + DhsmlDens);
+    a.dhsmldens[i] = DhsmlDens;
+    if(p.update_hsml) {
+        double desnumngb = p.DesNumNgb;
+        if(p.BlackHoleOn && type == 5)
+            desnumngb = p.DesNumNgbBH;
+        const double NumNgb = a.numngb[i];
+        double L = a.left[i], R = a.right[i];
+        if(NumNgb < (desnumngb - p.MaxDev) || (NumNgb > (desnumngb + p.MaxDev))) {
+            if((R - L) < 1.0e-5 * R) {
+                hs = R;
+                done = 1;
+            } else {
+                if(NumNgb < desnumngb)
+                    L = hs;
+                else
+                    R = hs;
+                if((R < p.Box && L > 0) || (hs * 1.26 > 0.99 * p.Box))
+                    hs = cbrt(0.5 * (L * L * L + R * R * R));
+                else {
+                    const double DensFac = DhsmlDens;
+                    double fac = 1.26;
+                    if(NumNgb > 0)
+                        fac = 1 - (NumNgb - desnumngb) / (3 * NumNgb) * DensFac;
+                    if(R > 0.99 * p.Box && L > 0)
+                        if(DensFac <= 0 || fabs(NumNgb - desnumngb) >= 0.5 * desnumngb || fac > 1.26)
+                            fac = 1.26;
+                    if(R < 0.99 * p.Box && L == 0)
+                        if(DensFac <= 0 || fac < 1. / 3)
+                            fac = 1. / 3;
+                    hs *= fac;
+                }
+                if(R < p.MinGasHsml) {
+                    hs = p.MinGasHsml;
+                    done = 1;
+                } else
+                    done = 0;
+            }
+            a.left[i] = L;
+            a.right[i] = R;
+        } else {
+            if(hs < p.MinGasHsml)
+                hs = p.MinGasHsml;
+            done = 1;
+        }
+        a.hsml[i] = hs;
+    }
+    if(type == 0) {
+        if(p.DoEgyDensity) {
+            const double EntPred = a.velp[i].w;
+            double d = a.dhsmlegy[i];
+            d *= hs / (3 * a.egyrho[i]);
+            d *= -DhsmlDens;
+            a.dhsmlegy[i] = d;
+            a.egyrho[i] = a.egyrho[i] / EntPred;
+        } else
+            a.dhsmlegy[i] = DhsmlDens;
+        const double r0 = a.rot[3 * i], r1 = a.rot[3 * i + 1], r2 = a.rot[3 * i + 2];
+        a.curl[i] = sqrt(r0 * r0 + r1 * r1 + r2 * r2) / density;
+        const double dv = a.div[i] / density;
+        a.div[i] = dv;
+        a.dthsml[i] = (1.0 / 3) * dv * hs;
+    } else if(type == 5) {
+        const double dv = a.div[i] / density;
+        a.div[i] = dv;
+        a.dthsml[i] = (1.0 / 3) * dv * hs;
+    }
+    if(todo)
+        todo[t] = done ? -1 : (int32_t) i;
+    if(done && p.update_hsml && type == 0 && a.pfather) {
+        /* update_tree_hmax_father, forcetree.cpp:1285-1313; non-negative doubles order like their bits */
+        const int no = a.pfather[i];
+        if(no >= 0) {
+            const NodeB B = a.nodeB[no];
+            const double4 P = a.posm[i];
+            double nh = 0;
+            nh = fmax(nh, fabs(P.x - B.center[0]) + hs - B.len / 2.);
+            nh = fmax(nh, fabs(P.y - B.center[1]) + hs - B.len / 2.);
+            nh = fmax(nh, fabs(P.z - B.center[2]) + hs - B.len / 2.);
+            atomicMax(reinterpret_cast<unsigned long long *>(&a.hmax[no]), (unsigned long long) __double_as_longlong(nh));
+        }
+    }
+}
+
+/* ---- order-preserving compaction of the redo queue (three small kernels) --------------------------- */
+__global__ void compact_count_kernel(const int32_t *todo, long long n, int32_t *blockcount)
+{
+    __shared__ int s;
+    if(threadIdx.x == 0)
+        s = 0;
+    __syncthreads();
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const bool f = (t < n) && (todo[t] >= 0);
+    const unsigned long long m = __ballot(f);
+    if((threadIdx.x & 63) == 0)
+        atomicAdd(&s, __popcll(m));
+    __syncthreads();
+    if(threadIdx.x == 0)
+        blockcount[blockIdx.x] = s;
+}
+__global__ void compact_scan_kernel(int32_t *blockcount, int nblocks, long long *total)
+{
+    /* single workgroup exclusive scan */
+    __shared__ long long carry;
+    __shared__ int buf[1024];
+    if(threadIdx.x == 0)
+        carry = 0;
+    __syncthreads();
+    for(int base = 0; base < nblocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = (i < nblocks) ? blockcount[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for(int off = 1; off < 1024; off <<= 1) {
+            int add = (threadIdx.x >= off) ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const int incl = buf[threadIdx.x];
+        if(i < nblocks)
+            blockcount[i] = (int32_t) (carry + incl - v);
+        __syncthreads();
+        if(threadIdx.x == 1023)
+            carry += incl;
+        __syncthreads();
+    }
+    if(threadIdx.x == 0)
+        *total = carry;
+}
+__global__ void compact_write_kernel(const int32_t *todo, long long n, const int32_t *blockoff, int32_t *out)
+{
+    __shared__ int wavebase[4];
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const bool f = (t < n) && (todo[t] >= 0);
+    const unsigned long long m = __ballot(f);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if(lane == 0)
+        wavebase[w] = __popcll(m);
+    __syncthreads();
+    int base = blockoff[blockIdx.x];
+    for(int k = 0; k < w; k++)
+        base += wavebase[k];
+    if(f) {
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        out[base + rank] = todo[t];
+    }
+}
+
+/* ---- hydro walk (HydroLocalTreeWalk::ngbiter, hydratree2.hpp:253-378) ----------------------------- */
+struct HydroConst {
+    double hubble_a2, fac_mu, fac_vsic_fix, ArtBulkViscConst, contrast;
+    int DISPH;
+};
+
+template <int KT> __global__ __launch_bounds__(256) void sph_hydro_kernel(const SphDev a, const int32_t *queue, long long nq,
+                                                                         const HydroConst hc, unsigned long long *nint_total)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long t = wave * 64 + lane;
+    const bool valid = t < nq;
+    long long pi = 0;
+    double px = 0, py = 0, pz = 0, mi = 0, hi = 1, vx = 0, vy = 0, vz = 0;
+    double4 Ci = make_double4(1, 1, 1, 1), Di = make_double4(0, 0, 0, 0);
+    if(valid) {
+        pi = queue ? (long long) queue[t] : t;
+        const double4 p = a.posm[pi];
+        px = p.x; py = p.y; pz = p.z; mi = p.w;
+        hi = a.hsml[pi];
+        const double4 v = a.velp[pi];
+        vx = v.x; vy = v.y; vz = v.z;
+        Ci = a.hydC[pi];
+        Di = a.hydD[pi];
+    }
+    /* HydroQuery ctor, hydratree2.hpp:165-191: for the target itself the un-drifted values apply, but a
+     * target is active, so its drift factor is zero and the predicted values coincide. */
+    const double iEntVarPred = Ci.x, iDensity = Ci.y, soundspeed_i = Ci.z, p_over_rho2_i = Ci.w;
+    const double iDhsml = Di.x, iF1 = Di.z, idloga = Di.w;
+    /* rr1 = EgyRho / Density with the contrast limit; Di.y holds exactly that for the target */
+    const double rr1 = Di.y;
+    const Kern<KT> kernel_i(hi);
+    const double hi2 = hi * hi;
+    double A0 = 0, A1 = 0, A2 = 0, DtE = 0;
+    double MaxSig = soundspeed_i; /* HydroResult ctor: sqrt(GAMMA P / EgyRho) */
+    unsigned int nint = 0;
+    int mynext = valid ? a.root : -2;
+    int cur = a.root;
+    while(cur >= 0) {
+        cur = __builtin_amdgcn_readfirstlane(cur);
+        const NodeB B = a.nodeB[cur];
+        const NodeC C = a.nodeC[cur];
+        const double hmax = a.hmax[cur];
+        const bool act = (mynext == cur);
+        const bool keep = act && cull_keep(B, px, py, pz, fmax(hmax, hi), a.Box, a.invBox);
+        int next;
+        if(C.type == SHQ_PARTICLE_NODE_TYPE) {
+            if(__ballot(keep) != 0ull) {
+                for(int k = 0; k < C.count; k++) {
+                    const int s = C.child + k;
+                    const uint8_t fl = a.flag_leaf[s];
+                    if(fl & 1)
+                        continue;
+                    const double4 q = a.posm_leaf[s];
+                    const double4 w = a.velp_leaf[s];
+                    const double hj = a.hsml_leaf[s];
+                    const double4 Cj = a.hydC_leaf[s];
+                    const double4 Dj = a.hydD_leaf[s];
+                    if(keep) {
+                        nint++;
+                        const double d0 = wrapd(px - q.x, a.Box, a.invBox);
+                        const double d1 = wrapd(py - q.y, a.Box, a.invBox);
+                        const double d2 = wrapd(pz - q.z, a.Box, a.invBox);
+                        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+                        if(r2 > 0 && (r2 < hi2 || r2 < hj * hj) && !(fl & 2)) {
+                            const Kern<KT> kernel_j(hj);
+                            const double EVP = Cj.x, density_j = Cj.y, soundspeed_j = Cj.z, p_over_rho2_j = Cj.w;
+                            double vsig = soundspeed_i + soundspeed_j;
+                            if(vsig > MaxSig)
+                                MaxSig = vsig;
+                            const double e0 = vx - w.x, e1 = vy - w.y, e2 = vz - w.z;
+                            const double vdotr = d0 * e0 + d1 * e1 + d2 * e2;
+                            const double vdotr2 = vdotr + hc.hubble_a2 * r2;
+                            const double r = sqrt(r2);
+                            const double dwk_i = kernel_i.dwk(r / kernel_i.H);
+                            const double dwk_j = kernel_j.dwk(r / kernel_j.H);
+                            double visc = 0;
+                            if(vdotr2 < 0) {
+                                const double mu_ij = hc.fac_mu * vdotr2 / r;
+                                const double rho_ij = 0.5 * (iDensity + density_j);
+                                vsig = soundspeed_i + soundspeed_j - 3 * mu_ij;
+                                if(vsig > MaxSig)
+                                    MaxSig = vsig;
+                                visc = 0.25 * hc.ArtBulkViscConst * vsig * (-mu_ij) / rho_ij * (iF1 + Dj.z);
+                                const double dloga = 2 * fmax(idloga, Dj.w);
+                                if(dloga > 0 && (dwk_i + dwk_j) < 0) {
+                                    if((mi + q.w) > 0)
+                                        visc = fmin(visc, 0.5 * hc.fac_vsic_fix * vdotr2 / (0.5 * (mi + q.w) * (dwk_i + dwk_j) * r * dloga));
+                                }
+                            }
+                            const double hfc_visc = 0.5 * q.w * visc * (dwk_i + dwk_j) / r;
+                            double hfc = hfc_visc;
+                            if(hc.DISPH)
+                                hfc += q.w * (dwk_i * p_over_rho2_i * EVP / iEntVarPred + dwk_j * p_over_rho2_j * iEntVarPred / EVP) / r;
+                            hfc += q.w * (p_over_rho2_i * iDhsml * dwk_i * rr1 + p_over_rho2_j * Dj.x * dwk_j * Dj.y) / r;
+                            A0 += -hfc * d0;
+                            A1 += -hfc * d1;
+                            A2 += -hfc * d2;
+                            DtE += 0.5 * hfc_visc * vdotr2;
+                        }
+                    }
+                }
+            }
+            if(act)
+                mynext = C.sibling;
+            next = C.sibling;
+        } else if(C.type == SHQ_PSEUDO_NODE_TYPE) {
+            if(act)
+                mynext = C.sibling;
+            next = C.sibling;
+        } else {
+            const bool any = __ballot(keep) != 0ull;
+            if(act)
+                mynext = keep ? C.child : C.sibling;
+            next = any ? C.child : C.sibling;
+        }
+        cur = next;
+    }
+    if(valid) {
+        a.hacc[3 * pi] = A0;
+        a.hacc[3 * pi + 1] = A1;
+        a.hacc[3 * pi + 2] = A2;
+        a.dtent[pi] = DtE;
+        a.maxsig[pi] = MaxSig;
+    }
+    unsigned int s = nint;
+    for(int off = 32; off > 0; off >>= 1)
+        s += __shfl_xor(s, off);
+    if(lane == 0 && nint_total)
+        atomicAdd(nint_total, (unsigned long long) s);
+}
+
+/* HydroOutput::postprocess, hydratree2.hpp:134-148 + winds_decoupled_hydro, winds.h:60-68 */
+__global__ void sph_hydro_post_kernel(const SphDev a, const int32_t *queue, long long nq, const double *density,
+                                      const double *delay, double hubble_a2, double atime, double WindSpeed, double WindThresh)
+{
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= nq)
+        return;
+    const long long i = queue ? (long long) queue[t] : t;
+    double de = a.dtent[i];
+    de *= SPH_GAMMA_MINUS1 / (hubble_a2 * pow(density[i], SPH_GAMMA_MINUS1));
+    if(delay && delay[i] > 0) {
+        a.hacc[3 * i] = 0;
+        a.hacc[3 * i + 1] = 0;
+        a.hacc[3 * i + 2] = 0;
+        de = 0;
+        double windspeed = WindSpeed * atime;
+        const double fac_mu = pow(atime, 3 * (SPH_GAMMA - 1) / 2) / atime;
+        windspeed *= fac_mu;
+        const double hsml_c = cbrt(WindThresh / density[i]) * atime;
+        a.maxsig[i] = hsml_c * fmax(2 * windspeed, a.maxsig[i]);
+    }
+    a.dtent[i] = de;
+}
+
+__global__ void fill_kernel(double *x, long long n, double v)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+        x[i] = v;
+}
+__global__ void gradmag_kernel(const double *g, double *out, long long n)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+        out[i] = sqrt(g[3 * i] * g[3 * i] + g[3 * i + 1] * g[3 * i + 1] + g[3 * i + 2] * g[3 * i + 2]);
+}
+
+inline unsigned nblk(long long n, int t = 256) { return (unsigned) ((n + t - 1) / t); }
+
+SphDev make_dev(shq_context *ctx)
+{
+    SphDev a;
+    a.nodeB = ctx->nodeB.ptr;
+    a.nodeC = ctx->nodeC.ptr;
+    a.hmax = ctx->node_hmax.ptr;
+    a.pfather = ctx->pfather.ptr;
+    a.root = ctx->root;
+    a.posm_leaf = ctx->posm_leaf.ptr;
+    a.velp_leaf = ctx->velp_leaf.ptr;
+    a.hydC_leaf = ctx->hydC_leaf.ptr;
+    a.hydD_leaf = ctx->hydD_leaf.ptr;
+    a.hsml_leaf = ctx->hsml_leaf.ptr;
+    a.flag_leaf = ctx->flag_leaf.ptr;
+    a.posm = ctx->posm.ptr;
+    a.pflags = ctx->pflags.ptr;
+    a.hsml = ctx->hsml.ptr;
+    a.dthsml = ctx->dthsml.ptr;
+    a.velp = ctx->velp.ptr;
+    a.hydC = ctx->hydC.ptr;
+    a.hydD = ctx->hydD.ptr;
+    a.numngb = ctx->s_numngb.ptr;
+    a.dhsmldens = ctx->s_dhsmldens.ptr;
+    a.left = ctx->s_left.ptr;
+    a.right = ctx->s_right.ptr;
+    a.rho = ctx->g_density.ptr;
+    a.egyrho = ctx->g_egywt.ptr;
+    a.dhsmlegy = ctx->g_dhsmlegy.ptr;
+    a.div = ctx->g_divvel.ptr;
+    a.curl = ctx->g_curlvel.ptr;
+    a.rot = ctx->s_rot.ptr;
+    a.gradrho = nullptr;
+    a.hacc = ctx->g_hydroaccel_out.ptr;
+    a.dtent = ctx->g_dtentropy_out.ptr;
+    a.maxsig = ctx->g_maxsignalvel.ptr;
+    a.Box = ctx->treeBox;
+    a.invBox = 1.0 / ctx->treeBox;
+    return a;
+}
+
+} // namespace
+
+/* Prepass + leaf gather: fills velp (and hydC/hydD when hp != NULL) and their leaf-order copies. */
+int shq_sph_prepare(shq_context *ctx, const shq_kick_factors *kf, const shq_hydro_params *hp, const double *d_evp_in)
+{
+    const long long n = ctx->numpart;
+    SHQ_TRY(ctx->velp.reserve(n > 0 ? n : 1));
+    SHQ_TRY(ctx->hydC.reserve(n > 0 ? n : 1));
+    SHQ_TRY(ctx->hydD.reserve(n > 0 ? n : 1));
+    const long long nl = ctx->ntreeparts + SHQ_NMAXCHILD;
+    SHQ_TRY(ctx->velp_leaf.reserve(nl));
+    SHQ_TRY(ctx->hydC_leaf.reserve(nl));
+    SHQ_TRY(ctx->hydD_leaf.reserve(nl));
+    SHQ_TRY(ctx->hsml_leaf.reserve(nl));
+    SHQ_TRY(ctx->flag_leaf.reserve(nl));
+    if(n == 0)
+        return SHQ_OK;
+    PredArgs a;
+    a.n = n;
+    a.pflags = ctx->pflags.ptr;
+    a.vel = ctx->vel.ptr;
+    a.treeacc = ctx->treeacc.ptr;
+    a.gravpm = ctx->gravpm.ptr;
+    a.hydroaccel = ctx->g_hydroaccel.ptr;
+    a.bin_grav = ctx->bin_grav.ptr;
+    a.bin_hydro = ctx->bin_hydro.ptr;
+    a.entropy = ctx->g_entropy.ptr;
+    a.dtentropy = ctx->g_dtentropy.ptr;
+    a.hsml = ctx->hsml.ptr;
+    a.density = ctx->g_density.ptr;
+    a.egywt = ctx->g_egywt.ptr;
+    a.dhsmlegy = ctx->g_dhsmlegy.ptr;
+    a.divvel = ctx->g_divvel.ptr;
+    a.curlvel = ctx->g_curlvel.ptr;
+    a.velp = ctx->velp.ptr;
+    a.hydC = ctx->hydC.ptr;
+    a.hydD = ctx->hydD.ptr;
+    a.evp_in = d_evp_in;
+    a.kf = *kf;
+    a.hydro = hp ? 1 : 0;
+    a.DISPH = hp ? hp->DensityIndependentSphOn : 0;
+    a.fac_mu = hp ? hp->fac_mu : 1;
+    a.contrast = hp ? hp->DensityContrastLimit : 0;
+    for(int i = 0; i <= SHQ_TIMEBINS; i++)
+        a.drifts[i] = hp ? hp->drifts[i] : 0;
+    sph_predict_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(a);
+    sph_gather_leaf_kernel<<<dim3(nblk(nl)), dim3(256), 0, ctx->stream>>>(
+        nl, ctx->leaf_pidx.ptr, ctx->velp.ptr, hp ? ctx->hydC.ptr : nullptr, hp ? ctx->hydD.ptr : nullptr, ctx->hsml.ptr,
+        ctx->pflags.ptr, ctx->g_delaytime.ptr, ctx->velp_leaf.ptr, hp ? ctx->hydC_leaf.ptr : nullptr,
+        hp ? ctx->hydD_leaf.ptr : nullptr, ctx->hsml_leaf.ptr, ctx->flag_leaf.ptr);
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}
+
+template <int KT>
+static void launch_density(shq_context *ctx, const SphDev &a, const int32_t *q, long long nq, int wd, unsigned long long *nint)
+{
+    const long long nwaves = (nq + 63) / 64;
+    sph_density_kernel<KT><<<dim3((unsigned) ((nwaves + 3) / 4)), dim3(256), 0, ctx->stream>>>(a, q, nq, wd, nint);
+}
+template <int KT>
+static void launch_hydro(shq_context *ctx, const SphDev &a, const int32_t *q, long long nq, const HydroConst &hc, unsigned long long *nint)
+{
+    const long long nwaves = (nq + 63) / 64;
+    sph_hydro_kernel<KT><<<dim3((unsigned) ((nwaves + 3) / 4)), dim3(256), 0, ctx->stream>>>(a, q, nq, hc, nint);
+}
+
+/* Device-resident density(): queue = d_queue[0..nq) of particle indices (already filtered by
+ * DensityQuery::haswork).  Runs the whole Hsml loop. */
+int shq_sph_density_device(shq_context *ctx, const shq_density_params *p, const int32_t *d_queue, int64_t nq, int want_gradrho,
+                           shq_sph_stats *stats)
+{
+    const long long n = ctx->numpart;
+    const size_t cap = (size_t) (n > 0 ? n : 1);
+    SHQ_TRY(ctx->s_numngb.reserve(cap));
+    SHQ_TRY(ctx->s_dhsmldens.reserve(cap));
+    SHQ_TRY(ctx->s_left.reserve(cap));
+    SHQ_TRY(ctx->s_right.reserve(cap));
+    SHQ_TRY(ctx->s_rot.reserve(3 * cap));
+    SHQ_TRY(ctx->s_todo.reserve(cap));
+    SHQ_TRY(ctx->s_queue2.reserve(cap));
+    SHQ_TRY(ctx->s_blockcount.reserve(nblk(n) + 1));
+    SHQ_TRY(ctx->s_counters.reserve(4));
+    if(want_gradrho)
+        SHQ_TRY(ctx->s_gradrho.reserve(3 * cap));
+    SHQ_CHECK(p->DensityKernelType == 1 || p->DensityKernelType == 2 || p->DensityKernelType == 4, SHQ_ERR_INVALID,
+              "unknown DensityKernelType %d", p->DensityKernelType);
+    /* DensityOutput ctor, densitytree2.hpp:92-98 */
+    if(n > 0) {
+        SHQ_HIP(hipMemsetAsync(ctx->s_left.ptr, 0, sizeof(double) * n, ctx->stream));
+        SHQ_HIP(hipMemsetAsync(ctx->s_numngb.ptr, 0, sizeof(double) * n, ctx->stream));
+        fill_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(ctx->s_right.ptr, n, p->BoxSize);
+    }
+    SHQ_HIP(hipMemsetAsync(ctx->s_counters.ptr, 0, sizeof(long long) * 4, ctx->stream));
+    SphDev a = make_dev(ctx);
+    a.gradrho = want_gradrho ? ctx->s_gradrho.ptr : nullptr;
+    a.Box = p->BoxSize;
+    a.invBox = 1.0 / p->BoxSize;
+    PostArgs pa;
+    pa.Box = p->BoxSize;
+    pa.DesNumNgb = p->DesNumNgb;
+    pa.DesNumNgbBH = p->DesNumNgbBH;
+    pa.MinGasHsml = p->MinGasHsml;
+    pa.MaxDev = p->MaxNumNgbDeviation;
+    pa.update_hsml = p->update_hsml;
+    pa.BlackHoleOn = p->BlackHoleOn;
+    pa.DoEgyDensity = p->DoEgyDensity;
+    unsigned long long *nint = reinterpret_cast<unsigned long long *>(ctx->s_counters.ptr + 1);
+    long long *total = ctx->s_counters.ptr;
+    SHQ_TRY(ctx->s_queue3.reserve(cap));
+    int32_t *bufs[2] = {ctx->s_queue2.ptr, ctx->s_queue3.ptr};
+    int wsel = 0;
+    const int32_t *cur = d_queue;
+    long long size = nq;
+    int niter = 0;
+    SHQ_HIP(hipEventRecord(ctx->ev_begin[14], ctx->stream));
+    while(true) {
+        if(size > 0) {
+            switch(p->DensityKernelType) {
+            case 1: launch_density<1>(ctx, a, cur, size, p->WindsDecouple, nint); break;
+            case 2: launch_density<2>(ctx, a, cur, size, p->WindsDecouple, nint); break;
+            default: launch_density<4>(ctx, a, cur, size, p->WindsDecouple, nint); break;
+            }
+            sph_density_post_kernel<<<dim3(nblk(size)), dim3(256), 0, ctx->stream>>>(a, cur, size, pa, ctx->s_todo.ptr);
+            SHQ_HIP(hipGetLastError());
+        }
+        niter++;
+        if(!p->update_hsml || size == 0)
+            break;
+        const int nb = (int) nblk(size);
+        compact_count_kernel<<<dim3(nb), dim3(256), 0, ctx->stream>>>(ctx->s_todo.ptr, size, ctx->s_blockcount.ptr);
+        compact_scan_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(ctx->s_blockcount.ptr, nb, total);
+        compact_write_kernel<<<dim3(nb), dim3(256), 0, ctx->stream>>>(ctx->s_todo.ptr, size, ctx->s_blockcount.ptr, bufs[wsel]);
+        long long newsize = 0;
+        SHQ_HIP(hipMemcpyAsync(&newsize, total, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+        size = newsize;
+        if(size == 0)
+            break;
+        /* the neighbours' Hsml copy in leaf order is only read by hydro, so no refresh is needed here */
+        cur = bufs[wsel];
+        wsel ^= 1;
+        if(niter > SPH_MAXITER) {
+            shq_set_error("failed to converge density for %lld particles", size);
+            return SHQ_ERR_NOCONV;
+        }
+    }
+    SHQ_HIP(hipEventRecord(ctx->ev_end[14], ctx->stream));
+    if(stats) {
+        unsigned long long h_nint = 0;
+        SHQ_HIP(hipMemcpyAsync(&h_nint, nint, sizeof(h_nint), hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+        float ms = 0;
+        (void) hipEventElapsedTime(&ms, ctx->ev_begin[14], ctx->ev_end[14]);
+        stats->ntargets = nq;
+        stats->ninteractions = (int64_t) h_nint;
+        stats->niterations = niter;
+        stats->kernel_ms = ms;
+    }
+    return SHQ_OK;
+}
+
+int shq_sph_hydro_device(shq_context *ctx, const shq_hydro_params *p, const int32_t *d_queue, int64_t nq, shq_sph_stats *stats)
+{
+    const long long n = ctx->numpart;
+    const size_t cap = (size_t) (n > 0 ? n : 1);
+    SHQ_TRY(ctx->g_hydroaccel_out.reserve(3 * cap));
+    SHQ_TRY(ctx->g_dtentropy_out.reserve(cap));
+    SHQ_TRY(ctx->g_maxsignalvel.reserve(cap));
+    SHQ_TRY(ctx->s_counters.reserve(4));
+    SHQ_CHECK(p->DensityKernelType == 1 || p->DensityKernelType == 2 || p->DensityKernelType == 4, SHQ_ERR_INVALID,
+              "unknown DensityKernelType %d", p->DensityKernelType);
+    SHQ_HIP(hipMemsetAsync(ctx->s_counters.ptr, 0, sizeof(long long) * 4, ctx->stream));
+    SphDev a = make_dev(ctx);
+    a.Box = p->BoxSize;
+    a.invBox = 1.0 / p->BoxSize;
+    HydroConst hc;
+    hc.hubble_a2 = p->hubble_a2;
+    hc.fac_mu = p->fac_mu;
+    hc.fac_vsic_fix = p->fac_vsic_fix;
+    hc.ArtBulkViscConst = p->ArtBulkViscConst;
+    hc.contrast = p->DensityContrastLimit;
+    hc.DISPH = p->DensityIndependentSphOn;
+    unsigned long long *nint = reinterpret_cast<unsigned long long *>(ctx->s_counters.ptr + 1);
+    SHQ_HIP(hipEventRecord(ctx->ev_begin[14], ctx->stream));
+    if(nq > 0) {
+        switch(p->DensityKernelType) {
+        case 1: launch_hydro<1>(ctx, a, d_queue, nq, hc, nint); break;
+        case 2: launch_hydro<2>(ctx, a, d_queue, nq, hc, nint); break;
+        default: launch_hydro<4>(ctx, a, d_queue, nq, hc, nint); break;
+        }
+        sph_hydro_post_kernel<<<dim3(nblk(nq)), dim3(256), 0, ctx->stream>>>(a, d_queue, nq, ctx->g_density.ptr, ctx->g_delaytime.ptr,
+                                                                            p->hubble_a2, p->atime, p->WindSpeed, p->WindFreeTravelDensThresh);
+        SHQ_HIP(hipGetLastError());
+    }
+    SHQ_HIP(hipEventRecord(ctx->ev_end[14], ctx->stream));
+    if(stats) {
+        unsigned long long h_nint = 0;
+        SHQ_HIP(hipMemcpyAsync(&h_nint, nint, sizeof(h_nint), hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+        float ms = 0;
+        (void) hipEventElapsedTime(&ms, ctx->ev_begin[14], ctx->ev_end[14]);
+        stats->ntargets = nq;
+        stats->ninteractions = (int64_t) h_nint;
+        stats->niterations = 1;
+        stats->kernel_ms = ms;
+    }
+    return SHQ_OK;
+}
+
+int shq_sph_gradrho_mag(shq_context *ctx, double *d_out)
+{
+    const long long n = ctx->numpart;
+    if(n > 0)
+        gradmag_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(ctx->s_gradrho.ptr, d_out, n);
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}

@@ -258,5 +258,6 @@ shq_tree_view force_tree_view(const ForceTree *tree)
     v.rootnode = (int32_t) tree->firstnode;
     v.full_particle_tree_flag = tree->full_particle_tree_flag;
     v.BoxSize = tree->BoxSize;
+    v.father = tree->Father;
     return v;
 }

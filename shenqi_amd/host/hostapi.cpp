@@ -181,3 +181,64 @@ void shqh_morton_order(const double *pos, int64_t n, double L, int32_t *order)
 }
 
 } /* extern "C" */
+
+/* ---- SPH test/driver API ---------------------------------------------------------------------- */
+#include "density.hpp"
+extern "C" {
+
+void shqh_set_densitypar(double eta, double MaxNumNgbDeviation, int kernel, double BlackHoleNgbFactor, double MinGasHsml)
+{
+    struct density_params dp;
+    memset(&dp, 0, sizeof(dp));
+    dp.DensityResolutionEta = eta;
+    dp.MaxNumNgbDeviation = MaxNumNgbDeviation;
+    dp.DensityKernelType = (enum DensityKernelType) kernel;
+    dp.BlackHoleNgbFactor = BlackHoleNgbFactor;
+    dp.MinGasHsml = MinGasHsml;
+    set_densitypar(dp);
+}
+double shqh_GetNumNgb(void) { return GetNumNgb(GetDensityKernelType()); }
+void shqh_set_hydropar(int DensityIndependentSphOn, double DensityContrastLimit, double ArtBulkViscConst)
+{
+    struct hydro_params hp;
+    hp.DensityIndependentSphOn = DensityIndependentSphOn;
+    hp.DensityContrastLimit = DensityContrastLimit;
+    hp.ArtBulkViscConst = ArtBulkViscConst;
+    set_hydropar(hp);
+}
+int shqh_set_init_hsml(ForceTree *tree, double MeanGasSeparation, part_manager_type *pm) { return set_init_hsml(tree, MeanGasSeparation, pm); }
+void shqh_force_tree_update_hmax(ForceTree *tree, part_manager_type *pm) { force_tree_update_hmax(tree, pm); }
+
+/* evp_out: [nsph] receives *EntVarPred (copied; the malloc'ed array is freed here) */
+int shqh_density(shq_context *ctx, part_manager_type *pm, ForceTree *tree, sph_particle_data *sph, int64_t nsph,
+                 bh_density_slot *bh, int64_t nbh, const int *active, int64_t nactive, int update_hsml, int DoEgyDensity,
+                 int BlackHoleOn, const shq_kick_factors *kick, double *evp_out, double *GradRho_mag, int UseGPU,
+                 shq_sph_stats *stats)
+{
+    slots_manager_type S = {sph, nsph, bh, nbh};
+    ActiveParticles act;
+    memset(&act, 0, sizeof(act));
+    act.ActiveParticle = (int *) active;
+    act.NumActiveParticle = active ? nactive : pm->NumPart;
+    MyFloat *evp = nullptr;
+    int rc = density(ctx, &act, update_hsml, DoEgyDensity, BlackHoleOn, kick, &evp, GradRho_mag, tree, pm, &S, UseGPU != 0, stats);
+    if(rc == 0 && evp) {
+        if(evp_out)
+            memcpy(evp_out, evp, sizeof(double) * (size_t) nsph);
+        free(evp);
+    }
+    return rc;
+}
+
+int shqh_hydro_force(shq_context *ctx, part_manager_type *pm, ForceTree *tree, sph_particle_data *sph, int64_t nsph,
+                     const int *active, int64_t nactive, double atime, double hubble, double *EntVarPred,
+                     const shq_kick_factors *kick, const double *drifts, int UseGPU, shq_sph_stats *stats)
+{
+    slots_manager_type S = {sph, nsph, nullptr, 0};
+    ActiveParticles act;
+    memset(&act, 0, sizeof(act));
+    act.ActiveParticle = (int *) active;
+    act.NumActiveParticle = active ? nactive : pm->NumPart;
+    return hydro_force(ctx, &act, atime, hubble, EntVarPred, kick, drifts, tree, pm, &S, UseGPU != 0, stats);
+}
+}

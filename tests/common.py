@@ -71,3 +71,78 @@ def force_err(a, ref):
     nr = np.linalg.norm(ref, axis=1)
     ok = nr > 0
     return np.abs(na[ok] / nr[ok] - 1)
+
+
+# ---- SPH set-up (tests/test_density.cpp:28-132) ---------------------------------------------
+def density_params(BoxSize=BOX, kernel=1, eta=1.0, MaxNumNgbDeviation=0.5, BlackHoleNgbFactor=2.0, update_hsml=1,
+                   DoEgyDensity=0, BlackHoleOn=0, MinGasHsml=None):
+    """setup_density, tests/test_density.cpp:28-70: cubic kernel, eta 1, MinGasHsml = 0.006 * (FORCE_SOFTENING()/2.8)
+    with FractionalGravitySoftening = 1 and mean separation 1."""
+    from shenqi_amd import capi
+    support = {1: 4, 2: 6, 4: 5}[kernel]
+    des = 4.0 / 3 * np.pi * (support / 2.0 * eta) ** 3          # DensityKrnl::desnumngb, densitykernel.hpp:36-41
+    dp = capi.DensityParams()
+    dp.BoxSize = BoxSize
+    dp.DesNumNgb = des
+    dp.DesNumNgbBH = des * BlackHoleNgbFactor
+    dp.MinGasHsml = 0.006 * 1.0 if MinGasHsml is None else MinGasHsml
+    dp.MaxNumNgbDeviation = MaxNumNgbDeviation
+    dp.update_hsml, dp.BlackHoleOn, dp.DoEgyDensity, dp.WindsDecouple = update_hsml, BlackHoleOn, DoEgyDensity, 0
+    dp.DensityKernelType = kernel
+    return dp                                                    # kick factors all zero: DriftKickTimes kick = {0}
+
+
+def hydro_params(BoxSize=BOX, atime=0.1, hubble=HUBBLE, kernel=1, DensityIndependentSphOn=1, DensityContrastLimit=100.0,
+                 ArtBulkViscConst=0.75):
+    """HydroPriv ctor, hydratree2.hpp:83-119, with set_hydropar{1, 100, 0.75}."""
+    from shenqi_amd import capi
+    g = 5.0 / 3.0
+    hp = capi.HydroParams()
+    hp.BoxSize, hp.atime = BoxSize, atime
+    hp.fac_mu = atime ** (3 * (g - 1) / 2) / atime
+    hp.fac_vsic_fix = hubble * atime ** (3 * (g - 1))
+    hp.hubble_a2 = hubble * atime * atime
+    hp.ArtBulkViscConst, hp.DensityContrastLimit = ArtBulkViscConst, DensityContrastLimit
+    hp.DensityIndependentSphOn, hp.DensityKernelType = DensityIndependentSphOn, kernel
+    return hp
+
+
+def make_gas(pos, hsml, box=BOX, lastisbh=False):
+    """setup_density_particles, tests/test_density.cpp:98-132: Mass 1, Vel 1.5, Entropy 1, Density 1."""
+    n = len(pos)
+    pm = sq.PartManager(n, box)
+    P = pm.Base
+    P["Pos"] = pos
+    P["Mass"] = 1.0
+    P["Hsml"] = hsml
+    P["Vel"] = 1.5
+    P["ID"] = np.arange(1, n + 1)
+    ngas = n - (1 if lastisbh else 0)
+    P["Type"][:ngas] = 0
+    P["PI"][:ngas] = np.arange(ngas)
+    if lastisbh:
+        P["Type"][ngas:] = 5
+        P["PI"][ngas:] = 0
+    SphP = np.zeros(ngas, dtype=sq.SPH_DTYPE)
+    SphP["Entropy"] = 1
+    SphP["Density"] = 1
+    BhP = np.zeros(2, dtype=[("Density", "<f8"), ("DivVel", "<f8")])
+    return pm, SphP, BhP
+
+
+def density_close_positions(ncbrt=32, box=BOX, close=500.0):
+    """tests/test_density.cpp:240-262 test_density_close (last particle is a black hole)."""
+    numpart = ncbrt**3
+    pos = np.empty((numpart, 3))
+    hsml = np.empty(numpart)
+    i = np.arange(numpart // 4)
+    hsml[: numpart // 4] = 4 * box / np.cbrt(numpart / 8)
+    pos[: numpart // 4, 0] = (box / ncbrt) * (i / (ncbrt / 2.0) / (ncbrt / 2.0))
+    pos[: numpart // 4, 1] = (box / ncbrt) * ((i * 2 // ncbrt) % (ncbrt // 2))
+    pos[: numpart // 4, 2] = (box / ncbrt) * (i % (ncbrt // 2))
+    i = np.arange(numpart // 4, numpart)
+    hsml[numpart // 4:] = 2 * ncbrt / close
+    pos[numpart // 4:, 0] = 4.1 + (i // ncbrt // ncbrt) / close
+    pos[numpart // 4:, 1] = 4.1 + ((i // ncbrt) % ncbrt) / close
+    pos[numpart // 4:, 2] = 4.1 + (i % ncbrt) / close
+    return pos, hsml

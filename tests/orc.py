@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-from shenqi_amd.capi import GravParams, PMParams, NODE_DTYPE, ptr
+from shenqi_amd.capi import GravParams, PMParams, DensityParams, HydroParams, NODE_DTYPE, ptr
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _path = os.path.join(ROOT, "oracle", "liboracle.so")
@@ -29,6 +29,70 @@ lib.orc_fft_c2r.argtypes = [C.c_int, _vp, _vp]
 lib.orc_fft_c2r.restype = None
 lib.orc_density_kernel.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, _vp]
 lib.orc_num_threads.restype = C.c_int
+
+
+class OrcSphArrays(C.Structure):
+    _fields_ = [("n", C.c_int64), ("nsph", C.c_int64)] + [(k, _vp) for k in (
+        "pos", "mass", "type", "flags", "pi", "hsml", "dthsml", "vel", "treeacc", "gravpm", "bin_grav", "bin_hydro",
+        "density", "egywtdensity", "entropy", "dtentropy", "maxsignalvel", "hydroaccel", "dhsmlegydensityfactor",
+        "divvel", "curlvel", "delaytime", "bh_density", "bh_divvel")]
+
+
+lib.orc_set_init_hsml.argtypes = [_vp, C.c_int64, _vp, C.POINTER(OrcSphArrays), C.c_double, C.c_double]
+lib.orc_set_init_hsml.restype = None
+lib.orc_density.argtypes = [_vp, C.c_int64, _vp, C.POINTER(OrcSphArrays), _vp, C.c_int64, C.POINTER(DensityParams), _vp, _vp,
+                            C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+lib.orc_update_hmax.argtypes = [_vp, C.c_int64, C.c_int64, C.POINTER(OrcSphArrays)]
+lib.orc_update_hmax.restype = None
+lib.orc_hydro.argtypes = [_vp, C.c_int64, C.POINTER(OrcSphArrays), _vp, C.c_int64, C.POINTER(HydroParams), _vp, C.POINTER(C.c_int64)]
+lib.orc_hydro.restype = None
+
+
+class SphState:
+    """SoA copy of the particle / slot state the oracle's SPH functions work on."""
+
+    def __init__(self, P, SphP, BhP=None):
+        n, ns = len(P), len(SphP)
+        f8 = lambda x: np.ascontiguousarray(x, dtype=np.float64)  # noqa: E731
+        self.pos, self.mass = f8(P["Pos"]), np.ascontiguousarray(P["Mass"], dtype=np.float32)
+        self.type = np.ascontiguousarray(P["Type"], dtype=np.uint8)
+        self.flags = np.ascontiguousarray(P["Flags"] & 3, dtype=np.uint8)
+        self.pi = np.ascontiguousarray(P["PI"], dtype=np.int32)
+        self.hsml, self.dthsml = f8(P["Hsml"]), f8(P["DtHsml"])
+        self.vel, self.treeacc, self.gravpm = f8(P["Vel"]), f8(P["FullTreeGravAccel"]), f8(P["GravPM"])
+        self.bin_grav = np.ascontiguousarray(P["TimeBinGravity"], dtype=np.uint8)
+        self.bin_hydro = np.ascontiguousarray(P["TimeBinHydro"], dtype=np.uint8)
+        for k, name in (("density", "Density"), ("egywtdensity", "EgyWtDensity"), ("entropy", "Entropy"),
+                        ("dtentropy", "DtEntropy"), ("maxsignalvel", "MaxSignalVel"), ("hydroaccel", "HydroAccel"),
+                        ("dhsmlegydensityfactor", "DhsmlEgyDensityFactor"), ("divvel", "DivVel"), ("curlvel", "CurlVel"),
+                        ("delaytime", "DelayTime")):
+            setattr(self, k, f8(SphP[name]))
+        nb = 0 if BhP is None else len(BhP)
+        self.bh_density, self.bh_divvel = np.zeros(max(nb, 1)), np.zeros(max(nb, 1))
+        self.c = OrcSphArrays(n, ns, *[ptr(getattr(self, k)) for k, _ in OrcSphArrays._fields_[2:]])
+
+
+def set_init_hsml(nodes, firstnode, father, st, MeanGasSeparation, DesNumNgb):
+    lib.orc_set_init_hsml(ptr(nodes), firstnode, ptr(father), C.byref(st.c), MeanGasSeparation, DesNumNgb)
+
+
+def density(nodes, firstnode, father, st, dp, active=None, want_entvarpred=True, want_gradrho=False):
+    evp = np.zeros(max(st.c.nsph, 1)) if want_entvarpred else None
+    gr = np.zeros((max(st.c.nsph, 1), 3)) if want_gradrho else None
+    niter, nint = C.c_int(0), C.c_int64(0)
+    rc = lib.orc_density(ptr(nodes), firstnode, ptr(father), C.byref(st.c), ptr(active), 0 if active is None else len(active),
+                         C.byref(dp), ptr(evp), ptr(gr), C.byref(niter), C.byref(nint))
+    return rc, evp, gr, niter.value, nint.value
+
+
+def update_hmax(nodes, firstnode, st):
+    lib.orc_update_hmax(ptr(nodes), firstnode, len(nodes), C.byref(st.c))
+
+
+def hydro(nodes, firstnode, st, hp, evp, active=None):
+    nint = C.c_int64(0)
+    lib.orc_hydro(ptr(nodes), firstnode, C.byref(st.c), ptr(active), 0 if active is None else len(active), C.byref(hp), ptr(evp), C.byref(nint))
+    return nint.value
 
 
 def tree_build(pos, mass, BoxSize, hsml=None, idx=None, numpart_total=None):

@@ -1,0 +1,162 @@
+"""GPU parity tests of SPH density (incl. the Hsml loop) and hydro force through the C-ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import shenqi_amd as sq
+from shenqi_amd import capi
+import orc
+import common as cm
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(pos, hsml, lastisbh=False, kernel=1):
+    pman, SphP, BhP = cm.make_gas(pos, hsml, lastisbh=lastisbh)
+    BhP = np.zeros(2, dtype=sq.BH_SLOT_DTYPE)
+    sq.set_densitypar(DensityResolutionEta=1.0, MaxNumNgbDeviation=0.5, DensityKernelType=kernel, BlackHoleNgbFactor=2.0,
+                      MinGasHsml=0.006)
+    return pman, SphP, BhP
+
+
+def _do_density_test(ctx, pos, hsml, expected, err, lastisbh=False):
+    """do_density_test, tests/test_density.cpp:134-206, through the host mirror of the reference API."""
+    pman, SphP, BhP = _setup(pos, hsml, lastisbh)
+    P = pman.Base
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK + sq.BHMASK)
+    sq.set_init_hsml(tree, pman.BoxSize, pman)
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+    evp, st = sq.density(ctx, None, 1, 0, 0, None, tree, pman, SphP, BhP)
+    # check_densities, tests/test_density.cpp:73-90
+    assert np.all(np.isfinite(P["Hsml"])) and np.all(np.isfinite(SphP["Density"])) and np.all(SphP["Density"] > 0)
+    assert P["Hsml"].min() >= 0.006 and P["Hsml"].max() <= pman.BoxSize
+    assert abs(P["Hsml"].mean() - expected) < err, P["Hsml"].mean()
+    h0 = P["Hsml"].copy()
+    evp, st2 = sq.density(ctx, None, 1, 0, 0, None, tree, pman, SphP, BhP)
+    assert np.all(np.abs(h0 / P["Hsml"] - 1) < 0.5 / sq.GetNumNgb())          # :203
+    return pman, SphP, tree, st
+
+
+def test_reference_gate_density_flat_gpu(ctx):
+    pos = cm.grid_positions(32)
+    pman, SphP, tree, st = _do_density_test(ctx, pos, np.full(len(pos), 1.5 * cm.BOX / 32), 0.5, 5e-4)
+    assert abs(pman.Base["Hsml"].mean() - 0.500387) < 2e-6        # the reference run
+    assert abs(SphP["Density"].mean() - 64.002) < 2e-3
+    print("density flat: %d iterations, %.1f candidates/target, %.2f ms" % (st.niterations, st.ninteractions / st.ntargets, st.kernel_ms))
+
+
+def test_reference_gate_density_close_gpu(ctx):
+    pos, hsml = cm.density_close_positions()
+    _do_density_test(ctx, pos, hsml, 0.131726, 1e-4, lastisbh=True)
+
+
+def test_reference_gate_density_random_gpu(ctx):
+    n = 32**3
+    pos = cm.random_positions(orc.boost_mt19937_uniform(0, 3 * n), n)
+    _do_density_test(ctx, pos, np.full(n, cm.BOX / 32), 0.187515, 1e-3)
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 4])
+@pytest.mark.parametrize("DoEgy", [0, 1])
+def test_density_parity_fixed_hsml(ctx, kernel, DoEgy):
+    """L1 ladder: identical Hsml in => identical candidate counts (integers) and all density outputs to
+    rounding, for all three kernels, against the oracle."""
+    n = 16**3
+    pos = cm.random_positions(orc.boost_mt19937_uniform(3, 3 * n), n)
+    rng = np.random.default_rng(kernel)
+    hsml = cm.BOX / 16 * rng.uniform(1.0, 2.5, size=n)
+    pman, SphP, BhP = _setup(pos, hsml, kernel=kernel)
+    P = pman.Base
+    P["Vel"] = rng.normal(size=(n, 3))
+    SphP["Entropy"] = rng.uniform(0.5, 2.0, size=n)
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+    dp = cm.density_params(kernel=kernel, update_hsml=0, DoEgyDensity=DoEgy)
+    st = orc.SphState(P, SphP, BhP)
+    rc, oevp, ogr, _, onint = orc.density(tree.Nodes_base.copy(), tree.firstnode, None, st, dp, want_gradrho=True)
+    assert rc == 0
+    gmag = np.zeros(n)
+    evp, gs = sq.density(ctx, None, 0, DoEgy, 0, None, tree, pman, SphP, BhP, GradRho_mag=gmag)
+    assert gs.ninteractions == onint
+    for name, ref in (("Density", st.density), ("EgyWtDensity", st.egywtdensity), ("DhsmlEgyDensityFactor", st.dhsmlegydensityfactor),
+                      ("DivVel", st.divvel), ("CurlVel", st.curlvel)):
+        scale = np.abs(ref).max()
+        assert np.abs(SphP[name] - ref).max() < 1e-10 * scale, name
+    assert np.abs(P["DtHsml"] - st.dthsml).max() < 1e-10 * np.abs(st.dthsml).max()
+    assert np.abs(evp - oevp).max() < 1e-13
+    assert np.abs(gmag - np.linalg.norm(ogr, axis=1)).max() < 1e-10 * np.linalg.norm(ogr, axis=1).max()
+    assert np.array_equal(P["Hsml"], hsml)       # update_hsml = 0 leaves Hsml alone
+
+
+def test_density_hsml_loop_parity(ctx):
+    """Whole Hsml iteration vs the oracle: same iteration count, Hsml equal to rounding, hmax of the leaves
+    raised as update_tree_hmax_father does; active subset leaves the others untouched."""
+    n = 16**3
+    pos = cm.random_positions(orc.boost_mt19937_uniform(9, 3 * n), n)
+    pman, SphP, BhP = _setup(pos, np.full(n, cm.BOX / 16))
+    P = pman.Base
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+    sq.set_init_hsml(tree, pman.BoxSize, pman)
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+    act = np.arange(0, n, 3, dtype=np.int32)
+    dp = cm.density_params(DoEgyDensity=1)
+    st = orc.SphState(P, SphP, BhP)
+    onodes = tree.Nodes_base.copy()
+    fp = capi.host.shqh_tree_father(tree._h)
+    father = np.frombuffer((C.c_char * (4 * n)).from_address(fp), dtype=np.int32).copy()
+    rc, oevp, _, oniter, _ = orc.density(onodes, tree.firstnode, father, st, dp, active=act)
+    h_before = P["Hsml"].copy()
+    evp, gs = sq.density(ctx, act, 1, 1, 0, None, tree, pman, SphP, BhP)
+    assert gs.niterations == oniter
+    assert np.abs(P["Hsml"][act] - st.hsml[act]).max() < 1e-12
+    mask = np.ones(n, dtype=bool)
+    mask[act] = False
+    assert np.array_equal(P["Hsml"][mask], h_before[mask])
+    assert np.abs(SphP["Density"][act] - st.density[act]).max() < 1e-10 * st.density.max()
+    assert np.abs(tree.Nodes_base["hmax"] - onodes["hmax"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("kernel,disph", [(1, 1), (2, 1), (4, 0)])
+def test_hydro_parity(ctx, kernel, disph):
+    """hydro_force vs the oracle (runtests.cpp:507-539 bar: max < 1e-5 on |a| and MaxSignalVel; here rounding level)."""
+    n = 16**3
+    pos = cm.random_positions(orc.boost_mt19937_uniform(21, 3 * n), n)
+    rng = np.random.default_rng(4)
+    pman, SphP, BhP = _setup(pos, np.full(n, cm.BOX / 16), kernel=kernel)
+    P = pman.Base
+    P["Vel"] = rng.normal(size=(n, 3)) * 3.0
+    SphP["Entropy"] = rng.uniform(0.5, 2.0, size=n)
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+    sq.set_init_hsml(tree, pman.BoxSize, pman)
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+    evp, _ = sq.density(ctx, None, 1, disph, 0, None, tree, pman, SphP, BhP)
+    sq.force_tree_update_hmax(tree, pman)            # force_tree_calc_moments between density and hydro (run.cpp:493)
+    sq.set_hydropar(DensityIndependentSphOn=disph, DensityContrastLimit=100.0, ArtBulkViscConst=0.75)
+    st = orc.SphState(P, SphP, BhP)
+    hp = cm.hydro_params(kernel=kernel, DensityIndependentSphOn=disph)
+    kf = sq.KickFactors()
+    for b in range(47):
+        kf.dloga_for_bin[b] = 0.01           # exercises the viscosity limiter branch
+        hp.kf.dloga_for_bin[b] = 0.01
+    onint = orc.hydro(tree.Nodes_base, tree.firstnode, st, hp, evp)
+    gs = sq.hydro_force(ctx, None, 0.1, cm.HUBBLE, evp, kf, tree, pman, SphP)
+    assert gs.ninteractions == onint
+    a, oa = SphP["HydroAccel"], st.hydroaccel
+    assert np.abs(a - oa).max() < 1e-10 * np.abs(oa).max()
+    assert cm.force_err(a, oa).max() < 1e-5
+    assert np.abs(SphP["DtEntropy"] - st.dtentropy).max() < 1e-10 * np.abs(st.dtentropy).max()
+    assert np.abs(SphP["MaxSignalVel"] / st.maxsignalvel - 1).max() < 1e-12
+    assert np.abs((P["Mass"][:, None] * a).sum(axis=0)).max() < 1e-9 * np.abs(a).sum()      # pair antisymmetry
+
+
+def test_sph_error_behaviour(ctx):
+    pos = cm.grid_positions(8)
+    pman, SphP, BhP = _setup(pos, np.full(len(pos), 1.5))
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+    with pytest.raises(sq.ShqError):
+        sq.density(ctx, None, 1, 0, 0, None, tree, pman, SphP, BhP, UseGPU=False)
+    with pytest.raises(sq.ShqError):
+        sq.hydro_force(ctx, None, 0.1, cm.HUBBLE, None, None, tree, pman, SphP, UseGPU=False)
+    dm_tree = sq.force_tree_rebuild_mask(pman, sq.DMMASK)
+    with pytest.raises(sq.ShqError):            # tree without gas
+        sq.density(ctx, None, 1, 0, 0, None, dm_tree, pman, SphP, BhP)
