@@ -110,6 +110,8 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
         ctx->walk_variant = atoi(v);
     if(const char *v = getenv("SHQ_WALK_STATS"))
         ctx->walk_stats = atoi(v);
+    if(const char *v = getenv("SHQ_XCD_K"))
+        ctx->xcd_k = atoi(v);
     *out = ctx;
     return SHQ_OK;
 }

@@ -49,6 +49,7 @@ struct WalkArgs {
     double inv_celldx;         /* 1 / (cellsize * dx) */
     double errtol, bh2;
     int useBH;
+    unsigned xcdK;
     const float *tab_f;
     const float *tab_p;
 };
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const long long wave = (long long) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long wave = (long long) xcd_block(blockIdx.x, gridDim.x, a.xcdK) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long t = wave * 64 + lane;
     const bool valid = t < a.ntargets;
     long long pi = 0;
@@ -402,6 +403,7 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     a.errtol = p->ErrTolForceAcc;
     a.bh2 = p->BHOpeningAngle2;
     a.useBH = p->TreeUseBH;
+    a.xcdK = (unsigned) ctx->xcd_k;
     a.tab_f = ctx->gravtab.ptr;
     a.tab_p = ctx->gravtab.ptr + SHQ_NGRAVTAB;
 

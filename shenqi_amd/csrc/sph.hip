@@ -245,7 +245,7 @@ template <int KT> __global__ __launch_bounds__(256) void sph_density_kernel(cons
                                                                            int WindsDecouple, unsigned long long *nint_total)
 {
     const int lane = threadIdx.x & 63;
-    const long long wave = (long long) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long wave = (long long) xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long t = wave * 64 + lane;
     const bool valid = t < nq;
     long long pi = 0;
@@ -535,7 +535,7 @@ template <int KT> __global__ __launch_bounds__(256) void sph_hydro_kernel(const 
                                                                          const HydroConst hc, unsigned long long *nint_total)
 {
     const int lane = threadIdx.x & 63;
-    const long long wave = (long long) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long wave = (long long) xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long t = wave * 64 + lane;
     const bool valid = t < nq;
     long long pi = 0;

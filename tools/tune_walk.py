@@ -36,10 +36,11 @@ pmp = sq.PMParams(nmesh, 0, L, 1.5, G)
 pv, tv = pman.view(), tree.view()
 
 ctxs = {}
-for st in (1, 0):
+ks = [int(k) for k in os.environ.get("TUNE_XCD_K", "16").split(",")]
+for st in ks:
     for v in variants:
         os.environ["SHQ_WALK_VARIANT"] = str(v)
-        os.environ["SHQ_WALK_STATS"] = str(st)
+        os.environ["SHQ_XCD_K"] = str(st)
         c = sq.Context(0)
         capi.check(capi.hip.shq_particles_upload(c.h, C.byref(pv)))
         capi.check(capi.hip.shq_tree_upload(c.h, C.byref(tv)))
@@ -56,4 +57,4 @@ for rnd in range(3):
         capi.check(capi.hip.shq_grav_short_download(c.h, None, None, None, C.byref(s)))
         res[k].append(s.kernel_ms)
 for k in sorted(res):
-    print("variant %d stats %d: walk ms min %.2f med %.2f" % (k[0], k[1], min(res[k]), sorted(res[k])[1]), flush=True)
+    print("variant %d xcdK %d: walk ms min %.2f med %.2f" % (k[0], k[1], min(res[k]), sorted(res[k])[1]), flush=True)
