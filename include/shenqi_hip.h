@@ -315,6 +315,31 @@ int shq_pm_phase_ms(shq_context *ctx, double ms[6]);
 int shq_pm_set_debug(shq_context *ctx, int keep_meshes);
 int shq_pm_download_mesh(shq_context *ctx, int which /*0 density,1 potential*/, double *mesh);
 
+/* ---- slab-sharded PM for multi-GPU runs (one rank per GPU, x-slabs of the mesh) ------------------
+ * The mesh is split into slabs of x-planes exactly as petapm splits its real-space pencils over
+ * np0 (petapm.cpp:243-257, here np1 = 1).  These are the LOCAL phases on device buffers the
+ * caller owns (e.g. torch tensors used for the RCCL exchanges); the exchanges themselves - ghost
+ * planes to the neighbours, the all-to-all transposes of the 2-D/1-D FFT stages - are done by the
+ * caller with torch.distributed.  See shenqi_amd/dist.py.
+ *   deposit : d_mesh_i64 is int64 [nplanes + 1][Nmesh][Nmesh + 2] (last plane = ghost of the right
+ *             neighbour; [Nmesh] planes and no ghost when nplanes == Nmesh); zeroed then filled with
+ *             the fixed-point CIC deposit of the uploaded particles, all of which must lie in the slab.
+ *   green   : potential_transfer on a y-slab of the transposed half spectrum, complex128
+ *             [nyl][Nmesh/2 + 1][Nmesh] (x fastest; the reference's Fourier layout, petapm.cpp:258-282).
+ *   readout : d_phi_ext is f64 [nplanes + 5][Nmesh][Nmesh + 2], planes plane0-2 .. plane0+nplanes+2
+ *             of the potential (periodic); fills the device-resident GravPM / PM potential. */
+/* Particle set already in HBM: d_posm = double[n][4] rows (x, y, z, m); the first nlocal rows are this
+ * rank's own particles (PM deposit/readout and the default walk targets), the rest imported ghosts
+ * that only act as sources in the tree.  Previous-step accelerations are kept when n is unchanged. */
+int shq_particles_set_device(shq_context *ctx, const void *d_posm, int64_t n, int64_t nlocal);
+int shq_pm_slab_deposit(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, void *d_mesh_i64);
+int shq_pm_slab_green(shq_context *ctx, const shq_pm_params *pm, int y0, int nyl, void *d_spec);
+int shq_pm_slab_readout(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, const void *d_phi_ext);
+/* Fixed-point deposit scale 2^e: chosen per context from the local mass sum at particle upload;
+ * ranks of one job must agree on it (set it from the global mass sum) so meshes add exactly. */
+int shq_pm_get_deposit_log2scale(shq_context *ctx);
+int shq_pm_set_deposit_log2scale(shq_context *ctx, int e);
+
 /* Drop-ins for petapm_fft_r2c / petapm_fft_c2r (libgadget/petapm.cpp:49-71): unscaled
  * single-rank 3-D transforms of an Nmesh^3 real array ([x][y][z], z fastest) to/from its
  * half-spectrum ([x][y][z'], z' <= Nmesh/2). Host pointers. */

@@ -279,3 +279,11 @@ host.shqh_density.argtypes = [_vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp
                               C.POINTER(KickFactors), _vp, _vp, C.c_int, C.POINTER(SphStats)]
 host.shqh_hydro_force.argtypes = [_vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_double, C.c_double, _vp,
                                   C.POINTER(KickFactors), _vp, C.c_int, C.POINTER(SphStats)]
+
+# ---- multi-GPU slab entry points -------------------------------------------------------------
+hip.shq_particles_set_device.argtypes = [_vp, _vp, C.c_int64, C.c_int64]
+hip.shq_pm_slab_deposit.argtypes = [_vp, C.POINTER(PMParams), C.c_int, C.c_int, _vp]
+hip.shq_pm_slab_green.argtypes = [_vp, C.POINTER(PMParams), C.c_int, C.c_int, _vp]
+hip.shq_pm_slab_readout.argtypes = [_vp, C.POINTER(PMParams), C.c_int, C.c_int, _vp]
+hip.shq_pm_get_deposit_log2scale.argtypes = [_vp]
+hip.shq_pm_set_deposit_log2scale.argtypes = [_vp, C.c_int]

@@ -139,7 +139,7 @@ extern "C" void shq_shutdown(shq_context *ctx)
     ctx->hydD_leaf.release(); ctx->hsml_leaf.release(); ctx->flag_leaf.release();
     ctx->s_numngb.release(); ctx->s_dhsmldens.release(); ctx->s_left.release(); ctx->s_right.release(); ctx->s_rot.release();
     ctx->s_gradrho.release(); ctx->s_evp_in.release(); ctx->s_todo.release(); ctx->s_queue2.release(); ctx->s_queue3.release();
-    ctx->s_blockcount.release(); ctx->s_counters.release();
+    ctx->s_blockcount.release(); ctx->s_counters.release(); ctx->pm_oob.release();
     for(int i = 0; i < SHQ_NTIMERS; i++) {
         (void) hipEventDestroy(ctx->ev_begin[i]);
         (void) hipEventDestroy(ctx->ev_end[i]);
@@ -254,6 +254,7 @@ extern "C" int shq_particles_upload(shq_context *ctx, const shq_part_view *parts
     }
     SHQ_HIP(hipStreamSynchronize(ctx->stream)); /* host vectors die here */
     ctx->numpart = n;
+    ctx->nlocal = 0;
     ctx->have_parts = true;
     ctx->have_tree = false; /* leaf copy refers to the old particles */
     ctx->have_pm_result = false;
@@ -401,6 +402,53 @@ extern "C" int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree)
     return SHQ_OK;
 }
 
+__global__ void fill_u8_kernel(uint8_t *x, long long n, uint8_t v)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+        x[i] = v;
+}
+
+/* Device-side particle set for multi-GPU runs: rows (x, y, z, m) already in HBM (e.g. a torch
+ * tensor holding local + imported ghost particles); the first nlocal rows are this rank's own. */
+extern "C" int shq_particles_set_device(shq_context *ctx, const void *d_posm, int64_t n, int64_t nlocal)
+{
+    SHQ_CHECK(ctx && (d_posm || n == 0), SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(n >= 0 && n < (1ll << 31) && nlocal >= 0 && nlocal <= n, SHQ_ERR_INVALID, "bad particle counts");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const size_t cap = (size_t) std::max<int64_t>(n, 1);
+    SHQ_TRY(ctx->posm.reserve(cap));
+    SHQ_TRY(ctx->oldacc.reserve(cap));
+    SHQ_TRY(ctx->treeacc.reserve(3 * cap));
+    SHQ_TRY(ctx->gravpm.reserve(3 * cap));
+    SHQ_TRY(ctx->pmpot.reserve(cap));
+    SHQ_TRY(ctx->acc.reserve(3 * cap));
+    SHQ_TRY(ctx->pot.reserve(cap));
+    SHQ_TRY(ctx->nint.reserve(cap));
+    SHQ_TRY(ctx->pflags.reserve(cap));
+    if(n > 0) {
+        SHQ_HIP(hipMemcpyAsync(ctx->posm.ptr, d_posm, sizeof(double4) * n, hipMemcpyDeviceToDevice, ctx->stream));
+        if(ctx->numpart != n) { /* a new particle set: previous-step accelerations no longer apply */
+            SHQ_HIP(hipMemsetAsync(ctx->treeacc.ptr, 0, sizeof(double) * 3 * n, ctx->stream));
+            SHQ_HIP(hipMemsetAsync(ctx->gravpm.ptr, 0, sizeof(double) * 3 * n, ctx->stream));
+            SHQ_HIP(hipMemsetAsync(ctx->oldacc.ptr, 0, sizeof(double) * n, ctx->stream));
+            SHQ_HIP(hipMemsetAsync(ctx->pmpot.ptr, 0, sizeof(double) * n, ctx->stream));
+            SHQ_HIP(hipMemsetAsync(ctx->acc.ptr, 0, sizeof(double) * 3 * n, ctx->stream));
+            SHQ_HIP(hipMemsetAsync(ctx->pot.ptr, 0, sizeof(double) * n, ctx->stream));
+            SHQ_HIP(hipMemsetAsync(ctx->nint.ptr, 0, sizeof(int32_t) * n, ctx->stream));
+        }
+        fill_u8_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->pflags.ptr, n, (uint8_t) (1 << 4));
+        SHQ_HIP(hipGetLastError());
+    }
+    if(ctx->numpart != n)
+        ctx->have_tree = false;
+    ctx->numpart = n;
+    ctx->nlocal = nlocal;
+    ctx->have_parts = true;
+    ctx->have_pm_result = false;
+    return SHQ_OK;
+}
+
 /* ---- gravity ---------------------------------------------------------------------------- */
 
 extern "C" int shq_grav_short_run(shq_context *ctx, const shq_grav_params *params, const int32_t *active,
@@ -410,7 +458,7 @@ extern "C" int shq_grav_short_run(shq_context *ctx, const shq_grav_params *param
     SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "grav_short_run: upload particles and tree first");
     SHQ_HIP(hipSetDevice(ctx->device));
     const int32_t *d_active = nullptr;
-    int64_t nt = active ? nactive : ctx->numpart;
+    int64_t nt = active ? nactive : (ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart);
     SHQ_TRY(upload_active(ctx, active, nt, &d_active));
     SHQ_TRY(shq_launch_grav_walk(ctx, params, d_active, nt, update_potential, walk_mode));
     SHQ_TRY(shq_launch_grav_postprocess(ctx, params, d_active, nt, update_potential));

@@ -142,6 +142,7 @@ struct shq_context {
 
     /* ---- particle store, by particle index (sorted SoA, Peano order as the host keeps it) */
     int64_t numpart = 0;
+    int64_t nlocal = 0;        /* >0: only the first nlocal particles are this rank's own (the rest are ghosts) */
     DevBuf<double4> posm;      /* x,y,z,mass */
     DevBuf<double> oldacc;     /* |FullTreeGravAccel + GravPM| / G */
     DevBuf<double> treeacc;    /* [N][3] FullTreeGravAccel */
@@ -192,6 +193,8 @@ struct shq_context {
     bool have_plans = false;
     DevBuf<double> mesh;       /* padded in-place real/complex mesh: N*N*(N+2) doubles */
     DevBuf<double> sinctab;    /* 1/sinc^2 per mesh index */
+    int sinctab_n = 0;
+    DevBuf<int> pm_oob;        /* out-of-slab flag written by the deposit/readout kernels */
     DevBuf<double> dbg_rho, dbg_pot;
     int pm_keep = 0;
     int pm_log2scale = 30;     /* fixed-point deposit scale 2^e, set at particle upload */

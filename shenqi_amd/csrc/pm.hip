@@ -24,6 +24,13 @@
 namespace {
 
 __device__ __forceinline__ int wrapi(int i, int N) { return i >= N ? i - N : (i < 0 ? i + N : i); }
+/* x-plane index into the (possibly slab-local) mesh: global plane gx -> (gx - xshift) mod N.
+ * xshift = 0 for the full periodic mesh; for a slab it is the global index of local plane 0. */
+__device__ __forceinline__ int xloc(int gx, int xshift, int N)
+{
+    int v = (gx - xshift) % N;
+    return v < 0 ? v + N : v;
+}
 
 /* CIC cell + residual: petapm.cpp:1147-1160 */
 __device__ __forceinline__ void cic_setup(double p, double cell, int N, int &ic, double &res)
@@ -61,7 +68,7 @@ __global__ void pm_zero_kernel(unsigned long long *mesh, size_t n)
 
 __global__ __launch_bounds__(256) void pm_deposit_kernel(const double4 *__restrict__ posm, const uint8_t *__restrict__ pflags,
                                                          long long n, unsigned long long *mesh, int N, double cell,
-                                                         double scale)
+                                                         double scale, int xshift, int nxalloc, int *oob)
 {
     __shared__ unsigned long long tile[DEP_T * DEP_T * DEP_T];
     __shared__ int s_min[3], s_max[3];
@@ -139,7 +146,12 @@ __global__ __launch_bounds__(256) void pm_deposit_kernel(const double4 *__restri
             const unsigned long long v = tile[c];
             if(v != 0ull) {
                 const int tz = c % DEP_T, ty = (c / DEP_T) % DEP_T, tx = c / (DEP_T * DEP_T);
-                const size_t lin = (size_t) wrapi(m0 + tx, N) * sx + (size_t) wrapi(m1 + ty, N) * sy + (size_t) wrapi(m2 + tz, N);
+                const int lx = xloc(m0 + tx, xshift, N);
+                if(lx >= nxalloc) {
+                    *oob = 1; /* a particle outside this rank's slab: refuse to write out of bounds */
+                    continue;
+                }
+                const size_t lin = (size_t) lx * sx + (size_t) wrapi(m1 + ty, N) * sy + (size_t) wrapi(m2 + tz, N);
                 atomicAdd(&mesh[lin], v);
             }
         }
@@ -152,15 +164,21 @@ __global__ __launch_bounds__(256) void pm_deposit_kernel(const double4 *__restri
             for(int c = 0; c < 8; c++) {
                 double w = 1.0;
                 size_t lin = 0;
+                bool inb = true;
 #pragma unroll
                 for(int k = 0; k < 3; k++) {
                     const int off = (c >> k) & 1;
-                    const int t = wrapi(ic[j][k] + off, N);
+                    const int t = (k == 0) ? xloc(ic[j][k] + off, xshift, N) : wrapi(ic[j][k] + off, N);
+                    if(k == 0 && t >= nxalloc)
+                        inb = false;
                     lin += (size_t) t * (k == 0 ? sx : (k == 1 ? sy : 1));
                     w *= off ? res[j][k] : (1 - res[j][k]);
                 }
                 const long long q = __double2ll_rn(w * mass[j] * scale);
-                atomicAdd(&mesh[lin], (unsigned long long) q);
+                if(inb)
+                    atomicAdd(&mesh[lin], (unsigned long long) q);
+                else
+                    *oob = 1;
             }
         }
     }
@@ -212,7 +230,8 @@ __global__ __launch_bounds__(256) void pm_green_kernel(double2 *cmesh, int N, in
  * 4-point differencing of the potential mesh (see file header). */
 __global__ __launch_bounds__(256) void pm_readout_kernel(const double4 *__restrict__ posm, const uint8_t *__restrict__ pflags,
                                                          long long n, const double *__restrict__ mesh, int N,
-                                                         double cell, double ffac, double *gravpm, double *pmpot)
+                                                         double cell, double ffac, double *gravpm, double *pmpot, int xshift,
+                                                         int nxalloc, int *oob)
 {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= n)
@@ -230,7 +249,10 @@ __global__ __launch_bounds__(256) void pm_readout_kernel(const double4 *__restri
         size_t ox[6], oy[6], oz[6];
 #pragma unroll
         for(int d = 0; d < 6; d++) {
-            ox[d] = (size_t) wrapi(ic[0] + d - 2, N) * sx;
+            const int lx = xloc(ic[0] + d - 2, xshift, N);
+            if(lx >= nxalloc && oob)
+                *oob = 1;
+            ox[d] = (size_t) (lx < nxalloc ? lx : 0) * sx;
             oy[d] = (size_t) wrapi(ic[1] + d - 2, N) * sy;
             oz[d] = (size_t) wrapi(ic[2] + d - 2, N);
         }
@@ -301,6 +323,8 @@ static int pm_prepare(shq_context *ctx, int N)
     const size_t padded = (size_t) N * N * (N + 2);
     SHQ_TRY(ctx->mesh.reserve(padded));
     SHQ_TRY(ctx->sinctab.reserve(N));
+    SHQ_TRY(ctx->pm_oob.reserve(1));
+    SHQ_HIP(hipMemset(ctx->pm_oob.ptr, 0, sizeof(int)));
     /* 1/sinc^2(pi k/N) per mesh index: gravpm.cpp:294-302, :398-402 */
     std::vector<double> tab(N);
     for(int i = 0; i < N; i++) {
@@ -315,6 +339,7 @@ static int pm_prepare(shq_context *ctx, int N)
         tab[i] = 1. / (s * s);
     }
     SHQ_HIP(hipMemcpy(ctx->sinctab.ptr, tab.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    ctx->sinctab_n = N;
     hipfftResult r = hipfftPlan3d(&ctx->plan_r2c, N, N, N, HIPFFT_D2Z);
     SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftPlan3d(D2Z, %d) failed: %d", N, (int) r);
     r = hipfftPlan3d(&ctx->plan_c2r, N, N, N, HIPFFT_Z2D);
@@ -345,7 +370,7 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
     pm_zero_kernel<<<dim3(2048), dim3(threads), 0, ctx->stream>>>((unsigned long long *) ctx->mesh.ptr, padded);
     if(n > 0)
         pm_deposit_kernel<<<dim3((unsigned) ((n + DEP_CHUNK - 1) / DEP_CHUNK)), dim3(256), 0, ctx->stream>>>(
-            ctx->posm.ptr, ctx->pflags.ptr, n, (unsigned long long *) ctx->mesh.ptr, N, cell, scale);
+            ctx->posm.ptr, ctx->pflags.ptr, n, (unsigned long long *) ctx->mesh.ptr, N, cell, scale, 0, N, ctx->pm_oob.ptr);
     pm_convert_kernel<<<dim3(2048), dim3(threads), 0, ctx->stream>>>(ctx->mesh.ptr, padded, 1.0 / scale);
     SHQ_HIP(hipGetLastError());
     if(ctx->pm_keep) {
@@ -376,7 +401,7 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
     if(n > 0) {
         const double ffac = -(N / pm->BoxSize);
         pm_readout_kernel<<<dim3((unsigned) ((n + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-            ctx->posm.ptr, ctx->pflags.ptr, n, ctx->mesh.ptr, N, cell, ffac, ctx->gravpm.ptr, ctx->pmpot.ptr);
+            ctx->posm.ptr, ctx->pflags.ptr, n, ctx->mesh.ptr, N, cell, ffac, ctx->gravpm.ptr, ctx->pmpot.ptr, 0, N, ctx->pm_oob.ptr);
     }
     SHQ_HIP(hipGetLastError());
     SHQ_HIP(hipEventRecord(ctx->ev_begin[13], ctx->stream));
@@ -415,5 +440,140 @@ int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double 
     SHQ_HIP(hipMemcpyAsync(real, dense.ptr, tot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     dense.release();
+    return SHQ_OK;
+}
+
+/* ---- slab-sharded PM (multi-GPU): local phases on caller-provided device buffers ------------------
+ * Rank r owns mesh planes [plane0, plane0 + nplanes).  The deposit writes nplanes + 1 planes (CIC
+ * reaches one plane to the right); the readout reads nplanes + 5 planes starting at plane0 - 2
+ * (CIC + the 4-point stencil).  Ghost planes are exchanged by the caller (RCCL). */
+static int slab_sinctab(shq_context *ctx, int N)
+{
+    if(ctx->sinctab_n == N)
+        return SHQ_OK;
+    SHQ_TRY(ctx->sinctab.reserve(N));
+    SHQ_TRY(ctx->pm_oob.reserve(1));
+    std::vector<double> tab(N);
+    for(int i = 0; i < N; i++) {
+        const int k = i <= N / 2 ? i : i - N;
+        double tmp = (k * M_PI) / N;
+        double s;
+        if(tmp < 1e-5 && tmp > -1e-5) {
+            double x2 = tmp * tmp;
+            s = 1.0 - x2 / 6. + x2 * x2 / 120.;
+        } else
+            s = sin(tmp) / tmp;
+        tab[i] = 1. / (s * s);
+    }
+    SHQ_HIP(hipMemcpy(ctx->sinctab.ptr, tab.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    ctx->sinctab_n = N;
+    return SHQ_OK;
+}
+
+static int check_oob(shq_context *ctx, const char *what)
+{
+    int h = 0;
+    SHQ_HIP(hipMemcpyAsync(&h, ctx->pm_oob.ptr, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    SHQ_CHECK(h == 0, SHQ_ERR_INVALID, "%s: a particle lies outside this rank's mesh slab", what);
+    return SHQ_OK;
+}
+
+extern "C" int shq_pm_slab_deposit(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, void *d_mesh_i64)
+{
+    SHQ_CHECK(ctx && pm && d_mesh_i64, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "pm_slab_deposit: particles must be uploaded first");
+    const int N = pm->Nmesh;
+    SHQ_CHECK(N >= 4 && N % 2 == 0 && nplanes > 0 && nplanes <= N && plane0 >= 0 && plane0 < N, SHQ_ERR_INVALID, "bad slab geometry");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(slab_sinctab(ctx, N));
+    SHQ_HIP(hipMemsetAsync(ctx->pm_oob.ptr, 0, sizeof(int), ctx->stream));
+    const int nalloc = nplanes == N ? N : nplanes + 1;
+    const size_t cnt = (size_t) nalloc * N * (N + 2);
+    pm_zero_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>((unsigned long long *) d_mesh_i64, cnt);
+    const long long n = ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart;
+    if(n > 0)
+        pm_deposit_kernel<<<dim3((unsigned) ((n + DEP_CHUNK - 1) / DEP_CHUNK)), dim3(256), 0, ctx->stream>>>(
+            ctx->posm.ptr, ctx->pflags.ptr, n, (unsigned long long *) d_mesh_i64, N, pm->BoxSize / N, ldexp(1.0, ctx->pm_log2scale),
+            plane0, nalloc, ctx->pm_oob.ptr);
+    SHQ_HIP(hipGetLastError());
+    return check_oob(ctx, "pm_slab_deposit");
+}
+
+extern "C" int shq_pm_slab_readout(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, const void *d_phi_ext)
+{
+    SHQ_CHECK(ctx && pm && d_phi_ext, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "pm_slab_readout: particles must be uploaded first");
+    const int N = pm->Nmesh;
+    SHQ_CHECK(N >= 4 && N % 2 == 0 && nplanes > 0 && nplanes <= N && plane0 >= 0 && plane0 < N, SHQ_ERR_INVALID, "bad slab geometry");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(ctx->pm_oob.reserve(1));
+    SHQ_HIP(hipMemsetAsync(ctx->pm_oob.ptr, 0, sizeof(int), ctx->stream));
+    const long long n = ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart;
+    const int nalloc = nplanes == N ? N : nplanes + 5;
+    const int xshift = nplanes == N ? 0 : plane0 - 2;
+    if(n > 0)
+        pm_readout_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(
+            ctx->posm.ptr, ctx->pflags.ptr, n, (const double *) d_phi_ext, N, pm->BoxSize / N, -(N / pm->BoxSize), ctx->gravpm.ptr,
+            ctx->pmpot.ptr, xshift, nalloc, ctx->pm_oob.ptr);
+    SHQ_HIP(hipGetLastError());
+    ctx->have_pm_result = true;
+    return check_oob(ctx, "pm_slab_readout");
+}
+
+/* potential_transfer (gravpm.cpp:378-444) on the transposed spectrum of a y-slab:
+ * layout [ylocal][z' <= N/2][x], x fastest — the reference's own Fourier layout (petapm.cpp:243-282). */
+__global__ __launch_bounds__(256) void pm_green_slab_kernel(double2 *c, int N, int Nc, int y0, int nyl, const double *__restrict__ sinctab,
+                                                            double asmth2, double pot_factor)
+{
+    const size_t total = (size_t) nyl * Nc * N;
+    const size_t ip = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if(ip >= total)
+        return;
+    const int x = (int) (ip % N);
+    const size_t yz = ip / N;
+    const int z = (int) (yz % Nc);
+    const int y = y0 + (int) (yz / Nc);
+    const int kx = x <= N / 2 ? x : x - N;
+    const int ky = y <= N / 2 ? y : y - N;
+    const long long k2 = (long long) kx * kx + (long long) ky * ky + (long long) z * z;
+    double2 v = c[ip];
+    if(k2 == 0) {
+        v.x = 0;
+        v.y = 0;
+    } else {
+        double f = 1.0;
+        const double smth = exp(-(double) k2 * asmth2) / (double) k2;
+        f *= sinctab[x];
+        f *= sinctab[y];
+        f *= sinctab[z];
+        const double fac = pot_factor * smth * f * f;
+        v.x *= fac;
+        v.y *= fac;
+    }
+    c[ip] = v;
+}
+
+extern "C" int shq_pm_slab_green(shq_context *ctx, const shq_pm_params *pm, int y0, int nyl, void *d_spec)
+{
+    SHQ_CHECK(ctx && pm && d_spec, SHQ_ERR_INVALID, "null argument");
+    const int N = pm->Nmesh;
+    SHQ_CHECK(N >= 4 && N % 2 == 0 && nyl > 0 && y0 >= 0 && y0 + nyl <= N, SHQ_ERR_INVALID, "bad slab geometry");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(slab_sinctab(ctx, N));
+    const int Nc = N / 2 + 1;
+    const size_t tot = (size_t) nyl * Nc * N;
+    pm_green_slab_kernel<<<dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, ctx->stream>>>(
+        (double2 *) d_spec, N, Nc, y0, nyl, ctx->sinctab.ptr, pow((2 * M_PI) * pm->Asmth / N, 2), -pm->G / (M_PI * pm->BoxSize));
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}
+
+extern "C" int shq_pm_get_deposit_log2scale(shq_context *ctx) { return ctx ? ctx->pm_log2scale : -1; }
+extern "C" int shq_pm_set_deposit_log2scale(shq_context *ctx, int e)
+{
+    SHQ_CHECK(ctx && e >= 0 && e < 62, SHQ_ERR_INVALID, "bad scale exponent");
+    ctx->pm_log2scale_user = e;
+    ctx->pm_log2scale = e;
     return SHQ_OK;
 }

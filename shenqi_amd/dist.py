@@ -1,0 +1,304 @@
+"""Multi-GPU TreePM: one process per GPU, x-slab domain decomposition, RCCL over xGMI.
+
+How the path shards:
+  * particles and the PM mesh are cut into equal x-slabs, one per rank (the reference cuts its
+    real-space PM pencils over a 2-D rank grid np0 x np1, petapm.cpp:217-257; here np1 = 1);
+  * PM: local CIC deposit (HIP kernel, 64-bit fixed point) -> one ghost plane to the right
+    neighbour (integer add: bit-identical for any rank count) -> 2-D r2c over (y, z) per local
+    plane -> all-to-all transpose (x-slabs -> y-slabs; the reference's heffte reshape /
+    petapm.cpp:1036 alltoallv) -> 1-D FFT along x -> Green's function on the transposed spectrum
+    [y][z'][x] (the reference's own Fourier layout) -> inverse 1-D -> all-to-all back -> 2-D c2r
+    -> 2+3 potential ghost planes from the neighbours -> CIC readout with the 4-point stencil;
+  * tree: instead of exporting queries to remote trees and importing results
+    (treewalk2.h:618-812, two alltoallv per walk and a second remote walk), every rank imports
+    the neighbours' particles within `halo` of its slab (one alltoallv of 32-byte records),
+    the host builds the local tree over local + ghost particles with the global root cell, and
+    the walk runs for the local targets only.  Nodes beyond TreeRcut are discarded by the walk,
+    so nothing farther than the halo can contribute.
+The FFT stages use rocFFT through torch.fft; torch.distributed (backend "nccl" = RCCL, or
+"gloo" with host staging for tests) carries every exchange.  The local compute is abstracted as
+`ops` so that the orchestration can be exercised on CPU (tests/cpu_ops.py) with gloo.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+
+
+class Comm:
+    """Thin wrapper over torch.distributed for the exchanges the path needs."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.size = dist.get_world_size(group) if self.on else 1
+        self.backend = dist.get_backend(group) if self.on else "none"
+
+    def _stage(self, t):
+        """gloo cannot move device tensors: stage through the host (tests only)."""
+        if self.backend == "gloo" and t.is_cuda:
+            return t.cpu(), t.device
+        return t, None
+
+    def all_to_all_rows(self, send, send_counts):
+        """Variable all-to-all of the rows of a 2-D+ tensor: rows [sum(c[:d]), sum(c[:d+1])) go to rank d.
+        Returns (recv, recv_counts)."""
+        if self.size == 1:
+            return send, list(send_counts)
+        cnt = torch.tensor(send_counts, dtype=torch.int64)
+        rcnt = torch.empty_like(cnt)
+        cdev = send.device if self.backend == "nccl" else torch.device("cpu")
+        cnt_d, rcnt_d = cnt.to(cdev), rcnt.to(cdev)
+        dist.all_to_all_single(rcnt_d, cnt_d, group=self.group)
+        recv_counts = [int(x) for x in rcnt_d.cpu()]
+        s, dev = self._stage(send.contiguous())
+        r = torch.empty((sum(recv_counts),) + tuple(s.shape[1:]), dtype=s.dtype, device=s.device)
+        dist.all_to_all_single(r, s, output_split_sizes=recv_counts, input_split_sizes=list(send_counts), group=self.group)
+        return (r.to(dev) if dev is not None else r), recv_counts
+
+    def all_to_all_equal(self, send):
+        """Equal-split all-to-all along dim 0 (dim 0 must be a multiple of size)."""
+        if self.size == 1:
+            return send
+        s, dev = self._stage(send.contiguous())
+        r = torch.empty_like(s)
+        dist.all_to_all_single(r, s, group=self.group)
+        return r.to(dev) if dev is not None else r
+
+    def shift(self, t, direction):
+        """Send `t` to rank + direction (periodic), receive the same-shaped tensor from rank - direction."""
+        if self.size == 1:
+            return t.clone()
+        dst = (self.rank + direction) % self.size
+        counts = [0] * self.size
+        counts[dst] = t.shape[0]
+        recv, _ = self.all_to_all_rows(t, counts)
+        return recv
+
+    def allreduce_sum(self, x):
+        if self.size == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        if self.backend == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, group=self.group)
+        return float(t.item())
+
+    def barrier(self):
+        if self.size > 1:
+            dist.barrier(group=self.group)
+
+
+class SlabDecomp:
+    """Equal x-slabs of the box / of the mesh planes."""
+
+    def __init__(self, comm, Nmesh, BoxSize):
+        if Nmesh % comm.size != 0:
+            raise ValueError("Nmesh %d must be divisible by the number of ranks %d" % (Nmesh, comm.size))
+        self.comm, self.N, self.L = comm, Nmesh, BoxSize
+        self.nxl = Nmesh // comm.size
+        self.plane0 = comm.rank * self.nxl
+        self.x0 = self.plane0 * (BoxSize / Nmesh)
+        self.x1 = (self.plane0 + self.nxl) * (BoxSize / Nmesh)
+
+    def owner_of(self, x):
+        """rank owning positions x (tensor), by the mesh plane of the CIC base cell (floor(x / cell))."""
+        cell = self.L / self.N
+        plane = torch.floor(x / cell).to(torch.int64) % self.N
+        return plane // self.nxl
+
+
+def exchange_to_owner(comm, decomp, posm):
+    """Domain exchange: send every particle (rows x, y, z, m) to the rank owning its slab."""
+    owner = decomp.owner_of(posm[:, 0])
+    order = torch.argsort(owner, stable=True)
+    counts = torch.bincount(owner, minlength=comm.size).tolist()
+    recv, _ = comm.all_to_all_rows(posm[order], counts)
+    return recv
+
+
+def ghost_exchange(comm, decomp, posm, halo):
+    """Import the neighbours' particles within `halo` of this rank's slab faces.  Returns the
+    ghost rows (x, y, z, m), in source-rank order.  Each particle goes at most once to a rank."""
+    if comm.size == 1:
+        return posm[:0]
+    width = decomp.x1 - decomp.x0
+    if halo > width:
+        raise ValueError("halo %g exceeds the slab width %g: more ranks than the tree cut-off allows" % (halo, width))
+    x = posm[:, 0]
+    left, right = (comm.rank - 1) % comm.size, (comm.rank + 1) % comm.size
+    near_left = x < decomp.x0 + halo
+    near_right = x >= decomp.x1 - halo
+    parts, counts = [], [0] * comm.size
+    for d in range(comm.size):
+        m = None
+        if d == left:
+            m = near_left
+        if d == right:
+            m = near_right if m is None else (m | near_right)
+        if m is not None and d != comm.rank:
+            sel = posm[m]
+            parts.append(sel)
+            counts[d] = int(sel.shape[0])
+    send = torch.cat(parts, dim=0) if parts else posm[:0]
+    recv, _ = comm.all_to_all_rows(send, counts)
+    return recv
+
+
+class SlabPM:
+    """Distributed PM force for the particles this rank owns."""
+
+    def __init__(self, comm, Nmesh, BoxSize, Asmth, G, ops):
+        self.comm, self.ops = comm, ops
+        self.N, self.L, self.Asmth, self.G = Nmesh, BoxSize, Asmth, G
+        self.d = SlabDecomp(comm, Nmesh, BoxSize)
+
+    def force(self):
+        """Runs one PM step for the particles loaded in `ops`; results stay in ops (gravpm, potential)."""
+        c, N, nxl, P = self.comm, self.N, self.d.nxl, self.comm.size
+        Nc = N // 2 + 1
+        # 1. deposit + ghost plane to the right neighbour (integer add)
+        mesh_i = self.ops.deposit(self.d.plane0, nxl)                 # int64 [nxl(+1), N, N+2]
+        if P > 1:
+            ghost = c.shift(mesh_i[nxl:nxl + 1], +1)
+            mesh_i[0:1] += ghost
+        real = self.ops.to_real(mesh_i[:nxl])                          # f64 [nxl, N, N+2]
+        # 2. forward: 2-D r2c over (y, z), transpose, 1-D along x
+        spec = torch.fft.rfft2(real[..., :N], dim=(1, 2))              # [nxl, N, Nc], unscaled
+        nyl = N // P
+        send = spec.reshape(nxl, P, nyl, Nc).permute(1, 0, 2, 3).contiguous()     # [dest q][x_l][y_l][z]
+        recv = c.all_to_all_equal(send.reshape(P * nxl, nyl, Nc))                # [src p][x_l][y_l][z]
+        spec_t = recv.reshape(N, nyl, Nc).permute(1, 2, 0).contiguous()         # [y_l][z][x]
+        spec_t = torch.fft.fft(spec_t, dim=2)
+        # 3. Green's function / CIC deconvolution on the transposed spectrum
+        self.ops.green(spec_t, c.rank * nyl, nyl)
+        # 4. inverse: 1-D along x, transpose back, 2-D c2r
+        spec_t = torch.fft.ifft(spec_t, dim=2, norm="forward")
+        send = spec_t.permute(2, 0, 1).reshape(P, nxl, nyl, Nc).contiguous()       # [dest p][x_l][y_l][z]
+        recv = c.all_to_all_equal(send.reshape(P * nxl, nyl, Nc))                # [src q][x_l][y_l][z]
+        spec = recv.reshape(P, nxl, nyl, Nc).permute(1, 0, 2, 3).reshape(nxl, N, Nc)
+        phi = torch.fft.irfft2(spec, s=(N, N), dim=(1, 2), norm="forward")       # [nxl, N, N], unscaled
+        # 5. potential ghost planes (2 from the left neighbour, 3 from the right) and readout
+        if P > 1:
+            ext = self.ops.empty((nxl + 5, N, N + 2), torch.float64)
+            ext[2:2 + nxl, :, :N] = phi
+            ext[0:2, :, :N] = c.shift(phi[nxl - 2:nxl].contiguous(), +1)          # my last 2 -> right rank's left ghosts
+            ext[2 + nxl:, :, :N] = c.shift(phi[0:3].contiguous(), -1)             # my first 3 -> left rank's right ghosts
+        else:
+            ext = self.ops.empty((N, N, N + 2), torch.float64)
+            ext[:, :, :N] = phi
+        self.ops.readout(ext, self.d.plane0, nxl)
+
+
+class GpuOps:
+    """Local compute phases on the device through the C-ABI (libshenqi_hip.so)."""
+
+    def __init__(self, ctx, Nmesh, BoxSize, Asmth, G, device):
+        self.ctx, self.device = ctx, device
+        self.pm = capi.PMParams(Nmesh, 0, BoxSize, Asmth, G)
+        self.N = Nmesh
+
+    def empty(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def set_particles(self, posm_all, nlocal):
+        """posm_all: device tensor [n, 4] (x, y, z, m), the first nlocal rows are this rank's own."""
+        t = posm_all.contiguous()
+        capi.check(capi.hip.shq_particles_set_device(self.ctx.h, C.c_void_p(t.data_ptr()), t.shape[0], nlocal))
+        self._keep = t
+
+    def set_deposit_scale(self, total_mass):
+        e = 61 - math.frexp(total_mass if total_mass > 0 else 1.0)[1]
+        capi.check(capi.hip.shq_pm_set_deposit_log2scale(self.ctx.h, e))
+        self.log2scale = e
+
+    def deposit(self, plane0, nxl):
+        nalloc = nxl if nxl == self.N else nxl + 1
+        mesh = torch.empty((nalloc, self.N, self.N + 2), dtype=torch.int64, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()
+        capi.check(capi.hip.shq_pm_slab_deposit(self.ctx.h, C.byref(self.pm), plane0, nxl, C.c_void_p(mesh.data_ptr())))
+        self.ctx.synchronize()
+        return mesh
+
+    def to_real(self, mesh_i):
+        return mesh_i.to(torch.float64) * (1.0 / 2.0 ** self.log2scale)
+
+    def green(self, spec_t, y0, nyl):
+        assert spec_t.is_contiguous() and spec_t.dtype == torch.complex128
+        torch.cuda.current_stream(self.device).synchronize()
+        capi.check(capi.hip.shq_pm_slab_green(self.ctx.h, C.byref(self.pm), y0, nyl, C.c_void_p(spec_t.data_ptr())))
+        self.ctx.synchronize()
+
+    def readout(self, ext, plane0, nxl):
+        assert ext.is_contiguous()
+        torch.cuda.current_stream(self.device).synchronize()
+        capi.check(capi.hip.shq_pm_slab_readout(self.ctx.h, C.byref(self.pm), plane0, nxl, C.c_void_p(ext.data_ptr())))
+        self.ctx.synchronize()
+
+    def results(self, nlocal):
+        g = np.zeros((self._keep.shape[0], 3))
+        p = np.zeros(self._keep.shape[0])
+        capi.check(capi.hip.shq_pm_download(self.ctx.h, capi.ptr(g), capi.ptr(p)))
+        return g[:nlocal], p[:nlocal]
+
+
+class DistTreePM:
+    """One rank of the sharded TreePM force: PM over x-slabs + tree walk over local + ghost particles."""
+
+    def __init__(self, comm, ctx, Nmesh, BoxSize, Asmth, G, device, halo_factor=1.5):
+        import shenqi_amd as sq
+        self.sq = sq
+        self.comm, self.ctx, self.device = comm, ctx, device
+        self.N, self.L, self.Asmth, self.G = Nmesh, BoxSize, Asmth, G
+        self.ops = GpuOps(ctx, Nmesh, BoxSize, Asmth, G, device)
+        self.pm = SlabPM(comm, Nmesh, BoxSize, Asmth, G, self.ops)
+        self.decomp = self.pm.d
+        self.halo_factor = halo_factor
+        self.tree = None
+
+    def setup(self, posm_local, Rcut):
+        """posm_local: device tensor [nloc, 4] of the particles this rank owns (already exchanged to
+        their owner).  Orders them along a space-filling curve, imports ghosts, builds and uploads the tree."""
+        sq = self.sq
+        host = posm_local.cpu().numpy()
+        order = sq.morton_order(np.ascontiguousarray(host[:, :3]), self.L)
+        self.local = posm_local[torch.from_numpy(order.astype(np.int64)).to(posm_local.device)].contiguous()
+        self.nloc = int(self.local.shape[0])
+        self.halo = self.halo_factor * Rcut
+        self.ops.set_deposit_scale(self.comm.allreduce_sum(float(self.local[:, 3].sum().item())))
+        self._load_particles()
+        allh = self.allp.cpu().numpy()
+        pman = sq.PartManager(allh.shape[0], self.L)
+        pman.Base["Pos"] = allh[:, :3]
+        pman.Base["Mass"] = allh[:, 3]
+        pman.Base["Type"] = 1
+        self.pman = pman
+        self.tree = sq.force_tree_full(pman)
+        tv = self.tree.view()
+        capi.check(capi.hip.shq_tree_upload(self.ctx.h, C.byref(tv)))
+
+    def _load_particles(self):
+        ghosts = ghost_exchange(self.comm, self.decomp, self.local, self.halo)
+        self.allp = torch.cat([self.local, ghosts], dim=0).contiguous()
+        self.nghost = int(ghosts.shape[0])
+        self.ops.set_particles(self.allp, self.nloc)
+
+    def step(self, gp, update_potential=1, walk_mode=0):
+        """One force evaluation: ghost import, PM, walk for the local targets, OldAcc refresh."""
+        self._load_particles()
+        self.pm.force()
+        capi.check(capi.hip.shq_grav_short_run(self.ctx.h, C.byref(gp), None, 0, int(update_potential), walk_mode))
+        capi.check(capi.hip.shq_grav_refresh_oldacc(self.ctx.h, self.G))
+
+    def download(self):
+        n = int(self.allp.shape[0])
+        acc = np.zeros((n, 3))
+        pot = np.zeros(n)
+        capi.check(capi.hip.shq_grav_short_download(self.ctx.h, capi.ptr(acc), capi.ptr(pot), None, None))
+        gpm, ppot = self.ops.results(self.nloc)
+        return acc[: self.nloc], pot[: self.nloc], gpm, ppot

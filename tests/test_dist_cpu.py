@@ -1,0 +1,122 @@
+"""world_size-2 / -4 gloo tests of the multi-GPU orchestration (shenqi_amd/dist.py) on CPU:
+slab PM with ghost planes and all-to-all transposes vs the monolithic oracle PM, domain exchange,
+and ghost-particle import for the tree vs the monolithic oracle walk."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+NPART = 16**3
+NMESH = 48
+BOX = 8.0
+G = 43.0071
+
+
+def _global_particles():
+    import orc
+    import common as cm
+    pos = cm.random_positions(orc.boost_mt19937_uniform(0, 3 * NPART), NPART)
+    posm = np.concatenate([pos, np.ones((NPART, 1))], axis=1)
+    return posm
+
+
+def _worker(rank, world, initfile, outdir):
+    os.environ["OMP_NUM_THREADS"] = "2"
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        import shenqi_amd as sq
+        from shenqi_amd import dist as sd
+        import orc
+        import common as cm
+        from cpu_ops import CpuOps
+
+        comm = sd.Comm()
+        posm_g = _global_particles()
+        mine = torch.from_numpy(posm_g[rank::world].copy())          # any initial distribution
+        decomp = sd.SlabDecomp(comm, NMESH, BOX)
+        local = sd.exchange_to_owner(comm, decomp, mine)
+        nloc = local.shape[0]
+        total = comm.allreduce_sum(float(nloc))
+        assert int(total) == NPART
+        x = local[:, 0].numpy()
+        assert np.all((np.floor(x / (BOX / NMESH)) % NMESH >= decomp.plane0) & (np.floor(x / (BOX / NMESH)) % NMESH < decomp.plane0 + decomp.nxl))
+        # ---- PM ----
+        ops = CpuOps(NMESH, BOX, 1.5, G)
+        ops.set_deposit_scale(comm.allreduce_sum(float(local[:, 3].sum())))
+        ops.set_particles(local, nloc)
+        pm = sd.SlabPM(comm, NMESH, BOX, 1.5, G, ops)
+        pm.force()
+        gpm, ppot = ops.results(nloc)
+        # ---- tree with imported ghosts ----
+        cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=0)
+        sq.gravshort_set_softenings(BOX / np.cbrt(NPART))
+        gp = sq.make_grav_params(BOX, 1.5, NMESH, G, cm.RHO0)
+        halo = min(2.0 * gp.Rcut, 0.98 * (decomp.x1 - decomp.x0))   # the test box is tiny: 4 slabs are narrower than 2 Rcut
+        ghosts = sd.ghost_exchange(comm, decomp, local, halo)
+        allp = torch.cat([local, ghosts], dim=0).numpy()
+        nodes, first, _ = orc.tree_build(allp[:, :3].copy(), allp[:, 3].astype(np.float32), BOX)
+        np.save(os.path.join(outdir, "r%d.npy" % rank), np.concatenate([local.numpy(), gpm, ppot[:, None]], axis=1))
+        np.save(os.path.join(outdir, "t%d.npy" % rank), allp)
+        np.save(os.path.join(outdir, "n%d.npy" % rank), np.array([nloc, len(ghosts)]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_slab_pm_and_ghost_tree_gloo(world):
+    import orc
+    import common as cm
+    import shenqi_amd as sq
+    with tempfile.TemporaryDirectory() as tmp:
+        initfile = os.path.join(tmp, "init")
+        mp.spawn(_worker, args=(world, initfile, tmp), nprocs=world, join=True)
+        posm_g = _global_particles()
+        mass = posm_g[:, 3].astype(np.float32)
+        e = 61 - int(np.frexp(float(NPART))[1])
+        og, opot, _, _ = orc.pm_force(posm_g[:, :3].copy(), mass, NMESH, BOX, 1.5, G, fixed_point_log2scale=e, use_stencil=1)
+        key = {tuple(p): i for i, p in enumerate(map(tuple, posm_g[:, :3]))}
+        seen = 0
+        # monolithic tree forces (relative criterion with OldAcc from a BH pass)
+        nodes, first, _ = orc.tree_build(posm_g[:, :3].copy(), mass, BOX)
+        cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=1)
+        sq.gravshort_set_softenings(BOX / np.cbrt(NPART))
+        gp_bh = sq.make_grav_params(BOX, 1.5, NMESH, G, cm.RHO0)
+        acc_bh, _, _ = orc.grav_walk(nodes, first, posm_g[:, :3].copy(), mass, np.zeros(NPART), gp_bh)
+        oldacc = np.linalg.norm(acc_bh * G + og, axis=1) / G
+        cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=0)
+        gp = sq.make_grav_params(BOX, 1.5, NMESH, G, cm.RHO0)
+        acc_mono, _, _ = orc.grav_walk(nodes, first, posm_g[:, :3].copy(), mass, oldacc, gp)
+        num = den = 0.0
+        for r in range(world):
+            a = np.load(os.path.join(tmp, "r%d.npy" % r))
+            idx = np.array([key[tuple(p)] for p in a[:, :3]])
+            seen += len(idx)
+            # PM: sharded == monolithic to FFT-decomposition rounding
+            assert np.abs(a[:, 4:7] - og[idx]).max() < 1e-11 * np.abs(og).max()
+            assert np.abs(a[:, 7] - opot[idx]).max() < 1e-11 * np.abs(opot).max()
+            # tree: local targets on the (local + ghost) tree
+            allp = np.load(os.path.join(tmp, "t%d.npy" % r))
+            nloc, ngh = np.load(os.path.join(tmp, "n%d.npy" % r))
+            lnodes, lfirst, _ = orc.tree_build(allp[:, :3].copy(), allp[:, 3].astype(np.float32), BOX)
+            gidx = np.array([key[tuple(p)] for p in allp[:, :3]])
+            assert len(set(gidx.tolist())) == len(gidx)           # no particle imported twice
+            acc_loc, _, _ = orc.grav_walk(lnodes, lfirst, allp[:, :3].copy(), allp[:, 3].astype(np.float32), oldacc[gidx], gp,
+                                          targets=np.arange(nloc, dtype=np.int32))
+            ref = acc_mono[gidx[:nloc]]
+            num += np.sum((acc_loc - ref) ** 2)
+            den += np.sum(ref**2)
+            assert 0 < ngh < NPART
+        assert seen == NPART
+        rms = np.sqrt(num / den)
+        print("world %d: sharded tree vs monolithic rms |dF|/|F| = %.3e" % (world, rms))
+        assert rms < 1e-3

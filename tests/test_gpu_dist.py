@@ -1,0 +1,112 @@
+"""GPU tests of the multi-GPU path on the one-GPU box: the slab PM / ghost-tree driver with one rank
+(device kernels through the slab entry points) and with two gloo ranks sharing the GPU (exchanges
+staged through the host), both against the monolithic single-GPU path and the oracle."""
+import ctypes as C
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+pytestmark = pytest.mark.gpu
+
+NPART, NMESH, BOX, G = 16**3, 48, 8.0, 43.0071
+
+
+def _global_particles():
+    import orc
+    import common as cm
+    pos = cm.random_positions(orc.boost_mt19937_uniform(0, 3 * NPART), NPART)
+    return np.concatenate([pos, np.ones((NPART, 1))], axis=1)
+
+
+def _run_rank(rank, world, outdir):
+    import shenqi_amd as sq
+    from shenqi_amd import capi, dist as sd
+    import common as cm
+    dev = torch.device("cuda", 0)
+    comm = sd.Comm()
+    posm_g = _global_particles()
+    mine = torch.from_numpy(posm_g[rank::world].copy()).to(dev)
+    ctx = sq.Context(0)
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=1)
+    sq.gravshort_set_softenings(BOX / np.cbrt(NPART))
+    gp_bh = sq.make_grav_params(BOX, 1.5, NMESH, G, cm.RHO0)
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=0)
+    gp = sq.make_grav_params(BOX, 1.5, NMESH, G, cm.RHO0)
+    drv = sd.DistTreePM(comm, ctx, NMESH, BOX, 1.5, G, dev, halo_factor=2.0 if world <= 2 else 1.3)
+    local = sd.exchange_to_owner(comm, drv.decomp, mine)
+    drv.setup(local, gp.Rcut)
+    drv.step(gp_bh)
+    drv.step(gp)
+    acc, pot, gpm, ppot = drv.download()
+    np.save(os.path.join(outdir, "g%d.npy" % rank), np.concatenate([drv.local.cpu().numpy(), acc, gpm, ppot[:, None]], axis=1))
+    ctx.close()
+
+
+def _worker(rank, world, initfile, outdir):
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        _run_rank(rank, world, outdir)
+    finally:
+        dist.destroy_process_group()
+
+
+def _reference():
+    """monolithic oracle: PM (stencil, fixed point) + BH pass + relative-criterion pass"""
+    import orc
+    import common as cm
+    import shenqi_amd as sq
+    posm_g = _global_particles()
+    pos, mass = posm_g[:, :3].copy(), posm_g[:, 3].astype(np.float32)
+    e = 61 - int(np.frexp(float(NPART))[1])
+    og, opot, _, _ = orc.pm_force(pos, mass, NMESH, BOX, 1.5, G, fixed_point_log2scale=e, use_stencil=1)
+    nodes, first, _ = orc.tree_build(pos, mass, BOX)
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=1)
+    sq.gravshort_set_softenings(BOX / np.cbrt(NPART))
+    gp_bh = sq.make_grav_params(BOX, 1.5, NMESH, G, cm.RHO0)
+    a1, _, _ = orc.grav_walk(nodes, first, pos, mass, np.zeros(NPART), gp_bh)
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=0)
+    gp = sq.make_grav_params(BOX, 1.5, NMESH, G, cm.RHO0)
+    a2, _, _ = orc.grav_walk(nodes, first, pos, mass, np.linalg.norm(a1 * G + og, axis=1) / G, gp)
+    return pos, og, opot, a2 * G
+
+
+def _check(tmp, world):
+    pos, og, opot, oacc = _reference()
+    key = {tuple(p): i for i, p in enumerate(map(tuple, pos))}
+    seen = 0
+    num = den = 0.0
+    for r in range(world):
+        a = np.load(os.path.join(tmp, "g%d.npy" % r))
+        idx = np.array([key[tuple(p)] for p in a[:, :3]])
+        seen += len(idx)
+        assert np.abs(a[:, 7:10] - og[idx]).max() < 1e-10 * np.abs(og).max()          # PM
+        assert np.abs(a[:, 10] - opot[idx]).max() < 1e-10 * np.abs(opot).max()
+        num += np.sum((a[:, 4:7] - oacc[idx]) ** 2)
+        den += np.sum(oacc[idx] ** 2)
+    assert seen == NPART
+    rms = np.sqrt(num / den)
+    print("world %d on one GPU: tree rms vs monolithic oracle %.3e" % (world, rms))
+    assert rms < 1e-3
+
+
+def test_dist_driver_single_rank():
+    with tempfile.TemporaryDirectory() as tmp:
+        _run_rank(0, 1, tmp)
+        _check(tmp, 1)
+
+
+def test_dist_driver_two_gloo_ranks_one_gpu():
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(2, os.path.join(tmp, "init"), tmp), nprocs=2, join=True)
+        _check(tmp, 2)
