@@ -9,8 +9,10 @@ build and host packing are outside it.
 
 Workload at N=1: BASELINE.json configs[1] — dm-only 256^3, Nmesh 768, S-cluster positions,
 Asmth 1.5, TreeRcut 6, softening 2.8 L/(30 n), exact window, ErrTolForceAcc 0.005, after a
-theta=0.175 Barnes-Hut seeding walk.  For N>1 every rank runs the same workload on its own GPU
-(independent replicas; the sharded multi-GPU exchange path is not built yet) => "scaling": "weak".
+theta=0.175 Barnes-Hut seeding walk.  For N>1 the box grows with the GPU count at fixed
+particles per GPU (n = 320, 408, 512 per dimension for N = 2, 4, 8; Nmesh = 3 n) and is sharded
+over x-slabs, one per rank (shenqi_amd/dist.py): RCCL all-to-all for the slab-FFT transposes,
+ghost mesh planes and ghost particles for the tree => "scaling": "weak".
 """
 import argparse
 import ctypes as C
@@ -77,18 +79,105 @@ def cpu_baseline(pos, mass, tree, gp_rel, oldacc, L):
     }
 
 
+def run_sharded(args, rank, local_rank, world):
+    """N > 1: one rank per GPU over RCCL; x-slab sharded TreePM (shenqi_amd/dist.py)."""
+    import torch
+    import torch.distributed as dist
+
+    # SHQ_BENCH_BACKEND=gloo is a rehearsal knob for the one-GPU box: every rank shares device 0 and the
+    # exchanges are staged through the host.  The driver's runs use nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get("SHQ_BENCH_BACKEND", "nccl")
+    devidx = local_rank if backend == "nccl" else 0
+    torch.cuda.set_device(devidx)
+    dev = torch.device("cuda", devidx)
+    cdev = dev if backend == "nccl" else torch.device("cpu")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    import shenqi_amd as sq
+    from shenqi_amd import capi, dist as sd
+
+    n1 = {2: 320, 4: 408, 8: 512}.get(world)
+    if n1 is None:
+        n1 = int(round(args.n * world ** (1.0 / 3.0) / (2 * world))) * 2 * world
+    if args.n != 256:      # reduced rehearsal sizes keep the same per-GPU share
+        n1 = int(round(args.n * world ** (1.0 / 3.0) / (2 * world))) * 2 * world
+    nmesh = 3 * n1
+    L = 1.0
+    nglobal = n1**3
+    nmine = nglobal // world + (1 if rank < nglobal % world else 0)
+    comm = sd.Comm()
+    t0 = time.perf_counter()
+    pos = sq.synth_positions(args.kind, nmine, seed=20240601 + rank, L=L)
+    posm = torch.from_numpy(np.concatenate([pos, np.ones((nmine, 1))], axis=1)).to(dev)
+    del pos
+    bounds = sd.balanced_bounds(comm, nmesh, L, posm[:, 0])
+    ctx = sq.Context(devidx, stream=torch.cuda.current_stream().cuda_stream)
+    sq.set_gravshort_treepar(ErrTolForceAcc=args.errtol, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=1, Rcut=6.0)
+    sq.gravshort_set_softenings(L / n1)
+    gp_bh = sq.make_grav_params(L, 1.5, nmesh, G, RHO0)
+    sq.set_gravshort_treepar(ErrTolForceAcc=args.errtol, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=0, Rcut=6.0)
+    gp_rel = sq.make_grav_params(L, 1.5, nmesh, G, RHO0)
+    drv = sd.DistTreePM(comm, ctx, nmesh, L, 1.5, G, dev, halo_factor=1.5, bounds=bounds)
+    local = sd.exchange_to_owner(comm, drv.decomp, posm)
+    del posm
+    drv.setup(local, gp_rel.Rcut)
+    t_setup = time.perf_counter() - t0
+    drv.step(gp_bh)
+    for _ in range(args.warmup):
+        drv.step(gp_rel)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        drv.step(gp_rel)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    st = sq.WalkStats()
+    capi.check(capi.hip.shq_grav_short_download(ctx.h, None, None, None, C.byref(st)))
+    loads = torch.tensor([float(drv.nloc), float(drv.nghost), st.kernel_ms], device=cdev, dtype=torch.float64)
+    gathered = [torch.zeros_like(loads) for _ in range(world)]
+    dist.all_gather(gathered, loads)
+    walk_s = max(float(g[2]) for g in gathered) * 1e-3
+    tree_bytes = 68.0 * drv.nloc + 76.0 * drv.tree.numnodes
+    ach = tree_bytes / max(st.kernel_ms * 1e-3, 1e-12) / 1e9
+    out = {
+        "metric": "particle-steps/sec (grav+PM+SPH) at 256^3; rms force error vs ref",
+        "value": nglobal * args.steps / elapsed, "unit": "particle-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "dm-only %d^3 TreePM sharded over %d x-slabs (S-%s, Nmesh %d, Asmth 1.5, Rcut 6, ErrTolForceAcc %g, "
+                               "exact window), %.3g particles per GPU" % (n1, world, args.kind, nmesh, args.errtol, nglobal / world),
+                   "particles_total": nglobal, "nmesh": nmesh, "parallelism": "x-slabs x%d, RCCL all-to-all + ghost exchange" % world,
+                   "slab_bounds": bounds, "walk": "exact (per-target reference opening decisions)"},
+        "roofline": {"bound": "hbm", "kernel": "grav_walk_exact_kernel (rank 0)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": None},
+        "kernels": {"per_rank_local_particles": [int(g[0]) for g in gathered], "per_rank_ghost_particles": [int(g[1]) for g in gathered],
+                    "per_rank_walk_ms": [float(g[2]) for g in gathered], "slowest_walk_ms": walk_s * 1e3},
+        "setup_s": {"generate_exchange_tree_upload": t_setup},
+    }
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
     if world > 1:
-        import torch
-        import torch.distributed as dist_mod
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist = dist_mod
+        return run_sharded(args, rank, local_rank, world)
+    dist = None
 
     import shenqi_amd as sq
     from shenqi_amd import capi

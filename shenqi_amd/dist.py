@@ -56,19 +56,23 @@ class Comm:
         cnt_d, rcnt_d = cnt.to(cdev), rcnt.to(cdev)
         dist.all_to_all_single(rcnt_d, cnt_d, group=self.group)
         recv_counts = [int(x) for x in rcnt_d.cpu()]
-        s, dev = self._stage(send.contiguous())
+        cplx = send.is_complex()
+        s, dev = self._stage(torch.view_as_real(send.contiguous()) if cplx else send.contiguous())
         r = torch.empty((sum(recv_counts),) + tuple(s.shape[1:]), dtype=s.dtype, device=s.device)
         dist.all_to_all_single(r, s, output_split_sizes=recv_counts, input_split_sizes=list(send_counts), group=self.group)
-        return (r.to(dev) if dev is not None else r), recv_counts
+        r = r.to(dev) if dev is not None else r
+        return (torch.view_as_complex(r) if cplx else r), recv_counts
 
     def all_to_all_equal(self, send):
         """Equal-split all-to-all along dim 0 (dim 0 must be a multiple of size)."""
         if self.size == 1:
             return send
-        s, dev = self._stage(send.contiguous())
+        cplx = send.is_complex()
+        s, dev = self._stage(torch.view_as_real(send.contiguous()) if cplx else send.contiguous())
         r = torch.empty_like(s)
         dist.all_to_all_single(r, s, group=self.group)
-        return r.to(dev) if dev is not None else r
+        r = r.to(dev) if dev is not None else r
+        return torch.view_as_complex(r) if cplx else r
 
     def shift(self, t, direction):
         """Send `t` to rank + direction (periodic), receive the same-shaped tensor from rank - direction."""
@@ -95,22 +99,64 @@ class Comm:
 
 
 class SlabDecomp:
-    """Equal x-slabs of the box / of the mesh planes."""
+    """x-slabs of the box = runs of mesh planes, one per rank.  `bounds` (P+1 plane indices, 0 ... Nmesh)
+    may be unequal: balanced_bounds() picks them so that every rank owns about the same number of
+    particles (the reference balances work through its Peano top-leaf assignment, domain.cpp:620)."""
 
-    def __init__(self, comm, Nmesh, BoxSize):
-        if Nmesh % comm.size != 0:
-            raise ValueError("Nmesh %d must be divisible by the number of ranks %d" % (Nmesh, comm.size))
-        self.comm, self.N, self.L = comm, Nmesh, BoxSize
-        self.nxl = Nmesh // comm.size
-        self.plane0 = comm.rank * self.nxl
-        self.x0 = self.plane0 * (BoxSize / Nmesh)
-        self.x1 = (self.plane0 + self.nxl) * (BoxSize / Nmesh)
+    MIN_PLANES = 3   # the readout needs 3 planes from the right neighbour and 2 from the left
+
+    def __init__(self, comm, Nmesh, BoxSize, bounds=None):
+        P = comm.size
+        if bounds is None:
+            if Nmesh % P != 0:
+                raise ValueError("Nmesh %d must be divisible by the number of ranks %d (or pass bounds)" % (Nmesh, P))
+            bounds = [r * (Nmesh // P) for r in range(P + 1)]
+        bounds = [int(b) for b in bounds]
+        if len(bounds) != P + 1 or bounds[0] != 0 or bounds[-1] != Nmesh:
+            raise ValueError("bounds must run from 0 to Nmesh with one entry per rank + 1")
+        widths = [bounds[r + 1] - bounds[r] for r in range(P)]
+        if P > 1 and min(widths) < self.MIN_PLANES:
+            raise ValueError("every slab needs at least %d mesh planes (got %s)" % (self.MIN_PLANES, widths))
+        if Nmesh % P != 0:
+            raise ValueError("Nmesh %d must be divisible by the number of ranks %d (equal y-slabs of the spectrum)" % (Nmesh, P))
+        self.comm, self.N, self.L, self.bounds, self.widths = comm, Nmesh, BoxSize, bounds, widths
+        self.cell = BoxSize / Nmesh
+        self.nxl = widths[comm.rank]
+        self.plane0 = bounds[comm.rank]
+        self.x0 = self.plane0 * self.cell
+        self.x1 = bounds[comm.rank + 1] * self.cell
 
     def owner_of(self, x):
         """rank owning positions x (tensor), by the mesh plane of the CIC base cell (floor(x / cell))."""
-        cell = self.L / self.N
-        plane = torch.floor(x / cell).to(torch.int64) % self.N
-        return plane // self.nxl
+        plane = torch.floor(x / self.cell).to(torch.int64) % self.N
+        inner = torch.tensor(self.bounds[1:-1], dtype=torch.int64, device=x.device)
+        return torch.searchsorted(inner, plane, right=True)
+
+    def slab_range(self, r):
+        return self.bounds[r] * self.cell, self.bounds[r + 1] * self.cell
+
+
+def balanced_bounds(comm, Nmesh, BoxSize, x):
+    """Plane boundaries giving every rank about the same number of particles (x: positions held by
+    this rank, any distribution).  One all-reduce of an Nmesh-long histogram."""
+    P = comm.size
+    cell = BoxSize / Nmesh
+    plane = (torch.floor(x / cell).to(torch.int64) % Nmesh).cpu()
+    hist = torch.bincount(plane, minlength=Nmesh).to(torch.float64)
+    if P > 1:
+        h = hist.cuda() if comm.backend == "nccl" else hist
+        dist.all_reduce(h, group=comm.group)
+        hist = h.cpu()
+    cum = torch.cumsum(hist, 0).numpy()
+    total = cum[-1]
+    bounds = [0]
+    for r in range(1, P):
+        b = int(np.searchsorted(cum, total * r / P, side="left")) + 1
+        b = max(b, bounds[-1] + SlabDecomp.MIN_PLANES)
+        b = min(b, Nmesh - SlabDecomp.MIN_PLANES * (P - r))
+        bounds.append(b)
+    bounds.append(Nmesh)
+    return bounds
 
 
 def exchange_to_owner(comm, decomp, posm):
@@ -123,28 +169,24 @@ def exchange_to_owner(comm, decomp, posm):
 
 
 def ghost_exchange(comm, decomp, posm, halo):
-    """Import the neighbours' particles within `halo` of this rank's slab faces.  Returns the
-    ghost rows (x, y, z, m), in source-rank order.  Each particle goes at most once to a rank."""
+    """Import every other rank's particles within `halo` (periodic) of this rank's slab.  Returns
+    the ghost rows (x, y, z, m) in source-rank order; a particle goes at most once to a rank."""
     if comm.size == 1:
         return posm[:0]
-    width = decomp.x1 - decomp.x0
-    if halo > width:
-        raise ValueError("halo %g exceeds the slab width %g: more ranks than the tree cut-off allows" % (halo, width))
+    L = decomp.L
     x = posm[:, 0]
-    left, right = (comm.rank - 1) % comm.size, (comm.rank + 1) % comm.size
-    near_left = x < decomp.x0 + halo
-    near_right = x >= decomp.x1 - halo
     parts, counts = [], [0] * comm.size
     for d in range(comm.size):
-        m = None
-        if d == left:
-            m = near_left
-        if d == right:
-            m = near_right if m is None else (m | near_right)
-        if m is not None and d != comm.rank:
-            sel = posm[m]
-            parts.append(sel)
-            counts[d] = int(sel.shape[0])
+        if d == comm.rank:
+            continue
+        a, b = decomp.slab_range(d)
+        span = (b - a) + 2 * halo
+        if span >= L:
+            sel = posm
+        else:
+            sel = posm[torch.remainder(x - (a - halo), L) < span]
+        parts.append(sel)
+        counts[d] = int(sel.shape[0])
     send = torch.cat(parts, dim=0) if parts else posm[:0]
     recv, _ = comm.all_to_all_rows(send, counts)
     return recv
@@ -153,36 +195,37 @@ def ghost_exchange(comm, decomp, posm, halo):
 class SlabPM:
     """Distributed PM force for the particles this rank owns."""
 
-    def __init__(self, comm, Nmesh, BoxSize, Asmth, G, ops):
+    def __init__(self, comm, Nmesh, BoxSize, Asmth, G, ops, bounds=None):
         self.comm, self.ops = comm, ops
         self.N, self.L, self.Asmth, self.G = Nmesh, BoxSize, Asmth, G
-        self.d = SlabDecomp(comm, Nmesh, BoxSize)
+        self.d = SlabDecomp(comm, Nmesh, BoxSize, bounds)
 
     def force(self):
         """Runs one PM step for the particles loaded in `ops`; results stay in ops (gravpm, potential)."""
         c, N, nxl, P = self.comm, self.N, self.d.nxl, self.comm.size
         Nc = N // 2 + 1
+        widths = self.d.widths
         # 1. deposit + ghost plane to the right neighbour (integer add)
         mesh_i = self.ops.deposit(self.d.plane0, nxl)                 # int64 [nxl(+1), N, N+2]
         if P > 1:
             ghost = c.shift(mesh_i[nxl:nxl + 1], +1)
             mesh_i[0:1] += ghost
         real = self.ops.to_real(mesh_i[:nxl])                          # f64 [nxl, N, N+2]
-        # 2. forward: 2-D r2c over (y, z), transpose, 1-D along x
+        # 2. forward: 2-D r2c over (y, z), transpose (x-slabs -> equal y-slabs), 1-D along x
         spec = torch.fft.rfft2(real[..., :N], dim=(1, 2))              # [nxl, N, Nc], unscaled
         nyl = N // P
-        send = spec.reshape(nxl, P, nyl, Nc).permute(1, 0, 2, 3).contiguous()     # [dest q][x_l][y_l][z]
-        recv = c.all_to_all_equal(send.reshape(P * nxl, nyl, Nc))                # [src p][x_l][y_l][z]
-        spec_t = recv.reshape(N, nyl, Nc).permute(1, 2, 0).contiguous()         # [y_l][z][x]
+        send = spec.reshape(nxl, P, nyl, Nc).permute(1, 0, 2, 3).reshape(P * nxl, nyl, Nc)   # rows [dest q][x_l]
+        recv, _ = c.all_to_all_rows(send, [nxl] * P)                                         # rows [src p][x_l] = all x
+        spec_t = recv.reshape(N, nyl, Nc).permute(1, 2, 0).contiguous()                      # [y_l][z][x]
         spec_t = torch.fft.fft(spec_t, dim=2)
         # 3. Green's function / CIC deconvolution on the transposed spectrum
         self.ops.green(spec_t, c.rank * nyl, nyl)
         # 4. inverse: 1-D along x, transpose back, 2-D c2r
         spec_t = torch.fft.ifft(spec_t, dim=2, norm="forward")
-        send = spec_t.permute(2, 0, 1).reshape(P, nxl, nyl, Nc).contiguous()       # [dest p][x_l][y_l][z]
-        recv = c.all_to_all_equal(send.reshape(P * nxl, nyl, Nc))                # [src q][x_l][y_l][z]
+        send = spec_t.permute(2, 0, 1).contiguous()                                          # rows = x planes, in order
+        recv, _ = c.all_to_all_rows(send, widths)                                            # rows [src q][x_l]
         spec = recv.reshape(P, nxl, nyl, Nc).permute(1, 0, 2, 3).reshape(nxl, N, Nc)
-        phi = torch.fft.irfft2(spec, s=(N, N), dim=(1, 2), norm="forward")       # [nxl, N, N], unscaled
+        phi = torch.fft.irfft2(spec, s=(N, N), dim=(1, 2), norm="forward")                   # [nxl, N, N], unscaled
         # 5. potential ghost planes (2 from the left neighbour, 3 from the right) and readout
         if P > 1:
             ext = self.ops.empty((nxl + 5, N, N + 2), torch.float64)
@@ -250,13 +293,13 @@ class GpuOps:
 class DistTreePM:
     """One rank of the sharded TreePM force: PM over x-slabs + tree walk over local + ghost particles."""
 
-    def __init__(self, comm, ctx, Nmesh, BoxSize, Asmth, G, device, halo_factor=1.5):
+    def __init__(self, comm, ctx, Nmesh, BoxSize, Asmth, G, device, halo_factor=1.5, bounds=None):
         import shenqi_amd as sq
         self.sq = sq
         self.comm, self.ctx, self.device = comm, ctx, device
         self.N, self.L, self.Asmth, self.G = Nmesh, BoxSize, Asmth, G
         self.ops = GpuOps(ctx, Nmesh, BoxSize, Asmth, G, device)
-        self.pm = SlabPM(comm, Nmesh, BoxSize, Asmth, G, self.ops)
+        self.pm = SlabPM(comm, Nmesh, BoxSize, Asmth, G, self.ops, bounds)
         self.decomp = self.pm.d
         self.halo_factor = halo_factor
         self.tree = None

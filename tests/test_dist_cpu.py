@@ -29,7 +29,7 @@ def _global_particles():
     return posm
 
 
-def _worker(rank, world, initfile, outdir):
+def _worker(rank, world, initfile, outdir, balanced):
     os.environ["OMP_NUM_THREADS"] = "2"
     torch.set_num_threads(2)
     dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
@@ -43,25 +43,28 @@ def _worker(rank, world, initfile, outdir):
         comm = sd.Comm()
         posm_g = _global_particles()
         mine = torch.from_numpy(posm_g[rank::world].copy())          # any initial distribution
-        decomp = sd.SlabDecomp(comm, NMESH, BOX)
+        bounds = sd.balanced_bounds(comm, NMESH, BOX, mine[:, 0]) if balanced else None
+        decomp = sd.SlabDecomp(comm, NMESH, BOX, bounds)
         local = sd.exchange_to_owner(comm, decomp, mine)
         nloc = local.shape[0]
         total = comm.allreduce_sum(float(nloc))
         assert int(total) == NPART
         x = local[:, 0].numpy()
         assert np.all((np.floor(x / (BOX / NMESH)) % NMESH >= decomp.plane0) & (np.floor(x / (BOX / NMESH)) % NMESH < decomp.plane0 + decomp.nxl))
+        if balanced:
+            assert nloc < 0.6 * NPART, (nloc, bounds)      # plane granularity limits the balance on this tiny mesh
         # ---- PM ----
         ops = CpuOps(NMESH, BOX, 1.5, G)
         ops.set_deposit_scale(comm.allreduce_sum(float(local[:, 3].sum())))
         ops.set_particles(local, nloc)
-        pm = sd.SlabPM(comm, NMESH, BOX, 1.5, G, ops)
+        pm = sd.SlabPM(comm, NMESH, BOX, 1.5, G, ops, bounds)
         pm.force()
         gpm, ppot = ops.results(nloc)
         # ---- tree with imported ghosts ----
         cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=0)
         sq.gravshort_set_softenings(BOX / np.cbrt(NPART))
         gp = sq.make_grav_params(BOX, 1.5, NMESH, G, cm.RHO0)
-        halo = min(2.0 * gp.Rcut, 0.98 * (decomp.x1 - decomp.x0))   # the test box is tiny: 4 slabs are narrower than 2 Rcut
+        halo = 1.3 * gp.Rcut
         ghosts = sd.ghost_exchange(comm, decomp, local, halo)
         allp = torch.cat([local, ghosts], dim=0).numpy()
         nodes, first, _ = orc.tree_build(allp[:, :3].copy(), allp[:, 3].astype(np.float32), BOX)
@@ -72,14 +75,14 @@ def _worker(rank, world, initfile, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_slab_pm_and_ghost_tree_gloo(world):
+@pytest.mark.parametrize("world,balanced", [(2, False), (4, False), (3, True), (4, True)])
+def test_slab_pm_and_ghost_tree_gloo(world, balanced):
     import orc
     import common as cm
     import shenqi_amd as sq
     with tempfile.TemporaryDirectory() as tmp:
         initfile = os.path.join(tmp, "init")
-        mp.spawn(_worker, args=(world, initfile, tmp), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, initfile, tmp, balanced), nprocs=world, join=True)
         posm_g = _global_particles()
         mass = posm_g[:, 3].astype(np.float32)
         e = 61 - int(np.frexp(float(NPART))[1])
@@ -118,5 +121,5 @@ def test_slab_pm_and_ghost_tree_gloo(world):
             assert 0 < ngh < NPART
         assert seen == NPART
         rms = np.sqrt(num / den)
-        print("world %d: sharded tree vs monolithic rms |dF|/|F| = %.3e" % (world, rms))
+        print("world %d balanced %s: sharded tree vs monolithic rms |dF|/|F| = %.3e" % (world, balanced, rms))
         assert rms < 1e-3

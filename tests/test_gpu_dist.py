@@ -42,7 +42,8 @@ def _run_rank(rank, world, outdir):
     gp_bh = sq.make_grav_params(BOX, 1.5, NMESH, G, cm.RHO0)
     cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=0)
     gp = sq.make_grav_params(BOX, 1.5, NMESH, G, cm.RHO0)
-    drv = sd.DistTreePM(comm, ctx, NMESH, BOX, 1.5, G, dev, halo_factor=2.0 if world <= 2 else 1.3)
+    bounds = sd.balanced_bounds(comm, NMESH, BOX, mine[:, 0]) if world > 1 else None
+    drv = sd.DistTreePM(comm, ctx, NMESH, BOX, 1.5, G, dev, halo_factor=1.3, bounds=bounds)
     local = sd.exchange_to_owner(comm, drv.decomp, mine)
     drv.setup(local, gp.Rcut)
     drv.step(gp_bh)
