@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=256, help="particles per dimension (default 256 = configs[1])")
+    ap.add_argument("--ngrid", dest="n", type=int, default=256, help="particles per dimension (default 256 = configs[1])")
     ap.add_argument("--errtol", type=float, default=0.005)
     ap.add_argument("--kind", default="cluster", choices=["cluster", "uniform", "grid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
