@@ -1,0 +1,97 @@
+"""Committed golden fixtures (tests/golden/, made by tools/make_golden.py from the pinned oracle):
+the oracle must keep reproducing them (CPU), and the HIP path must match them (GPU)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import shenqi_amd as sq
+from shenqi_amd import capi
+import orc
+import common as cm
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _grav_setup(g, usebh):
+    n = len(g["pos"])
+    cm.reference_treepar(ErrTolForceAcc=float(g["errtol"]), MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=usebh)
+    sq.gravshort_set_softenings(float(g["box"]) / np.cbrt(n))
+    return sq.make_grav_params(float(g["box"]), 1.5, int(g["nmesh"]), float(g["G"]), cm.RHO0)
+
+
+def test_oracle_reproduces_golden_treepm():
+    g = np.load(os.path.join(GOLD, "treepm_12cube.npz"))
+    pos, n = g["pos"], len(g["pos"])
+    mass = np.ones(n, dtype=np.float32)
+    nodes, first, _ = orc.tree_build(pos, mass, float(g["box"]))
+    a1, _, n1 = orc.grav_walk(nodes, first, pos, mass, np.zeros(n), _grav_setup(g, 1))
+    a2, p2, n2 = orc.grav_walk(nodes, first, pos, mass, g["oldacc"], _grav_setup(g, 0))
+    assert np.array_equal(n1, g["nint_bh"]) and np.array_equal(n2, g["nint_rel"])
+    assert np.allclose(a1, g["acc_bh"], rtol=0, atol=1e-13 * np.abs(g["acc_bh"]).max())
+    assert np.allclose(a2, g["acc_rel"], rtol=0, atol=1e-13 * np.abs(g["acc_rel"]).max())
+    gpm, ppot, _, _ = orc.pm_force(pos, mass, int(g["nmesh"]), float(g["box"]), 1.5, float(g["G"]))
+    assert np.abs(gpm - g["gravpm"]).max() < 1e-12 * np.abs(g["gravpm"]).max()
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_treepm(ctx):
+    g = np.load(os.path.join(GOLD, "treepm_12cube.npz"))
+    pos, n = g["pos"], len(g["pos"])
+    pman = cm.make_partmanager(pos, box=float(g["box"]))
+    tree = sq.force_tree_full(pman)
+    pv, tv = pman.view(), tree.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    capi.check(capi.hip.shq_tree_upload(ctx.h, C.byref(tv)))
+    pmp = sq.PMParams(int(g["nmesh"]), 0, float(g["box"]), 1.5, float(g["G"]))
+    capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
+    gpm = np.zeros((n, 3)); ppot = np.zeros(n)
+    capi.check(capi.hip.shq_pm_download(ctx.h, capi.ptr(gpm), capi.ptr(ppot)))
+    assert np.abs(gpm - g["gravpm"]).max() < 1e-9 * np.abs(g["gravpm"]).max()
+    assert np.abs(ppot - g["pm_potential"]).max() < 1e-9 * np.abs(g["pm_potential"]).max()
+    acc = np.zeros((n, 3)); pot = np.zeros(n); nint = np.zeros(n, dtype=np.int64)
+    capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(_grav_setup(g, 1)), None, 0, 0, 0))   # OldAcc = 0 after upload
+    capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), None, capi.ptr(nint), None))
+    assert np.array_equal(nint, g["nint_bh"])
+    assert np.abs(acc / float(g["G"]) - g["acc_bh"]).max() < 1e-11 * np.abs(g["acc_bh"]).max()
+
+
+def test_oracle_reproduces_golden_sph():
+    g = np.load(os.path.join(GOLD, "sph_10cube.npz"))
+    n = len(g["pos"])
+    pman, SphP, BhP = cm.make_gas(g["pos"], g["hsml0"], box=float(g["box"]))
+    pman.Base["Vel"] = g["vel"]
+    SphP["Entropy"] = g["entropy"]
+    dp = cm.density_params(DoEgyDensity=1)
+    st = orc.SphState(pman.Base, SphP, BhP)
+    nodes, first, father = orc.tree_build(g["pos"], pman.Base["Mass"], float(g["box"]))
+    rc, evp, _, niter, nint = orc.density(nodes, first, father, st, dp)
+    assert rc == 0 and niter == int(g["niter"]) and nint == int(g["nint_density"])
+    assert np.allclose(st.hsml, g["hsml"], rtol=1e-13) and np.allclose(st.density, g["density"], rtol=1e-12)
+    orc.update_hmax(nodes, first, st)
+    nint_h = orc.hydro(nodes, first, st, cm.hydro_params(), evp)
+    assert nint_h == int(g["nint_hydro"])
+    assert np.abs(st.hydroaccel - g["hydroaccel"]).max() < 1e-12 * np.abs(g["hydroaccel"]).max()
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_sph(ctx):
+    g = np.load(os.path.join(GOLD, "sph_10cube.npz"))
+    pman, SphP, BhP = cm.make_gas(g["pos"], g["hsml0"], box=float(g["box"]))
+    BhP = np.zeros(2, dtype=sq.BH_SLOT_DTYPE)
+    pman.Base["Vel"] = g["vel"]
+    SphP["Entropy"] = g["entropy"]
+    sq.set_densitypar(DensityResolutionEta=1.0, MaxNumNgbDeviation=0.5, DensityKernelType=1, BlackHoleNgbFactor=2.0, MinGasHsml=0.006)
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+    evp, st = sq.density(ctx, None, 1, 1, 0, None, tree, pman, SphP, BhP)
+    assert st.niterations == int(g["niter"]) and st.ninteractions == int(g["nint_density"])
+    assert np.abs(pman.Base["Hsml"] - g["hsml"]).max() < 1e-12
+    assert np.abs(SphP["Density"] - g["density"]).max() < 1e-10 * g["density"].max()
+    assert np.abs(evp - g["entvarpred"]).max() < 1e-13
+    sq.force_tree_update_hmax(tree, pman)
+    sq.set_hydropar(1, 100.0, 0.75)
+    hs = sq.hydro_force(ctx, None, 0.1, cm.HUBBLE, evp, None, tree, pman, SphP)
+    assert hs.ninteractions == int(g["nint_hydro"])
+    assert np.abs(SphP["HydroAccel"] - g["hydroaccel"]).max() < 1e-10 * np.abs(g["hydroaccel"]).max()
+    assert np.abs(SphP["MaxSignalVel"] / g["maxsignalvel"] - 1).max() < 1e-12
