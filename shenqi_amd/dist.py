@@ -252,7 +252,9 @@ class GpuOps:
     def set_particles(self, posm_all, nlocal):
         """posm_all: device tensor [n, 4] (x, y, z, m), the first nlocal rows are this rank's own."""
         t = posm_all.contiguous()
+        torch.cuda.current_stream(self.device).synchronize()   # torch produced t on its stream; the library copies on its own
         capi.check(capi.hip.shq_particles_set_device(self.ctx.h, C.c_void_p(t.data_ptr()), t.shape[0], nlocal))
+        self.ctx.synchronize()
         self._keep = t
 
     def set_deposit_scale(self, total_mass):
