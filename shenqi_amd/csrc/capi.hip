@@ -126,7 +126,7 @@ extern "C" void shq_shutdown(shq_context *ctx)
     ctx->posm.release(); ctx->oldacc.release(); ctx->treeacc.release(); ctx->gravpm.release();
     ctx->pmpot.release(); ctx->acc.release(); ctx->pot.release(); ctx->nint.release();
     ctx->pflags.release(); ctx->active.release(); ctx->gstats.release();
-    ctx->nodeA.release(); ctx->nodeB.release(); ctx->nodeC.release();
+    ctx->nodeA.release(); ctx->nodeB.release(); ctx->nodeC.release(); ctx->nodeG.release();
     ctx->posm_leaf.release(); ctx->leaf_pidx.release();
     ctx->mesh.release(); ctx->sinctab.release(); ctx->dbg_rho.release(); ctx->dbg_pot.release();
     ctx->gravtab.release(); ctx->stage.release();
@@ -358,6 +358,28 @@ extern "C" int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree)
     SHQ_HIP(hipMemcpyAsync(ctx->nodeA.ptr, hA.data(), sizeof(NodeA) * (nn + 1), hipMemcpyHostToDevice, ctx->stream));
     SHQ_HIP(hipMemcpyAsync(ctx->nodeB.ptr, hB.data(), sizeof(NodeB) * (nn + 1), hipMemcpyHostToDevice, ctx->stream));
     SHQ_HIP(hipMemcpyAsync(ctx->nodeC.ptr, hC.data(), sizeof(NodeC) * (nn + 1), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<NodeG> hG(nn + 1);
+    parallel_for(nn + 1, [&](int64_t lo, int64_t hi) {
+        for(int64_t j = lo; j < hi; j++) {
+            NodeG g;
+            memset(&g, 0, sizeof(g));
+            for(int k = 0; k < 3; k++) {
+                g.cofm[k] = hA[j].cofm[k];
+                g.center[k] = hB[j].center[k];
+            }
+            g.mass = hA[j].mass;
+            g.len = hB[j].len;
+            g.sibling = hC[j].sibling; g.child = hC[j].child; g.type = hC[j].type; g.count = hC[j].count;
+            g.len2 = g.len * g.len;
+            g.mlen2 = g.mass * g.len * g.len; /* (mass * len) * len, as shall_we_open_node evaluates it */
+            g.inside = 0.6 * g.len;
+            g.halflen = 0.5 * g.len;
+            hG[j] = g;
+        }
+    });
+    SHQ_TRY(ctx->nodeG.reserve(nn + 1));
+    SHQ_HIP(hipMemcpyAsync(ctx->nodeG.ptr, hG.data(), sizeof(NodeG) * (nn + 1), hipMemcpyHostToDevice, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
     {
         const int64_t npad = (int64_t) pidx.size();
         SHQ_HIP(hipMemcpyAsync(ctx->leaf_pidx.ptr, pidx.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice, ctx->stream));

@@ -102,6 +102,19 @@ struct NodeB { double center[3]; double len; };  /* 32 B */
 struct NodeC { int32_t sibling; int32_t child; int32_t type; int32_t count; }; /* 16 B: child = first
     child node (NODE) or first leaf-order particle slot (PARTICLE); count = noccupied for leaves */
 struct NodeH { double hmax; };                    /* SPH only */
+/* Gravity walk record: everything one node test needs in one 128-byte aligned line, including the
+ * per-node products the opening tests use (computed once at pack time instead of per visit). */
+struct alignas(128) NodeG {
+    double cofm[3], mass;
+    double center[3], len;
+    int32_t sibling, child, type, count;
+    double len2;     /* len * len */
+    double mlen2;    /* mass * len * len */
+    double inside;   /* 0.6 * len */
+    double halflen;  /* 0.5 * len */
+    double pad_[2];
+};
+static_assert(sizeof(NodeG) == 128, "NodeG must be one 128-byte line");
 
 struct GravStatsDev {
     unsigned long long ninteractions;
@@ -164,6 +177,7 @@ struct shq_context {
     DevBuf<NodeA> nodeA;
     DevBuf<NodeB> nodeB;
     DevBuf<NodeC> nodeC;
+    DevBuf<NodeG> nodeG;       /* merged record for the gravity walk */
     DevBuf<double4> posm_leaf; /* leaf-ordered copy of (x,y,z,m) */
     DevBuf<int32_t> leaf_pidx; /* leaf slot -> particle index */
     bool have_tree = false;

@@ -30,9 +30,7 @@
 namespace {
 
 struct WalkArgs {
-    const NodeA *nodeA;
-    const NodeB *nodeB;
-    const NodeC *nodeC;
+    const NodeG *nodeG;
     const double4 *posm;       /* by particle index */
     const double4 *posm_leaf;  /* leaf order */
     const double *oldacc;
@@ -43,7 +41,7 @@ struct WalkArgs {
     GravStatsDev *stats;
     long long ntargets;
     int root;
-    double Box, invBox;
+    double Box, invBox, halfBox;
     double rcut, rcut2;
     double h, h2, h_inv, h3_inv;
     double inv_celldx;         /* 1 / (cellsize * dx) */
@@ -124,9 +122,12 @@ __device__ __forceinline__ void leaf_particle(const double4 *__restrict__ tab, c
                                               double pz, const WalkArgs &a, double &ax, double &ay, double &az,
                                               double &pot)
 {
-    const double ex = wrapd(q.x - px, a.Box, a.invBox);
-    const double ey = wrapd(q.y - py, a.Box, a.invBox);
-    const double ez = wrapd(q.z - pz, a.Box, a.invBox);
+    double ex = q.x - px, ey = q.y - py, ez = q.z - pz;
+    if(__ballot(fmax(fmax(fabs(ex), fabs(ey)), fabs(ez)) > a.halfBox) != 0ull) {
+        ex = wrapd(ex, a.Box, a.invBox);
+        ey = wrapd(ey, a.Box, a.invBox);
+        ez = wrapd(ez, a.Box, a.invBox);
+    }
     const double rr2 = ex * ex + ey * ey + ez * ez;
     apply_accn<POT>(tab, ex, ey, ez, rr2, q.w, a, ax, ay, az, pot);
 }
@@ -164,40 +165,37 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
     int cur = a.root;
     unsigned int visited = 0, wave_applies = 0, wave_node_applies = 0;
 
-    NodeA A = a.nodeA[cur];
-    NodeB B = a.nodeB[cur];
-    NodeC C = a.nodeC[cur];
+    NodeG nd = a.nodeG[cur];
 
     while(cur >= 0) {
-        NodeA A1;
-        NodeB B1;
-        NodeC C1;
-        if(PREFETCH) { /* pool is padded by one record */
-            A1 = a.nodeA[cur + 1];
-            B1 = a.nodeB[cur + 1];
-            C1 = a.nodeC[cur + 1];
-        }
+        NodeG nd1;
+        if(PREFETCH) /* pool is padded by one record */
+            nd1 = a.nodeG[cur + 1];
         if(STATS)
             visited++;
         const bool act = (mynext == cur);
 
         /* gravshort2.hpp:262-265 */
-        const double dx = wrapd(A.cofm[0] - px, a.Box, a.invBox);
-        const double dy = wrapd(A.cofm[1] - py, a.Box, a.invBox);
-        const double dz = wrapd(A.cofm[2] - pz, a.Box, a.invBox);
+        /* The periodic wrap is the identity unless some |d| exceeds L/2; one wave-uniform test
+         * skips the six wraps (24 f64 instructions) for the overwhelming majority of nodes. */
+        double dx = nd.cofm[0] - px, dy = nd.cofm[1] - py, dz = nd.cofm[2] - pz;
+        double ux = nd.center[0] - px, uy = nd.center[1] - py, uz = nd.center[2] - pz;
+        if(__ballot(fmax(fmax(fmax(fabs(dx), fabs(dy)), fabs(dz)), fmax(fmax(fabs(ux), fabs(uy)), fabs(uz))) > a.halfBox) != 0ull) {
+            dx = wrapd(dx, a.Box, a.invBox);
+            dy = wrapd(dy, a.Box, a.invBox);
+            dz = wrapd(dz, a.Box, a.invBox);
+            ux = wrapd(ux, a.Box, a.invBox);
+            uy = wrapd(uy, a.Box, a.invBox);
+            uz = wrapd(uz, a.Box, a.invBox);
+        }
         const double r2 = dx * dx + dy * dy + dz * dz;
-        const double cx = fabs(wrapd(B.center[0] - px, a.Box, a.invBox));
-        const double cy = fabs(wrapd(B.center[1] - py, a.Box, a.invBox));
-        const double cz = fabs(wrapd(B.center[2] - pz, a.Box, a.invBox));
-        const double len = B.len;
+        const double cx = fabs(ux), cy = fabs(uy), cz = fabs(uz);
         /* shall_we_discard_node, gravshort2.hpp:152-167 */
-        const double eff = a.rcut + 0.5 * len;
-        const bool discard = (r2 > a.rcut2) && (fmax(fmax(cx, cy), cz) > eff);
-        /* shall_we_open_node, gravshort2.hpp:172-193 (len*len/r2 > theta2 written without the divide) */
-        const double len2 = len * len;
-        const double inside = 0.6 * len;
-        const bool open = ((a.useBH == 0) && (A.mass * len2 > r2 * r2 * aold)) || (len2 > r2 * a.bh2) ||
-                          (fmax(fmax(cx, cy), cz) < inside);
+        const double cmax = fmax(fmax(cx, cy), cz);
+        const bool discard = (r2 > a.rcut2) && (cmax > a.rcut + nd.halflen);
+        /* shall_we_open_node, gravshort2.hpp:172-193 (len*len/r2 > theta2 written without the divide;
+         * mass*len*len and 0.6*len come precomputed with the node) */
+        const bool open = ((a.useBH == 0) && (nd.mlen2 > r2 * r2 * aold)) || (nd.len2 > r2 * a.bh2) || (cmax < nd.inside);
         const bool accept = act && !discard && !open;
         const bool doopen = act && !discard && open;
 
@@ -207,18 +205,18 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
                 wave_node_applies++;
             }
             if(accept) {
-                apply_accn<POT>(tab, dx, dy, dz, r2, A.mass, a, ax, ay, az, pot);
+                apply_accn<POT>(tab, dx, dy, dz, r2, nd.mass, a, ax, ay, az, pot);
                 nint++;
                 if(STATS)
                     nint_node++;
             }
         }
         int next;
-        if(C.type == SHQ_PARTICLE_NODE_TYPE) {
+        if(nd.type == SHQ_PARTICLE_NODE_TYPE) {
             /* gravshort2.hpp:290-304: every particle of an opened leaf is evaluated */
             if(__ballot(doopen) != 0ull) {
-                const double4 *__restrict__ lp = a.posm_leaf + C.child;
-                const int cnt = C.count;
+                const double4 *__restrict__ lp = a.posm_leaf + nd.child;
+                const int cnt = nd.count;
                 if(STATS)
                     wave_applies += cnt;
                 /* leaf slots are contiguous and the array is padded by NMAXCHILD entries */
@@ -241,29 +239,24 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
                     nint += cnt;
             }
             if(act)
-                mynext = C.sibling;
-            next = C.sibling;
-        } else if(C.type == SHQ_PSEUDO_NODE_TYPE) {
+                mynext = nd.sibling;
+            next = nd.sibling;
+        } else if(nd.type == SHQ_PSEUDO_NODE_TYPE) {
             /* gravshort2.hpp:305-315: pseudo nodes are skipped by the local walk */
             if(act)
-                mynext = C.sibling;
-            next = C.sibling;
+                mynext = nd.sibling;
+            next = nd.sibling;
         } else {
             const bool anyopen = __ballot(doopen) != 0ull;
             if(act)
-                mynext = doopen ? C.child : C.sibling;
-            next = anyopen ? C.child : C.sibling;
+                mynext = doopen ? nd.child : nd.sibling;
+            next = anyopen ? nd.child : nd.sibling;
         }
         next = __builtin_amdgcn_readfirstlane(next);
-        if(PREFETCH && next == cur + 1) {
-            A = A1;
-            B = B1;
-            C = C1;
-        } else if(next >= 0) {
-            A = a.nodeA[next];
-            B = a.nodeB[next];
-            C = a.nodeC[next];
-        }
+        if(PREFETCH && next == cur + 1)
+            nd = nd1;
+        else if(next >= 0)
+            nd = a.nodeG[next];
         cur = next;
     }
 
@@ -378,9 +371,7 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
         return SHQ_OK;
 
     WalkArgs a;
-    a.nodeA = ctx->nodeA.ptr;
-    a.nodeB = ctx->nodeB.ptr;
-    a.nodeC = ctx->nodeC.ptr;
+    a.nodeG = ctx->nodeG.ptr;
     a.posm = ctx->posm.ptr;
     a.posm_leaf = ctx->posm_leaf.ptr;
     a.oldacc = ctx->oldacc.ptr;
@@ -393,6 +384,7 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     a.root = ctx->root;
     a.Box = p->BoxSize;
     a.invBox = 1.0 / p->BoxSize;
+    a.halfBox = 0.5 * p->BoxSize;
     a.rcut = p->Rcut;
     a.rcut2 = p->Rcut * p->Rcut;
     a.h = p->ForceSoftening;
