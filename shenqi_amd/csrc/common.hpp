@@ -205,6 +205,10 @@ struct shq_context {
     int pm_nmesh = 0;
     hipfftHandle plan_r2c = 0, plan_c2r = 0;
     bool have_plans = false;
+    bool pm_custom_fft = false; /* bespoke 5-pass FFT pipeline (fft3d.hip) instead of rocFFT */
+    int pm_zp = 0;             /* z pitch of the mesh in doubles */
+    DevBuf<double> fft_tw;     /* twiddles exp(-2 pi i k / N) */
+    int fft_tw_n = 0;
     DevBuf<double> mesh;       /* padded in-place real/complex mesh: N*N*(N+2) doubles */
     DevBuf<double> sinctab;    /* 1/sinc^2 per mesh index */
     int sinctab_n = 0;
@@ -238,6 +242,11 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm);
 void shq_pm_destroy_plans(shq_context *ctx);
 int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *complx);
 int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double *real);
+/* fft3d.hip */
+bool shq_fft3d_supported(int N);
+int shq_fft3d_pitch(int N);
+int shq_fft3d_run(shq_context *ctx, double *d_mesh, int N, int zp, int stage, bool from_i64, double inv_scale,
+                  const double *d_sinctab, double asmth2, double pot_factor);
 /* sph.hip */
 int shq_sph_prepare(shq_context *ctx, const shq_kick_factors *kf, const shq_hydro_params *hp, const double *d_evp_in);
 int shq_sph_density_device(shq_context *ctx, const shq_density_params *p, const int32_t *d_queue, int64_t nq,

@@ -20,6 +20,7 @@
  */
 #include "common.hpp"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -67,7 +68,7 @@ __global__ void pm_zero_kernel(unsigned long long *mesh, size_t n)
 #define DEP_CHUNK (256 * DEP_PPT)
 
 __global__ __launch_bounds__(256) void pm_deposit_kernel(const double4 *__restrict__ posm, const uint8_t *__restrict__ pflags,
-                                                         long long n, unsigned long long *mesh, int N, double cell,
+                                                         long long n, unsigned long long *mesh, int N, int zp, double cell,
                                                          double scale, int xshift, int nxalloc, int *oob)
 {
     __shared__ unsigned long long tile[DEP_T * DEP_T * DEP_T];
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void pm_deposit_kernel(const double4 *__restri
     __syncthreads();
     const int m0 = s_min[0], m1 = s_min[1], m2 = s_min[2];
     const bool fits = (s_max[0] - m0 + 2 <= DEP_T) && (s_max[1] - m1 + 2 <= DEP_T) && (s_max[2] - m2 + 2 <= DEP_T);
-    const size_t sy = (size_t) (N + 2), sx = (size_t) N * (N + 2);
+    const size_t sy = (size_t) zp, sx = (size_t) N * zp;
     if(fits) {
         for(int c = tid; c < DEP_T * DEP_T * DEP_T; c += 256)
             tile[c] = 0ull;
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void pm_green_kernel(double2 *cmesh, int N, in
 /* readout_potential / readout_force_{x,y,z}, gravpm.cpp:489-500, with the force obtained by
  * 4-point differencing of the potential mesh (see file header). */
 __global__ __launch_bounds__(256) void pm_readout_kernel(const double4 *__restrict__ posm, const uint8_t *__restrict__ pflags,
-                                                         long long n, const double *__restrict__ mesh, int N,
+                                                         long long n, const double *__restrict__ mesh, int N, int zp,
                                                          double cell, double ffac, double *gravpm, double *pmpot, int xshift,
                                                          int nxalloc, int *oob)
 {
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void pm_readout_kernel(const double4 *__restri
         cic_setup(p.x, cell, N, ic[0], res[0]);
         cic_setup(p.y, cell, N, ic[1], res[1]);
         cic_setup(p.z, cell, N, ic[2], res[2]);
-        const size_t sy = (size_t) (N + 2), sx = (size_t) N * (N + 2);
+        const size_t sy = (size_t) zp, sx = (size_t) N * zp;
         /* wrapped indices for offsets -2..3 along every axis */
         size_t ox[6], oy[6], oz[6];
 #pragma unroll
@@ -281,25 +282,20 @@ __global__ __launch_bounds__(256) void pm_readout_kernel(const double4 *__restri
     pmpot[i] = gp;
 }
 
-__global__ void pm_unpad_kernel(const double *mesh, double *dense, int N)
+/* copy rows of `len` doubles between pitches; as_i64: the source holds fixed-point integers */
+__global__ void pm_repitch_kernel(const double *src, double *dst, size_t nrows, int len, int spitch, int dpitch, int as_i64,
+                                  double inv_scale)
 {
-    const size_t total = (size_t) N * N * N;
+    const size_t total = nrows * (size_t) len;
     size_t ip = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if(ip >= total)
         return;
-    const int z = (int) (ip % N);
-    const size_t xy = ip / N;
-    dense[ip] = mesh[xy * (N + 2) + z];
-}
-__global__ void pm_pad_kernel(const double *dense, double *mesh, int N)
-{
-    const size_t total = (size_t) N * N * N;
-    size_t ip = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if(ip >= total)
-        return;
-    const int z = (int) (ip % N);
-    const size_t xy = ip / N;
-    mesh[xy * (N + 2) + z] = dense[ip];
+    const int z = (int) (ip % len);
+    const size_t row = ip / len;
+    if(as_i64)
+        dst[row * dpitch + z] = (double) reinterpret_cast<const long long *>(src)[row * spitch + z] * inv_scale;
+    else
+        dst[row * dpitch + z] = src[row * spitch + z];
 }
 
 } // namespace
@@ -310,17 +306,20 @@ void shq_pm_destroy_plans(shq_context *ctx)
         hipfftDestroy(ctx->plan_r2c);
         hipfftDestroy(ctx->plan_c2r);
         ctx->have_plans = false;
-        ctx->pm_nmesh = 0;
     }
+    ctx->pm_nmesh = 0;
+    ctx->pm_custom_fft = false;
 }
 
 static int pm_prepare(shq_context *ctx, int N)
 {
     SHQ_CHECK(N >= 4 && N % 2 == 0, SHQ_ERR_INVALID, "Nmesh must be even and >= 4 (got %d)", N);
-    if(ctx->have_plans && ctx->pm_nmesh == N)
+    if(ctx->pm_nmesh == N && (ctx->have_plans || ctx->pm_custom_fft))
         return SHQ_OK;
     shq_pm_destroy_plans(ctx);
-    const size_t padded = (size_t) N * N * (N + 2);
+    ctx->pm_custom_fft = shq_fft3d_supported(N) && !getenv("SHQ_PM_ROCFFT");
+    ctx->pm_zp = ctx->pm_custom_fft ? shq_fft3d_pitch(N) : N + 2;
+    const size_t padded = (size_t) N * N * ctx->pm_zp;
     SHQ_TRY(ctx->mesh.reserve(padded));
     SHQ_TRY(ctx->sinctab.reserve(N));
     SHQ_TRY(ctx->pm_oob.reserve(1));
@@ -340,6 +339,9 @@ static int pm_prepare(shq_context *ctx, int N)
     }
     SHQ_HIP(hipMemcpy(ctx->sinctab.ptr, tab.data(), sizeof(double) * N, hipMemcpyHostToDevice));
     ctx->sinctab_n = N;
+    ctx->pm_nmesh = N;
+    if(ctx->pm_custom_fft)
+        return SHQ_OK;
     hipfftResult r = hipfftPlan3d(&ctx->plan_r2c, N, N, N, HIPFFT_D2Z);
     SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftPlan3d(D2Z, %d) failed: %d", N, (int) r);
     r = hipfftPlan3d(&ctx->plan_c2r, N, N, N, HIPFFT_Z2D);
@@ -357,51 +359,62 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
     SHQ_CHECK(pm->BoxSize > 0 && pm->Asmth > 0, SHQ_ERR_INVALID, "pm params: BoxSize and Asmth must be > 0");
     const int N = pm->Nmesh;
     SHQ_TRY(pm_prepare(ctx, N));
-    const size_t padded = (size_t) N * N * (N + 2);
+    const int zp = ctx->pm_zp;
+    const size_t padded = (size_t) N * N * zp;
     const int Nc = N / 2 + 1;
     const double cell = pm->BoxSize / N; /* CellSize */
     const long long n = ctx->numpart;
     /* fixed-point scale: 2^e with e chosen so that the whole mass in one cell cannot overflow */
-    int e = ctx->pm_log2scale;
+    const int e = ctx->pm_log2scale;
     const double scale = ldexp(1.0, e);
     const int threads = 256;
+    const size_t dense = (size_t) N * N * N;
+    const double asmth2 = pow((2 * M_PI) * pm->Asmth / N, 2);
+    const double pot_factor = -pm->G / (M_PI * pm->BoxSize);
 
     SHQ_HIP(hipEventRecord(ctx->ev_begin[8], ctx->stream));
     pm_zero_kernel<<<dim3(2048), dim3(threads), 0, ctx->stream>>>((unsigned long long *) ctx->mesh.ptr, padded);
     if(n > 0)
         pm_deposit_kernel<<<dim3((unsigned) ((n + DEP_CHUNK - 1) / DEP_CHUNK)), dim3(256), 0, ctx->stream>>>(
-            ctx->posm.ptr, ctx->pflags.ptr, n, (unsigned long long *) ctx->mesh.ptr, N, cell, scale, 0, N, ctx->pm_oob.ptr);
-    pm_convert_kernel<<<dim3(2048), dim3(threads), 0, ctx->stream>>>(ctx->mesh.ptr, padded, 1.0 / scale);
-    SHQ_HIP(hipGetLastError());
+            ctx->posm.ptr, ctx->pflags.ptr, n, (unsigned long long *) ctx->mesh.ptr, N, zp, cell, scale, 0, N, ctx->pm_oob.ptr);
     if(ctx->pm_keep) {
-        SHQ_TRY(ctx->dbg_rho.reserve((size_t) N * N * N));
-        const size_t tot = (size_t) N * N * N;
-        pm_unpad_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(ctx->mesh.ptr, ctx->dbg_rho.ptr, N);
+        SHQ_TRY(ctx->dbg_rho.reserve(dense));
+        pm_repitch_kernel<<<dim3((unsigned) ((dense + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+            ctx->mesh.ptr, ctx->dbg_rho.ptr, (size_t) N * N, N, zp, N, 1, 1.0 / scale);
     }
-    SHQ_HIP(hipEventRecord(ctx->ev_begin[9], ctx->stream));
-    hipfftResult r = hipfftExecD2Z(ctx->plan_r2c, (hipfftDoubleReal *) ctx->mesh.ptr, (hipfftDoubleComplex *) ctx->mesh.ptr);
-    SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecD2Z failed: %d", (int) r);
-    SHQ_HIP(hipEventRecord(ctx->ev_begin[10], ctx->stream));
-    {
-        const size_t tot = (size_t) N * N * Nc;
-        const double asmth2 = pow((2 * M_PI) * pm->Asmth / N, 2);
-        const double pot_factor = -pm->G / (M_PI * pm->BoxSize);
-        pm_green_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-            (double2 *) ctx->mesh.ptr, N, Nc, ctx->sinctab.ptr, asmth2, pot_factor);
+    if(ctx->pm_custom_fft) {
+        /* five fused passes: Z fwd (+ int64 -> f64), Y fwd, X fwd + potential_transfer + X inv, Y inv, Z inv */
+        SHQ_HIP(hipEventRecord(ctx->ev_begin[9], ctx->stream));
+        SHQ_TRY(shq_fft3d_run(ctx, ctx->mesh.ptr, N, zp, 2, true, 1.0 / scale, ctx->sinctab.ptr, asmth2, pot_factor));
+        SHQ_HIP(hipEventRecord(ctx->ev_begin[10], ctx->stream));
+        SHQ_HIP(hipEventRecord(ctx->ev_begin[11], ctx->stream));
+        SHQ_HIP(hipEventRecord(ctx->ev_begin[12], ctx->stream));
+    } else {
+        pm_convert_kernel<<<dim3(2048), dim3(threads), 0, ctx->stream>>>(ctx->mesh.ptr, padded, 1.0 / scale);
+        SHQ_HIP(hipGetLastError());
+        SHQ_HIP(hipEventRecord(ctx->ev_begin[9], ctx->stream));
+        hipfftResult r = hipfftExecD2Z(ctx->plan_r2c, (hipfftDoubleReal *) ctx->mesh.ptr, (hipfftDoubleComplex *) ctx->mesh.ptr);
+        SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecD2Z failed: %d", (int) r);
+        SHQ_HIP(hipEventRecord(ctx->ev_begin[10], ctx->stream));
+        {
+            const size_t tot = (size_t) N * N * Nc;
+            pm_green_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+                (double2 *) ctx->mesh.ptr, N, Nc, ctx->sinctab.ptr, asmth2, pot_factor);
+        }
+        SHQ_HIP(hipEventRecord(ctx->ev_begin[11], ctx->stream));
+        r = hipfftExecZ2D(ctx->plan_c2r, (hipfftDoubleComplex *) ctx->mesh.ptr, (hipfftDoubleReal *) ctx->mesh.ptr);
+        SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecZ2D failed: %d", (int) r);
+        SHQ_HIP(hipEventRecord(ctx->ev_begin[12], ctx->stream));
     }
-    SHQ_HIP(hipEventRecord(ctx->ev_begin[11], ctx->stream));
-    r = hipfftExecZ2D(ctx->plan_c2r, (hipfftDoubleComplex *) ctx->mesh.ptr, (hipfftDoubleReal *) ctx->mesh.ptr);
-    SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecZ2D failed: %d", (int) r);
-    SHQ_HIP(hipEventRecord(ctx->ev_begin[12], ctx->stream));
     if(ctx->pm_keep) {
-        SHQ_TRY(ctx->dbg_pot.reserve((size_t) N * N * N));
-        const size_t tot = (size_t) N * N * N;
-        pm_unpad_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(ctx->mesh.ptr, ctx->dbg_pot.ptr, N);
+        SHQ_TRY(ctx->dbg_pot.reserve(dense));
+        pm_repitch_kernel<<<dim3((unsigned) ((dense + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+            ctx->mesh.ptr, ctx->dbg_pot.ptr, (size_t) N * N, N, zp, N, 0, 1.0);
     }
     if(n > 0) {
         const double ffac = -(N / pm->BoxSize);
         pm_readout_kernel<<<dim3((unsigned) ((n + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-            ctx->posm.ptr, ctx->pflags.ptr, n, ctx->mesh.ptr, N, cell, ffac, ctx->gravpm.ptr, ctx->pmpot.ptr, 0, N, ctx->pm_oob.ptr);
+            ctx->posm.ptr, ctx->pflags.ptr, n, ctx->mesh.ptr, N, zp, cell, ffac, ctx->gravpm.ptr, ctx->pmpot.ptr, 0, N, ctx->pm_oob.ptr);
     }
     SHQ_HIP(hipGetLastError());
     SHQ_HIP(hipEventRecord(ctx->ev_begin[13], ctx->stream));
@@ -412,15 +425,23 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
 int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *complx)
 {
     SHQ_TRY(pm_prepare(ctx, N));
-    const size_t tot = (size_t) N * N * N;
+    const int zp = ctx->pm_zp;
+    const size_t tot = (size_t) N * N * N, ctot = (size_t) N * N * (N + 2);
     DevBuf<double> dense;
-    SHQ_TRY(dense.reserve(tot));
+    SHQ_TRY(dense.reserve(ctot));
     SHQ_HIP(hipMemcpyAsync(dense.ptr, real, tot * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     const int threads = 256;
-    pm_pad_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(dense.ptr, ctx->mesh.ptr, N);
-    hipfftResult r = hipfftExecD2Z(ctx->plan_r2c, (hipfftDoubleReal *) ctx->mesh.ptr, (hipfftDoubleComplex *) ctx->mesh.ptr);
-    SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecD2Z failed: %d", (int) r);
-    SHQ_HIP(hipMemcpyAsync(complx, ctx->mesh.ptr, (size_t) N * N * (N + 2) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    pm_repitch_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+        dense.ptr, ctx->mesh.ptr, (size_t) N * N, N, N, zp, 0, 1.0);
+    if(ctx->pm_custom_fft)
+        SHQ_TRY(shq_fft3d_run(ctx, ctx->mesh.ptr, N, zp, 0, false, 1.0, ctx->sinctab.ptr, 0, 0));
+    else {
+        hipfftResult r = hipfftExecD2Z(ctx->plan_r2c, (hipfftDoubleReal *) ctx->mesh.ptr, (hipfftDoubleComplex *) ctx->mesh.ptr);
+        SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecD2Z failed: %d", (int) r);
+    }
+    pm_repitch_kernel<<<dim3((unsigned) ((ctot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+        ctx->mesh.ptr, dense.ptr, (size_t) N * N, N + 2, zp, N + 2, 0, 1.0);
+    SHQ_HIP(hipMemcpyAsync(complx, dense.ptr, ctot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     dense.release();
     return SHQ_OK;
@@ -429,14 +450,22 @@ int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *c
 int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double *real)
 {
     SHQ_TRY(pm_prepare(ctx, N));
-    const size_t tot = (size_t) N * N * N;
+    const int zp = ctx->pm_zp;
+    const size_t tot = (size_t) N * N * N, ctot = (size_t) N * N * (N + 2);
     DevBuf<double> dense;
-    SHQ_TRY(dense.reserve(tot));
-    SHQ_HIP(hipMemcpyAsync(ctx->mesh.ptr, complx, (size_t) N * N * (N + 2) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    hipfftResult r = hipfftExecZ2D(ctx->plan_c2r, (hipfftDoubleComplex *) ctx->mesh.ptr, (hipfftDoubleReal *) ctx->mesh.ptr);
-    SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecZ2D failed: %d", (int) r);
+    SHQ_TRY(dense.reserve(ctot));
+    SHQ_HIP(hipMemcpyAsync(dense.ptr, complx, ctot * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     const int threads = 256;
-    pm_unpad_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(ctx->mesh.ptr, dense.ptr, N);
+    pm_repitch_kernel<<<dim3((unsigned) ((ctot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+        dense.ptr, ctx->mesh.ptr, (size_t) N * N, N + 2, N + 2, zp, 0, 1.0);
+    if(ctx->pm_custom_fft)
+        SHQ_TRY(shq_fft3d_run(ctx, ctx->mesh.ptr, N, zp, 1, false, 1.0, ctx->sinctab.ptr, 0, 0));
+    else {
+        hipfftResult r = hipfftExecZ2D(ctx->plan_c2r, (hipfftDoubleComplex *) ctx->mesh.ptr, (hipfftDoubleReal *) ctx->mesh.ptr);
+        SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecZ2D failed: %d", (int) r);
+    }
+    pm_repitch_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+        ctx->mesh.ptr, dense.ptr, (size_t) N * N, N, zp, N, 0, 1.0);
     SHQ_HIP(hipMemcpyAsync(real, dense.ptr, tot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     dense.release();
@@ -494,7 +523,7 @@ extern "C" int shq_pm_slab_deposit(shq_context *ctx, const shq_pm_params *pm, in
     const long long n = ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart;
     if(n > 0)
         pm_deposit_kernel<<<dim3((unsigned) ((n + DEP_CHUNK - 1) / DEP_CHUNK)), dim3(256), 0, ctx->stream>>>(
-            ctx->posm.ptr, ctx->pflags.ptr, n, (unsigned long long *) d_mesh_i64, N, pm->BoxSize / N, ldexp(1.0, ctx->pm_log2scale),
+            ctx->posm.ptr, ctx->pflags.ptr, n, (unsigned long long *) d_mesh_i64, N, N + 2, pm->BoxSize / N, ldexp(1.0, ctx->pm_log2scale),
             plane0, nalloc, ctx->pm_oob.ptr);
     SHQ_HIP(hipGetLastError());
     return check_oob(ctx, "pm_slab_deposit");
@@ -514,7 +543,7 @@ extern "C" int shq_pm_slab_readout(shq_context *ctx, const shq_pm_params *pm, in
     const int xshift = nplanes == N ? 0 : plane0 - 2;
     if(n > 0)
         pm_readout_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(
-            ctx->posm.ptr, ctx->pflags.ptr, n, (const double *) d_phi_ext, N, pm->BoxSize / N, -(N / pm->BoxSize), ctx->gravpm.ptr,
+            ctx->posm.ptr, ctx->pflags.ptr, n, (const double *) d_phi_ext, N, N + 2, pm->BoxSize / N, -(N / pm->BoxSize), ctx->gravpm.ptr,
             ctx->pmpot.ptr, xshift, nalloc, ctx->pm_oob.ptr);
     SHQ_HIP(hipGetLastError());
     ctx->have_pm_result = true;
