@@ -22,18 +22,12 @@
  */
 #include "common.hpp"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
 #define FFT_C 4        /* complex lines per workgroup */
 #define FFT_T 256      /* threads per workgroup */
-#define FFT_K 4        /* max butterflies per thread per stage (N <= 1024) */
-
-struct FftPlan {
-    int N;
-    int nstages;
-    int radix[12];
-};
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
@@ -46,53 +40,112 @@ template <int DIR> __device__ __forceinline__ double2 tw(const double2 *__restri
     const double2 w = W[idx];
     return DIR < 0 ? w : conj2(w);
 }
-
-/* One Stockham stage of radix R on C lines of length N held in LDS with line stride LS.
- * n = current sub-transform length, s = stride (product of the radices already applied). */
-template <int R, int DIR>
-__device__ __forceinline__ void fft_stage(double2 *buf, const int N, const int LS, const int n, const int s,
-                                          const double2 *__restrict__ W)
+/* exp(DIR * 2 pi i m / 16) for the in-register radix-16 butterfly */
+template <int DIR, int M> __device__ __forceinline__ double2 w16()
 {
-    const int m = n / R;
-    const int nb = N / R;               /* butterflies per line */
-    const int total = FFT_C * nb;
-    double2 v[FFT_K][R];
+    constexpr double c[16] = {1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173, 0.0,
+                              -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848, -1.0,
+                              -0.92387953251128673848, -0.70710678118654752440, -0.38268343236508977173, 0.0,
+                              0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848};
+    constexpr double sn[16] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848, 1.0,
+                               0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173, 0.0,
+                               -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848, -1.0,
+                               -0.92387953251128673848, -0.70710678118654752440, -0.38268343236508977173};
+    return make_double2(c[M & 15], (DIR < 0 ? -1.0 : 1.0) * sn[M & 15]);
+}
+
+template <int DIR> __device__ __forceinline__ void bfly4(double2 &a0, double2 &a1, double2 &a2, double2 &a3)
+{
+    const double2 t0 = cadd(a0, a2), t1 = csub(a0, a2);
+    const double2 t2 = cadd(a1, a3), t3 = rot<DIR>(csub(a1, a3));
+    a0 = cadd(t0, t2);
+    a1 = cadd(t1, t3);
+    a2 = csub(t0, t2);
+    a3 = csub(t1, t3);
+}
+
+/* b[k] = sum_j a[j] w16^(jk), in place, output in natural order k = k1 + 4 k0 stored at a[k] */
+template <int DIR> __device__ __forceinline__ void bfly16(double2 (&a)[16])
+{
+    /* j = j0 + 4 j1: radix-4 over j1 for every j0 -> t[j0][k1] stored at a[j0 + 4 k1] */
 #pragma unroll
-    for(int kk = 0; kk < FFT_K; kk++) {
+    for(int j0 = 0; j0 < 4; j0++)
+        bfly4<DIR>(a[j0], a[j0 + 4], a[j0 + 8], a[j0 + 12]);
+    /* twiddle w16^(j0 k1) */
+    a[1 + 4] = cmul(a[1 + 4], w16<DIR, 1>());
+    a[2 + 4] = cmul(a[2 + 4], w16<DIR, 2>());
+    a[3 + 4] = cmul(a[3 + 4], w16<DIR, 3>());
+    a[1 + 8] = cmul(a[1 + 8], w16<DIR, 2>());
+    a[2 + 8] = cmul(a[2 + 8], w16<DIR, 4>());
+    a[3 + 8] = cmul(a[3 + 8], w16<DIR, 6>());
+    a[1 + 12] = cmul(a[1 + 12], w16<DIR, 3>());
+    a[2 + 12] = cmul(a[2 + 12], w16<DIR, 6>());
+    a[3 + 12] = cmul(a[3 + 12], w16<DIR, 9>());
+    /* radix-4 over j0 for every k1: b[k1 + 4 k0] */
+#pragma unroll
+    for(int k1 = 0; k1 < 4; k1++)
+        bfly4<DIR>(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]);
+    /* now a[4 k1 + k0] holds b[k1 + 4 k0]: transpose the 4x4 index to natural order */
+#pragma unroll
+    for(int k1 = 0; k1 < 4; k1++)
+#pragma unroll
+        for(int k0 = k1 + 1; k0 < 4; k0++) {
+            const double2 tmp = a[4 * k1 + k0];
+            a[4 * k1 + k0] = a[4 * k0 + k1];
+            a[4 * k0 + k1] = tmp;
+        }
+}
+
+/* One Stockham stage of radix R on FFT_C lines of length N held in LDS with line stride N + 1.
+ * n = current sub-transform length, s = stride (product of the radices already applied); all are
+ * compile-time constants, so the index arithmetic folds into shifts and constant multiplies. */
+template <int N, int n, int s, int R, int DIR> __device__ __forceinline__ void fft_stage(double2 *buf, const double2 *__restrict__ W)
+{
+    constexpr int LS = N + 1;
+    constexpr int m = n / R;
+    constexpr int nb = N / R;               /* butterflies per line */
+    constexpr int total = FFT_C * nb;
+    constexpr int K = (total + FFT_T - 1) / FFT_T;
+    double2 v[K][R];
+#pragma unroll
+    for(int kk = 0; kk < K; kk++) {
         const int i = threadIdx.x + kk * FFT_T;
         if(i < total) {
             const int line = i / nb, b = i - line * nb;
             const int p = b / s, q = b - p * s;
             const double2 *x = buf + line * LS + q + s * p;
-            double2 a[R];
 #pragma unroll
             for(int j = 0; j < R; j++)
-                a[j] = x[s * m * j];
+                v[kk][j] = x[s * m * j];
             if(R == 2) {
-                v[kk][0] = cadd(a[0], a[1]);
-                v[kk][1] = cmul(csub(a[0], a[1]), tw<DIR>(W, p * s));
+                const double2 a0 = v[kk][0], a1 = v[kk][1];
+                v[kk][0] = cadd(a0, a1);
+                v[kk][1] = csub(a0, a1);
             } else if(R == 4) {
-                const double2 t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]);
-                const double2 t2 = cadd(a[1], a[3]), t3 = rot<DIR>(csub(a[1], a[3]));
-                v[kk][0] = cadd(t0, t2);
-                v[kk][1] = cmul(cadd(t1, t3), tw<DIR>(W, p * s));
-                v[kk][2] = cmul(csub(t0, t2), tw<DIR>(W, 2 * p * s));
-                v[kk][3] = cmul(csub(t1, t3), tw<DIR>(W, 3 * p * s));
-            } else { /* R == 3 */
+                bfly4<DIR>(v[kk][0], v[kk][1], v[kk][2], v[kk][3]);
+            } else if(R == 3) {
                 const double c = -0.5, sn = (DIR < 0 ? -1.0 : 1.0) * 0.86602540378443864676;
-                const double2 t1 = cadd(a[1], a[2]);
-                const double2 t2 = make_double2(a[0].x + c * t1.x, a[0].y + c * t1.y);
-                const double2 d = csub(a[1], a[2]);
+                const double2 a0 = v[kk][0];
+                const double2 t1 = cadd(v[kk][1], v[kk][2]);
+                const double2 t2 = make_double2(a0.x + c * t1.x, a0.y + c * t1.y);
+                const double2 d = csub(v[kk][1], v[kk][2]);
                 const double2 t3 = make_double2(-sn * d.y, sn * d.x); /* i * sn * d */
-                v[kk][0] = cadd(a[0], t1);
-                v[kk][1] = cmul(cadd(t2, t3), tw<DIR>(W, p * s));
-                v[kk][2] = cmul(csub(t2, t3), tw<DIR>(W, 2 * p * s));
+                v[kk][0] = cadd(a0, t1);
+                v[kk][1] = cadd(t2, t3);
+                v[kk][2] = csub(t2, t3);
+            } else {
+                bfly16<DIR>(reinterpret_cast<double2(&)[16]>(v[kk]));
+            }
+            if(m > 1) { /* w_n^(p k); the last stage (m == 1) has p == 0 */
+#pragma unroll
+                for(int k = 1; k < R; k++)
+                    v[kk][k] = cmul(v[kk][k], tw<DIR>(W, k * p * s));
             }
         }
     }
     __syncthreads();
 #pragma unroll
-    for(int kk = 0; kk < FFT_K; kk++) {
+    for(int kk = 0; kk < K; kk++) {
         const int i = threadIdx.x + kk * FFT_T;
         if(i < total) {
             const int line = i / nb, b = i - line * nb;
@@ -106,30 +159,39 @@ __device__ __forceinline__ void fft_stage(double2 *buf, const int N, const int L
     __syncthreads();
 }
 
-template <int DIR> __device__ __forceinline__ void fft_lines(double2 *buf, const FftPlan &pl, const int LS, const double2 *__restrict__ W)
-{
-    int n = pl.N, s = 1;
-    for(int st = 0; st < pl.nstages; st++) {
-        const int r = pl.radix[st];
-        if(r == 3)
-            fft_stage<3, DIR>(buf, pl.N, LS, n, s, W);
-        else if(r == 4)
-            fft_stage<4, DIR>(buf, pl.N, LS, n, s, W);
-        else
-            fft_stage<2, DIR>(buf, pl.N, LS, n, s, W);
-        n /= r;
-        s *= r;
+/* radix sequence: 16 while possible, then 4, 2, and a final 3 */
+template <int N, int n, int s, int DIR> struct Stages {
+    static __device__ __forceinline__ void run(double2 *buf, const double2 *__restrict__ W)
+    {
+        if constexpr(n % 16 == 0) {
+            fft_stage<N, n, s, 16, DIR>(buf, W);
+            Stages<N, n / 16, s * 16, DIR>::run(buf, W);
+        } else if constexpr(n % 4 == 0) {
+            fft_stage<N, n, s, 4, DIR>(buf, W);
+            Stages<N, n / 4, s * 4, DIR>::run(buf, W);
+        } else if constexpr(n % 2 == 0) {
+            fft_stage<N, n, s, 2, DIR>(buf, W);
+            Stages<N, n / 2, s * 2, DIR>::run(buf, W);
+        } else if constexpr(n % 3 == 0) {
+            fft_stage<N, n, s, 3, DIR>(buf, W);
+            Stages<N, n / 3, s * 3, DIR>::run(buf, W);
+        }
     }
+};
+
+template <int N, int DIR> __device__ __forceinline__ void fft_lines(double2 *buf, const double2 *__restrict__ W)
+{
+    Stages<N, N, 1, DIR>::run(buf, W);
 }
 
 /* ---- pass Z forward: two real rows -> two half spectra, in place ---------------------------------
  * mesh: [nrows][zp] doubles (zp = pitch, >= N + 2).  Workgroup = FFT_C complex lines = 2 FFT_C rows. */
-template <bool FROM_I64>
-__global__ __launch_bounds__(FFT_T) void fft_pass_z_fwd(double *mesh, const long long nrows, const int zp, const FftPlan pl,
+template <int N, bool FROM_I64>
+__global__ __launch_bounds__(FFT_T) void fft_pass_z_fwd(double *mesh, const long long nrows, const int zp,
                                                         const double2 *__restrict__ W, const double inv_scale)
 {
     extern __shared__ double2 buf[];
-    const int N = pl.N, LS = N + 1;
+    constexpr int LS = N + 1;
     const long long row0 = (long long) blockIdx.x * (2 * FFT_C);
     for(int e = threadIdx.x; e < 2 * FFT_C * N; e += FFT_T) {
         const int r = e / N, z = e - r * N;
@@ -145,7 +207,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_fwd(double *mesh, const long
         dst[r & 1] = v;
     }
     __syncthreads();
-    fft_lines<-1>(buf, pl, LS, W);
+    fft_lines<N, -1>(buf, W);
     /* separate the two real transforms: XA[k] = (Z[k] + conj Z[N-k]) / 2, XB[k] = -i (Z[k] - conj Z[N-k]) / 2 */
     const int Nc = N / 2 + 1;
     double2 *cm = reinterpret_cast<double2 *>(mesh);
@@ -166,11 +228,12 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_fwd(double *mesh, const long
 }
 
 /* ---- pass Z inverse (c2r): two half spectra -> two real rows, in place -------------------------------- */
-__global__ __launch_bounds__(FFT_T) void fft_pass_z_inv(double *mesh, const long long nrows, const int zp, const FftPlan pl,
+template <int N>
+__global__ __launch_bounds__(FFT_T) void fft_pass_z_inv(double *mesh, const long long nrows, const int zp,
                                                         const double2 *__restrict__ W)
 {
     extern __shared__ double2 buf[];
-    const int N = pl.N, LS = N + 1, Nc = N / 2 + 1;
+    constexpr int LS = N + 1, Nc = N / 2 + 1;
     const long long row0 = (long long) blockIdx.x * (2 * FFT_C);
     const double2 *cm = reinterpret_cast<const double2 *>(mesh);
     const int zpc = zp / 2;
@@ -192,7 +255,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_inv(double *mesh, const long
             buf[l * LS + N - k] = make_double2(xa.x + xb.y, -xa.y + xb.x);
     }
     __syncthreads();
-    fft_lines<+1>(buf, pl, LS, W);
+    fft_lines<N, +1>(buf, W);
     for(int e = threadIdx.x; e < 2 * FFT_C * N; e += FFT_T) {
         const int r = e / N, z = e - r * N;
         const long long row = row0 + r;
@@ -210,14 +273,16 @@ struct GreenArgs {
     double asmth2, pot_factor;
 };
 
-template <int MODE>
+template <int N, int MODE>
 __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const long long es, const long long outer_stride,
-                                                          const int ntiles, const FftPlan pl, const double2 *__restrict__ W,
-                                                          const GreenArgs ga)
+                                                          const int ntiles, const double2 *__restrict__ W, const GreenArgs ga, const unsigned xcdk)
 {
     extern __shared__ double2 buf[];
-    const int N = pl.N, LS = N + 1;
-    const int outer = blockIdx.x / ntiles, tile = blockIdx.x - outer * ntiles;
+    constexpr int LS = N + 1;
+    /* XCD-chunked block order: neighbouring column tiles share 128-byte lines (a tile row is 64 bytes), so
+     * they should run on the same XCD at about the same time and find the other half of the line in its L2 */
+    const unsigned bid = xcd_block(blockIdx.x, gridDim.x, xcdk);
+    const int outer = bid / ntiles, tile = bid - outer * ntiles;
     double2 *base = cm + (long long) outer * outer_stride + (long long) tile * FFT_C;
     for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T) {
         const int row = e / FFT_C, col = e - row * FFT_C;
@@ -225,7 +290,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
     }
     __syncthreads();
     if(MODE == 0 || MODE == 2)
-        fft_lines<-1>(buf, pl, LS, W);
+        fft_lines<N, -1>(buf, W);
     if(MODE == 2) {
         /* potential_transfer, gravpm.cpp:378-444: line index = kx, outer = y, column = z' */
         const int y = outer;
@@ -254,55 +319,67 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
         __syncthreads();
     }
     if(MODE == 1 || MODE == 2)
-        fft_lines<+1>(buf, pl, LS, W);
+        fft_lines<N, +1>(buf, W);
     for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T) {
         const int row = e / FFT_C, col = e - row * FFT_C;
         base[(long long) row * es + col] = buf[col * LS + row];
     }
 }
 
-bool make_plan(int N, FftPlan *pl)
+template <int N>
+int run_n(shq_context *ctx, double *d_mesh, int zp, int stage, bool from_i64, double inv_scale, const GreenArgs &ga)
 {
-    if(N < 4 || N > 1024)
-        return false;
-    int n = N, ns = 0;
-    pl->N = N;
-    int threes = 0;
-    while(n % 3 == 0) {
-        n /= 3;
-        threes++;
+    const double2 *W = reinterpret_cast<const double2 *>(ctx->fft_tw.ptr);
+    constexpr size_t lds = sizeof(double2) * FFT_C * (N + 1);
+    const long long nrows = (long long) N * N;
+    const int zpc = zp / 2;
+    const int ntiles = zpc / FFT_C;
+    const unsigned zblocks = (unsigned) ((nrows + 2 * FFT_C - 1) / (2 * FFT_C));
+    double2 *cm = reinterpret_cast<double2 *>(d_mesh);
+    hipStream_t s = ctx->stream;
+    if(lds > 48 * 1024) { /* allow > 48 KB of dynamic LDS */
+        (void) hipFuncSetAttribute((const void *) fft_pass_z_fwd<N, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        (void) hipFuncSetAttribute((const void *) fft_pass_z_fwd<N, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        (void) hipFuncSetAttribute((const void *) fft_pass_z_inv<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        (void) hipFuncSetAttribute((const void *) fft_pass_strided<N, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        (void) hipFuncSetAttribute((const void *) fft_pass_strided<N, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        (void) hipFuncSetAttribute((const void *) fft_pass_strided<N, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     }
-    if(threes > 1)
-        return false;
-    int twos = 0;
-    while(n % 2 == 0) {
-        n /= 2;
-        twos++;
+    const unsigned sblocks = (unsigned) (N * ntiles);
+    const unsigned xcdk = getenv("SHQ_FFT_XCD_K") ? (unsigned) atoi(getenv("SHQ_FFT_XCD_K")) : 8u;
+    if(stage == 0 || stage == 2) {
+        if(from_i64)
+            fft_pass_z_fwd<N, true><<<dim3(zblocks), dim3(FFT_T), lds, s>>>(d_mesh, nrows, zp, W, inv_scale);
+        else
+            fft_pass_z_fwd<N, false><<<dim3(zblocks), dim3(FFT_T), lds, s>>>(d_mesh, nrows, zp, W, 1.0);
+        /* Y: outer = x plane (stride N*zpc), element stride zpc */
+        fft_pass_strided<N, 0><<<dim3(sblocks), dim3(FFT_T), lds, s>>>(cm, zpc, (long long) N * zpc, ntiles, W, ga, xcdk);
     }
-    if(n != 1)
-        return false;
-    if(threes) {
-        if(FFT_C * (N / 3) > FFT_K * FFT_T)
-            return false;
-        pl->radix[ns++] = 3;
+    /* X: outer = y (stride zpc), element stride N*zpc */
+    if(stage == 0)
+        fft_pass_strided<N, 0><<<dim3(sblocks), dim3(FFT_T), lds, s>>>(cm, (long long) N * zpc, zpc, ntiles, W, ga, xcdk);
+    else if(stage == 1)
+        fft_pass_strided<N, 1><<<dim3(sblocks), dim3(FFT_T), lds, s>>>(cm, (long long) N * zpc, zpc, ntiles, W, ga, xcdk);
+    else
+        fft_pass_strided<N, 2><<<dim3(sblocks), dim3(FFT_T), lds, s>>>(cm, (long long) N * zpc, zpc, ntiles, W, ga, xcdk);
+    if(stage == 1 || stage == 2) {
+        fft_pass_strided<N, 1><<<dim3(sblocks), dim3(FFT_T), lds, s>>>(cm, zpc, (long long) N * zpc, ntiles, W, ga, xcdk);
+        fft_pass_z_inv<N><<<dim3(zblocks), dim3(FFT_T), lds, s>>>(d_mesh, nrows, zp, W);
     }
-    for(int i = 0; i < twos / 2; i++)
-        pl->radix[ns++] = 4;
-    if(twos % 2) {
-        if(FFT_C * (N / 2) > FFT_K * FFT_T)
-            return false;
-        pl->radix[ns++] = 2;
-    }
-    pl->nstages = ns;
-    return true;
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
 }
 
 } // namespace
 
+/* mesh sizes with a compiled pipeline: 2^a and 3 * 2^a */
 bool shq_fft3d_supported(int N)
 {
-    FftPlan pl;
-    return make_plan(N, &pl) && N % 2 == 0;
+    switch(N) {
+    case 16: case 24: case 32: case 48: case 64: case 96: case 128: case 192: case 256: case 384: case 512: case 768: case 1024:
+        return true;
+    }
+    return false;
 }
 
 /* z pitch (in doubles) the bespoke pipeline wants: N/2+1 complex rounded up to a multiple of 4. */
@@ -328,51 +405,19 @@ static int ensure_twiddles(shq_context *ctx, int N)
 int shq_fft3d_run(shq_context *ctx, double *d_mesh, int N, int zp, int stage, bool from_i64, double inv_scale,
                   const double *d_sinctab, double asmth2, double pot_factor)
 {
-    FftPlan pl;
-    SHQ_CHECK(make_plan(N, &pl) && N % 2 == 0, SHQ_ERR_INVALID, "fft3d: unsupported mesh size %d", N);
+    SHQ_CHECK(shq_fft3d_supported(N), SHQ_ERR_INVALID, "fft3d: unsupported mesh size %d", N);
     SHQ_CHECK(zp >= N + 2 && zp % 8 == 0, SHQ_ERR_INVALID, "fft3d: pitch %d must be a multiple of 8 doubles and >= N+2", zp);
     SHQ_TRY(ensure_twiddles(ctx, N));
-    const double2 *W = reinterpret_cast<const double2 *>(ctx->fft_tw.ptr);
-    const size_t lds = sizeof(double2) * FFT_C * (N + 1);
-    const long long nrows = (long long) N * N;
-    const int zpc = zp / 2;
-    const int ntiles = zpc / FFT_C;
-    const unsigned zblocks = (unsigned) ((nrows + 2 * FFT_C - 1) / (2 * FFT_C));
-    double2 *cm = reinterpret_cast<double2 *>(d_mesh);
     GreenArgs ga;
     ga.sinctab = d_sinctab;
     ga.asmth2 = asmth2;
     ga.pot_factor = pot_factor;
-    hipStream_t s = ctx->stream;
-    static bool attr_done = false;
-    if(!attr_done) { /* allow > 48 KB of dynamic LDS */
-        (void) hipFuncSetAttribute((const void *) fft_pass_z_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void) hipFuncSetAttribute((const void *) fft_pass_z_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void) hipFuncSetAttribute((const void *) fft_pass_z_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void) hipFuncSetAttribute((const void *) fft_pass_strided<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void) hipFuncSetAttribute((const void *) fft_pass_strided<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void) hipFuncSetAttribute((const void *) fft_pass_strided<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        attr_done = true;
+#define SHQ_FFT_CASE(NN) case NN: return run_n<NN>(ctx, d_mesh, zp, stage, from_i64, inv_scale, ga)
+    switch(N) {
+        SHQ_FFT_CASE(16); SHQ_FFT_CASE(24); SHQ_FFT_CASE(32); SHQ_FFT_CASE(48); SHQ_FFT_CASE(64); SHQ_FFT_CASE(96);
+        SHQ_FFT_CASE(128); SHQ_FFT_CASE(192); SHQ_FFT_CASE(256); SHQ_FFT_CASE(384); SHQ_FFT_CASE(512); SHQ_FFT_CASE(768);
+        SHQ_FFT_CASE(1024);
     }
-    if(stage == 0 || stage == 2) {
-        if(from_i64)
-            fft_pass_z_fwd<true><<<dim3(zblocks), dim3(FFT_T), lds, s>>>(d_mesh, nrows, zp, pl, W, inv_scale);
-        else
-            fft_pass_z_fwd<false><<<dim3(zblocks), dim3(FFT_T), lds, s>>>(d_mesh, nrows, zp, pl, W, 1.0);
-        /* Y: outer = x plane (stride N*zpc), element stride zpc */
-        fft_pass_strided<0><<<dim3((unsigned) (N * ntiles)), dim3(FFT_T), lds, s>>>(cm, zpc, (long long) N * zpc, ntiles, pl, W, ga);
-    }
-    /* X: outer = y (stride zpc), element stride N*zpc */
-    if(stage == 0)
-        fft_pass_strided<0><<<dim3((unsigned) (N * ntiles)), dim3(FFT_T), lds, s>>>(cm, (long long) N * zpc, zpc, ntiles, pl, W, ga);
-    else if(stage == 1)
-        fft_pass_strided<1><<<dim3((unsigned) (N * ntiles)), dim3(FFT_T), lds, s>>>(cm, (long long) N * zpc, zpc, ntiles, pl, W, ga);
-    else
-        fft_pass_strided<2><<<dim3((unsigned) (N * ntiles)), dim3(FFT_T), lds, s>>>(cm, (long long) N * zpc, zpc, ntiles, pl, W, ga);
-    if(stage == 1 || stage == 2) {
-        fft_pass_strided<1><<<dim3((unsigned) (N * ntiles)), dim3(FFT_T), lds, s>>>(cm, zpc, (long long) N * zpc, ntiles, pl, W, ga);
-        fft_pass_z_inv<<<dim3(zblocks), dim3(FFT_T), lds, s>>>(d_mesh, nrows, zp, pl, W);
-    }
-    SHQ_HIP(hipGetLastError());
-    return SHQ_OK;
+#undef SHQ_FFT_CASE
+    return SHQ_ERR_INVALID;
 }
