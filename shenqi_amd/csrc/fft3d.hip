@@ -13,10 +13,12 @@
  *           sits in LDS, inverse FFT (fuses pm_green_kernel and saves a whole read+write pass)
  *   Y inv, Z inv (c2r, two-for-one).
  *
- * Every 1-D transform is a Stockham autosort FFT in LDS (radix 3, then radix 4, then radix 2):
- * each stage reads its butterflies' inputs into registers, barrier, writes the outputs to the same
- * buffer, barrier — one LDS buffer per line (N+1 elements: the +1 de-conflicts the four column
- * lines of a tile).  Unscaled in both directions, like FFTW/heffte.
+ * Every 1-D transform is a Stockham autosort FFT in LDS (radix 16 in registers while it divides,
+ * then 4, 2 and a final 3): each stage reads its butterflies' inputs into registers, barrier, writes
+ * the outputs to the same buffer, barrier — one LDS buffer per line (N+1 elements: the +1
+ * de-conflicts the four column lines of a tile); the twiddle table sits in LDS next to the lines.
+ * Workgroups are persistent and prefetch their next tile into registers (see below).
+ * Unscaled in both directions, like FFTW/heffte.
  * The z pitch of the mesh is padded to a multiple of 4 complex values so that every 4-column row
  * segment is one aligned 64-byte chunk.
  */
@@ -99,7 +101,12 @@ template <int DIR> __device__ __forceinline__ void bfly16(double2 (&a)[16])
 /* One Stockham stage of radix R on FFT_C lines of length N held in LDS with line stride N + 1.
  * n = current sub-transform length, s = stride (product of the radices already applied); all are
  * compile-time constants, so the index arithmetic folds into shifts and constant multiplies. */
-template <int N, int n, int s, int R, int DIR> __device__ __forceinline__ void fft_stage(double2 *buf, const double2 *__restrict__ W)
+struct NoLoadOp {
+    __device__ __forceinline__ double2 operator()(int, int, double2 v) const { return v; }
+};
+
+template <int N, int n, int s, int R, int DIR, typename StoreOp = NoLoadOp>
+__device__ __forceinline__ void fft_stage(double2 *buf, const double2 *__restrict__ W, const StoreOp op = StoreOp())
 {
     constexpr int LS = N + 1;
     constexpr int m = n / R;
@@ -153,7 +160,7 @@ template <int N, int n, int s, int R, int DIR> __device__ __forceinline__ void f
             double2 *y = buf + line * LS + q + s * R * p;
 #pragma unroll
             for(int k = 0; k < R; k++)
-                y[s * k] = v[kk][k];
+                y[s * k] = op(line, q + s * R * p + s * k, v[kk][k]);
         }
     }
     __syncthreads();
@@ -161,109 +168,176 @@ template <int N, int n, int s, int R, int DIR> __device__ __forceinline__ void f
 
 /* radix sequence: 16 while possible, then 4, 2, and a final 3 */
 template <int N, int n, int s, int DIR> struct Stages {
-    static __device__ __forceinline__ void run(double2 *buf, const double2 *__restrict__ W)
+    template <typename StoreOp> static __device__ __forceinline__ void run(double2 *buf, const double2 *__restrict__ W, const StoreOp op)
     {
-        if constexpr(n % 16 == 0) {
-            fft_stage<N, n, s, 16, DIR>(buf, W);
-            Stages<N, n / 16, s * 16, DIR>::run(buf, W);
-        } else if constexpr(n % 4 == 0) {
-            fft_stage<N, n, s, 4, DIR>(buf, W);
-            Stages<N, n / 4, s * 4, DIR>::run(buf, W);
-        } else if constexpr(n % 2 == 0) {
-            fft_stage<N, n, s, 2, DIR>(buf, W);
-            Stages<N, n / 2, s * 2, DIR>::run(buf, W);
-        } else if constexpr(n % 3 == 0) {
-            fft_stage<N, n, s, 3, DIR>(buf, W);
-            Stages<N, n / 3, s * 3, DIR>::run(buf, W);
-        }
+        constexpr int R = n % 16 == 0 ? 16 : (n % 4 == 0 ? 4 : (n % 2 == 0 ? 2 : 3));
+        if constexpr(n / R > 1) {
+            fft_stage<N, n, s, R, DIR>(buf, W);
+            Stages<N, n / R, s * R, DIR>::run(buf, W, op);
+        } else
+            fft_stage<N, n, s, R, DIR, StoreOp>(buf, W, op); /* the hook filters the outputs of the last stage */
     }
 };
 
-template <int N, int DIR> __device__ __forceinline__ void fft_lines(double2 *buf, const double2 *__restrict__ W)
+/* op(line, index, value) filters every output element as the last stage stores it */
+template <int N, int DIR, typename StoreOp = NoLoadOp>
+__device__ __forceinline__ void fft_lines(double2 *buf, const double2 *__restrict__ W, const StoreOp op = StoreOp())
 {
-    Stages<N, N, 1, DIR>::run(buf, W);
+    Stages<N, N, 1, DIR>::run(buf, W, op);
+}
+
+/* ---- persistent workgroups -------------------------------------------------------------------------
+ * Every pass runs as many workgroups as fit on the chip at once; workgroup b takes tiles b, b + G,
+ * b + 2G ...  The twiddle table lives in LDS behind the line buffers (loaded once per workgroup), so
+ * the FFT stages touch no global memory at all, and the NEXT tile is fetched into registers right
+ * after the current one has landed in LDS: its HBM latency hides behind the LDS work.  (Measured
+ * before: 70-80 % of wave cycles waiting, 15 dependent twiddle loads per radix-16 stage.)
+ * The prefetch of the last iteration re-reads the workgroup's own tile instead of branching around
+ * the loads, which keeps the loop-carried registers free of copies (and of an early s_waitcnt). */
+template <int N> __device__ __forceinline__ double2 *lds_twiddles(double2 *buf, const double2 *__restrict__ W)
+{
+    double2 *Wl = buf + FFT_C * (N + 1);
+    for(int i = threadIdx.x; i < N; i += FFT_T)
+        Wl[i] = W[i];
+    return Wl;
 }
 
 /* ---- pass Z forward: two real rows -> two half spectra, in place ---------------------------------
- * mesh: [nrows][zp] doubles (zp = pitch, >= N + 2).  Workgroup = FFT_C complex lines = 2 FFT_C rows. */
+ * mesh: [nrows][zp] doubles (zp = pitch, >= N + 2).  Workgroup tile = FFT_C complex lines = 2 FFT_C rows. */
 template <int N, bool FROM_I64>
-__global__ __launch_bounds__(FFT_T) void fft_pass_z_fwd(double *mesh, const long long nrows, const int zp,
+__global__ __launch_bounds__(FFT_T) void fft_pass_z_fwd(double *mesh, const int ntot, const int zp,
                                                         const double2 *__restrict__ W, const double inv_scale)
 {
     extern __shared__ double2 buf[];
-    constexpr int LS = N + 1;
-    const long long row0 = (long long) blockIdx.x * (2 * FFT_C);
-    for(int e = threadIdx.x; e < 2 * FFT_C * N; e += FFT_T) {
-        const int r = e / N, z = e - r * N;
-        const long long row = row0 + r;
-        double v = 0;
-        if(row < nrows) {
-            if(FROM_I64)
-                v = (double) reinterpret_cast<const long long *>(mesh)[row * zp + z] * inv_scale;
-            else
-                v = mesh[row * zp + z];
-        }
-        double *dst = reinterpret_cast<double *>(buf + (r >> 1) * LS + z);
-        dst[r & 1] = v;
-    }
-    __syncthreads();
-    fft_lines<N, -1>(buf, W);
-    /* separate the two real transforms: XA[k] = (Z[k] + conj Z[N-k]) / 2, XB[k] = -i (Z[k] - conj Z[N-k]) / 2 */
-    const int Nc = N / 2 + 1;
+    constexpr int LS = N + 1, H = N / 2, Nc = N / 2 + 1;
+    constexpr int E = (FFT_C * N + FFT_T - 1) / FFT_T; /* 16-byte pairs per thread: 2 FFT_C rows of N/2 pairs */
+    constexpr bool EXACT = E * FFT_T == FFT_C * N;
+    double2 *Wl = lds_twiddles<N>(buf, W);
     double2 *cm = reinterpret_cast<double2 *>(mesh);
     const int zpc = zp / 2;
-    for(int e = threadIdx.x; e < FFT_C * Nc; e += FFT_T) {
-        const int l = e / Nc, k = e - l * Nc;
-        const double2 zk = buf[l * LS + k];
-        const double2 zn = conj2(buf[l * LS + (k == 0 ? 0 : N - k)]);
-        const double2 xa = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y + zn.y));
-        const double2 d = make_double2(0.5 * (zk.x - zn.x), 0.5 * (zk.y - zn.y));
-        const double2 xb = make_double2(d.y, -d.x);
-        const long long ra = row0 + 2 * l, rb = ra + 1;
-        if(ra < nrows)
-            cm[ra * zpc + k] = xa;
-        if(rb < nrows)
-            cm[rb * zpc + k] = xb;
+    double pa[E], pb[E];
+#define FFT_FETCH(T_)                                                                            \
+    _Pragma("unroll") for(int i = 0; i < E; i++)                                                 \
+    {                                                                                            \
+        const int e = threadIdx.x + i * FFT_T;                                                   \
+        if(EXACT || e < FFT_C * N) {                                                             \
+            const long long row = (long long) (T_) * (2 * FFT_C) + e / H;                        \
+            const double2 v_ = cm[row * zpc + (e % H)];                                          \
+            pa[i] = v_.x;                                                                        \
+            pb[i] = v_.y;                                                                        \
+        }                                                                                        \
     }
+    int t = blockIdx.x;
+    if(t >= ntot)
+        return;
+    FFT_FETCH(t)
+    while(true) {
+#pragma unroll
+        for(int i = 0; i < E; i++) {
+            const int e = threadIdx.x + i * FFT_T;
+            if(EXACT || e < FFT_C * N) {
+                const int r = e / H, z = 2 * (e % H);
+                double a = pa[i], b = pb[i];
+                if(FROM_I64) {
+                    a = (double) __double_as_longlong(a) * inv_scale;
+                    b = (double) __double_as_longlong(b) * inv_scale;
+                }
+                double *dst = reinterpret_cast<double *>(buf + (r >> 1) * LS + z) + (r & 1);
+                dst[0] = a;
+                dst[2] = b;
+            }
+        }
+        __syncthreads();
+        const int tn = t + (int) gridDim.x;
+        const bool more = tn < ntot;
+        const int tf = more ? tn : t;
+        FFT_FETCH(tf)
+        fft_lines<N, -1>(buf, Wl);
+        /* separate the two real transforms: XA[k] = (Z[k] + conj Z[N-k]) / 2, XB[k] = -i (Z[k] - conj Z[N-k]) / 2 */
+        const long long row0 = (long long) t * (2 * FFT_C);
+        for(int e = threadIdx.x; e < FFT_C * Nc; e += FFT_T) {
+            const int l = e / Nc, k = e - l * Nc;
+            const double2 zk = buf[l * LS + k];
+            const double2 zn = conj2(buf[l * LS + (k == 0 ? 0 : N - k)]);
+            const double2 xa = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y + zn.y));
+            const double2 d = make_double2(0.5 * (zk.x - zn.x), 0.5 * (zk.y - zn.y));
+            const double2 xb = make_double2(d.y, -d.x);
+            const long long ra = row0 + 2 * l;
+            cm[ra * zpc + k] = xa;
+            cm[(ra + 1) * zpc + k] = xb;
+        }
+        if(!more)
+            break;
+        __syncthreads(); /* everyone has read its results out of LDS before the next tile lands there */
+        t = tn;
+    }
+#undef FFT_FETCH
 }
 
 /* ---- pass Z inverse (c2r): two half spectra -> two real rows, in place -------------------------------- */
 template <int N>
-__global__ __launch_bounds__(FFT_T) void fft_pass_z_inv(double *mesh, const long long nrows, const int zp,
-                                                        const double2 *__restrict__ W)
+__global__ __launch_bounds__(FFT_T) void fft_pass_z_inv(double *mesh, const int ntot, const int zp, const double2 *__restrict__ W)
 {
     extern __shared__ double2 buf[];
-    constexpr int LS = N + 1, Nc = N / 2 + 1;
-    const long long row0 = (long long) blockIdx.x * (2 * FFT_C);
-    const double2 *cm = reinterpret_cast<const double2 *>(mesh);
+    constexpr int LS = N + 1, H = N / 2, Nc = N / 2 + 1;
+    constexpr int E = (FFT_C * Nc + FFT_T - 1) / FFT_T;
+    double2 *Wl = lds_twiddles<N>(buf, W);
+    double2 *cm = reinterpret_cast<double2 *>(mesh);
     const int zpc = zp / 2;
-    for(int e = threadIdx.x; e < FFT_C * Nc; e += FFT_T) {
-        const int l = e / Nc, k = e - l * Nc;
-        const long long ra = row0 + 2 * l, rb = ra + 1;
-        double2 xa = make_double2(0, 0), xb = make_double2(0, 0);
-        if(ra < nrows)
-            xa = cm[ra * zpc + k];
-        if(rb < nrows)
-            xb = cm[rb * zpc + k];
-        if(k == 0 || 2 * k == N) { /* a c2r transform ignores the imaginary part of the self-conjugate modes */
-            xa.y = 0;
-            xb.y = 0;
-        }
-        /* Z[k] = XA[k] + i XB[k];  Z[N-k] = conj(XA[k]) + i conj(XB[k]) */
-        buf[l * LS + k] = make_double2(xa.x - xb.y, xa.y + xb.x);
-        if(k > 0 && 2 * k < N)
-            buf[l * LS + N - k] = make_double2(xa.x + xb.y, -xa.y + xb.x);
+    double ax[E], ay[E], bx[E], by[E];
+#define FFT_FETCH(T_)                                                                            \
+    _Pragma("unroll") for(int i = 0; i < E; i++)                                                 \
+    {                                                                                            \
+        const int e = threadIdx.x + i * FFT_T;                                                   \
+        if(e < FFT_C * Nc) {                                                                     \
+            const int l = e / Nc, k = e - l * Nc;                                                \
+            const long long ra = (long long) (T_) * (2 * FFT_C) + 2 * l;                         \
+            const double2 xa_ = cm[ra * zpc + k], xb_ = cm[(ra + 1) * zpc + k];                  \
+            ax[i] = xa_.x;                                                                       \
+            ay[i] = xa_.y;                                                                       \
+            bx[i] = xb_.x;                                                                       \
+            by[i] = xb_.y;                                                                       \
+        }                                                                                        \
     }
-    __syncthreads();
-    fft_lines<N, +1>(buf, W);
-    for(int e = threadIdx.x; e < 2 * FFT_C * N; e += FFT_T) {
-        const int r = e / N, z = e - r * N;
-        const long long row = row0 + r;
-        if(row < nrows) {
-            const double *src = reinterpret_cast<const double *>(buf + (r >> 1) * LS + z);
-            mesh[row * zp + z] = src[r & 1];
+    int t = blockIdx.x;
+    if(t >= ntot)
+        return;
+    FFT_FETCH(t)
+    while(true) {
+#pragma unroll
+        for(int i = 0; i < E; i++) {
+            const int e = threadIdx.x + i * FFT_T;
+            if(e < FFT_C * Nc) {
+                const int l = e / Nc, k = e - l * Nc;
+                double2 xa = make_double2(ax[i], ay[i]), xb = make_double2(bx[i], by[i]);
+                if(k == 0 || 2 * k == N) { /* a c2r transform ignores the imaginary part of the self-conjugate modes */
+                    xa.y = 0;
+                    xb.y = 0;
+                }
+                /* Z[k] = XA[k] + i XB[k];  Z[N-k] = conj(XA[k]) + i conj(XB[k]) */
+                buf[l * LS + k] = make_double2(xa.x - xb.y, xa.y + xb.x);
+                if(k > 0 && 2 * k < N)
+                    buf[l * LS + N - k] = make_double2(xa.x + xb.y, -xa.y + xb.x);
+            }
         }
+        __syncthreads();
+        const int tn = t + (int) gridDim.x;
+        const bool more = tn < ntot;
+        const int tf = more ? tn : t;
+        FFT_FETCH(tf)
+        fft_lines<N, +1>(buf, Wl);
+        const long long row0 = (long long) t * (2 * FFT_C);
+        for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T) {
+            const int r = e / H, z = 2 * (e % H);
+            const double *src = reinterpret_cast<const double *>(buf + (r >> 1) * LS + z) + (r & 1);
+            cm[(row0 + r) * zpc + (z >> 1)] = make_double2(src[0], src[2]);
+        }
+        if(!more)
+            break;
+        __syncthreads();
+        t = tn;
     }
+#undef FFT_FETCH
 }
 
 /* ---- passes Y and X: complex lines with element stride `es` (in complex units), FFT_C adjacent columns.
@@ -275,96 +349,151 @@ struct GreenArgs {
 
 template <int N, int MODE>
 __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const long long es, const long long outer_stride,
-                                                          const int ntiles, const double2 *__restrict__ W, const GreenArgs ga, const unsigned xcdk)
+                                                          const int ntiles, const int ntot, const double2 *__restrict__ W,
+                                                          const GreenArgs ga, const unsigned xcdk)
 {
     extern __shared__ double2 buf[];
     constexpr int LS = N + 1;
-    /* XCD-chunked block order: neighbouring column tiles share 128-byte lines (a tile row is 64 bytes), so
-     * they should run on the same XCD at about the same time and find the other half of the line in its L2 */
-    const unsigned bid = xcd_block(blockIdx.x, gridDim.x, xcdk);
-    const int outer = bid / ntiles, tile = bid - outer * ntiles;
-    double2 *base = cm + (long long) outer * outer_stride + (long long) tile * FFT_C;
-    for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T) {
-        const int row = e / FFT_C, col = e - row * FFT_C;
-        buf[col * LS + row] = base[(long long) row * es + col];
+    constexpr int E = (FFT_C * N + FFT_T - 1) / FFT_T; /* tile elements per thread */
+    constexpr bool EXACT = E * FFT_T == FFT_C * N;
+    double2 *Wl = lds_twiddles<N>(buf, W);
+    double *gax = reinterpret_cast<double *>(Wl + N); /* MODE 2 only: per-axis factor of the Green's function */
+    if(MODE == 2)
+        for(int i = threadIdx.x; i < N; i += FFT_T) {
+            const int k = i <= N / 2 ? i : i - N;
+            const double sc = ga.sinctab[i];
+            gax[i] = exp(-(double) k * (double) k * ga.asmth2) * sc * sc;
+        }
+    /* XCD-chunked workgroup order: neighbouring column tiles share 128-byte lines (a tile row is 64
+     * bytes), so they should run on the same XCD at about the same time and find the other half in its L2. */
+    const unsigned vb = xcd_block(blockIdx.x, gridDim.x, xcdk);
+    double prx[E], pry[E];
+#define FFT_FETCH(BASE)                                                                          \
+    _Pragma("unroll") for(int i = 0; i < E; i++)                                                 \
+    {                                                                                            \
+        const int e = threadIdx.x + i * FFT_T;                                                   \
+        if(EXACT || e < FFT_C * N) {                                                             \
+            const double2 t_ = (BASE)[(long long) (e / FFT_C) * es + (e % FFT_C)];               \
+            prx[i] = t_.x;                                                                       \
+            pry[i] = t_.y;                                                                       \
+        }                                                                                        \
     }
-    __syncthreads();
-    if(MODE == 0 || MODE == 2)
-        fft_lines<N, -1>(buf, W);
-    if(MODE == 2) {
-        /* potential_transfer, gravpm.cpp:378-444: line index = kx, outer = y, column = z' */
-        const int y = outer;
-        const int ky = y <= N / 2 ? y : y - N;
-        for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T) {
-            const int col = e / N, x = e - col * N;
-            const int z = tile * FFT_C + col;
-            const int kx = x <= N / 2 ? x : x - N;
-            const long long k2 = (long long) kx * kx + (long long) ky * ky + (long long) z * z;
-            double2 v = buf[col * LS + x];
-            if(k2 == 0 || z > N / 2) {
-                v.x = 0;
-                v.y = 0;
-            } else {
-                double f = 1.0;
-                const double smth = exp(-(double) k2 * ga.asmth2) / (double) k2;
-                f *= ga.sinctab[x];
-                f *= ga.sinctab[y];
-                f *= ga.sinctab[z];
-                const double fac = ga.pot_factor * smth * f * f;
-                v.x *= fac;
-                v.y *= fac;
-            }
-            buf[col * LS + x] = v;
+    int t = (int) vb;
+    if(t >= ntot)
+        return;
+    int outer = t / ntiles, tile = t - outer * ntiles;
+    double2 *base = cm + (long long) outer * outer_stride + (long long) tile * FFT_C;
+    FFT_FETCH(base)
+    while(true) {
+#pragma unroll
+        for(int i = 0; i < E; i++) {
+            const int e = threadIdx.x + i * FFT_T;
+            if(EXACT || e < FFT_C * N)
+                buf[(e % FFT_C) * LS + e / FFT_C] = make_double2(prx[i], pry[i]);
         }
         __syncthreads();
+        const int tn = t + (int) gridDim.x;
+        const bool more = tn < ntot;
+        const int outer_n = more ? tn / ntiles : outer, tile_n = more ? tn - outer_n * ntiles : tile;
+        double2 *base_n = cm + (long long) outer_n * outer_stride + (long long) tile_n * FFT_C;
+        FFT_FETCH(base_n)
+        if(MODE == 0)
+            fft_lines<N, -1>(buf, Wl);
+        if(MODE == 2) {
+            /* potential_transfer, gravpm.cpp:378-444, applied as the forward transform stores its last
+             * stage (line index = kx, outer = y, column = z'); gax[i] = exp(-k_i^2 asmth2) sinctab[i]^2, so
+             * the factor exp(-k^2 asmth2) f^2 / k^2 is a product of three table entries over k^2 */
+            const int y = outer, z0 = tile * FFT_C;
+            const int ky = y <= N / 2 ? y : y - N;
+            const double gy = gax[y] * ga.pot_factor, ky2 = (double) ky * (double) ky;
+            auto green = [=](int col, int x, double2 v) {
+                const int z = z0 + col;
+                const int kx = x <= N / 2 ? x : x - N;
+                const double k2 = (double) kx * (double) kx + (ky2 + (double) z * (double) z); /* exact: < 2^53 */
+                const double fac = (k2 == 0.0 || z > N / 2) ? 0.0 : gax[x] * gy * gax[z] / k2;
+                return make_double2(v.x * fac, v.y * fac);
+            };
+            fft_lines<N, -1>(buf, Wl, green);
+            fft_lines<N, +1>(buf, Wl);
+        }
+        if(MODE == 1)
+            fft_lines<N, +1>(buf, Wl);
+        for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T) {
+            const int row = e / FFT_C, col = e - row * FFT_C;
+            base[(long long) row * es + col] = buf[col * LS + row];
+        }
+        if(!more)
+            break;
+        __syncthreads(); /* everyone has read its results out of LDS before the next tile lands there */
+        t = tn;
+        outer = outer_n;
+        tile = tile_n;
+        base = base_n;
     }
-    if(MODE == 1 || MODE == 2)
-        fft_lines<N, +1>(buf, W);
-    for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T) {
-        const int row = e / FFT_C, col = e - row * FFT_C;
-        base[(long long) row * es + col] = buf[col * LS + row];
-    }
+#undef FFT_FETCH
 }
 
 template <int N>
 int run_n(shq_context *ctx, double *d_mesh, int zp, int stage, bool from_i64, double inv_scale, const GreenArgs &ga)
 {
     const double2 *W = reinterpret_cast<const double2 *>(ctx->fft_tw.ptr);
-    constexpr size_t lds = sizeof(double2) * FFT_C * (N + 1);
-    const long long nrows = (long long) N * N;
+    /* FFT_C padded lines + the twiddle table + (X pass) the sinc table */
+    constexpr size_t lds = sizeof(double2) * (FFT_C * (N + 1) + N) + sizeof(double) * N;
+    static_assert(((long long) N * N) % (2 * FFT_C) == 0, "rows must tile evenly");
+    const int ztot = (int) (((long long) N * N) / (2 * FFT_C));
     const int zpc = zp / 2;
     const int ntiles = zpc / FFT_C;
-    const unsigned zblocks = (unsigned) ((nrows + 2 * FFT_C - 1) / (2 * FFT_C));
+    const int stot = N * ntiles;
     double2 *cm = reinterpret_cast<double2 *>(d_mesh);
     hipStream_t s = ctx->stream;
-    if(lds > 48 * 1024) { /* allow > 48 KB of dynamic LDS */
-        (void) hipFuncSetAttribute((const void *) fft_pass_z_fwd<N, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        (void) hipFuncSetAttribute((const void *) fft_pass_z_fwd<N, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        (void) hipFuncSetAttribute((const void *) fft_pass_z_inv<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        (void) hipFuncSetAttribute((const void *) fft_pass_strided<N, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        (void) hipFuncSetAttribute((const void *) fft_pass_strided<N, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        (void) hipFuncSetAttribute((const void *) fft_pass_strided<N, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    /* persistent grids: as many workgroups as are resident on the chip at once (LDS-limited) */
+    static unsigned res_zf = 0, res_zi = 0, res_s = 0;
+    if(res_s == 0) {
+        const void *fns[6] = {(const void *) fft_pass_z_fwd<N, true>, (const void *) fft_pass_z_fwd<N, false>,
+                              (const void *) fft_pass_z_inv<N>,       (const void *) fft_pass_strided<N, 0>,
+                              (const void *) fft_pass_strided<N, 1>,  (const void *) fft_pass_strided<N, 2>};
+        int ncu = 0;
+        if(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || ncu < 1)
+            ncu = 256;
+        unsigned occ[6];
+        for(int i = 0; i < 6; i++) {
+            if(lds > 48 * 1024) /* allow > 48 KB of dynamic LDS */
+                SHQ_HIP(hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            int per_cu = 0;
+            if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fns[i], FFT_T, lds) != hipSuccess || per_cu < 1)
+                per_cu = 1;
+            occ[i] = (unsigned) per_cu * (unsigned) ncu;
+        }
+        res_zf = occ[0] < occ[1] ? occ[0] : occ[1];
+        res_zi = occ[2];
+        res_s = occ[3] < occ[4] ? occ[3] : occ[4];
+        res_s = res_s < occ[5] ? res_s : occ[5];
     }
-    const unsigned sblocks = (unsigned) (N * ntiles);
+    const unsigned gmul = getenv("SHQ_FFT_GRID_MUL") ? (unsigned) atoi(getenv("SHQ_FFT_GRID_MUL")) : 8u;
+    auto grid = [&](int tot, unsigned resident) {
+        const unsigned cap = gmul == 0 ? (unsigned) tot : resident * gmul;
+        return dim3((unsigned) tot < cap ? (unsigned) tot : cap);
+    };
+    const dim3 gzf = grid(ztot, res_zf), gzi = grid(ztot, res_zi), gs = grid(stot, res_s);
     const unsigned xcdk = getenv("SHQ_FFT_XCD_K") ? (unsigned) atoi(getenv("SHQ_FFT_XCD_K")) : 8u;
     if(stage == 0 || stage == 2) {
         if(from_i64)
-            fft_pass_z_fwd<N, true><<<dim3(zblocks), dim3(FFT_T), lds, s>>>(d_mesh, nrows, zp, W, inv_scale);
+            fft_pass_z_fwd<N, true><<<gzf, dim3(FFT_T), lds, s>>>(d_mesh, ztot, zp, W, inv_scale);
         else
-            fft_pass_z_fwd<N, false><<<dim3(zblocks), dim3(FFT_T), lds, s>>>(d_mesh, nrows, zp, W, 1.0);
+            fft_pass_z_fwd<N, false><<<gzf, dim3(FFT_T), lds, s>>>(d_mesh, ztot, zp, W, 1.0);
         /* Y: outer = x plane (stride N*zpc), element stride zpc */
-        fft_pass_strided<N, 0><<<dim3(sblocks), dim3(FFT_T), lds, s>>>(cm, zpc, (long long) N * zpc, ntiles, W, ga, xcdk);
+        fft_pass_strided<N, 0><<<gs, dim3(FFT_T), lds, s>>>(cm, zpc, (long long) N * zpc, ntiles, stot, W, ga, xcdk);
     }
     /* X: outer = y (stride zpc), element stride N*zpc */
     if(stage == 0)
-        fft_pass_strided<N, 0><<<dim3(sblocks), dim3(FFT_T), lds, s>>>(cm, (long long) N * zpc, zpc, ntiles, W, ga, xcdk);
+        fft_pass_strided<N, 0><<<gs, dim3(FFT_T), lds, s>>>(cm, (long long) N * zpc, zpc, ntiles, stot, W, ga, xcdk);
     else if(stage == 1)
-        fft_pass_strided<N, 1><<<dim3(sblocks), dim3(FFT_T), lds, s>>>(cm, (long long) N * zpc, zpc, ntiles, W, ga, xcdk);
+        fft_pass_strided<N, 1><<<gs, dim3(FFT_T), lds, s>>>(cm, (long long) N * zpc, zpc, ntiles, stot, W, ga, xcdk);
     else
-        fft_pass_strided<N, 2><<<dim3(sblocks), dim3(FFT_T), lds, s>>>(cm, (long long) N * zpc, zpc, ntiles, W, ga, xcdk);
+        fft_pass_strided<N, 2><<<gs, dim3(FFT_T), lds, s>>>(cm, (long long) N * zpc, zpc, ntiles, stot, W, ga, xcdk);
     if(stage == 1 || stage == 2) {
-        fft_pass_strided<N, 1><<<dim3(sblocks), dim3(FFT_T), lds, s>>>(cm, zpc, (long long) N * zpc, ntiles, W, ga, xcdk);
-        fft_pass_z_inv<N><<<dim3(zblocks), dim3(FFT_T), lds, s>>>(d_mesh, nrows, zp, W);
+        fft_pass_strided<N, 1><<<gs, dim3(FFT_T), lds, s>>>(cm, zpc, (long long) N * zpc, ntiles, stot, W, ga, xcdk);
+        fft_pass_z_inv<N><<<gzi, dim3(FFT_T), lds, s>>>(d_mesh, ztot, zp, W);
     }
     SHQ_HIP(hipGetLastError());
     return SHQ_OK;
