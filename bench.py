@@ -188,7 +188,7 @@ def main():
     nmesh = 3 * n1 if n1 != 512 else 1024
     t_setup = time.perf_counter()
     pos = sq.synth_positions(args.kind, n, seed=20240601 + rank, L=L)
-    pos = pos[sq.morton_order(pos, L)]
+    pos = pos[sq.hilbert_order(pos, L)]  # Peano-Hilbert order, as the reference keeps its particles (domain.cpp:268)
     pman = sq.PartManager(n, L)
     P = pman.Base
     P["Pos"] = pos

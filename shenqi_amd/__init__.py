@@ -171,6 +171,14 @@ def morton_order(pos, L):
     return order
 
 
+def hilbert_order(pos, L):
+    """Peano-Hilbert order (what the reference keeps particles in, domain.cpp:268)."""
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    order = np.empty(len(pos), dtype=np.int32)
+    capi.host.shqh_hilbert_order(capi.ptr(pos), len(pos), L, capi.ptr(order))
+    return order
+
+
 # ---- SPH operators (libgadget/density2.h, hydra2.h) ---------------------------------------------
 from .capi import KickFactors, DensityParams, HydroParams, SphStats  # noqa: E402
 

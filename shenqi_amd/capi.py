@@ -232,6 +232,8 @@ host.shqh_synth_positions.argtypes = [C.c_int, C.c_int64, C.c_uint64, C.c_double
 host.shqh_synth_positions.restype = None
 host.shqh_morton_order.argtypes = [_vp, C.c_int64, C.c_double, _vp]
 host.shqh_morton_order.restype = None
+host.shqh_hilbert_order.argtypes = [_vp, C.c_int64, C.c_double, _vp]
+host.shqh_hilbert_order.restype = None
 
 
 def check(rc, where="shq"):

@@ -520,6 +520,16 @@ extern "C" int shq_grav_short_download(shq_context *ctx, double (*accel)[3], dou
         stats->nnode_interactions = (int64_t) gs.nnode_interactions;
         stats->min_interactions = stats->ntargets > 0 ? gs.min_int : 0;
         stats->max_interactions = gs.max_int;
+        if(ctx->walk_stats == 2) { /* diagnostic: rounds by participating lanes, to stderr */
+            const char *names[3] = {"visit", "node", "leaf"};
+            const unsigned long long *h[3] = {gs.hist_visit, gs.hist_node, gs.hist_leaf};
+            for(int k = 0; k < 3; k++) {
+                fprintf(stderr, "[shq] walk rounds by lanes (1-8 .. 57-64) %-5s:", names[k]);
+                for(int b = 0; b < 8; b++)
+                    fprintf(stderr, " %llu", h[k][b]);
+                fprintf(stderr, "\n");
+            }
+        }
         float ms = 0;
         if(stats->ntargets > 0 && hipEventElapsedTime(&ms, ctx->ev_begin[SHQ_NTIMERS - 1], ctx->ev_end[SHQ_NTIMERS - 1]) == hipSuccess)
             stats->kernel_ms = ms;

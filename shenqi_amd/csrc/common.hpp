@@ -124,6 +124,8 @@ struct GravStatsDev {
     unsigned long long nnode_interactions;
     long long min_int;
     long long max_int;
+    /* SHQ_WALK_STATS=2 diagnostics: rounds by number of participating lanes (8 buckets of 8 lanes) */
+    unsigned long long hist_visit[8], hist_node[8], hist_leaf[8];
 };
 
 /* XCD-aware block remap (bijective for any grid size): workgroups are dealt round-robin over the

@@ -134,7 +134,7 @@ __device__ __forceinline__ void leaf_particle(const double4 *__restrict__ tab, c
 
 /* POT: accumulate the potential.  PREFETCH: speculative fetch of pool[cur+1].  LEAFB: leaf
  * particles fetched per batch (2 or 4).  STATS: wave-level counters for the bench. */
-template <bool POT, bool PREFETCH, int LEAFB, bool STATS>
+template <bool POT, bool PREFETCH, int LEAFB, int STATS>
 __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
 {
     __shared__ double4 tab[SHQ_NGRAVTAB];
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
     int mynext = valid ? a.root : -2;
     int cur = a.root;
     unsigned int visited = 0, wave_applies = 0, wave_node_applies = 0;
+    unsigned int hv[8] = {}, hn[8] = {}, hl[8] = {};
 
     NodeG nd = a.nodeG[cur];
 
@@ -174,6 +175,8 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
         if(STATS)
             visited++;
         const bool act = (mynext == cur);
+        if(STATS == 2)
+            hv[(__popcll(__ballot(act)) - 1) >> 3 & 7]++;
 
         /* gravshort2.hpp:262-265 */
         /* The periodic wrap is the identity unless some |d| exceeds L/2; one wave-uniform test
@@ -204,6 +207,8 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
                 wave_applies++;
                 wave_node_applies++;
             }
+            if(STATS == 2)
+                hn[(__popcll(__ballot(accept)) - 1) >> 3 & 7]++;
             if(accept) {
                 apply_accn<POT>(tab, dx, dy, dz, r2, nd.mass, a, ax, ay, az, pot);
                 nint++;
@@ -219,6 +224,8 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
                 const int cnt = nd.count;
                 if(STATS)
                     wave_applies += cnt;
+                if(STATS == 2)
+                    hl[(__popcll(__ballot(doopen)) - 1) >> 3 & 7] += cnt;
                 /* leaf slots are contiguous and the array is padded by NMAXCHILD entries */
 #pragma unroll
                 for(int b = 0; b < SHQ_NMAXCHILD; b += LEAFB) {
@@ -289,6 +296,12 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
             atomicAdd(&a.stats->nwave_node_applies, (unsigned long long) wave_node_applies);
             atomicAdd(&a.stats->nnode_interactions, (unsigned long long) smn);
         }
+        if(STATS == 2)
+            for(int b = 0; b < 8; b++) {
+                atomicAdd(&a.stats->hist_visit[b], (unsigned long long) hv[b]);
+                atomicAdd(&a.stats->hist_node[b], (unsigned long long) hn[b]);
+                atomicAdd(&a.stats->hist_leaf[b], (unsigned long long) hl[b]);
+            }
     }
 }
 
@@ -341,15 +354,19 @@ __global__ void stats_init_kernel(GravStatsDev *s)
     s->nnode_interactions = 0;
     s->min_int = 0x7fffffffffffll;
     s->max_int = 0;
+    for(int b = 0; b < 8; b++)
+        s->hist_visit[b] = s->hist_node[b] = s->hist_leaf[b] = 0;
 }
 
 template <bool POT, bool PREFETCH, int LEAFB>
-void launch_variant(bool stats, dim3 grid, dim3 block, hipStream_t stream, const WalkArgs &a)
+void launch_variant(int stats, dim3 grid, dim3 block, hipStream_t stream, const WalkArgs &a)
 {
-    if(stats)
-        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, true><<<grid, block, 0, stream>>>(a);
+    if(stats == 2 && POT && !PREFETCH && LEAFB == 2)
+        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, (POT && !PREFETCH && LEAFB == 2) ? 2 : 1><<<grid, block, 0, stream>>>(a);
+    else if(stats)
+        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 1><<<grid, block, 0, stream>>>(a);
     else
-        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, false><<<grid, block, 0, stream>>>(a);
+        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 0><<<grid, block, 0, stream>>>(a);
 }
 
 } // namespace
@@ -407,7 +424,7 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     /* tuning knobs (diagnostic): SHQ_WALK_VARIANT = 0..3 selects prefetch/leaf-batch; the
      * default is the measured-fastest one. */
     const int variant = ctx->walk_variant;
-    const bool stats = ctx->walk_stats != 0;
+    const int stats = ctx->walk_stats;
     SHQ_HIP(hipEventRecord(ctx->ev_begin[SHQ_NTIMERS - 1], ctx->stream));
     if(update_potential) {
         switch(variant) {

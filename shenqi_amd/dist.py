@@ -311,7 +311,7 @@ class DistTreePM:
         their owner).  Orders them along a space-filling curve, imports ghosts, builds and uploads the tree."""
         sq = self.sq
         host = posm_local.cpu().numpy()
-        order = sq.morton_order(np.ascontiguousarray(host[:, :3]), self.L)
+        order = sq.hilbert_order(np.ascontiguousarray(host[:, :3]), self.L)
         self.local = posm_local[torch.from_numpy(order.astype(np.int64)).to(posm_local.device)].contiguous()
         self.nloc = int(self.local.shape[0])
         self.halo = self.halo_factor * Rcut

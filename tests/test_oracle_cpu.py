@@ -261,3 +261,19 @@ def test_oracle_pm_stencil_equals_kspace_difference():
     g2, _, rho2, _ = orc.pm_force(pos, m, 48, cm.BOX, 1.5, cm.G, fixed_point_log2scale=48, use_stencil=1, want_mesh=True)
     assert np.abs(rho2 - rho).max() < 8 * 2.0**-48 * 64
     assert np.abs(g2 - g1).max() < 1e-10 * np.abs(g1).max()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "cluster"])
+def test_space_filling_orders(kind):
+    """Both particle orders are permutations; the Peano-Hilbert one (what the reference sorts by,
+    domain.cpp:268) is a continuous curve: consecutive particles of a dense sample are neighbours."""
+    n, L = 32768, 1.0
+    pos = sq.synth_positions(kind, n, L=L)
+    for fn in (sq.morton_order, sq.hilbert_order):
+        o = fn(pos, L)
+        assert np.array_equal(np.sort(o), np.arange(n))
+    if kind == "uniform":
+        step_h = np.linalg.norm(np.diff(pos[sq.hilbert_order(pos, L)], axis=0), axis=1)
+        step_m = np.linalg.norm(np.diff(pos[sq.morton_order(pos, L)], axis=0), axis=1)
+        assert step_h.max() < 0.25 * L < step_m.max()  # no long jumps along the Hilbert curve
+        assert step_h.mean() < step_m.mean()

@@ -21,7 +21,7 @@ n = n1**3
 L = 1.0
 nmesh = 3 * n1
 pos = sq.synth_positions(kind, n, L=L)
-pos = pos[sq.morton_order(pos, L)]
+pos = pos[(sq.hilbert_order if os.environ.get("TUNE_ORDER", "morton") == "hilbert" else sq.morton_order)(pos, L)]
 pman = sq.PartManager(n, L)
 pman.Base["Pos"] = pos
 pman.Base["Type"] = 1
@@ -56,5 +56,9 @@ for rnd in range(3):
         s = sq.WalkStats()
         capi.check(capi.hip.shq_grav_short_download(c.h, None, None, None, C.byref(s)))
         res[k].append(s.kernel_ms)
+        last = s
 for k in sorted(res):
     print("variant %d xcdK %d: walk ms min %.2f med %.2f" % (k[0], k[1], min(res[k]), sorted(res[k])[1]), flush=True)
+print("order %s: visits/wave %.1f node rounds/wave %.1f lane eff %.3f" % (
+    os.environ.get("TUNE_ORDER", "morton"), last.nnodes_visited / (n / 64.0), last.nwave_node_interactions / (n / 64.0),
+    last.ninteractions / max(1.0, 64.0 * last.nwave_interactions)), flush=True)
