@@ -16,7 +16,7 @@ knob = sys.argv[2] if len(sys.argv) > 2 else "SHQ_FFT_XCD_K"
 vals = sys.argv[3].split(",") if len(sys.argv) > 3 else ["0", "4", "8", "32"]
 n = n1**3
 pos = sq.synth_positions("cluster", n, L=1.0)
-pos = pos[sq.morton_order(pos, 1.0)]
+pos = pos[sq.hilbert_order(pos, 1.0)]
 pman = sq.PartManager(n, 1.0)
 pman.Base["Pos"] = pos
 pman.Base["Type"] = 1
