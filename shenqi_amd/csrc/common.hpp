@@ -198,9 +198,10 @@ struct shq_context {
     DevBuf<double> g_hydroaccel_out, g_dtentropy_out, g_maxsignalvel;
     DevBuf<double4> velp, hydC, hydD, velp_leaf, hydC_leaf, hydD_leaf;
     DevBuf<double> hsml_leaf;
-    DevBuf<uint8_t> flag_leaf;
+    DevBuf<int32_t> flag_leaf;
     DevBuf<double> s_numngb, s_dhsmldens, s_left, s_right, s_rot, s_gradrho, s_evp_in;
     DevBuf<int32_t> s_todo, s_queue2, s_queue3, s_blockcount;
+    DevBuf<int32_t> s_nlist;   /* per-lane neighbour lists of the SPH walks */
     DevBuf<long long> s_counters;
 
     /* ---- PM */

@@ -13,7 +13,10 @@
  *   - per-neighbour quantities that the reference recomputes for every pair (SPH_VelPred,
  *     SPH_EntVarPred, density/pressure prediction, sound speed, the Balsara factor f2 of j) are
  *     pure functions of particle j, so a prepass evaluates them once per particle and stores them
- *     in leaf order: a neighbour costs two (density) or four (hydro) 32-byte uniform loads;
+ *     in leaf order;
+ *   - node records and candidate particles are staged through LDS (64-node window of the pre-order
+ *     pool, 64-candidate tile) and accepted neighbours go to per-lane lists that are evaluated lane
+ *     by lane (see ngb_walk below);
  *   - the Hsml iteration runs on the device: walk -> postprocess (bisection / Newton step,
  *     Left/Right brackets) -> order-preserving compaction of the redo queue; the host only reads
  *     back the queue length once per iteration.
@@ -21,6 +24,7 @@
  */
 #include "common.hpp"
 #include <math.h>
+#include <stdlib.h>
 
 #define SPH_GAMMA (5.0 / 3.0)      /* physconst.h:35 */
 #define SPH_GAMMA_MINUS1 (SPH_GAMMA - 1)
@@ -117,13 +121,14 @@ struct SphDev {
     double *hmax;               /* per node */
     const int32_t *pfather;     /* particle -> packed father leaf */
     int root;
+    int npool;                  /* packed nodes */
     /* leaf-order neighbour data */
     const double4 *posm_leaf;   /* x,y,z,m */
     const double4 *velp_leaf;   /* predicted velocity, EntVarPred */
     const double4 *hydC_leaf;   /* EntVarPred, density_j, soundspeed_j, p_over_rho2_j */
     const double4 *hydD_leaf;   /* Dhsml_j, rr2_j, f2_j, dloga_for_bin_j */
     const double *hsml_leaf;
-    const uint8_t *flag_leaf;   /* bit0 skip (garbage / not gas), bit1 wind-decoupled */
+    const int32_t *flag_leaf;   /* bit0 skip (garbage / not gas), bit1 wind-decoupled */
     /* per particle */
     const double4 *posm;
     const uint8_t *pflags;
@@ -142,21 +147,6 @@ struct SphDev {
     double *dtent, *maxsig;
     double Box, invBox;
 };
-
-/* cull_node<symmetric>, localtreewalk2.h:154-182 */
-__device__ __forceinline__ bool cull_keep(const NodeB &B, double px, double py, double pz, double search, double Box,
-                                          double invBox)
-{
-    double dist = search + 0.5 * B.len;
-    const double dx = wrapd(B.center[0] - px, Box, invBox);
-    const double dy = wrapd(B.center[1] - py, Box, invBox);
-    const double dz = wrapd(B.center[2] - pz, Box, invBox);
-    if(fmax(fmax(fabs(dx), fabs(dy)), fabs(dz)) > dist)
-        return false;
-    const double r2 = dx * dx + dy * dy + dz * dz;
-    dist += (0.5 * (1.7320508075688772 - 1.0)) * B.len;
-    return !(r2 > dist * dist);
-}
 
 /* ---- prepass: per-particle predicted quantities -------------------------------------------- */
 struct PredArgs {
@@ -219,7 +209,7 @@ __global__ void sph_predict_kernel(const PredArgs a)
 __global__ void sph_gather_leaf_kernel(long long nleaf, const int32_t *pidx, const double4 *velp, const double4 *hydC,
                                        const double4 *hydD, const double *hsml, const uint8_t *pflags, const double *delay,
                                        double4 *velp_leaf, double4 *hydC_leaf, double4 *hydD_leaf, double *hsml_leaf,
-                                       uint8_t *flag_leaf)
+                                       int32_t *flag_leaf)
 {
     const long long s = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if(s >= nleaf)
@@ -241,11 +231,198 @@ __global__ void sph_gather_leaf_kernel(long long nleaf, const int32_t *pidx, con
 }
 
 /* ---- density walk ------------------------------------------------------------------------------ */
-template <int KT> __global__ __launch_bounds__(256) void sph_density_kernel(const SphDev a, const int32_t *queue, long long nq,
-                                                                           int WindsDecouple, unsigned long long *nint_total)
+/* Per-lane neighbour lists.  The union walk hands every leaf particle to all lanes whose search
+ * sphere touches the leaf, but only a few of them actually have it within their kernel support; doing
+ * the pair arithmetic (~100 f64 instructions for density, ~200 for hydro) under that mask keeps 10-20 %
+ * of the lanes busy.  So the walk only runs the distance test (a dozen instructions) and appends the
+ * accepted leaf slot to the lane's list; at the end of the walk (or when a list is full) every lane
+ * works through ITS OWN list with vector loads, all lanes busy.  A lane meets its neighbours in exactly
+ * the order of the depth-first walk, so sums are bit-identical to the immediate evaluation.
+ * A lane collects its ~100 neighbours in a burst while the walk passes its corner of the group's
+ * volume, so short LDS lists flushed whenever one lane fills up ran 431 pair rounds per wave for 112
+ * pairs per target; the lists therefore live in global memory (L2-resident scratch, one region per
+ * resident wave of a persistent grid, [entry][lane] so appends and reads coalesce) and are long enough
+ * to be drained once. */
+#define NL_CAP 160      /* list entries per lane; quintic-kernel neighbourhoods hold ~113 */
+#define NL_MAXBLOCKS 4096 /* persistent workgroups (4 waves each) that own a list region */
+
+template <class F> __device__ __forceinline__ void nl_flush(const int32_t *myl, int &fill, F &&pair)
 {
+    int s_next = fill > 0 ? myl[0] : 0;
+    for(int j = 0; __ballot(j < fill) != 0ull; j++) {
+        const int s = s_next;
+        if(j + 1 < fill)
+            s_next = myl[(j + 1) * 64]; /* in flight while this pair is evaluated */
+        if(j < fill)
+            pair(s);
+    }
+    fill = 0;
+}
+
+/* ---- the neighbour walk shared by density and hydro ------------------------------------------------
+ * Same wavefront-collective union walk as before (wave-uniform `cur`, per-lane `mynext`, cull_node per
+ * lane), restructured around LDS so that no step waits on a dependent global load per node or per
+ * candidate (with 4 waves per SIMD those ~1000-cycle waits kept the VALUs 44 % busy):
+ *   - node window: the pool is in depth-first pre-order and a walk mostly moves forward in it, so the
+ *     wave fetches 64 consecutive node records at a time (coalesced) into LDS and reads the node under
+ *     the cursor from there; a jump outside the window reloads it;
+ *   - candidate tile: leaves some lane wants are queued (slot range + the mask of interested lanes);
+ *     when 64 candidates are queued the wave gathers them in ONE coalesced load, parks position, Hsml
+ *     and flag in LDS, and every lane runs the distance test over the tile with broadcast reads;
+ *   - accepted candidates go to the lane's list (see above) and are evaluated lane by lane.
+ * Leaves are queued and tiles are scanned in walk order, so each lane still meets its neighbours in
+ * depth-first order. */
+#define NW_WIN 64
+#define NW_LDS_PER_WAVE (NW_WIN * (32 + 16 + 8) + 64 * (32 + 8 + 8 + 4 + 4))
+
+template <bool SYM, class Accept, class Pair>
+__device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave, int32_t *myl, const bool valid, const double px,
+                                                 const double py, const double pz, const double h, Accept &&accept, Pair &&pair,
+                                                 unsigned int *dbg)
+{
+    double4 *winB = reinterpret_cast<double4 *>(lds_wave);
+    int4 *winC = reinterpret_cast<int4 *>(lds_wave + NW_WIN * 32);
+    double *winH = reinterpret_cast<double *>(lds_wave + NW_WIN * 48);
+    char *tl = lds_wave + NW_WIN * 56;
+    double4 *tq = reinterpret_cast<double4 *>(tl);
+    unsigned long long *tmask = reinterpret_cast<unsigned long long *>(tl + 64 * 32);
+    double *th = reinterpret_cast<double *>(tl + 64 * 40);
+    int *tsl = reinterpret_cast<int *>(tl + 64 * 48);
+    int *tfl = reinterpret_cast<int *>(tl + 64 * 52);
     const int lane = threadIdx.x & 63;
-    const long long wave = (long long) xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const double halfBox = 0.5 * a.Box;
+    unsigned int nint = 0;
+    int fill = 0, ncand = 0;
+
+    /* scan the queued candidates: one coalesced gather, then broadcast reads */
+    auto scan_tile = [&]() {
+        if(lane < ncand) {
+            const int s = tsl[lane];
+            tq[lane] = a.posm_leaf[s];
+            tfl[lane] = a.flag_leaf[s];
+            if(SYM)
+                th[lane] = a.hsml_leaf[s];
+        }
+        __builtin_amdgcn_wave_barrier();
+        for(int j = 0; j < ncand; j++) {
+            const double4 q = tq[j];
+            const unsigned long long km = tmask[j];
+            const int fl = tfl[j], s = tsl[j];
+            const double hj = SYM ? th[j] : 0.0;
+            const bool keep = ((km >> lane) & 1ull) && !(fl & 1);
+            double d0 = px - q.x, d1 = py - q.y, d2 = pz - q.z;
+            if(__ballot(keep && fmax(fmax(fabs(d0), fabs(d1)), fabs(d2)) > halfBox) != 0ull) {
+                d0 = wrapd(d0, a.Box, a.invBox);
+                d1 = wrapd(d1, a.Box, a.invBox);
+                d2 = wrapd(d2, a.Box, a.invBox);
+            }
+            const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+            if(keep) {
+                nint++;
+                if(accept(r2, hj, fl)) {
+                    myl[fill * 64] = s;
+                    fill++;
+                }
+            }
+            if(__ballot(fill == NL_CAP) != 0ull) {
+                if(dbg)
+                    dbg[2] += NL_CAP;
+                nl_flush(myl, fill, pair);
+            }
+        }
+        if(dbg)
+            dbg[1] += ncand;
+        __builtin_amdgcn_wave_barrier();
+        ncand = 0;
+    };
+
+    int mynext = valid ? a.root : -2;
+    int cur = a.root, wbase = -(1 << 30);
+    while(cur >= 0) {
+        if(cur < wbase || cur >= wbase + NW_WIN) {
+            wbase = cur;
+            __builtin_amdgcn_wave_barrier();
+            const int idx = min(cur + lane, a.npool - 1);
+            const NodeB nb = a.nodeB[idx];
+            const NodeC nc = a.nodeC[idx];
+            winB[lane] = make_double4(nb.center[0], nb.center[1], nb.center[2], nb.len);
+            winC[lane] = make_int4(nc.sibling, nc.child, nc.type, nc.count);
+            if(SYM)
+                winH[lane] = a.hmax[idx];
+            __builtin_amdgcn_wave_barrier();
+        }
+        const int w = cur - wbase;
+        const double4 B = winB[w];
+        const int4 Cv = winC[w];
+        const int Csib = __builtin_amdgcn_readfirstlane(Cv.x), Cchild = __builtin_amdgcn_readfirstlane(Cv.y);
+        const int Ctype = __builtin_amdgcn_readfirstlane(Cv.z), Ccount = __builtin_amdgcn_readfirstlane(Cv.w);
+        if(dbg)
+            dbg[0]++;
+        const bool act = (mynext == cur);
+        /* cull_node<symmetric>, localtreewalk2.h:154-182 */
+        bool keep = false;
+        {
+            double dist = (SYM ? fmax(winH[w], h) : h) + 0.5 * B.w;
+            double dx = B.x - px, dy = B.y - py, dz = B.z - pz;
+            if(__ballot(act && fmax(fmax(fabs(dx), fabs(dy)), fabs(dz)) > halfBox) != 0ull) {
+                dx = wrapd(dx, a.Box, a.invBox);
+                dy = wrapd(dy, a.Box, a.invBox);
+                dz = wrapd(dz, a.Box, a.invBox);
+            }
+            if(!(fmax(fmax(fabs(dx), fabs(dy)), fabs(dz)) > dist)) {
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                dist += (0.5 * (1.7320508075688772 - 1.0)) * B.w;
+                keep = act && !(r2 > dist * dist);
+            }
+        }
+        int next;
+        if(Ctype == SHQ_PARTICLE_NODE_TYPE) {
+            const unsigned long long km = __ballot(keep);
+            if(km != 0ull && Ccount > 0) {
+                if(ncand + Ccount > 64)
+                    scan_tile();
+                if(lane < Ccount) {
+                    tsl[ncand + lane] = Cchild + lane;
+                    tmask[ncand + lane] = km;
+                }
+                ncand += Ccount;
+            }
+            if(act)
+                mynext = Csib;
+            next = Csib;
+        } else if(Ctype == SHQ_PSEUDO_NODE_TYPE) {
+            if(act)
+                mynext = Csib;
+            next = Csib;
+        } else {
+            const bool any = __ballot(keep) != 0ull;
+            if(act)
+                mynext = keep ? Cchild : Csib;
+            next = any ? Cchild : Csib;
+        }
+        cur = next;
+    }
+    if(ncand > 0)
+        scan_tile();
+    if(dbg) {
+        int mf = fill;
+        for(int off = 32; off > 0; off >>= 1)
+            mf = max(mf, __shfl_xor(mf, off));
+        dbg[2] += mf;
+    }
+    nl_flush(myl, fill, pair);
+    return nint;
+}
+
+template <int KT> __global__ __launch_bounds__(256) void sph_density_kernel(const SphDev a, const int32_t *queue, long long nq,
+                                                                           int WindsDecouple, unsigned long long *nint_total,
+                                                                           int32_t *__restrict__ nlist, long long ntasks)
+{
+    __shared__ __attribute__((aligned(32))) char lds[4 * NW_LDS_PER_WAVE];
+    const int lane = threadIdx.x & 63;
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
+    const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long t = wave * 64 + lane;
     const bool valid = t < nq;
     long long pi = 0;
@@ -262,76 +439,45 @@ template <int KT> __global__ __launch_bounds__(256) void sph_density_kernel(cons
     }
     const Kern<KT> kernel(valid ? h : 1.0);
     const double h2 = h * h, Hinv = 1.0 / kernel.H, vol = kernel.volume();
+    const bool nowind = WindsDecouple && type == 5; /* wind-decoupled neighbours are invisible to black holes */
     double Ngb = 0, Rho = 0, DhsmlDensity = 0, EgyRho = 0, DhsmlEgy = 0, Div = 0;
     double R0 = 0, R1 = 0, R2 = 0, G0 = 0, G1 = 0, G2 = 0;
-    unsigned int nint = 0;
-    int mynext = valid ? a.root : -2;
-    int cur = a.root;
-    while(cur >= 0) {
-        cur = __builtin_amdgcn_readfirstlane(cur);
-        const NodeB B = a.nodeB[cur];
-        const NodeC C = a.nodeC[cur];
-        const bool act = (mynext == cur);
-        const bool keep = act && cull_keep(B, px, py, pz, h, a.Box, a.invBox);
-        int next;
-        if(C.type == SHQ_PARTICLE_NODE_TYPE) {
-            if(__ballot(keep) != 0ull) {
-                for(int k = 0; k < C.count; k++) {
-                    const int s = C.child + k;
-                    const uint8_t fl = a.flag_leaf[s];
-                    if(fl & 1)
-                        continue;
-                    const double4 q = a.posm_leaf[s];
-                    const double4 w = a.velp_leaf[s];
-                    if(keep) {
-                        nint++;
-                        /* ngbiter, densitytree2.hpp:362-423; dist points from the neighbour to the target */
-                        const double d0 = wrapd(px - q.x, a.Box, a.invBox);
-                        const double d1 = wrapd(py - q.y, a.Box, a.invBox);
-                        const double d2 = wrapd(pz - q.z, a.Box, a.invBox);
-                        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
-                        if(r2 < h2 && !(WindsDecouple && type == 5 && (fl & 2))) {
-                            const double r = sqrt(r2);
-                            const double u = r * Hinv;
-                            const double wk = kernel.wk(u);
-                            const double dwk = kernel.dwk(u);
-                            Ngb += wk * vol;
-                            const double mj = q.w;
-                            Rho += mj * wk;
-                            const double dW = -(3 * wk * Hinv + u * dwk); /* DensityKrnl::dW, densitykernel.hpp:58-61 */
-                            DhsmlDensity += mj * dW;
-                            EgyRho += mj * w.w * wk;
-                            DhsmlEgy += mj * w.w * dW;
-                            if(r > 0) {
-                                const double fac = mj * dwk / r;
-                                const double e0 = vx - w.x, e1 = vy - w.y, e2 = vz - w.z;
-                                Div += -fac * (d0 * e0 + d1 * e1 + d2 * e2);
-                                R0 += fac * (e1 * d2 - e2 * d1);
-                                R1 += fac * (e2 * d0 - e0 * d2);
-                                R2 += fac * (e0 * d1 - e1 * d0);
-                                G0 += fac * d0;
-                                G1 += fac * d1;
-                                G2 += fac * d2;
-                            }
-                        }
-                    }
-                }
-            }
-            if(act)
-                mynext = C.sibling;
-            next = C.sibling;
-        } else if(C.type == SHQ_PSEUDO_NODE_TYPE) {
-            if(act)
-                mynext = C.sibling;
-            next = C.sibling;
-        } else {
-            const bool any = __ballot(keep) != 0ull;
-            if(act)
-                mynext = keep ? C.child : C.sibling;
-            next = any ? C.child : C.sibling;
+
+    /* ngbiter, densitytree2.hpp:362-423; dist points from the neighbour to the target */
+    auto pair = [&](const int s) {
+        const double4 q = a.posm_leaf[s];
+        const double4 w = a.velp_leaf[s];
+        const double d0 = wrapd(px - q.x, a.Box, a.invBox);
+        const double d1 = wrapd(py - q.y, a.Box, a.invBox);
+        const double d2 = wrapd(pz - q.z, a.Box, a.invBox);
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        const double r = sqrt(r2);
+        const double u = r * Hinv;
+        const double wk = kernel.wk(u);
+        const double dwk = kernel.dwk(u);
+        Ngb += wk * vol;
+        const double mj = q.w;
+        Rho += mj * wk;
+        const double dW = -(3 * wk * Hinv + u * dwk); /* DensityKrnl::dW, densitykernel.hpp:58-61 */
+        DhsmlDensity += mj * dW;
+        EgyRho += mj * w.w * wk;
+        DhsmlEgy += mj * w.w * dW;
+        if(r > 0) {
+            const double fac = mj * dwk / r;
+            const double e0 = vx - w.x, e1 = vy - w.y, e2 = vz - w.z;
+            Div += -fac * (d0 * e0 + d1 * e1 + d2 * e2);
+            R0 += fac * (e1 * d2 - e2 * d1);
+            R1 += fac * (e2 * d0 - e0 * d2);
+            R2 += fac * (e0 * d1 - e1 * d0);
+            G0 += fac * d0;
+            G1 += fac * d1;
+            G2 += fac * d2;
         }
-        cur = next;
-    }
+    };
+
+    auto accept = [&](const double r2, const double, const int fl) { return r2 < h2 && !(nowind && (fl & 2)); };
+    const unsigned int nint = ngb_walk<false>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE, myl, valid, px, py, pz, h, accept, pair,
+                                              (unsigned int *) nullptr);
     if(valid) {
         /* DensityResult::reduce<PRIMARY>, densitytree2.hpp:308-343 */
         a.numngb[pi] = Ngb;
@@ -351,11 +497,12 @@ template <int KT> __global__ __launch_bounds__(256) void sph_density_kernel(cons
             a.dhsmlegy[pi] = DhsmlEgy;
         }
     }
-    unsigned int s = nint;
+    unsigned int sn = nint;
     for(int off = 32; off > 0; off >>= 1)
-        s += __shfl_xor(s, off);
+        sn += __shfl_xor(sn, off);
     if(lane == 0 && nint_total)
-        atomicAdd(nint_total, (unsigned long long) s);
+        atomicAdd(nint_total, (unsigned long long) sn);
+    } /* task loop */
 }
 
 /* ---- density postprocess + Hsml update (DensityOutput::postprocess, density_check_neighbours) -- */
@@ -531,11 +678,15 @@ struct HydroConst {
     int DISPH;
 };
 
-template <int KT> __global__ __launch_bounds__(256) void sph_hydro_kernel(const SphDev a, const int32_t *queue, long long nq,
-                                                                         const HydroConst hc, unsigned long long *nint_total)
+template <int KT> __global__ __launch_bounds__(256, 4) void sph_hydro_kernel(const SphDev a, const int32_t *queue, long long nq,
+                                                                         const HydroConst hc, unsigned long long *nint_total,
+                                                                         int32_t *__restrict__ nlist, long long ntasks)
 {
+    __shared__ __attribute__((aligned(32))) char lds[4 * NW_LDS_PER_WAVE];
     const int lane = threadIdx.x & 63;
-    const long long wave = (long long) xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
+    const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long t = wave * 64 + lane;
     const bool valid = t < nq;
     long long pi = 0;
@@ -561,89 +712,58 @@ template <int KT> __global__ __launch_bounds__(256) void sph_hydro_kernel(const 
     const double hi2 = hi * hi;
     double A0 = 0, A1 = 0, A2 = 0, DtE = 0;
     double MaxSig = soundspeed_i; /* HydroResult ctor: sqrt(GAMMA P / EgyRho) */
-    unsigned int nint = 0;
-    int mynext = valid ? a.root : -2;
-    int cur = a.root;
-    while(cur >= 0) {
-        cur = __builtin_amdgcn_readfirstlane(cur);
-        const NodeB B = a.nodeB[cur];
-        const NodeC C = a.nodeC[cur];
-        const double hmax = a.hmax[cur];
-        const bool act = (mynext == cur);
-        const bool keep = act && cull_keep(B, px, py, pz, fmax(hmax, hi), a.Box, a.invBox);
-        int next;
-        if(C.type == SHQ_PARTICLE_NODE_TYPE) {
-            if(__ballot(keep) != 0ull) {
-                for(int k = 0; k < C.count; k++) {
-                    const int s = C.child + k;
-                    const uint8_t fl = a.flag_leaf[s];
-                    if(fl & 1)
-                        continue;
-                    const double4 q = a.posm_leaf[s];
-                    const double4 w = a.velp_leaf[s];
-                    const double hj = a.hsml_leaf[s];
-                    const double4 Cj = a.hydC_leaf[s];
-                    const double4 Dj = a.hydD_leaf[s];
-                    if(keep) {
-                        nint++;
-                        const double d0 = wrapd(px - q.x, a.Box, a.invBox);
-                        const double d1 = wrapd(py - q.y, a.Box, a.invBox);
-                        const double d2 = wrapd(pz - q.z, a.Box, a.invBox);
-                        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
-                        if(r2 > 0 && (r2 < hi2 || r2 < hj * hj) && !(fl & 2)) {
-                            const Kern<KT> kernel_j(hj);
-                            const double EVP = Cj.x, density_j = Cj.y, soundspeed_j = Cj.z, p_over_rho2_j = Cj.w;
-                            double vsig = soundspeed_i + soundspeed_j;
-                            if(vsig > MaxSig)
-                                MaxSig = vsig;
-                            const double e0 = vx - w.x, e1 = vy - w.y, e2 = vz - w.z;
-                            const double vdotr = d0 * e0 + d1 * e1 + d2 * e2;
-                            const double vdotr2 = vdotr + hc.hubble_a2 * r2;
-                            const double r = sqrt(r2);
-                            const double dwk_i = kernel_i.dwk(r / kernel_i.H);
-                            const double dwk_j = kernel_j.dwk(r / kernel_j.H);
-                            double visc = 0;
-                            if(vdotr2 < 0) {
-                                const double mu_ij = hc.fac_mu * vdotr2 / r;
-                                const double rho_ij = 0.5 * (iDensity + density_j);
-                                vsig = soundspeed_i + soundspeed_j - 3 * mu_ij;
-                                if(vsig > MaxSig)
-                                    MaxSig = vsig;
-                                visc = 0.25 * hc.ArtBulkViscConst * vsig * (-mu_ij) / rho_ij * (iF1 + Dj.z);
-                                const double dloga = 2 * fmax(idloga, Dj.w);
-                                if(dloga > 0 && (dwk_i + dwk_j) < 0) {
-                                    if((mi + q.w) > 0)
-                                        visc = fmin(visc, 0.5 * hc.fac_vsic_fix * vdotr2 / (0.5 * (mi + q.w) * (dwk_i + dwk_j) * r * dloga));
-                                }
-                            }
-                            const double hfc_visc = 0.5 * q.w * visc * (dwk_i + dwk_j) / r;
-                            double hfc = hfc_visc;
-                            if(hc.DISPH)
-                                hfc += q.w * (dwk_i * p_over_rho2_i * EVP / iEntVarPred + dwk_j * p_over_rho2_j * iEntVarPred / EVP) / r;
-                            hfc += q.w * (p_over_rho2_i * iDhsml * dwk_i * rr1 + p_over_rho2_j * Dj.x * dwk_j * Dj.y) / r;
-                            A0 += -hfc * d0;
-                            A1 += -hfc * d1;
-                            A2 += -hfc * d2;
-                            DtE += 0.5 * hfc_visc * vdotr2;
-                        }
-                    }
-                }
+
+    /* HydroLocalTreeWalk::ngbiter, hydratree2.hpp:253-378, for one accepted neighbour (leaf slot s) */
+    auto pair = [&](const int s) {
+        const double4 q = a.posm_leaf[s];
+        const double4 w = a.velp_leaf[s];
+        const double hj = a.hsml_leaf[s];
+        const double4 Cj = a.hydC_leaf[s];
+        const double4 Dj = a.hydD_leaf[s];
+        const double d0 = wrapd(px - q.x, a.Box, a.invBox);
+        const double d1 = wrapd(py - q.y, a.Box, a.invBox);
+        const double d2 = wrapd(pz - q.z, a.Box, a.invBox);
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        const Kern<KT> kernel_j(hj);
+        const double EVP = Cj.x, density_j = Cj.y, soundspeed_j = Cj.z, p_over_rho2_j = Cj.w;
+        double vsig = soundspeed_i + soundspeed_j;
+        if(vsig > MaxSig)
+            MaxSig = vsig;
+        const double e0 = vx - w.x, e1 = vy - w.y, e2 = vz - w.z;
+        const double vdotr = d0 * e0 + d1 * e1 + d2 * e2;
+        const double vdotr2 = vdotr + hc.hubble_a2 * r2;
+        const double r = sqrt(r2);
+        const double dwk_i = kernel_i.dwk(r / kernel_i.H);
+        const double dwk_j = kernel_j.dwk(r / kernel_j.H);
+        double visc = 0;
+        if(vdotr2 < 0) {
+            const double mu_ij = hc.fac_mu * vdotr2 / r;
+            const double rho_ij = 0.5 * (iDensity + density_j);
+            vsig = soundspeed_i + soundspeed_j - 3 * mu_ij;
+            if(vsig > MaxSig)
+                MaxSig = vsig;
+            visc = 0.25 * hc.ArtBulkViscConst * vsig * (-mu_ij) / rho_ij * (iF1 + Dj.z);
+            const double dloga = 2 * fmax(idloga, Dj.w);
+            if(dloga > 0 && (dwk_i + dwk_j) < 0) {
+                if((mi + q.w) > 0)
+                    visc = fmin(visc, 0.5 * hc.fac_vsic_fix * vdotr2 / (0.5 * (mi + q.w) * (dwk_i + dwk_j) * r * dloga));
             }
-            if(act)
-                mynext = C.sibling;
-            next = C.sibling;
-        } else if(C.type == SHQ_PSEUDO_NODE_TYPE) {
-            if(act)
-                mynext = C.sibling;
-            next = C.sibling;
-        } else {
-            const bool any = __ballot(keep) != 0ull;
-            if(act)
-                mynext = keep ? C.child : C.sibling;
-            next = any ? C.child : C.sibling;
         }
-        cur = next;
-    }
+        const double hfc_visc = 0.5 * q.w * visc * (dwk_i + dwk_j) / r;
+        double hfc = hfc_visc;
+        if(hc.DISPH)
+            hfc += q.w * (dwk_i * p_over_rho2_i * EVP / iEntVarPred + dwk_j * p_over_rho2_j * iEntVarPred / EVP) / r;
+        hfc += q.w * (p_over_rho2_i * iDhsml * dwk_i * rr1 + p_over_rho2_j * Dj.x * dwk_j * Dj.y) / r;
+        A0 += -hfc * d0;
+        A1 += -hfc * d1;
+        A2 += -hfc * d2;
+        DtE += 0.5 * hfc_visc * vdotr2;
+    };
+
+    auto accept = [&](const double r2, const double hj, const int fl) { return r2 > 0 && (r2 < hi2 || r2 < hj * hj) && !(fl & 2); };
+    unsigned int dbgc[3] = {0, 0, 0};
+    const unsigned int nint = ngb_walk<true>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE, myl, valid, px, py, pz, hi, accept, pair,
+                                             nint_total ? dbgc : (unsigned int *) nullptr);
     if(valid) {
         a.hacc[3 * pi] = A0;
         a.hacc[3 * pi + 1] = A1;
@@ -651,11 +771,19 @@ template <int KT> __global__ __launch_bounds__(256) void sph_hydro_kernel(const 
         a.dtent[pi] = DtE;
         a.maxsig[pi] = MaxSig;
     }
-    unsigned int s = nint;
+    unsigned int sn = nint;
     for(int off = 32; off > 0; off >>= 1)
-        s += __shfl_xor(s, off);
+        sn += __shfl_xor(sn, off);
     if(lane == 0 && nint_total)
-        atomicAdd(nint_total, (unsigned long long) s);
+        atomicAdd(nint_total, (unsigned long long) sn);
+    if(nint_total) { /* diagnostics behind SHQ_SPH_DEBUG: [1] nodes/wave [2] candidates/wave [3] pairs (lanes) [4] flush rounds/wave */
+        if(lane == 0) {
+            atomicAdd(nint_total + 1, (unsigned long long) dbgc[0]);
+            atomicAdd(nint_total + 2, (unsigned long long) dbgc[1]);
+            atomicAdd(nint_total + 4, (unsigned long long) dbgc[2]);
+        }
+    }
+    } /* task loop */
 }
 
 /* HydroOutput::postprocess, hydratree2.hpp:134-148 + winds_decoupled_hydro, winds.h:60-68 */
@@ -705,6 +833,7 @@ SphDev make_dev(shq_context *ctx)
     a.hmax = ctx->node_hmax.ptr;
     a.pfather = ctx->pfather.ptr;
     a.root = ctx->root;
+    a.npool = (int) ctx->numnodes;
     a.posm_leaf = ctx->posm_leaf.ptr;
     a.velp_leaf = ctx->velp_leaf.ptr;
     a.hydC_leaf = ctx->hydC_leaf.ptr;
@@ -791,17 +920,27 @@ int shq_sph_prepare(shq_context *ctx, const shq_kick_factors *kf, const shq_hydr
     return SHQ_OK;
 }
 
+/* neighbour-list scratch: one NL_CAP x 64 region per wave of the persistent grid */
+static int reserve_nlist(shq_context *ctx, long long nq)
+{
+    const long long ntasks = (nq + 255) / 256;
+    const long long grid = ntasks < NL_MAXBLOCKS ? ntasks : NL_MAXBLOCKS;
+    return ctx->s_nlist.reserve((size_t) (grid > 0 ? grid : 1) * 4 * NL_CAP * 64);
+}
+
 template <int KT>
 static void launch_density(shq_context *ctx, const SphDev &a, const int32_t *q, long long nq, int wd, unsigned long long *nint)
 {
-    const long long nwaves = (nq + 63) / 64;
-    sph_density_kernel<KT><<<dim3((unsigned) ((nwaves + 3) / 4)), dim3(256), 0, ctx->stream>>>(a, q, nq, wd, nint);
+    const long long ntasks = (nq + 255) / 256;
+    const unsigned grid = (unsigned) (ntasks < NL_MAXBLOCKS ? ntasks : NL_MAXBLOCKS);
+    sph_density_kernel<KT><<<dim3(grid), dim3(256), 0, ctx->stream>>>(a, q, nq, wd, nint, ctx->s_nlist.ptr, ntasks);
 }
 template <int KT>
 static void launch_hydro(shq_context *ctx, const SphDev &a, const int32_t *q, long long nq, const HydroConst &hc, unsigned long long *nint)
 {
-    const long long nwaves = (nq + 63) / 64;
-    sph_hydro_kernel<KT><<<dim3((unsigned) ((nwaves + 3) / 4)), dim3(256), 0, ctx->stream>>>(a, q, nq, hc, nint);
+    const long long ntasks = (nq + 255) / 256;
+    const unsigned grid = (unsigned) (ntasks < NL_MAXBLOCKS ? ntasks : NL_MAXBLOCKS);
+    sph_hydro_kernel<KT><<<dim3(grid), dim3(256), 0, ctx->stream>>>(a, q, nq, hc, nint, ctx->s_nlist.ptr, ntasks);
 }
 
 /* Device-resident density(): queue = d_queue[0..nq) of particle indices (already filtered by
@@ -819,7 +958,8 @@ int shq_sph_density_device(shq_context *ctx, const shq_density_params *p, const 
     SHQ_TRY(ctx->s_todo.reserve(cap));
     SHQ_TRY(ctx->s_queue2.reserve(cap));
     SHQ_TRY(ctx->s_blockcount.reserve(nblk(n) + 1));
-    SHQ_TRY(ctx->s_counters.reserve(4));
+    SHQ_TRY(ctx->s_counters.reserve(8));
+    SHQ_TRY(reserve_nlist(ctx, nq));
     if(want_gradrho)
         SHQ_TRY(ctx->s_gradrho.reserve(3 * cap));
     SHQ_CHECK(p->DensityKernelType == 1 || p->DensityKernelType == 2 || p->DensityKernelType == 4, SHQ_ERR_INVALID,
@@ -830,7 +970,7 @@ int shq_sph_density_device(shq_context *ctx, const shq_density_params *p, const 
         SHQ_HIP(hipMemsetAsync(ctx->s_numngb.ptr, 0, sizeof(double) * n, ctx->stream));
         fill_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(ctx->s_right.ptr, n, p->BoxSize);
     }
-    SHQ_HIP(hipMemsetAsync(ctx->s_counters.ptr, 0, sizeof(long long) * 4, ctx->stream));
+    SHQ_HIP(hipMemsetAsync(ctx->s_counters.ptr, 0, sizeof(long long) * 8, ctx->stream));
     SphDev a = make_dev(ctx);
     a.gradrho = want_gradrho ? ctx->s_gradrho.ptr : nullptr;
     a.Box = p->BoxSize;
@@ -906,10 +1046,11 @@ int shq_sph_hydro_device(shq_context *ctx, const shq_hydro_params *p, const int3
     SHQ_TRY(ctx->g_hydroaccel_out.reserve(3 * cap));
     SHQ_TRY(ctx->g_dtentropy_out.reserve(cap));
     SHQ_TRY(ctx->g_maxsignalvel.reserve(cap));
-    SHQ_TRY(ctx->s_counters.reserve(4));
+    SHQ_TRY(ctx->s_counters.reserve(8));
+    SHQ_TRY(reserve_nlist(ctx, nq));
     SHQ_CHECK(p->DensityKernelType == 1 || p->DensityKernelType == 2 || p->DensityKernelType == 4, SHQ_ERR_INVALID,
               "unknown DensityKernelType %d", p->DensityKernelType);
-    SHQ_HIP(hipMemsetAsync(ctx->s_counters.ptr, 0, sizeof(long long) * 4, ctx->stream));
+    SHQ_HIP(hipMemsetAsync(ctx->s_counters.ptr, 0, sizeof(long long) * 8, ctx->stream));
     SphDev a = make_dev(ctx);
     a.Box = p->BoxSize;
     a.invBox = 1.0 / p->BoxSize;
@@ -943,6 +1084,13 @@ int shq_sph_hydro_device(shq_context *ctx, const shq_hydro_params *p, const int3
         stats->ninteractions = (int64_t) h_nint;
         stats->niterations = 1;
         stats->kernel_ms = ms;
+        if(getenv("SHQ_SPH_DEBUG")) {
+            unsigned long long d[5];
+            SHQ_HIP(hipMemcpy(d, nint, sizeof(d), hipMemcpyDeviceToHost));
+            const double nw = (double) ((nq + 63) / 64);
+            fprintf(stderr, "[shq] hydro per wave: nodes %.1f candidates %.1f pair rounds %.1f; per target: candidates %.1f\n",
+                    d[1] / nw, d[2] / nw, d[4] / nw, (double) d[0] / nq);
+        }
     }
     return SHQ_OK;
 }

@@ -19,7 +19,7 @@ kernel = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 n = n1**3
 L = 1.0
 pos = sq.synth_positions(kind, n, L=L)
-pos = pos[sq.morton_order(pos, L)]
+pos = pos[sq.hilbert_order(pos, L)]
 pman = sq.PartManager(n, L)
 P = pman.Base
 P["Pos"] = pos
