@@ -255,16 +255,40 @@ def main():
     ph = list(ph)
 
     ncells = float(nmesh) ** 3
-    # algorithmic bytes
-    tree_bytes = 68.0 * n + 76.0 * tree.numnodes          # compulsory: targets in/out + node pool once
-    pm_bytes = 468.0 * n + 240.0 * ncells                  # fused minimum of the reference structure
+    # ---- algorithmic bytes ------------------------------------------
+    # tree walk: compulsory traffic only (targets in/out + node pool once); the walk is not HBM-bound
+    tree_bytes = 68.0 * n + 76.0 * tree.numnodes
+    # PM as THIS pipeline runs it: zero (8 C write) + deposit (32 N read, 8 cells x 8 B RMW) +
+    # 5 fused FFT passes (read + write of the padded mesh each) + readout (32 N read, 56 cells x 8 B
+    # gathered, 32 N written)
+    zp = 2 * (((nmesh // 2 + 1) + 3) // 4 * 4)
+    mesh_bytes = 8.0 * nmesh * nmesh * zp
+    fft_bytes = 5 * 2 * mesh_bytes
+    pm_bytes = mesh_bytes + (32.0 + 128.0) * n + fft_bytes + (32.0 + 448.0 + 32.0) * n
+    # PM with the reference's structure (1 r2c + 4 c2r, separate transfer sweeps), for comparison only
+    pm_bytes_reference_structure = 468.0 * n + 240.0 * ncells
     walk_s = st.kernel_ms * 1e-3
     pm_s = ph[5] * 1e-3
-    dominant = "grav_walk_exact_kernel" if walk_s >= pm_s else "pm (deposit+r2c+transfer+c2r+readout)"
-    if walk_s >= pm_s:
-        ach = tree_bytes / walk_s / 1e9
-    else:
-        ach = pm_bytes / pm_s / 1e9
+    fft_s = (ph[1] + ph[2] + ph[3]) * 1e-3
+    dominant = "grav_walk_exact_kernel" if walk_s >= pm_s else "pm (deposit + 5 fused FFT passes + readout)"
+    ach = (tree_bytes / walk_s if walk_s >= pm_s else pm_bytes / pm_s) / 1e9
+    # HBM traffic per launch from the committed PMC summary of this same command (profiles/, made with
+    # tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), if present
+    traffic = traffic_fft = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_bench256_pmc_hbm.json")) as f:
+            pj = json.load(f)
+        if n1 == 256 and world == 1:
+            def hbm(e):
+                return e.get("fetch_bytes_corrected", 0.0) + e.get("write_bytes", 0.0)
+            key = [k for k in pj if k.startswith("grav_walk_exact_kernel") and k.rstrip(">").endswith("false")]
+            if key:
+                traffic = hbm(pj[key[0]])
+            fk = [k for k in pj if k.startswith("fft_pass_")]
+            if len(fk) == 5:
+                traffic_fft = sum(hbm(pj[k]) for k in fk)
+    except (OSError, ValueError):
+        traffic = traffic_fft = None
     out = {
         "metric": "particle-steps/sec (grav+PM+SPH) at 256^3; rms force error vs ref",
         "value": n * world * args.steps / elapsed,
@@ -278,7 +302,14 @@ def main():
                    "particles_per_gpu": n, "nmesh": nmesh, "parallelism": "replicas x%d" % world if world > 1 else "1 GPU",
                    "walk": "exact (per-target reference opening decisions)"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": None},
+                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": tree_bytes if walk_s >= pm_s else pm_bytes,
+                     "note": "the walk is FP64 VALU-issue bound, not HBM bound (compulsory traffic ~0.1 kB/target for ~500 "
+                             "interactions): see kernels.tree_fp64_frac_of_vector_peak and profiles/; the HBM-bound part of "
+                             "the step is the PM, see roofline_pm_fft"},
+        "roofline_pm_fft": {"bound": "hbm", "kernel": "fft_pass_z_fwd/strided/z_inv (5 fused passes)",
+                            "achieved": fft_bytes / max(fft_s, 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": fft_bytes / max(fft_s, 1e-12) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_fft,
+                            "algorithmic_bytes": fft_bytes},
         "kernels": {
             "tree_walk_ms": st.kernel_ms, "tree_interactions_per_target": st.ninteractions / max(1, st.ntargets),
             "tree_interactions_per_s": st.ninteractions / max(walk_s, 1e-12),
@@ -292,6 +323,7 @@ def main():
             "pm_ms": {"deposit": ph[0], "r2c": ph[1], "transfer": ph[2], "c2r": ph[3], "readout": ph[4], "total": ph[5]},
             "pm_algorithmic_GBs": pm_bytes / max(pm_s, 1e-12) / 1e9,
             "pm_frac_of_hbm_peak": pm_bytes / max(pm_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
+            "pm_reference_structure_GBs": pm_bytes_reference_structure / max(pm_s, 1e-12) / 1e9,
             "event_ms_per_step": ev_ms / args.steps,
         },
         "setup_s": {"tree_build": t_tree_build, "upload": t_upload, "seed_step": t_seed},

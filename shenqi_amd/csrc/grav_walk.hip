@@ -134,7 +134,7 @@ __device__ __forceinline__ void leaf_particle(const double4 *__restrict__ tab, c
 
 /* POT: accumulate the potential.  PREFETCH: speculative fetch of pool[cur+1].  LEAFB: leaf
  * particles fetched per batch (2 or 4).  STATS: wave-level counters for the bench. */
-template <bool POT, bool PREFETCH, int LEAFB, int STATS>
+template <bool POT, bool PREFETCH, int LEAFB, int STATS, bool BH>
 __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
 {
     __shared__ double4 tab[SHQ_NGRAVTAB];
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
         const bool discard = (r2 > a.rcut2) && (cmax > a.rcut + nd.halflen);
         /* shall_we_open_node, gravshort2.hpp:172-193 (len*len/r2 > theta2 written without the divide;
          * mass*len*len and 0.6*len come precomputed with the node) */
-        const bool open = ((a.useBH == 0) && (nd.mlen2 > r2 * r2 * aold)) || (nd.len2 > r2 * a.bh2) || (cmax < nd.inside);
+        const bool open = (!BH && (nd.mlen2 > r2 * r2 * aold)) || (nd.len2 > r2 * a.bh2) || (cmax < nd.inside);
         const bool accept = act && !discard && !open;
         const bool doopen = act && !discard && open;
 
@@ -358,15 +358,27 @@ __global__ void stats_init_kernel(GravStatsDev *s)
         s->hist_visit[b] = s->hist_node[b] = s->hist_leaf[b] = 0;
 }
 
+/* BH: pure Barnes-Hut opening angle (TreeUseBH, the seeding walk before any acceleration exists) as its
+ * own instantiation: the relative criterion drops out at compile time, and a profile lists the seeding
+ * walk and the production walk as two kernels. */
+template <bool POT, bool PREFETCH, int LEAFB, bool BH>
+void launch_variant_bh(int stats, dim3 grid, dim3 block, hipStream_t stream, const WalkArgs &a)
+{
+    if(stats == 2 && POT && !PREFETCH && LEAFB == 2)
+        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, (POT && !PREFETCH && LEAFB == 2) ? 2 : 1, BH><<<grid, block, 0, stream>>>(a);
+    else if(stats)
+        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 1, BH><<<grid, block, 0, stream>>>(a);
+    else
+        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 0, BH><<<grid, block, 0, stream>>>(a);
+}
+
 template <bool POT, bool PREFETCH, int LEAFB>
 void launch_variant(int stats, dim3 grid, dim3 block, hipStream_t stream, const WalkArgs &a)
 {
-    if(stats == 2 && POT && !PREFETCH && LEAFB == 2)
-        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, (POT && !PREFETCH && LEAFB == 2) ? 2 : 1><<<grid, block, 0, stream>>>(a);
-    else if(stats)
-        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 1><<<grid, block, 0, stream>>>(a);
+    if(a.useBH)
+        launch_variant_bh<POT, PREFETCH, LEAFB, true>(stats, grid, block, stream, a);
     else
-        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 0><<<grid, block, 0, stream>>>(a);
+        launch_variant_bh<POT, PREFETCH, LEAFB, false>(stats, grid, block, stream, a);
 }
 
 } // namespace
