@@ -194,8 +194,7 @@ def main():
     P["Pos"] = pos
     P["Type"] = 1
     P["Mass"] = 1.0
-    tree = sq.force_tree_full(pman)
-    t_tree_build = time.perf_counter() - t_setup
+    t_setup = time.perf_counter() - t_setup
 
     ctx = sq.Context(local_rank if world > 1 else 0)
     sq.set_gravshort_treepar(ErrTolForceAcc=args.errtol, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=1, Rcut=6.0)
@@ -205,11 +204,17 @@ def main():
     gp_rel = sq.make_grav_params(L, 1.5, nmesh, G, RHO0)
     pmp = sq.PMParams(nmesh, 0, L, 1.5, G)
 
-    pv, tv = pman.view(), tree.view()
+    pv = pman.view()
     t0 = time.perf_counter()
     capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
-    capi.check(capi.hip.shq_tree_upload(ctx.h, C.byref(tv)))
     t_upload = time.perf_counter() - t0
+    # the tree is built on the device (shq_tree_build: bit-identical to the host / reference tree, see
+    # tests/test_gpu_treebuild.py); outside the timed region like the host build it replaces
+    sq.tree_build_device(ctx, L)             # first call allocates the scratch
+    t0 = time.perf_counter()
+    tb = sq.tree_build_device(ctx, L)
+    t_tree_build = time.perf_counter() - t0
+    numnodes = int(tb.numnodes)
 
     def step(gp):
         capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
@@ -257,7 +262,7 @@ def main():
     ncells = float(nmesh) ** 3
     # ---- algorithmic bytes ------------------------------------------
     # tree walk: compulsory traffic only (targets in/out + node pool once); the walk is not HBM-bound
-    tree_bytes = 68.0 * n + 76.0 * tree.numnodes
+    tree_bytes = 68.0 * n + 76.0 * numnodes
     # PM as THIS pipeline runs it: zero (8 C write) + deposit (32 N read, 8 cells x 8 B RMW) +
     # 5 fused FFT passes (read + write of the padded mesh each) + readout (32 N read, 56 cells x 8 B
     # gathered, 32 N written)
@@ -326,9 +331,14 @@ def main():
             "pm_reference_structure_GBs": pm_bytes_reference_structure / max(pm_s, 1e-12) / 1e9,
             "event_ms_per_step": ev_ms / args.steps,
         },
-        "setup_s": {"tree_build": t_tree_build, "upload": t_upload, "seed_step": t_seed},
+        "setup_s": {"synthetic_input": t_setup, "upload": t_upload, "tree_build_device": t_tree_build,
+                    "tree_build_device_kernels_ms": float(tb.build_ms), "tree_nodes": numnodes, "tree_depth": int(tb.maxdepth),
+                    "seed_step": t_seed},
     }
     if rank == 0 and not args.no_cpu_baseline:
+        t0 = time.perf_counter()
+        tree = sq.force_tree_full(pman)      # host build of the same tree, for the oracle only
+        out["setup_s"]["tree_build_host_for_oracle"] = time.perf_counter() - t0
         oldacc = np.zeros(n)
         acc = np.zeros((n, 3))
         gpm = np.zeros((n, 3))

@@ -186,6 +186,31 @@ int shq_grav_short_tree(shq_context *ctx, const shq_tree_view *tree, const shq_p
 /* Resident API. */
 int shq_particles_upload(shq_context *ctx, const shq_part_view *parts);
 int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree);
+
+/* Device tree build.  Replaces, for a single-domain tree, force_tree_rebuild / force_tree_create_nodes
+ * (libgadget/forcetree.cpp:727-859), force_tree_calc_moments / force_update_node_parallel (:1016-1142)
+ * and the host repack + H2D of shq_tree_upload: builds the oct-tree of the uploaded particles whose type
+ * is in `mask` (bit t = particle type t; garbage and swallowed particles are skipped, as in
+ * forcetree.cpp:692-705), optionally restricted to the `active` list (host pointer, ActiveParticles
+ * order), computes mass / centre of mass / hmax and installs it as the context's current tree.
+ * The tree is the one the reference's insertion build produces for the same particles (same cells,
+ * same leaves in the same particle order, same moments to the bit).  Returns SHQ_ERR_INVALID when more
+ * than 8 particles lie within Box/2^21 of each other (deeper than the device build supports): the caller
+ * then keeps its host build; nothing is truncated. */
+typedef struct shq_tree_build_stats {
+    int64_t nparticles;   /* particles in the tree */
+    int64_t numnodes;
+    int32_t maxdepth;
+    float build_ms;       /* device time, HIP events */
+} shq_tree_build_stats;
+int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const int32_t *active, int64_t nactive,
+                   shq_tree_build_stats *stats);
+/* The device-built tree in the reference's format (struct NODE, forcetree.h:38-66): `nodes[k]` is node
+ * number firstnode + k (pre-order, root first), links (sibling, father, suns of internal nodes) are node
+ * numbers, leaf suns are particle indices; `father[i]` = node number of the leaf holding particle i or
+ * -1 (ForceTree.Father).  Either output may be NULL; *numnodes always returns the node count. */
+int shq_tree_download(shq_context *ctx, int64_t firstnode, shq_node *nodes, int64_t capacity, int32_t *father,
+                      int64_t *numnodes);
 /* active: host int32 list or NULL. The walk and postprocess are queued on the stream. */
 int shq_grav_short_run(shq_context *ctx, const shq_grav_params *params, const int32_t *active,
                        int64_t nactive, int update_potential, int walk_mode);

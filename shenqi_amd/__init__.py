@@ -111,6 +111,28 @@ def force_tree_rebuild_mask(pman, mask, active=None, full=False):
     return ForceTree(h, pman)
 
 
+def tree_build_device(ctx, BoxSize, mask=None, active=None):
+    """shq_tree_build: build the tree of the uploaded particles on the device and install it in `ctx`.
+    Returns capi.TreeBuildStats."""
+    st = capi.TreeBuildStats()
+    act = None if active is None else np.ascontiguousarray(active, dtype=np.int32)
+    capi.check(capi.hip.shq_tree_build(ctx.h, float(BoxSize), ALLMASK if mask is None else int(mask), capi.ptr(act),
+                                       0 if act is None else len(act), C.byref(st)), "shq_tree_build")
+    return st
+
+
+def tree_download(ctx, firstnode, numpart=0):
+    """shq_tree_download: the device-built tree as a NODE array (numbered from `firstnode` in pre-order)
+    and, if numpart > 0, the Father array."""
+    nn = C.c_int64()
+    capi.check(capi.hip.shq_tree_download(ctx.h, int(firstnode), None, 0, None, C.byref(nn)), "shq_tree_download")
+    nodes = np.zeros(nn.value, dtype=NODE_DTYPE)
+    father = np.full(int(numpart), -1, dtype=np.int32) if numpart > 0 else None
+    capi.check(capi.hip.shq_tree_download(ctx.h, int(firstnode), capi.ptr(nodes), nn.value, capi.ptr(father), C.byref(nn)),
+               "shq_tree_download")
+    return nodes, father
+
+
 def force_tree_full(pman):
     return force_tree_rebuild_mask(pman, ALLMASK, None, full=True)
 

@@ -112,6 +112,10 @@ class GravParams(C.Structure):
     ]
 
 
+class TreeBuildStats(C.Structure):
+    _fields_ = [("nparticles", C.c_int64), ("numnodes", C.c_int64), ("maxdepth", C.c_int32), ("build_ms", C.c_float)]
+
+
 class WalkStats(C.Structure):
     _fields_ = [
         ("ntargets", C.c_int64), ("ninteractions", C.c_int64), ("min_interactions", C.c_int64),
@@ -185,6 +189,10 @@ hip.shq_timer_end.argtypes = [_vp, C.c_int]
 hip.shq_timer_elapsed_ms.argtypes = [_vp, C.c_int, C.POINTER(C.c_double)]
 hip.shq_particles_upload.argtypes = [_vp, C.POINTER(PartView)]
 hip.shq_tree_upload.argtypes = [_vp, C.POINTER(TreeView)]
+hip.shq_tree_build.argtypes = [_vp, C.c_double, C.c_int, _vp, C.c_int64, C.POINTER(TreeBuildStats)]
+hip.shq_tree_build.restype = C.c_int
+hip.shq_tree_download.argtypes = [_vp, C.c_int64, _vp, C.c_int64, _vp, C.POINTER(C.c_int64)]
+hip.shq_tree_download.restype = C.c_int
 hip.shq_grav_short_run.argtypes = [_vp, C.POINTER(GravParams), _vp, C.c_int64, C.c_int, C.c_int]
 hip.shq_grav_short_download.argtypes = [_vp, _vp, _vp, _vp, C.POINTER(WalkStats)]
 hip.shq_grav_refresh_oldacc.argtypes = [_vp, C.c_double]

@@ -139,7 +139,7 @@ extern "C" void shq_shutdown(shq_context *ctx)
     ctx->hydD_leaf.release(); ctx->hsml_leaf.release(); ctx->flag_leaf.release();
     ctx->s_numngb.release(); ctx->s_dhsmldens.release(); ctx->s_left.release(); ctx->s_right.release(); ctx->s_rot.release();
     ctx->s_gradrho.release(); ctx->s_evp_in.release(); ctx->s_todo.release(); ctx->s_queue2.release(); ctx->s_queue3.release();
-    ctx->s_blockcount.release(); ctx->s_nlist.release(); ctx->s_counters.release(); ctx->pm_oob.release(); ctx->fft_tw.release();
+    ctx->tb.release(); ctx->s_blockcount.release(); ctx->s_nlist.release(); ctx->s_counters.release(); ctx->pm_oob.release(); ctx->fft_tw.release();
     for(int i = 0; i < SHQ_NTIMERS; i++) {
         (void) hipEventDestroy(ctx->ev_begin[i]);
         (void) hipEventDestroy(ctx->ev_end[i]);
@@ -421,6 +421,7 @@ extern "C" int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree)
     ctx->ntreeparts = nleafparts;
     ctx->treeBox = tree->BoxSize;
     ctx->have_tree = true;
+    ctx->tb_built = false;
     return SHQ_OK;
 }
 

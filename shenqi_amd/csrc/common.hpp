@@ -146,7 +146,27 @@ __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb, unsigned 
     return super * 8u * K + (within & 7u) * K + (within >> 3);
 }
 
-#define SHQ_NTIMERS 16
+#define SHQ_NTIMERS 20 /* 0-7 caller, 8-13 PM phases, 14 SPH, 16 tree build, last: walk */
+
+/* scratch of the device tree build (tree_build.hip) */
+struct TreeBuildBufs {
+    DevBuf<unsigned long long> keys[2], okeys[2], packed[2], counters;
+    DevBuf<int32_t> idx[2], order[2], rank, frontier[2], bounds;
+    DevBuf<int32_t> lo, hi, parent, sibling, firstchild, nchild, level;
+    DevBuf<double4> cen, mom;
+    DevBuf<double> hmax;
+    DevBuf<char> temp;
+    DevBuf<shq_node> exportbuf;
+    void release()
+    {
+        for(int i = 0; i < 2; i++) {
+            keys[i].release(); okeys[i].release(); packed[i].release(); idx[i].release(); order[i].release(); frontier[i].release();
+        }
+        counters.release(); rank.release(); bounds.release(); lo.release(); hi.release(); parent.release(); sibling.release();
+        firstchild.release(); nchild.release(); level.release(); cen.release(); mom.release(); hmax.release(); temp.release();
+        exportbuf.release();
+    }
+};
 
 struct shq_context {
     int device = 0;
@@ -188,6 +208,8 @@ struct shq_context {
     DevBuf<int32_t> pfather;   /* particle -> packed index of the leaf holding it, or -1 */
     std::vector<int32_t> node_order; /* packed index -> index into the caller's nodes_base */
     bool have_father = false;
+    TreeBuildBufs tb;
+    bool tb_built = false;     /* the current tree came from shq_tree_build (downloadable) */
 
     /* ---- SPH state, by particle index (gas fields gathered from their slots at upload) */
     bool have_sph = false;

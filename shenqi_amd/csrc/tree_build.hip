@@ -1,0 +1,624 @@
+/* tree_build.hip — oct-tree construction + moments on the device (gfx950).
+ *
+ * Replaces, for a single-domain tree, force_tree_rebuild / force_tree_create_nodes (insertion build,
+ * libgadget/forcetree.cpp:727-859 with create_new_node_layer :393-470), force_tree_calc_moments /
+ * force_update_node_parallel (:1118-1142, :1016-1103: sibling/child threading, mass, cofm, hmax) and
+ * the host-side repack of shq_tree_upload.  SURVEY.md §8(f) rank 1: with hierarchical time steps the
+ * reference rebuilds a tree twice per step, and once the walks are fast the host build dominates.
+ *
+ * The reference inserts particles one by one; the tree it ends up with does not depend on the
+ * insertion order: a node holding more than NMAXCHILD = 8 particles is split into the sub-octants that
+ * are not empty (get_subnode, forcetree.cpp:277-283: `pos > center` per axis; child centre = centre +-
+ * len/4, init_internal_node :302-328), recursively.  So the tree is built top-down from sorted keys:
+ *   1. every particle descends 21 levels from the root cell with exactly the reference's floating-point
+ *      operations and records its octant at each level: a 63-bit key (excluded particles get ~0);
+ *   2. a radix sort by key (rocPRIM) puts the particles in depth-first leaf order; inside a leaf the
+ *      reference keeps them in insertion (= candidate sequence) order, which a small per-leaf sort of
+ *      the <= 8 sequence numbers restores once the leaves are known;
+ *   3. breadth-first, one pair of kernels per level: every internal node of the level finds its eight
+ *      octant boundaries by binary search on the key digit, an exclusive scan allocates the children
+ *      (contiguous per parent), a second kernel writes them (centre, len, father, sibling threading)
+ *      and queues those with more than 8 particles for the next level;
+ *   4. moments bottom-up, level by level, summed in the reference's order without fma contraction;
+ *   5. nodes are ranked in depth-first pre-order (sort by first particle, then level) and written
+ *      straight into the walk kernels' pool records; the particle copy in leaf order is the sorted order.
+ * Trees deeper than 21 levels (more than 8 particles within Box/2^21 of each other) are refused with an
+ * error: the caller must fall back to its host build; nothing is truncated silently. */
+#include <cstring>
+#include <math.h>
+#include <vector>
+#include "common.hpp"
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace {
+
+constexpr int TB_LEVELS = 21;
+
+/* octant digit of `key` at level l (0 = children of the root) */
+__device__ __forceinline__ int key_digit(unsigned long long key, int l) { return (int) ((key >> (3 * (TB_LEVELS - 1 - l))) & 7ull); }
+
+__global__ void tb_key_kernel(long long ncand, const int32_t *__restrict__ cand, const double4 *__restrict__ posm,
+                              const uint8_t *__restrict__ pflags, int mask, double Box, unsigned long long *keys, int32_t *idx,
+                              unsigned long long *nvalid)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = false;
+    if(i < ncand) {
+        const int p = cand ? cand[i] : (int) i;
+        const unsigned f = pflags[p];
+        ok = !(f & 3u) && (((1u << (f >> 4)) & (unsigned) mask) != 0u);
+        unsigned long long key = ~0ull;
+        if(ok) {
+            const double4 q = posm[p];
+            double cx = Box / 2., cy = Box / 2., cz = Box / 2., len = Box * 1.001; /* forcetree.cpp:661 */
+            key = 0;
+            for(int l = 0; l < TB_LEVELS; l++) {
+                const int s = (q.x > cx) + ((q.y > cy) << 1) + ((q.z > cz) << 2);
+                key = (key << 3) | (unsigned long long) s;
+                const double lenhalf = 0.25 * len;
+                cx = cx + ((s & 1) ? lenhalf : -lenhalf);
+                cy = cy + ((s & 2) ? lenhalf : -lenhalf);
+                cz = cz + ((s & 4) ? lenhalf : -lenhalf);
+                len = 0.5 * len;
+            }
+        }
+        keys[i] = key;
+        idx[i] = (int32_t) i; /* position in the candidate sequence: restores the order inside a leaf */
+    }
+    const unsigned long long m = __ballot(ok);
+    if((threadIdx.x & 63) == 0 && m)
+        atomicAdd(nvalid, (unsigned long long) __popcll(m));
+}
+
+struct TbNodes {
+    int32_t *lo, *hi, *parent, *sibling, *firstchild, *nchild, *level;
+    double4 *cen;  /* centre, len */
+    double4 *mom;  /* cofm, mass */
+    double *hmax;
+};
+
+__global__ void tb_root_kernel(TbNodes nd, int n, double Box)
+{
+    nd.lo[0] = 0;
+    nd.hi[0] = n;
+    nd.parent[0] = -1;
+    nd.sibling[0] = -1;
+    nd.firstchild[0] = -1;
+    nd.nchild[0] = 0;
+    nd.level[0] = 0;
+    nd.cen[0] = make_double4(Box / 2., Box / 2., Box / 2., Box * 1.001);
+}
+
+/* octant boundaries of every internal node of the level: bounds[9 f + s] = first sorted position whose
+ * digit is >= s; packed[f] = (#children << 32) | #children with more than NMAXCHILD particles */
+__global__ void tb_split_kernel(int nf, const int32_t *__restrict__ frontier, TbNodes nd, const unsigned long long *__restrict__ keys,
+                                int level, int32_t *bounds, unsigned long long *packed)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if(f >= nf)
+        return;
+    const int no = frontier[f];
+    const int lo = nd.lo[no], hi = nd.hi[no];
+    int b[9];
+    b[0] = lo;
+    b[8] = hi;
+    for(int s = 1; s < 8; s++) {
+        int a = b[s - 1], e = hi; /* first k in [a, e) with digit >= s */
+        while(a < e) {
+            const int mid = a + ((e - a) >> 1);
+            if(key_digit(keys[mid], level) < s)
+                a = mid + 1;
+            else
+                e = mid;
+        }
+        b[s] = a;
+    }
+    unsigned nch = 0, nint = 0;
+    for(int s = 0; s < 8; s++) {
+        const int c = b[s + 1] - b[s];
+        nch += c > 0;
+        nint += c > SHQ_NMAXCHILD;
+    }
+    for(int s = 0; s < 9; s++)
+        bounds[9 * f + s] = b[s];
+    packed[f] = ((unsigned long long) nch << 32) | nint;
+}
+
+__global__ void tb_children_kernel(int nf, const int32_t *__restrict__ frontier, TbNodes nd, int level, const int32_t *__restrict__ bounds,
+                                   const unsigned long long *__restrict__ scan, int nnodes, int32_t *next_frontier, int *err)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if(f >= nf)
+        return;
+    const int no = frontier[f];
+    const int base = nnodes + (int) (scan[f] >> 32);
+    int qoff = (int) (scan[f] & 0xffffffffull);
+    const double4 pc = nd.cen[no];
+    const int psib = nd.sibling[no];
+    const double lenhalf = 0.25 * pc.w; /* init_internal_node, forcetree.cpp:302-328 */
+    int nch = 0;
+    for(int s = 0; s < 8; s++)
+        nch += bounds[9 * f + s + 1] > bounds[9 * f + s];
+    int j = 0;
+    for(int s = 0; s < 8; s++) {
+        const int lo = bounds[9 * f + s], hi = bounds[9 * f + s + 1];
+        if(hi == lo)
+            continue;
+        const int c = base + j;
+        nd.lo[c] = lo;
+        nd.hi[c] = hi;
+        nd.parent[c] = no;
+        nd.level[c] = level + 1;
+        nd.firstchild[c] = -1;
+        nd.nchild[c] = 0;
+        nd.sibling[c] = (j + 1 < nch) ? c + 1 : psib; /* forcetree.cpp:968-983,1055-1061 */
+        nd.cen[c] = make_double4(pc.x + ((s & 1) ? lenhalf : -lenhalf), pc.y + ((s & 2) ? lenhalf : -lenhalf),
+                                 pc.z + ((s & 4) ? lenhalf : -lenhalf), 0.5 * pc.w);
+        if(hi - lo > SHQ_NMAXCHILD) {
+            if(level + 1 >= TB_LEVELS)
+                *err = 2; /* more than NMAXCHILD particles in one cell of the deepest level */
+            else
+                next_frontier[qoff++] = c;
+        }
+        j++;
+    }
+    nd.firstchild[no] = base;
+    nd.nchild[no] = nch;
+}
+
+/* leaves list their particles in candidate-sequence order (the sort ordered them by the deeper key
+ * digits); also turns sequence numbers into particle indices */
+__global__ void tb_leafsort_kernel(int nn, TbNodes nd, const int32_t *__restrict__ seq, const int32_t *__restrict__ cand, int32_t *idx)
+{
+    const int no = blockIdx.x * blockDim.x + threadIdx.x;
+    if(no >= nn || nd.nchild[no] != 0)
+        return;
+    const int lo = nd.lo[no], cnt = nd.hi[no] - lo;
+    if(cnt > SHQ_NMAXCHILD) { /* only in the refused too-deep case */
+        for(int k = 0; k < cnt; k++)
+            idx[lo + k] = cand ? cand[seq[lo + k]] : seq[lo + k];
+        return;
+    }
+    int v[SHQ_NMAXCHILD];
+#pragma unroll
+    for(int k = 0; k < SHQ_NMAXCHILD; k++)
+        v[k] = k < cnt ? seq[lo + k] : 0x7fffffff;
+#pragma unroll
+    for(int i = 1; i < SHQ_NMAXCHILD; i++) /* insertion sort, fully unrolled: v stays in registers */
+#pragma unroll
+        for(int j = i; j > 0; j--)
+            if(v[j] < v[j - 1]) {
+                const int t = v[j];
+                v[j] = v[j - 1];
+                v[j - 1] = t;
+            }
+#pragma unroll
+    for(int k = 0; k < SHQ_NMAXCHILD; k++)
+        if(k < cnt)
+            idx[lo + k] = cand ? cand[v[k]] : v[k];
+}
+
+/* mass, centre of mass, hmax of the nodes [first, last) of one level; children are one level deeper and done */
+__global__ void tb_moments_kernel(int first, int last, TbNodes nd, const int32_t *__restrict__ idx, const double4 *__restrict__ posm,
+                                  const uint8_t *__restrict__ pflags, const double *__restrict__ hsml)
+{
+#pragma clang fp contract(off) /* the reference's sums are separate multiplies and adds */
+    const int no = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if(no >= last)
+        return;
+    const double4 c = nd.cen[no];
+    double mass = 0, c0 = 0, c1 = 0, c2 = 0, hmax = 0;
+    const int nch = nd.nchild[no];
+    if(nch == 0) { /* leaf: forcetree.cpp:947-966 (moments) and :985-1005 (hmax), particles in leaf order */
+        for(int k = nd.lo[no]; k < nd.hi[no]; k++) {
+            const int p = idx[k];
+            const double4 q = posm[p];
+            mass = mass + q.w;
+            c0 = c0 + q.w * q.x;
+            c1 = c1 + q.w * q.y;
+            c2 = c2 + q.w * q.z;
+            const unsigned type = pflags[p] >> 4;
+            if(hsml && (type == 0 || type == 5)) {
+                const double h = hsml[p];
+                hmax = fmax(hmax, fabs(q.x - c.x) + h - c.w / 2.);
+                hmax = fmax(hmax, fabs(q.y - c.y) + h - c.w / 2.);
+                hmax = fmax(hmax, fabs(q.z - c.z) + h - c.w / 2.);
+            }
+        }
+        if(mass > 0) {
+            c0 /= mass;
+            c1 /= mass;
+            c2 /= mass;
+        } else {
+            c0 = c.x;
+            c1 = c.y;
+            c2 = c.z;
+        }
+    } else { /* forcetree.cpp:1080-1101 */
+        const int fc = nd.firstchild[no];
+        for(int j = 0; j < nch; j++) {
+            const double4 m = nd.mom[fc + j];
+            mass = mass + m.w;
+            c0 = c0 + m.w * m.x;
+            c1 = c1 + m.w * m.y;
+            c2 = c2 + m.w * m.z;
+            hmax = fmax(hmax, nd.hmax[fc + j]);
+        }
+        if(mass > 0) {
+            c0 /= mass;
+            c1 /= mass;
+            c2 /= mass;
+        }
+    }
+    nd.mom[no] = make_double4(c0, c1, c2, mass);
+    nd.hmax[no] = hmax;
+}
+
+__global__ void tb_orderkey_kernel(int nn, TbNodes nd, unsigned long long *okeys, int32_t *oval)
+{
+    const int no = blockIdx.x * blockDim.x + threadIdx.x;
+    if(no >= nn)
+        return;
+    okeys[no] = ((unsigned long long) (unsigned) nd.lo[no] << 8) | (unsigned long long) nd.level[no];
+    oval[no] = no;
+}
+
+__global__ void tb_rank_kernel(int nn, const int32_t *__restrict__ order, int32_t *rank)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if(r < nn)
+        rank[order[r]] = r;
+}
+
+/* pool records in pre-order (common.hpp); record nn is the pad the walks may touch */
+__global__ void tb_pack_kernel(int nn, const int32_t *__restrict__ order, const int32_t *__restrict__ rank, TbNodes nd,
+                               const int32_t *__restrict__ idx, NodeA *A, NodeB *B, NodeC *C, NodeG *G, double *H, int32_t *pfather)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if(r > nn)
+        return;
+    NodeA a;
+    NodeB b;
+    NodeC c;
+    double hmax = 0;
+    if(r == nn) {
+        memset(&a, 0, sizeof(a));
+        memset(&b, 0, sizeof(b));
+        c.sibling = -1;
+        c.child = -1;
+        c.type = SHQ_PSEUDO_NODE_TYPE;
+        c.count = 0;
+    } else {
+        const int no = order[r];
+        const double4 m = nd.mom[no], ce = nd.cen[no];
+        a.cofm[0] = m.x; a.cofm[1] = m.y; a.cofm[2] = m.z; a.mass = m.w;
+        b.center[0] = ce.x; b.center[1] = ce.y; b.center[2] = ce.z; b.len = ce.w;
+        const int sib = nd.sibling[no];
+        c.sibling = sib >= 0 ? rank[sib] : -1;
+        if(nd.nchild[no] == 0) {
+            c.type = SHQ_PARTICLE_NODE_TYPE;
+            c.child = nd.lo[no];
+            c.count = nd.hi[no] - nd.lo[no];
+            if(pfather)
+                for(int k = nd.lo[no]; k < nd.hi[no]; k++)
+                    pfather[idx[k]] = r;
+        } else {
+            c.type = SHQ_NODE_NODE_TYPE;
+            c.child = rank[nd.firstchild[no]];
+            c.count = 0;
+        }
+        hmax = nd.hmax[no];
+    }
+    A[r] = a;
+    B[r] = b;
+    C[r] = c;
+    H[r] = hmax;
+    NodeG g;
+    memset(&g, 0, sizeof(g));
+    for(int k = 0; k < 3; k++) {
+        g.cofm[k] = a.cofm[k];
+        g.center[k] = b.center[k];
+    }
+    g.mass = a.mass;
+    g.len = b.len;
+    g.sibling = c.sibling; g.child = c.child; g.type = c.type; g.count = c.count;
+    g.len2 = g.len * g.len;
+    g.mlen2 = g.mass * g.len * g.len; /* (mass * len) * len, as shall_we_open_node evaluates it */
+    g.inside = 0.6 * g.len;
+    g.halflen = 0.5 * g.len;
+    G[r] = g;
+}
+
+__global__ void tb_leafcopy_kernel(long long n, long long npad, const int32_t *__restrict__ idx, const double4 *__restrict__ posm,
+                                   double4 *posm_leaf, int32_t *leaf_pidx)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= npad)
+        return;
+    if(k < n) {
+        const int p = idx[k];
+        posm_leaf[k] = posm[p];
+        leaf_pidx[k] = p;
+    } else {
+        posm_leaf[k] = make_double4(0, 0, 0, 0);
+        leaf_pidx[k] = 0;
+    }
+}
+
+/* the tree in the reference's NODE format (forcetree.h:38-66), numbered in pre-order from `firstnode` */
+__global__ void tb_export_kernel(int nn, long long firstnode, const int32_t *__restrict__ order, const int32_t *__restrict__ rank,
+                                 TbNodes nd, const int32_t *__restrict__ idx, shq_node *out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if(r >= nn)
+        return;
+    const int no = order[r];
+    shq_node o;
+    const double4 m = nd.mom[no], ce = nd.cen[no];
+    const int sib = nd.sibling[no], par = nd.parent[no];
+    o.sibling = sib >= 0 ? (int32_t) (firstnode + rank[sib]) : -1;
+    o.father = par >= 0 ? (int32_t) (firstnode + rank[par]) : -1;
+    o.len = ce.w;
+    o.center[0] = ce.x; o.center[1] = ce.y; o.center[2] = ce.z;
+    o.cofm[0] = m.x; o.cofm[1] = m.y; o.cofm[2] = m.z;
+    o.mass = m.w;
+    o.hmax = nd.hmax[no];
+    for(int j = 0; j < SHQ_NMAXCHILD; j++)
+        o.suns[j] = -1;
+    const int nch = nd.nchild[no];
+    if(nch == 0) {
+        const int cnt = nd.hi[no] - nd.lo[no];
+        for(int k = 0; k < cnt && k < SHQ_NMAXCHILD; k++)
+            o.suns[k] = idx[nd.lo[no] + k];
+        o.noccupied = cnt;
+        o.flags = (unsigned) SHQ_PARTICLE_NODE_TYPE << 3;
+    } else {
+        for(int j = 0; j < nch; j++)
+            o.suns[j] = (int32_t) (firstnode + rank[nd.firstchild[no] + j]);
+        o.noccupied = 1 << 16; /* NODEFULL */
+        o.flags = (unsigned) SHQ_NODE_NODE_TYPE << 3;
+    }
+    if(par < 0)
+        o.flags |= 2u | 4u; /* TopLevel, DependsOnLocalMass */
+    out[r] = o;
+}
+
+__global__ void tb_father_kernel(long long np, long long firstnode, const int32_t *__restrict__ pfather, int32_t *out)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < np)
+        out[i] = pfather[i] >= 0 ? (int32_t) (firstnode + pfather[i]) : -1;
+}
+
+inline unsigned nblk(long long n, int t = 256) { return (unsigned) ((n + t - 1) / t); }
+
+int reserve_nodes(shq_context *ctx, size_t cap)
+{
+    TreeBuildBufs &b = ctx->tb;
+    SHQ_TRY(b.lo.reserve(cap));
+    SHQ_TRY(b.hi.reserve(cap));
+    SHQ_TRY(b.parent.reserve(cap));
+    SHQ_TRY(b.sibling.reserve(cap));
+    SHQ_TRY(b.firstchild.reserve(cap));
+    SHQ_TRY(b.nchild.reserve(cap));
+    SHQ_TRY(b.level.reserve(cap));
+    SHQ_TRY(b.cen.reserve(cap));
+    SHQ_TRY(b.mom.reserve(cap));
+    SHQ_TRY(b.hmax.reserve(cap));
+    SHQ_TRY(b.frontier[0].reserve(cap));
+    SHQ_TRY(b.frontier[1].reserve(cap));
+    SHQ_TRY(b.okeys[0].reserve(cap));
+    SHQ_TRY(b.okeys[1].reserve(cap));
+    SHQ_TRY(b.order[0].reserve(cap));
+    SHQ_TRY(b.order[1].reserve(cap));
+    SHQ_TRY(b.rank.reserve(cap));
+    return SHQ_OK;
+}
+
+TbNodes node_view(shq_context *ctx)
+{
+    TreeBuildBufs &b = ctx->tb;
+    TbNodes v;
+    v.lo = b.lo.ptr; v.hi = b.hi.ptr; v.parent = b.parent.ptr; v.sibling = b.sibling.ptr;
+    v.firstchild = b.firstchild.ptr; v.nchild = b.nchild.ptr; v.level = b.level.ptr;
+    v.cen = b.cen.ptr; v.mom = b.mom.ptr; v.hmax = b.hmax.ptr;
+    return v;
+}
+
+} // namespace
+
+extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const int32_t *active, int64_t nactive,
+                              shq_tree_build_stats *stats)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "tree_build: upload particles first");
+    SHQ_CHECK(BoxSize > 0, SHQ_ERR_INVALID, "tree_build: BoxSize must be > 0");
+    SHQ_CHECK(!active || nactive >= 0, SHQ_ERR_INVALID, "tree_build: bad active list");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    TreeBuildBufs &b = ctx->tb;
+    const long long np = ctx->numpart;
+    const long long ncand = active ? nactive : np;
+    SHQ_CHECK(ncand < (1ll << 31) - 64, SHQ_ERR_INVALID, "tree_build: too many particles");
+    ctx->have_tree = false;
+    SHQ_HIP(hipEventRecord(ctx->ev_begin[16], st));
+
+    /* 1. keys */
+    const size_t pcap = (size_t) (ncand > 0 ? ncand : 1);
+    SHQ_TRY(b.keys[0].reserve(pcap));
+    SHQ_TRY(b.keys[1].reserve(pcap));
+    SHQ_TRY(b.idx[0].reserve(pcap));
+    SHQ_TRY(b.idx[1].reserve(pcap));
+    SHQ_TRY(b.counters.reserve(4));
+    SHQ_HIP(hipMemsetAsync(b.counters.ptr, 0, sizeof(unsigned long long) * 4, st));
+    const int32_t *d_cand = nullptr;
+    if(active && nactive > 0) {
+        SHQ_TRY(ctx->active.reserve((size_t) nactive));
+        SHQ_HIP(hipMemcpyAsync(ctx->active.ptr, active, sizeof(int32_t) * nactive, hipMemcpyHostToDevice, st));
+        d_cand = ctx->active.ptr;
+    }
+    if(ncand > 0) {
+        tb_key_kernel<<<dim3(nblk(ncand)), dim3(256), 0, st>>>(ncand, d_cand, ctx->posm.ptr, ctx->pflags.ptr, mask, BoxSize,
+                                                               b.keys[0].ptr, b.idx[0].ptr, b.counters.ptr);
+        SHQ_HIP(hipGetLastError());
+    }
+    unsigned long long h_nvalid = 0;
+    SHQ_HIP(hipMemcpyAsync(&h_nvalid, b.counters.ptr, sizeof(h_nvalid), hipMemcpyDeviceToHost, st));
+
+    /* 2. stable sort by key: depth-first leaf order, ties in candidate order */
+    if(ncand > 0) {
+        size_t tmp = 0;
+        SHQ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, b.keys[0].ptr, b.keys[1].ptr, b.idx[0].ptr, b.idx[1].ptr, (size_t) ncand, 0, 64, st));
+        SHQ_TRY(b.temp.reserve(tmp + 16));
+        SHQ_HIP(rocprim::radix_sort_pairs(b.temp.ptr, tmp, b.keys[0].ptr, b.keys[1].ptr, b.idx[0].ptr, b.idx[1].ptr, (size_t) ncand, 0, 64, st));
+    }
+    SHQ_HIP(hipStreamSynchronize(st));
+    const long long n = (long long) h_nvalid;
+    const unsigned long long *keys = b.keys[1].ptr;
+    const int32_t *seq = b.idx[1].ptr; /* candidate sequence numbers in key order */
+    int32_t *idx = b.idx[0].ptr;       /* particle indices in leaf order, filled once the leaves are known */
+
+    /* 3. nodes, breadth first */
+    int level_start[TB_LEVELS + 2];
+    int nn = 0, maxdepth = 0;
+    size_t cap = (size_t) (0.6 * (double) n) + 4096;
+    for(int attempt = 0;; attempt++) {
+        SHQ_CHECK(attempt < 5, SHQ_ERR_NOMEM, "tree_build: node pool overflow");
+        SHQ_TRY(reserve_nodes(ctx, cap));
+        SHQ_TRY(b.bounds.reserve(9 * cap));
+        SHQ_TRY(b.packed[0].reserve(cap + 1));
+        SHQ_TRY(b.packed[1].reserve(cap + 1));
+        TbNodes nd = node_view(ctx);
+        tb_root_kernel<<<1, 1, 0, st>>>(nd, (int) n, BoxSize);
+        nn = 1;
+        level_start[0] = 0;
+        level_start[1] = 1;
+        maxdepth = 0;
+        int nf = n > SHQ_NMAXCHILD ? 1 : 0, fsel = 0;
+        if(nf)
+            SHQ_HIP(hipMemsetAsync(b.frontier[0].ptr, 0, sizeof(int32_t), st)); /* frontier = {root} */
+        bool overflow = false;
+        for(int level = 0; nf > 0; level++) {
+            SHQ_CHECK(level < TB_LEVELS, SHQ_ERR_INVALID, "tree_build: tree deeper than %d levels", TB_LEVELS);
+            tb_split_kernel<<<dim3(nblk(nf)), dim3(256), 0, st>>>(nf, b.frontier[fsel].ptr, nd, keys, level, b.bounds.ptr, b.packed[0].ptr);
+            SHQ_HIP(hipMemsetAsync(b.packed[0].ptr + nf, 0, sizeof(unsigned long long), st));
+            size_t tmp = 0;
+            SHQ_HIP(rocprim::exclusive_scan(nullptr, tmp, b.packed[0].ptr, b.packed[1].ptr, 0ull, (size_t) nf + 1, rocprim::plus<unsigned long long>(), st));
+            SHQ_TRY(b.temp.reserve(tmp + 16));
+            SHQ_HIP(rocprim::exclusive_scan(b.temp.ptr, tmp, b.packed[0].ptr, b.packed[1].ptr, 0ull, (size_t) nf + 1, rocprim::plus<unsigned long long>(), st));
+            unsigned long long tot = 0;
+            SHQ_HIP(hipMemcpyAsync(&tot, b.packed[1].ptr + nf, sizeof(tot), hipMemcpyDeviceToHost, st));
+            SHQ_HIP(hipStreamSynchronize(st));
+            const int nch = (int) (tot >> 32), nint = (int) (tot & 0xffffffffull);
+            if((size_t) nn + (size_t) nch > cap) {
+                overflow = true;
+                break;
+            }
+            tb_children_kernel<<<dim3(nblk(nf)), dim3(256), 0, st>>>(nf, b.frontier[fsel].ptr, nd, level, b.bounds.ptr, b.packed[1].ptr, nn,
+                                                                     b.frontier[fsel ^ 1].ptr, reinterpret_cast<int *>(b.counters.ptr + 1));
+            SHQ_HIP(hipGetLastError());
+            nn += nch;
+            maxdepth = level + 1;
+            level_start[level + 2] = nn;
+            nf = nint;
+            fsel ^= 1;
+        }
+        if(!overflow)
+            break;
+        cap *= 2;
+    }
+    int h_err = 0;
+    SHQ_HIP(hipMemcpyAsync(&h_err, b.counters.ptr + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    SHQ_CHECK(h_err == 0, SHQ_ERR_INVALID, "tree_build: more than %d particles closer than Box/2^%d: deeper than the device build supports",
+              SHQ_NMAXCHILD, TB_LEVELS);
+    TbNodes nd = node_view(ctx);
+    tb_leafsort_kernel<<<dim3(nblk(nn)), dim3(256), 0, st>>>(nn, nd, seq, d_cand, idx);
+    SHQ_HIP(hipGetLastError());
+
+    /* 4. moments, deepest level first */
+    const double *d_hsml = ctx->have_sph ? ctx->hsml.ptr : nullptr;
+    for(int l = maxdepth; l >= 0; l--) {
+        const int first = level_start[l], last = level_start[l + 1];
+        if(last > first)
+            tb_moments_kernel<<<dim3(nblk(last - first)), dim3(256), 0, st>>>(first, last, nd, idx, ctx->posm.ptr, ctx->pflags.ptr, d_hsml);
+    }
+    SHQ_HIP(hipGetLastError());
+
+    /* 5. pre-order ranks and the walk pool */
+    {
+        tb_orderkey_kernel<<<dim3(nblk(nn)), dim3(256), 0, st>>>(nn, nd, b.okeys[0].ptr, b.order[0].ptr);
+        size_t tmp = 0;
+        SHQ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, b.okeys[0].ptr, b.okeys[1].ptr, b.order[0].ptr, b.order[1].ptr, (size_t) nn, 0, 40, st));
+        SHQ_TRY(b.temp.reserve(tmp + 16));
+        SHQ_HIP(rocprim::radix_sort_pairs(b.temp.ptr, tmp, b.okeys[0].ptr, b.okeys[1].ptr, b.order[0].ptr, b.order[1].ptr, (size_t) nn, 0, 40, st));
+        tb_rank_kernel<<<dim3(nblk(nn)), dim3(256), 0, st>>>(nn, b.order[1].ptr, b.rank.ptr);
+    }
+    SHQ_TRY(ctx->nodeA.reserve((size_t) nn + 1));
+    SHQ_TRY(ctx->nodeB.reserve((size_t) nn + 1));
+    SHQ_TRY(ctx->nodeC.reserve((size_t) nn + 1));
+    SHQ_TRY(ctx->nodeG.reserve((size_t) nn + 1));
+    SHQ_TRY(ctx->node_hmax.reserve((size_t) nn + 1));
+    SHQ_TRY(ctx->pfather.reserve((size_t) (np > 0 ? np : 1)));
+    SHQ_HIP(hipMemsetAsync(ctx->pfather.ptr, 0xff, sizeof(int32_t) * (size_t) (np > 0 ? np : 1), st));
+    tb_pack_kernel<<<dim3(nblk(nn + 1)), dim3(256), 0, st>>>(nn, b.order[1].ptr, b.rank.ptr, nd, idx, ctx->nodeA.ptr, ctx->nodeB.ptr,
+                                                              ctx->nodeC.ptr, ctx->nodeG.ptr, ctx->node_hmax.ptr, ctx->pfather.ptr);
+    const long long npad = n + SHQ_NMAXCHILD;
+    SHQ_TRY(ctx->posm_leaf.reserve((size_t) npad));
+    SHQ_TRY(ctx->leaf_pidx.reserve((size_t) npad));
+    tb_leafcopy_kernel<<<dim3(nblk(npad)), dim3(256), 0, st>>>(n, npad, idx, ctx->posm.ptr, ctx->posm_leaf.ptr, ctx->leaf_pidx.ptr);
+    SHQ_HIP(hipGetLastError());
+    SHQ_HIP(hipEventRecord(ctx->ev_end[16], st));
+    SHQ_HIP(hipStreamSynchronize(st));
+
+    ctx->node_order.resize((size_t) nn);
+    for(int j = 0; j < nn; j++)
+        ctx->node_order[j] = j; /* a downloaded tree is numbered in pool order */
+    ctx->numnodes = nn;
+    ctx->firstnode = np;
+    ctx->root = 0;
+    ctx->ntreeparts = n;
+    ctx->treeBox = BoxSize;
+    ctx->have_tree = true;
+    ctx->have_father = true;
+    ctx->tb_built = true;
+    if(stats) {
+        stats->nparticles = n;
+        stats->numnodes = nn;
+        stats->maxdepth = maxdepth;
+        float ms = 0;
+        (void) hipEventElapsedTime(&ms, ctx->ev_begin[16], ctx->ev_end[16]);
+        stats->build_ms = ms;
+    }
+    return SHQ_OK;
+}
+
+extern "C" int shq_tree_download(shq_context *ctx, int64_t firstnode, shq_node *nodes, int64_t capacity, int32_t *father,
+                                 int64_t *numnodes)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_CHECK(ctx->have_tree && ctx->tb_built, SHQ_ERR_STATE, "tree_download: no device-built tree (call shq_tree_build first)");
+    const int nn = (int) ctx->numnodes;
+    if(numnodes)
+        *numnodes = nn;
+    SHQ_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    TreeBuildBufs &b = ctx->tb;
+    if(nodes) {
+        SHQ_CHECK(capacity >= nn, SHQ_ERR_INVALID, "tree_download: capacity %ld < %d nodes", (long) capacity, nn);
+        SHQ_CHECK(firstnode >= ctx->numpart && firstnode + nn < (1ll << 31), SHQ_ERR_INVALID, "tree_download: firstnode %ld must be >= NumPart and fit int32", (long) firstnode);
+        SHQ_TRY(b.exportbuf.reserve((size_t) nn));
+        tb_export_kernel<<<dim3(nblk(nn)), dim3(256), 0, st>>>(nn, firstnode, b.order[1].ptr, b.rank.ptr, node_view(ctx), b.idx[0].ptr, b.exportbuf.ptr);
+        SHQ_HIP(hipGetLastError());
+        SHQ_HIP(hipMemcpyAsync(nodes, b.exportbuf.ptr, sizeof(shq_node) * (size_t) nn, hipMemcpyDeviceToHost, st));
+    }
+    if(father && ctx->numpart > 0) {
+        SHQ_TRY(b.idx[1].reserve((size_t) ctx->numpart)); /* the sequence numbers are no longer needed */
+        tb_father_kernel<<<dim3(nblk(ctx->numpart)), dim3(256), 0, st>>>(ctx->numpart, firstnode, ctx->pfather.ptr, b.idx[1].ptr);
+        SHQ_HIP(hipGetLastError());
+        SHQ_HIP(hipMemcpyAsync(father, b.idx[1].ptr, sizeof(int32_t) * (size_t) ctx->numpart, hipMemcpyDeviceToHost, st));
+    }
+    SHQ_HIP(hipStreamSynchronize(st));
+    return SHQ_OK;
+}
