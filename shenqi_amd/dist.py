@@ -308,7 +308,7 @@ class DistTreePM:
 
     def setup(self, posm_local, Rcut):
         """posm_local: device tensor [nloc, 4] of the particles this rank owns (already exchanged to
-        their owner).  Orders them along a space-filling curve, imports ghosts, builds and uploads the tree."""
+        their owner).  Orders them along a space-filling curve, imports ghosts, builds the tree on the device."""
         sq = self.sq
         host = posm_local.cpu().numpy()
         order = sq.hilbert_order(np.ascontiguousarray(host[:, :3]), self.L)
@@ -317,15 +317,8 @@ class DistTreePM:
         self.halo = self.halo_factor * Rcut
         self.ops.set_deposit_scale(self.comm.allreduce_sum(float(self.local[:, 3].sum().item())))
         self._load_particles()
-        allh = self.allp.cpu().numpy()
-        pman = sq.PartManager(allh.shape[0], self.L)
-        pman.Base["Pos"] = allh[:, :3]
-        pman.Base["Mass"] = allh[:, 3]
-        pman.Base["Type"] = 1
-        self.pman = pman
-        self.tree = sq.force_tree_full(pman)
-        tv = self.tree.view()
-        capi.check(capi.hip.shq_tree_upload(self.ctx.h, C.byref(tv)))
+        # local + ghost particles are resident: build their tree (global root cell) on the device
+        self.tree = sq.tree_build_device(self.ctx, self.L)
 
     def _load_particles(self):
         ghosts = ghost_exchange(self.comm, self.decomp, self.local, self.halo)
