@@ -172,6 +172,10 @@ typedef struct shq_walk_stats {
  * interaction set (parity bar runtests.cpp:441-443). */
 #define SHQ_WALK_EXACT 0
 #define SHQ_WALK_GROUP 1
+/* flag, or-ed into walk_mode: with active == NULL, take the targets in tree (leaf) order instead of
+ * particle-index order — same results per particle; keeps target groups compact when the particle
+ * order has gone stale (resident stepping without the reference's periodic Peano-Hilbert re-sort) */
+#define SHQ_WALK_TREE_ORDER 0x100
 
 /* One-shot replacement of grav_short_tree_cuda(): walks the local tree for the `nactive`
  * targets in `active` (NULL => all particles, as ActiveParticles with a NULL list), writes
@@ -211,6 +215,29 @@ int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const int32_t *ac
  * -1 (ForceTree.Father).  Either output may be NULL; *numnodes always returns the node count. */
 int shq_tree_download(shq_context *ctx, int64_t firstnode, shq_node *nodes, int64_t capacity, int32_t *father,
                       int64_t *numnodes);
+
+/* Resident drift and kick: with the particles, their velocities and the force
+ * arrays in HBM a step is  shq_drift -> shq_tree_build -> shq_pm_run / shq_grav_short_run -> kicks,
+ * without a PCIe crossing.  Same operations in the same order as the reference, so the state stays
+ * bit-identical to a host integration.  Black-hole repositioning (drift.cpp:32-53) and do_hydro_kick
+ * (timestep.cpp:970-1003) are not covered; the integer time line stays with the host.
+ *
+ * shq_dynamics_upload: Vel, Hsml, DtHsml, TimeBinGravity of the particles uploaded before.
+ * shq_drift: drift_all_particles / real_drift_particle (libgadget/drift.cpp:16-99):
+ *     Pos += Vel * ddrift + random_shift, wrapped into (0, BoxSize]; gas Hsml += DtHsml * ddrift, capped at
+ *     BoxSize / 2; garbage / swallowed particles only follow the shift.  Invalidates the tree and the PM result.
+ *     SHQ_ERR_INVALID for a non-finite position or a gas Hsml <= 0 (the reference ends the run).
+ * shq_kick_short: apply_half_kick, gravity part (timestep.cpp:838-872, 962-968):
+ *     Vel += A * gravkick[TimeBinGravity] for the active list (NULL => all), A = FullTreeGravAccel, or the
+ *     walk's Accel output (AccelStore, timestep.cpp:273) when from_accel_store; inactive bins carry 0.
+ * shq_kick_pm: apply_PM_half_kick (timestep.cpp:937-959): Vel += GravPM * Fgravkick for every particle.
+ * shq_dynamics_download: Pos, Vel, Hsml back into the caller's particle array. */
+int shq_dynamics_upload(shq_context *ctx, const shq_part_view *parts);
+int shq_drift(shq_context *ctx, double ddrift, double BoxSize, const double random_shift[3]);
+int shq_kick_short(shq_context *ctx, const double gravkick[SHQ_TIMEBINS + 1], const int32_t *active, int64_t nactive,
+                   int from_accel_store);
+int shq_kick_pm(shq_context *ctx, double Fgravkick);
+int shq_dynamics_download(shq_context *ctx, const shq_part_view *parts);
 /* active: host int32 list or NULL. The walk and postprocess are queued on the stream. */
 int shq_grav_short_run(shq_context *ctx, const shq_grav_params *params, const int32_t *active,
                        int64_t nactive, int update_potential, int walk_mode);

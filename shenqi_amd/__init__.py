@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import (PARTICLE_DTYPE, SPH_DTYPE, NODE_DTYPE, WALK_EXACT, WALK_GROUP, GravParams, PMParams,
+from .capi import (PARTICLE_DTYPE, SPH_DTYPE, NODE_DTYPE, WALK_EXACT, WALK_GROUP, WALK_TREE_ORDER, GravParams, PMParams,
                    WalkStats, ShqError)
 
 GASMASK, DMMASK, NUMASK, STARMASK, BHMASK = 1, 2, 4, 16, 32
@@ -131,6 +131,36 @@ def tree_download(ctx, firstnode, numpart=0):
     capi.check(capi.hip.shq_tree_download(ctx.h, int(firstnode), capi.ptr(nodes), nn.value, capi.ptr(father), C.byref(nn)),
                "shq_tree_download")
     return nodes, father
+
+
+def dynamics_upload(ctx, pman):
+    pv = pman.view()
+    capi.check(capi.hip.shq_dynamics_upload(ctx.h, C.byref(pv)), "shq_dynamics_upload")
+
+
+def drift(ctx, ddrift, BoxSize, random_shift=None):
+    """shq_drift: drift_all_particles (libgadget/drift.cpp:16-99) on the resident particles."""
+    rs = None if random_shift is None else np.ascontiguousarray(random_shift, dtype=np.float64)
+    capi.check(capi.hip.shq_drift(ctx.h, float(ddrift), float(BoxSize), capi.ptr(rs)), "shq_drift")
+
+
+def kick_short(ctx, gravkick, active=None, from_accel_store=False):
+    """shq_kick_short: gravity part of apply_half_kick (libgadget/timestep.cpp:838-872)."""
+    gk = np.ascontiguousarray(gravkick, dtype=np.float64)
+    assert gk.shape == (capi.TIMEBINS + 1,)
+    act = None if active is None else np.ascontiguousarray(active, dtype=np.int32)
+    capi.check(capi.hip.shq_kick_short(ctx.h, capi.ptr(gk), capi.ptr(act), 0 if act is None else len(act), int(from_accel_store)),
+               "shq_kick_short")
+
+
+def kick_pm(ctx, Fgravkick):
+    """shq_kick_pm: apply_PM_half_kick (libgadget/timestep.cpp:937-959)."""
+    capi.check(capi.hip.shq_kick_pm(ctx.h, float(Fgravkick)), "shq_kick_pm")
+
+
+def dynamics_download(ctx, pman):
+    pv = pman.view()
+    capi.check(capi.hip.shq_dynamics_download(ctx.h, C.byref(pv)), "shq_dynamics_download")
 
 
 def force_tree_full(pman):

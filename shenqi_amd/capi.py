@@ -18,6 +18,7 @@ NOFIELD = C.c_size_t(-1).value
 
 WALK_EXACT = 0
 WALK_GROUP = 1
+WALK_TREE_ORDER = 0x100
 
 
 class ShqError(RuntimeError):
@@ -193,6 +194,16 @@ hip.shq_tree_build.argtypes = [_vp, C.c_double, C.c_int, _vp, C.c_int64, C.POINT
 hip.shq_tree_build.restype = C.c_int
 hip.shq_tree_download.argtypes = [_vp, C.c_int64, _vp, C.c_int64, _vp, C.POINTER(C.c_int64)]
 hip.shq_tree_download.restype = C.c_int
+hip.shq_dynamics_upload.argtypes = [_vp, C.POINTER(PartView)]
+hip.shq_dynamics_upload.restype = C.c_int
+hip.shq_drift.argtypes = [_vp, C.c_double, C.c_double, _vp]
+hip.shq_drift.restype = C.c_int
+hip.shq_kick_short.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int]
+hip.shq_kick_short.restype = C.c_int
+hip.shq_kick_pm.argtypes = [_vp, C.c_double]
+hip.shq_kick_pm.restype = C.c_int
+hip.shq_dynamics_download.argtypes = [_vp, C.POINTER(PartView)]
+hip.shq_dynamics_download.restype = C.c_int
 hip.shq_grav_short_run.argtypes = [_vp, C.POINTER(GravParams), _vp, C.c_int64, C.c_int, C.c_int]
 hip.shq_grav_short_download.argtypes = [_vp, _vp, _vp, _vp, C.POINTER(WalkStats)]
 hip.shq_grav_refresh_oldacc.argtypes = [_vp, C.c_double]

@@ -139,7 +139,7 @@ extern "C" void shq_shutdown(shq_context *ctx)
     ctx->hydD_leaf.release(); ctx->hsml_leaf.release(); ctx->flag_leaf.release();
     ctx->s_numngb.release(); ctx->s_dhsmldens.release(); ctx->s_left.release(); ctx->s_right.release(); ctx->s_rot.release();
     ctx->s_gradrho.release(); ctx->s_evp_in.release(); ctx->s_todo.release(); ctx->s_queue2.release(); ctx->s_queue3.release();
-    ctx->tb.release(); ctx->s_blockcount.release(); ctx->s_nlist.release(); ctx->s_counters.release(); ctx->pm_oob.release(); ctx->fft_tw.release();
+    ctx->tb.release(); ctx->tree_targets.release(); ctx->s_blockcount.release(); ctx->s_nlist.release(); ctx->s_counters.release(); ctx->pm_oob.release(); ctx->fft_tw.release();
     for(int i = 0; i < SHQ_NTIMERS; i++) {
         (void) hipEventDestroy(ctx->ev_begin[i]);
         (void) hipEventDestroy(ctx->ev_end[i]);
@@ -422,6 +422,7 @@ extern "C" int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree)
     ctx->treeBox = tree->BoxSize;
     ctx->have_tree = true;
     ctx->tb_built = false;
+    ctx->have_tree_targets = false;
     return SHQ_OK;
 }
 
@@ -482,7 +483,14 @@ extern "C" int shq_grav_short_run(shq_context *ctx, const shq_grav_params *param
     SHQ_HIP(hipSetDevice(ctx->device));
     const int32_t *d_active = nullptr;
     int64_t nt = active ? nactive : (ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart);
-    SHQ_TRY(upload_active(ctx, active, nt, &d_active));
+    if((walk_mode & SHQ_WALK_TREE_ORDER) && !active) {
+        /* all own particles of the tree, taken in leaf order */
+        SHQ_TRY(shq_build_tree_targets(ctx));
+        d_active = ctx->tree_targets.ptr;
+        nt = ctx->ntree_targets;
+    } else
+        SHQ_TRY(upload_active(ctx, active, nt, &d_active));
+    walk_mode &= 0xff;
     SHQ_TRY(shq_launch_grav_walk(ctx, params, d_active, nt, update_potential, walk_mode));
     SHQ_TRY(shq_launch_grav_postprocess(ctx, params, d_active, nt, update_potential));
     ctx->last_stats.ntargets = nt;

@@ -209,10 +209,14 @@ struct shq_context {
     std::vector<int32_t> node_order; /* packed index -> index into the caller's nodes_base */
     bool have_father = false;
     TreeBuildBufs tb;
+    DevBuf<int32_t> tree_targets; /* own particles in leaf order (SHQ_WALK_TREE_ORDER) */
+    int64_t ntree_targets = 0;
+    bool have_tree_targets = false;
     bool tb_built = false;     /* the current tree came from shq_tree_build (downloadable) */
 
     /* ---- SPH state, by particle index (gas fields gathered from their slots at upload) */
     bool have_sph = false;
+    bool have_dyn = false;     /* Vel / Hsml / DtHsml / TimeBinGravity resident (shq_dynamics_upload) */
     DevBuf<double> hsml, dthsml, vel;
     DevBuf<uint8_t> bin_grav, bin_hydro;
     DevBuf<double> g_entropy, g_dtentropy, g_hydroaccel, g_delaytime;
@@ -267,6 +271,8 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm);
 void shq_pm_destroy_plans(shq_context *ctx);
 int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *complx);
 int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double *real);
+/* tree_build.hip */
+int shq_build_tree_targets(shq_context *ctx);
 /* fft3d.hip */
 bool shq_fft3d_supported(int N);
 int shq_fft3d_pitch(int N);

@@ -30,6 +30,7 @@
 #include "common.hpp"
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
 
 namespace {
 
@@ -428,6 +429,41 @@ TbNodes node_view(shq_context *ctx)
 
 } // namespace
 
+struct BelowLimit {
+    int limit;
+    __device__ bool operator()(const int32_t &p) const { return p < limit; }
+};
+
+/* Walk targets in tree (leaf) order: the particles of the tree that are this rank's own, in the order
+ * the leaves list them.  64 consecutive entries are 8-16 neighbouring leaves, so a wave's targets stay
+ * spatially compact even when the particle index order has gone stale after many drifts (the reference
+ * re-sorts its particle array along the Peano-Hilbert curve at every domain decomposition instead). */
+int shq_build_tree_targets(shq_context *ctx)
+{
+    if(ctx->have_tree_targets)
+        return SHQ_OK;
+    SHQ_CHECK(ctx->have_tree, SHQ_ERR_STATE, "tree-order targets: no tree");
+    const long long n = ctx->ntreeparts;
+    const int limit = (int) (ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart);
+    TreeBuildBufs &b = ctx->tb;
+    SHQ_TRY(ctx->tree_targets.reserve((size_t) (n > 0 ? n : 1)));
+    SHQ_TRY(b.counters.reserve(4));
+    ctx->ntree_targets = 0;
+    if(n > 0) {
+        size_t tmp = 0;
+        unsigned long long *d_count = b.counters.ptr + 2;
+        SHQ_HIP(rocprim::select(nullptr, tmp, ctx->leaf_pidx.ptr, ctx->tree_targets.ptr, d_count, (size_t) n, BelowLimit{limit}, ctx->stream));
+        SHQ_TRY(b.temp.reserve(tmp + 16));
+        SHQ_HIP(rocprim::select(b.temp.ptr, tmp, ctx->leaf_pidx.ptr, ctx->tree_targets.ptr, d_count, (size_t) n, BelowLimit{limit}, ctx->stream));
+        unsigned long long h = 0;
+        SHQ_HIP(hipMemcpyAsync(&h, d_count, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->ntree_targets = (int64_t) h;
+    }
+    ctx->have_tree_targets = true;
+    return SHQ_OK;
+}
+
 extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const int32_t *active, int64_t nactive,
                               shq_tree_build_stats *stats)
 {
@@ -442,6 +478,7 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
     const long long ncand = active ? nactive : np;
     SHQ_CHECK(ncand < (1ll << 31) - 64, SHQ_ERR_INVALID, "tree_build: too many particles");
     ctx->have_tree = false;
+    ctx->have_tree_targets = false;
     SHQ_HIP(hipEventRecord(ctx->ev_begin[16], st));
 
     /* 1. keys */

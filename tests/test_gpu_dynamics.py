@@ -1,0 +1,162 @@
+"""GPU parity tests of the resident drift / kick (csrc/dynamics.hip) against a numpy restatement of
+libgadget/drift.cpp:16-99 and libgadget/timestep.cpp:838-872, 937-968 (plain IEEE multiplies and adds in
+the reference's order: results must agree to the bit)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import shenqi_amd as sq
+from shenqi_amd import capi
+import common as cm
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_drift(P, ddrift, box, shift):
+    """real_drift_particle, drift.cpp:16-86 (no black-hole repositioning)."""
+    pos, vel = P["Pos"].copy(), P["Vel"]
+    hsml = P["Hsml"].copy()
+    dead = (P["Flags"] & 3) != 0
+    gas = (P["Type"] == 0) & ~dead
+    hsml[gas] = hsml[gas] + P["DtHsml"][gas] * ddrift
+    hsml[gas] = np.minimum(hsml[gas], box / 2.0)
+    step = vel * ddrift + shift
+    step[dead] = shift
+    pos = pos + step
+    for _ in range(8):
+        pos = np.where(pos > box, pos - box, pos)
+        pos = np.where(pos <= 0, pos + box, pos)
+    return pos, hsml
+
+
+def _setup(n=20000, seed=4):
+    rng = np.random.default_rng(seed)
+    pos = rng.random((n, 3)) * cm.BOX
+    pman = cm.make_partmanager(pos)
+    P = pman.Base
+    P["Type"] = rng.choice([0, 1, 4, 5], size=n).astype(np.uint8)
+    P["Vel"] = rng.normal(size=(n, 3)) * 300.0
+    P["Hsml"] = 0.01 * cm.BOX * (1 + rng.random(n))
+    P["DtHsml"] = rng.normal(size=n) * 1e-4 * cm.BOX
+    P["TimeBinGravity"] = rng.integers(20, 30, size=n).astype(np.uint8)
+    fl = np.zeros(n, dtype=np.uint8)
+    fl[rng.random(n) < 0.03] |= 1
+    fl[rng.random(n) < 0.03] |= 2
+    P["Flags"] = fl
+    P["FullTreeGravAccel"] = rng.normal(size=(n, 3)) * 1e3
+    P["GravPM"] = rng.normal(size=(n, 3)) * 1e2
+    return pman, rng
+
+
+def test_drift_bit_exact(ctx):
+    pman, rng = _setup()
+    P = pman.Base
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    sq.dynamics_upload(ctx, pman)
+    ddrift, shift = 3.7e-4, np.array([0.31, -0.27, 0.05]) * cm.BOX  # fast particles cross the box edge
+    rpos, rhsml = ref_drift(P, ddrift, cm.BOX, shift)
+    sq.drift(ctx, ddrift, cm.BOX, shift)
+    sq.dynamics_download(ctx, pman)
+    assert np.array_equal(P["Pos"], rpos)
+    assert np.array_equal(P["Hsml"], rhsml)
+    assert P["Pos"].min() > 0 and P["Pos"].max() <= cm.BOX
+    # a drift makes the tree stale: a walk without a rebuild must be refused
+    cm.reference_treepar()
+    sq.gravshort_set_softenings(cm.BOX / 27.0)
+    gp = sq.make_grav_params(cm.BOX, 1.5, 48, cm.G, cm.RHO0)
+    assert capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, sq.WALK_EXACT) != 0
+
+
+def test_drift_rejects_bad_hsml(ctx):
+    pman, _ = _setup(n=1000)
+    P = pman.Base
+    P["Type"] = 0
+    P["Flags"] = 0
+    P["DtHsml"] = -1e6
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    sq.dynamics_upload(ctx, pman)
+    with pytest.raises(sq.ShqError):
+        sq.drift(ctx, 1.0, cm.BOX)
+
+
+def test_kicks_bit_exact(ctx):
+    pman, rng = _setup()
+    P = pman.Base
+    n = len(P)
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    sq.dynamics_upload(ctx, pman)
+    gravkick = np.zeros(capi.TIMEBINS + 1)
+    gravkick[22:28] = rng.random(6) * 1e-3  # bins outside are inactive: factor 0
+    active = np.sort(rng.choice(n, size=n // 3, replace=False)).astype(np.int32)
+    alive = (P["Flags"] & 3) == 0
+    vel = P["Vel"].copy()
+    sel = active[alive[active]]
+    vel[sel] = vel[sel] + P["FullTreeGravAccel"][sel] * gravkick[P["TimeBinGravity"][sel]][:, None]
+    sq.kick_short(ctx, gravkick, active)
+    Fpm = 2.5e-4
+    vel[alive] = vel[alive] + P["GravPM"][alive] * Fpm
+    sq.kick_pm(ctx, Fpm)
+    sq.dynamics_download(ctx, pman)
+    assert np.array_equal(P["Vel"], vel)
+
+
+def test_resident_step_equals_reupload(ctx):
+    """drift -> device tree build -> walk on resident data gives the forces of a fresh upload of the
+    drifted particles with a host-built tree, bit for bit."""
+    n = 24**3
+    L = cm.BOX
+    pos = sq.synth_positions("cluster", n, L=L)
+    pman = cm.make_partmanager(pos)
+    P = pman.Base
+    P["Vel"] = np.random.default_rng(9).normal(size=(n, 3)) * 50.0
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=1)
+    sq.gravshort_set_softenings(L / 24)
+    gp = sq.make_grav_params(L, 1.5, 72, cm.G, cm.RHO0)
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    sq.dynamics_upload(ctx, pman)
+    sq.drift(ctx, 2e-3, L)
+    sq.tree_build_device(ctx, L)
+    capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, sq.WALK_EXACT))
+    acc = np.zeros((n, 3)); nint = np.zeros(n, dtype=np.int64)
+    capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), None, capi.ptr(nint), None))
+    sq.dynamics_download(ctx, pman)       # host copy now holds the drifted positions
+    host = sq.force_tree_full(pman)
+    pv, tv = pman.view(), host.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    capi.check(capi.hip.shq_tree_upload(ctx.h, C.byref(tv)))
+    capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, sq.WALK_EXACT))
+    acc2 = np.zeros((n, 3)); nint2 = np.zeros(n, dtype=np.int64)
+    capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc2), None, capi.ptr(nint2), None))
+    assert np.array_equal(nint, nint2) and np.array_equal(acc, acc2)
+
+
+def test_tree_order_targets_same_forces(ctx):
+    """SHQ_WALK_TREE_ORDER only changes which wave handles which target: per-particle results are
+    bit-identical to the index-order walk."""
+    n = 24**3
+    L = cm.BOX
+    pos = sq.synth_positions("cluster", n, L=L)     # deliberately NOT sorted along a space-filling curve
+    pman = cm.make_partmanager(pos)
+    pman.Base["Flags"][::97] = 1                     # some garbage particles: not in the tree, not targets
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=1)
+    sq.gravshort_set_softenings(L / 24)
+    gp = sq.make_grav_params(L, 1.5, 72, cm.G, cm.RHO0)
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    sq.tree_build_device(ctx, L)
+    out = []
+    for mode in (sq.WALK_EXACT, sq.WALK_EXACT | sq.WALK_TREE_ORDER):
+        capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, mode))
+        acc = np.zeros((n, 3)); pot = np.zeros(n); nint = np.zeros(n, dtype=np.int64)
+        st = sq.WalkStats()
+        capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), capi.ptr(pot), capi.ptr(nint), C.byref(st)))
+        out.append((acc, pot, nint, st.ntargets))
+    alive = (pman.Base["Flags"] & 3) == 0
+    assert out[1][3] == alive.sum()
+    for k in range(3):
+        assert np.array_equal(out[0][k][alive], out[1][k][alive])
