@@ -257,6 +257,10 @@ extern "C" int shq_particles_upload(shq_context *ctx, const shq_part_view *parts
     ctx->nlocal = 0;
     ctx->have_parts = true;
     ctx->have_tree = false; /* leaf copy refers to the old particles */
+    ctx->have_tree_targets = false;
+    ctx->tb_built = false;
+    ctx->have_sph = false;  /* Hsml / Vel / slot data of the previous particle set */
+    ctx->have_dyn = false;
     ctx->have_pm_result = false;
     return SHQ_OK;
 }
@@ -464,8 +468,13 @@ extern "C" int shq_particles_set_device(shq_context *ctx, const void *d_posm, in
         fill_u8_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->pflags.ptr, n, (uint8_t) (1 << 4));
         SHQ_HIP(hipGetLastError());
     }
-    if(ctx->numpart != n)
+    if(ctx->numpart != n) {
         ctx->have_tree = false;
+        ctx->tb_built = false;
+    }
+    ctx->have_tree_targets = false; /* nlocal may have changed */
+    ctx->have_sph = false;
+    ctx->have_dyn = false;
     ctx->numpart = n;
     ctx->nlocal = nlocal;
     ctx->have_parts = true;

@@ -575,7 +575,7 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
     SHQ_HIP(hipGetLastError());
 
     /* 4. moments, deepest level first */
-    const double *d_hsml = ctx->have_sph ? ctx->hsml.ptr : nullptr;
+    const double *d_hsml = (ctx->have_sph || ctx->have_dyn) ? ctx->hsml.ptr : nullptr;
     for(int l = maxdepth; l >= 0; l--) {
         const int first = level_start[l], last = level_start[l + 1];
         if(last > first)

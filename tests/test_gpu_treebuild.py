@@ -90,15 +90,18 @@ def test_device_tree_mask_and_active(ctx):
     flags[rng.random(n) < 0.05] |= 1   # IsGarbage
     flags[rng.random(n) < 0.05] |= 2   # Swallowed
     P["Flags"] = flags
+    P["Hsml"] = 0.02 * cm.BOX * (0.5 + rng.random(n))   # hmax of gas / BH particles (forcetree.cpp:985-1005)
     active = np.sort(rng.choice(n, size=n // 2, replace=False)).astype(np.int32)
     pv = pman.view()
     capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    sq.dynamics_upload(ctx, pman)                        # makes Hsml resident
     for mask, act in ((sq.GASMASK, None), (sq.GASMASK + sq.BHMASK, active), (sq.ALLMASK, active)):
         host = sq.force_tree_rebuild_mask(pman, mask, act)
         st = sq.tree_build_device(ctx, cm.BOX, mask, act)
         dnodes, _ = sq.tree_download(ctx, host.firstnode, 0)
         a, b = canonical(host.Nodes_base, host.firstnode), canonical(dnodes, host.firstnode)
         assert st.numnodes == len(a["len"])
+        assert a["hmax"].max() > 0
         for k in a:
             assert np.array_equal(a[k], b[k]), (mask, k)
 
