@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--errtol", type=float, default=0.005)
     ap.add_argument("--kind", default="cluster", choices=["cluster", "uniform", "grid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sph", action="store_true", help="skip the SPH operator figures (kernels.sph_*)")
     ap.add_argument("--walk-mode", type=int, default=0)
     return ap.parse_args()
 
@@ -77,6 +78,46 @@ def cpu_baseline(pos, mass, tree, gp_rel, oldacc, L):
                   "fraction of the full job" % (len(targets), n, t_tree, len(sub), t_pm),
         "tree_s_sample": t_tree, "pm_s_sample": t_pm,
     }
+
+
+def sph_figures(ctx, n1=128, kernel=2):
+    """SPH operators of BASELINE configs[2] (density with the Hsml loop, hydro force) on n1^3 uniformly
+    placed gas particles, quintic kernel, pressure-entropy SPH: HIP-event time of the walk kernels through
+    the one-shot C-ABI calls (tools/bench_sph.py is the stand-alone version).  Reported under kernels.sph_*;
+    not part of `value`."""
+    import shenqi_amd as sq
+    n = n1**3
+    L = 1.0
+    pos = sq.synth_positions("uniform", n, L=L)
+    pos = pos[sq.hilbert_order(pos, L)]
+    pman = sq.PartManager(n, L)
+    P = pman.Base
+    P["Pos"] = pos
+    P["Mass"] = 1.0
+    P["Type"] = 0
+    P["PI"] = np.arange(n)
+    P["Vel"] = np.random.default_rng(1).normal(size=(n, 3)) * 0.01
+    P["Hsml"] = 1.5 * L / n1
+    SphP = np.zeros(n, dtype=sq.SPH_DTYPE)
+    SphP["Entropy"] = 1
+    SphP["Density"] = 1
+    BhP = np.zeros(2, dtype=sq.BH_SLOT_DTYPE)
+    sq.set_densitypar(DensityResolutionEta=1.0, MaxNumNgbDeviation=0.5, DensityKernelType=kernel, BlackHoleNgbFactor=2.0,
+                      MinGasHsml=1e-6)
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+    sq.set_init_hsml(tree, L / n1, pman)
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+    evp, st0 = sq.density(ctx, None, 1, 1, 0, None, tree, pman, SphP, BhP)   # converges Hsml from the initial guess
+    evp, st = sq.density(ctx, None, 1, 1, 0, None, tree, pman, SphP, BhP)    # steady state: one iteration
+    sq.force_tree_update_hmax(tree, pman)
+    sq.set_hydropar(1, 100.0, 0.75)
+    hs = sq.hydro_force(ctx, None, 0.1, 0.1, evp, None, tree, pman, SphP)
+    hs = sq.hydro_force(ctx, None, 0.1, 0.1, evp, None, tree, pman, SphP)
+    return {"sph_workload": "%d^3 gas, uniform, quintic kernel, %.0f neighbours" % (n1, sq.GetNumNgb()),
+            "sph_density_first_call_iterations": int(st0.niterations), "sph_density_first_call_ms": float(st0.kernel_ms),
+            "sph_density_iteration_ms": float(st.kernel_ms) / max(1, int(st.niterations)),
+            "sph_density_particles_per_s": n / (1e-3 * float(st.kernel_ms) / max(1, int(st.niterations))),
+            "sph_hydro_ms": float(hs.kernel_ms), "sph_hydro_particles_per_s": n / (1e-3 * float(hs.kernel_ms))}
 
 
 def run_sharded(args, rank, local_rank, world):
@@ -368,6 +409,8 @@ def main():
     t_res = time.perf_counter() - t0
     out["kernels"]["resident_full_step_ms"] = 1e3 * t_res / nres
     out["kernels"]["resident_full_step_particle_steps_per_s"] = n * nres / t_res
+    if not args.no_sph:
+        out["kernels"].update(sph_figures(ctx))
     ctx.close()
     if dist is not None:
         dist.barrier()
