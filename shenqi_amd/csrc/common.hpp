@@ -222,12 +222,14 @@ struct shq_context {
     DevBuf<double> g_entropy, g_dtentropy, g_hydroaccel, g_delaytime;
     DevBuf<double> g_density, g_egywt, g_dhsmlegy, g_divvel, g_curlvel;
     DevBuf<double> g_hydroaccel_out, g_dtentropy_out, g_maxsignalvel;
-    DevBuf<double4> velp, hydC, hydD, velp_leaf, hydC_leaf, hydD_leaf;
+    DevBuf<double4> velp, hydC, hydD, velp_leaf;
+    DevBuf<char> hydrec_leaf;  /* HydRec[] (sph.hip): 128-byte neighbour records for the hydro evaluation */
     DevBuf<double> hsml_leaf;
     DevBuf<int32_t> flag_leaf;
     DevBuf<double> s_numngb, s_dhsmldens, s_left, s_right, s_rot, s_gradrho, s_evp_in;
     DevBuf<int32_t> s_todo, s_queue2, s_queue3, s_blockcount;
     DevBuf<int32_t> s_nlist;   /* per-lane neighbour lists of the SPH walks */
+    DevBuf<int32_t> s_ncount, s_redo; /* list lengths; targets of waves whose lists overflowed */
     DevBuf<long long> s_counters;
 
     /* ---- PM */

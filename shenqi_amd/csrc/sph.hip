@@ -114,6 +114,18 @@ __device__ __forceinline__ double pressure_predict(double eom, double evp)
     return exp(SPH_GAMMA * log(evp * eom));
 }
 
+/* Everything the hydro pair evaluation needs of neighbour j besides its position, in ONE cache line:
+ * five separate leaf-ordered arrays cost five line fetches per (lane, pair), and the evaluation kernel
+ * is bound by exactly that L2 -> L1 traffic. */
+struct alignas(128) HydRec {
+    double4 velp; /* predicted velocity, EntVarPred */
+    double4 C;    /* EntVarPred, density_j, soundspeed_j, p_over_rho2_j */
+    double4 D;    /* Dhsml_j, rr2_j, f2_j, dloga_for_bin_j */
+    double hsml;
+    double pad_[3];
+};
+static_assert(sizeof(HydRec) == 128, "HydRec must be one 128-byte line");
+
 struct SphDev {
     /* node pool */
     const NodeB *nodeB;
@@ -125,8 +137,7 @@ struct SphDev {
     /* leaf-order neighbour data */
     const double4 *posm_leaf;   /* x,y,z,m */
     const double4 *velp_leaf;   /* predicted velocity, EntVarPred */
-    const double4 *hydC_leaf;   /* EntVarPred, density_j, soundspeed_j, p_over_rho2_j */
-    const double4 *hydD_leaf;   /* Dhsml_j, rr2_j, f2_j, dloga_for_bin_j */
+    const HydRec *hydrec_leaf;  /* one 128-byte line per neighbour for the hydro pair evaluation */
     const double *hsml_leaf;
     const int32_t *flag_leaf;   /* bit0 skip (garbage / not gas), bit1 wind-decoupled */
     /* per particle */
@@ -208,7 +219,7 @@ __global__ void sph_predict_kernel(const PredArgs a)
 
 __global__ void sph_gather_leaf_kernel(long long nleaf, const int32_t *pidx, const double4 *velp, const double4 *hydC,
                                        const double4 *hydD, const double *hsml, const uint8_t *pflags, const double *delay,
-                                       double4 *velp_leaf, double4 *hydC_leaf, double4 *hydD_leaf, double *hsml_leaf,
+                                       double4 *velp_leaf, HydRec *hydrec_leaf, double *hsml_leaf,
                                        int32_t *flag_leaf)
 {
     const long long s = (long long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -216,9 +227,14 @@ __global__ void sph_gather_leaf_kernel(long long nleaf, const int32_t *pidx, con
         return;
     const int p = pidx[s];
     velp_leaf[s] = velp[p];
-    if(hydC_leaf) {
-        hydC_leaf[s] = hydC[p];
-        hydD_leaf[s] = hydD[p];
+    if(hydrec_leaf) {
+        HydRec r;
+        r.velp = velp[p];
+        r.C = hydC[p];
+        r.D = hydD[p];
+        r.hsml = hsml[p];
+        r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+        hydrec_leaf[s] = r;
     }
     hsml_leaf[s] = hsml[p];
     const uint8_t f = pflags[p];
@@ -243,7 +259,7 @@ __global__ void sph_gather_leaf_kernel(long long nleaf, const int32_t *pidx, con
  * pairs per target; the lists therefore live in global memory (L2-resident scratch, one region per
  * resident wave of a persistent grid, [entry][lane] so appends and reads coalesce) and are long enough
  * to be drained once. */
-#define NL_CAP 160      /* list entries per lane; quintic-kernel neighbourhoods hold ~113 */
+#define NL_CAP 256      /* list entries per lane; quintic-kernel neighbourhoods hold ~113, symmetric hydro lists up to ~200 */
 #define NL_MAXBLOCKS 4096 /* persistent workgroups (4 waves each) that own a list region */
 
 template <class F> __device__ __forceinline__ void nl_flush(const int32_t *myl, int &fill, F &&pair)
@@ -275,10 +291,12 @@ template <class F> __device__ __forceinline__ void nl_flush(const int32_t *myl, 
 #define NW_WIN 64
 #define NW_LDS_PER_WAVE (NW_WIN * (32 + 16 + 8) + 64 * (32 + 8 + 8 + 4 + 4))
 
-template <bool SYM, class Accept, class Pair>
+/* KEEP: only build the lists (two-kernel path): nothing is evaluated, `fill` returns the list length, and a
+ * lane whose list would overflow sets `ovf` (its wave is then redone by the fused kernel). */
+template <bool SYM, bool KEEP, class Accept, class Pair>
 __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave, int32_t *myl, const bool valid, const double px,
                                                  const double py, const double pz, const double h, Accept &&accept, Pair &&pair,
-                                                 unsigned int *dbg)
+                                                 unsigned int *dbg, int &fill, bool &ovf)
 {
     double4 *winB = reinterpret_cast<double4 *>(lds_wave);
     int4 *winC = reinterpret_cast<int4 *>(lds_wave + NW_WIN * 32);
@@ -292,7 +310,9 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
     const int lane = threadIdx.x & 63;
     const double halfBox = 0.5 * a.Box;
     unsigned int nint = 0;
-    int fill = 0, ncand = 0;
+    int ncand = 0;
+    fill = 0;
+    ovf = false;
 
     /* scan the queued candidates: one coalesced gather, then broadcast reads */
     auto scan_tile = [&]() {
@@ -324,7 +344,12 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
                     fill++;
                 }
             }
-            if(__ballot(fill == NL_CAP) != 0ull) {
+            if(KEEP) {
+                if(fill == NL_CAP) {
+                    ovf = true;
+                    fill = 0;
+                }
+            } else if(__ballot(fill == NL_CAP) != 0ull) {
                 if(dbg)
                     dbg[2] += NL_CAP;
                 nl_flush(myl, fill, pair);
@@ -410,19 +435,29 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
             mf = max(mf, __shfl_xor(mf, off));
         dbg[2] += mf;
     }
-    nl_flush(myl, fill, pair);
+    if(!KEEP)
+        nl_flush(myl, fill, pair);
     return nint;
 }
 
-template <int KT> __global__ __launch_bounds__(256) void sph_density_kernel(const SphDev a, const int32_t *queue, long long nq,
-                                                                           int WindsDecouple, unsigned long long *nint_total,
-                                                                           int32_t *__restrict__ nlist, long long ntasks)
+/* MODE 0: fused walk + evaluation (persistent grid, one list region per resident wave; also the redo path:
+ * d_nq != NULL takes the queue length from the device).  MODE 1: walk only, lists and their lengths go to
+ * global memory (one region per wave of the launch).  MODE 2: evaluation only, from those lists.  The
+ * two-kernel path lets the walk run at twice the occupancy the register-heavy evaluation allows. */
+template <int KT, int MODE>
+__global__ __launch_bounds__(256) void sph_density_kernel(const SphDev a, const int32_t *queue, long long nq, int WindsDecouple,
+                                                          unsigned long long *nint_total, int32_t *__restrict__ nlist, long long ntasks,
+                                                          int32_t *__restrict__ counts, const long long *d_nq)
 {
-    __shared__ __attribute__((aligned(32))) char lds[4 * NW_LDS_PER_WAVE];
+    __shared__ __attribute__((aligned(32))) char lds[(MODE == 2 ? 1 : 4 * NW_LDS_PER_WAVE)];
     const int lane = threadIdx.x & 63;
-    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    if(MODE == 0 && d_nq) {
+        nq = *d_nq;
+        ntasks = (nq + 255) / 256;
+    }
     for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
     const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int32_t *myl = nlist + (MODE == 0 ? ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) : (size_t) wave) * (size_t) (NL_CAP * 64) + lane;
     const long long t = wave * 64 + lane;
     const bool valid = t < nq;
     long long pi = 0;
@@ -476,9 +511,25 @@ template <int KT> __global__ __launch_bounds__(256) void sph_density_kernel(cons
     };
 
     auto accept = [&](const double r2, const double, const int fl) { return r2 < h2 && !(nowind && (fl & 2)); };
-    const unsigned int nint = ngb_walk<false>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE, myl, valid, px, py, pz, h, accept, pair,
-                                              (unsigned int *) nullptr);
-    if(valid) {
+    unsigned int nint = 0;
+    int fill = 0;
+    bool ovf = false;
+    if(MODE != 2)
+        nint = ngb_walk<false, MODE == 1>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE, myl, valid, px, py, pz, h, accept, pair,
+                                          (unsigned int *) nullptr, fill, ovf);
+    if(MODE == 1) {
+        const bool wave_ovf = __ballot(ovf) != 0ull;
+        counts[wave * 64 + lane] = wave_ovf ? -1 : fill;
+        if(wave_ovf)
+            nint = 0; /* counted when the wave is redone */
+    }
+    if(MODE == 2) {
+        fill = counts[wave * 64 + lane];
+        if(fill < 0)
+            continue; /* the whole wave overflowed: left to the fused kernel */
+        nl_flush(myl, fill, pair);
+    }
+    if(MODE != 1 && valid) {
         /* DensityResult::reduce<PRIMARY>, densitytree2.hpp:308-343 */
         a.numngb[pi] = Ngb;
         a.dhsmldens[pi] = DhsmlDensity;
@@ -678,15 +729,21 @@ struct HydroConst {
     int DISPH;
 };
 
-template <int KT> __global__ __launch_bounds__(256, 4) void sph_hydro_kernel(const SphDev a, const int32_t *queue, long long nq,
-                                                                         const HydroConst hc, unsigned long long *nint_total,
-                                                                         int32_t *__restrict__ nlist, long long ntasks)
+/* MODE as for sph_density_kernel */
+template <int KT, int MODE>
+__global__ __launch_bounds__(256, 4) void sph_hydro_kernel(const SphDev a, const int32_t *queue, long long nq, const HydroConst hc,
+                                                           unsigned long long *nint_total, int32_t *__restrict__ nlist, long long ntasks,
+                                                           int32_t *__restrict__ counts, const long long *d_nq)
 {
-    __shared__ __attribute__((aligned(32))) char lds[4 * NW_LDS_PER_WAVE];
+    __shared__ __attribute__((aligned(32))) char lds[(MODE == 2 ? 1 : 4 * NW_LDS_PER_WAVE)];
     const int lane = threadIdx.x & 63;
-    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    if(MODE == 0 && d_nq) {
+        nq = *d_nq;
+        ntasks = (nq + 255) / 256;
+    }
     for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
     const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int32_t *myl = nlist + (MODE == 0 ? ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) : (size_t) wave) * (size_t) (NL_CAP * 64) + lane;
     const long long t = wave * 64 + lane;
     const bool valid = t < nq;
     long long pi = 0;
@@ -710,21 +767,26 @@ template <int KT> __global__ __launch_bounds__(256, 4) void sph_hydro_kernel(con
     const double rr1 = Di.y;
     const Kern<KT> kernel_i(hi);
     const double hi2 = hi * hi;
+    const double si = (Kern<KT>::support / 2.) / hi, dnorm_i = kernel_i.dnorm, inv_iEVP = 1.0 / iEntVarPred;
     double A0 = 0, A1 = 0, A2 = 0, DtE = 0;
     double MaxSig = soundspeed_i; /* HydroResult ctor: sqrt(GAMMA P / EgyRho) */
 
     /* HydroLocalTreeWalk::ngbiter, hydratree2.hpp:253-378, for one accepted neighbour (leaf slot s) */
     auto pair = [&](const int s) {
         const double4 q = a.posm_leaf[s];
-        const double4 w = a.velp_leaf[s];
-        const double hj = a.hsml_leaf[s];
-        const double4 Cj = a.hydC_leaf[s];
-        const double4 Dj = a.hydD_leaf[s];
+        const HydRec *rec = a.hydrec_leaf + s;
+        const double4 w = rec->velp;
+        const double4 Cj = rec->C;
+        const double4 Dj = rec->D;
+        const double hj = rec->hsml;
         const double d0 = wrapd(px - q.x, a.Box, a.invBox);
         const double d1 = wrapd(py - q.y, a.Box, a.invBox);
         const double d2 = wrapd(pz - q.z, a.Box, a.invBox);
         const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
-        const Kern<KT> kernel_j(hj);
+        /* The reference divides by r, H and the entropy variables at every use; with ~10 f64 divisions
+         * (a dozen instructions each) they were half of this function.  Here 1/r comes from v_rsq_f64 + a
+         * Newton step and the kernel of j from one reciprocal of h_j: same formulas, results differ from
+         * the oracle's at the 1e-16 level. */
         const double EVP = Cj.x, density_j = Cj.y, soundspeed_j = Cj.z, p_over_rho2_j = Cj.w;
         double vsig = soundspeed_i + soundspeed_j;
         if(vsig > MaxSig)
@@ -732,12 +794,18 @@ template <int KT> __global__ __launch_bounds__(256, 4) void sph_hydro_kernel(con
         const double e0 = vx - w.x, e1 = vy - w.y, e2 = vz - w.z;
         const double vdotr = d0 * e0 + d1 * e1 + d2 * e2;
         const double vdotr2 = vdotr + hc.hubble_a2 * r2;
-        const double r = sqrt(r2);
-        const double dwk_i = kernel_i.dwk(r / kernel_i.H);
-        const double dwk_j = kernel_j.dwk(r / kernel_j.H);
+        const double y0 = __builtin_amdgcn_rsq(r2);
+        const double ye = fma(-r2 * y0, y0, 1.0);
+        const double rinv = fma(y0 * ye, fma(ye, 0.375, 0.5), y0);
+        const double r = r2 * rinv;
+        const double sj = (Kern<KT>::support / 2.) / hj; /* q = r * support / (2 H) */
+        const double sigma = (KT == 1) ? (1 / M_PI) : ((KT == 2) ? (1 / (120 * M_PI)) : (1 / (20 * M_PI)));
+        const double dnorm_j = sigma * (sj * sj) * (sj * sj);
+        const double dwk_i = dnorm_i * kernel_i.dwk_int(r * si);
+        const double dwk_j = dnorm_j * kernel_i.dwk_int(r * sj);
         double visc = 0;
         if(vdotr2 < 0) {
-            const double mu_ij = hc.fac_mu * vdotr2 / r;
+            const double mu_ij = hc.fac_mu * vdotr2 * rinv;
             const double rho_ij = 0.5 * (iDensity + density_j);
             vsig = soundspeed_i + soundspeed_j - 3 * mu_ij;
             if(vsig > MaxSig)
@@ -749,11 +817,14 @@ template <int KT> __global__ __launch_bounds__(256, 4) void sph_hydro_kernel(con
                     visc = fmin(visc, 0.5 * hc.fac_vsic_fix * vdotr2 / (0.5 * (mi + q.w) * (dwk_i + dwk_j) * r * dloga));
             }
         }
-        const double hfc_visc = 0.5 * q.w * visc * (dwk_i + dwk_j) / r;
+        const double mr = q.w * rinv;
+        const double hfc_visc = 0.5 * mr * visc * (dwk_i + dwk_j);
         double hfc = hfc_visc;
-        if(hc.DISPH)
-            hfc += q.w * (dwk_i * p_over_rho2_i * EVP / iEntVarPred + dwk_j * p_over_rho2_j * iEntVarPred / EVP) / r;
-        hfc += q.w * (p_over_rho2_i * iDhsml * dwk_i * rr1 + p_over_rho2_j * Dj.x * dwk_j * Dj.y) / r;
+        if(hc.DISPH) {
+            const double ratio = EVP * inv_iEVP; /* EVP_j / EVP_i */
+            hfc += mr * (dwk_i * p_over_rho2_i * ratio + dwk_j * p_over_rho2_j / ratio);
+        }
+        hfc += mr * (p_over_rho2_i * iDhsml * dwk_i * rr1 + p_over_rho2_j * Dj.x * dwk_j * Dj.y);
         A0 += -hfc * d0;
         A1 += -hfc * d1;
         A2 += -hfc * d2;
@@ -762,9 +833,25 @@ template <int KT> __global__ __launch_bounds__(256, 4) void sph_hydro_kernel(con
 
     auto accept = [&](const double r2, const double hj, const int fl) { return r2 > 0 && (r2 < hi2 || r2 < hj * hj) && !(fl & 2); };
     unsigned int dbgc[3] = {0, 0, 0};
-    const unsigned int nint = ngb_walk<true>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE, myl, valid, px, py, pz, hi, accept, pair,
-                                             nint_total ? dbgc : (unsigned int *) nullptr);
-    if(valid) {
+    unsigned int nint = 0;
+    int fill = 0;
+    bool ovf = false;
+    if(MODE != 2)
+        nint = ngb_walk<true, MODE == 1>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE, myl, valid, px, py, pz, hi, accept, pair,
+                                         (MODE == 0 && nint_total) ? dbgc : (unsigned int *) nullptr, fill, ovf);
+    if(MODE == 1) {
+        const bool wave_ovf = __ballot(ovf) != 0ull;
+        counts[wave * 64 + lane] = wave_ovf ? -1 : fill;
+        if(wave_ovf)
+            nint = 0; /* counted when the wave is redone */
+    }
+    if(MODE == 2) {
+        fill = counts[wave * 64 + lane];
+        if(fill < 0)
+            continue; /* the whole wave overflowed: left to the fused kernel */
+        nl_flush(myl, fill, pair);
+    }
+    if(MODE != 1 && valid) {
         a.hacc[3 * pi] = A0;
         a.hacc[3 * pi + 1] = A1;
         a.hacc[3 * pi + 2] = A2;
@@ -776,7 +863,7 @@ template <int KT> __global__ __launch_bounds__(256, 4) void sph_hydro_kernel(con
         sn += __shfl_xor(sn, off);
     if(lane == 0 && nint_total)
         atomicAdd(nint_total, (unsigned long long) sn);
-    if(nint_total) { /* diagnostics behind SHQ_SPH_DEBUG: [1] nodes/wave [2] candidates/wave [3] pairs (lanes) [4] flush rounds/wave */
+    if(MODE == 0 && nint_total) { /* diagnostics behind SHQ_SPH_DEBUG: [1] nodes/wave [2] candidates/wave [3] pairs (lanes) [4] flush rounds/wave */
         if(lane == 0) {
             atomicAdd(nint_total + 1, (unsigned long long) dbgc[0]);
             atomicAdd(nint_total + 2, (unsigned long long) dbgc[1]);
@@ -836,8 +923,7 @@ SphDev make_dev(shq_context *ctx)
     a.npool = (int) ctx->numnodes;
     a.posm_leaf = ctx->posm_leaf.ptr;
     a.velp_leaf = ctx->velp_leaf.ptr;
-    a.hydC_leaf = ctx->hydC_leaf.ptr;
-    a.hydD_leaf = ctx->hydD_leaf.ptr;
+    a.hydrec_leaf = reinterpret_cast<const HydRec *>(ctx->hydrec_leaf.ptr);
     a.hsml_leaf = ctx->hsml_leaf.ptr;
     a.flag_leaf = ctx->flag_leaf.ptr;
     a.posm = ctx->posm.ptr;
@@ -877,8 +963,7 @@ int shq_sph_prepare(shq_context *ctx, const shq_kick_factors *kf, const shq_hydr
     SHQ_TRY(ctx->hydD.reserve(n > 0 ? n : 1));
     const long long nl = ctx->ntreeparts + SHQ_NMAXCHILD;
     SHQ_TRY(ctx->velp_leaf.reserve(nl));
-    SHQ_TRY(ctx->hydC_leaf.reserve(nl));
-    SHQ_TRY(ctx->hydD_leaf.reserve(nl));
+    SHQ_TRY(ctx->hydrec_leaf.reserve(nl * sizeof(HydRec) + 128));
     SHQ_TRY(ctx->hsml_leaf.reserve(nl));
     SHQ_TRY(ctx->flag_leaf.reserve(nl));
     if(n == 0)
@@ -914,33 +999,101 @@ int shq_sph_prepare(shq_context *ctx, const shq_kick_factors *kf, const shq_hydr
     sph_predict_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(a);
     sph_gather_leaf_kernel<<<dim3(nblk(nl)), dim3(256), 0, ctx->stream>>>(
         nl, ctx->leaf_pidx.ptr, ctx->velp.ptr, hp ? ctx->hydC.ptr : nullptr, hp ? ctx->hydD.ptr : nullptr, ctx->hsml.ptr,
-        ctx->pflags.ptr, ctx->g_delaytime.ptr, ctx->velp_leaf.ptr, hp ? ctx->hydC_leaf.ptr : nullptr,
-        hp ? ctx->hydD_leaf.ptr : nullptr, ctx->hsml_leaf.ptr, ctx->flag_leaf.ptr);
+        ctx->pflags.ptr, ctx->g_delaytime.ptr, ctx->velp_leaf.ptr, hp ? reinterpret_cast<HydRec *>(ctx->hydrec_leaf.ptr) : nullptr,
+        ctx->hsml_leaf.ptr, ctx->flag_leaf.ptr);
     SHQ_HIP(hipGetLastError());
     return SHQ_OK;
 }
 
-/* neighbour-list scratch: one NL_CAP x 64 region per wave of the persistent grid */
+/* ---- launch: two kernels per chunk of targets + redo of overflowed waves ---------------------------- */
+#define NL_CHUNK (1ll << 20)  /* targets per chunk: 1 Mi x NL_CAP x 4 B = 1 GB of list scratch */
+#define NL_REDO_BLOCKS 1024
+
+/* waves of the chunk whose lists overflowed: append their targets to the redo queue */
+__global__ void sph_collect_redo_kernel(const int32_t *__restrict__ counts, const int32_t *__restrict__ queue, long long nq, int32_t *redo,
+                                        long long *nredo)
+{
+    const long long w = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(w * 64 >= nq || counts[w * 64] >= 0)
+        return;
+    const long long first = w * 64, cnt = (nq - first < 64) ? nq - first : 64;
+    const long long at = (long long) atomicAdd((unsigned long long *) nredo, (unsigned long long) cnt);
+    for(long long k = 0; k < cnt; k++)
+        redo[at + k] = queue ? queue[first + k] : (int32_t) (first + k);
+}
+
+static long long nl_chunk_waves(long long nq)
+{
+    const long long chunk = nq < NL_CHUNK ? nq : NL_CHUNK;
+    return ((chunk + 255) / 256) * 4;
+}
+
+/* list scratch: one region per wave of a chunk, followed by one per wave of the fused redo kernel */
 static int reserve_nlist(shq_context *ctx, long long nq)
 {
-    const long long ntasks = (nq + 255) / 256;
-    const long long grid = ntasks < NL_MAXBLOCKS ? ntasks : NL_MAXBLOCKS;
-    return ctx->s_nlist.reserve((size_t) (grid > 0 ? grid : 1) * 4 * NL_CAP * 64);
+    const long long waves = nl_chunk_waves(nq) + NL_REDO_BLOCKS * 4;
+    SHQ_TRY(ctx->s_nlist.reserve((size_t) waves * NL_CAP * 64));
+    SHQ_TRY(ctx->s_ncount.reserve((size_t) (nl_chunk_waves(nq) + 4) * 64));
+    SHQ_TRY(ctx->s_redo.reserve((size_t) (nq > 0 ? nq : 1)));
+    return SHQ_OK;
+}
+
+/* Runs walk<1> and eval<2> over [q, q + nq) in chunks, then the fused kernel <0> over the waves whose
+ * lists overflowed (their number is only known on the device: the fused kernel reads it there). */
+template <class LaunchW, class LaunchP, class LaunchF>
+static int launch_two_kernel(shq_context *ctx, const int32_t *q, long long nq, long long nq_reserved, LaunchW &&walk, LaunchP &&eval,
+                             LaunchF &&fused)
+{
+    long long *d_nredo = ctx->s_counters.ptr + 6;
+    SHQ_HIP(hipMemsetAsync(d_nredo, 0, sizeof(long long), ctx->stream));
+    int32_t *lists = ctx->s_nlist.ptr;
+    int32_t *fused_lists = ctx->s_nlist.ptr + (size_t) nl_chunk_waves(nq_reserved) * NL_CAP * 64;
+    SHQ_CHECK(q || nq <= NL_CHUNK, SHQ_ERR_INVALID, "SPH walk: more than %lld targets need an explicit queue", (long long) NL_CHUNK);
+    for(long long off = 0; off < nq; off += NL_CHUNK) {
+        const long long m = (nq - off < NL_CHUNK) ? nq - off : NL_CHUNK;
+        const long long ntasks = (m + 255) / 256;
+        const int32_t *qc = q ? q + off : nullptr;
+        walk((unsigned) ntasks, qc, m, ntasks, lists, ctx->s_ncount.ptr);
+        eval((unsigned) ntasks, qc, m, ntasks, lists, ctx->s_ncount.ptr);
+        sph_collect_redo_kernel<<<dim3(nblk((m + 63) / 64)), dim3(256), 0, ctx->stream>>>(ctx->s_ncount.ptr, qc, m, ctx->s_redo.ptr, d_nredo);
+    }
+    fused((unsigned) NL_REDO_BLOCKS, ctx->s_redo.ptr, fused_lists, d_nredo);
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
 }
 
 template <int KT>
-static void launch_density(shq_context *ctx, const SphDev &a, const int32_t *q, long long nq, int wd, unsigned long long *nint)
+static int launch_density(shq_context *ctx, const SphDev &a, const int32_t *q, long long nq, long long nq_reserved, int wd,
+                          unsigned long long *nint)
 {
-    const long long ntasks = (nq + 255) / 256;
-    const unsigned grid = (unsigned) (ntasks < NL_MAXBLOCKS ? ntasks : NL_MAXBLOCKS);
-    sph_density_kernel<KT><<<dim3(grid), dim3(256), 0, ctx->stream>>>(a, q, nq, wd, nint, ctx->s_nlist.ptr, ntasks);
+    hipStream_t st = ctx->stream;
+    return launch_two_kernel(
+        ctx, q, nq, nq_reserved,
+        [&](unsigned grid, const int32_t *qc, long long m, long long ntasks, int32_t *lists, int32_t *counts) {
+            sph_density_kernel<KT, 1><<<dim3(grid), dim3(256), 0, st>>>(a, qc, m, wd, nint, lists, ntasks, counts, nullptr);
+        },
+        [&](unsigned grid, const int32_t *qc, long long m, long long ntasks, int32_t *lists, int32_t *counts) {
+            sph_density_kernel<KT, 2><<<dim3(grid), dim3(256), 0, st>>>(a, qc, m, wd, nint, lists, ntasks, counts, nullptr);
+        },
+        [&](unsigned grid, const int32_t *redo, int32_t *lists, const long long *d_nredo) {
+            sph_density_kernel<KT, 0><<<dim3(grid), dim3(256), 0, st>>>(a, redo, 0, wd, nint, lists, 0, nullptr, d_nredo);
+        });
 }
 template <int KT>
-static void launch_hydro(shq_context *ctx, const SphDev &a, const int32_t *q, long long nq, const HydroConst &hc, unsigned long long *nint)
+static int launch_hydro(shq_context *ctx, const SphDev &a, const int32_t *q, long long nq, const HydroConst &hc, unsigned long long *nint)
 {
-    const long long ntasks = (nq + 255) / 256;
-    const unsigned grid = (unsigned) (ntasks < NL_MAXBLOCKS ? ntasks : NL_MAXBLOCKS);
-    sph_hydro_kernel<KT><<<dim3(grid), dim3(256), 0, ctx->stream>>>(a, q, nq, hc, nint, ctx->s_nlist.ptr, ntasks);
+    hipStream_t st = ctx->stream;
+    return launch_two_kernel(
+        ctx, q, nq, nq,
+        [&](unsigned grid, const int32_t *qc, long long m, long long ntasks, int32_t *lists, int32_t *counts) {
+            sph_hydro_kernel<KT, 1><<<dim3(grid), dim3(256), 0, st>>>(a, qc, m, hc, nint, lists, ntasks, counts, nullptr);
+        },
+        [&](unsigned grid, const int32_t *qc, long long m, long long ntasks, int32_t *lists, int32_t *counts) {
+            sph_hydro_kernel<KT, 2><<<dim3(grid), dim3(256), 0, st>>>(a, qc, m, hc, nint, lists, ntasks, counts, nullptr);
+        },
+        [&](unsigned grid, const int32_t *redo, int32_t *lists, const long long *d_nredo) {
+            sph_hydro_kernel<KT, 0><<<dim3(grid), dim3(256), 0, st>>>(a, redo, 0, hc, nint, lists, 0, nullptr, d_nredo);
+        });
 }
 
 /* Device-resident density(): queue = d_queue[0..nq) of particle indices (already filtered by
@@ -996,9 +1149,9 @@ int shq_sph_density_device(shq_context *ctx, const shq_density_params *p, const 
     while(true) {
         if(size > 0) {
             switch(p->DensityKernelType) {
-            case 1: launch_density<1>(ctx, a, cur, size, p->WindsDecouple, nint); break;
-            case 2: launch_density<2>(ctx, a, cur, size, p->WindsDecouple, nint); break;
-            default: launch_density<4>(ctx, a, cur, size, p->WindsDecouple, nint); break;
+            case 1: SHQ_TRY(launch_density<1>(ctx, a, cur, size, nq, p->WindsDecouple, nint)); break;
+            case 2: SHQ_TRY(launch_density<2>(ctx, a, cur, size, nq, p->WindsDecouple, nint)); break;
+            default: SHQ_TRY(launch_density<4>(ctx, a, cur, size, nq, p->WindsDecouple, nint)); break;
             }
             sph_density_post_kernel<<<dim3(nblk(size)), dim3(256), 0, ctx->stream>>>(a, cur, size, pa, ctx->s_todo.ptr);
             SHQ_HIP(hipGetLastError());
@@ -1065,9 +1218,9 @@ int shq_sph_hydro_device(shq_context *ctx, const shq_hydro_params *p, const int3
     SHQ_HIP(hipEventRecord(ctx->ev_begin[14], ctx->stream));
     if(nq > 0) {
         switch(p->DensityKernelType) {
-        case 1: launch_hydro<1>(ctx, a, d_queue, nq, hc, nint); break;
-        case 2: launch_hydro<2>(ctx, a, d_queue, nq, hc, nint); break;
-        default: launch_hydro<4>(ctx, a, d_queue, nq, hc, nint); break;
+        case 1: SHQ_TRY(launch_hydro<1>(ctx, a, d_queue, nq, hc, nint)); break;
+        case 2: SHQ_TRY(launch_hydro<2>(ctx, a, d_queue, nq, hc, nint)); break;
+        default: SHQ_TRY(launch_hydro<4>(ctx, a, d_queue, nq, hc, nint)); break;
         }
         sph_hydro_post_kernel<<<dim3(nblk(nq)), dim3(256), 0, ctx->stream>>>(a, d_queue, nq, ctx->g_density.ptr, ctx->g_delaytime.ptr,
                                                                             p->hubble_a2, p->atime, p->WindSpeed, p->WindFreeTravelDensThresh);
