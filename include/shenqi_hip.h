@@ -364,6 +364,16 @@ int shq_pm_download(shq_context *ctx, double (*gravpm)[3], double *pm_potential)
 /* HIP-event durations (ms) of the last shq_pm_run's phases: [0] zero+deposit+convert, [1] r2c,
  * [2] potential transfer, [3] c2r, [4] readout, [5] total. Synchronises. */
 int shq_pm_phase_ms(shq_context *ctx, double ms[6]);
+/* Power spectrum of the PM density, the side product of potential_transfer (measure_power_spectrum /
+ * powerspectrum_add_mode, libgadget/gravpm.cpp:323-376, :430).  After shq_pm_measure_power(ctx, 1) every PM
+ * run (shq_pm_run / shq_pm_force) also accumulates, per logarithmic k bin (size = Nmesh bins, bin =
+ * floor((size-1) / log(sqrt(3) Nmesh / 2) * log(k2) / 2)): power[i] += w |delta_k|^2 / (sinc^2 ...)^2,
+ * kk[i] += w |k| (mesh units), nmodes[i] += w, and norm = |delta_0|^2 — the sums pm->ps holds before
+ * powerspectrum_sum (powerspectrum.cpp:53-88), which the caller applies (MPI reduction, normalisation, units).
+ * Costs one extra pass pair per PM run (the fused X pass never materialises the spectrum), so it is off
+ * by default.  Single-GPU PM only. */
+int shq_pm_measure_power(shq_context *ctx, int enable);
+int shq_pm_download_power(shq_context *ctx, int size, double *kk, double *power, int64_t *nmodes, double *norm);
 int shq_pm_set_debug(shq_context *ctx, int keep_meshes);
 int shq_pm_download_mesh(shq_context *ctx, int which /*0 density,1 potential*/, double *mesh);
 

@@ -194,6 +194,10 @@ hip.shq_tree_build.argtypes = [_vp, C.c_double, C.c_int, _vp, C.c_int64, C.POINT
 hip.shq_tree_build.restype = C.c_int
 hip.shq_tree_download.argtypes = [_vp, C.c_int64, _vp, C.c_int64, _vp, C.POINTER(C.c_int64)]
 hip.shq_tree_download.restype = C.c_int
+hip.shq_pm_measure_power.argtypes = [_vp, C.c_int]
+hip.shq_pm_measure_power.restype = C.c_int
+hip.shq_pm_download_power.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
+hip.shq_pm_download_power.restype = C.c_int
 hip.shq_dynamics_upload.argtypes = [_vp, C.POINTER(PartView)]
 hip.shq_dynamics_upload.restype = C.c_int
 hip.shq_drift.argtypes = [_vp, C.c_double, C.c_double, _vp]

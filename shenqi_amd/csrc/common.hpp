@@ -251,6 +251,11 @@ struct shq_context {
     double mass_sum = 0;
     DevBuf<float> gravtab;     /* [2][512] window table */
     bool have_pm_result = false;
+    bool pm_measure_power = false; /* shq_pm_measure_power: accumulate P(k) during the next PM runs */
+    bool have_power = false;
+    int ps_nbins = 0, ps_bintab_n = 0;
+    DevBuf<double> ps_sums;    /* [nbins] power, [nbins] kk, [nbins] modes (u64), norm */
+    DevBuf<int32_t> ps_bintab; /* bin of every k2 */
 
     shq_walk_stats last_stats = {};
     int walk_variant = 3;      /* SHQ_WALK_VARIANT: 0 prefetch+leaf4, 1 prefetch+leaf2, 2 leaf4, 3 leaf2 (fastest: no SGPR spills) */

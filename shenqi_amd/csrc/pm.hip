@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -195,7 +196,7 @@ __global__ void pm_convert_kernel(double *mesh, size_t n, double inv_scale)
 }
 
 /* potential_transfer, gravpm.cpp:378-444, on the [x][y][z'] half spectrum */
-__global__ __launch_bounds__(256) void pm_green_kernel(double2 *cmesh, int N, int Nc, const double *__restrict__ sinctab,
+__global__ __launch_bounds__(256) void pm_green_kernel(double2 *cmesh, int N, int Nc, int zpc, const double *__restrict__ sinctab,
                                                        double asmth2, double pot_factor)
 {
     const size_t total = (size_t) N * N * Nc;
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(256) void pm_green_kernel(double2 *cmesh, int N, in
         return;
     const int z = (int) (ip % Nc);
     const size_t xy = ip / Nc;
+    ip = xy * (size_t) zpc + z; /* complex pitch of the half spectrum */
     const int y = (int) (xy % N);
     const int x = (int) (xy / N);
     const int kx = x <= N / 2 ? x : x - N; /* petapm_mesh_to_k, petapm.cpp:159-162 */
@@ -401,6 +403,84 @@ static int pm_prepare(shq_context *ctx, int N)
     return SHQ_OK;
 }
 
+namespace {
+
+/* powerspectrum_add_mode (libgadget/gravpm.cpp:323-356) through measure_power_spectrum / potential_transfer
+ * (:360-376, :430): every mode of the density half spectrum adds w |delta_k|^2 f^2 (f = the CIC
+ * deconvolution, w = 1 on the kz = 0 and Nmesh/2 planes, else 2), w and w |k| to bin
+ * floor(binsperunit log(k2) / 2); the zero mode sets Norm.  The bin of every k2 comes from a table made on
+ * the host with the reference's expression, so modes land in exactly the bins the reference puts them in.
+ * Each workgroup histograms in LDS and flushes with one atomic per non-empty bin. */
+__global__ __launch_bounds__(256) void pm_power_kernel(const double2 *__restrict__ cmesh, int N, int Nc, int zpc, const double *__restrict__ sinctab,
+                                                       const int32_t *__restrict__ bintab, int nbins, double *power, double *kk,
+                                                       unsigned long long *nmodes, double *norm)
+{
+    extern __shared__ double hist[]; /* [3][nbins]: power, kk, modes */
+    for(int i = threadIdx.x; i < 3 * nbins; i += blockDim.x)
+        hist[i] = 0;
+    __syncthreads();
+    const size_t total = (size_t) N * N * Nc;
+    for(size_t ip = (size_t) blockIdx.x * blockDim.x + threadIdx.x; ip < total; ip += (size_t) gridDim.x * blockDim.x) {
+        const int z = (int) (ip % Nc);
+        const size_t xy = ip / Nc;
+        const int y = (int) (xy % N), x = (int) (xy / N);
+        const int kx = x <= N / 2 ? x : x - N, ky = y <= N / 2 ? y : y - N, kz = z;
+        const long long k2 = (long long) kx * kx + (long long) ky * ky + (long long) kz * kz;
+        const double2 v = cmesh[xy * (size_t) zpc + z];
+        const double m = v.x * v.x + v.y * v.y;
+        if(k2 == 0) {
+            *norm = m;
+            continue;
+        }
+        const int kint = bintab[k2];
+        if(kint >= nbins)
+            continue;
+        const double f = sinctab[x] * sinctab[y] * sinctab[z];
+        const double w = (kz == 0 || kz == N / 2) ? 1.0 : 2.0;
+        atomicAdd(&hist[kint], w * m * f * f);
+        atomicAdd(&hist[nbins + kint], w * sqrt((double) k2));
+        atomicAdd(&hist[2 * nbins + kint], w);
+    }
+    __syncthreads();
+    for(int i = threadIdx.x; i < nbins; i += blockDim.x) {
+        if(hist[2 * nbins + i] != 0) {
+            atomicAdd(&power[i], hist[i]);
+            atomicAdd(&kk[i], hist[nbins + i]);
+            atomicAdd(&nmodes[i], (unsigned long long) hist[2 * nbins + i]);
+        }
+    }
+}
+
+int pm_measure_power(shq_context *ctx, int N, int zpc)
+{
+    const int nbins = N; /* powerspectrum_alloc(pm->ps, pm->Nmesh, ...), gravpm.cpp:207 */
+    const long long k2max = 3ll * (N / 2) * (N / 2);
+    if(ctx->ps_bintab_n != N) {
+        std::vector<int32_t> tab((size_t) k2max + 1, 0);
+        const double binsperunit = (nbins - 1) / log(sqrt(3) * N / 2.0);
+        for(long long k2 = 1; k2 <= k2max; k2++)
+            tab[k2] = (int32_t) floor(binsperunit * log((double) k2) / 2.);
+        SHQ_TRY(ctx->ps_bintab.reserve(tab.size()));
+        SHQ_HIP(hipMemcpy(ctx->ps_bintab.ptr, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice));
+        ctx->ps_bintab_n = N;
+    }
+    SHQ_TRY(ctx->ps_sums.reserve(3 * (size_t) nbins + 1));
+    SHQ_HIP(hipMemsetAsync(ctx->ps_sums.ptr, 0, sizeof(double) * (3 * (size_t) nbins + 1), ctx->stream));
+    double *power = ctx->ps_sums.ptr, *kk = power + nbins, *norm = power + 3 * nbins;
+    unsigned long long *nmodes = reinterpret_cast<unsigned long long *>(power + 2 * nbins);
+    const size_t lds = sizeof(double) * 3 * nbins;
+    if(lds > 48 * 1024)
+        SHQ_HIP(hipFuncSetAttribute((const void *) pm_power_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    pm_power_kernel<<<dim3(2048), dim3(256), lds, ctx->stream>>>((const double2 *) ctx->mesh.ptr, N, N / 2 + 1, zpc, ctx->sinctab.ptr,
+                                                                ctx->ps_bintab.ptr, nbins, power, kk, nmodes, norm);
+    SHQ_HIP(hipGetLastError());
+    ctx->ps_nbins = nbins;
+    ctx->have_power = true;
+    return SHQ_OK;
+}
+
+} // namespace
+
 int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
 {
     SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "pm: particles must be uploaded first");
@@ -430,7 +510,20 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
         pm_repitch_kernel<<<dim3((unsigned) ((dense + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
             ctx->mesh.ptr, ctx->dbg_rho.ptr, (size_t) N * N, N, zp, N, 1, 1.0 / scale);
     }
-    if(ctx->pm_custom_fft) {
+    if(ctx->pm_custom_fft && ctx->pm_measure_power) {
+        /* P(k) is taken from the density spectrum, which the fused X pass never writes out: when it is
+         * wanted the forward and inverse transforms run separately (6 passes + 2 sweeps instead of 5) */
+        SHQ_HIP(hipEventRecord(ctx->ev_begin[9], ctx->stream));
+        SHQ_TRY(shq_fft3d_run(ctx, ctx->mesh.ptr, N, zp, 0, true, 1.0 / scale, ctx->sinctab.ptr, asmth2, pot_factor));
+        SHQ_HIP(hipEventRecord(ctx->ev_begin[10], ctx->stream));
+        SHQ_TRY(pm_measure_power(ctx, N, zp / 2));
+        const size_t tot = (size_t) N * N * Nc;
+        pm_green_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+            (double2 *) ctx->mesh.ptr, N, Nc, zp / 2, ctx->sinctab.ptr, asmth2, pot_factor);
+        SHQ_HIP(hipEventRecord(ctx->ev_begin[11], ctx->stream));
+        SHQ_TRY(shq_fft3d_run(ctx, ctx->mesh.ptr, N, zp, 1, false, 1.0, ctx->sinctab.ptr, asmth2, pot_factor));
+        SHQ_HIP(hipEventRecord(ctx->ev_begin[12], ctx->stream));
+    } else if(ctx->pm_custom_fft) {
         /* five fused passes: Z fwd (+ int64 -> f64), Y fwd, X fwd + potential_transfer + X inv, Y inv, Z inv */
         SHQ_HIP(hipEventRecord(ctx->ev_begin[9], ctx->stream));
         SHQ_TRY(shq_fft3d_run(ctx, ctx->mesh.ptr, N, zp, 2, true, 1.0 / scale, ctx->sinctab.ptr, asmth2, pot_factor));
@@ -446,8 +539,10 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
         SHQ_HIP(hipEventRecord(ctx->ev_begin[10], ctx->stream));
         {
             const size_t tot = (size_t) N * N * Nc;
+            if(ctx->pm_measure_power)
+                SHQ_TRY(pm_measure_power(ctx, N, zp / 2));
             pm_green_kernel<<<dim3((unsigned) ((tot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-                (double2 *) ctx->mesh.ptr, N, Nc, ctx->sinctab.ptr, asmth2, pot_factor);
+                (double2 *) ctx->mesh.ptr, N, Nc, zp / 2, ctx->sinctab.ptr, asmth2, pot_factor);
         }
         SHQ_HIP(hipEventRecord(ctx->ev_begin[11], ctx->stream));
         r = hipfftExecZ2D(ctx->plan_c2r, (hipfftDoubleComplex *) ctx->mesh.ptr, (hipfftDoubleReal *) ctx->mesh.ptr);
@@ -467,6 +562,35 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
     SHQ_HIP(hipGetLastError());
     SHQ_HIP(hipEventRecord(ctx->ev_begin[13], ctx->stream));
     ctx->have_pm_result = true;
+    return SHQ_OK;
+}
+
+extern "C" int shq_pm_measure_power(shq_context *ctx, int enable)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    ctx->pm_measure_power = enable != 0;
+    if(!enable)
+        ctx->have_power = false;
+    return SHQ_OK;
+}
+
+extern "C" int shq_pm_download_power(shq_context *ctx, int size, double *kk, double *power, int64_t *nmodes, double *norm)
+{
+    SHQ_CHECK(ctx && kk && power && nmodes && norm, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_power && ctx->have_pm_result, SHQ_ERR_STATE, "pm_download_power: enable shq_pm_measure_power before the PM run");
+    SHQ_CHECK(size == ctx->ps_nbins, SHQ_ERR_INVALID, "pm_download_power: size %d, the spectrum has %d bins (= Nmesh)", size, ctx->ps_nbins);
+    const int nb = ctx->ps_nbins;
+    std::vector<double> h(3 * (size_t) nb + 1);
+    SHQ_HIP(hipMemcpyAsync(h.data(), ctx->ps_sums.ptr, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    for(int i = 0; i < nb; i++) {
+        power[i] = h[i];
+        kk[i] = h[nb + i];
+        unsigned long long c;
+        memcpy(&c, &h[2 * (size_t) nb + i], sizeof(c));
+        nmodes[i] = (int64_t) c;
+    }
+    *norm = h[3 * (size_t) nb];
     return SHQ_OK;
 }
 

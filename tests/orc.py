@@ -191,3 +191,36 @@ def boost_mt19937_uniform(seed, n, skip=0):
     rs.set_state(("MT19937", mt.astype(np.uint32), 624))
     raw = rs.randint(0, 2**32, size=skip + n, dtype=np.uint64)  # one tempered 32-bit output each
     return raw[skip:].astype(np.float64) / 4294967296.0
+
+
+def power_spectrum(rho, Nmesh):
+    """numpy restatement of what potential_transfer leaves in pm->ps for the density mesh `rho`
+    (measure_power_spectrum / powerspectrum_add_mode, libgadget/gravpm.cpp:323-376, :430; bins as
+    powerspectrum_alloc(pm->ps, pm->Nmesh, ...), gravpm.cpp:207): raw sums before powerspectrum_sum.
+    Returns kk, power, nmodes (arrays of Nmesh bins) and norm."""
+    N = int(Nmesh)
+    dk = np.fft.rfftn(rho)                      # unnormalised forward transform, like petapm_fft_r2c
+    k1 = np.fft.fftfreq(N, 1.0 / N).astype(np.int64)          # petapm_mesh_to_k: 0..N/2, -(N/2-1)..-1
+    k1[N // 2] = N // 2
+    kx, ky, kz = np.meshgrid(k1, k1, np.arange(N // 2 + 1, dtype=np.int64), indexing="ij")
+    k2 = kx * kx + ky * ky + kz * kz
+    m = dk.real**2 + dk.imag**2
+    norm = float(m[0, 0, 0])
+
+    def invsinc2(k):
+        t = k * np.pi / N
+        s = np.where(k == 0, 1.0, np.sin(t) / np.where(t == 0, 1.0, t))
+        return 1.0 / (s * s)
+
+    f = invsinc2(kx) * invsinc2(ky) * invsinc2(kz)
+    size = N
+    binsperunit = (size - 1) / np.log(np.sqrt(3) * N / 2.0)
+    sel = k2 > 0
+    kint = np.floor(binsperunit * np.log(k2[sel].astype(np.float64)) / 2.0).astype(np.int64)
+    ok = kint < size
+    w = np.where((kz[sel] == 0) | (kz[sel] == N // 2), 1, 2)[ok]
+    kint = kint[ok]
+    power = np.bincount(kint, weights=(w * m[sel][ok] * f[sel][ok] ** 2), minlength=size)
+    kk = np.bincount(kint, weights=w * np.sqrt(k2[sel][ok].astype(np.float64)), minlength=size)
+    nmodes = np.bincount(kint, weights=w, minlength=size).astype(np.int64)
+    return kk, power, nmodes, norm

@@ -250,3 +250,35 @@ def test_reference_gate_force_vs_direct_gpu(ctx, kind):
     (meanerr, maxerr), st = _do_force_test(ctx, pos)
     assert maxerr < 3 * 0.002                   # tests/test_gravity.cpp:165-166
     assert meanerr < 0.8 * 0.002
+
+
+@pytest.mark.parametrize("nmesh", [48, 40])
+def test_pm_power_spectrum(ctx, nmesh):
+    """P(k) accumulated during the PM run (powerspectrum_add_mode, gravpm.cpp:323-356) against the numpy
+    restatement applied to the oracle's density mesh; also for a mesh size without a bespoke FFT (40: rocFFT
+    path).  Forces must not depend on whether the spectrum is measured."""
+    n = 16**3
+    pos = sq.synth_positions("cluster", n, L=cm.BOX)
+    pman = cm.make_partmanager(pos)
+    mass = pman.Base["Mass"]
+    pmp = sq.PMParams(nmesh, 0, cm.BOX, 1.5, cm.G)
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
+    g0 = np.zeros((n, 3)); p0 = np.zeros(n)
+    capi.check(capi.hip.shq_pm_download(ctx.h, capi.ptr(g0), capi.ptr(p0)))
+    capi.check(capi.hip.shq_pm_measure_power(ctx.h, 1))
+    capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
+    g1 = np.zeros((n, 3)); p1 = np.zeros(n)
+    capi.check(capi.hip.shq_pm_download(ctx.h, capi.ptr(g1), capi.ptr(p1)))
+    kk = np.zeros(nmesh); power = np.zeros(nmesh); nmodes = np.zeros(nmesh, dtype=np.int64); norm = C.c_double()
+    capi.check(capi.hip.shq_pm_download_power(ctx.h, nmesh, capi.ptr(kk), capi.ptr(power), capi.ptr(nmodes), C.byref(norm)))
+    capi.check(capi.hip.shq_pm_measure_power(ctx.h, 0))
+    _, _, rho, _ = orc.pm_force(pos, mass, nmesh, cm.BOX, 1.5, cm.G, want_mesh=True)
+    okk, opower, onmodes, onorm = orc.power_spectrum(rho, nmesh)
+    assert np.array_equal(nmodes, onmodes) and nmodes.sum() > 0
+    assert abs(norm.value - onorm) < 1e-10 * onorm and abs(onorm - float(mass.sum()) ** 2) < 1e-9 * onorm
+    assert np.abs(kk - okk).max() < 1e-10 * okk.max()
+    assert np.abs(power - opower).max() < 1e-9 * opower.max()
+    # the separate forward / Green / inverse passes give the forces of the fused pipeline
+    assert np.abs(g1 - g0).max() < 1e-12 * np.abs(g0).max() and np.abs(p1 - p0).max() < 1e-12 * np.abs(p0).max()
