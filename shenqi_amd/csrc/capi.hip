@@ -106,6 +106,17 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
         (void) hipEventCreate(&ctx->ev_begin[i]);
         (void) hipEventCreate(&ctx->ev_end[i]);
     }
+    int prio_lo = 0, prio_hi = 0;
+    (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if(hipStreamCreateWithPriority(&ctx->stream_pm, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+       hipEventCreateWithFlags(&ctx->ev_pm_ready, hipEventDisableTiming) != hipSuccess ||
+       hipEventCreateWithFlags(&ctx->ev_pm_done, hipEventDisableTiming) != hipSuccess) {
+        shq_set_error("creating the PM stream failed");
+        delete ctx;
+        return SHQ_ERR_DEVICE;
+    }
+    if(const char *v = getenv("SHQ_PM_OVERLAP"))
+        ctx->pm_overlap = atoi(v) != 0;
     if(const char *v = getenv("SHQ_WALK_VARIANT"))
         ctx->walk_variant = atoi(v);
     if(const char *v = getenv("SHQ_WALK_STATS"))
@@ -121,6 +132,8 @@ extern "C" void shq_shutdown(shq_context *ctx)
     if(!ctx)
         return;
     (void) hipSetDevice(ctx->device);
+    if(ctx->stream_pm)
+        (void) hipStreamSynchronize(ctx->stream_pm);
     (void) hipStreamSynchronize(ctx->stream);
     shq_pm_destroy_plans(ctx);
     ctx->posm.release(); ctx->oldacc.release(); ctx->treeacc.release(); ctx->gravpm.release();
@@ -146,12 +159,28 @@ extern "C" void shq_shutdown(shq_context *ctx)
     }
     if(ctx->own_stream)
         (void) hipStreamDestroy(ctx->stream);
+    if(ctx->stream_pm)
+        (void) hipStreamDestroy(ctx->stream_pm);
+    if(ctx->ev_pm_ready)
+        (void) hipEventDestroy(ctx->ev_pm_ready);
+    if(ctx->ev_pm_done)
+        (void) hipEventDestroy(ctx->ev_pm_done);
     delete ctx;
+}
+
+int shq_join_pm(shq_context *ctx)
+{
+    if(ctx->pm_pending) {
+        SHQ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_pm_done, 0));
+        ctx->pm_pending = false;
+    }
+    return SHQ_OK;
 }
 
 extern "C" int shq_synchronize(shq_context *ctx)
 {
     SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_TRY(shq_join_pm(ctx));
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     return SHQ_OK;
 }
@@ -189,6 +218,7 @@ extern "C" int shq_particles_upload(shq_context *ctx, const shq_part_view *parts
     SHQ_CHECK(parts->numpart == 0 || parts->base, SHQ_ERR_INVALID, "particle base is NULL");
     SHQ_CHECK(parts->off_pos != SHQ_NOFIELD && parts->off_mass != SHQ_NOFIELD, SHQ_ERR_INVALID, "particle view needs Pos and Mass");
     SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_join_pm(ctx));
     const int64_t n = parts->numpart;
     const size_t cap = (size_t) std::max<int64_t>(n, 1);
     SHQ_TRY(ctx->posm.reserve(cap));
@@ -444,6 +474,7 @@ extern "C" int shq_particles_set_device(shq_context *ctx, const void *d_posm, in
     SHQ_CHECK(ctx && (d_posm || n == 0), SHQ_ERR_INVALID, "null argument");
     SHQ_CHECK(n >= 0 && n < (1ll << 31) && nlocal >= 0 && nlocal <= n, SHQ_ERR_INVALID, "bad particle counts");
     SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_join_pm(ctx));
     const size_t cap = (size_t) std::max<int64_t>(n, 1);
     SHQ_TRY(ctx->posm.reserve(cap));
     SHQ_TRY(ctx->oldacc.reserve(cap));
@@ -561,6 +592,7 @@ extern "C" int shq_grav_refresh_oldacc(shq_context *ctx, double G)
 {
     SHQ_CHECK(ctx && G > 0, SHQ_ERR_INVALID, "bad argument");
     SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_join_pm(ctx));
     return shq_launch_oldacc(ctx, G);
 }
 
@@ -601,7 +633,25 @@ extern "C" int shq_pm_run(shq_context *ctx, const shq_pm_params *pm)
 {
     SHQ_CHECK(ctx && pm, SHQ_ERR_INVALID, "null argument");
     SHQ_HIP(hipSetDevice(ctx->device));
-    return shq_pm_execute(ctx, pm);
+    SHQ_TRY(shq_join_pm(ctx));
+    if(!ctx->pm_overlap)
+        return shq_pm_execute(ctx, pm);
+    /* The PM reads only the positions and writes only GravPM / the PM potential: it runs on its own stream
+     * behind everything queued so far, and the main stream goes on (typically with the tree walk, which is
+     * VALU bound while the PM is HBM bound).  Consumers of its results join it (shq_join_pm). */
+    SHQ_HIP(hipEventRecord(ctx->ev_pm_ready, ctx->stream));
+    SHQ_HIP(hipStreamWaitEvent(ctx->stream_pm, ctx->ev_pm_ready, 0));
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = ctx->stream_pm;
+    const int rc = shq_pm_execute(ctx, pm);
+    ctx->stream = main_stream;
+    if(rc != SHQ_OK) {
+        (void) hipStreamSynchronize(ctx->stream_pm);
+        return rc;
+    }
+    SHQ_HIP(hipEventRecord(ctx->ev_pm_done, ctx->stream_pm));
+    ctx->pm_pending = true;
+    return SHQ_OK;
 }
 
 extern "C" int shq_pm_download(shq_context *ctx, double (*gravpm)[3], double *pm_potential)
@@ -609,6 +659,7 @@ extern "C" int shq_pm_download(shq_context *ctx, double (*gravpm)[3], double *pm
     SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
     SHQ_CHECK(ctx->have_pm_result, SHQ_ERR_STATE, "pm_download before pm_run");
     SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_join_pm(ctx));
     const int64_t n = ctx->numpart;
     if(gravpm && n > 0)
         SHQ_HIP(hipMemcpyAsync(gravpm, ctx->gravpm.ptr, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -638,6 +689,7 @@ extern "C" int shq_pm_phase_ms(shq_context *ctx, double ms[6])
     SHQ_CHECK(ctx && ms, SHQ_ERR_INVALID, "null argument");
     SHQ_CHECK(ctx->have_pm_result, SHQ_ERR_STATE, "pm_phase_ms before pm_run");
     SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_join_pm(ctx));
     SHQ_HIP(hipEventSynchronize(ctx->ev_begin[13]));
     for(int i = 0; i < 5; i++) {
         float f = 0;
@@ -664,6 +716,7 @@ extern "C" int shq_pm_download_mesh(shq_context *ctx, int which, double *mesh)
     SHQ_CHECK(which == 0 || which == 1, SHQ_ERR_INVALID, "which must be 0 or 1");
     const size_t tot = (size_t) ctx->pm_nmesh * ctx->pm_nmesh * ctx->pm_nmesh;
     SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_join_pm(ctx));
     SHQ_HIP(hipMemcpyAsync(mesh, which == 0 ? ctx->dbg_rho.ptr : ctx->dbg_pot.ptr, tot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     return SHQ_OK;

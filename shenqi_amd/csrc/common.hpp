@@ -172,6 +172,15 @@ struct shq_context {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    /* SHQ_PM_OVERLAP=1: shq_pm_run works on its own (high-priority) stream so that the bandwidth-bound PM
+     * could overlap the VALU-bound walk; every entry point that reads PM results or changes PM inputs joins
+     * it first (shq_join_pm).  Off by default: measured, nothing overlaps — the walk's 7 waves x 72 VGPRs
+     * per SIMD are refilled by the next walk workgroup the moment one retires, so a PM workgroup (200+ VGPRs
+     * per wave, 61 KB LDS) never finds room until the walk has drained (its first kernel waits 49 ms). */
+    hipStream_t stream_pm = nullptr;
+    hipEvent_t ev_pm_ready = nullptr, ev_pm_done = nullptr;
+    bool pm_pending = false;
+    bool pm_overlap = false;
     hipEvent_t ev_begin[SHQ_NTIMERS] = {};
     hipEvent_t ev_end[SHQ_NTIMERS] = {};
 
@@ -267,6 +276,8 @@ struct shq_context {
     PinBuf<char> stage;
 };
 
+/* capi.hip: make the main stream wait for an outstanding asynchronous PM run */
+int shq_join_pm(shq_context *ctx);
 /* grav_walk.hip */
 int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active,
                          int64_t ntargets, int update_potential, int walk_mode);

@@ -149,6 +149,7 @@ extern "C" int shq_drift(shq_context *ctx, double ddrift, double BoxSize, const 
     SHQ_CHECK(ctx->have_parts && ctx->have_dyn, SHQ_ERR_STATE, "drift: shq_particles_upload and shq_dynamics_upload first");
     SHQ_CHECK(BoxSize > 0, SHQ_ERR_INVALID, "drift: BoxSize must be > 0");
     SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_join_pm(ctx));
     const long long n = ctx->numpart;
     Shift3 sh;
     for(int j = 0; j < 3; j++)
@@ -206,6 +207,7 @@ extern "C" int shq_kick_pm(shq_context *ctx, double Fgravkick)
     SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
     SHQ_CHECK(ctx->have_parts && ctx->have_dyn, SHQ_ERR_STATE, "kick_pm: shq_particles_upload and shq_dynamics_upload first");
     SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_join_pm(ctx));
     const long long n = ctx->numpart;
     if(n > 0) {
         kick_pm_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(n, ctx->vel.ptr, ctx->gravpm.ptr, ctx->pflags.ptr, Fgravkick);
@@ -221,6 +223,7 @@ extern "C" int shq_dynamics_download(shq_context *ctx, const shq_part_view *part
     SHQ_CHECK(ctx->have_parts && ctx->have_dyn && parts->numpart == ctx->numpart, SHQ_ERR_STATE, "dynamics_download: nothing resident for this view");
     SHQ_CHECK(parts->off_pos != SHQ_NOFIELD && parts->off_vel != SHQ_NOFIELD, SHQ_ERR_INVALID, "dynamics_download: the view needs Pos and Vel");
     SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_join_pm(ctx));
     const int64_t n = parts->numpart;
     const size_t cap = (size_t) (n > 0 ? n : 1);
     std::vector<double4> posm(cap);

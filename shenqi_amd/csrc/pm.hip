@@ -534,6 +534,7 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
         pm_convert_kernel<<<dim3(2048), dim3(threads), 0, ctx->stream>>>(ctx->mesh.ptr, padded, 1.0 / scale);
         SHQ_HIP(hipGetLastError());
         SHQ_HIP(hipEventRecord(ctx->ev_begin[9], ctx->stream));
+        hipfftSetStream(ctx->plan_r2c, ctx->stream);
         hipfftResult r = hipfftExecD2Z(ctx->plan_r2c, (hipfftDoubleReal *) ctx->mesh.ptr, (hipfftDoubleComplex *) ctx->mesh.ptr);
         SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecD2Z failed: %d", (int) r);
         SHQ_HIP(hipEventRecord(ctx->ev_begin[10], ctx->stream));
@@ -545,6 +546,7 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
                 (double2 *) ctx->mesh.ptr, N, Nc, zp / 2, ctx->sinctab.ptr, asmth2, pot_factor);
         }
         SHQ_HIP(hipEventRecord(ctx->ev_begin[11], ctx->stream));
+        hipfftSetStream(ctx->plan_c2r, ctx->stream);
         r = hipfftExecZ2D(ctx->plan_c2r, (hipfftDoubleComplex *) ctx->mesh.ptr, (hipfftDoubleReal *) ctx->mesh.ptr);
         SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecZ2D failed: %d", (int) r);
         SHQ_HIP(hipEventRecord(ctx->ev_begin[12], ctx->stream));
@@ -576,6 +578,8 @@ extern "C" int shq_pm_measure_power(shq_context *ctx, int enable)
 
 extern "C" int shq_pm_download_power(shq_context *ctx, int size, double *kk, double *power, int64_t *nmodes, double *norm)
 {
+    if(ctx)
+        SHQ_TRY(shq_join_pm(ctx));
     SHQ_CHECK(ctx && kk && power && nmodes && norm, SHQ_ERR_INVALID, "null argument");
     SHQ_CHECK(ctx->have_power && ctx->have_pm_result, SHQ_ERR_STATE, "pm_download_power: enable shq_pm_measure_power before the PM run");
     SHQ_CHECK(size == ctx->ps_nbins, SHQ_ERR_INVALID, "pm_download_power: size %d, the spectrum has %d bins (= Nmesh)", size, ctx->ps_nbins);
@@ -608,6 +612,7 @@ int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *c
     if(ctx->pm_custom_fft)
         SHQ_TRY(shq_fft3d_run(ctx, ctx->mesh.ptr, N, zp, 0, false, 1.0, ctx->sinctab.ptr, 0, 0));
     else {
+        hipfftSetStream(ctx->plan_r2c, ctx->stream);
         hipfftResult r = hipfftExecD2Z(ctx->plan_r2c, (hipfftDoubleReal *) ctx->mesh.ptr, (hipfftDoubleComplex *) ctx->mesh.ptr);
         SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecD2Z failed: %d", (int) r);
     }
@@ -633,6 +638,7 @@ int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double 
     if(ctx->pm_custom_fft)
         SHQ_TRY(shq_fft3d_run(ctx, ctx->mesh.ptr, N, zp, 1, false, 1.0, ctx->sinctab.ptr, 0, 0));
     else {
+        hipfftSetStream(ctx->plan_c2r, ctx->stream);
         hipfftResult r = hipfftExecZ2D(ctx->plan_c2r, (hipfftDoubleComplex *) ctx->mesh.ptr, (hipfftDoubleReal *) ctx->mesh.ptr);
         SHQ_CHECK(r == HIPFFT_SUCCESS, SHQ_ERR_DEVICE, "hipfftExecZ2D failed: %d", (int) r);
     }
@@ -682,6 +688,8 @@ static int check_oob(shq_context *ctx, const char *what)
 
 extern "C" int shq_pm_slab_deposit(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, void *d_mesh_i64)
 {
+    if(ctx)
+        SHQ_TRY(shq_join_pm(ctx));
     SHQ_CHECK(ctx && pm && d_mesh_i64, SHQ_ERR_INVALID, "null argument");
     SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "pm_slab_deposit: particles must be uploaded first");
     const int N = pm->Nmesh;
@@ -703,6 +711,8 @@ extern "C" int shq_pm_slab_deposit(shq_context *ctx, const shq_pm_params *pm, in
 
 extern "C" int shq_pm_slab_readout(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, const void *d_phi_ext)
 {
+    if(ctx)
+        SHQ_TRY(shq_join_pm(ctx));
     SHQ_CHECK(ctx && pm && d_phi_ext, SHQ_ERR_INVALID, "null argument");
     SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "pm_slab_readout: particles must be uploaded first");
     const int N = pm->Nmesh;
@@ -757,6 +767,8 @@ __global__ __launch_bounds__(256) void pm_green_slab_kernel(double2 *c, int N, i
 
 extern "C" int shq_pm_slab_green(shq_context *ctx, const shq_pm_params *pm, int y0, int nyl, void *d_spec)
 {
+    if(ctx)
+        SHQ_TRY(shq_join_pm(ctx));
     SHQ_CHECK(ctx && pm && d_spec, SHQ_ERR_INVALID, "null argument");
     const int N = pm->Nmesh;
     SHQ_CHECK(N >= 4 && N % 2 == 0 && nyl > 0 && y0 >= 0 && y0 + nyl <= N, SHQ_ERR_INVALID, "bad slab geometry");
