@@ -578,6 +578,9 @@ extern "C" int shq_grav_short_download(shq_context *ctx, double (*accel)[3], dou
                     fprintf(stderr, " %llu", h[k][b]);
                 fprintf(stderr, "\n");
             }
+            const double nw = (double) ((stats->ntargets + 63) / 64);
+            fprintf(stderr, "[shq] interactions in rounds of <= 8 lanes: %.1f per lane, wave max %.1f; <= 16 lanes: %.1f per lane, wave max %.1f\n",
+                    gs.lonely[0] / nw / 64., gs.lonely[1] / nw, gs.lonely[2] / nw / 64., gs.lonely[3] / nw);
         }
         float ms = 0;
         if(stats->ntargets > 0 && hipEventElapsedTime(&ms, ctx->ev_begin[SHQ_NTIMERS - 1], ctx->ev_end[SHQ_NTIMERS - 1]) == hipSuccess)

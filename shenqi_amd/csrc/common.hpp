@@ -126,6 +126,7 @@ struct GravStatsDev {
     long long max_int;
     /* SHQ_WALK_STATS=2 diagnostics: rounds by number of participating lanes (8 buckets of 8 lanes) */
     unsigned long long hist_visit[8], hist_node[8], hist_leaf[8];
+    unsigned long long lonely[4]; /* per wave: sum / max over lanes of interactions met in rounds of <= 8, <= 16 lanes */
 };
 
 /* XCD-aware block remap (bijective for any grid size): workgroups are dealt round-robin over the

@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
     int cur = a.root;
     unsigned int visited = 0, wave_applies = 0, wave_node_applies = 0;
     unsigned int hv[8] = {}, hn[8] = {}, hl[8] = {};
+    unsigned int lonely8 = 0, lonely16 = 0; /* STATS == 2: this lane's interactions in rounds of <= 8 / <= 16 lanes */
 
     NodeG nd = a.nodeG[cur];
 
@@ -207,8 +208,14 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
                 wave_applies++;
                 wave_node_applies++;
             }
-            if(STATS == 2)
-                hn[(__popcll(__ballot(accept)) - 1) >> 3 & 7]++;
+            if(STATS == 2) {
+                const int pc = __popcll(__ballot(accept));
+                hn[(pc - 1) >> 3 & 7]++;
+                if(accept && pc <= 8)
+                    lonely8++;
+                if(accept && pc <= 16)
+                    lonely16++;
+            }
             if(accept) {
                 apply_accn<POT>(tab, dx, dy, dz, r2, nd.mass, a, ax, ay, az, pot);
                 nint++;
@@ -224,8 +231,14 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
                 const int cnt = nd.count;
                 if(STATS)
                     wave_applies += cnt;
-                if(STATS == 2)
-                    hl[(__popcll(__ballot(doopen)) - 1) >> 3 & 7] += cnt;
+                if(STATS == 2) {
+                    const int pc = __popcll(__ballot(doopen));
+                    hl[(pc - 1) >> 3 & 7] += cnt;
+                    if(doopen && pc <= 8)
+                        lonely8 += cnt;
+                    if(doopen && pc <= 16)
+                        lonely16 += cnt;
+                }
                 /* leaf slots are contiguous and the array is padded by NMAXCHILD entries */
 #pragma unroll
                 for(int b = 0; b < SHQ_NMAXCHILD; b += LEAFB) {
@@ -286,6 +299,14 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
         if(STATS)
             smn += __shfl_xor(smn, off);
     }
+    unsigned int l8s = lonely8, l8m = lonely8, l16s = lonely16, l16m = lonely16;
+    if(STATS == 2)
+        for(int off = 32; off > 0; off >>= 1) {
+            l8s += __shfl_xor(l8s, off);
+            l16s += __shfl_xor(l16s, off);
+            l8m = max(l8m, (unsigned int) __shfl_xor(l8m, off));
+            l16m = max(l16m, (unsigned int) __shfl_xor(l16m, off));
+        }
     if(lane == 0 && a.stats) {
         atomicAdd(&a.stats->ninteractions, (unsigned long long) sm);
         atomicMin(&a.stats->min_int, mn);
@@ -302,6 +323,12 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
                 atomicAdd(&a.stats->hist_node[b], (unsigned long long) hn[b]);
                 atomicAdd(&a.stats->hist_leaf[b], (unsigned long long) hl[b]);
             }
+        if(STATS == 2) {
+            atomicAdd(&a.stats->lonely[0], (unsigned long long) l8s);
+            atomicAdd(&a.stats->lonely[1], (unsigned long long) l8m);
+            atomicAdd(&a.stats->lonely[2], (unsigned long long) l16s);
+            atomicAdd(&a.stats->lonely[3], (unsigned long long) l16m);
+        }
     }
 }
 
@@ -356,6 +383,8 @@ __global__ void stats_init_kernel(GravStatsDev *s)
     s->max_int = 0;
     for(int b = 0; b < 8; b++)
         s->hist_visit[b] = s->hist_node[b] = s->hist_leaf[b] = 0;
+    for(int b = 0; b < 4; b++)
+        s->lonely[b] = 0;
 }
 
 /* BH: pure Barnes-Hut opening angle (TreeUseBH, the seeding walk before any acceleration exists) as its
