@@ -245,6 +245,25 @@ int shq_grav_short_run(shq_context *ctx, const shq_grav_params *params, const in
  * ninteractions[numpart] (may be NULL). Synchronises. */
 int shq_grav_short_download(shq_context *ctx, double (*accel)[3], double *potential,
                             int64_t *ninteractions, shq_walk_stats *stats);
+/* Secondary walk: TreeWalk::ev_secondary (libgadget/treewalk2.h:618-700) with GravLocalTreeWalk::visit
+ * <TREEWALK_GHOSTS> (gravshort2.hpp:243-322).  `queries` are the imported GravTreeQuery records of other ranks'
+ * particles (binary mirror: Pos[3], NodeList[NODELISTLENGTH = 4], OldAcc; gravshort2.hpp:123-128,
+ * localtreewalk2.h:76-115); each walks the branches under the top-level nodes of its NodeList (node numbers
+ * of the uploaded tree, -1 terminated) of the context's current tree and particles.  `results` receive the raw
+ * GravTreeResult sums (Acc not multiplied by G, Potential without the self term: the exporting rank reduces and
+ * post-processes them, treewalk2.h:780-812).  Synchronous; host pointers.  With this entry point the library
+ * also serves under shenqi's own export / import machinery on multi-rank runs. */
+typedef struct shq_grav_query {
+    double Pos[3];
+    int32_t NodeList[4];
+    double OldAcc;
+} shq_grav_query;
+typedef struct shq_grav_result {
+    double Acc[3];
+    double Potential;
+} shq_grav_result;
+int shq_grav_short_secondary(shq_context *ctx, const shq_grav_params *params, const shq_grav_query *queries, int64_t nq,
+                             shq_grav_result *results, int64_t *ninteractions, int update_potential);
 /* Set the per-particle OldAcc inputs on the device from the device-resident
  * FullTreeGravAccel + GravPM of the last shq_grav_short_run / shq_pm_run
  * (grav_get_abs_accel, gravshort2.hpp:111-121). */

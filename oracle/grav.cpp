@@ -374,6 +374,75 @@ extern "C" void orc_grav_walk(const shq_node *nodes, int64_t firstnode, const do
     }
 }
 
+/* libgadget/gravshort2.hpp:227-322 GravLocalTreeWalk::visit<TREEWALK_GHOSTS>: an imported query (position and
+ * OldAcc of a particle of another rank, treewalk2.h:742-812) walks the branches hanging off the top-level
+ * nodes in its NodeList (NODELISTLENGTH = 4, -1 terminated): each branch from its start node until the walk
+ * reaches another TopLevel node (gravshort2.hpp:258-261).  Raw sums, no postprocess: the exporting rank
+ * reduces and post-processes them (ev_reduce_export_result). */
+extern "C" void orc_grav_walk_secondary(const shq_node *nodes, int64_t firstnode, const double *pos, const float *mass,
+                                        const double *qpos, const int32_t *qnodelist, const double *qoldacc, int64_t nq,
+                                        const shq_grav_params *p, double *acc_out, double *pot_out, int64_t *nint_out)
+{
+    const shq_node *N = nodes - firstnode;
+    const double rcut = p->Rcut, rcut2 = rcut * rcut, Box = p->BoxSize;
+#pragma omp parallel for schedule(dynamic, 64)
+    for(int64_t t = 0; t < nq; t++) {
+        const double *inpos = &qpos[3 * t];
+        const double aold = p->ErrTolForceAcc * qoldacc[t];
+        double acc[3] = {0, 0, 0}, pot = 0;
+        int64_t nint = 0;
+        for(int listindex = 0; listindex < 4; listindex++) {
+            int no = qnodelist[4 * t + listindex];
+            const int startno = no;
+            if(no < 0)
+                break;
+            while(no >= 0) {
+                const shq_node *nop = &N[no];
+                if(SHQ_NODE_TOPLEVEL(nop->flags) && no != startno)
+                    break;
+                double dx[3];
+                for(int k = 0; k < 3; k++)
+                    dx[k] = orc_nearest(nop->cofm[k] - inpos[k], Box);
+                const double r2 = dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2];
+                if(discard_node(nop->len, r2, nop->center, inpos, Box, rcut, rcut2)) {
+                    no = nop->sibling;
+                    continue;
+                }
+                if(!open_node(nop->len, nop->mass, r2, nop->center, inpos, Box, aold, p->TreeUseBH, p->BHOpeningAngle2)) {
+                    no = nop->sibling;
+                    orc_apply_accn(dx, r2, nop->mass, p, acc, &pot);
+                    nint++;
+                    continue;
+                }
+                const unsigned ct = SHQ_NODE_CHILDTYPE(nop->flags);
+                if(ct == SHQ_PARTICLE_NODE_TYPE) {
+                    for(int c = 0; c < nop->noccupied; c++) {
+                        const int pp = nop->suns[c];
+                        for(int k = 0; k < 3; k++)
+                            dx[k] = orc_nearest(pos[3 * (int64_t) pp + k] - inpos[k], Box);
+                        const double rr2 = dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2];
+                        orc_apply_accn(dx, rr2, mass[pp], p, acc, &pot);
+                        nint++;
+                    }
+                    no = nop->sibling;
+                    continue;
+                } else if(ct == SHQ_PSEUDO_NODE_TYPE) {
+                    no = nop->sibling;
+                    continue;
+                }
+                no = nop->suns[0];
+            }
+        }
+        acc_out[3 * t + 0] = acc[0];
+        acc_out[3 * t + 1] = acc[1];
+        acc_out[3 * t + 2] = acc[2];
+        if(pot_out)
+            pot_out[t] = pot;
+        if(nint_out)
+            nint_out[t] = nint;
+    }
+}
+
 /* libgadget/gravshort2.hpp:88-107 GravTreeOutput::postprocess */
 extern "C" void orc_grav_postprocess(const float *mass, const int32_t *targets, int64_t ntargets,
                                      const shq_grav_params *p, int update_potential, double *acc,

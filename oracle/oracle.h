@@ -37,6 +37,9 @@ int64_t orc_tree_build(const double *pos, const float *mass, const double *hsml,
 /* ---- short-range gravity (libgadget/gravshort2.hpp) ---- */
 /* Per-target stackless primary walk; acc_out[n][3], pot_out[n] raw (before postprocess),
  * nint_out[n].  oldacc = |FullTreeGravAccel+GravPM|/G per particle. targets NULL => all. */
+void orc_grav_walk_secondary(const shq_node *nodes, int64_t firstnode, const double *pos, const float *mass,
+                             const double *qpos, const int32_t *qnodelist, const double *qoldacc, int64_t nq,
+                             const shq_grav_params *p, double *acc_out, double *pot_out, int64_t *nint_out);
 void orc_grav_walk(const shq_node *nodes, int64_t firstnode, const double *pos,
                    const float *mass, const double *oldacc, const int32_t *targets,
                    int64_t ntargets, const shq_grav_params *p, double *acc_out,

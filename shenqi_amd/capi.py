@@ -194,6 +194,11 @@ hip.shq_tree_build.argtypes = [_vp, C.c_double, C.c_int, _vp, C.c_int64, C.POINT
 hip.shq_tree_build.restype = C.c_int
 hip.shq_tree_download.argtypes = [_vp, C.c_int64, _vp, C.c_int64, _vp, C.POINTER(C.c_int64)]
 hip.shq_tree_download.restype = C.c_int
+GRAV_QUERY_DTYPE = np.dtype({"names": ["Pos", "NodeList", "OldAcc"], "formats": [("<f8", 3), ("<i4", 4), "<f8"],
+                             "offsets": [0, 24, 40], "itemsize": 48})
+GRAV_RESULT_DTYPE = np.dtype({"names": ["Acc", "Potential"], "formats": [("<f8", 3), "<f8"], "offsets": [0, 24], "itemsize": 32})
+hip.shq_grav_short_secondary.argtypes = [_vp, C.POINTER(GravParams), _vp, C.c_int64, _vp, _vp, C.c_int]
+hip.shq_grav_short_secondary.restype = C.c_int
 hip.shq_pm_measure_power.argtypes = [_vp, C.c_int]
 hip.shq_pm_measure_power.restype = C.c_int
 hip.shq_pm_download_power.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]

@@ -448,6 +448,7 @@ extern "C" int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree)
         SHQ_HIP(hipStreamSynchronize(ctx->stream));
     }
     ctx->node_order = order;
+    ctx->node_rank = newidx;
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     ctx->numnodes = nn;
     ctx->firstnode = fn;
@@ -589,6 +590,76 @@ extern "C" int shq_grav_short_download(shq_context *ctx, double (*accel)[3], dou
             stats->kernel_ms = 0;
     }
     return SHQ_OK;
+}
+
+/* TreeWalk::ev_secondary (treewalk2.h:618-700) for the gravity walk: imported queries against the local tree */
+extern "C" int shq_grav_short_secondary(shq_context *ctx, const shq_grav_params *params, const shq_grav_query *queries, int64_t nq,
+                                        shq_grav_result *results, int64_t *ninteractions, int update_potential)
+{
+    SHQ_CHECK(ctx && params && (nq == 0 || (queries && results)), SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "grav_short_secondary: upload particles and tree first");
+    SHQ_CHECK(nq >= 0 && nq < (1ll << 31), SHQ_ERR_INVALID, "bad query count");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    if(nq == 0)
+        return SHQ_OK;
+    const size_t n = (size_t) nq;
+    std::vector<double4> hpos(n);
+    std::vector<double> hold(n);
+    std::vector<int32_t> hstart(4 * n);
+    const int64_t fn = ctx->firstnode, nn = ctx->numnodes;
+    const int64_t nall = ctx->node_rank.empty() ? nn : (int64_t) ctx->node_rank.size();
+    for(size_t q = 0; q < n; q++) {
+        hpos[q] = make_double4(queries[q].Pos[0], queries[q].Pos[1], queries[q].Pos[2], 0.0);
+        hold[q] = queries[q].OldAcc;
+        int32_t st[4];
+        int ns = 0;
+        for(int k = 0; k < 4 && queries[q].NodeList[k] >= 0; k++) { /* -1 terminates the list, gravshort2.hpp:249-250 */
+            const int64_t no = queries[q].NodeList[k];
+            SHQ_CHECK(no >= fn && no < fn + nall, SHQ_ERR_INVALID, "query %ld: NodeList entry %ld is not a local node", (long) q, (long) no);
+            const int32_t r = ctx->node_rank.empty() ? (int32_t) (no - fn) : ctx->node_rank[(size_t) (no - fn)];
+            SHQ_CHECK(r >= 0 && r < nn, SHQ_ERR_INVALID, "query %ld: NodeList entry %ld is not reachable from the root", (long) q, (long) no);
+            st[ns++] = r;
+        }
+        std::sort(st, st + ns); /* branches are disjoint; the wave cursor meets them in pre-order */
+        for(int k = 0; k < 4; k++)
+            hstart[4 * q + k] = k < ns ? st[k] : -1;
+    }
+    DevBuf<double4> dpos;
+    DevBuf<double> dold, dacc, dpot;
+    DevBuf<int32_t> dstart, dnint;
+    int rc = SHQ_OK;
+    auto run = [&]() -> int {
+        SHQ_TRY(dpos.reserve(n));
+        SHQ_TRY(dold.reserve(n));
+        SHQ_TRY(dacc.reserve(3 * n));
+        SHQ_TRY(dpot.reserve(n));
+        SHQ_TRY(dstart.reserve(4 * n));
+        SHQ_TRY(dnint.reserve(n));
+        SHQ_HIP(hipMemcpyAsync(dpos.ptr, hpos.data(), sizeof(double4) * n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(dold.ptr, hold.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(dstart.ptr, hstart.data(), sizeof(int32_t) * 4 * n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemsetAsync(dpot.ptr, 0, sizeof(double) * n, ctx->stream));
+        SHQ_TRY(shq_launch_grav_walk_ghosts(ctx, params, dpos.ptr, dold.ptr, dstart.ptr, nq, dacc.ptr, dpot.ptr, dnint.ptr, update_potential));
+        std::vector<double> hacc(3 * n), hpot(n);
+        std::vector<int32_t> hn(n);
+        SHQ_HIP(hipMemcpyAsync(hacc.data(), dacc.ptr, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(hpot.data(), dpot.ptr, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(hn.data(), dnint.ptr, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+        for(size_t q = 0; q < n; q++) {
+            results[q].Acc[0] = hacc[3 * q];
+            results[q].Acc[1] = hacc[3 * q + 1];
+            results[q].Acc[2] = hacc[3 * q + 2];
+            results[q].Potential = hpot[q];
+            if(ninteractions)
+                ninteractions[q] = hn[q];
+        }
+        return SHQ_OK;
+    };
+    rc = run();
+    (void) hipStreamSynchronize(ctx->stream);
+    dpos.release(); dold.release(); dacc.release(); dpot.release(); dstart.release(); dnint.release();
+    return rc;
 }
 
 extern "C" int shq_grav_refresh_oldacc(shq_context *ctx, double G)

@@ -217,6 +217,7 @@ struct shq_context {
     DevBuf<double> node_hmax;  /* mom.hmax per packed node (SPH symmetric cull) */
     DevBuf<int32_t> pfather;   /* particle -> packed index of the leaf holding it, or -1 */
     std::vector<int32_t> node_order; /* packed index -> index into the caller's nodes_base */
+    std::vector<int32_t> node_rank;  /* caller's node index -> packed index (-1: unreachable); empty = identity */
     bool have_father = false;
     TreeBuildBufs tb;
     DevBuf<int32_t> tree_targets; /* own particles in leaf order (SHQ_WALK_TREE_ORDER) */
@@ -285,6 +286,8 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
 int shq_launch_grav_postprocess(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active,
                                 int64_t ntargets, int update_potential);
 int shq_launch_oldacc(shq_context *ctx, double G);
+int shq_launch_grav_walk_ghosts(shq_context *ctx, const shq_grav_params *p, const double4 *d_qpos, const double *d_qoldacc,
+                                const int32_t *d_qstart, int64_t nq, double *d_acc, double *d_pot, int32_t *d_nint, int update_potential);
 /* pm.hip */
 int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm);
 void shq_pm_destroy_plans(shq_context *ctx);

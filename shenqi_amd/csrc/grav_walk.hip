@@ -35,6 +35,7 @@ struct WalkArgs {
     const double4 *posm_leaf;  /* leaf order */
     const double *oldacc;
     const int32_t *targets;    /* may be null */
+    const int32_t *qstart;     /* GHOSTS: [ntargets][4] packed start nodes of every query, ascending, -1 = unused */
     double *acc;               /* [N][3] by particle index */
     double *pot;
     int32_t *nint;
@@ -134,7 +135,7 @@ __device__ __forceinline__ void leaf_particle(const double4 *__restrict__ tab, c
 
 /* POT: accumulate the potential.  PREFETCH: speculative fetch of pool[cur+1].  LEAFB: leaf
  * particles fetched per batch (2 or 4).  STATS: wave-level counters for the bench. */
-template <bool POT, bool PREFETCH, int LEAFB, int STATS, bool BH>
+template <bool POT, bool PREFETCH, int LEAFB, int STATS, bool BH, bool GHOSTS = false>
 __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
 {
     __shared__ double4 tab[SHQ_NGRAVTAB];
@@ -163,6 +164,21 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
     int nint = 0, nint_node = 0;
     int mynext = valid ? a.root : -2;
     int cur = a.root;
+    /* GHOSTS (GravLocalTreeWalk::visit<TREEWALK_GHOSTS>, gravshort2.hpp:243-261): an imported query walks only
+     * the branches under the top-level nodes of its NodeList, i.e. the pre-order index ranges
+     * [start, sibling(start)).  The lane waits at the start of its next branch; the wave cursor still begins
+     * at the root and descends wherever an awake lane opens OR a lane waits further down (see below). */
+    int seg1 = -1, seg2 = -1, seg3 = -1, myend = -1;
+    if(GHOSTS) {
+        mynext = -2;
+        if(valid) {
+            const int4 st = *reinterpret_cast<const int4 *>(a.qstart + 4 * t);
+            mynext = st.x >= 0 ? st.x : -2;
+            seg1 = st.y; seg2 = st.z; seg3 = st.w;
+            if(mynext >= 0)
+                myend = a.nodeG[mynext].sibling;
+        }
+    }
     unsigned int visited = 0, wave_applies = 0, wave_node_applies = 0;
     unsigned int hv[8] = {}, hn[8] = {}, hl[8] = {};
     unsigned int lonely8 = 0, lonely16 = 0; /* STATS == 2: this lane's interactions in rounds of <= 8 / <= 16 lanes */
@@ -267,10 +283,19 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
                 mynext = nd.sibling;
             next = nd.sibling;
         } else {
-            const bool anyopen = __ballot(doopen) != 0ull;
+            bool anyopen = __ballot(doopen) != 0ull;
+            if(GHOSTS) /* a lane waits at a branch below this node: go down even if nobody opens it */
+                anyopen = anyopen || __ballot(mynext > cur && (nd.sibling < 0 || mynext < nd.sibling)) != 0ull;
             if(act)
                 mynext = doopen ? nd.child : nd.sibling;
             next = anyopen ? nd.child : nd.sibling;
+        }
+        if(GHOSTS && act && mynext == myend) { /* branch done: wait at the next one of the NodeList */
+            mynext = seg1 >= 0 ? seg1 : -2;
+            seg1 = seg2;
+            seg2 = seg3;
+            seg3 = -1;
+            myend = mynext >= 0 ? a.nodeG[mynext].sibling : -1;
         }
         next = __builtin_amdgcn_readfirstlane(next);
         if(PREFETCH && next == cur + 1)
@@ -412,33 +437,19 @@ void launch_variant(int stats, dim3 grid, dim3 block, hipStream_t stream, const 
 
 } // namespace
 
-int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets,
-                         int update_potential, int walk_mode)
+static void fill_walk_args(shq_context *ctx, const shq_grav_params *p, WalkArgs &a)
 {
-    SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "grav walk: particles and tree must be uploaded first");
-    SHQ_CHECK(walk_mode == SHQ_WALK_EXACT || walk_mode == SHQ_WALK_GROUP, SHQ_ERR_INVALID, "unknown walk_mode %d", walk_mode);
-    SHQ_CHECK(p->ForceSoftening > 0 && p->cellsize > 0 && p->dx > 0, SHQ_ERR_INVALID, "grav params: softening/cellsize/dx must be > 0");
-    SHQ_CHECK(ntargets >= 0 && ntargets <= ctx->numpart, SHQ_ERR_INVALID, "grav walk: ntargets %ld out of range", (long) ntargets);
-    SHQ_TRY(ctx->gravtab.reserve(2 * SHQ_NGRAVTAB));
-    SHQ_TRY(ctx->gstats.reserve(1));
-    SHQ_HIP(hipMemcpyAsync(ctx->gravtab.ptr, p->shortrange_table, sizeof(float) * SHQ_NGRAVTAB, hipMemcpyHostToDevice, ctx->stream));
-    SHQ_HIP(hipMemcpyAsync(ctx->gravtab.ptr + SHQ_NGRAVTAB, p->shortrange_table_potential, sizeof(float) * SHQ_NGRAVTAB,
-                           hipMemcpyHostToDevice, ctx->stream));
-    stats_init_kernel<<<1, 1, 0, ctx->stream>>>(ctx->gstats.ptr);
-    if(ntargets == 0)
-        return SHQ_OK;
-
-    WalkArgs a;
     a.nodeG = ctx->nodeG.ptr;
     a.posm = ctx->posm.ptr;
     a.posm_leaf = ctx->posm_leaf.ptr;
     a.oldacc = ctx->oldacc.ptr;
-    a.targets = d_active;
+    a.targets = nullptr;
+    a.qstart = nullptr;
     a.acc = ctx->acc.ptr;
     a.pot = ctx->pot.ptr;
     a.nint = ctx->nint.ptr;
     a.stats = ctx->gstats.ptr;
-    a.ntargets = ntargets;
+    a.ntargets = 0;
     a.root = ctx->root;
     a.Box = p->BoxSize;
     a.invBox = 1.0 / p->BoxSize;
@@ -456,6 +467,69 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     a.xcdK = (unsigned) ctx->xcd_k;
     a.tab_f = ctx->gravtab.ptr;
     a.tab_p = ctx->gravtab.ptr + SHQ_NGRAVTAB;
+}
+
+/* secondary (GHOSTS) walk over query arrays already on the device: a carries the query positions as posm, the
+ * queries' OldAcc, qstart, and the result arrays */
+int shq_launch_grav_walk_ghosts(shq_context *ctx, const shq_grav_params *p, const double4 *d_qpos, const double *d_qoldacc,
+                                const int32_t *d_qstart, int64_t nq, double *d_acc, double *d_pot, int32_t *d_nint, int update_potential)
+{
+    SHQ_CHECK(ctx->have_tree, SHQ_ERR_STATE, "secondary walk: no tree");
+    SHQ_CHECK(p->ForceSoftening > 0 && p->cellsize > 0 && p->dx > 0, SHQ_ERR_INVALID, "grav params: softening/cellsize/dx must be > 0");
+    SHQ_TRY(ctx->gravtab.reserve(2 * SHQ_NGRAVTAB));
+    SHQ_TRY(ctx->gstats.reserve(1));
+    SHQ_HIP(hipMemcpyAsync(ctx->gravtab.ptr, p->shortrange_table, sizeof(float) * SHQ_NGRAVTAB, hipMemcpyHostToDevice, ctx->stream));
+    SHQ_HIP(hipMemcpyAsync(ctx->gravtab.ptr + SHQ_NGRAVTAB, p->shortrange_table_potential, sizeof(float) * SHQ_NGRAVTAB,
+                           hipMemcpyHostToDevice, ctx->stream));
+    stats_init_kernel<<<1, 1, 0, ctx->stream>>>(ctx->gstats.ptr);
+    if(nq == 0)
+        return SHQ_OK;
+    WalkArgs a;
+    fill_walk_args(ctx, p, a);
+    a.posm = d_qpos;
+    a.oldacc = d_qoldacc;
+    a.qstart = d_qstart;
+    a.acc = d_acc;
+    a.pot = d_pot;
+    a.nint = d_nint;
+    a.ntargets = nq;
+    const long long nwaves = (nq + 63) / 64;
+    const dim3 grid((unsigned) ((nwaves + 3) / 4)), block(256);
+    if(update_potential) {
+        if(a.useBH)
+            grav_walk_exact_kernel<true, false, 2, 0, true, true><<<grid, block, 0, ctx->stream>>>(a);
+        else
+            grav_walk_exact_kernel<true, false, 2, 0, false, true><<<grid, block, 0, ctx->stream>>>(a);
+    } else {
+        if(a.useBH)
+            grav_walk_exact_kernel<false, false, 2, 0, true, true><<<grid, block, 0, ctx->stream>>>(a);
+        else
+            grav_walk_exact_kernel<false, false, 2, 0, false, true><<<grid, block, 0, ctx->stream>>>(a);
+    }
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}
+
+int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets,
+                         int update_potential, int walk_mode)
+{
+    SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "grav walk: particles and tree must be uploaded first");
+    SHQ_CHECK(walk_mode == SHQ_WALK_EXACT || walk_mode == SHQ_WALK_GROUP, SHQ_ERR_INVALID, "unknown walk_mode %d", walk_mode);
+    SHQ_CHECK(p->ForceSoftening > 0 && p->cellsize > 0 && p->dx > 0, SHQ_ERR_INVALID, "grav params: softening/cellsize/dx must be > 0");
+    SHQ_CHECK(ntargets >= 0 && ntargets <= ctx->numpart, SHQ_ERR_INVALID, "grav walk: ntargets %ld out of range", (long) ntargets);
+    SHQ_TRY(ctx->gravtab.reserve(2 * SHQ_NGRAVTAB));
+    SHQ_TRY(ctx->gstats.reserve(1));
+    SHQ_HIP(hipMemcpyAsync(ctx->gravtab.ptr, p->shortrange_table, sizeof(float) * SHQ_NGRAVTAB, hipMemcpyHostToDevice, ctx->stream));
+    SHQ_HIP(hipMemcpyAsync(ctx->gravtab.ptr + SHQ_NGRAVTAB, p->shortrange_table_potential, sizeof(float) * SHQ_NGRAVTAB,
+                           hipMemcpyHostToDevice, ctx->stream));
+    stats_init_kernel<<<1, 1, 0, ctx->stream>>>(ctx->gstats.ptr);
+    if(ntargets == 0)
+        return SHQ_OK;
+
+    WalkArgs a;
+    fill_walk_args(ctx, p, a);
+    a.targets = d_active;
+    a.ntargets = ntargets;
 
     const int threads = 256;
     const long long nwaves = (ntargets + 63) / 64;

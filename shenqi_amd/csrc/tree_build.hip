@@ -612,6 +612,7 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
     ctx->node_order.resize((size_t) nn);
     for(int j = 0; j < nn; j++)
         ctx->node_order[j] = j; /* a downloaded tree is numbered in pool order */
+    ctx->node_rank.clear();     /* identity */
     ctx->numnodes = nn;
     ctx->firstnode = np;
     ctx->root = 0;

@@ -16,6 +16,8 @@ lib.orc_tree_build.argtypes = [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_dou
 lib.orc_tree_build.restype = C.c_int64
 lib.orc_grav_walk.argtypes = [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int64, C.POINTER(GravParams), _vp, _vp, _vp]
 lib.orc_grav_walk.restype = None
+lib.orc_grav_walk_secondary.argtypes = [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.POINTER(GravParams), _vp, _vp, _vp]
+lib.orc_grav_walk_secondary.restype = None
 lib.orc_grav_postprocess.argtypes = [_vp, _vp, C.c_int64, C.POINTER(GravParams), C.c_int, _vp, _vp]
 lib.orc_grav_postprocess.restype = None
 lib.orc_apply_accn.argtypes = [_vp, C.c_double, C.c_double, C.POINTER(GravParams), _vp, _vp]
@@ -119,6 +121,20 @@ def grav_walk(nodes, firstnode, pos, mass, oldacc, gp, targets=None):
     pot = np.zeros(nt)
     nint = np.zeros(nt, dtype=np.int64)
     lib.orc_grav_walk(ptr(nodes), firstnode, ptr(pos), ptr(mass), ptr(oldacc), ptr(targets), nt, C.byref(gp), ptr(acc), ptr(pot), ptr(nint))
+    return acc, pot, nint
+
+
+def grav_walk_secondary(nodes, firstnode, pos, mass, qpos, qnodelist, qoldacc, gp):
+    """GravLocalTreeWalk::visit<TREEWALK_GHOSTS> (gravshort2.hpp:227-322) for imported queries."""
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    mass = np.ascontiguousarray(mass, dtype=np.float32)
+    qpos = np.ascontiguousarray(qpos, dtype=np.float64)
+    qnodelist = np.ascontiguousarray(qnodelist, dtype=np.int32)
+    qoldacc = np.ascontiguousarray(qoldacc, dtype=np.float64)
+    nq = len(qpos)
+    acc = np.zeros((nq, 3)); pot = np.zeros(nq); nint = np.zeros(nq, dtype=np.int64)
+    lib.orc_grav_walk_secondary(ptr(nodes), firstnode, ptr(pos), ptr(mass), ptr(qpos), ptr(qnodelist), ptr(qoldacc), nq,
+                                C.byref(gp), ptr(acc), ptr(pot), ptr(nint))
     return acc, pot, nint
 
 

@@ -282,3 +282,70 @@ def test_pm_power_spectrum(ctx, nmesh):
     assert np.abs(power - opower).max() < 1e-9 * opower.max()
     # the separate forward / Green / inverse passes give the forces of the fused pipeline
     assert np.abs(g1 - g0).max() < 1e-12 * np.abs(g0).max() and np.abs(p1 - p0).max() < 1e-12 * np.abs(p0).max()
+
+
+def test_secondary_walk_matches_oracle(ctx):
+    """shq_grav_short_secondary = visit<TREEWALK_GHOSTS> (gravshort2.hpp:243-322): imported queries (positions
+    that are not local particles) walk the branches under the top-level nodes of their NodeList.  The host tree
+    gets a two-level top tree (root, its children and grandchildren flagged TopLevel, as a domain
+    decomposition would), queries list 1-4 of the deepest top-level nodes in arbitrary order."""
+    n = 20**3
+    pos = sq.synth_positions("cluster", n, L=cm.BOX)
+    pman = cm.make_partmanager(pos)
+    tree = sq.force_tree_full(pman)
+    nodes = tree.Nodes_base          # writable view of the host tree
+    fn = tree.firstnode
+    ctype = (nodes["flags"] >> 3) & 3
+    root = nodes[0]
+    lvl1 = [s for s in root["suns"] if s >= 0] if ctype[0] == 1 else []
+    top = []
+    for c in lvl1:
+        nodes["flags"][c - fn] |= 2
+        if ctype[c - fn] == 1:
+            for g in nodes["suns"][c - fn]:
+                if g >= 0:
+                    nodes["flags"][g - fn] |= 2
+                    top.append(int(g))
+        else:
+            top.append(int(c))
+    assert len(top) >= 8
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=0)
+    sq.gravshort_set_softenings(cm.BOX / 20)
+    gp = sq.make_grav_params(cm.BOX, 1.5, 60, cm.G, cm.RHO0)
+    rng = np.random.default_rng(12)
+    nq = 3000
+    q = np.zeros(nq, dtype=capi.GRAV_QUERY_DTYPE)
+    q["Pos"] = rng.random((nq, 3)) * cm.BOX
+    q["OldAcc"] = 10 ** rng.uniform(1, 4, size=nq)
+    q["NodeList"] = -1
+    for i in range(nq):
+        k = rng.integers(1, 5)
+        q["NodeList"][i, :k] = rng.choice(top, size=k, replace=False)
+    pv, tv = pman.view(), tree.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    capi.check(capi.hip.shq_tree_upload(ctx.h, C.byref(tv)))
+    res = np.zeros(nq, dtype=capi.GRAV_RESULT_DTYPE)
+    nint = np.zeros(nq, dtype=np.int64)
+    capi.check(capi.hip.shq_grav_short_secondary(ctx.h, C.byref(gp), capi.ptr(q), nq, capi.ptr(res), capi.ptr(nint), 1))
+    # the reference visits the NodeList in the given order; the branches are disjoint, so only the summation
+    # order can differ: compare with the oracle run on the list sorted the way the device walks it
+    rank = {no: i for i, no in enumerate(cm_preorder(nodes, fn))}
+    qs = q["NodeList"].copy()
+    for i in range(nq):
+        lst = sorted([x for x in qs[i] if x >= 0], key=lambda no: rank[no])
+        qs[i] = lst + [-1] * (4 - len(lst))
+    oacc, opot, onint = orc.grav_walk_secondary(nodes, fn, pos, pman.Base["Mass"], q["Pos"], qs, q["OldAcc"], gp)
+    assert np.array_equal(nint, onint) and nint.max() > 0
+    scale = np.abs(oacc).max()
+    assert np.abs(res["Acc"] - oacc).max() < 1e-11 * scale
+    assert np.allclose(res["Potential"], opot, rtol=1e-10, atol=1e-10 * np.abs(opot).max())
+
+
+def cm_preorder(nodes, firstnode):
+    out = []
+    no = firstnode
+    while firstnode <= no < firstnode + len(nodes):
+        out.append(int(no))
+        nd = nodes[no - firstnode]
+        no = nd["suns"][0] if ((nd["flags"] >> 3) & 3) == 1 else nd["sibling"]
+    return out
