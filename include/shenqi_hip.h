@@ -416,6 +416,25 @@ int shq_particles_set_device(shq_context *ctx, const void *d_posm, int64_t n, in
 int shq_pm_slab_deposit(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, void *d_mesh_i64);
 int shq_pm_slab_green(shq_context *ctx, const shq_pm_params *pm, int y0, int nyl, void *d_spec);
 int shq_pm_slab_readout(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, const void *d_phi_ext);
+/* The same phases on the bespoke FFT passes (csrc/fft3d.hip), for mesh sizes that have them
+ * (shq_pm_slab_pitch != 0): replaces the 2-D r2c / 1-D FFT / c2r of the slab pipeline (heffte's role in
+ * petapm.cpp:281-303) and the separate convert, transpose-to-x-fastest and Green sweeps.  One buffer
+ * [nalloc][Nmesh][zp] doubles (zp = shq_pm_slab_pitch, in doubles) is in turn the int64 deposit mesh, the
+ * (y, z) half spectrum (complex pitch zp / 2) and the potential; the slab's first own plane is buffer plane
+ * `xoff` (2 ghost planes in front, 1 + 3 behind; xoff = 0 and nalloc = Nmesh for a single rank).
+ *   slab2_deposit : zero + fixed-point CIC deposit; the plane behind the slab receives the right ghost.
+ *   slab2_fft_yz  : direction 0: int64 planes -> half spectrum in (y, z) (in place, `nplanes` planes starting
+ *                   at d_planes); direction 1: back to real space.  Unscaled both ways.
+ *   slab2_xgreen  : on the y-slab [Nmesh][nyl][zp / 2] the all-to-all delivers (x slowest: the received
+ *                   blocks are used as they are), x forward, potential_transfer, x inverse in ONE pass.
+ *   slab2_readout : as readout, pitch zp, first own plane at `xoff` of `nalloc` planes. */
+int shq_pm_slab_pitch(int Nmesh);
+int shq_pm_slab2_deposit(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, int xoff, int nalloc,
+                         void *d_mesh_i64);
+int shq_pm_slab2_fft_yz(shq_context *ctx, int Nmesh, void *d_planes, int nplanes, int direction);
+int shq_pm_slab2_xgreen(shq_context *ctx, const shq_pm_params *pm, void *d_spec, int y0, int nyl);
+int shq_pm_slab2_readout(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, int xoff, int nalloc,
+                         const void *d_phi);
 /* Fixed-point deposit scale 2^e: chosen per context from the local mass sum at particle upload;
  * ranks of one job must agree on it (set it from the global mass sum) so meshes add exactly. */
 int shq_pm_get_deposit_log2scale(shq_context *ctx);

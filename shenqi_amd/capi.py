@@ -199,6 +199,16 @@ GRAV_QUERY_DTYPE = np.dtype({"names": ["Pos", "NodeList", "OldAcc"], "formats": 
 GRAV_RESULT_DTYPE = np.dtype({"names": ["Acc", "Potential"], "formats": [("<f8", 3), "<f8"], "offsets": [0, 24], "itemsize": 32})
 hip.shq_grav_short_secondary.argtypes = [_vp, C.POINTER(GravParams), _vp, C.c_int64, _vp, _vp, C.c_int]
 hip.shq_grav_short_secondary.restype = C.c_int
+hip.shq_pm_slab_pitch.argtypes = [C.c_int]
+hip.shq_pm_slab_pitch.restype = C.c_int
+hip.shq_pm_slab2_deposit.argtypes = [_vp, C.POINTER(PMParams), C.c_int, C.c_int, C.c_int, C.c_int, _vp]
+hip.shq_pm_slab2_deposit.restype = C.c_int
+hip.shq_pm_slab2_fft_yz.argtypes = [_vp, C.c_int, _vp, C.c_int, C.c_int]
+hip.shq_pm_slab2_fft_yz.restype = C.c_int
+hip.shq_pm_slab2_xgreen.argtypes = [_vp, C.POINTER(PMParams), _vp, C.c_int, C.c_int]
+hip.shq_pm_slab2_xgreen.restype = C.c_int
+hip.shq_pm_slab2_readout.argtypes = [_vp, C.POINTER(PMParams), C.c_int, C.c_int, C.c_int, C.c_int, _vp]
+hip.shq_pm_slab2_readout.restype = C.c_int
 hip.shq_pm_measure_power.argtypes = [_vp, C.c_int]
 hip.shq_pm_measure_power.restype = C.c_int
 hip.shq_pm_download_power.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]

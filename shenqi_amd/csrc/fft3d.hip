@@ -345,6 +345,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_inv(double *mesh, const int 
 struct GreenArgs {
     const double *sinctab; /* 1 / sinc^2(pi k / N) per mesh index */
     double asmth2, pot_factor;
+    int y0;                /* mesh index of outer = 0 in the X pass (y-slab of a distributed mesh) */
 };
 
 template <int N, int MODE>
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
             /* potential_transfer, gravpm.cpp:378-444, applied as the forward transform stores its last
              * stage (line index = kx, outer = y, column = z'); gax[i] = exp(-k_i^2 asmth2) sinctab[i]^2, so
              * the factor exp(-k^2 asmth2) f^2 / k^2 is a product of three table entries over k^2 */
-            const int y = outer, z0 = tile * FFT_C;
+            const int y = ga.y0 + outer, z0 = tile * FFT_C;
             const int ky = y <= N / 2 ? y : y - N;
             const double gy = gax[y] * ga.pot_factor, ky2 = (double) ky * (double) ky;
             auto green = [=](int col, int x, double2 v) {
@@ -433,17 +434,20 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
 #undef FFT_FETCH
 }
 
+/* stage 0 / 1 / 2 as shq_fft3d_run on a full cube (nslab = N).  Slab stages for a distributed mesh:
+ * 10: Z forward + Y forward on `nslab` x-planes [nslab][N][zp];  11: Y inverse + Z inverse on them;
+ * 12: X forward + potential_transfer + X inverse on a y-slab [N][nslab][zpc] (lines along the slowest axis). */
 template <int N>
-int run_n(shq_context *ctx, double *d_mesh, int zp, int stage, bool from_i64, double inv_scale, const GreenArgs &ga)
+int run_n(shq_context *ctx, double *d_mesh, int zp, int stage, bool from_i64, double inv_scale, const GreenArgs &ga, int nslab)
 {
     const double2 *W = reinterpret_cast<const double2 *>(ctx->fft_tw.ptr);
     /* FFT_C padded lines + the twiddle table + (X pass) the sinc table */
     constexpr size_t lds = sizeof(double2) * (FFT_C * (N + 1) + N) + sizeof(double) * N;
-    static_assert(((long long) N * N) % (2 * FFT_C) == 0, "rows must tile evenly");
-    const int ztot = (int) (((long long) N * N) / (2 * FFT_C));
+    static_assert(N % (2 * FFT_C) == 0, "rows must tile evenly");
+    const int ztot = (int) (((long long) nslab * N) / (2 * FFT_C)); /* row groups of the Z passes */
     const int zpc = zp / 2;
     const int ntiles = zpc / FFT_C;
-    const int stot = N * ntiles;
+    const int stot = nslab * ntiles;                                  /* tiles of a strided pass */
     double2 *cm = reinterpret_cast<double2 *>(d_mesh);
     hipStream_t s = ctx->stream;
     /* persistent grids: as many workgroups as are resident on the chip at once (LDS-limited) */
@@ -476,6 +480,25 @@ int run_n(shq_context *ctx, double *d_mesh, int zp, int stage, bool from_i64, do
     };
     const dim3 gzf = grid(ztot, res_zf), gzi = grid(ztot, res_zi), gs = grid(stot, res_s);
     const unsigned xcdk = getenv("SHQ_FFT_XCD_K") ? (unsigned) atoi(getenv("SHQ_FFT_XCD_K")) : 8u;
+    if(stage == 12) { /* lines along x of a y-slab: element stride nslab * zpc, outer = local y */
+        fft_pass_strided<N, 2><<<gs, dim3(FFT_T), lds, s>>>(cm, (long long) nslab * zpc, zpc, ntiles, stot, W, ga, xcdk);
+        SHQ_HIP(hipGetLastError());
+        return SHQ_OK;
+    }
+    if(stage == 10 || stage == 11) {
+        if(stage == 10) {
+            if(from_i64)
+                fft_pass_z_fwd<N, true><<<gzf, dim3(FFT_T), lds, s>>>(d_mesh, ztot, zp, W, inv_scale);
+            else
+                fft_pass_z_fwd<N, false><<<gzf, dim3(FFT_T), lds, s>>>(d_mesh, ztot, zp, W, 1.0);
+            fft_pass_strided<N, 0><<<gs, dim3(FFT_T), lds, s>>>(cm, zpc, (long long) N * zpc, ntiles, stot, W, ga, xcdk);
+        } else {
+            fft_pass_strided<N, 1><<<gs, dim3(FFT_T), lds, s>>>(cm, zpc, (long long) N * zpc, ntiles, stot, W, ga, xcdk);
+            fft_pass_z_inv<N><<<gzi, dim3(FFT_T), lds, s>>>(d_mesh, ztot, zp, W);
+        }
+        SHQ_HIP(hipGetLastError());
+        return SHQ_OK;
+    }
     if(stage == 0 || stage == 2) {
         if(from_i64)
             fft_pass_z_fwd<N, true><<<gzf, dim3(FFT_T), lds, s>>>(d_mesh, ztot, zp, W, inv_scale);
@@ -534,14 +557,23 @@ static int ensure_twiddles(shq_context *ctx, int N)
 int shq_fft3d_run(shq_context *ctx, double *d_mesh, int N, int zp, int stage, bool from_i64, double inv_scale,
                   const double *d_sinctab, double asmth2, double pot_factor)
 {
+    return shq_fft3d_run_slab(ctx, d_mesh, N, zp, stage, from_i64, inv_scale, d_sinctab, asmth2, pot_factor, N, 0);
+}
+
+/* nslab: x-planes (stages 10, 11) or y-rows (stage 12, starting at mesh row y0) of this rank's slab */
+int shq_fft3d_run_slab(shq_context *ctx, double *d_mesh, int N, int zp, int stage, bool from_i64, double inv_scale,
+                       const double *d_sinctab, double asmth2, double pot_factor, int nslab, int y0)
+{
     SHQ_CHECK(shq_fft3d_supported(N), SHQ_ERR_INVALID, "fft3d: unsupported mesh size %d", N);
+    SHQ_CHECK(nslab > 0 && nslab <= N && y0 >= 0 && y0 + (stage == 12 ? nslab : 0) <= N, SHQ_ERR_INVALID, "fft3d: bad slab geometry");
     SHQ_CHECK(zp >= N + 2 && zp % 8 == 0, SHQ_ERR_INVALID, "fft3d: pitch %d must be a multiple of 8 doubles and >= N+2", zp);
     SHQ_TRY(ensure_twiddles(ctx, N));
     GreenArgs ga;
     ga.sinctab = d_sinctab;
     ga.asmth2 = asmth2;
     ga.pot_factor = pot_factor;
-#define SHQ_FFT_CASE(NN) case NN: return run_n<NN>(ctx, d_mesh, zp, stage, from_i64, inv_scale, ga)
+    ga.y0 = y0;
+#define SHQ_FFT_CASE(NN) case NN: return run_n<NN>(ctx, d_mesh, zp, stage, from_i64, inv_scale, ga, nslab)
     switch(N) {
         SHQ_FFT_CASE(16); SHQ_FFT_CASE(24); SHQ_FFT_CASE(32); SHQ_FFT_CASE(48); SHQ_FFT_CASE(64); SHQ_FFT_CASE(96);
         SHQ_FFT_CASE(128); SHQ_FFT_CASE(192); SHQ_FFT_CASE(256); SHQ_FFT_CASE(384); SHQ_FFT_CASE(512); SHQ_FFT_CASE(768);

@@ -782,6 +782,91 @@ extern "C" int shq_pm_slab_green(shq_context *ctx, const shq_pm_params *pm, int 
     return SHQ_OK;
 }
 
+/* ---- slab entry points on the bespoke FFT passes (mesh pitch zp = shq_pm_slab_pitch) -----------------
+ * The x-slab of a rank lives in ONE buffer [nalloc][N][zp] that is in turn the int64 deposit mesh, the
+ * (y, z) half spectrum and the potential, with ghost planes in place: the slab's first own plane sits at
+ * buffer plane `xoff` (2 when the slab has neighbours: two potential ghost planes in front, the deposit
+ * ghost plane and three potential ghost planes behind; 0 for a single rank, nalloc = N). */
+extern "C" int shq_pm_slab_pitch(int Nmesh) { return shq_fft3d_supported(Nmesh) ? shq_fft3d_pitch(Nmesh) : 0; }
+
+extern "C" int shq_pm_slab2_deposit(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, int xoff, int nalloc,
+                                    void *d_mesh_i64)
+{
+    if(ctx)
+        SHQ_TRY(shq_join_pm(ctx));
+    SHQ_CHECK(ctx && pm && d_mesh_i64, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "pm_slab2_deposit: particles must be uploaded first");
+    const int N = pm->Nmesh;
+    SHQ_CHECK(shq_fft3d_supported(N), SHQ_ERR_INVALID, "pm_slab2: mesh size %d has no bespoke FFT", N);
+    SHQ_CHECK(nplanes > 0 && nplanes <= N && plane0 >= 0 && plane0 < N && xoff >= 0 && xoff + nplanes <= nalloc && nalloc <= N + 5,
+              SHQ_ERR_INVALID, "bad slab geometry");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(slab_sinctab(ctx, N));
+    SHQ_HIP(hipMemsetAsync(ctx->pm_oob.ptr, 0, sizeof(int), ctx->stream));
+    const int zp = shq_fft3d_pitch(N);
+    const size_t cnt = (size_t) nalloc * N * zp;
+    pm_zero_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>((unsigned long long *) d_mesh_i64, cnt);
+    const long long n = ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart;
+    /* buffer plane of mesh plane ix: (ix - (plane0 - xoff)) mod N; own planes and the right ghost must fit */
+    const int nfit = nplanes == N ? N : xoff + nplanes + 1;
+    SHQ_CHECK(nfit <= nalloc, SHQ_ERR_INVALID, "pm_slab2_deposit: no room for the deposit ghost plane");
+    if(n > 0)
+        pm_deposit_kernel<<<dim3((unsigned) ((n + DEP_CHUNK - 1) / DEP_CHUNK)), dim3(256), 0, ctx->stream>>>(
+            ctx->posm.ptr, ctx->pflags.ptr, n, (unsigned long long *) d_mesh_i64, N, zp, pm->BoxSize / N, ldexp(1.0, ctx->pm_log2scale),
+            plane0 - xoff, nfit, ctx->pm_oob.ptr);
+    SHQ_HIP(hipGetLastError());
+    return check_oob(ctx, "pm_slab2_deposit");
+}
+
+/* direction 0: int64 deposit planes -> (y, z) half spectrum (Z forward, Y forward); 1: back to real space.
+ * d_planes points at the first of `nplanes` planes of N x zp doubles. */
+extern "C" int shq_pm_slab2_fft_yz(shq_context *ctx, int Nmesh, void *d_planes, int nplanes, int direction)
+{
+    SHQ_CHECK(ctx && d_planes, SHQ_ERR_INVALID, "null argument");
+    SHQ_TRY(shq_join_pm(ctx));
+    SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(slab_sinctab(ctx, Nmesh));
+    const int zp = shq_fft3d_pitch(Nmesh);
+    return shq_fft3d_run_slab(ctx, (double *) d_planes, Nmesh, zp, direction == 0 ? 10 : 11, direction == 0,
+                              ldexp(1.0, -ctx->pm_log2scale), ctx->sinctab.ptr, 0, 0, nplanes, 0);
+}
+
+/* X forward + potential_transfer + X inverse on the y-slab [N][nyl][zp / 2] (complex) received by the transpose */
+extern "C" int shq_pm_slab2_xgreen(shq_context *ctx, const shq_pm_params *pm, void *d_spec, int y0, int nyl)
+{
+    SHQ_CHECK(ctx && pm && d_spec, SHQ_ERR_INVALID, "null argument");
+    SHQ_TRY(shq_join_pm(ctx));
+    const int N = pm->Nmesh;
+    SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(slab_sinctab(ctx, N));
+    return shq_fft3d_run_slab(ctx, (double *) d_spec, N, shq_fft3d_pitch(N), 12, false, 1.0, ctx->sinctab.ptr,
+                              pow((2 * M_PI) * pm->Asmth / N, 2), -pm->G / (M_PI * pm->BoxSize), nyl, y0);
+}
+
+extern "C" int shq_pm_slab2_readout(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, int xoff, int nalloc,
+                                    const void *d_phi)
+{
+    if(ctx)
+        SHQ_TRY(shq_join_pm(ctx));
+    SHQ_CHECK(ctx && pm && d_phi, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "pm_slab2_readout: particles must be uploaded first");
+    const int N = pm->Nmesh;
+    SHQ_CHECK(shq_fft3d_supported(N) && nplanes > 0 && nplanes <= N && plane0 >= 0 && plane0 < N && xoff >= 0 && xoff + nplanes <= nalloc,
+              SHQ_ERR_INVALID, "bad slab geometry");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(ctx->pm_oob.reserve(4));
+    SHQ_HIP(hipMemsetAsync(ctx->pm_oob.ptr, 0, sizeof(int), ctx->stream));
+    const long long n = ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart;
+    const int zp = shq_fft3d_pitch(N);
+    if(n > 0)
+        pm_readout_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(
+            ctx->posm.ptr, ctx->pflags.ptr, n, (const double *) d_phi, N, zp, pm->BoxSize / N, -(N / pm->BoxSize), ctx->gravpm.ptr,
+            ctx->pmpot.ptr, plane0 - xoff, nalloc, ctx->pm_oob.ptr);
+    SHQ_HIP(hipGetLastError());
+    ctx->have_pm_result = true;
+    return check_oob(ctx, "pm_slab2_readout");
+}
+
 extern "C" int shq_pm_get_deposit_log2scale(shq_context *ctx) { return ctx ? ctx->pm_log2scale : -1; }
 extern "C" int shq_pm_set_deposit_log2scale(shq_context *ctx, int e)
 {

@@ -21,6 +21,7 @@ The FFT stages use rocFFT through torch.fft; torch.distributed (backend "nccl" =
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -202,6 +203,49 @@ class SlabPM:
 
     def force(self):
         """Runs one PM step for the particles loaded in `ops`; results stay in ops (gravpm, potential)."""
+        if getattr(self.ops, "pitch", None) is not None and self.ops.pitch() > 0 and os.environ.get("SHQ_SLAB_TORCH_FFT", "0") != "1":
+            return self._force_bespoke()
+        return self._force_torch()
+
+    def _force_bespoke(self):
+        """The slab pipeline on the library's own FFT passes (csrc/fft3d.hip): ONE buffer [nalloc][N][zp] is the
+        int64 deposit mesh, the (y, z) half spectrum and the potential, ghost planes in place; the blocks the
+        all-to-all delivers are transformed along x as they are (x slowest), fused with the Green's function.
+        Passes over the slab: zero, deposit, Z, Y, pack | x+Green+x | unpack, Y, Z, readout."""
+        c, N, nxl, P = self.comm, self.N, self.d.nxl, self.comm.size
+        ops = self.ops
+        zp = ops.pitch()
+        zpc = zp // 2
+        xoff, nalloc = (0, N) if P == 1 else (2, nxl + 5)
+        buf = ops.mesh_buffer(nalloc, N, zp)                               # int64 [nalloc, N, zp]
+        ops.deposit2(buf, self.d.plane0, nxl, xoff, nalloc)
+        if P > 1:
+            ghost = c.shift(buf[xoff + nxl:xoff + nxl + 1].contiguous(), +1)
+            buf[xoff:xoff + 1] += ghost
+        own = buf[xoff:xoff + nxl]
+        ops.fft_yz(own, nxl, 0)
+        spec = own.view(torch.float64).view(torch.complex128)               # [nxl, N, zpc]
+        nyl = N // P
+        if P > 1:
+            send = spec.reshape(nxl, P, nyl, zpc).permute(1, 0, 2, 3).reshape(P * nxl, nyl, zpc)   # rows [dest q][x_l]
+            spec_t, _ = c.all_to_all_rows(send, [nxl] * P)                                         # [x (all)][y_l][z']
+            spec_t = spec_t.contiguous()
+        else:
+            spec_t = spec
+        ops.xgreen(spec_t, c.rank * nyl, nyl)
+        if P > 1:
+            recv, _ = c.all_to_all_rows(spec_t, self.d.widths)                                     # rows [src q][x_l]
+            spec.copy_(recv.reshape(P, nxl, nyl, zpc).permute(1, 0, 2, 3).reshape(nxl, N, zpc))
+        ops.fft_yz(own, nxl, 1)
+        phi = buf.view(torch.float64)
+        if P > 1:
+            phi[0:2] = c.shift(phi[xoff + nxl - 2:xoff + nxl].contiguous(), +1)    # my last 2 -> right rank's left ghosts
+            phi[xoff + nxl:xoff + nxl + 3] = c.shift(phi[xoff:xoff + 3].contiguous(), -1)  # my first 3 -> left rank's right ghosts
+        ops.readout2(phi, self.d.plane0, nxl, xoff, nalloc)
+
+    def _force_torch(self):
+        """The same pipeline with torch.fft (rocFFT) for mesh sizes without a bespoke transform, and on the
+        CPU stand-ins of the gloo tests."""
         c, N, nxl, P = self.comm, self.N, self.d.nxl, self.comm.size
         Nc = N // 2 + 1
         widths = self.d.widths
@@ -256,6 +300,37 @@ class GpuOps:
         capi.check(capi.hip.shq_particles_set_device(self.ctx.h, C.c_void_p(t.data_ptr()), t.shape[0], nlocal))
         self.ctx.synchronize()
         self._keep = t
+
+    # ---- phases on the bespoke FFT passes (shq_pm_slab2_*) ----
+    def pitch(self):
+        return int(capi.hip.shq_pm_slab_pitch(self.N))
+
+    def mesh_buffer(self, nalloc, N, zp):
+        key = (nalloc, N, zp)
+        if getattr(self, "_mesh_key", None) != key:
+            self._mesh = torch.empty((nalloc, N, zp), dtype=torch.int64, device=self.device)
+            self._mesh_key = key
+        return self._mesh
+
+    def _call(self, fn, *args):
+        torch.cuda.current_stream(self.device).synchronize()
+        capi.check(fn(self.ctx.h, *args))
+        self.ctx.synchronize()
+
+    def deposit2(self, buf, plane0, nxl, xoff, nalloc):
+        self._call(capi.hip.shq_pm_slab2_deposit, C.byref(self.pm), plane0, nxl, xoff, nalloc, C.c_void_p(buf.data_ptr()))
+
+    def fft_yz(self, planes, nplanes, direction):
+        assert planes.is_contiguous()
+        self._call(capi.hip.shq_pm_slab2_fft_yz, self.N, C.c_void_p(planes.data_ptr()), nplanes, direction)
+
+    def xgreen(self, spec_t, y0, nyl):
+        assert spec_t.is_contiguous() and spec_t.dtype == torch.complex128
+        self._call(capi.hip.shq_pm_slab2_xgreen, C.byref(self.pm), C.c_void_p(spec_t.data_ptr()), y0, nyl)
+
+    def readout2(self, phi, plane0, nxl, xoff, nalloc):
+        assert phi.is_contiguous()
+        self._call(capi.hip.shq_pm_slab2_readout, C.byref(self.pm), plane0, nxl, xoff, nalloc, C.c_void_p(phi.data_ptr()))
 
     def set_deposit_scale(self, total_mass):
         e = 61 - math.frexp(total_mass if total_mass > 0 else 1.0)[1]
