@@ -10,7 +10,7 @@ build and host packing are outside it.
 Workload at N=1: BASELINE.json configs[1] — dm-only 256^3, Nmesh 768, S-cluster positions,
 Asmth 1.5, TreeRcut 6, softening 2.8 L/(30 n), exact window, ErrTolForceAcc 0.005, after a
 theta=0.175 Barnes-Hut seeding walk.  For N>1 the box grows with the GPU count at fixed
-particles per GPU (n = 320, 408, 512 per dimension for N = 2, 4, 8; Nmesh = 3 n) and is sharded
+particles per GPU (n = 320, 400, 512 per dimension for N = 2, 4, 8; Nmesh = 3 n) and is sharded
 over x-slabs, one per rank (shenqi_amd/dist.py): RCCL all-to-all for the slab-FFT transposes,
 ghost mesh planes and ghost particles for the tree => "scaling": "weak".
 """
@@ -139,7 +139,8 @@ def run_sharded(args, rank, local_rank, world):
     import shenqi_amd as sq
     from shenqi_amd import capi, dist as sd
 
-    n1 = {2: 320, 4: 408, 8: 512}.get(world)
+    # 256^3 particles per GPU (weak scaling); meshes 3 n1 = 960, 1200, 1536 all have a bespoke FFT
+    n1 = {2: 320, 4: 400, 8: 512}.get(world)
     if n1 is None:
         n1 = int(round(args.n * world ** (1.0 / 3.0) / (2 * world))) * 2 * world
     if args.n != 256:      # reduced rehearsal sizes keep the same per-GPU share

@@ -2,7 +2,7 @@
  *
  * Replaces the reference's heffte/cuFFT r2c + c2r (libgadget/petapm.cpp:49-71) and the separate
  * transfer-function sweep (pm_apply_transfer_function, petapm.cpp:1258-1298) for mesh sizes
- * N = 2^a 3^b (b <= 1, N <= 1024).  rocFFT spends 6 memory passes per 3-D transform (3 FFT + 3
+ * N = 2^a 3^b 5^c up to 1536 (the compiled list is in shq_fft3d_supported).  rocFFT spends 6 memory passes per 3-D transform (3 FFT + 3
  * transpose kernels, 8.4 + 9.7 ms at 768^3); this pipeline needs FIVE passes for the whole
  * forward -> Green's function -> inverse sequence, each one read + one write of the mesh:
  *
@@ -140,6 +140,24 @@ __device__ __forceinline__ void fft_stage(double2 *buf, const double2 *__restric
                 v[kk][0] = cadd(a0, t1);
                 v[kk][1] = cadd(t2, t3);
                 v[kk][2] = csub(t2, t3);
+            } else if(R == 5) {
+                /* y_k = sum_j x_j w5^(jk), w5 = exp(DIR 2 pi i / 5) */
+                const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410; /* cos 72, cos 144 */
+                const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;  /* sin 72, sin 144 */
+                const double2 x0 = v[kk][0];
+                const double2 t1 = cadd(v[kk][1], v[kk][4]), t2 = cadd(v[kk][2], v[kk][3]);
+                const double2 t3 = csub(v[kk][1], v[kk][4]), t4 = csub(v[kk][2], v[kk][3]);
+                const double2 a1 = make_double2(x0.x + c1 * t1.x + c2 * t2.x, x0.y + c1 * t1.y + c2 * t2.y);
+                const double2 a2 = make_double2(x0.x + c2 * t1.x + c1 * t2.x, x0.y + c2 * t1.y + c1 * t2.y);
+                const double2 b1 = make_double2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+                const double2 b2 = make_double2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+                /* DIR < 0: y1 = a1 - i b1, y4 = a1 + i b1, y2 = a2 - i b2, y3 = a2 + i b2; conjugated for DIR > 0 */
+                const double sg = DIR < 0 ? 1.0 : -1.0;
+                v[kk][0] = make_double2(x0.x + t1.x + t2.x, x0.y + t1.y + t2.y);
+                v[kk][1] = make_double2(a1.x + sg * b1.y, a1.y - sg * b1.x);
+                v[kk][4] = make_double2(a1.x - sg * b1.y, a1.y + sg * b1.x);
+                v[kk][2] = make_double2(a2.x + sg * b2.y, a2.y - sg * b2.x);
+                v[kk][3] = make_double2(a2.x - sg * b2.y, a2.y + sg * b2.x);
             } else {
                 bfly16<DIR>(reinterpret_cast<double2(&)[16]>(v[kk]));
             }
@@ -170,7 +188,8 @@ __device__ __forceinline__ void fft_stage(double2 *buf, const double2 *__restric
 template <int N, int n, int s, int DIR> struct Stages {
     template <typename StoreOp> static __device__ __forceinline__ void run(double2 *buf, const double2 *__restrict__ W, const StoreOp op)
     {
-        constexpr int R = n % 16 == 0 ? 16 : (n % 4 == 0 ? 4 : (n % 2 == 0 ? 2 : 3));
+        constexpr int R = n % 16 == 0 ? 16 : (n % 4 == 0 ? 4 : (n % 2 == 0 ? 2 : (n % 3 == 0 ? 3 : 5)));
+        static_assert(n % R == 0, "mesh size must be 2^a 3^b 5^c");
         if constexpr(n / R > 1) {
             fft_stage<N, n, s, R, DIR>(buf, W);
             Stages<N, n / R, s * R, DIR>::run(buf, W, op);
@@ -524,11 +543,12 @@ int run_n(shq_context *ctx, double *d_mesh, int zp, int stage, bool from_i64, do
 
 } // namespace
 
-/* mesh sizes with a compiled pipeline: 2^a and 3 * 2^a */
+/* mesh sizes with a compiled pipeline (multiples of 8 of the form 2^a 3^b 5^c) */
 bool shq_fft3d_supported(int N)
 {
     switch(N) {
-    case 16: case 24: case 32: case 48: case 64: case 96: case 128: case 192: case 256: case 384: case 512: case 768: case 1024:
+    case 16: case 24: case 32: case 40: case 48: case 64: case 80: case 96: case 128: case 192: case 256: case 384: case 512: case 768:
+    case 960: case 1024: case 1152: case 1200: case 1536:
         return true;
     }
     return false;
@@ -575,9 +595,10 @@ int shq_fft3d_run_slab(shq_context *ctx, double *d_mesh, int N, int zp, int stag
     ga.y0 = y0;
 #define SHQ_FFT_CASE(NN) case NN: return run_n<NN>(ctx, d_mesh, zp, stage, from_i64, inv_scale, ga, nslab)
     switch(N) {
-        SHQ_FFT_CASE(16); SHQ_FFT_CASE(24); SHQ_FFT_CASE(32); SHQ_FFT_CASE(48); SHQ_FFT_CASE(64); SHQ_FFT_CASE(96);
-        SHQ_FFT_CASE(128); SHQ_FFT_CASE(192); SHQ_FFT_CASE(256); SHQ_FFT_CASE(384); SHQ_FFT_CASE(512); SHQ_FFT_CASE(768);
-        SHQ_FFT_CASE(1024);
+        SHQ_FFT_CASE(16); SHQ_FFT_CASE(24); SHQ_FFT_CASE(32); SHQ_FFT_CASE(40); SHQ_FFT_CASE(48); SHQ_FFT_CASE(64);
+        SHQ_FFT_CASE(80); SHQ_FFT_CASE(96); SHQ_FFT_CASE(128); SHQ_FFT_CASE(192); SHQ_FFT_CASE(256); SHQ_FFT_CASE(384);
+        SHQ_FFT_CASE(512); SHQ_FFT_CASE(768); SHQ_FFT_CASE(960); SHQ_FFT_CASE(1024); SHQ_FFT_CASE(1152); SHQ_FFT_CASE(1200);
+        SHQ_FFT_CASE(1536);
     }
 #undef SHQ_FFT_CASE
     return SHQ_ERR_INVALID;
