@@ -394,6 +394,9 @@ def main():
     sq.dynamics_upload(ctx, pman)
     gk = np.full(capi.TIMEBINS + 1, 1e-9)
     nres = 3
+    # without the wave-level counters: a different kernel instantiation, so that a profile of this command lists
+    # the timed production walk (counters on) separately from the walks of this loop (moved particles, tree order)
+    capi.check(capi.hip.shq_set_walk_stats(ctx.h, 0))
     for it in range(nres + 1):              # the first pass is a warm-up (the GPU idled during the CPU baseline)
         if it == 1:
             ctx.synchronize()

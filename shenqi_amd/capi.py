@@ -199,6 +199,8 @@ GRAV_QUERY_DTYPE = np.dtype({"names": ["Pos", "NodeList", "OldAcc"], "formats": 
 GRAV_RESULT_DTYPE = np.dtype({"names": ["Acc", "Potential"], "formats": [("<f8", 3), "<f8"], "offsets": [0, 24], "itemsize": 32})
 hip.shq_grav_short_secondary.argtypes = [_vp, C.POINTER(GravParams), _vp, C.c_int64, _vp, _vp, C.c_int]
 hip.shq_grav_short_secondary.restype = C.c_int
+hip.shq_set_walk_stats.argtypes = [_vp, C.c_int]
+hip.shq_set_walk_stats.restype = C.c_int
 hip.shq_pm_slab_pitch.argtypes = [C.c_int]
 hip.shq_pm_slab_pitch.restype = C.c_int
 hip.shq_pm_slab2_deposit.argtypes = [_vp, C.POINTER(PMParams), C.c_int, C.c_int, C.c_int, C.c_int, _vp]

@@ -168,6 +168,13 @@ extern "C" void shq_shutdown(shq_context *ctx)
     delete ctx;
 }
 
+extern "C" int shq_set_walk_stats(shq_context *ctx, int level)
+{
+    SHQ_CHECK(ctx && level >= 0 && level <= 2, SHQ_ERR_INVALID, "walk stats level must be 0, 1 or 2");
+    ctx->walk_stats = level;
+    return SHQ_OK;
+}
+
 int shq_join_pm(shq_context *ctx)
 {
     if(ctx->pm_pending) {
