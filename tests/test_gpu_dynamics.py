@@ -160,3 +160,17 @@ def test_tree_order_targets_same_forces(ctx):
     assert out[1][3] == alive.sum()
     for k in range(3):
         assert np.array_equal(out[0][k][alive], out[1][k][alive])
+
+
+def test_dynamics_empty(ctx):
+    """No particles: every resident call is a no-op that succeeds."""
+    pman = cm.make_partmanager(np.zeros((0, 3)))
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    sq.dynamics_upload(ctx, pman)
+    sq.drift(ctx, 0.1, cm.BOX, [0.1, 0.2, 0.3])
+    sq.kick_pm(ctx, 1.0)
+    sq.kick_short(ctx, np.zeros(capi.TIMEBINS + 1))
+    sq.dynamics_download(ctx, pman)
+    st = sq.tree_build_device(ctx, cm.BOX)
+    assert st.nparticles == 0

@@ -145,3 +145,35 @@ def test_device_tree_refuses_too_deep(ctx):
     capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
     with pytest.raises(sq.ShqError):
         sq.tree_build_device(ctx, cm.BOX)
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 8, 9, 65])
+def test_device_tree_tiny_inputs(ctx, n):
+    """Empty, single-leaf (<= 8 particles: the root is the leaf) and just-split inputs; ragged target counts."""
+    rng = np.random.default_rng(n)
+    pos = rng.random((n, 3)) * cm.BOX
+    pman = cm.make_partmanager(pos)
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    st = sq.tree_build_device(ctx, cm.BOX)
+    assert st.nparticles == n and st.numnodes >= 1
+    dnodes, father = sq.tree_download(ctx, n, n)
+    if n > 0:
+        host = sq.force_tree_full(pman)
+        a, b = canonical(host.Nodes_base, host.firstnode), canonical(dnodes, n)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+        assert np.all(father >= n)
+    else:
+        assert dnodes["noccupied"][0] == 0 and ((dnodes["flags"][0] >> 3) & 3) == 0
+    # a walk over the tiny tree runs and counts n - 1 ... n interactions per target (direct sum inside Rcut or monopoles)
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=1)
+    sq.gravshort_set_softenings(cm.BOX / 4)
+    gp = sq.make_grav_params(cm.BOX, 1.5, 16, cm.G, cm.RHO0)
+    capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, sq.WALK_EXACT | sq.WALK_TREE_ORDER))
+    acc = np.zeros((n, 3)); nint = np.zeros(n, dtype=np.int64)
+    capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), None, capi.ptr(nint), None))
+    if n > 0:
+        oacc, _, onint = orc.grav_walk(dnodes, n, pos, pman.Base["Mass"], np.zeros(n), gp)
+        assert np.array_equal(nint, onint)
+        assert np.abs(acc - oacc * cm.G).max() <= 1e-11 * max(np.abs(oacc * cm.G).max(), 1e-300)
