@@ -393,7 +393,19 @@ class DistTreePM:
         self.ops.set_deposit_scale(self.comm.allreduce_sum(float(self.local[:, 3].sum().item())))
         self._load_particles()
         # local + ghost particles are resident: build their tree (global root cell) on the device
-        self.tree = sq.tree_build_device(self.ctx, self.L)
+        try:
+            self.tree = sq.tree_build_device(self.ctx, self.L)
+        except sq.ShqError:
+            # deeper than the device build's 21 levels (more than 8 particles within L / 2^21): host build + upload
+            allh = self.allp.cpu().numpy()
+            pman = sq.PartManager(allh.shape[0], self.L)
+            pman.Base["Pos"] = allh[:, :3]
+            pman.Base["Mass"] = allh[:, 3]
+            pman.Base["Type"] = 1
+            self.pman = pman
+            self.tree = sq.force_tree_full(pman)
+            tv = self.tree.view()
+            capi.check(capi.hip.shq_tree_upload(self.ctx.h, C.byref(tv)))
 
     def _load_particles(self):
         ghosts = ghost_exchange(self.comm, self.decomp, self.local, self.halo)
