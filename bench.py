@@ -199,8 +199,12 @@ def run_sharded(args, rank, local_rank, world):
                                "exact window), %.3g particles per GPU" % (n1, world, args.kind, nmesh, args.errtol, nglobal / world),
                    "particles_total": nglobal, "nmesh": nmesh, "parallelism": "x-slabs x%d, RCCL all-to-all + ghost exchange" % world,
                    "slab_bounds": bounds, "walk": "exact (per-target reference opening decisions)"},
-        "roofline": {"bound": "hbm", "kernel": "grav_walk_exact_kernel (rank 0)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": None},
+        "roofline": {"bound": "mfma", "kernel": "grav_walk_exact_kernel (rank 0)",
+                     "achieved": 45.0 * st.ninteractions / max(st.kernel_ms * 1e-3, 1e-12) / 1e12, "peak": FP64_VECTOR_PEAK_TF,
+                     "unit": "TFLOP/s", "frac": 45.0 * st.ninteractions / max(st.kernel_ms * 1e-3, 1e-12) / 1e12 / FP64_VECTOR_PEAK_TF,
+                     "traffic": None, "algorithmic_flops": 45.0 * st.ninteractions, "algorithmic_bytes": tree_bytes,
+                     "hbm_algorithmic_GBs": ach,
+                     "note": "FP64-issue bound walk: 45 flop per interaction against the 78.6 TFLOP/s FP64 peak (see the N=1 line)"},
         "kernels": {"per_rank_local_particles": [int(g[0]) for g in gathered], "per_rank_ghost_particles": [int(g[1]) for g in gathered],
                     "per_rank_walk_ms": [float(g[2]) for g in gathered], "slowest_walk_ms": walk_s * 1e3},
         "setup_s": {"generate_exchange_tree_upload": t_setup},
@@ -346,6 +350,19 @@ def main():
                 traffic_fft = sum(hbm(pj[k]) for k in fk)
     except (OSError, ValueError):
         traffic = traffic_fft = None
+    # The dominant kernel, the tree walk, is bound by FP64 issue, not by HBM (0.1 kB of compulsory traffic per
+    # target against ~500 interactions of ~45 flop): its roofline is the FP64 compute peak (78.6
+    # TFLOP/s on MI355X, vector and matrix alike — the "mfma" kind of bound; no MFMA instruction is used or
+    # usable).  The HBM view of the same launch stays alongside: algorithmic bytes, measured traffic.
+    walk_flops = 45.0 * st.ninteractions
+    walk_roofline = {"bound": "mfma", "kernel": "grav_walk_exact_kernel", "achieved": walk_flops / max(walk_s, 1e-12) / 1e12,
+                     "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": walk_flops / max(walk_s, 1e-12) / 1e12 / FP64_VECTOR_PEAK_TF, "traffic": traffic,
+                     "algorithmic_flops": walk_flops, "algorithmic_bytes": tree_bytes, "hbm_algorithmic_GBs": tree_bytes / max(walk_s, 1e-12) / 1e9,
+                     "note": "FP64-issue bound: 45 flop per interaction (SURVEY 8(d)) x interactions / kernel time against the FP64 "
+                             "peak; VALU busy 84 % (profiles/r01_bench256_pmc_sq.json); `traffic` = HBM bytes per launch from the "
+                             "FETCH_SIZE/WRITE_SIZE passes, 6x the compulsory bytes and 0.2 TB/s: not a bandwidth problem.  "
+                             "The HBM-bound part of the step is the PM: roofline_pm_fft"}
     out = {
         "metric": "particle-steps/sec (grav+PM+SPH) at 256^3; rms force error vs ref",
         "value": n * world * args.steps / elapsed,
@@ -358,11 +375,9 @@ def main():
                                % (n1, args.kind, nmesh, args.errtol),
                    "particles_per_gpu": n, "nmesh": nmesh, "parallelism": "replicas x%d" % world if world > 1 else "1 GPU",
                    "walk": "exact (per-target reference opening decisions)"},
-        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": tree_bytes if walk_s >= pm_s else pm_bytes,
-                     "note": "the walk is FP64 VALU-issue bound, not HBM bound (compulsory traffic ~0.1 kB/target for ~500 "
-                             "interactions): see kernels.tree_fp64_frac_of_vector_peak and profiles/; the HBM-bound part of "
-                             "the step is the PM, see roofline_pm_fft"},
+        "roofline": walk_roofline if walk_s >= pm_s else
+                    {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": pm_bytes},
         "roofline_pm_fft": {"bound": "hbm", "kernel": "fft_pass_z_fwd/strided/z_inv (5 fused passes)",
                             "achieved": fft_bytes / max(fft_s, 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": fft_bytes / max(fft_s, 1e-12) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_fft,
