@@ -40,8 +40,7 @@ constexpr int TB_LEVELS = 21;
 __device__ __forceinline__ int key_digit(unsigned long long key, int l) { return (int) ((key >> (3 * (TB_LEVELS - 1 - l))) & 7ull); }
 
 __global__ void tb_key_kernel(long long ncand, const int32_t *__restrict__ cand, const double4 *__restrict__ posm,
-                              const uint8_t *__restrict__ pflags, int mask, double Box, unsigned long long *keys, int32_t *idx,
-                              unsigned long long *nvalid)
+                              const uint8_t *__restrict__ pflags, int mask, double Box, unsigned long long *keys, int32_t *idx)
 {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     bool ok = false;
@@ -52,24 +51,62 @@ __global__ void tb_key_kernel(long long ncand, const int32_t *__restrict__ cand,
         unsigned long long key = ~0ull;
         if(ok) {
             const double4 q = posm[p];
-            double cx = Box / 2., cy = Box / 2., cz = Box / 2., len = Box * 1.001; /* forcetree.cpp:661 */
-            key = 0;
-            for(int l = 0; l < TB_LEVELS; l++) {
-                const int s = (q.x > cx) + ((q.y > cy) << 1) + ((q.z > cz) << 2);
-                key = (key << 3) | (unsigned long long) s;
-                const double lenhalf = 0.25 * len;
-                cx = cx + ((s & 1) ? lenhalf : -lenhalf);
-                cy = cy + ((s & 2) ? lenhalf : -lenhalf);
-                cz = cz + ((s & 4) ? lenhalf : -lenhalf);
-                len = 0.5 * len;
+            /* Fast path: the cell boundaries of every level are, up to the rounding of the reference's centre
+             * updates (~1e-16 L), the dyadic fractions of the root cell, so a position that is not within
+             * 2^-20 of a finest-level (2^-21) cell boundary falls on the same side of every centre as its
+             * fixed-point coordinate says: the key is the bit interleave of the three 21-bit cell indices.
+             * The few positions that close to a boundary (6e-6 of all) take the
+             * level-by-level descent below, which repeats the reference's arithmetic exactly. */
+            const double len0 = Box * 1.001, lo0 = Box / 2. - 0.5 * len0, sc = 2097152.0 / len0; /* 2^21 cells */
+            const double tx = (q.x - lo0) * sc, ty = (q.y - lo0) * sc, tz = (q.z - lo0) * sc;
+            const double fx = tx - floor(tx), fy = ty - floor(ty), fz = tz - floor(tz);
+            const double eps = 1.0 / 1048576.; /* 1e-6 cells: >> the 1e-8 the roundings can add up to, and rare enough
+                                                  that hardly any wave has to run both paths */
+            const bool safe = fx > eps && fx < 1 - eps && fy > eps && fy < 1 - eps && fz > eps && fz < 1 - eps && tx > 0 && ty > 0 &&
+                              tz > 0 && tx < 2097152.0 && ty < 2097152.0 && tz < 2097152.0;
+            if(safe) {
+                auto spread = [](unsigned long long v) { /* 21 bits -> every third bit */
+                    v &= 0x1fffffull;
+                    v = (v | (v << 32)) & 0x1f00000000ffffull;
+                    v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+                    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+                    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+                    v = (v | (v << 2)) & 0x1249249249249249ull;
+                    return v;
+                };
+                key = spread((unsigned long long) tx) | (spread((unsigned long long) ty) << 1) | (spread((unsigned long long) tz) << 2);
+            } else {
+                double cx = Box / 2., cy = Box / 2., cz = Box / 2., len = Box * 1.001; /* forcetree.cpp:661 */
+                key = 0;
+                for(int l = 0; l < TB_LEVELS; l++) {
+                    const int s = (q.x > cx) + ((q.y > cy) << 1) + ((q.z > cz) << 2);
+                    key = (key << 3) | (unsigned long long) s;
+                    const double lenhalf = 0.25 * len;
+                    cx = cx + ((s & 1) ? lenhalf : -lenhalf);
+                    cy = cy + ((s & 2) ? lenhalf : -lenhalf);
+                    cz = cz + ((s & 4) ? lenhalf : -lenhalf);
+                    len = 0.5 * len;
+                }
             }
         }
         keys[i] = key;
         idx[i] = (int32_t) i; /* position in the candidate sequence: restores the order inside a leaf */
     }
-    const unsigned long long m = __ballot(ok);
-    if((threadIdx.x & 63) == 0 && m)
-        atomicAdd(nvalid, (unsigned long long) __popcll(m));
+}
+
+/* number of particles in the tree = first sorted position holding the excluded-particle key ~0
+ * (one counter bumped by every wave cost 3 ms of same-address atomics at 256^3) */
+__global__ void tb_count_kernel(const unsigned long long *__restrict__ keys, long long ncand, unsigned long long *nvalid)
+{
+    long long a = 0, e = ncand;
+    while(a < e) {
+        const long long mid = a + ((e - a) >> 1);
+        if(keys[mid] != ~0ull)
+            a = mid + 1;
+        else
+            e = mid;
+    }
+    *nvalid = (unsigned long long) a;
 }
 
 struct TbNodes {
@@ -497,11 +534,10 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
     }
     if(ncand > 0) {
         tb_key_kernel<<<dim3(nblk(ncand)), dim3(256), 0, st>>>(ncand, d_cand, ctx->posm.ptr, ctx->pflags.ptr, mask, BoxSize,
-                                                               b.keys[0].ptr, b.idx[0].ptr, b.counters.ptr);
+                                                               b.keys[0].ptr, b.idx[0].ptr);
         SHQ_HIP(hipGetLastError());
     }
     unsigned long long h_nvalid = 0;
-    SHQ_HIP(hipMemcpyAsync(&h_nvalid, b.counters.ptr, sizeof(h_nvalid), hipMemcpyDeviceToHost, st));
 
     /* 2. stable sort by key: depth-first leaf order, ties in candidate order */
     if(ncand > 0) {
@@ -509,6 +545,8 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
         SHQ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, b.keys[0].ptr, b.keys[1].ptr, b.idx[0].ptr, b.idx[1].ptr, (size_t) ncand, 0, 64, st));
         SHQ_TRY(b.temp.reserve(tmp + 16));
         SHQ_HIP(rocprim::radix_sort_pairs(b.temp.ptr, tmp, b.keys[0].ptr, b.keys[1].ptr, b.idx[0].ptr, b.idx[1].ptr, (size_t) ncand, 0, 64, st));
+        tb_count_kernel<<<1, 1, 0, st>>>(b.keys[1].ptr, ncand, b.counters.ptr);
+        SHQ_HIP(hipMemcpyAsync(&h_nvalid, b.counters.ptr, sizeof(h_nvalid), hipMemcpyDeviceToHost, st));
     }
     SHQ_HIP(hipStreamSynchronize(st));
     const long long n = (long long) h_nvalid;
