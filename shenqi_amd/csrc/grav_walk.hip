@@ -531,6 +531,8 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     a.targets = d_active;
     a.ntargets = ntargets;
 
+    /* 4 waves per workgroup: measured 86.9 / 55.4 / 46.7 / 50.5 ms for 64 / 128 / 256 / 512 threads (the LDS window
+     * table is per workgroup; larger groups wait for their slowest wave) */
     const int threads = 256;
     const long long nwaves = (ntargets + 63) / 64;
     const long long blocks = (nwaves + (threads / 64) - 1) / (threads / 64);
