@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
         aold = a.errtol * a.oldacc[pi];
     }
     double ax = 0, ay = 0, az = 0, pot = 0;
-    int nint = 0, nint_node = 0;
+    int nint = 0;
+    unsigned int node_int_wave = 0; /* STATS: monopole interactions of the whole wave (wave-uniform: no VGPR) */
     int mynext = valid ? a.root : -2;
     int cur = a.root;
     /* GHOSTS (GravLocalTreeWalk::visit<TREEWALK_GHOSTS>, gravshort2.hpp:243-261): an imported query walks only
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
             if(STATS) {
                 wave_applies++;
                 wave_node_applies++;
+                node_int_wave += (unsigned int) __popcll(__ballot(accept));
             }
             if(STATS == 2) {
                 const int pc = __popcll(__ballot(accept));
@@ -235,8 +237,6 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
             if(accept) {
                 apply_accn<POT>(tab, dx, dy, dz, r2, nd.mass, a, ax, ay, az, pot);
                 nint++;
-                if(STATS)
-                    nint_node++;
             }
         }
         int next;
@@ -315,14 +315,11 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
     }
     /* statistics (treewalk2.h:446-448 interaction min/max) */
     long long mn = valid ? nint : 0x7fffffffffffll, mx = valid ? nint : 0, sm = valid ? nint : 0;
-    int smn = valid ? nint_node : 0;
     for(int off = 32; off > 0; off >>= 1) {
         long long o1 = __shfl_xor(mn, off), o2 = __shfl_xor(mx, off), o3 = __shfl_xor(sm, off);
         mn = o1 < mn ? o1 : mn;
         mx = o2 > mx ? o2 : mx;
         sm += o3;
-        if(STATS)
-            smn += __shfl_xor(smn, off);
     }
     unsigned int l8s = lonely8, l8m = lonely8, l16s = lonely16, l16m = lonely16;
     if(STATS == 2)
@@ -340,7 +337,7 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
             atomicAdd(&a.stats->nvisited, (unsigned long long) visited);
             atomicAdd(&a.stats->nwave_applies, (unsigned long long) wave_applies);
             atomicAdd(&a.stats->nwave_node_applies, (unsigned long long) wave_node_applies);
-            atomicAdd(&a.stats->nnode_interactions, (unsigned long long) smn);
+            atomicAdd(&a.stats->nnode_interactions, (unsigned long long) node_int_wave);
         }
         if(STATS == 2)
             for(int b = 0; b < 8; b++) {
