@@ -168,10 +168,11 @@ typedef struct shq_walk_stats {
     double kernel_ms;           /* HIP-event time of the walk kernel(s) */
 } shq_walk_stats;
 
-/* Walk flavours. EXACT reproduces the reference's per-target opening decisions and
- * interaction set (parity bar runtests.cpp:441-443). */
+/* Walk flavour: EXACT reproduces the reference's per-target opening decisions and interaction set (parity bar
+ * runtests.cpp:441-443).  It is the only one: a group-level opening criterion (every lane of a wave taking the
+ * most conservative lane's decision) costs a wave the same instruction stream as the union walk and adds
+ * interactions, so it would be slower as well as different. */
 #define SHQ_WALK_EXACT 0
-#define SHQ_WALK_GROUP 1
 /* flag, or-ed into walk_mode: with active == NULL, take the targets in tree (leaf) order instead of
  * particle-index order — same results per particle; keeps target groups compact when the particle
  * order has gone stale (resident stepping without the reference's periodic Peano-Hilbert re-sort) */

@@ -17,7 +17,6 @@ NMAXCHILD = 8
 NOFIELD = C.c_size_t(-1).value
 
 WALK_EXACT = 0
-WALK_GROUP = 1
 WALK_TREE_ORDER = 0x100
 
 

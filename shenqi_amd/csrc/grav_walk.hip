@@ -511,7 +511,7 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
                          int update_potential, int walk_mode)
 {
     SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "grav walk: particles and tree must be uploaded first");
-    SHQ_CHECK(walk_mode == SHQ_WALK_EXACT || walk_mode == SHQ_WALK_GROUP, SHQ_ERR_INVALID, "unknown walk_mode %d", walk_mode);
+    SHQ_CHECK(walk_mode == SHQ_WALK_EXACT, SHQ_ERR_INVALID, "unknown walk_mode %d", walk_mode);
     SHQ_CHECK(p->ForceSoftening > 0 && p->cellsize > 0 && p->dx > 0, SHQ_ERR_INVALID, "grav params: softening/cellsize/dx must be > 0");
     SHQ_CHECK(ntargets >= 0 && ntargets <= ctx->numpart, SHQ_ERR_INVALID, "grav walk: ntargets %ld out of range", (long) ntargets);
     SHQ_TRY(ctx->gravtab.reserve(2 * SHQ_NGRAVTAB));
