@@ -415,6 +415,7 @@ extern "C" int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree)
             g.mlen2 = g.mass * g.len * g.len; /* (mass * len) * len, as shall_we_open_node evaluates it */
             g.inside = 0.6 * g.len;
             g.halflen = 0.5 * g.len;
+            g.wraplim = 0.5 * tree->BoxSize - g.halflen;
             hG[j] = g;
         }
     });

@@ -112,7 +112,9 @@ struct alignas(128) NodeG {
     double mlen2;    /* mass * len * len */
     double inside;   /* 0.6 * len */
     double halflen;  /* 0.5 * len */
-    double pad_[2];
+    double wraplim;  /* Box / 2 - len / 2: while every |center - pos| stays below it, neither the centre nor the
+                        centre of mass (inside the cell) needs the periodic wrap */
+    double pad_[1];
 };
 static_assert(sizeof(NodeG) == 128, "NodeG must be one 128-byte line");
 

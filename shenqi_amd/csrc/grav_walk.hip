@@ -118,13 +118,15 @@ __device__ __forceinline__ void apply_accn(const double4 *__restrict__ tab, doub
     }
 }
 
+/* wrap: wave-uniform, false when the leaf's own visit found every awake lane further than len/2 from the L/2 limit:
+ * the particles lie inside the leaf cell, so their displacements need no periodic wrap either */
 template <bool POT>
 __device__ __forceinline__ void leaf_particle(const double4 *__restrict__ tab, const double4 q, double px, double py,
                                               double pz, const WalkArgs &a, double &ax, double &ay, double &az,
-                                              double &pot)
+                                              double &pot, const bool wrap)
 {
     double ex = q.x - px, ey = q.y - py, ez = q.z - pz;
-    if(__ballot(fmax(fmax(fabs(ex), fabs(ey)), fabs(ez)) > a.halfBox) != 0ull) {
+    if(wrap) {
         ex = wrapd(ex, a.Box, a.invBox);
         ey = wrapd(ey, a.Box, a.invBox);
         ez = wrapd(ez, a.Box, a.invBox);
@@ -197,22 +199,25 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
             hv[(__popcll(__ballot(act)) - 1) >> 3 & 7]++;
 
         /* gravshort2.hpp:262-265 */
-        /* The periodic wrap is the identity unless some |d| exceeds L/2; one wave-uniform test
-         * skips the six wraps (24 f64 instructions) for the overwhelming majority of nodes. */
+        /* The periodic wrap is the identity unless some |d| exceeds L/2.  The centre of mass lies inside the cell,
+         * so while every |center - pos| of the awake lanes stays below L/2 - len/2 (precomputed with the node)
+         * neither vector needs it: one wave-uniform test on the maximum that the opening tests need anyway
+         * skips the six wraps for the overwhelming majority of nodes. */
         double dx = nd.cofm[0] - px, dy = nd.cofm[1] - py, dz = nd.cofm[2] - pz;
         double ux = nd.center[0] - px, uy = nd.center[1] - py, uz = nd.center[2] - pz;
-        if(__ballot(fmax(fmax(fmax(fabs(dx), fabs(dy)), fabs(dz)), fmax(fmax(fabs(ux), fabs(uy)), fabs(uz))) > a.halfBox) != 0ull) {
+        double cmax = fmax(fmax(fabs(ux), fabs(uy)), fabs(uz));
+        const bool wrap = __ballot(act && cmax > nd.wraplim) != 0ull;
+        if(wrap) {
             dx = wrapd(dx, a.Box, a.invBox);
             dy = wrapd(dy, a.Box, a.invBox);
             dz = wrapd(dz, a.Box, a.invBox);
             ux = wrapd(ux, a.Box, a.invBox);
             uy = wrapd(uy, a.Box, a.invBox);
             uz = wrapd(uz, a.Box, a.invBox);
+            cmax = fmax(fmax(fabs(ux), fabs(uy)), fabs(uz));
         }
         const double r2 = dx * dx + dy * dy + dz * dz;
-        const double cx = fabs(ux), cy = fabs(uy), cz = fabs(uz);
         /* shall_we_discard_node, gravshort2.hpp:152-167 */
-        const double cmax = fmax(fmax(cx, cy), cz);
         const bool discard = (r2 > a.rcut2) && (cmax > a.rcut + nd.halflen);
         /* shall_we_open_node, gravshort2.hpp:172-193 (len*len/r2 > theta2 written without the divide;
          * mass*len*len and 0.6*len come precomputed with the node) */
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
 #pragma unroll
                             for(int k = 0; k < LEAFB; k++)
                                 if(b + k < cnt)
-                                    leaf_particle<POT>(tab, q[k], px, py, pz, a, ax, ay, az, pot);
+                                    leaf_particle<POT>(tab, q[k], px, py, pz, a, ax, ay, az, pot, wrap);
                         }
                     }
                 }

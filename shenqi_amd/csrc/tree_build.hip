@@ -311,7 +311,8 @@ __global__ void tb_rank_kernel(int nn, const int32_t *__restrict__ order, int32_
 
 /* pool records in pre-order (common.hpp); record nn is the pad the walks may touch */
 __global__ void tb_pack_kernel(int nn, const int32_t *__restrict__ order, const int32_t *__restrict__ rank, TbNodes nd,
-                               const int32_t *__restrict__ idx, NodeA *A, NodeB *B, NodeC *C, NodeG *G, double *H, int32_t *pfather)
+                               const int32_t *__restrict__ idx, NodeA *A, NodeB *B, NodeC *C, NodeG *G, double *H, int32_t *pfather,
+                               double Box)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if(r > nn)
@@ -365,6 +366,7 @@ __global__ void tb_pack_kernel(int nn, const int32_t *__restrict__ order, const 
     g.mlen2 = g.mass * g.len * g.len; /* (mass * len) * len, as shall_we_open_node evaluates it */
     g.inside = 0.6 * g.len;
     g.halflen = 0.5 * g.len;
+    g.wraplim = 0.5 * Box - g.halflen;
     G[r] = g;
 }
 
@@ -638,7 +640,7 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
     SHQ_TRY(ctx->pfather.reserve((size_t) (np > 0 ? np : 1)));
     SHQ_HIP(hipMemsetAsync(ctx->pfather.ptr, 0xff, sizeof(int32_t) * (size_t) (np > 0 ? np : 1), st));
     tb_pack_kernel<<<dim3(nblk(nn + 1)), dim3(256), 0, st>>>(nn, b.order[1].ptr, b.rank.ptr, nd, idx, ctx->nodeA.ptr, ctx->nodeB.ptr,
-                                                              ctx->nodeC.ptr, ctx->nodeG.ptr, ctx->node_hmax.ptr, ctx->pfather.ptr);
+                                                              ctx->nodeC.ptr, ctx->nodeG.ptr, ctx->node_hmax.ptr, ctx->pfather.ptr, BoxSize);
     const long long npad = n + SHQ_NMAXCHILD;
     SHQ_TRY(ctx->posm_leaf.reserve((size_t) npad));
     SHQ_TRY(ctx->leaf_pidx.reserve((size_t) npad));
