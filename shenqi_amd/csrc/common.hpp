@@ -131,6 +131,11 @@ struct GravStatsDev {
     unsigned long long lonely[4]; /* per wave: sum / max over lanes of interactions met in rounds of <= 8, <= 16 lanes */
 };
 
+/* Wave-wide vote as a 64-bit lane mask.  HIP's __ballot(int) compares its argument with zero, so a boolean
+ * predicate is first materialised (v_cndmask) and then compared again (v_cmp_ne): two VALU instructions per
+ * vote, a third of the walk's per-node instruction count.  The builtin takes the predicate as it is. */
+__device__ __forceinline__ unsigned long long shq_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 /* XCD-aware block remap (bijective for any grid size): workgroups are dealt round-robin over the
  * 8 XCDs, so block b runs on XCD b % 8.  Give every XCD one contiguous eighth of the work so
  * that spatially adjacent target groups share an L2 (4 MiB per XCD, not coherent across XCDs).

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
             visited++;
         const bool act = (mynext == cur);
         if(STATS == 2)
-            hv[(__popcll(__ballot(act)) - 1) >> 3 & 7]++;
+            hv[(__popcll(shq_ballot(mynext == cur)) - 1) >> 3 & 7]++;
 
         /* gravshort2.hpp:262-265 */
         /* The periodic wrap is the identity unless some |d| exceeds L/2.  The centre of mass lies inside the cell,
@@ -206,7 +206,11 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
         double dx = nd.cofm[0] - px, dy = nd.cofm[1] - py, dz = nd.cofm[2] - pz;
         double ux = nd.center[0] - px, uy = nd.center[1] - py, uz = nd.center[2] - pz;
         double cmax = fmax(fmax(fabs(ux), fabs(uy)), fabs(uz));
-        const bool wrap = __ballot(act && cmax > nd.wraplim) != 0ull;
+        /* Wave votes are formed from the lane masks of the single comparisons (shq_ballot of one compare is that
+         * compare's own result) and combined with scalar logic; a vote on a compound boolean would cost two
+         * extra VALU instructions each, three times per node. */
+        const unsigned long long actm = shq_ballot(mynext == cur);
+        const bool wrap = (shq_ballot(cmax > nd.wraplim) & actm) != 0ull;
         if(wrap) {
             dx = wrapd(dx, a.Box, a.invBox);
             dy = wrapd(dy, a.Box, a.invBox);
@@ -224,15 +228,19 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
         const bool open = (!BH && (nd.mlen2 > r2 * r2 * aold)) || (nd.len2 > r2 * a.bh2) || (cmax < nd.inside);
         const bool accept = act && !discard && !open;
         const bool doopen = act && !discard && open;
+        const unsigned long long discardm = shq_ballot(r2 > a.rcut2) & shq_ballot(cmax > a.rcut + nd.halflen);
+        const unsigned long long openm = (BH ? 0ull : shq_ballot(nd.mlen2 > r2 * r2 * aold)) | shq_ballot(nd.len2 > r2 * a.bh2) |
+                                         shq_ballot(cmax < nd.inside);
+        const unsigned long long acceptm = actm & ~discardm & ~openm, doopenm = actm & ~discardm & openm;
 
-        if(__ballot(accept) != 0ull) {
+        if(acceptm != 0ull) {
             if(STATS) {
                 wave_applies++;
                 wave_node_applies++;
-                node_int_wave += (unsigned int) __popcll(__ballot(accept));
+                node_int_wave += (unsigned int) __popcll(acceptm);
             }
             if(STATS == 2) {
-                const int pc = __popcll(__ballot(accept));
+                const int pc = __popcll(acceptm);
                 hn[(pc - 1) >> 3 & 7]++;
                 if(accept && pc <= 8)
                     lonely8++;
@@ -247,13 +255,13 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
         int next;
         if(nd.type == SHQ_PARTICLE_NODE_TYPE) {
             /* gravshort2.hpp:290-304: every particle of an opened leaf is evaluated */
-            if(__ballot(doopen) != 0ull) {
+            if(doopenm != 0ull) {
                 const double4 *__restrict__ lp = a.posm_leaf + nd.child;
                 const int cnt = nd.count;
                 if(STATS)
                     wave_applies += cnt;
                 if(STATS == 2) {
-                    const int pc = __popcll(__ballot(doopen));
+                    const int pc = __popcll(doopenm);
                     hl[(pc - 1) >> 3 & 7] += cnt;
                     if(doopen && pc <= 8)
                         lonely8 += cnt;
@@ -288,9 +296,9 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
                 mynext = nd.sibling;
             next = nd.sibling;
         } else {
-            bool anyopen = __ballot(doopen) != 0ull;
+            bool anyopen = doopenm != 0ull;
             if(GHOSTS) /* a lane waits at a branch below this node: go down even if nobody opens it */
-                anyopen = anyopen || __ballot(mynext > cur && (nd.sibling < 0 || mynext < nd.sibling)) != 0ull;
+                anyopen = anyopen || shq_ballot(mynext > cur && (nd.sibling < 0 || mynext < nd.sibling)) != 0ull;
             if(act)
                 mynext = doopen ? nd.child : nd.sibling;
             next = anyopen ? nd.child : nd.sibling;

@@ -265,7 +265,7 @@ __global__ void sph_gather_leaf_kernel(long long nleaf, const int32_t *pidx, con
 template <class F> __device__ __forceinline__ void nl_flush(const int32_t *myl, int &fill, F &&pair)
 {
     int s_next = fill > 0 ? myl[0] : 0;
-    for(int j = 0; __ballot(j < fill) != 0ull; j++) {
+    for(int j = 0; shq_ballot(j < fill) != 0ull; j++) {
         const int s = s_next;
         if(j + 1 < fill)
             s_next = myl[(j + 1) * 64]; /* in flight while this pair is evaluated */
@@ -331,7 +331,7 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
             const double hj = SYM ? th[j] : 0.0;
             const bool keep = ((km >> lane) & 1ull) && !(fl & 1);
             double d0 = px - q.x, d1 = py - q.y, d2 = pz - q.z;
-            if(__ballot(keep && fmax(fmax(fabs(d0), fabs(d1)), fabs(d2)) > halfBox) != 0ull) {
+            if(shq_ballot(keep && fmax(fmax(fabs(d0), fabs(d1)), fabs(d2)) > halfBox) != 0ull) {
                 d0 = wrapd(d0, a.Box, a.invBox);
                 d1 = wrapd(d1, a.Box, a.invBox);
                 d2 = wrapd(d2, a.Box, a.invBox);
@@ -349,7 +349,7 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
                     ovf = true;
                     fill = 0;
                 }
-            } else if(__ballot(fill == NL_CAP) != 0ull) {
+            } else if(shq_ballot(fill == NL_CAP) != 0ull) {
                 if(dbg)
                     dbg[2] += NL_CAP;
                 nl_flush(myl, fill, pair);
@@ -389,7 +389,7 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
         {
             double dist = (SYM ? fmax(winH[w], h) : h) + 0.5 * B.w;
             double dx = B.x - px, dy = B.y - py, dz = B.z - pz;
-            if(__ballot(act && fmax(fmax(fabs(dx), fabs(dy)), fabs(dz)) > halfBox) != 0ull) {
+            if(shq_ballot(act && fmax(fmax(fabs(dx), fabs(dy)), fabs(dz)) > halfBox) != 0ull) {
                 dx = wrapd(dx, a.Box, a.invBox);
                 dy = wrapd(dy, a.Box, a.invBox);
                 dz = wrapd(dz, a.Box, a.invBox);
@@ -402,7 +402,7 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
         }
         int next;
         if(Ctype == SHQ_PARTICLE_NODE_TYPE) {
-            const unsigned long long km = __ballot(keep);
+            const unsigned long long km = shq_ballot(keep);
             if(km != 0ull && Ccount > 0) {
                 if(ncand + Ccount > 64)
                     scan_tile();
@@ -420,7 +420,7 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
                 mynext = Csib;
             next = Csib;
         } else {
-            const bool any = __ballot(keep) != 0ull;
+            const bool any = shq_ballot(keep) != 0ull;
             if(act)
                 mynext = keep ? Cchild : Csib;
             next = any ? Cchild : Csib;
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void sph_density_kernel(const SphDev a, const 
         nint = ngb_walk<false, MODE == 1>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE, myl, valid, px, py, pz, h, accept, pair,
                                           (unsigned int *) nullptr, fill, ovf);
     if(MODE == 1) {
-        const bool wave_ovf = __ballot(ovf) != 0ull;
+        const bool wave_ovf = shq_ballot(ovf) != 0ull;
         counts[wave * 64 + lane] = wave_ovf ? -1 : fill;
         if(wave_ovf)
             nint = 0; /* counted when the wave is redone */
@@ -667,7 +667,7 @@ __global__ void compact_count_kernel(const int32_t *todo, long long n, int32_t *
     __syncthreads();
     const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     const bool f = (t < n) && (todo[t] >= 0);
-    const unsigned long long m = __ballot(f);
+    const unsigned long long m = shq_ballot(f);
     if((threadIdx.x & 63) == 0)
         atomicAdd(&s, __popcll(m));
     __syncthreads();
@@ -709,7 +709,7 @@ __global__ void compact_write_kernel(const int32_t *todo, long long n, const int
     __shared__ int wavebase[4];
     const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     const bool f = (t < n) && (todo[t] >= 0);
-    const unsigned long long m = __ballot(f);
+    const unsigned long long m = shq_ballot(f);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if(lane == 0)
         wavebase[w] = __popcll(m);
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(256, 4) void sph_hydro_kernel(const SphDev a, const
         nint = ngb_walk<true, MODE == 1>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE, myl, valid, px, py, pz, hi, accept, pair,
                                          (MODE == 0 && nint_total) ? dbgc : (unsigned int *) nullptr, fill, ovf);
     if(MODE == 1) {
-        const bool wave_ovf = __ballot(ovf) != 0ull;
+        const bool wave_ovf = shq_ballot(ovf) != 0ull;
         counts[wave * 64 + lane] = wave_ovf ? -1 : fill;
         if(wave_ovf)
             nint = 0; /* counted when the wave is redone */
