@@ -74,12 +74,15 @@ __device__ __forceinline__ double rsqrt_fast(double x)
  * mass/(r2*r) is formed as mass*rinv^3 (a few ulp from the reference's sqrt + divide); a
  * coincident source (r2 == 0, the target itself) is clamped to a tiny r2 so that it falls in
  * the softened branch and contributes dx*fac = 0 exactly as in the reference. */
-template <bool POT>
+/* CLAMP: the source may coincide with the target (a leaf particle that is the target itself).  An accepted
+ * node never does: a target inside the node's cell opens it (0.6 len test), and outside the cell it cannot sit on
+ * the centre of mass, which lies inside. */
+template <bool POT, bool CLAMP = true>
 __device__ __forceinline__ void apply_accn(const double4 *__restrict__ tab, double dx, double dy, double dz, double r2,
                                            double mass, const WalkArgs &a, double &ax, double &ay, double &az,
                                            double &pot)
 {
-    const double r2c = fmax(r2, 1e-280);
+    const double r2c = CLAMP ? fmax(r2, 1e-280) : r2;
     const double rinv = rsqrt_fast(r2c);
     const double r = r2c * rinv;
     const double mr = mass * rinv;
@@ -118,15 +121,15 @@ __device__ __forceinline__ void apply_accn(const double4 *__restrict__ tab, doub
     }
 }
 
-/* wrap: wave-uniform, false when the leaf's own visit found every awake lane further than len/2 from the L/2 limit:
+/* wrapm: wave-uniform, zero when the leaf's own visit found every awake lane further than len/2 from the L/2 limit:
  * the particles lie inside the leaf cell, so their displacements need no periodic wrap either */
 template <bool POT>
 __device__ __forceinline__ void leaf_particle(const double4 *__restrict__ tab, const double4 q, double px, double py,
                                               double pz, const WalkArgs &a, double &ax, double &ay, double &az,
-                                              double &pot, const bool wrap)
+                                              double &pot, const unsigned long long wrapm)
 {
     double ex = q.x - px, ey = q.y - py, ez = q.z - pz;
-    if(wrap) {
+    if(wrapm != 0ull) { /* a scalar compare: a bool would be turned into a lane mask and back */
         ex = wrapd(ex, a.Box, a.invBox);
         ey = wrapd(ey, a.Box, a.invBox);
         ez = wrapd(ez, a.Box, a.invBox);
@@ -210,8 +213,8 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
          * compare's own result) and combined with scalar logic; a vote on a compound boolean would cost two
          * extra VALU instructions each, three times per node. */
         const unsigned long long actm = shq_ballot(mynext == cur);
-        const bool wrap = (shq_ballot(cmax > nd.wraplim) & actm) != 0ull;
-        if(wrap) {
+        const unsigned long long wrapm = shq_ballot(cmax > nd.wraplim) & actm;
+        if(wrapm != 0ull) {
             dx = wrapd(dx, a.Box, a.invBox);
             dy = wrapd(dy, a.Box, a.invBox);
             dz = wrapd(dz, a.Box, a.invBox);
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
                     lonely16++;
             }
             if(accept) {
-                apply_accn<POT>(tab, dx, dy, dz, r2, nd.mass, a, ax, ay, az, pot);
+                apply_accn<POT, false>(tab, dx, dy, dz, r2, nd.mass, a, ax, ay, az, pot);
                 nint++;
             }
         }
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
 #pragma unroll
                             for(int k = 0; k < LEAFB; k++)
                                 if(b + k < cnt)
-                                    leaf_particle<POT>(tab, q[k], px, py, pz, a, ax, ay, az, pot, wrap);
+                                    leaf_particle<POT>(tab, q[k], px, py, pz, a, ax, ay, az, pot, wrapm);
                         }
                     }
                 }
