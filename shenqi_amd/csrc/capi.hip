@@ -464,6 +464,7 @@ extern "C" int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree)
     ctx->ntreeparts = nleafparts;
     ctx->treeBox = tree->BoxSize;
     ctx->have_tree = true;
+    ctx->node_rcut = -1;
     ctx->tb_built = false;
     ctx->have_tree_targets = false;
     return SHQ_OK;

@@ -114,7 +114,7 @@ struct alignas(128) NodeG {
     double halflen;  /* 0.5 * len */
     double wraplim;  /* Box / 2 - len / 2: while every |center - pos| stays below it, neither the centre nor the
                         centre of mass (inside the cell) needs the periodic wrap */
-    double pad_[1];
+    double rcuthl;   /* Rcut + len / 2 of the discard test, filled for the Rcut of the current walk parameters */
 };
 static_assert(sizeof(NodeG) == 128, "NodeG must be one 128-byte line");
 
@@ -220,6 +220,7 @@ struct shq_context {
     DevBuf<double4> posm_leaf; /* leaf-ordered copy of (x,y,z,m) */
     DevBuf<int32_t> leaf_pidx; /* leaf slot -> particle index */
     bool have_tree = false;
+    double node_rcut = -1;     /* Rcut the pool's rcuthl field was filled for (< 0: stale) */
     double treeBox = 0;
     DevBuf<double> node_hmax;  /* mom.hmax per packed node (SPH symmetric cull) */
     DevBuf<int32_t> pfather;   /* particle -> packed index of the leaf holding it, or -1 */
