@@ -411,7 +411,7 @@ extern "C" int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree)
             g.mass = hA[j].mass;
             g.len = hB[j].len;
             g.sibling = hC[j].sibling; g.child = hC[j].child; g.type = hC[j].type; g.count = hC[j].count;
-            g.len2 = g.len * g.len;
+            g.bhlim = 0; /* filled per walk, like rcuthl */
             g.mlen2 = g.mass * g.len * g.len; /* (mass * len) * len, as shall_we_open_node evaluates it */
             g.inside = 0.6 * g.len;
             g.halflen = 0.5 * g.len;

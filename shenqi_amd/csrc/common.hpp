@@ -108,7 +108,7 @@ struct alignas(128) NodeG {
     double cofm[3], mass;
     double center[3], len;
     int32_t sibling, child, type, count;
-    double len2;     /* len * len */
+    double bhlim;    /* len * len / BHOpeningAngle^2 of the current walk parameters: the Barnes-Hut test is r2 < bhlim */
     double mlen2;    /* mass * len * len */
     double inside;   /* 0.6 * len */
     double halflen;  /* 0.5 * len */
@@ -220,7 +220,8 @@ struct shq_context {
     DevBuf<double4> posm_leaf; /* leaf-ordered copy of (x,y,z,m) */
     DevBuf<int32_t> leaf_pidx; /* leaf slot -> particle index */
     bool have_tree = false;
-    double node_rcut = -1;     /* Rcut the pool's rcuthl field was filled for (< 0: stale) */
+    double node_rcut = -1;     /* Rcut / BHOpeningAngle2 the pool's rcuthl and bhlim fields were filled for (< 0: stale) */
+    double node_bh2 = -1;
     double treeBox = 0;
     DevBuf<double> node_hmax;  /* mom.hmax per packed node (SPH symmetric cull) */
     DevBuf<int32_t> pfather;   /* particle -> packed index of the leaf holding it, or -1 */

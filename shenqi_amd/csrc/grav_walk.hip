@@ -228,11 +228,11 @@ __global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
         const bool discard = (r2 > a.rcut2) && (cmax > nd.rcuthl); /* rcuthl = Rcut + len / 2, per node */
         /* shall_we_open_node, gravshort2.hpp:172-193 (len*len/r2 > theta2 written without the divide;
          * mass*len*len and 0.6*len come precomputed with the node) */
-        const bool open = (!BH && (nd.mlen2 > r2 * r2 * aold)) || (nd.len2 > r2 * a.bh2) || (cmax < nd.inside);
+        const bool open = (!BH && (nd.mlen2 > r2 * r2 * aold)) || (r2 < nd.bhlim) || (cmax < nd.inside);
         const bool accept = act && !discard && !open;
         const bool doopen = act && !discard && open;
         const unsigned long long discardm = shq_ballot(r2 > a.rcut2) & shq_ballot(cmax > nd.rcuthl);
-        const unsigned long long openm = (BH ? 0ull : shq_ballot(nd.mlen2 > r2 * r2 * aold)) | shq_ballot(nd.len2 > r2 * a.bh2) |
+        const unsigned long long openm = (BH ? 0ull : shq_ballot(nd.mlen2 > r2 * r2 * aold)) | shq_ballot(r2 < nd.bhlim) |
                                          shq_ballot(cmax < nd.inside);
         const unsigned long long acceptm = actm & ~discardm & ~openm, doopenm = actm & ~discardm & openm;
 
@@ -410,13 +410,16 @@ __global__ void oldacc_kernel(long long n, const double *treeacc, const double *
     oldacc[i] = sqrt(s) / G;
 }
 
-/* the discard test compares with Rcut + len / 2: a wave-uniform sum of two scalars that would cost every visit a
- * v_mov + v_add (there is no scalar f64 ALU); it is stored with the node whenever Rcut or the tree changes */
-__global__ void fill_rcuthl_kernel(NodeG *g, long long n, double rcut)
+/* the discard test compares with Rcut + len / 2 and the Barnes-Hut test with len^2 / theta^2: wave-uniform
+ * expressions that would cost every visit VALU instructions (there is no scalar f64 ALU); they are stored with the
+ * node whenever the walk parameters or the tree change */
+__global__ void fill_rcuthl_kernel(NodeG *g, long long n, double rcut, double bh2)
 {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if(i < n)
+    if(i < n) {
         g[i].rcuthl = rcut + g[i].halflen;
+        g[i].bhlim = g[i].len * g[i].len / bh2; /* len^2 / r2 > theta^2 (gravshort2.hpp:179-182) as r2 < len^2 / theta^2 */
+    }
 }
 
 __global__ void stats_init_kernel(GravStatsDev *s)
@@ -461,10 +464,11 @@ void launch_variant(int stats, dim3 grid, dim3 block, hipStream_t stream, const 
 
 static void fill_walk_args(shq_context *ctx, const shq_grav_params *p, WalkArgs &a)
 {
-    if(ctx->node_rcut != p->Rcut && ctx->numnodes > 0) {
+    if((ctx->node_rcut != p->Rcut || ctx->node_bh2 != p->BHOpeningAngle2) && ctx->numnodes > 0) {
         const long long n = ctx->numnodes + 1;
-        fill_rcuthl_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->nodeG.ptr, n, p->Rcut);
+        fill_rcuthl_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->nodeG.ptr, n, p->Rcut, p->BHOpeningAngle2);
         ctx->node_rcut = p->Rcut;
+        ctx->node_bh2 = p->BHOpeningAngle2;
     }
     a.nodeG = ctx->nodeG.ptr;
     a.posm = ctx->posm.ptr;

@@ -362,7 +362,7 @@ __global__ void tb_pack_kernel(int nn, const int32_t *__restrict__ order, const 
     g.mass = a.mass;
     g.len = b.len;
     g.sibling = c.sibling; g.child = c.child; g.type = c.type; g.count = c.count;
-    g.len2 = g.len * g.len;
+    g.bhlim = 0; /* filled per walk, like rcuthl */
     g.mlen2 = g.mass * g.len * g.len; /* (mass * len) * len, as shall_we_open_node evaluates it */
     g.inside = 0.6 * g.len;
     g.halflen = 0.5 * g.len;
