@@ -27,6 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # host-side OpenMP (tree build, CPU baseline) uses the cores this process may run on
 os.environ.setdefault("OMP_NUM_THREADS", str(len(os.sched_getaffinity(0))))
+# idle OpenMP workers sleep instead of spinning: after the CPU baseline they otherwise keep every core busy and slow
+# the host thread that launches the GPU work (measured: resident step 95 ms instead of 75 ms)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 
 G = 43.0071
 RHO0 = 0.3 * 3 * 0.1 * 0.1 / (8 * np.pi * G)
