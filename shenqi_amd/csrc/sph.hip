@@ -288,8 +288,11 @@ template <class F> __device__ __forceinline__ void nl_flush(const int32_t *myl, 
  *   - accepted candidates go to the lane's list (see above) and are evaluated lane by lane.
  * Leaves are queued and tiles are scanned in walk order, so each lane still meets its neighbours in
  * depth-first order. */
-#define NW_WIN 64
-#define NW_LDS_PER_WAVE (NW_WIN * (32 + 16 + 8) + 64 * (32 + 8 + 8 + 4 + 4))
+#define NW_WIN 32 /* nodes per window: half a window costs a few more reloads and buys 1.8 KB of LDS per wave */
+/* per wave: node window (centre + len, links, hmax for the symmetric cull) and candidate tile (position, interested
+ * lanes, slot with the two flag bits on top, Hsml for the symmetric test): 4.3 KB (density) / 5.1 KB (hydro), so
+ * that the walk kernels reach 7-8 waves per SIMD instead of 5 */
+#define NW_LDS_PER_WAVE(SYM) (NW_WIN * (32 + 16 + ((SYM) ? 8 : 0)) + 64 * (32 + 8 + 4 + ((SYM) ? 8 : 0)))
 
 /* KEEP: only build the lists (two-kernel path): nothing is evaluated, `fill` returns the list length, and a
  * lane whose list would overflow sets `ovf` (its wave is then redone by the fused kernel). */
@@ -300,13 +303,12 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
 {
     double4 *winB = reinterpret_cast<double4 *>(lds_wave);
     int4 *winC = reinterpret_cast<int4 *>(lds_wave + NW_WIN * 32);
-    double *winH = reinterpret_cast<double *>(lds_wave + NW_WIN * 48);
-    char *tl = lds_wave + NW_WIN * 56;
+    double *winH = reinterpret_cast<double *>(lds_wave + NW_WIN * 48); /* SYM only */
+    char *tl = lds_wave + NW_WIN * (SYM ? 56 : 48);
     double4 *tq = reinterpret_cast<double4 *>(tl);
     unsigned long long *tmask = reinterpret_cast<unsigned long long *>(tl + 64 * 32);
-    double *th = reinterpret_cast<double *>(tl + 64 * 40);
-    int *tsl = reinterpret_cast<int *>(tl + 64 * 48);
-    int *tfl = reinterpret_cast<int *>(tl + 64 * 52);
+    int *tsl = reinterpret_cast<int *>(tl + 64 * 40);                  /* leaf slot | flags << 30 once gathered */
+    double *th = reinterpret_cast<double *>(tl + 64 * 44);             /* SYM only */
     const int lane = threadIdx.x & 63;
     const double halfBox = 0.5 * a.Box;
     unsigned int nint = 0;
@@ -319,7 +321,7 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
         if(lane < ncand) {
             const int s = tsl[lane];
             tq[lane] = a.posm_leaf[s];
-            tfl[lane] = a.flag_leaf[s];
+            tsl[lane] = s | (a.flag_leaf[s] << 30);
             if(SYM)
                 th[lane] = a.hsml_leaf[s];
         }
@@ -327,7 +329,7 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
         for(int j = 0; j < ncand; j++) {
             const double4 q = tq[j];
             const unsigned long long km = tmask[j];
-            const int fl = tfl[j], s = tsl[j];
+            const int sf = tsl[j], s = sf & 0x3fffffff, fl = (int) ((unsigned) sf >> 30);
             const double hj = SYM ? th[j] : 0.0;
             const bool keep = ((km >> lane) & 1ull) && !(fl & 1);
             double d0 = px - q.x, d1 = py - q.y, d2 = pz - q.z;
@@ -367,13 +369,15 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
         if(cur < wbase || cur >= wbase + NW_WIN) {
             wbase = cur;
             __builtin_amdgcn_wave_barrier();
-            const int idx = min(cur + lane, a.npool - 1);
-            const NodeB nb = a.nodeB[idx];
-            const NodeC nc = a.nodeC[idx];
-            winB[lane] = make_double4(nb.center[0], nb.center[1], nb.center[2], nb.len);
-            winC[lane] = make_int4(nc.sibling, nc.child, nc.type, nc.count);
-            if(SYM)
-                winH[lane] = a.hmax[idx];
+            if(lane < NW_WIN) {
+                const int idx = min(cur + lane, a.npool - 1);
+                const NodeB nb = a.nodeB[idx];
+                const NodeC nc = a.nodeC[idx];
+                winB[lane] = make_double4(nb.center[0], nb.center[1], nb.center[2], nb.len);
+                winC[lane] = make_int4(nc.sibling, nc.child, nc.type, nc.count);
+                if(SYM)
+                    winH[lane] = a.hmax[idx];
+            }
             __builtin_amdgcn_wave_barrier();
         }
         const int w = cur - wbase;
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(256) void sph_density_kernel(const SphDev a, const 
                                                           unsigned long long *nint_total, int32_t *__restrict__ nlist, long long ntasks,
                                                           int32_t *__restrict__ counts, const long long *d_nq)
 {
-    __shared__ __attribute__((aligned(32))) char lds[(MODE == 2 ? 1 : 4 * NW_LDS_PER_WAVE)];
+    __shared__ __attribute__((aligned(32))) char lds[(MODE == 2 ? 1 : 4 * NW_LDS_PER_WAVE(false))];
     const int lane = threadIdx.x & 63;
     if(MODE == 0 && d_nq) {
         nq = *d_nq;
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(256) void sph_density_kernel(const SphDev a, const 
     int fill = 0;
     bool ovf = false;
     if(MODE != 2)
-        nint = ngb_walk<false, MODE == 1>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE, myl, valid, px, py, pz, h, accept, pair,
+        nint = ngb_walk<false, MODE == 1>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(false), myl, valid, px, py, pz, h, accept, pair,
                                           (unsigned int *) nullptr, fill, ovf);
     if(MODE == 1) {
         const bool wave_ovf = shq_ballot(ovf) != 0ull;
@@ -735,7 +739,7 @@ __global__ __launch_bounds__(256, 4) void sph_hydro_kernel(const SphDev a, const
                                                            unsigned long long *nint_total, int32_t *__restrict__ nlist, long long ntasks,
                                                            int32_t *__restrict__ counts, const long long *d_nq)
 {
-    __shared__ __attribute__((aligned(32))) char lds[(MODE == 2 ? 1 : 4 * NW_LDS_PER_WAVE)];
+    __shared__ __attribute__((aligned(32))) char lds[(MODE == 2 ? 1 : 4 * NW_LDS_PER_WAVE(true))];
     const int lane = threadIdx.x & 63;
     if(MODE == 0 && d_nq) {
         nq = *d_nq;
@@ -837,7 +841,7 @@ __global__ __launch_bounds__(256, 4) void sph_hydro_kernel(const SphDev a, const
     int fill = 0;
     bool ovf = false;
     if(MODE != 2)
-        nint = ngb_walk<true, MODE == 1>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE, myl, valid, px, py, pz, hi, accept, pair,
+        nint = ngb_walk<true, MODE == 1>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(true), myl, valid, px, py, pz, hi, accept, pair,
                                          (MODE == 0 && nint_total) ? dbgc : (unsigned int *) nullptr, fill, ovf);
     if(MODE == 1) {
         const bool wave_ovf = shq_ballot(ovf) != 0ull;
@@ -962,6 +966,7 @@ int shq_sph_prepare(shq_context *ctx, const shq_kick_factors *kf, const shq_hydr
     SHQ_TRY(ctx->hydC.reserve(n > 0 ? n : 1));
     SHQ_TRY(ctx->hydD.reserve(n > 0 ? n : 1));
     const long long nl = ctx->ntreeparts + SHQ_NMAXCHILD;
+    SHQ_CHECK(nl < (1ll << 30), SHQ_ERR_INVALID, "SPH walk: more than 2^30 leaf slots (the candidate tile keeps two flag bits on top of the slot)");
     SHQ_TRY(ctx->velp_leaf.reserve(nl));
     SHQ_TRY(ctx->hydrec_leaf.reserve(nl * sizeof(HydRec) + 128));
     SHQ_TRY(ctx->hsml_leaf.reserve(nl));
