@@ -333,7 +333,7 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
             const double hj = SYM ? th[j] : 0.0;
             const bool keep = ((km >> lane) & 1ull) && !(fl & 1);
             double d0 = px - q.x, d1 = py - q.y, d2 = pz - q.z;
-            if(shq_ballot(keep && fmax(fmax(fabs(d0), fabs(d1)), fabs(d2)) > halfBox) != 0ull) {
+            if(shq_ballot(fmax(fmax(fabs(d0), fabs(d1)), fabs(d2)) > halfBox) != 0ull) { /* any lane: a rare, harmless over-trigger */
                 d0 = wrapd(d0, a.Box, a.invBox);
                 d1 = wrapd(d1, a.Box, a.invBox);
                 d2 = wrapd(d2, a.Box, a.invBox);
@@ -388,25 +388,26 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
         if(dbg)
             dbg[0]++;
         const bool act = (mynext == cur);
-        /* cull_node<symmetric>, localtreewalk2.h:154-182 */
-        bool keep = false;
-        {
-            double dist = (SYM ? fmax(winH[w], h) : h) + 0.5 * B.w;
-            double dx = B.x - px, dy = B.y - py, dz = B.z - pz;
-            if(shq_ballot(act && fmax(fmax(fabs(dx), fabs(dy)), fabs(dz)) > halfBox) != 0ull) {
-                dx = wrapd(dx, a.Box, a.invBox);
-                dy = wrapd(dy, a.Box, a.invBox);
-                dz = wrapd(dz, a.Box, a.invBox);
-            }
-            if(!(fmax(fmax(fabs(dx), fabs(dy)), fabs(dz)) > dist)) {
-                const double r2 = dx * dx + dy * dy + dz * dz;
-                dist += (0.5 * (1.7320508075688772 - 1.0)) * B.w;
-                keep = act && !(r2 > dist * dist);
-            }
+        /* cull_node<symmetric>, localtreewalk2.h:154-182.  The wave votes are formed from the lane masks of the single
+         * comparisons and combined with scalar logic (a vote on a compound boolean costs two extra VALU instructions). */
+        const unsigned long long actm = shq_ballot(mynext == cur);
+        double dist = (SYM ? fmax(winH[w], h) : h) + 0.5 * B.w;
+        double dx = B.x - px, dy = B.y - py, dz = B.z - pz;
+        double dmax = fmax(fmax(fabs(dx), fabs(dy)), fabs(dz));
+        if((shq_ballot(dmax > halfBox) & actm) != 0ull) {
+            dx = wrapd(dx, a.Box, a.invBox);
+            dy = wrapd(dy, a.Box, a.invBox);
+            dz = wrapd(dz, a.Box, a.invBox);
+            dmax = fmax(fmax(fabs(dx), fabs(dy)), fabs(dz));
         }
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        const double dist2 = dist + (0.5 * (1.7320508075688772 - 1.0)) * B.w;
+        const bool far1 = dmax > dist, far2 = r2 > dist2 * dist2;
+        const bool keep = act && !far1 && !far2;
+        const unsigned long long keepm = actm & ~shq_ballot(dmax > dist) & ~shq_ballot(r2 > dist2 * dist2);
         int next;
         if(Ctype == SHQ_PARTICLE_NODE_TYPE) {
-            const unsigned long long km = shq_ballot(keep);
+            const unsigned long long km = keepm;
             if(km != 0ull && Ccount > 0) {
                 if(ncand + Ccount > 64)
                     scan_tile();
@@ -424,7 +425,7 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
                 mynext = Csib;
             next = Csib;
         } else {
-            const bool any = shq_ballot(keep) != 0ull;
+            const bool any = keepm != 0ull;
             if(act)
                 mynext = keep ? Cchild : Csib;
             next = any ? Cchild : Csib;
