@@ -234,6 +234,32 @@ int shq_tree_download(shq_context *ctx, int64_t firstnode, shq_node *nodes, int6
  * shq_kick_pm: apply_PM_half_kick (timestep.cpp:937-959): Vel += GravPM * Fgravkick for every particle.
  * shq_dynamics_download: Pos, Vel, Hsml back into the caller's particle array. */
 int shq_dynamics_upload(shq_context *ctx, const shq_part_view *parts);
+
+/* Active-particle lists on the device (build_active_particles / build_active_sublist,
+ * libgadget/timestep.cpp:1286-1390).  The lists stay in HBM; SHQ_ACTIVE_RESIDENT / SHQ_SUBLIST_RESIDENT passed as
+ * the `active` argument of shq_tree_build, shq_grav_short_run and shq_kick_short select them (nactive is ignored),
+ * so a sub-step of the hierarchical integrator never moves an index list over PCIe.
+ *
+ * shq_timebins_upload: TimeBinGravity / TimeBinHydro of the resident particles (host arrays of numpart bytes;
+ *     NULL keeps what is there, zero if nothing is).  shq_dynamics_upload and shq_sph_upload also set them.
+ * shq_build_active_particles: ActivePredicate (timestep.cpp:1265-1282) over all particles, in index order (std::copy_if
+ *     is stable): not garbage / swallowed, and gravity bin active or (gas / BH and hydro bin active) at Ti_Current
+ *     (is_timebin_active, timestep.cpp:132-139).  is_pm_step: the reference's PM-step branch, every particle is active
+ *     and ActiveParticle stays NULL (NumActiveHydro then counts the type-0/5 records, where the reference reports its
+ *     slot-array sizes).  info may be NULL.
+ * shq_build_active_sublist: SubActivePredicate (timestep.cpp:1354-1371) over the resident list: gravity bin <= maxtimebin
+ *     and active.
+ * shq_active_download: either list to the host (count always returned; list may be NULL). */
+typedef struct shq_active_info {
+    int64_t NumActiveParticle, NumActiveGravity, NumActiveHydro;
+    int64_t TimeBinCountType[6 * (SHQ_TIMEBINS + 1)];   /* [(TIMEBINS + 1) * type + bin] */
+} shq_active_info;
+#define SHQ_ACTIVE_RESIDENT ((const int32_t *) (intptr_t) -1)
+#define SHQ_SUBLIST_RESIDENT ((const int32_t *) (intptr_t) -2)
+int shq_timebins_upload(shq_context *ctx, const uint8_t *bin_gravity, const uint8_t *bin_hydro);
+int shq_build_active_particles(shq_context *ctx, int64_t Ti_Current, int is_pm_step, shq_active_info *info);
+int shq_build_active_sublist(shq_context *ctx, int maxtimebin, int64_t Ti_Current, int64_t *nsub);
+int shq_active_download(shq_context *ctx, int sublist, int32_t *list, int64_t capacity, int64_t *count);
 int shq_drift(shq_context *ctx, double ddrift, double BoxSize, const double random_shift[3]);
 int shq_kick_short(shq_context *ctx, const double gravkick[SHQ_TIMEBINS + 1], const int32_t *active, int64_t nactive,
                    int from_accel_store);

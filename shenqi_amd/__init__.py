@@ -115,10 +115,55 @@ def tree_build_device(ctx, BoxSize, mask=None, active=None):
     """shq_tree_build: build the tree of the uploaded particles on the device and install it in `ctx`.
     Returns capi.TreeBuildStats."""
     st = capi.TreeBuildStats()
-    act = None if active is None else np.ascontiguousarray(active, dtype=np.int32)
-    capi.check(capi.hip.shq_tree_build(ctx.h, float(BoxSize), ALLMASK if mask is None else int(mask), capi.ptr(act),
-                                       0 if act is None else len(act), C.byref(st)), "shq_tree_build")
+    act, nact = _active_arg(active)
+    capi.check(capi.hip.shq_tree_build(ctx.h, float(BoxSize), ALLMASK if mask is None else int(mask), act, nact, C.byref(st)),
+               "shq_tree_build")
     return st
+
+
+RESIDENT = "resident"        # the list of the last build_active_particles (SHQ_ACTIVE_RESIDENT)
+RESIDENT_SUB = "resident-sub"  # the list of the last build_active_sublist (SHQ_SUBLIST_RESIDENT)
+
+
+def _active_arg(active):
+    """(pointer, count) for the `active` argument of the C-ABI: None, a host index list or a resident handle."""
+    if active is None:
+        return None, 0
+    if isinstance(active, str):
+        return {RESIDENT: capi.ACTIVE_RESIDENT, RESIDENT_SUB: capi.SUBLIST_RESIDENT}[active], 0
+    act = np.ascontiguousarray(active, dtype=np.int32)
+    _active_arg.keep = act
+    return capi.ptr(act), len(act)
+
+
+def timebins_upload(ctx, bin_gravity=None, bin_hydro=None):
+    bg = None if bin_gravity is None else np.ascontiguousarray(bin_gravity, dtype=np.uint8)
+    bh = None if bin_hydro is None else np.ascontiguousarray(bin_hydro, dtype=np.uint8)
+    capi.check(capi.hip.shq_timebins_upload(ctx.h, capi.ptr(bg), capi.ptr(bh)), "shq_timebins_upload")
+
+
+def build_active_particles(ctx, Ti_Current, is_pm_step=False):
+    """shq_build_active_particles: build_active_particles (libgadget/timestep.cpp:1286-1349) on the device.
+    Returns capi.ActiveInfo; the list stays resident (pass active=RESIDENT)."""
+    info = capi.ActiveInfo()
+    capi.check(capi.hip.shq_build_active_particles(ctx.h, int(Ti_Current), int(bool(is_pm_step)), C.byref(info)),
+               "shq_build_active_particles")
+    return info
+
+
+def build_active_sublist(ctx, maxtimebin, Ti_Current):
+    """shq_build_active_sublist: build_active_sublist (libgadget/timestep.cpp:1373-1399). Returns its length."""
+    n = C.c_int64()
+    capi.check(capi.hip.shq_build_active_sublist(ctx.h, int(maxtimebin), int(Ti_Current), C.byref(n)), "shq_build_active_sublist")
+    return n.value
+
+
+def active_download(ctx, sublist=False):
+    n = C.c_int64()
+    capi.check(capi.hip.shq_active_download(ctx.h, int(sublist), None, 0, C.byref(n)), "shq_active_download")
+    out = np.zeros(n.value, dtype=np.int32)
+    capi.check(capi.hip.shq_active_download(ctx.h, int(sublist), capi.ptr(out), n.value, C.byref(n)), "shq_active_download")
+    return out
 
 
 def tree_download(ctx, firstnode, numpart=0):
@@ -148,9 +193,8 @@ def kick_short(ctx, gravkick, active=None, from_accel_store=False):
     """shq_kick_short: gravity part of apply_half_kick (libgadget/timestep.cpp:838-872)."""
     gk = np.ascontiguousarray(gravkick, dtype=np.float64)
     assert gk.shape == (capi.TIMEBINS + 1,)
-    act = None if active is None else np.ascontiguousarray(active, dtype=np.int32)
-    capi.check(capi.hip.shq_kick_short(ctx.h, capi.ptr(gk), capi.ptr(act), 0 if act is None else len(act), int(from_accel_store)),
-               "shq_kick_short")
+    act, nact = _active_arg(active)
+    capi.check(capi.hip.shq_kick_short(ctx.h, capi.ptr(gk), act, nact, int(from_accel_store)), "shq_kick_short")
 
 
 def kick_pm(ctx, Fgravkick):

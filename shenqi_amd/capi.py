@@ -116,6 +116,18 @@ class TreeBuildStats(C.Structure):
     _fields_ = [("nparticles", C.c_int64), ("numnodes", C.c_int64), ("maxdepth", C.c_int32), ("build_ms", C.c_float)]
 
 
+TIMEBINS = 46
+
+
+class ActiveInfo(C.Structure):
+    _fields_ = [("NumActiveParticle", C.c_int64), ("NumActiveGravity", C.c_int64), ("NumActiveHydro", C.c_int64),
+                ("TimeBinCountType", C.c_int64 * (6 * (TIMEBINS + 1)))]
+
+
+ACTIVE_RESIDENT = C.c_void_p(2**64 - 1)    # SHQ_ACTIVE_RESIDENT
+SUBLIST_RESIDENT = C.c_void_p(2**64 - 2)   # SHQ_SUBLIST_RESIDENT
+
+
 class WalkStats(C.Structure):
     _fields_ = [
         ("ntargets", C.c_int64), ("ninteractions", C.c_int64), ("min_interactions", C.c_int64),
@@ -128,7 +140,6 @@ class WalkStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
-TIMEBINS = 46
 
 
 class KickFactors(C.Structure):
@@ -220,6 +231,14 @@ hip.shq_drift.argtypes = [_vp, C.c_double, C.c_double, _vp]
 hip.shq_drift.restype = C.c_int
 hip.shq_kick_short.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int]
 hip.shq_kick_short.restype = C.c_int
+hip.shq_timebins_upload.argtypes = [_vp, _vp, _vp]
+hip.shq_timebins_upload.restype = C.c_int
+hip.shq_build_active_particles.argtypes = [_vp, C.c_int64, C.c_int, C.POINTER(ActiveInfo)]
+hip.shq_build_active_particles.restype = C.c_int
+hip.shq_build_active_sublist.argtypes = [_vp, C.c_int, C.c_int64, C.POINTER(C.c_int64)]
+hip.shq_build_active_sublist.restype = C.c_int
+hip.shq_active_download.argtypes = [_vp, C.c_int, _vp, C.c_int64, C.POINTER(C.c_int64)]
+hip.shq_active_download.restype = C.c_int
 hip.shq_kick_pm.argtypes = [_vp, C.c_double]
 hip.shq_kick_pm.restype = C.c_int
 hip.shq_dynamics_download.argtypes = [_vp, C.POINTER(PartView)]

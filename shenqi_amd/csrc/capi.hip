@@ -63,20 +63,6 @@ __global__ void gather_leaf_kernel(const double4 *posm, const int32_t *pidx, dou
         out[i] = posm[pidx[i]];
 }
 
-int upload_active(shq_context *ctx, const int32_t *active, int64_t nactive, const int32_t **d_active)
-{
-    *d_active = nullptr;
-    if(!active)
-        return SHQ_OK;
-    for(int64_t k = 0; k < nactive; k++)
-        SHQ_CHECK(active[k] >= 0 && active[k] < ctx->numpart, SHQ_ERR_INVALID, "active[%ld] = %d out of range", (long) k, active[k]);
-    SHQ_TRY(ctx->active.reserve((size_t) std::max<int64_t>(nactive, 1)));
-    if(nactive > 0)
-        SHQ_HIP(hipMemcpyAsync(ctx->active.ptr, active, sizeof(int32_t) * nactive, hipMemcpyHostToDevice, ctx->stream));
-    *d_active = ctx->active.ptr;
-    return SHQ_OK;
-}
-
 } // namespace
 
 extern "C" int shq_init(int device, void *stream, shq_context **out)
@@ -138,7 +124,7 @@ extern "C" void shq_shutdown(shq_context *ctx)
     shq_pm_destroy_plans(ctx);
     ctx->posm.release(); ctx->oldacc.release(); ctx->treeacc.release(); ctx->gravpm.release();
     ctx->pmpot.release(); ctx->acc.release(); ctx->pot.release(); ctx->nint.release();
-    ctx->pflags.release(); ctx->active.release(); ctx->gstats.release();
+    ctx->pflags.release(); ctx->active.release(); ctx->act_list.release(); ctx->act_sub.release(); ctx->act_counts.release(); ctx->act_temp.release(); ctx->act_flag.release(); ctx->gstats.release();
     ctx->nodeA.release(); ctx->nodeB.release(); ctx->nodeC.release(); ctx->nodeG.release();
     ctx->posm_leaf.release(); ctx->leaf_pidx.release();
     ctx->mesh.release(); ctx->sinctab.release(); ctx->dbg_rho.release(); ctx->dbg_pot.release();
@@ -298,6 +284,7 @@ extern "C" int shq_particles_upload(shq_context *ctx, const shq_part_view *parts
     ctx->tb_built = false;
     ctx->have_sph = false;  /* Hsml / Vel / slot data of the previous particle set */
     ctx->have_dyn = false;
+    ctx->n_act = ctx->n_sub = -1;
     ctx->have_pm_result = false;
     return SHQ_OK;
 }
@@ -516,6 +503,7 @@ extern "C" int shq_particles_set_device(shq_context *ctx, const void *d_posm, in
     ctx->have_tree_targets = false; /* nlocal may have changed */
     ctx->have_sph = false;
     ctx->have_dyn = false;
+    ctx->n_act = ctx->n_sub = -1;
     ctx->numpart = n;
     ctx->nlocal = nlocal;
     ctx->have_parts = true;
@@ -532,14 +520,14 @@ extern "C" int shq_grav_short_run(shq_context *ctx, const shq_grav_params *param
     SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "grav_short_run: upload particles and tree first");
     SHQ_HIP(hipSetDevice(ctx->device));
     const int32_t *d_active = nullptr;
-    int64_t nt = active ? nactive : (ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart);
+    int64_t nt = 0;
     if((walk_mode & SHQ_WALK_TREE_ORDER) && !active) {
         /* all own particles of the tree, taken in leaf order */
         SHQ_TRY(shq_build_tree_targets(ctx));
         d_active = ctx->tree_targets.ptr;
         nt = ctx->ntree_targets;
     } else
-        SHQ_TRY(upload_active(ctx, active, nt, &d_active));
+        SHQ_TRY(shq_resolve_active(ctx, active, nactive, ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart, &d_active, &nt));
     walk_mode &= 0xff;
     SHQ_TRY(shq_launch_grav_walk(ctx, params, d_active, nt, update_potential, walk_mode));
     SHQ_TRY(shq_launch_grav_postprocess(ctx, params, d_active, nt, update_potential));

@@ -205,6 +205,12 @@ struct shq_context {
     DevBuf<int32_t> nint;      /* [N] interactions */
     DevBuf<uint8_t> pflags;    /* bit0 garbage, bit1 swallowed; bits 4-7 type */
     DevBuf<int32_t> active;    /* uploaded active list */
+    DevBuf<int32_t> act_list, act_sub;   /* resident ActiveParticle list and gravity sub-list (shq_build_active_*) */
+    DevBuf<unsigned long long> act_counts;
+    DevBuf<char> act_temp;
+    DevBuf<uint8_t> act_flag;
+    int64_t n_act = -1, n_sub = -1;      /* -1: not built */
+    bool act_all = false;                /* PM step: the list is NULL, every particle is active */
     DevBuf<GravStatsDev> gstats;
     bool have_parts = false;
 
@@ -290,6 +296,9 @@ struct shq_context {
 /* capi.hip: make the main stream wait for an outstanding asynchronous PM run */
 int shq_join_pm(shq_context *ctx);
 /* grav_walk.hip */
+/* Device pointer and length of an active list argument of the C-ABI: NULL (all n_all), a host list
+ * (uploaded), or one of the SHQ_ACTIVE_RESIDENT / SHQ_SUBLIST_RESIDENT handles. dynamics.hip */
+int shq_resolve_active(shq_context *ctx, const int32_t *active, int64_t nactive, int64_t n_all, const int32_t **d_active, int64_t *nt);
 int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active,
                          int64_t ntargets, int update_potential, int walk_mode);
 int shq_launch_grav_postprocess(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active,

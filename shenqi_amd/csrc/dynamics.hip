@@ -10,7 +10,10 @@
  * (drift.cpp:32-53) and do_hydro_kick.  The integer time line (Ti_drift, Ti_kick) stays with the host. */
 #include "common.hpp"
 #include <string.h>
+#include <cstring>
 #include <vector>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 namespace {
 
@@ -99,6 +102,100 @@ template <typename T> T *wfield(const shq_part_view *v, int64_t i, size_t off)
     return reinterpret_cast<T *>(static_cast<char *>(v->base) + (size_t) i * v->elsize + off);
 }
 
+/* is_timebin_active, timestep.cpp:132-139 (dti_from_timebin(bin) = 1 << bin, timebinmgr.h:42-45) */
+__device__ __forceinline__ bool timebin_active(int bin, long long Ti)
+{
+    if(bin <= 0 || Ti <= 0)
+        return true;
+    return (Ti & ((1ll << bin) - 1)) == 0; /* Ti > 0: Ti % 2^bin == 0 */
+}
+
+constexpr int ACT_NB = 6 * (SHQ_TIMEBINS + 1);
+
+/* ActivePredicate (timestep.cpp:1265-1282) as a flag per particle, plus the TimeBinCountType / NumActiveGravity /
+ * NumActiveHydro tallies of build_active_particles (timestep.cpp:1296-1343). counts: [ACT_NB] bins, then
+ * nactivegrav, nactivehydro.  all != 0 is the PM-step branch: every particle is on the list, the tally skips
+ * garbage / swallowed ones and nactivehydro counts every type-0/5 record. */
+__global__ __launch_bounds__(256) void active_flag_kernel(long long n, const uint8_t *__restrict__ pflags, const uint8_t *__restrict__ bin_grav,
+                                                           const uint8_t *__restrict__ bin_hydro, long long Ti, int all, uint8_t *flag,
+                                                           unsigned long long *counts)
+{
+    __shared__ unsigned int hist[ACT_NB + 2];
+    for(int k = threadIdx.x; k < ACT_NB + 2; k += blockDim.x)
+        hist[k] = 0;
+    __syncthreads();
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) {
+        const unsigned f = pflags[i];
+        const int type = f >> 4;
+        const bool dead = (f & 3u) != 0;
+        const bool hydro_particle = type == 0 || type == 5;
+        const int bg = bin_grav[i], bh = bin_hydro[i];
+        const bool ga = timebin_active(bg, Ti);
+        const bool on = all ? true : (!dead && (ga || (hydro_particle && timebin_active(bh, Ti))));
+        flag[i] = on ? 1 : 0;
+        if(all && hydro_particle)
+            atomicAdd(&hist[ACT_NB + 1], 1u);
+        if(on && !dead && type < 6) {
+            if(!all) {
+                if(ga)
+                    atomicAdd(&hist[ACT_NB], 1u);
+                if(hydro_particle)
+                    atomicAdd(&hist[ACT_NB + 1], 1u);
+            }
+            atomicAdd(&hist[(SHQ_TIMEBINS + 1) * type + (hydro_particle ? bh : bg)], 1u);
+        }
+    }
+    __syncthreads();
+    for(int k = threadIdx.x; k < ACT_NB + 2; k += blockDim.x)
+        if(hist[k])
+            atomicAdd(&counts[k], (unsigned long long) hist[k]);
+}
+
+/* SubActivePredicate, timestep.cpp:1354-1371 */
+struct SubActive {
+    const uint8_t *pflags, *bin_grav;
+    long long Ti;
+    int maxtimebin;
+    __device__ bool operator()(const int pi) const
+    {
+        const int bin = bin_grav[pi];
+        if(pflags[pi] & 3u)
+            return false;
+        if(bin > maxtimebin)
+            return false;
+        return timebin_active(bin, Ti);
+    }
+};
+
+template <typename In> int select_flagged(shq_context *ctx, In in, const uint8_t *flags, int32_t *out, size_t n, int64_t *count)
+{
+    size_t tmp = 0;
+    size_t *d_count = reinterpret_cast<size_t *>(ctx->act_counts.ptr + ACT_NB + 2);
+    SHQ_HIP(rocprim::select(nullptr, tmp, in, flags, out, d_count, n, ctx->stream));
+    SHQ_TRY(ctx->act_temp.reserve(tmp + 16));
+    SHQ_HIP(rocprim::select((void *) ctx->act_temp.ptr, tmp, in, flags, out, d_count, n, ctx->stream));
+    size_t h = 0;
+    SHQ_HIP(hipMemcpyAsync(&h, d_count, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    *count = (int64_t) h;
+    return SHQ_OK;
+}
+
+template <typename In> int select_if(shq_context *ctx, In in, SubActive pred, int32_t *out, size_t n, int64_t *count)
+{
+    size_t tmp = 0;
+    size_t *d_count = reinterpret_cast<size_t *>(ctx->act_counts.ptr + ACT_NB + 2);
+    SHQ_HIP(rocprim::select(nullptr, tmp, in, out, d_count, n, pred, ctx->stream));
+    SHQ_TRY(ctx->act_temp.reserve(tmp + 16));
+    SHQ_HIP(rocprim::select((void *) ctx->act_temp.ptr, tmp, in, out, d_count, n, pred, ctx->stream));
+    size_t h = 0;
+    SHQ_HIP(hipMemcpyAsync(&h, d_count, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    *count = (int64_t) h;
+    return SHQ_OK;
+}
+
 } // namespace
 
 extern "C" int shq_dynamics_upload(shq_context *ctx, const shq_part_view *parts)
@@ -110,7 +207,7 @@ extern "C" int shq_dynamics_upload(shq_context *ctx, const shq_part_view *parts)
     const int64_t n = parts->numpart;
     const size_t cap = (size_t) (n > 0 ? n : 1);
     std::vector<double> vel(3 * cap), hsml(cap, 0.0), dth(cap, 0.0);
-    std::vector<uint8_t> bg(cap, 0);
+    std::vector<uint8_t> bg(cap, 0), bh(cap, 0);
     int bad = 0;
     for(int64_t i = 0; i < n; i++) {
         const double *v = cfield<double>(parts, i, parts->off_vel);
@@ -123,7 +220,9 @@ extern "C" int shq_dynamics_upload(shq_context *ctx, const shq_part_view *parts)
             dth[i] = *cfield<double>(parts, i, parts->off_dthsml);
         if(parts->off_timebin_gravity != SHQ_NOFIELD)
             bg[i] = *cfield<uint8_t>(parts, i, parts->off_timebin_gravity);
-        if(bg[i] > SHQ_TIMEBINS)
+        if(parts->off_timebin_hydro != SHQ_NOFIELD)
+            bh[i] = *cfield<uint8_t>(parts, i, parts->off_timebin_hydro);
+        if(bg[i] > SHQ_TIMEBINS || bh[i] > SHQ_TIMEBINS)
             bad |= 1;
     }
     SHQ_CHECK(!bad, SHQ_ERR_INVALID, "time bin out of range (TIMEBINS = %d)", SHQ_TIMEBINS);
@@ -131,15 +230,160 @@ extern "C" int shq_dynamics_upload(shq_context *ctx, const shq_part_view *parts)
     SHQ_TRY(ctx->hsml.reserve(cap));
     SHQ_TRY(ctx->dthsml.reserve(cap));
     SHQ_TRY(ctx->bin_grav.reserve(cap));
+    SHQ_TRY(ctx->bin_hydro.reserve(cap));
     SHQ_TRY(ctx->pm_oob.reserve(4));
     if(n > 0) {
         SHQ_HIP(hipMemcpyAsync(ctx->vel.ptr, vel.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
         SHQ_HIP(hipMemcpyAsync(ctx->hsml.ptr, hsml.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
         SHQ_HIP(hipMemcpyAsync(ctx->dthsml.ptr, dth.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
         SHQ_HIP(hipMemcpyAsync(ctx->bin_grav.ptr, bg.data(), n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(ctx->bin_hydro.ptr, bh.data(), n, hipMemcpyHostToDevice, ctx->stream));
     }
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     ctx->have_dyn = true;
+    ctx->n_act = ctx->n_sub = -1;
+    return SHQ_OK;
+}
+
+int shq_resolve_active(shq_context *ctx, const int32_t *active, int64_t nactive, int64_t n_all, const int32_t **d_active, int64_t *nt)
+{
+    *d_active = nullptr;
+    *nt = n_all;
+    if(!active)
+        return SHQ_OK;
+    if(active == SHQ_ACTIVE_RESIDENT || active == SHQ_SUBLIST_RESIDENT) {
+        const bool sub = active == SHQ_SUBLIST_RESIDENT;
+        SHQ_CHECK((sub ? ctx->n_sub : ctx->n_act) >= 0, SHQ_ERR_STATE, "no resident active %s: call shq_build_active_%s first",
+                  sub ? "sub-list" : "list", sub ? "sublist" : "particles");
+        if(sub) {
+            *d_active = ctx->act_sub.ptr;
+            *nt = ctx->n_sub;
+        } else if(!ctx->act_all) {
+            *d_active = ctx->act_list.ptr;
+            *nt = ctx->n_act;
+        } else
+            *nt = std::min<int64_t>(n_all, ctx->n_act); /* PM step: ActiveParticle == NULL, everything is active */
+        return SHQ_OK;
+    }
+    SHQ_CHECK(nactive >= 0, SHQ_ERR_INVALID, "bad active list length %ld", (long) nactive);
+    for(int64_t k = 0; k < nactive; k++)
+        SHQ_CHECK(active[k] >= 0 && active[k] < ctx->numpart, SHQ_ERR_INVALID, "active[%ld] = %d out of range", (long) k, active[k]);
+    SHQ_TRY(ctx->active.reserve((size_t) std::max<int64_t>(nactive, 1)));
+    if(nactive > 0)
+        SHQ_HIP(hipMemcpyAsync(ctx->active.ptr, active, sizeof(int32_t) * nactive, hipMemcpyHostToDevice, ctx->stream));
+    *d_active = ctx->active.ptr;
+    *nt = nactive;
+    return SHQ_OK;
+}
+
+extern "C" int shq_timebins_upload(shq_context *ctx, const uint8_t *bin_gravity, const uint8_t *bin_hydro)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "timebins_upload: upload particles first");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t n = ctx->numpart;
+    const size_t cap = (size_t) (n > 0 ? n : 1);
+    for(int w = 0; w < 2; w++) {
+        const uint8_t *src = w ? bin_hydro : bin_gravity;
+        DevBuf<uint8_t> &dst = w ? ctx->bin_hydro : ctx->bin_grav;
+        const bool fresh = dst.ptr == nullptr || dst.cap < cap;
+        if(!src && !fresh)
+            continue;
+        if(src)
+            for(int64_t i = 0; i < n; i++)
+                SHQ_CHECK(src[i] <= SHQ_TIMEBINS, SHQ_ERR_INVALID, "time bin %d of particle %ld out of range (TIMEBINS = %d)", src[i], (long) i, SHQ_TIMEBINS);
+        SHQ_TRY(dst.reserve(cap));
+        if(src && n > 0)
+            SHQ_HIP(hipMemcpyAsync(dst.ptr, src, (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+        else
+            SHQ_HIP(hipMemsetAsync(dst.ptr, 0, cap, ctx->stream));
+    }
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->n_act = ctx->n_sub = -1;
+    return SHQ_OK;
+}
+
+extern "C" int shq_build_active_particles(shq_context *ctx, int64_t Ti_Current, int is_pm_step, shq_active_info *info)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_CHECK(ctx->have_parts && ctx->bin_grav.ptr && ctx->bin_hydro.ptr, SHQ_ERR_STATE,
+              "build_active_particles: upload particles and time bins (shq_dynamics_upload / shq_timebins_upload) first");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t n = ctx->numpart;
+    SHQ_CHECK(n < (1ll << 31) - 64, SHQ_ERR_INVALID, "build_active_particles: too many particles");
+    const size_t cap = (size_t) (n > 0 ? n : 1);
+    SHQ_TRY(ctx->act_counts.reserve(ACT_NB + 4));
+    SHQ_TRY(ctx->act_list.reserve(cap));
+    SHQ_TRY(ctx->act_flag.reserve(cap));
+    SHQ_HIP(hipMemsetAsync(ctx->act_counts.ptr, 0, sizeof(unsigned long long) * (ACT_NB + 4), ctx->stream));
+    ctx->n_act = ctx->n_sub = -1;
+    if(n > 0) {
+        active_flag_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(n, ctx->pflags.ptr, ctx->bin_grav.ptr, ctx->bin_hydro.ptr,
+                                                                        (long long) Ti_Current, is_pm_step ? 1 : 0, ctx->act_flag.ptr,
+                                                                        ctx->act_counts.ptr);
+        SHQ_HIP(hipGetLastError());
+    }
+    int64_t nact = n;
+    if(!is_pm_step) {
+        nact = 0;
+        if(n > 0)
+            SHQ_TRY(select_flagged(ctx, rocprim::counting_iterator<int32_t>(0), (const uint8_t *) ctx->act_flag.ptr, ctx->act_list.ptr, (size_t) n, &nact));
+    }
+    unsigned long long h[ACT_NB + 2];
+    SHQ_HIP(hipMemcpyAsync(h, ctx->act_counts.ptr, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->act_all = is_pm_step != 0;
+    ctx->n_act = nact;
+    if(info) {
+        info->NumActiveParticle = nact;
+        info->NumActiveGravity = is_pm_step ? n : (int64_t) h[ACT_NB];
+        info->NumActiveHydro = (int64_t) h[ACT_NB + 1];
+        for(int k = 0; k < ACT_NB; k++)
+            info->TimeBinCountType[k] = (int64_t) h[k];
+    }
+    return SHQ_OK;
+}
+
+extern "C" int shq_build_active_sublist(shq_context *ctx, int maxtimebin, int64_t Ti_Current, int64_t *nsub)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_CHECK(ctx->n_act >= 0, SHQ_ERR_STATE, "build_active_sublist: call shq_build_active_particles first");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t n = ctx->n_act;
+    SHQ_TRY(ctx->act_sub.reserve((size_t) (n > 0 ? n : 1)));
+    const SubActive pred{ctx->pflags.ptr, ctx->bin_grav.ptr, (long long) Ti_Current, maxtimebin};
+    int64_t cnt = 0;
+    ctx->n_sub = -1;
+    if(n > 0) {
+        if(ctx->act_all)
+            SHQ_TRY(select_if(ctx, rocprim::counting_iterator<int32_t>(0), pred, ctx->act_sub.ptr, (size_t) n, &cnt));
+        else
+            SHQ_TRY(select_if(ctx, (const int32_t *) ctx->act_list.ptr, pred, ctx->act_sub.ptr, (size_t) n, &cnt));
+    }
+    ctx->n_sub = cnt;
+    if(nsub)
+        *nsub = cnt;
+    return SHQ_OK;
+}
+
+extern "C" int shq_active_download(shq_context *ctx, int sublist, int32_t *list, int64_t capacity, int64_t *count)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    const int64_t n = sublist ? ctx->n_sub : ctx->n_act;
+    SHQ_CHECK(n >= 0, SHQ_ERR_STATE, "active_download: no resident list");
+    if(count)
+        *count = n;
+    if(!list)
+        return SHQ_OK;
+    SHQ_CHECK(capacity >= n, SHQ_ERR_INVALID, "active_download: capacity %ld < %ld", (long) capacity, (long) n);
+    SHQ_HIP(hipSetDevice(ctx->device));
+    if(!sublist && ctx->act_all) { /* the reference keeps ActiveParticle == NULL here; hand out the identity */
+        for(int64_t i = 0; i < n; i++)
+            list[i] = (int32_t) i;
+        return SHQ_OK;
+    }
+    if(n > 0)
+        SHQ_HIP(hipMemcpy(list, sublist ? ctx->act_sub.ptr : ctx->act_list.ptr, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
     return SHQ_OK;
 }
 
@@ -186,16 +430,10 @@ extern "C" int shq_kick_short(shq_context *ctx, const double gravkick[SHQ_TIMEBI
     KickTab tab;
     memcpy(tab.k, gravkick, sizeof(tab.k));
     const int32_t *d_act = nullptr;
-    long long nt = ctx->numpart;
-    if(active) {
-        nt = nactive;
-        SHQ_TRY(ctx->active.reserve((size_t) (nactive > 0 ? nactive : 1)));
-        if(nactive > 0)
-            SHQ_HIP(hipMemcpyAsync(ctx->active.ptr, active, sizeof(int32_t) * nactive, hipMemcpyHostToDevice, ctx->stream));
-        d_act = ctx->active.ptr;
-    }
+    int64_t nt = 0;
+    SHQ_TRY(shq_resolve_active(ctx, active, nactive, ctx->numpart, &d_act, &nt));
     if(nt > 0) {
-        kick_short_kernel<<<dim3(nblk(nt)), dim3(256), 0, ctx->stream>>>(nt, d_act, ctx->vel.ptr, acc, ctx->pflags.ptr, ctx->bin_grav.ptr, tab);
+        kick_short_kernel<<<dim3(nblk(nt)), dim3(256), 0, ctx->stream>>>((long long) nt, d_act, ctx->vel.ptr, acc, ctx->pflags.ptr, ctx->bin_grav.ptr, tab);
         SHQ_HIP(hipGetLastError());
     }
     SHQ_HIP(hipStreamSynchronize(ctx->stream));

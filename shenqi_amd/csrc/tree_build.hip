@@ -514,7 +514,10 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
     hipStream_t st = ctx->stream;
     TreeBuildBufs &b = ctx->tb;
     const long long np = ctx->numpart;
-    const long long ncand = active ? nactive : np;
+    const int32_t *d_cand = nullptr;
+    int64_t ncand_ = 0;
+    SHQ_TRY(shq_resolve_active(ctx, active, nactive, np, &d_cand, &ncand_));
+    const long long ncand = ncand_;
     SHQ_CHECK(ncand < (1ll << 31) - 64, SHQ_ERR_INVALID, "tree_build: too many particles");
     ctx->have_tree = false;
     ctx->have_tree_targets = false;
@@ -528,12 +531,6 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
     SHQ_TRY(b.idx[1].reserve(pcap));
     SHQ_TRY(b.counters.reserve(4));
     SHQ_HIP(hipMemsetAsync(b.counters.ptr, 0, sizeof(unsigned long long) * 4, st));
-    const int32_t *d_cand = nullptr;
-    if(active && nactive > 0) {
-        SHQ_TRY(ctx->active.reserve((size_t) nactive));
-        SHQ_HIP(hipMemcpyAsync(ctx->active.ptr, active, sizeof(int32_t) * nactive, hipMemcpyHostToDevice, st));
-        d_cand = ctx->active.ptr;
-    }
     if(ncand > 0) {
         tb_key_kernel<<<dim3(nblk(ncand)), dim3(256), 0, st>>>(ncand, d_cand, ctx->posm.ptr, ctx->pflags.ptr, mask, BoxSize,
                                                                b.keys[0].ptr, b.idx[0].ptr);

@@ -174,3 +174,111 @@ def test_dynamics_empty(ctx):
     sq.dynamics_download(ctx, pman)
     st = sq.tree_build_device(ctx, cm.BOX)
     assert st.nparticles == 0
+
+
+def ref_timebin_active(bins, Ti):
+    """is_timebin_active, timestep.cpp:132-139."""
+    bins = bins.astype(np.int64)
+    return (bins <= 0) | (Ti <= 0) | (Ti % (np.int64(1) << np.maximum(bins, 0)) == 0)
+
+
+def ref_active(P, Ti, pm_step):
+    """build_active_particles, timestep.cpp:1286-1349: (list or None, NumActiveGravity, NumActiveHydro, TimeBinCountType)."""
+    n = len(P)
+    dead = (P["Flags"] & 3) != 0
+    hydro = (P["Type"] == 0) | (P["Type"] == 5)
+    ga = ref_timebin_active(P["TimeBinGravity"], Ti)
+    counts = np.zeros((6, capi.TIMEBINS + 1), dtype=np.int64)
+    bins = np.where(hydro, P["TimeBinHydro"], P["TimeBinGravity"])
+    if pm_step:
+        keep = ~dead
+        np.add.at(counts, (P["Type"][keep], bins[keep]), 1)
+        return None, n, int(hydro.sum()), counts.ravel()
+    on = ~dead & (ga | (hydro & ref_timebin_active(P["TimeBinHydro"], Ti)))
+    act = np.nonzero(on)[0].astype(np.int32)
+    np.add.at(counts, (P["Type"][act], bins[act]), 1)
+    return act, int(ga[act].sum()), int(hydro[act].sum()), counts.ravel()
+
+
+@pytest.mark.parametrize("Ti", [0, 1 << 22, 3 << 20, (1 << 26) + (1 << 21), 12345])
+def test_active_lists_equal_reference(ctx, Ti):
+    """ActivePredicate / SubActivePredicate (timestep.cpp:1265-1282, 1354-1371) on the device: same lists in the
+    same (index) order, same tallies."""
+    pman, rng = _setup(n=50001)
+    P = pman.Base
+    P["TimeBinGravity"] = rng.integers(18, 28, size=len(P)).astype(np.uint8)
+    P["TimeBinHydro"] = rng.integers(16, 26, size=len(P)).astype(np.uint8)
+    P["TimeBinGravity"][:7] = 0    # bin 0 is always active
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    sq.dynamics_upload(ctx, pman)
+    for pm_step in (False, True):
+        ract, rgrav, rhydro, rcounts = ref_active(P, Ti, pm_step)
+        info = sq.build_active_particles(ctx, Ti, pm_step)
+        got = sq.active_download(ctx)
+        want = np.arange(len(P), dtype=np.int32) if ract is None else ract
+        assert info.NumActiveParticle == len(want) and np.array_equal(got, want)
+        assert info.NumActiveGravity == rgrav and info.NumActiveHydro == rhydro
+        assert np.array_equal(np.array(info.TimeBinCountType[:]), rcounts)
+        for maxbin in (19, 22, 46):
+            dead = (P["Flags"][want] & 3) != 0
+            bg = P["TimeBinGravity"][want]
+            rsub = want[~dead & (bg <= maxbin) & ref_timebin_active(bg, Ti)]
+            assert sq.build_active_sublist(ctx, maxbin, Ti) == len(rsub)
+            assert np.array_equal(sq.active_download(ctx, sublist=True), rsub)
+
+
+def test_resident_active_list_drives_tree_walk_and_kick(ctx):
+    """SHQ_ACTIVE_RESIDENT / SHQ_SUBLIST_RESIDENT as the `active` argument give the same tree, forces and
+    velocities as the same list passed from the host."""
+    n = 24**3
+    L = cm.BOX
+    pos = sq.synth_positions("cluster", n, L=L)
+    pman = cm.make_partmanager(pos)
+    rng = np.random.default_rng(5)
+    P = pman.Base
+    P["TimeBinGravity"] = rng.integers(20, 24, size=n).astype(np.uint8)
+    P["Vel"] = rng.normal(size=(n, 3))
+    Ti = 1 << 22
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=1)
+    sq.gravshort_set_softenings(L / 24 / 30)
+    gp = sq.make_grav_params(L, 1.5, 72, cm.G, cm.RHO0)
+    gk = np.zeros(capi.TIMEBINS + 1)
+    gk[20:24] = [1e-3, 2e-3, 4e-3, 8e-3]
+    pv = pman.view()
+    out = []
+    vel0 = P["Vel"].copy()
+    for resident in (False, True):
+        P["Vel"] = vel0
+        capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+        sq.dynamics_upload(ctx, pman)
+        sq.build_active_particles(ctx, Ti)
+        nsub = sq.build_active_sublist(ctx, 21, Ti)
+        sub = sq.active_download(ctx, sublist=True)
+        assert 0 < nsub < sq.active_download(ctx).size < n
+        if resident:
+            act, nact = capi.SUBLIST_RESIDENT, 0
+            sq.tree_build_device(ctx, L, sq.ALLMASK, sq.RESIDENT)
+        else:
+            act, nact = capi.ptr(sub), len(sub)
+            sq.tree_build_device(ctx, L, sq.ALLMASK, sq.active_download(ctx))
+        capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), act, nact, 1, sq.WALK_EXACT))
+        acc = np.zeros((n, 3)); pot = np.zeros(n); nint = np.zeros(n, dtype=np.int64)
+        capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), capi.ptr(pot), capi.ptr(nint), None))
+        sq.kick_short(ctx, gk, sq.RESIDENT_SUB if resident else sub)
+        sq.dynamics_download(ctx, pman)
+        out.append((acc[sub].copy(), pot[sub].copy(), nint[sub].copy(), P["Vel"].copy()))
+    assert np.abs(out[0][0]).max() > 0 and not np.array_equal(out[0][3], vel0)
+    for x, y in zip(out[0], out[1]):
+        assert np.array_equal(x, y)
+
+
+def test_resident_active_list_requires_build(ctx):
+    pman, _ = _setup(n=100)
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    sq.dynamics_upload(ctx, pman)
+    with pytest.raises(sq.ShqError):
+        sq.tree_build_device(ctx, cm.BOX, sq.ALLMASK, sq.RESIDENT)
+    with pytest.raises(sq.ShqError):
+        sq.active_download(ctx)
