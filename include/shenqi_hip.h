@@ -294,6 +294,37 @@ typedef struct shq_grav_result {
 } shq_grav_result;
 int shq_grav_short_secondary(shq_context *ctx, const shq_grav_params *params, const shq_grav_query *queries, int64_t nq,
                              shq_grav_result *results, int64_t *ninteractions, int update_potential);
+/* ---- top-tree walk: which remote top-leaves must a target visit ----
+ * The reference's ev_count_exports + ev_toptree (treewalk2.cuh:243-334) for the host's own export / import
+ * machinery (treewalk2.h:618-812): per target, walk only the TopLevel nodes of the host tree; every pseudo node
+ * that the walk would open becomes an export, consecutive leaves of one task coalescing into NodeList[4]
+ * (TopTreeWalk::export_particle / export_count, localtreewalk2.h:269-324).
+ *
+ * shq_toptree_upload: the TopLevel nodes of `tree` and the domain's TopLeaves table (pseudo node suns[0] - lastnode
+ *     indexes it).  Only needed when the tree has pseudo nodes; independent of shq_tree_upload.
+ * shq_grav_toptree_exports: GravTopTreeWalk::toptree_visit (gravshort2.hpp:362-438) for the resident targets
+ *     (positions, OldAcc as for shq_grav_short_run).
+ * shq_ngb_toptree_exports: TopTreeWalk::toptree_visit with cull_node<symmetric> (localtreewalk2.h:154-182, 210-259),
+ *     search radius = the resident Hsml (density: symmetric 0; hydro: symmetric 1, needs the top nodes' hmax).
+ * Outputs: exportcounts[t] = inclusive running total of exports up to target t (the reference's scanned
+ * exportcounts, used by its BunchSize logic; may be NULL); table = the DataIndexTable, target t's entries contiguous at
+ * [exportcounts[t-1], exportcounts[t]) in the reference's order; *nexport always returns the total.  With table == NULL
+ * only counts are produced; with capacity < total nothing is written and SHQ_ERR_NOMEM is returned. */
+typedef struct shq_topleaf {   /* struct topleaf_data, libgadget/domain.h:20-24 */
+    int32_t Task;
+    int32_t topnode;
+    int32_t treenode;
+} shq_topleaf;
+typedef struct shq_data_index { /* struct data_index, libgadget/localtreewalk2.h:188-193 */
+    int32_t Task;
+    int32_t Index;
+    int32_t NodeList[4];
+} shq_data_index;
+int shq_toptree_upload(shq_context *ctx, const shq_tree_view *tree, const shq_topleaf *topleaves, int ntopleaves);
+int shq_grav_toptree_exports(shq_context *ctx, const shq_grav_params *params, const int32_t *active, int64_t nactive,
+                             int32_t *exportcounts, shq_data_index *table, int64_t capacity, int64_t *nexport);
+int shq_ngb_toptree_exports(shq_context *ctx, int symmetric, double BoxSize, const int32_t *active, int64_t nactive,
+                            int32_t *exportcounts, shq_data_index *table, int64_t capacity, int64_t *nexport);
 /* Set the per-particle OldAcc inputs on the device from the device-resident
  * FullTreeGravAccel + GravPM of the last shq_grav_short_run / shq_pm_run
  * (grav_get_abs_accel, gravshort2.hpp:111-121). */

@@ -40,6 +40,16 @@ int64_t orc_tree_build(const double *pos, const float *mass, const double *hsml,
 void orc_grav_walk_secondary(const shq_node *nodes, int64_t firstnode, const double *pos, const float *mass,
                              const double *qpos, const int32_t *qnodelist, const double *qoldacc, int64_t nq,
                              const shq_grav_params *p, double *acc_out, double *pot_out, int64_t *nint_out);
+/* Top-tree walks (toptree.cpp): GravTopTreeWalk::toptree_visit (gravshort2.hpp:362-438) and
+ * TopTreeWalk::toptree_visit (localtreewalk2.h:210-259) with export_particle (:269-312), one target after the other.
+ * counts[t] = exports of target t; table (capacity entries) receives them in target order; returns the total
+ * (table may be NULL to count only: export_count, :315-324). */
+int64_t orc_grav_toptree(const shq_node *nodes, int64_t firstnode, int64_t lastnode, const shq_topleaf *topleaves,
+                         const double *pos, const double *oldacc, const int32_t *targets, int64_t ntargets,
+                         const shq_grav_params *p, int32_t *counts, shq_data_index *table, int64_t capacity);
+int64_t orc_ngb_toptree(const shq_node *nodes, int64_t firstnode, int64_t lastnode, const shq_topleaf *topleaves,
+                        const double *pos, const double *hsml, int symmetric, double BoxSize, const int32_t *targets,
+                        int64_t ntargets, int32_t *counts, shq_data_index *table, int64_t capacity);
 void orc_grav_walk(const shq_node *nodes, int64_t firstnode, const double *pos,
                    const float *mass, const double *oldacc, const int32_t *targets,
                    int64_t ntargets, const shq_grav_params *p, double *acc_out,

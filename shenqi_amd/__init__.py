@@ -136,6 +136,43 @@ def _active_arg(active):
     return capi.ptr(act), len(act)
 
 
+def toptree_upload(ctx, tree, topleaves):
+    """shq_toptree_upload: the TopLevel nodes of the host tree + the domain's TopLeaves (capi.TOPLEAF_DTYPE)."""
+    tl = np.ascontiguousarray(topleaves, dtype=capi.TOPLEAF_DTYPE)
+    tv = tree.view()
+    capi.check(capi.hip.shq_toptree_upload(ctx.h, C.byref(tv), capi.ptr(tl), len(tl)), "shq_toptree_upload")
+
+
+def _toptree_exports(call, active):
+    act, nact = _active_arg(active)
+    n = C.c_int64()
+    capi.check(call(act, nact, None, None, 0, C.byref(n)))
+    return act, nact, n.value
+
+
+def grav_toptree_exports(ctx, gp, ntargets, active=None):
+    """shq_grav_toptree_exports: (exportcounts [ntargets] inclusive scan, DataIndexTable) of
+    GravTopTreeWalk::toptree_visit (libgadget/gravshort2.hpp:362-438)."""
+    call = lambda a, na, cnt, tab, cap, n: capi.hip.shq_grav_toptree_exports(ctx.h, C.byref(gp), a, na, cnt, tab, cap, n)
+    act, nact, total = _toptree_exports(call, active)
+    counts = np.zeros(ntargets, dtype=np.int32)
+    table = np.zeros(total, dtype=capi.DATA_INDEX_DTYPE)
+    n = C.c_int64()
+    capi.check(call(act, nact, capi.ptr(counts), capi.ptr(table), total, C.byref(n)), "shq_grav_toptree_exports")
+    return counts, table
+
+
+def ngb_toptree_exports(ctx, symmetric, BoxSize, ntargets, active=None):
+    """shq_ngb_toptree_exports: TopTreeWalk::toptree_visit with cull_node (libgadget/localtreewalk2.h:210-259)."""
+    call = lambda a, na, cnt, tab, cap, n: capi.hip.shq_ngb_toptree_exports(ctx.h, int(symmetric), float(BoxSize), a, na, cnt, tab, cap, n)
+    act, nact, total = _toptree_exports(call, active)
+    counts = np.zeros(ntargets, dtype=np.int32)
+    table = np.zeros(total, dtype=capi.DATA_INDEX_DTYPE)
+    n = C.c_int64()
+    capi.check(call(act, nact, capi.ptr(counts), capi.ptr(table), total, C.byref(n)), "shq_ngb_toptree_exports")
+    return counts, table
+
+
 def timebins_upload(ctx, bin_gravity=None, bin_hydro=None):
     bg = None if bin_gravity is None else np.ascontiguousarray(bin_gravity, dtype=np.uint8)
     bh = None if bin_hydro is None else np.ascontiguousarray(bin_hydro, dtype=np.uint8)

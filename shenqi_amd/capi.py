@@ -209,6 +209,14 @@ GRAV_QUERY_DTYPE = np.dtype({"names": ["Pos", "NodeList", "OldAcc"], "formats": 
 GRAV_RESULT_DTYPE = np.dtype({"names": ["Acc", "Potential"], "formats": [("<f8", 3), "<f8"], "offsets": [0, 24], "itemsize": 32})
 hip.shq_grav_short_secondary.argtypes = [_vp, C.POINTER(GravParams), _vp, C.c_int64, _vp, _vp, C.c_int]
 hip.shq_grav_short_secondary.restype = C.c_int
+TOPLEAF_DTYPE = np.dtype([("Task", "<i4"), ("topnode", "<i4"), ("treenode", "<i4")])
+DATA_INDEX_DTYPE = np.dtype([("Task", "<i4"), ("Index", "<i4"), ("NodeList", "<i4", 4)])
+hip.shq_toptree_upload.argtypes = [_vp, C.POINTER(TreeView), _vp, C.c_int]
+hip.shq_toptree_upload.restype = C.c_int
+hip.shq_grav_toptree_exports.argtypes = [_vp, C.POINTER(GravParams), _vp, C.c_int64, _vp, _vp, C.c_int64, C.POINTER(C.c_int64)]
+hip.shq_grav_toptree_exports.restype = C.c_int
+hip.shq_ngb_toptree_exports.argtypes = [_vp, C.c_int, C.c_double, _vp, C.c_int64, _vp, _vp, C.c_int64, C.POINTER(C.c_int64)]
+hip.shq_ngb_toptree_exports.restype = C.c_int
 hip.shq_set_walk_stats.argtypes = [_vp, C.c_int]
 hip.shq_set_walk_stats.restype = C.c_int
 hip.shq_pm_slab_pitch.argtypes = [C.c_int]

@@ -124,7 +124,8 @@ extern "C" void shq_shutdown(shq_context *ctx)
     shq_pm_destroy_plans(ctx);
     ctx->posm.release(); ctx->oldacc.release(); ctx->treeacc.release(); ctx->gravpm.release();
     ctx->pmpot.release(); ctx->acc.release(); ctx->pot.release(); ctx->nint.release();
-    ctx->pflags.release(); ctx->active.release(); ctx->act_list.release(); ctx->act_sub.release(); ctx->act_counts.release(); ctx->act_temp.release(); ctx->act_flag.release(); ctx->gstats.release();
+    ctx->pflags.release(); ctx->active.release(); ctx->act_list.release(); ctx->act_sub.release(); ctx->act_counts.release(); ctx->act_temp.release(); ctx->act_flag.release();
+    ctx->topnodes.release(); ctx->topleaves.release(); ctx->top_counts.release(); ctx->top_table.release(); ctx->gstats.release();
     ctx->nodeA.release(); ctx->nodeB.release(); ctx->nodeC.release(); ctx->nodeG.release();
     ctx->posm_leaf.release(); ctx->leaf_pidx.release();
     ctx->mesh.release(); ctx->sinctab.release(); ctx->dbg_rho.release(); ctx->dbg_pot.release();
@@ -284,6 +285,7 @@ extern "C" int shq_particles_upload(shq_context *ctx, const shq_part_view *parts
     ctx->tb_built = false;
     ctx->have_sph = false;  /* Hsml / Vel / slot data of the previous particle set */
     ctx->have_dyn = false;
+    ctx->have_toptree = false;
     ctx->n_act = ctx->n_sub = -1;
     ctx->have_pm_result = false;
     return SHQ_OK;
@@ -503,6 +505,7 @@ extern "C" int shq_particles_set_device(shq_context *ctx, const void *d_posm, in
     ctx->have_tree_targets = false; /* nlocal may have changed */
     ctx->have_sph = false;
     ctx->have_dyn = false;
+    ctx->have_toptree = false;
     ctx->n_act = ctx->n_sub = -1;
     ctx->numpart = n;
     ctx->nlocal = nlocal;

@@ -118,6 +118,18 @@ struct alignas(128) NodeG {
 };
 static_assert(sizeof(NodeG) == 128, "NodeG must be one 128-byte line");
 
+/* One TopLevel node of the host tree for the export-detection walk (toptree.hip) */
+struct alignas(32) TopNodeG {
+    double cofm[3], mass;
+    double center[3], len;
+    double hmax;
+    int32_t sibling, child; /* indices into the top-node array (pre-order), -1 = end */
+    int32_t kind;           /* 0 internal top-level node, 1 local top-level leaf, 2 pseudo node */
+    int32_t leaf;           /* pseudo: index into TopLeaves */
+    double pad;
+};
+static_assert(sizeof(TopNodeG) == 96, "TopNodeG layout");
+
 struct GravStatsDev {
     unsigned long long ninteractions;
     unsigned long long nvisited;
@@ -205,6 +217,12 @@ struct shq_context {
     DevBuf<int32_t> nint;      /* [N] interactions */
     DevBuf<uint8_t> pflags;    /* bit0 garbage, bit1 swallowed; bits 4-7 type */
     DevBuf<int32_t> active;    /* uploaded active list */
+    DevBuf<TopNodeG> topnodes;
+    DevBuf<int2> topleaves;
+    DevBuf<int32_t> top_counts;
+    DevBuf<shq_data_index> top_table;
+    int64_t ntopnodes = 0;
+    bool have_toptree = false;
     DevBuf<int32_t> act_list, act_sub;   /* resident ActiveParticle list and gravity sub-list (shq_build_active_*) */
     DevBuf<unsigned long long> act_counts;
     DevBuf<char> act_temp;

@@ -410,6 +410,7 @@ extern "C" int shq_drift(shq_context *ctx, double ddrift, double BoxSize, const 
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     /* positions moved: the tree, its leaf-ordered copies and the PM result are stale */
     ctx->have_tree = false;
+    ctx->have_toptree = false;
     ctx->tb_built = false;
     ctx->have_tree_targets = false;
     ctx->have_pm_result = false;

@@ -146,3 +146,38 @@ def density_close_positions(ncbrt=32, box=BOX, close=500.0):
     pos[numpart // 4:, 1] = 4.1 + ((i // ncbrt) % ncbrt) / close
     pos[numpart // 4:, 2] = 4.1 + (i % ncbrt) / close
     return pos, hsml
+
+
+def make_domain(tree, ntask=3, me=1, depth=2, pseudo=True):
+    """Give a single-domain host tree the top tree a domain decomposition would (forcetree.cpp:1155-1206):
+    the nodes down to `depth` below the root become TopLevel (internal ones InternalTopLevel too), the deepest
+    of them (or shallower leaves) are the top leaves, dealt to `ntask` ranks in contiguous pre-order runs.
+    With pseudo=True the leaves of other ranks than `me` become pseudo nodes (ChildType 2, suns[0] = lastnode + leaf index):
+    the tree rank `me` would hold; with pseudo=False only the flags are set: the tree a remote rank's secondary walk
+    sees.  Returns the TopLeaves table (capi.TOPLEAF_DTYPE)."""
+    from shenqi_amd import capi
+    nodes = tree.Nodes_base
+    fn, ln = tree.firstnode, tree.lastnode
+    leaves = []
+
+    def visit(no, d):
+        nd = nodes[no - fn]
+        ctype = (nd["flags"] >> 3) & 3
+        if ctype == 1 and d < depth:
+            nodes["flags"][no - fn] |= 3          # InternalTopLevel | TopLevel
+            for s in nd["suns"]:
+                if s >= fn:
+                    visit(int(s), d + 1)
+        else:
+            nodes["flags"][no - fn] |= 2          # TopLevel leaf
+            leaves.append(no)
+
+    visit(fn, 0)
+    tl = np.zeros(len(leaves), dtype=capi.TOPLEAF_DTYPE)
+    for k, no in enumerate(leaves):
+        tl[k] = ((k * ntask) // len(leaves), k, no)
+        if pseudo and tl["Task"][k] != me:
+            f = int(nodes["flags"][no - fn])
+            nodes["flags"][no - fn] = (f & ~(3 << 3)) | (2 << 3)
+            nodes["suns"][no - fn, 0] = ln + k
+    return tl

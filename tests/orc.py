@@ -138,6 +138,38 @@ def grav_walk_secondary(nodes, firstnode, pos, mass, qpos, qnodelist, qoldacc, g
     return acc, pot, nint
 
 
+def _toptree(fn_call, ntargets):
+    counts = np.zeros(ntargets, dtype=np.int32)
+    total = fn_call(ptr(counts), None, 0)
+    assert total >= 0
+    from shenqi_amd import capi
+    table = np.zeros(total, dtype=capi.DATA_INDEX_DTYPE)
+    counts2 = np.zeros(ntargets, dtype=np.int32)
+    assert fn_call(ptr(counts2), ptr(table), total) == total and np.array_equal(counts, counts2)
+    return counts, table
+
+
+def grav_toptree(nodes, firstnode, lastnode, topleaves, pos, oldacc, gp, targets=None):
+    """GravTopTreeWalk::toptree_visit (gravshort2.hpp:362-438): (exports per target, DataIndexTable)."""
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    oldacc = np.ascontiguousarray(oldacc, dtype=np.float64)
+    nt = len(pos) if targets is None else len(targets)
+    lib.orc_grav_toptree.restype = C.c_int64
+    return _toptree(lambda c, t, cap: lib.orc_grav_toptree(ptr(nodes), C.c_int64(firstnode), C.c_int64(lastnode), ptr(topleaves), ptr(pos),
+                                                         ptr(oldacc), ptr(targets), C.c_int64(nt), C.byref(gp), c, t, C.c_int64(cap)), nt)
+
+
+def ngb_toptree(nodes, firstnode, lastnode, topleaves, pos, hsml, symmetric, BoxSize, targets=None):
+    """TopTreeWalk::toptree_visit with cull_node (localtreewalk2.h:210-259)."""
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    hsml = np.ascontiguousarray(hsml, dtype=np.float64)
+    nt = len(pos) if targets is None else len(targets)
+    lib.orc_ngb_toptree.restype = C.c_int64
+    return _toptree(lambda c, t, cap: lib.orc_ngb_toptree(ptr(nodes), C.c_int64(firstnode), C.c_int64(lastnode), ptr(topleaves), ptr(pos),
+                                                        ptr(hsml), int(symmetric), C.c_double(BoxSize), ptr(targets), C.c_int64(nt), c, t,
+                                                        C.c_int64(cap)), nt)
+
+
 def grav_postprocess(mass, gp, acc, pot, update_potential, targets=None):
     mass = np.ascontiguousarray(mass, dtype=np.float32)
     lib.orc_grav_postprocess(ptr(mass), ptr(targets), len(acc), C.byref(gp), int(update_potential), ptr(acc), ptr(pot))

@@ -277,3 +277,55 @@ def test_space_filling_orders(kind):
         step_m = np.linalg.norm(np.diff(pos[sq.morton_order(pos, L)], axis=0), axis=1)
         assert step_h.max() < 0.25 * L < step_m.max()  # no long jumps along the Hilbert curve
         assert step_h.mean() < step_m.mean()
+
+
+def test_toptree_exports_close_the_distributed_walk():
+    """Pins oracle/toptree.cpp: primary walk over a tree with pseudo nodes + secondary walks at the exported
+    NodeLists visit exactly the interactions of the walk over the undivided tree (gravshort2.hpp:243-322, 362-438),
+    and the neighbour variant exports every remote top leaf that holds a particle within the search radius."""
+    import shenqi_amd as sq
+    n1 = 14
+    n = n1**3
+    pos = sq.synth_positions("cluster", n, L=cm.BOX)
+    pman = cm.make_partmanager(pos)
+    full = sq.force_tree_full(pman)
+    cm.make_domain(full, ntask=3, me=1, depth=2, pseudo=False)
+    dom = sq.force_tree_full(pman)
+    tl = cm.make_domain(dom, ntask=3, me=1, depth=2)
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=0)
+    sq.gravshort_set_softenings(cm.BOX / n1)
+    gp = sq.make_grav_params(cm.BOX, 1.5, 3 * n1, cm.G, cm.RHO0)
+    rng = np.random.default_rng(8)
+    oldacc = 10 ** rng.uniform(0, 3, size=n)
+    mass = pman.Base["Mass"]
+    a_full, _, n_full = orc.grav_walk(full.Nodes_base, full.firstnode, pos, mass, oldacc, gp)
+    a_loc, _, n_loc = orc.grav_walk(dom.Nodes_base, dom.firstnode, pos, mass, oldacc, gp)
+    counts, table = orc.grav_toptree(dom.Nodes_base, dom.firstnode, dom.lastnode, tl, pos, oldacc, gp)
+    assert counts.sum() == len(table) > 0
+    # entries of one target are contiguous and in target order
+    assert np.array_equal(table["Index"], np.repeat(np.arange(n), counts))
+    a2, _, n2 = orc.grav_walk_secondary(full.Nodes_base, full.firstnode, pos, mass, pos[table["Index"]], table["NodeList"],
+                                        oldacc[table["Index"]], gp)
+    nsum = n_loc.copy()
+    np.add.at(nsum, table["Index"], n2)
+    assert np.array_equal(nsum, n_full)
+    asum = a_loc.copy()
+    np.add.at(asum, table["Index"], a2)
+    assert np.abs(asum - a_full).max() < 1e-12 * np.abs(a_full).max()
+    # neighbour search: no remote neighbour may be missed
+    hsml = 0.05 * cm.BOX * (0.5 + rng.random(n))
+    counts, table = orc.ngb_toptree(dom.Nodes_base, dom.firstnode, dom.lastnode, tl, pos, hsml, 0, cm.BOX)
+    nodes, fn = full.Nodes_base, full.firstnode
+    leaf_of = np.full(n, -1)
+    for k, no in enumerate(tl["treenode"]):            # particles below each top leaf, by its cell
+        nd = nodes[no - fn]
+        inside = np.all(np.abs(pos - nd["center"]) <= 0.5 * nd["len"], axis=1)
+        leaf_of[inside & (leaf_of < 0)] = k
+    start = np.concatenate([[0], np.cumsum(counts)])
+    for i in rng.choice(n, size=60, replace=False):
+        d = pos - pos[i]
+        d -= cm.BOX * np.rint(d / cm.BOX)
+        ngb = np.nonzero(np.sum(d * d, axis=1) < hsml[i] ** 2)[0]
+        need = {int(tl["treenode"][leaf_of[j]]) for j in ngb if leaf_of[j] >= 0 and tl["Task"][leaf_of[j]] != 1}
+        got = {int(x) for x in table["NodeList"][start[i]:start[i + 1]].ravel() if x >= 0}
+        assert need <= got
