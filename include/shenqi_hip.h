@@ -177,6 +177,11 @@ typedef struct shq_walk_stats {
  * particle-index order — same results per particle; keeps target groups compact when the particle
  * order has gone stale (resident stepping without the reference's periodic Peano-Hilbert re-sort) */
 #define SHQ_WALK_TREE_ORDER 0x100
+/* flag, or-ed into walk_mode: leave the raw sums of the primary walk on the device and skip
+ * GravTreeOutput::postprocess; shq_grav_reduce_export_results then adds the results of the exported queries
+ * (ev_reduce_export_result, treewalk2.h:793-812) and shq_grav_postprocess finishes (ev_postprocess, :375-382) —
+ * the order the reference's distributed walk keeps. */
+#define SHQ_WALK_DEFER_POSTPROCESS 0x200
 
 /* One-shot replacement of grav_short_tree_cuda(): walks the local tree for the `nactive`
  * targets in `active` (NULL => all particles, as ActiveParticles with a NULL list), writes
@@ -325,6 +330,15 @@ int shq_grav_toptree_exports(shq_context *ctx, const shq_grav_params *params, co
                              int32_t *exportcounts, shq_data_index *table, int64_t capacity, int64_t *nexport);
 int shq_ngb_toptree_exports(shq_context *ctx, int symmetric, double BoxSize, const int32_t *active, int64_t nactive,
                             int32_t *exportcounts, shq_data_index *table, int64_t capacity, int64_t *nexport);
+/* GravTreeResult::reduce<TREEWALK_GHOSTS> (gravshort2.hpp:136-146) for n returned results: Accel[place[k]] += results[k].Acc
+ * and, with update_potential, Potential likewise, in the order k = 0..n-1 (the reference's loop over its export table, so
+ * a target's partial sums are added in the same order).  Needs a preceding shq_grav_short_run with
+ * SHQ_WALK_DEFER_POSTPROCESS.  shq_grav_postprocess: GravTreeOutput::postprocess (gravshort2.hpp:88-107) for the
+ * targets of that run (same active argument). */
+int shq_grav_reduce_export_results(shq_context *ctx, const int32_t *place, const shq_grav_result *results, int64_t n,
+                                   int update_potential);
+int shq_grav_postprocess(shq_context *ctx, const shq_grav_params *params, const int32_t *active, int64_t nactive,
+                         int update_potential);
 /* Set the per-particle OldAcc inputs on the device from the device-resident
  * FullTreeGravAccel + GravPM of the last shq_grav_short_run / shq_pm_run
  * (grav_get_abs_accel, gravshort2.hpp:111-121). */

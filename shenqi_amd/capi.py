@@ -18,6 +18,7 @@ NOFIELD = C.c_size_t(-1).value
 
 WALK_EXACT = 0
 WALK_TREE_ORDER = 0x100
+WALK_DEFER_POSTPROCESS = 0x200
 
 
 class ShqError(RuntimeError):
@@ -211,6 +212,10 @@ hip.shq_grav_short_secondary.argtypes = [_vp, C.POINTER(GravParams), _vp, C.c_in
 hip.shq_grav_short_secondary.restype = C.c_int
 TOPLEAF_DTYPE = np.dtype([("Task", "<i4"), ("topnode", "<i4"), ("treenode", "<i4")])
 DATA_INDEX_DTYPE = np.dtype([("Task", "<i4"), ("Index", "<i4"), ("NodeList", "<i4", 4)])
+hip.shq_grav_reduce_export_results.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int]
+hip.shq_grav_reduce_export_results.restype = C.c_int
+hip.shq_grav_postprocess.argtypes = [_vp, C.POINTER(GravParams), _vp, C.c_int64, C.c_int]
+hip.shq_grav_postprocess.restype = C.c_int
 hip.shq_toptree_upload.argtypes = [_vp, C.POINTER(TreeView), _vp, C.c_int]
 hip.shq_toptree_upload.restype = C.c_int
 hip.shq_grav_toptree_exports.argtypes = [_vp, C.POINTER(GravParams), _vp, C.c_int64, _vp, _vp, C.c_int64, C.POINTER(C.c_int64)]

@@ -125,7 +125,7 @@ extern "C" void shq_shutdown(shq_context *ctx)
     ctx->posm.release(); ctx->oldacc.release(); ctx->treeacc.release(); ctx->gravpm.release();
     ctx->pmpot.release(); ctx->acc.release(); ctx->pot.release(); ctx->nint.release();
     ctx->pflags.release(); ctx->active.release(); ctx->act_list.release(); ctx->act_sub.release(); ctx->act_counts.release(); ctx->act_temp.release(); ctx->act_flag.release();
-    ctx->topnodes.release(); ctx->topleaves.release(); ctx->top_counts.release(); ctx->top_table.release(); ctx->gstats.release();
+    ctx->gq_res.release(); ctx->topnodes.release(); ctx->topleaves.release(); ctx->top_counts.release(); ctx->top_table.release(); ctx->gstats.release();
     ctx->nodeA.release(); ctx->nodeB.release(); ctx->nodeC.release(); ctx->nodeG.release();
     ctx->posm_leaf.release(); ctx->leaf_pidx.release();
     ctx->mesh.release(); ctx->sinctab.release(); ctx->dbg_rho.release(); ctx->dbg_pot.release();
@@ -531,10 +531,99 @@ extern "C" int shq_grav_short_run(shq_context *ctx, const shq_grav_params *param
         nt = ctx->ntree_targets;
     } else
         SHQ_TRY(shq_resolve_active(ctx, active, nactive, ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart, &d_active, &nt));
+    const bool defer = (walk_mode & SHQ_WALK_DEFER_POSTPROCESS) != 0;
     walk_mode &= 0xff;
     SHQ_TRY(shq_launch_grav_walk(ctx, params, d_active, nt, update_potential, walk_mode));
-    SHQ_TRY(shq_launch_grav_postprocess(ctx, params, d_active, nt, update_potential));
+    if(!defer)
+        SHQ_TRY(shq_launch_grav_postprocess(ctx, params, d_active, nt, update_potential));
+    ctx->grav_raw = defer;
     ctx->last_stats.ntargets = nt;
+    return SHQ_OK;
+}
+
+namespace {
+/* one thread per entry; the first entry of a run of equal places adds the whole run in order */
+__global__ void grav_reduce_kernel(long long n, const int32_t *__restrict__ place, const shq_grav_result *__restrict__ res, double *acc,
+                                   double *pot, int update_potential)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    const int32_t pl = place[k];
+    if(k > 0 && place[k - 1] == pl)
+        return;
+    double a0 = acc[3 * (long long) pl], a1 = acc[3 * (long long) pl + 1], a2 = acc[3 * (long long) pl + 2];
+    double p = update_potential ? pot[pl] : 0.0;
+    for(long long j = k; j < n && place[j] == pl; j++) {
+        a0 += res[j].Acc[0];
+        a1 += res[j].Acc[1];
+        a2 += res[j].Acc[2];
+        p += res[j].Potential;
+    }
+    acc[3 * (long long) pl] = a0;
+    acc[3 * (long long) pl + 1] = a1;
+    acc[3 * (long long) pl + 2] = a2;
+    if(update_potential)
+        pot[pl] = p;
+}
+} // namespace
+
+extern "C" int shq_grav_reduce_export_results(shq_context *ctx, const int32_t *place, const shq_grav_result *results, int64_t n,
+                                              int update_potential)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_CHECK(n >= 0 && (n == 0 || (place && results)), SHQ_ERR_INVALID, "reduce_export_results: bad arguments");
+    SHQ_CHECK(ctx->have_parts && ctx->grav_raw, SHQ_ERR_STATE,
+              "reduce_export_results: needs the raw sums of a shq_grav_short_run with SHQ_WALK_DEFER_POSTPROCESS");
+    if(n == 0)
+        return SHQ_OK;
+    SHQ_HIP(hipSetDevice(ctx->device));
+    /* group the entries by target, keeping their order within a target (the reference's table is built per
+     * particle, so it normally is grouped already) */
+    bool grouped = true;
+    for(int64_t k = 0; k < n; k++) {
+        SHQ_CHECK(place[k] >= 0 && place[k] < ctx->numpart, SHQ_ERR_INVALID, "reduce_export_results: place[%ld] = %d out of range", (long) k, place[k]);
+        if(k > 0 && place[k] < place[k - 1])
+            grouped = false;
+    }
+    std::vector<int32_t> hp;
+    std::vector<shq_grav_result> hr;
+    if(!grouped) {
+        std::vector<int64_t> ord((size_t) n);
+        for(int64_t k = 0; k < n; k++)
+            ord[k] = k;
+        std::stable_sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) { return place[x] < place[y]; });
+        hp.resize((size_t) n);
+        hr.resize((size_t) n);
+        for(int64_t k = 0; k < n; k++) {
+            hp[k] = place[ord[k]];
+            hr[k] = results[ord[k]];
+        }
+        place = hp.data();
+        results = hr.data();
+    }
+    SHQ_TRY(ctx->active.reserve((size_t) n));
+    SHQ_TRY(ctx->gq_res.reserve((size_t) n));
+    SHQ_HIP(hipMemcpyAsync(ctx->active.ptr, place, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    SHQ_HIP(hipMemcpyAsync(ctx->gq_res.ptr, results, sizeof(shq_grav_result) * n, hipMemcpyHostToDevice, ctx->stream));
+    grav_reduce_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(n, ctx->active.ptr, ctx->gq_res.ptr, ctx->acc.ptr,
+                                                                                         ctx->pot.ptr, update_potential);
+    SHQ_HIP(hipGetLastError());
+    SHQ_HIP(hipStreamSynchronize(ctx->stream)); /* the host staging vectors die here */
+    return SHQ_OK;
+}
+
+extern "C" int shq_grav_postprocess(shq_context *ctx, const shq_grav_params *params, const int32_t *active, int64_t nactive,
+                                    int update_potential)
+{
+    SHQ_CHECK(ctx && params, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts && ctx->grav_raw, SHQ_ERR_STATE, "grav_postprocess: no deferred walk result on the device");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int32_t *d_active = nullptr;
+    int64_t nt = 0;
+    SHQ_TRY(shq_resolve_active(ctx, active, nactive, ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart, &d_active, &nt));
+    SHQ_TRY(shq_launch_grav_postprocess(ctx, params, d_active, nt, update_potential));
+    ctx->grav_raw = false;
     return SHQ_OK;
 }
 

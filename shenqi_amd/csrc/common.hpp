@@ -223,6 +223,8 @@ struct shq_context {
     DevBuf<shq_data_index> top_table;
     int64_t ntopnodes = 0;
     bool have_toptree = false;
+    bool grav_raw = false;     /* acc / pot hold raw sums of a deferred-postprocess walk */
+    DevBuf<shq_grav_result> gq_res;
     DevBuf<int32_t> act_list, act_sub;   /* resident ActiveParticle list and gravity sub-list (shq_build_active_*) */
     DevBuf<unsigned long long> act_counts;
     DevBuf<char> act_temp;

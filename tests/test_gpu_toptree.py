@@ -124,6 +124,58 @@ def test_primary_plus_secondary_equals_single_domain_walk(ctx):
     assert np.abs(acc_sum - acc_full).max() < 1e-11 * np.abs(acc_full).max()
 
 
+def test_distributed_walk_through_the_abi(ctx):
+    """The same closure with the library's own reduction: deferred postprocess, shq_grav_reduce_export_results
+    (entries of a target added in table order, ev_reduce_export_result), shq_grav_postprocess — against the one-shot
+    run on the undivided tree, potential included."""
+    pman, pos, rng = _setup(n1=20)
+    n = len(pos)
+    full = sq.force_tree_full(pman)
+    cm.make_domain(full, ntask=4, me=0, depth=2, pseudo=False)
+    dom = sq.force_tree_full(pman)
+    tl = cm.make_domain(dom, ntask=4, me=0, depth=2)
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=0)
+    sq.gravshort_set_softenings(cm.BOX / 20)
+    gp = sq.make_grav_params(cm.BOX, 1.5, 60, cm.G, cm.RHO0)
+    pv = pman.view()
+    oldacc = pman.Base["FullTreeGravAccel"][:, 0] / cm.G
+
+    def download():
+        acc = np.zeros((n, 3)); pot = np.zeros(n)
+        capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), capi.ptr(pot), None, None))
+        return acc, pot
+
+    tv = full.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    capi.check(capi.hip.shq_tree_upload(ctx.h, C.byref(tv)))
+    capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, cm.G))
+    capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, sq.WALK_EXACT))
+    acc_full, pot_full = download()
+    # "remote" side first (same device, the undivided tree is still loaded): secondary walks of the exports
+    sq.toptree_upload(ctx, dom, tl)
+    counts, table = sq.grav_toptree_exports(ctx, gp, n)
+    q = np.zeros(len(table), dtype=capi.GRAV_QUERY_DTYPE)
+    q["Pos"], q["OldAcc"], q["NodeList"] = pos[table["Index"]], oldacc[table["Index"]], table["NodeList"]
+    res = np.zeros(len(q), dtype=capi.GRAV_RESULT_DTYPE)
+    capi.check(capi.hip.shq_grav_short_secondary(ctx.h, C.byref(gp), capi.ptr(q), len(q), capi.ptr(res), None, 1))
+    # local side: primary walk with the postprocess deferred, reduce, postprocess
+    tv = dom.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    capi.check(capi.hip.shq_tree_upload(ctx.h, C.byref(tv)))
+    capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, cm.G))
+    assert capi.hip.shq_grav_postprocess(ctx.h, C.byref(gp), None, 0, 1) != 0       # nothing deferred yet
+    capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, sq.WALK_EXACT | sq.WALK_DEFER_POSTPROCESS))
+    place = np.ascontiguousarray(table["Index"])
+    perm = rng.permutation(len(place))                 # any order of the table must give the grouped result
+    capi.check(capi.hip.shq_grav_reduce_export_results(ctx.h, capi.ptr(np.ascontiguousarray(place[perm])),
+                                                       capi.ptr(np.ascontiguousarray(res[perm])), len(place), 1))
+    capi.check(capi.hip.shq_grav_postprocess(ctx.h, C.byref(gp), None, 0, 1))
+    acc, pot = download()
+    assert np.abs(acc - acc_full).max() < 1e-11 * np.abs(acc_full).max()
+    assert np.abs(pot - pot_full).max() < 1e-11 * np.abs(pot_full).max()
+    assert np.abs(acc_full).max() > 0 and len(table) > 0
+
+
 def test_toptree_edge_cases(ctx):
     pman, pos, rng = _setup(n1=10)
     tree = sq.force_tree_full(pman)
