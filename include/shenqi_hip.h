@@ -261,6 +261,7 @@ typedef struct shq_active_info {
 } shq_active_info;
 #define SHQ_ACTIVE_RESIDENT ((const int32_t *) (intptr_t) -1)
 #define SHQ_SUBLIST_RESIDENT ((const int32_t *) (intptr_t) -2)
+#define SHQ_SPH_QUEUE_RESIDENT ((const int32_t *) (intptr_t) -3)   /* the current work queue of an open SPH walk */
 int shq_timebins_upload(shq_context *ctx, const uint8_t *bin_gravity, const uint8_t *bin_hydro);
 int shq_build_active_particles(shq_context *ctx, int64_t Ti_Current, int is_pm_step, shq_active_info *info);
 int shq_build_active_sublist(shq_context *ctx, int maxtimebin, int64_t Ti_Current, int64_t *nsub);
@@ -431,6 +432,82 @@ int shq_density(shq_context *ctx, const shq_tree_view *tree, shq_node *nodes_rw,
 int shq_hydro_force(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts,
                     const shq_sph_view *sph, const int32_t *active, int64_t nactive,
                     const shq_hydro_params *params, const double *EntVarPred, shq_sph_stats *stats);
+
+/* ---- SPH walks in phases: the reference's distributed walk (treewalk2.h:277-373, do_hsml_loop :480-557) ----------
+ * shq_density / shq_hydro_force above are  open -> { ev_primary -> ev_postprocess } -> close  in one call.  A multi-rank
+ * run under shenqi's own export / import machinery drives the same phases itself — they are the hooks a TreeWalk
+ * backend overrides (treewalk2.cuh:212-394) — and inserts the exchange between ev_primary and ev_postprocess:
+ *
+ *   shq_density_open(...)                        upload, predicted velocities, Left/Right bounds, work queue (haswork)
+ *   repeat:
+ *     shq_density_ev_primary(ctx)                raw sums of the queue's targets over the local tree (pseudo nodes skipped)
+ *     shq_sph_exports(ctx, ...)                  top-tree walk of the queue with its current Hsml -> data_index table
+ *                                                (needs shq_toptree_upload; symmetric for hydro)
+ *     shq_sph_fill_queries(ctx, table, n, q)     DensityQuery / HydroQuery records of the table's entries
+ *     ... MPI: queries out, other ranks' queries in ...
+ *     shq_density_ev_secondary(ctx, ...)         visit<TREEWALK_GHOSTS> of imported queries against the local tree: raw
+ *                                                DensityResult sums (any rank may call this while its own walk is open)
+ *     ... MPI: results back ...
+ *     shq_density_ev_reduce(ctx, place, res, n)  DensityResult::reduce<TREEWALK_GHOSTS>, entries of a target in order
+ *     shq_density_ev_postprocess(ctx, &nredo)    DensityOutput::postprocess + Hsml update; nredo = targets to redo
+ *   until every rank reports nredo == 0 (ranks with an empty queue keep serving secondaries)
+ *   shq_density_close(...)                       results back into the caller's arrays
+ *
+ * Hydro is the same with one pass.  The structs are binary mirrors of DensityQuery / DensityResult
+ * (densitytree2.hpp:260-344) and HydroQuery / HydroResult (hydratree2.hpp:151-228). */
+typedef struct shq_density_query {
+    double Pos[3];
+    int32_t NodeList[4];
+    double Vel[3];
+    double Hsml;
+    int32_t Type;
+    int32_t pad_;
+} shq_density_query;               /* 80 bytes */
+typedef struct shq_density_result {
+    double EgyRho, DhsmlEgyDensity, Rho, DhsmlDensity, Ngb, Div;
+    double Rot[3];
+    double GradRho[3];
+} shq_density_result;              /* 96 bytes */
+typedef struct shq_hydro_query {
+    double Pos[3];
+    int32_t NodeList[4];
+    double EgyRho, EntVarPred;
+    double Vel[3];
+    double Hsml, Mass, Density, Pressure, F1, SPH_DhsmlDensityFactor;
+    int32_t TimeBinHydro;
+    int32_t pad_;
+} shq_hydro_query;                 /* 136 bytes */
+typedef struct shq_hydro_result {
+    double Acc[3];
+    double DtEntropy, MaxSignalVel;
+} shq_hydro_result;                /* 40 bytes */
+
+int shq_density_open(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph,
+                     const shq_bh_view *bh, const int32_t *active, int64_t nactive, const shq_density_params *params,
+                     int want_gradrho, int64_t *nqueue);
+int shq_density_ev_primary(shq_context *ctx);
+int shq_density_ev_secondary(shq_context *ctx, const shq_density_params *params, const shq_density_query *queries, int64_t nq,
+                             shq_density_result *results, int64_t *ninteractions_total);
+int shq_density_ev_reduce(shq_context *ctx, const int32_t *place, const shq_density_result *results, int64_t n);
+int shq_density_ev_postprocess(shq_context *ctx, int64_t *nredo);
+int shq_density_close(shq_context *ctx, shq_node *nodes_rw, const shq_part_view *parts, const shq_sph_view *sph,
+                      const shq_bh_view *bh, double *EntVarPred, double *GradRho_mag, shq_sph_stats *stats);
+
+int shq_hydro_open(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph,
+                   const int32_t *active, int64_t nactive, const shq_hydro_params *params, const double *EntVarPred,
+                   int64_t *nqueue);
+int shq_hydro_ev_primary(shq_context *ctx);
+int shq_hydro_ev_secondary(shq_context *ctx, const shq_hydro_params *params, const shq_hydro_query *queries, int64_t nq,
+                           shq_hydro_result *results, int64_t *ninteractions_total);
+int shq_hydro_ev_reduce(shq_context *ctx, const int32_t *place, const shq_hydro_result *results, int64_t n);
+int shq_hydro_ev_postprocess(shq_context *ctx);
+int shq_hydro_close(shq_context *ctx, const shq_part_view *parts, const shq_sph_view *sph, shq_sph_stats *stats);
+
+/* For the walk that is open: the export table of its current queue (TopTreeWalk::toptree_visit with cull_node, symmetric
+ * for hydro; outputs as shq_ngb_toptree_exports, exportcounts indexed by queue position) and the query records of a
+ * table's entries (queries: n records of shq_density_query or shq_hydro_query, whichever walk is open). */
+int shq_sph_exports(shq_context *ctx, int32_t *exportcounts, shq_data_index *table, int64_t capacity, int64_t *nexport);
+int shq_sph_fill_queries(shq_context *ctx, const shq_data_index *table, int64_t n, void *queries);
 
 /* ---- long-range PM --------------------------------------------------------------------- */
 

@@ -176,6 +176,38 @@ class BhView(C.Structure):
                 ("off_density", C.c_size_t), ("off_divvel", C.c_size_t)]
 
 
+def sph_view(SphP):
+    """shq_sph_view of a numpy array of SPH_DTYPE records."""
+    v = SphView()
+    f = SphP.dtype.fields
+    v.base, v.elsize, v.numslots = SphP.ctypes.data, SphP.dtype.itemsize, len(SphP)
+    v.off_density, v.off_egywtdensity, v.off_entropy = f["Density"][1], f["EgyWtDensity"][1], f["Entropy"][1]
+    v.off_dtentropy, v.off_maxsignalvel, v.off_hydroaccel = f["DtEntropy"][1], f["MaxSignalVel"][1], f["HydroAccel"][1]
+    v.off_dhsmlegydensityfactor, v.off_divvel, v.off_curlvel = f["DhsmlEgyDensityFactor"][1], f["DivVel"][1], f["CurlVel"][1]
+    v.off_delaytime = f["DelayTime"][1]
+    return v
+
+
+def bh_view(BhP):
+    v = BhView()
+    f = BhP.dtype.fields
+    v.base, v.elsize, v.numslots = BhP.ctypes.data, BhP.dtype.itemsize, len(BhP)
+    v.off_density, v.off_divvel = f["Density"][1], f["DivVel"][1]
+    return v
+
+
+DENSITY_QUERY_DTYPE = np.dtype({"names": ["Pos", "NodeList", "Vel", "Hsml", "Type"], "formats": [("<f8", 3), ("<i4", 4), ("<f8", 3), "<f8", "<i4"],
+                                "offsets": [0, 24, 40, 64, 72], "itemsize": 80})
+DENSITY_RESULT_DTYPE = np.dtype([("EgyRho", "<f8"), ("DhsmlEgyDensity", "<f8"), ("Rho", "<f8"), ("DhsmlDensity", "<f8"), ("Ngb", "<f8"),
+                                 ("Div", "<f8"), ("Rot", "<f8", 3), ("GradRho", "<f8", 3)])
+HYDRO_QUERY_DTYPE = np.dtype({"names": ["Pos", "NodeList", "EgyRho", "EntVarPred", "Vel", "Hsml", "Mass", "Density", "Pressure", "F1",
+                                        "SPH_DhsmlDensityFactor", "TimeBinHydro"],
+                              "formats": [("<f8", 3), ("<i4", 4), "<f8", "<f8", ("<f8", 3), "<f8", "<f8", "<f8", "<f8", "<f8", "<f8", "<i4"],
+                              "offsets": [0, 24, 40, 48, 56, 80, 88, 96, 104, 112, 120, 128], "itemsize": 136})
+HYDRO_RESULT_DTYPE = np.dtype([("Acc", "<f8", 3), ("DtEntropy", "<f8"), ("MaxSignalVel", "<f8")])
+assert DENSITY_RESULT_DTYPE.itemsize == 96 and HYDRO_RESULT_DTYPE.itemsize == 40
+
+
 class SphStats(C.Structure):
     _fields_ = [("ntargets", C.c_int64), ("ninteractions", C.c_int64), ("niterations", C.c_int32), ("pad_", C.c_int32),
                 ("kernel_ms", C.c_double)]
@@ -338,6 +370,27 @@ host.shqh_set_kernel_table(ptr(_KERNELS))
 # ---- SPH host-mirror prototypes --------------------------------------------------------------
 hip.shq_density.argtypes = [_vp, C.POINTER(TreeView), _vp, C.POINTER(PartView), C.POINTER(SphView), C.POINTER(BhView),
                             _vp, C.c_int64, C.POINTER(DensityParams), _vp, _vp, C.POINTER(SphStats)]
+_i64p = C.POINTER(C.c_int64)
+hip.shq_density_open.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(SphView), C.POINTER(BhView), _vp, C.c_int64,
+                                 C.POINTER(DensityParams), C.c_int, _i64p]
+hip.shq_density_ev_primary.argtypes = [_vp]
+hip.shq_density_ev_secondary.argtypes = [_vp, C.POINTER(DensityParams), _vp, C.c_int64, _vp, _i64p]
+hip.shq_density_ev_reduce.argtypes = [_vp, _vp, _vp, C.c_int64]
+hip.shq_density_ev_postprocess.argtypes = [_vp, _i64p]
+hip.shq_density_close.argtypes = [_vp, _vp, C.POINTER(PartView), C.POINTER(SphView), C.POINTER(BhView), _vp, _vp, C.POINTER(SphStats)]
+hip.shq_hydro_open.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(SphView), _vp, C.c_int64, C.POINTER(HydroParams),
+                               _vp, _i64p]
+hip.shq_hydro_ev_primary.argtypes = [_vp]
+hip.shq_hydro_ev_secondary.argtypes = [_vp, C.POINTER(HydroParams), _vp, C.c_int64, _vp, _i64p]
+hip.shq_hydro_ev_reduce.argtypes = [_vp, _vp, _vp, C.c_int64]
+hip.shq_hydro_ev_postprocess.argtypes = [_vp]
+hip.shq_hydro_close.argtypes = [_vp, C.POINTER(PartView), C.POINTER(SphView), C.POINTER(SphStats)]
+hip.shq_sph_exports.argtypes = [_vp, _vp, _vp, C.c_int64, _i64p]
+hip.shq_sph_fill_queries.argtypes = [_vp, _vp, C.c_int64, _vp]
+for _f in ("shq_density_open", "shq_density_ev_primary", "shq_density_ev_secondary", "shq_density_ev_reduce", "shq_density_ev_postprocess",
+           "shq_density_close", "shq_hydro_open", "shq_hydro_ev_primary", "shq_hydro_ev_secondary", "shq_hydro_ev_reduce",
+           "shq_hydro_ev_postprocess", "shq_hydro_close", "shq_sph_exports", "shq_sph_fill_queries"):
+    getattr(hip, _f).restype = C.c_int
 hip.shq_hydro_force.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(SphView), _vp, C.c_int64,
                                 C.POINTER(HydroParams), _vp, C.POINTER(SphStats)]
 host.shqh_set_densitypar.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]

@@ -125,7 +125,7 @@ extern "C" void shq_shutdown(shq_context *ctx)
     ctx->posm.release(); ctx->oldacc.release(); ctx->treeacc.release(); ctx->gravpm.release();
     ctx->pmpot.release(); ctx->acc.release(); ctx->pot.release(); ctx->nint.release();
     ctx->pflags.release(); ctx->active.release(); ctx->act_list.release(); ctx->act_sub.release(); ctx->act_counts.release(); ctx->act_temp.release(); ctx->act_flag.release();
-    ctx->gq_res.release(); ctx->topnodes.release(); ctx->topleaves.release(); ctx->top_counts.release(); ctx->top_table.release(); ctx->gstats.release();
+    ctx->gq_res.release(); ctx->s_queue0.release(); ctx->s_nlist2.release(); ctx->topnodes.release(); ctx->topleaves.release(); ctx->top_counts.release(); ctx->top_table.release(); ctx->gstats.release();
     ctx->nodeA.release(); ctx->nodeB.release(); ctx->nodeC.release(); ctx->nodeG.release();
     ctx->posm_leaf.release(); ctx->leaf_pidx.release();
     ctx->mesh.release(); ctx->sinctab.release(); ctx->dbg_rho.release(); ctx->dbg_pot.release();

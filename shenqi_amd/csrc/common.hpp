@@ -275,6 +275,18 @@ struct shq_context {
     DevBuf<double> s_numngb, s_dhsmldens, s_left, s_right, s_rot, s_gradrho, s_evp_in;
     DevBuf<int32_t> s_todo, s_queue2, s_queue3, s_blockcount;
     DevBuf<int32_t> s_nlist;   /* per-lane neighbour lists of the SPH walks */
+    DevBuf<int32_t> s_queue0;  /* the work queue of the open SPH walk */
+    std::vector<int32_t> sph_queue_host;
+    DevBuf<int32_t> s_nlist2;  /* ... of the secondary (imported-query) walks, which run while a primary walk is open */
+    struct SphRun {            /* a density / hydro walk opened in phases (shq_sph_*_begin ... _end) */
+        shq_density_params dp;
+        shq_hydro_params hp;
+        int want_gradrho = 0;
+        const int32_t *cur = nullptr;
+        long long size = 0, nq0 = 0;
+        int wsel = 0, niter = 0;
+        int phase = 0;          /* 0 none, 1 density, 2 hydro */
+    } sphrun;
     DevBuf<int32_t> s_ncount, s_redo; /* list lengths; targets of waves whose lists overflowed */
     DevBuf<long long> s_counters;
 
@@ -345,6 +357,23 @@ int shq_sph_prepare(shq_context *ctx, const shq_kick_factors *kf, const shq_hydr
 int shq_sph_density_device(shq_context *ctx, const shq_density_params *p, const int32_t *d_queue, int64_t nq,
                            int want_gradrho, shq_sph_stats *stats);
 int shq_sph_hydro_device(shq_context *ctx, const shq_hydro_params *p, const int32_t *d_queue, int64_t nq, shq_sph_stats *stats);
+int shq_sph_hydro_begin(shq_context *ctx, const shq_hydro_params *p, const int32_t *d_queue, int64_t nq);
+int shq_sph_hydro_primary(shq_context *ctx);
+int shq_sph_hydro_post(shq_context *ctx);
+int shq_sph_hydro_end(shq_context *ctx, shq_sph_stats *stats);
+int shq_sph_hydro_reduce(shq_context *ctx, const int32_t *d_place, const void *d_results, int64_t n);
+int shq_sph_hydro_secondary(shq_context *ctx, const shq_hydro_params *p, const double4 *d_qposm, const double *d_qhsml,
+                            const double4 *d_qvelp, const double4 *d_qC, const double4 *d_qD, const int4 *d_qseg, int64_t nq, double *d_out,
+                            unsigned long long *d_nint);
+int shq_sph_fill_queries_device(shq_context *ctx, const shq_data_index *d_table, int64_t n, void *d_out);
+int shq_sph_density_begin(shq_context *ctx, const shq_density_params *p, const int32_t *d_queue, int64_t nq, int want_gradrho);
+int shq_sph_density_primary(shq_context *ctx);
+int shq_sph_density_post(shq_context *ctx, int64_t *nredo);
+int shq_sph_density_end(shq_context *ctx, shq_sph_stats *stats);
+int shq_sph_density_reduce(shq_context *ctx, const int32_t *d_place, const void *d_results, int64_t n);
+int shq_sph_density_secondary(shq_context *ctx, const shq_density_params *p, const double4 *d_qposm, const double *d_qhsml,
+                              const double4 *d_qvelp, const uint8_t *d_qflags, const int4 *d_qseg, int64_t nq, double *d_out,
+                              unsigned long long *d_nint);
 int shq_sph_gradrho_mag(shq_context *ctx, double *d_out);
 
 #endif

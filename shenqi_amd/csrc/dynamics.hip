@@ -251,6 +251,12 @@ int shq_resolve_active(shq_context *ctx, const int32_t *active, int64_t nactive,
     *nt = n_all;
     if(!active)
         return SHQ_OK;
+    if(active == SHQ_SPH_QUEUE_RESIDENT) {
+        SHQ_CHECK(ctx->sphrun.phase != 0, SHQ_ERR_STATE, "no SPH walk is open");
+        *d_active = ctx->sphrun.cur;
+        *nt = ctx->sphrun.size;
+        return SHQ_OK;
+    }
     if(active == SHQ_ACTIVE_RESIDENT || active == SHQ_SUBLIST_RESIDENT) {
         const bool sub = active == SHQ_SUBLIST_RESIDENT;
         SHQ_CHECK((sub ? ctx->n_sub : ctx->n_act) >= 0, SHQ_ERR_STATE, "no resident active %s: call shq_build_active_%s first",

@@ -296,10 +296,14 @@ template <class F> __device__ __forceinline__ void nl_flush(const int32_t *myl, 
 
 /* KEEP: only build the lists (two-kernel path): nothing is evaluated, `fill` returns the list length, and a
  * lane whose list would overflow sets `ovf` (its wave is then redone by the fused kernel). */
-template <bool SYM, bool KEEP, class Accept, class Pair>
+/* GHOSTS (LocalNgbTreeWalk::visit<TREEWALK_GHOSTS>, localtreewalk2.h:378-437): an imported query walks only the branches
+ * under the top-level nodes of its NodeList = the pre-order index ranges [start, sibling(start)); `seg` holds the (sorted)
+ * packed start indices.  As in the gravity walk a lane waits at the start of its next branch and the wave cursor, which
+ * still begins at the root, also descends wherever a lane waits further down. */
+template <bool SYM, bool KEEP, bool GHOSTS, class Accept, class Pair>
 __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave, int32_t *myl, const bool valid, const double px,
                                                  const double py, const double pz, const double h, Accept &&accept, Pair &&pair,
-                                                 unsigned int *dbg, int &fill, bool &ovf)
+                                                 unsigned int *dbg, int &fill, bool &ovf, const int4 seg = make_int4(-1, -1, -1, -1))
 {
     double4 *winB = reinterpret_cast<double4 *>(lds_wave);
     int4 *winC = reinterpret_cast<int4 *>(lds_wave + NW_WIN * 32);
@@ -364,6 +368,13 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
     };
 
     int mynext = valid ? a.root : -2;
+    int seg1 = -1, seg2 = -1, seg3 = -1, myend = -1;
+    if(GHOSTS) {
+        mynext = (valid && seg.x >= 0) ? seg.x : -2;
+        seg1 = seg.y; seg2 = seg.z; seg3 = seg.w;
+        if(mynext >= 0)
+            myend = a.nodeC[mynext].sibling;
+    }
     int cur = a.root, wbase = -(1 << 30);
     while(cur >= 0) {
         if(cur < wbase || cur >= wbase + NW_WIN) {
@@ -425,10 +436,19 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
                 mynext = Csib;
             next = Csib;
         } else {
-            const bool any = keepm != 0ull;
+            bool any = keepm != 0ull;
+            if(GHOSTS) /* a lane waits at a branch below this node: go down even if nobody opens it */
+                any = any || shq_ballot(mynext > cur && (Csib < 0 || mynext < Csib)) != 0ull;
             if(act)
                 mynext = keep ? Cchild : Csib;
             next = any ? Cchild : Csib;
+        }
+        if(GHOSTS && act && mynext == myend) { /* branch done: wait at the next one of the NodeList */
+            mynext = seg1 >= 0 ? seg1 : -2;
+            seg1 = seg2;
+            seg2 = seg3;
+            seg3 = -1;
+            myend = mynext >= 0 ? a.nodeC[mynext].sibling : -1;
         }
         cur = next;
     }
@@ -449,10 +469,10 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
  * d_nq != NULL takes the queue length from the device).  MODE 1: walk only, lists and their lengths go to
  * global memory (one region per wave of the launch).  MODE 2: evaluation only, from those lists.  The
  * two-kernel path lets the walk run at twice the occupancy the register-heavy evaluation allows. */
-template <int KT, int MODE>
+template <int KT, int MODE, bool GHOSTS = false>
 __global__ __launch_bounds__(256) void sph_density_kernel(const SphDev a, const int32_t *queue, long long nq, int WindsDecouple,
                                                           unsigned long long *nint_total, int32_t *__restrict__ nlist, long long ntasks,
-                                                          int32_t *__restrict__ counts, const long long *d_nq)
+                                                          int32_t *__restrict__ counts, const long long *d_nq, const int4 *qseg = nullptr)
 {
     __shared__ __attribute__((aligned(32))) char lds[(MODE == 2 ? 1 : 4 * NW_LDS_PER_WAVE(false))];
     const int lane = threadIdx.x & 63;
@@ -520,8 +540,9 @@ __global__ __launch_bounds__(256) void sph_density_kernel(const SphDev a, const 
     int fill = 0;
     bool ovf = false;
     if(MODE != 2)
-        nint = ngb_walk<false, MODE == 1>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(false), myl, valid, px, py, pz, h, accept, pair,
-                                          (unsigned int *) nullptr, fill, ovf);
+        nint = ngb_walk<false, MODE == 1, GHOSTS>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(false), myl, valid, px, py, pz, h, accept, pair,
+                                                  (unsigned int *) nullptr, fill, ovf,
+                                                  (GHOSTS && valid) ? qseg[t] : make_int4(-1, -1, -1, -1));
     if(MODE == 1) {
         const bool wave_ovf = shq_ballot(ovf) != 0ull;
         counts[wave * 64 + lane] = wave_ovf ? -1 : fill;
@@ -540,7 +561,7 @@ __global__ __launch_bounds__(256) void sph_density_kernel(const SphDev a, const 
         a.dhsmldens[pi] = DhsmlDensity;
         a.rho[pi] = Rho;
         a.div[pi] = Div;
-        if(type == 0) {
+        if(type == 0 || GHOSTS) { /* an imported query returns every sum; its owner's reduce picks by type */
             a.rot[3 * pi] = R0;
             a.rot[3 * pi + 1] = R1;
             a.rot[3 * pi + 2] = R2;
@@ -735,10 +756,10 @@ struct HydroConst {
 };
 
 /* MODE as for sph_density_kernel */
-template <int KT, int MODE>
+template <int KT, int MODE, bool GHOSTS = false>
 __global__ __launch_bounds__(256, 4) void sph_hydro_kernel(const SphDev a, const int32_t *queue, long long nq, const HydroConst hc,
                                                            unsigned long long *nint_total, int32_t *__restrict__ nlist, long long ntasks,
-                                                           int32_t *__restrict__ counts, const long long *d_nq)
+                                                           int32_t *__restrict__ counts, const long long *d_nq, const int4 *qseg = nullptr)
 {
     __shared__ __attribute__((aligned(32))) char lds[(MODE == 2 ? 1 : 4 * NW_LDS_PER_WAVE(true))];
     const int lane = threadIdx.x & 63;
@@ -842,8 +863,9 @@ __global__ __launch_bounds__(256, 4) void sph_hydro_kernel(const SphDev a, const
     int fill = 0;
     bool ovf = false;
     if(MODE != 2)
-        nint = ngb_walk<true, MODE == 1>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(true), myl, valid, px, py, pz, hi, accept, pair,
-                                         (MODE == 0 && nint_total) ? dbgc : (unsigned int *) nullptr, fill, ovf);
+        nint = ngb_walk<true, MODE == 1, GHOSTS>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(true), myl, valid, px, py, pz, hi, accept, pair,
+                                                 (MODE == 0 && nint_total && !GHOSTS) ? dbgc : (unsigned int *) nullptr, fill, ovf,
+                                                 (GHOSTS && valid) ? qseg[t] : make_int4(-1, -1, -1, -1));
     if(MODE == 1) {
         const bool wave_ovf = shq_ballot(ovf) != 0ull;
         counts[wave * 64 + lane] = wave_ovf ? -1 : fill;
@@ -868,7 +890,7 @@ __global__ __launch_bounds__(256, 4) void sph_hydro_kernel(const SphDev a, const
         sn += __shfl_xor(sn, off);
     if(lane == 0 && nint_total)
         atomicAdd(nint_total, (unsigned long long) sn);
-    if(MODE == 0 && nint_total) { /* diagnostics behind SHQ_SPH_DEBUG: [1] nodes/wave [2] candidates/wave [3] pairs (lanes) [4] flush rounds/wave */
+    if(MODE == 0 && nint_total && !GHOSTS) { /* diagnostics behind SHQ_SPH_DEBUG: [1] nodes/wave [2] candidates/wave [3] pairs (lanes) [4] flush rounds/wave */
         if(lane == 0) {
             atomicAdd(nint_total + 1, (unsigned long long) dbgc[0]);
             atomicAdd(nint_total + 2, (unsigned long long) dbgc[1]);
@@ -1104,8 +1126,19 @@ static int launch_hydro(shq_context *ctx, const SphDev &a, const int32_t *q, lon
 
 /* Device-resident density(): queue = d_queue[0..nq) of particle indices (already filtered by
  * DensityQuery::haswork).  Runs the whole Hsml loop. */
-int shq_sph_density_device(shq_context *ctx, const shq_density_params *p, const int32_t *d_queue, int64_t nq, int want_gradrho,
-                           shq_sph_stats *stats)
+/* ---- density in phases: the set of hooks a TreeWalk backend overrides (treewalk2.cuh:212-394) --------------------
+ * begin (DensityOutput ctor) -> { primary (ev_primary) -> [reduce of returned export results] -> post (ev_postprocess +
+ * the do_hsml_loop bookkeeping, treewalk2.h:480-557) } until the redo queue is empty -> end. */
+static SphDev density_dev(shq_context *ctx)
+{
+    SphDev a = make_dev(ctx);
+    a.gradrho = ctx->sphrun.want_gradrho ? ctx->s_gradrho.ptr : nullptr;
+    a.Box = ctx->sphrun.dp.BoxSize;
+    a.invBox = 1.0 / ctx->sphrun.dp.BoxSize;
+    return a;
+}
+
+int shq_sph_density_begin(shq_context *ctx, const shq_density_params *p, const int32_t *d_queue, int64_t nq, int want_gradrho)
 {
     const long long n = ctx->numpart;
     const size_t cap = (size_t) (n > 0 ? n : 1);
@@ -1116,6 +1149,7 @@ int shq_sph_density_device(shq_context *ctx, const shq_density_params *p, const 
     SHQ_TRY(ctx->s_rot.reserve(3 * cap));
     SHQ_TRY(ctx->s_todo.reserve(cap));
     SHQ_TRY(ctx->s_queue2.reserve(cap));
+    SHQ_TRY(ctx->s_queue3.reserve(cap));
     SHQ_TRY(ctx->s_blockcount.reserve(nblk(n) + 1));
     SHQ_TRY(ctx->s_counters.reserve(8));
     SHQ_TRY(reserve_nlist(ctx, nq));
@@ -1130,75 +1164,221 @@ int shq_sph_density_device(shq_context *ctx, const shq_density_params *p, const 
         fill_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(ctx->s_right.ptr, n, p->BoxSize);
     }
     SHQ_HIP(hipMemsetAsync(ctx->s_counters.ptr, 0, sizeof(long long) * 8, ctx->stream));
-    SphDev a = make_dev(ctx);
-    a.gradrho = want_gradrho ? ctx->s_gradrho.ptr : nullptr;
-    a.Box = p->BoxSize;
-    a.invBox = 1.0 / p->BoxSize;
-    PostArgs pa;
-    pa.Box = p->BoxSize;
-    pa.DesNumNgb = p->DesNumNgb;
-    pa.DesNumNgbBH = p->DesNumNgbBH;
-    pa.MinGasHsml = p->MinGasHsml;
-    pa.MaxDev = p->MaxNumNgbDeviation;
-    pa.update_hsml = p->update_hsml;
-    pa.BlackHoleOn = p->BlackHoleOn;
-    pa.DoEgyDensity = p->DoEgyDensity;
-    unsigned long long *nint = reinterpret_cast<unsigned long long *>(ctx->s_counters.ptr + 1);
-    long long *total = ctx->s_counters.ptr;
-    SHQ_TRY(ctx->s_queue3.reserve(cap));
-    int32_t *bufs[2] = {ctx->s_queue2.ptr, ctx->s_queue3.ptr};
-    int wsel = 0;
-    const int32_t *cur = d_queue;
-    long long size = nq;
-    int niter = 0;
+    shq_context::SphRun &r = ctx->sphrun;
+    r.dp = *p;
+    r.want_gradrho = want_gradrho;
+    r.cur = d_queue;
+    r.size = nq;
+    r.nq0 = nq;
+    r.wsel = 0;
+    r.niter = 0;
+    r.phase = 1;
     SHQ_HIP(hipEventRecord(ctx->ev_begin[14], ctx->stream));
-    while(true) {
-        if(size > 0) {
-            switch(p->DensityKernelType) {
-            case 1: SHQ_TRY(launch_density<1>(ctx, a, cur, size, nq, p->WindsDecouple, nint)); break;
-            case 2: SHQ_TRY(launch_density<2>(ctx, a, cur, size, nq, p->WindsDecouple, nint)); break;
-            default: SHQ_TRY(launch_density<4>(ctx, a, cur, size, nq, p->WindsDecouple, nint)); break;
-            }
-            sph_density_post_kernel<<<dim3(nblk(size)), dim3(256), 0, ctx->stream>>>(a, cur, size, pa, ctx->s_todo.ptr);
-            SHQ_HIP(hipGetLastError());
-        }
-        niter++;
-        if(!p->update_hsml || size == 0)
-            break;
-        const int nb = (int) nblk(size);
-        compact_count_kernel<<<dim3(nb), dim3(256), 0, ctx->stream>>>(ctx->s_todo.ptr, size, ctx->s_blockcount.ptr);
-        compact_scan_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(ctx->s_blockcount.ptr, nb, total);
-        compact_write_kernel<<<dim3(nb), dim3(256), 0, ctx->stream>>>(ctx->s_todo.ptr, size, ctx->s_blockcount.ptr, bufs[wsel]);
-        long long newsize = 0;
-        SHQ_HIP(hipMemcpyAsync(&newsize, total, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-        SHQ_HIP(hipStreamSynchronize(ctx->stream));
-        size = newsize;
-        if(size == 0)
-            break;
-        /* the neighbours' Hsml copy in leaf order is only read by hydro, so no refresh is needed here */
-        cur = bufs[wsel];
-        wsel ^= 1;
-        if(niter > SPH_MAXITER) {
-            shq_set_error("failed to converge density for %lld particles", size);
-            return SHQ_ERR_NOCONV;
-        }
+    return SHQ_OK;
+}
+
+int shq_sph_density_primary(shq_context *ctx)
+{
+    shq_context::SphRun &r = ctx->sphrun;
+    SHQ_CHECK(r.phase == 1, SHQ_ERR_STATE, "density primary: no density walk is open");
+    if(r.size == 0)
+        return SHQ_OK;
+    const SphDev a = density_dev(ctx);
+    unsigned long long *nint = reinterpret_cast<unsigned long long *>(ctx->s_counters.ptr + 1);
+    switch(r.dp.DensityKernelType) {
+    case 1: SHQ_TRY(launch_density<1>(ctx, a, r.cur, r.size, r.nq0, r.dp.WindsDecouple, nint)); break;
+    case 2: SHQ_TRY(launch_density<2>(ctx, a, r.cur, r.size, r.nq0, r.dp.WindsDecouple, nint)); break;
+    default: SHQ_TRY(launch_density<4>(ctx, a, r.cur, r.size, r.nq0, r.dp.WindsDecouple, nint)); break;
     }
+    return SHQ_OK;
+}
+
+int shq_sph_density_post(shq_context *ctx, int64_t *nredo)
+{
+    shq_context::SphRun &r = ctx->sphrun;
+    SHQ_CHECK(r.phase == 1, SHQ_ERR_STATE, "density postprocess: no density walk is open");
+    const shq_density_params *p = &r.dp;
+    *nredo = 0;
+    if(r.size > 0) {
+        const SphDev a = density_dev(ctx);
+        PostArgs pa;
+        pa.Box = p->BoxSize;
+        pa.DesNumNgb = p->DesNumNgb;
+        pa.DesNumNgbBH = p->DesNumNgbBH;
+        pa.MinGasHsml = p->MinGasHsml;
+        pa.MaxDev = p->MaxNumNgbDeviation;
+        pa.update_hsml = p->update_hsml;
+        pa.BlackHoleOn = p->BlackHoleOn;
+        pa.DoEgyDensity = p->DoEgyDensity;
+        sph_density_post_kernel<<<dim3(nblk(r.size)), dim3(256), 0, ctx->stream>>>(a, r.cur, r.size, pa, ctx->s_todo.ptr);
+        SHQ_HIP(hipGetLastError());
+    }
+    r.niter++;
+    if(!p->update_hsml || r.size == 0) {
+        r.size = 0;
+        return SHQ_OK;
+    }
+    int32_t *bufs[2] = {ctx->s_queue2.ptr, ctx->s_queue3.ptr};
+    long long *total = ctx->s_counters.ptr;
+    const int nb = (int) nblk(r.size);
+    compact_count_kernel<<<dim3(nb), dim3(256), 0, ctx->stream>>>(ctx->s_todo.ptr, r.size, ctx->s_blockcount.ptr);
+    compact_scan_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(ctx->s_blockcount.ptr, nb, total);
+    compact_write_kernel<<<dim3(nb), dim3(256), 0, ctx->stream>>>(ctx->s_todo.ptr, r.size, ctx->s_blockcount.ptr, bufs[r.wsel]);
+    long long newsize = 0;
+    SHQ_HIP(hipMemcpyAsync(&newsize, total, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    r.size = newsize;
+    if(newsize == 0)
+        return SHQ_OK;
+    /* the neighbours' Hsml copy in leaf order is only read by hydro, so no refresh is needed here */
+    r.cur = bufs[r.wsel];
+    r.wsel ^= 1;
+    if(r.niter > SPH_MAXITER) {
+        shq_set_error("failed to converge density for %lld particles", newsize);
+        return SHQ_ERR_NOCONV;
+    }
+    *nredo = newsize;
+    return SHQ_OK;
+}
+
+int shq_sph_density_end(shq_context *ctx, shq_sph_stats *stats)
+{
+    shq_context::SphRun &r = ctx->sphrun;
+    SHQ_CHECK(r.phase == 1, SHQ_ERR_STATE, "density end: no density walk is open");
+    r.phase = 0;
     SHQ_HIP(hipEventRecord(ctx->ev_end[14], ctx->stream));
     if(stats) {
         unsigned long long h_nint = 0;
-        SHQ_HIP(hipMemcpyAsync(&h_nint, nint, sizeof(h_nint), hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(&h_nint, ctx->s_counters.ptr + 1, sizeof(h_nint), hipMemcpyDeviceToHost, ctx->stream));
         SHQ_HIP(hipStreamSynchronize(ctx->stream));
         float ms = 0;
         (void) hipEventElapsedTime(&ms, ctx->ev_begin[14], ctx->ev_end[14]);
-        stats->ntargets = nq;
+        stats->ntargets = r.nq0;
         stats->ninteractions = (int64_t) h_nint;
-        stats->niterations = niter;
+        stats->niterations = r.niter;
         stats->kernel_ms = ms;
     }
     return SHQ_OK;
 }
 
-int shq_sph_hydro_device(shq_context *ctx, const shq_hydro_params *p, const int32_t *d_queue, int64_t nq, shq_sph_stats *stats)
+int shq_sph_density_device(shq_context *ctx, const shq_density_params *p, const int32_t *d_queue, int64_t nq, int want_gradrho,
+                           shq_sph_stats *stats)
+{
+    SHQ_TRY(shq_sph_density_begin(ctx, p, d_queue, nq, want_gradrho));
+    int64_t nredo = 0;
+    do {
+        SHQ_TRY(shq_sph_density_primary(ctx));
+        SHQ_TRY(shq_sph_density_post(ctx, &nredo));
+    } while(nredo > 0);
+    return shq_sph_density_end(ctx, stats);
+}
+
+/* DensityResult::reduce<TREEWALK_GHOSTS> (densitytree2.hpp:308-343): one thread per table entry, the first entry of
+ * a run of equal places adds the run in order (entries arrive grouped by target). */
+__global__ void sph_density_reduce_kernel(const SphDev a, long long n, const int32_t *__restrict__ place, const shq_density_result *__restrict__ res)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    const long long i = place[k];
+    if(k > 0 && place[k - 1] == i)
+        return;
+    const int type = a.pflags[i] >> 4;
+    for(long long j = k; j < n && place[j] == i; j++) {
+        const shq_density_result r = res[j];
+        a.numngb[i] += r.Ngb;
+        a.dhsmldens[i] += r.DhsmlDensity;
+        if(type == 0 || type == 5) {
+            a.rho[i] += r.Rho;
+            a.div[i] += r.Div;
+        }
+        if(type == 0) {
+            a.rot[3 * i] += r.Rot[0];
+            a.rot[3 * i + 1] += r.Rot[1];
+            a.rot[3 * i + 2] += r.Rot[2];
+            if(a.gradrho) {
+                a.gradrho[3 * i] += r.GradRho[0];
+                a.gradrho[3 * i + 1] += r.GradRho[1];
+                a.gradrho[3 * i + 2] += r.GradRho[2];
+            }
+            a.egyrho[i] += r.EgyRho;
+            a.dhsmlegy[i] += r.DhsmlEgyDensity;
+        }
+    }
+}
+
+int shq_sph_density_reduce(shq_context *ctx, const int32_t *d_place, const void *d_results, int64_t n)
+{
+    SHQ_CHECK(ctx->sphrun.phase == 1, SHQ_ERR_STATE, "density reduce: no density walk is open");
+    if(n == 0)
+        return SHQ_OK;
+    const SphDev a = density_dev(ctx);
+    sph_density_reduce_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(a, n, d_place, static_cast<const shq_density_result *>(d_results));
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}
+
+/* LocalNgbTreeWalk::visit<TREEWALK_GHOSTS> for imported DensityQuery records: the target-side arrays of the
+ * walk kernel are swapped for query-indexed ones, the neighbour side stays the local tree.  d_q* are nq long;
+ * d_out holds 12 nq doubles: Ngb, DhsmlDensity, Rho, Div, EgyRho, DhsmlEgyDensity, Rot[3], GradRho[3] (SoA). */
+int shq_sph_density_secondary(shq_context *ctx, const shq_density_params *p, const double4 *d_qposm, const double *d_qhsml,
+                              const double4 *d_qvelp, const uint8_t *d_qflags, const int4 *d_qseg, int64_t nq, double *d_out,
+                              unsigned long long *d_nint)
+{
+    if(nq == 0)
+        return SHQ_OK;
+    SHQ_CHECK(p->DensityKernelType == 1 || p->DensityKernelType == 2 || p->DensityKernelType == 4, SHQ_ERR_INVALID,
+              "unknown DensityKernelType %d", p->DensityKernelType);
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    SphDev a = make_dev(ctx);
+    a.Box = p->BoxSize;
+    a.invBox = 1.0 / p->BoxSize;
+    a.posm = d_qposm;
+    a.hsml = const_cast<double *>(d_qhsml);
+    a.velp = d_qvelp;
+    a.pflags = d_qflags;
+    a.numngb = d_out;
+    a.dhsmldens = d_out + nq;
+    a.rho = d_out + 2 * nq;
+    a.div = d_out + 3 * nq;
+    a.egyrho = d_out + 4 * nq;
+    a.dhsmlegy = d_out + 5 * nq;
+    a.rot = d_out + 6 * nq;
+    a.gradrho = d_out + 9 * nq;
+    const long long ntasks = (nq + 255) / 256;
+    const unsigned grid = (unsigned) (ntasks < NL_REDO_BLOCKS ? ntasks : NL_REDO_BLOCKS);
+    hipStream_t st = ctx->stream;
+    switch(p->DensityKernelType) {
+    case 1: sph_density_kernel<1, 0, true><<<dim3(grid), dim3(256), 0, st>>>(a, nullptr, nq, p->WindsDecouple, d_nint, ctx->s_nlist2.ptr, ntasks, nullptr, nullptr, d_qseg); break;
+    case 2: sph_density_kernel<2, 0, true><<<dim3(grid), dim3(256), 0, st>>>(a, nullptr, nq, p->WindsDecouple, d_nint, ctx->s_nlist2.ptr, ntasks, nullptr, nullptr, d_qseg); break;
+    default: sph_density_kernel<4, 0, true><<<dim3(grid), dim3(256), 0, st>>>(a, nullptr, nq, p->WindsDecouple, d_nint, ctx->s_nlist2.ptr, ntasks, nullptr, nullptr, d_qseg); break;
+    }
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}
+
+/* ---- hydro in phases: begin -> primary (ev_primary) -> [reduce of returned export results] -> post (ev_postprocess) -> end */
+static HydroConst hydro_const(const shq_hydro_params *p)
+{
+    HydroConst hc;
+    hc.hubble_a2 = p->hubble_a2;
+    hc.fac_mu = p->fac_mu;
+    hc.fac_vsic_fix = p->fac_vsic_fix;
+    hc.ArtBulkViscConst = p->ArtBulkViscConst;
+    hc.contrast = p->DensityContrastLimit;
+    hc.DISPH = p->DensityIndependentSphOn;
+    return hc;
+}
+
+static SphDev hydro_dev(shq_context *ctx, const shq_hydro_params *p)
+{
+    SphDev a = make_dev(ctx);
+    a.Box = p->BoxSize;
+    a.invBox = 1.0 / p->BoxSize;
+    return a;
+}
+
+int shq_sph_hydro_begin(shq_context *ctx, const shq_hydro_params *p, const int32_t *d_queue, int64_t nq)
 {
     const long long n = ctx->numpart;
     const size_t cap = (size_t) (n > 0 ? n : 1);
@@ -1210,47 +1390,218 @@ int shq_sph_hydro_device(shq_context *ctx, const shq_hydro_params *p, const int3
     SHQ_CHECK(p->DensityKernelType == 1 || p->DensityKernelType == 2 || p->DensityKernelType == 4, SHQ_ERR_INVALID,
               "unknown DensityKernelType %d", p->DensityKernelType);
     SHQ_HIP(hipMemsetAsync(ctx->s_counters.ptr, 0, sizeof(long long) * 8, ctx->stream));
-    SphDev a = make_dev(ctx);
-    a.Box = p->BoxSize;
-    a.invBox = 1.0 / p->BoxSize;
-    HydroConst hc;
-    hc.hubble_a2 = p->hubble_a2;
-    hc.fac_mu = p->fac_mu;
-    hc.fac_vsic_fix = p->fac_vsic_fix;
-    hc.ArtBulkViscConst = p->ArtBulkViscConst;
-    hc.contrast = p->DensityContrastLimit;
-    hc.DISPH = p->DensityIndependentSphOn;
-    unsigned long long *nint = reinterpret_cast<unsigned long long *>(ctx->s_counters.ptr + 1);
+    shq_context::SphRun &r = ctx->sphrun;
+    r.hp = *p;
+    r.cur = d_queue;
+    r.size = nq;
+    r.nq0 = nq;
+    r.niter = 0;
+    r.phase = 2;
     SHQ_HIP(hipEventRecord(ctx->ev_begin[14], ctx->stream));
-    if(nq > 0) {
-        switch(p->DensityKernelType) {
-        case 1: SHQ_TRY(launch_hydro<1>(ctx, a, d_queue, nq, hc, nint)); break;
-        case 2: SHQ_TRY(launch_hydro<2>(ctx, a, d_queue, nq, hc, nint)); break;
-        default: SHQ_TRY(launch_hydro<4>(ctx, a, d_queue, nq, hc, nint)); break;
-        }
-        sph_hydro_post_kernel<<<dim3(nblk(nq)), dim3(256), 0, ctx->stream>>>(a, d_queue, nq, ctx->g_density.ptr, ctx->g_delaytime.ptr,
-                                                                            p->hubble_a2, p->atime, p->WindSpeed, p->WindFreeTravelDensThresh);
+    return SHQ_OK;
+}
+
+int shq_sph_hydro_primary(shq_context *ctx)
+{
+    shq_context::SphRun &r = ctx->sphrun;
+    SHQ_CHECK(r.phase == 2, SHQ_ERR_STATE, "hydro primary: no hydro walk is open");
+    if(r.size == 0)
+        return SHQ_OK;
+    const SphDev a = hydro_dev(ctx, &r.hp);
+    const HydroConst hc = hydro_const(&r.hp);
+    unsigned long long *nint = reinterpret_cast<unsigned long long *>(ctx->s_counters.ptr + 1);
+    switch(r.hp.DensityKernelType) {
+    case 1: SHQ_TRY(launch_hydro<1>(ctx, a, r.cur, r.size, hc, nint)); break;
+    case 2: SHQ_TRY(launch_hydro<2>(ctx, a, r.cur, r.size, hc, nint)); break;
+    default: SHQ_TRY(launch_hydro<4>(ctx, a, r.cur, r.size, hc, nint)); break;
+    }
+    return SHQ_OK;
+}
+
+int shq_sph_hydro_post(shq_context *ctx)
+{
+    shq_context::SphRun &r = ctx->sphrun;
+    SHQ_CHECK(r.phase == 2, SHQ_ERR_STATE, "hydro postprocess: no hydro walk is open");
+    if(r.size > 0) {
+        const SphDev a = hydro_dev(ctx, &r.hp);
+        const shq_hydro_params *p = &r.hp;
+        sph_hydro_post_kernel<<<dim3(nblk(r.size)), dim3(256), 0, ctx->stream>>>(a, r.cur, r.size, ctx->g_density.ptr, ctx->g_delaytime.ptr,
+                                                                                p->hubble_a2, p->atime, p->WindSpeed, p->WindFreeTravelDensThresh);
         SHQ_HIP(hipGetLastError());
     }
+    r.niter = 1;
+    return SHQ_OK;
+}
+
+int shq_sph_hydro_end(shq_context *ctx, shq_sph_stats *stats)
+{
+    shq_context::SphRun &r = ctx->sphrun;
+    SHQ_CHECK(r.phase == 2, SHQ_ERR_STATE, "hydro end: no hydro walk is open");
+    r.phase = 0;
     SHQ_HIP(hipEventRecord(ctx->ev_end[14], ctx->stream));
     if(stats) {
+        unsigned long long *nint = reinterpret_cast<unsigned long long *>(ctx->s_counters.ptr + 1);
         unsigned long long h_nint = 0;
         SHQ_HIP(hipMemcpyAsync(&h_nint, nint, sizeof(h_nint), hipMemcpyDeviceToHost, ctx->stream));
         SHQ_HIP(hipStreamSynchronize(ctx->stream));
         float ms = 0;
         (void) hipEventElapsedTime(&ms, ctx->ev_begin[14], ctx->ev_end[14]);
-        stats->ntargets = nq;
+        stats->ntargets = r.nq0;
         stats->ninteractions = (int64_t) h_nint;
         stats->niterations = 1;
         stats->kernel_ms = ms;
-        if(getenv("SHQ_SPH_DEBUG")) {
+        if(getenv("SHQ_SPH_DEBUG") && r.nq0 > 0) {
             unsigned long long d[5];
             SHQ_HIP(hipMemcpy(d, nint, sizeof(d), hipMemcpyDeviceToHost));
-            const double nw = (double) ((nq + 63) / 64);
+            const double nw = (double) ((r.nq0 + 63) / 64);
             fprintf(stderr, "[shq] hydro per wave: nodes %.1f candidates %.1f pair rounds %.1f; per target: candidates %.1f\n",
-                    d[1] / nw, d[2] / nw, d[4] / nw, (double) d[0] / nq);
+                    d[1] / nw, d[2] / nw, d[4] / nw, (double) d[0] / r.nq0);
         }
     }
+    return SHQ_OK;
+}
+
+int shq_sph_hydro_device(shq_context *ctx, const shq_hydro_params *p, const int32_t *d_queue, int64_t nq, shq_sph_stats *stats)
+{
+    SHQ_TRY(shq_sph_hydro_begin(ctx, p, d_queue, nq));
+    SHQ_TRY(shq_sph_hydro_primary(ctx));
+    SHQ_TRY(shq_sph_hydro_post(ctx));
+    return shq_sph_hydro_end(ctx, stats);
+}
+
+/* HydroResult::reduce<TREEWALK_GHOSTS>, hydratree2.hpp:213-227 */
+__global__ void sph_hydro_reduce_kernel(const SphDev a, long long n, const int32_t *__restrict__ place, const shq_hydro_result *__restrict__ res)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    const long long i = place[k];
+    if(k > 0 && place[k - 1] == i)
+        return;
+    double a0 = a.hacc[3 * i], a1 = a.hacc[3 * i + 1], a2 = a.hacc[3 * i + 2], de = a.dtent[i], ms = a.maxsig[i];
+    for(long long j = k; j < n && place[j] == i; j++) {
+        const shq_hydro_result r = res[j];
+        a0 += r.Acc[0];
+        a1 += r.Acc[1];
+        a2 += r.Acc[2];
+        de += r.DtEntropy;
+        if(ms < r.MaxSignalVel)
+            ms = r.MaxSignalVel;
+    }
+    a.hacc[3 * i] = a0;
+    a.hacc[3 * i + 1] = a1;
+    a.hacc[3 * i + 2] = a2;
+    a.dtent[i] = de;
+    a.maxsig[i] = ms;
+}
+
+int shq_sph_hydro_reduce(shq_context *ctx, const int32_t *d_place, const void *d_results, int64_t n)
+{
+    SHQ_CHECK(ctx->sphrun.phase == 2, SHQ_ERR_STATE, "hydro reduce: no hydro walk is open");
+    if(n == 0)
+        return SHQ_OK;
+    const SphDev a = hydro_dev(ctx, &ctx->sphrun.hp);
+    sph_hydro_reduce_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(a, n, d_place, static_cast<const shq_hydro_result *>(d_results));
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}
+
+/* visit<TREEWALK_GHOSTS> for imported HydroQuery records; d_out: 5 nq doubles, Acc[3] (AoS, 3 nq), DtEntropy, MaxSignalVel */
+int shq_sph_hydro_secondary(shq_context *ctx, const shq_hydro_params *p, const double4 *d_qposm, const double *d_qhsml,
+                            const double4 *d_qvelp, const double4 *d_qC, const double4 *d_qD, const int4 *d_qseg, int64_t nq, double *d_out,
+                            unsigned long long *d_nint)
+{
+    if(nq == 0)
+        return SHQ_OK;
+    SHQ_CHECK(p->DensityKernelType == 1 || p->DensityKernelType == 2 || p->DensityKernelType == 4, SHQ_ERR_INVALID,
+              "unknown DensityKernelType %d", p->DensityKernelType);
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    SphDev a = hydro_dev(ctx, p);
+    a.posm = d_qposm;
+    a.hsml = const_cast<double *>(d_qhsml);
+    a.velp = d_qvelp;
+    a.hydC = d_qC;
+    a.hydD = d_qD;
+    a.hacc = d_out;
+    a.dtent = d_out + 3 * nq;
+    a.maxsig = d_out + 4 * nq;
+    const HydroConst hc = hydro_const(p);
+    const long long ntasks = (nq + 255) / 256;
+    const unsigned grid = (unsigned) (ntasks < NL_REDO_BLOCKS ? ntasks : NL_REDO_BLOCKS);
+    hipStream_t st = ctx->stream;
+    switch(p->DensityKernelType) {
+    case 1: sph_hydro_kernel<1, 0, true><<<dim3(grid), dim3(256), 0, st>>>(a, nullptr, nq, hc, d_nint, ctx->s_nlist2.ptr, ntasks, nullptr, nullptr, d_qseg); break;
+    case 2: sph_hydro_kernel<2, 0, true><<<dim3(grid), dim3(256), 0, st>>>(a, nullptr, nq, hc, d_nint, ctx->s_nlist2.ptr, ntasks, nullptr, nullptr, d_qseg); break;
+    default: sph_hydro_kernel<4, 0, true><<<dim3(grid), dim3(256), 0, st>>>(a, nullptr, nq, hc, d_nint, ctx->s_nlist2.ptr, ntasks, nullptr, nullptr, d_qseg); break;
+    }
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}
+
+/* The export queries of a walk in progress, one record per table entry (DensityQuery / HydroQuery ctors,
+ * densitytree2.hpp:267-278, hydratree2.hpp:165-191): everything comes from the resident arrays. */
+__global__ void sph_fill_density_queries_kernel(const SphDev a, long long n, const shq_data_index *__restrict__ table, shq_density_query *out)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    const shq_data_index e = table[k];
+    const long long i = e.Index;
+    shq_density_query q;
+    const double4 p = a.posm[i], v = a.velp[i];
+    q.Pos[0] = p.x; q.Pos[1] = p.y; q.Pos[2] = p.z;
+    for(int j = 0; j < 4; j++)
+        q.NodeList[j] = e.NodeList[j];
+    q.Vel[0] = v.x; q.Vel[1] = v.y; q.Vel[2] = v.z;
+    q.Hsml = a.hsml[i];
+    q.Type = a.pflags[i] >> 4;
+    q.pad_ = 0;
+    out[k] = q;
+}
+
+__global__ void sph_fill_hydro_queries_kernel(const SphDev a, long long n, const shq_data_index *__restrict__ table, const double *__restrict__ density,
+                                              const uint8_t *__restrict__ bin_hydro, int DISPH, double fac_mu, shq_hydro_query *out)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    const shq_data_index e = table[k];
+    const long long i = e.Index;
+    shq_hydro_query q;
+    const double4 p = a.posm[i], v = a.velp[i];
+    q.Pos[0] = p.x; q.Pos[1] = p.y; q.Pos[2] = p.z;
+    for(int j = 0; j < 4; j++)
+        q.NodeList[j] = e.NodeList[j];
+    const double eom = DISPH ? a.egyrho[i] : density[i]; /* SPH_EOMDensity, hydratree2.hpp:36-45 */
+    q.EgyRho = eom;
+    q.EntVarPred = v.w;
+    q.Vel[0] = v.x; q.Vel[1] = v.y; q.Vel[2] = v.z;
+    q.Hsml = a.hsml[i];
+    q.Mass = p.w;
+    q.Density = density[i];
+    q.Pressure = pressure_predict(eom, v.w);
+    q.SPH_DhsmlDensityFactor = a.dhsmlegy[i];
+    const double cs = sqrt(SPH_GAMMA * q.Pressure / eom);
+    q.F1 = fabs(a.div[i]) / (fabs(a.div[i]) + a.curl[i] + 0.0001 * cs / q.Hsml / fac_mu);
+    q.TimeBinHydro = bin_hydro[i];
+    q.pad_ = 0;
+    out[k] = q;
+}
+
+int shq_sph_fill_queries_device(shq_context *ctx, const shq_data_index *d_table, int64_t n, void *d_out)
+{
+    const shq_context::SphRun &r = ctx->sphrun;
+    SHQ_CHECK(r.phase == 1 || r.phase == 2, SHQ_ERR_STATE, "fill_queries: no SPH walk is open");
+    if(n == 0)
+        return SHQ_OK;
+    const SphDev a = make_dev(ctx);
+    if(r.phase == 1)
+        sph_fill_density_queries_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(a, n, d_table, static_cast<shq_density_query *>(d_out));
+    else
+        sph_fill_hydro_queries_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(a, n, d_table, ctx->g_density.ptr, ctx->bin_hydro.ptr,
+                                                                                   r.hp.DensityIndependentSphOn, r.hp.fac_mu,
+                                                                                   static_cast<shq_hydro_query *>(d_out));
+    SHQ_HIP(hipGetLastError());
     return SHQ_OK;
 }
 

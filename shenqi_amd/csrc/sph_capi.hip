@@ -115,11 +115,15 @@ std::vector<int32_t> build_queue(const shq_part_view *parts, const int32_t *acti
 
 } // namespace
 
-extern "C" int shq_density(shq_context *ctx, const shq_tree_view *tree, shq_node *nodes_rw, const shq_part_view *parts,
-                           const shq_sph_view *sph, const shq_bh_view *bh, const int32_t *active, int64_t nactive,
-                           const shq_density_params *params, double *EntVarPred, double *GradRho_mag, shq_sph_stats *stats)
+/* the host copy of the work queue of the open walk: close() assigns results only to the walked targets */
+static std::vector<int32_t> &run_queue(shq_context *ctx) { return ctx->sph_queue_host; }
+
+extern "C" int shq_density_open(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph,
+                                const shq_bh_view *bh, const int32_t *active, int64_t nactive, const shq_density_params *params,
+                                int want_gradrho, int64_t *nqueue)
 {
     SHQ_CHECK(ctx && tree && parts && sph && params, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->sphrun.phase == 0, SHQ_ERR_STATE, "density_open: another SPH walk is open");
     SHQ_HIP(hipSetDevice(ctx->device));
     const int64_t n = parts->numpart;
     if(active)
@@ -128,25 +132,62 @@ extern "C" int shq_density(shq_context *ctx, const shq_tree_view *tree, shq_node
     SHQ_TRY(shq_particles_upload(ctx, parts));
     SHQ_TRY(sph_upload(ctx, parts, sph));
     SHQ_TRY(shq_tree_upload(ctx, tree));
-    SHQ_CHECK(!params->update_hsml || ctx->have_father || nodes_rw == nullptr, SHQ_ERR_INVALID,
-              "density with update_hsml needs tree->father to update hmax (update_tree_hmax_father)");
-    std::vector<int32_t> queue = build_queue(parts, active, nactive, true);
+    std::vector<int32_t> &queue = run_queue(ctx);
+    queue = build_queue(parts, active, nactive, true);
     for(int32_t i : queue) {
         if(*pfield<uint8_t>(parts, i, parts->off_type) == 5)
             SHQ_CHECK(bh && bh->base, SHQ_ERR_INVALID, "black-hole density target but no BH slot view");
     }
     const int64_t nq = (int64_t) queue.size();
-    SHQ_TRY(ctx->active.reserve((size_t) std::max<int64_t>(nq, 1)));
+    SHQ_TRY(ctx->s_queue0.reserve((size_t) std::max<int64_t>(nq, 1)));
     if(nq > 0)
-        SHQ_HIP(hipMemcpyAsync(ctx->active.ptr, queue.data(), sizeof(int32_t) * nq, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(ctx->s_queue0.ptr, queue.data(), sizeof(int32_t) * nq, hipMemcpyHostToDevice, ctx->stream));
     if(!ctx->have_father) { /* no hmax updates */
         SHQ_TRY(ctx->pfather.reserve((size_t) std::max<int64_t>(n, 1)));
         if(n > 0)
             SHQ_HIP(hipMemsetAsync(ctx->pfather.ptr, 0xff, sizeof(int32_t) * n, ctx->stream));
     }
     SHQ_TRY(shq_sph_prepare(ctx, &params->kf, nullptr, nullptr));
-    SHQ_TRY(shq_sph_density_device(ctx, params, ctx->active.ptr, nq, GradRho_mag != nullptr, stats));
+    SHQ_TRY(shq_sph_density_begin(ctx, params, ctx->s_queue0.ptr, nq, want_gradrho));
+    if(nqueue)
+        *nqueue = nq;
+    return SHQ_OK;
+}
 
+extern "C" int shq_density_ev_primary(shq_context *ctx)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    return shq_sph_density_primary(ctx);
+}
+
+extern "C" int shq_density_ev_postprocess(shq_context *ctx, int64_t *nredo)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    int64_t nr = 0;
+    const int rc = shq_sph_density_post(ctx, &nr);
+    if(nredo)
+        *nredo = nr;
+    if(rc != SHQ_OK)
+        ctx->sphrun.phase = 0; /* not converged: the walk is abandoned */
+    return rc;
+}
+
+extern "C" int shq_density_close(shq_context *ctx, shq_node *nodes_rw, const shq_part_view *parts, const shq_sph_view *sph,
+                                 const shq_bh_view *bh, double *EntVarPred, double *GradRho_mag, shq_sph_stats *stats)
+{
+    SHQ_CHECK(ctx && parts && sph, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->sphrun.phase == 1, SHQ_ERR_STATE, "density_close: no density walk is open");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const shq_density_params *params = &ctx->sphrun.dp;
+    SHQ_CHECK(!GradRho_mag || ctx->sphrun.want_gradrho, SHQ_ERR_INVALID, "density_close: GradRho_mag needs want_gradrho at open");
+    SHQ_CHECK(!params->update_hsml || ctx->have_father || nodes_rw == nullptr, SHQ_ERR_INVALID,
+              "density with update_hsml needs tree->father to update hmax (update_tree_hmax_father)");
+    const int64_t n = parts->numpart;
+    SHQ_CHECK(n == ctx->numpart, SHQ_ERR_INVALID, "density_close: not the particle array of density_open");
+    SHQ_TRY(shq_sph_density_end(ctx, stats));
+    const std::vector<int32_t> &queue = run_queue(ctx);
     /* results back into the caller's arrays: only the walked targets are assigned
      * (reduce<PRIMARY>, localtreewalk2.h:39) */
     std::vector<double> hsml, dthsml, density, egywt, dhsml, divvel, curl, gmag;
@@ -182,7 +223,7 @@ extern "C" int shq_density(shq_context *ctx, const shq_tree_view *tree, shq_node
             if(GradRho_mag)
                 GradRho_mag[pi] = gmag[i];
         } else {
-            SHQ_CHECK(pi >= 0 && pi < bh->numslots, SHQ_ERR_INVALID, "BH particle with PI outside the BH slot array");
+            SHQ_CHECK(bh && pi >= 0 && pi < bh->numslots, SHQ_ERR_INVALID, "BH particle with PI outside the BH slot array");
             char *b = static_cast<char *>(bh->base) + (size_t) pi * bh->elsize;
             *reinterpret_cast<double *>(b + bh->off_density) = density[i];
             *reinterpret_cast<double *>(b + bh->off_divvel) = divvel[i];
@@ -207,11 +248,34 @@ extern "C" int shq_density(shq_context *ctx, const shq_tree_view *tree, shq_node
     return SHQ_OK;
 }
 
-extern "C" int shq_hydro_force(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts,
-                               const shq_sph_view *sph, const int32_t *active, int64_t nactive,
-                               const shq_hydro_params *params, const double *EntVarPred, shq_sph_stats *stats)
+extern "C" int shq_density(shq_context *ctx, const shq_tree_view *tree, shq_node *nodes_rw, const shq_part_view *parts,
+                           const shq_sph_view *sph, const shq_bh_view *bh, const int32_t *active, int64_t nactive,
+                           const shq_density_params *params, double *EntVarPred, double *GradRho_mag, shq_sph_stats *stats)
 {
     SHQ_CHECK(ctx && tree && parts && sph && params, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(!params->update_hsml || tree->father || nodes_rw == nullptr, SHQ_ERR_INVALID,
+              "density with update_hsml needs tree->father to update hmax (update_tree_hmax_father)");
+    ctx->sphrun.phase = 0; /* a one-shot call supersedes whatever an earlier, failed walk left open */
+    SHQ_TRY(shq_density_open(ctx, tree, parts, sph, bh, active, nactive, params, GradRho_mag != nullptr, nullptr));
+    int64_t nredo = 0;
+    do {
+        int rc = shq_density_ev_primary(ctx);
+        if(rc == SHQ_OK)
+            rc = shq_density_ev_postprocess(ctx, &nredo);
+        if(rc != SHQ_OK) {
+            ctx->sphrun.phase = 0;
+            return rc;
+        }
+    } while(nredo > 0);
+    return shq_density_close(ctx, nodes_rw, parts, sph, bh, EntVarPred, GradRho_mag, stats);
+}
+
+extern "C" int shq_hydro_open(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph,
+                              const int32_t *active, int64_t nactive, const shq_hydro_params *params, const double *EntVarPred,
+                              int64_t *nqueue)
+{
+    SHQ_CHECK(ctx && tree && parts && sph && params, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->sphrun.phase == 0, SHQ_ERR_STATE, "hydro_open: another SPH walk is open");
     SHQ_HIP(hipSetDevice(ctx->device));
     const int64_t n = parts->numpart;
     if(active)
@@ -220,11 +284,12 @@ extern "C" int shq_hydro_force(shq_context *ctx, const shq_tree_view *tree, cons
     SHQ_TRY(shq_particles_upload(ctx, parts));
     SHQ_TRY(sph_upload(ctx, parts, sph));
     SHQ_TRY(shq_tree_upload(ctx, tree));
-    std::vector<int32_t> queue = build_queue(parts, active, nactive, false);
+    std::vector<int32_t> &queue = run_queue(ctx);
+    queue = build_queue(parts, active, nactive, false);
     const int64_t nq = (int64_t) queue.size();
-    SHQ_TRY(ctx->active.reserve((size_t) std::max<int64_t>(nq, 1)));
+    SHQ_TRY(ctx->s_queue0.reserve((size_t) std::max<int64_t>(nq, 1)));
     if(nq > 0)
-        SHQ_HIP(hipMemcpyAsync(ctx->active.ptr, queue.data(), sizeof(int32_t) * nq, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(ctx->s_queue0.ptr, queue.data(), sizeof(int32_t) * nq, hipMemcpyHostToDevice, ctx->stream));
     const double *d_evp = nullptr;
     std::vector<double> evp_by_part;
     if(EntVarPred) { /* hydro reuses density()'s EntVarPred array (hydra2.cpp:76, HydroPriv::EntVarPred) */
@@ -239,7 +304,36 @@ extern "C" int shq_hydro_force(shq_context *ctx, const shq_tree_view *tree, cons
         d_evp = ctx->s_evp_in.ptr;
     }
     SHQ_TRY(shq_sph_prepare(ctx, &params->kf, params, d_evp));
-    SHQ_TRY(shq_sph_hydro_device(ctx, params, ctx->active.ptr, nq, stats));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream)); /* evp_by_part dies here */
+    SHQ_TRY(shq_sph_hydro_begin(ctx, params, ctx->s_queue0.ptr, nq));
+    if(nqueue)
+        *nqueue = nq;
+    return SHQ_OK;
+}
+
+extern "C" int shq_hydro_ev_primary(shq_context *ctx)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    return shq_sph_hydro_primary(ctx);
+}
+
+extern "C" int shq_hydro_ev_postprocess(shq_context *ctx)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    return shq_sph_hydro_post(ctx);
+}
+
+extern "C" int shq_hydro_close(shq_context *ctx, const shq_part_view *parts, const shq_sph_view *sph, shq_sph_stats *stats)
+{
+    SHQ_CHECK(ctx && parts && sph, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->sphrun.phase == 2, SHQ_ERR_STATE, "hydro_close: no hydro walk is open");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t n = parts->numpart;
+    SHQ_CHECK(n == ctx->numpart, SHQ_ERR_INVALID, "hydro_close: not the particle array of hydro_open");
+    SHQ_TRY(shq_sph_hydro_end(ctx, stats));
+    const std::vector<int32_t> &queue = run_queue(ctx);
     std::vector<double> hacc, dtent, maxsig;
     SHQ_TRY(down(ctx, ctx->g_hydroaccel_out, hacc, 3 * n));
     SHQ_TRY(down(ctx, ctx->g_dtentropy_out, dtent, n));
@@ -255,4 +349,301 @@ extern "C" int shq_hydro_force(shq_context *ctx, const shq_tree_view *tree, cons
         *sfield(sph, pi, sph->off_maxsignalvel) = maxsig[i];
     }
     return SHQ_OK;
+}
+
+extern "C" int shq_hydro_force(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts,
+                               const shq_sph_view *sph, const int32_t *active, int64_t nactive,
+                               const shq_hydro_params *params, const double *EntVarPred, shq_sph_stats *stats)
+{
+    SHQ_CHECK(ctx && tree && parts && sph && params, SHQ_ERR_INVALID, "null argument");
+    ctx->sphrun.phase = 0;
+    SHQ_TRY(shq_hydro_open(ctx, tree, parts, sph, active, nactive, params, EntVarPred, nullptr));
+    int rc = shq_hydro_ev_primary(ctx);
+    if(rc == SHQ_OK)
+        rc = shq_hydro_ev_postprocess(ctx);
+    if(rc != SHQ_OK) {
+        ctx->sphrun.phase = 0;
+        return rc;
+    }
+    return shq_hydro_close(ctx, parts, sph, stats);
+}
+
+/* ---- the exchange between ev_primary and ev_postprocess ------------------------------------------------------------ */
+namespace {
+
+/* group (place, result) pairs by place, keeping the order within a place; returns pointers to use */
+template <typename R> void group_by_place(const int32_t *&place, const R *&results, int64_t n, std::vector<int32_t> &hp, std::vector<R> &hr)
+{
+    bool grouped = true;
+    for(int64_t k = 1; k < n; k++)
+        if(place[k] < place[k - 1]) {
+            grouped = false;
+            break;
+        }
+    if(grouped)
+        return;
+    std::vector<int64_t> ord((size_t) n);
+    for(int64_t k = 0; k < n; k++)
+        ord[k] = k;
+    std::stable_sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) { return place[x] < place[y]; });
+    hp.resize((size_t) n);
+    hr.resize((size_t) n);
+    for(int64_t k = 0; k < n; k++) {
+        hp[k] = place[ord[k]];
+        hr[k] = results[ord[k]];
+    }
+    place = hp.data();
+    results = hr.data();
+}
+
+template <typename R, class Fn> int reduce_results(shq_context *ctx, const int32_t *place, const R *results, int64_t n, Fn &&launch)
+{
+    SHQ_CHECK(n >= 0 && (n == 0 || (place && results)), SHQ_ERR_INVALID, "ev_reduce: bad arguments");
+    if(n == 0)
+        return SHQ_OK;
+    for(int64_t k = 0; k < n; k++)
+        SHQ_CHECK(place[k] >= 0 && place[k] < ctx->numpart, SHQ_ERR_INVALID, "ev_reduce: place[%ld] = %d out of range", (long) k, place[k]);
+    std::vector<int32_t> hp;
+    std::vector<R> hr;
+    group_by_place(place, results, n, hp, hr);
+    DevBuf<int32_t> dplace;
+    DevBuf<R> dres;
+    auto run = [&]() -> int {
+        SHQ_TRY(dplace.reserve((size_t) n));
+        SHQ_TRY(dres.reserve((size_t) n));
+        SHQ_HIP(hipMemcpyAsync(dplace.ptr, place, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(dres.ptr, results, sizeof(R) * n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_TRY(launch(dplace.ptr, (const void *) dres.ptr));
+        return SHQ_OK;
+    };
+    const int rc = run();
+    (void) hipStreamSynchronize(ctx->stream);
+    dplace.release();
+    dres.release();
+    return rc;
+}
+
+/* NodeList (host node numbers) -> sorted packed start indices of the branches */
+int query_segments(shq_context *ctx, const int32_t *nodelist, int64_t q, int4 *seg)
+{
+    const int64_t fn = ctx->firstnode, nn = ctx->numnodes;
+    const int64_t nall = ctx->node_rank.empty() ? nn : (int64_t) ctx->node_rank.size();
+    int32_t st[4];
+    int ns = 0;
+    for(int k = 0; k < 4 && nodelist[k] >= 0; k++) {
+        const int64_t no = nodelist[k];
+        SHQ_CHECK(no >= fn && no < fn + nall, SHQ_ERR_INVALID, "query %ld: NodeList entry %ld is not a local node", (long) q, (long) no);
+        const int32_t r = ctx->node_rank.empty() ? (int32_t) (no - fn) : ctx->node_rank[(size_t) (no - fn)];
+        SHQ_CHECK(r >= 0 && r < nn, SHQ_ERR_INVALID, "query %ld: NodeList entry %ld is not reachable from the root", (long) q, (long) no);
+        st[ns++] = r;
+    }
+    std::sort(st, st + ns);
+    *seg = make_int4(ns > 0 ? st[0] : -1, ns > 1 ? st[1] : -1, ns > 2 ? st[2] : -1, ns > 3 ? st[3] : -1);
+    return SHQ_OK;
+}
+
+} // namespace
+
+extern "C" int shq_density_ev_reduce(shq_context *ctx, const int32_t *place, const shq_density_result *results, int64_t n)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_CHECK(ctx->sphrun.phase == 1, SHQ_ERR_STATE, "density_ev_reduce: no density walk is open");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    return reduce_results(ctx, place, results, n, [&](const int32_t *dp, const void *dr) { return shq_sph_density_reduce(ctx, dp, dr, n); });
+}
+
+extern "C" int shq_hydro_ev_reduce(shq_context *ctx, const int32_t *place, const shq_hydro_result *results, int64_t n)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_CHECK(ctx->sphrun.phase == 2, SHQ_ERR_STATE, "hydro_ev_reduce: no hydro walk is open");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    return reduce_results(ctx, place, results, n, [&](const int32_t *dp, const void *dr) { return shq_sph_hydro_reduce(ctx, dp, dr, n); });
+}
+
+extern "C" int shq_density_ev_secondary(shq_context *ctx, const shq_density_params *params, const shq_density_query *queries, int64_t nq,
+                                        shq_density_result *results, int64_t *ninteractions_total)
+{
+    SHQ_CHECK(ctx && params && (nq == 0 || (queries && results)), SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts && ctx->have_tree && ctx->have_sph, SHQ_ERR_STATE, "density_ev_secondary: no SPH state on the device (open a walk first)");
+    SHQ_CHECK(nq >= 0 && nq < (1ll << 31), SHQ_ERR_INVALID, "bad query count");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    if(ninteractions_total)
+        *ninteractions_total = 0;
+    if(nq == 0)
+        return SHQ_OK;
+    const size_t n = (size_t) nq;
+    std::vector<double4> hpos(n), hvel(n);
+    std::vector<double> hh(n);
+    std::vector<uint8_t> hf(n);
+    std::vector<int4> hseg(n);
+    for(size_t q = 0; q < n; q++) {
+        const shq_density_query &Q = queries[q];
+        hpos[q] = make_double4(Q.Pos[0], Q.Pos[1], Q.Pos[2], 0.0);
+        hvel[q] = make_double4(Q.Vel[0], Q.Vel[1], Q.Vel[2], 0.0);
+        hh[q] = Q.Hsml;
+        SHQ_CHECK(Q.Type >= 0 && Q.Type < 6 && Q.Hsml > 0, SHQ_ERR_INVALID, "query %ld: bad Type %d or Hsml %g", (long) q, Q.Type, Q.Hsml);
+        hf[q] = (uint8_t) (Q.Type << 4);
+        SHQ_TRY(query_segments(ctx, Q.NodeList, (int64_t) q, &hseg[q]));
+    }
+    DevBuf<double4> dpos, dvel;
+    DevBuf<double> dh, dout;
+    DevBuf<uint8_t> df;
+    DevBuf<int4> dseg;
+    DevBuf<unsigned long long> dn;
+    std::vector<double> hout(12 * n);
+    unsigned long long hn = 0;
+    auto run = [&]() -> int {
+        SHQ_TRY(dpos.reserve(n)); SHQ_TRY(dvel.reserve(n)); SHQ_TRY(dh.reserve(n)); SHQ_TRY(df.reserve(n)); SHQ_TRY(dseg.reserve(n));
+        SHQ_TRY(dout.reserve(12 * n)); SHQ_TRY(dn.reserve(8));
+        hipStream_t st = ctx->stream;
+        SHQ_HIP(hipMemcpyAsync(dpos.ptr, hpos.data(), sizeof(double4) * n, hipMemcpyHostToDevice, st));
+        SHQ_HIP(hipMemcpyAsync(dvel.ptr, hvel.data(), sizeof(double4) * n, hipMemcpyHostToDevice, st));
+        SHQ_HIP(hipMemcpyAsync(dh.ptr, hh.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
+        SHQ_HIP(hipMemcpyAsync(df.ptr, hf.data(), n, hipMemcpyHostToDevice, st));
+        SHQ_HIP(hipMemcpyAsync(dseg.ptr, hseg.data(), sizeof(int4) * n, hipMemcpyHostToDevice, st));
+        SHQ_HIP(hipMemsetAsync(dout.ptr, 0, sizeof(double) * 12 * n, st));
+        SHQ_HIP(hipMemsetAsync(dn.ptr, 0, sizeof(unsigned long long) * 8, st));
+        SHQ_TRY(shq_sph_density_secondary(ctx, params, dpos.ptr, dh.ptr, dvel.ptr, df.ptr, dseg.ptr, nq, dout.ptr, dn.ptr));
+        SHQ_HIP(hipMemcpyAsync(hout.data(), dout.ptr, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipMemcpyAsync(&hn, dn.ptr, sizeof(hn), hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipStreamSynchronize(st));
+        return SHQ_OK;
+    };
+    const int rc = run();
+    (void) hipStreamSynchronize(ctx->stream);
+    dpos.release(); dvel.release(); dh.release(); df.release(); dseg.release(); dout.release(); dn.release();
+    SHQ_TRY(rc);
+    for(size_t q = 0; q < n; q++) {
+        shq_density_result &R = results[q];
+        R.Ngb = hout[q];
+        R.DhsmlDensity = hout[n + q];
+        R.Rho = hout[2 * n + q];
+        R.Div = hout[3 * n + q];
+        R.EgyRho = hout[4 * n + q];
+        R.DhsmlEgyDensity = hout[5 * n + q];
+        for(int k = 0; k < 3; k++) {
+            R.Rot[k] = hout[6 * n + 3 * q + k];
+            R.GradRho[k] = hout[9 * n + 3 * q + k];
+        }
+    }
+    if(ninteractions_total)
+        *ninteractions_total = (int64_t) hn;
+    return SHQ_OK;
+}
+
+extern "C" int shq_hydro_ev_secondary(shq_context *ctx, const shq_hydro_params *params, const shq_hydro_query *queries, int64_t nq,
+                                      shq_hydro_result *results, int64_t *ninteractions_total)
+{
+    SHQ_CHECK(ctx && params && (nq == 0 || (queries && results)), SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts && ctx->have_tree && ctx->have_sph, SHQ_ERR_STATE, "hydro_ev_secondary: no SPH state on the device (open a walk first)");
+    SHQ_CHECK(nq >= 0 && nq < (1ll << 31), SHQ_ERR_INVALID, "bad query count");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    if(ninteractions_total)
+        *ninteractions_total = 0;
+    if(nq == 0)
+        return SHQ_OK;
+    const size_t n = (size_t) nq;
+    std::vector<double4> hpos(n), hvel(n), hC(n), hD(n);
+    std::vector<double> hh(n);
+    std::vector<int4> hseg(n);
+    const double GAMMA = 5.0 / 3.0;
+    for(size_t q = 0; q < n; q++) {
+        const shq_hydro_query &Q = queries[q];
+        SHQ_CHECK(Q.Hsml > 0 && Q.EgyRho > 0 && Q.TimeBinHydro >= 0 && Q.TimeBinHydro <= SHQ_TIMEBINS, SHQ_ERR_INVALID,
+                  "query %ld: bad Hsml %g, EgyRho %g or TimeBinHydro %d", (long) q, Q.Hsml, Q.EgyRho, Q.TimeBinHydro);
+        hpos[q] = make_double4(Q.Pos[0], Q.Pos[1], Q.Pos[2], Q.Mass);
+        hvel[q] = make_double4(Q.Vel[0], Q.Vel[1], Q.Vel[2], Q.EntVarPred);
+        hh[q] = Q.Hsml;
+        /* HydroLocalTreeWalk ctor, hydratree2.hpp:240-245, and the rr1 of ngbiter (:353-367) */
+        const double cs = sqrt(GAMMA * Q.Pressure / Q.EgyRho);
+        hC[q] = make_double4(Q.EntVarPred, Q.Density, cs, Q.Pressure / (Q.EgyRho * Q.EgyRho));
+        double rr1 = 1;
+        if(params->DensityIndependentSphOn) {
+            rr1 = 0;
+            if(params->DensityContrastLimit >= 0) {
+                rr1 = Q.EgyRho / Q.Density;
+                if(params->DensityContrastLimit > 0)
+                    rr1 = std::min(rr1, params->DensityContrastLimit);
+            }
+        }
+        hD[q] = make_double4(Q.SPH_DhsmlDensityFactor, rr1, Q.F1, params->kf.dloga_for_bin[Q.TimeBinHydro]);
+        SHQ_TRY(query_segments(ctx, Q.NodeList, (int64_t) q, &hseg[q]));
+    }
+    DevBuf<double4> dpos, dvel, dC, dD;
+    DevBuf<double> dh, dout;
+    DevBuf<int4> dseg;
+    DevBuf<unsigned long long> dn;
+    std::vector<double> hout(5 * n);
+    unsigned long long hn = 0;
+    auto run = [&]() -> int {
+        SHQ_TRY(dpos.reserve(n)); SHQ_TRY(dvel.reserve(n)); SHQ_TRY(dC.reserve(n)); SHQ_TRY(dD.reserve(n)); SHQ_TRY(dh.reserve(n));
+        SHQ_TRY(dseg.reserve(n)); SHQ_TRY(dout.reserve(5 * n)); SHQ_TRY(dn.reserve(8));
+        hipStream_t st = ctx->stream;
+        SHQ_HIP(hipMemcpyAsync(dpos.ptr, hpos.data(), sizeof(double4) * n, hipMemcpyHostToDevice, st));
+        SHQ_HIP(hipMemcpyAsync(dvel.ptr, hvel.data(), sizeof(double4) * n, hipMemcpyHostToDevice, st));
+        SHQ_HIP(hipMemcpyAsync(dC.ptr, hC.data(), sizeof(double4) * n, hipMemcpyHostToDevice, st));
+        SHQ_HIP(hipMemcpyAsync(dD.ptr, hD.data(), sizeof(double4) * n, hipMemcpyHostToDevice, st));
+        SHQ_HIP(hipMemcpyAsync(dh.ptr, hh.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
+        SHQ_HIP(hipMemcpyAsync(dseg.ptr, hseg.data(), sizeof(int4) * n, hipMemcpyHostToDevice, st));
+        SHQ_HIP(hipMemsetAsync(dout.ptr, 0, sizeof(double) * 5 * n, st));
+        SHQ_HIP(hipMemsetAsync(dn.ptr, 0, sizeof(unsigned long long) * 8, st));
+        SHQ_TRY(shq_sph_hydro_secondary(ctx, params, dpos.ptr, dh.ptr, dvel.ptr, dC.ptr, dD.ptr, dseg.ptr, nq, dout.ptr, dn.ptr));
+        SHQ_HIP(hipMemcpyAsync(hout.data(), dout.ptr, sizeof(double) * 5 * n, hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipMemcpyAsync(&hn, dn.ptr, sizeof(hn), hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipStreamSynchronize(st));
+        return SHQ_OK;
+    };
+    const int rc = run();
+    (void) hipStreamSynchronize(ctx->stream);
+    dpos.release(); dvel.release(); dC.release(); dD.release(); dh.release(); dseg.release(); dout.release(); dn.release();
+    SHQ_TRY(rc);
+    for(size_t q = 0; q < n; q++) {
+        shq_hydro_result &R = results[q];
+        R.Acc[0] = hout[3 * q];
+        R.Acc[1] = hout[3 * q + 1];
+        R.Acc[2] = hout[3 * q + 2];
+        R.DtEntropy = hout[3 * n + q];
+        R.MaxSignalVel = hout[4 * n + q];
+    }
+    if(ninteractions_total)
+        *ninteractions_total = (int64_t) hn;
+    return SHQ_OK;
+}
+
+extern "C" int shq_sph_exports(shq_context *ctx, int32_t *exportcounts, shq_data_index *table, int64_t capacity, int64_t *nexport)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    const int phase = ctx->sphrun.phase;
+    SHQ_CHECK(phase == 1 || phase == 2, SHQ_ERR_STATE, "sph_exports: no SPH walk is open");
+    const double Box = phase == 1 ? ctx->sphrun.dp.BoxSize : ctx->sphrun.hp.BoxSize;
+    return shq_ngb_toptree_exports(ctx, phase == 2, Box, SHQ_SPH_QUEUE_RESIDENT, 0, exportcounts, table, capacity, nexport);
+}
+
+extern "C" int shq_sph_fill_queries(shq_context *ctx, const shq_data_index *table, int64_t n, void *queries)
+{
+    SHQ_CHECK(ctx && n >= 0 && (n == 0 || (table && queries)), SHQ_ERR_INVALID, "bad argument");
+    const int phase = ctx->sphrun.phase;
+    SHQ_CHECK(phase == 1 || phase == 2, SHQ_ERR_STATE, "sph_fill_queries: no SPH walk is open");
+    if(n == 0)
+        return SHQ_OK;
+    SHQ_HIP(hipSetDevice(ctx->device));
+    for(int64_t k = 0; k < n; k++)
+        SHQ_CHECK(table[k].Index >= 0 && table[k].Index < ctx->numpart, SHQ_ERR_INVALID, "table[%ld].Index = %d out of range", (long) k, table[k].Index);
+    const size_t rec = phase == 1 ? sizeof(shq_density_query) : sizeof(shq_hydro_query);
+    DevBuf<shq_data_index> dt;
+    DevBuf<char> dq;
+    auto run = [&]() -> int {
+        SHQ_TRY(dt.reserve((size_t) n));
+        SHQ_TRY(dq.reserve((size_t) n * rec));
+        SHQ_HIP(hipMemcpyAsync(dt.ptr, table, sizeof(shq_data_index) * n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_TRY(shq_sph_fill_queries_device(ctx, (const shq_data_index *) dt.ptr, n, (void *) dq.ptr));
+        SHQ_HIP(hipMemcpyAsync(queries, dq.ptr, (size_t) n * rec, hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+        return SHQ_OK;
+    };
+    const int rc = run();
+    (void) hipStreamSynchronize(ctx->stream);
+    dt.release();
+    dq.release();
+    return rc;
 }
