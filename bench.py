@@ -51,7 +51,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(pos, mass, tree, gp_rel, oldacc, L):
+def cpu_baseline(pos, mass, tree, gp_rel, oldacc, L, acc_gpu=None):
     """Oracle (CPU port of the reference algorithm) on a bounded 1/64 sample of the workload:
     the tree walk of every 64th 64-target group on the SAME tree, plus a full PM step of a
     64^3-particle / 192^3-mesh sub-problem (1/64 of the particles and of the mesh)."""
@@ -64,8 +64,15 @@ def cpu_baseline(pos, mass, tree, gp_rel, oldacc, L):
     if len(targets) == 0:
         targets = np.arange(n, dtype=np.int32)
     t0 = time.perf_counter()
-    orc.grav_walk(tree.Nodes_base, tree.firstnode, pos, mass, oldacc, gp_rel, targets=targets)
+    oacc, _, _ = orc.grav_walk(tree.Nodes_base, tree.firstnode, pos, mass, oldacc, gp_rel, targets=targets)
     t_tree = time.perf_counter() - t0
+    # the metric's second half: rms |dF| / |F| of the device's short-range forces against the CPU walk, same targets
+    ferr = None
+    if acc_gpu is not None:
+        ref = oacc * G
+        rel = np.linalg.norm(acc_gpu[targets] - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-300)
+        ferr = {"rms_rel_tree_force_error_vs_cpu_walk": float(np.sqrt(np.mean(rel**2))), "max_rel": float(rel.max()),
+                "targets": int(len(targets)), "tolerance_north_star": 1e-3}
     nsub = min(n, 64**3)
     sub = pos[:: max(1, n // nsub)][:nsub]
     t0 = time.perf_counter()
@@ -79,7 +86,7 @@ def cpu_baseline(pos, mass, tree, gp_rel, oldacc, L):
         "sample": "oracle tree walk of %d of %d targets (every 64th 64-target group, same tree) in %.2f s + oracle PM step "
                   "(reference structure, 5 FFTs) on a %d-particle/192^3-mesh sub-problem in %.2f s; each scaled by its "
                   "fraction of the full job" % (len(targets), n, t_tree, len(sub), t_pm),
-        "tree_s_sample": t_tree, "pm_s_sample": t_pm,
+        "tree_s_sample": t_tree, "pm_s_sample": t_pm, "force_error": ferr,
     }
 
 
@@ -415,7 +422,12 @@ def main():
         capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), None, None, None))
         capi.check(capi.hip.shq_pm_download(ctx.h, capi.ptr(gpm), None))
         oldacc = np.linalg.norm(acc + gpm, axis=1) / G
-        out["cpu_baseline"] = cpu_baseline(pos, P["Mass"], tree, gp_rel, oldacc, L)
+        # one more device walk from exactly this OldAcc (the last timed step refreshed it from these same arrays), so that
+        # the CPU walk and the device walk under comparison start from the same inputs
+        capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp_rel), None, 0, 1, args.walk_mode))
+        capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), None, None, None))
+        out["cpu_baseline"] = cpu_baseline(pos, P["Mass"], tree, gp_rel, oldacc, L, acc_gpu=acc)
+        out["force_error"] = out["cpu_baseline"].pop("force_error")
     # Extra figure, outside `value`: a fully resident step with moving particles — drift, device tree
     # build, PM, walk, OldAcc, short-range and PM kicks — nothing crosses PCIe.
     try:
@@ -426,8 +438,8 @@ def main():
         # without the wave-level counters: a different kernel instantiation, so that a profile of this command lists
         # the timed production walk (counters on) separately from the walks of this loop (moved particles, tree order)
         capi.check(capi.hip.shq_set_walk_stats(ctx.h, 0))
-        for it in range(nres + 1):              # the first pass is a warm-up (the GPU idled during the CPU baseline)
-            if it == 1:
+        for it in range(nres + 2):              # two warm-up passes (the GPU idled during the CPU baseline)
+            if it == 2:
                 ctx.synchronize()
                 t0 = time.perf_counter()
             sq.drift(ctx, 1e-4 * L / n1, L)
