@@ -225,8 +225,8 @@ int shq_tree_download(shq_context *ctx, int64_t firstnode, shq_node *nodes, int6
 /* Resident drift and kick: with the particles, their velocities and the force
  * arrays in HBM a step is  shq_drift -> shq_tree_build -> shq_pm_run / shq_grav_short_run -> kicks,
  * without a PCIe crossing.  Same operations in the same order as the reference, so the state stays
- * bit-identical to a host integration.  Black-hole repositioning (drift.cpp:32-53) and do_hydro_kick
- * (timestep.cpp:970-1003) are not covered; the integer time line stays with the host.
+ * bit-identical to a host integration.  Black-hole repositioning (drift.cpp:32-53) and the black-hole part of
+ * do_hydro_kick are not covered; the integer time line stays with the host.
  *
  * shq_dynamics_upload: Vel, Hsml, DtHsml, TimeBinGravity of the particles uploaded before.
  * shq_drift: drift_all_particles / real_drift_particle (libgadget/drift.cpp:16-99):
@@ -270,6 +270,15 @@ int shq_drift(shq_context *ctx, double ddrift, double BoxSize, const double rand
 int shq_kick_short(shq_context *ctx, const double gravkick[SHQ_TIMEBINS + 1], const int32_t *active, int64_t nactive,
                    int from_accel_store);
 int shq_kick_pm(shq_context *ctx, double Fgravkick);
+/* do_hydro_kick for gas (timestep.cpp:970-1003) as apply_half_kick / apply_hydro_half_kick call it (:875-886, :914-934):
+ * Vel += HydroAccel * hydrokick[TimeBinHydro], the MaxGasVel clamp (|Vel| / atime <= MaxGasVel; *nlimited counts the
+ * clamped particles, which the reference logs), Entropy += DtEntropy * dt_entr[TimeBinHydro] — on the SPH state the last
+ * shq_density / shq_hydro_force (or phase calls) left resident; from_hydro_output takes HydroAccel / DtEntropy from that
+ * hydro run instead of the uploaded SphP values.  Inactive bins carry 0 in both tables.  The black-hole part (DFAccel,
+ * DragAccel) needs the BH slot arrays and stays with the host.  shq_entropy_download: Entropy by particle index. */
+int shq_kick_hydro(shq_context *ctx, const double hydrokick[SHQ_TIMEBINS + 1], const double dt_entr[SHQ_TIMEBINS + 1], double atime,
+                   double MaxGasVel, const int32_t *active, int64_t nactive, int from_hydro_output, int64_t *nlimited);
+int shq_entropy_download(shq_context *ctx, double *entropy_by_particle);
 int shq_dynamics_download(shq_context *ctx, const shq_part_view *parts);
 /* active: host int32 list or NULL. The walk and postprocess are queued on the stream. */
 int shq_grav_short_run(shq_context *ctx, const shq_grav_params *params, const int32_t *active,

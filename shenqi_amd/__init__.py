@@ -234,6 +234,24 @@ def kick_short(ctx, gravkick, active=None, from_accel_store=False):
     capi.check(capi.hip.shq_kick_short(ctx.h, capi.ptr(gk), act, nact, int(from_accel_store)), "shq_kick_short")
 
 
+def kick_hydro(ctx, hydrokick, dt_entr, atime, MaxGasVel, active=None, from_hydro_output=True):
+    """shq_kick_hydro: do_hydro_kick for gas (libgadget/timestep.cpp:970-1003). Returns the number of clamped particles."""
+    hk = np.ascontiguousarray(hydrokick, dtype=np.float64)
+    de = np.ascontiguousarray(dt_entr, dtype=np.float64)
+    assert hk.shape == (capi.TIMEBINS + 1,) and de.shape == (capi.TIMEBINS + 1,)
+    act, nact = _active_arg(active)
+    nlim = C.c_int64()
+    capi.check(capi.hip.shq_kick_hydro(ctx.h, capi.ptr(hk), capi.ptr(de), float(atime), float(MaxGasVel), act, nact, int(from_hydro_output),
+                                       C.byref(nlim)), "shq_kick_hydro")
+    return nlim.value
+
+
+def entropy_download(ctx, n):
+    out = np.zeros(n)
+    capi.check(capi.hip.shq_entropy_download(ctx.h, capi.ptr(out)), "shq_entropy_download")
+    return out
+
+
 def kick_pm(ctx, Fgravkick):
     """shq_kick_pm: apply_PM_half_kick (libgadget/timestep.cpp:937-959)."""
     capi.check(capi.hip.shq_kick_pm(ctx.h, float(Fgravkick)), "shq_kick_pm")

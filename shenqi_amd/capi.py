@@ -284,6 +284,10 @@ hip.shq_build_active_sublist.argtypes = [_vp, C.c_int, C.c_int64, C.POINTER(C.c_
 hip.shq_build_active_sublist.restype = C.c_int
 hip.shq_active_download.argtypes = [_vp, C.c_int, _vp, C.c_int64, C.POINTER(C.c_int64)]
 hip.shq_active_download.restype = C.c_int
+hip.shq_kick_hydro.argtypes = [_vp, _vp, _vp, C.c_double, C.c_double, _vp, C.c_int64, C.c_int, C.POINTER(C.c_int64)]
+hip.shq_kick_hydro.restype = C.c_int
+hip.shq_entropy_download.argtypes = [_vp, _vp]
+hip.shq_entropy_download.restype = C.c_int
 hip.shq_kick_pm.argtypes = [_vp, C.c_double]
 hip.shq_kick_pm.restype = C.c_int
 hip.shq_dynamics_download.argtypes = [_vp, C.POINTER(PartView)]

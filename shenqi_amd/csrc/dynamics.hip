@@ -83,6 +83,39 @@ __global__ void kick_short_kernel(long long nt, const int32_t *__restrict__ targ
         vel[3 * i + j] += accel[3 * i + j] * F;
 }
 
+/* do_hydro_kick for gas (timestep.cpp:970-1003) over the active list of apply_half_kick / apply_hydro_half_kick (:875-886, :914-934) */
+__global__ void kick_hydro_kernel(long long nt, const int32_t *__restrict__ targets, double *vel, const double *__restrict__ hacc,
+                                  const double *__restrict__ dtent, double *entropy, const uint8_t *__restrict__ pflags,
+                                  const uint8_t *__restrict__ bin_hydro, KickTab hk, KickTab dte, double atime, double MaxGasVel,
+                                  unsigned long long *nlimited)
+{
+#pragma clang fp contract(off)
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= nt)
+        return;
+    const long long i = targets ? (long long) targets[t] : t;
+    const unsigned f = pflags[i];
+    if((f & 3u) || (f >> 4) != 0)
+        return;
+    const int bin = bin_hydro[i];
+    const double F = hk.k[bin];
+    double v[3];
+    for(int j = 0; j < 3; j++)
+        v[j] = vel[3 * i + j] + hacc[3 * i + j] * F;
+    double vv = 0;
+    for(int j = 0; j < 3; j++)
+        vv += v[j] * v[j];
+    vv = sqrt(vv);
+    if(vv > 0 && vv / atime > MaxGasVel) {
+        for(int j = 0; j < 3; j++)
+            v[j] *= MaxGasVel * atime / vv;
+        atomicAdd(nlimited, 1ull);
+    }
+    for(int j = 0; j < 3; j++)
+        vel[3 * i + j] = v[j];
+    entropy[i] += dtent[i] * dte.k[bin];
+}
+
 __global__ void kick_pm_kernel(long long n, double *vel, const double *__restrict__ gravpm, const uint8_t *__restrict__ pflags, double F)
 {
 #pragma clang fp contract(off)
@@ -444,6 +477,50 @@ extern "C" int shq_kick_short(shq_context *ctx, const double gravkick[SHQ_TIMEBI
         SHQ_HIP(hipGetLastError());
     }
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    return SHQ_OK;
+}
+
+extern "C" int shq_kick_hydro(shq_context *ctx, const double hydrokick[SHQ_TIMEBINS + 1], const double dt_entr[SHQ_TIMEBINS + 1], double atime,
+                              double MaxGasVel, const int32_t *active, int64_t nactive, int from_hydro_output, int64_t *nlimited)
+{
+    SHQ_CHECK(ctx && hydrokick && dt_entr, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts && ctx->have_sph && ctx->vel.ptr && ctx->g_entropy.ptr, SHQ_ERR_STATE,
+              "kick_hydro: no SPH state on the device (shq_density / shq_hydro_force, or their phase calls, load it)");
+    SHQ_CHECK(ctx->sphrun.phase == 0, SHQ_ERR_STATE, "kick_hydro: an SPH walk is still open");
+    SHQ_CHECK(atime > 0 && MaxGasVel > 0, SHQ_ERR_INVALID, "kick_hydro: atime and MaxGasVel must be > 0");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const double *hacc = from_hydro_output ? ctx->g_hydroaccel_out.ptr : ctx->g_hydroaccel.ptr;
+    const double *dtent = from_hydro_output ? ctx->g_dtentropy_out.ptr : ctx->g_dtentropy.ptr;
+    SHQ_CHECK(hacc && dtent, SHQ_ERR_STATE, "kick_hydro: no hydro accelerations on the device yet");
+    KickTab hk, dte;
+    memcpy(hk.k, hydrokick, sizeof(hk.k));
+    memcpy(dte.k, dt_entr, sizeof(dte.k));
+    const int32_t *d_act = nullptr;
+    int64_t nt = 0;
+    SHQ_TRY(shq_resolve_active(ctx, active, nactive, ctx->numpart, &d_act, &nt));
+    SHQ_TRY(ctx->act_counts.reserve(6 * (SHQ_TIMEBINS + 1) + 4));
+    unsigned long long *d_n = ctx->act_counts.ptr;
+    SHQ_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), ctx->stream));
+    if(nt > 0) {
+        kick_hydro_kernel<<<dim3(nblk(nt)), dim3(256), 0, ctx->stream>>>((long long) nt, d_act, ctx->vel.ptr, hacc, dtent, ctx->g_entropy.ptr,
+                                                                        ctx->pflags.ptr, ctx->bin_hydro.ptr, hk, dte, atime, MaxGasVel, d_n);
+        SHQ_HIP(hipGetLastError());
+    }
+    unsigned long long h = 0;
+    SHQ_HIP(hipMemcpyAsync(&h, d_n, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    if(nlimited)
+        *nlimited = (int64_t) h;
+    return SHQ_OK;
+}
+
+extern "C" int shq_entropy_download(shq_context *ctx, double *entropy_by_particle)
+{
+    SHQ_CHECK(ctx && entropy_by_particle, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts && ctx->have_sph && ctx->g_entropy.ptr, SHQ_ERR_STATE, "entropy_download: no SPH state on the device");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    if(ctx->numpart > 0)
+        SHQ_HIP(hipMemcpy(entropy_by_particle, ctx->g_entropy.ptr, sizeof(double) * ctx->numpart, hipMemcpyDeviceToHost));
     return SHQ_OK;
 }
 

@@ -179,3 +179,46 @@ def test_sph_phase_state_errors(ctx):
     capi.check(capi.hip.shq_density_open(ctx.h, C.byref(tv), C.byref(pv), C.byref(sv), C.byref(bv), None, 0, C.byref(dp), 0, None))
     evp, st = sq.density(ctx, None, 0, 0, 0, None, tree, pman, SphP, BhP)
     assert st.ntargets == len(SphP)
+
+
+def test_hydro_kick_bit_exact(ctx):
+    """shq_kick_hydro = do_hydro_kick for gas (timestep.cpp:970-1003) on the state a hydro run leaves resident: plain IEEE
+    operations in the reference's order, so velocities and entropies equal a numpy restatement to the bit."""
+    pman, SphP, BhP, rng = _gas(n1=12, seed=11)
+    P = pman.Base
+    n = len(P)
+    P["TimeBinHydro"] = rng.integers(20, 24, size=n).astype(np.uint8)
+    P["Flags"] = (rng.random(n) < 0.03).astype(np.uint8)            # some garbage
+    P["Vel"] *= 40.0                                                # a few beyond the velocity limit below
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+    evp, _ = sq.density(ctx, None, 1, 1, 0, None, tree, pman, SphP, BhP)
+    sq.force_tree_update_hmax(tree, pman)
+    sq.set_hydropar(1, 100.0, 0.75)
+    sq.hydro_force(ctx, None, 0.1, 0.1, evp, None, tree, pman, SphP)
+    hk = np.zeros(capi.TIMEBINS + 1); de = np.zeros(capi.TIMEBINS + 1)
+    hk[20:24] = [1e-3, 2e-3, 4e-3, 8e-3]
+    de[20:24] = [3e-4, 6e-4, 1.2e-3, 2.4e-3]
+    atime, vmax = 0.1, 900.0
+    act = np.sort(rng.choice(n, size=n // 2, replace=False)).astype(np.int32)
+    # numpy restatement
+    vel, ent = P["Vel"].copy(), SphP["Entropy"].copy()
+    nlim = 0
+    for i in act:
+        if P["Flags"][i] & 3 or P["Type"][i] != 0:
+            continue
+        b = P["TimeBinHydro"][i]
+        v = vel[i] + SphP["HydroAccel"][P["PI"][i]] * hk[b]
+        vv = np.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])
+        if vv > 0 and vv / atime > vmax:
+            v = v * (vmax * atime / vv)
+            nlim += 1
+        vel[i] = v
+        ent[P["PI"][i]] = ent[P["PI"][i]] + SphP["DtEntropy"][P["PI"][i]] * de[b]
+    sq.dynamics_upload(ctx, pman)          # makes the velocities downloadable again (same values: the SPH calls do not move them)
+    got_lim = sq.kick_hydro(ctx, hk, de, atime, vmax, act, from_hydro_output=True)
+    sq.dynamics_download(ctx, pman)
+    ent_dev = sq.entropy_download(ctx, n)
+    assert got_lim == nlim and nlim > 0
+    gas = P["Type"] == 0
+    assert np.array_equal(ent_dev[gas], ent[P["PI"][gas]])
+    assert np.array_equal(P["Vel"], vel)
