@@ -123,11 +123,60 @@ def sph_figures(ctx, n1=128, kernel=2):
     sq.set_hydropar(1, 100.0, 0.75)
     hs = sq.hydro_force(ctx, None, 0.1, 0.1, evp, None, tree, pman, SphP)
     hs = sq.hydro_force(ctx, None, 0.1, 0.1, evp, None, tree, pman, SphP)
-    return {"sph_workload": "%d^3 gas, uniform, quintic kernel, %.0f neighbours" % (n1, sq.GetNumNgb()),
+    out = c3_step(ctx, pos, n1, float(st.kernel_ms) / max(1, int(st.niterations)), float(hs.kernel_ms))
+    out.update({"sph_workload": "%d^3 gas, uniform, quintic kernel, %.0f neighbours" % (n1, sq.GetNumNgb()),
             "sph_density_first_call_iterations": int(st0.niterations), "sph_density_first_call_ms": float(st0.kernel_ms),
             "sph_density_iteration_ms": float(st.kernel_ms) / max(1, int(st.niterations)),
             "sph_density_particles_per_s": n / (1e-3 * float(st.kernel_ms) / max(1, int(st.niterations))),
-            "sph_hydro_ms": float(hs.kernel_ms), "sph_hydro_particles_per_s": n / (1e-3 * float(hs.kernel_ms))}
+            "sph_hydro_ms": float(hs.kernel_ms), "sph_hydro_particles_per_s": n / (1e-3 * float(hs.kernel_ms))})
+    return out
+
+
+def c3_step(ctx, gas_pos, n1, density_ms, hydro_ms):
+    """BASELINE configs[2] as one force step: 2 x n1^3 gas + dark matter (uniform, as the z = 99 initial conditions of
+    examples/small nearly are), Nmesh 3 n1: PM + short-range walk over all particles, plus the density and hydro times
+    of the gas measured above.  Extra figure (kernels.c3_*), not part of `value`."""
+    import shenqi_amd as sq
+    from shenqi_amd import capi
+    n = len(gas_pos)
+    L = 1.0
+    dm = sq.synth_positions("uniform", n, seed=77, L=L)
+    pos = np.concatenate([gas_pos, dm])
+    order = sq.hilbert_order(pos, L)
+    pos = pos[order]
+    pman = sq.PartManager(2 * n, L)
+    P = pman.Base
+    P["Pos"] = pos
+    P["Type"] = np.where(order < n, 0, 1).astype(np.uint8)
+    P["Mass"] = np.where(order < n, 0.16, 0.84)       # Omega_b / Omega_m of a gas + dark matter pair
+    nmesh = 3 * n1
+    sq.set_gravshort_treepar(ErrTolForceAcc=0.005, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=1, Rcut=6.0)
+    sq.gravshort_set_softenings(L / n1)
+    gp_bh = sq.make_grav_params(L, 1.5, nmesh, G, RHO0)
+    sq.set_gravshort_treepar(ErrTolForceAcc=0.005, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=0, Rcut=6.0)
+    gp_rel = sq.make_grav_params(L, 1.5, nmesh, G, RHO0)
+    pmp = sq.PMParams(nmesh, 0, L, 1.5, G)
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    try:
+        sq.tree_build_device(ctx, L)
+    except sq.ShqError:
+        tree = sq.force_tree_full(pman)
+        tv = tree.view()
+        capi.check(capi.hip.shq_tree_upload(ctx.h, C.byref(tv)))
+    for k, gp in enumerate((gp_bh, gp_rel, gp_rel)):
+        capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
+        capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, 0))
+        capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, G))
+    st = sq.WalkStats()
+    capi.check(capi.hip.shq_grav_short_download(ctx.h, None, None, None, C.byref(st)))
+    ph = (C.c_double * 6)()
+    capi.check(capi.hip.shq_pm_phase_ms(ctx.h, C.byref(ph)))
+    total = float(st.kernel_ms) + float(ph[5]) + density_ms + hydro_ms
+    return {"c3_workload": "2 x %d^3 gas + dark matter, uniform, Nmesh %d: PM + walk over all, density + hydro of the gas" % (n1, nmesh),
+            "c3_tree_walk_ms": float(st.kernel_ms), "c3_tree_interactions_per_target": st.ninteractions / max(1, st.ntargets),
+            "c3_pm_ms": float(ph[5]), "c3_density_iteration_ms": density_ms, "c3_hydro_ms": hydro_ms, "c3_force_step_ms": total,
+            "c3_particle_steps_per_s": 2 * n / (1e-3 * total)}
 
 
 def run_sharded(args, rank, local_rank, world):

@@ -1034,7 +1034,7 @@ int shq_sph_prepare(shq_context *ctx, const shq_kick_factors *kf, const shq_hydr
 }
 
 /* ---- launch: two kernels per chunk of targets + redo of overflowed waves ---------------------------- */
-#define NL_CHUNK (1ll << 20)  /* targets per chunk: 1 Mi x NL_CAP x 4 B = 1 GB of list scratch */
+#define NL_CHUNK (1ll << 22)  /* targets per chunk: 4 Mi x NL_CAP x 4 B = 4 GB of list scratch */
 #define NL_REDO_BLOCKS 1024
 
 /* waves of the chunk whose lists overflowed: append their targets to the redo queue */
