@@ -419,7 +419,7 @@ def main():
                      "frac": walk_flops / max(walk_s, 1e-12) / 1e12 / FP64_VECTOR_PEAK_TF, "traffic": traffic,
                      "algorithmic_flops": walk_flops, "algorithmic_bytes": tree_bytes, "hbm_algorithmic_GBs": tree_bytes / max(walk_s, 1e-12) / 1e9,
                      "note": "FP64-issue bound: 45 flop per interaction (SURVEY 8(d)) x interactions / kernel time against the FP64 "
-                             "peak; VALU busy 84 % (profiles/r01_bench256_pmc_sq.json); `traffic` = HBM bytes per launch from the "
+                             "peak; VALU busy 74 % (profiles/r01_bench256_pmc_sq.json); `traffic` = HBM bytes per launch from the "
                              "FETCH_SIZE/WRITE_SIZE passes, 6x the compulsory bytes and 0.2 TB/s: not a bandwidth problem.  "
                              "The HBM-bound part of the step is the PM: roofline_pm_fft"}
     out = {
