@@ -288,6 +288,9 @@ template <class F> __device__ __forceinline__ void nl_flush(const int32_t *myl, 
  *   - accepted candidates go to the lane's list (see above) and are evaluated lane by lane.
  * Leaves are queued and tiles are scanned in walk order, so each lane still meets its neighbours in
  * depth-first order. */
+#ifndef SPH_WALK_WPB
+#define SPH_WALK_WPB 1 /* waves per block of the walk-only kernels (MODE 1) */
+#endif
 #define NW_WIN 32 /* nodes per window: half a window costs a few more reloads and buys 1.8 KB of LDS per wave */
 /* per wave: node window (centre + len, links, hmax for the symmetric cull) and candidate tile (position, interested
  * lanes, slot with the two flag bits on top, Hsml for the symmetric test): 4.3 KB (density) / 5.1 KB (hydro), so
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(256) void sph_density_kernel(const SphDev a, const 
                                                           unsigned long long *nint_total, int32_t *__restrict__ nlist, long long ntasks,
                                                           int32_t *__restrict__ counts, const long long *d_nq, const int4 *qseg = nullptr)
 {
-    __shared__ __attribute__((aligned(32))) char lds[(MODE == 2 ? 1 : 4 * NW_LDS_PER_WAVE(false))];
+    __shared__ __attribute__((aligned(32))) char lds[(MODE == 2 ? 1 : (MODE == 1 ? SPH_WALK_WPB : 4) * NW_LDS_PER_WAVE(false))];
     const int lane = threadIdx.x & 63;
     if(MODE == 0 && d_nq) {
         nq = *d_nq;
@@ -761,7 +764,7 @@ __global__ __launch_bounds__(256, 4) void sph_hydro_kernel(const SphDev a, const
                                                            unsigned long long *nint_total, int32_t *__restrict__ nlist, long long ntasks,
                                                            int32_t *__restrict__ counts, const long long *d_nq, const int4 *qseg = nullptr)
 {
-    __shared__ __attribute__((aligned(32))) char lds[(MODE == 2 ? 1 : 4 * NW_LDS_PER_WAVE(true))];
+    __shared__ __attribute__((aligned(32))) char lds[(MODE == 2 ? 1 : (MODE == 1 ? SPH_WALK_WPB : 4) * NW_LDS_PER_WAVE(true))];
     const int lane = threadIdx.x & 63;
     if(MODE == 0 && d_nq) {
         nq = *d_nq;
@@ -1081,7 +1084,8 @@ static int launch_two_kernel(shq_context *ctx, const int32_t *q, long long nq, l
         const long long m = (nq - off < NL_CHUNK) ? nq - off : NL_CHUNK;
         const long long ntasks = (m + 255) / 256;
         const int32_t *qc = q ? q + off : nullptr;
-        walk((unsigned) ntasks, qc, m, ntasks, lists, ctx->s_ncount.ptr);
+        const long long wtasks = (m + 64 * SPH_WALK_WPB - 1) / (64 * SPH_WALK_WPB);
+        walk((unsigned) wtasks, qc, m, wtasks, lists, ctx->s_ncount.ptr);
         eval((unsigned) ntasks, qc, m, ntasks, lists, ctx->s_ncount.ptr);
         sph_collect_redo_kernel<<<dim3(nblk((m + 63) / 64)), dim3(256), 0, ctx->stream>>>(ctx->s_ncount.ptr, qc, m, ctx->s_redo.ptr, d_nredo);
     }
@@ -1098,7 +1102,7 @@ static int launch_density(shq_context *ctx, const SphDev &a, const int32_t *q, l
     return launch_two_kernel(
         ctx, q, nq, nq_reserved,
         [&](unsigned grid, const int32_t *qc, long long m, long long ntasks, int32_t *lists, int32_t *counts) {
-            sph_density_kernel<KT, 1><<<dim3(grid), dim3(256), 0, st>>>(a, qc, m, wd, nint, lists, ntasks, counts, nullptr);
+            sph_density_kernel<KT, 1><<<dim3(grid), dim3(64 * SPH_WALK_WPB), 0, st>>>(a, qc, m, wd, nint, lists, ntasks, counts, nullptr);
         },
         [&](unsigned grid, const int32_t *qc, long long m, long long ntasks, int32_t *lists, int32_t *counts) {
             sph_density_kernel<KT, 2><<<dim3(grid), dim3(256), 0, st>>>(a, qc, m, wd, nint, lists, ntasks, counts, nullptr);
@@ -1114,7 +1118,7 @@ static int launch_hydro(shq_context *ctx, const SphDev &a, const int32_t *q, lon
     return launch_two_kernel(
         ctx, q, nq, nq,
         [&](unsigned grid, const int32_t *qc, long long m, long long ntasks, int32_t *lists, int32_t *counts) {
-            sph_hydro_kernel<KT, 1><<<dim3(grid), dim3(256), 0, st>>>(a, qc, m, hc, nint, lists, ntasks, counts, nullptr);
+            sph_hydro_kernel<KT, 1><<<dim3(grid), dim3(64 * SPH_WALK_WPB), 0, st>>>(a, qc, m, hc, nint, lists, ntasks, counts, nullptr);
         },
         [&](unsigned grid, const int32_t *qc, long long m, long long ntasks, int32_t *lists, int32_t *counts) {
             sph_hydro_kernel<KT, 2><<<dim3(grid), dim3(256), 0, st>>>(a, qc, m, hc, nint, lists, ntasks, counts, nullptr);
