@@ -518,6 +518,24 @@ int shq_hydro_close(shq_context *ctx, const shq_part_view *parts, const shq_sph_
 int shq_sph_exports(shq_context *ctx, int32_t *exportcounts, shq_data_index *table, int64_t capacity, int64_t *nexport);
 int shq_sph_fill_queries(shq_context *ctx, const shq_data_index *table, int64_t n, void *queries);
 
+/* ---- stellar density ------------------------------------------------------------------------------
+ * stellar_density() (libgadget/stellar_density2.cpp:306-341): the SPH volume weight sum(m_j / rho_j [* w_k]) of the gas
+ * around each star of `queue` (the reference's StarQueue: build_stellar_density_queue, :285-303, stays on the host — it reads
+ * the star slots), with its own Hsml iteration over ten trial radii per walk (stellareffhsml, ngbiter, postprocess,
+ * ngb_narrow_down).  `tree` is the gas tree (GASMASK); gas densities come from the SPH view.  Writes Part[].Hsml of the
+ * stars and StarVolumeSPH[PI of the star].  A star with Hsml == 0 is refused (the reference re-seeds it from its father
+ * node).  SHQ_ERR_NOCONV beyond MAXITER iterations. */
+typedef struct shq_stellar_params {
+    double BoxSize;
+    double DesNumNgb;           /* GetNumNgb(GetDensityKernelType()) */
+    double MaxNgbDeviation;
+    int32_t SPHWeighting;
+    int32_t DensityKernelType;
+} shq_stellar_params;
+int shq_stellar_density(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph,
+                        const int32_t *queue, int64_t nqueue, const shq_stellar_params *params, double *StarVolumeSPH,
+                        shq_sph_stats *stats);
+
 /* ---- long-range PM --------------------------------------------------------------------- */
 
 /* Mirror of the PetaPM fields gravpm.cpp reads (libgadget/petapm.h:87-112). */

@@ -120,6 +120,14 @@ void orc_hydro(const shq_node *nodes, int64_t firstnode, orc_sph_arrays *a, cons
 
 int orc_num_threads(void);
 
+/* stellar_density() (stellar_density2.cpp:306-341) with its ten-radius ngbiter, postprocess and ngb_narrow_down: the
+ * SPH volume weights of the star particles in `queue` over the gas neighbours; updates a->hsml of the stars.
+ * StarVolumeSPH is indexed by particle.  No reference fixture exists for it ("parity unpinned": restated line by line
+ * and exercised against brute-force sums in tests/test_oracle_cpu.py). */
+int orc_stellar_density(const shq_node *nodes, int64_t firstnode, orc_sph_arrays *a, const int32_t *queue, int64_t nqueue,
+                        double BoxSize, double DesNumNgb, double MaxNgbDeviation, int SPHWeighting, int ktype,
+                        double *StarVolumeSPH, int *niter_out, int64_t *nint_out);
+
 #ifdef __cplusplus
 }
 #endif

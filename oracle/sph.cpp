@@ -577,3 +577,184 @@ extern "C" void orc_hydro(const shq_node *nodes, int64_t firstnode, orc_sph_arra
     if(nint_out)
         *nint_out = nint;
 }
+
+/* ---- stellar density ------------------------------------------------------------------------
+ * stellar_density(): stellar_density2.cpp:306-341; StellarDensityLocalTreeWalk::ngbiter :219-254; stellareffhsml :38-54;
+ * StellarDensityOutput::postprocess :113-154; ngb_narrow_down treewalk.c:1349-1406; loop treewalk2.h:480-557.
+ * Targets: the star particles in `queue`; neighbours: gas (a->density by slot).  Per star NHSML = 10 trial radii are evaluated
+ * in one walk; the search radius shrinks during the walk once an inner radius already holds enough neighbours.
+ * StarVolumeSPH is indexed by particle (the reference indexes by star slot; the caller maps).  Returns 0, or 1 if MAXITER
+ * is exceeded. */
+#define ORC_NHSML 10
+
+static double stellareffhsml(int i, double left, double right, double Hsml, double BoxSize)
+{
+    if(right > 0.99 * BoxSize)
+        right = Hsml * ((1. + ORC_NHSML) / ORC_NHSML);
+    if(left == 0)
+        left = 0.1 * Hsml;
+    const double rvol = pow(right, 3), lvol = pow(left, 3);
+    return pow((1. * i + 1) / (1. * ORC_NHSML + 1) * (rvol - lvol) + lvol, 1. / 3);
+}
+
+/* treewalk.c:1349-1406 (note the integer desnumngb) */
+static double ngb_narrow_down(double *right, double *left, const double *radius, const double *numNgb, int maxcmpt, int desnumngb,
+                              int *closeidx, double BoxSize)
+{
+    int close = 0;
+    double ngbdist = fabs(numNgb[0] - desnumngb);
+    for(int j = 1; j < maxcmpt; j++) {
+        const double newdist = fabs(numNgb[j] - desnumngb);
+        if(newdist < ngbdist) {
+            ngbdist = newdist;
+            close = j;
+        }
+    }
+    if(closeidx)
+        *closeidx = close;
+    for(int j = 0; j < maxcmpt; j++) {
+        if(numNgb[j] < desnumngb)
+            *left = radius[j];
+        if(numNgb[j] > desnumngb) {
+            *right = radius[j];
+            break;
+        }
+    }
+    double hsml = radius[close];
+    if(*right > 0.99 * BoxSize) {
+        double dngbdv = 0;
+        if(maxcmpt > 1 && (radius[maxcmpt - 1] > radius[maxcmpt - 2]))
+            dngbdv = (numNgb[maxcmpt - 1] - numNgb[maxcmpt - 2]) / (pow(radius[maxcmpt - 1], 3) - pow(radius[maxcmpt - 2], 3));
+        double newhsml = 4 * hsml;
+        if(dngbdv > 0) {
+            const double dngb = (desnumngb - numNgb[maxcmpt - 1]);
+            const double newvolume = pow(hsml, 3) + dngb / dngbdv;
+            if(pow(newvolume, 1. / 3) < newhsml)
+                newhsml = pow(newvolume, 1. / 3);
+        }
+        hsml = newhsml;
+    }
+    if(hsml > *right)
+        hsml = *right;
+    if(*left == 0) {
+        double dngbdv = 0;
+        if(radius[1] > radius[0])
+            dngbdv = (numNgb[1] - numNgb[0]) / (pow(radius[1], 3) - pow(radius[0], 3));
+        if(maxcmpt == 1 && radius[0] > 0)
+            dngbdv = numNgb[0] / pow(radius[0], 3);
+        if(dngbdv > 0) {
+            const double dngb = desnumngb - numNgb[0];
+            const double newvolume = pow(hsml, 3) + dngb / dngbdv;
+            hsml = pow(newvolume, 1. / 3);
+        }
+    }
+    if(hsml < *left)
+        hsml = *left;
+    return hsml;
+}
+
+extern "C" int orc_stellar_density(const shq_node *nodes, int64_t firstnode, orc_sph_arrays *a, const int32_t *queue, int64_t nqueue,
+                                   double BoxSize, double DesNumNgb, double MaxNgbDeviation, int SPHWeighting, int ktype,
+                                   double *StarVolumeSPH, int *niter_out, int64_t *nint_out)
+{
+    const shq_node *N = nodes - firstnode;
+    const int64_t n = a->n;
+    std::vector<double> Left(n, 0.0), Right(n, BoxSize);
+    std::vector<int32_t> cur(queue, queue + nqueue);
+    int niter = 0;
+    int64_t nint = 0;
+    while(true) {
+        const int64_t size = (int64_t) cur.size();
+        std::vector<int32_t> todo(size, -1);
+        int64_t nint_iter = 0;
+#pragma omp parallel for schedule(dynamic, 8) reduction(+ : nint_iter)
+        for(int64_t q = 0; q < size; q++) {
+            const int32_t i = cur[q];
+            const double *Pos = &a->pos[3 * (int64_t) i];
+            double HsmlEval[ORC_NHSML], Ngb[ORC_NHSML] = {0}, Vol[ORC_NHSML] = {0};
+            for(int k = 0; k < ORC_NHSML; k++)
+                HsmlEval[k] = stellareffhsml(k, Left[i], Right[i], a->hsml[i], BoxSize);
+            double Hsml = HsmlEval[ORC_NHSML - 1];
+            int maxcmpte = ORC_NHSML;
+            int64_t no = firstnode;
+            while(no >= 0) {
+                const shq_node *c = &N[no];
+                if(0 == cull_node(Pos, BoxSize, Hsml, c, false)) {
+                    no = c->sibling;
+                    continue;
+                }
+                const unsigned ct = SHQ_NODE_CHILDTYPE(c->flags);
+                if(ct == SHQ_PARTICLE_NODE_TYPE) {
+                    for(int s = 0; s < c->noccupied; s++) {
+                        const int64_t other = c->suns[s];
+                        if(is_garbage(a, other) || !((1 << a->type[other]) & 1))
+                            continue;
+                        nint_iter++;
+                        /* ngbiter, stellar_density2.cpp:219-254 */
+                        double r2 = 0;
+                        for(int d = 0; d < 3; d++) {
+                            const double dd = orc_nearest(Pos[d] - a->pos[3 * other + d], BoxSize);
+                            r2 += dd * dd;
+                        }
+                        if(!(r2 < HsmlEval[maxcmpte - 1] * HsmlEval[maxcmpte - 1]))
+                            continue;
+                        const double r = sqrt(r2);
+                        for(int k = 0; k < maxcmpte; k++) {
+                            if(r2 < HsmlEval[k] * HsmlEval[k]) {
+                                OrcKernel kernel(ktype, HsmlEval[k]);
+                                const double wk = kernel.wk(r / HsmlEval[k]);
+                                Ngb[k] += wk * kernel.volume();
+                                double thisvol = a->mass[other] / a->density[a->pi[other]];
+                                if(SPHWeighting)
+                                    thisvol *= wk;
+                                Vol[k] += thisvol;
+                            }
+                        }
+                        for(int k = 0; k < ORC_NHSML; k++) {
+                            if(Ngb[k] > DesNumNgb) {
+                                maxcmpte = k + 1;
+                                Hsml = HsmlEval[k];
+                                break;
+                            }
+                        }
+                    }
+                    no = c->sibling;
+                    continue;
+                } else if(ct == SHQ_PSEUDO_NODE_TYPE) {
+                    no = c->sibling;
+                    continue;
+                }
+                no = c->suns[0];
+            }
+            /* StellarDensityOutput::postprocess, stellar_density2.cpp:113-154 */
+            double evalhsml[ORC_NHSML];
+            for(int k = 0; k < maxcmpte; k++)
+                evalhsml[k] = HsmlEval[k];
+            int close = 0;
+            a->hsml[i] = ngb_narrow_down(&Right[i], &Left[i], evalhsml, Ngb, maxcmpte, (int) DesNumNgb, &close, BoxSize);
+            const double numngb = Ngb[close];
+            StarVolumeSPH[i] = Vol[close];
+            if(numngb < (DesNumNgb - MaxNgbDeviation) || numngb > (DesNumNgb + MaxNgbDeviation)) {
+                if((Right[i] - Left[i]) < 1.0e-4 * Left[i])
+                    continue; /* very tight bounds: done */
+                todo[q] = i;
+            }
+        }
+        nint += nint_iter;
+        niter++;
+        std::vector<int32_t> next;
+        for(int64_t q = 0; q < size; q++)
+            if(todo[q] >= 0)
+                next.push_back(todo[q]);
+        cur.swap(next);
+        if(cur.empty())
+            break;
+        if(niter > ORC_MAXITER)
+            return 1;
+    }
+    if(niter_out)
+        *niter_out = niter;
+    if(nint_out)
+        *nint_out = nint;
+    return 0;
+}

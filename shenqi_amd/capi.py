@@ -208,6 +208,11 @@ HYDRO_RESULT_DTYPE = np.dtype([("Acc", "<f8", 3), ("DtEntropy", "<f8"), ("MaxSig
 assert DENSITY_RESULT_DTYPE.itemsize == 96 and HYDRO_RESULT_DTYPE.itemsize == 40
 
 
+class StellarParams(C.Structure):
+    _fields_ = [("BoxSize", C.c_double), ("DesNumNgb", C.c_double), ("MaxNgbDeviation", C.c_double), ("SPHWeighting", C.c_int32),
+                ("DensityKernelType", C.c_int32)]
+
+
 class SphStats(C.Structure):
     _fields_ = [("ntargets", C.c_int64), ("ninteractions", C.c_int64), ("niterations", C.c_int32), ("pad_", C.c_int32),
                 ("kernel_ms", C.c_double)]
@@ -395,6 +400,9 @@ for _f in ("shq_density_open", "shq_density_ev_primary", "shq_density_ev_seconda
            "shq_density_close", "shq_hydro_open", "shq_hydro_ev_primary", "shq_hydro_ev_secondary", "shq_hydro_ev_reduce",
            "shq_hydro_ev_postprocess", "shq_hydro_close", "shq_sph_exports", "shq_sph_fill_queries"):
     getattr(hip, _f).restype = C.c_int
+hip.shq_stellar_density.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(SphView), _vp, C.c_int64,
+                                    C.POINTER(StellarParams), _vp, C.POINTER(SphStats)]
+hip.shq_stellar_density.restype = C.c_int
 hip.shq_hydro_force.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(SphView), _vp, C.c_int64,
                                 C.POINTER(HydroParams), _vp, C.POINTER(SphStats)]
 host.shqh_set_densitypar.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]

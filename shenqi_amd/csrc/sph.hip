@@ -1609,6 +1609,282 @@ int shq_sph_fill_queries_device(shq_context *ctx, const shq_data_index *d_table,
     return SHQ_OK;
 }
 
+/* ---- stellar density: stellar_density2.cpp ------------------------------------------------------
+ * The SPH volume weights around star particles for the metal return: a density-like walk over the gas tree that evaluates
+ * NHSML = 10 trial radii per star in one pass (stellareffhsml :38-54, ngbiter :219-254), then narrows the Hsml bounds
+ * (postprocess :113-154, ngb_narrow_down treewalk.c:1349-1406) until every star has DesNumNgb +- MaxNgbDeviation neighbours.
+ * Same walk machinery as the density (fused variant: stars are few); the walk uses the largest trial radius throughout — the
+ * reference shrinks its search radius on the way, which only skips candidates its ngbiter would reject anyway — and each
+ * lane works through its neighbours in depth-first order with the reference's per-neighbour logic, including the running
+ * `maxcmpte` cut. */
+#define ST_NHSML 10
+
+__device__ __forceinline__ double st_effhsml(int i, double left, double right, double Hsml, double Box)
+{
+    if(right > 0.99 * Box)
+        right = Hsml * ((1. + ST_NHSML) / ST_NHSML);
+    if(left == 0)
+        left = 0.1 * Hsml;
+    const double rvol = pow(right, 3), lvol = pow(left, 3);
+    return pow((1. * i + 1) / (1. * ST_NHSML + 1) * (rvol - lvol) + lvol, 1. / 3);
+}
+
+struct StellarArgs {
+    double Box, DesNumNgb, MaxDev;
+    int SPHWeighting;
+    const double *rho_leaf;   /* gas density by leaf slot */
+    double *starvol;          /* by particle index */
+    int32_t *todo;
+};
+
+template <int KT>
+__global__ __launch_bounds__(256) void sph_stellar_kernel(const SphDev a, const int32_t *queue, long long nq, const StellarArgs sa,
+                                                          unsigned long long *nint_total, int32_t *__restrict__ nlist, long long ntasks)
+{
+    __shared__ __attribute__((aligned(32))) char lds[4 * NW_LDS_PER_WAVE(false)];
+    const int lane = threadIdx.x & 63;
+    for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
+    const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    const long long t = wave * 64 + lane;
+    const bool valid = t < nq;
+    long long pi = 0;
+    double px = 0, py = 0, pz = 0, h = 1, L = 0, R = sa.Box;
+    if(valid) {
+        pi = queue[t];
+        const double4 p = a.posm[pi];
+        px = p.x; py = p.y; pz = p.z;
+        h = a.hsml[pi];
+        L = a.left[pi];
+        R = a.right[pi];
+    }
+    double he[ST_NHSML], he2[ST_NHSML], hinv[ST_NHSML], wnorm[ST_NHSML], Ngb[ST_NHSML], Vol[ST_NHSML];
+#pragma unroll
+    for(int k = 0; k < ST_NHSML; k++) {
+        he[k] = st_effhsml(k, L, R, h, sa.Box);
+        he2[k] = he[k] * he[k];
+        const Kern<KT> kr(he[k]);
+        hinv[k] = 1.0 / he[k];
+        wnorm[k] = kr.Wknorm;
+        Ngb[k] = 0;
+        Vol[k] = 0;
+    }
+    int maxcmpte = ST_NHSML;
+    const Kern<KT> k0(1.0);
+
+    /* ngbiter, stellar_density2.cpp:219-254 */
+    auto pair = [&](const int s) {
+        const double4 q = a.posm_leaf[s];
+        const double d0 = wrapd(px - q.x, a.Box, a.invBox);
+        const double d1 = wrapd(py - q.y, a.Box, a.invBox);
+        const double d2 = wrapd(pz - q.z, a.Box, a.invBox);
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        double lim = he2[0];
+#pragma unroll
+        for(int k = 1; k < ST_NHSML; k++)
+            lim = (k == maxcmpte - 1) ? he2[k] : lim;
+        if(maxcmpte == 1)
+            lim = he2[0];
+        if(!(r2 < lim))
+            return;
+        const double r = sqrt(r2);
+        const double vj = q.w / sa.rho_leaf[s];
+#pragma unroll
+        for(int k = 0; k < ST_NHSML; k++) {
+            if(k < maxcmpte && r2 < he2[k]) {
+                const double wk = wnorm[k] * k0.wk_int(r * hinv[k] * (Kern<KT>::support / 2.));
+                Ngb[k] += wk * ((4.0 / 3 * M_PI) * (he[k] * he[k] * he[k]));
+                Vol[k] += sa.SPHWeighting ? vj * wk : vj;
+            }
+        }
+        int first = ST_NHSML;
+#pragma unroll
+        for(int k = ST_NHSML - 1; k >= 0; k--)
+            first = (Ngb[k] > sa.DesNumNgb) ? k : first;
+        if(first < ST_NHSML)
+            maxcmpte = first + 1;
+    };
+    const double hwalk2 = he2[ST_NHSML - 1];
+    auto accept = [&](const double r2, const double, const int) { return r2 < hwalk2; };
+    int fill = 0;
+    bool ovf = false;
+    unsigned int nint = ngb_walk<false, false, false>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(false), myl, valid, px, py, pz, he[ST_NHSML - 1],
+                                                      accept, pair, (unsigned int *) nullptr, fill, ovf);
+    if(valid) {
+        /* StellarDensityOutput::postprocess (stellar_density2.cpp:113-154) with ngb_narrow_down (treewalk.c:1349-1406) */
+        const int desi = (int) sa.DesNumNgb;
+        int close = 0;
+        double ngbdist = fabs(Ngb[0] - desi);
+#pragma unroll
+        for(int k = 1; k < ST_NHSML; k++) {
+            const double nd = fabs(Ngb[k] - desi);
+            if(k < maxcmpte && nd < ngbdist) {
+                ngbdist = nd;
+                close = k;
+            }
+        }
+        bool stop = false;
+#pragma unroll
+        for(int k = 0; k < ST_NHSML; k++) {
+            if(k < maxcmpte && !stop) {
+                if(Ngb[k] < desi)
+                    L = he[k];
+                if(Ngb[k] > desi) {
+                    R = he[k];
+                    stop = true;
+                }
+            }
+        }
+        double hc = he[0], nc = Ngb[0], vc = Vol[0], rl = he[0], rl1 = he[0], nl = Ngb[0], nl1 = Ngb[0];
+#pragma unroll
+        for(int k = 1; k < ST_NHSML; k++) {
+            if(k == close) { hc = he[k]; nc = Ngb[k]; vc = Vol[k]; }
+            if(k == maxcmpte - 1) { rl = he[k]; nl = Ngb[k]; rl1 = he[k - 1]; nl1 = Ngb[k - 1]; }
+        }
+        double hs = hc;
+        if(R > 0.99 * sa.Box) {
+            double dngbdv = 0;
+            if(maxcmpte > 1 && rl > rl1)
+                dngbdv = (nl - nl1) / (pow(rl, 3) - pow(rl1, 3));
+            double newh = 4 * hs;
+            if(dngbdv > 0) {
+                const double dngb = desi - nl;
+                const double nv = pow(hs, 3) + dngb / dngbdv;
+                if(pow(nv, 1. / 3) < newh)
+                    newh = pow(nv, 1. / 3);
+            }
+            hs = newh;
+        }
+        if(hs > R)
+            hs = R;
+        if(L == 0) {
+            double dngbdv = 0;
+            if(he[1] > he[0])
+                dngbdv = (Ngb[1] - Ngb[0]) / (pow(he[1], 3) - pow(he[0], 3));
+            if(maxcmpte == 1 && he[0] > 0)
+                dngbdv = Ngb[0] / pow(he[0], 3);
+            if(dngbdv > 0) {
+                const double dngb = desi - Ngb[0];
+                const double nv = pow(hs, 3) + dngb / dngbdv;
+                hs = pow(nv, 1. / 3);
+            }
+        }
+        if(hs < L)
+            hs = L;
+        a.hsml[pi] = hs;
+        a.left[pi] = L;
+        a.right[pi] = R;
+        a.numngb[pi] = nc;
+        sa.starvol[pi] = vc;
+        int redo = 0;
+        if(nc < (sa.DesNumNgb - sa.MaxDev) || nc > (sa.DesNumNgb + sa.MaxDev))
+            redo = ((R - L) < 1.0e-4 * L) ? 0 : 1;
+        sa.todo[t] = redo ? (int32_t) pi : -1;
+    }
+    unsigned int sn = nint;
+    for(int off = 32; off > 0; off >>= 1)
+        sn += __shfl_xor(sn, off);
+    if(lane == 0 && nint_total)
+        atomicAdd(nint_total, (unsigned long long) sn);
+    } /* task loop */
+}
+
+__global__ void gather_rho_leaf_kernel(long long nleaf, const int32_t *__restrict__ pidx, const double *__restrict__ density, double *out)
+{
+    const long long s = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(s < nleaf)
+        out[s] = density[pidx[s]];
+}
+
+int shq_sph_stellar_density_device(shq_context *ctx, const shq_stellar_params *p, const int32_t *d_queue, int64_t nq, double *d_starvol,
+                                   shq_sph_stats *stats)
+{
+    const long long n = ctx->numpart;
+    const size_t cap = (size_t) (n > 0 ? n : 1);
+    SHQ_CHECK(p->DensityKernelType == 1 || p->DensityKernelType == 2 || p->DensityKernelType == 4, SHQ_ERR_INVALID,
+              "unknown DensityKernelType %d", p->DensityKernelType);
+    SHQ_TRY(ctx->s_numngb.reserve(cap));
+    SHQ_TRY(ctx->s_left.reserve(cap));
+    SHQ_TRY(ctx->s_right.reserve(cap));
+    SHQ_TRY(ctx->s_todo.reserve(cap));
+    SHQ_TRY(ctx->s_queue2.reserve(cap));
+    SHQ_TRY(ctx->s_queue3.reserve(cap));
+    SHQ_TRY(ctx->s_blockcount.reserve(nblk(n) + 1));
+    SHQ_TRY(ctx->s_counters.reserve(8));
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    const long long nl = ctx->ntreeparts + SHQ_NMAXCHILD;
+    SHQ_TRY(ctx->hsml_leaf.reserve(nl));   /* reused as the density-by-slot array */
+    SHQ_TRY(ctx->flag_leaf.reserve(nl));
+    SHQ_TRY(ctx->velp_leaf.reserve(nl));
+    hipStream_t st = ctx->stream;
+    if(n > 0) {
+        SHQ_HIP(hipMemsetAsync(ctx->s_left.ptr, 0, sizeof(double) * n, st));
+        fill_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(ctx->s_right.ptr, n, p->BoxSize);
+    }
+    SHQ_HIP(hipMemsetAsync(ctx->s_counters.ptr, 0, sizeof(long long) * 8, st));
+    /* neighbour-side arrays in leaf order: density and the skip flags (garbage / no longer gas) */
+    gather_rho_leaf_kernel<<<dim3(nblk(nl)), dim3(256), 0, st>>>(nl, ctx->leaf_pidx.ptr, ctx->g_density.ptr, ctx->hsml_leaf.ptr);
+    sph_gather_leaf_kernel<<<dim3(nblk(nl)), dim3(256), 0, st>>>(nl, ctx->leaf_pidx.ptr, ctx->velp.ptr, nullptr, nullptr, ctx->hsml.ptr, ctx->pflags.ptr,
+                                                                nullptr, ctx->velp_leaf.ptr, nullptr, ctx->s_evp_in.ptr, ctx->flag_leaf.ptr);
+    SHQ_HIP(hipGetLastError());
+    SphDev a = make_dev(ctx);
+    a.Box = p->BoxSize;
+    a.invBox = 1.0 / p->BoxSize;
+    StellarArgs sa;
+    sa.Box = p->BoxSize;
+    sa.DesNumNgb = p->DesNumNgb;
+    sa.MaxDev = p->MaxNgbDeviation;
+    sa.SPHWeighting = p->SPHWeighting;
+    sa.rho_leaf = ctx->hsml_leaf.ptr;
+    sa.starvol = d_starvol;
+    sa.todo = ctx->s_todo.ptr;
+    unsigned long long *nint = reinterpret_cast<unsigned long long *>(ctx->s_counters.ptr + 1);
+    long long *total = ctx->s_counters.ptr;
+    int32_t *bufs[2] = {ctx->s_queue2.ptr, ctx->s_queue3.ptr};
+    int wsel = 0, niter = 0;
+    const int32_t *cur = d_queue;
+    long long size = nq;
+    SHQ_HIP(hipEventRecord(ctx->ev_begin[14], st));
+    while(size > 0) {
+        const long long ntasks = (size + 255) / 256;
+        const unsigned grid = (unsigned) (ntasks < NL_REDO_BLOCKS ? ntasks : NL_REDO_BLOCKS);
+        switch(p->DensityKernelType) {
+        case 1: sph_stellar_kernel<1><<<dim3(grid), dim3(256), 0, st>>>(a, cur, size, sa, nint, ctx->s_nlist2.ptr, ntasks); break;
+        case 2: sph_stellar_kernel<2><<<dim3(grid), dim3(256), 0, st>>>(a, cur, size, sa, nint, ctx->s_nlist2.ptr, ntasks); break;
+        default: sph_stellar_kernel<4><<<dim3(grid), dim3(256), 0, st>>>(a, cur, size, sa, nint, ctx->s_nlist2.ptr, ntasks); break;
+        }
+        SHQ_HIP(hipGetLastError());
+        niter++;
+        const int nb = (int) nblk(size);
+        compact_count_kernel<<<dim3(nb), dim3(256), 0, st>>>(ctx->s_todo.ptr, size, ctx->s_blockcount.ptr);
+        compact_scan_kernel<<<dim3(1), dim3(1024), 0, st>>>(ctx->s_blockcount.ptr, nb, total);
+        compact_write_kernel<<<dim3(nb), dim3(256), 0, st>>>(ctx->s_todo.ptr, size, ctx->s_blockcount.ptr, bufs[wsel]);
+        long long newsize = 0;
+        SHQ_HIP(hipMemcpyAsync(&newsize, total, sizeof(long long), hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipStreamSynchronize(st));
+        size = newsize;
+        cur = bufs[wsel];
+        wsel ^= 1;
+        if(size > 0 && niter > SPH_MAXITER) {
+            shq_set_error("failed to converge the stellar density for %lld stars", size);
+            return SHQ_ERR_NOCONV;
+        }
+    }
+    SHQ_HIP(hipEventRecord(ctx->ev_end[14], st));
+    if(stats) {
+        unsigned long long h_nint = 0;
+        SHQ_HIP(hipMemcpyAsync(&h_nint, nint, sizeof(h_nint), hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipStreamSynchronize(st));
+        float ms = 0;
+        (void) hipEventElapsedTime(&ms, ctx->ev_begin[14], ctx->ev_end[14]);
+        stats->ntargets = nq;
+        stats->ninteractions = (int64_t) h_nint;
+        stats->niterations = niter;
+        stats->kernel_ms = ms;
+    }
+    return SHQ_OK;
+}
+
 int shq_sph_gradrho_mag(shq_context *ctx, double *d_out)
 {
     const long long n = ctx->numpart;

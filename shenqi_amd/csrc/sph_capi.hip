@@ -647,3 +647,47 @@ extern "C" int shq_sph_fill_queries(shq_context *ctx, const shq_data_index *tabl
     dq.release();
     return rc;
 }
+
+extern "C" int shq_stellar_density(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph,
+                                   const int32_t *queue, int64_t nqueue, const shq_stellar_params *params, double *StarVolumeSPH,
+                                   shq_sph_stats *stats)
+{
+    SHQ_CHECK(ctx && tree && parts && sph && params && StarVolumeSPH && (nqueue == 0 || queue), SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->sphrun.phase == 0, SHQ_ERR_STATE, "stellar_density: an SPH walk is open");
+    SHQ_CHECK(nqueue >= 0, SHQ_ERR_INVALID, "stellar_density: bad queue length");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t n = parts->numpart;
+    for(int64_t k = 0; k < nqueue; k++) {
+        const int32_t i = queue[k];
+        SHQ_CHECK(i >= 0 && i < n, SHQ_ERR_INVALID, "stellar_density: queue[%ld] = %d out of range", (long) k, i);
+        SHQ_CHECK(*pfield<uint8_t>(parts, i, parts->off_type) == 4, SHQ_ERR_INVALID, "stellar_density: particle %d in the queue is not a star", i);
+        SHQ_CHECK(*pfield<double>(parts, i, parts->off_hsml) > 0, SHQ_ERR_INVALID,
+                  "stellar_density: star %d has Hsml <= 0 (the reference re-seeds it from its father node; do that before the call)", i);
+    }
+    SHQ_TRY(shq_particles_upload(ctx, parts));
+    SHQ_TRY(sph_upload(ctx, parts, sph));
+    SHQ_TRY(shq_tree_upload(ctx, tree));
+    if(nqueue == 0) {
+        if(stats)
+            memset(stats, 0, sizeof(*stats));
+        return SHQ_OK;
+    }
+    SHQ_TRY(ctx->s_queue0.reserve((size_t) nqueue));
+    SHQ_HIP(hipMemcpyAsync(ctx->s_queue0.ptr, queue, sizeof(int32_t) * nqueue, hipMemcpyHostToDevice, ctx->stream));
+    /* velp (only its garbage / type flags matter here) and a scratch Hsml-by-slot array for the shared leaf gather */
+    SHQ_TRY(ctx->velp.reserve((size_t) std::max<int64_t>(n, 1)));
+    SHQ_TRY(ctx->s_evp_in.reserve((size_t) (ctx->ntreeparts + SHQ_NMAXCHILD)));
+    SHQ_TRY(ctx->s_gradrho.reserve((size_t) std::max<int64_t>(n, 1)));
+    SHQ_HIP(hipMemsetAsync(ctx->s_gradrho.ptr, 0, sizeof(double) * std::max<int64_t>(n, 1), ctx->stream));
+    SHQ_TRY(shq_sph_stellar_density_device(ctx, params, ctx->s_queue0.ptr, nqueue, ctx->s_gradrho.ptr, stats));
+    std::vector<double> hsml, vol;
+    SHQ_TRY(down(ctx, ctx->hsml, hsml, n));
+    SHQ_TRY(down(ctx, ctx->s_gradrho, vol, n));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    for(int64_t k = 0; k < nqueue; k++) {
+        const int32_t i = queue[k];
+        *pfield_w<double>(parts, i, parts->off_hsml) = hsml[i];
+        StarVolumeSPH[*pfield<int32_t>(parts, i, parts->off_pi)] = vol[i];
+    }
+    return SHQ_OK;
+}

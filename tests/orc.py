@@ -50,6 +50,18 @@ lib.orc_hydro.argtypes = [_vp, C.c_int64, C.POINTER(OrcSphArrays), _vp, C.c_int6
 lib.orc_hydro.restype = None
 
 
+def stellar_density(nodes, firstnode, st, queue, BoxSize, DesNumNgb, MaxNgbDeviation, SPHWeighting, kernel):
+    """stellar_density() (stellar_density2.cpp:306-341): returns (rc, StarVolumeSPH by particle, iterations, candidates)."""
+    q = np.ascontiguousarray(queue, dtype=np.int32)
+    vol = np.zeros(st.c.n)
+    niter, nint = C.c_int(), C.c_int64()
+    lib.orc_stellar_density.argtypes = [_vp, C.c_int64, C.POINTER(OrcSphArrays), _vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int,
+                                        C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    rc = lib.orc_stellar_density(ptr(nodes), firstnode, C.byref(st.c), ptr(q), len(q), BoxSize, DesNumNgb, MaxNgbDeviation, int(SPHWeighting),
+                                 int(kernel), ptr(vol), C.byref(niter), C.byref(nint))
+    return rc, vol, niter.value, nint.value
+
+
 class SphState:
     """SoA copy of the particle / slot state the oracle's SPH functions work on."""
 

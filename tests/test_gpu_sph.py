@@ -167,3 +167,39 @@ def test_sph_error_behaviour(ctx):
     dm_tree = sq.force_tree_rebuild_mask(pman, sq.DMMASK)
     with pytest.raises(sq.ShqError):            # tree without gas
         sq.density(ctx, None, 1, 0, 0, None, dm_tree, pman, SphP, BhP)
+
+
+@pytest.mark.parametrize("kernel,weighting", [(1, 0), (2, 1), (4, 1)])
+def test_stellar_density_matches_oracle(ctx, kernel, weighting):
+    """shq_stellar_density (stellar_density2.cpp) against the oracle's restatement: same number of Hsml iterations, same
+    candidates met, final star Hsml and StarVolumeSPH to rounding (the trial radii go through pow() on both sides)."""
+    import test_oracle_cpu as toc
+    pman, SphP, ng, nstar = toc._stars_in_gas(n1=16, nstar=500, seed=kernel)
+    P = pman.Base
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+    support = {1: 4, 2: 6, 4: 5}[kernel]
+    des = 4.0 / 3 * np.pi * (support / 2.0) ** 3
+    queue = np.arange(ng, ng + nstar, dtype=np.int32)[::-1].copy()      # any order
+    st = orc.SphState(P, SphP)
+    rc, ovol, oniter, onint = orc.stellar_density(tree.Nodes_base, tree.firstnode, st, queue, cm.BOX, des, 2.0, weighting, kernel)
+    assert rc == 0
+    sp = capi.StellarParams(cm.BOX, des, 2.0, weighting, kernel)
+    vol = np.zeros(nstar)
+    stats = capi.SphStats()
+    pv, tv, sv = pman.view(), tree.view(), capi.sph_view(SphP)
+    hs0 = P["Hsml"].copy()
+    capi.check(capi.hip.shq_stellar_density(ctx.h, C.byref(tv), C.byref(pv), C.byref(sv), capi.ptr(queue), len(queue), C.byref(sp),
+                                            capi.ptr(vol), C.byref(stats)))
+    assert stats.niterations == oniter
+    assert np.array_equal(P["Hsml"][:ng], hs0[:ng])                      # gas untouched
+    assert np.abs(P["Hsml"][ng:] / st.hsml[ng:] - 1).max() < 1e-9
+    assert np.abs(vol - ovol[ng:]).max() < 1e-8 * np.abs(ovol[ng:]).max()
+    # the device walk keeps the largest trial radius throughout, the reference shrinks it: it meets at least as many candidates
+    assert stats.ninteractions >= onint
+    # edge cases: empty queue, a non-star in the queue, Hsml == 0
+    capi.check(capi.hip.shq_stellar_density(ctx.h, C.byref(tv), C.byref(pv), C.byref(sv), None, 0, C.byref(sp), capi.ptr(vol), None))
+    bad = np.array([0], dtype=np.int32)
+    assert capi.hip.shq_stellar_density(ctx.h, C.byref(tv), C.byref(pv), C.byref(sv), capi.ptr(bad), 1, C.byref(sp), capi.ptr(vol), None) != 0
+    P["Hsml"][ng] = 0
+    assert capi.hip.shq_stellar_density(ctx.h, C.byref(tv), C.byref(pv), C.byref(sv), capi.ptr(queue), len(queue), C.byref(sp), capi.ptr(vol),
+                                        None) != 0

@@ -329,3 +329,60 @@ def test_toptree_exports_close_the_distributed_walk():
         need = {int(tl["treenode"][leaf_of[j]]) for j in ngb if leaf_of[j] >= 0 and tl["Task"][leaf_of[j]] != 1}
         got = {int(x) for x in table["NodeList"][start[i]:start[i + 1]].ravel() if x >= 0}
         assert need <= got
+
+
+def _stars_in_gas(n1=14, nstar=300, seed=4):
+    """Gas on a jittered lattice with a density gradient in its SPH densities, plus star particles at random places."""
+    import shenqi_amd as sq
+    rng = np.random.default_rng(seed)
+    ng = n1**3
+    gas = cm.grid_positions(n1) + rng.normal(size=(ng, 3)) * 0.15 * cm.BOX / n1
+    gas = np.mod(gas, cm.BOX)
+    gas[gas == 0] = 1e-9
+    stars = rng.random((nstar, 3)) * cm.BOX
+    pos = np.concatenate([gas, stars])
+    pman = sq.PartManager(ng + nstar, cm.BOX)
+    P = pman.Base
+    P["Pos"] = pos
+    P["Mass"] = 1.0 + 0.5 * rng.random(ng + nstar)
+    P["Type"][:ng] = 0
+    P["Type"][ng:] = 4
+    P["PI"][:ng] = np.arange(ng)
+    P["PI"][ng:] = np.arange(nstar)
+    P["Hsml"] = cm.BOX / n1 * rng.uniform(0.8, 3.0, size=ng + nstar)
+    SphP = np.zeros(ng, dtype=sq.SPH_DTYPE)
+    SphP["Density"] = 1.0 + 3.0 * pos[:ng, 0] / cm.BOX
+    SphP["Entropy"] = 1.0
+    return pman, SphP, ng, nstar
+
+
+def test_stellar_density_oracle_against_brute_force():
+    """oracle/sph.cpp orc_stellar_density has no reference fixture: check what it must deliver — every star ends with
+    DesNumNgb +- MaxNgbDeviation kernel-weighted neighbours at its final Hsml, and StarVolumeSPH is the brute-force sum
+    of m_j / rho_j (times w_k) over the gas inside that radius."""
+    import shenqi_amd as sq
+    pman, SphP, ng, nstar = _stars_in_gas()
+    P = pman.Base
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+    kernel = 1
+    des = 4.0 / 3 * np.pi * 2.0**3          # cubic spline, eta = 1
+    for weighting in (0, 1):
+        st = orc.SphState(P, SphP)
+        queue = np.arange(ng, ng + nstar, dtype=np.int32)
+        rc, vol, niter, nint = orc.stellar_density(tree.Nodes_base, tree.firstnode, st, queue, cm.BOX, des, 2.0, weighting, kernel)
+        assert rc == 0 and 1 < niter < 60 and nint > 0
+        out = np.zeros(5)
+        for i in queue[:80]:
+            h = st.hsml[i]
+            d = P["Pos"][:ng] - P["Pos"][i]
+            d -= cm.BOX * np.rint(d / cm.BOX)
+            r = np.sqrt(np.sum(d * d, axis=1))
+            inside = np.nonzero(r < h)[0]
+            ngb, v = 0.0, 0.0
+            for j in inside:
+                orc.lib.orc_density_kernel(kernel, h, r[j] / h, 1.0, orc.ptr(out))
+                wk, kvol = out[2], out[1]
+                ngb += wk * kvol
+                v += P["Mass"][j] / SphP["Density"][j] * (wk if weighting else 1.0)
+            assert abs(ngb - des) <= 2.0 + 1e-9, (i, ngb)
+            assert abs(v - vol[i]) <= 1e-9 * max(v, 1e-300), (i, v, vol[i])
