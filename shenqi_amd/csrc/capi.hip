@@ -76,11 +76,30 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
     SHQ_HIP(hipSetDevice(device));
     shq_context *ctx = new shq_context();
     ctx->device = device;
+    /* SHQ_PM_CUS = k: with the PM on its own stream (SHQ_PM_OVERLAP), give it k compute units of every XCD and the
+     * main stream the other 32 - k, so that the HBM-bound PM passes and the VALU-bound walk share the chip in space
+     * (the walk's waves fill every register file, nothing of the PM fits beside them on the same CU).  The bit
+     * pattern picks k CUs per XCD whether mask bits run XCD-major or interleave the XCDs. */
+    uint32_t mask_pm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mask_main[8];
+    int pm_cus = 0;
+    if(const char *v = getenv("SHQ_PM_CUS"))
+        pm_cus = atoi(v);
+    if(pm_cus < 0 || pm_cus > 16)
+        pm_cus = 0;
+    for(int a = 0; a < 8; a++)
+        for(int c = 0; c < pm_cus; c++) {
+            const int bit = 32 * a + ((a + c / 4) % 8) + 8 * (c % 4);
+            mask_pm[bit >> 5] |= 1u << (bit & 31);
+        }
+    for(int w = 0; w < 8; w++)
+        mask_main[w] = ~mask_pm[w];
     if(stream) {
         ctx->stream = (hipStream_t) stream;
         ctx->own_stream = false;
+        pm_cus = 0;
     } else {
-        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        hipError_t e = pm_cus > 0 ? hipExtStreamCreateWithCUMask(&ctx->stream, 8, mask_main)
+                                  : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
         if(e != hipSuccess) {
             shq_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
             delete ctx;
@@ -94,7 +113,8 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
     }
     int prio_lo = 0, prio_hi = 0;
     (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if(hipStreamCreateWithPriority(&ctx->stream_pm, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+    if((pm_cus > 0 ? hipExtStreamCreateWithCUMask(&ctx->stream_pm, 8, mask_pm)
+                   : hipStreamCreateWithPriority(&ctx->stream_pm, hipStreamNonBlocking, prio_hi)) != hipSuccess ||
        hipEventCreateWithFlags(&ctx->ev_pm_ready, hipEventDisableTiming) != hipSuccess ||
        hipEventCreateWithFlags(&ctx->ev_pm_done, hipEventDisableTiming) != hipSuccess) {
         shq_set_error("creating the PM stream failed");
