@@ -139,9 +139,11 @@ __device__ __forceinline__ void leaf_particle(const double4 *__restrict__ tab, c
 }
 
 /* POT: accumulate the potential.  PREFETCH: speculative fetch of pool[cur+1].  LEAFB: leaf
- * particles fetched per batch (2 or 4).  STATS: wave-level counters for the bench. */
+ * particles fetched per batch (2 or 4).  STATS: wave-level counters for the bench.
+ * amdgpu_num_sgpr(96): the kernel wants 106 SGPRs, which allocates 112 and caps a SIMD at 7 waves; held to 96 (ten values
+ * parked in lanes of a spare VGPR, still 64 VGPRs) it runs 8: walk 44.45 -> 43.6 ms in a same-box A/B. */
 template <bool POT, bool PREFETCH, int LEAFB, int STATS, bool BH, bool GHOSTS = false>
-__global__ __launch_bounds__(256) void grav_walk_exact_kernel(const WalkArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void grav_walk_exact_kernel(const WalkArgs a)
 {
     __shared__ double4 tab[SHQ_NGRAVTAB];
     for(int i = threadIdx.x; i < SHQ_NGRAVTAB; i += blockDim.x) {
