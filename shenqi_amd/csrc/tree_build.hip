@@ -477,6 +477,54 @@ struct BelowLimit {
  * the leaves list them.  64 consecutive entries are 8-16 neighbouring leaves, so a wave's targets stay
  * spatially compact even when the particle index order has gone stale after many drifts (the reference
  * re-sorts its particle array along the Peano-Hilbert curve at every domain decomposition instead). */
+/* Peano-Hilbert key of a position (Skilling's axes-to-transpose transform, as host/hostapi.cpp shqh_hilbert_order):
+ * consecutive keys are spatial neighbours — an octant (Morton) order jumps across the box at every octant boundary —
+ * so 64 consecutive targets make a more compact group and a shorter union walk. */
+__global__ void hilbert_key_kernel(long long n, const int32_t *__restrict__ targets, const double4 *__restrict__ posm, double L,
+                                   unsigned long long *keys)
+{
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= n)
+        return;
+    const double4 p = posm[targets[t]];
+    const int bits = 21;
+    const double scale = (double) (1 << bits) / (L * 1.001);
+    const double xs[3] = {p.x, p.y, p.z};
+    unsigned int X[3];
+    for(int j = 0; j < 3; j++) {
+        double v = (xs[j] + L / 2000.) * scale;
+        v = v < 0 ? 0 : v;
+        v = v > (double) ((1 << bits) - 1) ? (double) ((1 << bits) - 1) : v;
+        X[j] = (unsigned int) v;
+    }
+    const unsigned int M = 1u << (bits - 1);
+    for(unsigned int Q = M; Q > 1; Q >>= 1) {
+        const unsigned int P = Q - 1;
+        for(int j = 0; j < 3; j++) {
+            if(X[j] & Q)
+                X[0] ^= P;
+            else {
+                const unsigned int tt = (X[0] ^ X[j]) & P;
+                X[0] ^= tt;
+                X[j] ^= tt;
+            }
+        }
+    }
+    X[1] ^= X[0];
+    X[2] ^= X[1];
+    unsigned int tt = 0;
+    for(unsigned int Q = M; Q > 1; Q >>= 1)
+        if(X[2] & Q)
+            tt ^= Q - 1;
+    for(int j = 0; j < 3; j++)
+        X[j] ^= tt;
+    unsigned long long key = 0;
+    for(int b = bits - 1; b >= 0; b--)
+        key = (key << 3) | ((unsigned long long) ((X[0] >> b) & 1) << 2) | ((unsigned long long) ((X[1] >> b) & 1) << 1) |
+              (unsigned long long) ((X[2] >> b) & 1);
+    keys[t] = key;
+}
+
 int shq_build_tree_targets(shq_context *ctx)
 {
     if(ctx->have_tree_targets)
@@ -498,6 +546,21 @@ int shq_build_tree_targets(shq_context *ctx)
         SHQ_HIP(hipMemcpyAsync(&h, d_count, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         SHQ_HIP(hipStreamSynchronize(ctx->stream));
         ctx->ntree_targets = (int64_t) h;
+        /* leaf order is an octant order: re-sort the targets along the Peano-Hilbert curve */
+        const long long nt = (long long) h;
+        if(nt > 64 && ctx->treeBox > 0) {
+            SHQ_TRY(b.keys[0].reserve((size_t) nt));
+            SHQ_TRY(b.keys[1].reserve((size_t) nt));
+            SHQ_TRY(b.idx[0].reserve((size_t) nt));
+            hilbert_key_kernel<<<dim3(nblk(nt)), dim3(256), 0, ctx->stream>>>(nt, ctx->tree_targets.ptr, ctx->posm.ptr, ctx->treeBox, b.keys[0].ptr);
+            SHQ_HIP(hipGetLastError());
+            SHQ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, b.keys[0].ptr, b.keys[1].ptr, ctx->tree_targets.ptr, b.idx[0].ptr, (size_t) nt, 0, 63,
+                                              ctx->stream));
+            SHQ_TRY(b.temp.reserve(tmp + 16));
+            SHQ_HIP(rocprim::radix_sort_pairs(b.temp.ptr, tmp, b.keys[0].ptr, b.keys[1].ptr, ctx->tree_targets.ptr, b.idx[0].ptr, (size_t) nt, 0, 63,
+                                              ctx->stream));
+            SHQ_HIP(hipMemcpyAsync(ctx->tree_targets.ptr, b.idx[0].ptr, sizeof(int32_t) * (size_t) nt, hipMemcpyDeviceToDevice, ctx->stream));
+        }
     }
     ctx->have_tree_targets = true;
     return SHQ_OK;
