@@ -94,13 +94,14 @@ __device__ __forceinline__ void apply_accn(const double4 *__restrict__ tab, doub
         if(u < 0.5) {
             fac = mass * a.h3_inv * (10.666666666667 + u * u * (32.0 * u - 38.4));
             wp = -2.8 + u * u * (5.333333333333 + u * u * (6.4 * u - 9.6));
+            facpot = mass * a.h_inv * wp;
         } else {
-            fac = mass * a.h3_inv *
-                  (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u -
-                   0.066666666667 / (u * u * u));
-            wp = -3.2 + 0.066666666667 / u + u * u * (10.666666666667 + u * (-16.0 + u * (9.6 - 2.133333333333 * u)));
+            /* the reference's 0.0667 / u^3 and 0.0667 / u terms are the Newtonian force and potential themselves
+             * (mass h^-3 / u^3 = mass / r^3, mass h^-1 / u = mass / r), already formed above from 1/r: no divisions */
+            fac = fma(mass * a.h3_inv, 21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u, -0.066666666667 * fac);
+            wp = -3.2 + u * u * (10.666666666667 + u * (-16.0 + u * (9.6 - 2.133333333333 * u)));
+            facpot = fma(mass * a.h_inv, wp, 0.066666666667 * mr);
         }
-        facpot = mass * a.h_inv * wp;
     }
     const double fi = r * a.inv_celldx;
     if(fi < (double) (SHQ_NGRAVTAB - 1)) {
