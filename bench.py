@@ -336,6 +336,9 @@ def main():
         capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, args.walk_mode))
         capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, G))
 
+    # the timed steps run the production walk (no diagnostic counters); the wave-level figures under kernels.tree_* come from
+    # one more, untimed step with the counters on (a separate kernel instantiation: its own row in a profile)
+    capi.check(capi.hip.shq_set_walk_stats(ctx.h, 0))
     # seeding: PM + Barnes-Hut walk (theta = 0.175) so that the timed walks use the relative criterion
     t0 = time.perf_counter()
     step(gp_bh)
@@ -373,6 +376,13 @@ def main():
     ph = (C.c_double * 6)()
     capi.check(capi.hip.shq_pm_phase_ms(ctx.h, C.byref(ph)))
     ph = list(ph)
+    capi.check(capi.hip.shq_set_walk_stats(ctx.h, 1))
+    step(gp_rel)
+    stw = sq.WalkStats()
+    capi.check(capi.hip.shq_grav_short_download(ctx.h, None, None, None, C.byref(stw)))
+    for k in ("nnodes_visited", "nwave_interactions", "nwave_node_interactions", "nnode_interactions"):
+        setattr(st, k, getattr(stw, k))
+    counted_walk_ms = float(stw.kernel_ms)
 
     ncells = float(nmesh) ** 3
     # ---- algorithmic bytes ------------------------------------------
@@ -442,7 +452,7 @@ def main():
                             "frac": fft_bytes / max(fft_s, 1e-12) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_fft,
                             "algorithmic_bytes": fft_bytes},
         "kernels": {
-            "tree_walk_ms": st.kernel_ms, "tree_interactions_per_target": st.ninteractions / max(1, st.ntargets),
+            "tree_walk_ms": st.kernel_ms, "tree_walk_with_counters_ms": counted_walk_ms, "tree_interactions_per_target": st.ninteractions / max(1, st.ntargets),
             "tree_interactions_per_s": st.ninteractions / max(walk_s, 1e-12),
             "tree_fp64_frac_of_vector_peak": 45.0 * st.ninteractions / max(walk_s, 1e-12) / 1e12 / FP64_VECTOR_PEAK_TF,
             "tree_nodes_visited_per_wave": st.nnodes_visited / max(1.0, st.ntargets / 64.0),
@@ -484,9 +494,9 @@ def main():
         sq.dynamics_upload(ctx, pman)
         gk = np.full(capi.TIMEBINS + 1, 1e-9)
         nres = 3
-        # without the wave-level counters: a different kernel instantiation, so that a profile of this command lists
-        # the timed production walk (counters on) separately from the walks of this loop (moved particles, tree order)
         capi.check(capi.hip.shq_set_walk_stats(ctx.h, 0))
+        # a sub-step of the hierarchical integrator: no potential update (update_potential = 0, its own kernel instantiation and
+        # so its own row in a profile), kicks from the walk's Accel output (AccelStore, timestep.cpp:273)
         for it in range(nres + 2):              # two warm-up passes (the GPU idled during the CPU baseline)
             if it == 2:
                 ctx.synchronize()
@@ -495,9 +505,9 @@ def main():
             sq.tree_build_device(ctx, L)
             capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
             # targets in tree order: the particle index order goes stale as the particles move
-            capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp_rel), None, 0, 1, args.walk_mode | sq.WALK_TREE_ORDER))
+            capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp_rel), None, 0, 0, args.walk_mode | sq.WALK_TREE_ORDER))
             capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, G))
-            sq.kick_short(ctx, gk)
+            sq.kick_short(ctx, gk, from_accel_store=True)
             sq.kick_pm(ctx, 1e-9)
         ctx.synchronize()
         t_res = time.perf_counter() - t0

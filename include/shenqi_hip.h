@@ -286,8 +286,9 @@ int shq_grav_short_run(shq_context *ctx, const shq_grav_params *params, const in
                        int64_t nactive, int update_potential, int walk_mode);
 /* Copy results back: accel[numpart][3] (may be NULL), potential[numpart] (may be NULL),
  * ninteractions[numpart] (may be NULL). Synchronises. */
-/* Wave-level walk counters in shq_walk_stats (nnodes_visited, nwave_*): 0 off, 1 on (default; costs < 1 %),
- * 2 also prints lane-participation histograms to stderr at download.  Each level is its own kernel instantiation. */
+/* Wave-level walk counters in shq_walk_stats (nnodes_visited, nwave_*, nnode_interactions): 0 off (default: they stay
+ * zero; the counters cost the walk ~4 %, they press on its scalar register budget), 1 on, 2 plus per-lane-participation
+ * histograms printed to stderr.  ninteractions, min / max and kernel_ms are always filled. */
 int shq_set_walk_stats(shq_context *ctx, int level);
 int shq_grav_short_download(shq_context *ctx, double (*accel)[3], double *potential,
                             int64_t *ninteractions, shq_walk_stats *stats);

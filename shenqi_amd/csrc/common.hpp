@@ -317,7 +317,7 @@ struct shq_context {
 
     shq_walk_stats last_stats = {};
     int walk_variant = 3;      /* SHQ_WALK_VARIANT: 0 prefetch+leaf4, 1 prefetch+leaf2, 2 leaf4, 3 leaf2 (fastest: no SGPR spills) */
-    int walk_stats = 1;        /* SHQ_WALK_STATS: wave-level counters on/off */
+    int walk_stats = 0;        /* SHQ_WALK_STATS / shq_set_walk_stats: wave-level counters (1), + histograms (2); off by default: 4 % */
     int xcd_k = 32;            /* SHQ_XCD_K: blocks per XCD chunk in the remap (0 = off); 32 measured best (2 %) */
     float last_walk_ms = 0;
 

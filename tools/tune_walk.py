@@ -9,6 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_NUM_THREADS", str(len(os.sched_getaffinity(0))))
+os.environ.setdefault("SHQ_WALK_STATS", "1")  # these tools print the wave-level counters
 import shenqi_amd as sq  # noqa: E402
 from shenqi_amd import capi  # noqa: E402
 
