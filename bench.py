@@ -157,6 +157,7 @@ def c3_step(ctx, gas_pos, n1, density_ms, hydro_ms):
     gp_rel = sq.make_grav_params(L, 1.5, nmesh, G, RHO0)
     pmp = sq.PMParams(nmesh, 0, L, 1.5, G)
     pv = pman.view()
+    capi.check(capi.hip.shq_set_walk_stats(ctx.h, 1))   # keeps these walks out of the production walk's row of a profile
     capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
     try:
         sq.tree_build_device(ctx, L)

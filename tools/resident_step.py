@@ -31,7 +31,8 @@ acc = {k: [] for k in names}
 for it in range(4):
     def t(name, fn):
         ctx.synchronize(); t0 = time.perf_counter(); fn(); ctx.synchronize(); acc[name].append(1e3 * (time.perf_counter() - t0))
-    t("drift", lambda: sq.drift(ctx, 1e-4 * L / n1, L))
+    if not os.environ.get("NODRIFT"):
+        t("drift", lambda: sq.drift(ctx, float(os.environ.get("DDRIFT", "1e-4")) * L / n1, L))
     t("tree_build", lambda: sq.tree_build_device(ctx, L))
     t("pm", lambda: capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp))))
     t("walk", lambda: capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, MODE)))
@@ -39,7 +40,8 @@ for it in range(4):
     capi.check(capi.hip.shq_grav_short_download(ctx.h, None, None, None, C.byref(st)))
     print("iter", it, "walk kernel %.2f ms, interactions/target %.1f, visits/wave %.1f" % (st.kernel_ms, st.ninteractions / n, st.nnodes_visited / (n / 64)), flush=True)
     t("oldacc", lambda: capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, G)))
-    t("kick_short", lambda: sq.kick_short(ctx, gk))
-    t("kick_pm", lambda: sq.kick_pm(ctx, 1e-9))
+    if not os.environ.get("NOKICK"):
+        t("kick_short", lambda: sq.kick_short(ctx, gk))
+        t("kick_pm", lambda: sq.kick_pm(ctx, 1e-9))
 print({k: [round(x, 2) for x in v] for k, v in acc.items()})
-print({k: round(min(v), 2) for k, v in acc.items()}, "sum", round(sum(min(v) for v in acc.values()), 2))
+print({k: round(min(v), 2) for k, v in acc.items() if v}, "sum", round(sum(min(v) for v in acc.values() if v), 2))
