@@ -29,7 +29,7 @@ pman.Base["Type"] = 1
 pman.Base["Mass"] = 1.0
 tree = sq.force_tree_full(pman)
 sq.set_gravshort_treepar(ErrTolForceAcc=0.005, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=1, Rcut=6.0)
-sq.gravshort_set_softenings(L / n1)
+sq.gravshort_set_softenings(L / n1 * float(os.environ.get("TUNE_SOFT", "1")))
 gp_bh = sq.make_grav_params(L, 1.5, nmesh, G, RHO0)
 sq.set_gravshort_treepar(ErrTolForceAcc=0.005, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=0, Rcut=6.0)
 gp_rel = sq.make_grav_params(L, 1.5, nmesh, G, RHO0)
