@@ -498,8 +498,9 @@ def main():
         capi.check(capi.hip.shq_set_walk_stats(ctx.h, 0))
         # a sub-step of the hierarchical integrator: no potential update (update_potential = 0, its own kernel instantiation and
         # so its own row in a profile), kicks from the walk's Accel output (AccelStore, timestep.cpp:273)
-        for it in range(nres + 2):              # two warm-up passes (the GPU idled during the CPU baseline)
-            if it == 2:
+        nwarm = 6                               # the GPU idled for seconds during the CPU baseline: let the clocks come back
+        for it in range(nres + nwarm):
+            if it == nwarm:
                 ctx.synchronize()
                 t0 = time.perf_counter()
             sq.drift(ctx, 1e-4 * L / n1, L)
