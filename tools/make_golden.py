@@ -62,3 +62,34 @@ np.savez_compressed(os.path.join(out, "sph_10cube.npz"), pos=pos, vel=pman.Base[
                     divvel=st.divvel, curlvel=st.curlvel, entvarpred=evp, niter=niter, nint_density=nint,
                     hydroaccel=st.hydroaccel, dtentropy=st.dtentropy, maxsignalvel=st.maxsignalvel, nint_hydro=nint_h, box=cm.BOX)
 print("wrote", os.listdir(out))
+
+# distributed walk: export table of a fabricated three-task domain over the 12^3 gravity fixture, and the stellar
+# density of 200 stars in a 12^3 gas box (oracle/toptree.cpp, oracle/sph.cpp)
+g = np.load(os.path.join(out, "treepm_12cube.npz"))
+pos = g["pos"]
+n = len(pos)
+pman = cm.make_partmanager(pos)
+dom = sq.force_tree_full(pman)
+tl = cm.make_domain(dom, ntask=3, me=1, depth=2)
+cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=0)
+sq.gravshort_set_softenings(cm.BOX / np.cbrt(n))
+gp = sq.make_grav_params(cm.BOX, 1.5, 36, cm.G, cm.RHO0)
+counts, table = orc.grav_toptree(dom.Nodes_base, dom.firstnode, dom.lastnode, tl, pos, g["oldacc"], gp)
+hs = 0.08 * cm.BOX * (0.5 + np.random.default_rng(3).random(n))
+ncounts, ntable = orc.ngb_toptree(dom.Nodes_base, dom.firstnode, dom.lastnode, tl, pos, hs, 0, cm.BOX)
+np.savez_compressed(os.path.join(out, "toptree_12cube.npz"), topleaves=tl, counts=counts, table=table, hsml=hs, ngb_counts=ncounts,
+                    ngb_table=ntable, ntask=3, me=1, depth=2)
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_oracle_cpu as toc  # noqa: E402
+pman, SphP, ng, nstar = toc._stars_in_gas(n1=12, nstar=200, seed=2)
+tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+st = orc.SphState(pman.Base, SphP)
+des = 4.0 / 3 * np.pi * 2.0**3
+queue = np.arange(ng, ng + nstar, dtype=np.int32)
+hs0 = pman.Base["Hsml"].copy()
+rc, vol, niter, nint = orc.stellar_density(tree.Nodes_base, tree.firstnode, st, queue, cm.BOX, des, 2.0, 1, 1)
+assert rc == 0
+np.savez_compressed(os.path.join(out, "stellar_12cube.npz"), pos=pman.Base["Pos"], mass=pman.Base["Mass"], hsml0=hs0, density=SphP["Density"],
+                    ng=ng, nstar=nstar, hsml=st.hsml[ng:], starvol=vol[ng:], niter=niter, des=des)
+print("wrote", os.listdir(out))
