@@ -90,6 +90,48 @@ def cpu_baseline(pos, mass, tree, gp_rel, oldacc, L, acc_gpu=None):
     }
 
 
+def distributed_walk_figures(ctx, sq, capi, tree, pos, oldacc, gp_rel, n):
+    """The pieces shenqi's own multi-rank walk would call, timed on the bench's tree turned into the local tree
+    of rank 0 of an 8-rank domain (512 top leaves, 7/8 of them pseudo nodes): export detection for all local targets and the
+    secondary walk of that many imported queries.  Extra figures (kernels.dist_*), host-inclusive wall times."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import common as cm  # test helper that fabricates the domain flags (no oracle involved)
+    nodes = tree.Nodes_base
+    keep_flags, keep_suns = nodes["flags"].copy(), nodes["suns"].copy()
+    tl = cm.make_domain(tree, ntask=8, me=0, depth=3)
+    fn = tree.firstnode
+    leaf_nodes = tl["treenode"][tl["Task"] == 0]
+    # local targets: the particles under rank 0's top leaves
+    local = np.zeros(n, dtype=bool)
+    for no in leaf_nodes:
+        nd = nodes[no - fn]
+        local |= np.all(np.abs(pos - nd["center"]) <= 0.5 * nd["len"], axis=1)
+    act = np.nonzero(local)[0].astype(np.int32)
+    tv = tree.view()
+    capi.check(capi.hip.shq_tree_upload(ctx.h, C.byref(tv)))
+    sq.toptree_upload(ctx, tree, tl)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    counts, table = sq.grav_toptree_exports(ctx, gp_rel, len(act), act)
+    t_top = time.perf_counter() - t0
+    # the owners' side: restore the undivided tree (flags only) and walk the exported queries
+    nodes["flags"][:] = keep_flags | (nodes["flags"] & 3)
+    nodes["suns"][:] = keep_suns
+    capi.check(capi.hip.shq_tree_upload(ctx.h, C.byref(tv)))
+    q = np.zeros(len(table), dtype=capi.GRAV_QUERY_DTYPE)
+    q["Pos"], q["OldAcc"], q["NodeList"] = pos[table["Index"]], oldacc[table["Index"]], table["NodeList"]
+    res = np.zeros(len(q), dtype=capi.GRAV_RESULT_DTYPE)
+    nint = np.zeros(len(q), dtype=np.int64)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    capi.check(capi.hip.shq_grav_short_secondary(ctx.h, C.byref(gp_rel), capi.ptr(q), len(q), capi.ptr(res), capi.ptr(nint), 1))
+    t_sec = time.perf_counter() - t0
+    nodes["flags"][:] = keep_flags
+    return {"dist_workload": "rank 0 of a fabricated 8-rank domain (512 top leaves) over the bench's tree", "dist_local_targets": int(len(act)),
+            "dist_exports": int(len(table)), "dist_export_detection_ms": 1e3 * t_top, "dist_secondary_queries": int(len(q)),
+            "dist_secondary_walk_ms": 1e3 * t_sec, "dist_secondary_interactions_per_query": float(nint.mean()) if len(q) else 0.0}
+
+
 def sph_figures(ctx, n1=128, kernel=2):
     """SPH operators of BASELINE configs[2] (density with the Hsml loop, hydro force) on n1^3 uniformly
     placed gas particles, quintic kernel, pressure-entropy SPH: HIP-event time of the walk kernels through
@@ -488,6 +530,10 @@ def main():
         capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), None, None, None))
         out["cpu_baseline"] = cpu_baseline(pos, P["Mass"], tree, gp_rel, oldacc, L, acc_gpu=acc)
         out["force_error"] = out["cpu_baseline"].pop("force_error")
+        try:
+            out["kernels"].update(distributed_walk_figures(ctx, sq, capi, tree, pos, oldacc, gp_rel, n))
+        except Exception as e:  # an extra figure: never fatal
+            out["kernels"]["dist_note"] = "distributed-walk figures skipped: %s" % e
     # Extra figure, outside `value`: a fully resident step with moving particles — drift, device tree
     # build, PM, walk, OldAcc, short-range and PM kicks — nothing crosses PCIe.
     try:
