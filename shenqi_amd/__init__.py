@@ -143,34 +143,32 @@ def toptree_upload(ctx, tree, topleaves):
     capi.check(capi.hip.shq_toptree_upload(ctx.h, C.byref(tv), capi.ptr(tl), len(tl)), "shq_toptree_upload")
 
 
-def _toptree_exports(call, active):
+def _toptree_exports(call, ntargets, active):
+    """One call with a generous table; a second, exactly sized one only if that was too small."""
     act, nact = _active_arg(active)
+    counts = np.zeros(ntargets, dtype=np.int32)
     n = C.c_int64()
-    capi.check(call(act, nact, None, None, 0, C.byref(n)))
-    return act, nact, n.value
+    cap = max(1024, ntargets // 4)
+    table = np.zeros(cap, dtype=capi.DATA_INDEX_DTYPE)
+    rc = call(act, nact, capi.ptr(counts), capi.ptr(table), cap, C.byref(n))
+    if rc != 0 and n.value > cap:
+        table = np.zeros(n.value, dtype=capi.DATA_INDEX_DTYPE)
+        rc = call(act, nact, capi.ptr(counts), capi.ptr(table), n.value, C.byref(n))
+    capi.check(rc, "toptree exports")
+    return counts, table[: n.value].copy()
 
 
 def grav_toptree_exports(ctx, gp, ntargets, active=None):
     """shq_grav_toptree_exports: (exportcounts [ntargets] inclusive scan, DataIndexTable) of
     GravTopTreeWalk::toptree_visit (libgadget/gravshort2.hpp:362-438)."""
-    call = lambda a, na, cnt, tab, cap, n: capi.hip.shq_grav_toptree_exports(ctx.h, C.byref(gp), a, na, cnt, tab, cap, n)
-    act, nact, total = _toptree_exports(call, active)
-    counts = np.zeros(ntargets, dtype=np.int32)
-    table = np.zeros(total, dtype=capi.DATA_INDEX_DTYPE)
-    n = C.c_int64()
-    capi.check(call(act, nact, capi.ptr(counts), capi.ptr(table), total, C.byref(n)), "shq_grav_toptree_exports")
-    return counts, table
+    return _toptree_exports(lambda a, na, cnt, tab, cap, n: capi.hip.shq_grav_toptree_exports(ctx.h, C.byref(gp), a, na, cnt, tab, cap, n),
+                            ntargets, active)
 
 
 def ngb_toptree_exports(ctx, symmetric, BoxSize, ntargets, active=None):
     """shq_ngb_toptree_exports: TopTreeWalk::toptree_visit with cull_node (libgadget/localtreewalk2.h:210-259)."""
-    call = lambda a, na, cnt, tab, cap, n: capi.hip.shq_ngb_toptree_exports(ctx.h, int(symmetric), float(BoxSize), a, na, cnt, tab, cap, n)
-    act, nact, total = _toptree_exports(call, active)
-    counts = np.zeros(ntargets, dtype=np.int32)
-    table = np.zeros(total, dtype=capi.DATA_INDEX_DTYPE)
-    n = C.c_int64()
-    capi.check(call(act, nact, capi.ptr(counts), capi.ptr(table), total, C.byref(n)), "shq_ngb_toptree_exports")
-    return counts, table
+    return _toptree_exports(lambda a, na, cnt, tab, cap, n: capi.hip.shq_ngb_toptree_exports(ctx.h, int(symmetric), float(BoxSize), a, na, cnt, tab,
+                                                                                           cap, n), ntargets, active)
 
 
 def timebins_upload(ctx, bin_gravity=None, bin_hydro=None):
