@@ -538,6 +538,15 @@ int shq_stellar_density(shq_context *ctx, const shq_tree_view *tree, const shq_p
                         const int32_t *queue, int64_t nqueue, const shq_stellar_params *params, double *StarVolumeSPH,
                         shq_sph_stats *stats);
 
+/* blackhole_veldisp() (libgadget/veldisp2.cpp:164-199): for the active black holes (type 5, not garbage / swallowed) the
+ * number of dark-matter particles inside Hsml and the first and second moments of their predicted velocities
+ * (DM_VelPred, density2.h:104-111) relative to the hole's, and VDisp = sqrt((V2/N - |V1/N|^2) / 3) where that is positive
+ * (BHVelDispOutput::postprocess, :49-63).  `tree` is the dark-matter tree (DMMASK); the particle view needs Vel,
+ * FullTreeGravAccel, GravPM, Hsml, TimeBinGravity and PI.  Outputs are indexed by black-hole slot PI; NumDM / V1sumDM /
+ * V2sumDM may be NULL; VDisp[PI] is written only where NumDM > 0 and the variance is positive, as the reference does. */
+int shq_bh_veldisp(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const int32_t *active, int64_t nactive,
+                   const shq_kick_factors *kf, double *NumDM, double (*V1sumDM)[3], double *V2sumDM, double *VDisp);
+
 /* ---- long-range PM --------------------------------------------------------------------- */
 
 /* Mirror of the PetaPM fields gravpm.cpp reads (libgadget/petapm.h:87-112). */

@@ -128,6 +128,11 @@ int orc_stellar_density(const shq_node *nodes, int64_t firstnode, orc_sph_arrays
                         double BoxSize, double DesNumNgb, double MaxNgbDeviation, int SPHWeighting, int ktype,
                         double *StarVolumeSPH, int *niter_out, int64_t *nint_out);
 
+/* blackhole_veldisp() (veldisp2.cpp:164-199): out[q][5] = NumDM, V1sumDM[3], V2sumDM of the q-th black hole in `queue` over the
+ * dark-matter tree; vdisp[q] set where the reference sets BHP().VDisp.  "Parity unpinned" (no reference fixture). */
+void orc_bh_veldisp(const shq_node *nodes, int64_t firstnode, const orc_sph_arrays *a, const int32_t *queue, int64_t nqueue,
+                    double BoxSize, const shq_kick_factors *kf, double *out, double *vdisp);
+
 #ifdef __cplusplus
 }
 #endif

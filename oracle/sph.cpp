@@ -758,3 +758,70 @@ extern "C" int orc_stellar_density(const shq_node *nodes, int64_t firstnode, orc
         *nint_out = nint;
     return 0;
 }
+
+/* ---- black-hole velocity dispersion: blackhole_veldisp(), veldisp2.cpp:164-199 --------------------------------------
+ * BHVelDispLocalTreeWalk::ngbiter (:126-144) over the dark-matter tree, DM_VelPred (density2.h:104-111), postprocess
+ * (:49-63).  out[q][5] = NumDM, V1sumDM[3], V2sumDM for the q-th black hole of `queue`; vdisp[q] as BHP().VDisp would
+ * be set (left untouched where the reference leaves it).  No reference fixture ("parity unpinned"): a dozen lines, checked
+ * against brute-force sums in tests/test_oracle_cpu.py. */
+extern "C" void orc_bh_veldisp(const shq_node *nodes, int64_t firstnode, const orc_sph_arrays *a, const int32_t *queue, int64_t nqueue,
+                               double BoxSize, const shq_kick_factors *kf, double *out, double *vdisp)
+{
+    const shq_node *N = nodes - firstnode;
+#pragma omp parallel for schedule(dynamic, 4)
+    for(int64_t q = 0; q < nqueue; q++) {
+        const int64_t i = queue[q];
+        const double *Pos = &a->pos[3 * i];
+        const double Hsml = a->hsml[i];
+        double num = 0, v1[3] = {0, 0, 0}, v2 = 0;
+        int64_t no = firstnode;
+        while(no >= 0) {
+            const shq_node *c = &N[no];
+            if(0 == cull_node(Pos, BoxSize, Hsml, c, false)) {
+                no = c->sibling;
+                continue;
+            }
+            const unsigned ct = SHQ_NODE_CHILDTYPE(c->flags);
+            if(ct == SHQ_PARTICLE_NODE_TYPE) {
+                for(int s = 0; s < c->noccupied; s++) {
+                    const int64_t other = c->suns[s];
+                    if(is_garbage(a, other) || !((1 << a->type[other]) & 2)) /* DMMASK */
+                        continue;
+                    double r2 = 0;
+                    for(int d = 0; d < 3; d++) {
+                        const double dd = orc_nearest(Pos[d] - a->pos[3 * other + d], BoxSize);
+                        r2 += dd * dd;
+                    }
+                    if(r2 <= 0 || !(r2 < Hsml * Hsml))
+                        continue;
+                    num += 1;
+                    for(int d = 0; d < 3; d++) {
+                        const double vp = a->vel[3 * other + d] + kf->gravkicks[a->bin_grav[other]] * a->treeacc[3 * other + d] +
+                                          a->gravpm[3 * other + d] * kf->FgravkickB;
+                        const double vel = vp - a->vel[3 * i + d];
+                        v1[d] += vel;
+                        v2 += vel * vel;
+                    }
+                }
+                no = c->sibling;
+                continue;
+            } else if(ct == SHQ_PSEUDO_NODE_TYPE) {
+                no = c->sibling;
+                continue;
+            }
+            no = c->suns[0];
+        }
+        out[5 * q] = num;
+        out[5 * q + 1] = v1[0];
+        out[5 * q + 2] = v1[1];
+        out[5 * q + 3] = v1[2];
+        out[5 * q + 4] = v2;
+        if(num > 0) {
+            double vd = v2 / num;
+            for(int d = 0; d < 3; d++)
+                vd -= pow(v1[d] / num, 2);
+            if(vd > 0)
+                vdisp[q] = sqrt(vd / 3);
+        }
+    }
+}

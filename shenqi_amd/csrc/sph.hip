@@ -1885,6 +1885,105 @@ int shq_sph_stellar_density_device(shq_context *ctx, const shq_stellar_params *p
     return SHQ_OK;
 }
 
+/* ---- black-hole velocity dispersion: veldisp2.cpp:20-199 ----------------------------------------
+ * BHVelDispLocalTreeWalk::ngbiter (:126-144): over the dark matter inside a black hole's Hsml, the count and the first and
+ * second moments of the predicted DM velocity (KickFactorData::DM_VelPred, density2.h:104-111) relative to the hole's;
+ * BHVelDispOutput::postprocess (:49-63) turns them into VDisp.  Same fused walk as the other neighbour operators; the tree is
+ * the caller's dark-matter tree. */
+struct BhVdArgs {
+    const double4 *vel_leaf;  /* predicted DM velocity by leaf slot */
+    const double *vel;        /* [N][3] raw velocities (the hole's own) */
+    double *out;              /* [nq][5]: NumDM, V1sumDM[3], V2sumDM, by queue position */
+};
+
+__global__ __launch_bounds__(256) void bh_veldisp_kernel(const SphDev a, const int32_t *queue, long long nq, const BhVdArgs ba,
+                                                         int32_t *__restrict__ nlist, long long ntasks)
+{
+    __shared__ __attribute__((aligned(32))) char lds[4 * NW_LDS_PER_WAVE(false)];
+    const int lane = threadIdx.x & 63;
+    for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
+    const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    const long long t = wave * 64 + lane;
+    const bool valid = t < nq;
+    double px = 0, py = 0, pz = 0, h = 1, vx = 0, vy = 0, vz = 0;
+    if(valid) {
+        const long long pi = queue[t];
+        const double4 p = a.posm[pi];
+        px = p.x; py = p.y; pz = p.z;
+        h = a.hsml[pi];
+        vx = ba.vel[3 * pi]; vy = ba.vel[3 * pi + 1]; vz = ba.vel[3 * pi + 2];
+    }
+    const double h2 = h * h;
+    double num = 0, s0 = 0, s1 = 0, s2 = 0, v2 = 0;
+    auto pair = [&](const int s) {
+        const double4 w = ba.vel_leaf[s];
+        num += 1;
+        const double e0 = w.x - vx, e1 = w.y - vy, e2 = w.z - vz;
+        s0 += e0; v2 += e0 * e0;
+        s1 += e1; v2 += e1 * e1;
+        s2 += e2; v2 += e2 * e2;
+    };
+    auto accept = [&](const double r2, const double, const int) { return r2 > 0 && r2 < h2; };
+    int fill = 0;
+    bool ovf = false;
+    (void) ngb_walk<false, false, false>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(false), myl, valid, px, py, pz, h, accept, pair,
+                                         (unsigned int *) nullptr, fill, ovf);
+    if(valid) {
+        ba.out[5 * t] = num;
+        ba.out[5 * t + 1] = s0;
+        ba.out[5 * t + 2] = s1;
+        ba.out[5 * t + 3] = s2;
+        ba.out[5 * t + 4] = v2;
+    }
+    } /* task loop */
+}
+
+/* neighbour-side arrays of the DM tree in leaf order: DM_VelPred and the skip flag (garbage / not dark matter any more) */
+__global__ void bh_veldisp_gather_kernel(long long nleaf, const int32_t *__restrict__ pidx, const double *__restrict__ vel,
+                                         const double *__restrict__ treeacc, const double *__restrict__ gravpm, const uint8_t *__restrict__ bin_grav,
+                                         const uint8_t *__restrict__ pflags, shq_kick_factors kf, int typemask, double4 *vel_leaf, int32_t *flag_leaf)
+{
+#pragma clang fp contract(off)
+    const long long s = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(s >= nleaf)
+        return;
+    const long long p = pidx[s];
+    double v[3];
+    for(int j = 0; j < 3; j++)
+        v[j] = vel[3 * p + j] + kf.gravkicks[bin_grav[p]] * treeacc[3 * p + j] + gravpm[3 * p + j] * kf.FgravkickB;
+    vel_leaf[s] = make_double4(v[0], v[1], v[2], 0.0);
+    const unsigned f = pflags[p];
+    flag_leaf[s] = ((f & 1u) || !((1 << (f >> 4)) & typemask)) ? 1 : 0;
+}
+
+int shq_bh_veldisp_device(shq_context *ctx, const shq_kick_factors *kf, double BoxSize, const int32_t *d_queue, int64_t nq, double *d_out)
+{
+    if(nq == 0)
+        return SHQ_OK;
+    const long long nl = ctx->ntreeparts + SHQ_NMAXCHILD;
+    SHQ_TRY(ctx->velp_leaf.reserve(nl));
+    SHQ_TRY(ctx->flag_leaf.reserve(nl));
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    hipStream_t st = ctx->stream;
+    bh_veldisp_gather_kernel<<<dim3(nblk(nl)), dim3(256), 0, st>>>(nl, ctx->leaf_pidx.ptr, ctx->vel.ptr, ctx->treeacc.ptr, ctx->gravpm.ptr,
+                                                                  ctx->bin_grav.ptr, ctx->pflags.ptr, *kf, 1 << 1, ctx->velp_leaf.ptr,
+                                                                  ctx->flag_leaf.ptr);
+    SHQ_HIP(hipGetLastError());
+    SphDev a = make_dev(ctx);
+    a.Box = BoxSize;
+    a.invBox = 1.0 / BoxSize;
+    BhVdArgs ba;
+    ba.vel_leaf = ctx->velp_leaf.ptr;
+    ba.vel = ctx->vel.ptr;
+    ba.out = d_out;
+    const long long ntasks = (nq + 255) / 256;
+    const unsigned grid = (unsigned) (ntasks < NL_REDO_BLOCKS ? ntasks : NL_REDO_BLOCKS);
+    bh_veldisp_kernel<<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, ba, ctx->s_nlist2.ptr, ntasks);
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}
+
 int shq_sph_gradrho_mag(shq_context *ctx, double *d_out)
 {
     const long long n = ctx->numpart;

@@ -691,3 +691,68 @@ extern "C" int shq_stellar_density(shq_context *ctx, const shq_tree_view *tree, 
     }
     return SHQ_OK;
 }
+
+extern "C" int shq_bh_veldisp(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const int32_t *active, int64_t nactive,
+                              const shq_kick_factors *kf, double *NumDM, double (*V1sumDM)[3], double *V2sumDM, double *VDisp)
+{
+    SHQ_CHECK(ctx && tree && parts && kf && VDisp, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->sphrun.phase == 0, SHQ_ERR_STATE, "bh_veldisp: an SPH walk is open");
+    SHQ_CHECK(parts->off_vel != SHQ_NOFIELD && parts->off_hsml != SHQ_NOFIELD && parts->off_pi != SHQ_NOFIELD &&
+                  parts->off_type != SHQ_NOFIELD && parts->off_treeacc != SHQ_NOFIELD && parts->off_gravpm != SHQ_NOFIELD,
+              SHQ_ERR_INVALID, "bh_veldisp: the particle view needs Vel, Hsml, PI, Type, FullTreeGravAccel and GravPM");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t n = parts->numpart;
+    std::vector<int32_t> queue;
+    const int64_t nloop = active ? nactive : n;
+    for(int64_t k = 0; k < nloop; k++) {
+        const int32_t i = active ? active[k] : (int32_t) k;
+        SHQ_CHECK(i >= 0 && i < n, SHQ_ERR_INVALID, "bh_veldisp: active[%ld] = %d out of range", (long) k, i);
+        if(parts->off_flags != SHQ_NOFIELD && (*pfield<uint32_t>(parts, i, parts->off_flags) & 3u))
+            continue;
+        if(*pfield<uint8_t>(parts, i, parts->off_type) == 5) {
+            SHQ_CHECK(*pfield<double>(parts, i, parts->off_hsml) > 0, SHQ_ERR_INVALID, "bh_veldisp: black hole %d has Hsml <= 0", i);
+            queue.push_back(i);
+        }
+    }
+    SHQ_TRY(shq_particles_upload(ctx, parts));
+    SHQ_TRY(shq_dynamics_upload(ctx, parts));
+    SHQ_TRY(shq_tree_upload(ctx, tree));
+    const int64_t nq = (int64_t) queue.size();
+    if(nq == 0)
+        return SHQ_OK;
+    DevBuf<double> dout;
+    std::vector<double> hout(5 * (size_t) nq);
+    auto run = [&]() -> int {
+        SHQ_TRY(ctx->s_queue0.reserve((size_t) nq));
+        SHQ_TRY(dout.reserve(5 * (size_t) nq));
+        SHQ_HIP(hipMemcpyAsync(ctx->s_queue0.ptr, queue.data(), sizeof(int32_t) * nq, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_TRY(shq_bh_veldisp_device(ctx, kf, tree->BoxSize, ctx->s_queue0.ptr, nq, dout.ptr));
+        SHQ_HIP(hipMemcpyAsync(hout.data(), dout.ptr, sizeof(double) * 5 * nq, hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+        return SHQ_OK;
+    };
+    const int rc = run();
+    (void) hipStreamSynchronize(ctx->stream);
+    dout.release();
+    SHQ_TRY(rc);
+    for(int64_t q = 0; q < nq; q++) {
+        const int32_t pi = *pfield<int32_t>(parts, queue[q], parts->off_pi);
+        SHQ_CHECK(pi >= 0, SHQ_ERR_INVALID, "bh_veldisp: black hole %d has a negative slot index", queue[q]);
+        const double num = hout[5 * q], *v1 = &hout[5 * q + 1], v2 = hout[5 * q + 4];
+        if(NumDM)
+            NumDM[pi] = num;
+        if(V1sumDM)
+            for(int d = 0; d < 3; d++)
+                V1sumDM[pi][d] = v1[d];
+        if(V2sumDM)
+            V2sumDM[pi] = v2;
+        if(num > 0) { /* BHVelDispOutput::postprocess, veldisp2.cpp:49-63 */
+            double vdisp = v2 / num;
+            for(int d = 0; d < 3; d++)
+                vdisp -= pow(v1[d] / num, 2);
+            if(vdisp > 0)
+                VDisp[pi] = sqrt(vdisp / 3);
+        }
+    }
+    return SHQ_OK;
+}

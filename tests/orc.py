@@ -62,6 +62,17 @@ def stellar_density(nodes, firstnode, st, queue, BoxSize, DesNumNgb, MaxNgbDevia
     return rc, vol, niter.value, nint.value
 
 
+def bh_veldisp(nodes, firstnode, st, queue, BoxSize, kf):
+    """blackhole_veldisp() (veldisp2.cpp:164-199): (sums [nq, 5], vdisp [nq], NaN where the reference leaves VDisp alone)."""
+    q = np.ascontiguousarray(queue, dtype=np.int32)
+    out = np.zeros((len(q), 5))
+    vd = np.full(len(q), np.nan)
+    lib.orc_bh_veldisp.argtypes = [_vp, C.c_int64, C.POINTER(OrcSphArrays), _vp, C.c_int64, C.c_double, _vp, _vp, _vp]
+    lib.orc_bh_veldisp.restype = None
+    lib.orc_bh_veldisp(ptr(nodes), firstnode, C.byref(st.c), ptr(q), len(q), BoxSize, C.byref(kf), ptr(out), ptr(vd))
+    return out, vd
+
+
 class SphState:
     """SoA copy of the particle / slot state the oracle's SPH functions work on."""
 

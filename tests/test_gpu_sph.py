@@ -203,3 +203,28 @@ def test_stellar_density_matches_oracle(ctx, kernel, weighting):
     P["Hsml"][ng] = 0
     assert capi.hip.shq_stellar_density(ctx.h, C.byref(tv), C.byref(pv), C.byref(sv), capi.ptr(queue), len(queue), C.byref(sp), capi.ptr(vol),
                                         None) != 0
+
+
+def test_bh_veldisp_matches_oracle(ctx):
+    """shq_bh_veldisp (veldisp2.cpp:20-199) against the oracle: neighbour counts as integers, moments and VDisp to rounding,
+    outputs placed by black-hole slot, an active list that skips some holes, swallowed holes ignored."""
+    import test_oracle_cpu as toc
+    pman, kf, nd, nbh = toc._bhs_in_dm(n1=16, nbh=150, seed=9)
+    P = pman.Base
+    P["Flags"][nd + 3] = 2                                   # a swallowed black hole has no work
+    tree = sq.force_tree_rebuild_mask(pman, sq.DMMASK)
+    st = orc.SphState(P, np.zeros(1, dtype=sq.SPH_DTYPE))
+    act = np.arange(nd - 10, nd + nbh - 20, dtype=np.int32)  # some DM (no work), most of the holes
+    work = np.array([i for i in act if P["Type"][i] == 5 and not (P["Flags"][i] & 3)], dtype=np.int32)
+    out, vd = orc.bh_veldisp(tree.Nodes_base, tree.firstnode, st, work, cm.BOX, kf)
+    num = np.full(nbh, -1.0); v1 = np.full((nbh, 3), np.nan); v2 = np.full(nbh, np.nan); vdisp = np.full(nbh, -7.0)
+    pv, tv = pman.view(), tree.view()
+    capi.check(capi.hip.shq_bh_veldisp(ctx.h, C.byref(tv), C.byref(pv), capi.ptr(act), len(act), C.byref(kf), capi.ptr(num), capi.ptr(v1),
+                                       capi.ptr(v2), capi.ptr(vdisp)))
+    slots = P["PI"][work]
+    assert np.array_equal(num[slots], out[:, 0]) and out[:, 0].min() > 0
+    assert np.abs(v1[slots] - out[:, 1:4]).max() < 1e-10 * np.abs(out[:, 1:4]).max()
+    assert np.abs(v2[slots] / out[:, 4] - 1).max() < 1e-12
+    assert np.abs(vdisp[slots] / vd - 1).max() < 1e-10
+    untouched = np.setdiff1d(np.arange(nbh), slots)
+    assert len(untouched) > 0 and np.all(num[untouched] == -1.0) and np.all(vdisp[untouched] == -7.0)

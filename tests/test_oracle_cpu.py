@@ -386,3 +386,52 @@ def test_stellar_density_oracle_against_brute_force():
                 v += P["Mass"][j] / SphP["Density"][j] * (wk if weighting else 1.0)
             assert abs(ngb - des) <= 2.0 + 1e-9, (i, ngb)
             assert abs(v - vol[i]) <= 1e-9 * max(v, 1e-300), (i, v, vol[i])
+
+
+def _bhs_in_dm(n1=14, nbh=60, seed=6):
+    """Dark matter with random velocities and accelerations plus a few black holes; one DM particle is garbage."""
+    import shenqi_amd as sq
+    rng = np.random.default_rng(seed)
+    nd = n1**3
+    pos = np.concatenate([rng.random((nd, 3)) * cm.BOX, rng.random((nbh, 3)) * cm.BOX])
+    pman = sq.PartManager(nd + nbh, cm.BOX)
+    P = pman.Base
+    P["Pos"] = pos
+    P["Mass"] = 1.0
+    P["Type"][:nd] = 1
+    P["Type"][nd:] = 5
+    P["PI"][nd:] = np.arange(nbh)[::-1]               # slots in another order than the particles
+    P["Hsml"] = cm.BOX / n1 * rng.uniform(1.5, 3.5, size=nd + nbh)
+    P["Vel"] = rng.normal(size=(nd + nbh, 3)) * 100.0
+    P["FullTreeGravAccel"] = rng.normal(size=(nd + nbh, 3)) * 1e3
+    P["GravPM"] = rng.normal(size=(nd + nbh, 3)) * 1e2
+    P["TimeBinGravity"] = rng.integers(20, 24, size=nd + nbh).astype(np.uint8)
+    P["Flags"][5] = 1
+    kf = sq.KickFactors()
+    kf.FgravkickB = 3e-3
+    for b in range(20, 24):
+        kf.gravkicks[b] = 1e-3 * (b - 18)
+    return pman, kf, nd, nbh
+
+
+def test_bh_veldisp_oracle_against_brute_force():
+    import shenqi_amd as sq
+    pman, kf, nd, nbh = _bhs_in_dm()
+    P = pman.Base
+    tree = sq.force_tree_rebuild_mask(pman, sq.DMMASK)
+    st = orc.SphState(P, np.zeros(1, dtype=sq.SPH_DTYPE))
+    queue = np.arange(nd, nd + nbh, dtype=np.int32)
+    out, vd = orc.bh_veldisp(tree.Nodes_base, tree.firstnode, st, queue, cm.BOX, kf)
+    gk = np.array([kf.gravkicks[b] for b in P["TimeBinGravity"][:nd]])
+    vp = P["Vel"][:nd] + gk[:, None] * P["FullTreeGravAccel"][:nd] + P["GravPM"][:nd] * kf.FgravkickB
+    for q, i in enumerate(queue):
+        d = P["Pos"][:nd] - P["Pos"][i]
+        d -= cm.BOX * np.rint(d / cm.BOX)
+        r2 = np.sum(d * d, axis=1)
+        sel = (r2 > 0) & (r2 < P["Hsml"][i] ** 2) & (P["Flags"][:nd] == 0)
+        rel = vp[sel] - P["Vel"][i]
+        assert out[q, 0] == sel.sum() > 0
+        assert np.allclose(out[q, 1:4], rel.sum(axis=0), rtol=1e-11, atol=1e-9)
+        assert np.isclose(out[q, 4], (rel * rel).sum(), rtol=1e-12)
+        var = (rel * rel).sum() / sel.sum() - np.sum((rel.sum(axis=0) / sel.sum()) ** 2)
+        assert np.isclose(vd[q], np.sqrt(var / 3), rtol=1e-10)
