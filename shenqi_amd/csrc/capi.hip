@@ -56,6 +56,20 @@ template <typename T> inline T *field_w(const shq_part_view *v, int64_t i, size_
     return reinterpret_cast<T *>(static_cast<char *>(v->base) + (size_t) i * v->elsize + off);
 }
 
+/* the split streams of the SPH walks (centre + len, links) and of shq_tree_download, cut from the merged walk records */
+__global__ void split_nodeG_kernel(const NodeG *__restrict__ g, long long n, NodeA *A, NodeB *B, NodeC *Cc)
+{
+    const long long j = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= n)
+        return;
+    const NodeG x = g[j];
+    NodeA a; NodeB b; NodeC c;
+    a.cofm[0] = x.cofm[0]; a.cofm[1] = x.cofm[1]; a.cofm[2] = x.cofm[2]; a.mass = x.mass;
+    b.center[0] = x.center[0]; b.center[1] = x.center[1]; b.center[2] = x.center[2]; b.len = x.len;
+    c.sibling = x.sibling; c.child = x.child; c.type = x.type; c.count = x.count;
+    A[j] = a; B[j] = b; Cc[j] = c;
+}
+
 __global__ void gather_leaf_kernel(const double4 *posm, const int32_t *pidx, double4 *out, long long n)
 {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -245,38 +259,73 @@ extern "C" int shq_particles_upload(shq_context *ctx, const shq_part_view *parts
     SHQ_TRY(ctx->nint.reserve(cap));
     SHQ_TRY(ctx->pflags.reserve(cap));
 
-    std::vector<double4> h_posm(cap);
-    std::vector<double> h_tree(3 * cap, 0.0), h_pm(3 * cap, 0.0);
-    std::vector<uint8_t> h_flags(cap, 0);
-    std::vector<double> partial_mass(64, 0.0);
+    /* AoS -> SoA into pinned staging, chunk by chunk, each chunk copied while the next is packed */
+    const int64_t CH = 1 << 21;
+    const size_t rec = sizeof(double4) + 6 * sizeof(double) + 1;
+    SHQ_TRY(ctx->stage.reserve(2 * (size_t) CH * rec + 256));
     std::atomic<int> bad(0);
-    parallel_for(n, [&](int64_t lo, int64_t hi) {
-        for(int64_t i = lo; i < hi; i++) {
-            const double *pos = field<double>(parts, i, parts->off_pos);
-            const float m = *field<float>(parts, i, parts->off_mass);
-            h_posm[i] = make_double4(pos[0], pos[1], pos[2], (double) m);
-            if(!(isfinite(pos[0]) && isfinite(pos[1]) && isfinite(pos[2]) && isfinite(m)))
-                bad.store(1);
-            if(parts->off_treeacc != SHQ_NOFIELD) {
-                const double *a = field<double>(parts, i, parts->off_treeacc);
-                h_tree[3 * i] = a[0]; h_tree[3 * i + 1] = a[1]; h_tree[3 * i + 2] = a[2];
-            }
-            if(parts->off_gravpm != SHQ_NOFIELD) {
-                const double *a = field<double>(parts, i, parts->off_gravpm);
-                h_pm[3 * i] = a[0]; h_pm[3 * i + 1] = a[1]; h_pm[3 * i + 2] = a[2];
-            }
-            uint8_t fl = 0;
-            if(parts->off_flags != SHQ_NOFIELD)
-                fl |= (uint8_t) (*field<uint32_t>(parts, i, parts->off_flags) & 3u);
-            if(parts->off_type != SHQ_NOFIELD)
-                fl |= (uint8_t) ((*field<uint8_t>(parts, i, parts->off_type) & 0xf) << 4);
-            h_flags[i] = fl;
-        }
-    });
-    SHQ_CHECK(bad.load() == 0, SHQ_ERR_INVALID, "non-finite particle position or mass");
     double msum = 0;
-    for(int64_t i = 0; i < n; i++)
-        msum += fabs(h_posm[i].w);
+    hipEvent_t ev[2] = {ctx->ev_begin[SHQ_NTIMERS - 2], ctx->ev_end[SHQ_NTIMERS - 2]};
+    int nchunk = 0;
+    for(int64_t c0 = 0; c0 < n; c0 += CH, nchunk++) {
+        const int64_t m = std::min<int64_t>(CH, n - c0);
+        const int sl = nchunk & 1;
+        char *base = static_cast<char *>(ctx->stage.ptr) + (size_t) sl * CH * rec;
+        double4 *h_posm = reinterpret_cast<double4 *>(base);
+        double *h_tree = reinterpret_cast<double *>(base + (size_t) CH * sizeof(double4));
+        double *h_pm = h_tree + 3 * CH;
+        uint8_t *h_flags = reinterpret_cast<uint8_t *>(h_pm + 3 * CH);
+        if(nchunk >= 2)
+            SHQ_HIP(hipEventSynchronize(ev[sl])); /* the copies that read this half of the staging buffer are done */
+        std::vector<double> part(64, 0.0);
+        std::atomic<int> slot(0);
+        parallel_for(m, [&](int64_t lo, int64_t hi) {
+            double ms = 0;
+            for(int64_t k = lo; k < hi; k++) {
+                const int64_t i = c0 + k;
+                const double *pos = field<double>(parts, i, parts->off_pos);
+                const float mf = *field<float>(parts, i, parts->off_mass);
+                h_posm[k] = make_double4(pos[0], pos[1], pos[2], (double) mf);
+                ms += fabs((double) mf);
+                if(!(isfinite(pos[0]) && isfinite(pos[1]) && isfinite(pos[2]) && isfinite(mf)))
+                    bad.store(1);
+                double t0 = 0, t1 = 0, t2 = 0, g0 = 0, g1 = 0, g2 = 0;
+                if(parts->off_treeacc != SHQ_NOFIELD) {
+                    const double *a = field<double>(parts, i, parts->off_treeacc);
+                    t0 = a[0]; t1 = a[1]; t2 = a[2];
+                }
+                if(parts->off_gravpm != SHQ_NOFIELD) {
+                    const double *a = field<double>(parts, i, parts->off_gravpm);
+                    g0 = a[0]; g1 = a[1]; g2 = a[2];
+                }
+                h_tree[3 * k] = t0; h_tree[3 * k + 1] = t1; h_tree[3 * k + 2] = t2;
+                h_pm[3 * k] = g0; h_pm[3 * k + 1] = g1; h_pm[3 * k + 2] = g2;
+                uint8_t fl = 0;
+                if(parts->off_flags != SHQ_NOFIELD)
+                    fl |= (uint8_t) (*field<uint32_t>(parts, i, parts->off_flags) & 3u);
+                if(parts->off_type != SHQ_NOFIELD)
+                    fl |= (uint8_t) ((*field<uint8_t>(parts, i, parts->off_type) & 0xf) << 4);
+                h_flags[k] = fl;
+            }
+            part[slot.fetch_add(1) & 63] += ms; /* at most 32 workers: one slot each */
+        });
+        for(double x : part)
+            msum += x;
+        SHQ_HIP(hipMemcpyAsync(ctx->posm.ptr + c0, h_posm, sizeof(double4) * m, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(ctx->treeacc.ptr + 3 * c0, h_tree, sizeof(double) * 3 * m, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(ctx->gravpm.ptr + 3 * c0, h_pm, sizeof(double) * 3 * m, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(ctx->pflags.ptr + c0, h_flags, (size_t) m, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipEventRecord(ev[sl], ctx->stream));
+    }
+    if(n > 0) {
+        SHQ_HIP(hipMemsetAsync(ctx->oldacc.ptr, 0, sizeof(double) * n, ctx->stream));
+        SHQ_HIP(hipMemsetAsync(ctx->pmpot.ptr, 0, sizeof(double) * n, ctx->stream));
+        SHQ_HIP(hipMemsetAsync(ctx->acc.ptr, 0, sizeof(double) * 3 * n, ctx->stream));
+        SHQ_HIP(hipMemsetAsync(ctx->pot.ptr, 0, sizeof(double) * n, ctx->stream));
+        SHQ_HIP(hipMemsetAsync(ctx->nint.ptr, 0, sizeof(int32_t) * n, ctx->stream));
+    }
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    SHQ_CHECK(bad.load() == 0, SHQ_ERR_INVALID, "non-finite particle position or mass");
     ctx->mass_sum = msum;
     if(ctx->pm_log2scale_user >= 0)
         ctx->pm_log2scale = ctx->pm_log2scale_user;
@@ -285,18 +334,6 @@ extern "C" int shq_particles_upload(shq_context *ctx, const shq_part_view *parts
         (void) frexp(msum > 0 ? msum : 1.0, &ex); /* msum < 2^ex */
         ctx->pm_log2scale = 61 - ex;
     }
-    if(n > 0) {
-        SHQ_HIP(hipMemcpyAsync(ctx->posm.ptr, h_posm.data(), sizeof(double4) * n, hipMemcpyHostToDevice, ctx->stream));
-        SHQ_HIP(hipMemcpyAsync(ctx->treeacc.ptr, h_tree.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
-        SHQ_HIP(hipMemcpyAsync(ctx->gravpm.ptr, h_pm.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
-        SHQ_HIP(hipMemcpyAsync(ctx->pflags.ptr, h_flags.data(), n, hipMemcpyHostToDevice, ctx->stream));
-        SHQ_HIP(hipMemsetAsync(ctx->oldacc.ptr, 0, sizeof(double) * n, ctx->stream));
-        SHQ_HIP(hipMemsetAsync(ctx->pmpot.ptr, 0, sizeof(double) * n, ctx->stream));
-        SHQ_HIP(hipMemsetAsync(ctx->acc.ptr, 0, sizeof(double) * 3 * n, ctx->stream));
-        SHQ_HIP(hipMemsetAsync(ctx->pot.ptr, 0, sizeof(double) * n, ctx->stream));
-        SHQ_HIP(hipMemsetAsync(ctx->nint.ptr, 0, sizeof(int32_t) * n, ctx->stream));
-    }
-    SHQ_HIP(hipStreamSynchronize(ctx->stream)); /* host vectors die here */
     ctx->numpart = n;
     ctx->nlocal = 0;
     ctx->have_parts = true;
@@ -326,146 +363,256 @@ extern "C" int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree)
      * (open -> suns[0], otherwise -> sibling; forcetree.cpp:1016-1103 sets both).  The device
      * pool is stored in this order so that the record after the current one is almost always
      * the next one visited. */
+    /* The threaded walk is one long chain of dependent loads (7e6 nodes x ~60 ns).  It is cut into independent pieces: the
+     * nodes of the top levels are listed sequentially, every subtree hanging below them is traversed by its own host thread
+     * (from its root until the walk reaches the root's sibling), and the pieces are stitched together in pre-order. */
     std::vector<int32_t> order;
-    order.reserve((size_t) nall);
     std::vector<int32_t> newidx((size_t) nall, -1);
+    std::vector<int64_t> pstart; /* leaf slot offsets: exclusive prefix sum of noccupied over leaves in pre-order */
     {
-        int64_t no = tree->rootnode;
-        while(no >= fn && no < fn + nall) {
-            const int64_t i = no - fn;
-            SHQ_CHECK(newidx[i] < 0, SHQ_ERR_INVALID, "tree threading revisits node %ld (cycle)", (long) no);
-            newidx[i] = (int32_t) order.size();
-            order.push_back((int32_t) i);
-            const shq_node &s = src[i];
-            if(SHQ_NODE_CHILDTYPE(s.flags) == SHQ_NODE_NODE_TYPE && s.suns[0] >= fn && s.suns[0] < fn + nall)
-                no = s.suns[0];
-            else
-                no = s.sibling;
+        auto valid = [&](int64_t no) { return no >= fn && no < fn + nall; };
+        auto internal = [&](int64_t no) {
+            const shq_node &s = src[no - fn];
+            return SHQ_NODE_CHILDTYPE(s.flags) == SHQ_NODE_NODE_TYPE && valid(s.suns[0]);
+        };
+        struct Seg { int64_t node; bool expand; int64_t size, leafparts; };
+        std::vector<Seg> segs;
+        /* pieces of about 1/512 of the tree each, judged by node mass: a fixed depth gives a handful of huge pieces and
+         * a million tiny ones in a clustered tree */
+        const double heavy = fabs(src[tree->rootnode - fn].mass) / 512.0;
+        const int DEPTH = 40;
+        {
+            /* explicit stack of (node, depth); children of P: the sibling chain from suns[0] up to P.sibling */
+            std::vector<std::pair<int64_t, int>> stack;
+            stack.push_back({tree->rootnode, 0});
+            int64_t guard = 0;
+            while(!stack.empty()) {
+                const auto [no, depth] = stack.back();
+                stack.pop_back();
+                SHQ_CHECK(++guard <= nall, SHQ_ERR_INVALID, "tree threading does not terminate (cycle near the root)");
+                if(depth >= DEPTH || !internal(no) || !(fabs(src[no - fn].mass) > heavy)) {
+                    segs.push_back({no, internal(no), 1, 0});
+                    continue;
+                }
+                segs.push_back({no, false, 1, 0});
+                const shq_node &P = src[no - fn];
+                int64_t kids[9];
+                int nk = 0;
+                for(int64_t c = P.suns[0]; valid(c) && c != P.sibling && nk <= 8; c = src[c - fn].sibling)
+                    kids[nk++] = c;
+                SHQ_CHECK(nk <= 8, SHQ_ERR_INVALID, "node %ld has more than 8 children in its sibling chain", (long) no);
+                for(int q = nk - 1; q >= 0; q--)
+                    stack.push_back({kids[q], depth + 1});
+            }
         }
-    }
-    const int64_t nn = (int64_t) order.size();
-    std::vector<NodeA> hA(nn + 1);
-    std::vector<NodeB> hB(nn + 1);
-    std::vector<NodeC> hC(nn + 1);
-    /* leaf slot offsets: exclusive prefix sum of noccupied over leaves in pre-order */
-    std::vector<int64_t> pstart(nn + 1, 0);
-    for(int64_t j = 0; j < nn; j++) {
-        const shq_node &s = src[order[j]];
-        int cnt = 0;
-        if(SHQ_NODE_CHILDTYPE(s.flags) == SHQ_PARTICLE_NODE_TYPE) {
-            cnt = s.noccupied;
-            SHQ_CHECK(cnt >= 0 && cnt <= SHQ_NMAXCHILD, SHQ_ERR_INVALID, "leaf node %ld has noccupied = %d", (long) (order[j] + fn), cnt);
-        }
-        pstart[j + 1] = pstart[j] + cnt;
-    }
-    const int64_t nleafparts = pstart[nn];
-    SHQ_CHECK(nleafparts < (1ll << 31) - 16, SHQ_ERR_INVALID, "too many leaf particles");
-    std::vector<int32_t> pidx((size_t) nleafparts + SHQ_NMAXCHILD, 0); /* padded: the walk fetches 4 slots at a time */
-    std::atomic<int> bad(0);
-    const int64_t np = ctx->numpart;
-    parallel_for(nn, [&](int64_t lo, int64_t hi) {
-        for(int64_t j = lo; j < hi; j++) {
-            const shq_node &s = src[order[j]];
-            NodeA a; NodeB b; NodeC c;
-            a.cofm[0] = s.cofm[0]; a.cofm[1] = s.cofm[1]; a.cofm[2] = s.cofm[2]; a.mass = s.mass;
-            b.center[0] = s.center[0]; b.center[1] = s.center[1]; b.center[2] = s.center[2]; b.len = s.len;
-            const int64_t sib = s.sibling;
-            c.sibling = (sib >= fn && sib < fn + nall) ? newidx[sib - fn] : -1;
-            c.type = (int32_t) SHQ_NODE_CHILDTYPE(s.flags);
-            c.count = 0;
-            c.child = -1;
-            if(c.type == SHQ_PARTICLE_NODE_TYPE) {
-                const int cnt = (int) (pstart[j + 1] - pstart[j]);
-                c.count = cnt;
-                c.child = (int32_t) pstart[j];
-                for(int k = 0; k < cnt; k++) {
-                    const int32_t p = s.suns[k];
-                    if(p < 0 || p >= np) {
-                        bad.store(1);
+        const int64_t nseg = (int64_t) segs.size();
+        std::atomic<int> bad_tree(0);
+        auto leaf_count = [&](const shq_node &s, int &cnt) {
+            cnt = 0;
+            if(SHQ_NODE_CHILDTYPE(s.flags) == SHQ_PARTICLE_NODE_TYPE) {
+                cnt = s.noccupied;
+                if(cnt < 0 || cnt > SHQ_NMAXCHILD)
+                    bad_tree.store(2);
+            }
+        };
+        auto run_threads = [&](auto &&fn_) {
+            unsigned nt = std::thread::hardware_concurrency();
+            nt = nt == 0 ? 1 : (nt > 32 ? 32 : nt);
+            std::vector<std::thread> th;
+            for(unsigned t = 1; t < nt; t++)
+                th.emplace_back(fn_);
+            fn_();
+            for(auto &x : th)
+                x.join();
+        };
+        /* pass 1: the size of every piece (nothing is stored: no allocation per piece) */
+        std::atomic<int64_t> next_seg(0);
+        run_threads([&]() {
+            for(;;) {
+                const int64_t k = next_seg.fetch_add(1);
+                if(k >= nseg)
+                    break;
+                Seg &sg = segs[k];
+                int cnt;
+                if(!sg.expand) {
+                    leaf_count(src[sg.node - fn], cnt);
+                    sg.size = 1;
+                    sg.leafparts = cnt;
+                    continue;
+                }
+                const int64_t end = src[sg.node - fn].sibling;
+                int64_t no = sg.node, lp = 0, sz = 0;
+                while(valid(no) && no != end) {
+                    if(++sz > nall) { /* cannot happen in a tree: a cycle */
+                        bad_tree.store(1);
                         break;
                     }
-                    pidx[pstart[j] + k] = p;
+                    const shq_node &sn = src[no - fn];
+                    leaf_count(sn, cnt);
+                    lp += cnt;
+                    no = internal(no) ? sn.suns[0] : sn.sibling;
                 }
-            } else if(c.type == SHQ_NODE_NODE_TYPE) {
-                const int64_t ch = s.suns[0];
-                c.child = (ch >= fn && ch < fn + nall) ? newidx[ch - fn] : -1;
-                if(c.child < 0)
-                    c.type = SHQ_PSEUDO_NODE_TYPE; /* never descend into an invalid link */
+                sg.size = sz;
+                sg.leafparts = lp;
             }
-            hA[j] = a; hB[j] = b; hC[j] = c;
+        });
+        SHQ_CHECK(bad_tree.load() != 1, SHQ_ERR_INVALID, "tree threading revisits a node (cycle)");
+        SHQ_CHECK(bad_tree.load() != 2, SHQ_ERR_INVALID, "a leaf node has noccupied outside [0, %d]", SHQ_NMAXCHILD);
+        std::vector<int64_t> off((size_t) nseg + 1, 0), loff((size_t) nseg + 1, 0);
+        for(int64_t k = 0; k < nseg; k++) {
+            off[k + 1] = off[k] + segs[k].size;
+            loff[k + 1] = loff[k] + segs[k].leafparts;
         }
-    });
-    SHQ_CHECK(bad.load() == 0, SHQ_ERR_INVALID, "tree leaf refers to a particle index outside [0, numpart)");
-    /* pad record: speculative fetch of pool[cur + 1] at the last node */
-    memset(&hA[nn], 0, sizeof(NodeA));
-    memset(&hB[nn], 0, sizeof(NodeB));
-    hC[nn].sibling = -1; hC[nn].child = -1; hC[nn].type = SHQ_PSEUDO_NODE_TYPE; hC[nn].count = 0;
+        const int64_t total = off[nseg];
+        SHQ_CHECK(total <= nall, SHQ_ERR_INVALID, "tree threading visits %ld nodes, the tree has %ld (a node is reached twice)", (long) total, (long) nall);
+        order.resize((size_t) total);
+        pstart.resize((size_t) total + 1);
+        /* pass 2: the same traversals again, writing at the pieces' offsets */
+        std::atomic<int> twice(0);
+        next_seg.store(0);
+        run_threads([&]() {
+            for(;;) {
+                const int64_t k = next_seg.fetch_add(1);
+                if(k >= nseg)
+                    break;
+                const Seg &sg = segs[k];
+                const int64_t end = sg.expand ? (int64_t) src[sg.node - fn].sibling : -3;
+                int64_t no = sg.node, lp = loff[k];
+                for(int64_t j = off[k]; j < off[k + 1]; j++) {
+                    const shq_node &sn = src[no - fn];
+                    int cnt;
+                    leaf_count(sn, cnt);
+                    order[j] = (int32_t) (no - fn);
+                    if(newidx[no - fn] != -1)
+                        twice.store(1);
+                    newidx[no - fn] = (int32_t) j;
+                    pstart[j] = lp;
+                    lp += cnt;
+                    no = internal(no) ? sn.suns[0] : sn.sibling;
+                    (void) end;
+                }
+            }
+        });
+        pstart[total] = loff[nseg];
+        SHQ_CHECK(twice.load() == 0, SHQ_ERR_INVALID, "tree threading revisits a node (cycle)");
+    }
+    const int64_t nn = (int64_t) order.size();
+    const int64_t nleafparts = pstart[nn];
+    SHQ_CHECK(nleafparts < (1ll << 31) - 16, SHQ_ERR_INVALID, "too many leaf particles");
+    const int64_t npad = nleafparts + SHQ_NMAXCHILD; /* padded: the walk fetches several slots at a time */
+    const int64_t np = ctx->numpart;
     SHQ_TRY(ctx->nodeA.reserve(nn + 1));
     SHQ_TRY(ctx->nodeB.reserve(nn + 1));
     SHQ_TRY(ctx->nodeC.reserve(nn + 1));
-    SHQ_TRY(ctx->leaf_pidx.reserve(pidx.size()));
-    SHQ_TRY(ctx->posm_leaf.reserve(pidx.size()));
-    SHQ_HIP(hipMemcpyAsync(ctx->nodeA.ptr, hA.data(), sizeof(NodeA) * (nn + 1), hipMemcpyHostToDevice, ctx->stream));
-    SHQ_HIP(hipMemcpyAsync(ctx->nodeB.ptr, hB.data(), sizeof(NodeB) * (nn + 1), hipMemcpyHostToDevice, ctx->stream));
-    SHQ_HIP(hipMemcpyAsync(ctx->nodeC.ptr, hC.data(), sizeof(NodeC) * (nn + 1), hipMemcpyHostToDevice, ctx->stream));
-    std::vector<NodeG> hG(nn + 1);
-    parallel_for(nn + 1, [&](int64_t lo, int64_t hi) {
-        for(int64_t j = lo; j < hi; j++) {
-            NodeG g;
-            memset(&g, 0, sizeof(g));
-            for(int k = 0; k < 3; k++) {
-                g.cofm[k] = hA[j].cofm[k];
-                g.center[k] = hB[j].center[k];
-            }
-            g.mass = hA[j].mass;
-            g.len = hB[j].len;
-            g.sibling = hC[j].sibling; g.child = hC[j].child; g.type = hC[j].type; g.count = hC[j].count;
-            g.bhlim = 0; /* filled per walk, like rcuthl */
-            g.mlen2 = g.mass * g.len * g.len; /* (mass * len) * len, as shall_we_open_node evaluates it */
-            g.inside = 0.6 * g.len;
-            g.halflen = 0.5 * g.len;
-            g.wraplim = 0.5 * tree->BoxSize - g.halflen;
-            hG[j] = g;
-        }
-    });
     SHQ_TRY(ctx->nodeG.reserve(nn + 1));
-    SHQ_HIP(hipMemcpyAsync(ctx->nodeG.ptr, hG.data(), sizeof(NodeG) * (nn + 1), hipMemcpyHostToDevice, ctx->stream));
-    SHQ_HIP(hipStreamSynchronize(ctx->stream));
-    {
-        const int64_t npad = (int64_t) pidx.size();
-        SHQ_HIP(hipMemcpyAsync(ctx->leaf_pidx.ptr, pidx.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice, ctx->stream));
-        if(np > 0) {
-            const int threads = 256;
-            gather_leaf_kernel<<<dim3((unsigned) ((npad + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-                ctx->posm.ptr, ctx->leaf_pidx.ptr, ctx->posm_leaf.ptr, npad);
-            SHQ_HIP(hipGetLastError());
-        } else
-            SHQ_HIP(hipMemsetAsync(ctx->posm_leaf.ptr, 0, sizeof(double4) * npad, ctx->stream));
-    }
-    /* SPH extras: mom.hmax per node and the leaf holding each particle (ForceTree.Father) */
-    {
-        std::vector<double> hH(nn + 1, 0.0);
-        for(int64_t j = 0; j < nn; j++)
-            hH[j] = src[order[j]].hmax;
-        SHQ_TRY(ctx->node_hmax.reserve(nn + 1));
-        SHQ_HIP(hipMemcpyAsync(ctx->node_hmax.ptr, hH.data(), sizeof(double) * (nn + 1), hipMemcpyHostToDevice, ctx->stream));
-        ctx->have_father = false;
-        if(tree->father && np > 0) {
-            std::vector<int32_t> pf((size_t) np, -1);
-            for(int64_t i = 0; i < np; i++) {
-                const int64_t f = tree->father[i];
-                if(f >= fn && f < fn + nall)
-                    pf[i] = newidx[f - fn];
+    SHQ_TRY(ctx->node_hmax.reserve(nn + 1));
+    SHQ_TRY(ctx->leaf_pidx.reserve((size_t) npad));
+    SHQ_TRY(ctx->posm_leaf.reserve((size_t) npad));
+    /* Pack the merged 128-byte walk records (plus hmax and the leaves' particle indices) straight into pinned staging,
+     * a chunk of nodes at a time, each chunk copied while the next is packed; the split A / B / C streams of the SPH
+     * walks are cut from the merged records on the device. */
+    const int64_t CH = 1 << 20;
+    const size_t chunk_bytes = (size_t) CH * (sizeof(NodeG) + sizeof(double) + SHQ_NMAXCHILD * sizeof(int32_t));
+    SHQ_TRY(ctx->stage.reserve(2 * chunk_bytes + 256));
+    std::atomic<int> bad(0);
+    hipEvent_t ev[2] = {ctx->ev_begin[SHQ_NTIMERS - 2], ctx->ev_end[SHQ_NTIMERS - 2]};
+    int nchunk = 0;
+    for(int64_t c0 = 0; c0 < nn + 1; c0 += CH, nchunk++) {
+        const int64_t m = std::min<int64_t>(CH, nn + 1 - c0);
+        const int sl = nchunk & 1;
+        char *base = ctx->stage.ptr + (size_t) sl * chunk_bytes;
+        NodeG *hG = reinterpret_cast<NodeG *>(base);
+        double *hH = reinterpret_cast<double *>(base + (size_t) CH * sizeof(NodeG));
+        int32_t *hP = reinterpret_cast<int32_t *>(hH + CH);
+        const int64_t p0 = pstart[c0], p1 = pstart[std::min<int64_t>(c0 + m, nn)];
+        if(nchunk >= 2)
+            SHQ_HIP(hipEventSynchronize(ev[sl]));
+        parallel_for(m, [&](int64_t lo, int64_t hi) {
+            for(int64_t k = lo; k < hi; k++) {
+                const int64_t j = c0 + k;
+                NodeG g;
+                memset(&g, 0, sizeof(g));
+                if(j == nn) { /* pad record: speculative fetch of pool[cur + 1] at the last node */
+                    g.sibling = -1; g.child = -1; g.type = SHQ_PSEUDO_NODE_TYPE; g.count = 0;
+                    g.wraplim = 0.5 * tree->BoxSize;
+                    hG[k] = g;
+                    hH[k] = 0;
+                    continue;
+                }
+                const shq_node &sn = src[order[j]];
+                for(int d = 0; d < 3; d++) {
+                    g.cofm[d] = sn.cofm[d];
+                    g.center[d] = sn.center[d];
+                }
+                g.mass = sn.mass;
+                g.len = sn.len;
+                const int64_t sib = sn.sibling;
+                g.sibling = (sib >= fn && sib < fn + nall) ? newidx[sib - fn] : -1;
+                g.type = (int32_t) SHQ_NODE_CHILDTYPE(sn.flags);
+                g.count = 0;
+                g.child = -1;
+                if(g.type == SHQ_PARTICLE_NODE_TYPE) {
+                    const int cnt = (int) (pstart[j + 1] - pstart[j]);
+                    g.count = cnt;
+                    g.child = (int32_t) pstart[j];
+                    for(int c = 0; c < cnt; c++) {
+                        const int32_t pp = sn.suns[c];
+                        if(pp < 0 || pp >= np) {
+                            bad.store(1);
+                            break;
+                        }
+                        hP[pstart[j] - p0 + c] = pp;
+                    }
+                } else if(g.type == SHQ_NODE_NODE_TYPE) {
+                    const int64_t ch = sn.suns[0];
+                    g.child = (ch >= fn && ch < fn + nall) ? newidx[ch - fn] : -1;
+                    if(g.child < 0)
+                        g.type = SHQ_PSEUDO_NODE_TYPE; /* never descend into an invalid link */
+                }
+                g.bhlim = 0; /* filled per walk, like rcuthl */
+                g.mlen2 = g.mass * g.len * g.len; /* (mass * len) * len, as shall_we_open_node evaluates it */
+                g.inside = 0.6 * g.len;
+                g.halflen = 0.5 * g.len;
+                g.wraplim = 0.5 * tree->BoxSize - g.halflen;
+                hG[k] = g;
+                hH[k] = sn.hmax;
             }
-            SHQ_TRY(ctx->pfather.reserve((size_t) np));
-            SHQ_HIP(hipMemcpyAsync(ctx->pfather.ptr, pf.data(), sizeof(int32_t) * np, hipMemcpyHostToDevice, ctx->stream));
-            SHQ_HIP(hipStreamSynchronize(ctx->stream));
-            ctx->have_father = true;
-        }
-        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+        });
+        SHQ_HIP(hipMemcpyAsync(ctx->nodeG.ptr + c0, hG, sizeof(NodeG) * m, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(ctx->node_hmax.ptr + c0, hH, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
+        if(p1 > p0)
+            SHQ_HIP(hipMemcpyAsync(ctx->leaf_pidx.ptr + p0, hP, sizeof(int32_t) * (p1 - p0), hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipEventRecord(ev[sl], ctx->stream));
     }
-    ctx->node_order = order;
-    ctx->node_rank = newidx;
+    SHQ_HIP(hipMemsetAsync(ctx->leaf_pidx.ptr + nleafparts, 0, sizeof(int32_t) * SHQ_NMAXCHILD, ctx->stream));
+    split_nodeG_kernel<<<dim3((unsigned) ((nn + 1 + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->nodeG.ptr, nn + 1, ctx->nodeA.ptr, ctx->nodeB.ptr,
+                                                                                           ctx->nodeC.ptr);
+    if(np > 0)
+        gather_leaf_kernel<<<dim3((unsigned) ((npad + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->posm.ptr, ctx->leaf_pidx.ptr, ctx->posm_leaf.ptr,
+                                                                                           npad);
+    else
+        SHQ_HIP(hipMemsetAsync(ctx->posm_leaf.ptr, 0, sizeof(double4) * npad, ctx->stream));
+    SHQ_HIP(hipGetLastError());
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    SHQ_CHECK(bad.load() == 0, SHQ_ERR_INVALID, "tree leaf refers to a particle index outside [0, numpart)");
+    /* SPH extra: the leaf holding each particle (ForceTree.Father) */
+    ctx->have_father = false;
+    if(tree->father && np > 0) {
+        SHQ_TRY(ctx->pfather.reserve((size_t) np));
+        SHQ_TRY(ctx->stage.reserve(sizeof(int32_t) * (size_t) np));
+        int32_t *pf = reinterpret_cast<int32_t *>(ctx->stage.ptr);
+        parallel_for(np, [&](int64_t lo, int64_t hi) {
+            for(int64_t i = lo; i < hi; i++) {
+                const int64_t f = tree->father[i];
+                pf[i] = (f >= fn && f < fn + nall) ? newidx[f - fn] : -1;
+            }
+        });
+        SHQ_HIP(hipMemcpyAsync(ctx->pfather.ptr, pf, sizeof(int32_t) * np, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->have_father = true;
+    }
+    ctx->node_order = std::move(order);
+    ctx->node_rank = std::move(newidx);
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     ctx->numnodes = nn;
     ctx->firstnode = fn;
