@@ -2,6 +2,8 @@
 #include "common.hpp"
 #include <string.h>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 
 namespace {
 
@@ -40,54 +42,90 @@ int sph_upload(shq_context *ctx, const shq_part_view *parts, const shq_sph_view 
                   parts->off_type != SHQ_NOFIELD, SHQ_ERR_INVALID, "SPH needs Hsml, Vel, PI and Type in the particle view");
     SHQ_CHECK(sph && (sph->numslots == 0 || sph->base), SHQ_ERR_INVALID, "SPH slot view is NULL");
     const int64_t n = parts->numpart;
-    std::vector<double> hsml(n), vel(3 * n), entropy(n, 0.0), dtentropy(n, 0.0), hacc(3 * n, 0.0), delay(n, 0.0);
-    std::vector<double> density(n, 0.0), egywt(n, 0.0), dhsml(n, 0.0), divvel(n, 0.0), curl(n, 0.0);
-    std::vector<uint8_t> bg(n, 0), bh(n, 0);
-    int bad = 0;
-    for(int64_t i = 0; i < n; i++) {
-        hsml[i] = *pfield<double>(parts, i, parts->off_hsml);
-        const double *v = pfield<double>(parts, i, parts->off_vel);
-        vel[3 * i] = v[0]; vel[3 * i + 1] = v[1]; vel[3 * i + 2] = v[2];
-        if(parts->off_timebin_gravity != SHQ_NOFIELD)
-            bg[i] = *pfield<uint8_t>(parts, i, parts->off_timebin_gravity);
-        if(parts->off_timebin_hydro != SHQ_NOFIELD)
-            bh[i] = *pfield<uint8_t>(parts, i, parts->off_timebin_hydro);
-        if(bg[i] > SHQ_TIMEBINS || bh[i] > SHQ_TIMEBINS)
-            bad = 1;
-        if(*pfield<uint8_t>(parts, i, parts->off_type) == 0) {
-            const int32_t pi = *pfield<int32_t>(parts, i, parts->off_pi);
-            if(pi < 0 || pi >= sph->numslots) {
-                bad = 2;
-                continue;
+    /* one parallel pass into pinned staging (15 doubles + 2 bytes per particle), then one copy per array */
+    const size_t cap = (size_t) std::max<int64_t>(n, 1);
+    SHQ_TRY(ctx->stage.reserve(cap * (15 * sizeof(double) + 2) + 256));
+    double *hsml = reinterpret_cast<double *>(ctx->stage.ptr);
+    double *vel = hsml + cap, *entropy = vel + 3 * cap, *dtentropy = entropy + cap, *hacc = dtentropy + cap, *delay = hacc + 3 * cap;
+    double *density = delay + cap, *egywt = density + cap, *dhsml = egywt + cap, *divvel = dhsml + cap, *curl = divvel + cap;
+    uint8_t *bg = reinterpret_cast<uint8_t *>(curl + cap), *bh = bg + cap;
+    std::atomic<int> bad(0);
+    {
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = nt == 0 ? 1 : (nt > 32 ? 32 : nt);
+        if(n < 65536)
+            nt = 1;
+        const int64_t chunk = (n + nt - 1) / nt;
+        auto work = [&](int64_t lo, int64_t hi) {
+            for(int64_t i = lo; i < hi; i++) {
+                hsml[i] = *pfield<double>(parts, i, parts->off_hsml);
+                const double *v = pfield<double>(parts, i, parts->off_vel);
+                vel[3 * i] = v[0]; vel[3 * i + 1] = v[1]; vel[3 * i + 2] = v[2];
+                bg[i] = parts->off_timebin_gravity != SHQ_NOFIELD ? *pfield<uint8_t>(parts, i, parts->off_timebin_gravity) : 0;
+                bh[i] = parts->off_timebin_hydro != SHQ_NOFIELD ? *pfield<uint8_t>(parts, i, parts->off_timebin_hydro) : 0;
+                if(bg[i] > SHQ_TIMEBINS || bh[i] > SHQ_TIMEBINS)
+                    bad.store(1);
+                double e = 0, de = 0, h0 = 0, h1 = 0, h2 = 0, dl = 0, rho = 0, eg = 0, dh = 0, dv = 0, cv = 0;
+                if(*pfield<uint8_t>(parts, i, parts->off_type) == 0) {
+                    const int32_t pi = *pfield<int32_t>(parts, i, parts->off_pi);
+                    if(pi < 0 || pi >= sph->numslots)
+                        bad.store(2);
+                    else {
+                        e = *sfield(sph, pi, sph->off_entropy);
+                        de = *sfield(sph, pi, sph->off_dtentropy);
+                        const double *ha = sfield(sph, pi, sph->off_hydroaccel);
+                        h0 = ha[0]; h1 = ha[1]; h2 = ha[2];
+                        if(sph->off_delaytime != SHQ_NOFIELD)
+                            dl = *sfield(sph, pi, sph->off_delaytime);
+                        rho = *sfield(sph, pi, sph->off_density);
+                        eg = *sfield(sph, pi, sph->off_egywtdensity);
+                        dh = *sfield(sph, pi, sph->off_dhsmlegydensityfactor);
+                        dv = *sfield(sph, pi, sph->off_divvel);
+                        cv = *sfield(sph, pi, sph->off_curlvel);
+                    }
+                }
+                entropy[i] = e; dtentropy[i] = de;
+                hacc[3 * i] = h0; hacc[3 * i + 1] = h1; hacc[3 * i + 2] = h2;
+                delay[i] = dl; density[i] = rho; egywt[i] = eg; dhsml[i] = dh; divvel[i] = dv; curl[i] = cv;
             }
-            entropy[i] = *sfield(sph, pi, sph->off_entropy);
-            dtentropy[i] = *sfield(sph, pi, sph->off_dtentropy);
-            const double *ha = sfield(sph, pi, sph->off_hydroaccel);
-            hacc[3 * i] = ha[0]; hacc[3 * i + 1] = ha[1]; hacc[3 * i + 2] = ha[2];
-            if(sph->off_delaytime != SHQ_NOFIELD)
-                delay[i] = *sfield(sph, pi, sph->off_delaytime);
-            density[i] = *sfield(sph, pi, sph->off_density);
-            egywt[i] = *sfield(sph, pi, sph->off_egywtdensity);
-            dhsml[i] = *sfield(sph, pi, sph->off_dhsmlegydensityfactor);
-            divvel[i] = *sfield(sph, pi, sph->off_divvel);
-            curl[i] = *sfield(sph, pi, sph->off_curlvel);
+        };
+        std::vector<std::thread> th;
+        for(unsigned t = 1; t < nt; t++) {
+            const int64_t lo = (int64_t) t * chunk, hi = std::min(n, lo + chunk);
+            if(lo < hi)
+                th.emplace_back(work, lo, hi);
         }
+        work(0, std::min(n, chunk));
+        for(auto &x : th)
+            x.join();
     }
-    SHQ_CHECK(bad != 1, SHQ_ERR_INVALID, "time bin out of range (TIMEBINS = %d)", SHQ_TIMEBINS);
-    SHQ_CHECK(bad != 2, SHQ_ERR_INVALID, "gas particle with PI outside the SPH slot array");
-    SHQ_TRY(up(ctx, ctx->hsml, hsml));
-    SHQ_TRY(up(ctx, ctx->vel, vel));
-    SHQ_TRY(up(ctx, ctx->bin_grav, bg));
-    SHQ_TRY(up(ctx, ctx->bin_hydro, bh));
-    SHQ_TRY(up(ctx, ctx->g_entropy, entropy));
-    SHQ_TRY(up(ctx, ctx->g_dtentropy, dtentropy));
-    SHQ_TRY(up(ctx, ctx->g_hydroaccel, hacc));
-    SHQ_TRY(up(ctx, ctx->g_delaytime, delay));
-    SHQ_TRY(up(ctx, ctx->g_density, density));
-    SHQ_TRY(up(ctx, ctx->g_egywt, egywt));
-    SHQ_TRY(up(ctx, ctx->g_dhsmlegy, dhsml));
-    SHQ_TRY(up(ctx, ctx->g_divvel, divvel));
-    SHQ_TRY(up(ctx, ctx->g_curlvel, curl));
+    SHQ_CHECK(bad.load() != 1, SHQ_ERR_INVALID, "time bin out of range (TIMEBINS = %d)", SHQ_TIMEBINS);
+    SHQ_CHECK(bad.load() != 2, SHQ_ERR_INVALID, "gas particle with PI outside the SPH slot array");
+    auto upd = [&](DevBuf<double> &b, const double *h, size_t cnt) -> int {
+        SHQ_TRY(b.reserve(std::max<size_t>(cnt, 1)));
+        if(cnt > 0)
+            SHQ_HIP(hipMemcpyAsync(b.ptr, h, sizeof(double) * cnt, hipMemcpyHostToDevice, ctx->stream));
+        return SHQ_OK;
+    };
+    auto upb = [&](DevBuf<uint8_t> &b, const uint8_t *h, size_t cnt) -> int {
+        SHQ_TRY(b.reserve(std::max<size_t>(cnt, 1)));
+        if(cnt > 0)
+            SHQ_HIP(hipMemcpyAsync(b.ptr, h, cnt, hipMemcpyHostToDevice, ctx->stream));
+        return SHQ_OK;
+    };
+    SHQ_TRY(upd(ctx->hsml, hsml, n));
+    SHQ_TRY(upd(ctx->vel, vel, 3 * n));
+    SHQ_TRY(upb(ctx->bin_grav, bg, n));
+    SHQ_TRY(upb(ctx->bin_hydro, bh, n));
+    SHQ_TRY(upd(ctx->g_entropy, entropy, n));
+    SHQ_TRY(upd(ctx->g_dtentropy, dtentropy, n));
+    SHQ_TRY(upd(ctx->g_hydroaccel, hacc, 3 * n));
+    SHQ_TRY(upd(ctx->g_delaytime, delay, n));
+    SHQ_TRY(upd(ctx->g_density, density, n));
+    SHQ_TRY(upd(ctx->g_egywt, egywt, n));
+    SHQ_TRY(upd(ctx->g_dhsmlegy, dhsml, n));
+    SHQ_TRY(upd(ctx->g_divvel, divvel, n));
+    SHQ_TRY(upd(ctx->g_curlvel, curl, n));
     SHQ_TRY(ctx->dthsml.reserve(std::max<int64_t>(n, 1)));
     if(n > 0)
         SHQ_HIP(hipMemsetAsync(ctx->dthsml.ptr, 0, sizeof(double) * n, ctx->stream));
@@ -190,23 +228,34 @@ extern "C" int shq_density_close(shq_context *ctx, shq_node *nodes_rw, const shq
     const std::vector<int32_t> &queue = run_queue(ctx);
     /* results back into the caller's arrays: only the walked targets are assigned
      * (reduce<PRIMARY>, localtreewalk2.h:39) */
-    std::vector<double> hsml, dthsml, density, egywt, dhsml, divvel, curl, gmag;
-    std::vector<double4> velp;
-    SHQ_TRY(down(ctx, ctx->hsml, hsml, n));
-    SHQ_TRY(down(ctx, ctx->dthsml, dthsml, n));
-    SHQ_TRY(down(ctx, ctx->g_density, density, n));
-    SHQ_TRY(down(ctx, ctx->g_egywt, egywt, n));
-    SHQ_TRY(down(ctx, ctx->g_dhsmlegy, dhsml, n));
-    SHQ_TRY(down(ctx, ctx->g_divvel, divvel, n));
-    SHQ_TRY(down(ctx, ctx->g_curlvel, curl, n));
-    SHQ_TRY(down(ctx, ctx->velp, velp, n));
+    /* D2H into pinned staging */
+    const size_t cap = (size_t) std::max<int64_t>(n, 1);
+    const size_t nnodes = (size_t) std::max<int64_t>(ctx->numnodes, 1);
+    SHQ_TRY(ctx->stage.reserve(cap * (8 * sizeof(double) + sizeof(double4)) + nnodes * sizeof(double) + 256));
+    double *hsml = reinterpret_cast<double *>(ctx->stage.ptr);
+    double *dthsml = hsml + cap, *density = dthsml + cap, *egywt = density + cap, *dhsml = egywt + cap, *divvel = dhsml + cap,
+           *curl = divvel + cap, *gmag = curl + cap;
+    double4 *velp = reinterpret_cast<double4 *>(gmag + cap);
+    double *hmax = reinterpret_cast<double *>(velp + cap);
+    auto dn = [&](void *dst, const void *src, size_t bytes) -> int {
+        if(bytes > 0)
+            SHQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return SHQ_OK;
+    };
+    SHQ_TRY(dn(hsml, ctx->hsml.ptr, sizeof(double) * n));
+    SHQ_TRY(dn(dthsml, ctx->dthsml.ptr, sizeof(double) * n));
+    SHQ_TRY(dn(density, ctx->g_density.ptr, sizeof(double) * n));
+    SHQ_TRY(dn(egywt, ctx->g_egywt.ptr, sizeof(double) * n));
+    SHQ_TRY(dn(dhsml, ctx->g_dhsmlegy.ptr, sizeof(double) * n));
+    SHQ_TRY(dn(divvel, ctx->g_divvel.ptr, sizeof(double) * n));
+    SHQ_TRY(dn(curl, ctx->g_curlvel.ptr, sizeof(double) * n));
+    SHQ_TRY(dn(velp, ctx->velp.ptr, sizeof(double4) * n));
     if(GradRho_mag) {
-        SHQ_TRY(ctx->s_evp_in.reserve((size_t) std::max<int64_t>(n, 1)));
+        SHQ_TRY(ctx->s_evp_in.reserve(cap));
         SHQ_TRY(shq_sph_gradrho_mag(ctx, ctx->s_evp_in.ptr));
-        SHQ_TRY(down(ctx, ctx->s_evp_in, gmag, n));
+        SHQ_TRY(dn(gmag, ctx->s_evp_in.ptr, sizeof(double) * n));
     }
-    std::vector<double> hmax;
-    SHQ_TRY(down(ctx, ctx->node_hmax, hmax, ctx->numnodes));
+    SHQ_TRY(dn(hmax, ctx->node_hmax.ptr, sizeof(double) * (size_t) ctx->numnodes));
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     for(int32_t i : queue) {
         *pfield_w<double>(parts, i, parts->off_hsml) = hsml[i];
@@ -334,10 +383,14 @@ extern "C" int shq_hydro_close(shq_context *ctx, const shq_part_view *parts, con
     SHQ_CHECK(n == ctx->numpart, SHQ_ERR_INVALID, "hydro_close: not the particle array of hydro_open");
     SHQ_TRY(shq_sph_hydro_end(ctx, stats));
     const std::vector<int32_t> &queue = run_queue(ctx);
-    std::vector<double> hacc, dtent, maxsig;
-    SHQ_TRY(down(ctx, ctx->g_hydroaccel_out, hacc, 3 * n));
-    SHQ_TRY(down(ctx, ctx->g_dtentropy_out, dtent, n));
-    SHQ_TRY(down(ctx, ctx->g_maxsignalvel, maxsig, n));
+    const size_t cap = (size_t) std::max<int64_t>(n, 1);
+    SHQ_TRY(ctx->stage.reserve(cap * 5 * sizeof(double) + 256));
+    double *hacc = reinterpret_cast<double *>(ctx->stage.ptr), *dtent = hacc + 3 * cap, *maxsig = dtent + cap;
+    if(n > 0) {
+        SHQ_HIP(hipMemcpyAsync(hacc, ctx->g_hydroaccel_out.ptr, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(dtent, ctx->g_dtentropy_out.ptr, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(maxsig, ctx->g_maxsignalvel.ptr, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    }
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     for(int32_t i : queue) {
         const int32_t pi = *pfield<int32_t>(parts, i, parts->off_pi);
