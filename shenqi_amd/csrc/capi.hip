@@ -70,6 +70,20 @@ __global__ void split_nodeG_kernel(const NodeG *__restrict__ g, long long n, Nod
     A[j] = a; B[j] = b; Cc[j] = c;
 }
 
+/* rows (Acc[3], Potential) of an active list's targets, for the one-shot call's download */
+__global__ void gather_rows_kernel(long long nt, const int32_t *__restrict__ targets, const double *__restrict__ acc, const double *__restrict__ pot,
+                                   double *out)
+{
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= nt)
+        return;
+    const long long i = targets[t];
+    out[4 * t] = acc[3 * i];
+    out[4 * t + 1] = acc[3 * i + 1];
+    out[4 * t + 2] = acc[3 * i + 2];
+    out[4 * t + 3] = pot[i];
+}
+
 __global__ void gather_leaf_kernel(const double4 *posm, const int32_t *pidx, double4 *out, long long n)
 {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -935,24 +949,67 @@ extern "C" int shq_grav_short_tree(shq_context *ctx, const shq_tree_view *tree, 
     SHQ_TRY(shq_tree_upload(ctx, tree));
     SHQ_TRY(shq_grav_refresh_oldacc(ctx, params->G));
     SHQ_TRY(shq_grav_short_run(ctx, params, active, nactive, update_potential, walk_mode));
+    SHQ_TRY(shq_grav_short_download(ctx, nullptr, nullptr, nullptr, stats));
+    /* results back: only the walked targets are assigned (reduce<PRIMARY>, localtreewalk2.h:39).  With an active list the
+     * targets' rows are gathered on the device first; then chunks of rows come down into pinned staging, each scattered into the
+     * caller's arrays by the host threads while the next one is in flight. */
     const int64_t n = parts->numpart;
-    std::vector<double> h_acc((size_t) std::max<int64_t>(3 * n, 1)), h_pot((size_t) std::max<int64_t>(n, 1));
-    SHQ_TRY(shq_grav_short_download(ctx, (double (*)[3]) h_acc.data(), update_potential ? h_pot.data() : nullptr, nullptr, stats));
-    /* reduce<PRIMARY> assigns only the walked targets (localtreewalk2.h:39) */
     const int64_t nt = active ? nactive : n;
-    for(int64_t t = 0; t < nt; t++) {
-        const int64_t i = active ? active[t] : t;
-        accel[i][0] = h_acc[3 * i];
-        accel[i][1] = h_acc[3 * i + 1];
-        accel[i][2] = h_acc[3 * i + 2];
-        if(update_potential) {
-            if(parts->off_treeacc != SHQ_NOFIELD) {
-                double *a = field_w<double>(parts, i, parts->off_treeacc);
-                a[0] = h_acc[3 * i]; a[1] = h_acc[3 * i + 1]; a[2] = h_acc[3 * i + 2];
+    const double *d_acc = ctx->acc.ptr, *d_pot = ctx->pot.ptr;
+    if(active && nt > 0) {
+        SHQ_TRY(ctx->gq_res.reserve((size_t) nt)); /* 32 bytes per row: Acc[3], Potential */
+        gather_rows_kernel<<<dim3((unsigned) ((nt + 255) / 256)), dim3(256), 0, ctx->stream>>>(nt, ctx->active.ptr, ctx->acc.ptr, ctx->pot.ptr,
+                                                                                          reinterpret_cast<double *>(ctx->gq_res.ptr));
+        SHQ_HIP(hipGetLastError());
+    }
+    const int64_t CH = 1 << 21;
+    SHQ_TRY(ctx->stage.reserve(2 * (size_t) CH * 32 + 256));
+    hipEvent_t ev[2] = {ctx->ev_begin[SHQ_NTIMERS - 2], ctx->ev_end[SHQ_NTIMERS - 2]};
+    auto scatter = [&](int64_t c0, int64_t m, const char *base) {
+        const double *rows = reinterpret_cast<const double *>(base);          /* active: [m][4]; else acc [m][3] then pot [m] */
+        const double *pots = rows + 3 * CH;
+        parallel_for(m, [&](int64_t lo, int64_t hi) {
+            for(int64_t k = lo; k < hi; k++) {
+                const int64_t i = active ? active[c0 + k] : c0 + k;
+                const double *r = active ? rows + 4 * k : rows + 3 * k;
+                const double p = active ? r[3] : pots[k];
+                accel[i][0] = r[0]; accel[i][1] = r[1]; accel[i][2] = r[2];
+                if(update_potential) {
+                    if(parts->off_treeacc != SHQ_NOFIELD) {
+                        double *a = field_w<double>(parts, i, parts->off_treeacc);
+                        a[0] = r[0]; a[1] = r[1]; a[2] = r[2];
+                    }
+                    if(parts->off_potential != SHQ_NOFIELD)
+                        *field_w<double>(parts, i, parts->off_potential) = p;
+                }
             }
-            if(parts->off_potential != SHQ_NOFIELD)
-                *field_w<double>(parts, i, parts->off_potential) = h_pot[i];
+        });
+    };
+    int64_t prev_c0 = -1, prev_m = 0;
+    int nchunk = 0;
+    for(int64_t c0 = 0; c0 < nt; c0 += CH, nchunk++) {
+        const int64_t m = std::min<int64_t>(CH, nt - c0);
+        const int sl = nchunk & 1;
+        char *base = ctx->stage.ptr + (size_t) sl * CH * 32;
+        if(active)
+            SHQ_HIP(hipMemcpyAsync(base, reinterpret_cast<const double *>(ctx->gq_res.ptr) + 4 * c0, 32 * (size_t) m, hipMemcpyDeviceToHost, ctx->stream));
+        else {
+            SHQ_HIP(hipMemcpyAsync(base, d_acc + 3 * c0, 24 * (size_t) m, hipMemcpyDeviceToHost, ctx->stream));
+            if(update_potential)
+                SHQ_HIP(hipMemcpyAsync(base + 24 * (size_t) CH, d_pot + c0, 8 * (size_t) m, hipMemcpyDeviceToHost, ctx->stream));
         }
+        SHQ_HIP(hipEventRecord(ev[sl], ctx->stream));
+        if(prev_c0 >= 0) /* the previous chunk has landed in the other half: scatter it while this one is in flight */
+        {
+            SHQ_HIP(hipEventSynchronize(ev[sl ^ 1]));
+            scatter(prev_c0, prev_m, ctx->stage.ptr + (size_t) (sl ^ 1) * CH * 32);
+        }
+        prev_c0 = c0;
+        prev_m = m;
+    }
+    if(prev_c0 >= 0) {
+        SHQ_HIP(hipEventSynchronize(ev[(nchunk - 1) & 1]));
+        scatter(prev_c0, prev_m, ctx->stage.ptr + (size_t) ((nchunk - 1) & 1) * CH * 32);
     }
     return SHQ_OK;
 }

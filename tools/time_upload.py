@@ -33,3 +33,15 @@ for it in range(3):
     t2 = time.perf_counter()
     print("pass %d: particles_upload %.1f ms (%.1f GB/s of the 160-byte records), tree_upload %.1f ms" %
           (it, 1e3 * (t1 - t0), 160.0 * n / (t1 - t0) / 1e9, 1e3 * (t2 - t1)), flush=True)
+
+# the whole one-shot call (hand-over both ways + kernels)
+sq.set_gravshort_treepar(ErrTolForceAcc=0.005, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=1, Rcut=6.0)
+sq.gravshort_set_softenings(L / n1)
+gp = sq.make_grav_params(L, 1.5, 3 * n1, 43.0071, 1.0)
+acc = np.zeros((n, 3))
+for it in range(2):
+    t0 = time.perf_counter()
+    st = sq.WalkStats()
+    capi.check(capi.hip.shq_grav_short_tree(ctx.h, C.byref(tv), C.byref(pv), None, 0, C.byref(gp), capi.ptr(acc), 1, 0, C.byref(st)))
+    t1 = time.perf_counter()
+    print("one-shot shq_grav_short_tree (BH walk): %.1f ms wall, kernel %.1f ms" % (1e3 * (t1 - t0), st.kernel_ms), flush=True)
