@@ -1062,12 +1062,43 @@ extern "C" int shq_pm_force(shq_context *ctx, const shq_pm_params *pm, const shq
     SHQ_CHECK(ctx && pm && parts && gravpm, SHQ_ERR_INVALID, "null argument");
     SHQ_TRY(shq_particles_upload(ctx, parts));
     SHQ_TRY(shq_pm_run(ctx, pm));
+    /* GravPM (assigned) and the PM potential (added: readout_potential adds, gravpm.cpp:489-491) come down through pinned
+     * staging in chunks; the host threads move each chunk into the caller's arrays while the next one is in flight */
+    SHQ_TRY(shq_join_pm(ctx));
     const int64_t n = parts->numpart;
-    std::vector<double> h_pot((size_t) std::max<int64_t>(n, 1));
-    SHQ_TRY(shq_pm_download(ctx, gravpm, potential ? h_pot.data() : nullptr));
-    if(potential)
-        for(int64_t i = 0; i < n; i++)
-            potential[i] += h_pot[i]; /* readout_potential adds, gravpm.cpp:489-491 */
+    const int64_t CH = 1 << 21;
+    SHQ_TRY(ctx->stage.reserve(2 * (size_t) CH * 32 + 256));
+    hipEvent_t ev[2] = {ctx->ev_begin[SHQ_NTIMERS - 2], ctx->ev_end[SHQ_NTIMERS - 2]};
+    auto land = [&](int64_t c0, int64_t m, const char *base) {
+        const double *g = reinterpret_cast<const double *>(base), *pp = g + 3 * CH;
+        parallel_for(m, [&](int64_t lo, int64_t hi) {
+            memcpy(&gravpm[c0 + lo][0], g + 3 * lo, sizeof(double) * 3 * (size_t) (hi - lo));
+            if(potential)
+                for(int64_t k = lo; k < hi; k++)
+                    potential[c0 + k] += pp[k];
+        });
+    };
+    int64_t prev_c0 = -1, prev_m = 0;
+    int nchunk = 0;
+    for(int64_t c0 = 0; c0 < n; c0 += CH, nchunk++) {
+        const int64_t m = std::min<int64_t>(CH, n - c0);
+        const int sl = nchunk & 1;
+        char *base = ctx->stage.ptr + (size_t) sl * CH * 32;
+        SHQ_HIP(hipMemcpyAsync(base, ctx->gravpm.ptr + 3 * c0, 24 * (size_t) m, hipMemcpyDeviceToHost, ctx->stream));
+        if(potential)
+            SHQ_HIP(hipMemcpyAsync(base + 24 * (size_t) CH, ctx->pmpot.ptr + c0, 8 * (size_t) m, hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipEventRecord(ev[sl], ctx->stream));
+        if(prev_c0 >= 0) {
+            SHQ_HIP(hipEventSynchronize(ev[sl ^ 1]));
+            land(prev_c0, prev_m, ctx->stage.ptr + (size_t) (sl ^ 1) * CH * 32);
+        }
+        prev_c0 = c0;
+        prev_m = m;
+    }
+    if(prev_c0 >= 0) {
+        SHQ_HIP(hipEventSynchronize(ev[(nchunk - 1) & 1]));
+        land(prev_c0, prev_m, ctx->stage.ptr + (size_t) ((nchunk - 1) & 1) * CH * 32);
+    }
     return SHQ_OK;
 }
 
