@@ -547,6 +547,15 @@ int shq_stellar_density(shq_context *ctx, const shq_tree_view *tree, const shq_p
 int shq_bh_veldisp(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const int32_t *active, int64_t nactive,
                    const shq_kick_factors *kf, double *NumDM, double (*V1sumDM)[3], double *V2sumDM, double *VDisp);
 
+/* winds_find_vel_disp(), wind part (libgadget/veldisp2.cpp:203-528): for the gas particles of `queue` (the reference's
+ * ActiveVDisp from build_vdisp_queue, :376-396, stays on the host: it reads densities and the star-formation threshold) the
+ * 1-D velocity dispersion of the ~40 nearest dark-matter particles, found by a density-like loop over five trial radii per
+ * walk (NUMDMNGB 40 +- 1), with the Hubble flow hubble * Time^2 * dist in the relative velocity.  `tree` is the dark-matter
+ * tree; the particle view needs Vel, FullTreeGravAccel, GravPM, Hsml (the starting DMRadius), TimeBinGravity and PI.
+ * VDisp[PI] is written where the reference sets SphP.VDisp (positive variance).  SHQ_ERR_NOCONV beyond MAXITER. */
+int shq_wind_veldisp(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const int32_t *queue, int64_t nqueue,
+                     const shq_kick_factors *kf, double Time, double hubble, double *VDisp, shq_sph_stats *stats);
+
 /* ---- long-range PM --------------------------------------------------------------------- */
 
 /* Mirror of the PetaPM fields gravpm.cpp reads (libgadget/petapm.h:87-112). */

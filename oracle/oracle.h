@@ -133,6 +133,12 @@ int orc_stellar_density(const shq_node *nodes, int64_t firstnode, orc_sph_arrays
 void orc_bh_veldisp(const shq_node *nodes, int64_t firstnode, const orc_sph_arrays *a, const int32_t *queue, int64_t nqueue,
                     double BoxSize, const shq_kick_factors *kf, double *out, double *vdisp);
 
+/* winds_find_vel_disp(), wind part (veldisp2.cpp:203-528): vdisp[q] / dmradius[q] of the q-th gas particle of `queue`.
+ * "Parity unpinned" (no reference fixture). */
+int orc_wind_veldisp(const shq_node *nodes, int64_t firstnode, const orc_sph_arrays *a, const int32_t *queue, int64_t nqueue,
+                     double BoxSize, const shq_kick_factors *kf, double Time, double hubble, double *vdisp, double *dmradius,
+                     int *niter_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -825,3 +825,118 @@ extern "C" void orc_bh_veldisp(const shq_node *nodes, int64_t firstnode, const o
         }
     }
 }
+
+/* ---- wind velocity dispersion: winds_find_vel_disp(), veldisp2.cpp:203-528 (see the stellar density above for the loop) --
+ * vdispeffdmradius :216-229, WindVDispLocalTreeWalk::ngbiter :440-479, WindVDispOutput::postprocess :285-320.
+ * vdisp[q] for the q-th gas particle of `queue` (left untouched where the reference leaves SphP.VDisp alone), dmradius[q] the
+ * converged radius.  "Parity unpinned": checked against brute-force sums in tests/test_oracle_cpu.py. */
+#define ORC_NWINDHSML 5
+#define ORC_NUMDMNGB 40
+extern "C" int orc_wind_veldisp(const shq_node *nodes, int64_t firstnode, const orc_sph_arrays *a, const int32_t *queue, int64_t nqueue,
+                                double BoxSize, const shq_kick_factors *kf, double Time, double hubble, double *vdisp, double *dmradius,
+                                int *niter_out)
+{
+    const shq_node *N = nodes - firstnode;
+    std::vector<double> Left(nqueue, 0.0), Right(nqueue, BoxSize), DM(nqueue);
+    for(int64_t q = 0; q < nqueue; q++)
+        DM[q] = a->hsml[queue[q]];
+    std::vector<int64_t> cur(nqueue);
+    for(int64_t q = 0; q < nqueue; q++)
+        cur[q] = q;
+    int niter = 0;
+    while(!cur.empty()) {
+        const int64_t size = (int64_t) cur.size();
+        std::vector<int64_t> todo(size, -1);
+#pragma omp parallel for schedule(dynamic, 8)
+        for(int64_t c = 0; c < size; c++) {
+            const int64_t q = cur[c], i = queue[q];
+            const double *Pos = &a->pos[3 * i];
+            double rad[ORC_NWINDHSML], num[ORC_NWINDHSML] = {0}, v1[ORC_NWINDHSML][3] = {{0}}, v2[ORC_NWINDHSML] = {0};
+            {
+                double right = Right[q], left = Left[q];
+                if(right > 0.99 * BoxSize)
+                    right = DM[q];
+                if(left == 0)
+                    left = 0.1 * DM[q];
+                const double rvol = pow(right, 3), lvol = pow(left, 3);
+                for(int k = 0; k < ORC_NWINDHSML; k++)
+                    rad[k] = pow((1.0 * k + 1) / (1.0 * ORC_NWINDHSML + 1) * (rvol - lvol) + lvol, 1. / 3);
+            }
+            double Hsml = rad[ORC_NWINDHSML - 1];
+            int maxcmpte = ORC_NWINDHSML;
+            int64_t no = firstnode;
+            while(no >= 0) {
+                const shq_node *nd = &N[no];
+                if(0 == cull_node(Pos, BoxSize, Hsml, nd, false)) {
+                    no = nd->sibling;
+                    continue;
+                }
+                const unsigned ct = SHQ_NODE_CHILDTYPE(nd->flags);
+                if(ct == SHQ_PARTICLE_NODE_TYPE) {
+                    for(int s = 0; s < nd->noccupied; s++) {
+                        const int64_t other = nd->suns[s];
+                        if(is_garbage(a, other) || !((1 << a->type[other]) & 2))
+                            continue;
+                        double dist[3], r2 = 0;
+                        for(int d = 0; d < 3; d++) {
+                            dist[d] = orc_nearest(Pos[d] - a->pos[3 * other + d], BoxSize);
+                            r2 += dist[d] * dist[d];
+                        }
+                        if(r2 <= 0 || !(r2 < rad[ORC_NWINDHSML - 1] * rad[ORC_NWINDHSML - 1]))
+                            continue;
+                        const double r = sqrt(r2);
+                        for(int k = 0; k < maxcmpte; k++) {
+                            if(r < rad[k]) {
+                                num[k] += 1;
+                                for(int d = 0; d < 3; d++) {
+                                    const double vp = a->vel[3 * other + d] + kf->gravkicks[a->bin_grav[other]] * a->treeacc[3 * other + d] +
+                                                      a->gravpm[3 * other + d] * kf->FgravkickB;
+                                    const double vel = vp - a->vel[3 * i + d] + hubble * Time * Time * dist[d];
+                                    v1[k][d] += vel;
+                                    v2[k] += vel * vel;
+                                }
+                            }
+                        }
+                        for(int k = 0; k < ORC_NWINDHSML; k++) {
+                            if(num[k] > ORC_NUMDMNGB) {
+                                maxcmpte = k + 1;
+                                Hsml = rad[k];
+                                break;
+                            }
+                        }
+                    }
+                    no = nd->sibling;
+                    continue;
+                } else if(ct == SHQ_PSEUDO_NODE_TYPE) {
+                    no = nd->sibling;
+                    continue;
+                }
+                no = nd->suns[0];
+            }
+            int close = 0;
+            DM[q] = ngb_narrow_down(&Right[q], &Left[q], rad, num, maxcmpte, ORC_NUMDMNGB, &close, BoxSize);
+            const double numngb = num[close];
+            if((numngb >= (ORC_NUMDMNGB - 1) && numngb <= (ORC_NUMDMNGB + 1)) || (Right[q] - Left[q] < 5e-6 * Left[q])) {
+                double vd = v2[close] / numngb;
+                for(int d = 0; d < 3; d++)
+                    vd -= pow(v1[close][d] / numngb, 2);
+                if(vd > 0)
+                    vdisp[q] = sqrt(vd / 3);
+            } else
+                todo[c] = q;
+        }
+        niter++;
+        std::vector<int64_t> next;
+        for(int64_t c = 0; c < size; c++)
+            if(todo[c] >= 0)
+                next.push_back(todo[c]);
+        cur.swap(next);
+        if(!cur.empty() && niter > ORC_MAXITER)
+            return 1;
+    }
+    for(int64_t q = 0; q < nqueue; q++)
+        dmradius[q] = DM[q];
+    if(niter_out)
+        *niter_out = niter;
+    return 0;
+}

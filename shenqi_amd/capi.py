@@ -405,6 +405,9 @@ hip.shq_stellar_density.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView
 hip.shq_stellar_density.restype = C.c_int
 hip.shq_bh_veldisp.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), _vp, C.c_int64, C.POINTER(KickFactors), _vp, _vp, _vp, _vp]
 hip.shq_bh_veldisp.restype = C.c_int
+hip.shq_wind_veldisp.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), _vp, C.c_int64, C.POINTER(KickFactors), C.c_double, C.c_double,
+                                 _vp, C.POINTER(SphStats)]
+hip.shq_wind_veldisp.restype = C.c_int
 hip.shq_hydro_force.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(SphView), _vp, C.c_int64,
                                 C.POINTER(HydroParams), _vp, C.POINTER(SphStats)]
 host.shqh_set_densitypar.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]

@@ -1984,6 +1984,277 @@ int shq_bh_veldisp_device(shq_context *ctx, const shq_kick_factors *kf, double B
     return SHQ_OK;
 }
 
+/* ---- wind velocity dispersion: winds_find_vel_disp, veldisp2.cpp:203-528 --------------------------
+ * The 1-D velocity dispersion of the ~40 nearest dark-matter particles around star-forming gas: a density-like loop over the
+ * DM tree with NWINDHSML = 5 trial radii per walk (vdispeffdmradius :216-229, ngbiter :440-479 with the Hubble flow in the
+ * relative velocity), WindVDispOutput::postprocess + ngb_narrow_down (:285-320) until 40 +- 1 neighbours.  Same structure
+ * as the stellar density; the reference's integer neighbour counts make the result independent of summation order. */
+#define WV_NH 5
+#define WV_NUMDMNGB 40
+#define WV_MAXDEV 1
+
+template <int NH> __device__ __forceinline__ double narrow_down(double &R, double &L, const double *radius, const double *numNgb, int maxcmpt,
+                                                                 int desnumngb, int &close, double Box)
+{
+    /* ngb_narrow_down, treewalk.c:1349-1406, with the dynamic indices written as selects over the NH trial radii */
+    close = 0;
+    double ngbdist = fabs(numNgb[0] - desnumngb);
+#pragma unroll
+    for(int k = 1; k < NH; k++) {
+        const double nd = fabs(numNgb[k] - desnumngb);
+        if(k < maxcmpt && nd < ngbdist) {
+            ngbdist = nd;
+            close = k;
+        }
+    }
+    bool stop = false;
+#pragma unroll
+    for(int k = 0; k < NH; k++) {
+        if(k < maxcmpt && !stop) {
+            if(numNgb[k] < desnumngb)
+                L = radius[k];
+            if(numNgb[k] > desnumngb) {
+                R = radius[k];
+                stop = true;
+            }
+        }
+    }
+    double hc = radius[0], rl = radius[0], rl1 = radius[0], nl = numNgb[0], nl1 = numNgb[0];
+#pragma unroll
+    for(int k = 1; k < NH; k++) {
+        if(k == close)
+            hc = radius[k];
+        if(k == maxcmpt - 1) {
+            rl = radius[k]; nl = numNgb[k]; rl1 = radius[k - 1]; nl1 = numNgb[k - 1];
+        }
+    }
+    double hs = hc;
+    if(R > 0.99 * Box) {
+        double dngbdv = 0;
+        if(maxcmpt > 1 && rl > rl1)
+            dngbdv = (nl - nl1) / (pow(rl, 3) - pow(rl1, 3));
+        double newh = 4 * hs;
+        if(dngbdv > 0) {
+            const double dngb = desnumngb - nl;
+            const double nv = pow(hs, 3) + dngb / dngbdv;
+            if(pow(nv, 1. / 3) < newh)
+                newh = pow(nv, 1. / 3);
+        }
+        hs = newh;
+    }
+    if(hs > R)
+        hs = R;
+    if(L == 0) {
+        double dngbdv = 0;
+        if(radius[1] > radius[0])
+            dngbdv = (numNgb[1] - numNgb[0]) / (pow(radius[1], 3) - pow(radius[0], 3));
+        if(maxcmpt == 1 && radius[0] > 0)
+            dngbdv = numNgb[0] / pow(radius[0], 3);
+        if(dngbdv > 0) {
+            const double dngb = desnumngb - numNgb[0];
+            const double nv = pow(hs, 3) + dngb / dngbdv;
+            hs = pow(nv, 1. / 3);
+        }
+    }
+    if(hs < L)
+        hs = L;
+    return hs;
+}
+
+struct WindVdArgs {
+    double Box, hubble_a2;     /* hubble * atime^2 */
+    const double4 *vel_leaf;   /* DM_VelPred by leaf slot */
+    const double *vel;         /* [N][3] */
+    double *dmradius;          /* by particle index: the current DMRadius (starts as Hsml) */
+    double *vdisp;             /* by particle index; < 0 where not set */
+    int32_t *todo;
+};
+
+__global__ __launch_bounds__(256) void wind_veldisp_kernel(const SphDev a, const int32_t *queue, long long nq, const WindVdArgs wa,
+                                                           unsigned long long *nint_total, int32_t *__restrict__ nlist, long long ntasks)
+{
+    __shared__ __attribute__((aligned(32))) char lds[4 * NW_LDS_PER_WAVE(false)];
+    const int lane = threadIdx.x & 63;
+    for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
+    const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    const long long t = wave * 64 + lane;
+    const bool valid = t < nq;
+    long long pi = 0;
+    double px = 0, py = 0, pz = 0, vx = 0, vy = 0, vz = 0, dm = 1, L = 0, R = wa.Box;
+    if(valid) {
+        pi = queue[t];
+        const double4 p = a.posm[pi];
+        px = p.x; py = p.y; pz = p.z;
+        vx = wa.vel[3 * pi]; vy = wa.vel[3 * pi + 1]; vz = wa.vel[3 * pi + 2];
+        dm = wa.dmradius[pi];
+        L = a.left[pi];
+        R = a.right[pi];
+    }
+    double rad[WV_NH], num[WV_NH], v1x[WV_NH], v1y[WV_NH], v1z[WV_NH], v2[WV_NH];
+    {
+        /* vdispeffdmradius, veldisp2.cpp:216-229 */
+        double right = R, left = L;
+        if(right > 0.99 * wa.Box)
+            right = dm;
+        if(left == 0)
+            left = 0.1 * dm;
+        const double rvol = pow(right, 3), lvol = pow(left, 3);
+#pragma unroll
+        for(int k = 0; k < WV_NH; k++) {
+            rad[k] = pow((1.0 * k + 1) / (1.0 * WV_NH + 1) * (rvol - lvol) + lvol, 1. / 3);
+            num[k] = 0; v1x[k] = 0; v1y[k] = 0; v1z[k] = 0; v2[k] = 0;
+        }
+    }
+    int maxcmpte = WV_NH;
+    auto pair = [&](const int s) {
+        const double4 q = a.posm_leaf[s];
+        const double4 w = wa.vel_leaf[s];
+        const double d0 = wrapd(px - q.x, a.Box, a.invBox);
+        const double d1 = wrapd(py - q.y, a.Box, a.invBox);
+        const double d2 = wrapd(pz - q.z, a.Box, a.invBox);
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        if(r2 <= 0 || !(r2 < rad[WV_NH - 1] * rad[WV_NH - 1]))
+            return;
+        const double r = sqrt(r2);
+        const double e0 = w.x - vx + wa.hubble_a2 * d0, e1 = w.y - vy + wa.hubble_a2 * d1, e2 = w.z - vz + wa.hubble_a2 * d2;
+#pragma unroll
+        for(int k = 0; k < WV_NH; k++) {
+            if(k < maxcmpte && r < rad[k]) {
+                num[k] += 1;
+                v1x[k] += e0; v2[k] += e0 * e0;
+                v1y[k] += e1; v2[k] += e1 * e1;
+                v1z[k] += e2; v2[k] += e2 * e2;
+            }
+        }
+        int first = WV_NH;
+#pragma unroll
+        for(int k = WV_NH - 1; k >= 0; k--)
+            first = (num[k] > WV_NUMDMNGB) ? k : first;
+        if(first < WV_NH)
+            maxcmpte = first + 1;
+    };
+    const double rw2 = rad[WV_NH - 1] * rad[WV_NH - 1];
+    auto accept = [&](const double r2, const double, const int) { return r2 > 0 && r2 < rw2; };
+    int fill = 0;
+    bool ovf = false;
+    unsigned int nint = ngb_walk<false, false, false>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(false), myl, valid, px, py, pz, rad[WV_NH - 1],
+                                                      accept, pair, (unsigned int *) nullptr, fill, ovf);
+    if(valid) {
+        /* WindVDispOutput::postprocess, veldisp2.cpp:285-320 */
+        int close = 0;
+        const double newdm = narrow_down<WV_NH>(R, L, rad, num, maxcmpte, WV_NUMDMNGB, close, wa.Box);
+        double nc = num[0], s0 = v1x[0], s1 = v1y[0], s2 = v1z[0], q2 = v2[0];
+#pragma unroll
+        for(int k = 1; k < WV_NH; k++)
+            if(k == close) {
+                nc = num[k]; s0 = v1x[k]; s1 = v1y[k]; s2 = v1z[k]; q2 = v2[k];
+            }
+        wa.dmradius[pi] = newdm;
+        a.left[pi] = L;
+        a.right[pi] = R;
+        a.numngb[pi] = nc;
+        int done = 0;
+        if((nc >= (WV_NUMDMNGB - WV_MAXDEV) && nc <= (WV_NUMDMNGB + WV_MAXDEV)) || (R - L < 5e-6 * L)) {
+            double vd = q2 / nc;
+            vd -= (s0 / nc) * (s0 / nc);
+            vd -= (s1 / nc) * (s1 / nc);
+            vd -= (s2 / nc) * (s2 / nc);
+            if(vd > 0)
+                wa.vdisp[pi] = sqrt(vd / 3);
+            done = 1;
+        }
+        wa.todo[t] = done ? -1 : (int32_t) pi;
+    }
+    unsigned int sn = nint;
+    for(int off = 32; off > 0; off >>= 1)
+        sn += __shfl_xor(sn, off);
+    if(lane == 0 && nint_total)
+        atomicAdd(nint_total, (unsigned long long) sn);
+    } /* task loop */
+}
+
+int shq_wind_veldisp_device(shq_context *ctx, const shq_kick_factors *kf, double BoxSize, double hubble_a2, const int32_t *d_queue, int64_t nq,
+                            double *d_dmradius, double *d_vdisp, shq_sph_stats *stats)
+{
+    const long long n = ctx->numpart;
+    const size_t cap = (size_t) (n > 0 ? n : 1);
+    SHQ_TRY(ctx->s_numngb.reserve(cap));
+    SHQ_TRY(ctx->s_left.reserve(cap));
+    SHQ_TRY(ctx->s_right.reserve(cap));
+    SHQ_TRY(ctx->s_todo.reserve(cap));
+    SHQ_TRY(ctx->s_queue2.reserve(cap));
+    SHQ_TRY(ctx->s_queue3.reserve(cap));
+    SHQ_TRY(ctx->s_blockcount.reserve(nblk(n) + 1));
+    SHQ_TRY(ctx->s_counters.reserve(8));
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    const long long nl = ctx->ntreeparts + SHQ_NMAXCHILD;
+    SHQ_TRY(ctx->velp_leaf.reserve(nl));
+    SHQ_TRY(ctx->flag_leaf.reserve(nl));
+    hipStream_t st = ctx->stream;
+    if(n > 0) {
+        SHQ_HIP(hipMemsetAsync(ctx->s_left.ptr, 0, sizeof(double) * n, st));
+        fill_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(ctx->s_right.ptr, n, BoxSize);
+    }
+    SHQ_HIP(hipMemsetAsync(ctx->s_counters.ptr, 0, sizeof(long long) * 8, st));
+    bh_veldisp_gather_kernel<<<dim3(nblk(nl)), dim3(256), 0, st>>>(nl, ctx->leaf_pidx.ptr, ctx->vel.ptr, ctx->treeacc.ptr, ctx->gravpm.ptr,
+                                                                  ctx->bin_grav.ptr, ctx->pflags.ptr, *kf, 1 << 1, ctx->velp_leaf.ptr,
+                                                                  ctx->flag_leaf.ptr);
+    SHQ_HIP(hipGetLastError());
+    SphDev a = make_dev(ctx);
+    a.Box = BoxSize;
+    a.invBox = 1.0 / BoxSize;
+    WindVdArgs wa;
+    wa.Box = BoxSize;
+    wa.hubble_a2 = hubble_a2;
+    wa.vel_leaf = ctx->velp_leaf.ptr;
+    wa.vel = ctx->vel.ptr;
+    wa.dmradius = d_dmradius;
+    wa.vdisp = d_vdisp;
+    wa.todo = ctx->s_todo.ptr;
+    unsigned long long *nint = reinterpret_cast<unsigned long long *>(ctx->s_counters.ptr + 1);
+    long long *total = ctx->s_counters.ptr;
+    int32_t *bufs[2] = {ctx->s_queue2.ptr, ctx->s_queue3.ptr};
+    int wsel = 0, niter = 0;
+    const int32_t *cur = d_queue;
+    long long size = nq;
+    SHQ_HIP(hipEventRecord(ctx->ev_begin[14], st));
+    while(size > 0) {
+        const long long ntasks = (size + 255) / 256;
+        const unsigned grid = (unsigned) (ntasks < NL_REDO_BLOCKS ? ntasks : NL_REDO_BLOCKS);
+        wind_veldisp_kernel<<<dim3(grid), dim3(256), 0, st>>>(a, cur, size, wa, nint, ctx->s_nlist2.ptr, ntasks);
+        SHQ_HIP(hipGetLastError());
+        niter++;
+        const int nb = (int) nblk(size);
+        compact_count_kernel<<<dim3(nb), dim3(256), 0, st>>>(ctx->s_todo.ptr, size, ctx->s_blockcount.ptr);
+        compact_scan_kernel<<<dim3(1), dim3(1024), 0, st>>>(ctx->s_blockcount.ptr, nb, total);
+        compact_write_kernel<<<dim3(nb), dim3(256), 0, st>>>(ctx->s_todo.ptr, size, ctx->s_blockcount.ptr, bufs[wsel]);
+        long long newsize = 0;
+        SHQ_HIP(hipMemcpyAsync(&newsize, total, sizeof(long long), hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipStreamSynchronize(st));
+        size = newsize;
+        cur = bufs[wsel];
+        wsel ^= 1;
+        if(size > 0 && niter > SPH_MAXITER) {
+            shq_set_error("failed to converge the wind velocity dispersion for %lld particles", size);
+            return SHQ_ERR_NOCONV;
+        }
+    }
+    SHQ_HIP(hipEventRecord(ctx->ev_end[14], st));
+    if(stats) {
+        unsigned long long h_nint = 0;
+        SHQ_HIP(hipMemcpyAsync(&h_nint, nint, sizeof(h_nint), hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipStreamSynchronize(st));
+        float ms = 0;
+        (void) hipEventElapsedTime(&ms, ctx->ev_begin[14], ctx->ev_end[14]);
+        stats->ntargets = nq;
+        stats->ninteractions = (int64_t) h_nint;
+        stats->niterations = niter;
+        stats->kernel_ms = ms;
+    }
+    return SHQ_OK;
+}
+
 int shq_sph_gradrho_mag(shq_context *ctx, double *d_out)
 {
     const long long n = ctx->numpart;

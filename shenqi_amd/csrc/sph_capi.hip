@@ -809,3 +809,51 @@ extern "C" int shq_bh_veldisp(shq_context *ctx, const shq_tree_view *tree, const
     }
     return SHQ_OK;
 }
+
+extern "C" int shq_wind_veldisp(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const int32_t *queue, int64_t nqueue,
+                                const shq_kick_factors *kf, double Time, double hubble, double *VDisp, shq_sph_stats *stats)
+{
+    SHQ_CHECK(ctx && tree && parts && kf && VDisp && (nqueue == 0 || queue), SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->sphrun.phase == 0, SHQ_ERR_STATE, "wind_veldisp: an SPH walk is open");
+    SHQ_CHECK(nqueue >= 0 && Time > 0, SHQ_ERR_INVALID, "wind_veldisp: bad queue length or Time");
+    SHQ_CHECK(parts->off_vel != SHQ_NOFIELD && parts->off_hsml != SHQ_NOFIELD && parts->off_pi != SHQ_NOFIELD &&
+                  parts->off_type != SHQ_NOFIELD && parts->off_treeacc != SHQ_NOFIELD && parts->off_gravpm != SHQ_NOFIELD,
+              SHQ_ERR_INVALID, "wind_veldisp: the particle view needs Vel, Hsml, PI, Type, FullTreeGravAccel and GravPM");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t n = parts->numpart;
+    for(int64_t k = 0; k < nqueue; k++) {
+        const int32_t i = queue[k];
+        SHQ_CHECK(i >= 0 && i < n, SHQ_ERR_INVALID, "wind_veldisp: queue[%ld] = %d out of range", (long) k, i);
+        SHQ_CHECK(*pfield<uint8_t>(parts, i, parts->off_type) == 0, SHQ_ERR_INVALID, "wind_veldisp: particle %d in the queue is not gas", i);
+        SHQ_CHECK(*pfield<double>(parts, i, parts->off_hsml) > 0, SHQ_ERR_INVALID, "wind_veldisp: gas particle %d has Hsml <= 0", i);
+    }
+    SHQ_TRY(shq_particles_upload(ctx, parts));
+    SHQ_TRY(shq_dynamics_upload(ctx, parts));
+    SHQ_TRY(shq_tree_upload(ctx, tree));
+    if(nqueue == 0) {
+        if(stats)
+            memset(stats, 0, sizeof(*stats));
+        return SHQ_OK;
+    }
+    const size_t cap = (size_t) std::max<int64_t>(n, 1);
+    SHQ_TRY(ctx->s_queue0.reserve((size_t) nqueue));
+    SHQ_TRY(ctx->s_gradrho.reserve(2 * cap)); /* DMRadius and VDisp by particle index */
+    double *d_dm = ctx->s_gradrho.ptr, *d_vd = ctx->s_gradrho.ptr + cap;
+    SHQ_HIP(hipMemcpyAsync(ctx->s_queue0.ptr, queue, sizeof(int32_t) * nqueue, hipMemcpyHostToDevice, ctx->stream));
+    SHQ_HIP(hipMemcpyAsync(d_dm, ctx->hsml.ptr, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream)); /* DMRadius starts as Hsml, :261 */
+    {
+        std::vector<double> neg(cap, -1.0);
+        SHQ_HIP(hipMemcpyAsync(d_vd, neg.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    SHQ_TRY(shq_wind_veldisp_device(ctx, kf, tree->BoxSize, hubble * Time * Time, ctx->s_queue0.ptr, nqueue, d_dm, d_vd, stats));
+    std::vector<double> vd(cap);
+    SHQ_HIP(hipMemcpyAsync(vd.data(), d_vd, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    for(int64_t k = 0; k < nqueue; k++) {
+        const int32_t i = queue[k];
+        if(vd[i] >= 0)
+            VDisp[*pfield<int32_t>(parts, i, parts->off_pi)] = vd[i];
+    }
+    return SHQ_OK;
+}

@@ -73,6 +73,19 @@ def bh_veldisp(nodes, firstnode, st, queue, BoxSize, kf):
     return out, vd
 
 
+def wind_veldisp(nodes, firstnode, st, queue, BoxSize, kf, Time, hubble):
+    """winds_find_vel_disp wind part (veldisp2.cpp:203-528): (rc, vdisp [nq] NaN where unset, dmradius [nq], iterations)."""
+    q = np.ascontiguousarray(queue, dtype=np.int32)
+    vd = np.full(len(q), np.nan)
+    dm = np.zeros(len(q))
+    niter = C.c_int()
+    lib.orc_wind_veldisp.argtypes = [_vp, C.c_int64, C.POINTER(OrcSphArrays), _vp, C.c_int64, C.c_double, _vp, C.c_double, C.c_double, _vp, _vp,
+                                     C.POINTER(C.c_int)]
+    rc = lib.orc_wind_veldisp(ptr(nodes), firstnode, C.byref(st.c), ptr(q), len(q), BoxSize, C.byref(kf), Time, hubble, ptr(vd), ptr(dm),
+                              C.byref(niter))
+    return rc, vd, dm, niter.value
+
+
 class SphState:
     """SoA copy of the particle / slot state the oracle's SPH functions work on."""
 

@@ -228,3 +228,30 @@ def test_bh_veldisp_matches_oracle(ctx):
     assert np.abs(vdisp[slots] / vd - 1).max() < 1e-10
     untouched = np.setdiff1d(np.arange(nbh), slots)
     assert len(untouched) > 0 and np.all(num[untouched] == -1.0) and np.all(vdisp[untouched] == -7.0)
+
+
+def test_wind_veldisp_matches_oracle(ctx):
+    """shq_wind_veldisp (veldisp2.cpp:203-528) against the oracle: same number of iterations of the five-radius loop, VDisp
+    to rounding (neighbour counts are integers, so the converged sets are the same), written by gas slot."""
+    import test_oracle_cpu as toc
+    pman, kf, nd, ngas = toc._gas_in_dm(n1=16, ngas=400, seed=21)
+    P = pman.Base
+    tree = sq.force_tree_rebuild_mask(pman, sq.DMMASK)
+    st = orc.SphState(P, np.zeros(ngas, dtype=sq.SPH_DTYPE))
+    queue = np.arange(nd, nd + ngas, dtype=np.int32)[::3].copy()
+    Time, hubble = 0.25, 3.0
+    rc, ovd, odm, oniter = orc.wind_veldisp(tree.Nodes_base, tree.firstnode, st, queue, cm.BOX, kf, Time, hubble)
+    assert rc == 0
+    vdisp = np.full(ngas, -5.0)
+    stats = capi.SphStats()
+    pv, tv = pman.view(), tree.view()
+    capi.check(capi.hip.shq_wind_veldisp(ctx.h, C.byref(tv), C.byref(pv), capi.ptr(queue), len(queue), C.byref(kf), Time, hubble,
+                                         capi.ptr(vdisp), C.byref(stats)))
+    assert stats.niterations == oniter
+    slots = P["PI"][queue]
+    assert np.abs(vdisp[slots] / ovd - 1).max() < 1e-9
+    untouched = np.setdiff1d(np.arange(ngas), slots)
+    assert np.all(vdisp[untouched] == -5.0)
+    # a non-gas particle in the queue is refused
+    bad = np.array([0], dtype=np.int32)
+    assert capi.hip.shq_wind_veldisp(ctx.h, C.byref(tv), C.byref(pv), capi.ptr(bad), 1, C.byref(kf), Time, hubble, capi.ptr(vdisp), None) != 0

@@ -435,3 +435,47 @@ def test_bh_veldisp_oracle_against_brute_force():
         assert np.isclose(out[q, 4], (rel * rel).sum(), rtol=1e-12)
         var = (rel * rel).sum() / sel.sum() - np.sum((rel.sum(axis=0) / sel.sum()) ** 2)
         assert np.isclose(vd[q], np.sqrt(var / 3), rtol=1e-10)
+
+
+def _gas_in_dm(n1=14, ngas=200, seed=12):
+    """Dark matter with velocities / accelerations and a few gas particles whose DM neighbourhoods are wanted."""
+    pman, kf, nd, _ = _bhs_in_dm(n1=n1, nbh=ngas, seed=seed)
+    P = pman.Base
+    P["Type"][nd:] = 0
+    P["PI"][nd:] = np.arange(ngas)[::-1]
+    P["Hsml"][nd:] = cm.BOX / n1 * np.random.default_rng(seed).uniform(0.8, 4.0, size=ngas)
+    return pman, kf, nd, ngas
+
+
+def test_wind_veldisp_oracle_against_brute_force():
+    """orc_wind_veldisp: every gas particle ends with 39..41 dark-matter neighbours inside its DMRadius, and VDisp is the
+    dispersion of their (Hubble-flow corrected) predicted velocities."""
+    import shenqi_amd as sq
+    pman, kf, nd, ngas = _gas_in_dm()
+    P = pman.Base
+    tree = sq.force_tree_rebuild_mask(pman, sq.DMMASK)
+    st = orc.SphState(P, np.zeros(ngas, dtype=sq.SPH_DTYPE))
+    queue = np.arange(nd, nd + ngas, dtype=np.int32)
+    Time, hubble = 0.25, 3.0
+    rc, vd, dm, niter = orc.wind_veldisp(tree.Nodes_base, tree.firstnode, st, queue, cm.BOX, kf, Time, hubble)
+    assert rc == 0 and 1 < niter < 80 and np.all(np.isfinite(vd))
+    gk = np.array([kf.gravkicks[b] for b in P["TimeBinGravity"][:nd]])
+    vp = P["Vel"][:nd] + gk[:, None] * P["FullTreeGravAccel"][:nd] + P["GravPM"][:nd] * kf.FgravkickB
+    ok = P["Flags"][:nd] == 0
+    for q, i in enumerate(queue[:60]):
+        d = P["Pos"][i] - P["Pos"][:nd]
+        d -= cm.BOX * np.rint(d / cm.BOX)
+        r = np.sqrt(np.sum(d * d, axis=1))
+        # VDisp belongs to the trial radius that enclosed 39..41 neighbours, i.e. to the 39, 40 or 41 nearest dark-matter
+        # particles (the stored DMRadius may have been extrapolated past it)
+        r[~ok] = np.inf
+        r[r <= 0] = np.inf
+        nearest = np.argsort(r)
+        cands = []
+        for nn in (39, 40, 41):
+            sel = nearest[:nn]
+            rel = vp[sel] - P["Vel"][i] + hubble * Time * Time * d[sel]
+            var = (rel * rel).sum() / nn - np.sum((rel.sum(axis=0) / nn) ** 2)
+            cands.append(np.sqrt(var / 3))
+        assert any(np.isclose(vd[q], c, rtol=1e-9) for c in cands), (q, vd[q], cands)
+        assert dm[q] > 0
