@@ -556,6 +556,28 @@ int shq_bh_veldisp(shq_context *ctx, const shq_tree_view *tree, const shq_part_v
 int shq_wind_veldisp(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const int32_t *queue, int64_t nqueue,
                      const shq_kick_factors *kf, double Time, double hubble, double *VDisp, shq_sph_stats *stats);
 
+/* blackhole_minpot() and the treewalk of blackhole_dynfric() (libgadget/bhdynfric.cpp:44-295, 313-345): for the black holes
+ * of `queue` (ActiveBlackHoles / DynFricActive) over the caller's tree (ALLMASK for repositioning; STARMASK + BHMASK, plus
+ * DMMASK for BH_DynFrictionMethod > 1, for friction — `typemask` says which types of the tree's particles count):
+ *   - the neighbour of lowest Potential inside the hole's Hsml: MinPot / MinPotPos / MinPotVel of slot PI are replaced where it
+ *     lies below the value already there (BHReposResult::reduce, :106-118; the caller initialises them as
+ *     blackhole_init_potential does, :296-310) and `updated[PI]` is set to 1;
+ *   - with method > 0 the friction sums after BHDynFricOutput::postprocess (:66-82): DF_SurroundingDensity (the raw
+ *     kernel-weighted mass), DF_SurroundingVel and DF_SurroundingRmsVel normalised where the density is positive.
+ * The particle view needs Vel, FullTreeGravAccel, GravPM, Potential, Hsml, TimeBinGravity, Type and PI. */
+typedef struct shq_bh_dynfric_out {
+    double *MinPot;               /* [nslots], in / out */
+    double (*MinPotPos)[3];       /* in / out */
+    double (*MinPotVel)[3];       /* in / out */
+    int32_t *updated;             /* [nslots] or NULL */
+    double *DF_SurroundingDensity; /* out (method > 0), may be NULL */
+    double (*DF_SurroundingVel)[3];
+    double *DF_SurroundingRmsVel;
+} shq_bh_dynfric_out;
+int shq_bh_dynfric(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const int32_t *queue, int64_t nqueue,
+                   const shq_kick_factors *kf, int BH_DynFrictionMethod, int DensityKernelType, int typemask,
+                   const shq_bh_dynfric_out *out);
+
 /* ---- long-range PM --------------------------------------------------------------------- */
 
 /* Mirror of the PetaPM fields gravpm.cpp reads (libgadget/petapm.h:87-112). */

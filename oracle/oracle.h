@@ -139,6 +139,11 @@ int orc_wind_veldisp(const shq_node *nodes, int64_t firstnode, const orc_sph_arr
                      double BoxSize, const shq_kick_factors *kf, double Time, double hubble, double *vdisp, double *dmradius,
                      int *niter_out);
 
+/* blackhole_minpot / blackhole_dynfric treewalks (bhdynfric.cpp:44-295): raw results, 12 doubles per black hole of `queue`
+ * (MinPot, MinPotPos[3], MinPotVel[3], SurroundingDensity, SurroundingVel[3], SurroundingRmsVel).  "Parity unpinned". */
+void orc_bh_dynfric(const shq_node *nodes, int64_t firstnode, const orc_sph_arrays *a, const double *potential, const int32_t *queue,
+                    int64_t nqueue, double BoxSize, const shq_kick_factors *kf, int method, int ktype, int typemask, double *out);
+
 #ifdef __cplusplus
 }
 #endif

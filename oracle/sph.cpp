@@ -940,3 +940,77 @@ extern "C" int orc_wind_veldisp(const shq_node *nodes, int64_t firstnode, const 
         *niter_out = niter;
     return 0;
 }
+
+/* ---- black-hole repositioning / dynamical-friction sums: bhdynfric.cpp:44-295 ------------------------------------------
+ * BHReposLocalTreeWalk::ngbiter :160-174, BHDynFricLocalTreeWalk::ngbiter :193-224, raw results per black hole of `queue`:
+ * out[q][12] = MinPot, MinPotPos[3], MinPotVel[3], SurroundingDensity, SurroundingVel[3], SurroundingRmsVel (before
+ * postprocess).  potential: by particle.  "Parity unpinned": checked against brute force in tests/test_oracle_cpu.py. */
+extern "C" void orc_bh_dynfric(const shq_node *nodes, int64_t firstnode, const orc_sph_arrays *a, const double *potential,
+                               const int32_t *queue, int64_t nqueue, double BoxSize, const shq_kick_factors *kf, int method, int ktype,
+                               int typemask, double *out)
+{
+    const shq_node *N = nodes - firstnode;
+#pragma omp parallel for schedule(dynamic, 4)
+    for(int64_t q = 0; q < nqueue; q++) {
+        const int64_t i = queue[q];
+        const double *Pos = &a->pos[3 * i];
+        OrcKernel kernel(ktype, a->hsml[i]);
+        const double H = kernel.H;
+        double minpot = 1.0e29, mp[3] = {-1, -1, -1}, mv[3] = {0, 0, 0}, dens = 0, sv[3] = {0, 0, 0}, rms = 0;
+        int64_t no = firstnode;
+        while(no >= 0) {
+            const shq_node *c = &N[no];
+            if(0 == cull_node(Pos, BoxSize, a->hsml[i], c, false)) {
+                no = c->sibling;
+                continue;
+            }
+            const unsigned ct = SHQ_NODE_CHILDTYPE(c->flags);
+            if(ct == SHQ_PARTICLE_NODE_TYPE) {
+                for(int s = 0; s < c->noccupied; s++) {
+                    const int64_t other = c->suns[s];
+                    if(is_garbage(a, other) || !((1 << a->type[other]) & typemask))
+                        continue;
+                    double r2 = 0;
+                    for(int d = 0; d < 3; d++) {
+                        const double dd = orc_nearest(Pos[d] - a->pos[3 * other + d], BoxSize);
+                        r2 += dd * dd;
+                    }
+                    if(r2 >= H * H)
+                        continue;
+                    if(potential[other] < minpot) {
+                        minpot = potential[other];
+                        for(int d = 0; d < 3; d++) {
+                            mp[d] = a->pos[3 * other + d];
+                            mv[d] = a->vel[3 * other + d];
+                        }
+                    }
+                    if(method > 0 && (a->type[other] == 4 || (a->type[other] == 1 && method > 1))) {
+                        const double wk = kernel.wk(sqrt(r2) / H);
+                        dens += a->mass[other] * wk;
+                        for(int d = 0; d < 3; d++) {
+                            const double vp = a->vel[3 * other + d] + kf->gravkicks[a->bin_grav[other]] * a->treeacc[3 * other + d] +
+                                              a->gravpm[3 * other + d] * kf->FgravkickB;
+                            sv[d] += a->mass[other] * wk * vp;
+                            rms += a->mass[other] * wk * pow(vp, 2);
+                        }
+                    }
+                }
+                no = c->sibling;
+                continue;
+            } else if(ct == SHQ_PSEUDO_NODE_TYPE) {
+                no = c->sibling;
+                continue;
+            }
+            no = c->suns[0];
+        }
+        double *o = out + 12 * q;
+        o[0] = minpot;
+        for(int d = 0; d < 3; d++) {
+            o[1 + d] = mp[d];
+            o[4 + d] = mv[d];
+            o[8 + d] = sv[d];
+        }
+        o[7] = dens;
+        o[11] = rms;
+    }
+}

@@ -408,6 +408,14 @@ hip.shq_bh_veldisp.restype = C.c_int
 hip.shq_wind_veldisp.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), _vp, C.c_int64, C.POINTER(KickFactors), C.c_double, C.c_double,
                                  _vp, C.POINTER(SphStats)]
 hip.shq_wind_veldisp.restype = C.c_int
+class BhDynFricOut(C.Structure):
+    _fields_ = [("MinPot", _vp), ("MinPotPos", _vp), ("MinPotVel", _vp), ("updated", _vp), ("DF_SurroundingDensity", _vp),
+                ("DF_SurroundingVel", _vp), ("DF_SurroundingRmsVel", _vp)]
+
+
+hip.shq_bh_dynfric.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), _vp, C.c_int64, C.POINTER(KickFactors), C.c_int, C.c_int, C.c_int,
+                               C.POINTER(BhDynFricOut)]
+hip.shq_bh_dynfric.restype = C.c_int
 hip.shq_hydro_force.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(SphView), _vp, C.c_int64,
                                 C.POINTER(HydroParams), _vp, C.POINTER(SphStats)]
 host.shqh_set_densitypar.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]

@@ -375,6 +375,8 @@ int shq_sph_density_secondary(shq_context *ctx, const shq_density_params *p, con
                               const double4 *d_qvelp, const uint8_t *d_qflags, const int4 *d_qseg, int64_t nq, double *d_out,
                               unsigned long long *d_nint);
 int shq_sph_gradrho_mag(shq_context *ctx, double *d_out);
+int shq_bh_dynfric_device(shq_context *ctx, const shq_kick_factors *kf, double BoxSize, int kernel_type, int typemask, int method,
+                          const double *d_potential, const int32_t *d_queue, int64_t nq, double *d_out);
 int shq_wind_veldisp_device(shq_context *ctx, const shq_kick_factors *kf, double BoxSize, double hubble_a2, const int32_t *d_queue, int64_t nq,
                             double *d_dmradius, double *d_vdisp, shq_sph_stats *stats);
 int shq_bh_veldisp_device(shq_context *ctx, const shq_kick_factors *kf, double BoxSize, const int32_t *d_queue, int64_t nq, double *d_out);

@@ -2255,6 +2255,130 @@ int shq_wind_veldisp_device(shq_context *ctx, const shq_kick_factors *kf, double
     return SHQ_OK;
 }
 
+/* ---- black-hole repositioning and dynamical-friction sums: bhdynfric.cpp:44-295 --------------------
+ * BHReposLocalTreeWalk::ngbiter (:160-174): the particle of lowest potential inside the hole's kernel radius (position and
+ * velocity kept; first one met in depth-first order on ties).  BHDynFricLocalTreeWalk::ngbiter (:193-224): the same plus the
+ * kernel-weighted mass, momentum (DM_VelPred) and squared velocity of the surrounding stars (and dark matter for method > 1).
+ * BHDynFricOutput::postprocess (:66-82) normalises.  The tree (ALLMASK, or STARMASK + BHMASK [+ DMMASK]) is the caller's. */
+struct BhDfArgs {
+    const double4 *vp_leaf;    /* DM_VelPred, weight: 1 if the particle counts for the friction sums */
+    const double4 *rv_leaf;    /* raw Vel, Potential */
+    double *out;               /* [nq][12]: MinPot, MinPotPos[3], MinPotVel[3], Density, Vel[3], RmsVel (raw sums) */
+    int dosums;
+};
+
+template <int KT>
+__global__ __launch_bounds__(256) void bh_dynfric_kernel(const SphDev a, const int32_t *queue, long long nq, const BhDfArgs da,
+                                                         int32_t *__restrict__ nlist, long long ntasks)
+{
+    __shared__ __attribute__((aligned(32))) char lds[4 * NW_LDS_PER_WAVE(false)];
+    const int lane = threadIdx.x & 63;
+    for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
+    const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    const long long t = wave * 64 + lane;
+    const bool valid = t < nq;
+    double px = 0, py = 0, pz = 0, h = 1;
+    if(valid) {
+        const long long pi = queue[t];
+        const double4 p = a.posm[pi];
+        px = p.x; py = p.y; pz = p.z;
+        h = a.hsml[pi];
+    }
+    const Kern<KT> kernel(h);
+    const double h2 = kernel.H * kernel.H, Hinv = 1.0 / kernel.H;
+    double minpot = 1.0e29 /* BHPOTVALUEINIT */, mp0 = -1, mp1 = -1, mp2 = -1, mv0 = 0, mv1 = 0, mv2 = 0;
+    double dens = 0, sv0 = 0, sv1 = 0, sv2 = 0, rms = 0;
+    auto pair = [&](const int s) {
+        const double4 q = a.posm_leaf[s];
+        const double4 rv = da.rv_leaf[s];
+        if(rv.w < minpot) {
+            minpot = rv.w;
+            mp0 = q.x; mp1 = q.y; mp2 = q.z;
+            mv0 = rv.x; mv1 = rv.y; mv2 = rv.z;
+        }
+        if(da.dosums) {
+            const double4 vp = da.vp_leaf[s];
+            if(vp.w != 0) {
+                const double d0 = wrapd(px - q.x, a.Box, a.invBox), d1 = wrapd(py - q.y, a.Box, a.invBox), d2 = wrapd(pz - q.z, a.Box, a.invBox);
+                const double u = sqrt(d0 * d0 + d1 * d1 + d2 * d2) * Hinv;
+                const double mw = q.w * kernel.wk(u);
+                dens += mw;
+                sv0 += mw * vp.x; rms += mw * (vp.x * vp.x);
+                sv1 += mw * vp.y; rms += mw * (vp.y * vp.y);
+                sv2 += mw * vp.z; rms += mw * (vp.z * vp.z);
+            }
+        }
+    };
+    auto accept = [&](const double r2, const double, const int) { return r2 < h2; };
+    int fill = 0;
+    bool ovf = false;
+    (void) ngb_walk<false, false, false>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(false), myl, valid, px, py, pz, kernel.H, accept, pair,
+                                         (unsigned int *) nullptr, fill, ovf);
+    if(valid) {
+        double *o = da.out + 12 * t;
+        o[0] = minpot; o[1] = mp0; o[2] = mp1; o[3] = mp2; o[4] = mv0; o[5] = mv1; o[6] = mv2;
+        o[7] = dens; o[8] = sv0; o[9] = sv1; o[10] = sv2; o[11] = rms;
+    }
+    } /* task loop */
+}
+
+__global__ void bh_dynfric_gather_kernel(long long nleaf, const int32_t *__restrict__ pidx, const double *__restrict__ vel,
+                                         const double *__restrict__ treeacc, const double *__restrict__ gravpm, const uint8_t *__restrict__ bin_grav,
+                                         const uint8_t *__restrict__ pflags, const double *__restrict__ potential, shq_kick_factors kf,
+                                         int typemask, int method, double4 *vp_leaf, double4 *rv_leaf, int32_t *flag_leaf)
+{
+#pragma clang fp contract(off)
+    const long long s = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(s >= nleaf)
+        return;
+    const long long p = pidx[s];
+    double v[3];
+    for(int j = 0; j < 3; j++)
+        v[j] = vel[3 * p + j] + kf.gravkicks[bin_grav[p]] * treeacc[3 * p + j] + gravpm[3 * p + j] * kf.FgravkickB;
+    const unsigned f = pflags[p];
+    const int type = f >> 4;
+    vp_leaf[s] = make_double4(v[0], v[1], v[2], (type == 4 || (type == 1 && method > 1)) ? 1.0 : 0.0);
+    rv_leaf[s] = make_double4(vel[3 * p], vel[3 * p + 1], vel[3 * p + 2], potential[p]);
+    flag_leaf[s] = ((f & 1u) || !((1 << type) & typemask)) ? 1 : 0;
+}
+
+int shq_bh_dynfric_device(shq_context *ctx, const shq_kick_factors *kf, double BoxSize, int kernel_type, int typemask, int method,
+                          const double *d_potential, const int32_t *d_queue, int64_t nq, double *d_out)
+{
+    if(nq == 0)
+        return SHQ_OK;
+    SHQ_CHECK(kernel_type == 1 || kernel_type == 2 || kernel_type == 4, SHQ_ERR_INVALID, "unknown DensityKernelType %d", kernel_type);
+    const long long nl = ctx->ntreeparts + SHQ_NMAXCHILD;
+    SHQ_TRY(ctx->velp_leaf.reserve(nl));
+    SHQ_TRY(ctx->hydrec_leaf.reserve((size_t) nl * sizeof(double4) + 128)); /* reused for the raw velocity + potential stream */
+    SHQ_TRY(ctx->flag_leaf.reserve(nl));
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    hipStream_t st = ctx->stream;
+    double4 *rv_leaf = reinterpret_cast<double4 *>(ctx->hydrec_leaf.ptr);
+    bh_dynfric_gather_kernel<<<dim3(nblk(nl)), dim3(256), 0, st>>>(nl, ctx->leaf_pidx.ptr, ctx->vel.ptr, ctx->treeacc.ptr, ctx->gravpm.ptr,
+                                                                  ctx->bin_grav.ptr, ctx->pflags.ptr, d_potential, *kf, typemask, method,
+                                                                  ctx->velp_leaf.ptr, rv_leaf, ctx->flag_leaf.ptr);
+    SHQ_HIP(hipGetLastError());
+    SphDev a = make_dev(ctx);
+    a.Box = BoxSize;
+    a.invBox = 1.0 / BoxSize;
+    BhDfArgs da;
+    da.vp_leaf = ctx->velp_leaf.ptr;
+    da.rv_leaf = rv_leaf;
+    da.out = d_out;
+    da.dosums = method > 0;
+    const long long ntasks = (nq + 255) / 256;
+    const unsigned grid = (unsigned) (ntasks < NL_REDO_BLOCKS ? ntasks : NL_REDO_BLOCKS);
+    switch(kernel_type) {
+    case 1: bh_dynfric_kernel<1><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, da, ctx->s_nlist2.ptr, ntasks); break;
+    case 2: bh_dynfric_kernel<2><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, da, ctx->s_nlist2.ptr, ntasks); break;
+    default: bh_dynfric_kernel<4><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, da, ctx->s_nlist2.ptr, ntasks); break;
+    }
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}
+
 int shq_sph_gradrho_mag(shq_context *ctx, double *d_out)
 {
     const long long n = ctx->numpart;

@@ -857,3 +857,72 @@ extern "C" int shq_wind_veldisp(shq_context *ctx, const shq_tree_view *tree, con
     }
     return SHQ_OK;
 }
+
+extern "C" int shq_bh_dynfric(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const int32_t *queue, int64_t nqueue,
+                              const shq_kick_factors *kf, int BH_DynFrictionMethod, int DensityKernelType, int typemask,
+                              const shq_bh_dynfric_out *out)
+{
+    SHQ_CHECK(ctx && tree && parts && kf && out && out->MinPot && out->MinPotPos && out->MinPotVel && (nqueue == 0 || queue), SHQ_ERR_INVALID,
+              "null argument");
+    SHQ_CHECK(ctx->sphrun.phase == 0, SHQ_ERR_STATE, "bh_dynfric: an SPH walk is open");
+    SHQ_CHECK(BH_DynFrictionMethod == 0 || (out->DF_SurroundingDensity && out->DF_SurroundingVel && out->DF_SurroundingRmsVel), SHQ_ERR_INVALID,
+              "bh_dynfric: the friction outputs are needed for BH_DynFrictionMethod > 0");
+    SHQ_CHECK(parts->off_vel != SHQ_NOFIELD && parts->off_hsml != SHQ_NOFIELD && parts->off_pi != SHQ_NOFIELD && parts->off_type != SHQ_NOFIELD &&
+                  parts->off_treeacc != SHQ_NOFIELD && parts->off_gravpm != SHQ_NOFIELD && parts->off_potential != SHQ_NOFIELD,
+              SHQ_ERR_INVALID, "bh_dynfric: the particle view needs Vel, Hsml, PI, Type, FullTreeGravAccel, GravPM and Potential");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t n = parts->numpart;
+    for(int64_t k = 0; k < nqueue; k++) {
+        const int32_t i = queue[k];
+        SHQ_CHECK(i >= 0 && i < n, SHQ_ERR_INVALID, "bh_dynfric: queue[%ld] = %d out of range", (long) k, i);
+        SHQ_CHECK(*pfield<uint8_t>(parts, i, parts->off_type) == 5, SHQ_ERR_INVALID, "bh_dynfric: particle %d in the queue is not a black hole", i);
+        SHQ_CHECK(*pfield<double>(parts, i, parts->off_hsml) > 0, SHQ_ERR_INVALID, "bh_dynfric: black hole %d has Hsml <= 0", i);
+    }
+    SHQ_TRY(shq_particles_upload(ctx, parts));
+    SHQ_TRY(shq_dynamics_upload(ctx, parts));
+    SHQ_TRY(shq_tree_upload(ctx, tree));
+    if(nqueue == 0)
+        return SHQ_OK;
+    const size_t cap = (size_t) std::max<int64_t>(n, 1);
+    SHQ_TRY(ctx->stage.reserve(sizeof(double) * cap + 256));
+    double *hp = reinterpret_cast<double *>(ctx->stage.ptr);
+    for(int64_t i = 0; i < n; i++)
+        hp[i] = *pfield<double>(parts, i, parts->off_potential);
+    SHQ_TRY(ctx->s_gradrho.reserve(cap + 12 * (size_t) nqueue));
+    double *d_pot = ctx->s_gradrho.ptr, *d_out = ctx->s_gradrho.ptr + cap;
+    SHQ_TRY(ctx->s_queue0.reserve((size_t) nqueue));
+    SHQ_HIP(hipMemcpyAsync(d_pot, hp, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    SHQ_HIP(hipMemcpyAsync(ctx->s_queue0.ptr, queue, sizeof(int32_t) * nqueue, hipMemcpyHostToDevice, ctx->stream));
+    SHQ_TRY(shq_bh_dynfric_device(ctx, kf, tree->BoxSize, DensityKernelType, typemask, BH_DynFrictionMethod, d_pot, ctx->s_queue0.ptr, nqueue, d_out));
+    std::vector<double> ho(12 * (size_t) nqueue);
+    SHQ_HIP(hipMemcpyAsync(ho.data(), d_out, sizeof(double) * 12 * nqueue, hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    for(int64_t q = 0; q < nqueue; q++) {
+        const int32_t pi = *pfield<int32_t>(parts, queue[q], parts->off_pi);
+        SHQ_CHECK(pi >= 0, SHQ_ERR_INVALID, "bh_dynfric: black hole %d has a negative slot index", queue[q]);
+        const double *o = &ho[12 * q];
+        if(out->MinPot[pi] > o[0]) { /* BHReposResult::reduce, bhdynfric.cpp:106-118 */
+            out->MinPot[pi] = o[0];
+            for(int d = 0; d < 3; d++) {
+                out->MinPotPos[pi][d] = o[1 + d];
+                out->MinPotVel[pi][d] = o[4 + d];
+            }
+            if(out->updated)
+                out->updated[pi] = 1;
+        }
+        if(BH_DynFrictionMethod > 0) { /* BHDynFricResult::reduce<PRIMARY> assigns, then postprocess (:66-82) */
+            const double dens = o[7];
+            out->DF_SurroundingDensity[pi] = dens;
+            double rms = o[11];
+            if(dens > 0) {
+                rms = sqrt(rms / dens);
+                for(int d = 0; d < 3; d++)
+                    out->DF_SurroundingVel[pi][d] = o[8 + d] / dens;
+            } else
+                for(int d = 0; d < 3; d++)
+                    out->DF_SurroundingVel[pi][d] = o[8 + d];
+            out->DF_SurroundingRmsVel[pi] = rms;
+        }
+    }
+    return SHQ_OK;
+}

@@ -86,6 +86,18 @@ def wind_veldisp(nodes, firstnode, st, queue, BoxSize, kf, Time, hubble):
     return rc, vd, dm, niter.value
 
 
+def bh_dynfric(nodes, firstnode, st, potential, queue, BoxSize, kf, method, kernel, typemask):
+    """bhdynfric.cpp treewalks: raw [nq, 12] results (MinPot, MinPotPos, MinPotVel, density, vel, rmsvel)."""
+    q = np.ascontiguousarray(queue, dtype=np.int32)
+    pot = np.ascontiguousarray(potential, dtype=np.float64)
+    out = np.zeros((len(q), 12))
+    lib.orc_bh_dynfric.argtypes = [_vp, C.c_int64, C.POINTER(OrcSphArrays), _vp, _vp, C.c_int64, C.c_double, _vp, C.c_int, C.c_int, C.c_int, _vp]
+    lib.orc_bh_dynfric.restype = None
+    lib.orc_bh_dynfric(ptr(nodes), firstnode, C.byref(st.c), ptr(pot), ptr(q), len(q), BoxSize, C.byref(kf), int(method), int(kernel), int(typemask),
+                       ptr(out))
+    return out
+
+
 class SphState:
     """SoA copy of the particle / slot state the oracle's SPH functions work on."""
 

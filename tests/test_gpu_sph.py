@@ -255,3 +255,43 @@ def test_wind_veldisp_matches_oracle(ctx):
     # a non-gas particle in the queue is refused
     bad = np.array([0], dtype=np.int32)
     assert capi.hip.shq_wind_veldisp(ctx.h, C.byref(tv), C.byref(pv), capi.ptr(bad), 1, C.byref(kf), Time, hubble, capi.ptr(vdisp), None) != 0
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_bh_dynfric_matches_oracle(ctx, method):
+    """shq_bh_dynfric (bhdynfric.cpp:44-295): the potential minimum (same particle as the oracle, depth-first tie-breaking),
+    its reduce into the caller's MinPot arrays, and the post-processed friction sums."""
+    import test_oracle_cpu as toc
+    pman, kf, nd, nbh = toc._bhs_in_stars_and_dm(n1=16, nbh=120, seed=30 + method)
+    P = pman.Base
+    mask = {0: sq.ALLMASK, 1: sq.STARMASK + sq.BHMASK, 2: sq.STARMASK + sq.BHMASK + sq.DMMASK}[method]
+    tree = sq.force_tree_rebuild_mask(pman, mask)
+    st = orc.SphState(P, np.zeros(1, dtype=sq.SPH_DTYPE))
+    queue = np.arange(nd, nd + nbh, dtype=np.int32)[::2].copy()
+    raw = orc.bh_dynfric(tree.Nodes_base, tree.firstnode, st, P["Potential"], queue, cm.BOX, kf, method, 2, mask)
+    slots = P["PI"][queue]
+    # blackhole_init_potential (:296-310): start from the hole's own potential and position; make half of them unbeatable
+    minpot = np.full(nbh, 1e29); minpos = np.zeros((nbh, 3)); minvel = np.zeros((nbh, 3)); upd = np.zeros(nbh, dtype=np.int32)
+    minpot[slots] = P["Potential"][queue]
+    minpos[slots] = P["Pos"][queue]
+    minpot[slots[::2]] = -1e30
+    want_pot, want_pos = minpot.copy(), minpos.copy()
+    better = raw[:, 0] < minpot[slots]
+    want_pot[slots[better]] = raw[better, 0]
+    want_pos[slots[better]] = raw[better, 1:4]
+    dens = np.full(nbh, np.nan); dvel = np.full((nbh, 3), np.nan); drms = np.full(nbh, np.nan)
+    out = capi.BhDynFricOut(capi.ptr(minpot), capi.ptr(minpos), capi.ptr(minvel), capi.ptr(upd), capi.ptr(dens), capi.ptr(dvel), capi.ptr(drms))
+    pv, tv = pman.view(), tree.view()
+    capi.check(capi.hip.shq_bh_dynfric(ctx.h, C.byref(tv), C.byref(pv), capi.ptr(queue), len(queue), C.byref(kf), method, 2, mask, C.byref(out)))
+    assert np.array_equal(minpot, want_pot) and np.array_equal(minpos, want_pos)
+    assert np.array_equal(np.nonzero(upd)[0], np.sort(slots[better])) and better.any() and (~better).any()
+    assert np.array_equal(minvel[slots[better]], raw[better, 4:7])
+    if method > 0:
+        d = raw[:, 7]
+        assert (d > 0).any()
+        assert np.abs(dens[slots] - d).max() < 1e-11 * d.max()
+        pos = d > 0
+        assert np.abs(dvel[slots][pos] - raw[pos, 8:11] / d[pos, None]).max() < 1e-9 * np.abs(raw[pos, 8:11] / d[pos, None]).max()
+        assert np.abs(drms[slots][pos] / np.sqrt(raw[pos, 11] / d[pos]) - 1).max() < 1e-11
+    else:
+        assert np.all(np.isnan(dens))

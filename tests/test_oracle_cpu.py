@@ -479,3 +479,50 @@ def test_wind_veldisp_oracle_against_brute_force():
             cands.append(np.sqrt(var / 3))
         assert any(np.isclose(vd[q], c, rtol=1e-9) for c in cands), (q, vd[q], cands)
         assert dm[q] > 0
+
+
+def _bhs_in_stars_and_dm(n1=14, nbh=50, seed=15):
+    pman, kf, nd, nbh = _bhs_in_dm(n1=n1, nbh=nbh, seed=seed)
+    P = pman.Base
+    rng = np.random.default_rng(seed + 1)
+    P["Type"][:nd] = rng.choice([0, 1, 4], size=nd, p=[0.2, 0.5, 0.3]).astype(np.uint8)
+    P["Mass"][:nd] = 1.0 + rng.random(nd)
+    P["Potential"] = rng.normal(size=len(P)) * 1e4
+    return pman, kf, nd, nbh
+
+
+def test_bh_dynfric_oracle_against_brute_force():
+    import shenqi_amd as sq
+    pman, kf, nd, nbh = _bhs_in_stars_and_dm()
+    P = pman.Base
+    n = len(P)
+    queue = np.arange(nd, nd + nbh, dtype=np.int32)
+    gk = np.array([kf.gravkicks[b] for b in P["TimeBinGravity"]])
+    vp = P["Vel"] + gk[:, None] * P["FullTreeGravAccel"] + P["GravPM"] * kf.FgravkickB
+    kout = np.zeros(5)
+    for method, mask in ((0, sq.ALLMASK), (1, sq.STARMASK + sq.BHMASK), (2, sq.STARMASK + sq.BHMASK + sq.DMMASK)):
+        tree = sq.force_tree_rebuild_mask(pman, mask)
+        st = orc.SphState(P, np.zeros(1, dtype=sq.SPH_DTYPE))
+        out = orc.bh_dynfric(tree.Nodes_base, tree.firstnode, st, P["Potential"], queue, cm.BOX, kf, method, 1, mask)
+        intree = ((1 << P["Type"].astype(np.int64)) & mask) != 0
+        intree &= (P["Flags"] & 1) == 0
+        for q, i in enumerate(queue[:25]):
+            d = P["Pos"][i] - P["Pos"]
+            d -= cm.BOX * np.rint(d / cm.BOX)
+            r = np.sqrt(np.sum(d * d, axis=1))
+            sel = np.nonzero((r < P["Hsml"][i]) & intree)[0]
+            j = sel[np.argmin(P["Potential"][sel])]
+            assert out[q, 0] == P["Potential"][j] and np.array_equal(out[q, 1:4], P["Pos"][j]) and np.array_equal(out[q, 4:7], P["Vel"][j])
+            if method > 0:
+                cnt = sel[(P["Type"][sel] == 4) | ((P["Type"][sel] == 1) & (method > 1))]
+                dens = 0.0
+                svel = np.zeros(3)
+                rms = 0.0
+                for jj in cnt:
+                    orc.lib.orc_density_kernel(1, P["Hsml"][i], r[jj] / P["Hsml"][i], 1.0, orc.ptr(kout))
+                    mw = P["Mass"][jj] * kout[2]
+                    dens += mw
+                    svel += mw * vp[jj]
+                    rms += mw * np.sum(vp[jj] ** 2)
+                assert np.isclose(out[q, 7], dens, rtol=1e-11) and np.allclose(out[q, 8:11], svel, rtol=1e-9, atol=1e-9 * abs(dens) * 1e3)
+                assert np.isclose(out[q, 11], rms, rtol=1e-11)
