@@ -12,6 +12,9 @@
 #include <string.h>
 #include <cstring>
 #include <vector>
+#include <atomic>
+#include <thread>
+#include <algorithm>
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 
@@ -239,25 +242,40 @@ extern "C" int shq_dynamics_upload(shq_context *ctx, const shq_part_view *parts)
     SHQ_HIP(hipSetDevice(ctx->device));
     const int64_t n = parts->numpart;
     const size_t cap = (size_t) (n > 0 ? n : 1);
-    std::vector<double> vel(3 * cap), hsml(cap, 0.0), dth(cap, 0.0);
-    std::vector<uint8_t> bg(cap, 0), bh(cap, 0);
-    int bad = 0;
-    for(int64_t i = 0; i < n; i++) {
-        const double *v = cfield<double>(parts, i, parts->off_vel);
-        vel[3 * i] = v[0];
-        vel[3 * i + 1] = v[1];
-        vel[3 * i + 2] = v[2];
-        if(parts->off_hsml != SHQ_NOFIELD)
-            hsml[i] = *cfield<double>(parts, i, parts->off_hsml);
-        if(parts->off_dthsml != SHQ_NOFIELD)
-            dth[i] = *cfield<double>(parts, i, parts->off_dthsml);
-        if(parts->off_timebin_gravity != SHQ_NOFIELD)
-            bg[i] = *cfield<uint8_t>(parts, i, parts->off_timebin_gravity);
-        if(parts->off_timebin_hydro != SHQ_NOFIELD)
-            bh[i] = *cfield<uint8_t>(parts, i, parts->off_timebin_hydro);
-        if(bg[i] > SHQ_TIMEBINS || bh[i] > SHQ_TIMEBINS)
-            bad |= 1;
+    /* packed by the host threads into the pinned staging buffer (5 doubles + 2 bytes per particle) */
+    SHQ_TRY(ctx->stage.reserve(cap * (5 * sizeof(double) + 2) + 256));
+    double *vel = reinterpret_cast<double *>(ctx->stage.ptr), *hsml = vel + 3 * cap, *dth = hsml + cap;
+    uint8_t *bg = reinterpret_cast<uint8_t *>(dth + cap), *bh = bg + cap;
+    std::atomic<int> badbin(0);
+    {
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = (nt == 0 || n < 65536) ? 1 : (nt > 32 ? 32 : nt);
+        const int64_t chunk = (n + nt - 1) / nt;
+        auto work = [&](int64_t lo, int64_t hi) {
+            for(int64_t i = lo; i < hi; i++) {
+                const double *v = cfield<double>(parts, i, parts->off_vel);
+                vel[3 * i] = v[0];
+                vel[3 * i + 1] = v[1];
+                vel[3 * i + 2] = v[2];
+                hsml[i] = parts->off_hsml != SHQ_NOFIELD ? *cfield<double>(parts, i, parts->off_hsml) : 0.0;
+                dth[i] = parts->off_dthsml != SHQ_NOFIELD ? *cfield<double>(parts, i, parts->off_dthsml) : 0.0;
+                bg[i] = parts->off_timebin_gravity != SHQ_NOFIELD ? *cfield<uint8_t>(parts, i, parts->off_timebin_gravity) : 0;
+                bh[i] = parts->off_timebin_hydro != SHQ_NOFIELD ? *cfield<uint8_t>(parts, i, parts->off_timebin_hydro) : 0;
+                if(bg[i] > SHQ_TIMEBINS || bh[i] > SHQ_TIMEBINS)
+                    badbin.store(1);
+            }
+        };
+        std::vector<std::thread> th;
+        for(unsigned t = 1; t < nt; t++) {
+            const int64_t lo = (int64_t) t * chunk, hi = std::min<int64_t>(n, lo + chunk);
+            if(lo < hi)
+                th.emplace_back(work, lo, hi);
+        }
+        work(0, std::min<int64_t>(n, chunk));
+        for(auto &x : th)
+            x.join();
     }
+    const int bad = badbin.load();
     SHQ_CHECK(!bad, SHQ_ERR_INVALID, "time bin out of range (TIMEBINS = %d)", SHQ_TIMEBINS);
     SHQ_TRY(ctx->vel.reserve(3 * cap));
     SHQ_TRY(ctx->hsml.reserve(cap));
@@ -266,11 +284,11 @@ extern "C" int shq_dynamics_upload(shq_context *ctx, const shq_part_view *parts)
     SHQ_TRY(ctx->bin_hydro.reserve(cap));
     SHQ_TRY(ctx->pm_oob.reserve(4));
     if(n > 0) {
-        SHQ_HIP(hipMemcpyAsync(ctx->vel.ptr, vel.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
-        SHQ_HIP(hipMemcpyAsync(ctx->hsml.ptr, hsml.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
-        SHQ_HIP(hipMemcpyAsync(ctx->dthsml.ptr, dth.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
-        SHQ_HIP(hipMemcpyAsync(ctx->bin_grav.ptr, bg.data(), n, hipMemcpyHostToDevice, ctx->stream));
-        SHQ_HIP(hipMemcpyAsync(ctx->bin_hydro.ptr, bh.data(), n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(ctx->vel.ptr, vel, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(ctx->hsml.ptr, hsml, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(ctx->dthsml.ptr, dth, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(ctx->bin_grav.ptr, bg, (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+        SHQ_HIP(hipMemcpyAsync(ctx->bin_hydro.ptr, bh, (size_t) n, hipMemcpyHostToDevice, ctx->stream));
     }
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     ctx->have_dyn = true;
