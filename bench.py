@@ -323,7 +323,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    if world > 1 or os.environ.get("SHQ_COMM_FORCE", "0") == "1":   # the latter: one-rank RCCL rehearsal (needs MASTER_ADDR/PORT)
         return run_sharded(args, rank, local_rank, world)
     dist = None
 

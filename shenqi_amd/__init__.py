@@ -64,7 +64,7 @@ class PartManager:
         self._h = capi.host.shqh_partmanager_create(capi.ptr(self.Base), self.NumPart, self.BoxSize)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and capi is not None:   # capi is None when the interpreter is shutting down
             capi.host.shqh_partmanager_free(self._h)
             self._h = None
 

@@ -39,6 +39,9 @@ class Comm:
         self.rank = dist.get_rank(group) if self.on else 0
         self.size = dist.get_world_size(group) if self.on else 1
         self.backend = dist.get_backend(group) if self.on else "none"
+        # SHQ_COMM_FORCE=1: a one-rank group still goes through the collectives (particle / ghost exchange, the two
+        # mesh transposes, the scalar all-reduce): rehearses the RCCL calls of an N-GPU run on a one-GPU box.
+        self.multi = self.size > 1 or (self.on and os.environ.get("SHQ_COMM_FORCE", "0") == "1")
 
     def _stage(self, t):
         """gloo cannot move device tensors: stage through the host (tests only)."""
@@ -46,27 +49,43 @@ class Comm:
             return t.cpu(), t.device
         return t, None
 
+    # RCCL moved a single 3.6 GB peer message wrongly (768^3 spectrum of a one-rank rehearsal: PM force off by 10^2 while
+    # the same code is exact at 48^3); messages are therefore kept below 1 GiB: larger ones go as K row-chunked rounds.
+    MAX_MSG_BYTES = int(os.environ.get("SHQ_COMM_MAX_MSG", str(1 << 30)))   # the tests lower it to reach the chunked rounds
+
     def all_to_all_rows(self, send, send_counts):
         """Variable all-to-all of the rows of a 2-D+ tensor: rows [sum(c[:d]), sum(c[:d+1])) go to rank d.
         Returns (recv, recv_counts)."""
-        if self.size == 1:
+        if not self.multi:
             return send, list(send_counts)
-        cnt = torch.tensor(send_counts, dtype=torch.int64)
+        cplx = send.is_complex()
+        s, dev = self._stage(torch.view_as_real(send.contiguous()) if cplx else send.contiguous())
+        row_bytes = (s[0].numel() if s.shape[0] else int(np.prod(s.shape[1:]))) * s.element_size()
+        # counts and the largest message any rank sends travel together, so that every rank derives the same K
+        cnt = torch.tensor([[c, max(send_counts) * row_bytes] for c in send_counts], dtype=torch.int64)
         rcnt = torch.empty_like(cnt)
         cdev = send.device if self.backend == "nccl" else torch.device("cpu")
         cnt_d, rcnt_d = cnt.to(cdev), rcnt.to(cdev)
         dist.all_to_all_single(rcnt_d, cnt_d, group=self.group)
-        recv_counts = [int(x) for x in rcnt_d.cpu()]
-        cplx = send.is_complex()
-        s, dev = self._stage(torch.view_as_real(send.contiguous()) if cplx else send.contiguous())
+        rc = rcnt_d.cpu()
+        recv_counts = [int(x) for x in rc[:, 0]]
+        K = max(1, -(-int(rc[:, 1].max()) // self.MAX_MSG_BYTES)) if self.backend == "nccl" else 1
         r = torch.empty((sum(recv_counts),) + tuple(s.shape[1:]), dtype=s.dtype, device=s.device)
-        dist.all_to_all_single(r, s, output_split_sizes=recv_counts, input_split_sizes=list(send_counts), group=self.group)
+        if K == 1:
+            dist.all_to_all_single(r, s, output_split_sizes=recv_counts, input_split_sizes=list(send_counts), group=self.group)
+        else:
+            soff = np.concatenate([[0], np.cumsum(send_counts)])
+            roff = np.concatenate([[0], np.cumsum(recv_counts)])
+            for k in range(K):   # chunk k of every peer segment: rows [c k / K, c (k + 1) / K) of its c rows, views, no copies
+                ins = [s[soff[d] + send_counts[d] * k // K:soff[d] + send_counts[d] * (k + 1) // K] for d in range(self.size)]
+                outs = [r[roff[d] + recv_counts[d] * k // K:roff[d] + recv_counts[d] * (k + 1) // K] for d in range(self.size)]
+                dist.all_to_all(outs, ins, group=self.group)
         r = r.to(dev) if dev is not None else r
         return (torch.view_as_complex(r) if cplx else r), recv_counts
 
     def all_to_all_equal(self, send):
         """Equal-split all-to-all along dim 0 (dim 0 must be a multiple of size)."""
-        if self.size == 1:
+        if not self.multi:
             return send
         cplx = send.is_complex()
         s, dev = self._stage(torch.view_as_real(send.contiguous()) if cplx else send.contiguous())
@@ -77,7 +96,7 @@ class Comm:
 
     def shift(self, t, direction):
         """Send `t` to rank + direction (periodic), receive the same-shaped tensor from rank - direction."""
-        if self.size == 1:
+        if not self.multi:
             return t.clone()
         dst = (self.rank + direction) % self.size
         counts = [0] * self.size
@@ -86,7 +105,7 @@ class Comm:
         return recv
 
     def allreduce_sum(self, x):
-        if self.size == 1:
+        if not self.multi:
             return x
         t = torch.tensor([x], dtype=torch.float64)
         if self.backend == "nccl":
@@ -172,7 +191,7 @@ def exchange_to_owner(comm, decomp, posm):
 def ghost_exchange(comm, decomp, posm, halo):
     """Import every other rank's particles within `halo` (periodic) of this rank's slab.  Returns
     the ghost rows (x, y, z, m) in source-rank order; a particle goes at most once to a rank."""
-    if comm.size == 1:
+    if not comm.multi:
         return posm[:0]
     L = decomp.L
     x = posm[:, 0]
@@ -216,6 +235,7 @@ class SlabPM:
         ops = self.ops
         zp = ops.pitch()
         zpc = zp // 2
+        multi = c.multi   # SHQ_COMM_FORCE: one rank keeps its periodic geometry but still runs the transposes as collectives
         xoff, nalloc = (0, N) if P == 1 else (2, nxl + 5)
         buf = ops.mesh_buffer(nalloc, N, zp)                               # int64 [nalloc, N, zp]
         ops.deposit2(buf, self.d.plane0, nxl, xoff, nalloc)
@@ -226,14 +246,14 @@ class SlabPM:
         ops.fft_yz(own, nxl, 0)
         spec = own.view(torch.float64).view(torch.complex128)               # [nxl, N, zpc]
         nyl = N // P
-        if P > 1:
+        if multi:
             send = spec.reshape(nxl, P, nyl, zpc).permute(1, 0, 2, 3).reshape(P * nxl, nyl, zpc)   # rows [dest q][x_l]
             spec_t, _ = c.all_to_all_rows(send, [nxl] * P)                                         # [x (all)][y_l][z']
             spec_t = spec_t.contiguous()
         else:
             spec_t = spec
         ops.xgreen(spec_t, c.rank * nyl, nyl)
-        if P > 1:
+        if multi:
             recv, _ = c.all_to_all_rows(spec_t, self.d.widths)                                     # rows [src q][x_l]
             spec.copy_(recv.reshape(P, nxl, nyl, zpc).permute(1, 0, 2, 3).reshape(nxl, N, zpc))
         ops.fft_yz(own, nxl, 1)

@@ -53,9 +53,16 @@ def _run_rank(rank, world, outdir):
     ctx.close()
 
 
-def _worker(rank, world, initfile, outdir):
+def _worker(rank, world, initfile, outdir, backend="gloo"):
     os.environ["OMP_NUM_THREADS"] = "2"
-    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    if backend == "nccl":
+        os.environ["SHQ_COMM_FORCE"] = "1"
+        os.environ["SHQ_COMM_MAX_MSG"] = "300000"   # the 48 x 48 x 25 spectrum is 0.9 MB: sent as 4 row-chunked rounds
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method="file://" + initfile, rank=rank, world_size=world,
+                                device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, init_method="file://" + initfile, rank=rank, world_size=world)
     try:
         _run_rank(rank, world, outdir)
     finally:
@@ -111,3 +118,11 @@ def test_dist_driver_two_gloo_ranks_one_gpu():
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker, args=(2, os.path.join(tmp, "init"), tmp), nprocs=2, join=True)
         _check(tmp, 2)
+
+
+def test_dist_driver_one_rccl_rank_collectives_forced():
+    """The RCCL calls of the N-GPU run (device-side all_to_all_single of particle rows and of the complex mesh
+    transposes, the scalar all-reduce) on the one GPU there is: a one-rank nccl group with SHQ_COMM_FORCE=1."""
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(1, os.path.join(tmp, "init"), tmp, "nccl"), nprocs=1, join=True)
+        _check(tmp, 1)
