@@ -230,6 +230,10 @@ def run_sharded(args, rank, local_rank, world):
     # SHQ_BENCH_BACKEND=gloo is a rehearsal knob for the one-GPU box: every rank shares device 0 and the
     # exchanges are staged through the host.  The driver's runs use nccl (= RCCL), one GPU per rank.
     backend = os.environ.get("SHQ_BENCH_BACKEND", "nccl")
+    # RCCL prints a version banner on stdout when its communicator comes up: everything but the one JSON line goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     devidx = local_rank if backend == "nccl" else 0
     torch.cuda.set_device(devidx)
     dev = torch.device("cuda", devidx)
@@ -314,8 +318,10 @@ def run_sharded(args, rank, local_rank, world):
     ctx.close()
     dist.barrier()
     dist.destroy_process_group()
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 def main():
@@ -326,6 +332,9 @@ def main():
     if world > 1 or os.environ.get("SHQ_COMM_FORCE", "0") == "1":   # the latter: one-rank RCCL rehearsal (needs MASTER_ADDR/PORT)
         return run_sharded(args, rank, local_rank, world)
     dist = None
+    sys.stdout.flush()   # stdout carries the one JSON line only; anything a library prints goes to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import shenqi_amd as sq
     from shenqi_amd import capi
@@ -570,8 +579,10 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":
