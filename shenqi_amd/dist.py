@@ -156,18 +156,21 @@ class SlabDecomp:
         return self.bounds[r] * self.cell, self.bounds[r + 1] * self.cell
 
 
-def balanced_bounds(comm, Nmesh, BoxSize, x):
-    """Plane boundaries giving every rank about the same number of particles (x: positions held by
-    this rank, any distribution).  One all-reduce of an Nmesh-long histogram."""
+def balanced_bounds(comm, Nmesh, BoxSize, x, weights=None, plane_cost=0.0):
+    """Plane boundaries giving every rank about the same share of the work (x: positions held by this rank, any
+    distribution).  Work of a plane = the sum of `weights` over its particles (1 each when None: equal counts) +
+    `plane_cost` (what a mesh plane costs whoever owns it, in the units of the weights).  One all-reduce of an
+    Nmesh-long histogram."""
     P = comm.size
     cell = BoxSize / Nmesh
     plane = (torch.floor(x / cell).to(torch.int64) % Nmesh).cpu()
-    hist = torch.bincount(plane, minlength=Nmesh).to(torch.float64)
+    w = None if weights is None else torch.as_tensor(weights).to(torch.float64).cpu()
+    hist = torch.bincount(plane, weights=w, minlength=Nmesh).to(torch.float64)
     if P > 1:
         h = hist.cuda() if comm.backend == "nccl" else hist
         dist.all_reduce(h, group=comm.group)
         hist = h.cpu()
-    cum = torch.cumsum(hist, 0).numpy()
+    cum = torch.cumsum(hist + float(plane_cost), 0).numpy()
     total = cum[-1]
     bounds = [0]
     for r in range(1, P):
@@ -177,6 +180,26 @@ def balanced_bounds(comm, Nmesh, BoxSize, x):
         bounds.append(b)
     bounds.append(Nmesh)
     return bounds
+
+
+# Cost model of one force step on an MI355X, from the one-GPU bench: the walk takes 39.5 ms for 8.5e9 interactions,
+# deposit + readout 4.2 ms for 1.7e7 particles, the four (y, z) FFT passes 7.9 ms for 768^3 cells.
+COST_MS_PER_INTERACTION = 39.5 / 8.5e9
+COST_MS_PER_PARTICLE = 4.2 / 16777216
+COST_MS_PER_CELL = 7.9 / 768.0**3
+
+
+def cost_balanced_bounds(comm, drv):
+    """Slab boundaries that even out the measured work instead of the particle count: every local particle weighs its
+    interaction count of the last walk (plus its deposit / readout), every mesh plane its share of the (y, z) passes.
+    The reference balances its domains the same way, by the work counted in the previous step (domain.cpp:620-700,
+    GravCost).  Call after a drv.step(); all ranks get the same list."""
+    n = int(drv.allp.shape[0])
+    nint = np.zeros(n, dtype=np.int64)
+    capi.check(capi.hip.shq_grav_short_download(drv.ctx.h, None, None, capi.ptr(nint), None))
+    w = COST_MS_PER_INTERACTION * nint[: drv.nloc].astype(np.float64) + COST_MS_PER_PARTICLE
+    return balanced_bounds(comm, drv.N, drv.L, drv.local[:, 0], weights=torch.from_numpy(w),
+                           plane_cost=COST_MS_PER_CELL * float(drv.N) ** 2)
 
 
 def exchange_to_owner(comm, decomp, posm):

@@ -123,3 +123,30 @@ def test_slab_pm_and_ghost_tree_gloo(world, balanced):
         rms = np.sqrt(num / den)
         print("world %d balanced %s: sharded tree vs monolithic rms |dF|/|F| = %.3e" % (world, balanced, rms))
         assert rms < 1e-3
+
+
+def _weights_worker(rank, world, initfile):
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        from shenqi_amd import dist as sd
+        comm = sd.Comm()
+        N, L = 64, 1.0
+        rng = np.random.default_rng(5 + rank)
+        x = torch.from_numpy(rng.random(20000) * L)
+        # unit weights = the count balance; uniform particles split the planes evenly
+        assert sd.balanced_bounds(comm, N, L, x) == sd.balanced_bounds(comm, N, L, x, weights=torch.ones(20000))
+        b = sd.balanced_bounds(comm, N, L, x)
+        assert abs(b[1] - N // 2) <= 2
+        # particles of the left half weigh three times as much: the cut moves to the plane splitting the weight in halves
+        w = torch.where(x < 0.5 * L, 3.0, 1.0)
+        bw = sd.balanced_bounds(comm, N, L, x, weights=w)
+        assert abs(bw[1] - N // 3) <= 2, bw      # 3 t = (3 / 2 + 1 / 2) / 2 -> t = 1 / 3 of the box
+        # a plane cost that dwarfs the particle work brings back equal widths
+        assert sd.balanced_bounds(comm, N, L, x, weights=w, plane_cost=1e9) == [0, N // 2, N]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_balanced_bounds_weighted_gloo():
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_weights_worker, args=(2, os.path.join(tmp, "init")), nprocs=2, join=True)
