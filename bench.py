@@ -224,6 +224,10 @@ def c3_step(ctx, gas_pos, n1, density_ms, hydro_ms):
 
 def run_sharded(args, rank, local_rank, world):
     """N > 1: one rank per GPU over RCCL; x-slab sharded TreePM (shenqi_amd/dist.py)."""
+    # torchrun exports OMP_NUM_THREADS=1 when the variable is unset; the host side (Hilbert order, tree hand-over) is threaded:
+    # give every rank its share of the node's cores (must happen before anything loads libgomp)
+    if os.environ.get("OMP_NUM_THREADS", "1") == "1":
+        os.environ["OMP_NUM_THREADS"] = str(max(1, len(os.sched_getaffinity(0)) // max(1, world)))
     import torch
     import torch.distributed as dist
 
@@ -242,10 +246,6 @@ def run_sharded(args, rank, local_rank, world):
         dist.init_process_group("nccl", device_id=dev)
     else:
         dist.init_process_group(backend)
-    # torchrun exports OMP_NUM_THREADS=1 when the variable is unset; the host side (Hilbert order, tree hand-over) is threaded:
-    # give every rank its share of the node's cores (must happen before the host library loads libgomp)
-    if os.environ.get("OMP_NUM_THREADS", "1") == "1":
-        os.environ["OMP_NUM_THREADS"] = str(max(1, len(os.sched_getaffinity(0)) // max(1, world)))
     import shenqi_amd as sq
     from shenqi_amd import capi, dist as sd
 
@@ -304,6 +304,10 @@ def run_sharded(args, rank, local_rank, world):
     tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
+    # the timed steps cut the walk in two pieces around the mesh transposes; the per-rank walk figures below come from one
+    # more, untimed step with the walk as a single launch
+    drv.step(gp_rel, overlap=False)
+    ctx.synchronize()
     st = sq.WalkStats()
     capi.check(capi.hip.shq_grav_short_download(ctx.h, None, None, None, C.byref(st)))
     loads = torch.tensor([float(drv.nloc), float(drv.nghost), st.kernel_ms], device=cdev, dtype=torch.float64)

@@ -284,6 +284,12 @@ int shq_dynamics_download(shq_context *ctx, const shq_part_view *parts);
 /* active: host int32 list or NULL. The walk and postprocess are queued on the stream. */
 int shq_grav_short_run(shq_context *ctx, const shq_grav_params *params, const int32_t *active,
                        int64_t nactive, int update_potential, int walk_mode);
+/* The same walk + postprocess for the own particles [first, first + count) without a list: a piece of the work-set
+ * TreeWalk::run_on_queue (libgadget/treewalk2.h:282-330) is given.  The pieces of one evaluation must start at first = 0 and
+ * together cover what shq_grav_short_run(active = NULL) covers; their interaction statistics add up (kernel_ms is the last
+ * piece's).  Lets the caller queue other work on the stream between the pieces. */
+int shq_grav_short_run_range(shq_context *ctx, const shq_grav_params *params, int64_t first, int64_t count,
+                             int update_potential, int walk_mode);
 /* Copy results back: accel[numpart][3] (may be NULL), potential[numpart] (may be NULL),
  * ninteractions[numpart] (may be NULL). Synchronises. */
 /* Wave-level walk counters in shq_walk_stats (nnodes_visited, nwave_*, nnode_interactions): 0 off (default: they stay

@@ -722,6 +722,25 @@ extern "C" int shq_grav_short_run(shq_context *ctx, const shq_grav_params *param
     return SHQ_OK;
 }
 
+/* The particles [first, first + count) as targets, no list: lets a caller cut one walk into pieces it interleaves with other
+ * work on the stream (shenqi_amd/dist.py starts a mesh transpose between the pieces). */
+extern "C" int shq_grav_short_run_range(shq_context *ctx, const shq_grav_params *params, int64_t first, int64_t count,
+                                        int update_potential, int walk_mode)
+{
+    SHQ_CHECK(ctx && params, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "grav_short_run_range: upload particles and tree first");
+    const int64_t nown = ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart;
+    SHQ_CHECK(first >= 0 && count >= 0 && first + count <= nown, SHQ_ERR_INVALID, "grav_short_run_range: [%ld, +%ld) outside the %ld own particles",
+              (long) first, (long) count, (long) nown);
+    SHQ_CHECK((walk_mode & ~0xff) == 0, SHQ_ERR_INVALID, "grav_short_run_range: walk_mode flags are not supported");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_launch_grav_walk(ctx, params, nullptr, count, update_potential, walk_mode, first));
+    SHQ_TRY(shq_launch_grav_postprocess(ctx, params, nullptr, count, update_potential, first));
+    ctx->grav_raw = false;
+    ctx->last_stats.ntargets = first == 0 ? count : ctx->last_stats.ntargets + count;
+    return SHQ_OK;
+}
+
 namespace {
 /* one thread per entry; the first entry of a run of equal places adds the whole run in order */
 __global__ void grav_reduce_kernel(long long n, const int32_t *__restrict__ place, const shq_grav_result *__restrict__ res, double *acc,

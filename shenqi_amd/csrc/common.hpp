@@ -331,10 +331,12 @@ int shq_join_pm(shq_context *ctx);
 /* Device pointer and length of an active list argument of the C-ABI: NULL (all n_all), a host list
  * (uploaded), or one of the SHQ_ACTIVE_RESIDENT / SHQ_SUBLIST_RESIDENT handles. dynamics.hip */
 int shq_resolve_active(shq_context *ctx, const int32_t *active, int64_t nactive, int64_t n_all, const int32_t **d_active, int64_t *nt);
+/* first: with d_active == NULL the targets are the particles [first, first + ntargets) (the per-particle arrays are handed to
+ * the kernels shifted by `first`); a range with first > 0 adds to the interaction statistics of the ranges before it */
 int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active,
-                         int64_t ntargets, int update_potential, int walk_mode);
+                         int64_t ntargets, int update_potential, int walk_mode, int64_t first = 0);
 int shq_launch_grav_postprocess(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active,
-                                int64_t ntargets, int update_potential);
+                                int64_t ntargets, int update_potential, int64_t first = 0);
 int shq_launch_oldacc(shq_context *ctx, double G);
 int shq_launch_grav_walk_ghosts(shq_context *ctx, const shq_grav_params *p, const double4 *d_qpos, const double *d_qoldacc,
                                 const int32_t *d_qstart, int64_t nq, double *d_acc, double *d_pot, int32_t *d_nint, int update_potential);

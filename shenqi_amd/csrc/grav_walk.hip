@@ -545,8 +545,10 @@ int shq_launch_grav_walk_ghosts(shq_context *ctx, const shq_grav_params *p, cons
 }
 
 int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets,
-                         int update_potential, int walk_mode)
+                         int update_potential, int walk_mode, int64_t first)
 {
+    SHQ_CHECK(first >= 0 && (first == 0 || !d_active) && first + ntargets <= ctx->numpart, SHQ_ERR_INVALID,
+              "grav walk: bad target range [%ld, +%ld)", (long) first, (long) ntargets);
     SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "grav walk: particles and tree must be uploaded first");
     SHQ_CHECK(walk_mode == SHQ_WALK_EXACT, SHQ_ERR_INVALID, "unknown walk_mode %d", walk_mode);
     SHQ_CHECK(p->ForceSoftening > 0 && p->cellsize > 0 && p->dx > 0, SHQ_ERR_INVALID, "grav params: softening/cellsize/dx must be > 0");
@@ -556,7 +558,8 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     SHQ_HIP(hipMemcpyAsync(ctx->gravtab.ptr, p->shortrange_table, sizeof(float) * SHQ_NGRAVTAB, hipMemcpyHostToDevice, ctx->stream));
     SHQ_HIP(hipMemcpyAsync(ctx->gravtab.ptr + SHQ_NGRAVTAB, p->shortrange_table_potential, sizeof(float) * SHQ_NGRAVTAB,
                            hipMemcpyHostToDevice, ctx->stream));
-    stats_init_kernel<<<1, 1, 0, ctx->stream>>>(ctx->gstats.ptr);
+    if(first == 0)
+        stats_init_kernel<<<1, 1, 0, ctx->stream>>>(ctx->gstats.ptr);
     if(ntargets == 0)
         return SHQ_OK;
 
@@ -564,6 +567,12 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     fill_walk_args(ctx, p, a);
     a.targets = d_active;
     a.ntargets = ntargets;
+    /* a range of targets: target t of the launch is particle first + t (the leaf copies and the tree are not indexed by target) */
+    a.posm += first;
+    a.oldacc += first;
+    a.acc += 3 * first;
+    a.pot += first;
+    a.nint += first;
 
     /* 4 waves per workgroup: measured 86.9 / 55.4 / 46.7 / 50.5 ms for 64 / 128 / 256 / 512 threads (the LDS window
      * table is per workgroup; larger groups wait for their slowest wave) */
@@ -598,15 +607,15 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
 }
 
 int shq_launch_grav_postprocess(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets,
-                                int update_potential)
+                                int update_potential, int64_t first)
 {
     if(ntargets == 0)
         return SHQ_OK;
     const int threads = 256;
     const long long blocks = (ntargets + threads - 1) / threads;
     grav_postprocess_kernel<<<dim3((unsigned) blocks), dim3(threads), 0, ctx->stream>>>(
-        d_active, ntargets, ctx->posm.ptr, ctx->acc.ptr, ctx->pot.ptr, ctx->treeacc.ptr, p->G, p->ForceSoftening,
-        p->cbrtrho0, update_potential);
+        d_active, ntargets, ctx->posm.ptr + first, ctx->acc.ptr + 3 * first, ctx->pot.ptr + first, ctx->treeacc.ptr + 3 * first, p->G,
+        p->ForceSoftening, p->cbrtrho0, update_potential);
     SHQ_HIP(hipGetLastError());
     return SHQ_OK;
 }

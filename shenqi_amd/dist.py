@@ -30,6 +30,27 @@ import torch.distributed as dist
 from . import capi
 
 
+class _Done:
+    def __init__(self, recv):
+        self.recv = recv
+
+    def wait(self):
+        return self.recv
+
+
+class _Pending:
+    """A started all-to-all: keeps the buffers alive until the communicator's stream is done with them."""
+
+    def __init__(self, works, send, recv, cplx):
+        self.works, self.send, self.recv, self.cplx = works, send, recv, cplx
+
+    def wait(self):
+        for w in self.works:
+            w.wait()           # the current stream waits for the communicator's; the host does not block
+        self.send = None
+        return torch.view_as_complex(self.recv) if self.cplx else self.recv
+
+
 class Comm:
     """Thin wrapper over torch.distributed for the exchanges the path needs."""
 
@@ -82,6 +103,33 @@ class Comm:
                 dist.all_to_all(outs, ins, group=self.group)
         r = r.to(dev) if dev is not None else r
         return (torch.view_as_complex(r) if cplx else r), recv_counts
+
+    def all_to_all_rows_start(self, send, send_counts, recv_counts):
+        """all_to_all_rows with the receive counts known to the caller (the mesh transposes), started without waiting:
+        returns a handle whose wait() gives the received rows.  Over RCCL the rounds run on the communicator's stream and
+        the caller may queue independent kernels in the meantime; the other backends complete here."""
+        if not self.multi or self.backend != "nccl":
+            recv, _ = self.all_to_all_rows(send, send_counts)
+            return _Done(recv)
+        cplx = send.is_complex()
+        s = torch.view_as_real(send.contiguous()) if cplx else send.contiguous()
+        row_bytes = int(np.prod(s.shape[1:])) * s.element_size()
+        # every rank sees the same counts matrix through (send_counts, recv_counts) only if the caller's counts are global
+        # knowledge (slab widths): K follows from the largest width, which all ranks know
+        K = max(1, -(-max(max(send_counts), max(recv_counts)) * row_bytes // self.MAX_MSG_BYTES))
+        r = torch.empty((sum(recv_counts),) + tuple(s.shape[1:]), dtype=s.dtype, device=s.device)
+        works = []
+        if K == 1:
+            works.append(dist.all_to_all_single(r, s, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts),
+                                                group=self.group, async_op=True))
+        else:
+            soff = np.concatenate([[0], np.cumsum(send_counts)])
+            roff = np.concatenate([[0], np.cumsum(recv_counts)])
+            for k in range(K):
+                ins = [s[soff[d] + send_counts[d] * k // K:soff[d] + send_counts[d] * (k + 1) // K] for d in range(self.size)]
+                outs = [r[roff[d] + recv_counts[d] * k // K:roff[d] + recv_counts[d] * (k + 1) // K] for d in range(self.size)]
+                works.append(dist.all_to_all(outs, ins, group=self.group, async_op=True))
+        return _Pending(works, s, r, cplx)
 
     def all_to_all_equal(self, send):
         """Equal-split all-to-all along dim 0 (dim 0 must be a multiple of size)."""
@@ -243,13 +291,18 @@ class SlabPM:
         self.N, self.L, self.Asmth, self.G = Nmesh, BoxSize, Asmth, G
         self.d = SlabDecomp(comm, Nmesh, BoxSize, bounds)
 
-    def force(self):
-        """Runs one PM step for the particles loaded in `ops`; results stay in ops (gravpm, potential)."""
+    def force(self, hooks=()):
+        """Runs one PM step for the particles loaded in `ops`; results stay in ops (gravpm, potential).
+        hooks: up to two callables that queue work independent of the PM (pieces of the tree walk); the bespoke pipeline
+        calls them right after starting its first and its second mesh transpose, so that work runs while the spectrum
+        travels."""
         if getattr(self.ops, "pitch", None) is not None and self.ops.pitch() > 0 and os.environ.get("SHQ_SLAB_TORCH_FFT", "0") != "1":
-            return self._force_bespoke()
-        return self._force_torch()
+            return self._force_bespoke(list(hooks))
+        self._force_torch()
+        for h in hooks:
+            h()
 
-    def _force_bespoke(self):
+    def _force_bespoke(self, hooks=()):
         """The slab pipeline on the library's own FFT passes (csrc/fft3d.hip): ONE buffer [nalloc][N][zp] is the
         int64 deposit mesh, the (y, z) half spectrum and the potential, ghost planes in place; the blocks the
         all-to-all delivers are transformed along x as they are (x slowest), fused with the Green's function.
@@ -269,16 +322,28 @@ class SlabPM:
         ops.fft_yz(own, nxl, 0)
         spec = own.view(torch.float64).view(torch.complex128)               # [nxl, N, zpc]
         nyl = N // P
+        hooks = list(hooks) + [None, None]
         if multi:
             send = spec.reshape(nxl, P, nyl, zpc).permute(1, 0, 2, 3).reshape(P * nxl, nyl, zpc)   # rows [dest q][x_l]
-            spec_t, _ = c.all_to_all_rows(send, [nxl] * P)                                         # [x (all)][y_l][z']
-            spec_t = spec_t.contiguous()
+            pend = c.all_to_all_rows_start(send, [nxl] * P, self.d.widths)                         # [x (all)][y_l][z']
+            del send
+            if hooks[0]:
+                hooks[0]()
+            spec_t = pend.wait().contiguous()
         else:
+            if hooks[0]:
+                hooks[0]()
             spec_t = spec
         ops.xgreen(spec_t, c.rank * nyl, nyl)
         if multi:
-            recv, _ = c.all_to_all_rows(spec_t, self.d.widths)                                     # rows [src q][x_l]
+            pend = c.all_to_all_rows_start(spec_t, self.d.widths, [nxl] * P)                       # rows [src q][x_l]
+            if hooks[1]:
+                hooks[1]()
+            recv = pend.wait()
             spec.copy_(recv.reshape(P, nxl, nyl, zpc).permute(1, 0, 2, 3).reshape(nxl, N, zpc))
+            del recv, pend
+        elif hooks[1]:
+            hooks[1]()
         ops.fft_yz(own, nxl, 1)
         phi = buf.view(torch.float64)
         if P > 1:
@@ -456,11 +521,24 @@ class DistTreePM:
         self.nghost = int(ghosts.shape[0])
         self.ops.set_particles(self.allp, self.nloc)
 
-    def step(self, gp, update_potential=1, walk_mode=0):
-        """One force evaluation: ghost import, PM, walk for the local targets, OldAcc refresh."""
+    def step(self, gp, update_potential=1, walk_mode=0, overlap=None):
+        """One force evaluation: ghost import, PM, walk for the local targets, OldAcc refresh.
+        overlap (default: whenever the transposes are collectives; SHQ_DIST_OVERLAP=0 turns it off): the walk does not need
+        the PM result of its own step (OldAcc is the previous step's), so it is cut in two pieces that are queued behind the
+        start of the two mesh transposes: the walk computes while the spectrum travels over xGMI."""
         self._load_particles()
-        self.pm.force()
-        capi.check(capi.hip.shq_grav_short_run(self.ctx.h, C.byref(gp), None, 0, int(update_potential), walk_mode))
+        if overlap is None:
+            overlap = self.comm.multi and os.environ.get("SHQ_DIST_OVERLAP", "1") != "0"
+        if overlap and self.nloc >= 512:
+            half = (self.nloc // 2) // 256 * 256
+
+            def piece(first, count):
+                return lambda: capi.check(capi.hip.shq_grav_short_run_range(self.ctx.h, C.byref(gp), first, count,
+                                                                           int(update_potential), walk_mode))
+            self.pm.force([piece(0, half), piece(half, self.nloc - half)])
+        else:
+            self.pm.force()
+            capi.check(capi.hip.shq_grav_short_run(self.ctx.h, C.byref(gp), None, 0, int(update_potential), walk_mode))
         capi.check(capi.hip.shq_grav_refresh_oldacc(self.ctx.h, self.G))
 
     def download(self):
