@@ -350,3 +350,29 @@ def cm_preorder(nodes, firstnode):
         nd = nodes[no - firstnode]
         no = nd["suns"][0] if ((nd["flags"] >> 3) & 3) == 1 else nd["sibling"]
     return out
+
+
+def test_walk_in_ranges_equals_one_launch(ctx):
+    """shq_grav_short_run_range: the walk cut into ragged pieces (not multiples of the wave size, an empty one) gives the
+    bits of the single launch; the interaction statistics of the pieces add up; bad ranges are refused."""
+    pos = _positions("random")
+    n = len(pos)
+    pman = cm.make_partmanager(pos)
+    tree = sq.force_tree_full(pman)
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, TreeUseBH=0)
+    sq.gravshort_set_softenings(cm.BOX / np.cbrt(n))
+    gp = sq.make_grav_params(cm.BOX, 1.5, 48, cm.G, cm.RHO0)
+    rng = np.random.default_rng(11)
+    old = (rng.normal(size=(n, 3)), rng.normal(size=(n, 3)))
+    acc0, pot0, nint0, st0 = _gpu_walk(ctx, pman, tree, gp, old)
+    cuts = [0, 100, 100, 1357, 2048, n]
+    for first, last in zip(cuts[:-1], cuts[1:]):
+        capi.check(capi.hip.shq_grav_short_run_range(ctx.h, C.byref(gp), first, last - first, 1, sq.WALK_EXACT))
+    acc = np.zeros((n, 3)); pot = np.zeros(n); nint = np.zeros(n, dtype=np.int64)
+    st = sq.WalkStats()
+    capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), capi.ptr(pot), capi.ptr(nint), C.byref(st)))
+    assert np.array_equal(acc, acc0) and np.array_equal(pot, pot0) and np.array_equal(nint, nint0)
+    assert st.ninteractions == st0.ninteractions == nint0.sum() and st.ntargets == n
+    assert (st.min_interactions, st.max_interactions) == (st0.min_interactions, st0.max_interactions)
+    assert capi.hip.shq_grav_short_run_range(ctx.h, C.byref(gp), n - 10, 11, 1, sq.WALK_EXACT) != 0
+    assert capi.hip.shq_grav_short_run_range(ctx.h, C.byref(gp), -1, 5, 1, sq.WALK_EXACT) != 0
