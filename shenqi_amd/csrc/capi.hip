@@ -149,6 +149,26 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
         delete ctx;
         return SHQ_ERR_DEVICE;
     }
+    if(const char *v = getenv("SHQ_WALK_FREE_CUS")) {
+        const int k = atoi(v);
+        if(k > 0 && k <= 16) {
+            uint32_t mask_walk[8];
+            for(int w = 0; w < 8; w++)
+                mask_walk[w] = ~0u;
+            for(int a = 0; a < 8; a++)
+                for(int c = 0; c < k; c++) { /* the same k-CUs-of-every-XCD pattern as SHQ_PM_CUS */
+                    const int bit = 32 * a + ((a + c / 4) % 8) + 8 * (c % 4);
+                    mask_walk[bit >> 5] &= ~(1u << (bit & 31));
+                }
+            if(hipExtStreamCreateWithCUMask(&ctx->stream_walk, 8, mask_walk) != hipSuccess ||
+               hipEventCreateWithFlags(&ctx->ev_walk_in, hipEventDisableTiming) != hipSuccess ||
+               hipEventCreateWithFlags(&ctx->ev_walk_out, hipEventDisableTiming) != hipSuccess) {
+                shq_set_error("creating the CU-masked walk stream failed");
+                delete ctx;
+                return SHQ_ERR_DEVICE;
+            }
+        }
+    }
     if(const char *v = getenv("SHQ_PM_OVERLAP"))
         ctx->pm_overlap = atoi(v) != 0;
     if(const char *v = getenv("SHQ_WALK_VARIANT"))
@@ -166,6 +186,8 @@ extern "C" void shq_shutdown(shq_context *ctx)
     if(!ctx)
         return;
     (void) hipSetDevice(ctx->device);
+    if(ctx->stream_walk)
+        (void) hipStreamSynchronize(ctx->stream_walk);
     if(ctx->stream_pm)
         (void) hipStreamSynchronize(ctx->stream_pm);
     (void) hipStreamSynchronize(ctx->stream);
@@ -194,6 +216,8 @@ extern "C" void shq_shutdown(shq_context *ctx)
     }
     if(ctx->own_stream)
         (void) hipStreamDestroy(ctx->stream);
+    if(ctx->stream_walk)
+        (void) hipStreamDestroy(ctx->stream_walk);
     if(ctx->stream_pm)
         (void) hipStreamDestroy(ctx->stream_pm);
     if(ctx->ev_pm_ready)
@@ -734,8 +758,21 @@ extern "C" int shq_grav_short_run_range(shq_context *ctx, const shq_grav_params 
               (long) first, (long) count, (long) nown);
     SHQ_CHECK((walk_mode & ~0xff) == 0, SHQ_ERR_INVALID, "grav_short_run_range: walk_mode flags are not supported");
     SHQ_HIP(hipSetDevice(ctx->device));
-    SHQ_TRY(shq_launch_grav_walk(ctx, params, nullptr, count, update_potential, walk_mode, first));
-    SHQ_TRY(shq_launch_grav_postprocess(ctx, params, nullptr, count, update_potential, first));
+    hipStream_t main = ctx->stream;
+    if(ctx->stream_walk) { /* the piece runs on the CU-masked stream, in the main stream's order on both sides */
+        SHQ_HIP(hipEventRecord(ctx->ev_walk_in, main));
+        SHQ_HIP(hipStreamWaitEvent(ctx->stream_walk, ctx->ev_walk_in, 0));
+        ctx->stream = ctx->stream_walk;
+    }
+    int rc = shq_launch_grav_walk(ctx, params, nullptr, count, update_potential, walk_mode, first);
+    if(rc == SHQ_OK)
+        rc = shq_launch_grav_postprocess(ctx, params, nullptr, count, update_potential, first);
+    ctx->stream = main;
+    if(ctx->stream_walk) {
+        SHQ_HIP(hipEventRecord(ctx->ev_walk_out, ctx->stream_walk));
+        SHQ_HIP(hipStreamWaitEvent(main, ctx->ev_walk_out, 0));
+    }
+    SHQ_TRY(rc);
     ctx->grav_raw = false;
     ctx->last_stats.ntargets = first == 0 ? count : ctx->last_stats.ntargets + count;
     return SHQ_OK;

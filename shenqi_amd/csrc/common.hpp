@@ -197,6 +197,11 @@ struct shq_context {
      * it first (shq_join_pm).  Off by default: measured, nothing overlaps — the walk's 7 waves x 72 VGPRs
      * per SIMD are refilled by the next walk workgroup the moment one retires, so a PM workgroup (200+ VGPRs
      * per wave, 61 KB LDS) never finds room until the walk has drained (its first kernel waits 49 ms). */
+    /* SHQ_WALK_FREE_CUS = k: the pieces of shq_grav_short_run_range run on a stream masked to leave k compute units of every
+     * XCD free, for the collective the caller runs beside them.  Off by default: measured with k = 2 on a one-rank RCCL group,
+     * the walk pieces got 10 % slower and the RCCL round queued beside them still ended only when the walk drained */
+    hipStream_t stream_walk = nullptr;
+    hipEvent_t ev_walk_in = nullptr, ev_walk_out = nullptr;
     hipStream_t stream_pm = nullptr;
     hipEvent_t ev_pm_ready = nullptr, ev_pm_done = nullptr;
     bool pm_pending = false;
