@@ -222,7 +222,11 @@ def balanced_bounds(comm, Nmesh, BoxSize, x, weights=None, plane_cost=0.0):
     total = cum[-1]
     bounds = [0]
     for r in range(1, P):
-        b = int(np.searchsorted(cum, total * r / P, side="left")) + 1
+        target = total * r / P
+        i = int(np.searchsorted(cum, target, side="left"))          # first plane whose cumulated work reaches the target
+        # cut before or after that plane, whichever leaves the left ranks closer to their share (a plane through the
+        # cluster's core carries several per cent of the work)
+        b = i if (i > 0 and target - cum[i - 1] < cum[min(i, Nmesh - 1)] - target) else i + 1
         b = max(b, bounds[-1] + SlabDecomp.MIN_PLANES)
         b = min(b, Nmesh - SlabDecomp.MIN_PLANES * (P - r))
         bounds.append(b)
