@@ -168,11 +168,16 @@ typedef struct shq_walk_stats {
     double kernel_ms;           /* HIP-event time of the walk kernel(s) */
 } shq_walk_stats;
 
-/* Walk flavour: EXACT reproduces the reference's per-target opening decisions and interaction set (parity bar
- * runtests.cpp:441-443).  It is the only one: a group-level opening criterion (every lane of a wave taking the
- * most conservative lane's decision) costs a wave the same instruction stream as the union walk and adds
- * interactions, so it would be slower as well as different. */
+/* Walk flavour.  Both reproduce the reference's per-target opening decisions and interaction set (interaction counts equal
+ * the reference's as integers; parity bar runtests.cpp:441-443, SURVEY.md §8(c) rung L1).
+ * EXACT: one target per lane, the wave walks the union of its 64 targets' walks depth-first; every target's contributions are
+ *   summed in the reference's order.  Also serves the secondary (imported-query) walks.
+ * GROUP: one SOURCE per lane; the wave takes its 64 targets as 8 groups of 8, every pending node carries the mask of the
+ *   members whose own walk reaches it, node tests run 64 nodes at a time and each accepted source is applied to exactly the
+ *   members that accept it.  Same interaction set per target, summed in a different order (forces agree to ~1e-15
+ *   relative).  The faster of the two for primary walks. */
 #define SHQ_WALK_EXACT 0
+#define SHQ_WALK_GROUP 1
 /* flag, or-ed into walk_mode: with active == NULL, take the targets of the tree's particles sorted along a
  * Peano-Hilbert curve of their CURRENT positions (keys + radix sort on the device, ~2 ms for 1.7e7) instead of
  * particle-index order — same results per particle; keeps target groups compact when the particle

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import (PARTICLE_DTYPE, SPH_DTYPE, NODE_DTYPE, WALK_EXACT, WALK_TREE_ORDER, WALK_DEFER_POSTPROCESS, GravParams, PMParams,
+from .capi import (PARTICLE_DTYPE, SPH_DTYPE, NODE_DTYPE, WALK_EXACT, WALK_GROUP, WALK_TREE_ORDER, WALK_DEFER_POSTPROCESS, GravParams, PMParams,
                    WalkStats, ShqError)
 
 GASMASK, DMMASK, NUMASK, STARMASK, BHMASK = 1, 2, 4, 16, 32

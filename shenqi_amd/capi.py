@@ -17,6 +17,7 @@ NMAXCHILD = 8
 NOFIELD = C.c_size_t(-1).value
 
 WALK_EXACT = 0
+WALK_GROUP = 1
 WALK_TREE_ORDER = 0x100
 WALK_DEFER_POSTPROCESS = 0x200
 

@@ -251,6 +251,10 @@ struct shq_context {
     DevBuf<double4> posm_leaf; /* leaf-ordered copy of (x,y,z,m) */
     DevBuf<int32_t> leaf_pidx; /* leaf slot -> particle index */
     bool have_tree = false;
+    /* source-parallel walk (grav_group.hip): per-tree children lists, rebuilt when have_group_aux is false */
+    DevBuf<int4> nodeK;
+    bool have_group_aux = false;
+    DevBuf<int> walk_err;
     double node_rcut = -1;     /* Rcut / BHOpeningAngle2 the pool's rcuthl and bhlim fields were filled for (< 0: stale) */
     double node_bh2 = -1;
     double treeBox = 0;
@@ -343,6 +347,11 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
 int shq_launch_grav_postprocess(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active,
                                 int64_t ntargets, int update_potential, int64_t first = 0);
 int shq_launch_oldacc(shq_context *ctx, double G);
+void shq_launch_stats_init(shq_context *ctx);
+void shq_fill_node_walk_params(shq_context *ctx, const shq_grav_params *p);
+/* grav_group.hip */
+int shq_launch_grav_walk_group(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets, int update_potential,
+                               int64_t first);
 int shq_launch_grav_walk_ghosts(shq_context *ctx, const shq_grav_params *p, const double4 *d_qpos, const double *d_qoldacc,
                                 const int32_t *d_qstart, int64_t nq, double *d_acc, double *d_pot, int32_t *d_nint, int update_potential);
 /* pm.hip */

@@ -465,7 +465,10 @@ void launch_variant(int stats, dim3 grid, dim3 block, hipStream_t stream, const 
 
 } // namespace
 
-static void fill_walk_args(shq_context *ctx, const shq_grav_params *p, WalkArgs &a)
+void shq_launch_stats_init(shq_context *ctx) { stats_init_kernel<<<1, 1, 0, ctx->stream>>>(ctx->gstats.ptr); }
+
+/* the per-node fields that depend on the walk parameters (rcuthl, bhlim), refilled when Rcut, the opening angle or the tree change */
+void shq_fill_node_walk_params(shq_context *ctx, const shq_grav_params *p)
 {
     if((ctx->node_rcut != p->Rcut || ctx->node_bh2 != p->BHOpeningAngle2) && ctx->numnodes > 0) {
         const long long n = ctx->numnodes + 1;
@@ -473,6 +476,11 @@ static void fill_walk_args(shq_context *ctx, const shq_grav_params *p, WalkArgs 
         ctx->node_rcut = p->Rcut;
         ctx->node_bh2 = p->BHOpeningAngle2;
     }
+}
+
+static void fill_walk_args(shq_context *ctx, const shq_grav_params *p, WalkArgs &a)
+{
+    shq_fill_node_walk_params(ctx, p);
     a.nodeG = ctx->nodeG.ptr;
     a.posm = ctx->posm.ptr;
     a.posm_leaf = ctx->posm_leaf.ptr;
@@ -547,6 +555,8 @@ int shq_launch_grav_walk_ghosts(shq_context *ctx, const shq_grav_params *p, cons
 int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets,
                          int update_potential, int walk_mode, int64_t first)
 {
+    if(walk_mode == SHQ_WALK_GROUP)
+        return shq_launch_grav_walk_group(ctx, p, d_active, ntargets, update_potential, first);
     SHQ_CHECK(first >= 0 && (first == 0 || !d_active) && first + ntargets <= ctx->numpart, SHQ_ERR_INVALID,
               "grav walk: bad target range [%ld, +%ld)", (long) first, (long) ntargets);
     SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "grav walk: particles and tree must be uploaded first");

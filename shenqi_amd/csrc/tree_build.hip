@@ -720,6 +720,7 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
     ctx->treeBox = BoxSize;
     ctx->have_tree = true;
     ctx->node_rcut = -1;
+    ctx->have_group_aux = false;
     ctx->have_father = true;
     ctx->tb_built = true;
     if(stats) {

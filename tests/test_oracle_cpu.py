@@ -526,3 +526,4 @@ def test_bh_dynfric_oracle_against_brute_force():
                     rms += mw * np.sum(vp[jj] ** 2)
                 assert np.isclose(out[q, 7], dens, rtol=1e-11) and np.allclose(out[q, 8:11], svel, rtol=1e-9, atol=1e-9 * abs(dens) * 1e3)
                 assert np.isclose(out[q, 11], rms, rtol=1e-11)
+
