@@ -195,7 +195,7 @@ extern "C" void shq_shutdown(shq_context *ctx)
     ctx->posm.release(); ctx->oldacc.release(); ctx->treeacc.release(); ctx->gravpm.release();
     ctx->pmpot.release(); ctx->acc.release(); ctx->pot.release(); ctx->nint.release();
     ctx->pflags.release(); ctx->active.release(); ctx->act_list.release(); ctx->act_sub.release(); ctx->act_counts.release(); ctx->act_temp.release(); ctx->act_flag.release();
-    ctx->gq_res.release(); ctx->s_queue0.release(); ctx->s_nlist2.release(); ctx->topnodes.release(); ctx->topleaves.release(); ctx->top_counts.release(); ctx->top_table.release(); ctx->gstats.release(); ctx->nodeK.release(); ctx->walk_err.release();
+    ctx->gq_res.release(); ctx->s_queue0.release(); ctx->s_nlist2.release(); ctx->topnodes.release(); ctx->topleaves.release(); ctx->top_counts.release(); ctx->top_table.release(); ctx->gstats.release(); ctx->nodeF.release(); ctx->walk_counters.release(); ctx->walk_pool_idx.release(); ctx->walk_pool_msk.release(); ctx->walk_chunk_cnt.release(); ctx->walk_chunk_next.release(); ctx->walk_group_head.release();
     ctx->nodeA.release(); ctx->nodeB.release(); ctx->nodeC.release(); ctx->nodeG.release();
     ctx->posm_leaf.release(); ctx->leaf_pidx.release();
     ctx->mesh.release(); ctx->sinctab.release(); ctx->dbg_rho.release(); ctx->dbg_pot.release();
@@ -884,11 +884,7 @@ extern "C" int shq_grav_short_download(shq_context *ctx, double (*accel)[3], dou
     GravStatsDev gs = {};
     if(stats && ctx->gstats.ptr)
         SHQ_HIP(hipMemcpyAsync(&gs, ctx->gstats.ptr, sizeof(gs), hipMemcpyDeviceToHost, ctx->stream));
-    int walk_err = 0;
-    if(ctx->walk_err.ptr)
-        SHQ_HIP(hipMemcpyAsync(&walk_err, ctx->walk_err.ptr, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
-    SHQ_CHECK(walk_err == 0, SHQ_ERR_DEVICE, "source-parallel walk: node stack overflow (tree deeper than the walk supports); results are invalid");
     if(ninteractions)
         for(int64_t i = 0; i < n; i++)
             ninteractions[i] = h_nint[i];

@@ -251,10 +251,15 @@ struct shq_context {
     DevBuf<double4> posm_leaf; /* leaf-ordered copy of (x,y,z,m) */
     DevBuf<int32_t> leaf_pidx; /* leaf slot -> particle index */
     bool have_tree = false;
-    /* source-parallel walk (grav_group.hip): per-tree children lists, rebuilt when have_group_aux is false */
-    DevBuf<int4> nodeK;
+    /* source-parallel walk (grav_group.hip): per-tree children lists, rebuilt when have_group_aux is false; the pool of
+     * interaction-list chunks and its bookkeeping */
+    DevBuf<float4> nodeF;      /* 64-byte T1 records: f32 (cofm, mass), (centre, len) + children / leaf slots */
     bool have_group_aux = false;
-    DevBuf<int> walk_err;
+    DevBuf<int> walk_counters;
+    DevBuf<int32_t> walk_pool_idx, walk_chunk_cnt, walk_chunk_next, walk_group_head;
+    DevBuf<uint8_t> walk_pool_msk;
+    int64_t walk_pool_chunks = 0;
+    double walk_chunks_per_target = 0; /* measured in the last batch: sizes the next one */
     double node_rcut = -1;     /* Rcut / BHOpeningAngle2 the pool's rcuthl and bhlim fields were filled for (< 0: stale) */
     double node_bh2 = -1;
     double treeBox = 0;
