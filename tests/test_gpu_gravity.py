@@ -376,3 +376,31 @@ def test_walk_in_ranges_equals_one_launch(ctx):
     assert (st.min_interactions, st.max_interactions) == (st0.min_interactions, st0.max_interactions)
     assert capi.hip.shq_grav_short_run_range(ctx.h, C.byref(gp), n - 10, 11, 1, sq.WALK_EXACT) != 0
     assert capi.hip.shq_grav_short_run_range(ctx.h, C.byref(gp), -1, 5, 1, sq.WALK_EXACT) != 0
+
+
+def test_reference_runtests_force_gates_gpu(ctx):
+    """runtests.cpp:289-352 through the device path (host mirror of the reference API): default tree vs open tree (mean <= 1.2
+    ErrTol, :314), a larger Rcut stays within ErrTol (:330), half the mesh is not more accurate (:351)."""
+    from test_oracle_cpu import _runtests_sequence, check_runtests_gates
+    n = 16**3
+    pos = cm.random_positions(orc.boost_mt19937_uniform(0, 3 * n), n)
+    pman = cm.make_partmanager(pos)
+    tree = sq.force_tree_full(pman)
+    P = pman.Base
+
+    def pmforce(nmesh):
+        sq.gravpm_force(ctx, dict(Asmth=1.5, Nmesh=nmesh, G=cm.G), pman)
+        return P["GravPM"].copy()
+
+    def walk(nmesh, par, treeacc, gpm):
+        cm.reference_treepar(**par)
+        sq.gravshort_set_softenings(cm.BOX / np.cbrt(n))
+        P["FullTreeGravAccel"] = treeacc
+        P["GravPM"] = gpm
+        sq.grav_short_tree(ctx, None, dict(Asmth=1.5, Nmesh=nmesh, G=cm.G), tree, None, cm.RHO0)
+        return P["FullTreeGravAccel"].copy()
+
+    errtol, e_def, e_rcut, e_nmesh = _runtests_sequence(walk, pmforce, n)
+    check_runtests_gates(errtol, e_def, e_rcut, e_nmesh)
+    print("runtests gates on the device: default mean %.2e max %.2e, Rcut 9.5 mean %.2e, Nmesh/2 mean %.2e max %.2e"
+          % (e_def.mean(), e_def.max(), e_rcut.mean(), e_nmesh.mean(), e_nmesh.max()))

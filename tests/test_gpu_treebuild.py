@@ -177,3 +177,27 @@ def test_device_tree_tiny_inputs(ctx, n):
         oacc, _, onint = orc.grav_walk(dnodes, n, pos, pman.Base["Mass"], np.zeros(n), gp)
         assert np.array_equal(nint, onint)
         assert np.abs(acc - oacc * cm.G).max() <= 1e-11 * max(np.abs(oacc * cm.G).max(), 1e-300)
+
+
+@pytest.mark.parametrize("kind,ncbrt", [("flat", 128), ("close", 64), ("random2", 64)])
+def test_device_tree_reference_invariants(ctx, kind, ncbrt):
+    """The reference's own tree tests (tests/test_forcetree.cpp: check_tree :111-168, check_moments :21-109, check_hmax :237-253
+    and the root hmax gate :369 on the 128^3 lattice) on the DEVICE-built tree, downloaded in the reference's NODE format."""
+    import forcetree_checks as ft
+    from test_forcetree_cpu import positions, hsml_table
+    pos = positions(kind, ncbrt)
+    n = len(pos)
+    pman = cm.make_partmanager(pos, ptype=0)
+    pman.Base["Hsml"] = hsml_table(n)
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    sq.dynamics_upload(ctx, pman)                        # Hsml: the moments pass computes hmax from it
+    st = sq.tree_build_device(ctx, cm.BOX, mask=sq.GASMASK)
+    assert st.nparticles == n and st.numnodes < 0.7 * n
+    nodes, father = sq.tree_download(ctx, n, n)
+    nreal = ft.check_tree(nodes, n, father, pos)
+    assert abs(nodes["mass"][0] - n) < 0.5
+    ft.check_moments(nodes, n, father, pman.Base["Mass"], cm.BOX, nreal)
+    ft.check_hmax(nodes, n, father, pos, pman.Base["Hsml"])
+    if kind == "flat":
+        assert nodes["hmax"][0] >= 0.0584                # test_forcetree.cpp:369

@@ -527,3 +527,51 @@ def test_bh_dynfric_oracle_against_brute_force():
                 assert np.isclose(out[q, 7], dens, rtol=1e-11) and np.allclose(out[q, 8:11], svel, rtol=1e-9, atol=1e-9 * abs(dens) * 1e3)
                 assert np.isclose(out[q, 11], rms, rtol=1e-11)
 
+
+
+def _runtests_sequence(walk, pmforce, n):
+    """The force checks of runtests.cpp:289-352 (run_gravity_test) with callables for the tree walk and the PM:
+    open tree -> default tree (two calls) -> Rcut 9.5 (two calls) -> Nmesh / 2.  Returns the (mean, max) errors of
+    check_accns (:126-170: | |F| / |F_open| - 1 | on the TOTAL force GravPM + FullTreeGravAccel)."""
+    errtol = 0.002
+    gpm = pmforce(48)
+    z = np.zeros((n, 3))
+    f_open = walk(48, dict(ErrTolForceAcc=0.0, MaxBHOpeningAngle=0.0, Rcut=6.0, TreeUseBH=0), z, gpm)          # :297-300
+    pair = gpm + f_open
+    par = dict(ErrTolForceAcc=errtol, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=0)
+    f = walk(48, par, walk(48, par, f_open, gpm), gpm)                                                       # :304-306
+    e_def = cm.force_err(gpm + f, pair)
+    par95 = dict(par, Rcut=9.5)
+    f95 = walk(48, par95, walk(48, par95, f, gpm), gpm)                                                     # :320-323
+    e_rcut = cm.force_err(gpm + f95, pair)
+    gpm2 = pmforce(24)                                                                                       # :337-343
+    f2 = walk(24, par, walk(24, par, f95, gpm2), gpm2)
+    e_nmesh = cm.force_err(gpm2 + f2, pair)
+    return errtol, e_def, e_rcut, e_nmesh
+
+
+def check_runtests_gates(errtol, e_def, e_rcut, e_nmesh):
+    assert e_def.mean() <= 1.2 * errtol                       # runtests.cpp:314
+    assert e_rcut.mean() <= errtol                            # :330 (a larger Rcut must stay within the tolerance)
+    assert not (e_nmesh.max() < e_def.max() or e_nmesh.mean() < e_def.mean())     # :351 (half the mesh must not be more accurate)
+
+
+def test_oracle_runtests_force_gates():
+    """runtests.cpp:304-352 on the oracle: default tree vs open tree, larger Rcut, coarser mesh."""
+    n = 16**3
+    pos = cm.random_positions(orc.boost_mt19937_uniform(0, 3 * n), n)
+    mass = np.ones(n, dtype=np.float32)
+    nodes, first, _ = orc.tree_build(pos, mass, cm.BOX)
+
+    def pmforce(nmesh):
+        return orc.pm_force(pos, mass, nmesh, cm.BOX, 1.5, cm.G)[0]
+
+    def walk(nmesh, par, treeacc, gpm):
+        cm.reference_treepar(**par)
+        sq.gravshort_set_softenings(cm.BOX / np.cbrt(n))
+        gp = sq.make_grav_params(cm.BOX, 1.5, nmesh, cm.G, cm.RHO0)
+        acc, pot, _ = orc.grav_walk(nodes, first, pos, mass, np.linalg.norm(treeacc + gpm, axis=1) / cm.G, gp)
+        orc.grav_postprocess(mass, gp, acc, pot, True)
+        return acc
+
+    check_runtests_gates(*_runtests_sequence(walk, pmforce, n))
