@@ -404,3 +404,71 @@ def test_reference_runtests_force_gates_gpu(ctx):
     check_runtests_gates(errtol, e_def, e_rcut, e_nmesh)
     print("runtests gates on the device: default mean %.2e max %.2e, Rcut 9.5 mean %.2e, Nmesh/2 mean %.2e max %.2e"
           % (e_def.mean(), e_def.max(), e_rcut.mean(), e_nmesh.mean(), e_nmesh.max()))
+
+
+def test_pm_excludes_swallowed_black_holes(ctx):
+    """gravpm.cpp:176-178: a swallowed black hole stays in the particle table but does not gravitate (RegionInd = -2): it
+    deposits nothing and reads nothing out (GravPM stays at the zero gravpm_force starts from, :88-92); the tree leaves it out
+    as well (forcetree.cpp:805-806)"""
+    n = 16**3
+    pos = cm.random_positions(orc.boost_mt19937_uniform(4, 3 * n), n)
+    pman = cm.make_partmanager(pos)
+    P = pman.Base
+    rng = np.random.default_rng(1)
+    bh = rng.choice(n, size=60, replace=False)
+    P["Type"][bh] = 5
+    P["Mass"][bh] = 25.0                                   # heavy: leaving them in would change every force
+    swallowed = bh[::2]
+    P["Flags"][swallowed] |= 2
+    P["GravPM"] = 7.0                                      # must be overwritten, zero for the swallowed
+    skip = np.zeros(n, dtype=np.uint8)
+    skip[swallowed] = 1
+    sq.gravpm_force(ctx, dict(Asmth=1.5, Nmesh=48, G=cm.G), pman)
+    ogpm, opot, rho, _ = orc.pm_force(pos, P["Mass"], 48, cm.BOX, 1.5, cm.G, skip=skip, want_mesh=True)
+    assert abs(rho.sum() - P["Mass"][skip == 0].astype(np.float64).sum()) < 1e-6
+    live = skip == 0
+    assert np.abs(P["GravPM"][live] - ogpm[live]).max() < 1e-10 * np.abs(ogpm).max()
+    assert np.all(P["GravPM"][swallowed] == 0)
+    # with the holes gravitating the forces are different: the exclusion is what is being tested
+    ogpm_all, _, _, _ = orc.pm_force(pos, P["Mass"], 48, cm.BOX, 1.5, cm.G)
+    assert np.abs(ogpm_all[live] - ogpm[live]).max() > 1e-2 * np.abs(ogpm).max()
+    # short-range side: the tree is built without them and they are no targets
+    tree = sq.force_tree_full(pman)
+    cm.reference_treepar(ErrTolForceAcc=0.002, MaxBHOpeningAngle=0.9, TreeUseBH=1)
+    sq.gravshort_set_softenings(cm.BOX / 16)
+    sq.grav_short_tree(ctx, None, dict(Asmth=1.5, Nmesh=48, G=cm.G), tree, None, cm.RHO0)
+    assert abs(tree.Nodes_base["mass"][0] - P["Mass"][live].astype(np.float64).sum()) < 1e-6
+
+
+@pytest.mark.parametrize("usebh", [1, 0])
+def test_walk_erfc_window(ctx, usebh):
+    """SHORTRANGE_FORCE_WINDOW_TYPE_ERFC (gravshort-tree2.cpp:55-60): the table is erfc(u) + 2u/sqrt(pi) exp(-u^2) and erfc(u)
+    at u = x / (2 Asmth); the walk with it against the oracle's walk, and against the closed form evaluated per pair for a
+    direct sum over a small particle set (no tree)"""
+    from math import erfc, exp, pi, sqrt
+    n = 16**3
+    pos = cm.random_positions(orc.boost_mt19937_uniform(6, 3 * n), n)
+    pman = cm.make_partmanager(pos)
+    tree = sq.force_tree_full(pman)
+    sq.set_gravshort_treepar(ErrTolForceAcc=0.002, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=usebh, Rcut=6.0,
+                             FractionalGravitySoftening=1.0 / 30.0, ShortRangeForceWindowType=sq.SHORTRANGE_FORCE_WINDOW_TYPE_ERFC)
+    sq.gravshort_set_softenings(cm.BOX / 16)
+    asmth = 1.25                                            # the erfc window is not tied to the calibrated Asmth = 1.5
+    gp = sq.make_grav_params(cm.BOX, asmth, 48, cm.G, cm.RHO0)
+    x = gp.dx * np.arange(capi.NGRAVTAB)
+    u = x * 0.5 / asmth
+    want_f = np.array([erfc(v) + 2 * v / sqrt(pi) * exp(-v * v) for v in u])
+    want_p = np.array([erfc(v) for v in u])
+    assert np.abs(np.array(gp.shortrange_table) - want_f.astype(np.float32)).max() == 0
+    assert np.abs(np.array(gp.shortrange_table_potential) - want_p.astype(np.float32)).max() == 0
+    rng = np.random.default_rng(2)
+    told = rng.normal(size=(n, 3)) * 300.0
+    z = np.zeros((n, 3))
+    acc, pot, nint, st = _gpu_walk(ctx, pman, tree, gp, (told, z))
+    mass = pman.Base["Mass"]
+    oacc, opot, onint = orc.grav_walk(tree.Nodes_base, tree.firstnode, pos, mass, np.linalg.norm(told, axis=1) / cm.G, gp)
+    orc.grav_postprocess(mass, gp, oacc, opot, True)
+    assert np.array_equal(nint, onint)
+    assert np.abs(acc - oacc).max() < 1e-11 * np.abs(oacc).max()
+    assert np.allclose(pot, opot, rtol=1e-10, atol=1e-10 * np.abs(opot).max())
+    cm.reference_treepar()                                  # back to the exact window for the tests that follow
