@@ -81,13 +81,56 @@ def cpu_baseline(pos, mass, tree, gp_rel, oldacc, L, acc_gpu=None):
     frac_tree = len(targets) / n
     frac_pm = len(sub) / n
     est_full = t_tree / frac_tree + t_pm / frac_pm
+    model, phys = cpu_info()
     return {
         "value": n / est_full, "unit": "particle-steps/s", "cores": orc.lib.orc_num_threads(), "kind": "port",
+        "cpu_model": model, "physical_cores": phys,
+        # the two legs separately: the oracle's PM runs on its own mixed-radix FFT (the reference's FFTW / heffte is absent), which
+        # dominates the combined figure; the tree leg is the like-for-like part
+        "tree_value": n / (t_tree / frac_tree), "pm_value": n / (t_pm / frac_pm),
         "sample": "oracle tree walk of %d of %d targets (every 64th 64-target group, same tree) in %.2f s + oracle PM step "
                   "(reference structure, 5 FFTs) on a %d-particle/192^3-mesh sub-problem in %.2f s; each scaled by its "
                   "fraction of the full job" % (len(targets), n, t_tree, len(sub), t_pm),
         "tree_s_sample": t_tree, "pm_s_sample": t_pm, "force_error": ferr,
     }
+
+
+def cpu_info():
+    """CPU model string and number of physical cores of the host (/proc/cpuinfo), as SURVEY.md section 8(d) asks"""
+    model, cores = None, set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return model, (len(cores) or None)
+
+
+def load_profile(name):
+    """the newest committed rocprof summary profiles/rNN_<name> (tools/pmc_summary.py output), or None"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + name)))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def hbm_bytes(e):
+    return e.get("fetch_bytes_corrected", 0.0) + e.get("write_bytes", 0.0)
 
 
 def distributed_walk_figures(ctx, sq, capi, tree, pos, oldacc, gp_rel, n):
@@ -171,6 +214,29 @@ def sph_figures(ctx, n1=128, kernel=2):
             "sph_density_iteration_ms": float(st.kernel_ms) / max(1, int(st.niterations)),
             "sph_density_particles_per_s": n / (1e-3 * float(st.kernel_ms) / max(1, int(st.niterations))),
             "sph_hydro_ms": float(hs.kernel_ms), "sph_hydro_particles_per_s": n / (1e-3 * float(hs.kernel_ms))})
+    # ---- rooflines of the two SPH operators: gather-bound, so algorithmic STREAM bytes against the HBM peak:
+    # density per target and iteration = candidates x 32 B (pos, mass, type / flags) + NumNgb neighbours x 114 B (Vel,
+    # FullTreeGravAccel, GravPM, HydroAccel, bins, Entropy, DtEntropy); hydro per target = NumNgb pairs x 200 B (the lower end of
+    # 8(d)'s 113-300 pairs).  `traffic` = HBM bytes of the walk + evaluation kernels from the committed counter passes.
+    ngb = float(sq.GetNumNgb())
+    dens_iter_s = 1e-3 * float(st.kernel_ms) / max(1, int(st.niterations))
+    cand = float(st.ninteractions) / max(1, int(st.ntargets)) / max(1, int(st.niterations))
+    dens_bytes = n * (cand * 32.0 + ngb * 114.0)
+    hyd_bytes = n * ngb * 200.0
+    pj = load_profile("sph128_pmc_hbm.json") or {}
+
+    def traffic_of(prefixes):
+        ks = [k for k in pj if any(k.startswith(p) for p in prefixes)]
+        return sum(hbm_bytes(pj[k]) for k in ks) if ks else None
+    out["roofline_sph_density"] = {"bound": "hbm", "kernel": "sph_density_kernel, walk + evaluation launches of one Hsml iteration",
+                                   "achieved": dens_bytes / dens_iter_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": dens_bytes / dens_iter_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of(("sph_density_kernel",)),
+                                   "algorithmic_bytes": dens_bytes, "candidates_per_target": cand, "neighbours": ngb}
+    out["roofline_sph_hydro"] = {"bound": "hbm", "kernel": "sph_hydro_kernel, walk + evaluation launches",
+                                 "achieved": hyd_bytes / (1e-3 * float(hs.kernel_ms)) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": hyd_bytes / (1e-3 * float(hs.kernel_ms)) / 1e9 / HBM_PEAK_GBS,
+                                 "traffic": traffic_of(("sph_hydro_kernel",)), "algorithmic_bytes": hyd_bytes,
+                                 "candidates_per_target": float(hs.ninteractions) / max(1, int(hs.ntargets)), "neighbours": ngb}
     return out
 
 
@@ -230,6 +296,8 @@ def run_sharded(args, rank, local_rank, world):
         os.environ["OMP_NUM_THREADS"] = str(max(1, len(os.sched_getaffinity(0)) // max(1, world)))
     import torch
     import torch.distributed as dist
+    if args.gpus not in (1, world):      # --gpus keeps its default under a bare torchrun; anything else must agree
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
 
     # SHQ_BENCH_BACKEND=gloo is a rehearsal knob for the one-GPU box: every rank shares device 0 and the
     # exchanges are staged through the host.  The driver's runs use nccl (= RCCL), one GPU per rank.
@@ -318,6 +386,8 @@ def run_sharded(args, rank, local_rank, world):
     ach = tree_bytes / max(st.kernel_ms * 1e-3, 1e-12) / 1e9
     out = {
         "metric": "particle-steps/sec (grav+PM+SPH) at 256^3; rms force error vs ref",
+        "metric_note": "BASELINE.json's metric name; this N-GPU line runs the dm-only TreePM step of config.workload (no SPH, which is "
+                       "not sharded here)",
         "value": nglobal * args.steps / elapsed, "unit": "particle-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -344,8 +414,23 @@ def run_sharded(args, rank, local_rank, world):
     os.close(json_fd)
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks the way the driver does (torch.distributed.run, one rank
+    per GPU over RCCL) as a child process, before this process touches torch or the GPU, and pass its JSON line through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("SHQ_COMM_FORCE", "0") != "1":
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -475,22 +560,27 @@ def main():
     dominant = "grav_walk_exact_kernel" if walk_s >= pm_s else "pm (deposit + 5 fused FFT passes + readout)"
     ach = (tree_bytes / walk_s if walk_s >= pm_s else pm_bytes / pm_s) / 1e9
     # HBM traffic per launch from the committed PMC summary of this same command (profiles/, made with
-    # tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), if present
+    # tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), if present: a counter pass cannot
+    # run inside this process, so these two numbers are the committed measurement of the same kernels on the same workload
     traffic = traffic_fft = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_bench256_pmc_hbm.json")) as f:
-            pj = json.load(f)
-        if n1 == 256 and world == 1:
-            def hbm(e):
-                return e.get("fetch_bytes_corrected", 0.0) + e.get("write_bytes", 0.0)
-            key = [k for k in pj if k.startswith("grav_walk_exact_kernel") and k.rstrip(">").endswith("false")]
-            if key:
-                traffic = hbm(pj[key[0]])
-            fk = [k for k in pj if k.startswith("fft_pass_")]
-            if len(fk) == 5:
-                traffic_fft = sum(hbm(pj[k]) for k in fk)
-    except (OSError, ValueError):
-        traffic = traffic_fft = None
+    valu_busy = None
+    pj = load_profile("bench256_pmc_hbm.json")
+    if pj and n1 == 256 and world == 1:
+        # the production walk: potential on, no prefetch, leaf batch 2, no counters, relative criterion, primary walk
+        key = [k for k in pj if k.startswith("grav_walk_exact_kernel<true, false, 2, 0, false, false>")]
+        if key:
+            traffic = hbm_bytes(pj[key[0]])
+        fk = [k for k in pj if k.startswith("fft_pass_")]
+        if len(fk) == 5:
+            traffic_fft = sum(hbm_bytes(pj[k]) for k in fk)
+    sj = load_profile("bench256_pmc_sq.json")
+    if sj:
+        key = [k for k in sj if k.startswith("grav_walk_exact_kernel<true, false, 2, 0, false, false>")]
+        if key and sj[key[0]].get("SQ_BUSY_CYCLES"):
+            e = sj[key[0]]
+            # SQ_INSTS_VALU x 4 cycles per wave instruction over the SIMD cycles the kernel was resident (SQ_BUSY_CYCLES counts per
+            # shader engine: / 32 engines x 1024 SIMDs)
+            valu_busy = e.get("SQ_INSTS_VALU", 0.0) * 4.0 / (e["SQ_BUSY_CYCLES"] / 32.0 * 1024.0)
     # The dominant kernel, the tree walk, is bound by FP64 issue, not by HBM (0.1 kB of compulsory traffic per
     # target against ~500 interactions of ~45 flop): its roofline is the FP64 compute peak (78.6
     # TFLOP/s on MI355X, vector and matrix alike — the "mfma" kind of bound; no MFMA instruction is used or
@@ -500,10 +590,12 @@ def main():
                      "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
                      "frac": walk_flops / max(walk_s, 1e-12) / 1e12 / FP64_VECTOR_PEAK_TF, "traffic": traffic,
                      "algorithmic_flops": walk_flops, "algorithmic_bytes": tree_bytes, "hbm_algorithmic_GBs": tree_bytes / max(walk_s, 1e-12) / 1e9,
+                     "valu_busy": valu_busy,
                      "note": "FP64-issue bound: 45 flop per interaction (SURVEY 8(d)) x interactions / kernel time against the FP64 "
-                             "peak; VALU busy 74 % (profiles/r01_bench256_pmc_sq.json); `traffic` = HBM bytes per launch from the "
-                             "FETCH_SIZE/WRITE_SIZE passes, 6x the compulsory bytes and 0.2 TB/s: not a bandwidth problem.  "
-                             "The HBM-bound part of the step is the PM: roofline_pm_fft"}
+                             "peak; valu_busy = SQ_INSTS_VALU x 4 / resident SIMD cycles from the committed SQ pass; `traffic` = HBM "
+                             "bytes per launch of the production walk from the committed FETCH_SIZE / WRITE_SIZE passes (several "
+                             "times the compulsory bytes, still a fraction of a TB/s: not a bandwidth problem).  The HBM-bound part "
+                             "of the step is the PM: roofline_pm_fft"}
     out = {
         "metric": "particle-steps/sec (grav+PM+SPH) at 256^3; rms force error vs ref",
         "value": n * world * args.steps / elapsed,
@@ -533,7 +625,9 @@ def main():
             "tree_particle_rounds_per_wave": (st.nwave_interactions - st.nwave_node_interactions) / max(1.0, st.ntargets / 64.0),
             "tree_node_interactions_per_target": st.nnode_interactions / max(1, st.ntargets),
             "tree_algorithmic_GBs": tree_bytes / max(walk_s, 1e-12) / 1e9,
-            "pm_ms": {"deposit": ph[0], "r2c": ph[1], "transfer": ph[2], "c2r": ph[3], "readout": ph[4], "total": ph[5]},
+            # the bespoke pipeline runs forward FFT, Green's function and inverse FFT as five fused passes: one phase
+            "pm_ms": {"zero_and_deposit": ph[0], "fft_pipeline_5_passes_incl_greens_function": ph[1] + ph[2] + ph[3], "readout": ph[4],
+                      "total": ph[5]},
             "pm_algorithmic_GBs": pm_bytes / max(pm_s, 1e-12) / 1e9,
             "pm_frac_of_hbm_peak": pm_bytes / max(pm_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
             "pm_reference_structure_GBs": pm_bytes_reference_structure / max(pm_s, 1e-12) / 1e9,
@@ -594,7 +688,10 @@ def main():
         out["kernels"]["resident_full_step_ms"] = None
         out["kernels"]["resident_full_step_note"] = str(e)
     if not args.no_sph:
-        out["kernels"].update(sph_figures(ctx))
+        figs = sph_figures(ctx)
+        for k in ("roofline_sph_density", "roofline_sph_hydro"):
+            out[k] = figs.pop(k)
+        out["kernels"].update(figs)
     ctx.close()
     if dist is not None:
         dist.barrier()

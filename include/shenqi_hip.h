@@ -643,8 +643,11 @@ int shq_pm_download_mesh(shq_context *ctx, int which /*0 density,1 potential*/, 
  *             of the potential (periodic); fills the device-resident GravPM / PM potential. */
 /* Particle set already in HBM: d_posm = double[n][4] rows (x, y, z, m); the first nlocal rows are this
  * rank's own particles (PM deposit/readout and the default walk targets), the rest imported ghosts
- * that only act as sources in the tree.  Previous-step accelerations are kept when n is unchanged. */
-int shq_particles_set_device(shq_context *ctx, const void *d_posm, int64_t n, int64_t nlocal);
+ * that only act as sources in the tree; nlocal == 0 is a rank that owns nothing (no targets, no deposit, no readout).
+ * Previous-step accelerations are kept when n is unchanged.  The tree of the previous set is dropped — a walk before the next
+ * shq_tree_build / shq_tree_upload is refused — unless keep_tree != 0, by which the caller states that these are the very
+ * positions (same count, same order) the current tree was built from (a force evaluation repeated on frozen positions). */
+int shq_particles_set_device(shq_context *ctx, const void *d_posm, int64_t n, int64_t nlocal, int keep_tree);
 int shq_pm_slab_deposit(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, void *d_mesh_i64);
 int shq_pm_slab_green(shq_context *ctx, const shq_pm_params *pm, int y0, int nyl, void *d_spec);
 int shq_pm_slab_readout(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, const void *d_phi_ext);
@@ -668,7 +671,8 @@ int shq_pm_slab2_xgreen(shq_context *ctx, const shq_pm_params *pm, void *d_spec,
 int shq_pm_slab2_readout(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, int xoff, int nalloc,
                          const void *d_phi);
 /* Fixed-point deposit scale 2^e: chosen per context from the local mass sum at particle upload;
- * ranks of one job must agree on it (set it from the global mass sum) so meshes add exactly. */
+ * ranks of one job must agree on it (set it from the global mass sum) so meshes add exactly; e = -1 returns to the
+ * per-context choice at the next particle upload. */
 int shq_pm_get_deposit_log2scale(shq_context *ctx);
 int shq_pm_set_deposit_log2scale(shq_context *ctx, int e);
 

@@ -434,7 +434,7 @@ host.shqh_hydro_force.argtypes = [_vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64,
                                   C.POINTER(KickFactors), _vp, C.c_int, C.POINTER(SphStats)]
 
 # ---- multi-GPU slab entry points -------------------------------------------------------------
-hip.shq_particles_set_device.argtypes = [_vp, _vp, C.c_int64, C.c_int64]
+hip.shq_particles_set_device.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int]
 hip.shq_pm_slab_deposit.argtypes = [_vp, C.POINTER(PMParams), C.c_int, C.c_int, _vp]
 hip.shq_pm_slab_green.argtypes = [_vp, C.POINTER(PMParams), C.c_int, C.c_int, _vp]
 hip.shq_pm_slab_readout.argtypes = [_vp, C.POINTER(PMParams), C.c_int, C.c_int, _vp]

@@ -373,7 +373,7 @@ extern "C" int shq_particles_upload(shq_context *ctx, const shq_part_view *parts
         ctx->pm_log2scale = 61 - ex;
     }
     ctx->numpart = n;
-    ctx->nlocal = 0;
+    ctx->nlocal = n; /* all particles are this rank's own */
     ctx->have_parts = true;
     ctx->have_tree = false; /* leaf copy refers to the old particles */
     ctx->have_tree_targets = false;
@@ -674,7 +674,7 @@ __global__ void fill_u8_kernel(uint8_t *x, long long n, uint8_t v)
 
 /* Device-side particle set for multi-GPU runs: rows (x, y, z, m) already in HBM (e.g. a torch
  * tensor holding local + imported ghost particles); the first nlocal rows are this rank's own. */
-extern "C" int shq_particles_set_device(shq_context *ctx, const void *d_posm, int64_t n, int64_t nlocal)
+extern "C" int shq_particles_set_device(shq_context *ctx, const void *d_posm, int64_t n, int64_t nlocal, int keep_tree)
 {
     SHQ_CHECK(ctx && (d_posm || n == 0), SHQ_ERR_INVALID, "null argument");
     SHQ_CHECK(n >= 0 && n < (1ll << 31) && nlocal >= 0 && nlocal <= n, SHQ_ERR_INVALID, "bad particle counts");
@@ -704,7 +704,9 @@ extern "C" int shq_particles_set_device(shq_context *ctx, const void *d_posm, in
         fill_u8_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->pflags.ptr, n, (uint8_t) (1 << 4));
         SHQ_HIP(hipGetLastError());
     }
-    if(ctx->numpart != n) {
+    /* new positions: the tree and its leaf copies refer to the old ones even when the count is the same (a walk without a
+     * rebuild is refused, as after shq_drift), unless the caller vouches that nothing moved */
+    if(!(keep_tree && ctx->numpart == n && ctx->have_tree)) {
         ctx->have_tree = false;
         ctx->tb_built = false;
     }
@@ -736,7 +738,7 @@ extern "C" int shq_grav_short_run(shq_context *ctx, const shq_grav_params *param
         d_active = ctx->tree_targets.ptr;
         nt = ctx->ntree_targets;
     } else
-        SHQ_TRY(shq_resolve_active(ctx, active, nactive, ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart, &d_active, &nt));
+        SHQ_TRY(shq_resolve_active(ctx, active, nactive, ctx->nlocal, &d_active, &nt));
     const bool defer = (walk_mode & SHQ_WALK_DEFER_POSTPROCESS) != 0;
     walk_mode &= 0xff;
     SHQ_TRY(shq_launch_grav_walk(ctx, params, d_active, nt, update_potential, walk_mode));
@@ -754,7 +756,7 @@ extern "C" int shq_grav_short_run_range(shq_context *ctx, const shq_grav_params 
 {
     SHQ_CHECK(ctx && params, SHQ_ERR_INVALID, "null argument");
     SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "grav_short_run_range: upload particles and tree first");
-    const int64_t nown = ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart;
+    const int64_t nown = ctx->nlocal;
     SHQ_CHECK(first >= 0 && count >= 0 && first + count <= nown, SHQ_ERR_INVALID, "grav_short_run_range: [%ld, +%ld) outside the %ld own particles",
               (long) first, (long) count, (long) nown);
     SHQ_CHECK((walk_mode & ~0xff) == 0, SHQ_ERR_INVALID, "grav_short_run_range: walk_mode flags are not supported");
@@ -859,7 +861,7 @@ extern "C" int shq_grav_postprocess(shq_context *ctx, const shq_grav_params *par
     SHQ_HIP(hipSetDevice(ctx->device));
     const int32_t *d_active = nullptr;
     int64_t nt = 0;
-    SHQ_TRY(shq_resolve_active(ctx, active, nactive, ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart, &d_active, &nt));
+    SHQ_TRY(shq_resolve_active(ctx, active, nactive, ctx->nlocal, &d_active, &nt));
     SHQ_TRY(shq_launch_grav_postprocess(ctx, params, d_active, nt, update_potential));
     ctx->grav_raw = false;
     return SHQ_OK;

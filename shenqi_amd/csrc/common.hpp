@@ -211,7 +211,8 @@ struct shq_context {
 
     /* ---- particle store, by particle index (sorted SoA, Peano order as the host keeps it) */
     int64_t numpart = 0;
-    int64_t nlocal = 0;        /* >0: only the first nlocal particles are this rank's own (the rest are ghosts) */
+    int64_t nlocal = 0;        /* the first nlocal particles are this rank's own (targets, PM deposit / readout); the rest are
+                                  imported ghosts.  shq_particles_upload: all of them; shq_particles_set_device: as given, 0 included */
     DevBuf<double4> posm;      /* x,y,z,mass */
     DevBuf<double> oldacc;     /* |FullTreeGravAccel + GravPM| / G */
     DevBuf<double> treeacc;    /* [N][3] FullTreeGravAccel */

@@ -700,7 +700,7 @@ extern "C" int shq_pm_slab_deposit(shq_context *ctx, const shq_pm_params *pm, in
     const int nalloc = nplanes == N ? N : nplanes + 1;
     const size_t cnt = (size_t) nalloc * N * (N + 2);
     pm_zero_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>((unsigned long long *) d_mesh_i64, cnt);
-    const long long n = ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart;
+    const long long n = ctx->nlocal;
     if(n > 0)
         pm_deposit_kernel<<<dim3((unsigned) ((n + DEP_CHUNK - 1) / DEP_CHUNK)), dim3(256), 0, ctx->stream>>>(
             ctx->posm.ptr, ctx->pflags.ptr, n, (unsigned long long *) d_mesh_i64, N, N + 2, pm->BoxSize / N, ldexp(1.0, ctx->pm_log2scale),
@@ -720,7 +720,7 @@ extern "C" int shq_pm_slab_readout(shq_context *ctx, const shq_pm_params *pm, in
     SHQ_HIP(hipSetDevice(ctx->device));
     SHQ_TRY(ctx->pm_oob.reserve(1));
     SHQ_HIP(hipMemsetAsync(ctx->pm_oob.ptr, 0, sizeof(int), ctx->stream));
-    const long long n = ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart;
+    const long long n = ctx->nlocal;
     const int nalloc = nplanes == N ? N : nplanes + 5;
     const int xshift = nplanes == N ? 0 : plane0 - 2;
     if(n > 0)
@@ -806,7 +806,7 @@ extern "C" int shq_pm_slab2_deposit(shq_context *ctx, const shq_pm_params *pm, i
     const int zp = shq_fft3d_pitch(N);
     const size_t cnt = (size_t) nalloc * N * zp;
     pm_zero_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>((unsigned long long *) d_mesh_i64, cnt);
-    const long long n = ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart;
+    const long long n = ctx->nlocal;
     /* buffer plane of mesh plane ix: (ix - (plane0 - xoff)) mod N; own planes and the right ghost must fit */
     const int nfit = nplanes == N ? N : xoff + nplanes + 1;
     SHQ_CHECK(nfit <= nalloc, SHQ_ERR_INVALID, "pm_slab2_deposit: no room for the deposit ghost plane");
@@ -856,7 +856,7 @@ extern "C" int shq_pm_slab2_readout(shq_context *ctx, const shq_pm_params *pm, i
     SHQ_HIP(hipSetDevice(ctx->device));
     SHQ_TRY(ctx->pm_oob.reserve(4));
     SHQ_HIP(hipMemsetAsync(ctx->pm_oob.ptr, 0, sizeof(int), ctx->stream));
-    const long long n = ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart;
+    const long long n = ctx->nlocal;
     const int zp = shq_fft3d_pitch(N);
     if(n > 0)
         pm_readout_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(
@@ -870,8 +870,9 @@ extern "C" int shq_pm_slab2_readout(shq_context *ctx, const shq_pm_params *pm, i
 extern "C" int shq_pm_get_deposit_log2scale(shq_context *ctx) { return ctx ? ctx->pm_log2scale : -1; }
 extern "C" int shq_pm_set_deposit_log2scale(shq_context *ctx, int e)
 {
-    SHQ_CHECK(ctx && e >= 0 && e < 62, SHQ_ERR_INVALID, "bad scale exponent");
-    ctx->pm_log2scale_user = e;
-    ctx->pm_log2scale = e;
+    SHQ_CHECK(ctx && e >= -1 && e < 62, SHQ_ERR_INVALID, "bad scale exponent");
+    ctx->pm_log2scale_user = e; /* -1: back to the scale chosen from the mass sum at the next particle upload */
+    if(e >= 0)
+        ctx->pm_log2scale = e;
     return SHQ_OK;
 }

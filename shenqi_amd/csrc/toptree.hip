@@ -142,7 +142,7 @@ int run_toptree(shq_context *ctx, const GravTopArgs &ga, const NgbTopArgs &na, c
 {
     const int32_t *d_act = nullptr;
     int64_t nt = 0;
-    SHQ_TRY(shq_resolve_active(ctx, active, nactive, ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart, &d_act, &nt));
+    SHQ_TRY(shq_resolve_active(ctx, active, nactive, ctx->nlocal, &d_act, &nt));
     if(nexport)
         *nexport = 0;
     if(nt == 0)

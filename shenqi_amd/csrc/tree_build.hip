@@ -531,7 +531,7 @@ int shq_build_tree_targets(shq_context *ctx)
         return SHQ_OK;
     SHQ_CHECK(ctx->have_tree, SHQ_ERR_STATE, "tree-order targets: no tree");
     const long long n = ctx->ntreeparts;
-    const int limit = (int) (ctx->nlocal > 0 ? ctx->nlocal : ctx->numpart);
+    const int limit = (int) (ctx->nlocal);
     TreeBuildBufs &b = ctx->tb;
     SHQ_TRY(ctx->tree_targets.reserve((size_t) (n > 0 ? n : 1)));
     SHQ_TRY(b.counters.reserve(4));

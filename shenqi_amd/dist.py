@@ -405,11 +405,12 @@ class GpuOps:
     def empty(self, shape, dtype):
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
-    def set_particles(self, posm_all, nlocal):
-        """posm_all: device tensor [n, 4] (x, y, z, m), the first nlocal rows are this rank's own."""
+    def set_particles(self, posm_all, nlocal, keep_tree=False):
+        """posm_all: device tensor [n, 4] (x, y, z, m), the first nlocal rows are this rank's own.  keep_tree: these are the
+        positions the resident tree was built from (nothing moved since)."""
         t = posm_all.contiguous()
         torch.cuda.current_stream(self.device).synchronize()   # torch produced t on its stream; the library copies on its own
-        capi.check(capi.hip.shq_particles_set_device(self.ctx.h, C.c_void_p(t.data_ptr()), t.shape[0], nlocal))
+        capi.check(capi.hip.shq_particles_set_device(self.ctx.h, C.c_void_p(t.data_ptr()), t.shape[0], nlocal, int(keep_tree)))
         self.ctx.synchronize()
         self._keep = t
 
@@ -504,10 +505,16 @@ class DistTreePM:
         self.halo = self.halo_factor * Rcut
         self.ops.set_deposit_scale(self.comm.allreduce_sum(float(self.local[:, 3].sum().item())))
         self._load_particles()
-        # local + ghost particles are resident: build their tree (global root cell) on the device
+        self._build_tree()
+
+    def _build_tree(self):
+        """local + ghost particles are resident: build their tree (global root cell) on the device"""
+        sq = self.sq
         try:
             self.tree = sq.tree_build_device(self.ctx, self.L)
-        except sq.ShqError:
+        except sq.ShqError as e:
+            if "deeper" not in str(e) and "levels" not in str(e):
+                raise       # out of memory, invalid state ...: not something a host build would cure
             # deeper than the device build's 21 levels (more than 8 particles within L / 2^21): host build + upload
             allh = self.allp.cpu().numpy()
             pman = sq.PartManager(allh.shape[0], self.L)
@@ -519,18 +526,23 @@ class DistTreePM:
             tv = self.tree.view()
             capi.check(capi.hip.shq_tree_upload(self.ctx.h, C.byref(tv)))
 
-    def _load_particles(self):
+    def _load_particles(self, keep_tree=False):
         ghosts = ghost_exchange(self.comm, self.decomp, self.local, self.halo)
         self.allp = torch.cat([self.local, ghosts], dim=0).contiguous()
         self.nghost = int(ghosts.shape[0])
-        self.ops.set_particles(self.allp, self.nloc)
+        self.ops.set_particles(self.allp, self.nloc, keep_tree)
 
-    def step(self, gp, update_potential=1, walk_mode=0, overlap=None):
+    def step(self, gp, update_potential=1, walk_mode=0, overlap=None, moved=False):
         """One force evaluation: ghost import, PM, walk for the local targets, OldAcc refresh.
+        moved: self.local changed since the tree was built (a drift): the ghosts are imported for the new positions and the
+        tree is rebuilt.  Without it the step repeats the evaluation on the positions of setup(): the ghost exchange still
+        runs (it is part of a step), the tree is kept.
         overlap (default: whenever the transposes are collectives; SHQ_DIST_OVERLAP=0 turns it off): the walk does not need
         the PM result of its own step (OldAcc is the previous step's), so it is cut in two pieces that are queued behind the
         start of the two mesh transposes: the walk computes while the spectrum travels over xGMI."""
-        self._load_particles()
+        self._load_particles(keep_tree=not moved)
+        if moved:
+            self._build_tree()
         if overlap is None:
             overlap = self.comm.multi and os.environ.get("SHQ_DIST_OVERLAP", "1") != "0"
         if overlap and self.nloc >= 512:

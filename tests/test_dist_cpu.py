@@ -150,3 +150,58 @@ def _weights_worker(rank, world, initfile):
 def test_balanced_bounds_weighted_gloo():
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_weights_worker, args=(2, os.path.join(tmp, "init")), nprocs=2, join=True)
+
+
+def _empty_slab_worker(rank, world, initfile, outdir):
+    os.environ["OMP_NUM_THREADS"] = "2"
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        from shenqi_amd import dist as sd
+        from cpu_ops import CpuOps
+        comm = sd.Comm()
+        posm_g = _global_particles()
+        posm_g = posm_g[(posm_g[:, 0] < BOX / 3) | (posm_g[:, 0] >= 2 * BOX / 3)]     # nothing in the middle third of the box
+        mine = torch.from_numpy(posm_g[rank::world].copy())
+        bounds = [0, NMESH // 3, 2 * NMESH // 3, NMESH]
+        decomp = sd.SlabDecomp(comm, NMESH, BOX, bounds)
+        local = sd.exchange_to_owner(comm, decomp, mine)
+        nloc = local.shape[0]
+        assert (nloc == 0) == (rank == 1)
+        ops = CpuOps(NMESH, BOX, 1.5, G)
+        ops.set_deposit_scale(comm.allreduce_sum(float(local[:, 3].sum())))
+        # the empty rank still imports ghosts for nobody's benefit: they must neither deposit nor be read out
+        ghosts = sd.ghost_exchange(comm, decomp, local, 0.2 * BOX)
+        ops.set_particles(torch.cat([local, ghosts], dim=0), nloc)
+        pm = sd.SlabPM(comm, NMESH, BOX, 1.5, G, ops, bounds)
+        pm.force()
+        gpm, ppot = ops.results(nloc)
+        np.save(os.path.join(outdir, "e%d.npy" % rank), np.concatenate([local.numpy().reshape(-1, 4), gpm.reshape(-1, 3), ppot.reshape(-1, 1)], axis=1))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_slab_pm_with_an_empty_slab_gloo():
+    """a rank whose slab holds no particle (nlocal = 0) takes part in the transposes and the ghost-plane exchange, deposits
+    nothing - not even the ghosts it imported - and the others' forces equal the monolithic PM"""
+    import orc
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_empty_slab_worker, args=(3, os.path.join(tmp, "init"), tmp), nprocs=3, join=True)
+        posm_g = _global_particles()
+        posm_g = posm_g[(posm_g[:, 0] < BOX / 3) | (posm_g[:, 0] >= 2 * BOX / 3)]
+        n = len(posm_g)
+        e = 61 - int(np.frexp(float(n))[1])
+        og, opot, _, _ = orc.pm_force(posm_g[:, :3].copy(), posm_g[:, 3].astype(np.float32), NMESH, BOX, 1.5, G, fixed_point_log2scale=e,
+                                      use_stencil=1)
+        key = {tuple(p): i for i, p in enumerate(map(tuple, posm_g[:, :3]))}
+        seen = 0
+        for r in range(3):
+            a = np.load(os.path.join(tmp, "e%d.npy" % r))
+            if r == 1:
+                assert len(a) == 0
+                continue
+            idx = np.array([key[tuple(p)] for p in a[:, :3]])
+            seen += len(idx)
+            assert np.abs(a[:, 4:7] - og[idx]).max() < 1e-11 * np.abs(og).max()
+            assert np.abs(a[:, 7] - opot[idx]).max() < 1e-11 * np.abs(opot).max()
+        assert seen == n

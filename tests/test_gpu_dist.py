@@ -126,3 +126,44 @@ def test_dist_driver_one_rccl_rank_collectives_forced():
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker, args=(1, os.path.join(tmp, "init"), tmp, "nccl"), nprocs=1, join=True)
         _check(tmp, 1)
+
+
+def test_device_particle_set_semantics(ctx):
+    """shq_particles_set_device: nlocal = 0 is a rank that owns nothing (no deposit, no targets); a new set drops the tree
+    (a walk is refused until the next build) unless the caller vouches the positions are the tree's"""
+    import shenqi_amd as sq
+    from shenqi_amd import capi
+    import common as cm
+    posm = torch.from_numpy(_global_particles()[:2000].copy()).to("cuda:0")
+    pm = capi.PMParams(NMESH, 0, BOX, 1.5, G)
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=1)
+    sq.gravshort_set_softenings(BOX / 16)
+    gp = sq.make_grav_params(BOX, 1.5, NMESH, G, cm.RHO0)
+    torch.cuda.synchronize()
+    # all 2000 rows are ghosts: nothing may be deposited (the old "0 means all" reading put every ghost on the mesh)
+    capi.check(capi.hip.shq_particles_set_device(ctx.h, C.c_void_p(posm.data_ptr()), 2000, 0, 0))
+    capi.check(capi.hip.shq_pm_set_deposit_log2scale(ctx.h, 40))
+    mesh = torch.ones((NMESH, NMESH, NMESH + 2), dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    capi.check(capi.hip.shq_pm_slab_deposit(ctx.h, C.byref(pm), 0, NMESH, C.c_void_p(mesh.data_ptr())))
+    ctx.synchronize()
+    assert int(mesh.abs().sum().item()) == 0
+    sq.tree_build_device(ctx, BOX)
+    capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, sq.WALK_EXACT))
+    st = sq.WalkStats()
+    capi.check(capi.hip.shq_grav_short_download(ctx.h, None, None, None, C.byref(st)))
+    assert st.ntargets == 0 and st.ninteractions == 0
+    # own particles: the first 1500
+    capi.check(capi.hip.shq_particles_set_device(ctx.h, C.c_void_p(posm.data_ptr()), 2000, 1500, 0))
+    assert capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, sq.WALK_EXACT) != 0      # same count, but the tree was dropped
+    sq.tree_build_device(ctx, BOX)
+    capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, sq.WALK_EXACT))
+    capi.check(capi.hip.shq_grav_short_download(ctx.h, None, None, None, C.byref(st)))
+    assert st.ntargets == 1500
+    n1 = st.ninteractions
+    capi.check(capi.hip.shq_particles_set_device(ctx.h, C.c_void_p(posm.data_ptr()), 2000, 1500, 1))    # frozen positions: the tree stays
+    capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, sq.WALK_EXACT))
+    capi.check(capi.hip.shq_grav_short_download(ctx.h, None, None, None, C.byref(st)))
+    assert st.ntargets == 1500 and st.ninteractions == n1
+    capi.check(capi.hip.shq_pm_set_deposit_log2scale(ctx.h, -1))     # the session context goes back to its own scale rule
+    cm.reference_treepar()

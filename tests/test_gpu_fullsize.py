@@ -31,6 +31,31 @@ def test_baseline_256_properties(ctx):
     P["Pos"] = pos
     P["Type"] = 1
     P["Mass"] = 1.0
+    _treepm_properties(ctx, pman, n1, nmesh, L, stride=256)
+
+
+def test_c3_gravity_2x128_properties(ctx):
+    """BASELINE.json configs[2], gravity half: 2 x 128^3 gas + dark matter (uniform, as the initial conditions of examples/small
+    nearly are; masses Omega_b : Omega_m - Omega_b), Nmesh 384: PM + short-range walk over both species, same properties and
+    the same sampled oracle comparison as the 256^3 case (bench.py's kernels.c3_* figures time exactly this)."""
+    n1, L = 128, 1.0
+    n = n1**3
+    gas = sq.synth_positions("uniform", n, L=L)
+    dm = sq.synth_positions("uniform", n, seed=77, L=L)
+    pos = np.concatenate([gas, dm])
+    order = sq.hilbert_order(pos, L)
+    pman = sq.PartManager(2 * n, L)
+    P = pman.Base
+    P["Pos"] = pos[order]
+    P["Type"] = np.where(order < n, 0, 1).astype(np.uint8)
+    P["Mass"] = np.where(order < n, 0.16, 0.84)
+    _treepm_properties(ctx, pman, n1, 3 * n1, L, stride=64)
+
+
+def _treepm_properties(ctx, pman, n1, nmesh, L, stride):
+    P = pman.Base
+    n = pman.NumPart
+    pos = P["Pos"].copy()
     pv = pman.view()
     capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
     tb = sq.tree_build_device(ctx, L)
@@ -45,7 +70,8 @@ def test_baseline_256_properties(ctx):
         capi.check(capi.hip.shq_pm_download(ctx.h, capi.ptr(gpm[k]), capi.ptr(ppot[k])))
     assert np.array_equal(gpm[0], gpm[1]) and np.array_equal(ppot[0], ppot[1])
     assert np.all(np.isfinite(gpm[0]))
-    assert np.abs(gpm[0].sum(axis=0)).max() < 1e-9 * np.abs(gpm[0]).sum()
+    mg = P["Mass"][:, None].astype(np.float64) * gpm[0]
+    assert np.abs(mg.sum(axis=0)).max() < 1e-9 * np.abs(mg).sum()
 
     # ---- walks: Barnes-Hut seed, then the relative criterion of the north-star setting
     sq.set_gravshort_treepar(ErrTolForceAcc=0.005, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=1, Rcut=6.0)
@@ -64,11 +90,12 @@ def test_baseline_256_properties(ctx):
     assert st.ninteractions == int(nint.sum()) and st.min_interactions == nint.min() and st.max_interactions == nint.max()
     assert np.all(np.isfinite(acc)) and np.all(np.isfinite(pot))
     # tree code: momentum is conserved to the force accuracy, not exactly
-    assert np.abs(acc.sum(axis=0)).max() < 1e-3 * np.abs(acc).sum()
+    macc = P["Mass"][:, None].astype(np.float64) * acc
+    assert np.abs(macc.sum(axis=0)).max() < 1e-3 * np.abs(macc).sum()
 
     # ---- oracle on every 256th 64-target group, walking the DEVICE-built tree
     nodes, _ = sq.tree_download(ctx, n, 0)
-    groups = np.arange(0, n // 64, 256)
+    groups = np.arange(0, n // 64, stride)
     targets = (groups[:, None] * 64 + np.arange(64)[None, :]).ravel().astype(np.int32)
     oldacc = np.linalg.norm(seed + gpm[0], axis=1) / G
     oacc, opot, onint = orc.grav_walk(nodes, n, pos, P["Mass"], oldacc, gp, targets=targets)
