@@ -302,7 +302,7 @@ struct shq_context {
         int wsel = 0, niter = 0;
         int phase = 0;          /* 0 none, 1 density, 2 hydro */
     } sphrun;
-    DevBuf<int32_t> s_ncount, s_redo; /* list lengths; targets of waves whose lists overflowed */
+    DevBuf<int32_t> s_ncount, s_redo, s_redo2; /* list lengths; targets whose lists overflowed (a wave each); the heaviest of those (a workgroup each) */
     DevBuf<long long> s_counters;
 
     /* ---- PM */

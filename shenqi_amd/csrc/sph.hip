@@ -157,6 +157,9 @@ struct SphDev {
     double *hacc;     /* [N][3] */
     double *dtent, *maxsig;
     double Box, invBox;
+    /* targets too heavy even for a wave of their own: handed on to the one-target-per-workgroup kernel */
+    int32_t *heavy2;
+    long long *nheavy2;
 };
 
 /* ---- prepass: per-particle predicted quantities -------------------------------------------- */
@@ -322,6 +325,7 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
     int ncand = 0;
     fill = 0;
     ovf = false;
+    int mynext = valid ? a.root : -2;
 
     /* scan the queued candidates: one coalesced gather, then broadcast reads */
     auto scan_tile = [&]() {
@@ -338,7 +342,7 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
             const unsigned long long km = tmask[j];
             const int sf = tsl[j], s = sf & 0x3fffffff, fl = (int) ((unsigned) sf >> 30);
             const double hj = SYM ? th[j] : 0.0;
-            const bool keep = ((km >> lane) & 1ull) && !(fl & 1);
+            const bool keep = ((km >> lane) & 1ull) && !(fl & 1) && !(KEEP && ovf);
             double d0 = px - q.x, d1 = py - q.y, d2 = pz - q.z;
             if(shq_ballot(fmax(fmax(fabs(d0), fabs(d1)), fabs(d2)) > halfBox) != 0ull) { /* any lane: a rare, harmless over-trigger */
                 d0 = wrapd(d0, a.Box, a.invBox);
@@ -354,9 +358,11 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
                 }
             }
             if(KEEP) {
-                if(fill == NL_CAP) {
+                if(fill == NL_CAP) { /* this target's list does not fit: it leaves the walk (the others' lists stay good) and is
+                                        walked on its own by a whole wave afterwards (heavy_walk) */
                     ovf = true;
                     fill = 0;
+                    mynext = -2;
                 }
             } else if(shq_ballot(fill == NL_CAP) != 0ull) {
                 if(dbg)
@@ -370,7 +376,6 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
         ncand = 0;
     };
 
-    int mynext = valid ? a.root : -2;
     int seg1 = -1, seg2 = -1, seg3 = -1, myend = -1;
     if(GHOSTS) {
         mynext = (valid && seg.x >= 0) ? seg.x : -2;
@@ -431,18 +436,18 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
                 }
                 ncand += Ccount;
             }
-            if(act)
+            if(act && !(KEEP && ovf)) /* a target that left the walk inside scan_tile stays out */
                 mynext = Csib;
             next = Csib;
         } else if(Ctype == SHQ_PSEUDO_NODE_TYPE) {
-            if(act)
+            if(act && !(KEEP && ovf))
                 mynext = Csib;
             next = Csib;
         } else {
             bool any = keepm != 0ull;
             if(GHOSTS) /* a lane waits at a branch below this node: go down even if nobody opens it */
                 any = any || shq_ballot(mynext > cur && (Csib < 0 || mynext < Csib)) != 0ull;
-            if(act)
+            if(act && !(KEEP && ovf))
                 mynext = keep ? Cchild : Csib;
             next = any ? Cchild : Csib;
         }
@@ -468,26 +473,314 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
     return nint;
 }
 
+/* ---- one target, one wave --------------------------------------------------------------------------------------
+ * A target whose neighbour list outgrows NL_CAP (gas next to a density caustic: the kernel-weighted count reaches its
+ * target only when the support sphere already holds thousands of particles near its rim) would keep one lane busy for
+ * as many rounds as it has neighbours while the other 63 idle.  Such targets are taken out of the group walks and each
+ * gets a wave to itself, with the lanes on the work instead of on targets: node rounds pop up to 64 nodes of an LDS
+ * stack and cull them one per lane (cull_node, localtreewalk2.h:154-182, against the one target), kept leaves queue
+ * their particle slots, and candidate rounds take 64 queued particles, one per lane, through the same accept / pair
+ * code; the lanes' partial sums are added across the wave at the end.  Same neighbour set and candidate count as the
+ * group walk; the sum runs in a different order (rounding-level differences). */
+#define HW_STACK 1024
+#define HW_SOFT 512   /* above this fill the walk goes depth-first, one node per round: at most 7 more per tree level */
+#define HW_CAND 640   /* < 64 pending + <= 64 x 8 queued per node round */
+#define HW_LDS ((HW_STACK + HW_CAND) * 4)
+
+#define HW_ABORT 16384 /* candidates after which a wave gives its target up to a whole workgroup (heavy_block) */
+
+template <bool SYM, class Accept, class Pair>
+__device__ __forceinline__ unsigned int heavy_walk(const SphDev &a, char *lds_wave, const double px, const double py, const double pz,
+                                                   const double h, Accept &&accept, Pair &&pair, bool &aborted)
+{
+    int *stk = reinterpret_cast<int *>(lds_wave);
+    int *cq = stk + HW_STACK;
+    const int lane = threadIdx.x & 63;
+    unsigned int nint = 0;
+    int S = 1, nc = 0, chead = 0, done = 0;
+    aborted = false;
+    if(lane == 0)
+        stk[0] = a.root;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for(;;) {
+        if(nc >= 64 || (S == 0 && nc > 0)) {
+            /* candidate round */
+            const int m = nc < 64 ? nc : 64;
+            if(lane < m) {
+                const int s = cq[(chead + lane) % HW_CAND];
+                const double4 q = a.posm_leaf[s];
+                const int fl = a.flag_leaf[s];
+                const double hj = SYM ? a.hsml_leaf[s] : 0.0;
+                if(!(fl & 1)) {
+                    nint++;
+                    const double d0 = wrapd(px - q.x, a.Box, a.invBox), d1 = wrapd(py - q.y, a.Box, a.invBox), d2 = wrapd(pz - q.z, a.Box, a.invBox);
+                    if(accept(d0 * d0 + d1 * d1 + d2 * d2, hj, fl))
+                        pair(s);
+                }
+            }
+            chead = (chead + m) % HW_CAND;
+            nc -= m;
+            done += m;
+            if(done > HW_ABORT && a.heavy2) {
+                aborted = true;
+                return 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else if(S > 0) {
+            /* node round */
+            int k = S < 64 ? S : 64;
+            const int room = (HW_SOFT - S) / 7;
+            if(room < k)
+                k = room > 1 ? room : 1;
+            const bool on = lane < k;
+            const int node = on ? stk[S - 1 - lane] : 0;
+            S -= k;
+            __builtin_amdgcn_wave_barrier();
+            bool keep = false;
+            NodeC nc4;
+            nc4.sibling = nc4.child = -1;
+            nc4.type = SHQ_PSEUDO_NODE_TYPE;
+            nc4.count = 0;
+            if(on) {
+                const NodeB nb = a.nodeB[node];
+                nc4 = a.nodeC[node];
+                const double dist = (SYM ? fmax(a.hmax[node], h) : h) + 0.5 * nb.len;
+                const double dx = wrapd(nb.center[0] - px, a.Box, a.invBox), dy = wrapd(nb.center[1] - py, a.Box, a.invBox),
+                             dz = wrapd(nb.center[2] - pz, a.Box, a.invBox);
+                const double dmax = fmax(fmax(fabs(dx), fabs(dy)), fabs(dz));
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                const double dist2 = dist + (0.5 * (1.7320508075688772 - 1.0)) * nb.len;
+                keep = !(dmax > dist) && !(r2 > dist2 * dist2);
+            }
+            /* kept leaves queue their particle slots */
+            const bool leaf = keep && nc4.type == SHQ_PARTICLE_NODE_TYPE;
+#pragma unroll
+            for(int j = 0; j < SHQ_NMAXCHILD; j++) {
+                const bool has = leaf && j < nc4.count;
+                const unsigned long long msk = shq_ballot(has);
+                if(msk == 0ull)
+                    break;
+                if(has)
+                    cq[(chead + nc + __builtin_amdgcn_mbcnt_hi((unsigned) (msk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) msk, 0u))) % HW_CAND] =
+                        nc4.child + j;
+                nc += __popcll(msk);
+            }
+            /* kept internal nodes push their children: the first one, then along the sibling links up to the node's own sibling */
+            int c = (keep && nc4.type == SHQ_NODE_NODE_TYPE) ? nc4.child : -1;
+            for(int j = 0; j < 8; j++) {
+                const bool has = c >= 0 && c != nc4.sibling;
+                const unsigned long long msk = shq_ballot(has);
+                if(msk == 0ull)
+                    break;
+                if(has) {
+                    const int at = S + __builtin_amdgcn_mbcnt_hi((unsigned) (msk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) msk, 0u));
+                    if(at < HW_STACK)
+                        stk[at] = c;
+                    c = a.nodeC[c].sibling;
+                }
+                S += __popcll(msk);
+            }
+            if(S > HW_STACK) { /* deeper than the slack allows (64 levels): stop rather than walk a truncated stack; the sums come out wrong and
+                                  the Hsml loop reports non-convergence */
+                S = 0;
+                nc = 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else
+            break;
+    }
+    return nint;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for(int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off);
+    return v;
+}
+
+/* ---- one target, one workgroup of 8 waves: the same walk for the few targets whose support sphere holds a good part of a
+ * dense clump (10^5 - 10^6 candidates: a wave alone would need tens of milliseconds).  Stack and candidate queue are shared
+ * in LDS; every position comes from prefix sums over the thread index, so which thread meets which candidate — and with it
+ * the order of the sum — is fixed: results are reproducible run to run. */
+#define HB_THREADS 512
+#define HB_WAVES (HB_THREADS / 64)
+#define HB_STACK 8192
+#define HB_SOFT 4096
+#define HB_CAND (HB_THREADS * 9)
+
+struct HbShared {
+    int stk[HB_STACK];
+    int cq[HB_CAND];
+    int wtot[2][HB_WAVES];
+    double red[HB_WAVES];
+    int S, nc, chead;
+};
+
+/* exclusive prefix over the threads of the workgroup of a count in [0, 8]; total to all */
+__device__ __forceinline__ int hb_scan8(int v, int *wtot, int &total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long b0 = shq_ballot((v & 1) != 0), b1 = shq_ballot((v & 2) != 0), b2 = shq_ballot((v & 4) != 0), b3 = shq_ballot((v & 8) != 0);
+    auto mb = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u)); };
+    const int pre = mb(b0) + 2 * mb(b1) + 4 * mb(b2) + 8 * mb(b3);
+    if(lane == 0)
+        wtot[wv] = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3);
+    __syncthreads();
+    int base = 0;
+    total = 0;
+    for(int w = 0; w < HB_WAVES; w++) {
+        const int c = wtot[w];
+        if(w < wv)
+            base += c;
+        total += c;
+    }
+    return base + pre;
+}
+
+__device__ __forceinline__ double hb_sum(double v, double *red)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0;
+    for(int w = 0; w < HB_WAVES; w++)
+        t += red[w];
+    return t;
+}
+
+__device__ __forceinline__ double hb_max(double v, double *red)
+{
+    for(int off = 32; off > 0; off >>= 1)
+        v = fmax(v, __shfl_xor(v, off));
+    __syncthreads();
+    if((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = red[0];
+    for(int w = 1; w < HB_WAVES; w++)
+        t = fmax(t, red[w]);
+    return t;
+}
+
+template <bool SYM, class Accept, class Pair>
+__device__ __forceinline__ unsigned int heavy_block(const SphDev &a, HbShared &sh, const double px, const double py, const double pz, const double h,
+                                                    Accept &&accept, Pair &&pair)
+{
+    const int tid = threadIdx.x;
+    unsigned int nint = 0;
+    __syncthreads();
+    if(tid == 0) {
+        sh.stk[0] = a.root;
+        sh.S = 1;
+        sh.nc = 0;
+        sh.chead = 0;
+    }
+    for(;;) {
+        __syncthreads();
+        const int S = sh.S, nc = sh.nc, chead = sh.chead;
+        __syncthreads();
+        if(nc >= HB_THREADS || (S == 0 && nc > 0)) {
+            const int m = nc < HB_THREADS ? nc : HB_THREADS;
+            if(tid < m) {
+                const int s = sh.cq[(chead + tid) % HB_CAND];
+                const double4 q = a.posm_leaf[s];
+                const int fl = a.flag_leaf[s];
+                const double hj = SYM ? a.hsml_leaf[s] : 0.0;
+                if(!(fl & 1)) {
+                    nint++;
+                    const double d0 = wrapd(px - q.x, a.Box, a.invBox), d1 = wrapd(py - q.y, a.Box, a.invBox), d2 = wrapd(pz - q.z, a.Box, a.invBox);
+                    if(accept(d0 * d0 + d1 * d1 + d2 * d2, hj, fl))
+                        pair(s);
+                }
+            }
+            if(tid == 0) {
+                sh.chead = (chead + m) % HB_CAND;
+                sh.nc = nc - m;
+            }
+        } else if(S > 0) {
+            int k = S < HB_THREADS ? S : HB_THREADS;
+            const int room = (HB_SOFT - S) / 7;
+            if(room < k)
+                k = room > 1 ? room : 1;
+            const bool on = tid < k;
+            const int node = on ? sh.stk[S - 1 - tid] : 0;
+            bool keep = false;
+            NodeC nc4;
+            nc4.sibling = nc4.child = -1;
+            nc4.type = SHQ_PSEUDO_NODE_TYPE;
+            nc4.count = 0;
+            if(on) {
+                const NodeB nb = a.nodeB[node];
+                nc4 = a.nodeC[node];
+                const double dist = (SYM ? fmax(a.hmax[node], h) : h) + 0.5 * nb.len;
+                const double dx = wrapd(nb.center[0] - px, a.Box, a.invBox), dy = wrapd(nb.center[1] - py, a.Box, a.invBox),
+                             dz = wrapd(nb.center[2] - pz, a.Box, a.invBox);
+                const double dmax = fmax(fmax(fabs(dx), fabs(dy)), fabs(dz));
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                const double dist2 = dist + (0.5 * (1.7320508075688772 - 1.0)) * nb.len;
+                keep = !(dmax > dist) && !(r2 > dist2 * dist2);
+            }
+            const int cl = (keep && nc4.type == SHQ_PARTICLE_NODE_TYPE) ? nc4.count : 0;
+            int kid[8], nk = 0;
+            {
+                int c = (keep && nc4.type == SHQ_NODE_NODE_TYPE) ? nc4.child : -1;
+#pragma unroll
+                for(int j = 0; j < 8; j++) {
+                    const bool has = c >= 0 && c != nc4.sibling;
+                    kid[j] = has ? c : -1;
+                    if(has) {
+                        nk++;
+                        c = a.nodeC[c].sibling;
+                    } else
+                        c = -1;
+                }
+            }
+            int totc = 0, totk = 0;
+            const int offc = hb_scan8(cl, sh.wtot[0], totc); /* its barrier also orders the pops above before the pushes below */
+            const int offk = hb_scan8(nk, sh.wtot[1], totk);
+#pragma unroll
+            for(int j = 0; j < 8; j++) {
+                if(j < cl)
+                    sh.cq[(chead + nc + offc + j) % HB_CAND] = nc4.child + j;
+                if(j < nk && S - k + offk + j < HB_STACK)
+                    sh.stk[S - k + offk + j] = kid[j];
+            }
+            if(tid == 0) {
+                sh.nc = nc + totc;
+                sh.S = (S - k + totk > HB_STACK) ? 0 : S - k + totk; /* deeper than the slack allows: stop (see heavy_walk) */
+            }
+        } else
+            break;
+    }
+    return nint;
+}
+
 /* MODE 0: fused walk + evaluation (persistent grid, one list region per resident wave; also the redo path:
  * d_nq != NULL takes the queue length from the device).  MODE 1: walk only, lists and their lengths go to
- * global memory (one region per wave of the launch).  MODE 2: evaluation only, from those lists.  The
+ * global memory (one region per wave of the launch).  MODE 2: evaluation only, from those lists.  MODE 3: one target
+ * per wave (heavy_walk) for the targets whose list did not fit; launched with 64 threads per block.  The
  * two-kernel path lets the walk run at twice the occupancy the register-heavy evaluation allows. */
-template <int KT, int MODE, bool GHOSTS = false>
-__global__ __launch_bounds__(256) void sph_density_kernel(const SphDev a, const int32_t *queue, long long nq, int WindsDecouple,
-                                                          unsigned long long *nint_total, int32_t *__restrict__ nlist, long long ntasks,
-                                                          int32_t *__restrict__ counts, const long long *d_nq, const int4 *qseg = nullptr)
+template <int KT, int MODE, bool GHOSTS>
+__device__ __forceinline__ void sph_density_body(const SphDev &a, const int32_t *queue, long long nq, int WindsDecouple,
+                                                 unsigned long long *nint_total, int32_t *__restrict__ nlist, long long ntasks,
+                                                 int32_t *__restrict__ counts, const long long *d_nq, const int4 *qseg)
 {
-    __shared__ __attribute__((aligned(32))) char lds[(MODE == 2 ? 1 : (MODE == 1 ? SPH_WALK_WPB : 4) * NW_LDS_PER_WAVE(false))];
+    __shared__ __attribute__((aligned(32))) char lds[MODE == 4 ? sizeof(HbShared) : (MODE == 3 ? HW_LDS : (MODE == 2 ? 1 : (MODE == 1 ? SPH_WALK_WPB : 4) * NW_LDS_PER_WAVE(false)))];
     const int lane = threadIdx.x & 63;
-    if(MODE == 0 && d_nq) {
+    if((MODE == 0 || MODE >= 3) && d_nq) {
         nq = *d_nq;
-        ntasks = (nq + 255) / 256;
+        ntasks = MODE >= 3 ? nq : (nq + 255) / 256;
     }
     for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
-    const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long wave = MODE == 4 ? task : task * (blockDim.x >> 6) + (threadIdx.x >> 6);
     int32_t *myl = nlist + (MODE == 0 ? ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) : (size_t) wave) * (size_t) (NL_CAP * 64) + lane;
-    const long long t = wave * 64 + lane;
-    const bool valid = t < nq;
+    const long long t = MODE >= 3 ? wave : wave * 64 + lane; /* MODE 3 / 4: every lane of the wave / workgroup works for the same target */
+    bool valid = t < nq;
     long long pi = 0;
     double px = 0, py = 0, pz = 0, h = 0, vx = 0, vy = 0, vz = 0;
     int type = 0;
@@ -542,20 +835,39 @@ __global__ __launch_bounds__(256) void sph_density_kernel(const SphDev a, const 
     unsigned int nint = 0;
     int fill = 0;
     bool ovf = false;
-    if(MODE != 2)
+    if(MODE == 4) {
+        HbShared &sh = *reinterpret_cast<HbShared *>(lds);
+        nint = heavy_block<false>(a, sh, px, py, pz, h, accept, pair);
+        Ngb = hb_sum(Ngb, sh.red); Rho = hb_sum(Rho, sh.red); DhsmlDensity = hb_sum(DhsmlDensity, sh.red); EgyRho = hb_sum(EgyRho, sh.red);
+        DhsmlEgy = hb_sum(DhsmlEgy, sh.red); Div = hb_sum(Div, sh.red); R0 = hb_sum(R0, sh.red); R1 = hb_sum(R1, sh.red); R2 = hb_sum(R2, sh.red);
+        G0 = hb_sum(G0, sh.red); G1 = hb_sum(G1, sh.red); G2 = hb_sum(G2, sh.red);
+        valid = threadIdx.x == 0;
+    } else if(MODE == 3) {
+        bool aborted = false;
+        nint = heavy_walk<false>(a, lds, px, py, pz, h, accept, pair, aborted);
+        if(aborted) { /* too much for one wave: a whole workgroup takes it */
+            if(lane == 0)
+                a.heavy2[atomicAdd((unsigned long long *) a.nheavy2, 1ull)] = (int32_t) pi;
+            continue;
+        }
+        Ngb = wave_sum(Ngb); Rho = wave_sum(Rho); DhsmlDensity = wave_sum(DhsmlDensity); EgyRho = wave_sum(EgyRho); DhsmlEgy = wave_sum(DhsmlEgy);
+        Div = wave_sum(Div); R0 = wave_sum(R0); R1 = wave_sum(R1); R2 = wave_sum(R2); G0 = wave_sum(G0); G1 = wave_sum(G1); G2 = wave_sum(G2);
+        valid = lane == 0;
+    } else if(MODE != 2)
         nint = ngb_walk<false, MODE == 1, GHOSTS>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(false), myl, valid, px, py, pz, h, accept, pair,
                                                   (unsigned int *) nullptr, fill, ovf,
                                                   (GHOSTS && valid) ? qseg[t] : make_int4(-1, -1, -1, -1));
     if(MODE == 1) {
-        const bool wave_ovf = shq_ballot(ovf) != 0ull;
-        counts[wave * 64 + lane] = wave_ovf ? -1 : fill;
-        if(wave_ovf)
-            nint = 0; /* counted when the wave is redone */
+        counts[wave * 64 + lane] = ovf ? -1 : fill; /* -1: this target goes to the one-target-per-wave kernel */
+        if(ovf)
+            nint = 0; /* counted there */
     }
     if(MODE == 2) {
         fill = counts[wave * 64 + lane];
-        if(fill < 0)
-            continue; /* the whole wave overflowed: left to the fused kernel */
+        if(fill < 0) { /* walked on its own (MODE 3) */
+            fill = 0;
+            valid = false;
+        }
         nl_flush(myl, fill, pair);
     }
     if(MODE != 1 && valid) {
@@ -583,6 +895,22 @@ __global__ __launch_bounds__(256) void sph_density_kernel(const SphDev a, const 
     if(lane == 0 && nint_total)
         atomicAdd(nint_total, (unsigned long long) sn);
     } /* task loop */
+}
+
+template <int KT, int MODE, bool GHOSTS = false>
+__global__ __launch_bounds__(256) void sph_density_kernel(const SphDev a, const int32_t *queue, long long nq, int WindsDecouple,
+                                                          unsigned long long *nint_total, int32_t *__restrict__ nlist, long long ntasks,
+                                                          int32_t *__restrict__ counts, const long long *d_nq, const int4 *qseg = nullptr)
+{
+    sph_density_body<KT, MODE, GHOSTS>(a, queue, nq, WindsDecouple, nint_total, nlist, ntasks, counts, d_nq, qseg);
+}
+
+/* MODE 4: one target per workgroup of 512 threads */
+template <int KT>
+__global__ __launch_bounds__(HB_THREADS) void sph_density_block_kernel(const SphDev a, const int32_t *queue, int WindsDecouple,
+                                                                       unsigned long long *nint_total, const long long *d_nq)
+{
+    sph_density_body<KT, 4, false>(a, queue, 0, WindsDecouple, nint_total, nullptr, 0, nullptr, d_nq, nullptr);
 }
 
 /* ---- density postprocess + Hsml update (DensityOutput::postprocess, density_check_neighbours) -- */
@@ -759,22 +1087,22 @@ struct HydroConst {
 };
 
 /* MODE as for sph_density_kernel */
-template <int KT, int MODE, bool GHOSTS = false>
-__global__ __launch_bounds__(256, 4) void sph_hydro_kernel(const SphDev a, const int32_t *queue, long long nq, const HydroConst hc,
-                                                           unsigned long long *nint_total, int32_t *__restrict__ nlist, long long ntasks,
-                                                           int32_t *__restrict__ counts, const long long *d_nq, const int4 *qseg = nullptr)
+template <int KT, int MODE, bool GHOSTS>
+__device__ __forceinline__ void sph_hydro_body(const SphDev &a, const int32_t *queue, long long nq, const HydroConst &hc,
+                                               unsigned long long *nint_total, int32_t *__restrict__ nlist, long long ntasks,
+                                               int32_t *__restrict__ counts, const long long *d_nq, const int4 *qseg)
 {
-    __shared__ __attribute__((aligned(32))) char lds[(MODE == 2 ? 1 : (MODE == 1 ? SPH_WALK_WPB : 4) * NW_LDS_PER_WAVE(true))];
+    __shared__ __attribute__((aligned(32))) char lds[MODE == 4 ? sizeof(HbShared) : (MODE == 3 ? HW_LDS : (MODE == 2 ? 1 : (MODE == 1 ? SPH_WALK_WPB : 4) * NW_LDS_PER_WAVE(true)))];
     const int lane = threadIdx.x & 63;
-    if(MODE == 0 && d_nq) {
+    if((MODE == 0 || MODE >= 3) && d_nq) {
         nq = *d_nq;
-        ntasks = (nq + 255) / 256;
+        ntasks = MODE >= 3 ? nq : (nq + 255) / 256;
     }
     for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
-    const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long wave = MODE == 4 ? task : task * (blockDim.x >> 6) + (threadIdx.x >> 6);
     int32_t *myl = nlist + (MODE == 0 ? ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) : (size_t) wave) * (size_t) (NL_CAP * 64) + lane;
-    const long long t = wave * 64 + lane;
-    const bool valid = t < nq;
+    const long long t = MODE >= 3 ? wave : wave * 64 + lane; /* MODE 3 / 4: every lane of the wave / workgroup works for the same target */
+    bool valid = t < nq;
     long long pi = 0;
     double px = 0, py = 0, pz = 0, mi = 0, hi = 1, vx = 0, vy = 0, vz = 0;
     double4 Ci = make_double4(1, 1, 1, 1), Di = make_double4(0, 0, 0, 0);
@@ -865,20 +1193,39 @@ __global__ __launch_bounds__(256, 4) void sph_hydro_kernel(const SphDev a, const
     unsigned int nint = 0;
     int fill = 0;
     bool ovf = false;
-    if(MODE != 2)
+    if(MODE == 4) {
+        HbShared &sh = *reinterpret_cast<HbShared *>(lds);
+        nint = heavy_block<true>(a, sh, px, py, pz, hi, accept, pair);
+        A0 = hb_sum(A0, sh.red); A1 = hb_sum(A1, sh.red); A2 = hb_sum(A2, sh.red); DtE = hb_sum(DtE, sh.red);
+        MaxSig = hb_max(MaxSig, sh.red);
+        valid = threadIdx.x == 0;
+    } else if(MODE == 3) {
+        bool aborted = false;
+        nint = heavy_walk<true>(a, lds, px, py, pz, hi, accept, pair, aborted);
+        if(aborted) { /* too much for one wave: a whole workgroup takes it */
+            if(lane == 0)
+                a.heavy2[atomicAdd((unsigned long long *) a.nheavy2, 1ull)] = (int32_t) pi;
+            continue;
+        }
+        A0 = wave_sum(A0); A1 = wave_sum(A1); A2 = wave_sum(A2); DtE = wave_sum(DtE);
+        for(int off = 32; off > 0; off >>= 1)
+            MaxSig = fmax(MaxSig, __shfl_xor(MaxSig, off));
+        valid = lane == 0;
+    } else if(MODE != 2)
         nint = ngb_walk<true, MODE == 1, GHOSTS>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(true), myl, valid, px, py, pz, hi, accept, pair,
                                                  (MODE == 0 && nint_total && !GHOSTS) ? dbgc : (unsigned int *) nullptr, fill, ovf,
                                                  (GHOSTS && valid) ? qseg[t] : make_int4(-1, -1, -1, -1));
     if(MODE == 1) {
-        const bool wave_ovf = shq_ballot(ovf) != 0ull;
-        counts[wave * 64 + lane] = wave_ovf ? -1 : fill;
-        if(wave_ovf)
-            nint = 0; /* counted when the wave is redone */
+        counts[wave * 64 + lane] = ovf ? -1 : fill; /* -1: this target goes to the one-target-per-wave kernel */
+        if(ovf)
+            nint = 0; /* counted there */
     }
     if(MODE == 2) {
         fill = counts[wave * 64 + lane];
-        if(fill < 0)
-            continue; /* the whole wave overflowed: left to the fused kernel */
+        if(fill < 0) { /* walked on its own (MODE 3) */
+            fill = 0;
+            valid = false;
+        }
         nl_flush(myl, fill, pair);
     }
     if(MODE != 1 && valid) {
@@ -901,6 +1248,22 @@ __global__ __launch_bounds__(256, 4) void sph_hydro_kernel(const SphDev a, const
         }
     }
     } /* task loop */
+}
+
+template <int KT, int MODE, bool GHOSTS = false>
+__global__ __launch_bounds__(256, 4) void sph_hydro_kernel(const SphDev a, const int32_t *queue, long long nq, const HydroConst hc,
+                                                           unsigned long long *nint_total, int32_t *__restrict__ nlist, long long ntasks,
+                                                           int32_t *__restrict__ counts, const long long *d_nq, const int4 *qseg = nullptr)
+{
+    sph_hydro_body<KT, MODE, GHOSTS>(a, queue, nq, hc, nint_total, nlist, ntasks, counts, d_nq, qseg);
+}
+
+/* MODE 4: one target per workgroup of 512 threads */
+template <int KT>
+__global__ __launch_bounds__(HB_THREADS) void sph_hydro_block_kernel(const SphDev a, const int32_t *queue, const HydroConst hc,
+                                                                     unsigned long long *nint_total, const long long *d_nq)
+{
+    sph_hydro_body<KT, 4, false>(a, queue, 0, hc, nint_total, nullptr, 0, nullptr, d_nq, nullptr);
 }
 
 /* HydroOutput::postprocess, hydratree2.hpp:134-148 + winds_decoupled_hydro, winds.h:60-68 */
@@ -977,6 +1340,8 @@ SphDev make_dev(shq_context *ctx)
     a.hacc = ctx->g_hydroaccel_out.ptr;
     a.dtent = ctx->g_dtentropy_out.ptr;
     a.maxsig = ctx->g_maxsignalvel.ptr;
+    a.heavy2 = ctx->s_redo2.ptr;               /* null until a walk reserved it: the wave tier then never gives up */
+    a.nheavy2 = ctx->s_counters.ptr ? ctx->s_counters.ptr + 7 : nullptr;
     a.Box = ctx->treeBox;
     a.invBox = 1.0 / ctx->treeBox;
     return a;
@@ -1039,18 +1404,18 @@ int shq_sph_prepare(shq_context *ctx, const shq_kick_factors *kf, const shq_hydr
 /* ---- launch: two kernels per chunk of targets + redo of overflowed waves ---------------------------- */
 #define NL_CHUNK (1ll << 22)  /* targets per chunk: 4 Mi x NL_CAP x 4 B = 4 GB of list scratch */
 #define NL_REDO_BLOCKS 1024
+#define NL_BLOCK_BLOCKS 512  /* 512-thread workgroups of the one-target-per-workgroup kernel */
+#define NL_HEAVY_BLOCKS 8192 /* single-wave workgroups of the one-target-per-wave kernel (it takes its queue length from the device) */
 
-/* waves of the chunk whose lists overflowed: append their targets to the redo queue */
+/* targets of the chunk whose lists overflowed: append them to the queue of the one-target-per-wave kernel */
 __global__ void sph_collect_redo_kernel(const int32_t *__restrict__ counts, const int32_t *__restrict__ queue, long long nq, int32_t *redo,
                                         long long *nredo)
 {
-    const long long w = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if(w * 64 >= nq || counts[w * 64] >= 0)
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= nq || counts[t] >= 0)
         return;
-    const long long first = w * 64, cnt = (nq - first < 64) ? nq - first : 64;
-    const long long at = (long long) atomicAdd((unsigned long long *) nredo, (unsigned long long) cnt);
-    for(long long k = 0; k < cnt; k++)
-        redo[at + k] = queue ? queue[first + k] : (int32_t) (first + k);
+    const long long at = (long long) atomicAdd((unsigned long long *) nredo, 1ull);
+    redo[at] = queue ? queue[t] : (int32_t) t;
 }
 
 static long long nl_chunk_waves(long long nq)
@@ -1066,17 +1431,18 @@ static int reserve_nlist(shq_context *ctx, long long nq)
     SHQ_TRY(ctx->s_nlist.reserve((size_t) waves * NL_CAP * 64));
     SHQ_TRY(ctx->s_ncount.reserve((size_t) (nl_chunk_waves(nq) + 4) * 64));
     SHQ_TRY(ctx->s_redo.reserve((size_t) (nq > 0 ? nq : 1)));
+    SHQ_TRY(ctx->s_redo2.reserve((size_t) (nq > 0 ? nq : 1)));
     return SHQ_OK;
 }
 
-/* Runs walk<1> and eval<2> over [q, q + nq) in chunks, then the fused kernel <0> over the waves whose
- * lists overflowed (their number is only known on the device: the fused kernel reads it there). */
-template <class LaunchW, class LaunchP, class LaunchF>
+/* Runs walk<1> and eval<2> over [q, q + nq) in chunks, then the one-target-per-wave kernel <3> over the targets whose
+ * lists overflowed (their number is only known on the device: the kernel reads it there). */
+template <class LaunchW, class LaunchP, class LaunchF, class LaunchB>
 static int launch_two_kernel(shq_context *ctx, const int32_t *q, long long nq, long long nq_reserved, LaunchW &&walk, LaunchP &&eval,
-                             LaunchF &&fused)
+                             LaunchF &&fused, LaunchB &&block)
 {
     long long *d_nredo = ctx->s_counters.ptr + 6;
-    SHQ_HIP(hipMemsetAsync(d_nredo, 0, sizeof(long long), ctx->stream));
+    SHQ_HIP(hipMemsetAsync(d_nredo, 0, 2 * sizeof(long long), ctx->stream)); /* [6] targets for a wave of their own, [7] for a workgroup */
     int32_t *lists = ctx->s_nlist.ptr;
     int32_t *fused_lists = ctx->s_nlist.ptr + (size_t) nl_chunk_waves(nq_reserved) * NL_CAP * 64;
     SHQ_CHECK(q || nq <= NL_CHUNK, SHQ_ERR_INVALID, "SPH walk: more than %lld targets need an explicit queue", (long long) NL_CHUNK);
@@ -1087,9 +1453,10 @@ static int launch_two_kernel(shq_context *ctx, const int32_t *q, long long nq, l
         const long long wtasks = (m + 64 * SPH_WALK_WPB - 1) / (64 * SPH_WALK_WPB);
         walk((unsigned) wtasks, qc, m, wtasks, lists, ctx->s_ncount.ptr);
         eval((unsigned) ntasks, qc, m, ntasks, lists, ctx->s_ncount.ptr);
-        sph_collect_redo_kernel<<<dim3(nblk((m + 63) / 64)), dim3(256), 0, ctx->stream>>>(ctx->s_ncount.ptr, qc, m, ctx->s_redo.ptr, d_nredo);
+        sph_collect_redo_kernel<<<dim3(nblk(m)), dim3(256), 0, ctx->stream>>>(ctx->s_ncount.ptr, qc, m, ctx->s_redo.ptr, d_nredo);
     }
-    fused((unsigned) NL_REDO_BLOCKS, ctx->s_redo.ptr, fused_lists, d_nredo);
+    fused((unsigned) NL_HEAVY_BLOCKS, ctx->s_redo.ptr, fused_lists, d_nredo);
+    block((unsigned) NL_BLOCK_BLOCKS, ctx->s_redo2.ptr, d_nredo + 1);
     SHQ_HIP(hipGetLastError());
     return SHQ_OK;
 }
@@ -1108,7 +1475,10 @@ static int launch_density(shq_context *ctx, const SphDev &a, const int32_t *q, l
             sph_density_kernel<KT, 2><<<dim3(grid), dim3(256), 0, st>>>(a, qc, m, wd, nint, lists, ntasks, counts, nullptr);
         },
         [&](unsigned grid, const int32_t *redo, int32_t *lists, const long long *d_nredo) {
-            sph_density_kernel<KT, 0><<<dim3(grid), dim3(256), 0, st>>>(a, redo, 0, wd, nint, lists, 0, nullptr, d_nredo);
+            sph_density_kernel<KT, 3><<<dim3(grid), dim3(64), 0, st>>>(a, redo, 0, wd, nint, lists, 0, nullptr, d_nredo);
+        },
+        [&](unsigned grid, const int32_t *redo2, const long long *d_n2) {
+            sph_density_block_kernel<KT><<<dim3(grid), dim3(HB_THREADS), 0, st>>>(a, redo2, wd, nint, d_n2);
         });
 }
 template <int KT>
@@ -1124,7 +1494,10 @@ static int launch_hydro(shq_context *ctx, const SphDev &a, const int32_t *q, lon
             sph_hydro_kernel<KT, 2><<<dim3(grid), dim3(256), 0, st>>>(a, qc, m, hc, nint, lists, ntasks, counts, nullptr);
         },
         [&](unsigned grid, const int32_t *redo, int32_t *lists, const long long *d_nredo) {
-            sph_hydro_kernel<KT, 0><<<dim3(grid), dim3(256), 0, st>>>(a, redo, 0, hc, nint, lists, 0, nullptr, d_nredo);
+            sph_hydro_kernel<KT, 3><<<dim3(grid), dim3(64), 0, st>>>(a, redo, 0, hc, nint, lists, 0, nullptr, d_nredo);
+        },
+        [&](unsigned grid, const int32_t *redo2, const long long *d_n2) {
+            sph_hydro_block_kernel<KT><<<dim3(grid), dim3(HB_THREADS), 0, st>>>(a, redo2, hc, nint, d_n2);
         });
 }
 

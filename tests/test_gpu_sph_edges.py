@@ -216,3 +216,56 @@ def test_density_bh_targets_skip_wind_gas(ctx):
         else:
             assert np.all(B["Density"][:nbh] >= bh_wd) and (B["Density"][:nbh] > bh_wd * (1 + 1e-6)).any()
             assert np.array_equal(S["Density"], gas_wd)         # gas targets never skip wind neighbours
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_heavy_targets_get_a_wave_or_a_workgroup(ctx, kernel):
+    """targets whose neighbour list does not fit a lane's list (NL_CAP 256) leave the group walk and are walked by a whole wave
+    (lanes on candidates); the heaviest of those (> 16384 candidates) by a whole workgroup.  Same candidate counts as the
+    oracle, sums to rounding (their order differs), for density and hydro."""
+    n1 = 32
+    n = n1**3
+    pos = cm.random_positions(orc.boost_mt19937_uniform(31, 3 * n), n)
+    rng = np.random.default_rng(kernel)
+    hsml = cm.BOX / n1 * rng.uniform(1.0, 2.0, size=n)
+    wave_tier = rng.choice(n, size=300, replace=False)
+    hsml[wave_tier] *= 4.0                                  # ~64 x the neighbours: thousands
+    block_tier = wave_tier[:3]
+    hsml[block_tier] = 0.49 * cm.BOX                        # half the box: tens of thousands of candidates
+    pman, SphP, BhP = cm.make_gas(pos, hsml)
+    BhP = np.zeros(2, dtype=sq.BH_SLOT_DTYPE)
+    sq.set_densitypar(DensityResolutionEta=1.0, MaxNumNgbDeviation=0.5, DensityKernelType=kernel, BlackHoleNgbFactor=2.0, MinGasHsml=0.006)
+    P = pman.Base
+    P["Vel"] = rng.normal(size=(n, 3))
+    SphP["Entropy"] = rng.uniform(0.5, 2.0, size=n)
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+    dp = cm.density_params(kernel=kernel, update_hsml=0, DoEgyDensity=1)
+    st = orc.SphState(P, SphP, BhP)
+    rc, oevp, ogr, _, onint = orc.density(tree.Nodes_base.copy(), tree.firstnode, None, st, dp, want_gradrho=True)
+    assert rc == 0
+    gmag = np.zeros(n)
+    evp, gs = sq.density(ctx, None, 0, 1, 0, None, tree, pman, SphP, BhP, GradRho_mag=gmag)
+    assert gs.ninteractions == onint
+    for name, oname in (("Density", "density"), ("EgyWtDensity", "egywtdensity"), ("DivVel", "divvel"), ("CurlVel", "curlvel")):
+        ref = getattr(st, oname)
+        assert np.abs(SphP[name] - ref).max() < 1e-10 * np.abs(ref).max(), name
+        assert np.abs(SphP[name][block_tier] / ref[block_tier] - 1).max() < 1e-10, name
+    assert np.abs(gmag - np.linalg.norm(ogr, axis=1)).max() < 1e-10 * np.linalg.norm(ogr, axis=1).max()
+    assert np.abs(P["DtHsml"] - st.dthsml).max() < 1e-10 * np.abs(st.dthsml).max()
+    # hydro: the three giants are neighbours of everybody within half a box (r < h_j), and targets with huge lists themselves
+    sq.force_tree_update_hmax(tree, pman)
+    sq.set_hydropar(DensityIndependentSphOn=1, DensityContrastLimit=100.0, ArtBulkViscConst=0.75)
+    hp = cm.hydro_params(kernel=kernel)
+    st = orc.SphState(P, SphP, BhP)
+    onint = orc.hydro(tree.Nodes_base, tree.firstnode, st, hp, evp)
+    hs = sq.hydro_force(ctx, None, 0.1, cm.HUBBLE, evp, None, tree, pman, SphP)
+    assert hs.ninteractions == onint
+    a, oa = SphP["HydroAccel"], st.hydroaccel
+    assert np.abs(a - oa).max() < 1e-10 * np.abs(oa).max()
+    assert np.abs(a[block_tier] - oa[block_tier]).max() < 1e-10 * np.abs(oa[block_tier]).max()
+    assert np.abs(SphP["DtEntropy"] - st.dtentropy).max() < 1e-10 * np.abs(st.dtentropy).max()
+    assert np.abs(SphP["MaxSignalVel"] / st.maxsignalvel - 1).max() < 1e-12
+    # run-to-run reproducibility of the heavy tiers (fixed assignment of candidates to threads)
+    S2 = SphP.copy()
+    sq.hydro_force(ctx, None, 0.1, cm.HUBBLE, evp, None, tree, pman, S2)
+    assert np.array_equal(S2["HydroAccel"], SphP["HydroAccel"])
