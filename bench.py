@@ -175,15 +175,12 @@ def distributed_walk_figures(ctx, sq, capi, tree, pos, oldacc, gp_rel, n):
             "dist_secondary_walk_ms": 1e3 * t_sec, "dist_secondary_interactions_per_query": float(nint.mean()) if len(q) else 0.0}
 
 
-def sph_figures(ctx, n1=128, kernel=2):
-    """SPH operators of BASELINE configs[2] (density with the Hsml loop, hydro force) on n1^3 uniformly
-    placed gas particles, quintic kernel, pressure-entropy SPH: HIP-event time of the walk kernels through
-    the one-shot C-ABI calls (tools/bench_sph.py is the stand-alone version).  Reported under kernels.sph_*;
-    not part of `value`."""
+def sph_run(ctx, kind, n1, kernel):
+    """density (first call: the whole Hsml loop from the initial guess; second call: steady state) and hydro of n1^3 gas"""
     import shenqi_amd as sq
     n = n1**3
     L = 1.0
-    pos = sq.synth_positions("uniform", n, L=L)
+    pos = sq.synth_positions(kind, n, L=L)
     pos = pos[sq.hilbert_order(pos, L)]
     pman = sq.PartManager(n, L)
     P = pman.Base
@@ -208,12 +205,33 @@ def sph_figures(ctx, n1=128, kernel=2):
     sq.set_hydropar(1, 100.0, 0.75)
     hs = sq.hydro_force(ctx, None, 0.1, 0.1, evp, None, tree, pman, SphP)
     hs = sq.hydro_force(ctx, None, 0.1, 0.1, evp, None, tree, pman, SphP)
+    return pos, st0, st, hs
+
+
+def sph_figures(ctx, n1=128, kernel=2):
+    """SPH operators of BASELINE configs[2] (density with the Hsml loop, hydro force) on n1^3 uniformly
+    placed gas particles, quintic kernel, pressure-entropy SPH: HIP-event time of the walk kernels through
+    the one-shot C-ABI calls (tools/bench_sph.py is the stand-alone version).  Reported under kernels.sph_*;
+    not part of `value`.  kernels.sph_cluster_* are the same operators on S-cluster gas (a density caustic: a few targets
+    next to it have 10^5 neighbours; they are walked by a wave or a workgroup each)."""
+    import shenqi_amd as sq
+    n = n1**3
+    pos, st0, st, hs = sph_run(ctx, "uniform", n1, kernel)
     out = c3_step(ctx, pos, n1, float(st.kernel_ms) / max(1, int(st.niterations)), float(hs.kernel_ms))
     out.update({"sph_workload": "%d^3 gas, uniform, quintic kernel, %.0f neighbours" % (n1, sq.GetNumNgb()),
             "sph_density_first_call_iterations": int(st0.niterations), "sph_density_first_call_ms": float(st0.kernel_ms),
             "sph_density_iteration_ms": float(st.kernel_ms) / max(1, int(st.niterations)),
             "sph_density_particles_per_s": n / (1e-3 * float(st.kernel_ms) / max(1, int(st.niterations))),
             "sph_hydro_ms": float(hs.kernel_ms), "sph_hydro_particles_per_s": n / (1e-3 * float(hs.kernel_ms))})
+    try:
+        _, c0, c1, ch = sph_run(ctx, "cluster", n1, kernel)
+        out.update({"sph_cluster_density_first_call_iterations": int(c0.niterations), "sph_cluster_density_first_call_ms": float(c0.kernel_ms),
+                    "sph_cluster_density_iteration_ms": float(c1.kernel_ms) / max(1, int(c1.niterations)),
+                    "sph_cluster_density_candidates_per_target": float(c1.ninteractions) / max(1, int(c1.ntargets)) / max(1, int(c1.niterations)),
+                    "sph_cluster_hydro_ms": float(ch.kernel_ms),
+                    "sph_cluster_hydro_candidates_per_target": float(ch.ninteractions) / max(1, int(ch.ntargets))})
+    except Exception as e:  # an extra figure: never fatal
+        out["sph_cluster_note"] = "skipped: %s" % e
     # ---- rooflines of the two SPH operators: gather-bound (SURVEY.md 8(d)), so algorithmic STREAM bytes against the HBM peak:
     # density per target and iteration = candidates x 32 B (pos, mass, type / flags) + NumNgb neighbours x 114 B (Vel,
     # FullTreeGravAccel, GravPM, HydroAccel, bins, Entropy, DtEntropy); hydro per target = NumNgb pairs x 200 B (the lower end of
@@ -323,7 +341,10 @@ def run_sharded(args, rank, local_rank, world):
         n1 = int(round(args.n * world ** (1.0 / 3.0) / (2 * world))) * 2 * world
     if args.n != 256:      # reduced rehearsal sizes keep the same per-GPU share
         n1 = int(round(args.n * world ** (1.0 / 3.0) / (2 * world))) * 2 * world
-    nmesh = 3 * n1
+    # Nmesh: the reference's rule 3 * 2^floor(log2(N_dm) / 3) (run.cpp:225-226) = 3 n1, as at N = 1 - except for the named
+    # 8-GPU configuration, BASELINE configs[3] = benchmarks/dm-50-512, whose parameter file fixes Nmesh 1024
+    # (paramfile.gadget:8): the same choice the 1-GPU branch makes for --ngrid 512
+    nmesh = 1024 if n1 == 512 else 3 * n1
     L = 1.0
     nglobal = n1**3
     nmine = nglobal // world + (1 if rank < nglobal % world else 0)
@@ -333,7 +354,11 @@ def run_sharded(args, rank, local_rank, world):
     posm = torch.from_numpy(np.concatenate([pos, np.ones((nmine, 1))], axis=1)).to(dev)
     del pos
     bounds = sd.balanced_bounds(comm, nmesh, L, posm[:, 0])
-    ctx = sq.Context(devidx, stream=torch.cuda.current_stream().cuda_stream)
+    # one stream for torch and the library (a real one: the null stream cannot be handed over), so that a step needs no host
+    # synchronisation between torch operators, RCCL rounds and library kernels
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)
+    ctx = sq.Context(devidx, stream=work_stream.cuda_stream)
     sq.set_gravshort_treepar(ErrTolForceAcc=args.errtol, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=1, Rcut=6.0)
     sq.gravshort_set_softenings(L / n1)
     gp_bh = sq.make_grav_params(L, 1.5, nmesh, G, RHO0)

@@ -676,11 +676,14 @@ int shq_pm_slab2_readout(shq_context *ctx, const shq_pm_params *pm, int plane0, 
 int shq_pm_get_deposit_log2scale(shq_context *ctx);
 int shq_pm_set_deposit_log2scale(shq_context *ctx, int e);
 
-/* Drop-ins for petapm_fft_r2c / petapm_fft_c2r (libgadget/petapm.cpp:49-71): unscaled
- * single-rank 3-D transforms of an Nmesh^3 real array ([x][y][z], z fastest) to/from its
- * half-spectrum ([x][y][z'], z' <= Nmesh/2). Host pointers. */
+/* Drop-ins for petapm_fft_r2c / petapm_fft_c2r (libgadget/petapm.cpp:49-71) on one rank: unscaled 3-D transforms of an
+ * Nmesh^3 real array ([x][y][z], z fastest: real_space_region, petapm.cpp:256-260) to / from its half spectrum in the
+ * reference's Fourier layout [y][z'][x], x fastest, z' <= Nmesh / 2 (fourier_space_region, petapm.cpp:262-270: what
+ * pm_apply_transfer_function, :1258-1298, enumerates).  Host pointers.  The _xyz pair keeps the spectrum as [x][y][z']. */
 int shq_fft_r2c(shq_context *ctx, int Nmesh, const double *real, double *complx);
 int shq_fft_c2r(shq_context *ctx, int Nmesh, const double *complx, double *real);
+int shq_fft_r2c_xyz(shq_context *ctx, int Nmesh, const double *real, double *complx);
+int shq_fft_c2r_xyz(shq_context *ctx, int Nmesh, const double *complx, double *real);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,7 @@ class Context:
         h = C.c_void_p()
         capi.check(capi.hip.shq_init(device, stream, C.byref(h)), "shq_init")
         self.h = h
+        self.stream = stream        # the caller's stream the library works on (None: its own)
 
     def close(self):
         if self.h:

@@ -311,6 +311,8 @@ hip.shq_pm_phase_ms.argtypes = [_vp, C.POINTER(C.c_double * 6)]
 hip.shq_pm_set_debug.argtypes = [_vp, C.c_int]
 hip.shq_pm_download_mesh.argtypes = [_vp, C.c_int, _vp]
 hip.shq_fft_r2c.argtypes = [_vp, C.c_int, _vp, _vp]
+hip.shq_fft_r2c_xyz.argtypes = [_vp, C.c_int, _vp, _vp]
+hip.shq_fft_c2r_xyz.argtypes = [_vp, C.c_int, _vp, _vp]
 hip.shq_fft_c2r.argtypes = [_vp, C.c_int, _vp, _vp]
 
 host.shqh_last_error.restype = C.c_char_p

@@ -1203,11 +1203,23 @@ extern "C" int shq_fft_r2c(shq_context *ctx, int Nmesh, const double *real, doub
 {
     SHQ_CHECK(ctx && real && complx, SHQ_ERR_INVALID, "null argument");
     SHQ_HIP(hipSetDevice(ctx->device));
-    return shq_fft_roundtrip_r2c(ctx, Nmesh, real, complx);
+    return shq_fft_roundtrip_r2c(ctx, Nmesh, real, complx, true);
 }
 extern "C" int shq_fft_c2r(shq_context *ctx, int Nmesh, const double *complx, double *real)
 {
     SHQ_CHECK(ctx && real && complx, SHQ_ERR_INVALID, "null argument");
     SHQ_HIP(hipSetDevice(ctx->device));
-    return shq_fft_roundtrip_c2r(ctx, Nmesh, complx, real);
+    return shq_fft_roundtrip_c2r(ctx, Nmesh, complx, real, true);
+}
+extern "C" int shq_fft_r2c_xyz(shq_context *ctx, int Nmesh, const double *real, double *complx)
+{
+    SHQ_CHECK(ctx && real && complx, SHQ_ERR_INVALID, "null argument");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    return shq_fft_roundtrip_r2c(ctx, Nmesh, real, complx, false);
+}
+extern "C" int shq_fft_c2r_xyz(shq_context *ctx, int Nmesh, const double *complx, double *real)
+{
+    SHQ_CHECK(ctx && real && complx, SHQ_ERR_INVALID, "null argument");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    return shq_fft_roundtrip_c2r(ctx, Nmesh, complx, real, false);
 }

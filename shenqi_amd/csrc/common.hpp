@@ -363,8 +363,8 @@ int shq_launch_grav_walk_ghosts(shq_context *ctx, const shq_grav_params *p, cons
 /* pm.hip */
 int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm);
 void shq_pm_destroy_plans(shq_context *ctx);
-int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *complx);
-int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double *real);
+int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *complx, bool ref_layout);
+int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double *real, bool ref_layout);
 /* tree_build.hip */
 int shq_build_tree_targets(shq_context *ctx);
 /* fft3d.hip */

@@ -598,7 +598,40 @@ extern "C" int shq_pm_download_power(shq_context *ctx, int size, double *kk, dou
     return SHQ_OK;
 }
 
-int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *complx)
+/* complex [x][y][z'] <-> [y][z'][x] for a fixed y per blockIdx.z: a 32 x 32 tile of the (x, z') plane goes through LDS so
+ * that both the reads and the writes run along the fastest index of their array */
+__global__ void fourier_layout_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, int N, int nz, int back)
+{
+    __shared__ double2 tile[32][33];
+    const int y = blockIdx.z, z0 = blockIdx.x * 32, x0 = blockIdx.y * 32;
+    if(!back) { /* in [x][y][z'] -> out [y][z'][x] */
+        for(int j = threadIdx.y; j < 32; j += 8) {
+            const int x = x0 + j, z = z0 + threadIdx.x;
+            if(x < N && z < nz)
+                tile[j][threadIdx.x] = in[((size_t) x * N + y) * nz + z];
+        }
+        __syncthreads();
+        for(int j = threadIdx.y; j < 32; j += 8) {
+            const int z = z0 + j, x = x0 + threadIdx.x;
+            if(x < N && z < nz)
+                out[((size_t) y * nz + z) * N + x] = tile[threadIdx.x][j];
+        }
+    } else { /* in [y][z'][x] -> out [x][y][z'] */
+        for(int j = threadIdx.y; j < 32; j += 8) {
+            const int z = z0 + j, x = x0 + threadIdx.x;
+            if(x < N && z < nz)
+                tile[threadIdx.x][j] = in[((size_t) y * nz + z) * N + x];
+        }
+        __syncthreads();
+        for(int j = threadIdx.y; j < 32; j += 8) {
+            const int x = x0 + j, z = z0 + threadIdx.x;
+            if(x < N && z < nz)
+                out[((size_t) x * N + y) * nz + z] = tile[j][threadIdx.x];
+        }
+    }
+}
+
+int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *complx, bool ref_layout)
 {
     SHQ_TRY(pm_prepare(ctx, N));
     const int zp = ctx->pm_zp;
@@ -618,21 +651,43 @@ int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *c
     }
     pm_repitch_kernel<<<dim3((unsigned) ((ctot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
         ctx->mesh.ptr, dense.ptr, (size_t) N * N, N + 2, zp, N + 2, 0, 1.0);
+    if(ref_layout) { /* [x][y][z'] -> the reference's Fourier layout [y][z'][x], x fastest (petapm.cpp:262-270) */
+        DevBuf<double> tr;
+        SHQ_TRY(tr.reserve(ctot));
+        const int nz = N / 2 + 1;
+        fourier_layout_kernel<<<dim3((unsigned) ((nz + 31) / 32), (unsigned) ((N + 31) / 32), (unsigned) N), dim3(32, 8), 0, ctx->stream>>>(
+            reinterpret_cast<const double2 *>(dense.ptr), reinterpret_cast<double2 *>(tr.ptr), N, nz, 0);
+        SHQ_HIP(hipMemcpyAsync(complx, tr.ptr, ctot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+        tr.release();
+        dense.release();
+        return SHQ_OK;
+    }
     SHQ_HIP(hipMemcpyAsync(complx, dense.ptr, ctot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     dense.release();
     return SHQ_OK;
 }
 
-int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double *real)
+int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double *real, bool ref_layout)
 {
     SHQ_TRY(pm_prepare(ctx, N));
     const int zp = ctx->pm_zp;
     const size_t tot = (size_t) N * N * N, ctot = (size_t) N * N * (N + 2);
     DevBuf<double> dense;
     SHQ_TRY(dense.reserve(ctot));
-    SHQ_HIP(hipMemcpyAsync(dense.ptr, complx, ctot * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     const int threads = 256;
+    if(ref_layout) {
+        DevBuf<double> tr;
+        SHQ_TRY(tr.reserve(ctot));
+        SHQ_HIP(hipMemcpyAsync(tr.ptr, complx, ctot * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        const int nz = N / 2 + 1;
+        fourier_layout_kernel<<<dim3((unsigned) ((nz + 31) / 32), (unsigned) ((N + 31) / 32), (unsigned) N), dim3(32, 8), 0, ctx->stream>>>(
+            reinterpret_cast<const double2 *>(tr.ptr), reinterpret_cast<double2 *>(dense.ptr), N, nz, 1);
+        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+        tr.release();
+    } else
+        SHQ_HIP(hipMemcpyAsync(dense.ptr, complx, ctot * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     pm_repitch_kernel<<<dim3((unsigned) ((ctot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
         dense.ptr, ctx->mesh.ptr, (size_t) N * N, N + 2, N + 2, zp, 0, 1.0);
     if(ctx->pm_custom_fft)

@@ -405,13 +405,30 @@ class GpuOps:
     def empty(self, shape, dtype):
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
+    def _shared(self):
+        """The context was created on torch's current stream: library kernels and torch operators are ordered by the stream
+        itself (and the RCCL rounds join it through their work handles), so no host synchronisation is needed anywhere in a
+        step.  With a stream of its own (the tests) every hand-over is a full synchronisation of both streams."""
+        if os.environ.get("SHQ_DIST_SYNC", "0") == "1":      # diagnostic: synchronise around every phase anyway
+            return False
+        s = getattr(self.ctx, "stream", None)      # 0 is the null stream: shq_init then made a stream of its own
+        return bool(s) and int(s) == int(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _before(self):
+        if not self._shared():
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def _after(self):
+        if not self._shared():
+            self.ctx.synchronize()
+
     def set_particles(self, posm_all, nlocal, keep_tree=False):
         """posm_all: device tensor [n, 4] (x, y, z, m), the first nlocal rows are this rank's own.  keep_tree: these are the
         positions the resident tree was built from (nothing moved since)."""
         t = posm_all.contiguous()
-        torch.cuda.current_stream(self.device).synchronize()   # torch produced t on its stream; the library copies on its own
+        self._before()                  # torch produced t on its stream; the library copies on its own
         capi.check(capi.hip.shq_particles_set_device(self.ctx.h, C.c_void_p(t.data_ptr()), t.shape[0], nlocal, int(keep_tree)))
-        self.ctx.synchronize()
+        self._after()
         self._keep = t
 
     # ---- phases on the bespoke FFT passes (shq_pm_slab2_*) ----
@@ -426,9 +443,9 @@ class GpuOps:
         return self._mesh
 
     def _call(self, fn, *args):
-        torch.cuda.current_stream(self.device).synchronize()
+        self._before()
         capi.check(fn(self.ctx.h, *args))
-        self.ctx.synchronize()
+        self._after()
 
     def deposit2(self, buf, plane0, nxl, xoff, nalloc):
         self._call(capi.hip.shq_pm_slab2_deposit, C.byref(self.pm), plane0, nxl, xoff, nalloc, C.c_void_p(buf.data_ptr()))
@@ -453,9 +470,7 @@ class GpuOps:
     def deposit(self, plane0, nxl):
         nalloc = nxl if nxl == self.N else nxl + 1
         mesh = torch.empty((nalloc, self.N, self.N + 2), dtype=torch.int64, device=self.device)
-        torch.cuda.current_stream(self.device).synchronize()
-        capi.check(capi.hip.shq_pm_slab_deposit(self.ctx.h, C.byref(self.pm), plane0, nxl, C.c_void_p(mesh.data_ptr())))
-        self.ctx.synchronize()
+        self._call(capi.hip.shq_pm_slab_deposit, C.byref(self.pm), plane0, nxl, C.c_void_p(mesh.data_ptr()))
         return mesh
 
     def to_real(self, mesh_i):
@@ -463,15 +478,11 @@ class GpuOps:
 
     def green(self, spec_t, y0, nyl):
         assert spec_t.is_contiguous() and spec_t.dtype == torch.complex128
-        torch.cuda.current_stream(self.device).synchronize()
-        capi.check(capi.hip.shq_pm_slab_green(self.ctx.h, C.byref(self.pm), y0, nyl, C.c_void_p(spec_t.data_ptr())))
-        self.ctx.synchronize()
+        self._call(capi.hip.shq_pm_slab_green, C.byref(self.pm), y0, nyl, C.c_void_p(spec_t.data_ptr()))
 
     def readout(self, ext, plane0, nxl):
         assert ext.is_contiguous()
-        torch.cuda.current_stream(self.device).synchronize()
-        capi.check(capi.hip.shq_pm_slab_readout(self.ctx.h, C.byref(self.pm), plane0, nxl, C.c_void_p(ext.data_ptr())))
-        self.ctx.synchronize()
+        self._call(capi.hip.shq_pm_slab_readout, C.byref(self.pm), plane0, nxl, C.c_void_p(ext.data_ptr()))
 
     def results(self, nlocal):
         g = np.zeros((self._keep.shape[0], 3))
@@ -564,3 +575,141 @@ class DistTreePM:
         capi.check(capi.hip.shq_grav_short_download(self.ctx.h, capi.ptr(acc), capi.ptr(pot), None, None))
         gpm, ppot = self.ops.results(self.nloc)
         return acc[: self.nloc], pot[: self.nloc], gpm, ppot
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Sharded SPH (density with the Hsml loop, hydro force): the same ghost-import design as the tree.
+# The reference exports queries to the ranks whose top-leaves a target's search sphere touches, walks them there and
+# imports the partial results (treewalk2.h:480-557 do_hsml_loop with exports, DensityQuery / HydroQuery wire formats,
+# densitytree2.hpp:260-344, hydratree2.hpp:151-228), once per Hsml iteration.  Here every rank imports, once per operator,
+# the records of the other ranks' gas within reach of its slab and runs the whole operator locally for its own targets:
+#   density: a neighbour j matters to target i if r_ij < Hsml_i           -> import within halo = hfac * max local Hsml;
+#            the Hsml loop may grow a target's Hsml past the halo: then the import is repeated with a larger one;
+#   hydro:   symmetric, r_ij < max(Hsml_i, Hsml_j) (hydratree2.hpp:258-259; the reference propagates hmax for this,
+#            run.cpp:493)                                                 -> a particle goes to rank d if it lies within
+#            max(its own Hsml, max Hsml of d's targets) of d's slab; its record carries the density results of its owner.
+# Records travel whole (particle_data 160 B + sph_particle_data 176 B), so predicted velocities and entropies of ghosts are
+# evaluated from the same fields as on their owner.
+
+
+def ghost_records(comm, decomp, x, reach, recs, reach_of_rank):
+    """Import the records (uint8 rows) of other ranks' particles: a particle at x with own reach `reach` goes to rank d if it
+    lies within max(reach, reach_of_rank[d]) of d's slab (periodic).  Returns the received rows in source-rank order."""
+    if not comm.multi:
+        return recs[:0]
+    L = decomp.L
+    parts, counts = [], [0] * comm.size
+    for d in range(comm.size):
+        if d == comm.rank:
+            continue
+        a, b = decomp.slab_range(d)
+        halo = torch.clamp(reach, min=float(reach_of_rank[d]))
+        span = (b - a) + 2 * halo
+        sel = (span >= L) | (torch.remainder(x - (a - halo), L) < span)
+        parts.append(recs[sel])
+        counts[d] = int(sel.sum())
+    send = torch.cat(parts, dim=0) if parts else recs[:0]
+    recv, _ = comm.all_to_all_rows(send, counts)
+    return recv
+
+
+class DistSPH:
+    """One rank of the sharded SPH operators.  `P` / `SphP`: numpy arrays (capi.PARTICLE_DTYPE / capi.SPH_DTYPE) of the gas this
+    rank owns (PI = slot index).  `ops` runs an operator on local + ghost particles for the first `nloc` of them:
+    ops.density(P, SphP, nloc, **kw) updates Hsml / DtHsml / the density fields of the targets in place;
+    ops.hydro(P, SphP, nloc, **kw) likewise HydroAccel / DtEntropy / MaxSignalVel (GpuSphOps below; the tests use the oracle)."""
+
+    def __init__(self, comm, decomp, ops, hfac=1.3):
+        self.comm, self.d, self.ops, self.hfac = comm, decomp, ops, hfac
+        self.nghost = 0
+
+    def _allmax(self, v):
+        if not self.comm.multi:
+            return [float(v)] * max(1, self.comm.size)
+        t = torch.zeros(self.comm.size, dtype=torch.float64)
+        t[self.comm.rank] = float(v)
+        if self.comm.backend == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, group=self.comm.group)
+        return [float(x) for x in t.cpu()]
+
+    def _import(self, P, SphP, reach, reach_of_rank):
+        """local + ghost records: ghosts get consecutive slots after the local ones"""
+        nloc = len(P)
+        rec = np.concatenate([P.view(np.uint8).reshape(nloc, -1), SphP[P["PI"]].view(np.uint8).reshape(nloc, -1)], axis=1)
+        got = ghost_records(self.comm, self.d, torch.from_numpy(np.ascontiguousarray(P["Pos"][:, 0])), torch.from_numpy(reach),
+                            torch.from_numpy(rec), reach_of_rank).numpy()
+        ng = len(got)
+        self.nghost = ng
+        psz = P.dtype.itemsize
+        # not np.concatenate: it repacks structured dtypes (sph_particle_data's padding would go, 176 -> 168 bytes)
+        Pall = np.empty(nloc + ng, dtype=P.dtype)
+        Sall = np.empty(nloc + ng, dtype=SphP.dtype)
+        Pall[:nloc] = P
+        Sall[:nloc] = SphP[P["PI"]]
+        Pall[nloc:] = np.ascontiguousarray(got[:, :psz]).view(P.dtype).reshape(ng)
+        Sall[nloc:] = np.ascontiguousarray(got[:, psz:]).view(SphP.dtype).reshape(ng)
+        Pall["PI"] = np.arange(nloc + ng)
+        return Pall, Sall
+
+    def density(self, P, SphP, **kw):
+        """density() for the local gas (Hsml loop included).  Returns the number of import rounds it took."""
+        nloc = len(P)
+        rounds = 0
+        halo = self.hfac * (float(P["Hsml"].max()) if nloc else 0.0)
+        h0 = P["Hsml"].copy()
+        while True:
+            rounds += 1
+            halos = self._allmax(halo)
+            Pall, Sall = self._import(P, SphP, np.zeros(nloc), halos)
+            Pall["Hsml"][:nloc] = h0
+            self.ops.density(Pall, Sall, nloc, **kw)
+            hmax = float(Pall["Hsml"][:nloc].max()) if nloc else 0.0
+            # every rank must agree on repeating: a target whose sphere outgrew the halo may have missed neighbours
+            worst = max(h / max(hl, 1e-300) for h, hl in zip(self._allmax(hmax), halos)) if self.comm.multi else 0.0
+            if worst <= 1.0 or not self.comm.multi:
+                break
+            halo = self.hfac * max(hmax, halo)
+        for k in ("Hsml", "DtHsml"):
+            P[k] = Pall[k][:nloc]
+        for k in ("Density", "EgyWtDensity", "DhsmlEgyDensityFactor", "DivVel", "CurlVel"):
+            SphP[k][P["PI"]] = Sall[k][:nloc]
+        return rounds
+
+    def hydro(self, P, SphP, **kw):
+        """hydro_force() for the local gas; needs the density fields of density() above on every rank"""
+        nloc = len(P)
+        hmax = self._allmax(float(P["Hsml"].max()) if nloc else 0.0)
+        Pall, Sall = self._import(P, SphP, P["Hsml"].astype(np.float64), hmax)
+        self.ops.hydro(Pall, Sall, nloc, **kw)
+        for k in ("HydroAccel", "DtEntropy", "MaxSignalVel"):
+            SphP[k][P["PI"]] = Sall[k][:nloc]
+
+
+class GpuSphOps:
+    """DistSPH's operators on the device library, through the host mirror of the reference API (one-shot calls: the records
+    cross PCIe once per operator)."""
+
+    def __init__(self, ctx, BoxSize):
+        import shenqi_amd as sq
+        self.sq, self.ctx, self.L = sq, ctx, BoxSize
+
+    def _pman(self, Pall):
+        pman = self.sq.PartManager(len(Pall), self.L)
+        pman.Base[:] = Pall
+        return pman
+
+    def density(self, Pall, Sall, nloc, DoEgyDensity=1, kick=None, **_):
+        sq = self.sq
+        pman = self._pman(Pall)
+        tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+        BhP = np.zeros(2, dtype=sq.BH_SLOT_DTYPE)
+        sq.density(self.ctx, np.arange(nloc, dtype=np.int32), 1, DoEgyDensity, 0, kick, tree, pman, Sall, BhP)
+        Pall[:] = pman.Base
+
+    def hydro(self, Pall, Sall, nloc, atime=0.1, hubble=0.1, kick=None, **_):
+        sq = self.sq
+        pman = self._pman(Pall)
+        tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+        sq.force_tree_update_hmax(tree, pman)
+        sq.hydro_force(self.ctx, np.arange(nloc, dtype=np.int32), atime, hubble, None, kick, tree, pman, Sall)

@@ -167,3 +167,51 @@ def test_device_particle_set_semantics(ctx):
     assert st.ntargets == 1500 and st.ninteractions == n1
     capi.check(capi.hip.shq_pm_set_deposit_log2scale(ctx.h, -1))     # the session context goes back to its own scale rule
     cm.reference_treepar()
+
+
+def _sph_worker(rank, world, initfile, outdir):
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        import shenqi_amd as sq
+        from shenqi_amd import dist as sd
+        from test_dist_sph_cpu import global_gas
+        comm = sd.Comm()
+        decomp = sd.SlabDecomp(comm, NMESH, BOX)
+        Pg, Sg = global_gas()
+        mine = (decomp.owner_of(torch.from_numpy(np.ascontiguousarray(Pg["Pos"][:, 0]))) == rank).numpy()
+        P = Pg[mine].copy()
+        SphP = Sg[Pg["PI"][mine]].copy()
+        P["PI"] = np.arange(len(P))
+        sq.set_densitypar(DensityResolutionEta=1.0, MaxNumNgbDeviation=0.5, DensityKernelType=1, BlackHoleNgbFactor=2.0, MinGasHsml=0.006)
+        sq.set_hydropar(DensityIndependentSphOn=1, DensityContrastLimit=100.0, ArtBulkViscConst=0.75)
+        with sq.Context(0) as ctx:
+            drv = sd.DistSPH(comm, decomp, sd.GpuSphOps(ctx, BOX))
+            drv.density(P, SphP)
+            drv.hydro(P, SphP, atime=0.1, hubble=0.1)
+        np.save(os.path.join(outdir, "p%d.npy" % rank), P)
+        np.save(os.path.join(outdir, "s%d.npy" % rank), SphP)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dist_sph_two_gloo_ranks_one_gpu():
+    """sharded density (Hsml loop) + hydro with the DEVICE operators on two ranks sharing the GPU (records exchanged over gloo)
+    against the oracle on the undivided gas"""
+    from test_dist_sph_cpu import monolithic
+    Pm, Sm, _ = monolithic(1.5)
+    key = {int(i): k for k, i in enumerate(Pm["ID"])}
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_sph_worker, args=(2, os.path.join(tmp, "init"), tmp), nprocs=2, join=True)
+        seen = 0
+        for r in range(2):
+            P = np.load(os.path.join(tmp, "p%d.npy" % r))
+            S = np.load(os.path.join(tmp, "s%d.npy" % r))
+            idx = np.array([key[int(i)] for i in P["ID"]])
+            seen += len(idx)
+            assert np.abs(P["Hsml"] / Pm["Hsml"][idx] - 1).max() < 1e-9
+            for name in ("Density", "EgyWtDensity", "DivVel", "CurlVel"):
+                assert np.abs(S[name] - Sm[name][idx]).max() < 1e-8 * np.abs(Sm[name]).max(), name
+            assert np.abs(S["HydroAccel"] - Sm["HydroAccel"][idx]).max() < 1e-7 * np.abs(Sm["HydroAccel"]).max()
+            assert np.abs(S["MaxSignalVel"] / Sm["MaxSignalVel"][idx] - 1).max() < 1e-8
+        assert seen == 16**3

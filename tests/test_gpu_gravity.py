@@ -202,16 +202,41 @@ def test_pm_parity_16(ctx, kind):
 
 @pytest.mark.parametrize("N", [24, 40, 64, 80, 18])
 def test_fft_dropins(ctx, N):
-    """petapm_fft_r2c / petapm_fft_c2r drop-ins: unscaled, round trip = N^3 * identity.  24, 64: radix 16/4/2/3
-    stages of the bespoke pipeline; 40, 80: radix 5; 18: no bespoke transform (rocFFT)."""
+    """petapm_fft_r2c / petapm_fft_c2r drop-ins: unscaled, spectrum in the reference's Fourier layout [y][z'][x]
+    (petapm.cpp:262-270), round trip = N^3 * identity.  24, 64: radix 16/4/2/3 stages of the bespoke pipeline; 40, 80:
+    radix 5; 18: no bespoke transform (rocFFT).  The _xyz pair keeps [x][y][z']."""
     a = np.random.default_rng(2).normal(size=(N, N, N))
-    out = np.zeros((N, N, N // 2 + 1), dtype=np.complex128)
+    ref = orc.fft_r2c(a)                                     # [x][y][z']
+    out = np.zeros((N, N // 2 + 1, N), dtype=np.complex128)  # [y][z'][x]
     capi.check(capi.hip.shq_fft_r2c(ctx.h, N, capi.ptr(a), capi.ptr(out)))
-    ref = orc.fft_r2c(a)
-    assert np.abs(out - ref).max() < 1e-12 * np.abs(ref).max()
+    assert np.abs(out - ref.transpose(1, 2, 0)).max() < 1e-12 * np.abs(ref).max()
     back = np.zeros((N, N, N))
     capi.check(capi.hip.shq_fft_c2r(ctx.h, N, capi.ptr(out), capi.ptr(back)))
     assert np.abs(back - a * N**3).max() < 1e-11 * N**3
+    out2 = np.zeros((N, N, N // 2 + 1), dtype=np.complex128)
+    capi.check(capi.hip.shq_fft_r2c_xyz(ctx.h, N, capi.ptr(a), capi.ptr(out2)))
+    assert np.abs(out2 - ref).max() < 1e-12 * np.abs(ref).max()
+    capi.check(capi.hip.shq_fft_c2r_xyz(ctx.h, N, capi.ptr(out2), capi.ptr(back)))
+    assert np.abs(back - a * N**3).max() < 1e-11 * N**3
+
+
+def test_fft_seam_feeds_the_reference_transfer_function(ctx):
+    """what a shenqi build would do with the drop-ins (petapm.cpp:403-452): r2c of the density mesh, potential_transfer applied
+    to the [y][z'][x] spectrum exactly as pm_apply_transfer_function enumerates it (:1258-1298; restated in numpy on that
+    layout in tests/cpu_ops.py), c2r: the potential mesh of the oracle's PM"""
+    from cpu_ops import CpuOps
+    import torch
+    N, n = 48, 16**3
+    pos = cm.random_positions(orc.boost_mt19937_uniform(0, 3 * n), n)
+    mass = np.ones(n, dtype=np.float32)
+    _, _, rho, phi = orc.pm_force(pos, mass, N, cm.BOX, 1.5, cm.G, want_mesh=True)
+    spec = np.zeros((N, N // 2 + 1, N), dtype=np.complex128)
+    capi.check(capi.hip.shq_fft_r2c(ctx.h, N, capi.ptr(np.ascontiguousarray(rho)), capi.ptr(spec)))
+    t = torch.from_numpy(spec)
+    CpuOps(N, cm.BOX, 1.5, cm.G).green(t, 0, N)              # in place, all y rows
+    pot = np.zeros((N, N, N))
+    capi.check(capi.hip.shq_fft_c2r(ctx.h, N, capi.ptr(np.ascontiguousarray(t.numpy())), capi.ptr(pot)))
+    assert np.abs(pot - phi).max() < 1e-11 * np.abs(phi).max()
 
 
 def _do_force_test(ctx, pos, Nmesh=48, ErrTol=0.002, direct=True):

@@ -41,12 +41,17 @@ pv = pman.view()
 capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
 sq.tree_build_device(ctx, L)
 pmp = sq.PMParams(nmesh, 0, L, 1.5, G)
-for gp in (gp_bh, gp_rel, gp_rel):
+import time  # noqa: E402
+for gp in (gp_bh, gp_rel, gp_rel, gp_rel):
+    ctx.synchronize()
+    t0 = time.perf_counter()
     capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
     capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, 0))
     capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, G))
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
     st = stats(ctx)
-    print("mono: interactions/target %.1f walk %.2f ms" % (st.ninteractions / n, st.kernel_ms), flush=True)
+    print("mono: interactions/target %.1f walk %.2f ms, step %.2f ms" % (st.ninteractions / n, st.kernel_ms, 1e3 * dt), flush=True)
 acc0 = np.zeros((n, 3))
 capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc0), None, None, None))
 gpm0 = np.zeros((n, 3))
@@ -62,15 +67,21 @@ if os.environ.get("SHQ_COMM_FORCE", "0") == "1":
     os.environ.setdefault("MASTER_PORT", "29533")
     torch.cuda.set_device(0)
     tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-ctx = sq.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+work_stream = torch.cuda.Stream(device=dev)     # shared by torch and the library: no host synchronisation inside a step
+torch.cuda.set_stream(work_stream)
+ctx = sq.Context(0, stream=work_stream.cuda_stream)
 comm = sd.Comm()
 posm = torch.from_numpy(np.concatenate([pos, np.ones((n, 1))], axis=1)).to(dev)
 drv = sd.DistTreePM(comm, ctx, nmesh, L, 1.5, G, dev, halo_factor=1.5, bounds=None)
 drv.setup(sd.exchange_to_owner(comm, drv.decomp, posm), gp_rel.Rcut)
-for gp in (gp_bh, gp_rel, gp_rel):
+for gp in (gp_bh, gp_rel, gp_rel, gp_rel):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     drv.step(gp)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
     st = stats(ctx)
-    print("dist: interactions/target %.1f walk %.2f ms" % (st.ninteractions / n, st.kernel_ms), flush=True)
+    print("dist: interactions/target %.1f walk %.2f ms, step %.2f ms" % (st.ninteractions / n, st.kernel_ms, 1e3 * dt), flush=True)
 acc1, pot1, gpm1, ppot1 = drv.download()
 p1 = drv.local.cpu().numpy()[:, :3]
 print("same particle order:", bool(np.array_equal(p1, pos)))
