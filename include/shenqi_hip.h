@@ -232,7 +232,8 @@ int shq_tree_download(shq_context *ctx, int64_t firstnode, shq_node *nodes, int6
  * arrays in HBM a step is  shq_drift -> shq_tree_build -> shq_pm_run / shq_grav_short_run -> kicks,
  * without a PCIe crossing.  Same operations in the same order as the reference, so the state stays
  * bit-identical to a host integration.  Black-hole repositioning (drift.cpp:32-53) and the black-hole part of
- * do_hydro_kick are not covered; the integer time line stays with the host.
+ * do_hydro_kick need the BH slot fields (shq_bh_dynamics_upload below); the particle loops of the integer time line are
+ * shq_find_timesteps and its relatives below, DriftKickTimes and the sync points stay with the host.
  *
  * shq_dynamics_upload: Vel, Hsml, DtHsml, TimeBinGravity of the particles uploaded before.
  * shq_drift: drift_all_particles / real_drift_particle (libgadget/drift.cpp:16-99):
@@ -286,6 +287,103 @@ int shq_kick_hydro(shq_context *ctx, const double hydrokick[SHQ_TIMEBINS + 1], c
                    double MaxGasVel, const int32_t *active, int64_t nactive, int from_hydro_output, int64_t *nlimited);
 int shq_entropy_download(shq_context *ctx, double *entropy_by_particle);
 int shq_dynamics_download(shq_context *ctx, const shq_part_view *parts);
+
+/* The integer time line on the device (libgadget/timestep.cpp:157-194, 307-446, 584-822, 1012-1110):
+ * new time bins for the resident particles from the accelerations, smoothing lengths and signal velocities that are in HBM
+ * already.  The sync-point table, the cosmology and DriftKickTimes stay with the host (shenqi_amd/host/timestep.cpp mirrors
+ * find_timesteps / find_hydro_timesteps / hierarchical_gravity_and_timesteps over these calls); the per-particle loops and
+ * their reductions run here.  IEEE sqrt and divide, no fma contraction: the bins equal the host loop's as integers.
+ *
+ * shq_timeline: what TimeBinMgr::dti_from_dloga and get_dloga_for_bin read at Ti_Current (timebinmgr.h:120-176, 228-243):
+ *     loga_now = SyncPoints[lastsnap].loga + (Ti_Current & (TIMEBASE - 1)) * Dloga_interval; the segment the step starts in
+ *     (seg_snap[0], lower sync point index after the reference's clamps) with its two ends seg_loga[0..1], and when a further
+ *     sync point exists (nseg = 2) the one after, seg_snap[1] = seg_snap[0] + 1, ending at seg_loga[2]. */
+typedef struct shq_timeline {
+    int64_t Ti_Current;
+    double loga_now;
+    double Dloga_interval;      /* Dloga_interval_ti(Ti_Current), 0 past the last sync point */
+    int32_t nseg;
+    int32_t pad_;
+    int64_t seg_snap[2];
+    double seg_loga[3];
+} shq_timeline;
+
+/* TimestepParams (timestep.cpp:35-50) and the arguments of the loops.  fac3 = pow(atime, 3 (1 - GAMMA) / 2) (timestep.cpp:1049),
+ * ForceSoftening = FORCE_SOFTENING(), dti_max = times->PM_length after the PM-step update of the caller. */
+typedef struct shq_timestep_params {
+    double ErrTolIntAccuracy, CourantFac, MinSizeTimestep;
+    double ForceSoftening;
+    double atime, hubble, fac3;
+    int64_t dti_max;
+    int32_t ForceEqualTimesteps;
+    int32_t isFirstTimeStep;
+    int32_t mintimebin, mingravtimebin;   /* times->mintimebin / mingravtimebin on entry (find_hydro_timesteps reads them) */
+    shq_timeline tl;
+} shq_timestep_params;
+
+typedef struct shq_timestep_result {
+    int32_t badstepsizecount;
+    int32_t mTimeBin, maxTimeBin;         /* min / max new bin over the list (TIMEBINS / 0 when the list is empty) */
+    int32_t mintimebin;                   /* find_hydro_timesteps: times->mintimebin after its fix-ups (timestep.cpp:677-696) */
+    int64_t ntiaccel, nticourant, ntihsml, ntiaccrete, ntineighbour;
+    int64_t nbh, dynratio;                /* find_hydro_timesteps: BHs on the list, sum of TimeBinDynFric - TimeBinHydro */
+    int32_t maxdyndiff;
+    int32_t nbadbin;                      /* particles the reference would print_bad_timebin for */
+    int64_t dti_min;                      /* ForceEqualTimesteps: find_global_timestep (before the caller's MPI minimum) */
+    int64_t timebincounts[SHQ_TIMEBINS + 1]; /* shq_hier_gravity_bins */
+} shq_timestep_result;
+
+/* find_timesteps particle loop (timestep.cpp:733-792): new TimeBinHydro = TimeBinGravity for the list (NULL: all; the
+ * resident lists are accepted) from the gravity criterion on FullTreeGravAccel + GravPM and, for gas / BH, the hydro criteria
+ * (MaxSignalVel of the last hydro run or upload, Hsml, DtHsml; the BH neighbour limiter needs shq_bh_dynamics_upload).
+ * ForceEqualTimesteps: dti_min_global (the caller's reduction of shq_find_global_timestep over ranks) is every particle's step.
+ * isFirstTimeStep: set_bh_first_timestep(mTimeBin) with mTimeBin_global >= 0, otherwise with this list's own minimum.
+ * The caller applies the DriftKickTimes updates of timestep.cpp:707-722, 806-821. */
+int shq_find_timesteps(shq_context *ctx, const shq_timestep_params *p, const int32_t *active, int64_t nactive, int64_t dti_min_global,
+                       int mTimeBin_global, shq_timestep_result *res);
+/* find_global_timestep (timestep.cpp:195-221): min over all live particles of the converted step; res->dti_min, res->nbadbin. */
+int shq_find_global_timestep(shq_context *ctx, const shq_timestep_params *p, shq_timestep_result *res);
+/* find_hydro_timesteps (timestep.cpp:583-703): TimeBinHydro of gas and BH on the list, capped by TimeBinGravity; BHs also get
+ * TimeBinDynFric (get_timestep_dynfric_dloga, :1085-1110).  res->mintimebin carries the fix-ups of :677-696 for ONE rank; a
+ * caller with several ranks reduces mTimeBin first and passes it back as mTimeBin_global to shq_set_bh_first_timestep. */
+int shq_find_hydro_timesteps(shq_context *ctx, const shq_timestep_params *p, const int32_t *active, int64_t nactive, shq_timestep_result *res);
+int shq_set_bh_first_timestep(shq_context *ctx, int mTimeBin);
+/* hierarchical_gravity_and_timesteps, the three particle loops (timestep.cpp:356-380, 407-414, 449-464):
+ * shq_hier_gravity_bins: TimeBinGravity = min(bin of the rounded-down gravity step, largest_active) and timebincounts;
+ * shq_hier_push_down: TimeBinGravity = min(TimeBinGravity, push_down_bin) over the list;
+ * shq_hier_refine: TimeBinGravity = ti - 1 where the step from the CURRENT level's acceleration is shorter than bin ti's
+ *     (res->badstepsizecount counts them when ti == 1).
+ * from_accel_store: the acceleration is the last walk's Accel output (AccelStore) instead of FullTreeGravAccel. */
+int shq_hier_gravity_bins(shq_context *ctx, const shq_timestep_params *p, const int32_t *active, int64_t nactive, int from_accel_store,
+                          int largest_active, shq_timestep_result *res);
+int shq_hier_push_down(shq_context *ctx, const int32_t *active, int64_t nactive, int push_down_bin);
+int shq_hier_refine(shq_context *ctx, const shq_timestep_params *p, const int32_t *active, int64_t nactive, int from_accel_store, int ti,
+                    shq_timestep_result *res);
+/* get_long_range_timestep_dloga's particle loop (timestep.cpp:1153-1166): per type, sum of |Vel|^2, smallest positive mass and
+ * count over the live particles.  The sum runs in a fixed order (blocks of 256 in index order, then the block sums in order),
+ * so it is reproducible; the reference's OpenMP reduction has no fixed order. */
+int shq_velocity_moments(shq_context *ctx, double v2sum[6], double min_mass[6], int64_t count[6]);
+int shq_timebins_download(shq_context *ctx, uint8_t *bin_gravity, uint8_t *bin_hydro);
+/* SphP[].MaxSignalVel by particle index (what the hydro criterion reads): upload for a state that did not come from a hydro
+ * run of this context (NULL keeps it; gas particles only are read). */
+int shq_maxsignalvel_upload(shq_context *ctx, const double *maxsignalvel_by_particle);
+
+/* Black-hole slot fields of the resident step (bh_particle_data, slotsmanager.h:35-73).  With them on the device
+ * shq_drift repositions a BH with JumpToMinPot set (drift.cpp:32-53, when shq_set_bh_reposition is on), shq_kick_hydro adds
+ * the dynamic-friction and drag kicks (timestep.cpp:973-979, factor bh_gravkick[TimeBinHydro] as apply_half_kick passes it),
+ * the time-step loops read minTimeBin and write TimeBinDynFric.  download writes TimeBinDynFric and JumpToMinPot back. */
+typedef struct shq_bh_dyn_view {
+    void *base;
+    size_t elsize;
+    int64_t numslots;
+    size_t off_mintimebin, off_timebindynfric, off_jumptominpot;       /* unsigned char, unsigned char, char */
+    size_t off_dfaccel, off_df_surroundingvel, off_dragaccel;         /* MyFloat[3] (double) */
+    size_t off_minpotpos, off_minpotvel;                              /* double[3], MyFloat[3] */
+} shq_bh_dyn_view;
+int shq_bh_dynamics_upload(shq_context *ctx, const shq_part_view *parts, const shq_bh_dyn_view *bh);
+int shq_bh_dynamics_download(shq_context *ctx, const shq_part_view *parts, const shq_bh_dyn_view *bh);
+int shq_set_bh_reposition(shq_context *ctx, int enabled);
+int shq_kick_bh(shq_context *ctx, const double gravkick[SHQ_TIMEBINS + 1], const int32_t *active, int64_t nactive);
 /* active: host int32 list or NULL. The walk and postprocess are queued on the stream. */
 int shq_grav_short_run(shq_context *ctx, const shq_grav_params *params, const int32_t *active,
                        int64_t nactive, int update_potential, int walk_mode);

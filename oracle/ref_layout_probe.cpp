@@ -76,6 +76,20 @@ int main()
     printf(" \"sph_particle_data\": {\"ReverseLink\": %zu, \"Sfr\": %zu, \"Ne\": %zu, \"VDisp\": %zu, \"Metallicity\": %zu, \"Metals\": %zu},\n",
            offsetof(sph_particle_data, ReverseLink), offsetof(sph_particle_data, Sfr), offsetof(sph_particle_data, Ne),
            offsetof(sph_particle_data, VDisp), offsetof(sph_particle_data, Metallicity), offsetof(sph_particle_data, Metals));
-    printf(" \"bh_view\": {\"elsize\": %zu, \"off_density\": %zu, \"off_divvel\": %zu}}\n", bv.elsize, bv.off_density, bv.off_divvel);
+    printf(" \"bh_view\": {\"elsize\": %zu, \"off_density\": %zu, \"off_divvel\": %zu},\n", bv.elsize, bv.off_density, bv.off_divvel);
+    /* shq_bh_dyn_view as the reference-side shim fills it */
+    const shq_bh_dyn_view dv = { nullptr, sizeof(bh_particle_data), 0,
+        offsetof(bh_particle_data, minTimeBin), offsetof(bh_particle_data, TimeBinDynFric), offsetof(bh_particle_data, JumpToMinPot),
+        offsetof(bh_particle_data, DFAccel), offsetof(bh_particle_data, DF_SurroundingVel), offsetof(bh_particle_data, DragAccel),
+        offsetof(bh_particle_data, MinPotPos), offsetof(bh_particle_data, MinPotVel) };
+    printf(" \"bh_dyn_view\": {\"elsize\": %zu, \"off_mintimebin\": %zu, \"off_timebindynfric\": %zu, \"off_jumptominpot\": %zu, \"off_dfaccel\": %zu, "
+           "\"off_df_surroundingvel\": %zu, \"off_dragaccel\": %zu, \"off_minpotpos\": %zu, \"off_minpotvel\": %zu},\n",
+           dv.elsize, dv.off_mintimebin, dv.off_timebindynfric, dv.off_jumptominpot, dv.off_dfaccel, dv.off_df_surroundingvel, dv.off_dragaccel,
+           dv.off_minpotpos, dv.off_minpotvel);
+    printf(" \"bh_particle_data\": {\"ReverseLink\": %zu, \"Mass\": %zu, \"Mdot\": %zu, \"Density\": %zu, \"DivVel\": %zu, \"VDisp\": %zu, "
+           "\"SwallowID\": %zu, \"MinPot\": %zu, \"CountProgs\": %zu}}\n",
+           offsetof(bh_particle_data, ReverseLink), offsetof(bh_particle_data, Mass), offsetof(bh_particle_data, Mdot), offsetof(bh_particle_data, Density),
+           offsetof(bh_particle_data, DivVel), offsetof(bh_particle_data, VDisp), offsetof(bh_particle_data, SwallowID), offsetof(bh_particle_data, MinPot),
+           offsetof(bh_particle_data, CountProgs));
     return 0;
 }

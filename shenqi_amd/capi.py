@@ -172,6 +172,68 @@ class SphView(C.Structure):
                 ("off_delaytime", C.c_size_t)]
 
 
+# struct bh_particle_data, libgadget/slotsmanager.h:35-73 (248 B)
+BH_DTYPE = np.dtype(
+    {
+        "names": ["ReverseLink", "minTimeBin", "encounter", "TimeBinDynFric", "JumpToMinPot", "Mass", "Mdot", "Density", "DivVel", "Mtrack",
+                  "KineticFdbkEnergy", "VDisp", "DFAccel", "DF_SurroundingVel", "DF_SurroundingRmsVel", "DF_SurroundingDensity", "DragAccel",
+                  "SwallowTime", "SwallowID", "Mseed", "FormationTime", "MinPot", "MinPotPos", "MinPotVel", "CountProgs"],
+        "formats": ["<i4", "u1", "i1", "u1", "i1", "<f8", "<f8", "<f8", "<f8", "<f8", "<f8", "<f8", ("<f8", 3), ("<f8", 3), "<f8", "<f8",
+                    ("<f8", 3), "<f8", "<u8", "<f8", "<f8", "<f8", ("<f8", 3), ("<f8", 3), "<i4"],
+        "offsets": [0, 4, 5, 6, 7, 8, 16, 24, 32, 40, 48, 56, 64, 88, 112, 120, 128, 152, 160, 168, 176, 184, 192, 216, 240],
+        "itemsize": 248,
+    }
+)
+
+
+class BhDynView(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("elsize", C.c_size_t), ("numslots", C.c_int64),
+                ("off_mintimebin", C.c_size_t), ("off_timebindynfric", C.c_size_t), ("off_jumptominpot", C.c_size_t),
+                ("off_dfaccel", C.c_size_t), ("off_df_surroundingvel", C.c_size_t), ("off_dragaccel", C.c_size_t),
+                ("off_minpotpos", C.c_size_t), ("off_minpotvel", C.c_size_t)]
+
+
+def bh_dyn_view(BhP):
+    """shq_bh_dyn_view of a numpy array of BH_DTYPE records."""
+    v = BhDynView()
+    f = BhP.dtype.fields
+    v.base, v.elsize, v.numslots = BhP.ctypes.data, BhP.dtype.itemsize, len(BhP)
+    v.off_mintimebin, v.off_timebindynfric, v.off_jumptominpot = f["minTimeBin"][1], f["TimeBinDynFric"][1], f["JumpToMinPot"][1]
+    v.off_dfaccel, v.off_df_surroundingvel, v.off_dragaccel = f["DFAccel"][1], f["DF_SurroundingVel"][1], f["DragAccel"][1]
+    v.off_minpotpos, v.off_minpotvel = f["MinPotPos"][1], f["MinPotVel"][1]
+    return v
+
+
+class Timeline(C.Structure):
+    _fields_ = [("Ti_Current", C.c_int64), ("loga_now", C.c_double), ("Dloga_interval", C.c_double), ("nseg", C.c_int32), ("pad_", C.c_int32),
+                ("seg_snap", C.c_int64 * 2), ("seg_loga", C.c_double * 3)]
+
+
+class TimestepParams(C.Structure):
+    _fields_ = [("ErrTolIntAccuracy", C.c_double), ("CourantFac", C.c_double), ("MinSizeTimestep", C.c_double), ("ForceSoftening", C.c_double),
+                ("atime", C.c_double), ("hubble", C.c_double), ("fac3", C.c_double), ("dti_max", C.c_int64), ("ForceEqualTimesteps", C.c_int32),
+                ("isFirstTimeStep", C.c_int32), ("mintimebin", C.c_int32), ("mingravtimebin", C.c_int32), ("tl", Timeline)]
+
+
+class TimestepResult(C.Structure):
+    _fields_ = [("badstepsizecount", C.c_int32), ("mTimeBin", C.c_int32), ("maxTimeBin", C.c_int32), ("mintimebin", C.c_int32),
+                ("ntiaccel", C.c_int64), ("nticourant", C.c_int64), ("ntihsml", C.c_int64), ("ntiaccrete", C.c_int64), ("ntineighbour", C.c_int64),
+                ("nbh", C.c_int64), ("dynratio", C.c_int64), ("maxdyndiff", C.c_int32), ("nbadbin", C.c_int32), ("dti_min", C.c_int64),
+                ("timebincounts", C.c_int64 * (TIMEBINS + 1))]
+
+
+class DriftKickTimes(C.Structure):
+    """DriftKickTimes, libgadget/timestep.h:10-26"""
+    _fields_ = [("mintimebin", C.c_int), ("maxtimebin", C.c_int), ("mingravtimebin", C.c_int), ("Ti_kick", C.c_int64 * (TIMEBINS + 1)),
+                ("Ti_lastactivedrift", C.c_int64 * (TIMEBINS + 1)), ("Ti_Current", C.c_int64), ("PM_length", C.c_int64), ("PM_start", C.c_int64),
+                ("PM_kick", C.c_int64)]
+
+
+class HostCosmo(C.Structure):
+    _fields_ = [("OmegaBaryon", C.c_double), ("OmegaCDM", C.c_double), ("OmegaNu1", C.c_double), ("RhoCrit", C.c_double), ("Omega0", C.c_double),
+                ("Hubble", C.c_double), ("GravInternal", C.c_double), ("hubble_now", C.c_double)]
+
+
 class BhView(C.Structure):
     _fields_ = [("base", C.c_void_p), ("elsize", C.c_size_t), ("numslots", C.c_int64),
                 ("off_density", C.c_size_t), ("off_divvel", C.c_size_t)]
@@ -262,6 +324,25 @@ hip.shq_ngb_toptree_exports.argtypes = [_vp, C.c_int, C.c_double, _vp, C.c_int64
 hip.shq_ngb_toptree_exports.restype = C.c_int
 hip.shq_set_walk_stats.argtypes = [_vp, C.c_int]
 hip.shq_set_walk_stats.restype = C.c_int
+_tsp, _tsr = C.POINTER(TimestepParams), C.POINTER(TimestepResult)
+hip.shq_find_timesteps.argtypes = [_vp, _tsp, _vp, C.c_int64, C.c_int64, C.c_int, _tsr]
+hip.shq_find_global_timestep.argtypes = [_vp, _tsp, _tsr]
+hip.shq_find_hydro_timesteps.argtypes = [_vp, _tsp, _vp, C.c_int64, _tsr]
+hip.shq_set_bh_first_timestep.argtypes = [_vp, C.c_int]
+hip.shq_hier_gravity_bins.argtypes = [_vp, _tsp, _vp, C.c_int64, C.c_int, C.c_int, _tsr]
+hip.shq_hier_push_down.argtypes = [_vp, _vp, C.c_int64, C.c_int]
+hip.shq_hier_refine.argtypes = [_vp, _tsp, _vp, C.c_int64, C.c_int, C.c_int, _tsr]
+hip.shq_velocity_moments.argtypes = [_vp, _vp, _vp, _vp]
+hip.shq_timebins_download.argtypes = [_vp, _vp, _vp]
+hip.shq_maxsignalvel_upload.argtypes = [_vp, _vp]
+hip.shq_bh_dynamics_upload.argtypes = [_vp, C.POINTER(PartView), C.POINTER(BhDynView)]
+hip.shq_bh_dynamics_download.argtypes = [_vp, C.POINTER(PartView), C.POINTER(BhDynView)]
+hip.shq_set_bh_reposition.argtypes = [_vp, C.c_int]
+hip.shq_kick_bh.argtypes = [_vp, _vp, _vp, C.c_int64]
+for _f in ("shq_find_timesteps", "shq_find_global_timestep", "shq_find_hydro_timesteps", "shq_set_bh_first_timestep", "shq_hier_gravity_bins",
+           "shq_hier_push_down", "shq_hier_refine", "shq_velocity_moments", "shq_timebins_download", "shq_maxsignalvel_upload",
+           "shq_bh_dynamics_upload", "shq_bh_dynamics_download", "shq_set_bh_reposition", "shq_kick_bh"):
+    getattr(hip, _f).restype = C.c_int
 hip.shq_pm_slab_pitch.argtypes = [C.c_int]
 hip.shq_pm_slab_pitch.restype = C.c_int
 hip.shq_pm_slab2_deposit.argtypes = [_vp, C.POINTER(PMParams), C.c_int, C.c_int, C.c_int, C.c_int, _vp]
@@ -316,6 +397,40 @@ hip.shq_fft_c2r_xyz.argtypes = [_vp, C.c_int, _vp, _vp]
 hip.shq_fft_c2r.argtypes = [_vp, C.c_int, _vp, _vp]
 
 host.shqh_last_error.restype = C.c_char_p
+GRAVKICK_CB = C.CFUNCTYPE(C.c_double, C.c_int64, C.c_int64, C.c_void_p)
+host.shqh_timebinmgr_create.argtypes = [_vp, C.c_int]
+host.shqh_timebinmgr_create.restype = _vp
+host.shqh_timebinmgr_destroy.argtypes = [_vp]
+host.shqh_timebinmgr_destroy.restype = None
+host.shqh_timebinmgr_set_gravkick.argtypes = [_vp, GRAVKICK_CB, _vp]
+host.shqh_timebinmgr_set_gravkick.restype = None
+host.shqh_tbm_ti_from_loga.argtypes = [_vp, C.c_double]
+host.shqh_tbm_ti_from_loga.restype = C.c_int64
+host.shqh_tbm_loga_from_ti.argtypes = [_vp, C.c_int64]
+host.shqh_tbm_loga_from_ti.restype = C.c_double
+host.shqh_tbm_dti_from_dloga.argtypes = [_vp, C.c_double, C.c_int64]
+host.shqh_tbm_dti_from_dloga.restype = C.c_int64
+host.shqh_tbm_dloga_from_dti.argtypes = [_vp, C.c_int64, C.c_int64]
+host.shqh_tbm_dloga_from_dti.restype = C.c_double
+host.shqh_tbm_get_dloga_for_bin.argtypes = [_vp, C.c_int, C.c_int64]
+host.shqh_tbm_get_dloga_for_bin.restype = C.c_double
+host.shqh_tbm_find_next_ti_sync.argtypes = [_vp, C.c_int64]
+host.shqh_tbm_find_next_ti_sync.restype = C.c_int64
+host.shqh_tbm_timeline_at.argtypes = [_vp, C.c_int64, C.POINTER(Timeline)]
+host.shqh_tbm_timeline_at.restype = None
+host.shqh_round_down_power_of_two.argtypes = [C.c_int64]
+host.shqh_round_down_power_of_two.restype = C.c_int64
+host.shqh_get_timestep_bin.argtypes = [C.c_int64]
+host.shqh_is_timebin_active.argtypes = [C.c_int, C.c_int64]
+host.shqh_set_timestep_params.argtypes = [C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]
+host.shqh_set_timestep_params.restype = None
+host.shqh_find_timesteps.argtypes = [_vp, C.c_int, C.c_int64, C.POINTER(DriftKickTimes), _vp, C.c_double, C.c_int, C.POINTER(HostCosmo), C.c_double,
+                                     C.c_int, C.POINTER(C.c_int)]
+host.shqh_find_hydro_timesteps.argtypes = [_vp, C.c_int, C.c_int64, C.POINTER(DriftKickTimes), _vp, C.c_double, C.POINTER(HostCosmo), C.c_int,
+                                           C.POINTER(C.c_int)]
+host.shqh_hierarchical_gravity_and_timesteps.argtypes = [_vp, C.c_int, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int,
+                                                         C.POINTER(DriftKickTimes), _vp, C.c_double, C.c_int, C.c_int, C.POINTER(HostCosmo), C.c_int,
+                                                         C.POINTER(C.c_int64)]
 host.shqh_partmanager_create.argtypes = [_vp, C.c_int64, C.c_double]
 host.shqh_partmanager_create.restype = _vp
 host.shqh_partmanager_free.argtypes = [_vp]

@@ -205,6 +205,7 @@ extern "C" void shq_shutdown(shq_context *ctx)
     ctx->g_entropy.release(); ctx->g_dtentropy.release(); ctx->g_hydroaccel.release(); ctx->g_delaytime.release();
     ctx->g_density.release(); ctx->g_egywt.release(); ctx->g_dhsmlegy.release(); ctx->g_divvel.release(); ctx->g_curlvel.release();
     ctx->g_hydroaccel_out.release(); ctx->g_dtentropy_out.release(); ctx->g_maxsignalvel.release();
+    ctx->bh_pidx.release(); ctx->bh_u8.release(); ctx->bh_vec.release();
     ctx->velp.release(); ctx->hydC.release(); ctx->hydD.release(); ctx->velp_leaf.release(); ctx->hydrec_leaf.release();
     ctx->hsml_leaf.release(); ctx->flag_leaf.release();
     ctx->s_numngb.release(); ctx->s_dhsmldens.release(); ctx->s_left.release(); ctx->s_right.release(); ctx->s_rot.release();
@@ -380,6 +381,8 @@ extern "C" int shq_particles_upload(shq_context *ctx, const shq_part_view *parts
     ctx->tb_built = false;
     ctx->have_sph = false;  /* Hsml / Vel / slot data of the previous particle set */
     ctx->have_dyn = false;
+    ctx->have_bh_dyn = false;
+    ctx->nbh = 0;
     ctx->have_toptree = false;
     ctx->n_act = ctx->n_sub = -1;
     ctx->have_pm_result = false;
@@ -713,6 +716,8 @@ extern "C" int shq_particles_set_device(shq_context *ctx, const void *d_posm, in
     ctx->have_tree_targets = false; /* nlocal may have changed */
     ctx->have_sph = false;
     ctx->have_dyn = false;
+    ctx->have_bh_dyn = false;
+    ctx->nbh = 0;
     ctx->have_toptree = false;
     ctx->n_act = ctx->n_sub = -1;
     ctx->numpart = n;

@@ -283,6 +283,12 @@ struct shq_context {
     DevBuf<double> g_entropy, g_dtentropy, g_hydroaccel, g_delaytime;
     DevBuf<double> g_density, g_egywt, g_dhsmlegy, g_divvel, g_curlvel;
     DevBuf<double> g_hydroaccel_out, g_dtentropy_out, g_maxsignalvel;
+    /* black-hole slot fields of the resident step (timestep.hip): by BH ordinal, bh_pidx ascending particle indices */
+    bool have_bh_dyn = false, bh_reposition = false;
+    int64_t nbh = 0;
+    DevBuf<int32_t> bh_pidx;
+    DevBuf<uint8_t> bh_u8;     /* minTimeBin[nbh], TimeBinDynFric[nbh], JumpToMinPot[nbh] */
+    DevBuf<double> bh_vec;     /* DFAccel, DF_SurroundingVel, DragAccel, MinPotPos, MinPotVel: [5][nbh][3] */
     DevBuf<double4> velp, hydC, hydD, velp_leaf;
     DevBuf<char> hydrec_leaf;  /* HydRec[] (sph.hip): 128-byte neighbour records for the hydro evaluation */
     DevBuf<double> hsml_leaf;
@@ -345,6 +351,19 @@ int shq_join_pm(shq_context *ctx);
 /* grav_walk.hip */
 /* Device pointer and length of an active list argument of the C-ABI: NULL (all n_all), a host list
  * (uploaded), or one of the SHQ_ACTIVE_RESIDENT / SHQ_SUBLIST_RESIDENT handles. dynamics.hip */
+/* ordinal of particle i in the ascending list of black-hole particle indices, -1 if it is not there */
+__device__ inline long long shq_bh_ordinal(const int32_t *pidx, long long nbh, int32_t i)
+{
+    long long lo = 0, hi = nbh;
+    while(lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if(pidx[mid] < i)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return (lo < nbh && pidx[lo] == i) ? lo : -1;
+}
 int shq_resolve_active(shq_context *ctx, const int32_t *active, int64_t nactive, int64_t n_all, const int32_t **d_active, int64_t *nt);
 /* first: with d_active == NULL the targets are the particles [first, first + ntargets) (the per-particle arrays are handed to
  * the kernels shifted by `first`); a range with first > 0 adds to the interaction statistics of the ranges before it */

@@ -6,8 +6,9 @@
  *   do_grav_short_range_kick, apply_half_kick (gravity part)   libgadget/timestep.cpp:838-872, 962-968
  *   apply_PM_half_kick                          libgadget/timestep.cpp:937-959
  * with the reference's operation order (no fma contraction), so the state stays bit-identical to a
- * host integration.  Not covered (need the BH / SPH slot arrays): black-hole repositioning
- * (drift.cpp:32-53) and do_hydro_kick.  The integer time line (Ti_drift, Ti_kick) stays with the host. */
+ * host integration.  Black-hole repositioning (drift.cpp:32-53) runs when the BH slot fields are resident
+ * (shq_bh_dynamics_upload, timestep.hip) and shq_set_bh_reposition is on.  The per-particle loops of the integer time line
+ * are in timestep.hip; Ti_drift / Ti_kick stay with the host. */
 #include "common.hpp"
 #include <string.h>
 #include <cstring>
@@ -24,8 +25,15 @@ inline unsigned nblk(long long n, int t = 256) { return (unsigned) ((n + t - 1) 
 
 struct Shift3 { double s[3]; };
 
-__global__ void drift_kernel(long long n, double4 *posm, const double *__restrict__ vel, double *hsml, const double *__restrict__ dthsml,
-                             const uint8_t *__restrict__ pflags, double ddrift, double Box, Shift3 sh, int *err)
+struct BhJump { /* black-hole repositioning, drift.cpp:32-53; pidx == nullptr: off */
+    const int32_t *pidx;
+    long long nbh;
+    uint8_t *jump;
+    const double *minpotpos, *minpotvel;
+};
+
+__global__ void drift_kernel(long long n, double4 *posm, double *vel, double *hsml, const double *__restrict__ dthsml,
+                             const uint8_t *__restrict__ pflags, double ddrift, double Box, Shift3 sh, BhJump bh, int *err)
 {
 #pragma clang fp contract(off)
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -38,7 +46,22 @@ __global__ void drift_kernel(long long n, double4 *posm, const double *__restric
         for(int j = 0; j < 3; j++)
             x[j] += sh.s[j];
     } else {
-        if((f >> 4) == 0 && hsml) { /* gas: Hsml prediction, drift.cpp:55-69 */
+        if((f >> 4) == 5 && bh.pidx) {
+            const long long k = shq_bh_ordinal(bh.pidx, bh.nbh, (int32_t) i);
+            if(k >= 0) {
+                if(bh.jump[k]) {
+                    for(int j = 0; j < 3; j++) {
+                        const double d = x[j] - bh.minpotpos[3 * k + j];
+                        const double dx = d > 0.5 * Box ? d - Box : (d < -0.5 * Box ? d + Box : d); /* NEAREST, partmanager.h:99 */
+                        if(dx > 0.1 * Box)
+                            *err = 3;
+                        x[j] = bh.minpotpos[3 * k + j];
+                        vel[3 * i + j] = bh.minpotvel[3 * k + j];
+                    }
+                }
+                bh.jump[k] = 0;
+            }
+        } else if((f >> 4) == 0 && hsml) { /* gas: Hsml prediction, drift.cpp:55-69 */
             double h = hsml[i];
             h += dthsml[i] * ddrift;
             if(h <= 0)
@@ -457,9 +480,12 @@ extern "C" int shq_drift(shq_context *ctx, double ddrift, double BoxSize, const 
         sh.s[j] = random_shift ? random_shift[j] : 0.0;
     int *d_err = ctx->pm_oob.ptr + 1;
     SHQ_HIP(hipMemsetAsync(d_err, 0, sizeof(int), ctx->stream));
+    BhJump bh = {nullptr, 0, nullptr, nullptr, nullptr};
+    if(ctx->bh_reposition && ctx->have_bh_dyn && ctx->nbh > 0)
+        bh = BhJump{ctx->bh_pidx.ptr, ctx->nbh, ctx->bh_u8.ptr + 2 * ctx->nbh, ctx->bh_vec.ptr + 9 * ctx->nbh, ctx->bh_vec.ptr + 12 * ctx->nbh};
     if(n > 0) {
         drift_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(n, ctx->posm.ptr, ctx->vel.ptr, ctx->hsml.ptr, ctx->dthsml.ptr,
-                                                                 ctx->pflags.ptr, ddrift, BoxSize, sh, d_err);
+                                                                 ctx->pflags.ptr, ddrift, BoxSize, sh, bh, d_err);
         SHQ_HIP(hipGetLastError());
     }
     int h_err = 0;
@@ -473,6 +499,7 @@ extern "C" int shq_drift(shq_context *ctx, double ddrift, double BoxSize, const 
     ctx->have_pm_result = false;
     SHQ_CHECK(h_err != 1, SHQ_ERR_INVALID, "drift: a gas particle reached Hsml <= 0 (drift.cpp:61-63)");
     SHQ_CHECK(h_err != 2, SHQ_ERR_INVALID, "drift: a particle position is not finite (drift.cpp:72-75)");
+    SHQ_CHECK(h_err != 3, SHQ_ERR_INVALID, "drift: a black hole would jump further than 0.1 BoxSize to its potential minimum (drift.cpp:40-48)");
     return SHQ_OK;
 }
 

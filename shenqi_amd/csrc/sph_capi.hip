@@ -42,13 +42,14 @@ int sph_upload(shq_context *ctx, const shq_part_view *parts, const shq_sph_view 
                   parts->off_type != SHQ_NOFIELD, SHQ_ERR_INVALID, "SPH needs Hsml, Vel, PI and Type in the particle view");
     SHQ_CHECK(sph && (sph->numslots == 0 || sph->base), SHQ_ERR_INVALID, "SPH slot view is NULL");
     const int64_t n = parts->numpart;
-    /* one parallel pass into pinned staging (15 doubles + 2 bytes per particle), then one copy per array */
+    /* one parallel pass into pinned staging (17 doubles + 2 bytes per particle), then one copy per array */
     const size_t cap = (size_t) std::max<int64_t>(n, 1);
-    SHQ_TRY(ctx->stage.reserve(cap * (15 * sizeof(double) + 2) + 256));
+    SHQ_TRY(ctx->stage.reserve(cap * (17 * sizeof(double) + 2) + 256));
     double *hsml = reinterpret_cast<double *>(ctx->stage.ptr);
     double *vel = hsml + cap, *entropy = vel + 3 * cap, *dtentropy = entropy + cap, *hacc = dtentropy + cap, *delay = hacc + 3 * cap;
     double *density = delay + cap, *egywt = density + cap, *dhsml = egywt + cap, *divvel = dhsml + cap, *curl = divvel + cap;
-    uint8_t *bg = reinterpret_cast<uint8_t *>(curl + cap), *bh = bg + cap;
+    double *dth = curl + cap, *msv = dth + cap;
+    uint8_t *bg = reinterpret_cast<uint8_t *>(msv + cap), *bh = bg + cap;
     std::atomic<int> bad(0);
     {
         unsigned nt = std::thread::hardware_concurrency();
@@ -65,7 +66,8 @@ int sph_upload(shq_context *ctx, const shq_part_view *parts, const shq_sph_view 
                 bh[i] = parts->off_timebin_hydro != SHQ_NOFIELD ? *pfield<uint8_t>(parts, i, parts->off_timebin_hydro) : 0;
                 if(bg[i] > SHQ_TIMEBINS || bh[i] > SHQ_TIMEBINS)
                     bad.store(1);
-                double e = 0, de = 0, h0 = 0, h1 = 0, h2 = 0, dl = 0, rho = 0, eg = 0, dh = 0, dv = 0, cv = 0;
+                dth[i] = parts->off_dthsml != SHQ_NOFIELD ? *pfield<double>(parts, i, parts->off_dthsml) : 0.0;
+                double e = 0, de = 0, h0 = 0, h1 = 0, h2 = 0, dl = 0, rho = 0, eg = 0, dh = 0, dv = 0, cv = 0, ms = 0;
                 if(*pfield<uint8_t>(parts, i, parts->off_type) == 0) {
                     const int32_t pi = *pfield<int32_t>(parts, i, parts->off_pi);
                     if(pi < 0 || pi >= sph->numslots)
@@ -82,8 +84,11 @@ int sph_upload(shq_context *ctx, const shq_part_view *parts, const shq_sph_view 
                         dh = *sfield(sph, pi, sph->off_dhsmlegydensityfactor);
                         dv = *sfield(sph, pi, sph->off_divvel);
                         cv = *sfield(sph, pi, sph->off_curlvel);
+                        if(sph->off_maxsignalvel != SHQ_NOFIELD)
+                            ms = *sfield(sph, pi, sph->off_maxsignalvel);
                     }
                 }
+                msv[i] = ms;
                 entropy[i] = e; dtentropy[i] = de;
                 hacc[3 * i] = h0; hacc[3 * i + 1] = h1; hacc[3 * i + 2] = h2;
                 delay[i] = dl; density[i] = rho; egywt[i] = eg; dhsml[i] = dh; divvel[i] = dv; curl[i] = cv;
@@ -126,9 +131,8 @@ int sph_upload(shq_context *ctx, const shq_part_view *parts, const shq_sph_view 
     SHQ_TRY(upd(ctx->g_dhsmlegy, dhsml, n));
     SHQ_TRY(upd(ctx->g_divvel, divvel, n));
     SHQ_TRY(upd(ctx->g_curlvel, curl, n));
-    SHQ_TRY(ctx->dthsml.reserve(std::max<int64_t>(n, 1)));
-    if(n > 0)
-        SHQ_HIP(hipMemsetAsync(ctx->dthsml.ptr, 0, sizeof(double) * n, ctx->stream));
+    SHQ_TRY(upd(ctx->dthsml, dth, n));          /* Part[].DtHsml and SphP[].MaxSignalVel: what the time-step criteria read */
+    SHQ_TRY(upd(ctx->g_maxsignalvel, msv, n));
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     ctx->have_sph = true;
     return SHQ_OK;

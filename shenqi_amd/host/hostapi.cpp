@@ -298,3 +298,83 @@ int shqh_hydro_force(shq_context *ctx, part_manager_type *pm, ForceTree *tree, s
     return hydro_force(ctx, &act, atime, hubble, EntVarPred, kick, drifts, tree, pm, &S, UseGPU != 0, stats);
 }
 }
+
+/* ---- time line test/driver API ------------------------------------------------------------------ */
+#include "timestep.hpp"
+extern "C" {
+
+TimeBinMgr *shqh_timebinmgr_create(const double *sync_loga, int nsync) { return nsync >= 2 ? new TimeBinMgr(sync_loga, nsync) : nullptr; }
+void shqh_timebinmgr_destroy(TimeBinMgr *t) { delete t; }
+void shqh_timebinmgr_set_gravkick(TimeBinMgr *t, double (*cb)(inttime_t, inttime_t, void *), void *user)
+{
+    t->exact_gravkick = cb;
+    t->user = user;
+}
+inttime_t shqh_tbm_ti_from_loga(const TimeBinMgr *t, double loga) { return t->ti_from_loga(loga); }
+double shqh_tbm_loga_from_ti(const TimeBinMgr *t, inttime_t ti) { return t->loga_from_ti(ti); }
+inttime_t shqh_tbm_dti_from_dloga(const TimeBinMgr *t, double dloga, inttime_t Ti) { return t->dti_from_dloga(dloga, Ti); }
+double shqh_tbm_dloga_from_dti(const TimeBinMgr *t, inttime_t dti, inttime_t Ti) { return t->dloga_from_dti(dti, Ti); }
+double shqh_tbm_get_dloga_for_bin(const TimeBinMgr *t, int bin, inttime_t Ti) { return t->get_dloga_for_bin(bin, Ti); }
+inttime_t shqh_tbm_find_next_ti_sync(const TimeBinMgr *t, inttime_t ti) { return t->find_next_ti_sync(ti); }
+void shqh_tbm_timeline_at(const TimeBinMgr *t, inttime_t Ti, shq_timeline *out) { *out = t->timeline_at(Ti); }
+inttime_t shqh_round_down_power_of_two(inttime_t dti) { return round_down_power_of_two(dti); }
+int shqh_get_timestep_bin(inttime_t dti) { return get_timestep_bin(dti); }
+int shqh_is_timebin_active(int bin, inttime_t Ti) { return is_timebin_active(bin, Ti); }
+
+void shqh_set_timestep_params(double ErrTolIntAccuracy, int ForceEqualTimesteps, double MinSizeTimestep, double MaxSizeTimestep,
+                              double MaxRMSDisplacementFac, double MaxGasVel, double CourantFac)
+{
+    struct timestep_params p = {ErrTolIntAccuracy, ForceEqualTimesteps, MinSizeTimestep, MaxSizeTimestep, MaxRMSDisplacementFac, MaxGasVel, CourantFac};
+    set_timestep_params(p);
+}
+
+/* the test driver's cosmology: the Hubble function is one number per call (the loops evaluate it at one atime only) */
+struct shqh_cosmo {
+    double OmegaBaryon, OmegaCDM, OmegaNu1, RhoCrit, Omega0, Hubble, GravInternal, hubble_now;
+};
+static double g_hubble_now;
+static double hubble_const(const Cosmology *, double) { return g_hubble_now; }
+static Cosmology make_cosmo(const shqh_cosmo *c)
+{
+    g_hubble_now = c->hubble_now;
+    Cosmology CP = {c->OmegaBaryon, c->OmegaCDM, c->OmegaNu1, c->RhoCrit, c->Omega0, c->Hubble, c->GravInternal, hubble_const};
+    return CP;
+}
+static ActiveParticles make_act(int have_list, int64_t nactive, int64_t nactivegrav)
+{
+    ActiveParticles act;
+    memset(&act, 0, sizeof(act));
+    static int marker;
+    act.ActiveParticle = have_list ? &marker : nullptr; /* only tested against NULL: the list is the resident one */
+    act.NumActiveParticle = nactive;
+    act.NumActiveGravity = nactivegrav;
+    return act;
+}
+
+int shqh_find_timesteps(shq_context *ctx, int have_list, int64_t nactive, DriftKickTimes *times, TimeBinMgr *tbm, double atime,
+                        int FastParticleType, const shqh_cosmo *c, double asmth, int isFirstTimeStep, int *bad)
+{
+    Cosmology CP = make_cosmo(c);
+    ActiveParticles act = make_act(have_list, nactive, nactive);
+    return find_timesteps(ctx, &act, times, tbm, atime, FastParticleType, &CP, asmth, isFirstTimeStep, bad);
+}
+
+int shqh_find_hydro_timesteps(shq_context *ctx, int have_list, int64_t nactive, DriftKickTimes *times, TimeBinMgr *tbm, double atime,
+                              const shqh_cosmo *c, int isFirstTimeStep, int *bad)
+{
+    Cosmology CP = make_cosmo(c);
+    ActiveParticles act = make_act(have_list, nactive, nactive);
+    return find_hydro_timesteps(ctx, &act, times, tbm, atime, &CP, isFirstTimeStep, bad);
+}
+
+int shqh_hierarchical_gravity_and_timesteps(shq_context *ctx, int have_list, int64_t nactive, int64_t nactivegrav, double BoxSize, double Asmth,
+                                            int Nmesh, double G, int have_stored_accel, DriftKickTimes *times, TimeBinMgr *tbm, double atime,
+                                            int treemask, int FastParticleType, const shqh_cosmo *c, int walk_mode, int64_t *bad)
+{
+    Cosmology CP = make_cosmo(c);
+    ActiveParticles act = make_act(have_list, nactive, nactivegrav);
+    PetaPM pm;
+    gravpm_init_periodic(&pm, BoxSize, Asmth, Nmesh, G);
+    return hierarchical_gravity_and_timesteps(ctx, &act, &pm, have_stored_accel, times, tbm, atime, treemask, FastParticleType, &CP, walk_mode, bad);
+}
+}

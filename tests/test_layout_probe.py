@@ -73,3 +73,18 @@ def test_sph_and_bh_slot_layout(layout):
         assert getattr(sv, key) == v[key]
     # black-hole slots: the two fields density() writes (densitytree2.hpp:117-173)
     assert layout["bh_view"] == {"elsize": 248, "off_density": 24, "off_divvel": 32}
+    # ... and the fields of the resident step (repositioning, dynamic friction / drag kicks, time-step limiter)
+    b = capi.BH_DTYPE
+    fb = {k: b.fields[k][1] for k in b.names}
+    assert layout["sizeof_bh_particle_data"] == b.itemsize == 248
+    dv = layout["bh_dyn_view"]
+    wantb = {"off_mintimebin": "minTimeBin", "off_timebindynfric": "TimeBinDynFric", "off_jumptominpot": "JumpToMinPot", "off_dfaccel": "DFAccel",
+             "off_df_surroundingvel": "DF_SurroundingVel", "off_dragaccel": "DragAccel", "off_minpotpos": "MinPotPos", "off_minpotvel": "MinPotVel"}
+    for key, name in wantb.items():
+        assert dv[key] == fb[name], key
+    for name, off in layout["bh_particle_data"].items():
+        assert fb[name] == off, name
+    bv = capi.bh_dyn_view(np.zeros(2, dtype=b))
+    for key in wantb:
+        assert getattr(bv, key) == dv[key]
+    assert bv.elsize == dv["elsize"]
