@@ -224,9 +224,49 @@ int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const int32_t *ac
 /* The device-built tree in the reference's format (struct NODE, forcetree.h:38-66): `nodes[k]` is node
  * number firstnode + k (pre-order, root first), links (sibling, father, suns of internal nodes) are node
  * numbers, leaf suns are particle indices; `father[i]` = node number of the leaf holding particle i or
- * -1 (ForceTree.Father).  Either output may be NULL; *numnodes always returns the node count. */
+ * -1 (ForceTree.Father).  Either output may be NULL; *numnodes always returns the node count.  After shq_tree_build_domain the
+ * top-level nodes carry TopLevel / InternalTopLevel and pseudo nodes suns[0] = firstnode + capacity + leaf (lastnode is the end of
+ * the caller's node array). */
 int shq_tree_download(shq_context *ctx, int64_t firstnode, shq_node *nodes, int64_t capacity, int32_t *father,
                       int64_t *numnodes);
+
+/* Device tree build under a domain decomposition: the top-tree and pseudo-particle part of force_tree_create_nodes
+ * (force_tree_create_topnodes / force_create_node_for_topnode, libgadget/forcetree.cpp:651-690, 868-930), the moments of the
+ * local sub-trees, and force_exchange_pseudodata / force_treeupdate_pseudos (:1136-1281) around the caller's all-gather.
+ *
+ * The top tree arrives as geometry: for every TopNode its eight daughters in octant order `count = i + 2 j + 4 k`
+ * (the slot force_create_node_for_topnode puts TopNodes[Daughter + sub] in, sub = 7 & peano_hilbert_key(2x + i, 2y + j, 2z + k,
+ * bits) — the reference-side shim fills the table with its own key function), -1 eight times for a leaf, and
+ * the leaf's TopLeaves index.  topleaves[].Task says whose each leaf is.
+ *
+ * shq_tree_build_domain: as shq_tree_build, but every TopNode is a tree node whether or not it holds particles (empty top-level
+ * nodes are never removed, forcetree.cpp:1040-1045), a leaf of ThisTask roots an ordinary sub-tree of this rank's particles, a
+ * leaf of another task is a pseudo node (ChildType PSEUDO, suns[0] = lastnode + leaf).  SHQ_ERR_INVALID if a particle of the
+ * list lies in a leaf of another task (the reference ends the run: "Bad topleaf").  Outputs: topleaves[].treenode = firstnode +
+ * pre-order number of the leaf's node (what shq_tree_download numbers it), local_moments[leaf] = {s, mass, hmax} of the leaves
+ * of ThisTask (zero elsewhere): the caller's contribution to the all-gather of force_exchange_pseudodata.
+ * shq_tree_set_topleaf_moments: after the all-gather; the moments of the other tasks' leaves go into their pseudo nodes, the
+ * internal top-level nodes are re-summed over their eight daughters (force_treeupdate_pseudos) and the top tree is installed for
+ * shq_grav_toptree_exports / shq_ngb_toptree_exports (no shq_toptree_upload needed).  A one-task domain needs no second call. */
+typedef struct shq_topleaf {   /* struct topleaf_data, libgadget/domain.h:20-24 */
+    int32_t Task;
+    int32_t topnode;
+    int32_t treenode;
+} shq_topleaf;
+typedef struct shq_topnode_geo {
+    int32_t daughter[8];    /* TopNodes index per octant, all -1 for a leaf */
+    int32_t leaf;           /* TopLeaves index of a leaf, -1 otherwise */
+    int32_t pad_;
+} shq_topnode_geo;
+typedef struct shq_topleaf_moments {   /* struct topleaf_momentsdata, forcetree.cpp:1129-1134 */
+    double s[3];
+    double mass;
+    double hmax;
+} shq_topleaf_moments;
+int shq_tree_build_domain(shq_context *ctx, double BoxSize, int mask, const int32_t *active, int64_t nactive,
+                          const shq_topnode_geo *topnodes, int ntopnodes, shq_topleaf *topleaves, int ntopleaves, int ThisTask,
+                          int64_t firstnode, shq_topleaf_moments *local_moments, shq_tree_build_stats *stats);
+int shq_tree_set_topleaf_moments(shq_context *ctx, const shq_topleaf_moments *moments, int ntopleaves);
 
 /* Resident drift and kick: with the particles, their velocities and the force
  * arrays in HBM a step is  shq_drift -> shq_tree_build -> shq_pm_run / shq_grav_short_run -> kicks,
@@ -436,11 +476,6 @@ int shq_grav_short_secondary(shq_context *ctx, const shq_grav_params *params, co
  * exportcounts, used by its BunchSize logic; may be NULL); table = the DataIndexTable, target t's entries contiguous at
  * [exportcounts[t-1], exportcounts[t]) in the reference's order; *nexport always returns the total.  With table == NULL
  * only counts are produced; with capacity < total nothing is written and SHQ_ERR_NOMEM is returned. */
-typedef struct shq_topleaf {   /* struct topleaf_data, libgadget/domain.h:20-24 */
-    int32_t Task;
-    int32_t topnode;
-    int32_t treenode;
-} shq_topleaf;
 typedef struct shq_data_index { /* struct data_index, libgadget/localtreewalk2.h:188-193 */
     int32_t Task;
     int32_t Index;

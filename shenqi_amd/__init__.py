@@ -122,6 +122,26 @@ def tree_build_device(ctx, BoxSize, mask=None, active=None):
     return st
 
 
+def tree_build_domain(ctx, BoxSize, geo, topleaves, ThisTask, firstnode, mask=None, active=None):
+    """shq_tree_build_domain: the device tree under a domain decomposition.  geo: capi.TOPNODE_GEO_DTYPE array, topleaves:
+    capi.TOPLEAF_DTYPE array (Task read, treenode written).  Returns (stats, local moments as capi.TOPLEAF_MOMENTS_DTYPE)."""
+    st = capi.TreeBuildStats()
+    act, nact = _active_arg(active)
+    geo = np.ascontiguousarray(geo, dtype=capi.TOPNODE_GEO_DTYPE)
+    assert topleaves.dtype == capi.TOPLEAF_DTYPE and topleaves.flags["C_CONTIGUOUS"]
+    mom = np.zeros(len(topleaves), dtype=capi.TOPLEAF_MOMENTS_DTYPE)
+    capi.check(capi.hip.shq_tree_build_domain(ctx.h, float(BoxSize), ALLMASK if mask is None else int(mask), act, nact, capi.ptr(geo), len(geo),
+                                              capi.ptr(topleaves), len(topleaves), int(ThisTask), int(firstnode), capi.ptr(mom), C.byref(st)),
+               "shq_tree_build_domain")
+    return st, mom
+
+
+def tree_set_topleaf_moments(ctx, moments):
+    """shq_tree_set_topleaf_moments: the all-gathered top-leaf moments (capi.TOPLEAF_MOMENTS_DTYPE) into the pseudo nodes."""
+    moments = np.ascontiguousarray(moments, dtype=capi.TOPLEAF_MOMENTS_DTYPE)
+    capi.check(capi.hip.shq_tree_set_topleaf_moments(ctx.h, capi.ptr(moments), len(moments)), "shq_tree_set_topleaf_moments")
+
+
 RESIDENT = "resident"        # the list of the last build_active_particles (SHQ_ACTIVE_RESIDENT)
 RESIDENT_SUB = "resident-sub"  # the list of the last build_active_sublist (SHQ_SUBLIST_RESIDENT)
 

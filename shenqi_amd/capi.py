@@ -204,6 +204,18 @@ def bh_dyn_view(BhP):
     return v
 
 
+class TopNodeGeo(C.Structure):
+    _fields_ = [("daughter", C.c_int32 * 8), ("leaf", C.c_int32), ("pad_", C.c_int32)]
+
+
+class TopLeafMoments(C.Structure):
+    _fields_ = [("s", C.c_double * 3), ("mass", C.c_double), ("hmax", C.c_double)]
+
+
+TOPNODE_GEO_DTYPE = np.dtype([("daughter", "<i4", 8), ("leaf", "<i4"), ("pad_", "<i4")])
+TOPLEAF_MOMENTS_DTYPE = np.dtype([("s", "<f8", 3), ("mass", "<f8"), ("hmax", "<f8")])
+
+
 class Timeline(C.Structure):
     _fields_ = [("Ti_Current", C.c_int64), ("loga_now", C.c_double), ("Dloga_interval", C.c_double), ("nseg", C.c_int32), ("pad_", C.c_int32),
                 ("seg_snap", C.c_int64 * 2), ("seg_loga", C.c_double * 3)]
@@ -324,6 +336,10 @@ hip.shq_ngb_toptree_exports.argtypes = [_vp, C.c_int, C.c_double, _vp, C.c_int64
 hip.shq_ngb_toptree_exports.restype = C.c_int
 hip.shq_set_walk_stats.argtypes = [_vp, C.c_int]
 hip.shq_set_walk_stats.restype = C.c_int
+hip.shq_tree_build_domain.argtypes = [_vp, C.c_double, C.c_int, _vp, C.c_int64, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int64, _vp, _vp]
+hip.shq_tree_build_domain.restype = C.c_int
+hip.shq_tree_set_topleaf_moments.argtypes = [_vp, _vp, C.c_int]
+hip.shq_tree_set_topleaf_moments.restype = C.c_int
 _tsp, _tsr = C.POINTER(TimestepParams), C.POINTER(TimestepResult)
 hip.shq_find_timesteps.argtypes = [_vp, _tsp, _vp, C.c_int64, C.c_int64, C.c_int, _tsr]
 hip.shq_find_global_timestep.argtypes = [_vp, _tsp, _tsr]

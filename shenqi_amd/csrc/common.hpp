@@ -173,6 +173,11 @@ struct TreeBuildBufs {
     DevBuf<unsigned long long> keys[2], okeys[2], packed[2], counters;
     DevBuf<int32_t> idx[2], order[2], rank, frontier[2], bounds;
     DevBuf<int32_t> lo, hi, parent, sibling, firstchild, nchild, level;
+    DevBuf<int32_t> top;                 /* domain build: TopNodes index of a top-level node, -1 below the top tree */
+    DevBuf<unsigned long long> path;     /* domain build: octant digits from the root, left-aligned (pre-order sort key) */
+    DevBuf<int4> geo_child[2];           /* domain build: daughters 0-3 / 4-7 per TopNode */
+    DevBuf<int2> geo_kind;               /* (kind: 0 internal, 1 leaf of this task, 2 pseudo; TopLeaves index) */
+    DevBuf<double> topbuf;               /* gather / scatter of the top-level nodes' records */
     DevBuf<double4> cen, mom;
     DevBuf<double> hmax;
     DevBuf<char> temp;
@@ -184,7 +189,7 @@ struct TreeBuildBufs {
         }
         counters.release(); rank.release(); bounds.release(); lo.release(); hi.release(); parent.release(); sibling.release();
         firstchild.release(); nchild.release(); level.release(); cen.release(); mom.release(); hmax.release(); temp.release();
-        exportbuf.release();
+        exportbuf.release(); top.release(); path.release(); geo_child[0].release(); geo_child[1].release(); geo_kind.release(); topbuf.release();
     }
 };
 
@@ -228,6 +233,12 @@ struct shq_context {
     DevBuf<int32_t> top_counts;
     DevBuf<shq_data_index> top_table;
     int64_t ntopnodes = 0;
+    /* the domain of the last shq_tree_build_domain (host copies: the top tree has a few thousand nodes) */
+    bool tb_domain = false;
+    std::vector<shq_topnode_geo> dom_geo;
+    std::vector<int32_t> dom_kind, dom_rank, dom_leaf_task; /* per TopNode: kind, pre-order number; per leaf: Task */
+    std::vector<double> dom_rec;                           /* per TopNode: cofm[3], mass, hmax, center[3], len */
+    int dom_thistask = 0;
     bool have_toptree = false;
     bool grav_raw = false;     /* acc / pot hold raw sums of a deferred-postprocess walk */
     DevBuf<shq_grav_result> gq_res;

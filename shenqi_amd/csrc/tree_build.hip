@@ -114,10 +114,30 @@ struct TbNodes {
     double4 *cen;  /* centre, len */
     double4 *mom;  /* cofm, mass */
     double *hmax;
+    int32_t *top;              /* domain build: TopNodes index, -1 below the top tree */
+    unsigned long long *path;  /* domain build: octant digits from the root, left-aligned */
 };
 
-__global__ void tb_root_kernel(TbNodes nd, int n, double Box)
+/* The top tree of a domain decomposition as geometry (shq_topnode_geo): daughters per octant, and per TopNode
+ * kind 0 internal / 1 leaf of this task / 2 leaf of another task (pseudo) with its TopLeaves index. */
+struct TbGeo {
+    const int4 *c0, *c1;
+    const int2 *kind;
+    __device__ int child(int t, int s) const
+    {
+        const int4 v = s < 4 ? c0[t] : c1[t];
+        const int k = s & 3;
+        return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
+    }
+};
+enum { TOPK_INTERNAL = 0, TOPK_LOCAL = 1, TOPK_PSEUDO = 2 };
+
+__global__ void tb_root_kernel(TbNodes nd, int n, double Box, int dom)
 {
+    if(dom) {
+        nd.top[0] = 0;
+        nd.path[0] = 0ull;
+    }
     nd.lo[0] = 0;
     nd.hi[0] = n;
     nd.parent[0] = -1;
@@ -130,8 +150,9 @@ __global__ void tb_root_kernel(TbNodes nd, int n, double Box)
 
 /* octant boundaries of every internal node of the level: bounds[9 f + s] = first sorted position whose
  * digit is >= s; packed[f] = (#children << 32) | #children with more than NMAXCHILD particles */
+template <bool DOM>
 __global__ void tb_split_kernel(int nf, const int32_t *__restrict__ frontier, TbNodes nd, const unsigned long long *__restrict__ keys,
-                                int level, int32_t *bounds, unsigned long long *packed)
+                                int level, int32_t *bounds, unsigned long long *packed, TbGeo geo)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if(f >= nf)
@@ -153,18 +174,29 @@ __global__ void tb_split_kernel(int nf, const int32_t *__restrict__ frontier, Tb
         b[s] = a;
     }
     unsigned nch = 0, nint = 0;
-    for(int s = 0; s < 8; s++) {
-        const int c = b[s + 1] - b[s];
-        nch += c > 0;
-        nint += c > SHQ_NMAXCHILD;
-    }
+    const int t = DOM ? nd.top[no] : -1;
+    if(DOM && t >= 0 && geo.kind[t].x == TOPK_INTERNAL) {
+        /* an internal top-level node has all eight daughters whether or not they hold particles (forcetree.cpp:880-915,
+         * never removed: :1040-1045); a daughter goes on when it is internal too, or a leaf of this task with a sub-tree */
+        nch = 8;
+        for(int s = 0; s < 8; s++) {
+            const int k = geo.kind[geo.child(t, s)].x;
+            nint += (k == TOPK_INTERNAL) || (k == TOPK_LOCAL && b[s + 1] - b[s] > SHQ_NMAXCHILD);
+        }
+    } else
+        for(int s = 0; s < 8; s++) {
+            const int c = b[s + 1] - b[s];
+            nch += c > 0;
+            nint += c > SHQ_NMAXCHILD;
+        }
     for(int s = 0; s < 9; s++)
         bounds[9 * f + s] = b[s];
     packed[f] = ((unsigned long long) nch << 32) | nint;
 }
 
+template <bool DOM>
 __global__ void tb_children_kernel(int nf, const int32_t *__restrict__ frontier, TbNodes nd, int level, const int32_t *__restrict__ bounds,
-                                   const unsigned long long *__restrict__ scan, int nnodes, int32_t *next_frontier, int *err)
+                                   const unsigned long long *__restrict__ scan, int nnodes, int32_t *next_frontier, int *err, TbGeo geo)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if(f >= nf)
@@ -175,15 +207,28 @@ __global__ void tb_children_kernel(int nf, const int32_t *__restrict__ frontier,
     const double4 pc = nd.cen[no];
     const int psib = nd.sibling[no];
     const double lenhalf = 0.25 * pc.w; /* init_internal_node, forcetree.cpp:302-328 */
+    const int t = DOM ? nd.top[no] : -1;
+    const bool forced = DOM && t >= 0 && geo.kind[t].x == TOPK_INTERNAL;
     int nch = 0;
     for(int s = 0; s < 8; s++)
-        nch += bounds[9 * f + s + 1] > bounds[9 * f + s];
+        nch += forced || bounds[9 * f + s + 1] > bounds[9 * f + s];
     int j = 0;
     for(int s = 0; s < 8; s++) {
         const int lo = bounds[9 * f + s], hi = bounds[9 * f + s + 1];
-        if(hi == lo)
+        if(hi == lo && !forced)
             continue;
         const int c = base + j;
+        int ckind = -1;
+        if(DOM) {
+            const int ct = forced ? geo.child(t, s) : -1;
+            nd.top[c] = ct;
+            nd.path[c] = nd.path[no] | ((unsigned long long) s << (3 * (TB_LEVELS - 1 - level)));
+            if(ct >= 0) {
+                ckind = geo.kind[ct].x;
+                if(ckind == TOPK_PSEUDO && hi > lo)
+                    *err = 3; /* a particle of this rank inside another task's top leaf: "Bad topleaf", forcetree.cpp:807-808 */
+            }
+        }
         nd.lo[c] = lo;
         nd.hi[c] = hi;
         nd.parent[c] = no;
@@ -193,7 +238,9 @@ __global__ void tb_children_kernel(int nf, const int32_t *__restrict__ frontier,
         nd.sibling[c] = (j + 1 < nch) ? c + 1 : psib; /* forcetree.cpp:968-983,1055-1061 */
         nd.cen[c] = make_double4(pc.x + ((s & 1) ? lenhalf : -lenhalf), pc.y + ((s & 2) ? lenhalf : -lenhalf),
                                  pc.z + ((s & 4) ? lenhalf : -lenhalf), 0.5 * pc.w);
-        if(hi - lo > SHQ_NMAXCHILD) {
+        const bool goes_on = DOM && ckind >= 0 ? (ckind == TOPK_INTERNAL || (ckind == TOPK_LOCAL && hi - lo > SHQ_NMAXCHILD))
+                                               : hi - lo > SHQ_NMAXCHILD;
+        if(goes_on) {
             if(level + 1 >= TB_LEVELS)
                 *err = 2; /* more than NMAXCHILD particles in one cell of the deepest level */
             else
@@ -302,6 +349,23 @@ __global__ void tb_orderkey_kernel(int nn, TbNodes nd, unsigned long long *okeys
     oval[no] = no;
 }
 
+/* domain build: empty top-level nodes share `lo` with what follows them, so the pre-order comes from the octant path: sort by
+ * level first, then (stable) by the left-aligned path — an ancestor and its first-daughter chain tie on the path and keep level order */
+__global__ void tb_levelkey_kernel(int nn, TbNodes nd, unsigned long long *okeys, int32_t *oval)
+{
+    const int no = blockIdx.x * blockDim.x + threadIdx.x;
+    if(no >= nn)
+        return;
+    okeys[no] = (unsigned long long) nd.level[no];
+    oval[no] = no;
+}
+__global__ void tb_pathkey_kernel(int nn, TbNodes nd, const int32_t *__restrict__ order, unsigned long long *okeys)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if(r < nn)
+        okeys[r] = nd.path[order[r]];
+}
+
 __global__ void tb_rank_kernel(int nn, const int32_t *__restrict__ order, int32_t *rank)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -312,7 +376,7 @@ __global__ void tb_rank_kernel(int nn, const int32_t *__restrict__ order, int32_
 /* pool records in pre-order (common.hpp); record nn is the pad the walks may touch */
 __global__ void tb_pack_kernel(int nn, const int32_t *__restrict__ order, const int32_t *__restrict__ rank, TbNodes nd,
                                const int32_t *__restrict__ idx, NodeA *A, NodeB *B, NodeC *C, NodeG *G, double *H, int32_t *pfather,
-                               double Box)
+                               double Box, TbGeo geo)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if(r > nn)
@@ -335,7 +399,12 @@ __global__ void tb_pack_kernel(int nn, const int32_t *__restrict__ order, const 
         b.center[0] = ce.x; b.center[1] = ce.y; b.center[2] = ce.z; b.len = ce.w;
         const int sib = nd.sibling[no];
         c.sibling = sib >= 0 ? rank[sib] : -1;
-        if(nd.nchild[no] == 0) {
+        const int t = geo.kind ? nd.top[no] : -1;
+        if(t >= 0 && geo.kind[t].x == TOPK_PSEUDO) { /* another task's top leaf: skipped by the local walks */
+            c.type = SHQ_PSEUDO_NODE_TYPE;
+            c.child = geo.kind[t].y;
+            c.count = 0;
+        } else if(nd.nchild[no] == 0) {
             c.type = SHQ_PARTICLE_NODE_TYPE;
             c.child = nd.lo[no];
             c.count = nd.hi[no] - nd.lo[no];
@@ -388,7 +457,7 @@ __global__ void tb_leafcopy_kernel(long long n, long long npad, const int32_t *_
 
 /* the tree in the reference's NODE format (forcetree.h:38-66), numbered in pre-order from `firstnode` */
 __global__ void tb_export_kernel(int nn, long long firstnode, const int32_t *__restrict__ order, const int32_t *__restrict__ rank,
-                                 TbNodes nd, const int32_t *__restrict__ idx, shq_node *out)
+                                 TbNodes nd, const int32_t *__restrict__ idx, shq_node *out, TbGeo geo, long long lastnode)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if(r >= nn)
@@ -419,7 +488,22 @@ __global__ void tb_export_kernel(int nn, long long firstnode, const int32_t *__r
         o.noccupied = 1 << 16; /* NODEFULL */
         o.flags = (unsigned) SHQ_NODE_NODE_TYPE << 3;
     }
-    if(par < 0)
+    if(geo.kind) {
+        const int t = nd.top[no];
+        if(t >= 0) {
+            const int k = geo.kind[t].x;
+            o.flags |= 2u; /* TopLevel */
+            if(k == TOPK_INTERNAL)
+                o.flags |= 1u; /* InternalTopLevel */
+            if(k == TOPK_PSEUDO) {
+                o.flags = ((unsigned) SHQ_PSEUDO_NODE_TYPE << 3) | 2u;
+                o.suns[0] = (int32_t) (lastnode + geo.kind[t].y); /* forcetree.cpp:905 */
+                o.noccupied = 0;
+            }
+        }
+        if(nd.hi[no] > nd.lo[no])
+            o.flags |= 4u; /* DependsOnLocalMass */
+    } else if(par < 0)
         o.flags |= 2u | 4u; /* TopLevel, DependsOnLocalMass */
     out[r] = o;
 }
@@ -453,6 +537,8 @@ int reserve_nodes(shq_context *ctx, size_t cap)
     SHQ_TRY(b.order[0].reserve(cap));
     SHQ_TRY(b.order[1].reserve(cap));
     SHQ_TRY(b.rank.reserve(cap));
+    SHQ_TRY(b.top.reserve(cap));
+    SHQ_TRY(b.path.reserve(cap));
     return SHQ_OK;
 }
 
@@ -463,6 +549,7 @@ TbNodes node_view(shq_context *ctx)
     v.lo = b.lo.ptr; v.hi = b.hi.ptr; v.parent = b.parent.ptr; v.sibling = b.sibling.ptr;
     v.firstchild = b.firstchild.ptr; v.nchild = b.nchild.ptr; v.level = b.level.ptr;
     v.cen = b.cen.ptr; v.mom = b.mom.ptr; v.hmax = b.hmax.ptr;
+    v.top = b.top.ptr; v.path = b.path.ptr;
     return v;
 }
 
@@ -566,8 +653,9 @@ int shq_build_tree_targets(shq_context *ctx)
     return SHQ_OK;
 }
 
-extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const int32_t *active, int64_t nactive,
-                              shq_tree_build_stats *stats)
+/* dom: build under a domain decomposition (geo tables already on the device) */
+static int tree_build_impl(shq_context *ctx, double BoxSize, int mask, const int32_t *active, int64_t nactive,
+                           shq_tree_build_stats *stats, const bool dom)
 {
     SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
     SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "tree_build: upload particles first");
@@ -617,6 +705,9 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
     int32_t *idx = b.idx[0].ptr;       /* particle indices in leaf order, filled once the leaves are known */
 
     /* 3. nodes, breadth first */
+    TbGeo geo = {nullptr, nullptr, nullptr};
+    if(dom)
+        geo = TbGeo{b.geo_child[0].ptr, b.geo_child[1].ptr, b.geo_kind.ptr};
     int level_start[TB_LEVELS + 2];
     int nn = 0, maxdepth = 0;
     size_t cap = (size_t) (0.6 * (double) n) + 4096;
@@ -627,18 +718,21 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
         SHQ_TRY(b.packed[0].reserve(cap + 1));
         SHQ_TRY(b.packed[1].reserve(cap + 1));
         TbNodes nd = node_view(ctx);
-        tb_root_kernel<<<1, 1, 0, st>>>(nd, (int) n, BoxSize);
+        tb_root_kernel<<<1, 1, 0, st>>>(nd, (int) n, BoxSize, dom ? 1 : 0);
         nn = 1;
         level_start[0] = 0;
         level_start[1] = 1;
         maxdepth = 0;
-        int nf = n > SHQ_NMAXCHILD ? 1 : 0, fsel = 0;
+        int nf = (n > SHQ_NMAXCHILD || (dom && ctx->dom_kind[0] == TOPK_INTERNAL)) ? 1 : 0, fsel = 0;
         if(nf)
             SHQ_HIP(hipMemsetAsync(b.frontier[0].ptr, 0, sizeof(int32_t), st)); /* frontier = {root} */
         bool overflow = false;
         for(int level = 0; nf > 0; level++) {
             SHQ_CHECK(level < TB_LEVELS, SHQ_ERR_INVALID, "tree_build: tree deeper than %d levels", TB_LEVELS);
-            tb_split_kernel<<<dim3(nblk(nf)), dim3(256), 0, st>>>(nf, b.frontier[fsel].ptr, nd, keys, level, b.bounds.ptr, b.packed[0].ptr);
+            if(dom)
+                tb_split_kernel<true><<<dim3(nblk(nf)), dim3(256), 0, st>>>(nf, b.frontier[fsel].ptr, nd, keys, level, b.bounds.ptr, b.packed[0].ptr, geo);
+            else
+                tb_split_kernel<false><<<dim3(nblk(nf)), dim3(256), 0, st>>>(nf, b.frontier[fsel].ptr, nd, keys, level, b.bounds.ptr, b.packed[0].ptr, geo);
             SHQ_HIP(hipMemsetAsync(b.packed[0].ptr + nf, 0, sizeof(unsigned long long), st));
             size_t tmp = 0;
             SHQ_HIP(rocprim::exclusive_scan(nullptr, tmp, b.packed[0].ptr, b.packed[1].ptr, 0ull, (size_t) nf + 1, rocprim::plus<unsigned long long>(), st));
@@ -652,8 +746,12 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
                 overflow = true;
                 break;
             }
-            tb_children_kernel<<<dim3(nblk(nf)), dim3(256), 0, st>>>(nf, b.frontier[fsel].ptr, nd, level, b.bounds.ptr, b.packed[1].ptr, nn,
-                                                                     b.frontier[fsel ^ 1].ptr, reinterpret_cast<int *>(b.counters.ptr + 1));
+            if(dom)
+                tb_children_kernel<true><<<dim3(nblk(nf)), dim3(256), 0, st>>>(nf, b.frontier[fsel].ptr, nd, level, b.bounds.ptr, b.packed[1].ptr, nn,
+                                                                               b.frontier[fsel ^ 1].ptr, reinterpret_cast<int *>(b.counters.ptr + 1), geo);
+            else
+                tb_children_kernel<false><<<dim3(nblk(nf)), dim3(256), 0, st>>>(nf, b.frontier[fsel].ptr, nd, level, b.bounds.ptr, b.packed[1].ptr, nn,
+                                                                                b.frontier[fsel ^ 1].ptr, reinterpret_cast<int *>(b.counters.ptr + 1), geo);
             SHQ_HIP(hipGetLastError());
             nn += nch;
             maxdepth = level + 1;
@@ -668,6 +766,7 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
     int h_err = 0;
     SHQ_HIP(hipMemcpyAsync(&h_err, b.counters.ptr + 1, sizeof(int), hipMemcpyDeviceToHost, st));
     SHQ_HIP(hipStreamSynchronize(st));
+    SHQ_CHECK(h_err != 3, SHQ_ERR_INVALID, "tree_build: a particle of this rank lies in a top leaf of another task (Bad topleaf, forcetree.cpp:807)");
     SHQ_CHECK(h_err == 0, SHQ_ERR_INVALID, "tree_build: more than %d particles closer than Box/2^%d: deeper than the device build supports",
               SHQ_NMAXCHILD, TB_LEVELS);
     TbNodes nd = node_view(ctx);
@@ -684,12 +783,24 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
     SHQ_HIP(hipGetLastError());
 
     /* 5. pre-order ranks and the walk pool */
-    {
+    if(!dom) {
         tb_orderkey_kernel<<<dim3(nblk(nn)), dim3(256), 0, st>>>(nn, nd, b.okeys[0].ptr, b.order[0].ptr);
         size_t tmp = 0;
         SHQ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, b.okeys[0].ptr, b.okeys[1].ptr, b.order[0].ptr, b.order[1].ptr, (size_t) nn, 0, 40, st));
         SHQ_TRY(b.temp.reserve(tmp + 16));
         SHQ_HIP(rocprim::radix_sort_pairs(b.temp.ptr, tmp, b.okeys[0].ptr, b.okeys[1].ptr, b.order[0].ptr, b.order[1].ptr, (size_t) nn, 0, 40, st));
+        tb_rank_kernel<<<dim3(nblk(nn)), dim3(256), 0, st>>>(nn, b.order[1].ptr, b.rank.ptr);
+    } else {
+        size_t tmp = 0, tmp2 = 0;
+        SHQ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, b.okeys[0].ptr, b.okeys[1].ptr, b.order[0].ptr, b.order[1].ptr, (size_t) nn, 0, 8, st));
+        SHQ_HIP(rocprim::radix_sort_pairs(nullptr, tmp2, b.okeys[0].ptr, b.okeys[1].ptr, b.order[0].ptr, b.order[1].ptr, (size_t) nn, 0, 64, st));
+        SHQ_TRY(b.temp.reserve(std::max(tmp, tmp2) + 16));
+        tb_levelkey_kernel<<<dim3(nblk(nn)), dim3(256), 0, st>>>(nn, nd, b.okeys[0].ptr, b.order[0].ptr);
+        SHQ_HIP(rocprim::radix_sort_pairs(b.temp.ptr, tmp, b.okeys[0].ptr, b.okeys[1].ptr, b.order[0].ptr, b.order[1].ptr, (size_t) nn, 0, 8, st));
+        tb_pathkey_kernel<<<dim3(nblk(nn)), dim3(256), 0, st>>>(nn, nd, b.order[1].ptr, b.okeys[0].ptr);
+        SHQ_HIP(rocprim::radix_sort_pairs(b.temp.ptr, tmp2, b.okeys[0].ptr, b.okeys[1].ptr, b.order[1].ptr, b.order[0].ptr, (size_t) nn, 0, 64, st));
+        /* the pre-order is in order[0]; the rest of the file reads order[1] */
+        SHQ_HIP(hipMemcpyAsync(b.order[1].ptr, b.order[0].ptr, sizeof(int32_t) * (size_t) nn, hipMemcpyDeviceToDevice, st));
         tb_rank_kernel<<<dim3(nblk(nn)), dim3(256), 0, st>>>(nn, b.order[1].ptr, b.rank.ptr);
     }
     SHQ_TRY(ctx->nodeA.reserve((size_t) nn + 1));
@@ -700,7 +811,7 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
     SHQ_TRY(ctx->pfather.reserve((size_t) (np > 0 ? np : 1)));
     SHQ_HIP(hipMemsetAsync(ctx->pfather.ptr, 0xff, sizeof(int32_t) * (size_t) (np > 0 ? np : 1), st));
     tb_pack_kernel<<<dim3(nblk(nn + 1)), dim3(256), 0, st>>>(nn, b.order[1].ptr, b.rank.ptr, nd, idx, ctx->nodeA.ptr, ctx->nodeB.ptr,
-                                                              ctx->nodeC.ptr, ctx->nodeG.ptr, ctx->node_hmax.ptr, ctx->pfather.ptr, BoxSize);
+                                                              ctx->nodeC.ptr, ctx->nodeG.ptr, ctx->node_hmax.ptr, ctx->pfather.ptr, BoxSize, geo);
     const long long npad = n + SHQ_NMAXCHILD;
     SHQ_TRY(ctx->posm_leaf.reserve((size_t) npad));
     SHQ_TRY(ctx->leaf_pidx.reserve((size_t) npad));
@@ -723,6 +834,8 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
     ctx->have_group_aux = false;
     ctx->have_father = true;
     ctx->tb_built = true;
+    ctx->tb_domain = dom;
+    ctx->have_toptree = false;
     if(stats) {
         stats->nparticles = n;
         stats->numnodes = nn;
@@ -731,6 +844,276 @@ extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const 
         (void) hipEventElapsedTime(&ms, ctx->ev_begin[16], ctx->ev_end[16]);
         stats->build_ms = ms;
     }
+    return SHQ_OK;
+}
+
+extern "C" int shq_tree_build(shq_context *ctx, double BoxSize, int mask, const int32_t *active, int64_t nactive,
+                              shq_tree_build_stats *stats)
+{
+    return tree_build_impl(ctx, BoxSize, mask, active, nactive, stats, false);
+}
+
+namespace {
+
+/* per TopNode: rec[9 t ...] = cofm[3], mass, hmax, center[3], len; rank[t] = pre-order number */
+__global__ void tb_topgather_kernel(int nn, TbNodes nd, const int32_t *__restrict__ rank, double *rec, int32_t *toprank)
+{
+    const int no = blockIdx.x * blockDim.x + threadIdx.x;
+    if(no >= nn)
+        return;
+    const int t = nd.top[no];
+    if(t < 0)
+        return;
+    const double4 m = nd.mom[no], c = nd.cen[no];
+    double *o = rec + 9 * (size_t) t;
+    o[0] = m.x; o[1] = m.y; o[2] = m.z; o[3] = m.w; o[4] = nd.hmax[no];
+    o[5] = c.x; o[6] = c.y; o[7] = c.z; o[8] = c.w;
+    toprank[t] = rank[no];
+}
+
+/* moments of the top-level nodes after the exchange: into the build arrays (for a later download) and the walk pool */
+__global__ void tb_topscatter_kernel(int nn, TbNodes nd, const int32_t *__restrict__ rank, const double *__restrict__ rec, NodeA *A, NodeG *G, double *H)
+{
+    const int no = blockIdx.x * blockDim.x + threadIdx.x;
+    if(no >= nn)
+        return;
+    const int t = nd.top[no];
+    if(t < 0)
+        return;
+    const double *o = rec + 9 * (size_t) t;
+    nd.mom[no] = make_double4(o[0], o[1], o[2], o[3]);
+    nd.hmax[no] = o[4];
+    const int r = rank[no];
+    NodeA a = A[r];
+    a.cofm[0] = o[0]; a.cofm[1] = o[1]; a.cofm[2] = o[2]; a.mass = o[3];
+    A[r] = a;
+    NodeG g = G[r];
+    g.cofm[0] = o[0]; g.cofm[1] = o[1]; g.cofm[2] = o[2]; g.mass = o[3];
+    g.mlen2 = g.mass * g.len * g.len;
+    G[r] = g;
+    H[r] = o[4];
+}
+
+} // namespace
+
+extern "C" int shq_tree_build_domain(shq_context *ctx, double BoxSize, int mask, const int32_t *active, int64_t nactive,
+                                     const shq_topnode_geo *topnodes, int ntopnodes, shq_topleaf *topleaves, int ntopleaves, int ThisTask,
+                                     int64_t firstnode, shq_topleaf_moments *local_moments, shq_tree_build_stats *stats)
+{
+    SHQ_CHECK(ctx && topnodes && topleaves, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ntopnodes >= 1 && ntopleaves >= 1, SHQ_ERR_INVALID, "tree_build_domain: empty top tree");
+    SHQ_CHECK(ctx->have_parts && firstnode >= ctx->numpart, SHQ_ERR_INVALID, "tree_build_domain: upload particles first; firstnode must be >= NumPart");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    /* validate the table: every daughter in range, every leaf index in range and used once, reached once from the root */
+    std::vector<int32_t> kind((size_t) ntopnodes, -1), seen((size_t) ntopnodes, 0), leafseen((size_t) ntopleaves, 0);
+    std::vector<int4> c0((size_t) ntopnodes), c1((size_t) ntopnodes);
+    std::vector<int2> kk((size_t) ntopnodes);
+    {
+        std::vector<int32_t> stack(1, 0);
+        while(!stack.empty()) {
+            const int32_t t = stack.back();
+            stack.pop_back();
+            SHQ_CHECK(t >= 0 && t < ntopnodes, SHQ_ERR_INVALID, "tree_build_domain: daughter %d outside the TopNodes table", t);
+            SHQ_CHECK(!seen[t], SHQ_ERR_INVALID, "tree_build_domain: TopNode %d is reached twice", t);
+            seen[t] = 1;
+            const shq_topnode_geo &g = topnodes[t];
+            const bool leaf = g.daughter[0] < 0;
+            if(leaf) {
+                for(int s = 0; s < 8; s++)
+                    SHQ_CHECK(g.daughter[s] < 0, SHQ_ERR_INVALID, "tree_build_domain: TopNode %d has some daughters only", t);
+                SHQ_CHECK(g.leaf >= 0 && g.leaf < ntopleaves && !leafseen[g.leaf], SHQ_ERR_INVALID, "tree_build_domain: bad leaf index %d of TopNode %d", g.leaf, t);
+                leafseen[g.leaf] = 1;
+                kind[t] = topleaves[g.leaf].Task == ThisTask ? TOPK_LOCAL : TOPK_PSEUDO;
+            } else {
+                kind[t] = TOPK_INTERNAL;
+                for(int s = 7; s >= 0; s--)
+                    stack.push_back(g.daughter[s]);
+            }
+            c0[t] = make_int4(g.daughter[0], g.daughter[1], g.daughter[2], g.daughter[3]);
+            c1[t] = make_int4(g.daughter[4], g.daughter[5], g.daughter[6], g.daughter[7]);
+            kk[t] = make_int2(kind[t], leaf ? g.leaf : -1);
+        }
+    }
+    for(int t = 0; t < ntopnodes; t++)
+        SHQ_CHECK(seen[t], SHQ_ERR_INVALID, "tree_build_domain: TopNode %d is not reachable from the root", t);
+    for(int l = 0; l < ntopleaves; l++)
+        SHQ_CHECK(leafseen[l], SHQ_ERR_INVALID, "tree_build_domain: top leaf %d belongs to no TopNode", l);
+    TreeBuildBufs &b = ctx->tb;
+    SHQ_TRY(b.geo_child[0].reserve((size_t) ntopnodes));
+    SHQ_TRY(b.geo_child[1].reserve((size_t) ntopnodes));
+    SHQ_TRY(b.geo_kind.reserve((size_t) ntopnodes));
+    SHQ_HIP(hipMemcpy(b.geo_child[0].ptr, c0.data(), sizeof(int4) * (size_t) ntopnodes, hipMemcpyHostToDevice));
+    SHQ_HIP(hipMemcpy(b.geo_child[1].ptr, c1.data(), sizeof(int4) * (size_t) ntopnodes, hipMemcpyHostToDevice));
+    SHQ_HIP(hipMemcpy(b.geo_kind.ptr, kk.data(), sizeof(int2) * (size_t) ntopnodes, hipMemcpyHostToDevice));
+    ctx->dom_geo.assign(topnodes, topnodes + ntopnodes);
+    ctx->dom_kind = kind;
+    ctx->dom_thistask = ThisTask;
+    ctx->dom_leaf_task.resize((size_t) ntopleaves);
+    for(int l = 0; l < ntopleaves; l++)
+        ctx->dom_leaf_task[l] = topleaves[l].Task;
+    SHQ_TRY(tree_build_impl(ctx, BoxSize, mask, active, nactive, stats, true));
+
+    /* the top-level nodes back to the host: numbers for TopLeaves[].treenode, moments of this task's leaves */
+    const int nn = (int) ctx->numnodes;
+    SHQ_TRY(b.topbuf.reserve(9 * (size_t) ntopnodes + (size_t) ntopnodes));
+    double *d_rec = b.topbuf.ptr;
+    int32_t *d_rank = reinterpret_cast<int32_t *>(b.topbuf.ptr + 9 * (size_t) ntopnodes);
+    SHQ_HIP(hipMemsetAsync(d_rank, 0xff, sizeof(int32_t) * (size_t) ntopnodes, ctx->stream));
+    tb_topgather_kernel<<<dim3(nblk(nn)), dim3(256), 0, ctx->stream>>>(nn, node_view(ctx), b.rank.ptr, d_rec, d_rank);
+    SHQ_HIP(hipGetLastError());
+    ctx->dom_rec.resize(9 * (size_t) ntopnodes);
+    ctx->dom_rank.resize((size_t) ntopnodes);
+    SHQ_HIP(hipMemcpyAsync(ctx->dom_rec.data(), d_rec, sizeof(double) * 9 * (size_t) ntopnodes, hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipMemcpyAsync(ctx->dom_rank.data(), d_rank, sizeof(int32_t) * (size_t) ntopnodes, hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    bool remote = false;
+    for(int t = 0; t < ntopnodes; t++) {
+        SHQ_CHECK(ctx->dom_rank[t] >= 0, SHQ_ERR_DEVICE, "tree_build_domain: TopNode %d has no tree node", t);
+        if(kind[t] == TOPK_INTERNAL)
+            continue;
+        const int l = topnodes[t].leaf;
+        topleaves[l].treenode = (int32_t) (firstnode + ctx->dom_rank[t]);
+        if(local_moments) {
+            shq_topleaf_moments m = {{0, 0, 0}, 0, 0};
+            if(kind[t] == TOPK_LOCAL) {
+                const double *o = &ctx->dom_rec[9 * (size_t) t];
+                m.s[0] = o[0]; m.s[1] = o[1]; m.s[2] = o[2]; m.mass = o[3]; m.hmax = o[4];
+            }
+            local_moments[l] = m;
+        }
+        remote = remote || kind[t] == TOPK_PSEUDO;
+    }
+    ctx->firstnode = firstnode;
+    if(!remote) { /* a one-task domain: nothing to exchange, the top tree can be installed now */
+        std::vector<shq_topleaf_moments> own((size_t) ntopleaves);
+        for(int t = 0; t < ntopnodes; t++)
+            if(kind[t] != TOPK_INTERNAL) {
+                const double *o = &ctx->dom_rec[9 * (size_t) t];
+                own[topnodes[t].leaf] = shq_topleaf_moments{{o[0], o[1], o[2]}, o[3], o[4]};
+            }
+        SHQ_TRY(shq_tree_set_topleaf_moments(ctx, own.data(), ntopleaves));
+    }
+    return SHQ_OK;
+}
+
+extern "C" int shq_tree_set_topleaf_moments(shq_context *ctx, const shq_topleaf_moments *moments, int ntopleaves)
+{
+    SHQ_CHECK(ctx && moments, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_tree && ctx->tb_built && ctx->tb_domain, SHQ_ERR_STATE, "set_topleaf_moments: no tree from shq_tree_build_domain");
+    SHQ_CHECK(ntopleaves == (int) ctx->dom_leaf_task.size(), SHQ_ERR_INVALID, "set_topleaf_moments: %d leaves, the domain has %zu", ntopleaves,
+              ctx->dom_leaf_task.size());
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int ntop = (int) ctx->dom_geo.size();
+    std::vector<double> &rec = ctx->dom_rec;
+    /* force_exchange_pseudodata, forcetree.cpp:1186-1198: the other tasks' leaves take the gathered values */
+    for(int t = 0; t < ntop; t++)
+        if(ctx->dom_kind[t] == TOPK_PSEUDO) {
+            const shq_topleaf_moments &m = moments[ctx->dom_geo[t].leaf];
+            double *o = &rec[9 * (size_t) t];
+            o[0] = m.s[0]; o[1] = m.s[1]; o[2] = m.s[2]; o[3] = m.mass; o[4] = m.hmax;
+        }
+    /* force_treeupdate_pseudos, forcetree.cpp:1211-1281: post-order over the internal top-level nodes, eight daughters in order */
+    {
+        std::vector<int32_t> stack(1, 0), post;
+        while(!stack.empty()) {
+            const int32_t t = stack.back();
+            stack.pop_back();
+            if(ctx->dom_kind[t] != TOPK_INTERNAL)
+                continue;
+            post.push_back(t);
+            for(int s = 0; s < 8; s++)
+                stack.push_back(ctx->dom_geo[t].daughter[s]);
+        }
+        for(size_t k = post.size(); k-- > 0;) { /* reverse pre-order: daughters before their parent */
+            const int32_t t = post[k];
+            double mass = 0, c0 = 0, c1 = 0, c2 = 0, hmax = 0;
+            for(int s = 0; s < 8; s++) {
+                const double *p = &rec[9 * (size_t) ctx->dom_geo[t].daughter[s]];
+                mass += p[3];
+                c0 += p[3] * p[0];
+                c1 += p[3] * p[1];
+                c2 += p[3] * p[2];
+                if(p[4] > hmax)
+                    hmax = p[4];
+            }
+            double *o = &rec[9 * (size_t) t];
+            if(mass) {
+                c0 /= mass;
+                c1 /= mass;
+                c2 /= mass;
+            } else {
+                c0 = o[5];
+                c1 = o[6];
+                c2 = o[7];
+            }
+            o[0] = c0; o[1] = c1; o[2] = c2; o[3] = mass; o[4] = hmax;
+        }
+    }
+    TreeBuildBufs &b = ctx->tb;
+    const int nn = (int) ctx->numnodes;
+    SHQ_TRY(b.topbuf.reserve(9 * (size_t) ntop + (size_t) ntop));
+    SHQ_HIP(hipMemcpyAsync(b.topbuf.ptr, rec.data(), sizeof(double) * 9 * (size_t) ntop, hipMemcpyHostToDevice, ctx->stream));
+    tb_topscatter_kernel<<<dim3(nblk(nn)), dim3(256), 0, ctx->stream>>>(nn, node_view(ctx), b.rank.ptr, b.topbuf.ptr, ctx->nodeA.ptr, ctx->nodeG.ptr,
+                                                                        ctx->node_hmax.ptr);
+    SHQ_HIP(hipGetLastError());
+    ctx->node_rcut = -1; /* per-walk node fields are refilled */
+    ctx->have_group_aux = false;
+    /* the top tree for the export-detection walks (what shq_toptree_upload assembles from a host tree): pre-order over TopNodes */
+    std::vector<TopNodeG> h;
+    std::vector<int32_t> where((size_t) ntop, -1), sibling_of((size_t) ntop, -1);
+    {
+        struct Item { int32_t t, sib; };
+        std::vector<Item> stack(1, Item{0, -1});
+        std::vector<int32_t> order;
+        while(!stack.empty()) {
+            const Item it = stack.back();
+            stack.pop_back();
+            where[it.t] = (int32_t) order.size();
+            sibling_of[it.t] = it.sib;
+            order.push_back(it.t);
+            if(ctx->dom_kind[it.t] == TOPK_INTERNAL)
+                for(int s = 7; s >= 0; s--)
+                    stack.push_back(Item{ctx->dom_geo[it.t].daughter[s], s < 7 ? ctx->dom_geo[it.t].daughter[s + 1] : it.sib});
+        }
+        h.resize(order.size());
+        for(size_t j = 0; j < order.size(); j++) {
+            const int32_t t = order[j];
+            const double *o = &rec[9 * (size_t) t];
+            TopNodeG g;
+            memset(&g, 0, sizeof(g));
+            for(int k = 0; k < 3; k++) {
+                g.cofm[k] = o[k];
+                g.center[k] = o[5 + k];
+            }
+            g.mass = o[3];
+            g.hmax = o[4];
+            g.len = o[8];
+            g.sibling = sibling_of[t] >= 0 ? where[sibling_of[t]] : -1; /* a later node: filled below */
+            g.child = -1;
+            g.leaf = -1;
+            g.kind = ctx->dom_kind[t] == TOPK_INTERNAL ? 0 : (ctx->dom_kind[t] == TOPK_LOCAL ? 1 : 2);
+            if(ctx->dom_kind[t] == TOPK_PSEUDO)
+                g.leaf = ctx->dom_geo[t].leaf;
+            h[j] = g;
+        }
+        for(size_t j = 0; j < order.size(); j++) { /* links to nodes later in the pre-order */
+            const int32_t t = order[j];
+            h[j].sibling = sibling_of[t] >= 0 ? where[sibling_of[t]] : -1;
+            if(ctx->dom_kind[t] == TOPK_INTERNAL)
+                h[j].child = where[ctx->dom_geo[t].daughter[0]];
+        }
+    }
+    std::vector<int2> hl((size_t) ntopleaves);
+    for(int t = 0; t < ntop; t++)
+        if(ctx->dom_kind[t] != TOPK_INTERNAL)
+            hl[ctx->dom_geo[t].leaf] = make_int2(ctx->dom_leaf_task[ctx->dom_geo[t].leaf], (int32_t) (ctx->firstnode + ctx->dom_rank[t]));
+    SHQ_TRY(ctx->topnodes.reserve(h.size()));
+    SHQ_TRY(ctx->topleaves.reserve(hl.size()));
+    SHQ_HIP(hipMemcpyAsync(ctx->topnodes.ptr, h.data(), sizeof(TopNodeG) * h.size(), hipMemcpyHostToDevice, ctx->stream));
+    SHQ_HIP(hipMemcpyAsync(ctx->topleaves.ptr, hl.data(), sizeof(int2) * hl.size(), hipMemcpyHostToDevice, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->ntopnodes = (int64_t) h.size();
+    ctx->have_toptree = true;
     return SHQ_OK;
 }
 
@@ -749,7 +1132,11 @@ extern "C" int shq_tree_download(shq_context *ctx, int64_t firstnode, shq_node *
         SHQ_CHECK(capacity >= nn, SHQ_ERR_INVALID, "tree_download: capacity %ld < %d nodes", (long) capacity, nn);
         SHQ_CHECK(firstnode >= ctx->numpart && firstnode + nn < (1ll << 31), SHQ_ERR_INVALID, "tree_download: firstnode %ld must be >= NumPart and fit int32", (long) firstnode);
         SHQ_TRY(b.exportbuf.reserve((size_t) nn));
-        tb_export_kernel<<<dim3(nblk(nn)), dim3(256), 0, st>>>(nn, firstnode, b.order[1].ptr, b.rank.ptr, node_view(ctx), b.idx[0].ptr, b.exportbuf.ptr);
+        TbGeo geo = {nullptr, nullptr, nullptr};
+        if(ctx->tb_domain)
+            geo = TbGeo{b.geo_child[0].ptr, b.geo_child[1].ptr, b.geo_kind.ptr};
+        tb_export_kernel<<<dim3(nblk(nn)), dim3(256), 0, st>>>(nn, firstnode, b.order[1].ptr, b.rank.ptr, node_view(ctx), b.idx[0].ptr, b.exportbuf.ptr,
+                                                               geo, firstnode + capacity);
         SHQ_HIP(hipGetLastError());
         SHQ_HIP(hipMemcpyAsync(nodes, b.exportbuf.ptr, sizeof(shq_node) * (size_t) nn, hipMemcpyDeviceToHost, st));
     }

@@ -181,3 +181,55 @@ def make_domain(tree, ntask=3, me=1, depth=2, pseudo=True):
             nodes["flags"][no - fn] = (f & ~(3 << 3)) | (2 << 3)
             nodes["suns"][no - fn, 0] = ln + k
     return tl
+
+
+def make_topnodes(rng, ntask, maxdepth=3, psplit=0.6, shuffle=True):
+    """A top tree as a domain decomposition would hand it over (struct topnode_data, domain.h:12-18, reduced to geometry):
+    TopNodes refined at random down to `maxdepth`, the root always; the eight daughters of a node are consecutive table
+    entries (Daughter + sub) in a shuffled octant assignment, as the Peano-Hilbert numbering of the reference shuffles them;
+    top leaves numbered in table order and dealt to `ntask` tasks in contiguous runs (Tasks[].StartLeaf / EndLeaf).
+    Returns (geo: capi.TOPNODE_GEO_DTYPE, topleaves: capi.TOPLEAF_DTYPE)."""
+    from shenqi_amd import capi
+    nodes = [dict(d=[-1] * 8, leaf=-1, depth=0)]
+    queue = [0]
+    while queue:
+        t = queue.pop(0)
+        nd = nodes[t]
+        if nd["depth"] == 0 or (nd["depth"] < maxdepth and rng.random() < psplit):
+            base = len(nodes)
+            perm = rng.permutation(8) if shuffle else np.arange(8)
+            for s in range(8):
+                nodes.append(dict(d=[-1] * 8, leaf=-1, depth=nd["depth"] + 1))
+            for octant in range(8):
+                nd["d"][octant] = base + int(perm[octant])
+            queue.extend(range(base, base + 8))
+    nleaf = 0
+    for nd in nodes:
+        if nd["d"][0] < 0:
+            nd["leaf"] = nleaf
+            nleaf += 1
+    geo = np.zeros(len(nodes), dtype=capi.TOPNODE_GEO_DTYPE)
+    for t, nd in enumerate(nodes):
+        geo["daughter"][t] = nd["d"]
+        geo["leaf"][t] = nd["leaf"]
+    tl = np.zeros(nleaf, dtype=capi.TOPLEAF_DTYPE)
+    tl["Task"] = (np.arange(nleaf) * ntask) // nleaf
+    tl["topnode"] = [t for t, nd in enumerate(nodes) if nd["d"][0] < 0]
+    tl["treenode"] = -1
+    return geo, tl
+
+
+def topleaf_of(pos, geo, box):
+    """the top leaf every position falls in: descent from the root cell (centre Box/2, len 1.001 Box) by `pos > centre`, child
+    centres centre +- len/4 (get_subnode / init_internal_node, forcetree.cpp:277-328)"""
+    out = np.empty(len(pos), dtype=np.int32)
+    for i, p in enumerate(pos):
+        t, c, ln = 0, [box / 2.0] * 3, box * 1.001
+        while geo["daughter"][t][0] >= 0:
+            s = int(p[0] > c[0]) + (int(p[1] > c[1]) << 1) + (int(p[2] > c[2]) << 2)
+            lh = 0.25 * ln
+            c = [c[j] + (lh if (s >> j) & 1 else -lh) for j in range(3)]
+            ln = 0.5 * ln
+            t = int(geo["daughter"][t][s])
+        out[i] = geo["leaf"][t]
+    return out

@@ -1,0 +1,178 @@
+"""GPU parity tests of the device tree build under a domain decomposition (shq_tree_build_domain / shq_tree_set_topleaf_moments,
+csrc/tree_build.hip) against the restatement of forcetree.cpp:651-930, 1016-1281 in oracle/toptree_build.py: every rank's tree
+node for node (geometry, types, flags, links, particle lists, moments to the bit), the moments each rank contributes to the
+all-gather, and the trees after the gathered moments went into the pseudo nodes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import shenqi_amd as sq
+from shenqi_amd import capi
+import common as cm
+import orc
+import toptree_build_checks as chk
+from toptree_build_checks import tb
+
+pytestmark = pytest.mark.gpu
+
+
+def _particles(rng, n):
+    pos = np.concatenate([rng.random((n // 2, 3)), (0.3 + 0.03 * rng.normal(size=(n - n // 2, 3))) % 1.0]) * cm.BOX
+    ptype = rng.choice([0, 1, 5], size=n, p=[0.3, 0.65, 0.05]).astype(np.uint8)
+    mass = rng.choice([1.0, 0.25, 3.0], size=n)
+    hsml = 0.02 * cm.BOX * (1 + rng.random(n))
+    return pos, ptype, mass, hsml
+
+
+def _rank_build(ctx, pos, ptype, mass, hsml, mine, geo, tl, me, firstnode_pad=7):
+    """one rank: its particles (local numbering = order of `mine`), device build and oracle build.  Returns everything the
+    comparisons need."""
+    lp = np.ascontiguousarray(pos[mine])
+    pman = cm.make_partmanager(lp)
+    P = pman.Base
+    P["Type"], P["Mass"], P["Hsml"] = ptype[mine], mass[mine], hsml[mine]
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    sq.dynamics_upload(ctx, pman)                        # Hsml on the device: hmax of gas / BH
+    firstnode = len(mine) + firstnode_pad
+    tl_dev = tl.copy()
+    st, mom = sq.tree_build_domain(ctx, cm.BOX, geo, tl_dev, me, firstnode)
+    nodes, father = sq.tree_download(ctx, firstnode, numpart=len(mine))
+    lastnode_dev = firstnode + len(nodes)
+    hs = [float(h) if t in (0, 5) else None for h, t in zip(P["Hsml"], P["Type"])]
+    lastnode_orc = firstnode + 20 * len(mine) + 10 * len(geo)
+    t, ltn, omom = tb.build([[float(x) for x in p] for p in lp], [float(m) for m in P["Mass"]], hs, range(len(mine)), chk.geo_list(geo),
+                            [int(x) for x in tl["Task"]], me, cm.BOX, firstnode, lastnode_orc)
+    return dict(pman=pman, nodes=nodes, father=father, firstnode=firstnode, lastnode_dev=lastnode_dev, lastnode_orc=lastnode_orc, tl=tl_dev, mom=mom,
+                t=t, ltn=ltn, omom=omom, st=st)
+
+
+@pytest.mark.parametrize("seed,ntask,maxdepth", [(1, 3, 2), (2, 4, 3), (3, 2, 1)])
+def test_domain_tree_equals_reference_build(ctx, seed, ntask, maxdepth):
+    rng = np.random.default_rng(seed)
+    n = 6000
+    pos, ptype, mass, hsml = _particles(rng, n)
+    geo, tl = cm.make_topnodes(rng, ntask, maxdepth=maxdepth)
+    leaf = cm.topleaf_of(pos, geo, cm.BOX)
+    owner = tl["Task"][leaf]
+    nleaves = len(tl)
+    ranks = []
+    gathered = np.zeros(nleaves, dtype=capi.TOPLEAF_MOMENTS_DTYPE)
+    ogather = [None] * nleaves
+    for me in range(ntask):
+        mine = np.flatnonzero(owner == me)
+        r = _rank_build(ctx, pos, ptype, mass, hsml, mine, geo, tl, me)
+        # the local half: every node but the internal top-level ones and the pseudo leaves has its final moments
+        number = chk.compare(r["nodes"], r["firstnode"], r["lastnode_dev"], r["t"], r["lastnode_orc"], moments=False)
+        for k, (no, nd) in enumerate(tb.preorder(r["t"])):
+            if not nd.InternalTopLevel and nd.ChildType != tb.PSEUDO:
+                g = r["nodes"][k]
+                assert g["mass"] == nd.mass and tuple(g["cofm"]) == tuple(nd.cofm) and g["hmax"] == nd.hmax, (me, k)
+        # TopLeaves[].treenode and the Father array
+        for l in range(nleaves):
+            assert r["tl"]["treenode"][l] == number[r["ltn"][l]], (me, l)
+        ofather = {}
+        for no, nd in tb.preorder(r["t"]):
+            if nd.ChildType == tb.PARTICLE:
+                for p in nd.suns[:nd.nocc]:
+                    ofather[p] = number[no]
+        assert all(r["father"][p] == ofather[p] for p in range(len(mine)))
+        # this rank's contribution to force_exchange_pseudodata
+        for l in range(nleaves):
+            s, m, h = r["omom"][l]
+            assert tuple(r["mom"]["s"][l]) == tuple(s) and r["mom"]["mass"][l] == m and r["mom"]["hmax"][l] == h, (me, l)
+            if tl["Task"][l] == me:
+                gathered[l] = r["mom"][l]
+                ogather[l] = r["omom"][l]
+        assert r["st"].nparticles == len(mine)
+        ranks.append((me, mine))
+    assert all(x is not None for x in ogather)
+    # after the all-gather: pseudo nodes and internal top-level nodes
+    for me, mine in ranks:
+        r = _rank_build(ctx, pos, ptype, mass, hsml, mine, geo, tl, me)
+        sq.tree_set_topleaf_moments(ctx, gathered)
+        nodes, _ = sq.tree_download(ctx, r["firstnode"])
+        tb.finish(r["t"], r["ltn"], [int(x) for x in tl["Task"]], me, ogather)
+        chk.compare(nodes, r["firstnode"], r["lastnode_dev"], r["t"], r["lastnode_orc"], moments=True)
+        root = nodes[0]
+        assert abs(root["mass"] - mass.sum()) < 1e-9 * mass.sum()         # every rank's root carries the whole box
+
+
+def test_domain_tree_rejects_foreign_particle_and_bad_tables(ctx):
+    rng = np.random.default_rng(5)
+    pos, ptype, mass, hsml = _particles(rng, 500)
+    geo, tl = cm.make_topnodes(rng, 2, maxdepth=1)
+    pman = cm.make_partmanager(pos)
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    with pytest.raises(sq.ShqError, match="Bad topleaf"):
+        sq.tree_build_domain(ctx, cm.BOX, geo, tl.copy(), 0, len(pos))
+    bad = geo.copy()
+    bad["daughter"][0][3] = bad["daughter"][0][2]                       # a TopNode reached twice
+    with pytest.raises(sq.ShqError):
+        sq.tree_build_domain(ctx, cm.BOX, bad, tl.copy(), 0, len(pos))
+    bad = geo.copy()
+    bad["leaf"][1] = len(tl) + 3
+    with pytest.raises(sq.ShqError):
+        sq.tree_build_domain(ctx, cm.BOX, bad, tl.copy(), 0, len(pos))
+
+
+def test_domain_tree_walks_and_exports_like_the_uploaded_tree(ctx):
+    """the device-built domain tree through the walk and the export detection: same accelerations and interaction counts, and
+    the same export table, as the same tree downloaded and uploaded again the round-1 way (shq_tree_upload + shq_toptree_upload)"""
+    rng = np.random.default_rng(7)
+    n = 20 ** 3
+    pos = sq.synth_positions("cluster", n, L=cm.BOX)
+    geo, tl = cm.make_topnodes(rng, 3, maxdepth=2)
+    owner = tl["Task"][cm.topleaf_of(pos, geo, cm.BOX)]
+    me = 1
+    mine = np.flatnonzero(owner == me)
+    assert 100 < len(mine) < n
+    lp = np.ascontiguousarray(pos[mine])
+    pman = cm.make_partmanager(lp)
+    pv = pman.view()
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=1)
+    sq.gravshort_set_softenings(cm.BOX / 20)
+    gp = sq.make_grav_params(cm.BOX, 1.5, 60, cm.G, cm.RHO0)
+    # moments of the other ranks' leaves: from a build of all particles on a one-task domain of the same top tree
+    allp = cm.make_partmanager(pos)
+    apv = allp.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(apv)))
+    tl_all = tl.copy()
+    tl_all["Task"] = 0
+    _, mom_all = sq.tree_build_domain(ctx, cm.BOX, geo, tl_all, 0, n)
+
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    firstnode = len(mine)
+    tld = tl.copy()
+    _, mom = sq.tree_build_domain(ctx, cm.BOX, geo, tld, me, firstnode)
+    gathered = mom_all.copy()
+    gathered[tl["Task"] == me] = mom[tl["Task"] == me]
+    sq.tree_set_topleaf_moments(ctx, gathered)
+    capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, cm.G))
+    capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, sq.WALK_EXACT))
+    m = len(mine)
+    acc, pot, nint = np.zeros((m, 3)), np.zeros(m), np.zeros(m, dtype=np.int64)
+    st = sq.WalkStats()
+    capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), capi.ptr(pot), capi.ptr(nint), C.byref(st)))
+    cap = 8 * m
+    counts = np.zeros(m, dtype=np.int32)
+    table = np.zeros(cap, dtype=capi.DATA_INDEX_DTYPE)
+    nexp = C.c_int64()
+    capi.check(capi.hip.shq_grav_toptree_exports(ctx.h, C.byref(gp), None, 0, capi.ptr(counts), capi.ptr(table), cap, C.byref(nexp)))
+    nodes, _ = sq.tree_download(ctx, firstnode)
+    lastnode = firstnode + len(nodes)
+    # the oracle on the downloaded tree: local walk (pseudo nodes skipped) and export detection
+    oldacc = np.zeros(m)
+    oacc, opot, onint = orc.grav_walk(nodes, firstnode, lp, pman.Base["Mass"], oldacc, gp)
+    orc.grav_postprocess(pman.Base["Mass"], gp, oacc, opot, True)
+    assert np.array_equal(nint, onint)
+    assert np.abs(acc - oacc).max() < 1e-11 * np.abs(oacc).max()
+    ocounts, otable = orc.grav_toptree(nodes, firstnode, lastnode, tld, lp, oldacc, gp)
+    assert nexp.value == len(otable) > 0
+    assert np.array_equal(counts, np.cumsum(ocounts))
+    got = table[:nexp.value]
+    for f in ("Task", "Index"):
+        assert np.array_equal(got[f], otable[f]), f
+    assert np.array_equal(got["NodeList"], otable["NodeList"])
