@@ -408,6 +408,52 @@ int shq_timebins_download(shq_context *ctx, uint8_t *bin_gravity, uint8_t *bin_h
  * run of this context (NULL keeps it; gas particles only are read). */
 int shq_maxsignalvel_upload(shq_context *ctx, const double *maxsignalvel_by_particle);
 
+/* Friends-of-friends groups of the resident particles (the first legacy-API user: libgadget/fof.cpp, one task).
+ *   fof_label_primary (:368-581): particles of the primary types within LinkingLength of each other (r2 <= L^2, the neighbour
+ *       test of treewalk_visit_ngbiter, treewalk.c:946-961) are one group; the reference's lock-free union-find (fofp_merge,
+ *       update_root) ends in the connected components labelled with their smallest particle ID, and so does this one
+ *       (atomicCAS hooking of the larger root under the smaller, path halving, one pass over a tree of the primary types);
+ *   fof_label_secondary (:1142-1270): every particle of the secondary types takes the label of the nearest primary particle within
+ *       a search radius that starts at max(0.4 L, 0.5 Hsml) (float) and doubles while it is below 4 L; ties go to the particle met
+ *       first in the tree's depth-first order, as in the reference's nolist walk;
+ *   fof_fof / fof_compile_base / fof_assign_grnr / add_particle_to_group / fof_finish_group_properties (:159-256, 583-766, 1048-1096):
+ *       particles sorted by label, groups shorter than HaloMinLength dropped, GrNr = 1.. by decreasing length then MinID,
+ *       Length / LenType / MassType / Mass / CM / Vel / Imom / Jmom / MaxDens + seed_index per group, groups ordered by MinID.
+ * The reference's sort of the labels is not stable, so which member is FirstPos and the order of a group's sums are unspecified
+ * there; here the member with the lowest particle index comes first and sums run in index order (one thread per group: deterministic).
+ * The slot-resident sums (Sfr, metal masses, BH_Mass / BH_Mdot) stay with the caller: shq_fof_members hands it every group's member
+ * list.  Several tasks (ghost labels through the export walk, fof_reduce_groups) are not covered.
+ * shq_fof rebuilds the context's tree over the primary types (force_tree_rebuild_mask(&dmtree, ..., FOFPrimaryLinkTypes)).
+ * ids: Part[].ID by particle index (host).  minid_by_particle / grnr_by_particle (host, may be NULL): HaloLabel[].MinID and Part[].GrNr
+ * (-1 outside groups).  WindsDecoupleSph: winds_is_particle_decoupled applies (DelayTime > 0 gas never seeds). */
+typedef struct shq_fof_params {
+    double BoxSize;
+    double LinkingLength;       /* FOFHaloComovingLinkingLength */
+    int32_t PrimaryLinkTypes, SecondaryLinkTypes;   /* type masks */
+    int32_t HaloMinLength;
+    int32_t WindsDecoupleSph;
+} shq_fof_params;
+typedef struct shq_fof_group {
+    uint64_t MinID;
+    int32_t Length, GrNr;
+    int32_t LenType[6];
+    float FirstPos[3];
+    int32_t seed_index;
+    double MassType[6];
+    double Mass;
+    double CM[3];
+    double Vel[3];
+    double Imom[3][3];
+    double Jmom[3];
+    double MaxDens;
+    int64_t first_member;       /* offset of the group's members in the list of shq_fof_members */
+} shq_fof_group;
+int shq_fof(shq_context *ctx, const shq_fof_params *params, const uint64_t *ids, uint64_t *minid_by_particle, int32_t *grnr_by_particle,
+            int64_t *ngroups);
+int shq_fof_groups_download(shq_context *ctx, shq_fof_group *groups, int64_t capacity);
+/* particle indices of all kept groups, group after group (order of shq_fof_groups_download), members in index order */
+int shq_fof_members(shq_context *ctx, int32_t *members, int64_t capacity, int64_t *nmembers);
+
 /* Black-hole slot fields of the resident step (bh_particle_data, slotsmanager.h:35-73).  With them on the device
  * shq_drift repositions a BH with JumpToMinPot set (drift.cpp:32-53, when shq_set_bh_reposition is on), shq_kick_hydro adds
  * the dynamic-friction and drag kicks (timestep.cpp:973-979, factor bh_gravkick[TimeBinHydro] as apply_half_kick passes it),

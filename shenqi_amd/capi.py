@@ -204,6 +204,16 @@ def bh_dyn_view(BhP):
     return v
 
 
+class FofParams(C.Structure):
+    _fields_ = [("BoxSize", C.c_double), ("LinkingLength", C.c_double), ("PrimaryLinkTypes", C.c_int32), ("SecondaryLinkTypes", C.c_int32),
+                ("HaloMinLength", C.c_int32), ("WindsDecoupleSph", C.c_int32)]
+
+
+FOF_GROUP_DTYPE = np.dtype([("MinID", "<u8"), ("Length", "<i4"), ("GrNr", "<i4"), ("LenType", "<i4", 6), ("FirstPos", "<f4", 3), ("seed_index", "<i4"),
+                            ("MassType", "<f8", 6), ("Mass", "<f8"), ("CM", "<f8", 3), ("Vel", "<f8", 3), ("Imom", "<f8", (3, 3)), ("Jmom", "<f8", 3),
+                            ("MaxDens", "<f8"), ("first_member", "<i8")])
+
+
 class TopNodeGeo(C.Structure):
     _fields_ = [("daughter", C.c_int32 * 8), ("leaf", C.c_int32), ("pad_", C.c_int32)]
 
@@ -336,6 +346,12 @@ hip.shq_ngb_toptree_exports.argtypes = [_vp, C.c_int, C.c_double, _vp, C.c_int64
 hip.shq_ngb_toptree_exports.restype = C.c_int
 hip.shq_set_walk_stats.argtypes = [_vp, C.c_int]
 hip.shq_set_walk_stats.restype = C.c_int
+hip.shq_fof.argtypes = [_vp, C.POINTER(FofParams), _vp, _vp, _vp, C.POINTER(C.c_int64)]
+hip.shq_fof.restype = C.c_int
+hip.shq_fof_groups_download.argtypes = [_vp, _vp, C.c_int64]
+hip.shq_fof_groups_download.restype = C.c_int
+hip.shq_fof_members.argtypes = [_vp, _vp, C.c_int64, C.POINTER(C.c_int64)]
+hip.shq_fof_members.restype = C.c_int
 hip.shq_tree_build_domain.argtypes = [_vp, C.c_double, C.c_int, _vp, C.c_int64, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int64, _vp, _vp]
 hip.shq_tree_build_domain.restype = C.c_int
 hip.shq_tree_set_topleaf_moments.argtypes = [_vp, _vp, C.c_int]

@@ -206,6 +206,12 @@ extern "C" void shq_shutdown(shq_context *ctx)
     ctx->g_density.release(); ctx->g_egywt.release(); ctx->g_dhsmlegy.release(); ctx->g_divvel.release(); ctx->g_curlvel.release();
     ctx->g_hydroaccel_out.release(); ctx->g_dtentropy_out.release(); ctx->g_maxsignalvel.release();
     ctx->bh_pidx.release(); ctx->bh_u8.release(); ctx->bh_vec.release();
+    ctx->fof_parent.release(); ctx->fof_partgrnr.release(); ctx->fof_members.release(); ctx->fof_groups.release();
+    for(auto &b : ctx->fof_i32) b.release();
+    for(auto &b : ctx->fof_g32) b.release();
+    for(auto &b : ctx->fof_u64) b.release();
+    for(auto &b : ctx->fof_gkey) b.release();
+    for(auto &b : ctx->fof_goff) b.release();
     ctx->velp.release(); ctx->hydC.release(); ctx->hydD.release(); ctx->velp_leaf.release(); ctx->hydrec_leaf.release();
     ctx->hsml_leaf.release(); ctx->flag_leaf.release();
     ctx->s_numngb.release(); ctx->s_dhsmldens.release(); ctx->s_left.release(); ctx->s_right.release(); ctx->s_rot.release();
@@ -383,6 +389,7 @@ extern "C" int shq_particles_upload(shq_context *ctx, const shq_part_view *parts
     ctx->have_dyn = false;
     ctx->have_bh_dyn = false;
     ctx->nbh = 0;
+    ctx->fof_ngroups = -1;
     ctx->have_toptree = false;
     ctx->n_act = ctx->n_sub = -1;
     ctx->have_pm_result = false;
@@ -718,6 +725,7 @@ extern "C" int shq_particles_set_device(shq_context *ctx, const void *d_posm, in
     ctx->have_dyn = false;
     ctx->have_bh_dyn = false;
     ctx->nbh = 0;
+    ctx->fof_ngroups = -1;
     ctx->have_toptree = false;
     ctx->n_act = ctx->n_sub = -1;
     ctx->numpart = n;

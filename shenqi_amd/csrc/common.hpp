@@ -294,6 +294,13 @@ struct shq_context {
     DevBuf<double> g_entropy, g_dtentropy, g_hydroaccel, g_delaytime;
     DevBuf<double> g_density, g_egywt, g_dhsmlegy, g_divvel, g_curlvel;
     DevBuf<double> g_hydroaccel_out, g_dtentropy_out, g_maxsignalvel;
+    /* friends-of-friends (fof.hip) */
+    DevBuf<int32_t> fof_parent, fof_i32[6], fof_g32[5], fof_partgrnr, fof_members;
+    DevBuf<unsigned long long> fof_u64[4];
+    DevBuf<unsigned int> fof_gkey[2];
+    DevBuf<long long> fof_goff[2];
+    DevBuf<shq_fof_group> fof_groups;
+    int64_t fof_ngroups = -1, fof_nmembers = 0, fof_nruns = 0;
     /* black-hole slot fields of the resident step (timestep.hip): by BH ordinal, bh_pidx ascending particle indices */
     bool have_bh_dyn = false, bh_reposition = false;
     int64_t nbh = 0;

@@ -1,0 +1,566 @@
+/* fof.hip — friends-of-friends groups of the resident particles, one task (libgadget/fof.cpp).
+ *
+ *   fof_label_primary, fofp_merge, update_root, fof_primary_ngbiter     fof.cpp:300-581
+ *   fof_label_secondary, fof_secondary_ngbiter / _postprocess            fof.cpp:1142-1270
+ *   treewalk_visit_ngbiter / _nolist_ngbiter neighbour test, cull_node   treewalk.c:946-961, 1183-1196, 990-1019
+ *   fof_fof, fof_compile_base, fof_assign_grnr                            fof.cpp:159-256, 710-766, 1048-1096
+ *   add_particle_to_group, fof_finish_group_properties                    fof.cpp:583-705
+ *
+ * Linking is a union-find over particle indices: one thread per primary particle walks the tree of the primary types with the
+ * reference's cull, and every neighbour within the linking length is united with it — the larger root hooked under the smaller by
+ * atomicCAS, as fofp_merge does, with path halving on the way.  The end state does not depend on the order of the unions: the
+ * connected components, labelled with their smallest particle ID.  The walks are thread-per-particle on purpose: FOF runs at
+ * snapshot times only and is bound by the ~20 neighbours per particle, not by the node fetches the wave-union walks were built for.
+ * The catalogue is a radix sort by label, run detection by scans, and one thread per kept group for the property sums (in particle
+ * index order, so the sums are reproducible; the reference's order is whatever its unstable sort left). */
+#include "common.hpp"
+#include <string.h>
+#include <vector>
+#include <algorithm>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace {
+
+inline unsigned nblk(long long n, int t = 256) { return (unsigned) ((n + t - 1) / t); }
+
+__device__ __forceinline__ double nearest(double x, double Box) { return (x > 0.5 * Box) ? (x - Box) : ((x < -0.5 * Box) ? (x + Box) : x); }
+
+struct FofTree {
+    const NodeB *B;
+    const NodeC *C;
+    const double4 *posm_leaf;
+    const int32_t *leaf_pidx;
+    double Box;
+};
+
+/* cull_node, asymmetric (treewalk.c:990-1019): true = the node cannot hold a neighbour */
+__device__ __forceinline__ bool cull(const NodeB &b, const double4 p, double hsml, double Box)
+{
+#pragma clang fp contract(off)
+    double dist = hsml + 0.5 * b.len;
+    double r2 = 0;
+    const double pos[3] = {p.x, p.y, p.z};
+    for(int d = 0; d < 3; d++) {
+        const double dx = nearest(b.center[d] - pos[d], Box);
+        if(dx > dist || dx < -dist)
+            return true;
+        r2 += dx * dx;
+    }
+    dist += 0.366025403785 * b.len; /* FACT1, treewalk.c:19 */
+    return r2 > dist * dist;
+}
+
+/* r2 as treewalk_visit_ngbiter accumulates it (the early exit does not change the outcome) */
+__device__ __forceinline__ double ngb_r2(const double4 p, const double4 q, double Box)
+{
+#pragma clang fp contract(off)
+    const double d0 = nearest(p.x - q.x, Box), d1 = nearest(p.y - q.y, Box), d2 = nearest(p.z - q.z, Box);
+    double r2 = d0 * d0;
+    r2 += d1 * d1;
+    r2 += d2 * d2;
+    return r2;
+}
+
+__device__ __forceinline__ int uf_find(int32_t *parent, int i)
+{
+    int r = i;
+    while(true) {
+        const int p = ((volatile int32_t *) parent)[r];
+        if(p == r)
+            return r;
+        const int g = ((volatile int32_t *) parent)[p];
+        if(g != p)
+            atomicMin(&parent[r], g); /* path halving; parents only ever decrease (update_root's `t > r` condition) */
+        r = p;
+    }
+}
+
+/* fofp_merge, fof.cpp:481-542: the higher root becomes a child of the lower */
+__device__ void uf_unite(int32_t *parent, int a, int b)
+{
+    while(true) {
+        int h1 = uf_find(parent, a), h2 = uf_find(parent, b);
+        if(h1 == h2)
+            return;
+        if(h1 > h2) {
+            const int t = h1;
+            h1 = h2;
+            h2 = t;
+        }
+        if(atomicCAS(&parent[h2], h2, h1) == h2)
+            return;
+    }
+}
+
+__global__ __launch_bounds__(256) void fof_link_kernel(long long nt, FofTree t, double linkl, int32_t *parent)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= nt)
+        return;
+    const int i = t.leaf_pidx[k];
+    const double4 p = t.posm_leaf[k];
+    const double h2 = linkl * linkl;
+    int no = 0;
+    while(no >= 0) {
+        const NodeC c = t.C[no];
+        if(c.type == SHQ_PSEUDO_NODE_TYPE || cull(t.B[no], p, linkl, t.Box)) {
+            no = c.sibling;
+            continue;
+        }
+        if(c.type == SHQ_PARTICLE_NODE_TYPE) {
+            for(int s = c.child; s < c.child + c.count; s++) {
+                const int j = t.leaf_pidx[s];
+                if(i <= j && ngb_r2(p, t.posm_leaf[s], t.Box) <= h2) /* fof_primary_ngbiter: lv->target <= other */
+                    uf_unite(parent, i, j);
+            }
+            no = c.sibling;
+        } else
+            no = c.child;
+    }
+}
+
+__global__ void fof_init_kernel(long long n, int32_t *parent, const unsigned long long *ids, unsigned long long *minid, unsigned long long *label)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    parent[i] = (int32_t) i;
+    minid[i] = ids[i];
+    label[i] = ids[i];
+}
+
+__global__ void fof_minid_kernel(long long nt, const int32_t *leaf_pidx, int32_t *parent, const unsigned long long *ids, unsigned long long *minid)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= nt)
+        return;
+    const int i = leaf_pidx[k];
+    const int r = uf_find(parent, i);
+    if(r != i)
+        atomicMin(&minid[r], ids[i]);
+}
+
+__global__ void fof_label_kernel(long long nt, const int32_t *leaf_pidx, int32_t *parent, const unsigned long long *minid, unsigned long long *label)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= nt)
+        return;
+    const int i = leaf_pidx[k];
+    label[i] = minid[uf_find(parent, i)];
+}
+
+/* fof_label_secondary: the whole radius loop of one particle in one thread (the radii of different particles are independent) */
+__global__ __launch_bounds__(256) void fof_secondary_kernel(long long n, FofTree t, const double4 *posm, const uint8_t *pflags, const double *hsml,
+                                                            double linkl, int secondary_mask, const unsigned long long *label_in,
+                                                            unsigned long long *label_out, unsigned long long *nattached)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    const unsigned f = pflags[i];
+    const int type = f >> 4;
+    if((f & 3u) || !((1 << type) & secondary_mask))
+        return;
+    const double4 p = posm[i];
+    float h = (float) (0.4 * linkl);
+    if((type == 0 || type == 4 || type == 5) && hsml && (double) h < 0.5 * hsml[i])
+        h = (float) (0.5 * hsml[i]);
+    while(true) {
+        double cur = (double) h;         /* iter->base.Hsml */
+        double distance = 1e29;          /* O->Distance = LARGE */
+        int other = -1;
+        int no = 0;
+        while(no >= 0) {
+            const NodeC c = t.C[no];
+            if(c.type == SHQ_PSEUDO_NODE_TYPE || cull(t.B[no], p, cur, t.Box)) {
+                no = c.sibling;
+                continue;
+            }
+            if(c.type == SHQ_PARTICLE_NODE_TYPE) {
+                for(int s = c.child; s < c.child + c.count; s++) {
+                    const double r2 = ngb_r2(p, t.posm_leaf[s], t.Box);
+                    if(r2 > cur * cur)
+                        continue;
+                    const double r = sqrt(r2);
+                    if(r < distance) {
+                        distance = r;
+                        other = t.leaf_pidx[s];
+                    }
+                    cur = r; /* fof_secondary_ngbiter: no need to look further than this neighbour */
+                }
+                no = c.sibling;
+            } else
+                no = c.child;
+        }
+        if(other >= 0) {
+            label_out[i] = label_in[other];
+            atomicAdd(nattached, 1ull);
+            return;
+        }
+        if((double) h < 4 * linkl) /* fof_secondary_postprocess, fof.cpp:1176-1191 */
+            h *= 2.0f;
+        else
+            return;
+    }
+}
+
+__global__ void fof_iota_kernel(long long n, int32_t *v)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+        v[i] = (int32_t) i;
+}
+
+__global__ void fof_flag_kernel(long long n, const unsigned long long *keys, int32_t *flags)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k < n)
+        flags[k] = (k == 0 || keys[k] != keys[k - 1]) ? 1 : 0;
+}
+
+__global__ void fof_runstart_kernel(long long n, const int32_t *flags, const int32_t *runid_incl, int32_t *runstart, long long nruns)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k < n && flags[k])
+        runstart[runid_incl[k] - 1] = (int32_t) k;
+    if(k == 0)
+        runstart[nruns] = (int32_t) n;
+}
+
+__global__ void fof_keep_kernel(long long nruns, const int32_t *runstart, int minlength, int32_t *keep)
+{
+    const long long r = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(r < nruns)
+        keep[r] = (runstart[r + 1] - runstart[r] >= minlength) ? 1 : 0;
+}
+
+__global__ void fof_groups_kernel(long long nruns, const int32_t *runstart, const int32_t *keep, const int32_t *keptidx_excl, int32_t *gstart,
+                                  int32_t *glen, unsigned int *lenkey, int32_t *gval)
+{
+    const long long r = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(r >= nruns || !keep[r])
+        return;
+    const int g = keptidx_excl[r];
+    gstart[g] = runstart[r];
+    glen[g] = runstart[r + 1] - runstart[r];
+    lenkey[g] = 0xffffffffu - (unsigned) glen[g]; /* UINT64_MAX - Length, fof.cpp:1394 */
+    gval[g] = g;
+}
+
+__global__ void fof_grnr_kernel(long long ng, const int32_t *order, int32_t *grnr)
+{
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t < ng)
+        grnr[order[t]] = (int32_t) (t + 1);
+}
+
+__global__ void fof_partgrnr_kernel(long long n, const int32_t *idx, const int32_t *runid_incl, const int32_t *keep, const int32_t *keptidx_excl,
+                                    const int32_t *grnr, int32_t *part_grnr)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    const int r = runid_incl[k] - 1;
+    part_grnr[idx[k]] = keep[r] ? grnr[keptidx_excl[r]] : -1;
+}
+
+/* add_particle_to_group over the members in sorted (= particle index) order, then fof_finish_group_properties */
+__global__ __launch_bounds__(64) void fof_props_kernel(long long ng, const int32_t *gstart, const int32_t *glen, const int32_t *grnr, const int32_t *idx,
+                                                       const unsigned long long *keys, const double4 *posm, const double *vel, const uint8_t *pflags,
+                                                       const double *density, const double *delaytime, int winds_decouple, double Box,
+                                                       shq_fof_group *out)
+{
+#pragma clang fp contract(off)
+    const long long g = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(g >= ng)
+        return;
+    shq_fof_group G;
+    memset(&G, 0, sizeof(G));
+    const int s0 = gstart[g], len = glen[g];
+    G.MinID = keys[s0];
+    G.GrNr = grnr[g];
+    G.seed_index = -1;
+    G.first_member = 0;
+    double first[3];
+    {
+        const double4 q = posm[idx[s0]];
+        G.FirstPos[0] = (float) q.x;
+        G.FirstPos[1] = (float) q.y;
+        G.FirstPos[2] = (float) q.z;
+        for(int d = 0; d < 3; d++)
+            first[d] = (double) G.FirstPos[d];
+    }
+    for(int k = s0; k < s0 + len; k++) {
+        const int i = idx[k];
+        const double4 q = posm[i];
+        const unsigned type = pflags[i] >> 4;
+        const double m = q.w;
+        G.Length++;
+        G.Mass += m;
+        if(type < 6) {
+            G.LenType[type]++;
+            G.MassType[type] += m;
+        }
+        if(type == 0 && density && !(winds_decouple && delaytime && delaytime[i] > 0))
+            if(density[i] > G.MaxDens) {
+                G.MaxDens = density[i];
+                G.seed_index = i;
+            }
+        const double pos[3] = {q.x, q.y, q.z};
+        double rel[3], xyz[3], v[3], jm[3];
+        for(int d = 0; d < 3; d++) {
+            rel[d] = nearest(pos[d] - first[d], Box);
+            xyz[d] = rel[d] + first[d];
+            v[d] = vel ? vel[3 * (long long) i + d] : 0.0;
+        }
+        jm[0] = rel[1] * v[2] - v[1] * rel[2]; /* crossproduct, densitykernel.h:63-75 */
+        jm[1] = rel[2] * v[0] - v[2] * rel[0];
+        jm[2] = rel[0] * v[1] - v[0] * rel[1];
+        for(int d1 = 0; d1 < 3; d1++) {
+            G.CM[d1] += m * xyz[d1];
+            G.Vel[d1] += m * v[d1];
+            G.Jmom[d1] += m * jm[d1];
+            for(int d2 = 0; d2 < 3; d2++)
+                G.Imom[d1][d2] += m * rel[d1] * rel[d2];
+        }
+    }
+    double cm[3], rel[3], vcm[3], jcm[3];
+    for(int d = 0; d < 3; d++) {
+        G.Vel[d] /= G.Mass;
+        vcm[d] = G.Vel[d];
+        cm[d] = G.CM[d] / G.Mass;
+        rel[d] = nearest(cm[d] - first[d], Box);
+        int guard = 0;
+        while(cm[d] >= Box && guard++ < 64) /* fof_periodic_wrap */
+            cm[d] -= Box;
+        while(cm[d] < 0 && guard++ < 64)
+            cm[d] += Box;
+        G.CM[d] = cm[d];
+    }
+    jcm[0] = rel[1] * vcm[2] - vcm[1] * rel[2];
+    jcm[1] = rel[2] * vcm[0] - vcm[2] * rel[0];
+    jcm[2] = rel[0] * vcm[1] - vcm[0] * rel[1];
+    for(int d = 0; d < 3; d++)
+        G.Jmom[d] -= jcm[d] * G.Mass;
+    for(int d1 = 0; d1 < 3; d1++)
+        for(int d2 = 0; d2 < 3; d2++) {
+            const double diff = rel[d1] * rel[d2];
+            G.Imom[d1][d2] -= G.Mass * diff;
+        }
+    out[g] = G;
+}
+
+/* members of the kept groups, group after group */
+__global__ void fof_member_offsets_kernel(long long ng, const int32_t *glen, const long long *off_excl, shq_fof_group *groups)
+{
+    const long long g = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(g < ng)
+        groups[g].first_member = off_excl[g];
+}
+__global__ void fof_glen64_kernel(long long ng, const int32_t *glen, long long *out)
+{
+    const long long g = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(g < ng)
+        out[g] = glen[g];
+}
+__global__ void fof_members_kernel(long long n, const int32_t *idx, const int32_t *runid_incl, const int32_t *keep, const int32_t *keptidx_excl,
+                                   const int32_t *runstart, const long long *off_excl, int32_t *members)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    const int r = runid_incl[k] - 1;
+    if(keep[r])
+        members[off_excl[keptidx_excl[r]] + (k - runstart[r])] = idx[k];
+}
+
+template <typename T> int scan_excl(shq_context *ctx, const T *in, T *out, size_t n)
+{
+    size_t tmp = 0;
+    SHQ_HIP(rocprim::exclusive_scan(nullptr, tmp, in, out, T(0), n, rocprim::plus<T>(), ctx->stream));
+    SHQ_TRY(ctx->act_temp.reserve(tmp + 16));
+    SHQ_HIP(rocprim::exclusive_scan((void *) ctx->act_temp.ptr, tmp, in, out, T(0), n, rocprim::plus<T>(), ctx->stream));
+    return SHQ_OK;
+}
+template <typename T> int scan_incl(shq_context *ctx, const T *in, T *out, size_t n)
+{
+    size_t tmp = 0;
+    SHQ_HIP(rocprim::inclusive_scan(nullptr, tmp, in, out, n, rocprim::plus<T>(), ctx->stream));
+    SHQ_TRY(ctx->act_temp.reserve(tmp + 16));
+    SHQ_HIP(rocprim::inclusive_scan((void *) ctx->act_temp.ptr, tmp, in, out, n, rocprim::plus<T>(), ctx->stream));
+    return SHQ_OK;
+}
+
+} // namespace
+
+extern "C" int shq_fof(shq_context *ctx, const shq_fof_params *fp, const uint64_t *ids, uint64_t *minid_by_particle, int32_t *grnr_by_particle,
+                       int64_t *ngroups)
+{
+    SHQ_CHECK(ctx && fp && ids, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "fof: upload particles first");
+    SHQ_CHECK(fp->BoxSize > 0 && fp->LinkingLength > 0 && fp->HaloMinLength >= 1, SHQ_ERR_INVALID, "fof: BoxSize, LinkingLength, HaloMinLength must be > 0");
+    SHQ_CHECK(fp->PrimaryLinkTypes > 0 && fp->PrimaryLinkTypes < 64 && fp->SecondaryLinkTypes >= 0 && fp->SecondaryLinkTypes < 64, SHQ_ERR_INVALID,
+              "fof: bad type masks");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const long long n = ctx->numpart;
+    ctx->fof_ngroups = -1;
+    if(ngroups)
+        *ngroups = 0;
+    if(n == 0) {
+        ctx->fof_ngroups = 0;
+        ctx->fof_nmembers = 0;
+        return SHQ_OK;
+    }
+    SHQ_CHECK(n < (1ll << 31) - 64, SHQ_ERR_INVALID, "fof: too many particles");
+    /* the tree of the primary types (fof.cpp:176-178) */
+    SHQ_TRY(shq_tree_build(ctx, fp->BoxSize, fp->PrimaryLinkTypes, nullptr, 0, nullptr));
+    const long long nt = ctx->ntreeparts;
+    FofTree t = {ctx->nodeB.ptr, ctx->nodeC.ptr, ctx->posm_leaf.ptr, ctx->leaf_pidx.ptr, fp->BoxSize};
+
+    const size_t cap = (size_t) n;
+    SHQ_TRY(ctx->fof_parent.reserve(cap));
+    SHQ_TRY(ctx->fof_u64[0].reserve(cap)); /* ids, later sorted keys */
+    SHQ_TRY(ctx->fof_u64[1].reserve(cap)); /* minid of roots */
+    SHQ_TRY(ctx->fof_u64[2].reserve(cap)); /* labels */
+    SHQ_TRY(ctx->fof_u64[3].reserve(cap)); /* labels after the secondary pass */
+    SHQ_TRY(ctx->act_counts.reserve(6 * (SHQ_TIMEBINS + 1) + 64));
+    unsigned long long *d_ids = ctx->fof_u64[0].ptr, *d_minid = ctx->fof_u64[1].ptr, *d_label = ctx->fof_u64[2].ptr, *d_label2 = ctx->fof_u64[3].ptr;
+    SHQ_HIP(hipMemcpyAsync(d_ids, ids, sizeof(uint64_t) * cap, hipMemcpyHostToDevice, st));
+    fof_init_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, ctx->fof_parent.ptr, d_ids, d_minid, d_label);
+    if(nt > 0) {
+        fof_link_kernel<<<dim3(nblk(nt)), dim3(256), 0, st>>>(nt, t, fp->LinkingLength, ctx->fof_parent.ptr);
+        fof_minid_kernel<<<dim3(nblk(nt)), dim3(256), 0, st>>>(nt, ctx->leaf_pidx.ptr, ctx->fof_parent.ptr, d_ids, d_minid);
+        fof_label_kernel<<<dim3(nblk(nt)), dim3(256), 0, st>>>(nt, ctx->leaf_pidx.ptr, ctx->fof_parent.ptr, d_minid, d_label);
+    }
+    SHQ_HIP(hipGetLastError());
+    /* secondary types: nearest primary particle */
+    SHQ_HIP(hipMemcpyAsync(d_label2, d_label, sizeof(uint64_t) * cap, hipMemcpyDeviceToDevice, st));
+    unsigned long long *d_natt = ctx->act_counts.ptr;
+    SHQ_HIP(hipMemsetAsync(d_natt, 0, sizeof(unsigned long long), st));
+    if(nt > 0 && fp->SecondaryLinkTypes) {
+        const double *d_hsml = (ctx->have_sph || ctx->have_dyn) ? ctx->hsml.ptr : nullptr;
+        fof_secondary_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, t, ctx->posm.ptr, ctx->pflags.ptr, d_hsml, fp->LinkingLength, fp->SecondaryLinkTypes,
+                                                                  d_label, d_label2, d_natt);
+        SHQ_HIP(hipGetLastError());
+    }
+    if(minid_by_particle)
+        SHQ_HIP(hipMemcpyAsync(minid_by_particle, d_label2, sizeof(uint64_t) * cap, hipMemcpyDeviceToHost, st));
+
+    /* catalogue: sort by label (stable: members in particle index order) */
+    SHQ_TRY(ctx->fof_i32[0].reserve(cap + 1)); /* iota / flags */
+    SHQ_TRY(ctx->fof_i32[1].reserve(cap + 1)); /* sorted particle indices */
+    SHQ_TRY(ctx->fof_i32[2].reserve(cap + 1)); /* run id (inclusive scan of flags) */
+    SHQ_TRY(ctx->fof_i32[3].reserve(cap + 1)); /* run starts */
+    SHQ_TRY(ctx->fof_i32[4].reserve(cap + 1)); /* keep flag per run */
+    SHQ_TRY(ctx->fof_i32[5].reserve(cap + 1)); /* kept index per run (exclusive scan) */
+    int32_t *d_iota = ctx->fof_i32[0].ptr, *d_idx = ctx->fof_i32[1].ptr, *d_runid = ctx->fof_i32[2].ptr, *d_runstart = ctx->fof_i32[3].ptr,
+            *d_keep = ctx->fof_i32[4].ptr, *d_keptidx = ctx->fof_i32[5].ptr;
+    unsigned long long *d_keys = ctx->fof_u64[0].ptr; /* the ids are no longer needed */
+    fof_iota_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, d_iota);
+    {
+        size_t tmp = 0;
+        SHQ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, d_label2, d_keys, d_iota, d_idx, cap, 0, 64, st));
+        SHQ_TRY(ctx->act_temp.reserve(tmp + 16));
+        SHQ_HIP(rocprim::radix_sort_pairs((void *) ctx->act_temp.ptr, tmp, d_label2, d_keys, d_iota, d_idx, cap, 0, 64, st));
+    }
+    int32_t *d_flags = d_iota;
+    fof_flag_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, d_keys, d_flags);
+    SHQ_TRY(scan_incl(ctx, (const int32_t *) d_flags, d_runid, cap));
+    int32_t h_nruns = 0;
+    SHQ_HIP(hipMemcpyAsync(&h_nruns, d_runid + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    const long long nruns = h_nruns;
+    fof_runstart_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, d_flags, d_runid, d_runstart, nruns);
+    fof_keep_kernel<<<dim3(nblk(nruns)), dim3(256), 0, st>>>(nruns, d_runstart, fp->HaloMinLength, d_keep);
+    SHQ_HIP(hipMemsetAsync(d_keep + nruns, 0, sizeof(int32_t), st));
+    SHQ_TRY(scan_excl(ctx, (const int32_t *) d_keep, d_keptidx, (size_t) nruns + 1));
+    int32_t h_ng = 0;
+    SHQ_HIP(hipMemcpyAsync(&h_ng, d_keptidx + nruns, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    const long long ng = h_ng;
+    const size_t gcap = (size_t) std::max<long long>(ng, 1);
+    SHQ_TRY(ctx->fof_g32[0].reserve(gcap)); /* gstart */
+    SHQ_TRY(ctx->fof_g32[1].reserve(gcap)); /* glen */
+    SHQ_TRY(ctx->fof_g32[2].reserve(gcap)); /* grnr */
+    SHQ_TRY(ctx->fof_g32[3].reserve(gcap)); /* group ids / order */
+    SHQ_TRY(ctx->fof_g32[4].reserve(gcap));
+    SHQ_TRY(ctx->fof_gkey[0].reserve(gcap));
+    SHQ_TRY(ctx->fof_gkey[1].reserve(gcap));
+    SHQ_TRY(ctx->fof_groups.reserve(gcap));
+    SHQ_TRY(ctx->fof_goff[0].reserve(gcap + 1));
+    SHQ_TRY(ctx->fof_goff[1].reserve(gcap + 1));
+    SHQ_TRY(ctx->fof_partgrnr.reserve(cap));
+    int32_t *d_gstart = ctx->fof_g32[0].ptr, *d_glen = ctx->fof_g32[1].ptr, *d_grnr = ctx->fof_g32[2].ptr;
+    long long nmembers = 0;
+    if(ng > 0) {
+        fof_groups_kernel<<<dim3(nblk(nruns)), dim3(256), 0, st>>>(nruns, d_runstart, d_keep, d_keptidx, d_gstart, d_glen, ctx->fof_gkey[0].ptr, ctx->fof_g32[3].ptr);
+        {
+            /* groups are in MinID order; a stable sort on UINT_MAX - Length gives (length descending, MinID ascending) */
+            size_t tmp = 0;
+            SHQ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, ctx->fof_gkey[0].ptr, ctx->fof_gkey[1].ptr, ctx->fof_g32[3].ptr, ctx->fof_g32[4].ptr, (size_t) ng, 0, 32, st));
+            SHQ_TRY(ctx->act_temp.reserve(tmp + 16));
+            SHQ_HIP(rocprim::radix_sort_pairs((void *) ctx->act_temp.ptr, tmp, ctx->fof_gkey[0].ptr, ctx->fof_gkey[1].ptr, ctx->fof_g32[3].ptr, ctx->fof_g32[4].ptr,
+                                              (size_t) ng, 0, 32, st));
+        }
+        fof_grnr_kernel<<<dim3(nblk(ng)), dim3(256), 0, st>>>(ng, ctx->fof_g32[4].ptr, d_grnr);
+        const double *d_vel = (ctx->have_sph || ctx->have_dyn) ? ctx->vel.ptr : nullptr;
+        const double *d_dens = ctx->have_sph ? ctx->g_density.ptr : nullptr;
+        const double *d_delay = ctx->have_sph ? ctx->g_delaytime.ptr : nullptr;
+        fof_props_kernel<<<dim3(nblk(ng, 64)), dim3(64), 0, st>>>(ng, d_gstart, d_glen, d_grnr, d_idx, d_keys, ctx->posm.ptr, d_vel, ctx->pflags.ptr, d_dens, d_delay,
+                                                                  fp->WindsDecoupleSph, fp->BoxSize, ctx->fof_groups.ptr);
+        fof_glen64_kernel<<<dim3(nblk(ng)), dim3(256), 0, st>>>(ng, d_glen, ctx->fof_goff[0].ptr);
+        SHQ_HIP(hipMemsetAsync(ctx->fof_goff[0].ptr + ng, 0, sizeof(long long), st));
+        SHQ_TRY(scan_excl(ctx, (const long long *) ctx->fof_goff[0].ptr, ctx->fof_goff[1].ptr, (size_t) ng + 1));
+        fof_member_offsets_kernel<<<dim3(nblk(ng)), dim3(256), 0, st>>>(ng, d_glen, ctx->fof_goff[1].ptr, ctx->fof_groups.ptr);
+        SHQ_HIP(hipMemcpyAsync(&nmembers, ctx->fof_goff[1].ptr + ng, sizeof(long long), hipMemcpyDeviceToHost, st));
+    }
+    fof_partgrnr_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, d_idx, d_runid, d_keep, d_keptidx, d_grnr, ctx->fof_partgrnr.ptr);
+    SHQ_HIP(hipGetLastError());
+    if(grnr_by_particle)
+        SHQ_HIP(hipMemcpyAsync(grnr_by_particle, ctx->fof_partgrnr.ptr, sizeof(int32_t) * cap, hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    ctx->fof_ngroups = ng;
+    ctx->fof_nmembers = nmembers;
+    ctx->fof_nruns = nruns;
+    if(ngroups)
+        *ngroups = ng;
+    return SHQ_OK;
+}
+
+extern "C" int shq_fof_groups_download(shq_context *ctx, shq_fof_group *groups, int64_t capacity)
+{
+    SHQ_CHECK(ctx && (groups || capacity == 0), SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->fof_ngroups >= 0, SHQ_ERR_STATE, "fof_groups_download: run shq_fof first");
+    SHQ_CHECK(capacity >= ctx->fof_ngroups, SHQ_ERR_INVALID, "fof_groups_download: capacity %ld < %ld groups", (long) capacity, (long) ctx->fof_ngroups);
+    SHQ_HIP(hipSetDevice(ctx->device));
+    if(ctx->fof_ngroups > 0)
+        SHQ_HIP(hipMemcpy(groups, ctx->fof_groups.ptr, sizeof(shq_fof_group) * (size_t) ctx->fof_ngroups, hipMemcpyDeviceToHost));
+    return SHQ_OK;
+}
+
+extern "C" int shq_fof_members(shq_context *ctx, int32_t *members, int64_t capacity, int64_t *nmembers)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_CHECK(ctx->fof_ngroups >= 0, SHQ_ERR_STATE, "fof_members: run shq_fof first");
+    if(nmembers)
+        *nmembers = ctx->fof_nmembers;
+    if(!members)
+        return SHQ_OK;
+    SHQ_CHECK(capacity >= ctx->fof_nmembers, SHQ_ERR_INVALID, "fof_members: capacity %ld < %ld", (long) capacity, (long) ctx->fof_nmembers);
+    SHQ_CHECK(ctx->have_parts && ctx->fof_i32[1].ptr, SHQ_ERR_STATE, "fof_members: the particle set changed since shq_fof");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const long long n = ctx->numpart;
+    if(ctx->fof_nmembers > 0) {
+        SHQ_TRY(ctx->fof_members.reserve((size_t) ctx->fof_nmembers));
+        fof_members_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(n, ctx->fof_i32[1].ptr, ctx->fof_i32[2].ptr, ctx->fof_i32[4].ptr, ctx->fof_i32[5].ptr,
+                                                                        ctx->fof_i32[3].ptr, ctx->fof_goff[1].ptr, ctx->fof_members.ptr);
+        SHQ_HIP(hipGetLastError());
+        SHQ_HIP(hipMemcpyAsync(members, ctx->fof_members.ptr, sizeof(int32_t) * (size_t) ctx->fof_nmembers, hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return SHQ_OK;
+}
+
+static_assert(sizeof(shq_fof_group) == 272, "shq_fof_group layout (shenqi_amd/capi.py FOF_GROUP_DTYPE)");

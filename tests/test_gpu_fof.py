@@ -1,0 +1,135 @@
+"""GPU parity tests of the friends-of-friends finder (csrc/fof.hip) through the C-ABI: the reference's own fixtures
+(libgadget/tests/test_fof.cpp, at their full size) with every BOOST_TEST of theirs, and equality with the restatement
+(oracle/fof.py) — labels, group numbers and lengths as integers, the group sums to the bit (same order of the same operations)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import shenqi_amd as sq
+from shenqi_amd import capi
+import common as cm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import fof as ofof  # noqa: E402
+import fof_fixtures as fx  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_fof(ctx, pos, vel, mass, types, ids, box, linkl, minlength, flags=None, hsml=None, primary=2, secondary=1 + 16 + 32):
+    n = len(pos)
+    pman = cm.make_partmanager(pos, box=box)
+    P = pman.Base
+    P["Type"], P["Mass"], P["Vel"], P["ID"] = types, mass, vel, ids
+    if flags is not None:
+        P["Flags"] = flags
+    if hsml is not None:
+        P["Hsml"] = hsml
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    sq.dynamics_upload(ctx, pman)
+    fp = capi.FofParams(box, linkl, primary, secondary, minlength, 0)
+    minid = np.zeros(n, dtype=np.uint64)
+    grnr = np.zeros(n, dtype=np.int32)
+    ng = C.c_int64()
+    idarr = np.ascontiguousarray(ids, dtype=np.uint64)
+    capi.check(capi.hip.shq_fof(ctx.h, C.byref(fp), capi.ptr(idarr), capi.ptr(minid), capi.ptr(grnr), C.byref(ng)))
+    groups = np.zeros(ng.value, dtype=capi.FOF_GROUP_DTYPE)
+    capi.check(capi.hip.shq_fof_groups_download(ctx.h, capi.ptr(groups), len(groups)))
+    nm = C.c_int64()
+    capi.check(capi.hip.shq_fof_members(ctx.h, None, 0, C.byref(nm)))
+    members = np.zeros(nm.value, dtype=np.int32)
+    capi.check(capi.hip.shq_fof_members(ctx.h, capi.ptr(members), len(members), C.byref(nm)))
+    return minid, grnr, groups, members, P["Mass"].astype(np.float64)
+
+
+def as_dicts(groups):
+    return [dict(MinID=int(g["MinID"]), Length=int(g["Length"]), GrNr=int(g["GrNr"]), LenType=list(g["LenType"]), MassType=list(g["MassType"]),
+                 Mass=float(g["Mass"]), CM=g["CM"], Vel=g["Vel"]) for g in groups]
+
+
+def compare(groups, members, ogroups, grnr, ogrnr, minid, ominid):
+    assert np.array_equal(minid, ominid)
+    assert np.array_equal(grnr, ogrnr)
+    assert len(groups) == len(ogroups)
+    off = 0
+    for g, o in zip(groups, ogroups):
+        assert g["MinID"] == o["MinID"] and g["Length"] == o["Length"] and g["GrNr"] == o["GrNr"]
+        assert list(g["LenType"]) == o["LenType"] and g["seed_index"] == o["seed_index"]
+        assert tuple(g["FirstPos"]) == tuple(o["FirstPos"])
+        assert list(g["MassType"]) == o["MassType"] and g["Mass"] == o["Mass"] and g["MaxDens"] == o["MaxDens"]
+        for f in ("CM", "Vel", "Jmom", "Imom"):
+            assert np.array_equal(g[f], o[f]), (f, g[f], o[f])
+        assert g["first_member"] == off
+        mem = members[off:off + g["Length"]]
+        assert (np.diff(mem) > 0).all() and (ominid[mem] == o["MinID"]).all()
+        off += g["Length"]
+    assert off == len(members)
+
+
+def test_fof_line_reference_fixture(ctx):
+    f = fx.line()                                   # 512^2 particles, as the reference runs it
+    n = len(f["pos"])
+    minid, grnr, groups, members, _ = gpu_fof(ctx, f["pos"], f["vel"], f["mass"], f["types"], f["ids"], f["box"], f["linkl"], f["minlength"])
+    fx.check_line(as_dicts(groups), grnr, f)
+    assert (minid == 1).all() and len(members) == n and np.array_equal(members, np.arange(n))
+
+
+def test_fof_halos_reference_fixture(ctx):
+    f = fx.halos()
+    n = len(f["pos"])
+    minid, grnr, groups, members, massd = gpu_fof(ctx, f["pos"], f["vel"], f["mass"], f["types"], f["ids"], f["box"], f["linkl"], f["minlength"])
+    fx.check_halos(as_dicts(groups), grnr, f)
+    ominid, ogroups, ogrnr = ofof.fof(f["pos"], f["vel"], massd, f["types"], f["ids"], np.zeros(n, dtype=bool), np.zeros(n), f["box"], f["linkl"], f["minlength"])
+    compare(groups, members, ogroups, grnr, ogrnr, minid, ominid)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fof_clustered_mixed_types_equals_oracle(ctx, seed):
+    """dark matter in clumps of all sizes + a uniform part, gas / stars / black holes scattered around them with their own
+    smoothing lengths, a few garbage and swallowed particles, shuffled IDs: labels, group numbers and sums against the oracle"""
+    rng = np.random.default_rng(seed)
+    box = 1000.0
+    centres = rng.random((60, 3)) * box
+    sizes = rng.integers(3, 400, size=60)
+    dm = np.concatenate([c + rng.normal(size=(s, 3)) * rng.uniform(0.5, 3.0) for c, s in zip(centres, sizes)] + [rng.random((4000, 3)) * box])
+    nsec = 3000
+    sec = np.concatenate([centres[rng.integers(0, 60, size=nsec // 2)] + rng.normal(size=(nsec // 2, 3)) * 6.0, rng.random((nsec - nsec // 2, 3)) * box])
+    pos = np.mod(np.concatenate([dm, sec]), box)
+    n = len(pos)
+    types = np.concatenate([np.ones(len(dm), dtype=np.uint8), rng.choice([0, 4, 5], size=nsec, p=[0.7, 0.25, 0.05]).astype(np.uint8)])
+    perm = rng.permutation(n)
+    pos, types = pos[perm], types[perm]
+    ids = rng.permutation(n).astype(np.uint64) + 1000
+    vel = rng.normal(size=(n, 3)) * 100
+    mass = rng.choice([1.0, 0.5, 0.125], size=n).astype(np.float32).astype(np.float64)
+    hsml = rng.uniform(0.2, 12.0, size=n)
+    flags = np.zeros(n, dtype=np.uint8)
+    flags[rng.random(n) < 0.01] |= 1
+    flags[rng.random(n) < 0.01] |= 2
+    dead = (flags & 3) != 0
+    linkl = 2.0
+    minid, grnr, groups, members, massd = gpu_fof(ctx, pos, vel, mass, types, ids, box, linkl, 8, flags=flags, hsml=hsml)
+    ominid, ogroups, ogrnr = ofof.fof(pos, vel, massd, types, ids, dead, hsml, box, linkl, 8)
+    compare(groups, members, ogroups, grnr, ogrnr, minid, ominid)
+    nsec_attached = int((ominid[types != 1] != ids[types != 1]).sum())
+    assert len(groups) > 20 and 100 < nsec_attached < nsec
+    assert max(g["Length"] for g in groups) > 300
+
+
+def test_fof_requires_run_and_handles_empty_and_no_groups(ctx):
+    rng = np.random.default_rng(4)
+    pos = rng.random((500, 3)) * cm.BOX
+    n = len(pos)
+    minid, grnr, groups, members, _ = gpu_fof(ctx, pos, np.zeros((n, 3)), np.ones(n), np.ones(n, dtype=np.uint8), np.arange(1, n + 1, dtype=np.uint64), cm.BOX,
+                                              1e-4, 5)
+    assert len(groups) == 0 and len(members) == 0 and (grnr == -1).all() and np.array_equal(minid, np.arange(1, n + 1, dtype=np.uint64))
+    c2 = sq.Context(0)
+    try:
+        assert capi.hip.shq_fof_groups_download(c2.h, None, 0) != 0
+    finally:
+        c2.close()
