@@ -712,6 +712,33 @@ def main():
     except sq.ShqError as e:  # e.g. a tree deeper than the device build supports: the extra figure is simply absent
         out["kernels"]["resident_full_step_ms"] = None
         out["kernels"]["resident_full_step_note"] = str(e)
+    # Extra figures, outside `value`: the other particle loops of a step on the resident set — the
+    # time-step assignment (find_timesteps particle loop) and a friends-of-friends pass over the same box.
+    try:
+        tp = capi.TimestepParams()
+        tp.ErrTolIntAccuracy, tp.CourantFac, tp.MinSizeTimestep, tp.ForceSoftening = 0.02, 0.15, 1e-9, sq.FORCE_SOFTENING()
+        tp.atime, tp.hubble, tp.fac3, tp.dti_max = 0.5, 0.28, 0.5 ** -1.0, 1 << 40
+        tp.tl.Ti_Current, tp.tl.loga_now, tp.tl.Dloga_interval, tp.tl.nseg = 0, np.log(0.5), np.log(2.0) / (1 << 46), 1
+        tp.tl.seg_snap[0], tp.tl.seg_loga[0], tp.tl.seg_loga[1] = 0, np.log(0.5), 0.0
+        capi.check(capi.hip.shq_timebins_upload(ctx.h, None, None))
+        tr = capi.TimestepResult()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            capi.check(capi.hip.shq_find_timesteps(ctx.h, C.byref(tp), None, 0, 0, -1, C.byref(tr)))
+        out["kernels"]["find_timesteps_ms"] = 1e3 * (time.perf_counter() - t0) / 3
+        out["kernels"]["find_timesteps_bins"] = [int(tr.mTimeBin), int(tr.maxTimeBin)]
+        fp = capi.FofParams(L, 0.2 * L / n1, 2, 1 + 16 + 32, 32, 0)
+        ids = np.arange(1, n + 1, dtype=np.uint64)
+        ng = C.c_int64()
+        capi.check(capi.hip.shq_fof(ctx.h, C.byref(fp), capi.ptr(ids), None, None, C.byref(ng)))
+        t0 = time.perf_counter()
+        capi.check(capi.hip.shq_fof(ctx.h, C.byref(fp), capi.ptr(ids), None, None, C.byref(ng)))
+        out["kernels"]["fof_ms"] = 1e3 * (time.perf_counter() - t0)
+        out["kernels"]["fof_groups"] = int(ng.value)
+        out["kernels"]["fof_note"] = "shq_fof end to end (tree of the primary type, linking, catalogue), linking length 0.2 mean separations, groups of >= 32"
+    except sq.ShqError as e:
+        out["kernels"]["fof_note"] = "skipped: %s" % e
     if not args.no_sph:
         figs = sph_figures(ctx)
         for k in ("roofline_sph_density", "roofline_sph_hydro"):

@@ -295,7 +295,7 @@ struct shq_context {
     DevBuf<double> g_density, g_egywt, g_dhsmlegy, g_divvel, g_curlvel;
     DevBuf<double> g_hydroaccel_out, g_dtentropy_out, g_maxsignalvel;
     /* friends-of-friends (fof.hip) */
-    DevBuf<int32_t> fof_parent, fof_i32[6], fof_g32[5], fof_partgrnr, fof_members;
+    DevBuf<int32_t> fof_parent, fof_i32[6], fof_g32[5], fof_partgrnr, fof_members, fof_biglist;
     DevBuf<unsigned long long> fof_u64[4];
     DevBuf<unsigned int> fof_gkey[2];
     DevBuf<long long> fof_goff[2];

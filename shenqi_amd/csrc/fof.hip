@@ -32,6 +32,9 @@ struct FofTree {
     const double4 *posm_leaf;
     const int32_t *leaf_pidx;
     double Box;
+    /* leaf-slot range [lo, hi) of every node's particles, through the build's numbering: lo[order[r]] for pool record r */
+    const int32_t *order, *lo, *hi, *parent;
+    double clique_len; /* a node this small or smaller holds particles that are all within the linking length of each other */
 };
 
 /* cull_node, asymmetric (treewalk.c:990-1019): true = the node cannot hold a neighbour */
@@ -93,7 +96,27 @@ __device__ void uf_unite(int32_t *parent, int a, int b)
     }
 }
 
-__global__ __launch_bounds__(256) void fof_link_kernel(long long nt, FofTree t, double linkl, int32_t *parent)
+/* Nodes whose cube diagonal is at most the linking length are cliques: every particle inside is a friend of every other.
+ * fof_clique_kernel unites each top-most clique node's particles once; the walk then treats such a node as one unit — the first
+ * of its particles found within the linking length links the target to all of them — which is what keeps the caustic of the
+ * S-cluster (thousands of friends per particle) from costing a pair test per friend. */
+__global__ void fof_clique_kernel(long long nt, FofTree t, const int32_t *pfather, const double4 *cen, int32_t *parent)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= nt)
+        return;
+    const int i = t.leaf_pidx[k];
+    int bn = t.order[pfather[i]]; /* the particle's leaf, in the build's numbering */
+    if(!(cen[bn].w <= t.clique_len))
+        return;
+    for(int pa = t.parent[bn]; pa >= 0 && cen[pa].w <= t.clique_len; pa = t.parent[bn])
+        bn = pa; /* the top-most clique node above the particle */
+    const int first = t.leaf_pidx[t.lo[bn]];
+    if(first != i)
+        uf_unite(parent, first, i);
+}
+
+__global__ __launch_bounds__(256) void fof_link_kernel(long long nt, FofTree t, double linkl, int32_t *parent, int nn)
 {
     const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if(k >= nt)
@@ -102,19 +125,39 @@ __global__ __launch_bounds__(256) void fof_link_kernel(long long nt, FofTree t, 
     const double4 p = t.posm_leaf[k];
     const double h2 = linkl * linkl;
     int no = 0;
+    int cend = -1, cskip = -1; /* inside a clique node: pool records [.., cend) are its sub-tree, cskip is where the walk goes on after it */
     while(no >= 0) {
+        if(no >= cend)
+            cend = -1;
         const NodeC c = t.C[no];
-        if(c.type == SHQ_PSEUDO_NODE_TYPE || cull(t.B[no], p, linkl, t.Box)) {
+        const NodeB b = t.B[no];
+        if(c.type == SHQ_PSEUDO_NODE_TYPE || cull(b, p, linkl, t.Box)) {
             no = c.sibling;
             continue;
         }
+        if(cend < 0 && b.len <= t.clique_len) { /* a clique: ONE friend inside is enough; its sub-tree is searched, not listed */
+            cend = c.sibling >= 0 ? c.sibling : nn;
+            cskip = c.sibling;
+        }
         if(c.type == SHQ_PARTICLE_NODE_TYPE) {
+            bool hit = false;
             for(int s = c.child; s < c.child + c.count; s++) {
                 const int j = t.leaf_pidx[s];
-                if(i <= j && ngb_r2(p, t.posm_leaf[s], t.Box) <= h2) /* fof_primary_ngbiter: lv->target <= other */
+                /* the neighbour test of treewalk_visit_ngbiter, treewalk.c:946-961; outside cliques a pair is united by its lower
+                 * index (fof_primary_ngbiter: lv->target <= other) */
+                if((cend >= 0 || i <= j) && ngb_r2(p, t.posm_leaf[s], t.Box) <= h2) {
                     uf_unite(parent, i, j);
+                    if(cend >= 0) {
+                        hit = true;
+                        break;
+                    }
+                }
             }
-            no = c.sibling;
+            if(hit) {
+                no = cskip;
+                cend = -1;
+            } else
+                no = c.sibling;
         } else
             no = c.child;
     }
@@ -137,7 +180,7 @@ __global__ void fof_minid_kernel(long long nt, const int32_t *leaf_pidx, int32_t
         return;
     const int i = leaf_pidx[k];
     const int r = uf_find(parent, i);
-    if(r != i)
+    if(r != i && ids[i] < ((volatile unsigned long long *) minid)[r]) /* a group of millions has one root: only improvements go to the atomic */
         atomicMin(&minid[r], ids[i]);
 }
 
@@ -265,36 +308,33 @@ __global__ void fof_partgrnr_kernel(long long n, const int32_t *idx, const int32
     part_grnr[idx[k]] = keep[r] ? grnr[keptidx_excl[r]] : -1;
 }
 
-/* add_particle_to_group over the members in sorted (= particle index) order, then fof_finish_group_properties */
-__global__ __launch_bounds__(64) void fof_props_kernel(long long ng, const int32_t *gstart, const int32_t *glen, const int32_t *grnr, const int32_t *idx,
-                                                       const unsigned long long *keys, const double4 *posm, const double *vel, const uint8_t *pflags,
-                                                       const double *density, const double *delaytime, int winds_decouple, double Box,
-                                                       shq_fof_group *out)
+struct FofSums {
+    int Length;
+    int LenType[6];
+    double MassType[6], Mass, CM[3], Vel[3], Imom[3][3], Jmom[3], MaxDens;
+    int seed_index;
+};
+
+struct FofPropArgs {
+    const int32_t *gstart, *glen, *grnr, *idx;
+    const unsigned long long *keys;
+    const double4 *posm;
+    const double *vel;
+    const uint8_t *pflags;
+    const double *density, *delaytime;
+    int winds_decouple;
+    double Box;
+    shq_fof_group *out;
+};
+
+/* add_particle_to_group (fof.cpp:583-655) over the sorted positions [k0, k1) */
+__device__ void fof_accumulate(FofSums &G, int k0, int k1, const double first[3], const FofPropArgs &a)
 {
 #pragma clang fp contract(off)
-    const long long g = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if(g >= ng)
-        return;
-    shq_fof_group G;
-    memset(&G, 0, sizeof(G));
-    const int s0 = gstart[g], len = glen[g];
-    G.MinID = keys[s0];
-    G.GrNr = grnr[g];
-    G.seed_index = -1;
-    G.first_member = 0;
-    double first[3];
-    {
-        const double4 q = posm[idx[s0]];
-        G.FirstPos[0] = (float) q.x;
-        G.FirstPos[1] = (float) q.y;
-        G.FirstPos[2] = (float) q.z;
-        for(int d = 0; d < 3; d++)
-            first[d] = (double) G.FirstPos[d];
-    }
-    for(int k = s0; k < s0 + len; k++) {
-        const int i = idx[k];
-        const double4 q = posm[i];
-        const unsigned type = pflags[i] >> 4;
+    for(int k = k0; k < k1; k++) {
+        const int i = a.idx[k];
+        const double4 q = a.posm[i];
+        const unsigned type = a.pflags[i] >> 4;
         const double m = q.w;
         G.Length++;
         G.Mass += m;
@@ -302,17 +342,17 @@ __global__ __launch_bounds__(64) void fof_props_kernel(long long ng, const int32
             G.LenType[type]++;
             G.MassType[type] += m;
         }
-        if(type == 0 && density && !(winds_decouple && delaytime && delaytime[i] > 0))
-            if(density[i] > G.MaxDens) {
-                G.MaxDens = density[i];
+        if(type == 0 && a.density && !(a.winds_decouple && a.delaytime && a.delaytime[i] > 0))
+            if(a.density[i] > G.MaxDens) {
+                G.MaxDens = a.density[i];
                 G.seed_index = i;
             }
         const double pos[3] = {q.x, q.y, q.z};
         double rel[3], xyz[3], v[3], jm[3];
         for(int d = 0; d < 3; d++) {
-            rel[d] = nearest(pos[d] - first[d], Box);
+            rel[d] = nearest(pos[d] - first[d], a.Box);
             xyz[d] = rel[d] + first[d];
-            v[d] = vel ? vel[3 * (long long) i + d] : 0.0;
+            v[d] = a.vel ? a.vel[3 * (long long) i + d] : 0.0;
         }
         jm[0] = rel[1] * v[2] - v[1] * rel[2]; /* crossproduct, densitykernel.h:63-75 */
         jm[1] = rel[2] * v[0] - v[2] * rel[0];
@@ -325,17 +365,66 @@ __global__ __launch_bounds__(64) void fof_props_kernel(long long ng, const int32
                 G.Imom[d1][d2] += m * rel[d1] * rel[d2];
         }
     }
+}
+
+/* Group::reduce, fof.h:85-119 */
+__device__ void fof_reduce(FofSums &G, const FofSums &s)
+{
+#pragma clang fp contract(off)
+    G.Length += s.Length;
+    G.Mass += s.Mass;
+    for(int j = 0; j < 6; j++) {
+        G.LenType[j] += s.LenType[j];
+        G.MassType[j] += s.MassType[j];
+    }
+    if(s.MaxDens > G.MaxDens) {
+        G.MaxDens = s.MaxDens;
+        G.seed_index = s.seed_index;
+    }
+    for(int d1 = 0; d1 < 3; d1++) {
+        G.CM[d1] += s.CM[d1];
+        G.Vel[d1] += s.Vel[d1];
+        G.Jmom[d1] += s.Jmom[d1];
+        for(int d2 = 0; d2 < 3; d2++)
+            G.Imom[d1][d2] += s.Imom[d1][d2];
+    }
+}
+
+/* fof_finish_group_properties (fof.cpp:657-705) and the output record */
+__device__ void fof_finish(const FofSums &S, long long g, const double first[3], const float firstf[3], const FofPropArgs &a)
+{
+#pragma clang fp contract(off)
+    shq_fof_group G;
+    memset(&G, 0, sizeof(G));
+    G.MinID = a.keys[a.gstart[g]];
+    G.GrNr = a.grnr[g];
+    G.Length = S.Length;
+    G.seed_index = S.seed_index;
+    G.MaxDens = S.MaxDens;
+    G.Mass = S.Mass;
+    for(int j = 0; j < 6; j++) {
+        G.LenType[j] = S.LenType[j];
+        G.MassType[j] = S.MassType[j];
+    }
+    for(int d = 0; d < 3; d++) {
+        G.FirstPos[d] = firstf[d];
+        G.CM[d] = S.CM[d];
+        G.Vel[d] = S.Vel[d];
+        G.Jmom[d] = S.Jmom[d];
+        for(int d2 = 0; d2 < 3; d2++)
+            G.Imom[d][d2] = S.Imom[d][d2];
+    }
     double cm[3], rel[3], vcm[3], jcm[3];
     for(int d = 0; d < 3; d++) {
         G.Vel[d] /= G.Mass;
         vcm[d] = G.Vel[d];
         cm[d] = G.CM[d] / G.Mass;
-        rel[d] = nearest(cm[d] - first[d], Box);
+        rel[d] = nearest(cm[d] - first[d], a.Box);
         int guard = 0;
-        while(cm[d] >= Box && guard++ < 64) /* fof_periodic_wrap */
-            cm[d] -= Box;
+        while(cm[d] >= a.Box && guard++ < 64) /* fof_periodic_wrap */
+            cm[d] -= a.Box;
         while(cm[d] < 0 && guard++ < 64)
-            cm[d] += Box;
+            cm[d] += a.Box;
         G.CM[d] = cm[d];
     }
     jcm[0] = rel[1] * vcm[2] - vcm[1] * rel[2];
@@ -348,7 +437,76 @@ __global__ __launch_bounds__(64) void fof_props_kernel(long long ng, const int32
             const double diff = rel[d1] * rel[d2];
             G.Imom[d1][d2] -= G.Mass * diff;
         }
-    out[g] = G;
+    a.out[g] = G;
+}
+
+constexpr int FOF_BIG = 4096; /* groups longer than this are summed by a workgroup */
+
+__device__ __forceinline__ void fof_first(long long g, const FofPropArgs &a, double first[3], float firstf[3])
+{
+    const double4 q = a.posm[a.idx[a.gstart[g]]];
+    firstf[0] = (float) q.x;
+    firstf[1] = (float) q.y;
+    firstf[2] = (float) q.z;
+    for(int d = 0; d < 3; d++)
+        first[d] = (double) firstf[d];
+}
+
+/* groups up to FOF_BIG members: one thread each, members in sorted (= particle index) order — the reference's loop, fof.cpp:843-850 */
+__global__ __launch_bounds__(64) void fof_props_kernel(long long ng, const FofPropArgs a)
+{
+    const long long g = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(g >= ng || a.glen[g] > FOF_BIG)
+        return;
+    FofSums S;
+    memset(&S, 0, sizeof(S));
+    S.seed_index = -1;
+    double first[3];
+    float firstf[3];
+    fof_first(g, a, first, firstf);
+    fof_accumulate(S, a.gstart[g], a.gstart[g] + a.glen[g], first, a);
+    fof_finish(S, g, first, firstf, a);
+}
+
+/* longer groups: 256 threads sum 256 consecutive slices of the member list, thread 0 adds the partial groups in slice order with
+ * Group::reduce — the way the reference adds the parts of a group that lies on several tasks.  Deterministic; differs from the
+ * one-thread order by rounding only. */
+__global__ __launch_bounds__(256) void fof_props_big_kernel(int nbig, const int32_t *biglist, const FofPropArgs a)
+{
+    __shared__ FofSums part[256];
+    const long long g = biglist[blockIdx.x];
+    double first[3];
+    float firstf[3];
+    fof_first(g, a, first, firstf);
+    const long long s0 = a.gstart[g], len = a.glen[g];
+    const long long chunk = (len + 255) / 256;
+    const long long k0 = s0 + chunk * threadIdx.x, k1 = k0 + chunk < s0 + len ? k0 + chunk : s0 + len;
+    FofSums S;
+    memset(&S, 0, sizeof(S));
+    S.seed_index = -1;
+    if(k0 < k1)
+        fof_accumulate(S, (int) k0, (int) k1, first, a);
+    part[threadIdx.x] = S;
+    __syncthreads();
+    if(threadIdx.x == 0) {
+        FofSums T = part[0];
+        for(int t = 1; t < 256; t++)
+            fof_reduce(T, part[t]);
+        fof_finish(T, g, first, firstf, a);
+    }
+}
+
+__global__ void fof_bigflag_kernel(long long ng, const int32_t *glen, int32_t *flag)
+{
+    const long long g = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(g < ng)
+        flag[g] = glen[g] > FOF_BIG ? 1 : 0;
+}
+__global__ void fof_biglist_kernel(long long ng, const int32_t *flag, const int32_t *excl, int32_t *list)
+{
+    const long long g = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(g < ng && flag[g])
+        list[excl[g]] = (int32_t) g;
 }
 
 /* members of the kept groups, group after group */
@@ -417,7 +575,8 @@ extern "C" int shq_fof(shq_context *ctx, const shq_fof_params *fp, const uint64_
     /* the tree of the primary types (fof.cpp:176-178) */
     SHQ_TRY(shq_tree_build(ctx, fp->BoxSize, fp->PrimaryLinkTypes, nullptr, 0, nullptr));
     const long long nt = ctx->ntreeparts;
-    FofTree t = {ctx->nodeB.ptr, ctx->nodeC.ptr, ctx->posm_leaf.ptr, ctx->leaf_pidx.ptr, fp->BoxSize};
+    FofTree t = {ctx->nodeB.ptr, ctx->nodeC.ptr, ctx->posm_leaf.ptr, ctx->leaf_pidx.ptr, fp->BoxSize, ctx->tb.order[1].ptr, ctx->tb.lo.ptr, ctx->tb.hi.ptr,
+                 ctx->tb.parent.ptr, fp->LinkingLength / 1.7320508075688774 * (1 - 1e-12)};
 
     const size_t cap = (size_t) n;
     SHQ_TRY(ctx->fof_parent.reserve(cap));
@@ -430,7 +589,8 @@ extern "C" int shq_fof(shq_context *ctx, const shq_fof_params *fp, const uint64_
     SHQ_HIP(hipMemcpyAsync(d_ids, ids, sizeof(uint64_t) * cap, hipMemcpyHostToDevice, st));
     fof_init_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, ctx->fof_parent.ptr, d_ids, d_minid, d_label);
     if(nt > 0) {
-        fof_link_kernel<<<dim3(nblk(nt)), dim3(256), 0, st>>>(nt, t, fp->LinkingLength, ctx->fof_parent.ptr);
+        fof_clique_kernel<<<dim3(nblk(nt)), dim3(256), 0, st>>>(nt, t, ctx->pfather.ptr, ctx->tb.cen.ptr, ctx->fof_parent.ptr);
+        fof_link_kernel<<<dim3(nblk(nt)), dim3(256), 0, st>>>(nt, t, fp->LinkingLength, ctx->fof_parent.ptr, (int) ctx->numnodes);
         fof_minid_kernel<<<dim3(nblk(nt)), dim3(256), 0, st>>>(nt, ctx->leaf_pidx.ptr, ctx->fof_parent.ptr, d_ids, d_minid);
         fof_label_kernel<<<dim3(nblk(nt)), dim3(256), 0, st>>>(nt, ctx->leaf_pidx.ptr, ctx->fof_parent.ptr, d_minid, d_label);
     }
@@ -508,8 +668,25 @@ extern "C" int shq_fof(shq_context *ctx, const shq_fof_params *fp, const uint64_
         const double *d_vel = (ctx->have_sph || ctx->have_dyn) ? ctx->vel.ptr : nullptr;
         const double *d_dens = ctx->have_sph ? ctx->g_density.ptr : nullptr;
         const double *d_delay = ctx->have_sph ? ctx->g_delaytime.ptr : nullptr;
-        fof_props_kernel<<<dim3(nblk(ng, 64)), dim3(64), 0, st>>>(ng, d_gstart, d_glen, d_grnr, d_idx, d_keys, ctx->posm.ptr, d_vel, ctx->pflags.ptr, d_dens, d_delay,
-                                                                  fp->WindsDecoupleSph, fp->BoxSize, ctx->fof_groups.ptr);
+        const FofPropArgs pa = {d_gstart, d_glen, d_grnr, d_idx, d_keys, ctx->posm.ptr, d_vel, ctx->pflags.ptr, d_dens, d_delay, fp->WindsDecoupleSph, fp->BoxSize,
+                                ctx->fof_groups.ptr};
+        fof_props_kernel<<<dim3(nblk(ng, 64)), dim3(64), 0, st>>>(ng, pa);
+        {
+            /* the long groups: a list of their numbers, one workgroup each */
+            int32_t *d_flag = ctx->fof_g32[3].ptr, *d_excl = ctx->fof_g32[4].ptr; /* the GrNr sort is done with them */
+            SHQ_TRY(ctx->fof_biglist.reserve(gcap + 1));
+            fof_bigflag_kernel<<<dim3(nblk(ng)), dim3(256), 0, st>>>(ng, d_glen, d_flag);
+            SHQ_TRY(scan_excl(ctx, (const int32_t *) d_flag, d_excl, (size_t) ng));
+            int32_t lastf = 0, laste = 0;
+            SHQ_HIP(hipMemcpyAsync(&lastf, d_flag + (ng - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            SHQ_HIP(hipMemcpyAsync(&laste, d_excl + (ng - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            SHQ_HIP(hipStreamSynchronize(st));
+            const int nbig = lastf + laste;
+            if(nbig > 0) {
+                fof_biglist_kernel<<<dim3(nblk(ng)), dim3(256), 0, st>>>(ng, d_flag, d_excl, ctx->fof_biglist.ptr);
+                fof_props_big_kernel<<<dim3((unsigned) nbig), dim3(256), 0, st>>>(nbig, ctx->fof_biglist.ptr, pa);
+            }
+        }
         fof_glen64_kernel<<<dim3(nblk(ng)), dim3(256), 0, st>>>(ng, d_glen, ctx->fof_goff[0].ptr);
         SHQ_HIP(hipMemsetAsync(ctx->fof_goff[0].ptr + ng, 0, sizeof(long long), st));
         SHQ_TRY(scan_excl(ctx, (const long long *) ctx->fof_goff[0].ptr, ctx->fof_goff[1].ptr, (size_t) ng + 1));

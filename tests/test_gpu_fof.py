@@ -121,6 +121,36 @@ def test_fof_clustered_mixed_types_equals_oracle(ctx, seed):
     assert max(g["Length"] for g in groups) > 300
 
 
+def test_fof_long_group_is_summed_by_a_workgroup(ctx):
+    """a group of more than 4096 members: 256 slices of the member list summed in parallel and reduced in slice order (as the
+    reference reduces the parts of a group spread over tasks): integers exact, sums to rounding"""
+    rng = np.random.default_rng(9)
+    box = 500.0
+    blob = 250 + rng.normal(size=(9000, 3)) * 4.0
+    pos = np.mod(np.concatenate([blob, rng.random((3000, 3)) * box]), box)
+    n = len(pos)
+    ids = rng.permutation(n).astype(np.uint64) + 1
+    vel = rng.normal(size=(n, 3)) * 50
+    mass = rng.choice([1.0, 0.5], size=n)
+    types = np.ones(n, dtype=np.uint8)
+    minid, grnr, groups, members, massd = gpu_fof(ctx, pos, vel, mass, types, ids, box, 1.0, 8)
+    ominid, ogroups, ogrnr = ofof.fof(pos, vel, massd, types, ids, np.zeros(n, dtype=bool), np.zeros(n), box, 1.0, 8)
+    assert np.array_equal(minid, ominid) and np.array_equal(grnr, ogrnr) and len(groups) == len(ogroups)
+    big = 0
+    for g, o in zip(groups, ogroups):
+        assert g["MinID"] == o["MinID"] and g["Length"] == o["Length"] and g["GrNr"] == o["GrNr"] and list(g["LenType"]) == o["LenType"]
+        if g["Length"] > 4096:
+            big += 1
+            scale = {"CM": box, "Vel": 50.0, "Jmom": 50.0 * 4.0 * g["Mass"], "Imom": 16.0 * g["Mass"]}
+            assert abs(g["Mass"] - o["Mass"]) < 1e-12 * o["Mass"]
+            for f in ("CM", "Vel", "Jmom", "Imom"):
+                assert np.abs(g[f] - o[f]).max() < 1e-11 * scale[f], f
+        else:
+            for f in ("CM", "Vel", "Jmom", "Imom"):
+                assert np.array_equal(g[f], o[f]), f
+    assert big == 1
+
+
 def test_fof_requires_run_and_handles_empty_and_no_groups(ctx):
     rng = np.random.default_rng(4)
     pos = rng.random((500, 3)) * cm.BOX
