@@ -210,12 +210,9 @@ __device__ __forceinline__ void count_titype(int titype, unsigned long long *out
  * The tallies are 64-bit atomics into a handful of slots: a few per particle at most, and the loops are far from the step's
  * critical path (one pass over 16.8 M particles moves 60 B each). */
 template <int MODE>
-__global__ __launch_bounds__(256) void timestep_kernel(const TsArgs a)
+__device__ void timestep_body(const TsArgs &a, const long long t)
 {
 #pragma clang fp contract(off)
-    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if(t >= a.nt)
-        return;
     const long long i = a.targets ? (long long) a.targets[t] : t;
     const unsigned f = a.pflags[i];
     if(f & 3u)
@@ -325,6 +322,38 @@ __global__ __launch_bounds__(256) void timestep_kernel(const TsArgs a)
                 atomicAdd(&a.out[O_NBADBIN], 1ull);
             }
         }
+    }
+}
+
+/* The tallies of a workgroup go to a copy of the result slots in LDS first and from there with one global atomic per slot: with
+ * every thread on the same dozen global addresses the first version of this kernel took 207 ms at 256^3 (rocprofv3, round 2); the
+ * loop itself moves ~60 B per particle. */
+__device__ __forceinline__ bool slot_is_min(int k) { return k == O_MIN || k == O_DTIMIN; }
+__device__ __forceinline__ bool slot_is_max(int k) { return k == O_MAX || k == O_MAXDYN; }
+
+template <int MODE>
+__global__ __launch_bounds__(256) void timestep_kernel(TsArgs a)
+{
+    __shared__ unsigned long long sh[O_END];
+    for(int k = threadIdx.x; k < O_END; k += blockDim.x)
+        sh[k] = k == O_MIN ? (unsigned long long) (long long) TB : (k == O_DTIMIN ? (unsigned long long) TIMEBASE : 0ull);
+    __syncthreads();
+    unsigned long long *const gout = a.out;
+    a.out = sh;
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t < a.nt)
+        timestep_body<MODE>(a, t);
+    __syncthreads();
+    for(int k = threadIdx.x; k < O_END; k += blockDim.x) {
+        const unsigned long long v = sh[k];
+        if(slot_is_min(k)) {
+            if((long long) v < (k == O_MIN ? (long long) TB : (long long) TIMEBASE))
+                atomicMin((long long *) &gout[k], (long long) v);
+        } else if(slot_is_max(k)) {
+            if((long long) v > 0)
+                atomicMax((long long *) &gout[k], (long long) v);
+        } else if(v)
+            atomicAdd(&gout[k], v);
     }
 }
 
