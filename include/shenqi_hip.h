@@ -408,6 +408,37 @@ int shq_timebins_download(shq_context *ctx, uint8_t *bin_gravity, uint8_t *bin_h
  * run of this context (NULL keeps it; gas particles only are read). */
 int shq_maxsignalvel_upload(shq_context *ctx, const double *maxsignalvel_by_particle);
 
+/* Particle exchange between tasks on opaque records (ExchangePlan, libgadget/exchange.hpp:31-537).
+ * The arrays are the reference's own — particle_data[MaxPart] and the per-type slot arrays — through pointers the device can
+ * read and write (shenqi allocates them managed; a port keeps them in HBM); records are copied as bytes, the library reads only
+ * the flag byte, Type, PI and the slots' ReverseLink.  The collectives between the phases are the caller's.
+ *   shq_exchange_plan   build_exchange_list (:158-176) + the counting half of build_export_buffer (:178-204): particles whose
+ *                       d_target (layoutfunc, one int per particle) names another task, in index order, garbage / swallowed ones
+ *                       excluded; the first min(nexchange, maxlast) of them (maxlast <= 0: all; find_iter_space is the caller's
+ *                       memory policy) are counted into toGo[task] = {base, slots[6]}.
+ *   shq_exchange_pack   the pack loop of exchange_once (:369-392): per target task the base records in list order into
+ *                       d_partbuf at toGoOffset[task].base, the slot records of every enabled type in the same order into
+ *                       d_slotbuf[type] at toGoOffset[task].slots[type]; then slots_mark_garbage on the source (IsGarbage,
+ *                       ReverseLink = MaxPart + 100).
+ *   shq_exchange_unpack after the caller's alltoallv put the arrivals behind NumPart / behind each slot array's size: PI of
+ *                       every arrival renumbered in arrival order per source task and type (:483-511).
+ * The slot compaction the reference may interleave (slots_gc when memory is short) stays with the caller. */
+typedef struct shq_exchange_layout {
+    size_t part_elsize, off_flags, off_type, off_pi;
+    size_t slot_elsize[6];      /* 0: slot type not enabled */
+    size_t off_reverselink;     /* particle_data_ext::ReverseLink, first member of every slot struct */
+} shq_exchange_layout;
+typedef struct shq_exchange_entry {   /* ExchangePlanEntry, exchange.hpp:18-21 */
+    int64_t base;
+    int64_t slots[6];
+} shq_exchange_entry;
+int shq_exchange_plan(shq_context *ctx, const shq_exchange_layout *layout, const void *d_parts, int64_t numpart, const int32_t *d_target,
+                      int ThisTask, int NTask, int64_t maxlast, int64_t *nexchange, int64_t *last, shq_exchange_entry *toGo);
+int shq_exchange_pack(shq_context *ctx, const shq_exchange_layout *layout, void *d_parts, void *const d_slots[6], int64_t MaxPart,
+                      const shq_exchange_entry *toGoOffset, int NTask, void *d_partbuf, void *const d_slotbuf[6]);
+int shq_exchange_unpack(shq_context *ctx, const shq_exchange_layout *layout, void *d_parts, int64_t numpart_old, const int64_t slot_size_old[6],
+                        const shq_exchange_entry *toGet, const shq_exchange_entry *toGetOffset, int NTask);
+
 /* Friends-of-friends groups of the resident particles (the first legacy-API user: libgadget/fof.cpp, one task).
  *   fof_label_primary (:368-581): particles of the primary types within LinkingLength of each other (r2 <= L^2, the neighbour
  *       test of treewalk_visit_ngbiter, treewalk.c:946-961) are one group; the reference's lock-free union-find (fofp_merge,

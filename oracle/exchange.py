@@ -1,0 +1,107 @@
+"""CPU restatement (numpy) of the reference's particle exchange between tasks, all tasks in one process.
+
+TEST INFRASTRUCTURE ONLY.  Follows /root/reference/libgadget/exchange.hpp:
+  build_exchange_list      :158-176   particles whose layoutfunc names another task, in index order, garbage / swallowed excluded
+  build_export_buffer      :178-240   toGo / toGet per (task, type), offsets in task order
+  exchange_once            :334-535   pack in list order (slot first, then the base record), slots_mark_garbage on the source,
+                                       received particles appended after NumPart in source-task order, slots appended per type,
+                                       PI of every received particle renumbered in arrival order
+  slots_mark_garbage       slotsmanager.cpp:590-599
+The garbage collection the reference may run between pack and receive (slots_gc, when memory is short) is not restated: the
+arrays here are sized so that it is never needed, as in the reference's own tests/test_exchange.cpp, whose four cases
+(tests/test_exchange_cpu.py) pin this file."""
+import numpy as np
+
+
+class Task:
+    """one task's particle and slot arrays (structured numpy arrays with at least Flags, Type, PI / ReverseLink)"""
+
+    def __init__(self, parts, numpart, slots, slot_size):
+        self.parts, self.numpart = parts, int(numpart)
+        self.slots = slots                      # list of 6 arrays or None (type not enabled)
+        self.slot_size = [int(x) for x in slot_size]
+
+    @property
+    def maxpart(self):
+        return len(self.parts)
+
+
+def build_exchange_list(task, target, thistask):
+    P = task.parts[:task.numpart]
+    dead = (P["Flags"] & 3) != 0
+    t = np.asarray(target[:task.numpart])
+    return np.flatnonzero(~dead & (t != thistask) & (t >= 0)).astype(np.int64)
+
+
+def counts(task, lst, target, ntask):
+    """toGo[target] = (base, slots[6])"""
+    togo = np.zeros((ntask, 7), dtype=np.int64)
+    for i in lst:
+        togo[target[i], 0] += 1
+        togo[target[i], 1 + int(task.parts["Type"][i])] += 1
+    return togo
+
+
+def offsets(c):
+    """exclusive prefix over tasks, exchange.hpp:206-224"""
+    off = np.zeros_like(c)
+    off[1:] = np.cumsum(c[:-1], axis=0)
+    return off
+
+
+def domain_exchange(tasks, targets):
+    """one iteration of ExchangePlan::domain_exchange for all tasks at once (enough room everywhere, so `last == nexchange`).
+    tasks: list of Task, targets: list of per-particle target arrays.  Modifies the tasks in place."""
+    ntask = len(tasks)
+    lists = [build_exchange_list(tasks[r], targets[r], r) for r in range(ntask)]
+    togo = [counts(tasks[r], lists[r], targets[r], ntask) for r in range(ntask)]
+    toget = [np.stack([togo[src][r] for src in range(ntask)]) for r in range(ntask)]          # MPI_Alltoall of the entries
+    partbuf, slotbuf = [], []
+    for r in range(ntask):
+        T = tasks[r]
+        off = offsets(togo[r])
+        pb = np.zeros(int(togo[r][:, 0].sum()), dtype=T.parts.dtype)
+        sb = [None if T.slots[t] is None else np.zeros(int(togo[r][:, 1 + t].sum()), dtype=T.slots[t].dtype) for t in range(6)]
+        ptr = np.zeros((ntask, 7), dtype=np.int64)
+        for i in lists[r]:
+            tgt = int(targets[r][i])
+            ty = int(T.parts["Type"][i])
+            bufpi = ptr[tgt, 1 + ty]
+            ptr[tgt, 1 + ty] += 1
+            if T.slots[ty] is not None:
+                sb[ty][bufpi + off[tgt, 1 + ty]] = T.slots[ty][T.parts["PI"][i]]
+            pb[off[tgt, 0] + ptr[tgt, 0]] = T.parts[i]
+            ptr[tgt, 0] += 1
+            # slots_mark_garbage
+            T.parts["Flags"][i] |= 1
+            if T.slots[ty] is not None:
+                T.slots[ty]["ReverseLink"][T.parts["PI"][i]] = T.maxpart + 100
+        partbuf.append(pb)
+        slotbuf.append(sb)
+    for r in range(ntask):
+        T = tasks[r]
+        goff = offsets(toget[r])
+        newnum = T.numpart + int(toget[r][:, 0].sum())
+        assert newnum <= T.maxpart, "NumPart > MaxPart"
+        for src in range(ntask):
+            soff = offsets(togo[src])
+            nb = int(toget[r][src, 0])
+            T.parts[T.numpart + goff[src, 0]:T.numpart + goff[src, 0] + nb] = partbuf[src][soff[r, 0]:soff[r, 0] + nb]
+            for t in range(6):
+                if T.slots[t] is None:
+                    continue
+                ns = int(toget[r][src, 1 + t])
+                assert T.slot_size[t] + goff[src, 1 + t] + ns <= len(T.slots[t]), "slot array too small"
+                T.slots[t][T.slot_size[t] + goff[src, 1 + t]:T.slot_size[t] + goff[src, 1 + t] + ns] = slotbuf[src][t][soff[r, 1 + t]:soff[r, 1 + t] + ns]
+        # PI of the arrivals, exchange.hpp:483-511
+        for src in range(ntask):
+            newpi = [T.slot_size[t] + int(goff[src, 1 + t]) for t in range(6)]
+            for i in range(T.numpart + int(goff[src, 0]), T.numpart + int(goff[src, 0]) + int(toget[r][src, 0])):
+                ty = int(T.parts["Type"][i])
+                T.parts["PI"][i] = newpi[ty]
+                newpi[ty] += 1
+        T.numpart = newnum
+        for t in range(6):
+            if T.slots[t] is not None:
+                T.slot_size[t] += int(toget[r][:, 1 + t].sum())
+    return lists, togo, toget

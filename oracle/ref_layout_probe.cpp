@@ -58,7 +58,9 @@ int main()
     memset(&P, 0, sizeof(P));
     P.Swallowed = 1;
     const int bit_swallowed = first_set_bit(&P, sizeof(P));
-    printf("{\"sizeof_particle_data\": %zu, \"sizeof_sph_particle_data\": %zu, \"sizeof_bh_particle_data\": %zu,\n", sizeof(particle_data),
+    printf("{\"sizeof_star_particle_data\": %zu, \"star_particle_data\": {\"ReverseLink\": %zu, \"Metals\": %zu, \"FormationTime\": %zu},\n",
+           sizeof(star_particle_data), offsetof(star_particle_data, ReverseLink), offsetof(star_particle_data, Metals), offsetof(star_particle_data, FormationTime));
+    printf(" \"sizeof_particle_data\": %zu, \"sizeof_sph_particle_data\": %zu, \"sizeof_bh_particle_data\": %zu,\n", sizeof(particle_data),
            sizeof(sph_particle_data), sizeof(bh_particle_data));
     printf(" \"part_view\": {\"elsize\": %zu, \"off_pos\": %zu, \"off_mass\": %zu, \"off_type\": %zu, \"off_flags\": %zu, \"off_pi\": %zu, \"off_vel\": %zu, "
            "\"off_treeacc\": %zu, \"off_gravpm\": %zu, \"off_potential\": %zu, \"off_hsml\": %zu, \"off_dthsml\": %zu, \"off_timebin_hydro\": %zu, "

@@ -204,6 +204,20 @@ def bh_dyn_view(BhP):
     return v
 
 
+class ExchangeLayout(C.Structure):
+    _fields_ = [("part_elsize", C.c_size_t), ("off_flags", C.c_size_t), ("off_type", C.c_size_t), ("off_pi", C.c_size_t),
+                ("slot_elsize", C.c_size_t * 6), ("off_reverselink", C.c_size_t)]
+
+
+class ExchangeEntry(C.Structure):
+    _fields_ = [("base", C.c_int64), ("slots", C.c_int64 * 6)]
+
+
+# struct star_particle_data, libgadget/slotsmanager.h:77-92 (72 B)
+STAR_DTYPE = np.dtype({"names": ["ReverseLink", "LastEnrichmentMyr", "TotalMassReturned", "Metallicity", "Metals", "VDisp", "BirthDensity", "FormationTime"],
+                       "formats": ["<i4", "<f4", "<f8", "<f8", ("<f4", 9), "<f4", "<f4", "<f4"], "offsets": [0, 4, 8, 16, 24, 60, 64, 68], "itemsize": 72})
+
+
 class FofParams(C.Structure):
     _fields_ = [("BoxSize", C.c_double), ("LinkingLength", C.c_double), ("PrimaryLinkTypes", C.c_int32), ("SecondaryLinkTypes", C.c_int32),
                 ("HaloMinLength", C.c_int32), ("WindsDecoupleSph", C.c_int32)]
@@ -346,6 +360,11 @@ hip.shq_ngb_toptree_exports.argtypes = [_vp, C.c_int, C.c_double, _vp, C.c_int64
 hip.shq_ngb_toptree_exports.restype = C.c_int
 hip.shq_set_walk_stats.argtypes = [_vp, C.c_int]
 hip.shq_set_walk_stats.restype = C.c_int
+hip.shq_exchange_plan.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.c_int64, _vp, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _vp]
+hip.shq_exchange_pack.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, _vp, C.c_int64, _vp, C.c_int, _vp, _vp]
+hip.shq_exchange_unpack.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.c_int64, _vp, _vp, _vp, C.c_int]
+for _f in ("shq_exchange_plan", "shq_exchange_pack", "shq_exchange_unpack"):
+    getattr(hip, _f).restype = C.c_int
 hip.shq_fof.argtypes = [_vp, C.POINTER(FofParams), _vp, _vp, _vp, C.POINTER(C.c_int64)]
 hip.shq_fof.restype = C.c_int
 hip.shq_fof_groups_download.argtypes = [_vp, _vp, C.c_int64]

@@ -294,6 +294,14 @@ struct shq_context {
     DevBuf<double> g_entropy, g_dtentropy, g_hydroaccel, g_delaytime;
     DevBuf<double> g_density, g_egywt, g_dhsmlegy, g_divvel, g_curlvel;
     DevBuf<double> g_hydroaccel_out, g_dtentropy_out, g_maxsignalvel;
+    /* particle exchange (exchange.hip) */
+    DevBuf<int32_t> ex_list, ex_val[3];
+    DevBuf<unsigned int> ex_key[4];
+    DevBuf<unsigned long long> ex_counts;
+    DevBuf<long long> ex_i64;
+    std::vector<shq_exchange_entry> ex_togo;
+    int64_t ex_last = -1;
+    int ex_ntask = 0;
     /* friends-of-friends (fof.hip) */
     DevBuf<int32_t> fof_parent, fof_i32[6], fof_g32[5], fof_partgrnr, fof_members, fof_biglist;
     DevBuf<unsigned long long> fof_u64[4];

@@ -1,0 +1,359 @@
+/* exchange.hip — the pack / unpack loops of the reference's particle exchange between tasks, on opaque records
+ * (libgadget/exchange.hpp).
+ *
+ *   build_exchange_list, build_export_buffer (counts)   exchange.hpp:158-204
+ *   exchange_once: pack loop, slots_mark_garbage        exchange.hpp:369-392, slotsmanager.cpp:590-599
+ *   exchange_once: PI of the arrivals                   exchange.hpp:483-511
+ *
+ * The reference packs with one serial loop ("watch out thread unsafe"): its buffer order is the exchange list's order inside
+ * every target task, for the base records and for each slot type.  Here the list comes from a stable select, the per-task and
+ * per-(task, type) positions from two stable radix sorts of the list (so the orders are the serial loop's), and records move as
+ * 16-byte words, a few lanes per record.  The buffers come out byte-identical to the serial loop's. */
+#include "common.hpp"
+#include <string.h>
+#include <vector>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+namespace {
+
+inline unsigned nblk(long long n, int t = 256) { return (unsigned) ((n + t - 1) / t); }
+
+struct Leaving {
+    const char *parts;
+    size_t elsize, off_flags;
+    const int32_t *target;
+    int thistask;
+    __device__ bool operator()(const int32_t i) const
+    {
+        const unsigned f = *(const unsigned char *) (parts + (size_t) i * elsize + off_flags);
+        const int t = target[i];
+        return !(f & 3u) && t != thistask && t >= 0;
+    }
+};
+
+/* keys of the first `last` list entries: task, and task * 6 + type; bad targets are flagged */
+__global__ void ex_keys_kernel(long long last, const int32_t *list, const char *parts, size_t elsize, size_t off_type, const int32_t *target, int ntask,
+                               unsigned int *key_task, unsigned int *key_tt, int32_t *val, unsigned long long *counts, int *err)
+{
+    const long long n = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(n >= last)
+        return;
+    const int i = list[n];
+    const int t = target[i];
+    const unsigned type = *(const unsigned char *) (parts + (size_t) i * elsize + off_type);
+    if(t >= ntask || t < 0 || type >= 6) {
+        *err = 1; /* "layoutfunc for %d returned unreasonable %d", exchange.hpp:196 */
+        key_task[n] = 0;
+        key_tt[n] = 0;
+        val[n] = (int32_t) n;
+        return;
+    }
+    key_task[n] = (unsigned) t;
+    key_tt[n] = (unsigned) t * 6u + type;
+    val[n] = (int32_t) n;
+}
+
+/* toGo from the (task, type)-sorted keys: the length of every run, by two binary searches (no atomics on a few dozen counters) */
+__global__ void ex_count_kernel(int nkeys, long long last, const unsigned int *key_tt_sorted, unsigned long long *counts)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= nkeys)
+        return;
+    long long lo[2];
+    for(int w = 0; w < 2; w++) {
+        const unsigned want = (unsigned) k + (unsigned) w;
+        long long a = 0, e = last;
+        while(a < e) {
+            const long long mid = a + ((e - a) >> 1);
+            if(key_tt_sorted[mid] < want)
+                a = mid + 1;
+            else
+                e = mid;
+        }
+        lo[w] = a;
+    }
+    const unsigned long long c = (unsigned long long) (lo[1] - lo[0]);
+    counts[(size_t) (k / 6) * 7 + 1 + (k % 6)] = c;
+    if(c)
+        atomicAdd(&counts[(size_t) (k / 6) * 7], c);
+}
+
+/* one record per `lanes` threads, 16 bytes per thread and pass */
+__global__ void ex_copy_base_kernel(long long last, const int32_t *order /* list positions sorted by task */, const int32_t *list, const char *parts,
+                                    size_t elsize, char *buf)
+{
+    const long long gid = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const int words = (int) (elsize / 16);
+    const long long rec = gid / words;
+    const int w = (int) (gid % words);
+    if(rec >= last)
+        return;
+    const int i = list[order[rec]];
+    const uint4 v = *reinterpret_cast<const uint4 *>(parts + (size_t) i * elsize + 16 * (size_t) w);
+    *reinterpret_cast<uint4 *>(buf + (size_t) rec * elsize + 16 * (size_t) w) = v;
+}
+
+struct SlotTab {
+    char *ptr[6];
+    char *buf[6];
+    size_t elsize[6];
+    long long off[6]; /* start of type t's run inside the (task, type)-sorted order, per target task: not needed — see below */
+};
+
+/* The (task, type)-sorted order lists, for every task, its type-0 entries, then type-1 ... ; the slot buffer of type ty holds
+ * task 0's type-ty entries, then task 1's ...: position in the buffer = toGoOffset[task].slots[ty] + rank inside the (task, ty)
+ * run, and the run starts are the exclusive prefix of the counts in (task, type) order. */
+__global__ void ex_copy_slot_kernel(long long last, const int32_t *order_tt, const unsigned int *key_tt_sorted, const long long *runstart /* [ntask * 6] */,
+                                    const long long *slotoff /* toGoOffset[task].slots[ty], [ntask * 6] */, const int32_t *list, const char *parts,
+                                    size_t elsize, size_t off_pi, SlotTab st)
+{
+    const long long pos = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(pos >= last)
+        return;
+    const unsigned k = key_tt_sorted[pos];
+    const int ty = (int) (k % 6u);
+    if(!st.elsize[ty])
+        return;
+    const int i = list[order_tt[pos]];
+    const int pi = *reinterpret_cast<const int32_t *>(parts + (size_t) i * elsize + off_pi);
+    const long long dst = slotoff[k] + (pos - runstart[k]);
+    const char *src = st.ptr[ty] + (size_t) pi * st.elsize[ty];
+    char *out = st.buf[ty] + (size_t) dst * st.elsize[ty];
+    for(size_t b = 0; b < st.elsize[ty]; b += 8) /* slot structs are 8-byte aligned and sized */
+        *reinterpret_cast<unsigned long long *>(out + b) = *reinterpret_cast<const unsigned long long *>(src + b);
+}
+
+/* slots_mark_garbage, slotsmanager.cpp:590-599 */
+__global__ void ex_mark_kernel(long long last, const int32_t *list, char *parts, size_t elsize, size_t off_flags, size_t off_type, size_t off_pi, SlotTab st,
+                               size_t off_rl, int reverselink)
+{
+    const long long n = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(n >= last)
+        return;
+    const int i = list[n];
+    char *p = parts + (size_t) i * elsize;
+    *(unsigned char *) (p + off_flags) |= 1u;
+    const unsigned ty = *(const unsigned char *) (p + off_type);
+    if(ty < 6 && st.elsize[ty]) {
+        const int pi = *reinterpret_cast<const int32_t *>(p + off_pi);
+        *reinterpret_cast<int32_t *>(st.ptr[ty] + (size_t) pi * st.elsize[ty] + off_rl) = reverselink;
+    }
+}
+
+/* PI of the arrivals of one source task: arrival k of type ty gets base[ty] + (number of type-ty arrivals before it) */
+__global__ void ex_types_kernel(long long n, const char *parts, size_t elsize, size_t off_type, long long first, unsigned int *key, int32_t *val)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    key[k] = *(const unsigned char *) (parts + (size_t) (first + k) * elsize + off_type);
+    val[k] = (int32_t) k;
+}
+__global__ void ex_pi_kernel(long long n, char *parts, size_t elsize, size_t off_pi, long long first, const unsigned int *key_sorted, const int32_t *order,
+                             const long long *typestart /* [6] start of each type's run in the sorted order */, const long long *newpi /* [6] */)
+{
+    const long long pos = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(pos >= n)
+        return;
+    const unsigned ty = key_sorted[pos];
+    if(ty >= 6)
+        return;
+    const long long k = order[pos];
+    *reinterpret_cast<int32_t *>(parts + (size_t) (first + k) * elsize + off_pi) = (int32_t) (newpi[ty] + (pos - typestart[ty]));
+}
+
+int check_layout(const shq_exchange_layout *l)
+{
+    SHQ_CHECK(l && l->part_elsize >= 16 && l->part_elsize % 16 == 0, SHQ_ERR_INVALID, "exchange: particle records must be a multiple of 16 bytes");
+    SHQ_CHECK(l->off_flags < l->part_elsize && l->off_type < l->part_elsize && l->off_pi + 4 <= l->part_elsize && l->off_pi % 4 == 0, SHQ_ERR_INVALID,
+              "exchange: field offsets outside the particle record");
+    for(int t = 0; t < 6; t++)
+        SHQ_CHECK(l->slot_elsize[t] % 8 == 0 && (l->slot_elsize[t] == 0 || l->off_reverselink + 4 <= l->slot_elsize[t]), SHQ_ERR_INVALID,
+                  "exchange: slot type %d: record size %zu must be a multiple of 8 and hold ReverseLink", t, l->slot_elsize[t]);
+    return SHQ_OK;
+}
+
+template <typename K> int sort_pairs(shq_context *ctx, const K *kin, K *kout, const int32_t *vin, int32_t *vout, size_t n, int bits)
+{
+    size_t tmp = 0;
+    SHQ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0, bits, ctx->stream));
+    SHQ_TRY(ctx->act_temp.reserve(tmp + 16));
+    SHQ_HIP(rocprim::radix_sort_pairs((void *) ctx->act_temp.ptr, tmp, kin, kout, vin, vout, n, 0, bits, ctx->stream));
+    return SHQ_OK;
+}
+
+int bits_for(unsigned long long maxkey)
+{
+    int b = 1;
+    while(b < 32 && (1ull << b) <= maxkey)
+        b++;
+    return b;
+}
+
+} // namespace
+
+extern "C" int shq_exchange_plan(shq_context *ctx, const shq_exchange_layout *layout, const void *d_parts, int64_t numpart, const int32_t *d_target,
+                                 int ThisTask, int NTask, int64_t maxlast, int64_t *nexchange, int64_t *last_out, shq_exchange_entry *toGo)
+{
+    SHQ_CHECK(ctx && d_parts && d_target && toGo, SHQ_ERR_INVALID, "null argument");
+    SHQ_TRY(check_layout(layout));
+    SHQ_CHECK(NTask >= 1 && ThisTask >= 0 && ThisTask < NTask && numpart >= 0 && numpart < (1ll << 31) - 64, SHQ_ERR_INVALID, "exchange_plan: bad task / particle numbers");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    ctx->ex_last = -1;
+    memset(toGo, 0, sizeof(shq_exchange_entry) * (size_t) NTask);
+    const size_t cap = (size_t) std::max<int64_t>(numpart, 1);
+    SHQ_TRY(ctx->ex_list.reserve(cap));
+    SHQ_TRY(ctx->ex_counts.reserve((size_t) NTask * 7 + 8));
+    SHQ_HIP(hipMemsetAsync(ctx->ex_counts.ptr, 0, sizeof(unsigned long long) * ((size_t) NTask * 7 + 8), st));
+    int64_t nex = 0;
+    if(numpart > 0) {
+        const Leaving pred{(const char *) d_parts, layout->part_elsize, layout->off_flags, d_target, ThisTask};
+        size_t tmp = 0;
+        size_t *d_n = reinterpret_cast<size_t *>(ctx->ex_counts.ptr + (size_t) NTask * 7);
+        SHQ_HIP(rocprim::select(nullptr, tmp, rocprim::counting_iterator<int32_t>(0), ctx->ex_list.ptr, d_n, (size_t) numpart, pred, st));
+        SHQ_TRY(ctx->act_temp.reserve(tmp + 16));
+        SHQ_HIP(rocprim::select((void *) ctx->act_temp.ptr, tmp, rocprim::counting_iterator<int32_t>(0), ctx->ex_list.ptr, d_n, (size_t) numpart, pred, st));
+        size_t h = 0;
+        SHQ_HIP(hipMemcpyAsync(&h, d_n, sizeof(h), hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipStreamSynchronize(st));
+        nex = (int64_t) h;
+    }
+    const int64_t last = (maxlast > 0 && maxlast < nex) ? maxlast : nex;
+    if(nexchange)
+        *nexchange = nex;
+    if(last_out)
+        *last_out = last;
+    const size_t lcap = (size_t) std::max<int64_t>(last, 1);
+    SHQ_TRY(ctx->ex_key[0].reserve(lcap));
+    SHQ_TRY(ctx->ex_key[1].reserve(lcap));
+    SHQ_TRY(ctx->ex_key[2].reserve(lcap));
+    SHQ_TRY(ctx->ex_key[3].reserve(lcap));
+    SHQ_TRY(ctx->ex_val[0].reserve(lcap));
+    SHQ_TRY(ctx->ex_val[1].reserve(lcap));
+    SHQ_TRY(ctx->ex_val[2].reserve(lcap));
+    if(last > 0) {
+        int *d_err = reinterpret_cast<int *>(ctx->ex_counts.ptr + (size_t) NTask * 7 + 4);
+        ex_keys_kernel<<<dim3(nblk(last)), dim3(256), 0, st>>>(last, ctx->ex_list.ptr, (const char *) d_parts, layout->part_elsize, layout->off_type, d_target, NTask,
+                                                               ctx->ex_key[0].ptr, ctx->ex_key[1].ptr, ctx->ex_val[0].ptr, ctx->ex_counts.ptr, d_err);
+        SHQ_HIP(hipGetLastError());
+        /* order by task (base records) and by (task, type) (slot records); stable: list order inside every run */
+        SHQ_TRY(sort_pairs(ctx, (const unsigned int *) ctx->ex_key[0].ptr, ctx->ex_key[2].ptr, (const int32_t *) ctx->ex_val[0].ptr, ctx->ex_val[1].ptr, (size_t) last,
+                           bits_for((unsigned long long) NTask)));
+        SHQ_TRY(sort_pairs(ctx, (const unsigned int *) ctx->ex_key[1].ptr, ctx->ex_key[3].ptr, (const int32_t *) ctx->ex_val[0].ptr, ctx->ex_val[2].ptr, (size_t) last,
+                           bits_for((unsigned long long) NTask * 6)));
+        ex_count_kernel<<<dim3(nblk((long long) NTask * 6)), dim3(256), 0, st>>>(NTask * 6, last, ctx->ex_key[3].ptr, ctx->ex_counts.ptr);
+        SHQ_HIP(hipGetLastError());
+        std::vector<unsigned long long> h((size_t) NTask * 7 + 8);
+        SHQ_HIP(hipMemcpyAsync(h.data(), ctx->ex_counts.ptr, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipStreamSynchronize(st));
+        int h_err = 0;
+        memcpy(&h_err, &h[(size_t) NTask * 7 + 4], sizeof(int));
+        SHQ_CHECK(h_err == 0, SHQ_ERR_INVALID, "exchange_plan: a target task outside [0, %d) or a particle type > 5 (exchange.hpp:196)", NTask);
+        for(int t = 0; t < NTask; t++) {
+            toGo[t].base = (int64_t) h[(size_t) t * 7];
+            for(int ty = 0; ty < 6; ty++)
+                toGo[t].slots[ty] = (int64_t) h[(size_t) t * 7 + 1 + ty];
+        }
+    }
+    ctx->ex_last = last;
+    ctx->ex_ntask = NTask;
+    ctx->ex_togo.assign(toGo, toGo + NTask);
+    return SHQ_OK;
+}
+
+extern "C" int shq_exchange_pack(shq_context *ctx, const shq_exchange_layout *layout, void *d_parts, void *const d_slots[6], int64_t MaxPart,
+                                 const shq_exchange_entry *toGoOffset, int NTask, void *d_partbuf, void *const d_slotbuf[6])
+{
+    SHQ_CHECK(ctx && d_parts && toGoOffset, SHQ_ERR_INVALID, "null argument");
+    SHQ_TRY(check_layout(layout));
+    SHQ_CHECK(ctx->ex_last >= 0 && ctx->ex_ntask == NTask, SHQ_ERR_STATE, "exchange_pack: call shq_exchange_plan first");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const long long last = ctx->ex_last;
+    if(last == 0)
+        return SHQ_OK;
+    SHQ_CHECK(d_partbuf, SHQ_ERR_INVALID, "exchange_pack: no particle buffer");
+    SlotTab tab;
+    memset(&tab, 0, sizeof(tab));
+    for(int ty = 0; ty < 6; ty++) {
+        tab.elsize[ty] = layout->slot_elsize[ty];
+        if(tab.elsize[ty]) {
+            int64_t need = 0;
+            for(int t = 0; t < NTask; t++)
+                need += ctx->ex_togo[t].slots[ty];
+            SHQ_CHECK(need == 0 || (d_slots && d_slots[ty] && d_slotbuf && d_slotbuf[ty]), SHQ_ERR_INVALID, "exchange_pack: slot type %d enabled but no arrays", ty);
+            tab.ptr[ty] = d_slots ? (char *) d_slots[ty] : nullptr;
+            tab.buf[ty] = d_slotbuf ? (char *) d_slotbuf[ty] : nullptr;
+        }
+    }
+    /* the base buffer is dense in task order, so toGoOffset[t].base must be the prefix of toGo (build_export_buffer computes exactly that) */
+    std::vector<long long> runstart((size_t) NTask * 6), slotoff((size_t) NTask * 6);
+    long long acc = 0, basepref = 0;
+    for(int t = 0; t < NTask; t++) {
+        SHQ_CHECK(toGoOffset[t].base == basepref, SHQ_ERR_INVALID, "exchange_pack: toGoOffset[%d].base is not the prefix sum of toGo", t);
+        basepref += ctx->ex_togo[t].base;
+        for(int ty = 0; ty < 6; ty++) {
+            runstart[(size_t) t * 6 + ty] = acc;
+            acc += ctx->ex_togo[t].slots[ty];
+            slotoff[(size_t) t * 6 + ty] = toGoOffset[t].slots[ty];
+        }
+    }
+    SHQ_TRY(ctx->ex_i64.reserve((size_t) NTask * 12 + 16));
+    SHQ_HIP(hipMemcpyAsync(ctx->ex_i64.ptr, runstart.data(), sizeof(long long) * runstart.size(), hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemcpyAsync(ctx->ex_i64.ptr + (size_t) NTask * 6, slotoff.data(), sizeof(long long) * slotoff.size(), hipMemcpyHostToDevice, st));
+    const long long nthreads = last * (long long) (layout->part_elsize / 16);
+    ex_copy_base_kernel<<<dim3(nblk(nthreads)), dim3(256), 0, st>>>(last, ctx->ex_val[1].ptr, ctx->ex_list.ptr, (const char *) d_parts, layout->part_elsize,
+                                                                   (char *) d_partbuf);
+    ex_copy_slot_kernel<<<dim3(nblk(last)), dim3(256), 0, st>>>(last, ctx->ex_val[2].ptr, ctx->ex_key[3].ptr, ctx->ex_i64.ptr, ctx->ex_i64.ptr + (size_t) NTask * 6,
+                                                               ctx->ex_list.ptr, (const char *) d_parts, layout->part_elsize, layout->off_pi, tab);
+    /* the copies read what the marks overwrite: same stream, in order */
+    ex_mark_kernel<<<dim3(nblk(last)), dim3(256), 0, st>>>(last, ctx->ex_list.ptr, (char *) d_parts, layout->part_elsize, layout->off_flags, layout->off_type,
+                                                          layout->off_pi, tab, layout->off_reverselink, (int) (MaxPart + 100));
+    SHQ_HIP(hipGetLastError());
+    SHQ_HIP(hipStreamSynchronize(st)); /* runstart / slotoff live on this frame */
+    ctx->ex_last = -1;
+    return SHQ_OK;
+}
+
+extern "C" int shq_exchange_unpack(shq_context *ctx, const shq_exchange_layout *layout, void *d_parts, int64_t numpart_old, const int64_t slot_size_old[6],
+                                   const shq_exchange_entry *toGet, const shq_exchange_entry *toGetOffset, int NTask)
+{
+    SHQ_CHECK(ctx && d_parts && slot_size_old && toGet && toGetOffset, SHQ_ERR_INVALID, "null argument");
+    SHQ_TRY(check_layout(layout));
+    SHQ_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int64_t maxn = 0;
+    for(int s = 0; s < NTask; s++)
+        maxn = std::max(maxn, toGet[s].base);
+    if(maxn == 0)
+        return SHQ_OK;
+    SHQ_TRY(ctx->ex_key[0].reserve((size_t) maxn));
+    SHQ_TRY(ctx->ex_key[2].reserve((size_t) maxn));
+    SHQ_TRY(ctx->ex_val[0].reserve((size_t) maxn));
+    SHQ_TRY(ctx->ex_val[1].reserve((size_t) maxn));
+    SHQ_TRY(ctx->ex_i64.reserve((size_t) NTask * 12 + 16));
+    for(int src = 0; src < NTask; src++) {
+        const long long n = toGet[src].base;
+        if(n == 0)
+            continue;
+        const long long first = numpart_old + toGetOffset[src].base;
+        long long h[12], acc = 0;
+        for(int ty = 0; ty < 6; ty++) {
+            h[ty] = acc; /* start of the type's run in the type-sorted arrivals */
+            acc += toGet[src].slots[ty];
+            h[6 + ty] = slot_size_old[ty] + toGetOffset[src].slots[ty];
+        }
+        SHQ_CHECK(acc == n, SHQ_ERR_INVALID, "exchange_unpack: toGet[%d].slots do not add up to base (N_slots mismatched, exchange.hpp:505-509)", src);
+        SHQ_HIP(hipMemcpyAsync(ctx->ex_i64.ptr, h, sizeof(h), hipMemcpyHostToDevice, st));
+        ex_types_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, (const char *) d_parts, layout->part_elsize, layout->off_type, first, ctx->ex_key[0].ptr, ctx->ex_val[0].ptr);
+        SHQ_TRY(sort_pairs(ctx, (const unsigned int *) ctx->ex_key[0].ptr, ctx->ex_key[2].ptr, (const int32_t *) ctx->ex_val[0].ptr, ctx->ex_val[1].ptr, (size_t) n, 8));
+        ex_pi_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, (char *) d_parts, layout->part_elsize, layout->off_pi, first, ctx->ex_key[2].ptr, ctx->ex_val[1].ptr,
+                                                          ctx->ex_i64.ptr, ctx->ex_i64.ptr + 6);
+        SHQ_HIP(hipGetLastError());
+        SHQ_HIP(hipStreamSynchronize(st)); /* h lives on this frame */
+    }
+    return SHQ_OK;
+}

@@ -1,0 +1,169 @@
+"""GPU parity tests of the particle-exchange kernels (csrc/exchange.hip: shq_exchange_plan / _pack / _unpack) against the
+restatement of libgadget/exchange.hpp in oracle/exchange.py: all tasks of the reference's tests/test_exchange.cpp cases live in one
+process, each with its own device arrays, the alltoallv between pack and unpack is a set of device-to-device slice copies, and at
+the end every task's particle and slot arrays must equal the oracle's field for field, garbage-marked sources included."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import shenqi_amd as sq
+from shenqi_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import exchange as oex  # noqa: E402
+import exchange_fixtures as fx  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def layout_struct():
+    f = capi.PARTICLE_DTYPE.fields
+    L = capi.ExchangeLayout()
+    L.part_elsize, L.off_flags, L.off_type, L.off_pi = capi.PARTICLE_DTYPE.itemsize, f["Flags"][1], f["Type"][1], f["PI"][1]
+    for t in range(6):
+        L.slot_elsize[t] = 0 if fx.SLOT_DTYPES[t] is None else fx.SLOT_DTYPES[t].itemsize
+    L.off_reverselink = 0
+    return L
+
+
+def dev(a):
+    return torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(DEV)
+
+
+def same_records(a, b):
+    """every field equal (numpy leaves the padding bytes of a copied structured array undefined, so no raw byte compare)"""
+    return len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in a.dtype.names)
+
+
+def entries(arr):
+    e = (capi.ExchangeEntry * len(arr))()
+    for k, row in enumerate(arr):
+        e[k].base = int(row[0])
+        for t in range(6):
+            e[k].slots[t] = int(row[1 + t])
+    return e
+
+
+def gpu_exchange(ctx, tasks, targets, ntask, maxlast=0):
+    L = layout_struct()
+    esz = L.part_elsize
+    d_parts = [dev(T[0]) for T in tasks]
+    d_slots = [[None if s is None else dev(s) for s in T[2]] for T in tasks]
+    d_tgt = [torch.from_numpy(t.copy()).to(DEV) for t in targets]
+    togo = np.zeros((ntask, ntask, 7), dtype=np.int64)
+    partbuf, slotbuf, last = [], [], []
+    for r in range(ntask):
+        tg = (capi.ExchangeEntry * ntask)()
+        nex, la = C.c_int64(), C.c_int64()
+        capi.check(capi.hip.shq_exchange_plan(ctx.h, C.byref(L), d_parts[r].data_ptr(), tasks[r][1], d_tgt[r].data_ptr(), r, ntask, maxlast, C.byref(nex),
+                                              C.byref(la), tg))
+        for t in range(ntask):
+            togo[r, t, 0] = tg[t].base
+            togo[r, t, 1:] = list(tg[t].slots)
+        off = oex.offsets(togo[r])
+        pb = torch.zeros(max(int(togo[r][:, 0].sum()), 1) * esz, dtype=torch.uint8, device=DEV)
+        sb = [None if fx.SLOT_DTYPES[t] is None else torch.zeros(max(int(togo[r][:, 1 + t].sum()), 1) * fx.SLOT_DTYPES[t].itemsize, dtype=torch.uint8, device=DEV)
+              for t in range(6)]
+        sp = (C.c_void_p * 6)(*[None if s is None else s.data_ptr() for s in d_slots[r]])
+        bp = (C.c_void_p * 6)(*[None if s is None else s.data_ptr() for s in sb])
+        capi.check(capi.hip.shq_exchange_pack(ctx.h, C.byref(L), d_parts[r].data_ptr(), sp, len(tasks[r][0]), entries(off), ntask, pb.data_ptr(), bp))
+        partbuf.append(pb)
+        slotbuf.append(sb)
+        last.append((nex.value, la.value))
+    toget = np.stack([np.stack([togo[src][r] for src in range(ntask)]) for r in range(ntask)])
+    out = []
+    for r in range(ntask):
+        P, numpart, slots, slot_size = tasks[r]
+        goff = oex.offsets(toget[r])
+        for src in range(ntask):                        # the alltoallv: slices of the senders' buffers behind NumPart / the slot sizes
+            soff = oex.offsets(togo[src])
+            nb = int(toget[r][src, 0])
+            a = (numpart + int(goff[src, 0])) * esz
+            d_parts[r][a:a + nb * esz] = partbuf[src][int(soff[r, 0]) * esz:(int(soff[r, 0]) + nb) * esz]
+            for t in range(6):
+                if fx.SLOT_DTYPES[t] is None:
+                    continue
+                ssz = fx.SLOT_DTYPES[t].itemsize
+                ns = int(toget[r][src, 1 + t])
+                a = (slot_size[t] + int(goff[src, 1 + t])) * ssz
+                d_slots[r][t][a:a + ns * ssz] = slotbuf[src][t][int(soff[r, 1 + t]) * ssz:(int(soff[r, 1 + t]) + ns) * ssz]
+        torch.cuda.synchronize()
+        so = (C.c_int64 * 6)(*slot_size)
+        capi.check(capi.hip.shq_exchange_unpack(ctx.h, C.byref(L), d_parts[r].data_ptr(), numpart, so, entries(toget[r]), entries(goff), ntask))
+        newP = d_parts[r].cpu().numpy().view(capi.PARTICLE_DTYPE)
+        newS = [None if s is None else s.cpu().numpy().view(fx.SLOT_DTYPES[t]) for t, s in enumerate(d_slots[r])]
+        out.append((newP, numpart + int(toget[r][:, 0].sum()), newS, [slot_size[t] + (int(toget[r][:, 1 + t].sum()) if fx.SLOT_DTYPES[t] is not None else 0) for t in range(6)]))
+    return out, togo, last, partbuf, slotbuf
+
+
+def both(ctx, ntask, ntype, layout, garbage=False, swallowed=False):
+    tasks = [list(fx.setup_task(r, ntask, ntype)) for r in range(ntask)]
+    tot = ntask * sum(ntype)
+    if garbage:
+        for T in tasks:
+            T[0]["Flags"][0] |= 1
+            T[2][0]["ReverseLink"][T[0]["PI"][0]] = len(T[0]) + 100
+        tot -= ntask
+    targets = [layout(T[0], T[1], ntask) for T in tasks]
+    if swallowed:                                        # a swallowed particle stays where it is (exchange.hpp:170)
+        for r, T in enumerate(tasks):
+            k = int(np.flatnonzero(targets[r][:T[1]] != r)[0])
+            T[0]["Flags"][k] |= 2
+    gout, togo, last, _, _ = gpu_exchange(ctx, tasks, targets, ntask)
+    objs = [oex.Task(T[0].copy(), T[1], [None if s is None else s.copy() for s in T[2]], T[3]) for T in tasks]
+    olists, otogo, _ = oex.domain_exchange(objs, targets)
+    for r in range(ntask):
+        assert np.array_equal(togo[r], otogo[r]) and last[r] == (len(olists[r]), len(olists[r]))
+        gP, gn, gS, gsz = gout[r]
+        o = objs[r]
+        assert gn == o.numpart and gsz == o.slot_size
+        assert same_records(gP[:gn], o.parts[:gn])
+        for t in range(6):
+            if o.slots[t] is not None:
+                assert same_records(gS[t][:gsz[t]], o.slots[t][:gsz[t]]), (r, t)
+    return gout, tot
+
+
+@pytest.mark.parametrize("ntask", [1, 2, 3, 5])
+@pytest.mark.parametrize("ntype", [[8] * 6, [8, 0, 8, 0, 8, 0], [40, 13, 0, 7, 25, 3]])
+def test_exchange_equals_reference_loop(ctx, ntask, ntype):
+    gout, tot = both(ctx, ntask, ntype, fx.layout_id_mod)
+    fx.check_after(gout, ntask, tot)
+
+
+def test_exchange_with_garbage_and_swallowed(ctx):
+    gout, tot = both(ctx, 4, [8] * 6, fx.layout_id_mod, garbage=True)
+    fx.check_after(gout, 4, tot)
+    both(ctx, 3, [8] * 6, fx.layout_id_mod, swallowed=True)
+
+
+def test_exchange_uneven(ctx):
+    gout, tot = both(ctx, 4, [8] * 6, fx.layout_uneven)
+    fx.check_after(gout, 4, tot, uneven=True)
+    assert gout[0][3][0] == fx.NUMPART1 * 4
+
+
+def test_exchange_batches_and_bad_target(ctx):
+    """maxlast: only the first entries of the list go in this round (find_iter_space); a target outside [0, NTask) is refused"""
+    ntask = 3
+    tasks = [list(fx.setup_task(r, ntask, [8] * 6)) for r in range(ntask)]
+    targets = [fx.layout_id_mod(T[0], T[1], ntask) for T in tasks]
+    L = layout_struct()
+    d_parts = dev(tasks[0][0])
+    d_tgt = torch.from_numpy(targets[0].copy()).to(DEV)
+    tg = (capi.ExchangeEntry * ntask)()
+    nex, la = C.c_int64(), C.c_int64()
+    capi.check(capi.hip.shq_exchange_plan(ctx.h, C.byref(L), d_parts.data_ptr(), tasks[0][1], d_tgt.data_ptr(), 0, ntask, 5, C.byref(nex), C.byref(la), tg))
+    lst = oex.build_exchange_list(oex.Task(*tasks[0]), targets[0], 0)
+    assert nex.value == len(lst) and la.value == 5
+    want = oex.counts(oex.Task(*tasks[0]), lst[:5], targets[0], ntask)
+    assert [[tg[t].base] + list(tg[t].slots) for t in range(ntask)] == want.tolist()
+    targets[0][3] = 7
+    d_tgt = torch.from_numpy(targets[0].copy()).to(DEV)
+    assert capi.hip.shq_exchange_plan(ctx.h, C.byref(L), d_parts.data_ptr(), tasks[0][1], d_tgt.data_ptr(), 0, ntask, 0, C.byref(nex), C.byref(la), tg) != 0

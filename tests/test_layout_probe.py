@@ -84,6 +84,10 @@ def test_sph_and_bh_slot_layout(layout):
         assert dv[key] == fb[name], key
     for name, off in layout["bh_particle_data"].items():
         assert fb[name] == off, name
+    st = capi.STAR_DTYPE
+    assert layout["sizeof_star_particle_data"] == st.itemsize == 72
+    for name, off in layout["star_particle_data"].items():
+        assert st.fields[name][1] == off, name
     bv = capi.bh_dyn_view(np.zeros(2, dtype=b))
     for key in wantb:
         assert getattr(bv, key) == dv[key]
