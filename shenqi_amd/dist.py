@@ -713,3 +713,216 @@ class GpuSphOps:
         tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
         sq.force_tree_update_hmax(tree, pman)
         sq.hydro_force(self.ctx, np.arange(nloc, dtype=np.int32), atime, hubble, None, kick, tree, pman, Sall)
+
+
+class DistFOF:
+    """One rank of the friends-of-friends finder over x-slabs (fof.cpp's multi-task part, re-cut for ghost imports).
+
+    The reference links across tasks by exporting primary particles to the tasks whose top leaves they touch and lowering MinID
+    on both sides until nothing changes (fof_label_primary's do-while with the ghost branch of fof_primary_ngbiter, fof.cpp:404-470,
+    565-580), then reduces the groups that span tasks onto the task of their MinID particle (fof_reduce_groups).  Here every rank
+    imports the particles within `halo` of its slab once, labels local + ghost particles (ops.labels: shq_fof on the device, the
+    oracle in the CPU tests), and the ranks then lower labels through the particles they share — the owner's label goes to its
+    ghost copies, each rank takes the minimum over its local components — until no label changes anywhere.  The secondary types are
+    attached by a second labelling call that carries the final labels of the primaries as their "IDs".  Groups are summed per rank
+    over the particles it owns and reduced by MinID; FirstPos is the position of the group's MinID particle on every rank (the
+    reference uses whichever member its unstable sort put first on the prime task).
+
+    `P`: numpy records (capi.PARTICLE_DTYPE) of the particles this rank owns, all inside its slab.
+    ops.labels(Pall, ids, linkl, primary_mask, secondary_mask) -> MinID per particle of Pall (np.uint64)."""
+
+    def __init__(self, comm, decomp, ops):
+        self.comm, self.d, self.ops = comm, decomp, ops
+        self.rounds = 0
+        self.nghost = 0
+
+    def _allsum(self, v):
+        return int(round(self.comm.allreduce_sum(float(v)))) if self.comm.multi else int(v)
+
+    def _selections(self, x, halo):
+        """per destination rank: which of my particles it holds as ghosts (the same masks give the order of every later label
+        message, so labels travel as bare uint64 rows)"""
+        L = self.d.L
+        sels = []
+        for dd in range(self.comm.size):
+            if dd == self.comm.rank or not self.comm.multi:
+                sels.append(None)
+                continue
+            a, b = self.d.slab_range(dd)
+            span = (b - a) + 2 * halo
+            sels.append(np.ones(len(x), dtype=bool) if span >= L else (np.remainder(x - (a - halo), L) < span))
+        return sels
+
+    def _send(self, rows, sels):
+        parts, counts = [], [0] * self.comm.size
+        for dd, s in enumerate(sels):
+            if s is None:
+                continue
+            parts.append(rows[s])
+            counts[dd] = int(s.sum())
+        send = np.concatenate(parts, axis=0) if parts else rows[:0]
+        recv, _ = self.comm.all_to_all_rows(torch.from_numpy(np.ascontiguousarray(send)), counts)
+        return recv.numpy()
+
+    def fof(self, P, linkl, minlength, primary_mask=2, secondary_mask=1 + 16 + 32):
+        """Returns (MinID per local particle, groups hosted by this rank as a list of dicts ordered by MinID, GrNr per local
+        particle).  A group is hosted by the rank that owns its MinID particle; GrNr is global (by decreasing length, then MinID)."""
+        comm, L = self.comm, self.d.L
+        nloc = len(P)
+        ids = P["ID"].astype(np.uint64)
+        # the largest radius the secondary search can reach: the first of 0.4 L 2^k (or 0.5 Hsml 2^k) that is >= 4 linking lengths
+        hs = float(P["Hsml"].max()) if nloc else 0.0
+        halo = max(8.0 * linkl, hs if self.comm.multi else 0.0)
+        if comm.multi:
+            t = torch.tensor([halo], dtype=torch.float64)
+            t = t.cuda() if comm.backend == "nccl" else t
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=comm.group)
+            halo = float(t.item())
+        x = np.ascontiguousarray(P["Pos"][:, 0])
+        sels = self._selections(x, halo)
+        got = self._send(P.view(np.uint8).reshape(nloc, -1), sels) if comm.multi else P.view(np.uint8).reshape(nloc, -1)[:0]
+        ng = len(got)
+        self.nghost = ng
+        Pall = np.empty(nloc + ng, dtype=P.dtype)
+        Pall[:nloc] = P
+        Pall[nloc:] = np.ascontiguousarray(got).view(P.dtype).reshape(ng)
+        idall = Pall["ID"].astype(np.uint64)
+        prim = (((1 << Pall["Type"].astype(np.int64)) & primary_mask) != 0) & ((Pall["Flags"] & 3) == 0)
+        # 1. local components of the primaries (label = smallest ID inside local + ghost)
+        lab = self.ops.labels(Pall, idall, linkl, primary_mask, 0)
+        comp_key, comp = np.unique(lab, return_inverse=True)
+        # 2. lower the labels through the shared particles until nothing changes anywhere
+        self.rounds = 0
+        while comm.multi:
+            self.rounds += 1
+            # my owners' labels -> their ghost copies elsewhere (as int64 bit patterns: gloo / NCCL carry no uint64)
+            recv = np.ascontiguousarray(self._send(lab[:nloc].view(np.int64).reshape(-1, 1), sels).reshape(-1)).view(np.uint64)
+            new = lab.copy()
+            new[nloc:] = np.minimum(new[nloc:], recv)
+            low = np.full(len(comp_key), np.iinfo(np.uint64).max, dtype=np.uint64)
+            np.minimum.at(low, comp, new)
+            new = np.where(prim, low[comp], new)
+            changed = int((new != lab).sum())
+            lab = new
+            if self._allsum(changed) == 0:
+                break
+        # 3. secondary types: nearest primary; the primaries carry their final labels as IDs, everybody else its own ID
+        ids2 = np.where(prim, lab, idall)
+        lab2 = self.ops.labels(Pall, ids2, linkl, primary_mask, secondary_mask)
+        minid = lab2[:nloc].copy()
+        # 4. catalogue: lengths first (groups below minlength go), then the sums of the owned members, reduced by MinID
+        key, inv = np.unique(minid, return_inverse=True)
+        cnt = np.bincount(inv, minlength=len(key)).astype(np.int64)
+        allk, allc = self._gather_pairs(key, cnt)
+        tot_key, tinv = np.unique(allk, return_inverse=True)
+        tot_len = np.bincount(tinv, weights=allc, minlength=len(tot_key)).astype(np.int64)
+        keep = tot_len >= minlength
+        kept_key, kept_len = tot_key[keep], tot_len[keep]
+        order = np.lexsort((kept_key, -kept_len))
+        grnr_of = np.empty(len(kept_key), dtype=np.int64)
+        grnr_of[order] = np.arange(1, len(kept_key) + 1)
+        pos_in_kept = np.searchsorted(kept_key, minid)
+        pos_in_kept = np.minimum(pos_in_kept, max(len(kept_key) - 1, 0))
+        ingroup = (kept_key[pos_in_kept] == minid) if len(kept_key) else np.zeros(nloc, dtype=bool)
+        part_grnr = np.where(ingroup, grnr_of[pos_in_kept] if len(kept_key) else -1, -1)
+        groups = self._catalogue(P, minid, ingroup, pos_in_kept, kept_key, kept_len, grnr_of, ids)
+        return minid, groups, part_grnr
+
+    def _gather_pairs(self, key, val):
+        """all ranks' (key, value) rows"""
+        if not self.comm.multi:
+            return key, val
+        rows = np.stack([key.astype(np.uint64).view(np.int64), val.astype(np.int64)], axis=1)
+        counts = [len(rows)] * self.comm.size
+        send = np.concatenate([rows] * self.comm.size, axis=0) if len(rows) else rows
+        recv, _ = self.comm.all_to_all_rows(torch.from_numpy(np.ascontiguousarray(send)), counts)
+        r = recv.numpy()
+        return r[:, 0].copy().view(np.uint64), r[:, 1].copy()
+
+    def _catalogue(self, P, minid, ingroup, gidx, kept_key, kept_len, grnr_of, ids):
+        """add_particle_to_group over the owned members of every kept group, fof_reduce_groups by allgather, then
+        fof_finish_group_properties on the host rank of each group (fof.cpp:583-705, 903-1040)"""
+        comm, L = self.comm, self.d.L
+        ngk = len(kept_key)
+        # FirstPos: the position (as float, BaseGroup.FirstPos) of the MinID particle, known to its owner, gathered
+        fp = np.zeros((ngk, 4))
+        mine = np.flatnonzero(ingroup & (ids == minid))
+        fp[gidx[mine], :3] = P["Pos"][mine].astype(np.float32).astype(np.float64)
+        fp[gidx[mine], 3] = 1.0
+        fp = self._sum_rows(fp)
+        host = fp[:, 3] > 0                    # exactly one owner per kept group holds the MinID particle
+        first = fp[:, :3]
+        hosted = np.zeros(ngk, dtype=bool)
+        hosted[gidx[mine]] = True
+        nf = 1 + 6 + 6 + 3 + 3 + 9 + 3          # Mass, LenType, MassType, CM, Vel, Imom, Jmom
+        S = np.zeros((ngk, nf))
+        m = np.flatnonzero(ingroup)
+        if len(m):
+            g = gidx[m]
+            mass = P["Mass"][m].astype(np.float64)
+            ty = P["Type"][m].astype(np.int64)
+            d = P["Pos"][m] - first[g]
+            rel = np.where(d > 0.5 * L, d - L, np.where(d < -0.5 * L, d + L, d))
+            xyz = rel + first[g]
+            vel = P["Vel"][m]
+            jm = np.stack([rel[:, 1] * vel[:, 2] - vel[:, 1] * rel[:, 2], rel[:, 2] * vel[:, 0] - vel[:, 2] * rel[:, 0],
+                           rel[:, 0] * vel[:, 1] - vel[:, 0] * rel[:, 1]], axis=1)
+            np.add.at(S[:, 0], g, mass)
+            np.add.at(S, (g, 1 + ty), 1.0)
+            np.add.at(S, (g, 7 + ty), mass)
+            for k in range(3):
+                np.add.at(S[:, 13 + k], g, mass * xyz[:, k])
+                np.add.at(S[:, 16 + k], g, mass * vel[:, k])
+                np.add.at(S[:, 28 + k], g, mass * jm[:, k])
+                for k2 in range(3):
+                    np.add.at(S[:, 19 + 3 * k + k2], g, mass * rel[:, k] * rel[:, k2])
+        S = self._sum_rows(S)
+        groups = []
+        for gi in np.flatnonzero(hosted):
+            s = S[gi]
+            M = s[0]
+            G = dict(MinID=int(kept_key[gi]), Length=int(kept_len[gi]), GrNr=int(grnr_of[gi]), LenType=[int(round(v)) for v in s[1:7]],
+                     MassType=[float(v) for v in s[7:13]], Mass=float(M), FirstPos=first[gi].astype(np.float32))
+            vcm = s[16:19] / M
+            cm = s[13:16] / M
+            dcm = cm - first[gi]
+            rel = np.where(dcm > 0.5 * L, dcm - L, np.where(dcm < -0.5 * L, dcm + L, dcm))
+            G["CM"] = np.mod(cm, L)
+            G["Vel"] = vcm
+            jcm = np.array([rel[1] * vcm[2] - vcm[1] * rel[2], rel[2] * vcm[0] - vcm[2] * rel[0], rel[0] * vcm[1] - vcm[0] * rel[1]])
+            G["Jmom"] = s[28:31] - jcm * M
+            G["Imom"] = s[19:28].reshape(3, 3) - M * np.outer(rel, rel)
+            groups.append(G)
+        groups.sort(key=lambda G: G["MinID"])
+        return groups
+
+    def _sum_rows(self, a):
+        if not self.comm.multi:
+            return a
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        t = t.cuda() if self.comm.backend == "nccl" else t
+        dist.all_reduce(t, group=self.comm.group)
+        return t.cpu().numpy()
+
+
+class GpuFofOps:
+    """DistFOF's labelling on the device library (shq_fof: tree of the primary types, linking, secondary attachment)."""
+
+    def __init__(self, ctx, BoxSize):
+        import shenqi_amd as sq
+        self.sq, self.ctx, self.L = sq, ctx, BoxSize
+
+    def labels(self, Pall, ids, linkl, primary_mask, secondary_mask):
+        sq = self.sq
+        n = len(Pall)
+        pman = sq.PartManager(n, self.L)
+        pman.Base[:] = Pall
+        pv = pman.view()
+        capi.check(capi.hip.shq_particles_upload(self.ctx.h, C.byref(pv)))
+        sq.dynamics_upload(self.ctx, pman)
+        fp = capi.FofParams(self.L, linkl, primary_mask, secondary_mask, 1 << 30, 0)     # no catalogue wanted here
+        out = np.zeros(n, dtype=np.uint64)
+        idarr = np.ascontiguousarray(ids, dtype=np.uint64)
+        ng = C.c_int64()
+        capi.check(capi.hip.shq_fof(self.ctx.h, C.byref(fp), capi.ptr(idarr), capi.ptr(out), None, C.byref(ng)))
+        return out

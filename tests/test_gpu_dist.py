@@ -215,3 +215,41 @@ def test_dist_sph_two_gloo_ranks_one_gpu():
             assert np.abs(S["HydroAccel"] - Sm["HydroAccel"][idx]).max() < 1e-7 * np.abs(Sm["HydroAccel"]).max()
             assert np.abs(S["MaxSignalVel"] / Sm["MaxSignalVel"][idx] - 1).max() < 1e-8
         assert seen == 16**3
+
+
+def _fof_worker(rank, world, initfile, outdir):
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        import pickle
+        import shenqi_amd as sq
+        from shenqi_amd import dist as sd
+        import test_dist_fof_cpu as tf
+        comm = sd.Comm()
+        decomp = sd.SlabDecomp(comm, tf.NMESH, tf.BOX)
+        Pg = tf.global_set()
+        mine = (decomp.owner_of(torch.from_numpy(np.ascontiguousarray(Pg["Pos"][:, 0]))) == rank).numpy()
+        P = Pg[mine].copy()
+        with sq.Context(0) as ctx:
+            drv = sd.DistFOF(comm, decomp, sd.GpuFofOps(ctx, tf.BOX))
+            minid, groups, grnr = drv.fof(P, tf.LINKL, tf.MINLEN)
+        with open(os.path.join(outdir, "r%d.pkl" % rank), "wb") as f:
+            pickle.dump(dict(ids=P["ID"], minid=minid, groups=groups, grnr=grnr, rounds=drv.rounds, nghost=drv.nghost), f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dist_fof_two_gloo_ranks_one_gpu():
+    """sharded friends-of-friends with the DEVICE labelling (shq_fof) on two ranks sharing the GPU, labels exchanged over gloo,
+    against the oracle on the undivided set"""
+    import pickle
+    import test_dist_fof_cpu as tf
+    P, ref = tf.monolithic()
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_fof_worker, args=(2, os.path.join(tmp, "init"), tmp), nprocs=2, join=True)
+        results = []
+        for r in range(2):
+            with open(os.path.join(tmp, "r%d.pkl" % r), "rb") as f:
+                results.append(pickle.load(f))
+        tf.check(results, P, ref)
+        assert max(res["rounds"] for res in results) >= 2
