@@ -687,7 +687,10 @@ def main():
     try:
         P["Vel"] = np.random.default_rng(7).normal(size=(n, 3))
         sq.dynamics_upload(ctx, pman)
-        gk = np.full(capi.TIMEBINS + 1, 1e-9)
+        # kick factors small enough that the S-cluster (accelerations up to ~1e16 in its core) keeps its shape over the passes:
+        # with 1e-9 the core flew apart within a few passes and the loop timed another particle distribution (644 instead of 507
+        # interactions per target)
+        gk = np.full(capi.TIMEBINS + 1, 1e-24)
         nres = 3
         capi.check(capi.hip.shq_set_walk_stats(ctx.h, 0))
         # a sub-step of the hierarchical integrator: no potential update (update_potential = 0, its own kernel instantiation and
@@ -704,11 +707,15 @@ def main():
             capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp_rel), None, 0, 0, args.walk_mode | sq.WALK_TREE_ORDER))
             capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, G))
             sq.kick_short(ctx, gk, from_accel_store=True)
-            sq.kick_pm(ctx, 1e-9)
+            sq.kick_pm(ctx, 1e-24)
         ctx.synchronize()
         t_res = time.perf_counter() - t0
         out["kernels"]["resident_full_step_ms"] = 1e3 * t_res / nres
         out["kernels"]["resident_full_step_particle_steps_per_s"] = n * nres / t_res
+        rst = sq.WalkStats()
+        capi.check(capi.hip.shq_grav_short_download(ctx.h, None, None, None, C.byref(rst)))
+        out["kernels"]["resident_walk_ms"] = float(rst.kernel_ms)                 # the last pass's walk kernel
+        out["kernels"]["resident_interactions_per_target"] = rst.ninteractions / max(rst.ntargets, 1)
     except sq.ShqError as e:  # e.g. a tree deeper than the device build supports: the extra figure is simply absent
         out["kernels"]["resident_full_step_ms"] = None
         out["kernels"]["resident_full_step_note"] = str(e)

@@ -704,6 +704,8 @@ static int tree_build_impl(shq_context *ctx, double BoxSize, int mask, const int
     const int32_t *seq = b.idx[1].ptr; /* candidate sequence numbers in key order */
     int32_t *idx = b.idx[0].ptr;       /* particle indices in leaf order, filled once the leaves are known */
 
+    SHQ_CHECK(!(dom && ctx->dom_kind[0] == TOPK_PSEUDO && n > 0), SHQ_ERR_INVALID,
+              "tree_build: the whole box belongs to another task but this rank holds particles (Bad topleaf, forcetree.cpp:807)");
     /* 3. nodes, breadth first */
     TbGeo geo = {nullptr, nullptr, nullptr};
     if(dom)
