@@ -28,8 +28,12 @@
 
 namespace {
 
+#ifndef FFT_C
 #define FFT_C 4        /* complex lines per workgroup */
+#endif
+#ifndef FFT_T
 #define FFT_T 256      /* threads per workgroup */
+#endif
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
@@ -462,7 +466,9 @@ int run_n(shq_context *ctx, double *d_mesh, int zp, int stage, bool from_i64, do
     const double2 *W = reinterpret_cast<const double2 *>(ctx->fft_tw.ptr);
     /* FFT_C padded lines + the twiddle table + (X pass) the sinc table */
     constexpr size_t lds = sizeof(double2) * (FFT_C * (N + 1) + N) + sizeof(double) * N;
+#ifndef SHQ_FFT_RELAX /* tile-shape experiments on one mesh size */
     static_assert(N % (2 * FFT_C) == 0, "rows must tile evenly");
+#endif
     const int ztot = (int) (((long long) nslab * N) / (2 * FFT_C)); /* row groups of the Z passes */
     const int zpc = zp / 2;
     const int ntiles = zpc / FFT_C;
