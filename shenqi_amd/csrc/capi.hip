@@ -209,7 +209,7 @@ extern "C" void shq_shutdown(shq_context *ctx)
     ctx->ex_list.release(); ctx->ex_counts.release(); ctx->ex_i64.release();
     for(auto &b : ctx->ex_val) b.release();
     for(auto &b : ctx->ex_key) b.release();
-    ctx->fof_parent.release(); ctx->fof_partgrnr.release(); ctx->fof_members.release(); ctx->fof_groups.release(); ctx->fof_biglist.release();
+    ctx->fof_parent.release(); ctx->fof_partgrnr.release(); ctx->fof_members.release(); ctx->fof_groups.release(); ctx->fof_biglist.release(); ctx->fof_partial.release();
     for(auto &b : ctx->fof_i32) b.release();
     for(auto &b : ctx->fof_g32) b.release();
     for(auto &b : ctx->fof_u64) b.release();

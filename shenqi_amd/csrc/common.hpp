@@ -308,6 +308,7 @@ struct shq_context {
     DevBuf<unsigned int> fof_gkey[2];
     DevBuf<long long> fof_goff[2];
     DevBuf<shq_fof_group> fof_groups;
+    DevBuf<char> fof_partial;
     int64_t fof_ngroups = -1, fof_nmembers = 0, fof_nruns = 0;
     /* black-hole slot fields of the resident step (timestep.hip): by BH ordinal, bh_pidx ascending particle indices */
     bool have_bh_dyn = false, bh_reposition = false;

@@ -468,19 +468,23 @@ __global__ __launch_bounds__(64) void fof_props_kernel(long long ng, const FofPr
     fof_finish(S, g, first, firstf, a);
 }
 
-/* longer groups: 256 threads sum 256 consecutive slices of the member list, thread 0 adds the partial groups in slice order with
- * Group::reduce — the way the reference adds the parts of a group that lies on several tasks.  Deterministic; differs from the
- * one-thread order by rounding only. */
-__global__ __launch_bounds__(256) void fof_props_big_kernel(int nbig, const int32_t *biglist, const FofPropArgs a)
+/* longer groups: FOF_SPLIT workgroups of 256 threads sum FOF_SPLIT x 256 consecutive slices of the member list; the partial groups
+ * are added in slice order with Group::reduce — the way the reference adds the parts of a group that lies on several tasks — first
+ * inside a workgroup, then (second kernel) across the workgroups.  Deterministic; differs from the one-thread order by rounding only. */
+constexpr int FOF_SPLIT = 64;
+
+__global__ __launch_bounds__(256) void fof_props_big_kernel(int nbig, const int32_t *biglist, const FofPropArgs a, FofSums *partial)
 {
     __shared__ FofSums part[256];
-    const long long g = biglist[blockIdx.x];
+    const int b = blockIdx.x / FOF_SPLIT, piece = blockIdx.x % FOF_SPLIT;
+    const long long g = biglist[b];
     double first[3];
     float firstf[3];
     fof_first(g, a, first, firstf);
     const long long s0 = a.gstart[g], len = a.glen[g];
-    const long long chunk = (len + 255) / 256;
-    const long long k0 = s0 + chunk * threadIdx.x, k1 = k0 + chunk < s0 + len ? k0 + chunk : s0 + len;
+    const long long chunk = (len + (long long) FOF_SPLIT * 256 - 1) / ((long long) FOF_SPLIT * 256);
+    const long long slice = (long long) piece * 256 + threadIdx.x;
+    const long long k0 = s0 + chunk * slice, k1 = k0 + chunk < s0 + len ? k0 + chunk : s0 + len;
     FofSums S;
     memset(&S, 0, sizeof(S));
     S.seed_index = -1;
@@ -492,8 +496,23 @@ __global__ __launch_bounds__(256) void fof_props_big_kernel(int nbig, const int3
         FofSums T = part[0];
         for(int t = 1; t < 256; t++)
             fof_reduce(T, part[t]);
-        fof_finish(T, g, first, firstf, a);
+        partial[blockIdx.x] = T;
     }
+}
+
+__global__ void fof_props_big_finish_kernel(int nbig, const int32_t *biglist, const FofPropArgs a, const FofSums *partial)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if(b >= nbig)
+        return;
+    const long long g = biglist[b];
+    double first[3];
+    float firstf[3];
+    fof_first(g, a, first, firstf);
+    FofSums T = partial[(size_t) b * FOF_SPLIT];
+    for(int p = 1; p < FOF_SPLIT; p++)
+        fof_reduce(T, partial[(size_t) b * FOF_SPLIT + p]);
+    fof_finish(T, g, first, firstf, a);
 }
 
 __global__ void fof_bigflag_kernel(long long ng, const int32_t *glen, int32_t *flag)
@@ -684,7 +703,10 @@ extern "C" int shq_fof(shq_context *ctx, const shq_fof_params *fp, const uint64_
             const int nbig = lastf + laste;
             if(nbig > 0) {
                 fof_biglist_kernel<<<dim3(nblk(ng)), dim3(256), 0, st>>>(ng, d_flag, d_excl, ctx->fof_biglist.ptr);
-                fof_props_big_kernel<<<dim3((unsigned) nbig), dim3(256), 0, st>>>(nbig, ctx->fof_biglist.ptr, pa);
+                SHQ_TRY(ctx->fof_partial.reserve((size_t) nbig * FOF_SPLIT * sizeof(FofSums)));
+                FofSums *d_partial = reinterpret_cast<FofSums *>(ctx->fof_partial.ptr);
+                fof_props_big_kernel<<<dim3((unsigned) nbig * FOF_SPLIT), dim3(256), 0, st>>>(nbig, ctx->fof_biglist.ptr, pa, d_partial);
+                fof_props_big_finish_kernel<<<dim3(nblk(nbig, 64)), dim3(64), 0, st>>>(nbig, ctx->fof_biglist.ptr, pa, d_partial);
             }
         }
         fof_glen64_kernel<<<dim3(nblk(ng)), dim3(256), 0, st>>>(ng, d_glen, ctx->fof_goff[0].ptr);
