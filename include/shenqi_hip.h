@@ -438,6 +438,13 @@ int shq_exchange_pack(shq_context *ctx, const shq_exchange_layout *layout, void 
                       const shq_exchange_entry *toGoOffset, int NTask, void *d_partbuf, void *const d_slotbuf[6]);
 int shq_exchange_unpack(shq_context *ctx, const shq_exchange_layout *layout, void *d_parts, int64_t numpart_old, const int64_t slot_size_old[6],
                         const shq_exchange_entry *toGet, const shq_exchange_entry *toGetOffset, int NTask);
+/* slots_gc (libgadget/slotsmanager.cpp:132-370): garbage particles squeezed out of the particle array (order kept: slots_gc_base),
+ * then for every slot type with compact[type] != 0: ReverseLink = particle index (invalid for garbage: slots_gc_mark), unreferenced
+ * slots squeezed out in order (slots_gc_sweep), PI of the surviving particles renumbered (slots_gc_collect).  *numpart and
+ * slot_size[] are updated.  What the exchange runs between pack and receive when memory is short (exchange.hpp:398-406).
+ * Slot records of a type that is not compacted keep their places, as in the reference. */
+int shq_slots_gc(shq_context *ctx, const shq_exchange_layout *layout, void *d_parts, int64_t *numpart, int64_t MaxPart, void *const d_slots[6],
+                 int64_t slot_size[6], const int compact[6]);
 
 /* Friends-of-friends groups of the resident particles (the first legacy-API user: libgadget/fof.cpp, one task).
  *   fof_label_primary (:368-581): particles of the primary types within LinkingLength of each other (r2 <= L^2, the neighbour

@@ -7,9 +7,10 @@ TEST INFRASTRUCTURE ONLY.  Follows /root/reference/libgadget/exchange.hpp:
                                        received particles appended after NumPart in source-task order, slots appended per type,
                                        PI of every received particle renumbered in arrival order
   slots_mark_garbage       slotsmanager.cpp:590-599
-The garbage collection the reference may run between pack and receive (slots_gc, when memory is short) is not restated: the
-arrays here are sized so that it is never needed, as in the reference's own tests/test_exchange.cpp, whose four cases
-(tests/test_exchange_cpu.py) pin this file."""
+  slots_gc                 slotsmanager.cpp:132-370, with shall_we_compact_slots (exchange.hpp:300-317): the collection the
+                                       exchange runs between pack and receive when a round is capped or memory is short
+Pinned by the four cases of the reference's tests/test_exchange.cpp and by test_slots_gc of tests/test_slotsmanager.cpp
+(tests/test_exchange_cpu.py)."""
 import numpy as np
 
 
@@ -105,3 +106,122 @@ def domain_exchange(tasks, targets):
             if T.slots[t] is not None:
                 T.slot_size[t] += int(toget[r][:, 1 + t].sum())
     return lists, togo, toget
+
+
+def slots_gc(task, compact):
+    """slots_gc, slotsmanager.cpp:132-370: slots_gc_base (garbage particles squeezed out, order kept), slots_gc_mark, then per
+    compacted type slots_gc_sweep + slots_gc_collect.  Modifies the task in place."""
+    P = task.parts
+    n = task.numpart
+    keep = np.flatnonzero((P["Flags"][:n] & 1) == 0)
+    P[:len(keep)] = P[keep]
+    task.numpart = n = len(keep)
+    if not any(compact):
+        return
+    invalid = task.maxpart + 100
+    for i in range(n):                                   # slots_gc_mark (no garbage is left after the base pass)
+        t = int(P["Type"][i])
+        if task.slots[t] is None:
+            continue
+        pi = int(P["PI"][i])
+        assert 0 <= pi < task.slot_size[t]
+        task.slots[t]["ReverseLink"][pi] = invalid if (P["Flags"][i] & 1) else i
+    for t in range(6):
+        if not compact[t] or task.slots[t] is None:
+            continue
+        S = task.slots[t]
+        used = task.slot_size[t]
+        live = np.flatnonzero(S["ReverseLink"][:used] <= task.maxpart)
+        S[:len(live)] = S[live]
+        task.slot_size[t] = len(live)
+        P["PI"][S["ReverseLink"][:len(live)]] = np.arange(len(live))
+
+
+def shall_we_compact_slots(task, toget_sum, togo_sum):
+    """exchange.hpp:300-317 for one task (the caller ORs over tasks)"""
+    c = [0] * 6
+    for t in range(6):
+        if task.slots[t] is None:
+            continue
+        if task.slot_size[t] + toget_sum[1 + t] > 0.95 * len(task.slots[t]):
+            c[t] = 1
+        if togo_sum[1 + t] > 0.1 * task.slot_size[t]:
+            c[t] = 1
+    return c
+
+
+def domain_exchange_batched(tasks, layouts, maxlast, maxiter=10000):
+    """ExchangePlan::domain_exchange (exchange.hpp:88-153) with a cap of `maxlast` list entries per task and iteration
+    (find_iter_space), the garbage collection between pack and receive included (exchange_once :398-406).
+    layouts: per task a function parts, numpart -> target array.  Returns the number of iterations."""
+    ntask = len(tasks)
+    it = 0
+    while True:
+        assert it < maxiter
+        targets = [layouts[r](tasks[r].parts, tasks[r].numpart) for r in range(ntask)]
+        lists = [build_exchange_list(tasks[r], targets[r], r) for r in range(ntask)]
+        if not any(len(l) for l in lists):
+            break
+        lasts = [min(len(l), maxlast) for l in lists]
+        sub = [lists[r][:lasts[r]] for r in range(ntask)]
+        togo = [counts(tasks[r], sub[r], targets[r], ntask) for r in range(ntask)]
+        toget = [np.stack([togo[src][r] for src in range(ntask)]) for r in range(ntask)]
+        partbuf, slotbuf = [], []
+        for r in range(ntask):
+            T = tasks[r]
+            off = offsets(togo[r])
+            pb = np.zeros(int(togo[r][:, 0].sum()), dtype=T.parts.dtype)
+            sb = [None if T.slots[t] is None else np.zeros(int(togo[r][:, 1 + t].sum()), dtype=T.slots[t].dtype) for t in range(6)]
+            ptr = np.zeros((ntask, 7), dtype=np.int64)
+            for i in sub[r]:
+                tgt = int(targets[r][i])
+                ty = int(T.parts["Type"][i])
+                bufpi = ptr[tgt, 1 + ty]
+                ptr[tgt, 1 + ty] += 1
+                if T.slots[ty] is not None:
+                    sb[ty][bufpi + off[tgt, 1 + ty]] = T.slots[ty][T.parts["PI"][i]]
+                pb[off[tgt, 0] + ptr[tgt, 0]] = T.parts[i]
+                ptr[tgt, 0] += 1
+                T.parts["Flags"][i] |= 1
+                if T.slots[ty] is not None:
+                    T.slots[ty]["ReverseLink"][T.parts["PI"][i]] = T.maxpart + 100
+            partbuf.append(pb)
+            slotbuf.append(sb)
+        shall_gc = any(lasts[r] < len(lists[r]) or tasks[r].numpart + int(toget[r][:, 0].sum()) > tasks[r].maxpart for r in range(ntask))
+        if shall_gc:
+            compact = [0] * 6
+            for r in range(ntask):
+                c = shall_we_compact_slots(tasks[r], toget[r].sum(axis=0), togo[r].sum(axis=0))
+                compact = [a | b for a, b in zip(compact, c)]
+            for r in range(ntask):
+                slots_gc(tasks[r], compact)
+        for r in range(ntask):
+            T = tasks[r]
+            goff = offsets(toget[r])
+            newnum = T.numpart + int(toget[r][:, 0].sum())
+            assert newnum <= T.maxpart
+            for src in range(ntask):
+                soff = offsets(togo[src])
+                nb = int(toget[r][src, 0])
+                T.parts[T.numpart + goff[src, 0]:T.numpart + goff[src, 0] + nb] = partbuf[src][soff[r, 0]:soff[r, 0] + nb]
+                for t in range(6):
+                    if T.slots[t] is None:
+                        continue
+                    ns = int(toget[r][src, 1 + t])
+                    a = T.slot_size[t] + goff[src, 1 + t]
+                    assert a + ns <= len(T.slots[t])
+                    T.slots[t][a:a + ns] = slotbuf[src][t][soff[r, 1 + t]:soff[r, 1 + t] + ns]
+            for src in range(ntask):
+                newpi = [T.slot_size[t] + int(goff[src, 1 + t]) for t in range(6)]
+                for i in range(T.numpart + int(goff[src, 0]), T.numpart + int(goff[src, 0]) + int(toget[r][src, 0])):
+                    ty = int(T.parts["Type"][i])
+                    T.parts["PI"][i] = newpi[ty]
+                    newpi[ty] += 1
+            T.numpart = newnum
+            for t in range(6):
+                if T.slots[t] is not None:
+                    T.slot_size[t] += int(toget[r][:, 1 + t].sum())
+        it += 1
+        if not any(lasts[r] < len(lists[r]) for r in range(ntask)):
+            break
+    return it

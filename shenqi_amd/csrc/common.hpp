@@ -299,6 +299,7 @@ struct shq_context {
     DevBuf<unsigned int> ex_key[4];
     DevBuf<unsigned long long> ex_counts;
     DevBuf<long long> ex_i64;
+    DevBuf<char> ex_bytes;
     std::vector<shq_exchange_entry> ex_togo;
     int64_t ex_last = -1;
     int ex_ntask = 0;

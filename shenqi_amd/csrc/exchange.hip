@@ -121,8 +121,8 @@ __global__ void ex_copy_slot_kernel(long long last, const int32_t *order_tt, con
     const long long dst = slotoff[k] + (pos - runstart[k]);
     const char *src = st.ptr[ty] + (size_t) pi * st.elsize[ty];
     char *out = st.buf[ty] + (size_t) dst * st.elsize[ty];
-    for(size_t b = 0; b < st.elsize[ty]; b += 8) /* slot structs are 8-byte aligned and sized */
-        *reinterpret_cast<unsigned long long *>(out + b) = *reinterpret_cast<const unsigned long long *>(src + b);
+    for(size_t b = 0; b < st.elsize[ty]; b += 4) /* slot structs are at least 4-byte aligned and sized (bare particle_data_ext) */
+        *reinterpret_cast<uint32_t *>(out + b) = *reinterpret_cast<const uint32_t *>(src + b);
 }
 
 /* slots_mark_garbage, slotsmanager.cpp:590-599 */
@@ -164,14 +164,83 @@ __global__ void ex_pi_kernel(long long n, char *parts, size_t elsize, size_t off
     *reinterpret_cast<int32_t *>(parts + (size_t) (first + k) * elsize + off_pi) = (int32_t) (newpi[ty] + (pos - typestart[ty]));
 }
 
+struct LiveParticle {
+    const char *parts;
+    size_t elsize, off_flags;
+    __device__ bool operator()(const int32_t i) const { return !(*(const unsigned char *) (parts + (size_t) i * elsize + off_flags) & 1u); }
+};
+struct LiveSlot {
+    const char *slots;
+    size_t elsize, off_rl;
+    int maxpart;
+    __device__ bool operator()(const int32_t i) const { return *reinterpret_cast<const int32_t *>(slots + (size_t) i * elsize + off_rl) <= maxpart; }
+};
+
+/* records `keep[k]` of src to position k of dst, 4 bytes per thread and pass (slot structs of the bare particle_data_ext are 4 bytes) */
+__global__ void gc_gather_kernel(long long nkeep, const int32_t *keep, const char *src, size_t elsize, char *dst)
+{
+    const long long gid = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const int words = (int) (elsize / 4);
+    const long long rec = gid / words;
+    const int w = (int) (gid % words);
+    if(rec >= nkeep)
+        return;
+    *reinterpret_cast<uint32_t *>(dst + (size_t) rec * elsize + 4 * (size_t) w) =
+        *reinterpret_cast<const uint32_t *>(src + (size_t) keep[rec] * elsize + 4 * (size_t) w);
+}
+
+/* slots_gc_mark, slotsmanager.cpp:243-285 */
+__global__ void gc_mark_kernel(long long numpart, const char *parts, size_t elsize, size_t off_flags, size_t off_type, size_t off_pi, SlotTab st,
+                               const long long *slot_size, size_t off_rl, int invalid, int *err)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= numpart)
+        return;
+    const char *p = parts + (size_t) i * elsize;
+    const unsigned ty = *(const unsigned char *) (p + off_type);
+    if(ty >= 6 || !st.elsize[ty])
+        return;
+    const int pi = *reinterpret_cast<const int32_t *>(p + off_pi);
+    if(pi < 0 || pi >= slot_size[ty]) {
+        *err = 1; /* "Particle %ld, type %d has PI index %d beyond max slot size", slotsmanager.cpp:276 */
+        return;
+    }
+    const bool garbage = *(const unsigned char *) (p + off_flags) & 1u;
+    *reinterpret_cast<int32_t *>(st.ptr[ty] + (size_t) pi * st.elsize[ty] + off_rl) = garbage ? invalid : (int32_t) i;
+}
+
+/* slots_gc_collect, slotsmanager.cpp:301-322 */
+__global__ void gc_collect_kernel(long long nslots, const char *slots, size_t selsize, size_t off_rl, char *parts, size_t elsize, size_t off_pi)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= nslots)
+        return;
+    const int rl = *reinterpret_cast<const int32_t *>(slots + (size_t) i * selsize + off_rl);
+    *reinterpret_cast<int32_t *>(parts + (size_t) rl * elsize + off_pi) = (int32_t) i;
+}
+
+template <typename Pred> int select_keep(shq_context *ctx, Pred pred, size_t n, int32_t *out, int64_t *nkeep)
+{
+    size_t tmp = 0;
+    size_t *d_n = reinterpret_cast<size_t *>(ctx->ex_counts.ptr);
+    SHQ_HIP(rocprim::select(nullptr, tmp, rocprim::counting_iterator<int32_t>(0), out, d_n, n, pred, ctx->stream));
+    SHQ_TRY(ctx->act_temp.reserve(tmp + 16));
+    SHQ_HIP(rocprim::select((void *) ctx->act_temp.ptr, tmp, rocprim::counting_iterator<int32_t>(0), out, d_n, n, pred, ctx->stream));
+    size_t h = 0;
+    SHQ_HIP(hipMemcpyAsync(&h, d_n, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    *nkeep = (int64_t) h;
+    return SHQ_OK;
+}
+
 int check_layout(const shq_exchange_layout *l)
 {
     SHQ_CHECK(l && l->part_elsize >= 16 && l->part_elsize % 16 == 0, SHQ_ERR_INVALID, "exchange: particle records must be a multiple of 16 bytes");
     SHQ_CHECK(l->off_flags < l->part_elsize && l->off_type < l->part_elsize && l->off_pi + 4 <= l->part_elsize && l->off_pi % 4 == 0, SHQ_ERR_INVALID,
               "exchange: field offsets outside the particle record");
     for(int t = 0; t < 6; t++)
-        SHQ_CHECK(l->slot_elsize[t] % 8 == 0 && (l->slot_elsize[t] == 0 || l->off_reverselink + 4 <= l->slot_elsize[t]), SHQ_ERR_INVALID,
-                  "exchange: slot type %d: record size %zu must be a multiple of 8 and hold ReverseLink", t, l->slot_elsize[t]);
+        SHQ_CHECK(l->slot_elsize[t] % 4 == 0 && (l->slot_elsize[t] == 0 || l->off_reverselink + 4 <= l->slot_elsize[t]), SHQ_ERR_INVALID,
+                  "exchange: slot type %d: record size %zu must be a multiple of 4 and hold ReverseLink", t, l->slot_elsize[t]);
     return SHQ_OK;
 }
 
@@ -355,5 +424,82 @@ extern "C" int shq_exchange_unpack(shq_context *ctx, const shq_exchange_layout *
         SHQ_HIP(hipGetLastError());
         SHQ_HIP(hipStreamSynchronize(st)); /* h lives on this frame */
     }
+    return SHQ_OK;
+}
+
+extern "C" int shq_slots_gc(shq_context *ctx, const shq_exchange_layout *layout, void *d_parts, int64_t *numpart, int64_t MaxPart, void *const d_slots[6],
+                            int64_t slot_size[6], const int compact[6])
+{
+    SHQ_CHECK(ctx && d_parts && numpart && slot_size && compact, SHQ_ERR_INVALID, "null argument");
+    SHQ_TRY(check_layout(layout));
+    SHQ_CHECK(*numpart >= 0 && *numpart <= MaxPart && MaxPart < (1ll << 31) - 200, SHQ_ERR_INVALID, "slots_gc: bad particle numbers");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    SHQ_TRY(ctx->ex_counts.reserve(64));
+    const size_t esz = layout->part_elsize;
+    /* slots_gc_base: squeeze the garbage out of the particle array, order kept */
+    int64_t n = *numpart;
+    if(n > 0) {
+        SHQ_TRY(ctx->ex_list.reserve((size_t) n));
+        int64_t nkeep = 0;
+        SHQ_TRY(select_keep(ctx, LiveParticle{(const char *) d_parts, esz, layout->off_flags}, (size_t) n, ctx->ex_list.ptr, &nkeep));
+        if(nkeep < n) {
+            SHQ_TRY(ctx->ex_bytes.reserve((size_t) std::max<int64_t>(nkeep, 1) * esz));
+            if(nkeep > 0) {
+                gc_gather_kernel<<<dim3(nblk(nkeep * (long long) (esz / 4))), dim3(256), 0, st>>>(nkeep, ctx->ex_list.ptr, (const char *) d_parts, esz, ctx->ex_bytes.ptr);
+                SHQ_HIP(hipMemcpyAsync(d_parts, ctx->ex_bytes.ptr, (size_t) nkeep * esz, hipMemcpyDeviceToDevice, st));
+            }
+            n = nkeep;
+        }
+    }
+    *numpart = n;
+    bool any = false;
+    SlotTab tab;
+    memset(&tab, 0, sizeof(tab));
+    for(int ty = 0; ty < 6; ty++) {
+        any = any || compact[ty];
+        tab.elsize[ty] = layout->slot_elsize[ty];
+        tab.ptr[ty] = (tab.elsize[ty] && d_slots) ? (char *) d_slots[ty] : nullptr;
+        SHQ_CHECK(!tab.elsize[ty] || slot_size[ty] == 0 || tab.ptr[ty], SHQ_ERR_INVALID, "slots_gc: slot type %d enabled but no array", ty);
+    }
+    if(!any)
+        return SHQ_OK;
+    /* slots_gc_mark */
+    SHQ_TRY(ctx->ex_i64.reserve(16));
+    long long h_sz[6];
+    for(int ty = 0; ty < 6; ty++)
+        h_sz[ty] = slot_size[ty];
+    SHQ_HIP(hipMemcpyAsync(ctx->ex_i64.ptr, h_sz, sizeof(h_sz), hipMemcpyHostToDevice, st));
+    int *d_err = reinterpret_cast<int *>(ctx->ex_counts.ptr + 8);
+    SHQ_HIP(hipMemsetAsync(d_err, 0, sizeof(int), st));
+    if(n > 0) {
+        gc_mark_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, (const char *) d_parts, esz, layout->off_flags, layout->off_type, layout->off_pi, tab, ctx->ex_i64.ptr,
+                                                            layout->off_reverselink, (int) (MaxPart + 100), d_err);
+        SHQ_HIP(hipGetLastError());
+    }
+    int h_err = 0;
+    SHQ_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    SHQ_CHECK(h_err == 0, SHQ_ERR_INVALID, "slots_gc: a particle's PI lies outside its slot array (slotsmanager.cpp:276)");
+    for(int ty = 0; ty < 6; ty++) {
+        if(!compact[ty] || !tab.elsize[ty] || slot_size[ty] == 0)
+            continue;
+        /* slots_gc_sweep: slots nobody points to go; slots_gc_collect: PI follows */
+        const int64_t used = slot_size[ty];
+        SHQ_TRY(ctx->ex_list.reserve((size_t) used));
+        int64_t nkeep = 0;
+        SHQ_TRY(select_keep(ctx, LiveSlot{tab.ptr[ty], tab.elsize[ty], layout->off_reverselink, (int) MaxPart}, (size_t) used, ctx->ex_list.ptr, &nkeep));
+        if(nkeep < used && nkeep > 0) {
+            SHQ_TRY(ctx->ex_bytes.reserve((size_t) nkeep * tab.elsize[ty]));
+            gc_gather_kernel<<<dim3(nblk(nkeep * (long long) (tab.elsize[ty] / 4))), dim3(256), 0, st>>>(nkeep, ctx->ex_list.ptr, tab.ptr[ty], tab.elsize[ty], ctx->ex_bytes.ptr);
+            SHQ_HIP(hipMemcpyAsync(tab.ptr[ty], ctx->ex_bytes.ptr, (size_t) nkeep * tab.elsize[ty], hipMemcpyDeviceToDevice, st));
+        }
+        slot_size[ty] = nkeep;
+        if(nkeep > 0) {
+            gc_collect_kernel<<<dim3(nblk(nkeep)), dim3(256), 0, st>>>(nkeep, tab.ptr[ty], tab.elsize[ty], layout->off_reverselink, (char *) d_parts, esz, layout->off_pi);
+            SHQ_HIP(hipGetLastError());
+        }
+    }
+    SHQ_HIP(hipStreamSynchronize(st));
     return SHQ_OK;
 }

@@ -46,3 +46,30 @@ def test_exchange_uneven(ntask):
     tasks, tot = run(ntask, CASES["all"], fx.layout_uneven)
     fx.check_after(tasks, ntask, tot, uneven=True)
     assert tasks[0][3][0] == fx.NUMPART1 * ntask       # the gas slots of task 0 grew to hold everybody's gas (test_exchange.cpp:179)
+
+
+def test_slots_gc_reference_fixture():
+    """tests/test_slotsmanager.cpp:65-85 (test_slots_gc): 6 x 128 particles, the first of every type marked garbage, all types
+    compacted: 6 x 127 particles and 127 slots per enabled type remain, PI and payloads still belong together"""
+    P, numpart, slots, slot_size = fx.setup_task(0, 1, [128] * 6)
+    T = oex.Task(P, numpart, slots, slot_size)
+    for i in range(6):
+        k = 128 * i
+        P["Flags"][k] |= 1
+        t = int(P["Type"][k])
+        if slots[t] is not None:
+            slots[t]["ReverseLink"][P["PI"][k]] = len(P) + 100
+    oex.slots_gc(T, [1] * 6)
+    assert T.numpart == 127 * 6 and [T.slot_size[t] for t in (0, 4, 5)] == [127] * 3
+    fx.check_after([(T.parts, T.numpart, T.slots, T.slot_size)], 1, 127 * 6)
+
+
+def test_exchange_in_batches_with_gc():
+    """a cap of 5 list entries per round: several rounds with a garbage collection between pack and receive in each
+    (exchange.hpp:398-406), same end state as the fixture demands"""
+    ntask = 3
+    tasks = [oex.Task(*fx.setup_task(r, ntask, [8] * 6, maxpart=96)) for r in range(ntask)]
+    lay = [lambda P, n, nt=ntask: fx.layout_id_mod(P, n, nt)] * ntask
+    iters = oex.domain_exchange_batched(tasks, lay, 5)
+    assert iters >= 4
+    fx.check_after([(T.parts, T.numpart, T.slots, T.slot_size) for T in tasks], ntask, ntask * 48)

@@ -167,3 +167,127 @@ def test_exchange_batches_and_bad_target(ctx):
     targets[0][3] = 7
     d_tgt = torch.from_numpy(targets[0].copy()).to(DEV)
     assert capi.hip.shq_exchange_plan(ctx.h, C.byref(L), d_parts.data_ptr(), tasks[0][1], d_tgt.data_ptr(), 0, ntask, 0, C.byref(nex), C.byref(la), tg) != 0
+
+
+def test_slots_gc_reference_fixture(ctx):
+    """tests/test_slotsmanager.cpp:65-85 on the device, against the oracle field for field"""
+    P, numpart, slots, slot_size = fx.setup_task(0, 1, [128] * 6)
+    for i in range(6):
+        k = 128 * i
+        P["Flags"][k] |= 1
+        t = int(P["Type"][k])
+        if slots[t] is not None:
+            slots[t]["ReverseLink"][P["PI"][k]] = len(P) + 100
+    L = layout_struct()
+    d_parts = dev(P)
+    d_slots = [None if s is None else dev(s) for s in slots]
+    sp = (C.c_void_p * 6)(*[None if s is None else s.data_ptr() for s in d_slots])
+    n = C.c_int64(numpart)
+    sz = (C.c_int64 * 6)(*slot_size)
+    compact = (C.c_int * 6)(*[1] * 6)
+    capi.check(capi.hip.shq_slots_gc(ctx.h, C.byref(L), d_parts.data_ptr(), C.byref(n), len(P), sp, sz, compact))
+    T = oex.Task(P, numpart, slots, slot_size)
+    oex.slots_gc(T, [1] * 6)
+    assert n.value == T.numpart == 127 * 6 and list(sz) == T.slot_size
+    gP = d_parts.cpu().numpy().view(capi.PARTICLE_DTYPE)
+    assert same_records(gP[:n.value], T.parts[:T.numpart])
+    for t in range(6):
+        if slots[t] is not None:
+            gS = d_slots[t].cpu().numpy().view(fx.SLOT_DTYPES[t])
+            assert same_records(gS[:sz[t]], T.slots[t][:T.slot_size[t]]), t
+    fx.check_after([(gP, n.value, [None if s is None else d_slots[t].cpu().numpy().view(fx.SLOT_DTYPES[t]) for t, s in enumerate(slots)], list(sz))], 1, 127 * 6)
+
+
+def test_exchange_in_batches_with_gc_equals_oracle(ctx):
+    """ExchangePlan::domain_exchange with a cap of 5 list entries per round: plan / pack / gc / receive / unpack per round on the
+    device, the same rounds by the oracle; all arrays equal after every round"""
+    ntask, maxlast = 3, 5
+    L = layout_struct()
+    esz = L.part_elsize
+    host = [list(fx.setup_task(r, ntask, [8] * 6, maxpart=96)) for r in range(ntask)]
+    otasks = [oex.Task(h[0].copy(), h[1], [None if s is None else s.copy() for s in h[2]], list(h[3])) for h in host]
+    d_parts = [dev(h[0]) for h in host]
+    d_slots = [[None if s is None else dev(s) for s in h[2]] for h in host]
+    numpart = [h[1] for h in host]
+    slot_size = [list(h[3]) for h in host]
+    rounds = 0
+    while True:
+        rounds += 1
+        assert rounds < 50
+        cur = [d_parts[r].cpu().numpy().view(capi.PARTICLE_DTYPE) for r in range(ntask)]
+        targets = [fx.layout_id_mod(cur[r], numpart[r], ntask) for r in range(ntask)]
+        d_tgt = [torch.from_numpy(t.copy()).to(DEV) for t in targets]
+        togo = np.zeros((ntask, ntask, 7), dtype=np.int64)
+        nex, last, partbuf, slotbuf = [], [], [], []
+        for r in range(ntask):
+            tg = (capi.ExchangeEntry * ntask)()
+            a, b = C.c_int64(), C.c_int64()
+            capi.check(capi.hip.shq_exchange_plan(ctx.h, C.byref(L), d_parts[r].data_ptr(), numpart[r], d_tgt[r].data_ptr(), r, ntask, maxlast, C.byref(a), C.byref(b), tg))
+            nex.append(a.value)
+            last.append(b.value)
+            for t in range(ntask):
+                togo[r, t, 0] = tg[t].base
+                togo[r, t, 1:] = list(tg[t].slots)
+            off = oex.offsets(togo[r])
+            pb = torch.zeros(max(int(togo[r][:, 0].sum()), 1) * esz, dtype=torch.uint8, device=DEV)
+            sb = [None if fx.SLOT_DTYPES[t] is None else torch.zeros(max(int(togo[r][:, 1 + t].sum()), 1) * fx.SLOT_DTYPES[t].itemsize, dtype=torch.uint8, device=DEV)
+                  for t in range(6)]
+            sp = (C.c_void_p * 6)(*[None if s is None else s.data_ptr() for s in d_slots[r]])
+            bp = (C.c_void_p * 6)(*[None if s is None else s.data_ptr() for s in sb])
+            capi.check(capi.hip.shq_exchange_pack(ctx.h, C.byref(L), d_parts[r].data_ptr(), sp, 96, entries(off), ntask, pb.data_ptr(), bp))
+            partbuf.append(pb)
+            slotbuf.append(sb)
+        if not any(nex):
+            break
+        toget = np.stack([np.stack([togo[src][r] for src in range(ntask)]) for r in range(ntask)])
+        shall_gc = any(last[r] < nex[r] or numpart[r] + int(toget[r][:, 0].sum()) > 96 for r in range(ntask))
+        if shall_gc:
+            compact = [0] * 6
+            for r in range(ntask):
+                tmp = oex.Task(cur[r], numpart[r], host[r][2], slot_size[r])     # only sizes and capacities are read
+                c = oex.shall_we_compact_slots(tmp, toget[r].sum(axis=0), togo[r].sum(axis=0))
+                compact = [x | y for x, y in zip(compact, c)]
+            for r in range(ntask):
+                sp = (C.c_void_p * 6)(*[None if s is None else s.data_ptr() for s in d_slots[r]])
+                n = C.c_int64(numpart[r])
+                sz = (C.c_int64 * 6)(*slot_size[r])
+                capi.check(capi.hip.shq_slots_gc(ctx.h, C.byref(L), d_parts[r].data_ptr(), C.byref(n), 96, sp, sz, (C.c_int * 6)(*compact)))
+                numpart[r], slot_size[r] = n.value, list(sz)
+        for r in range(ntask):
+            goff = oex.offsets(toget[r])
+            for src in range(ntask):
+                soff = oex.offsets(togo[src])
+                nb = int(toget[r][src, 0])
+                a = (numpart[r] + int(goff[src, 0])) * esz
+                d_parts[r][a:a + nb * esz] = partbuf[src][int(soff[r, 0]) * esz:(int(soff[r, 0]) + nb) * esz]
+                for t in range(6):
+                    if fx.SLOT_DTYPES[t] is None:
+                        continue
+                    ssz = fx.SLOT_DTYPES[t].itemsize
+                    ns = int(toget[r][src, 1 + t])
+                    a = (slot_size[r][t] + int(goff[src, 1 + t])) * ssz
+                    d_slots[r][t][a:a + ns * ssz] = slotbuf[src][t][int(soff[r, 1 + t]) * ssz:(int(soff[r, 1 + t]) + ns) * ssz]
+            torch.cuda.synchronize()
+            so = (C.c_int64 * 6)(*slot_size[r])
+            capi.check(capi.hip.shq_exchange_unpack(ctx.h, C.byref(L), d_parts[r].data_ptr(), numpart[r], so, entries(toget[r]), entries(goff), ntask))
+            numpart[r] += int(toget[r][:, 0].sum())
+            for t in range(6):
+                if fx.SLOT_DTYPES[t] is not None:
+                    slot_size[r][t] += int(toget[r][:, 1 + t].sum())
+        if not any(last[r] < nex[r] for r in range(ntask)):
+            break
+    lay = [lambda P, n, nt=ntask: fx.layout_id_mod(P, n, nt)] * ntask
+    oiters = oex.domain_exchange_batched(otasks, lay, maxlast)
+    assert rounds == oiters >= 4
+    out = []
+    for r in range(ntask):
+        o = otasks[r]
+        gP = d_parts[r].cpu().numpy().view(capi.PARTICLE_DTYPE)
+        assert numpart[r] == o.numpart and slot_size[r] == o.slot_size
+        assert same_records(gP[:numpart[r]], o.parts[:o.numpart])
+        gS = [None if s is None else d_slots[r][t].cpu().numpy().view(fx.SLOT_DTYPES[t]) for t, s in enumerate(host[r][2])]
+        for t in range(6):
+            if gS[t] is not None:
+                assert same_records(gS[t][:slot_size[r][t]], o.slots[t][:o.slot_size[t]]), (r, t)
+        out.append((gP, numpart[r], gS, slot_size[r]))
+    fx.check_after(out, ntask, ntask * 48)
