@@ -411,8 +411,8 @@ def run_sharded(args, rank, local_rank, world):
     ach = tree_bytes / max(st.kernel_ms * 1e-3, 1e-12) / 1e9
     out = {
         "metric": "particle-steps/sec (grav+PM+SPH) at 256^3; rms force error vs ref",
-        "metric_note": "BASELINE.json's metric name; this N-GPU line runs the dm-only TreePM step of config.workload (no SPH, which is "
-                       "not sharded here)",
+        "metric_note": "BASELINE.json's metric name; this N-GPU line runs the dm-only TreePM step of config.workload (dm-only as "
+                       "BASELINE configs[1] is; the sharded SPH operators of dist.py, DistSPH, are covered by tests, not timed here)",
         "value": nglobal * args.steps / elapsed, "unit": "particle-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
