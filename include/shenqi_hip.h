@@ -445,6 +445,12 @@ int shq_exchange_unpack(shq_context *ctx, const shq_exchange_layout *layout, voi
  * Slot records of a type that is not compacted keep their places, as in the reference. */
 int shq_slots_gc(shq_context *ctx, const shq_exchange_layout *layout, void *d_parts, int64_t *numpart, int64_t MaxPart, void *const d_slots[6],
                  int64_t slot_size[6], const int compact[6]);
+/* slots_gc_sorted (libgadget/slotsmanager.cpp:417-510): the particle array sorted by type, then by Peano-Hilbert key, garbage
+ * (TypeKey 255) last and trimmed off; every enabled slot array sorted by its particles' new positions (ReverseLink), unreferenced
+ * slots trimmed, PI renumbered.  d_keys[i] = PEANO(Part[i].Pos, BoxSize) comes from the caller (its own key function: the loop at
+ * :439-447); equal (type, key) pairs keep their order here (the reference's sort is unstable). */
+int shq_slots_gc_sorted(shq_context *ctx, const shq_exchange_layout *layout, void *d_parts, int64_t *numpart, int64_t MaxPart, void *const d_slots[6],
+                        int64_t slot_size[6], const uint64_t *d_keys);
 
 /* Friends-of-friends groups of the resident particles (the first legacy-API user: libgadget/fof.cpp, one task).
  *   fof_label_primary (:368-581): particles of the primary types within LinkingLength of each other (r2 <= L^2, the neighbour

@@ -225,3 +225,33 @@ def domain_exchange_batched(tasks, layouts, maxlast, maxiter=10000):
         if not any(lasts[r] < len(lists[r]) for r in range(ntask)):
             break
     return it
+
+
+def slots_gc_sorted(task, keys):
+    """slots_gc_sorted, slotsmanager.cpp:417-510: keys[i] = PEANO(Pos[i]).  Equal (TypeKey, Key) pairs keep their order (a
+    stable sort; the reference's is not, which only matters for particles in the same 2^-21 cell)."""
+    P = task.parts
+    n = task.numpart
+    garbage = (P["Flags"][:n] & 1) != 0
+    typekey = np.where(garbage, 255, P["Type"][:n].astype(np.int64))
+    order = np.lexsort((np.asarray(keys[:n], dtype=np.uint64), typekey))
+    P[:n] = P[:n][order]
+    invalid = task.maxpart + 100
+    for i in range(n):                                   # slots_gc_mark, garbage included
+        t = int(P["Type"][i])
+        if task.slots[t] is None:
+            continue
+        pi = int(P["PI"][i])
+        assert 0 <= pi < task.slot_size[t]
+        task.slots[t]["ReverseLink"][pi] = invalid if (P["Flags"][i] & 1) else i
+    task.numpart = n - int(garbage.sum())
+    for t in range(6):
+        if task.slots[t] is None:
+            continue
+        S = task.slots[t]
+        used = task.slot_size[t]
+        so = np.argsort(S["ReverseLink"][:used], kind="stable")
+        S[:used] = S[:used][so]
+        live = int((S["ReverseLink"][:used] <= task.maxpart).sum())
+        task.slot_size[t] = live
+        P["PI"][S["ReverseLink"][:live]] = np.arange(live)

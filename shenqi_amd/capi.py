@@ -364,7 +364,8 @@ hip.shq_exchange_plan.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.c_int64
 hip.shq_exchange_pack.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, _vp, C.c_int64, _vp, C.c_int, _vp, _vp]
 hip.shq_exchange_unpack.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.c_int64, _vp, _vp, _vp, C.c_int]
 hip.shq_slots_gc.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.POINTER(C.c_int64), C.c_int64, _vp, _vp, _vp]
-for _f in ("shq_exchange_plan", "shq_exchange_pack", "shq_exchange_unpack", "shq_slots_gc"):
+hip.shq_slots_gc_sorted.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.POINTER(C.c_int64), C.c_int64, _vp, _vp, _vp]
+for _f in ("shq_exchange_plan", "shq_exchange_pack", "shq_exchange_unpack", "shq_slots_gc", "shq_slots_gc_sorted"):
     getattr(hip, _f).restype = C.c_int
 hip.shq_fof.argtypes = [_vp, C.POINTER(FofParams), _vp, _vp, _vp, C.POINTER(C.c_int64)]
 hip.shq_fof.restype = C.c_int

@@ -206,7 +206,7 @@ extern "C" void shq_shutdown(shq_context *ctx)
     ctx->g_density.release(); ctx->g_egywt.release(); ctx->g_dhsmlegy.release(); ctx->g_divvel.release(); ctx->g_curlvel.release();
     ctx->g_hydroaccel_out.release(); ctx->g_dtentropy_out.release(); ctx->g_maxsignalvel.release();
     ctx->bh_pidx.release(); ctx->bh_u8.release(); ctx->bh_vec.release();
-    ctx->ex_list.release(); ctx->ex_counts.release(); ctx->ex_i64.release(); ctx->ex_bytes.release();
+    ctx->ex_list.release(); ctx->ex_counts.release(); ctx->ex_i64.release(); ctx->ex_bytes.release(); ctx->ex_u64.release();
     for(auto &b : ctx->ex_val) b.release();
     for(auto &b : ctx->ex_key) b.release();
     ctx->fof_parent.release(); ctx->fof_partgrnr.release(); ctx->fof_members.release(); ctx->fof_groups.release(); ctx->fof_biglist.release(); ctx->fof_partial.release();

@@ -297,7 +297,7 @@ struct shq_context {
     /* particle exchange (exchange.hip) */
     DevBuf<int32_t> ex_list, ex_val[3];
     DevBuf<unsigned int> ex_key[4];
-    DevBuf<unsigned long long> ex_counts;
+    DevBuf<unsigned long long> ex_counts, ex_u64;
     DevBuf<long long> ex_i64;
     DevBuf<char> ex_bytes;
     std::vector<shq_exchange_entry> ex_togo;

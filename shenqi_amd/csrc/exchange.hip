@@ -219,6 +219,39 @@ __global__ void gc_collect_kernel(long long nslots, const char *slots, size_t se
     *reinterpret_cast<int32_t *>(parts + (size_t) rl * elsize + off_pi) = (int32_t) i;
 }
 
+/* TypeKey of slots_gc_sorted (slotsmanager.cpp:441-446) */
+__global__ void gcs_typekey_kernel(long long n, const char *parts, size_t elsize, size_t off_flags, size_t off_type, unsigned int *key, unsigned long long *ngarbage)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    const char *p = parts + (size_t) i * elsize;
+    const bool garbage = *(const unsigned char *) (p + off_flags) & 1u;
+    key[i] = garbage ? 255u : (unsigned) *(const unsigned char *) (p + off_type);
+    if(garbage)
+        atomicAdd(ngarbage, 1ull);
+}
+__global__ void gcs_gather_u32_kernel(long long n, const int32_t *order, const unsigned int *in, unsigned int *out)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+        out[i] = in[order[i]];
+}
+__global__ void gcs_iota_kernel(long long n, int32_t *v)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+        v[i] = (int32_t) i;
+}
+__global__ void gcs_rlkey_kernel(long long n, const char *slots, size_t elsize, size_t off_rl, unsigned int *key, int32_t *val)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    key[i] = (unsigned) *reinterpret_cast<const int32_t *>(slots + (size_t) i * elsize + off_rl);
+    val[i] = (int32_t) i;
+}
+
 template <typename Pred> int select_keep(shq_context *ctx, Pred pred, size_t n, int32_t *out, int64_t *nkeep)
 {
     size_t tmp = 0;
@@ -494,6 +527,97 @@ extern "C" int shq_slots_gc(shq_context *ctx, const shq_exchange_layout *layout,
             gc_gather_kernel<<<dim3(nblk(nkeep * (long long) (tab.elsize[ty] / 4))), dim3(256), 0, st>>>(nkeep, ctx->ex_list.ptr, tab.ptr[ty], tab.elsize[ty], ctx->ex_bytes.ptr);
             SHQ_HIP(hipMemcpyAsync(tab.ptr[ty], ctx->ex_bytes.ptr, (size_t) nkeep * tab.elsize[ty], hipMemcpyDeviceToDevice, st));
         }
+        slot_size[ty] = nkeep;
+        if(nkeep > 0) {
+            gc_collect_kernel<<<dim3(nblk(nkeep)), dim3(256), 0, st>>>(nkeep, tab.ptr[ty], tab.elsize[ty], layout->off_reverselink, (char *) d_parts, esz, layout->off_pi);
+            SHQ_HIP(hipGetLastError());
+        }
+    }
+    SHQ_HIP(hipStreamSynchronize(st));
+    return SHQ_OK;
+}
+
+extern "C" int shq_slots_gc_sorted(shq_context *ctx, const shq_exchange_layout *layout, void *d_parts, int64_t *numpart, int64_t MaxPart, void *const d_slots[6],
+                                   int64_t slot_size[6], const uint64_t *d_keys)
+{
+    SHQ_CHECK(ctx && d_parts && numpart && slot_size && d_keys, SHQ_ERR_INVALID, "null argument");
+    SHQ_TRY(check_layout(layout));
+    SHQ_CHECK(*numpart >= 0 && *numpart <= MaxPart && MaxPart < (1ll << 31) - 200, SHQ_ERR_INVALID, "slots_gc_sorted: bad particle numbers");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t esz = layout->part_elsize;
+    const int64_t n = *numpart;
+    SHQ_TRY(ctx->ex_counts.reserve(64));
+    SlotTab tab;
+    memset(&tab, 0, sizeof(tab));
+    for(int ty = 0; ty < 6; ty++) {
+        tab.elsize[ty] = layout->slot_elsize[ty];
+        tab.ptr[ty] = (tab.elsize[ty] && d_slots) ? (char *) d_slots[ty] : nullptr;
+        SHQ_CHECK(!tab.elsize[ty] || slot_size[ty] == 0 || tab.ptr[ty], SHQ_ERR_INVALID, "slots_gc_sorted: slot type %d enabled but no array", ty);
+    }
+    int64_t ngarbage = 0;
+    if(n > 0) {
+        const size_t cap = (size_t) n;
+        SHQ_TRY(ctx->ex_key[0].reserve(cap));
+        SHQ_TRY(ctx->ex_key[1].reserve(cap));
+        SHQ_TRY(ctx->ex_key[2].reserve(cap));
+        SHQ_TRY(ctx->ex_val[0].reserve(cap));
+        SHQ_TRY(ctx->ex_val[1].reserve(cap));
+        SHQ_TRY(ctx->ex_val[2].reserve(cap));
+        SHQ_TRY(ctx->ex_u64.reserve(cap));
+        SHQ_TRY(ctx->ex_bytes.reserve(cap * esz));
+        unsigned long long *d_ng = ctx->ex_counts.ptr + 16;
+        SHQ_HIP(hipMemsetAsync(d_ng, 0, sizeof(unsigned long long), st));
+        /* PeanoOrder::operator<: TypeKey first, then Key.  Least significant first: a stable sort by key, then by TypeKey */
+        gcs_iota_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, ctx->ex_val[0].ptr);
+        {
+            size_t tmp = 0;
+            SHQ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, (const unsigned long long *) d_keys, ctx->ex_u64.ptr, (const int32_t *) ctx->ex_val[0].ptr, ctx->ex_val[1].ptr, cap, 0, 64, st));
+            SHQ_TRY(ctx->act_temp.reserve(tmp + 16));
+            SHQ_HIP(rocprim::radix_sort_pairs((void *) ctx->act_temp.ptr, tmp, (const unsigned long long *) d_keys, ctx->ex_u64.ptr, (const int32_t *) ctx->ex_val[0].ptr,
+                                              ctx->ex_val[1].ptr, cap, 0, 64, st));
+        }
+        gcs_typekey_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, (const char *) d_parts, esz, layout->off_flags, layout->off_type, ctx->ex_key[0].ptr, d_ng);
+        gcs_gather_u32_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, ctx->ex_val[1].ptr, ctx->ex_key[0].ptr, ctx->ex_key[1].ptr);
+        SHQ_TRY(sort_pairs(ctx, (const unsigned int *) ctx->ex_key[1].ptr, ctx->ex_key[2].ptr, (const int32_t *) ctx->ex_val[1].ptr, ctx->ex_val[2].ptr, cap, 8));
+        gc_gather_kernel<<<dim3(nblk(n * (long long) (esz / 4))), dim3(256), 0, st>>>(n, ctx->ex_val[2].ptr, (const char *) d_parts, esz, ctx->ex_bytes.ptr);
+        SHQ_HIP(hipMemcpyAsync(d_parts, ctx->ex_bytes.ptr, cap * esz, hipMemcpyDeviceToDevice, st));
+        unsigned long long h = 0;
+        SHQ_HIP(hipMemcpyAsync(&h, d_ng, sizeof(h), hipMemcpyDeviceToHost, st));
+        /* slots_gc_mark over the sorted array, garbage included (:487) */
+        SHQ_TRY(ctx->ex_i64.reserve(16));
+        long long h_sz[6];
+        for(int ty = 0; ty < 6; ty++)
+            h_sz[ty] = slot_size[ty];
+        SHQ_HIP(hipMemcpyAsync(ctx->ex_i64.ptr, h_sz, sizeof(h_sz), hipMemcpyHostToDevice, st));
+        int *d_err = reinterpret_cast<int *>(ctx->ex_counts.ptr + 8);
+        SHQ_HIP(hipMemsetAsync(d_err, 0, sizeof(int), st));
+        gc_mark_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, (const char *) d_parts, esz, layout->off_flags, layout->off_type, layout->off_pi, tab, ctx->ex_i64.ptr,
+                                                            layout->off_reverselink, (int) (MaxPart + 100), d_err);
+        int h_err = 0;
+        SHQ_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipStreamSynchronize(st));
+        SHQ_CHECK(h_err == 0, SHQ_ERR_INVALID, "slots_gc_sorted: a particle's PI lies outside its slot array (slotsmanager.cpp:276)");
+        ngarbage = (int64_t) h;
+    }
+    *numpart = n - ngarbage;
+    for(int ty = 0; ty < 6; ty++) {
+        if(!tab.elsize[ty] || slot_size[ty] == 0)
+            continue;
+        /* slots sorted by ReverseLink (operator< of particle_data_ext): garbage (MaxPart + 100) last; then the first garbage is the size */
+        const int64_t used = slot_size[ty];
+        SHQ_TRY(ctx->ex_key[0].reserve((size_t) used));
+        SHQ_TRY(ctx->ex_key[1].reserve((size_t) used));
+        SHQ_TRY(ctx->ex_val[0].reserve((size_t) used));
+        SHQ_TRY(ctx->ex_val[1].reserve((size_t) used));
+        SHQ_TRY(ctx->ex_bytes.reserve((size_t) used * tab.elsize[ty]));
+        gcs_rlkey_kernel<<<dim3(nblk(used)), dim3(256), 0, st>>>(used, tab.ptr[ty], tab.elsize[ty], layout->off_reverselink, ctx->ex_key[0].ptr, ctx->ex_val[0].ptr);
+        SHQ_TRY(sort_pairs(ctx, (const unsigned int *) ctx->ex_key[0].ptr, ctx->ex_key[1].ptr, (const int32_t *) ctx->ex_val[0].ptr, ctx->ex_val[1].ptr, (size_t) used, 32));
+        gc_gather_kernel<<<dim3(nblk(used * (long long) (tab.elsize[ty] / 4))), dim3(256), 0, st>>>(used, ctx->ex_val[1].ptr, tab.ptr[ty], tab.elsize[ty], ctx->ex_bytes.ptr);
+        SHQ_HIP(hipMemcpyAsync(tab.ptr[ty], ctx->ex_bytes.ptr, (size_t) used * tab.elsize[ty], hipMemcpyDeviceToDevice, st));
+        SHQ_TRY(ctx->ex_list.reserve((size_t) used));
+        int64_t nkeep = 0;
+        SHQ_TRY(select_keep(ctx, LiveSlot{tab.ptr[ty], tab.elsize[ty], layout->off_reverselink, (int) MaxPart}, (size_t) used, ctx->ex_list.ptr, &nkeep));
         slot_size[ty] = nkeep;
         if(nkeep > 0) {
             gc_collect_kernel<<<dim3(nblk(nkeep)), dim3(256), 0, st>>>(nkeep, tab.ptr[ty], tab.elsize[ty], layout->off_reverselink, (char *) d_parts, esz, layout->off_pi);

@@ -73,3 +73,42 @@ def test_exchange_in_batches_with_gc():
     iters = oex.domain_exchange_batched(tasks, lay, 5)
     assert iters >= 4
     fx.check_after([(T.parts, T.numpart, T.slots, T.slot_size) for T in tasks], ntask, ntask * 48)
+
+
+def _ref_keys(P, n, box):
+    import ctypes as C
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libpeano_ref.so"))
+    lib.ref_PEANO.restype = C.c_uint64
+    lib.ref_PEANO.argtypes = [C.c_void_p, C.c_double]
+    return np.array([lib.ref_PEANO(np.ascontiguousarray(P["Pos"][i]).ctypes.data, box) for i in range(n)], dtype=np.uint64)
+
+
+def gc_sorted_setup(rng):
+    P, numpart, slots, slot_size = fx.setup_task(0, 1, [128] * 6)
+    P["Pos"][:numpart] = rng.random((numpart, 3)) * 25000.0
+    for i in range(6):
+        k = 128 * i
+        P["Flags"][k] |= 1
+        t = int(P["Type"][k])
+        if slots[t] is not None:
+            slots[t]["ReverseLink"][P["PI"][k]] = len(P) + 100
+    return P, numpart, slots, slot_size
+
+
+def check_gc_sorted(P, numpart, slots, slot_size, box=25000.0):
+    """tests/test_slotsmanager.cpp:87-115 (test_slots_gc_sorted)"""
+    assert numpart == 127 * 6 and [slot_size[t] for t in (0, 4, 5)] == [127] * 3
+    keys = _ref_keys(P, numpart, box)
+    ty = P["Type"][:numpart].astype(int)
+    assert (np.diff(ty) >= 0).all()
+    same = np.diff(ty) == 0
+    assert (keys[1:][same] >= keys[:-1][same]).all()
+    fx.check_after([(P, numpart, slots, slot_size)], 1, 127 * 6)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libpeano_ref.so")), reason="needs the reference's peano key (make -C oracle ref)")
+def test_slots_gc_sorted_reference_fixture():
+    P, numpart, slots, slot_size = gc_sorted_setup(np.random.default_rng(5))
+    T = oex.Task(P, numpart, slots, slot_size)
+    oex.slots_gc_sorted(T, _ref_keys(P, numpart, 25000.0))
+    check_gc_sorted(T.parts, T.numpart, T.slots, T.slot_size)

@@ -291,3 +291,31 @@ def test_exchange_in_batches_with_gc_equals_oracle(ctx):
                 assert same_records(gS[t][:slot_size[r][t]], o.slots[t][:o.slot_size[t]]), (r, t)
         out.append((gP, numpart[r], gS, slot_size[r]))
     fx.check_after(out, ntask, ntask * 48)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libpeano_ref.so")), reason="needs the reference's peano key (make -C oracle ref)")
+def test_slots_gc_sorted_reference_fixture(ctx):
+    """tests/test_slotsmanager.cpp:87-115 on the device with the reference's own keys, against the oracle field for field"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_exchange_cpu as tc
+    P, numpart, slots, slot_size = tc.gc_sorted_setup(np.random.default_rng(5))
+    P["Pos"][3] = P["Pos"][2]                     # two particles in one key cell: the order of equals
+    keys = tc._ref_keys(P, numpart, 25000.0)
+    L = layout_struct()
+    d_parts = dev(P)
+    d_slots = [None if s is None else dev(s) for s in slots]
+    d_keys = torch.from_numpy(keys.view(np.int64).copy()).to(DEV)
+    sp = (C.c_void_p * 6)(*[None if s is None else s.data_ptr() for s in d_slots])
+    n = C.c_int64(numpart)
+    sz = (C.c_int64 * 6)(*slot_size)
+    capi.check(capi.hip.shq_slots_gc_sorted(ctx.h, C.byref(L), d_parts.data_ptr(), C.byref(n), len(P), sp, sz, d_keys.data_ptr()))
+    T = oex.Task(P, numpart, slots, slot_size)
+    oex.slots_gc_sorted(T, keys)
+    assert n.value == T.numpart and list(sz) == T.slot_size
+    gP = d_parts.cpu().numpy().view(capi.PARTICLE_DTYPE)
+    assert same_records(gP[:n.value], T.parts[:T.numpart])
+    gS = [None if s is None else d_slots[t].cpu().numpy().view(fx.SLOT_DTYPES[t]) for t, s in enumerate(slots)]
+    for t in range(6):
+        if gS[t] is not None:
+            assert same_records(gS[t][:sz[t]], T.slots[t][:T.slot_size[t]]), t
+    tc.check_gc_sorted(gP, n.value, gS, list(sz))
