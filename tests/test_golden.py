@@ -1,5 +1,8 @@
-"""Committed golden fixtures (tests/golden/, made by tools/make_golden.py from the pinned oracle):
-the oracle must keep reproducing them (CPU), and the HIP path must match them (GPU)."""
+"""Committed regression fixtures (tests/golden/*.npz, made by tools/make_golden.py from the oracle): the oracle must keep
+reproducing them (CPU), and the HIP path must match them (GPU).  They are outputs of the oracle, so they guard against drift of
+either side and pin nothing by themselves; what pins the oracle are the reference-held values and gates in test_oracle_cpu.py,
+test_timeline_cpu.py, test_fof_cpu.py, test_exchange_cpu.py, test_forcetree_cpu.py and test_peano_ref_cpu.py (oracle/README.md).
+tests/golden/peano_keys.json is different: it is data of the reference's own test (test_peano.cpp)."""
 import ctypes as C
 import os
 
