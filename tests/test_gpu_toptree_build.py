@@ -99,6 +99,47 @@ def test_domain_tree_equals_reference_build(ctx, seed, ntask, maxdepth):
         assert abs(root["mass"] - mass.sum()) < 1e-9 * mass.sum()         # every rank's root carries the whole box
 
 
+def test_domain_tree_deep_top_tree_many_tasks(ctx):
+    """a deeper top tree (up to 4 levels, a few hundred leaves, 8 tasks) over 60 000 clustered particles: two of the ranks'
+    trees node for node, before and after the exchange (their pseudo moments come from one-task builds of everything)"""
+    rng = np.random.default_rng(12)
+    n = 60000
+    pos, ptype, mass, hsml = _particles(rng, n)
+    geo, tl = cm.make_topnodes(rng, 8, maxdepth=4, psplit=0.45)
+    assert len(tl) > 100
+    owner = tl["Task"][cm.topleaf_of(pos, geo, cm.BOX)]
+    # the gathered table: every leaf's moments from a build of its owner
+    gathered = np.zeros(len(tl), dtype=capi.TOPLEAF_MOMENTS_DTYPE)
+    ogather = [None] * len(tl)
+    builds = {}
+    for me in range(8):
+        mine = np.flatnonzero(owner == me)
+        if me in (2, 5):
+            builds[me] = _rank_build(ctx, pos, ptype, mass, hsml, mine, geo, tl, me)
+            mom, omom = builds[me]["mom"], builds[me]["omom"]
+        else:                                            # only the device side is needed for the other ranks' contributions
+            lp = np.ascontiguousarray(pos[mine])
+            pman = cm.make_partmanager(lp)
+            pman.Base["Type"], pman.Base["Mass"], pman.Base["Hsml"] = ptype[mine], mass[mine], hsml[mine]
+            pv = pman.view()
+            capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+            sq.dynamics_upload(ctx, pman)
+            _, mom = sq.tree_build_domain(ctx, cm.BOX, geo, tl.copy(), me, len(mine) + 3)
+            omom = [(list(mom["s"][l]), float(mom["mass"][l]), float(mom["hmax"][l])) for l in range(len(tl))]
+        for l in np.flatnonzero(tl["Task"] == me):
+            gathered[l] = mom[l]
+            ogather[l] = omom[l]
+    for me in (2, 5):
+        mine = np.flatnonzero(owner == me)
+        r = _rank_build(ctx, pos, ptype, mass, hsml, mine, geo, tl, me)
+        chk.compare(r["nodes"], r["firstnode"], r["lastnode_dev"], r["t"], r["lastnode_orc"], moments=False)
+        sq.tree_set_topleaf_moments(ctx, gathered)
+        nodes, _ = sq.tree_download(ctx, r["firstnode"])
+        tb.finish(r["t"], r["ltn"], [int(x) for x in tl["Task"]], me, ogather)
+        chk.compare(nodes, r["firstnode"], r["lastnode_dev"], r["t"], r["lastnode_orc"], moments=True)
+        assert abs(nodes[0]["mass"] - mass.sum()) < 1e-9 * mass.sum()
+
+
 def test_domain_tree_rejects_foreign_particle_and_bad_tables(ctx):
     rng = np.random.default_rng(5)
     pos, ptype, mass, hsml = _particles(rng, 500)
