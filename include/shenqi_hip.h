@@ -189,6 +189,12 @@ typedef struct shq_walk_stats {
  * the order the reference's distributed walk keeps. */
 #define SHQ_WALK_DEFER_POSTPROCESS 0x200
 
+/* Order of n device-resident positions (rows of 4 doubles: x, y, z, anything) along the Peano-Hilbert curve the walk groups its
+ * targets by (the order SHQ_WALK_TREE_ORDER walks in): d_order[k] = row index of the k-th particle, equal keys in index order.
+ * What a driver calls after a domain exchange in place of the reference's particle sort (domain.cpp:268, slots_gc_sorted), without
+ * bringing the positions to the host.  Both pointers are device pointers; the work is queued on the context's stream. */
+int shq_hilbert_order(shq_context *ctx, const double *d_posm, int64_t n, double BoxSize, int64_t *d_order);
+
 /* One-shot replacement of grav_short_tree_cuda(): walks the local tree for the `nactive`
  * targets in `active` (NULL => all particles, as ActiveParticles with a NULL list), writes
  * Accel[target][0..2] (already multiplied by G: GravTreeOutput::postprocess,

@@ -434,6 +434,7 @@ hip.shq_dynamics_download.argtypes = [_vp, C.POINTER(PartView)]
 hip.shq_dynamics_download.restype = C.c_int
 hip.shq_grav_short_run.argtypes = [_vp, C.POINTER(GravParams), _vp, C.c_int64, C.c_int, C.c_int]
 hip.shq_grav_short_run_range.argtypes = [_vp, C.POINTER(GravParams), C.c_int64, C.c_int64, C.c_int, C.c_int]
+hip.shq_hilbert_order.argtypes = [_vp, C.c_void_p, C.c_int64, C.c_double, C.c_void_p]
 hip.shq_grav_short_download.argtypes = [_vp, _vp, _vp, _vp, C.POINTER(WalkStats)]
 hip.shq_grav_refresh_oldacc.argtypes = [_vp, C.c_double]
 hip.shq_grav_short_tree.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), _vp, C.c_int64,

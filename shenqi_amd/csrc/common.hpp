@@ -284,6 +284,7 @@ struct shq_context {
     DevBuf<int32_t> tree_targets; /* own particles in leaf order (SHQ_WALK_TREE_ORDER) */
     int64_t ntree_targets = 0;
     bool have_tree_targets = false;
+    DevBuf<long long> hilb_iota;  /* shq_hilbert_order: 0 .. n-1, the values of its sort */
     bool tb_built = false;     /* the current tree came from shq_tree_build (downloadable) */
 
     /* ---- SPH state, by particle index (gas fields gathered from their slots at upload) */

@@ -573,7 +573,7 @@ __global__ void hilbert_key_kernel(long long n, const int32_t *__restrict__ targ
     const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if(t >= n)
         return;
-    const double4 p = posm[targets[t]];
+    const double4 p = posm[targets ? (long long) targets[t] : t];
     const int bits = 21;
     const double scale = (double) (1 << bits) / (L * 1.001);
     const double xs[3] = {p.x, p.y, p.z};
@@ -610,6 +610,37 @@ __global__ void hilbert_key_kernel(long long n, const int32_t *__restrict__ targ
         key = (key << 3) | ((unsigned long long) ((X[0] >> b) & 1) << 2) | ((unsigned long long) ((X[1] >> b) & 1) << 1) |
               (unsigned long long) ((X[2] >> b) & 1);
     keys[t] = key;
+}
+
+namespace {
+__global__ void iota64_kernel(long long n, long long *out)
+{
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t < n)
+        out[t] = t;
+}
+} // namespace
+
+extern "C" int shq_hilbert_order(shq_context *ctx, const double *d_posm, int64_t n, double BoxSize, int64_t *d_order)
+{
+    SHQ_CHECK(ctx && (n == 0 || (d_posm && d_order)), SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(n >= 0 && BoxSize > 0, SHQ_ERR_INVALID, "hilbert_order: n = %ld, BoxSize = %g", (long) n, BoxSize);
+    if(n == 0)
+        return SHQ_OK;
+    SHQ_HIP(hipSetDevice(ctx->device));
+    TreeBuildBufs &b = ctx->tb;
+    SHQ_TRY(b.keys[0].reserve((size_t) n));
+    SHQ_TRY(b.keys[1].reserve((size_t) n));
+    SHQ_TRY(ctx->hilb_iota.reserve((size_t) n));
+    hilbert_key_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(n, nullptr, (const double4 *) d_posm, BoxSize, b.keys[0].ptr);
+    SHQ_HIP(hipGetLastError());
+    iota64_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(n, ctx->hilb_iota.ptr);
+    SHQ_HIP(hipGetLastError());
+    size_t tmp = 0;
+    SHQ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, b.keys[0].ptr, b.keys[1].ptr, ctx->hilb_iota.ptr, (long long *) d_order, (size_t) n, 0, 63, ctx->stream));
+    SHQ_TRY(b.temp.reserve(tmp + 16));
+    SHQ_HIP(rocprim::radix_sort_pairs(b.temp.ptr, tmp, b.keys[0].ptr, b.keys[1].ptr, ctx->hilb_iota.ptr, (long long *) d_order, (size_t) n, 0, 63, ctx->stream));
+    return SHQ_OK;
 }
 
 int shq_build_tree_targets(shq_context *ctx)

@@ -462,6 +462,16 @@ class GpuOps:
         assert phi.is_contiguous()
         self._call(capi.hip.shq_pm_slab2_readout, C.byref(self.pm), plane0, nxl, xoff, nalloc, C.c_void_p(phi.data_ptr()))
 
+    def hilbert_sorted(self, posm, L):
+        """rows of posm (x, y, z, m) along the Peano-Hilbert curve, ordered on the device (shq_hilbert_order)"""
+        posm = posm.contiguous()
+        n = int(posm.shape[0])
+        if n == 0:
+            return posm
+        order = torch.empty(n, dtype=torch.int64, device=posm.device)
+        self._call(capi.hip.shq_hilbert_order, posm.data_ptr(), n, float(L), order.data_ptr())
+        return posm[order].contiguous()
+
     def set_deposit_scale(self, total_mass):
         e = 61 - math.frexp(total_mass if total_mass > 0 else 1.0)[1]
         capi.check(capi.hip.shq_pm_set_deposit_log2scale(self.ctx.h, e))
@@ -508,10 +518,7 @@ class DistTreePM:
     def setup(self, posm_local, Rcut):
         """posm_local: device tensor [nloc, 4] of the particles this rank owns (already exchanged to
         their owner).  Orders them along a space-filling curve, imports ghosts, builds the tree on the device."""
-        sq = self.sq
-        host = posm_local.cpu().numpy()
-        order = sq.hilbert_order(np.ascontiguousarray(host[:, :3]), self.L)
-        self.local = posm_local[torch.from_numpy(order.astype(np.int64)).to(posm_local.device)].contiguous()
+        self.local = self.ops.hilbert_sorted(posm_local, self.L)
         self.nloc = int(self.local.shape[0])
         self.halo = self.halo_factor * Rcut
         self.ops.set_deposit_scale(self.comm.allreduce_sum(float(self.local[:, 3].sum().item())))

@@ -128,6 +128,37 @@ def test_dist_driver_one_rccl_rank_collectives_forced():
         _check(tmp, 1)
 
 
+def test_hilbert_order_on_device_equals_host(ctx):
+    """shq_hilbert_order (what DistTreePM.setup orders a rank's particles with) = the host mirror's order, entry for entry;
+    equal keys (coincident particles) stay in index order; n = 0 and n = 1 are fine"""
+    import shenqi_amd as sq
+    from shenqi_amd import capi
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 77, 50000):
+        pos = rng.random((n, 4)) * BOX
+        if n > 10:
+            pos[5, :3] = pos[9, :3] = pos[2, :3]            # coincident: same key
+            pos[7, 0] = 0.0
+            pos[8, :3] = BOX * (1 - 1e-16)
+        t = torch.from_numpy(pos).to("cuda:0")
+        out = torch.full((n,), -1, dtype=torch.int64, device="cuda:0")
+        torch.cuda.synchronize()
+        capi.check(capi.hip.shq_hilbert_order(ctx.h, C.c_void_p(t.data_ptr()), n, BOX, C.c_void_p(out.data_ptr())))
+        ctx.synchronize()
+        dev = out.cpu().numpy()
+        assert sorted(dev.tolist()) == list(range(n))
+        host = sq.hilbert_order(np.ascontiguousarray(pos[:, :3]), BOX).astype(np.int64)
+        if n > 10:
+            k = [int(np.flatnonzero(dev == i)[0]) for i in (2, 5, 9)]
+            assert k[0] < k[1] < k[2] and k[2] - k[0] == 2
+            same = ~np.isin(host, (2, 5, 9))                 # the host sort need not be stable
+            assert np.array_equal(dev[same], host[same])
+        else:
+            assert np.array_equal(dev, host)
+    with pytest.raises(sq.ShqError):
+        capi.check(capi.hip.shq_hilbert_order(ctx.h, None, 5, BOX, None))
+
+
 def test_device_particle_set_semantics(ctx):
     """shq_particles_set_device: nlocal = 0 is a rank that owns nothing (no deposit, no targets); a new set drops the tree
     (a walk is refused until the next build) unless the caller vouches the positions are the tree's"""
