@@ -458,6 +458,31 @@ int shq_slots_gc(shq_context *ctx, const shq_exchange_layout *layout, void *d_pa
 int shq_slots_gc_sorted(shq_context *ctx, const shq_exchange_layout *layout, void *d_parts, int64_t *numpart, int64_t MaxPart, void *const d_slots[6],
                         int64_t slot_size[6], const uint64_t *d_keys);
 
+/* slots_split_particle and slots_convert (libgadget/slotsmanager.cpp:27-126) for lists of particles: what star formation does
+ * with NewStars / NewParents (sfr_eff.cpp:344-372, placement = firststarslot + i), black-hole seeding (blackhole.cpp:1040) and the
+ * wind spawns do one particle at a time.  The reference hands out new particle and slot indices with atomic counters, so their
+ * order is the threads'; here entry k of the list gets NumPart + k / slot_size + k.  All pointers except the size arrays are device
+ * pointers; the entries of a list must be distinct.
+ *   shq_slots_split_particles   entry k: Generation of the parent ++ (4 bits of the flag byte, wrapping as the bit field does),
+ *                               Base[NumPart + k] = Base[parent], child ID = (ID & 0x00ff..ff) + (Generation << 56), child Mass =
+ *                               childmass[k], parent Mass -= childmass[k] (float, formed in double), child PI = -1; *numpart += n;
+ *                               d_children (may be NULL) receives the new indices.  SHQ_ERR_NOMEM when NumPart + n > MaxPart
+ *                               ("Tried to spawn ... no space left", :107), nothing touched.
+ *   shq_slots_convert           entry k: the old slot (if the old type has slots and PI >= 0) gets ReverseLink = MaxPart + 100, a new
+ *                               slot of ptype at slot_size[ptype] + k is filled with the poison byte 101 (slots_connect_new_slot)
+ *                               and becomes the particle's PI, Type = ptype; slot_size[ptype] += n.  A ptype without slots only
+ *                               changes Type.  SHQ_ERR_NOMEM when the new slots would pass slot_maxsize[ptype] ("Tried to use
+ *                               non-allocated slot", :76): reserving is the caller's (sfr_reserve_slots, fof_seed), before the call. */
+typedef struct shq_spawn_layout {
+    size_t off_id, off_mass;    /* particle_data::ID (uint64), ::Mass (float) */
+    int generation_shift;       /* first bit of the 4-bit Generation field inside the flag byte at shq_exchange_layout::off_flags */
+    int pad_;
+} shq_spawn_layout;
+int shq_slots_split_particles(shq_context *ctx, const shq_exchange_layout *layout, const shq_spawn_layout *spawn, void *d_parts, int64_t *numpart,
+                              int64_t MaxPart, const int32_t *d_parents, const double *d_childmass, int64_t n, int32_t *d_children);
+int shq_slots_convert(shq_context *ctx, const shq_exchange_layout *layout, void *d_parts, int64_t numpart, int64_t MaxPart, void *const d_slots[6],
+                      int64_t slot_size[6], const int64_t slot_maxsize[6], const int32_t *d_index, int64_t n, int ptype);
+
 /* Friends-of-friends groups of the resident particles (the first legacy-API user: libgadget/fof.cpp, one task).
  *   fof_label_primary (:368-581): particles of the primary types within LinkingLength of each other (r2 <= L^2, the neighbour
  *       test of treewalk_visit_ngbiter, treewalk.c:946-961) are one group; the reference's lock-free union-find (fofp_merge,

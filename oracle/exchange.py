@@ -7,9 +7,11 @@ TEST INFRASTRUCTURE ONLY.  Follows /root/reference/libgadget/exchange.hpp:
                                        received particles appended after NumPart in source-task order, slots appended per type,
                                        PI of every received particle renumbered in arrival order
   slots_mark_garbage       slotsmanager.cpp:590-599
+  slots_split_particle, slots_convert   slotsmanager.cpp:27-126
   slots_gc                 slotsmanager.cpp:132-370, with shall_we_compact_slots (exchange.hpp:300-317): the collection the
                                        exchange runs between pack and receive when a round is capped or memory is short
-Pinned by the four cases of the reference's tests/test_exchange.cpp and by test_slots_gc of tests/test_slotsmanager.cpp
+Pinned by the four cases of the reference's tests/test_exchange.cpp and by test_slots_gc, test_slots_gc_sorted, test_slots_fork and
+test_slots_convert of tests/test_slotsmanager.cpp
 (tests/test_exchange_cpu.py)."""
 import numpy as np
 
@@ -255,3 +257,44 @@ def slots_gc_sorted(task, keys):
         live = int((S["ReverseLink"][:used] <= task.maxpart).sum())
         task.slot_size[t] = live
         P["PI"][S["ReverseLink"][:live]] = np.arange(live)
+
+
+def slots_split_particle(task, parent, childmass):
+    """slots_split_particle, slotsmanager.cpp:102-126: a new particle split off `parent` at index NumPart (serial: the atomic
+    counter's order is the call order).  Generation is the 4-bit field in the upper half of the flag byte (it wraps at 16: the
+    reference's "generation wrapped" test compares a 4-bit value with 256 and never fires).  Returns the child's index."""
+    P = task.parts
+    child = task.numpart
+    if child >= task.maxpart:
+        raise MemoryError("Tried to spawn: NumPart=%d MaxPart = %d. Sorry, no space left." % (child, task.maxpart))
+    task.numpart += 1
+    f = int(P["Flags"][parent])
+    g = ((f >> 4) + 1) & 15
+    P["Flags"][parent] = (f & 15) | (g << 4)
+    P[child] = P[parent]
+    P["ID"][child] = (int(P["ID"][parent]) & 0x00ffffffffffffff) + (g << 56)
+    P["Mass"][child] = np.float32(childmass)
+    P["Mass"][parent] = np.float32(np.float64(P["Mass"][parent]) - np.float64(childmass))
+    P["PI"][child] = -1
+    return child
+
+
+def slots_convert(task, parent, ptype, placement=-1, maxsize=None):
+    """slots_convert + slots_connect_new_slot, slotsmanager.cpp:27-84: the old slot becomes garbage (ReverseLink = MaxPart + 100),
+    a new slot of ptype (at `placement`, or at the end of the array) is filled with the poison byte 101 and linked, Type = ptype"""
+    P = task.parts
+    oldtype, oldpi = int(P["Type"][parent]), int(P["PI"][parent])
+    if oldpi >= 0 and task.slots[oldtype] is not None:
+        task.slots[oldtype]["ReverseLink"][oldpi] = task.maxpart + 100
+    if task.slots[ptype] is not None:
+        newpi = placement
+        if placement < 0:
+            newpi = task.slot_size[ptype]
+            task.slot_size[ptype] += 1
+        cap = len(task.slots[ptype]) if maxsize is None else maxsize[ptype]
+        if newpi >= cap:
+            raise MemoryError("Tried to use non-allocated slot %d (> %d)" % (newpi, cap))
+        task.slots[ptype][newpi:newpi + 1].view(np.uint8)[:] = 101
+        P["PI"][parent] = newpi
+    P["Type"][parent] = ptype
+    return parent

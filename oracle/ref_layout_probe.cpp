@@ -58,6 +58,12 @@ int main()
     memset(&P, 0, sizeof(P));
     P.Swallowed = 1;
     const int bit_swallowed = first_set_bit(&P, sizeof(P));
+    memset(&P, 0, sizeof(P));
+    P.Generation = 1;
+    const int bit_generation = first_set_bit(&P, sizeof(P));
+    P.Generation = 15;
+    P.Generation++; /* the 4-bit field wraps: slots_split_particle's "generation wrapped" test can never fire */
+    const int generation_after_15 = P.Generation;
     printf("{\"sizeof_star_particle_data\": %zu, \"star_particle_data\": {\"ReverseLink\": %zu, \"Metals\": %zu, \"FormationTime\": %zu},\n",
            sizeof(star_particle_data), offsetof(star_particle_data, ReverseLink), offsetof(star_particle_data, Metals), offsetof(star_particle_data, FormationTime));
     printf(" \"sizeof_particle_data\": %zu, \"sizeof_sph_particle_data\": %zu, \"sizeof_bh_particle_data\": %zu,\n", sizeof(particle_data),
@@ -69,7 +75,8 @@ int main()
            pv.off_hsml, pv.off_dthsml, pv.off_timebin_hydro, pv.off_timebin_gravity);
     printf(" \"particle_data\": {\"TopLeaf\": %zu, \"Ti_drift\": %zu, \"ID\": %zu, \"GrNr\": %zu},\n", offsetof(particle_data, TopLeaf),
            offsetof(particle_data, Ti_drift), offsetof(particle_data, ID), offsetof(particle_data, GrNr));
-    printf(" \"bit_IsGarbage\": %d, \"bit_Swallowed\": %d,\n", bit_garbage, bit_swallowed);
+    printf(" \"bit_IsGarbage\": %d, \"bit_Swallowed\": %d, \"bit_Generation\": %d, \"generation_after_15\": %d,\n", bit_garbage, bit_swallowed, bit_generation,
+           generation_after_15);
     printf(" \"sph_view\": {\"elsize\": %zu, \"off_density\": %zu, \"off_egywtdensity\": %zu, \"off_entropy\": %zu, \"off_dtentropy\": %zu, "
            "\"off_maxsignalvel\": %zu, \"off_hydroaccel\": %zu, \"off_dhsmlegydensityfactor\": %zu, \"off_divvel\": %zu, \"off_curlvel\": %zu, "
            "\"off_delaytime\": %zu},\n",

@@ -209,6 +209,10 @@ class ExchangeLayout(C.Structure):
                 ("slot_elsize", C.c_size_t * 6), ("off_reverselink", C.c_size_t)]
 
 
+class SpawnLayout(C.Structure):
+    _fields_ = [("off_id", C.c_size_t), ("off_mass", C.c_size_t), ("generation_shift", C.c_int), ("pad_", C.c_int)]
+
+
 class ExchangeEntry(C.Structure):
     _fields_ = [("base", C.c_int64), ("slots", C.c_int64 * 6)]
 
@@ -365,7 +369,9 @@ hip.shq_exchange_pack.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, _vp, C.c_
 hip.shq_exchange_unpack.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.c_int64, _vp, _vp, _vp, C.c_int]
 hip.shq_slots_gc.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.POINTER(C.c_int64), C.c_int64, _vp, _vp, _vp]
 hip.shq_slots_gc_sorted.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.POINTER(C.c_int64), C.c_int64, _vp, _vp, _vp]
-for _f in ("shq_exchange_plan", "shq_exchange_pack", "shq_exchange_unpack", "shq_slots_gc", "shq_slots_gc_sorted"):
+hip.shq_slots_split_particles.argtypes = [_vp, C.POINTER(ExchangeLayout), C.POINTER(SpawnLayout), _vp, C.POINTER(C.c_int64), C.c_int64, _vp, _vp, C.c_int64, _vp]
+hip.shq_slots_convert.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_int64, C.c_int]
+for _f in ("shq_exchange_plan", "shq_exchange_pack", "shq_exchange_unpack", "shq_slots_gc", "shq_slots_gc_sorted", "shq_slots_split_particles", "shq_slots_convert"):
     getattr(hip, _f).restype = C.c_int
 hip.shq_fof.argtypes = [_vp, C.POINTER(FofParams), _vp, _vp, _vp, C.POINTER(C.c_int64)]
 hip.shq_fof.restype = C.c_int

@@ -627,3 +627,203 @@ extern "C" int shq_slots_gc_sorted(shq_context *ctx, const shq_exchange_layout *
     SHQ_HIP(hipStreamSynchronize(st));
     return SHQ_OK;
 }
+
+/* ---- slots_split_particle / slots_convert for lists (slotsmanager.cpp:27-126) ----------------------------------------------------
+ * What star formation (sfr_eff.cpp:344-372: NewStars / NewParents, placement = firststarslot + i), black-hole seeding
+ * (blackhole.cpp:1040) and the wind spawns do one particle at a time.  The reference hands out the new particle indices and slot
+ * indices with atomic counters, so their order is the threads'; here entry k of the list gets NumPart + k / size + k. */
+namespace {
+
+/* the parent's half of slots_split_particle: Generation ++ (a 4-bit field of the flag byte), Mass -= childmass */
+__global__ void split_parent_kernel(long long n, const int32_t *parents, const double *childmass, char *parts, size_t elsize, size_t off_flags, int gen_shift,
+                                    size_t off_mass, long long numpart, int *err)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    const long long p = parents[k];
+    if(p < 0 || p >= numpart) {
+        *err = 1;
+        return;
+    }
+    char *rec = parts + (size_t) p * elsize;
+    unsigned char *fl = (unsigned char *) (rec + off_flags);
+    const unsigned f = *fl;
+    const unsigned g = ((f >> gen_shift) + 1u) & 15u;
+    *fl = (unsigned char) ((f & ~(15u << gen_shift)) | (g << gen_shift));
+    float *m = (float *) (rec + off_mass);
+    *m = (float) ((double) *m - childmass[k]);
+}
+
+/* Base[child] = Base[parent], 16 bytes per thread */
+__global__ void split_copy_kernel(long long n, const int32_t *parents, char *parts, size_t elsize, long long numpart)
+{
+    const long long gid = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const int words = (int) (elsize / 16);
+    const long long k = gid / words;
+    const int w = (int) (gid % words);
+    if(k >= n)
+        return;
+    const long long p = parents[k];
+    if(p < 0 || p >= numpart)
+        return;
+    const uint4 *src = (const uint4 *) (parts + (size_t) p * elsize);
+    uint4 *dst = (uint4 *) (parts + (size_t) (numpart + k) * elsize);
+    dst[w] = src[w];
+}
+
+/* the child's half: ID carries the generation in its highest 8 bits, Mass = childmass, PI = -1 */
+__global__ void split_child_kernel(long long n, const double *childmass, char *parts, size_t elsize, size_t off_flags, int gen_shift, size_t off_id, size_t off_mass,
+                                   size_t off_pi, long long numpart, int32_t *children)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    char *rec = parts + (size_t) (numpart + k) * elsize;
+    const unsigned long long g = (*(const unsigned char *) (rec + off_flags) >> gen_shift) & 15u;
+    unsigned long long *id = (unsigned long long *) (rec + off_id);
+    *id = (*id & 0x00ffffffffffffffull) + (g << 56);
+    *(float *) (rec + off_mass) = (float) childmass[k];
+    *(int32_t *) (rec + off_pi) = -1;
+    if(children)
+        children[k] = (int32_t) (numpart + k);
+}
+
+/* slots_convert of entry k with placement first + k: the old slot becomes garbage, the new one is poisoned with 'e' (101) bytes
+ * (slots_connect_new_slot), PI and Type follow.  A few threads per entry: thread w of an entry fills words w, w + T, ... */
+constexpr int CONV_T = 8;
+__global__ void convert_kernel(long long n, const int32_t *index, char *parts, size_t elsize, size_t off_type, size_t off_pi, SlotTab tab, size_t off_rl, int invalid,
+                               int ptype, long long first, long long numpart, int *err)
+{
+    const long long gid = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const long long k = gid / CONV_T;
+    const int w = (int) (gid % CONV_T);
+    if(k >= n)
+        return;
+    const long long p = index[k];
+    if(p < 0 || p >= numpart) {
+        *err = 1;
+        return;
+    }
+    char *rec = parts + (size_t) p * elsize;
+    const unsigned oldtype = *(const unsigned char *) (rec + off_type);
+    const int oldpi = *(const int32_t *) (rec + off_pi);
+    if(oldtype >= 6) {
+        *err = 2;
+        return;
+    }
+    const bool newslot = tab.elsize[ptype] != 0;
+    if(newslot) {
+        unsigned int *dst = (unsigned int *) (tab.ptr[ptype] + (size_t) (first + k) * tab.elsize[ptype]);
+        const int words = (int) (tab.elsize[ptype] / 4);
+        for(int j = w; j < words; j += CONV_T)
+            dst[j] = 0x65656565u;
+    }
+    if(w == 0) {
+        /* the old slot is another array's record unless the type stays: then it may be the array being written, at another index
+         * (oldpi < first), which no other entry touches */
+        if(oldpi >= 0 && tab.elsize[oldtype])
+            *(int32_t *) (tab.ptr[oldtype] + (size_t) oldpi * tab.elsize[oldtype] + off_rl) = invalid;
+    }
+}
+
+/* PI and Type after every slot has been written (an entry's old slot can never be another entry's new one: new ones lie past size) */
+__global__ void convert_link_kernel(long long n, const int32_t *index, char *parts, size_t elsize, size_t off_type, size_t off_pi, bool newslot, int ptype, long long first,
+                                    long long numpart)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    const long long p = index[k];
+    if(p < 0 || p >= numpart)
+        return;
+    char *rec = parts + (size_t) p * elsize;
+    if(newslot)
+        *(int32_t *) (rec + off_pi) = (int32_t) (first + k);
+    *(unsigned char *) (rec + off_type) = (unsigned char) ptype;
+}
+
+} // namespace
+
+extern "C" int shq_slots_split_particles(shq_context *ctx, const shq_exchange_layout *layout, const shq_spawn_layout *spawn, void *d_parts, int64_t *numpart,
+                                         int64_t MaxPart, const int32_t *d_parents, const double *d_childmass, int64_t n, int32_t *d_children)
+{
+    SHQ_CHECK(ctx && spawn && d_parts && numpart, SHQ_ERR_INVALID, "null argument");
+    SHQ_TRY(check_layout(layout));
+    SHQ_CHECK(n >= 0 && (n == 0 || (d_parents && d_childmass)), SHQ_ERR_INVALID, "slots_split_particles: bad list");
+    SHQ_CHECK(*numpart >= 0 && *numpart <= MaxPart && MaxPart < (1ll << 31) - 200, SHQ_ERR_INVALID, "slots_split_particles: bad particle numbers");
+    const size_t esz = layout->part_elsize;
+    SHQ_CHECK(spawn->generation_shift >= 0 && spawn->generation_shift <= 4 && spawn->off_id + 8 <= esz && spawn->off_id % 8 == 0 && spawn->off_mass + 4 <= esz &&
+                  spawn->off_mass % 4 == 0,
+              SHQ_ERR_INVALID, "slots_split_particles: bad spawn layout");
+    /* "Tried to spawn: NumPart=%ld MaxPart = %ld. Sorry, no space left." (slotsmanager.cpp:107-108), before anything is touched */
+    SHQ_CHECK(*numpart + n <= MaxPart, SHQ_ERR_NOMEM, "slots_split_particles: NumPart = %ld + %ld spawned > MaxPart = %ld: no space left", (long) *numpart, (long) n,
+              (long) MaxPart);
+    if(n == 0)
+        return SHQ_OK;
+    SHQ_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    SHQ_TRY(ctx->ex_counts.reserve(64));
+    int *d_err = reinterpret_cast<int *>(ctx->ex_counts.ptr + 8);
+    SHQ_HIP(hipMemsetAsync(d_err, 0, sizeof(int), st));
+    const long long np = *numpart;
+    split_parent_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, d_parents, d_childmass, (char *) d_parts, esz, layout->off_flags, spawn->generation_shift,
+                                                             spawn->off_mass, np, d_err);
+    SHQ_HIP(hipGetLastError());
+    split_copy_kernel<<<dim3(nblk(n * (long long) (esz / 16))), dim3(256), 0, st>>>(n, d_parents, (char *) d_parts, esz, np);
+    SHQ_HIP(hipGetLastError());
+    split_child_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, d_childmass, (char *) d_parts, esz, layout->off_flags, spawn->generation_shift, spawn->off_id,
+                                                            spawn->off_mass, layout->off_pi, np, d_children);
+    SHQ_HIP(hipGetLastError());
+    int h_err = 0;
+    SHQ_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    SHQ_CHECK(h_err == 0, SHQ_ERR_INVALID, "slots_split_particles: a parent index lies outside [0, NumPart)");
+    *numpart = np + n;
+    return SHQ_OK;
+}
+
+extern "C" int shq_slots_convert(shq_context *ctx, const shq_exchange_layout *layout, void *d_parts, int64_t numpart, int64_t MaxPart, void *const d_slots[6],
+                                 int64_t slot_size[6], const int64_t slot_maxsize[6], const int32_t *d_index, int64_t n, int ptype)
+{
+    SHQ_CHECK(ctx && d_parts && slot_size && slot_maxsize, SHQ_ERR_INVALID, "null argument");
+    SHQ_TRY(check_layout(layout));
+    SHQ_CHECK(ptype >= 0 && ptype < 6, SHQ_ERR_INVALID, "slots_convert: type %d", ptype);
+    SHQ_CHECK(n >= 0 && (n == 0 || d_index), SHQ_ERR_INVALID, "slots_convert: bad list");
+    SHQ_CHECK(numpart >= 0 && numpart <= MaxPart && MaxPart < (1ll << 31) - 200, SHQ_ERR_INVALID, "slots_convert: bad particle numbers");
+    SlotTab tab;
+    memset(&tab, 0, sizeof(tab));
+    for(int ty = 0; ty < 6; ty++) {
+        tab.elsize[ty] = layout->slot_elsize[ty];
+        tab.ptr[ty] = (tab.elsize[ty] && d_slots) ? (char *) d_slots[ty] : nullptr;
+        SHQ_CHECK(!tab.elsize[ty] || tab.ptr[ty] || (slot_size[ty] == 0 && (ty != ptype || n == 0)), SHQ_ERR_INVALID, "slots_convert: slot type %d enabled but no array",
+                  ty);
+    }
+    const bool newslot = tab.elsize[ptype] != 0;
+    const long long first = slot_size[ptype];
+    /* "Tried to use non-allocated slot %d (> %ld)" (slotsmanager.cpp:76-78): growing the arrays is the caller's (sfr_reserve_slots,
+     * fof_seed's slots_reserve), and has to happen before the call */
+    SHQ_CHECK(!newslot || first + n <= slot_maxsize[ptype], SHQ_ERR_NOMEM, "slots_convert: %ld + %ld slots of type %d > maxsize %ld", (long) first, (long) n, ptype,
+              (long) slot_maxsize[ptype]);
+    if(n == 0)
+        return SHQ_OK;
+    SHQ_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    SHQ_TRY(ctx->ex_counts.reserve(64));
+    int *d_err = reinterpret_cast<int *>(ctx->ex_counts.ptr + 8);
+    SHQ_HIP(hipMemsetAsync(d_err, 0, sizeof(int), st));
+    convert_kernel<<<dim3(nblk(n * CONV_T)), dim3(256), 0, st>>>(n, d_index, (char *) d_parts, layout->part_elsize, layout->off_type, layout->off_pi, tab,
+                                                                 layout->off_reverselink, (int) (MaxPart + 100), ptype, first, numpart, d_err);
+    SHQ_HIP(hipGetLastError());
+    convert_link_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, d_index, (char *) d_parts, layout->part_elsize, layout->off_type, layout->off_pi, newslot, ptype, first,
+                                                             numpart);
+    SHQ_HIP(hipGetLastError());
+    int h_err = 0;
+    SHQ_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    SHQ_CHECK(h_err != 1, SHQ_ERR_INVALID, "slots_convert: a particle index lies outside [0, NumPart)");
+    SHQ_CHECK(h_err == 0, SHQ_ERR_INVALID, "slots_convert: a particle's Type is not 0..5");
+    if(newslot)
+        slot_size[ptype] = first + n;
+    return SHQ_OK;
+}

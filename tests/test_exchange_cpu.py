@@ -112,3 +112,53 @@ def test_slots_gc_sorted_reference_fixture():
     T = oex.Task(P, numpart, slots, slot_size)
     oex.slots_gc_sorted(T, _ref_keys(P, numpart, 25000.0))
     check_gc_sorted(T.parts, T.numpart, T.slots, T.slot_size)
+
+
+def _fork_setup():
+    P, numpart, slots, slot_size = fx.setup_task(0, 1, [128] * 6)
+    return oex.Task(P, numpart, slots, slot_size)
+
+
+def test_slots_fork_reference_fixture():
+    """tests/test_slotsmanager.cpp:268-286 (test_slots_fork): the first particle of every type splits off a child of mass 0 and is
+    then converted to its own type: 6 x 129 particles, 129 slots of every enabled type"""
+    T = _fork_setup()
+    ids = T.parts["ID"].copy()
+    for i in range(6):
+        child = oex.slots_split_particle(T, 128 * i, 0.0)
+        assert child == 128 * 6 + i and T.parts["PI"][child] == -1 and T.parts["Mass"][child] == 0
+        assert T.parts["ID"][child] == ids[128 * i] + (1 << 56) and (T.parts["Flags"][128 * i] >> 4) == 1
+        oex.slots_convert(T, 128 * i, int(T.parts["Type"][128 * i]))
+    assert T.numpart == 129 * 6
+    assert [T.slot_size[t] for t in (0, 4, 5)] == [129] * 3
+
+
+def test_slots_convert_reference_fixture():
+    """tests/test_slotsmanager.cpp:288-304 (test_slots_convert): conversion to the own type makes a new slot, no new particle; the
+    old slot is garbage for the next collection"""
+    T = _fork_setup()
+    for i in range(6):
+        oex.slots_convert(T, 128 * i, int(T.parts["Type"][128 * i]))
+    assert T.numpart == 128 * 6
+    assert [T.slot_size[t] for t in (0, 4, 5)] == [129] * 3
+    for t in (0, 4, 5):
+        k = int(np.flatnonzero(T.parts["Type"][:T.numpart] == t)[0])
+        assert T.parts["PI"][k] == 128 and T.slots[t]["ReverseLink"][0] == T.maxpart + 100
+        assert (T.slots[t][128:129].view(np.uint8) == 101).all()
+    oex.slots_gc(T, [1] * 6)
+    assert T.numpart == 128 * 6 and [T.slot_size[t] for t in (0, 4, 5)] == [128] * 3
+
+
+def test_slots_split_and_convert_limits():
+    T = _fork_setup()
+    T.parts["Flags"][5] = 0xF0 | 0                       # Generation 15: the 4-bit field wraps to 0, as in the reference
+    c = oex.slots_split_particle(T, 5, 0.25)
+    assert (T.parts["Flags"][5] >> 4) == 0 and T.parts["ID"][c] == (int(T.parts["ID"][5]) & 0x00ffffffffffffff)
+    assert T.parts["Mass"][5] == np.float32(0.75) and T.parts["Mass"][c] == np.float32(0.25)
+    T.numpart = T.maxpart
+    with pytest.raises(MemoryError):
+        oex.slots_split_particle(T, 5, 0.1)
+    with pytest.raises(MemoryError):
+        oex.slots_convert(T, 5, 4, maxsize=[128] * 6)
+    oex.slots_convert(T, 5, 2)                           # a type without slots: only the type changes, the gas slot is garbage
+    assert T.parts["Type"][5] == 2 and T.slots[0]["ReverseLink"][5] == T.maxpart + 100

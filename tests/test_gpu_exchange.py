@@ -319,3 +319,140 @@ def test_slots_gc_sorted_reference_fixture(ctx):
         if gS[t] is not None:
             assert same_records(gS[t][:sz[t]], T.slots[t][:T.slot_size[t]]), t
     tc.check_gc_sorted(gP, n.value, gS, list(sz))
+
+
+# ---- slots_split_particle / slots_convert for lists ----------------------------------------------------------------------------
+def spawn_layout():
+    f = capi.PARTICLE_DTYPE.fields
+    S = capi.SpawnLayout()
+    S.off_id, S.off_mass, S.generation_shift = f["ID"][1], f["Mass"][1], 4
+    return S
+
+
+class DevTask:
+    def __init__(self, T):
+        self.P = dev(T.parts)
+        self.S = [None if s is None else dev(s) for s in T.slots]
+        self.sp = (C.c_void_p * 6)(*[None if s is None else s.data_ptr() for s in self.S])
+        self.n = C.c_int64(T.numpart)
+        self.sz = (C.c_int64 * 6)(*T.slot_size)
+        self.maxpart = T.maxpart
+        self.maxsize = (C.c_int64 * 6)(*[0 if s is None else len(s) for s in T.slots])
+
+    def split(self, ctx, parents, masses, want_children=True):
+        p = torch.from_numpy(np.asarray(parents, dtype=np.int32)).to(DEV)
+        m = torch.from_numpy(np.asarray(masses, dtype=np.float64)).to(DEV)
+        ch = torch.full((max(len(parents), 1),), -7, dtype=torch.int32, device=DEV)
+        capi.check(capi.hip.shq_slots_split_particles(ctx.h, C.byref(layout_struct()), C.byref(spawn_layout()), self.P.data_ptr(), C.byref(self.n), self.maxpart,
+                                                      p.data_ptr(), m.data_ptr(), len(parents), ch.data_ptr() if want_children else None))
+        return ch.cpu().numpy()[:len(parents)]
+
+    def convert(self, ctx, index, ptype, maxsize=None):
+        ix = torch.from_numpy(np.asarray(index, dtype=np.int32)).to(DEV)
+        ms = self.maxsize if maxsize is None else (C.c_int64 * 6)(*maxsize)
+        capi.check(capi.hip.shq_slots_convert(ctx.h, C.byref(layout_struct()), self.P.data_ptr(), self.n.value, self.maxpart, self.sp, self.sz, ms, ix.data_ptr(),
+                                              len(index), ptype))
+
+    def equals(self, T):
+        assert self.n.value == T.numpart and list(self.sz) == T.slot_size
+        gP = self.P.cpu().numpy().view(capi.PARTICLE_DTYPE)
+        assert same_records(gP[:T.numpart], T.parts[:T.numpart])
+        for t in range(6):
+            if T.slots[t] is not None:
+                gS = self.S[t].cpu().numpy().view(fx.SLOT_DTYPES[t])
+                # poisoned slots hold NaN-patterned floats: compare them as bytes, field by field
+                for f in gS.dtype.names:
+                    a = np.ascontiguousarray(gS[f][:T.slot_size[t]])
+                    b = np.ascontiguousarray(T.slots[t][f][:T.slot_size[t]])
+                    assert a.tobytes() == b.tobytes(), (t, f)
+
+
+def fork_task():
+    P, numpart, slots, slot_size = fx.setup_task(0, 1, [128] * 6)
+    return oex.Task(P, numpart, slots, slot_size)
+
+
+def test_slots_fork_reference_fixture(ctx):
+    """tests/test_slotsmanager.cpp:268-286 through the list calls: six parents split, then converted to their own types"""
+    T = fork_task()
+    D = DevTask(T)
+    parents = [128 * i for i in range(6)]
+    ch = D.split(ctx, parents, [0.0] * 6)
+    assert ch.tolist() == [768 + i for i in range(6)]
+    for i in range(6):
+        D.convert(ctx, [128 * i], i)
+        oex.slots_split_particle(T, 128 * i, 0.0)
+    for i in range(6):
+        oex.slots_convert(T, 128 * i, i)
+    assert D.n.value == 129 * 6 and [D.sz[t] for t in (0, 4, 5)] == [129] * 3
+    D.equals(T)
+
+
+def test_slots_convert_reference_fixture(ctx):
+    """tests/test_slotsmanager.cpp:288-304, then the collection that sweeps the abandoned slots"""
+    T = fork_task()
+    D = DevTask(T)
+    for i in range(6):
+        D.convert(ctx, [128 * i], i)
+        oex.slots_convert(T, 128 * i, i)
+    assert D.n.value == 128 * 6 and [D.sz[t] for t in (0, 4, 5)] == [129] * 3
+    D.equals(T)
+    compact = (C.c_int * 6)(*[1] * 6)
+    capi.check(capi.hip.shq_slots_gc(ctx.h, C.byref(layout_struct()), D.P.data_ptr(), C.byref(D.n), D.maxpart, D.sp, D.sz, compact))
+    oex.slots_gc(T, [1] * 6)
+    assert [D.sz[t] for t in (0, 4, 5)] == [128] * 3
+    D.equals(T)
+
+
+def test_star_formation_pattern_equals_serial_loop(ctx):
+    """the shape of sfr_eff.cpp:344-372: some gas particles turn into stars whole, others split a star off first; then black-hole
+    seeds from gas (blackhole.cpp:1040) and a conversion to a type without slots.  List entry k = the k-th call of the serial loop."""
+    rng = np.random.default_rng(8)
+    P, numpart, slots, slot_size = fx.setup_task(0, 1, [300, 20, 0, 5, 40, 6], maxpart=1024, rng=rng)
+    T = oex.Task(P, numpart, slots, slot_size)
+    T.parts["Mass"][:numpart] = rng.uniform(0.5, 2.0, numpart).astype(np.float32)
+    T.parts["Flags"][:numpart] |= (rng.integers(0, 16, numpart).astype(np.uint8) << 4)      # generations 0..15, wrap included
+    D = DevTask(T)
+    gas = rng.permutation(300)
+    whole, splitters, seeds, drop = gas[:60], gas[60:130], gas[130:137], gas[137:140]
+    cm = rng.uniform(0.05, 0.4, len(splitters))
+    ch = D.split(ctx, splitters, cm)
+    och = [oex.slots_split_particle(T, int(p), float(m)) for p, m in zip(splitters, cm)]
+    assert ch.tolist() == och
+    newstars = np.concatenate([whole, ch])                          # NewStars: converted parents and spawned children alike
+    D.convert(ctx, newstars, 4)
+    for s in newstars:
+        oex.slots_convert(T, int(s), 4)
+    D.convert(ctx, seeds, 5)
+    for s in seeds:
+        oex.slots_convert(T, int(s), 5)
+    D.convert(ctx, drop, 1)
+    for s in drop:
+        oex.slots_convert(T, int(s), 1)
+    D.equals(T)
+    assert D.n.value == numpart + len(splitters) and D.sz[4] == 40 + len(newstars) and D.sz[5] == 6 + len(seeds) and D.sz[0] == 300
+    # the children carry PI = -1 until converted: the spawned stars were converted, so no live particle has PI -1 in a slotted type
+    gP = D.P.cpu().numpy().view(capi.PARTICLE_DTYPE)[:D.n.value]
+    assert (gP["PI"][np.isin(gP["Type"], (0, 4, 5))] >= 0).all()
+    # an empty list is fine, children may be left unreported
+    D.split(ctx, [], [])
+    D.convert(ctx, [], 4)
+    D.split(ctx, [int(gas[200])], [0.01], want_children=False)
+    oex.slots_split_particle(T, int(gas[200]), 0.01)
+    D.equals(T)
+
+
+def test_slots_split_convert_errors(ctx):
+    T = fork_task()
+    D = DevTask(T)
+    with pytest.raises(sq.ShqError):                     # no space left: 768 + 300 > 1024, nothing touched
+        D.split(ctx, list(range(300)), [0.1] * 300)
+    with pytest.raises(sq.ShqError):                     # more stars than reserved slots
+        D.convert(ctx, [0, 1, 2], 4, maxsize=[1024, 0, 0, 0, 130, 1024])
+    D.equals(T)
+    with pytest.raises(sq.ShqError):
+        D.convert(ctx, [5], 6)
+    with pytest.raises(sq.ShqError):
+        D.convert(ctx, [5000], 4)
+    with pytest.raises(sq.ShqError):
+        D.split(ctx, [-1], [0.1])

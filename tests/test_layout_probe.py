@@ -41,6 +41,8 @@ def test_particle_data_layout(layout):
     # flag byte: bit 0 IsGarbage, bit 1 Swallowed (what the library's packer reads at off_flags)
     assert layout["bit_IsGarbage"] == 8 * f["Flags"] + 0
     assert layout["bit_Swallowed"] == 8 * f["Flags"] + 1
+    # Generation: the upper 4 bits of the same byte (shq_spawn_layout::generation_shift = 4), wrapping at 16
+    assert layout["bit_Generation"] == 8 * f["Flags"] + 4 and layout["generation_after_15"] == 0
     # field types the packer reads: f32 mass in an f64 record, 1-byte type and bins
     assert d.fields["Mass"][0] == np.dtype("<f4") and d.fields["Type"][0] == np.dtype("u1") and d.fields["Pos"][0].base == np.dtype("<f8")
 
