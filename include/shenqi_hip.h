@@ -413,6 +413,11 @@ int shq_timebins_download(shq_context *ctx, uint8_t *bin_gravity, uint8_t *bin_h
 /* SphP[].MaxSignalVel by particle index (what the hydro criterion reads): upload for a state that did not come from a hydro
  * run of this context (NULL keeps it; gas particles only are read). */
 int shq_maxsignalvel_upload(shq_context *ctx, const double *maxsignalvel_by_particle);
+/* The gas state the SPH operators keep resident (Hsml, Vel, time bins, and per gas particle Entropy, DtEntropy, HydroAccel, DelayTime,
+ * Density, EgyWtDensity, DhsmlEgyDensityFactor, DivVel, CurlVel, MaxSignalVel from its slot), without running one of them: what a
+ * caller does before shq_fof (MaxDens / seed_index read Density and DelayTime) or shq_find_timesteps when no density / hydro call
+ * preceded it in the step (e.g. right after a restart).  The particles must be the resident set. */
+int shq_sph_state_upload(shq_context *ctx, const shq_part_view *parts, const shq_sph_view *sph);
 
 /* Particle exchange between tasks on opaque records (ExchangePlan, libgadget/exchange.hpp:31-537).
  * The arrays are the reference's own — particle_data[MaxPart] and the per-type slot arrays — through pointers the device can
@@ -483,6 +488,33 @@ int shq_slots_split_particles(shq_context *ctx, const shq_exchange_layout *layou
 int shq_slots_convert(shq_context *ctx, const shq_exchange_layout *layout, void *d_parts, int64_t numpart, int64_t MaxPart, void *const d_slots[6],
                       int64_t slot_size[6], const int64_t slot_maxsize[6], const int32_t *d_index, int64_t n, int ptype);
 
+/* make_particle_star (libgadget/sfr_eff.cpp:604-630) for the lists of the star-formation merge step (:344-372): entry k converts
+ * children[k] (the parent itself, or the particle split off it) to a star at slot firststarslot + k and fills the slot from the
+ * PARENT's gas slot as it was before the conversion: FormationTime = Time, LastEnrichmentMyr = TotalMassReturned = 0, BirthDensity,
+ * VDisp, Metallicity, Metals[nmetals].  A parent that is not gas is SHQ_ERR_INVALID ("Only gas forms stars"), nothing touched.
+ * Field types are the reference's (star: float FormationTime / LastEnrichmentMyr / BirthDensity / VDisp / Metals, double
+ * TotalMassReturned / Metallicity; gas: double Density / VDisp / Metallicity, float Metals). */
+typedef struct shq_star_spawn_layout {
+    size_t star_formationtime, star_lastenrichmentmyr, star_totalmassreturned, star_birthdensity, star_vdisp, star_metallicity, star_metals;
+    size_t sph_density, sph_vdisp, sph_metallicity, sph_metals;
+    int nmetals, pad_;
+} shq_star_spawn_layout;
+int shq_make_particle_stars(shq_context *ctx, const shq_exchange_layout *layout, const shq_star_spawn_layout *sl, void *d_parts, int64_t numpart, int64_t MaxPart,
+                            void *const d_slots[6], int64_t slot_size[6], const int64_t slot_maxsize[6], const int32_t *d_children, const int32_t *d_parents,
+                            int64_t n, double Time);
+/* blackhole_make_one (libgadget/blackhole.cpp:1029-1088) for a list of gas particles (fof_seed's ImportGroups[n].seed_index,
+ * fof.cpp:1378-1381): conversion to type 5 + every field the reference initialises; seedmass[k] is BHP.Mass = Mseed
+ * (SeedBlackHoleMass, or the caller's bh_powerlaw_seed_mass(ID) draw); with SeedBHDynMass > 0 the particle's mass moves to Mtrack
+ * and becomes SeedBHDynMass, otherwise Mtrack = -1.  Not gas: SHQ_ERR_INVALID ("Only Gas turns into blackholes"). */
+typedef struct shq_bh_seed_layout {
+    size_t bh_mass, bh_mseed, bh_mdot, bh_formationtime, bh_swallowid, bh_density, bh_timebindynfric, bh_minpotpos, bh_dfaccel, bh_df_surroundingvel,
+        bh_dragaccel, bh_df_surroundingrmsvel, bh_df_surroundingdensity, bh_jumptominpot, bh_countprogs, bh_mtrack, bh_kineticfdbkenergy, bh_vdisp;
+    size_t part_pos, part_mass, part_timebin_hydro;
+} shq_bh_seed_layout;
+int shq_blackhole_make_seeds(shq_context *ctx, const shq_exchange_layout *layout, const shq_bh_seed_layout *bl, void *d_parts, int64_t numpart, int64_t MaxPart,
+                             void *const d_slots[6], int64_t slot_size[6], const int64_t slot_maxsize[6], const int32_t *d_index, const double *d_seedmass, int64_t n,
+                             double atime, double SeedBHDynMass);
+
 /* Friends-of-friends groups of the resident particles (the first legacy-API user: libgadget/fof.cpp, one task).
  *   fof_label_primary (:368-581): particles of the primary types within LinkingLength of each other (r2 <= L^2, the neighbour
  *       test of treewalk_visit_ngbiter, treewalk.c:946-961) are one group; the reference's lock-free union-find (fofp_merge,
@@ -526,6 +558,10 @@ typedef struct shq_fof_group {
 int shq_fof(shq_context *ctx, const shq_fof_params *params, const uint64_t *ids, uint64_t *minid_by_particle, int32_t *grnr_by_particle,
             int64_t *ngroups);
 int shq_fof_groups_download(shq_context *ctx, shq_fof_group *groups, int64_t capacity);
+/* The marking loop of fof_seed (fof.cpp:1290-1302) on the resident catalogue: the seed_index (densest gas particle) of every group
+ * with Mass >= MinFoFMassForNewSeed, MassType[4] >= MinMStarForNewSeed, no black hole yet and a seed candidate, in catalogue order,
+ * into the DEVICE array d_seed_index (NULL: count only) — the list shq_blackhole_make_seeds takes.  One task: seed_task is this task. */
+int shq_fof_seed_select(shq_context *ctx, double MinFoFMassForNewSeed, double MinMStarForNewSeed, int32_t *d_seed_index, int64_t capacity, int64_t *nseeds);
 /* particle indices of all kept groups, group after group (order of shq_fof_groups_download), members in index order */
 int shq_fof_members(shq_context *ctx, int32_t *members, int64_t capacity, int64_t *nmembers);
 

@@ -298,3 +298,55 @@ def slots_convert(task, parent, ptype, placement=-1, maxsize=None):
         P["PI"][parent] = newpi
     P["Type"][parent] = ptype
     return parent
+
+
+NMETALS = 9
+
+
+def make_particle_star(task, child, parent, placement, Time):
+    """make_particle_star, sfr_eff.cpp:604-630 (no fixture in the reference's tests: a field-by-field restatement)"""
+    P = task.parts
+    if P["Type"][parent] != 0:
+        raise ValueError("Only gas forms stars, what's wrong?")
+    old = task.slots[0][int(P["PI"][parent])].copy()
+    slots_convert(task, child, 4, placement)
+    S = task.slots[4]
+    pi = int(P["PI"][child])
+    S["FormationTime"][pi] = np.float32(Time)
+    S["LastEnrichmentMyr"][pi] = 0
+    S["TotalMassReturned"][pi] = 0
+    S["BirthDensity"][pi] = np.float32(old["Density"])
+    S["VDisp"][pi] = np.float32(old["VDisp"])
+    S["Metallicity"][pi] = old["Metallicity"]
+    S["Metals"][pi] = old["Metals"]
+
+
+def blackhole_make_one(task, index, atime, seedmass, SeedBHDynMass):
+    """blackhole_make_one, blackhole.cpp:1029-1088; seedmass is the caller's BHP.Mass (SeedBlackHoleMass or the power-law draw)"""
+    P = task.parts
+    if P["Type"][index] != 0:
+        raise ValueError("Only Gas turns into blackholes, what's wrong?")
+    slots_convert(task, index, 5, -1)
+    B = task.slots[5]
+    pi = int(P["PI"][index])
+    B["Mass"][pi] = B["Mseed"][pi] = seedmass
+    B["Mdot"][pi] = 0
+    B["FormationTime"][pi] = atime
+    B["SwallowID"][pi] = np.uint64(0xffffffffffffffff)
+    B["Density"][pi] = 0
+    B["TimeBinDynFric"][pi] = P["TimeBinHydro"][index]
+    B["MinPotPos"][pi] = P["Pos"][index]
+    B["DFAccel"][pi] = 0
+    B["DF_SurroundingVel"][pi] = 0
+    B["DragAccel"][pi] = 0
+    B["DF_SurroundingRmsVel"][pi] = 0
+    B["DF_SurroundingDensity"][pi] = 0
+    B["JumpToMinPot"][pi] = 0
+    B["CountProgs"][pi] = 1
+    if SeedBHDynMass > 0:
+        B["Mtrack"][pi] = np.float64(P["Mass"][index])
+        P["Mass"][index] = np.float32(SeedBHDynMass)
+    else:
+        B["Mtrack"][pi] = -1
+    B["KineticFdbkEnergy"][pi] = 0
+    B["VDisp"][pi] = 0

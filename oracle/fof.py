@@ -167,3 +167,9 @@ def fof(pos, vel, mass, types, ids, dead, hsml, box, linkl, minlength, primary_m
     minid, _ = label_secondary(pos, types, dead, hsml, minid, box, linkl, primary_mask, secondary_mask)
     groups, part_grnr = catalogue(pos, vel, mass, types, minid, box, minlength, density, decoupled)
     return minid, groups, part_grnr
+
+
+def seed_marks(groups, min_fof_mass, min_mstar):
+    """the marking loop of fof_seed, fof.cpp:1290-1302 (one task): seed_index of the marked groups in catalogue order"""
+    return [G["seed_index"] for G in groups
+            if G["Mass"] >= min_fof_mass and G["MassType"][4] >= min_mstar and G["LenType"][5] == 0 and G["seed_index"] >= 0]

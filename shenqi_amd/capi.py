@@ -213,6 +213,17 @@ class SpawnLayout(C.Structure):
     _fields_ = [("off_id", C.c_size_t), ("off_mass", C.c_size_t), ("generation_shift", C.c_int), ("pad_", C.c_int)]
 
 
+class StarSpawnLayout(C.Structure):
+    _fields_ = [(k, C.c_size_t) for k in ("star_formationtime", "star_lastenrichmentmyr", "star_totalmassreturned", "star_birthdensity", "star_vdisp",
+                                         "star_metallicity", "star_metals", "sph_density", "sph_vdisp", "sph_metallicity", "sph_metals")] + [("nmetals", C.c_int), ("pad_", C.c_int)]
+
+
+class BhSeedLayout(C.Structure):
+    _fields_ = [(k, C.c_size_t) for k in ("bh_mass", "bh_mseed", "bh_mdot", "bh_formationtime", "bh_swallowid", "bh_density", "bh_timebindynfric", "bh_minpotpos",
+                                         "bh_dfaccel", "bh_df_surroundingvel", "bh_dragaccel", "bh_df_surroundingrmsvel", "bh_df_surroundingdensity", "bh_jumptominpot",
+                                         "bh_countprogs", "bh_mtrack", "bh_kineticfdbkenergy", "bh_vdisp", "part_pos", "part_mass", "part_timebin_hydro")]
+
+
 class ExchangeEntry(C.Structure):
     _fields_ = [("base", C.c_int64), ("slots", C.c_int64 * 6)]
 
@@ -371,6 +382,14 @@ hip.shq_slots_gc.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.POINTER(C.c_
 hip.shq_slots_gc_sorted.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.POINTER(C.c_int64), C.c_int64, _vp, _vp, _vp]
 hip.shq_slots_split_particles.argtypes = [_vp, C.POINTER(ExchangeLayout), C.POINTER(SpawnLayout), _vp, C.POINTER(C.c_int64), C.c_int64, _vp, _vp, C.c_int64, _vp]
 hip.shq_slots_convert.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_int64, C.c_int]
+hip.shq_make_particle_stars.argtypes = [_vp, C.POINTER(ExchangeLayout), C.POINTER(StarSpawnLayout), _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_double]
+hip.shq_blackhole_make_seeds.argtypes = [_vp, C.POINTER(ExchangeLayout), C.POINTER(BhSeedLayout), _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.c_int64,
+                                         C.c_double, C.c_double]
+hip.shq_sph_state_upload.argtypes = [_vp, C.POINTER(PartView), C.POINTER(SphView)]
+hip.shq_sph_state_upload.restype = C.c_int
+hip.shq_fof_seed_select.argtypes = [_vp, C.c_double, C.c_double, _vp, C.c_int64, C.POINTER(C.c_int64)]
+for _f in ("shq_make_particle_stars", "shq_blackhole_make_seeds", "shq_fof_seed_select"):
+    getattr(hip, _f).restype = C.c_int
 for _f in ("shq_exchange_plan", "shq_exchange_pack", "shq_exchange_unpack", "shq_slots_gc", "shq_slots_gc_sorted", "shq_slots_split_particles", "shq_slots_convert"):
     getattr(hip, _f).restype = C.c_int
 hip.shq_fof.argtypes = [_vp, C.POINTER(FofParams), _vp, _vp, _vp, C.POINTER(C.c_int64)]

@@ -827,3 +827,156 @@ extern "C" int shq_slots_convert(shq_context *ctx, const shq_exchange_layout *la
         slot_size[ptype] = first + n;
     return SHQ_OK;
 }
+
+/* ---- make_particle_star (sfr_eff.cpp:604-630) and blackhole_make_one (blackhole.cpp:1029-1088) for lists -------------------------
+ * slots_convert of the list + the new slots' fields, read from the parents' gas slots / the particles themselves. */
+namespace {
+
+__global__ void parent_pi_kernel(long long n, const int32_t *parents, const char *parts, size_t elsize, size_t off_type, size_t off_pi, long long numpart,
+                                 long long sphsize, int32_t *pi, int *err)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    const long long p = parents[k];
+    if(p < 0 || p >= numpart) {
+        *err = 1;
+        pi[k] = -1;
+        return;
+    }
+    const char *rec = parts + (size_t) p * elsize;
+    const int v = *(const int32_t *) (rec + off_pi);
+    if(*(const unsigned char *) (rec + off_type) != 0 || v < 0 || v >= sphsize) {
+        *err = 3; /* "Only gas forms stars, what's wrong?" (sfr_eff.cpp:607) / "Only Gas turns into blackholes" (blackhole.cpp:1031) */
+        pi[k] = -1;
+        return;
+    }
+    pi[k] = v;
+}
+
+__global__ void star_init_kernel(long long n, const int32_t *children, const int32_t *sphpi, const char *parts, size_t elsize, size_t off_pi, char *star, size_t star_el,
+                                 const char *sph, size_t sph_el, shq_star_spawn_layout L, float Time)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n || sphpi[k] < 0)
+        return;
+    const int pi = *(const int32_t *) (parts + (size_t) children[k] * elsize + off_pi);
+    char *S = star + (size_t) pi * star_el;
+    const char *G = sph + (size_t) sphpi[k] * sph_el;
+    *(float *) (S + L.star_formationtime) = Time;
+    *(float *) (S + L.star_lastenrichmentmyr) = 0.f;
+    *(double *) (S + L.star_totalmassreturned) = 0.;
+    *(float *) (S + L.star_birthdensity) = (float) *(const double *) (G + L.sph_density);
+    *(float *) (S + L.star_vdisp) = (float) *(const double *) (G + L.sph_vdisp);
+    *(double *) (S + L.star_metallicity) = *(const double *) (G + L.sph_metallicity);
+    for(int j = 0; j < L.nmetals; j++)
+        ((float *) (S + L.star_metals))[j] = ((const float *) (G + L.sph_metals))[j];
+}
+
+__global__ void bh_seed_init_kernel(long long n, const int32_t *index, const double *seedmass, char *parts, size_t elsize, size_t off_pi, char *bh, size_t bh_el,
+                                    shq_bh_seed_layout L, double atime, double SeedBHDynMass)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    char *P = parts + (size_t) index[k] * elsize;
+    char *B = bh + (size_t) *(const int32_t *) (P + off_pi) * bh_el;
+    const double m = seedmass[k];
+    *(double *) (B + L.bh_mass) = m;
+    *(double *) (B + L.bh_mseed) = m;
+    *(double *) (B + L.bh_mdot) = 0;
+    *(double *) (B + L.bh_formationtime) = atime;
+    *(unsigned long long *) (B + L.bh_swallowid) = ~0ull;
+    *(double *) (B + L.bh_density) = 0;
+    *(unsigned char *) (B + L.bh_timebindynfric) = *(const unsigned char *) (P + L.part_timebin_hydro);
+    for(int j = 0; j < 3; j++) {
+        ((double *) (B + L.bh_minpotpos))[j] = ((const double *) (P + L.part_pos))[j];
+        ((double *) (B + L.bh_dfaccel))[j] = 0;
+        ((double *) (B + L.bh_df_surroundingvel))[j] = 0;
+        ((double *) (B + L.bh_dragaccel))[j] = 0;
+    }
+    *(double *) (B + L.bh_df_surroundingrmsvel) = 0;
+    *(double *) (B + L.bh_df_surroundingdensity) = 0;
+    *(signed char *) (B + L.bh_jumptominpot) = 0;
+    *(int32_t *) (B + L.bh_countprogs) = 1;
+    if(SeedBHDynMass > 0) {
+        *(double *) (B + L.bh_mtrack) = (double) *(const float *) (P + L.part_mass);
+        *(float *) (P + L.part_mass) = (float) SeedBHDynMass;
+    } else
+        *(double *) (B + L.bh_mtrack) = -1;
+    *(double *) (B + L.bh_kineticfdbkenergy) = 0;
+    *(double *) (B + L.bh_vdisp) = 0;
+}
+
+} // namespace
+
+extern "C" int shq_make_particle_stars(shq_context *ctx, const shq_exchange_layout *layout, const shq_star_spawn_layout *sl, void *d_parts, int64_t numpart,
+                                       int64_t MaxPart, void *const d_slots[6], int64_t slot_size[6], const int64_t slot_maxsize[6], const int32_t *d_children,
+                                       const int32_t *d_parents, int64_t n, double Time)
+{
+    SHQ_CHECK(ctx && sl && d_parts && slot_size && slot_maxsize && d_slots, SHQ_ERR_INVALID, "null argument");
+    SHQ_TRY(check_layout(layout));
+    SHQ_CHECK(layout->slot_elsize[0] && layout->slot_elsize[4] && d_slots[0] && d_slots[4], SHQ_ERR_INVALID, "make_particle_stars: gas and star slots must be enabled");
+    SHQ_CHECK(n >= 0 && (n == 0 || (d_children && d_parents)), SHQ_ERR_INVALID, "make_particle_stars: bad list");
+    SHQ_CHECK(sl->nmetals >= 0 && sl->star_metals + 4 * (size_t) sl->nmetals <= layout->slot_elsize[4] && sl->sph_metals + 4 * (size_t) sl->nmetals <= layout->slot_elsize[0],
+              SHQ_ERR_INVALID, "make_particle_stars: bad slot layout");
+    if(n == 0)
+        return SHQ_OK;
+    SHQ_CHECK(slot_size[4] + n <= slot_maxsize[4], SHQ_ERR_NOMEM, "make_particle_stars: %ld + %ld star slots > maxsize %ld (sfr_reserve_slots first)", (long) slot_size[4],
+              (long) n, (long) slot_maxsize[4]);
+    SHQ_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    SHQ_TRY(ctx->ex_counts.reserve(64));
+    SHQ_TRY(ctx->ex_val[2].reserve((size_t) n));
+    int *d_err = reinterpret_cast<int *>(ctx->ex_counts.ptr + 8);
+    SHQ_HIP(hipMemsetAsync(d_err, 0, sizeof(int), st));
+    /* oldslot = SPHP(parent), before the conversion overwrites a converted parent's PI */
+    parent_pi_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, d_parents, (const char *) d_parts, layout->part_elsize, layout->off_type, layout->off_pi, numpart, slot_size[0],
+                                                          ctx->ex_val[2].ptr, d_err);
+    SHQ_HIP(hipGetLastError());
+    int h_err = 0;
+    SHQ_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    SHQ_CHECK(h_err != 1, SHQ_ERR_INVALID, "make_particle_stars: a parent index lies outside [0, NumPart)");
+    SHQ_CHECK(h_err == 0, SHQ_ERR_INVALID, "make_particle_stars: only gas forms stars (sfr_eff.cpp:607)");
+    SHQ_TRY(shq_slots_convert(ctx, layout, d_parts, numpart, MaxPart, d_slots, slot_size, slot_maxsize, d_children, n, 4));
+    star_init_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, d_children, ctx->ex_val[2].ptr, (const char *) d_parts, layout->part_elsize, layout->off_pi, (char *) d_slots[4],
+                                                          layout->slot_elsize[4], (const char *) d_slots[0], layout->slot_elsize[0], *sl, (float) Time);
+    SHQ_HIP(hipGetLastError());
+    SHQ_HIP(hipStreamSynchronize(st));
+    return SHQ_OK;
+}
+
+extern "C" int shq_blackhole_make_seeds(shq_context *ctx, const shq_exchange_layout *layout, const shq_bh_seed_layout *bl, void *d_parts, int64_t numpart, int64_t MaxPart,
+                                        void *const d_slots[6], int64_t slot_size[6], const int64_t slot_maxsize[6], const int32_t *d_index, const double *d_seedmass,
+                                        int64_t n, double atime, double SeedBHDynMass)
+{
+    SHQ_CHECK(ctx && bl && d_parts && slot_size && slot_maxsize && d_slots, SHQ_ERR_INVALID, "null argument");
+    SHQ_TRY(check_layout(layout));
+    SHQ_CHECK(layout->slot_elsize[0] && layout->slot_elsize[5] && d_slots[5], SHQ_ERR_INVALID, "blackhole_make_seeds: gas and black-hole slots must be enabled");
+    SHQ_CHECK(n >= 0 && (n == 0 || (d_index && d_seedmass)), SHQ_ERR_INVALID, "blackhole_make_seeds: bad list");
+    if(n == 0)
+        return SHQ_OK;
+    SHQ_CHECK(slot_size[5] + n <= slot_maxsize[5], SHQ_ERR_NOMEM, "blackhole_make_seeds: %ld + %ld black-hole slots > maxsize %ld (fof_seed reserves first, fof.cpp:1343-1366)",
+              (long) slot_size[5], (long) n, (long) slot_maxsize[5]);
+    SHQ_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    SHQ_TRY(ctx->ex_counts.reserve(64));
+    SHQ_TRY(ctx->ex_val[2].reserve((size_t) n));
+    int *d_err = reinterpret_cast<int *>(ctx->ex_counts.ptr + 8);
+    SHQ_HIP(hipMemsetAsync(d_err, 0, sizeof(int), st));
+    parent_pi_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, d_index, (const char *) d_parts, layout->part_elsize, layout->off_type, layout->off_pi, numpart, slot_size[0],
+                                                          ctx->ex_val[2].ptr, d_err);
+    SHQ_HIP(hipGetLastError());
+    int h_err = 0;
+    SHQ_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    SHQ_CHECK(h_err != 1, SHQ_ERR_INVALID, "blackhole_make_seeds: a seed index lies outside [0, NumPart)");
+    SHQ_CHECK(h_err == 0, SHQ_ERR_INVALID, "blackhole_make_seeds: only gas turns into black holes (blackhole.cpp:1031)");
+    SHQ_TRY(shq_slots_convert(ctx, layout, d_parts, numpart, MaxPart, d_slots, slot_size, slot_maxsize, d_index, n, 5));
+    bh_seed_init_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, d_index, d_seedmass, (char *) d_parts, layout->part_elsize, layout->off_pi, (char *) d_slots[5],
+                                                             layout->slot_elsize[5], *bl, atime, SeedBHDynMass);
+    SHQ_HIP(hipGetLastError());
+    SHQ_HIP(hipStreamSynchronize(st));
+    return SHQ_OK;
+}

@@ -19,6 +19,8 @@
 #include <algorithm>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 namespace {
 
@@ -759,6 +761,55 @@ extern "C" int shq_fof_members(shq_context *ctx, int32_t *members, int64_t capac
         SHQ_HIP(hipMemcpyAsync(members, ctx->fof_members.ptr, sizeof(int32_t) * (size_t) ctx->fof_nmembers, hipMemcpyDeviceToHost, ctx->stream));
         SHQ_HIP(hipStreamSynchronize(ctx->stream));
     }
+    return SHQ_OK;
+}
+
+namespace {
+struct SeedGroup {
+    const shq_fof_group *g;
+    double minmass, minstar;
+    /* Marked[i], fof.cpp:1294-1298 */
+    __device__ bool operator()(const int32_t i) const
+    {
+        const shq_fof_group &G = g[i];
+        return G.Mass >= minmass && G.MassType[4] >= minstar && G.LenType[5] == 0 && G.seed_index >= 0;
+    }
+};
+__global__ void fof_seed_index_kernel(long long n, const int32_t *which, const shq_fof_group *g, int32_t *out)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k < n)
+        out[k] = g[which[k]].seed_index;
+}
+} // namespace
+
+extern "C" int shq_fof_seed_select(shq_context *ctx, double MinFoFMassForNewSeed, double MinMStarForNewSeed, int32_t *d_seed_index, int64_t capacity, int64_t *nseeds)
+{
+    SHQ_CHECK(ctx && nseeds, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->fof_ngroups >= 0, SHQ_ERR_STATE, "fof_seed_select: run shq_fof first");
+    *nseeds = 0;
+    const long long ng = ctx->fof_ngroups;
+    if(ng == 0)
+        return SHQ_OK;
+    SHQ_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    SHQ_TRY(ctx->ex_list.reserve((size_t) ng));
+    SHQ_TRY(ctx->ex_counts.reserve(64));
+    size_t tmp = 0;
+    rocprim::counting_iterator<int32_t> it(0);
+    const SeedGroup pred{ctx->fof_groups.ptr, MinFoFMassForNewSeed, MinMStarForNewSeed};
+    SHQ_HIP(rocprim::select(nullptr, tmp, it, ctx->ex_list.ptr, ctx->ex_counts.ptr, (size_t) ng, pred, st));
+    SHQ_TRY(ctx->ex_bytes.reserve(tmp + 16));
+    SHQ_HIP(rocprim::select(ctx->ex_bytes.ptr, tmp, it, ctx->ex_list.ptr, ctx->ex_counts.ptr, (size_t) ng, pred, st));
+    unsigned long long h = 0;
+    SHQ_HIP(hipMemcpyAsync(&h, ctx->ex_counts.ptr, sizeof(h), hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    *nseeds = (int64_t) h;
+    if(!d_seed_index || h == 0)
+        return SHQ_OK;
+    SHQ_CHECK(capacity >= (int64_t) h, SHQ_ERR_INVALID, "fof_seed_select: capacity %ld < %ld seeds", (long) capacity, (long) h);
+    fof_seed_index_kernel<<<dim3(nblk((long long) h)), dim3(256), 0, st>>>((long long) h, ctx->ex_list.ptr, ctx->fof_groups.ptr, d_seed_index);
+    SHQ_HIP(hipGetLastError());
     return SHQ_OK;
 }
 

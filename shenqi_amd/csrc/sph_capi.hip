@@ -157,6 +157,16 @@ std::vector<int32_t> build_queue(const shq_part_view *parts, const int32_t *acti
 
 } // namespace
 
+extern "C" int shq_sph_state_upload(shq_context *ctx, const shq_part_view *parts, const shq_sph_view *sph)
+{
+    SHQ_CHECK(ctx && parts && sph, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts && ctx->numpart == parts->numpart, SHQ_ERR_STATE, "sph_state_upload: upload these particles first (%ld resident, %ld in the view)",
+              (long) (ctx->have_parts ? ctx->numpart : -1), (long) parts->numpart);
+    SHQ_HIP(hipSetDevice(ctx->device));
+    return sph_upload(ctx, parts, sph);
+}
+
+
 /* the host copy of the work queue of the open walk: close() assigns results only to the walked targets */
 static std::vector<int32_t> &run_queue(shq_context *ctx) { return ctx->sph_queue_host; }
 

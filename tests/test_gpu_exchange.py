@@ -456,3 +456,103 @@ def test_slots_split_convert_errors(ctx):
         D.convert(ctx, [5000], 4)
     with pytest.raises(sq.ShqError):
         D.split(ctx, [-1], [0.1])
+
+
+# ---- make_particle_star / blackhole_make_one for lists ----------------------------------------------------------------------
+def star_layout():
+    st, sp = capi.STAR_DTYPE.fields, capi.SPH_DTYPE.fields
+    L = capi.StarSpawnLayout()
+    L.star_formationtime, L.star_lastenrichmentmyr, L.star_totalmassreturned = st["FormationTime"][1], st["LastEnrichmentMyr"][1], st["TotalMassReturned"][1]
+    L.star_birthdensity, L.star_vdisp, L.star_metallicity, L.star_metals = st["BirthDensity"][1], st["VDisp"][1], st["Metallicity"][1], st["Metals"][1]
+    L.sph_density, L.sph_vdisp, L.sph_metallicity, L.sph_metals = sp["Density"][1], sp["VDisp"][1], sp["Metallicity"][1], sp["Metals"][1]
+    L.nmetals = 9
+    return L
+
+
+def bh_seed_layout():
+    b, p = capi.BH_DTYPE.fields, capi.PARTICLE_DTYPE.fields
+    L = capi.BhSeedLayout()
+    for key, name in (("bh_mass", "Mass"), ("bh_mseed", "Mseed"), ("bh_mdot", "Mdot"), ("bh_formationtime", "FormationTime"), ("bh_swallowid", "SwallowID"),
+                      ("bh_density", "Density"), ("bh_timebindynfric", "TimeBinDynFric"), ("bh_minpotpos", "MinPotPos"), ("bh_dfaccel", "DFAccel"),
+                      ("bh_df_surroundingvel", "DF_SurroundingVel"), ("bh_dragaccel", "DragAccel"), ("bh_df_surroundingrmsvel", "DF_SurroundingRmsVel"),
+                      ("bh_df_surroundingdensity", "DF_SurroundingDensity"), ("bh_jumptominpot", "JumpToMinPot"), ("bh_countprogs", "CountProgs"),
+                      ("bh_mtrack", "Mtrack"), ("bh_kineticfdbkenergy", "KineticFdbkEnergy"), ("bh_vdisp", "VDisp")):
+        setattr(L, key, b[name][1])
+    L.part_pos, L.part_mass, L.part_timebin_hydro = p["Pos"][1], p["Mass"][1], p["TimeBinHydro"][1]
+    return L
+
+
+def gas_task(rng, ngas=200):
+    P, numpart, slots, slot_size = fx.setup_task(0, 1, [ngas, 30, 0, 0, 25, 4], maxpart=1024, rng=rng)
+    T = oex.Task(P, numpart, slots, slot_size)
+    S = T.slots[0]
+    S["Density"][:ngas] = rng.uniform(0.1, 50, ngas)
+    S["VDisp"][:ngas] = rng.uniform(1, 300, ngas)
+    S["Metallicity"][:ngas] = rng.uniform(0, 0.05, ngas)
+    S["Metals"][:ngas] = rng.uniform(0, 1e-3, (ngas, 9)).astype(np.float32)
+    T.parts["Mass"][:numpart] = rng.uniform(0.5, 2.0, numpart).astype(np.float32)
+    T.parts["TimeBinHydro"][:numpart] = rng.integers(20, 40, numpart)
+    T.parts["Pos"][:numpart] = rng.random((numpart, 3)) * 1000
+    return T
+
+
+def test_make_particle_stars_equals_serial_loop(ctx):
+    """sfr_eff.cpp:344-372: NewStars / NewParents with converted and spawned stars mixed, placement firststarslot + i; the star slots
+    carry the PARENT's gas fields, also for a converted parent whose own PI has been overwritten by then"""
+    rng = np.random.default_rng(31)
+    T = gas_task(rng)
+    D = DevTask(T)
+    gas = rng.permutation(200)
+    converted, splitters = gas[:40], gas[40:90]
+    cm_ = rng.uniform(0.05, 0.3, len(splitters))
+    ch = D.split(ctx, splitters, cm_)
+    for p, m in zip(splitters, cm_):
+        oex.slots_split_particle(T, int(p), float(m))
+    # the reference's lists are in active-particle order: converted and spawned entries interleave
+    order = rng.permutation(len(converted) + len(splitters))
+    children = np.concatenate([converted, ch])[order].astype(np.int32)
+    parents = np.concatenate([converted, splitters])[order].astype(np.int32)
+    dch, dpa = torch.from_numpy(children).to(DEV), torch.from_numpy(parents).to(DEV)
+    first = T.slot_size[4]
+    capi.check(capi.hip.shq_make_particle_stars(ctx.h, C.byref(layout_struct()), C.byref(star_layout()), D.P.data_ptr(), D.n.value, D.maxpart, D.sp, D.sz, D.maxsize,
+                                                dch.data_ptr(), dpa.data_ptr(), len(children), 0.3125))
+    for i, (c, p) in enumerate(zip(children, parents)):
+        oex.make_particle_star(T, int(c), int(p), first + i, 0.3125)
+    T.slot_size[4] += len(children)
+    D.equals(T)
+    gS = D.S[4].cpu().numpy().view(capi.STAR_DTYPE)
+    assert (gS["FormationTime"][first:first + len(children)] == np.float32(0.3125)).all() and (gS["BirthDensity"][first:first + len(children)] > 0).all()
+    # a parent that is not gas (any more): refused before anything changes
+    with pytest.raises(sq.ShqError):
+        capi.check(capi.hip.shq_make_particle_stars(ctx.h, C.byref(layout_struct()), C.byref(star_layout()), D.P.data_ptr(), D.n.value, D.maxpart, D.sp, D.sz, D.maxsize,
+                                                    dch.data_ptr(), dpa.data_ptr(), 1, 0.5))
+    few = (C.c_int64 * 6)(1024, 0, 0, 0, D.sz[4] + 1, 1024)
+    two = torch.from_numpy(gas[100:102].astype(np.int32)).to(DEV)
+    with pytest.raises(sq.ShqError):                     # sfr_reserve_slots was not called
+        capi.check(capi.hip.shq_make_particle_stars(ctx.h, C.byref(layout_struct()), C.byref(star_layout()), D.P.data_ptr(), D.n.value, D.maxpart, D.sp, D.sz, few,
+                                                    two.data_ptr(), two.data_ptr(), 2, 0.5))
+    D.equals(T)
+
+
+@pytest.mark.parametrize("dynmass", [0.0, 7.5])
+def test_blackhole_make_seeds_equals_serial_loop(ctx, dynmass):
+    """blackhole.cpp:1029-1088 for a list of seeds, with and without SeedBHDynMass"""
+    rng = np.random.default_rng(41)
+    T = gas_task(rng)
+    D = DevTask(T)
+    seeds = rng.permutation(200)[:9].astype(np.int32)
+    seedmass = rng.uniform(1e-5, 1e-3, len(seeds))
+    ds, dm = torch.from_numpy(seeds).to(DEV), torch.from_numpy(seedmass).to(DEV)
+    capi.check(capi.hip.shq_blackhole_make_seeds(ctx.h, C.byref(layout_struct()), C.byref(bh_seed_layout()), D.P.data_ptr(), D.n.value, D.maxpart, D.sp, D.sz, D.maxsize,
+                                                 ds.data_ptr(), dm.data_ptr(), len(seeds), 0.125, dynmass))
+    for s, m in zip(seeds, seedmass):
+        oex.blackhole_make_one(T, int(s), 0.125, float(m), dynmass)
+    D.equals(T)
+    gP = D.P.cpu().numpy().view(capi.PARTICLE_DTYPE)
+    gB = D.S[5].cpu().numpy().view(capi.BH_DTYPE)
+    assert (gP["Type"][seeds] == 5).all() and np.array_equal(gB["MinPotPos"][gP["PI"][seeds]], gP["Pos"][seeds])
+    assert (gB["Mtrack"][gP["PI"][seeds]] == -1).all() if dynmass == 0 else (gP["Mass"][seeds] == np.float32(dynmass)).all()
+    with pytest.raises(sq.ShqError):                     # "Only Gas turns into blackholes": the first seed is a black hole now
+        capi.check(capi.hip.shq_blackhole_make_seeds(ctx.h, C.byref(layout_struct()), C.byref(bh_seed_layout()), D.P.data_ptr(), D.n.value, D.maxpart, D.sp, D.sz,
+                                                     D.maxsize, ds.data_ptr(), dm.data_ptr(), 1, 0.125, dynmass))
+    D.equals(T)

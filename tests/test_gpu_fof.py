@@ -163,3 +163,69 @@ def test_fof_requires_run_and_handles_empty_and_no_groups(ctx):
         assert capi.hip.shq_fof_groups_download(c2.h, None, 0) != 0
     finally:
         c2.close()
+
+
+def test_fof_seed_candidates_and_seed_select(ctx):
+    """the gas state resident (shq_sph_state_upload): MaxDens / seed_index per group as add_particle_to_group finds them (densest gas
+    member that is not a decoupled wind particle, fof.cpp:619-628), then fof_seed's marking loop (fof.cpp:1290-1302) against the
+    restatement, with thresholds that keep some groups and drop others"""
+    rng = np.random.default_rng(21)
+    box = 400.0
+    centres = rng.random((40, 3)) * box
+    sizes = rng.integers(10, 300, size=40)
+    dm = np.concatenate([c + rng.normal(size=(s, 3)) * 1.5 for c, s in zip(centres, sizes)])
+    nsec = 2500
+    sec = centres[rng.integers(0, 40, size=nsec)] + rng.normal(size=(nsec, 3)) * 2.5
+    pos = np.mod(np.concatenate([dm, sec]), box)
+    n = len(pos)
+    types = np.concatenate([np.ones(len(dm), dtype=np.uint8), rng.choice([0, 4, 5], size=nsec, p=[0.6, 0.39, 0.01]).astype(np.uint8)])
+    perm = rng.permutation(n)
+    pos, types = pos[perm], types[perm]
+    ids = rng.permutation(n).astype(np.uint64) + 5
+    vel = rng.normal(size=(n, 3)) * 50
+    mass = rng.choice([1.0, 0.25], size=n).astype(np.float32).astype(np.float64)
+    hsml = rng.uniform(0.5, 4.0, size=n)
+    gas = np.flatnonzero(types == 0)
+    S = np.zeros(len(gas), dtype=capi.SPH_DTYPE)
+    S["Density"] = rng.uniform(1.0, 100.0, len(gas))
+    S["DelayTime"] = np.where(rng.random(len(gas)) < 0.3, 1.0, 0.0)      # winds: never a seed when WindsDecoupleSph is on
+    pman = cm.make_partmanager(pos, box=box)
+    P = pman.Base
+    P["Type"], P["Mass"], P["Vel"], P["ID"], P["Hsml"] = types, mass, vel, ids, hsml
+    P["PI"][gas] = np.arange(len(gas))
+    density = np.zeros(n)
+    density[gas] = S["Density"]
+    delayed = np.zeros(n, dtype=bool)
+    delayed[gas] = S["DelayTime"] > 0
+    pv, sv = pman.view(), capi.sph_view(S)
+    for winds in (0, 1):
+        capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+        sq.dynamics_upload(ctx, pman)
+        capi.check(capi.hip.shq_sph_state_upload(ctx.h, C.byref(pv), C.byref(sv)))
+        fp = capi.FofParams(box, 1.2, 2, 1 + 16 + 32, 8, winds)
+        minid = np.zeros(n, dtype=np.uint64)
+        grnr = np.zeros(n, dtype=np.int32)
+        ng = C.c_int64()
+        capi.check(capi.hip.shq_fof(ctx.h, C.byref(fp), capi.ptr(np.ascontiguousarray(ids)), capi.ptr(minid), capi.ptr(grnr), C.byref(ng)))
+        groups = np.zeros(ng.value, dtype=capi.FOF_GROUP_DTYPE)
+        capi.check(capi.hip.shq_fof_groups_download(ctx.h, capi.ptr(groups), len(groups)))
+        ominid, ogroups, _ = ofof.fof(pos, vel, mass, types, ids, np.zeros(n, dtype=bool), hsml, box, 1.2, 8, density=density,
+                                      decoupled=delayed if winds else None)
+        assert np.array_equal(minid, ominid) and len(groups) == len(ogroups) > 20
+        assert [int(g["seed_index"]) for g in groups] == [o["seed_index"] for o in ogroups]
+        assert [float(g["MaxDens"]) for g in groups] == [o["MaxDens"] for o in ogroups]
+        assert sum(o["seed_index"] >= 0 for o in ogroups) > 10
+        import torch
+        for minmass, minstar in ((0.0, 0.0), (150.0, 0.0), (60.0, 8.0), (1e9, 0.0)):
+            want = ofof.seed_marks(ogroups, minmass, minstar)
+            out = torch.full((max(len(groups), 1),), -9, dtype=torch.int32, device="cuda:0")
+            ns = C.c_int64(-1)
+            capi.check(capi.hip.shq_fof_seed_select(ctx.h, minmass, minstar, None, 0, C.byref(ns)))
+            assert ns.value == len(want)
+            capi.check(capi.hip.shq_fof_seed_select(ctx.h, minmass, minstar, out.data_ptr(), len(groups), C.byref(ns)))
+            ctx.synchronize()
+            assert out.cpu().numpy()[:ns.value].tolist() == want
+            if len(want) > 1:
+                with pytest.raises(sq.ShqError):
+                    capi.check(capi.hip.shq_fof_seed_select(ctx.h, minmass, minstar, out.data_ptr(), 1, C.byref(ns)))
+        assert 0 < len(ofof.seed_marks(ogroups, 60.0, 8.0)) < len(ofof.seed_marks(ogroups, 0.0, 0.0))
