@@ -879,6 +879,58 @@ int shq_bh_dynfric(shq_context *ctx, const shq_tree_view *tree, const shq_part_v
                    const shq_kick_factors *kf, int BH_DynFrictionMethod, int DensityKernelType, int typemask,
                    const shq_bh_dynfric_out *out);
 
+/* The two legacy-API tree walks of blackhole() (libgadget/blackhole.cpp:217-370), after blackhole_dynfric:
+ * symmetric neighbour search over gas + black holes on the caller's tree (GASMASK + BHMASK with hmax: blackhole() calls
+ * force_tree_calc_moments when it is missing), one black hole per lane of the SPH operators' wave-collective walk.
+ *   shq_bh_accretion   blackhole_accretion_ngbiter / _reduce / _postprocess (:373-692) for the holes of `queue` (ActiveBlackHoles):
+ *       BH_SwallowID marks for mergers (r < 2 ForceSoftening / 2.8, the reposition / MergeGravBound rule with check_grav_bound,
+ *       the reference's compare-and-swap: the larger ID swallows, an inactive hole can be swallowed by a smaller one);
+ *       SPH_SwallowID marks for stochastically swallowed gas (the largest ID + 1 that drew the particle: w = Table[ID % size] <
+ *       (BH_Mass - Mass or Mtrack) wk / Density); BH_FeedbackWeightSum, BH_Entropy, BH_SurroundingGasVel, MgasEnc; then Mdot
+ *       (Bondi-Hoyle, Eddington cap), BHP.Mass += Mdot dtime, DragAccel, KineticFdbkEnergy / KEflag.  encounter, Mdot, Mass,
+ *       DragAccel, KineticFdbkEnergy are written into the slots; the BHPriv arrays into `work` (by slot index, as there).
+ *   shq_bh_feedback    blackhole_feedback_ngbiter / _reduce / _postprocess (:728-965) for the holes of `queue` that are not marked
+ *       themselves: marked holes and gas are swallowed (Swallowed / slots_mark_garbage, SwallowID, SwallowTime, mass, momentum,
+ *       CountProgs), thermal energy into the unswallowed gas inside the kernel (compare-and-swap on the entropy, capped at
+ *       MaxThermalU; BHHeated where eeqos[i] != 0) or the released kinetic energy as kicks in the direction get_random_dir draws,
+ *       minTimeBin; then BHP.Mass, Part.Vel, Mtrack / Part.Mass and the KineticFdbkEnergy reset.  Particle flags, Vel, Mass, the gas
+ *       Entropy and the slots are updated in the caller's arrays.
+ * Derived constants are the caller's: EddingtonConst = 4 pi GRAVITY LIGHTCGS PROTONMASS / (0.1 LIGHTCGS^2 THOMPSON) (:379),
+ * LightOverUnitVel = LIGHTCGS / UnitVelocity_in_cm_per_s, MaxThermalU = 5e8 / u_to_temp_fac (add_injected_BH_energy, :700-710),
+ * Hubble = CP->Hubble, hubble = hubble_function(atime).  The random table is RandTable::Table.  ids[i] = Part[i].ID. */
+typedef struct shq_bh_params {
+    double BoxSize, ForceSoftening, SeedBHDynMass, atime, a3inv, hubble, GravInternal;
+    double BlackHoleAccretionFactor, BlackHoleEddingtonFactor, BlackHoleFeedbackFactor;
+    double EddingtonConst, UnitTime_in_s, HubbleParam, LightOverUnitVel, MaxThermalU, OmegaBaryon, Hubble;
+    double BHKE_EddingtonThrFactor, BHKE_EddingtonMFactor, BHKE_EddingtonMPivot, BHKE_EddingtonMIndex, BHKE_EffRhoFactor, BHKE_EffCap, BHKE_InjEnergyThr,
+        BHKE_SfrCritOverDensity;
+    int DensityKernelType, WindsDecoupleSph, RepositionEnabled, MergeGravBound, BH_DRAG, BlackHoleKineticOn;
+} shq_bh_params;
+typedef struct shq_bh_slot_view {
+    void *base;
+    size_t elsize;
+    int64_t numslots;
+    size_t off_mass, off_mdot, off_density, off_mtrack, off_dfaccel, off_vdisp, off_kineticfdbkenergy, off_dragaccel, off_encounter, off_countprogs,
+        off_mintimebin, off_swallowid, off_swallowtime;
+} shq_bh_slot_view;
+typedef struct shq_bh_work {        /* struct BHPriv, blackhole.h:9-45: the caller's arrays, by slot index */
+    uint64_t *SPH_SwallowID;        /* [gas slots] */
+    uint64_t *BH_SwallowID;         /* [black-hole slots] */
+    double *BH_FeedbackWeightSum, *BH_Entropy;
+    double (*BH_SurroundingGasVel)[3];
+    double *MgasEnc;
+    int32_t *KEflag;
+    double *BH_accreted_Mass, *BH_accreted_BHMass;   /* feedback only */
+    double (*BH_accreted_momentum)[3];
+} shq_bh_work;
+int shq_bh_accretion(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph, const shq_bh_slot_view *bh,
+                     const uint64_t *ids, const int32_t *queue, int64_t nqueue, const shq_kick_factors *kf, const shq_bh_params *params, int64_t Ti_Current,
+                     const double *rnd_table, int64_t rnd_size, const shq_bh_work *work);
+int shq_bh_feedback(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph, const shq_bh_slot_view *bh,
+                    const uint64_t *ids, const int32_t *queue, int64_t nqueue, const shq_kick_factors *kf, const shq_bh_params *params, int64_t MaxPart,
+                    const double *rnd_table, int64_t rnd_size, const uint8_t *eeqos, const shq_bh_work *work, int64_t *n_sph_swallowed,
+                    int64_t *n_bh_swallowed);
+
 /* ---- long-range PM --------------------------------------------------------------------- */
 
 /* Mirror of the PetaPM fields gravpm.cpp reads (libgadget/petapm.h:87-112). */

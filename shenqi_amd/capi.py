@@ -213,6 +213,38 @@ class SpawnLayout(C.Structure):
     _fields_ = [("off_id", C.c_size_t), ("off_mass", C.c_size_t), ("generation_shift", C.c_int), ("pad_", C.c_int)]
 
 
+class BhParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("BoxSize", "ForceSoftening", "SeedBHDynMass", "atime", "a3inv", "hubble", "GravInternal", "BlackHoleAccretionFactor",
+                                         "BlackHoleEddingtonFactor", "BlackHoleFeedbackFactor", "EddingtonConst", "UnitTime_in_s", "HubbleParam",
+                                         "LightOverUnitVel", "MaxThermalU", "OmegaBaryon", "Hubble", "BHKE_EddingtonThrFactor", "BHKE_EddingtonMFactor",
+                                         "BHKE_EddingtonMPivot", "BHKE_EddingtonMIndex", "BHKE_EffRhoFactor", "BHKE_EffCap", "BHKE_InjEnergyThr",
+                                         "BHKE_SfrCritOverDensity")] + \
+               [(k, C.c_int) for k in ("DensityKernelType", "WindsDecoupleSph", "RepositionEnabled", "MergeGravBound", "BH_DRAG", "BlackHoleKineticOn")]
+
+
+class BhSlotView(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("elsize", C.c_size_t), ("numslots", C.c_int64)] + \
+               [(k, C.c_size_t) for k in ("off_mass", "off_mdot", "off_density", "off_mtrack", "off_dfaccel", "off_vdisp", "off_kineticfdbkenergy", "off_dragaccel",
+                                          "off_encounter", "off_countprogs", "off_mintimebin", "off_swallowid", "off_swallowtime")]
+
+
+class BhWork(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("SPH_SwallowID", "BH_SwallowID", "BH_FeedbackWeightSum", "BH_Entropy", "BH_SurroundingGasVel", "MgasEnc", "KEflag",
+                                          "BH_accreted_Mass", "BH_accreted_BHMass", "BH_accreted_momentum")]
+
+
+def bh_slot_view(arr):
+    """shq_bh_slot_view of a numpy array of BH_DTYPE records"""
+    f = BH_DTYPE.fields
+    v = BhSlotView()
+    v.base, v.elsize, v.numslots = arr.ctypes.data, BH_DTYPE.itemsize, len(arr)
+    for key, name in (("off_mass", "Mass"), ("off_mdot", "Mdot"), ("off_density", "Density"), ("off_mtrack", "Mtrack"), ("off_dfaccel", "DFAccel"),
+                      ("off_vdisp", "VDisp"), ("off_kineticfdbkenergy", "KineticFdbkEnergy"), ("off_dragaccel", "DragAccel"), ("off_encounter", "encounter"),
+                      ("off_countprogs", "CountProgs"), ("off_mintimebin", "minTimeBin"), ("off_swallowid", "SwallowID"), ("off_swallowtime", "SwallowTime")):
+        setattr(v, key, f[name][1])
+    return v
+
+
 class StarSpawnLayout(C.Structure):
     _fields_ = [(k, C.c_size_t) for k in ("star_formationtime", "star_lastenrichmentmyr", "star_totalmassreturned", "star_birthdensity", "star_vdisp",
                                          "star_metallicity", "star_metals", "sph_density", "sph_vdisp", "sph_metallicity", "sph_metals")] + [("nmetals", C.c_int), ("pad_", C.c_int)]
@@ -385,6 +417,11 @@ hip.shq_slots_convert.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.c_int64
 hip.shq_make_particle_stars.argtypes = [_vp, C.POINTER(ExchangeLayout), C.POINTER(StarSpawnLayout), _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_double]
 hip.shq_blackhole_make_seeds.argtypes = [_vp, C.POINTER(ExchangeLayout), C.POINTER(BhSeedLayout), _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.c_int64,
                                          C.c_double, C.c_double]
+hip.shq_bh_accretion.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(SphView), C.POINTER(BhSlotView), _vp, _vp, C.c_int64, C.POINTER(KickFactors),
+                                 C.POINTER(BhParams), C.c_int64, _vp, C.c_int64, C.POINTER(BhWork)]
+hip.shq_bh_feedback.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(SphView), C.POINTER(BhSlotView), _vp, _vp, C.c_int64, C.POINTER(KickFactors),
+                                C.POINTER(BhParams), C.c_int64, _vp, C.c_int64, _vp, C.POINTER(BhWork), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+hip.shq_bh_accretion.restype = hip.shq_bh_feedback.restype = C.c_int
 hip.shq_sph_state_upload.argtypes = [_vp, C.POINTER(PartView), C.POINTER(SphView)]
 hip.shq_sph_state_upload.restype = C.c_int
 hip.shq_fof_seed_select.argtypes = [_vp, C.c_double, C.c_double, _vp, C.c_int64, C.POINTER(C.c_int64)]

@@ -285,6 +285,12 @@ struct shq_context {
     int64_t ntree_targets = 0;
     bool have_tree_targets = false;
     DevBuf<long long> hilb_iota;  /* shq_hilbert_order: 0 .. n-1, the values of its sort */
+    /* black-hole accretion / feedback walks: per-call uploads (sph_capi.hip) */
+    DevBuf<int32_t> bhw_bhp, bhw_queue;
+    DevBuf<char> bhw_rec;
+    DevBuf<unsigned long long> bhw_ids, bhw_sphsw, bhw_bhsw, bhw_swid;
+    DevBuf<double> bhw_rnd, bhw_out;
+    DevBuf<uint8_t> bhw_eeqos, bhw_heated;
     bool tb_built = false;     /* the current tree came from shq_tree_build (downloadable) */
 
     /* ---- SPH state, by particle index (gas fields gathered from their slots at upload) */
@@ -449,6 +455,38 @@ int shq_bh_dynfric_device(shq_context *ctx, const shq_kick_factors *kf, double B
                           const double *d_potential, const int32_t *d_queue, int64_t nq, double *d_out);
 int shq_wind_veldisp_device(shq_context *ctx, const shq_kick_factors *kf, double BoxSize, double hubble_a2, const int32_t *d_queue, int64_t nq,
                             double *d_dmradius, double *d_vdisp, shq_sph_stats *stats);
+/* black-hole accretion / feedback walks (sph.hip) */
+struct BhRec {
+    double Mass, Density, Mtrack, DFAccel[3], VDisp, KineticFdbkEnergy, Mdot, FeedbackWeightSum;
+    int32_t CountProgs, KEflag;
+};
+
+struct BhWalkArgs {
+    const int32_t *bhp;        /* particle indices of all black holes, ascending */
+    long long nbh;
+    BhRec *bh;
+    const unsigned long long *ids;
+    const double *rnd;
+    unsigned long long rndsize;
+    const double *vel, *treeacc, *gravpm, *delay;
+    double *velw;              /* Vel, written by the kinetic kicks */
+    double *entropy;           /* written by the thermal feedback */
+    const double *density;
+    const uint8_t *bin_grav, *bin_hydro;
+    uint8_t *pflags;
+    const uint8_t *eeqos;      /* sfreff_on_eeqos per particle, or NULL */
+    uint8_t *heated;           /* BHHeated per particle (out) */
+    const int32_t *leaf_pidx;
+    unsigned long long *sph_swallow; /* by particle index */
+    unsigned long long *bh_swallow;  /* by black-hole ordinal */
+    unsigned long long *bh_swallowid_out; /* BHP.SwallowID of swallowed holes, by ordinal */
+    double *out;
+    shq_bh_params P;
+    long long Ti_Current;
+};
+
+int shq_bh_accretion_device(shq_context *ctx, const shq_kick_factors *kf, const BhWalkArgs *w, const int32_t *d_queue, int64_t nq, double *d_post);
+int shq_bh_feedback_device(shq_context *ctx, const shq_kick_factors *kf, const BhWalkArgs *w, const int32_t *d_queue, int64_t nq);
 int shq_bh_veldisp_device(shq_context *ctx, const shq_kick_factors *kf, double BoxSize, const int32_t *d_queue, int64_t nq, double *d_out);
 int shq_sph_stellar_density_device(shq_context *ctx, const shq_stellar_params *p, const int32_t *d_queue, int64_t nq, double *d_starvol,
                                    shq_sph_stats *stats);

@@ -2760,3 +2760,429 @@ int shq_sph_gradrho_mag(shq_context *ctx, double *d_out)
     SHQ_HIP(hipGetLastError());
     return SHQ_OK;
 }
+
+/* ---- black-hole accretion and feedback: libgadget/blackhole.cpp:373-1003 ------------------------------
+ * The two legacy-API tree walks of blackhole(): symmetric neighbour search over gas + black holes (treewalk_visit_ngbiter,
+ * treewalk.c:925-975: r2 <= max(Hsml_i, Hsml_j)^2), one black hole per lane on the wave-collective walk of the SPH operators.
+ *   accretion (ngbiter :471-631, postprocess :373-468): merger marks (BH_SwallowID, the reference's compare-and-swap rule),
+ *     stochastic gas swallowing marks (SPH_SwallowID = the largest ID + 1 that drew the particle), the kernel-weighted entropy, gas
+ *     velocity and feedback weight around the hole, Bondi-Hoyle rate capped at the Eddington factor, drag, kinetic-feedback state;
+ *   feedback (ngbiter :728-876, postprocess :929-965): the marked mergers and gas particles are swallowed (mass, momentum, progenitor
+ *     count), thermal energy goes into the unswallowed gas inside the kernel (compare-and-swap on the entropy, temperature cap) or
+ *     the accumulated kinetic energy kicks it in a random direction, the hole takes the smallest neighbour time bin.
+ * Black-hole slot fields travel as one record per black hole of the particle set, in ascending particle order. */
+__device__ __forceinline__ bool bh_timebin_active(int bin, long long cur) /* is_timebin_active, timestep.cpp:132-139 */
+{
+    if(bin <= 0 || cur <= 0)
+        return true;
+    return cur % (1ll << bin) == 0;
+}
+
+#define BH_ACC_NOUT 8
+template <int KT>
+__global__ __launch_bounds__(256) void bh_accretion_kernel(const SphDev a, const int32_t *queue, long long nq, const BhWalkArgs w, const shq_kick_factors kf,
+                                                           int32_t *__restrict__ nlist, long long ntasks)
+{
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(32))) char lds[4 * NW_LDS_PER_WAVE(true)];
+    const int lane = threadIdx.x & 63;
+    for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
+    const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    const long long t = wave * 64 + lane;
+    const bool valid = t < nq;
+    double px = 0, py = 0, pz = 0, h = 1, imass = 0, ibhmass = 0, idens = 0, imtrack = 0;
+    double iv[3] = {0, 0, 0}, ia[3] = {0, 0, 0};
+    unsigned long long myid = 0;
+    if(valid) {
+        const long long pi = queue[t];
+        const double4 p = a.posm[pi];
+        px = p.x; py = p.y; pz = p.z;
+        imass = p.w;
+        h = a.hsml[pi];
+        myid = w.ids[pi];
+        const long long b = shq_bh_ordinal(w.bhp, w.nbh, (int32_t) pi);
+        const BhRec &B = w.bh[b];
+        ibhmass = B.Mass; idens = B.Density; imtrack = B.Mtrack;
+        for(int d = 0; d < 3; d++) {
+            iv[d] = w.vel[3 * pi + d];
+            ia[d] = w.treeacc[3 * pi + d] + w.gravpm[3 * pi + d] + B.DFAccel[d]; /* blackhole_accretion_copy, :661-662 */
+        }
+    }
+    const Kern<KT> kernel(h);
+    const double HH = kernel.H * kernel.H, Hinv = 1.0 / kernel.H;
+    const double h2 = h * h;
+    int encounter = 0;
+    double fws = 0, sment = 0, gv0 = 0, gv1 = 0, gv2 = 0, mgas = 0;
+    const double rmerge = 2 * w.P.ForceSoftening / 2.8;
+    auto pair = [&](const int s) {
+        const long long p = w.leaf_pidx[s];
+        const double4 q = a.posm_leaf[s];
+        const int type = w.pflags[p] >> 4;
+        if(q.w < 0)
+            return;
+        if(w.P.WindsDecoupleSph && type == 0 && w.delay[p] > 0) /* winds_is_particle_decoupled */
+            return;
+        if(w.ids[p] == myid)
+            return;
+        const double d0 = wrapd(px - q.x, a.Box, a.invBox), d1 = wrapd(py - q.y, a.Box, a.invBox), d2 = wrapd(pz - q.z, a.Box, a.invBox);
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        const double r = sqrt(r2);
+        if(type == 5 && r < rmerge) {
+            encounter = 1;
+            const long long ob = shq_bh_ordinal(w.bhp, w.nbh, (int32_t) p);
+            int flag = 0;
+            if(w.P.RepositionEnabled == 1 || w.P.MergeGravBound == 0)
+                flag = 1;
+            if(w.P.MergeGravBound == 1 && w.P.RepositionEnabled == 0 && ob >= 0) {
+                /* check_grav_bound, :160-180, with DM_VelPred of the other hole */
+                const double dx[3] = {d0, d1, d2};
+                double KE = 0, PE = 0;
+                const int bg = w.bin_grav[p];
+                for(int d = 0; d < 3; d++) {
+                    const double vp = w.vel[3 * p + d] + kf.gravkicks[bg] * w.treeacc[3 * p + d] + w.gravpm[3 * p + d] * kf.FgravkickB;
+                    const double dv = iv[d] - vp;
+                    const double da = ia[d] - w.treeacc[3 * p + d] - w.gravpm[3 * p + d] - w.bh[ob].DFAccel[d];
+                    KE += 0.5 * (dv * dv);
+                    PE += da * dx[d];
+                }
+                KE /= (w.P.atime * w.P.atime);
+                PE /= w.P.atime;
+                flag = (PE + KE <= 0);
+            }
+            if(flag == 1 && ob >= 0) {
+                const unsigned long long oid = w.ids[p];
+                const bool oactive = bh_timebin_active(w.bin_hydro[p], w.Ti_Current);
+                unsigned long long *swal = w.bh_swallow + ob;
+                unsigned long long readid = atomicAdd(swal, 0ull);
+                for(;;) {
+                    unsigned long long newid;
+                    if(readid != 0 && readid < myid)
+                        newid = myid + 1;
+                    else if(readid == 0 && (oid < myid || !oactive))
+                        newid = myid + 1;
+                    else
+                        break;
+                    const unsigned long long seen = atomicCAS(swal, readid, newid);
+                    if(seen == readid)
+                        break;
+                    readid = seen;
+                }
+            }
+        }
+        if(type == 0 && r2 < HH) {
+            const double u = r * Hinv;
+            const double wk = kernel.wk(u);
+            const double mass_j = q.w;
+            sment += (mass_j * wk * w.entropy[p]);
+            const double4 vp = a.velp[p]; /* SPH_VelPred */
+            gv0 += (mass_j * wk * vp.x);
+            gv1 += (mass_j * wk * vp.y);
+            gv2 += (mass_j * wk * vp.z);
+            double pacc = 0;
+            double BHPartMass = imass;
+            if(w.P.SeedBHDynMass > 0 && imtrack < w.P.SeedBHDynMass)
+                BHPartMass = imtrack;
+            if((ibhmass - BHPartMass) > 0 && idens > 0)
+                pacc = (ibhmass - BHPartMass) * wk / idens;
+            const double rn = w.rnd[w.ids[p] % w.rndsize];
+            if(rn < pacc)
+                atomicMax(w.sph_swallow + p, myid + 1); /* "prefer to be swallowed by a bigger ID" */
+            fws += (mass_j * wk);
+            if(w.P.BlackHoleKineticOn == 1)
+                mgas += mass_j;
+        }
+    };
+    auto accept = [&](const double r2, const double hj, const int) { return r2 <= h2 || r2 <= hj * hj; };
+    int fill = 0;
+    bool ovf = false;
+    (void) ngb_walk<true, false, false>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(true), myl, valid, px, py, pz, h, accept, pair,
+                                        (unsigned int *) nullptr, fill, ovf);
+    if(valid) {
+        double *o = w.out + BH_ACC_NOUT * t;
+        o[0] = encounter; o[1] = fws; o[2] = sment; o[3] = gv0; o[4] = gv1; o[5] = gv2; o[6] = mgas; o[7] = 0;
+    }
+    } /* task loop */
+}
+
+/* blackhole_accretion_postprocess (:373-468), one thread per active black hole; out[t] then holds BH_Entropy and
+ * BH_SurroundingGasVel normalised, and the hole's record Mdot, Mass, DragAccel (in out), KineticFdbkEnergy, KEflag */
+__global__ void bh_accretion_post_kernel(long long nq, const int32_t *queue, const BhWalkArgs w, const shq_kick_factors kf, const double4 *posm, double *post)
+{
+#pragma clang fp contract(off)
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= nq)
+        return;
+    const long long i = queue[t];
+    const long long b = shq_bh_ordinal(w.bhp, w.nbh, (int32_t) i);
+    BhRec &B = w.bh[b];
+    double *o = w.out + BH_ACC_NOUT * t;
+    const shq_bh_params &P = w.P;
+    double mdot = 0;
+    const double meddington = P.EddingtonConst * B.Mass * P.UnitTime_in_s / P.HubbleParam;
+    B.FeedbackWeightSum = o[1];
+    double ent = o[2], gv[3] = {o[3], o[4], o[5]};
+    if(B.Density > 0) {
+        ent /= B.Density;
+        for(int k = 0; k < 3; k++)
+            gv[k] /= B.Density;
+        double bhvel = 0;
+        for(int k = 0; k < 3; k++) {
+            const double dv = w.vel[3 * i + k] - gv[k];
+            bhvel += dv * dv;
+        }
+        bhvel = sqrt(bhvel);
+        bhvel /= P.atime;
+        const double rho = B.Density;
+        const double rho_proper = rho * P.a3inv;
+        double soundspeed = 0; /* blackhole_soundspeed, :147-157 */
+        if(rho > 0) {
+            soundspeed = sqrt(SPH_GAMMA * ent * pow(rho, SPH_GAMMA - 1));
+            soundspeed *= pow(P.atime, -1.5 * (SPH_GAMMA - 1));
+        }
+        const double norm = pow((soundspeed * soundspeed + bhvel * bhvel), 1.5);
+        if(norm > 0)
+            mdot = 4. * M_PI * P.BlackHoleAccretionFactor * P.GravInternal * P.GravInternal * B.Mass * B.Mass * rho_proper / norm;
+    }
+    if(P.BlackHoleEddingtonFactor > 0.0 && mdot > P.BlackHoleEddingtonFactor * meddington)
+        mdot = P.BlackHoleEddingtonFactor * meddington;
+    B.Mdot = mdot;
+    const double dtime = kf.dloga_for_bin[w.bin_hydro[i]] / P.hubble;
+    B.Mass += B.Mdot * dtime;
+    double drag[3] = {0, 0, 0};
+    if(P.BH_DRAG > 0) {
+        double fac = 0;
+        if(P.BH_DRAG == 1)
+            fac = B.Mdot / posm[i].w;
+        if(P.BH_DRAG == 2)
+            fac = P.BlackHoleEddingtonFactor * meddington / B.Mass;
+        fac *= P.atime;
+        for(int k = 0; k < 3; k++)
+            drag[k] = -(w.vel[3 * i + k] - gv[k]) * fac;
+    }
+    B.KEflag = 0;
+    if(P.BlackHoleKineticOn == 1) {
+        const double Edd_ratio = B.Mdot / meddington;
+        double lam_thresh = P.BHKE_EddingtonThrFactor;
+        const double x = P.BHKE_EddingtonMFactor * pow(B.Mass / P.BHKE_EddingtonMPivot, P.BHKE_EddingtonMIndex);
+        if(lam_thresh > x)
+            lam_thresh = x;
+        if(Edd_ratio < lam_thresh) {
+            B.KEflag = 1;
+            const double rho_crit_baryon = P.OmegaBaryon * 3 * (P.Hubble * P.Hubble) / (8 * M_PI * P.GravInternal);
+            const double rho_sfr = P.BHKE_SfrCritOverDensity * rho_crit_baryon;
+            double epsilon = (B.Density / rho_sfr) / P.BHKE_EffRhoFactor;
+            if(epsilon > P.BHKE_EffCap)
+                epsilon = P.BHKE_EffCap;
+            B.KineticFdbkEnergy += epsilon * (B.Mdot * dtime * (P.LightOverUnitVel * P.LightOverUnitVel));
+        }
+        double KE_thresh = 0.5 * B.VDisp * B.VDisp * o[6];
+        KE_thresh *= P.BHKE_InjEnergyThr;
+        if(B.VDisp > 0 && B.KineticFdbkEnergy > KE_thresh)
+            B.KEflag = 2;
+    }
+    double *q = post + 8 * t;
+    q[0] = ent; q[1] = gv[0]; q[2] = gv[1]; q[3] = gv[2]; q[4] = drag[0]; q[5] = drag[1]; q[6] = drag[2]; q[7] = 0;
+}
+
+__global__ void bh_gather_leaf_kernel(long long nleaf, const int32_t *__restrict__ pidx, const uint8_t *__restrict__ pflags, int32_t *flag_leaf)
+{
+    const long long s = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(s >= nleaf)
+        return;
+    const unsigned f = pflags[pidx[s]];
+    const int type = f >> 4;
+    flag_leaf[s] = ((f & 1u) || !(type == 0 || type == 5)) ? 1 : 0; /* IsGarbage; GASMASK + BHMASK (treewalk.c:943-949) */
+}
+
+#define BH_FB_NOUT 8
+template <int KT>
+__global__ __launch_bounds__(256) void bh_feedback_kernel(const SphDev a, const int32_t *queue, long long nq, const BhWalkArgs w, const shq_kick_factors kf,
+                                                          int32_t *__restrict__ nlist, long long ntasks)
+{
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(32))) char lds[4 * NW_LDS_PER_WAVE(true)];
+    const int lane = threadIdx.x & 63;
+    for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
+    const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    const long long t = wave * 64 + lane;
+    const bool valid = t < nq;
+    double px = 0, py = 0, pz = 0, h = 1, idens = 0, imtrack = 0, fws = 0, fbenergy = 0, kefb = 0;
+    int channel = 0;
+    unsigned long long myid = 0;
+    if(valid) {
+        const long long pi = queue[t];
+        const double4 p = a.posm[pi];
+        px = p.x; py = p.y; pz = p.z;
+        h = a.hsml[pi];
+        myid = w.ids[pi];
+        const long long b = shq_bh_ordinal(w.bhp, w.nbh, (int32_t) pi);
+        const BhRec &B = w.bh[b];
+        idens = B.Density; imtrack = B.Mtrack;
+        fws = B.FeedbackWeightSum;
+        /* blackhole_feedback_copy, :886-909 */
+        const double dtime = kf.dloga_for_bin[w.bin_hydro[pi]] / w.P.hubble;
+        fbenergy = w.P.BlackHoleFeedbackFactor * 0.1 * B.Mdot * dtime * (w.P.LightOverUnitVel * w.P.LightOverUnitVel);
+        if(w.P.BlackHoleKineticOn == 1 && B.KEflag > 0) {
+            channel = 1;
+            if(B.KEflag == 2)
+                kefb = B.KineticFdbkEnergy;
+        }
+    }
+    const Kern<KT> kernel(h);
+    const double HH = kernel.H * kernel.H, Hinv = 1.0 / kernel.H;
+    const double h2 = h * h;
+    int mintimebin = SHQ_TIMEBINS, countprogs = 0;
+    double accmass = 0, accbh = 0, mom0 = 0, mom1 = 0, mom2 = 0;
+    auto pair = [&](const int s) {
+        const long long p = w.leaf_pidx[s];
+        const double4 q = a.posm_leaf[s];
+        const int type = w.pflags[p] >> 4;
+        if(w.ids[p] == myid)
+            return;
+        if(w.P.WindsDecoupleSph && type == 0 && w.delay[p] > 0)
+            return;
+        if(type == 5) {
+            const long long ob = shq_bh_ordinal(w.bhp, w.nbh, (int32_t) p);
+            if(ob < 0 || w.bh_swallow[ob] == 0)
+                return;
+            if(w.bh_swallow[ob] != myid + 1)
+                return;
+            BhRec &O = w.bh[ob];
+            w.bh_swallowid_out[ob] = w.bh_swallow[ob] - 1;
+            atomicOr(reinterpret_cast<unsigned int *>(w.pflags + (p & ~3ll)), 2u << (8 * (p & 3))); /* Swallowed = 1 */
+            countprogs += O.CountProgs;
+            accbh += O.Mass;
+            double othermass = q.w;
+            if(w.P.SeedBHDynMass > 0 && imtrack > 0)
+                if(O.Mtrack < w.P.SeedBHDynMass)
+                    othermass = O.Mtrack;
+            accmass += othermass;
+            const int bg = w.bin_grav[p];
+            const double v0 = w.vel[3 * p] + kf.gravkicks[bg] * w.treeacc[3 * p] + w.gravpm[3 * p] * kf.FgravkickB;
+            const double v1 = w.vel[3 * p + 1] + kf.gravkicks[bg] * w.treeacc[3 * p + 1] + w.gravpm[3 * p + 1] * kf.FgravkickB;
+            const double v2 = w.vel[3 * p + 2] + kf.gravkicks[bg] * w.treeacc[3 * p + 2] + w.gravpm[3 * p + 2] * kf.FgravkickB;
+            mom0 += (othermass * v0);
+            mom1 += (othermass * v1);
+            mom2 += (othermass * v2);
+            return;
+        }
+        if(type != 0)
+            return;
+        const double d0 = wrapd(px - q.x, a.Box, a.invBox), d1 = wrapd(py - q.y, a.Box, a.invBox), d2 = wrapd(pz - q.z, a.Box, a.invBox);
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        const unsigned long long mark = w.sph_swallow[p];
+        if(mark == 0 && r2 < HH) {
+            const int bh = w.bin_hydro[p];
+            if(mintimebin > bh)
+                mintimebin = bh;
+            const double u = sqrt(r2) * Hinv;
+            const double mass_j = q.w;
+            const double wk = kernel.wk(u);
+            if(fws > 0 && fbenergy > 0 && channel == 0 && mass_j > 0) {
+                const double injected = fbenergy * mass_j * wk / fws;
+                if(w.eeqos && w.eeqos[p])
+                    w.heated[p] = 1;
+                const double enttou = pow(w.density[p] * w.P.a3inv, SPH_GAMMA - 1) / (SPH_GAMMA - 1);
+                unsigned long long *eptr = reinterpret_cast<unsigned long long *>(w.entropy + p);
+                unsigned long long oldb = atomicAdd(eptr, 0ull);
+                for(;;) {
+                    /* add_injected_BH_energy, :700-710 */
+                    double unew = __longlong_as_double((long long) oldb) * enttou;
+                    unew += injected / mass_j;
+                    if(unew > w.P.MaxThermalU)
+                        unew = w.P.MaxThermalU;
+                    const double entnew = unew / enttou;
+                    const unsigned long long seen = atomicCAS(eptr, oldb, (unsigned long long) __double_as_longlong(entnew));
+                    if(seen == oldb)
+                        break;
+                    oldb = seen;
+                }
+            }
+            if(kefb > 0 && channel == 1 && idens > 0) {
+                const double dvel = sqrt(2 * kefb * wk / idens);
+                /* get_random_dir, :712-723 */
+                const double theta = acos(2 * w.rnd[(w.ids[p] + 3) % w.rndsize] - 1);
+                const double phi = 2 * M_PI * w.rnd[(w.ids[p] + 4) % w.rndsize];
+                const double dir[3] = {sin(theta) * cos(phi), sin(theta) * sin(phi), cos(theta)};
+                for(int j = 0; j < 3; j++)
+                    atomicAdd(w.velw + 3 * p + j, dvel * dir[j]);
+            }
+        }
+        if(mark == myid + 1) {
+            accmass += q.w;
+            const double4 vp = a.velp[p];
+            mom0 += (q.w * vp.x);
+            mom1 += (q.w * vp.y);
+            mom2 += (q.w * vp.z);
+            atomicOr(reinterpret_cast<unsigned int *>(w.pflags + (p & ~3ll)), 1u << (8 * (p & 3))); /* slots_mark_garbage */
+        }
+    };
+    auto accept = [&](const double r2, const double hj, const int) { return r2 <= h2 || r2 <= hj * hj; };
+    int fill = 0;
+    bool ovf = false;
+    (void) ngb_walk<true, false, false>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(true), myl, valid, px, py, pz, h, accept, pair,
+                                        (unsigned int *) nullptr, fill, ovf);
+    if(valid) {
+        double *o = w.out + BH_FB_NOUT * t;
+        o[0] = accmass; o[1] = accbh; o[2] = mom0; o[3] = mom1; o[4] = mom2; o[5] = countprogs; o[6] = mintimebin; o[7] = 0;
+    }
+    } /* task loop */
+}
+
+static int bh_launch_prep(shq_context *ctx, const shq_kick_factors *kf)
+{
+    SHQ_TRY(shq_sph_prepare(ctx, kf, nullptr, nullptr)); /* SPH_VelPred of every gas particle, Hsml in leaf order */
+    const long long nl = ctx->ntreeparts + SHQ_NMAXCHILD;
+    bh_gather_leaf_kernel<<<dim3(nblk(nl)), dim3(256), 0, ctx->stream>>>(nl, ctx->leaf_pidx.ptr, ctx->pflags.ptr, ctx->flag_leaf.ptr);
+    SHQ_HIP(hipGetLastError());
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    return SHQ_OK;
+}
+
+int shq_bh_accretion_device(shq_context *ctx, const shq_kick_factors *kf, const BhWalkArgs *w, const int32_t *d_queue, int64_t nq, double *d_post)
+{
+    if(nq == 0)
+        return SHQ_OK;
+    const int kt = w->P.DensityKernelType;
+    SHQ_CHECK(kt == 1 || kt == 2 || kt == 4, SHQ_ERR_INVALID, "unknown DensityKernelType %d", kt);
+    SHQ_TRY(bh_launch_prep(ctx, kf));
+    hipStream_t st = ctx->stream;
+    SphDev a = make_dev(ctx);
+    a.Box = w->P.BoxSize;
+    a.invBox = 1.0 / w->P.BoxSize;
+    const long long ntasks = (nq + 255) / 256;
+    const unsigned grid = (unsigned) (ntasks < NL_REDO_BLOCKS ? ntasks : NL_REDO_BLOCKS);
+    switch(kt) {
+    case 1: bh_accretion_kernel<1><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, *kf, ctx->s_nlist2.ptr, ntasks); break;
+    case 2: bh_accretion_kernel<2><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, *kf, ctx->s_nlist2.ptr, ntasks); break;
+    default: bh_accretion_kernel<4><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, *kf, ctx->s_nlist2.ptr, ntasks); break;
+    }
+    SHQ_HIP(hipGetLastError());
+    bh_accretion_post_kernel<<<dim3(nblk(nq)), dim3(256), 0, st>>>(nq, d_queue, *w, *kf, ctx->posm.ptr, d_post);
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}
+
+int shq_bh_feedback_device(shq_context *ctx, const shq_kick_factors *kf, const BhWalkArgs *w, const int32_t *d_queue, int64_t nq)
+{
+    if(nq == 0)
+        return SHQ_OK;
+    const int kt = w->P.DensityKernelType;
+    SHQ_CHECK(kt == 1 || kt == 2 || kt == 4, SHQ_ERR_INVALID, "unknown DensityKernelType %d", kt);
+    SHQ_TRY(bh_launch_prep(ctx, kf));
+    hipStream_t st = ctx->stream;
+    SphDev a = make_dev(ctx);
+    a.Box = w->P.BoxSize;
+    a.invBox = 1.0 / w->P.BoxSize;
+    const long long ntasks = (nq + 255) / 256;
+    const unsigned grid = (unsigned) (ntasks < NL_REDO_BLOCKS ? ntasks : NL_REDO_BLOCKS);
+    switch(kt) {
+    case 1: bh_feedback_kernel<1><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, *kf, ctx->s_nlist2.ptr, ntasks); break;
+    case 2: bh_feedback_kernel<2><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, *kf, ctx->s_nlist2.ptr, ntasks); break;
+    default: bh_feedback_kernel<4><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, *kf, ctx->s_nlist2.ptr, ntasks); break;
+    }
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}

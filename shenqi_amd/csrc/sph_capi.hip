@@ -940,3 +940,331 @@ extern "C" int shq_bh_dynfric(shq_context *ctx, const shq_tree_view *tree, const
     }
     return SHQ_OK;
 }
+
+/* ---- black-hole accretion and feedback (blackhole.cpp:217-370) ------------------------------------------------------------- */
+namespace {
+
+template <typename T> inline T *bhfield(const shq_bh_slot_view *v, int64_t slot, size_t off)
+{
+    return reinterpret_cast<T *>(static_cast<char *>(v->base) + (size_t) slot * v->elsize + off);
+}
+
+struct BhSet {
+    std::vector<int32_t> bhp;   /* particle indices of the type-5 particles, ascending */
+    std::vector<BhRec> rec;
+    std::vector<int32_t> pi;    /* their slots */
+};
+
+int bh_collect(const shq_part_view *parts, const shq_bh_slot_view *bh, const shq_bh_work *work, bool feedback, BhSet &S)
+{
+    const int64_t n = parts->numpart;
+    for(int64_t i = 0; i < n; i++) {
+        if(*pfield<uint8_t>(parts, i, parts->off_type) != 5)
+            continue;
+        if(*pfield<uint8_t>(parts, i, parts->off_flags) & 1u)
+            continue;
+        const int32_t pi = *pfield<int32_t>(parts, i, parts->off_pi);
+        SHQ_CHECK(pi >= 0 && pi < bh->numslots, SHQ_ERR_INVALID, "black hole %ld has PI %d outside the slot array", (long) i, pi);
+        BhRec r;
+        memset(&r, 0, sizeof(r));
+        r.Mass = *bhfield<double>(bh, pi, bh->off_mass);
+        r.Density = *bhfield<double>(bh, pi, bh->off_density);
+        r.Mtrack = *bhfield<double>(bh, pi, bh->off_mtrack);
+        for(int d = 0; d < 3; d++)
+            r.DFAccel[d] = bhfield<double>(bh, pi, bh->off_dfaccel)[d];
+        r.VDisp = *bhfield<double>(bh, pi, bh->off_vdisp);
+        r.KineticFdbkEnergy = *bhfield<double>(bh, pi, bh->off_kineticfdbkenergy);
+        r.Mdot = *bhfield<double>(bh, pi, bh->off_mdot);
+        r.CountProgs = *bhfield<int32_t>(bh, pi, bh->off_countprogs);
+        if(feedback) {
+            r.FeedbackWeightSum = work->BH_FeedbackWeightSum[pi];
+            r.KEflag = work->KEflag ? work->KEflag[pi] : 0;
+        }
+        S.bhp.push_back((int32_t) i);
+        S.rec.push_back(r);
+        S.pi.push_back(pi);
+    }
+    return SHQ_OK;
+}
+
+int bh_check_common(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph, const shq_bh_slot_view *bh, const uint64_t *ids,
+                    const int32_t *queue, int64_t nqueue, const shq_kick_factors *kf, const shq_bh_params *params, const double *rnd_table, int64_t rnd_size,
+                    const shq_bh_work *work, const char *who)
+{
+    SHQ_CHECK(ctx && tree && parts && sph && bh && ids && kf && params && work && rnd_table && (nqueue == 0 || queue), SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->sphrun.phase == 0, SHQ_ERR_STATE, "%s: an SPH walk is open", who);
+    SHQ_CHECK(rnd_size > 0, SHQ_ERR_INVALID, "%s: empty random table", who);
+    SHQ_CHECK(work->SPH_SwallowID && work->BH_SwallowID && work->BH_FeedbackWeightSum && work->BH_Entropy && work->BH_SurroundingGasVel && work->MgasEnc,
+              SHQ_ERR_INVALID, "%s: the BHPriv arrays are needed", who);
+    SHQ_CHECK(params->BlackHoleKineticOn != 1 || work->KEflag, SHQ_ERR_INVALID, "%s: KEflag is needed with BlackHoleKineticOn", who);
+    SHQ_CHECK(parts->off_vel != SHQ_NOFIELD && parts->off_hsml != SHQ_NOFIELD && parts->off_pi != SHQ_NOFIELD && parts->off_type != SHQ_NOFIELD &&
+                  parts->off_treeacc != SHQ_NOFIELD && parts->off_gravpm != SHQ_NOFIELD && parts->off_flags != SHQ_NOFIELD &&
+                  parts->off_timebin_hydro != SHQ_NOFIELD && parts->off_timebin_gravity != SHQ_NOFIELD,
+              SHQ_ERR_INVALID, "%s: the particle view needs Vel, Hsml, PI, Type, flags, FullTreeGravAccel, GravPM and both time bins", who);
+    const int64_t n = parts->numpart;
+    for(int64_t k = 0; k < nqueue; k++) {
+        const int32_t i = queue[k];
+        SHQ_CHECK(i >= 0 && i < n, SHQ_ERR_INVALID, "%s: queue[%ld] = %d out of range", who, (long) k, i);
+        SHQ_CHECK(*pfield<uint8_t>(parts, i, parts->off_type) == 5 && !(*pfield<uint8_t>(parts, i, parts->off_flags) & 3u), SHQ_ERR_INVALID,
+                  "%s: particle %d in the queue is not a live black hole (blackhole_haswork)", who, i);
+        SHQ_CHECK(*pfield<double>(parts, i, parts->off_hsml) > 0, SHQ_ERR_INVALID, "%s: black hole %d has Hsml <= 0", who, i);
+    }
+    return SHQ_OK;
+}
+
+int bh_upload_common(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph, const uint64_t *ids, const double *rnd_table,
+                     int64_t rnd_size, const BhSet &S, const std::vector<int32_t> &queue)
+{
+    SHQ_TRY(shq_particles_upload(ctx, parts));
+    SHQ_TRY(sph_upload(ctx, parts, sph));
+    SHQ_TRY(shq_tree_upload(ctx, tree));
+    const size_t n = (size_t) parts->numpart, nbh = S.bhp.size();
+    hipStream_t st = ctx->stream;
+    SHQ_TRY(ctx->bhw_bhp.reserve(std::max<size_t>(nbh, 1)));
+    SHQ_TRY(ctx->bhw_rec.reserve(std::max<size_t>(nbh, 1) * sizeof(BhRec)));
+    SHQ_TRY(ctx->bhw_ids.reserve(std::max<size_t>(n, 1)));
+    SHQ_TRY(ctx->bhw_rnd.reserve((size_t) rnd_size));
+    SHQ_TRY(ctx->bhw_queue.reserve(std::max<size_t>(queue.size(), 1)));
+    SHQ_TRY(ctx->bhw_sphsw.reserve(std::max<size_t>(n, 1)));
+    SHQ_TRY(ctx->bhw_bhsw.reserve(std::max<size_t>(nbh, 1)));
+    SHQ_TRY(ctx->bhw_swid.reserve(std::max<size_t>(nbh, 1)));
+    SHQ_TRY(ctx->bhw_out.reserve(16 * std::max<size_t>(queue.size(), 1)));
+    if(nbh) {
+        SHQ_HIP(hipMemcpyAsync(ctx->bhw_bhp.ptr, S.bhp.data(), sizeof(int32_t) * nbh, hipMemcpyHostToDevice, st));
+        SHQ_HIP(hipMemcpyAsync(ctx->bhw_rec.ptr, S.rec.data(), sizeof(BhRec) * nbh, hipMemcpyHostToDevice, st));
+    }
+    if(n)
+        SHQ_HIP(hipMemcpyAsync(ctx->bhw_ids.ptr, ids, sizeof(uint64_t) * n, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemcpyAsync(ctx->bhw_rnd.ptr, rnd_table, sizeof(double) * (size_t) rnd_size, hipMemcpyHostToDevice, st));
+    if(!queue.empty())
+        SHQ_HIP(hipMemcpyAsync(ctx->bhw_queue.ptr, queue.data(), sizeof(int32_t) * queue.size(), hipMemcpyHostToDevice, st));
+    return SHQ_OK;
+}
+
+void bh_fill_args(shq_context *ctx, const shq_bh_params *params, int64_t rnd_size, size_t nbh, BhWalkArgs &w)
+{
+    memset(&w, 0, sizeof(w));
+    w.bhp = ctx->bhw_bhp.ptr;
+    w.nbh = (long long) nbh;
+    w.bh = reinterpret_cast<BhRec *>(ctx->bhw_rec.ptr);
+    w.ids = ctx->bhw_ids.ptr;
+    w.rnd = ctx->bhw_rnd.ptr;
+    w.rndsize = (unsigned long long) rnd_size;
+    w.vel = ctx->vel.ptr;
+    w.velw = ctx->vel.ptr;
+    w.treeacc = ctx->treeacc.ptr;
+    w.gravpm = ctx->gravpm.ptr;
+    w.delay = ctx->g_delaytime.ptr;
+    w.entropy = ctx->g_entropy.ptr;
+    w.density = ctx->g_density.ptr;
+    w.bin_grav = ctx->bin_grav.ptr;
+    w.bin_hydro = ctx->bin_hydro.ptr;
+    w.pflags = ctx->pflags.ptr;
+    w.leaf_pidx = ctx->leaf_pidx.ptr;
+    w.sph_swallow = ctx->bhw_sphsw.ptr;
+    w.bh_swallow = ctx->bhw_bhsw.ptr;
+    w.bh_swallowid_out = ctx->bhw_swid.ptr;
+    w.out = ctx->bhw_out.ptr;
+    w.P = *params;
+}
+
+} // namespace
+
+extern "C" int shq_bh_accretion(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph, const shq_bh_slot_view *bh,
+                                const uint64_t *ids, const int32_t *queue, int64_t nqueue, const shq_kick_factors *kf, const shq_bh_params *params,
+                                int64_t Ti_Current, const double *rnd_table, int64_t rnd_size, const shq_bh_work *work)
+{
+    SHQ_TRY(bh_check_common(ctx, tree, parts, sph, bh, ids, queue, nqueue, kf, params, rnd_table, rnd_size, work, "bh_accretion"));
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t n = parts->numpart;
+    BhSet S;
+    SHQ_TRY(bh_collect(parts, bh, work, false, S));
+    const size_t nbh = S.bhp.size();
+    std::vector<int32_t> q(queue, queue + nqueue);
+    SHQ_TRY(bh_upload_common(ctx, tree, parts, sph, ids, rnd_table, rnd_size, S, q));
+    hipStream_t st = ctx->stream;
+    if(n)
+        SHQ_HIP(hipMemsetAsync(ctx->bhw_sphsw.ptr, 0, sizeof(uint64_t) * (size_t) n, st));
+    if(nbh)
+        SHQ_HIP(hipMemsetAsync(ctx->bhw_bhsw.ptr, 0, sizeof(uint64_t) * nbh, st));
+    /* priv->SPH_SwallowID / BH_SwallowID start from zero (blackhole.cpp:270-274) */
+    memset(work->SPH_SwallowID, 0, sizeof(uint64_t) * (size_t) sph->numslots);
+    memset(work->BH_SwallowID, 0, sizeof(uint64_t) * (size_t) bh->numslots);
+    if(nqueue == 0)
+        return SHQ_OK;
+    BhWalkArgs w;
+    bh_fill_args(ctx, params, rnd_size, nbh, w);
+    w.Ti_Current = Ti_Current;
+    double *d_post = ctx->bhw_out.ptr + 8 * (size_t) nqueue;
+    SHQ_TRY(shq_bh_accretion_device(ctx, kf, &w, ctx->bhw_queue.ptr, nqueue, d_post));
+    std::vector<double> out(16 * (size_t) nqueue);
+    std::vector<uint64_t> sphsw((size_t) std::max<int64_t>(n, 1)), bhsw(std::max<size_t>(nbh, 1));
+    SHQ_HIP(hipMemcpyAsync(out.data(), ctx->bhw_out.ptr, sizeof(double) * out.size(), hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipMemcpyAsync(S.rec.data(), ctx->bhw_rec.ptr, sizeof(BhRec) * nbh, hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipMemcpyAsync(sphsw.data(), ctx->bhw_sphsw.ptr, sizeof(uint64_t) * (size_t) n, hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipMemcpyAsync(bhsw.data(), ctx->bhw_bhsw.ptr, sizeof(uint64_t) * nbh, hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    for(int64_t i = 0; i < n; i++)
+        if(sphsw[i]) {
+            SHQ_CHECK(*pfield<uint8_t>(parts, i, parts->off_type) == 0, SHQ_ERR_STATE, "bh_accretion: a swallow mark on a particle that is not gas");
+            work->SPH_SwallowID[*pfield<int32_t>(parts, i, parts->off_pi)] = sphsw[i];
+        }
+    for(size_t b = 0; b < nbh; b++)
+        if(bhsw[b])
+            work->BH_SwallowID[S.pi[b]] = bhsw[b];
+    for(int64_t t = 0; t < nqueue; t++) {
+        const size_t b = (size_t) (std::lower_bound(S.bhp.begin(), S.bhp.end(), queue[t]) - S.bhp.begin());
+        const int32_t pi = S.pi[b];
+        const double *o = &out[8 * (size_t) t], *p = &out[8 * (size_t) nqueue + 8 * (size_t) t];
+        const BhRec &R = S.rec[b];
+        *bhfield<int8_t>(bh, pi, bh->off_encounter) = (int8_t) o[0];          /* blackhole_accretion_reduce, PRIMARY */
+        work->BH_FeedbackWeightSum[pi] = o[1];
+        work->MgasEnc[pi] = o[6];
+        work->BH_Entropy[pi] = p[0];
+        for(int d = 0; d < 3; d++) {
+            work->BH_SurroundingGasVel[pi][d] = p[1 + d];
+            bhfield<double>(bh, pi, bh->off_dragaccel)[d] = p[4 + d];
+        }
+        *bhfield<double>(bh, pi, bh->off_mdot) = R.Mdot;
+        *bhfield<double>(bh, pi, bh->off_mass) = R.Mass;
+        *bhfield<double>(bh, pi, bh->off_kineticfdbkenergy) = R.KineticFdbkEnergy;
+        if(work->KEflag)
+            work->KEflag[pi] = R.KEflag;
+    }
+    return SHQ_OK;
+}
+
+extern "C" int shq_bh_feedback(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph, const shq_bh_slot_view *bh,
+                               const uint64_t *ids, const int32_t *queue, int64_t nqueue, const shq_kick_factors *kf, const shq_bh_params *params, int64_t MaxPart,
+                               const double *rnd_table, int64_t rnd_size, const uint8_t *eeqos, const shq_bh_work *work, int64_t *n_sph_swallowed,
+                               int64_t *n_bh_swallowed)
+{
+    SHQ_TRY(bh_check_common(ctx, tree, parts, sph, bh, ids, queue, nqueue, kf, params, rnd_table, rnd_size, work, "bh_feedback"));
+    SHQ_CHECK(work->BH_accreted_Mass && work->BH_accreted_BHMass && work->BH_accreted_momentum, SHQ_ERR_INVALID, "bh_feedback: the accreted-mass arrays are needed");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t n = parts->numpart;
+    if(n_sph_swallowed)
+        *n_sph_swallowed = 0;
+    if(n_bh_swallowed)
+        *n_bh_swallowed = 0;
+    BhSet S;
+    SHQ_TRY(bh_collect(parts, bh, work, true, S));
+    const size_t nbh = S.bhp.size();
+    /* blackhole_feedback_haswork (:878-883): a hole that is marked itself does not swallow or heat */
+    std::vector<int32_t> q;
+    for(int64_t k = 0; k < nqueue; k++)
+        if(work->BH_SwallowID[*pfield<int32_t>(parts, queue[k], parts->off_pi)] == 0)
+            q.push_back(queue[k]);
+    SHQ_TRY(bh_upload_common(ctx, tree, parts, sph, ids, rnd_table, rnd_size, S, q));
+    hipStream_t st = ctx->stream;
+    std::vector<uint64_t> sphsw((size_t) std::max<int64_t>(n, 1), 0), bhsw(std::max<size_t>(nbh, 1), 0), swid(std::max<size_t>(nbh, 1));
+    std::vector<uint8_t> flags0((size_t) std::max<int64_t>(n, 1));
+    for(int64_t i = 0; i < n; i++)
+        if(*pfield<uint8_t>(parts, i, parts->off_type) == 0 && !(*pfield<uint8_t>(parts, i, parts->off_flags) & 1u)) {
+            const int32_t pi = *pfield<int32_t>(parts, i, parts->off_pi);
+            SHQ_CHECK(pi >= 0 && pi < sph->numslots, SHQ_ERR_INVALID, "bh_feedback: gas particle %ld has PI %d outside the slot array", (long) i, pi);
+            sphsw[i] = work->SPH_SwallowID[pi];
+        }
+    for(size_t b = 0; b < nbh; b++)
+        bhsw[b] = work->BH_SwallowID[S.pi[b]];
+    SHQ_HIP(hipMemcpyAsync(ctx->bhw_sphsw.ptr, sphsw.data(), sizeof(uint64_t) * (size_t) n, hipMemcpyHostToDevice, st));
+    if(nbh) {
+        SHQ_HIP(hipMemcpyAsync(ctx->bhw_bhsw.ptr, bhsw.data(), sizeof(uint64_t) * nbh, hipMemcpyHostToDevice, st));
+        SHQ_HIP(hipMemsetAsync(ctx->bhw_swid.ptr, 0xff, sizeof(uint64_t) * nbh, st));
+    }
+    SHQ_TRY(ctx->bhw_eeqos.reserve((size_t) std::max<int64_t>(n, 1)));
+    SHQ_TRY(ctx->bhw_heated.reserve((size_t) std::max<int64_t>(n, 1)));
+    if(n) {
+        if(eeqos)
+            SHQ_HIP(hipMemcpyAsync(ctx->bhw_eeqos.ptr, eeqos, (size_t) n, hipMemcpyHostToDevice, st));
+        SHQ_HIP(hipMemsetAsync(ctx->bhw_heated.ptr, 0, (size_t) n, st));
+        SHQ_HIP(hipMemcpyAsync(flags0.data(), ctx->pflags.ptr, (size_t) n, hipMemcpyDeviceToHost, st));
+    }
+    const int64_t nq = (int64_t) q.size();
+    BhWalkArgs w;
+    bh_fill_args(ctx, params, rnd_size, nbh, w);
+    w.eeqos = eeqos ? ctx->bhw_eeqos.ptr : nullptr;
+    w.heated = ctx->bhw_heated.ptr;
+    SHQ_TRY(shq_bh_feedback_device(ctx, kf, &w, ctx->bhw_queue.ptr, nq));
+    std::vector<double> out(8 * (size_t) std::max<int64_t>(nq, 1)), vel(3 * (size_t) std::max<int64_t>(n, 1)), ent((size_t) std::max<int64_t>(n, 1));
+    std::vector<uint8_t> flags1((size_t) std::max<int64_t>(n, 1)), heated((size_t) std::max<int64_t>(n, 1));
+    if(nq)
+        SHQ_HIP(hipMemcpyAsync(out.data(), ctx->bhw_out.ptr, sizeof(double) * 8 * (size_t) nq, hipMemcpyDeviceToHost, st));
+    if(n) {
+        SHQ_HIP(hipMemcpyAsync(vel.data(), ctx->vel.ptr, sizeof(double) * 3 * (size_t) n, hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipMemcpyAsync(ent.data(), ctx->g_entropy.ptr, sizeof(double) * (size_t) n, hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipMemcpyAsync(flags1.data(), ctx->pflags.ptr, (size_t) n, hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipMemcpyAsync(heated.data(), ctx->bhw_heated.ptr, (size_t) n, hipMemcpyDeviceToHost, st));
+    }
+    if(nbh)
+        SHQ_HIP(hipMemcpyAsync(swid.data(), ctx->bhw_swid.ptr, sizeof(uint64_t) * nbh, hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    /* the neighbours' side of the walk, into the caller's arrays */
+    int64_t nsph = 0, nbhs = 0;
+    for(int64_t i = 0; i < n; i++) {
+        const unsigned type = *pfield<uint8_t>(parts, i, parts->off_type);
+        if(type == 0 && !(flags0[i] & 1u)) {
+            const int32_t pi = *pfield<int32_t>(parts, i, parts->off_pi);
+            *sfield(sph, pi, sph->off_entropy) = ent[i];
+            double *v = pfield_w<double>(parts, i, parts->off_vel);
+            for(int d = 0; d < 3; d++)
+                v[d] = vel[3 * i + d];
+            if(heated[i])
+                *pfield_w<uint8_t>(parts, i, parts->off_flags) |= 8u; /* BHHeated: bit 3 of the flag byte */
+            if(flags1[i] & 1u) { /* slots_mark_garbage, slotsmanager.cpp:590-599 */
+                *pfield_w<uint8_t>(parts, i, parts->off_flags) |= 1u;
+                *reinterpret_cast<int32_t *>(static_cast<char *>(sph->base) + (size_t) pi * sph->elsize) = (int32_t) (MaxPart + 100);
+                nsph++;
+            }
+        }
+    }
+    for(size_t b = 0; b < nbh; b++) {
+        const int64_t i = S.bhp[b];
+        if((flags1[i] & 2u) && !(flags0[i] & 2u)) {
+            const int32_t pi = S.pi[b];
+            *pfield_w<uint8_t>(parts, i, parts->off_flags) |= 2u; /* Swallowed */
+            *bhfield<uint64_t>(bh, pi, bh->off_swallowid) = swid[b];
+            *bhfield<double>(bh, pi, bh->off_swallowtime) = params->atime;
+            *bhfield<int8_t>(bh, pi, bh->off_encounter) = 0;
+            nbhs++;
+        }
+    }
+    /* blackhole_feedback_reduce (PRIMARY) + blackhole_feedback_postprocess (:912-965) */
+    for(int64_t t = 0; t < nq; t++) {
+        const int32_t i = q[t];
+        const size_t b = (size_t) (std::lower_bound(S.bhp.begin(), S.bhp.end(), i) - S.bhp.begin());
+        const int32_t pi = S.pi[b];
+        const double *o = &out[8 * (size_t) t];
+        work->BH_accreted_Mass[pi] = o[0];
+        work->BH_accreted_BHMass[pi] = o[1];
+        for(int d = 0; d < 3; d++)
+            work->BH_accreted_momentum[pi][d] = o[2 + d];
+        *bhfield<uint8_t>(bh, pi, bh->off_mintimebin) = (uint8_t) o[6];
+        *bhfield<int32_t>(bh, pi, bh->off_countprogs) += (int32_t) o[5];
+        if(o[1] > 0)
+            *bhfield<double>(bh, pi, bh->off_mass) += o[1];
+        if(o[0] > 0) {
+            const double accmass = o[0];
+            double *v = pfield_w<double>(parts, i, parts->off_vel);
+            float *pm = pfield_w<float>(parts, i, parts->off_mass);
+            double *mtrack = bhfield<double>(bh, pi, bh->off_mtrack);
+            for(int d = 0; d < 3; d++)
+                v[d] = (v[d] * *pm + o[2 + d]) / (*pm + accmass);
+            const double SeedBHDynMass = params->SeedBHDynMass;
+            if(SeedBHDynMass > 0 && *mtrack + accmass < SeedBHDynMass)
+                *mtrack += accmass;
+            else if(*mtrack < SeedBHDynMass) {
+                *pm = (float) (*mtrack + accmass);
+                *mtrack = SeedBHDynMass;
+            } else
+                *pm = (float) (*pm + accmass);
+        }
+        if(work->KEflag && work->KEflag[pi] == 2)
+            *bhfield<double>(bh, pi, bh->off_kineticfdbkenergy) = 0;
+    }
+    if(n_sph_swallowed)
+        *n_sph_swallowed = nsph;
+    if(n_bh_swallowed)
+        *n_bh_swallowed = nbhs;
+    return SHQ_OK;
+}
