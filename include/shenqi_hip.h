@@ -931,6 +931,35 @@ int shq_bh_feedback(shq_context *ctx, const shq_tree_view *tree, const shq_part_
                     const double *rnd_table, int64_t rnd_size, const uint8_t *eeqos, const shq_bh_work *work, int64_t *n_sph_swallowed,
                     int64_t *n_bh_swallowed);
 
+/* winds_and_feedback() (libgadget/winds.cpp:295-369): the two asymmetric walks over the gas tree for the new
+ * stars of the step — sfr_wind_weight_ngbiter (:411-447: mass of the gas inside the star's Hsml that is not already a wind particle,
+ * into TotalWeight[star slot]) and sfr_wind_feedback_ngbiter (:510-565: a gas particle becomes a kick candidate when
+ * Table[(star ID + gas ID) % size] < windeff Mass / TotalWeight, with get_wind_params, :489-507) — then the reference's own resolution on
+ * the host: the candidates sorted by (particle, distance, star ID), the first of every particle kicks (wind_do_kick, :449-471: Vel along
+ * get_wind_dir, Entropy += therm / enttou, DelayTime when winds decouple), in the caller's arrays.  WindModel carries the reference's
+ * flag bits (WIND_DECOUPLE_SPH 2, WIND_USE_HALO 4, WIND_FIXED_EFFICIENCY 8); the subgrid model (bit 1) does nothing here, as there.
+ * `tree` is the gas tree; the star view gives STARP.VDisp (float).  `kicks` (may be NULL) receives the sorted candidate list. */
+typedef struct shq_wind_params {
+    double BoxSize, Time;
+    double WindFreeTravelLength, MaxWindFreeTravelTime, WindEfficiency, WindSpeed, WindSigma0, WindSpeedFactor, MinWindVelocity, WindThermalFactor;
+    int WindModel, pad_;
+} shq_wind_params;
+typedef struct shq_wind_kick {      /* struct StarKick, winds.cpp:175-207 */
+    int32_t part_index, pad_;
+    double StarDistance;
+    uint64_t StarID;
+    double StarKickVelocity, StarTherm;
+} shq_wind_kick;
+typedef struct shq_star_view {
+    void *base;
+    size_t elsize;
+    int64_t numslots;
+    size_t off_vdisp;               /* float */
+} shq_star_view;
+int shq_winds_and_feedback(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph, const shq_star_view *stars,
+                           const uint64_t *ids, const int32_t *NewStars, int64_t NumNewStars, const shq_wind_params *params, const double *rnd_table,
+                           int64_t rnd_size, double *TotalWeight, shq_wind_kick *kicks, int64_t kicks_capacity, int64_t *nkicks, int64_t *nkicked);
+
 /* ---- long-range PM --------------------------------------------------------------------- */
 
 /* Mirror of the PetaPM fields gravpm.cpp reads (libgadget/petapm.h:87-112). */

@@ -245,6 +245,18 @@ def bh_slot_view(arr):
     return v
 
 
+class WindParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("BoxSize", "Time", "WindFreeTravelLength", "MaxWindFreeTravelTime", "WindEfficiency", "WindSpeed", "WindSigma0",
+                                         "WindSpeedFactor", "MinWindVelocity", "WindThermalFactor")] + [("WindModel", C.c_int), ("pad_", C.c_int)]
+
+
+WIND_KICK_DTYPE = np.dtype([("part_index", "<i4"), ("pad_", "<i4"), ("StarDistance", "<f8"), ("StarID", "<u8"), ("StarKickVelocity", "<f8"), ("StarTherm", "<f8")])
+
+
+class StarView(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("elsize", C.c_size_t), ("numslots", C.c_int64), ("off_vdisp", C.c_size_t)]
+
+
 class StarSpawnLayout(C.Structure):
     _fields_ = [(k, C.c_size_t) for k in ("star_formationtime", "star_lastenrichmentmyr", "star_totalmassreturned", "star_birthdensity", "star_vdisp",
                                          "star_metallicity", "star_metals", "sph_density", "sph_vdisp", "sph_metallicity", "sph_metals")] + [("nmetals", C.c_int), ("pad_", C.c_int)]
@@ -422,6 +434,9 @@ hip.shq_bh_accretion.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), 
 hip.shq_bh_feedback.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(SphView), C.POINTER(BhSlotView), _vp, _vp, C.c_int64, C.POINTER(KickFactors),
                                 C.POINTER(BhParams), C.c_int64, _vp, C.c_int64, _vp, C.POINTER(BhWork), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
 hip.shq_bh_accretion.restype = hip.shq_bh_feedback.restype = C.c_int
+hip.shq_winds_and_feedback.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(SphView), C.POINTER(StarView), _vp, _vp, C.c_int64, C.POINTER(WindParams),
+                                       _vp, C.c_int64, _vp, _vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+hip.shq_winds_and_feedback.restype = C.c_int
 hip.shq_sph_state_upload.argtypes = [_vp, C.POINTER(PartView), C.POINTER(SphView)]
 hip.shq_sph_state_upload.restype = C.c_int
 hip.shq_fof_seed_select.argtypes = [_vp, C.c_double, C.c_double, _vp, C.c_int64, C.POINTER(C.c_int64)]

@@ -291,6 +291,9 @@ struct shq_context {
     DevBuf<unsigned long long> bhw_ids, bhw_sphsw, bhw_bhsw, bhw_swid;
     DevBuf<double> bhw_rnd, bhw_out;
     DevBuf<uint8_t> bhw_eeqos, bhw_heated;
+    DevBuf<char> wind_kicks;
+    DevBuf<double> wind_d;
+    DevBuf<unsigned long long> wind_cnt;
     bool tb_built = false;     /* the current tree came from shq_tree_build (downloadable) */
 
     /* ---- SPH state, by particle index (gas fields gathered from their slots at upload) */
@@ -485,6 +488,20 @@ struct BhWalkArgs {
     long long Ti_Current;
 };
 
+/* wind walks (sph.hip) */
+struct WindWalkArgs {
+    const unsigned long long *ids;
+    const double *rnd;
+    unsigned long long rndsize;
+    const int32_t *leaf_pidx;
+    double *totalweight;           /* by queue entry */
+    const double *vdisp;           /* by queue entry */
+    unsigned long long *nvisited, *nkicks;
+    unsigned long long maxkicks;
+    shq_wind_kick *kicks;
+    shq_wind_params P;
+};
+int shq_wind_walk_device(shq_context *ctx, const WindWalkArgs *w, const int32_t *d_queue, int64_t nq, bool kick);
 int shq_bh_accretion_device(shq_context *ctx, const shq_kick_factors *kf, const BhWalkArgs *w, const int32_t *d_queue, int64_t nq, double *d_post);
 int shq_bh_feedback_device(shq_context *ctx, const shq_kick_factors *kf, const BhWalkArgs *w, const int32_t *d_queue, int64_t nq);
 int shq_bh_veldisp_device(shq_context *ctx, const shq_kick_factors *kf, double BoxSize, const int32_t *d_queue, int64_t nq, double *d_out);

@@ -3186,3 +3186,132 @@ int shq_bh_feedback_device(shq_context *ctx, const shq_kick_factors *kf, const B
     SHQ_HIP(hipGetLastError());
     return SHQ_OK;
 }
+
+/* ---- stellar winds from new stars: libgadget/winds.cpp:227-369, 411-447, 510-565 --------------------------
+ * Two asymmetric legacy-API walks over the gas tree for the new stars of the step: the total mass of the gas inside the star's
+ * Hsml that is not already a wind particle (sfr_wind_weight_ngbiter), then the kick candidates: every such gas particle whose
+ * draw Table[(star ID + gas ID) % size] falls below windeff * Mass / TotalWeight is appended to one list of (gas particle, distance,
+ * star ID, velocity, thermal energy) — sfr_wind_feedback_ngbiter's StarKick queue.  Which candidate kicks (the nearest star, ties to
+ * the smaller star ID) is resolved from the sorted list by the caller of these kernels, as the reference does after its walk. */
+__global__ void wind_gather_leaf_kernel(long long nleaf, const int32_t *__restrict__ pidx, const uint8_t *__restrict__ pflags, const double *__restrict__ delay,
+                                        int32_t *flag_leaf)
+{
+    const long long s = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(s >= nleaf)
+        return;
+    const int p = pidx[s];
+    const unsigned f = pflags[p];
+    flag_leaf[s] = ((f & 3u) || (f >> 4) != 0 || delay[p] > 0) ? 1 : 0; /* GASMASK, garbage, "skip earlier wind particles" */
+}
+
+template <bool KICK>
+__global__ __launch_bounds__(256) void wind_walk_kernel(const SphDev a, const int32_t *queue, long long nq, const WindWalkArgs w, int32_t *__restrict__ nlist,
+                                                        long long ntasks)
+{
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(32))) char lds[4 * NW_LDS_PER_WAVE(false)];
+    const int lane = threadIdx.x & 63;
+    for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
+    const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    const long long t = wave * 64 + lane;
+    const bool valid = t < nq;
+    double px = 0, py = 0, pz = 0, h = 1, imass = 0, tw = 0, vdisp = 0;
+    unsigned long long myid = 0;
+    if(valid) {
+        const long long pi = queue[t];
+        const double4 p = a.posm[pi];
+        px = p.x; py = p.y; pz = p.z;
+        imass = p.w;
+        h = a.hsml[pi];
+        if(KICK) {
+            myid = w.ids[pi];
+            tw = w.totalweight[t];
+            vdisp = w.vdisp[t];
+        }
+    }
+    const double h2 = h * h;
+    /* get_wind_params, winds.cpp:489-507 */
+    double vel = 0, windeff = 0, utherm = 0;
+    if(KICK) {
+        const double vphys = vdisp / w.P.Time;
+        utherm = w.P.WindThermalFactor * 1.5 * vphys * vphys;
+        if(w.P.WindModel & 8) {
+            windeff = w.P.WindEfficiency;
+            vel = w.P.WindSpeed * w.P.Time;
+        } else {
+            windeff = (w.P.WindSigma0 * w.P.WindSigma0) / (vphys * vphys + 2 * utherm);
+            vel = w.P.WindSpeedFactor * vdisp;
+        }
+        if(vel < w.P.MinWindVelocity * w.P.Time)
+            vel = w.P.MinWindVelocity * w.P.Time;
+    }
+    double sum = 0;
+    unsigned int visited = 0;
+    auto pair = [&](const int s) {
+        const double4 q = a.posm_leaf[s];
+        const double d0 = wrapd(px - q.x, a.Box, a.invBox), d1 = wrapd(py - q.y, a.Box, a.invBox), d2 = wrapd(pz - q.z, a.Box, a.invBox);
+        const double r = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        if(r > h)
+            return;
+        if(!KICK) {
+            sum += q.w; /* wk = 1 */
+            visited++;
+            return;
+        }
+        if(tw == 0 || vdisp <= 0)
+            return;
+        const long long p = w.leaf_pidx[s];
+        const double prob = windeff * imass / tw;
+        const double rn = w.rnd[(myid + w.ids[p]) % w.rndsize];
+        if(rn < prob && vel > 0) {
+            const unsigned long long k = atomicAdd(w.nkicks, 1ull);
+            if(k < w.maxkicks) {
+                shq_wind_kick &K = w.kicks[k];
+                K.part_index = (int32_t) p;
+                K.pad_ = 0;
+                K.StarDistance = r;
+                K.StarID = myid;
+                K.StarKickVelocity = vel;
+                K.StarTherm = utherm;
+            }
+        }
+    };
+    auto accept = [&](const double r2, const double, const int) { return r2 <= h2; };
+    int fill = 0;
+    bool ovf = false;
+    (void) ngb_walk<false, false, false>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(false), myl, valid, px, py, pz, h, accept, pair,
+                                         (unsigned int *) nullptr, fill, ovf);
+    if(!KICK) {
+        if(valid)
+            w.totalweight[t] = sum;
+        for(int off = 32; off > 0; off >>= 1)
+            visited += __shfl_xor(visited, off);
+        if(lane == 0 && visited)
+            atomicAdd(w.nvisited, (unsigned long long) visited);
+    }
+    } /* task loop */
+}
+
+int shq_wind_walk_device(shq_context *ctx, const WindWalkArgs *w, const int32_t *d_queue, int64_t nq, bool kick)
+{
+    if(nq == 0)
+        return SHQ_OK;
+    hipStream_t st = ctx->stream;
+    const long long nl = ctx->ntreeparts + SHQ_NMAXCHILD;
+    SHQ_TRY(ctx->flag_leaf.reserve(nl));
+    wind_gather_leaf_kernel<<<dim3(nblk(nl)), dim3(256), 0, st>>>(nl, ctx->leaf_pidx.ptr, ctx->pflags.ptr, ctx->g_delaytime.ptr, ctx->flag_leaf.ptr);
+    SHQ_HIP(hipGetLastError());
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    SphDev a = make_dev(ctx);
+    a.Box = w->P.BoxSize;
+    a.invBox = 1.0 / w->P.BoxSize;
+    const long long ntasks = (nq + 255) / 256;
+    const unsigned grid = (unsigned) (ntasks < NL_REDO_BLOCKS ? ntasks : NL_REDO_BLOCKS);
+    if(kick)
+        wind_walk_kernel<true><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, ctx->s_nlist2.ptr, ntasks);
+    else
+        wind_walk_kernel<false><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, ctx->s_nlist2.ptr, ntasks);
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}

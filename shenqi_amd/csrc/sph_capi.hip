@@ -1268,3 +1268,134 @@ extern "C" int shq_bh_feedback(shq_context *ctx, const shq_tree_view *tree, cons
         *n_bh_swallowed = nbhs;
     return SHQ_OK;
 }
+
+/* ---- winds_and_feedback (winds.cpp:295-369) ------------------------------------------------------------------------------------ */
+extern "C" int shq_winds_and_feedback(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph, const shq_star_view *stars,
+                                      const uint64_t *ids, const int32_t *NewStars, int64_t NumNewStars, const shq_wind_params *params, const double *rnd_table,
+                                      int64_t rnd_size, double *TotalWeight, shq_wind_kick *kicks, int64_t kicks_capacity, int64_t *nkicks, int64_t *nkicked)
+{
+    SHQ_CHECK(ctx && tree && parts && sph && stars && ids && params && rnd_table && (NumNewStars == 0 || NewStars), SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->sphrun.phase == 0, SHQ_ERR_STATE, "winds_and_feedback: an SPH walk is open");
+    SHQ_CHECK(rnd_size > 0, SHQ_ERR_INVALID, "winds_and_feedback: empty random table");
+    if(nkicks)
+        *nkicks = 0;
+    if(nkicked)
+        *nkicked = 0;
+    if(params->WindModel & 1) /* "The subgrid model does nothing here" */
+        return SHQ_OK;
+    SHQ_CHECK((params->WindModel & 8) || (params->WindModel & 4), SHQ_ERR_INVALID, "WindModel = 0x%X is strange (winds.cpp:503)", params->WindModel);
+    SHQ_CHECK(parts->off_vel != SHQ_NOFIELD && parts->off_hsml != SHQ_NOFIELD && parts->off_pi != SHQ_NOFIELD && parts->off_type != SHQ_NOFIELD &&
+                  parts->off_flags != SHQ_NOFIELD,
+              SHQ_ERR_INVALID, "winds_and_feedback: the particle view needs Vel, Hsml, PI, Type and the flag byte");
+    SHQ_CHECK(sph->off_delaytime != SHQ_NOFIELD, SHQ_ERR_INVALID, "winds_and_feedback: the gas view needs DelayTime");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t n = parts->numpart, nq = NumNewStars;
+    std::vector<double> vdisp((size_t) std::max<int64_t>(nq, 1));
+    for(int64_t k = 0; k < nq; k++) {
+        const int32_t i = NewStars[k];
+        SHQ_CHECK(i >= 0 && i < n, SHQ_ERR_INVALID, "winds_and_feedback: NewStars[%ld] = %d out of range", (long) k, i);
+        SHQ_CHECK(*pfield<uint8_t>(parts, i, parts->off_type) == 4, SHQ_ERR_INVALID, "Particle %d has type %d not a star (winds.cpp:402)", i,
+                  (int) *pfield<uint8_t>(parts, i, parts->off_type));
+        const int32_t pi = *pfield<int32_t>(parts, i, parts->off_pi);
+        SHQ_CHECK(pi >= 0 && pi < stars->numslots, SHQ_ERR_INVALID, "winds_and_feedback: star %d has PI %d outside the slot array", i, pi);
+        vdisp[(size_t) k] = (double) *reinterpret_cast<const float *>(static_cast<const char *>(stars->base) + (size_t) pi * stars->elsize + stars->off_vdisp);
+    }
+    SHQ_TRY(shq_particles_upload(ctx, parts));
+    SHQ_TRY(sph_upload(ctx, parts, sph));
+    SHQ_TRY(shq_tree_upload(ctx, tree));
+    if(nq == 0)
+        return SHQ_OK;
+    hipStream_t st = ctx->stream;
+    SHQ_TRY(ctx->bhw_ids.reserve((size_t) std::max<int64_t>(n, 1)));
+    SHQ_TRY(ctx->bhw_rnd.reserve((size_t) rnd_size));
+    SHQ_TRY(ctx->bhw_queue.reserve((size_t) nq));
+    SHQ_TRY(ctx->wind_d.reserve(2 * (size_t) nq));
+    SHQ_TRY(ctx->wind_cnt.reserve(4));
+    SHQ_HIP(hipMemcpyAsync(ctx->bhw_ids.ptr, ids, sizeof(uint64_t) * (size_t) n, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemcpyAsync(ctx->bhw_rnd.ptr, rnd_table, sizeof(double) * (size_t) rnd_size, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemcpyAsync(ctx->bhw_queue.ptr, NewStars, sizeof(int32_t) * (size_t) nq, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemcpyAsync(ctx->wind_d.ptr + nq, vdisp.data(), sizeof(double) * (size_t) nq, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemsetAsync(ctx->wind_cnt.ptr, 0, sizeof(unsigned long long) * 4, st));
+    WindWalkArgs w;
+    memset(&w, 0, sizeof(w));
+    w.ids = ctx->bhw_ids.ptr;
+    w.rnd = ctx->bhw_rnd.ptr;
+    w.rndsize = (unsigned long long) rnd_size;
+    w.leaf_pidx = ctx->leaf_pidx.ptr;
+    w.totalweight = ctx->wind_d.ptr;
+    w.vdisp = ctx->wind_d.ptr + nq;
+    w.nvisited = ctx->wind_cnt.ptr;
+    w.nkicks = ctx->wind_cnt.ptr + 1;
+    w.P = *params;
+    SHQ_TRY(shq_wind_walk_device(ctx, &w, ctx->bhw_queue.ptr, nq, false));
+    std::vector<double> tw((size_t) nq);
+    unsigned long long cnt[2] = {0, 0};
+    SHQ_HIP(hipMemcpyAsync(tw.data(), ctx->wind_d.ptr, sizeof(double) * (size_t) nq, hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipMemcpyAsync(cnt, ctx->wind_cnt.ptr, sizeof(cnt), hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    if(TotalWeight)
+        for(int64_t k = 0; k < nq; k++) /* sfr_wind_reduce_weight, PRIMARY */
+            TotalWeight[*pfield<int32_t>(parts, NewStars[k], parts->off_pi)] = tw[(size_t) k];
+    /* priv->maxkicks = nvisited + 2 (:311): every candidate was a visit of the first walk */
+    const unsigned long long maxkicks = cnt[0] + 2;
+    SHQ_TRY(ctx->wind_kicks.reserve((size_t) maxkicks * sizeof(shq_wind_kick)));
+    w.kicks = reinterpret_cast<shq_wind_kick *>(ctx->wind_kicks.ptr);
+    w.maxkicks = maxkicks;
+    SHQ_TRY(shq_wind_walk_device(ctx, &w, ctx->bhw_queue.ptr, nq, true));
+    SHQ_HIP(hipMemcpyAsync(cnt, ctx->wind_cnt.ptr, sizeof(cnt), hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    SHQ_CHECK(cnt[1] <= maxkicks, SHQ_ERR_STATE, "Not enough room in kick queue: %llu > %llu (winds.cpp:552)", cnt[1], maxkicks);
+    std::vector<shq_wind_kick> K((size_t) cnt[1]);
+    if(cnt[1])
+        SHQ_HIP(hipMemcpy(K.data(), ctx->wind_kicks.ptr, sizeof(shq_wind_kick) * K.size(), hipMemcpyDeviceToHost));
+    /* StarKick::operator< (:189-207): by particle, then distance, then star ID */
+    std::sort(K.begin(), K.end(), [](const shq_wind_kick &a, const shq_wind_kick &b) {
+        if(a.part_index != b.part_index)
+            return a.part_index < b.part_index;
+        if(a.StarDistance != b.StarDistance)
+            return a.StarDistance < b.StarDistance;
+        return a.StarID < b.StarID;
+    });
+    if(nkicks)
+        *nkicks = (int64_t) K.size();
+    if(kicks) {
+        SHQ_CHECK(kicks_capacity >= (int64_t) K.size(), SHQ_ERR_INVALID, "winds_and_feedback: room for %ld kicks, %ld found", (long) kicks_capacity, (long) K.size());
+        if(!K.empty())
+            memcpy(kicks, K.data(), sizeof(shq_wind_kick) * K.size());
+    }
+    const bool decouple = (params->WindModel & 2) && params->MaxWindFreeTravelTime > 0; /* winds_ever_decouple */
+    int64_t last = -1, applied = 0;
+    for(const shq_wind_kick &k : K) {
+        if(k.part_index == last)
+            continue;
+        const int32_t other = k.part_index;
+        last = other;
+        applied++;
+        /* wind_do_kick, :449-471 */
+        const uint64_t id = ids[other];
+        const double theta = acos(2 * rnd_table[(id + 3) % (uint64_t) rnd_size] - 1);
+        const double phi = 2 * M_PI * rnd_table[(id + 4) % (uint64_t) rnd_size];
+        const double dir[3] = {sin(theta) * cos(phi), sin(theta) * sin(phi), cos(theta)};
+        const double vel = k.StarKickVelocity, atime = params->Time;
+        const int32_t pi = *pfield<int32_t>(parts, other, parts->off_pi);
+        if(vel > 0 && atime > 0) {
+            double *v = pfield_w<double>(parts, other, parts->off_vel);
+            for(int j = 0; j < 3; j++)
+                v[j] += vel * dir[j];
+            const double gm1 = 5.0 / 3 - 1; /* GAMMA_MINUS1, physconst.h */
+            const double enttou = pow(*sfield(sph, pi, sph->off_density) / pow(atime, 3), gm1) / gm1;
+            *sfield(sph, pi, sph->off_entropy) += k.StarTherm / enttou;
+            if(decouple) {
+                double delay = params->WindFreeTravelLength / (vel / atime);
+                if(delay > params->MaxWindFreeTravelTime)
+                    delay = params->MaxWindFreeTravelTime;
+                *sfield(sph, pi, sph->off_delaytime) = delay;
+            }
+        }
+        SHQ_CHECK(vel > 0 && std::isfinite(vel) && std::isfinite(*sfield(sph, pi, sph->off_delaytime)), SHQ_ERR_STATE, "Odd v: other = %d, v = %g (winds.cpp:344)", other,
+                  vel);
+    }
+    if(nkicked)
+        *nkicked = applied;
+    return SHQ_OK;
+}
