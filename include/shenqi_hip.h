@@ -960,6 +960,27 @@ int shq_winds_and_feedback(shq_context *ctx, const shq_tree_view *tree, const sh
                            const uint64_t *ids, const int32_t *NewStars, int64_t NumNewStars, const shq_wind_params *params, const double *rnd_table,
                            int64_t rnd_size, double *TotalWeight, shq_wind_kick *kicks, int64_t kicks_capacity, int64_t *nkicks, int64_t *nkicked);
 
+/* The treewalk of metal_return() (libgadget/metal_return.cpp:513-530, 573-667), after stellar_density
+ * (shq_stellar_density) and with the per-star yields of metal_return_copy (:540-571: the IMF / yield-table integrals stay with the
+ * caller): every gas particle inside the kernel of a star of `queue` (r2 > 0, r2 < H^2) receives
+ * returnfraction = wk (Mass / Density) / StarVolumeSPH of the star's MassGenerated, MetalGenerated and MetalSpeciesGenerated, unless that
+ * would lift it above MaxGasMass: Metals[] (float), Metallicity, Mass (float) and Density are updated with the reference's expressions
+ * (:622-660).  The reference serialises the updates of a particle with a spin lock, in whatever order its threads arrive; here the
+ * stars reach a particle in queue order (a triple list sorted by particle and queue position, applied by one thread per particle).
+ * MassReturn[k] = the mass star queue[k] gave away (metal_return_reduce); the star's own bookkeeping (metal_return_postprocess:
+ * Mass -= MassReturn, TotalMassReturned, LastEnrichmentMyr) is three assignments the caller keeps.  All per-star arrays are indexed by
+ * queue position. */
+typedef struct shq_gas_metal_view {
+    void *base;
+    size_t elsize;
+    int64_t numslots;
+    size_t off_density, off_metallicity, off_metals;   /* double, double, float[nmetals] */
+    int nmetals, pad_;                                 /* NMETALS = 9 */
+} shq_gas_metal_view;
+int shq_metal_return(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_gas_metal_view *gas, const int32_t *queue, int64_t nqueue,
+                     const double *StarVolumeSPH, const double *MassGenerated, const double *MetalGenerated, const double *MetalSpeciesGenerated /* [nqueue][nmetals] */,
+                     double MaxGasMass, int SPHWeighting, int DensityKernelType, double *MassReturn, int64_t *npairs);
+
 /* ---- long-range PM --------------------------------------------------------------------- */
 
 /* Mirror of the PetaPM fields gravpm.cpp reads (libgadget/petapm.h:87-112). */

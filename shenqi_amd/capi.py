@@ -245,6 +245,11 @@ def bh_slot_view(arr):
     return v
 
 
+class GasMetalView(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("elsize", C.c_size_t), ("numslots", C.c_int64), ("off_density", C.c_size_t), ("off_metallicity", C.c_size_t),
+                ("off_metals", C.c_size_t), ("nmetals", C.c_int), ("pad_", C.c_int)]
+
+
 class WindParams(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("BoxSize", "Time", "WindFreeTravelLength", "MaxWindFreeTravelTime", "WindEfficiency", "WindSpeed", "WindSigma0",
                                          "WindSpeedFactor", "MinWindVelocity", "WindThermalFactor")] + [("WindModel", C.c_int), ("pad_", C.c_int)]
@@ -437,6 +442,9 @@ hip.shq_bh_accretion.restype = hip.shq_bh_feedback.restype = C.c_int
 hip.shq_winds_and_feedback.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(SphView), C.POINTER(StarView), _vp, _vp, C.c_int64, C.POINTER(WindParams),
                                        _vp, C.c_int64, _vp, _vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
 hip.shq_winds_and_feedback.restype = C.c_int
+hip.shq_metal_return.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(GasMetalView), _vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp,
+                                 C.POINTER(C.c_int64)]
+hip.shq_metal_return.restype = C.c_int
 hip.shq_sph_state_upload.argtypes = [_vp, C.POINTER(PartView), C.POINTER(SphView)]
 hip.shq_sph_state_upload.restype = C.c_int
 hip.shq_fof_seed_select.argtypes = [_vp, C.c_double, C.c_double, _vp, C.c_int64, C.POINTER(C.c_int64)]

@@ -291,6 +291,9 @@ struct shq_context {
     DevBuf<unsigned long long> bhw_ids, bhw_sphsw, bhw_bhsw, bhw_swid;
     DevBuf<double> bhw_rnd, bhw_out;
     DevBuf<uint8_t> bhw_eeqos, bhw_heated;
+    DevBuf<unsigned long long> metal_keys[2];
+    DevBuf<double> metal_val[2], metal_star, metal_gd;
+    DevBuf<float> metal_gf;
     DevBuf<char> wind_kicks;
     DevBuf<double> wind_d;
     DevBuf<unsigned long long> wind_cnt;
@@ -502,6 +505,24 @@ struct WindWalkArgs {
     shq_wind_params P;
 };
 int shq_wind_walk_device(shq_context *ctx, const WindWalkArgs *w, const int32_t *d_queue, int64_t nq, bool kick);
+/* metal return (sph.hip) */
+#define SHQ_NMETALS 9
+struct MetalWalkArgs {
+    unsigned long long *cursor;
+    unsigned long long capacity;
+    unsigned long long *keys;      /* particle << 32 | queue position */
+    double *wk;
+    const int32_t *leaf_pidx;
+    int SPHWeighting;
+    double MaxGasMass;
+    /* by queue position */
+    const double *starvolume, *massgenerated, *metalgenerated, *speciesgenerated;
+    /* gas state by particle index */
+    float *gmass, *gmetals;
+    double *gdensity, *gmetallicity;
+};
+int shq_metal_return_device(shq_context *ctx, MetalWalkArgs *w, int kernel_type, double BoxSize, const int32_t *d_queue, int64_t nq, double *d_massreturn,
+                            int64_t *npairs_out);
 int shq_bh_accretion_device(shq_context *ctx, const shq_kick_factors *kf, const BhWalkArgs *w, const int32_t *d_queue, int64_t nq, double *d_post);
 int shq_bh_feedback_device(shq_context *ctx, const shq_kick_factors *kf, const BhWalkArgs *w, const int32_t *d_queue, int64_t nq);
 int shq_bh_veldisp_device(shq_context *ctx, const shq_kick_factors *kf, double BoxSize, const int32_t *d_queue, int64_t nq, double *d_out);

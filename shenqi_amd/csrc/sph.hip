@@ -23,6 +23,7 @@
  * All arithmetic is f64.
  */
 #include "common.hpp"
+#include <rocprim/device/device_radix_sort.hpp>
 #include <math.h>
 #include <stdlib.h>
 
@@ -3312,6 +3313,209 @@ int shq_wind_walk_device(shq_context *ctx, const WindWalkArgs *w, const int32_t 
         wind_walk_kernel<true><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, ctx->s_nlist2.ptr, ntasks);
     else
         wind_walk_kernel<false><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, ctx->s_nlist2.ptr, ntasks);
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}
+
+/* ---- metal return to the gas around dying stars: libgadget/metal_return.cpp:582-667 -----------------------
+ * metal_return_ngbiter updates every gas particle inside a star's kernel under a per-particle spin lock: the result depends on the
+ * order the stars reach a particle in (float mass, the MaxGasMass cut).  Here the walk (one star per lane, asymmetric, gas tree) only
+ * EMITS (gas particle, star, wk) triples; they are sorted by (particle, position of the star in the queue) and one thread per gas
+ * particle applies its triples in that order with the reference's arithmetic — the serial loop over the queue, deterministic.  The
+ * mass each star gave away is then summed per star in particle order. */
+template <int KT, bool EMIT>
+__global__ __launch_bounds__(256) void metal_emit_kernel(const SphDev a, const int32_t *queue, long long nq, const MetalWalkArgs w, int32_t *__restrict__ nlist,
+                                                         long long ntasks)
+{
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(32))) char lds[4 * NW_LDS_PER_WAVE(false)];
+    const int lane = threadIdx.x & 63;
+    for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
+    const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    const long long t = wave * 64 + lane;
+    const bool valid = t < nq;
+    double px = 0, py = 0, pz = 0, h = 1;
+    if(valid) {
+        const double4 p = a.posm[queue[t]];
+        px = p.x; py = p.y; pz = p.z;
+        h = a.hsml[queue[t]];
+    }
+    const Kern<KT> kernel(h);
+    const double HH = kernel.H * kernel.H, Hinv = 1.0 / kernel.H;
+    unsigned int mine = 0;
+    auto pair = [&](const int s) {
+        if(!EMIT) {
+            mine++;
+            return;
+        }
+        const double4 q = a.posm_leaf[s];
+        const double d0 = wrapd(px - q.x, a.Box, a.invBox), d1 = wrapd(py - q.y, a.Box, a.invBox), d2 = wrapd(pz - q.z, a.Box, a.invBox);
+        const double r = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        double wk = 1;
+        if(w.SPHWeighting)
+            wk = kernel.wk(r * Hinv);
+        const unsigned long long k = atomicAdd(w.cursor, 1ull);
+        if(k < w.capacity) {
+            w.keys[k] = ((unsigned long long) (unsigned) w.leaf_pidx[s] << 32) | (unsigned long long) t;
+            w.wk[k] = wk;
+        }
+    };
+    auto accept = [&](const double r2, const double, const int) { return r2 > 0 && r2 < HH; };
+    int fill = 0;
+    bool ovf = false;
+    (void) ngb_walk<false, false, false>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(false), myl, valid, px, py, pz, h, accept, pair,
+                                         (unsigned int *) nullptr, fill, ovf);
+    if(!EMIT) {
+        for(int off = 32; off > 0; off >>= 1)
+            mine += __shfl_xor(mine, off);
+        if(lane == 0 && mine)
+            atomicAdd(w.cursor, (unsigned long long) mine);
+    }
+    } /* task loop */
+}
+
+/* one thread per run of equal gas particles in the (particle, star)-sorted list: metal_return_ngbiter's body, :622-660 */
+__global__ void metal_apply_kernel(long long npairs, const unsigned long long *__restrict__ keys, const double *__restrict__ wk, const MetalWalkArgs w, double *thismass_out)
+{
+#pragma clang fp contract(off)
+    const long long k0 = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k0 >= npairs)
+        return;
+    const unsigned p = (unsigned) (keys[k0] >> 32);
+    if(k0 > 0 && (unsigned) (keys[k0 - 1] >> 32) == p)
+        return;
+    float mass = w.gmass[p];
+    double density = w.gdensity[p], metallicity = w.gmetallicity[p];
+    float metals[SHQ_NMETALS];
+    for(int i = 0; i < SHQ_NMETALS; i++)
+        metals[i] = w.gmetals[(size_t) p * SHQ_NMETALS + i];
+    for(long long k = k0; k < npairs && (unsigned) (keys[k] >> 32) == p; k++) {
+        const unsigned t = (unsigned) (keys[k] & 0xffffffffull);
+        const double volume = mass / density;
+        const double returnfraction = wk[k] * volume / w.starvolume[t];
+        const double thismass = returnfraction * w.massgenerated[t];
+        if(mass + thismass > w.MaxGasMass) {
+            thismass_out[k] = 0;
+            continue;
+        }
+        for(int i = 0; i < SHQ_NMETALS; i++) {
+            const double tm = returnfraction * w.speciesgenerated[(size_t) t * SHQ_NMETALS + i];
+            metals[i] = (float) ((metals[i] * mass + tm) / (mass + thismass));
+        }
+        const double thismetal = returnfraction * w.metalgenerated[t];
+        metallicity = (metallicity * mass + thismetal) / (mass + thismass);
+        const double massfrac = (mass + thismass) / mass;
+        mass = (float) (mass * massfrac);
+        density *= massfrac;
+        thismass_out[k] = thismass;
+    }
+    w.gmass[p] = mass;
+    w.gdensity[p] = density;
+    w.gmetallicity[p] = metallicity;
+    for(int i = 0; i < SHQ_NMETALS; i++)
+        w.gmetals[(size_t) p * SHQ_NMETALS + i] = metals[i];
+}
+
+__global__ void metal_rekey_kernel(long long npairs, const unsigned long long *keys, unsigned long long *out)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k < npairs)
+        out[k] = (keys[k] << 32) | (keys[k] >> 32); /* (star, particle) */
+}
+
+/* O->MassReturn += thismass over a star's neighbours, in particle order */
+__global__ void metal_sum_kernel(long long npairs, const unsigned long long *__restrict__ keys_tp, const double *__restrict__ thismass, double *massreturn)
+{
+#pragma clang fp contract(off)
+    const long long k0 = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k0 >= npairs)
+        return;
+    const unsigned t = (unsigned) (keys_tp[k0] >> 32);
+    if(k0 > 0 && (unsigned) (keys_tp[k0 - 1] >> 32) == t)
+        return;
+    double s = 0;
+    for(long long k = k0; k < npairs && (unsigned) (keys_tp[k] >> 32) == t; k++)
+        s += thismass[k];
+    massreturn[t] = s;
+}
+
+int shq_metal_return_device(shq_context *ctx, MetalWalkArgs *w, int kernel_type, double BoxSize, const int32_t *d_queue, int64_t nq, double *d_massreturn, int64_t *npairs_out)
+{
+    if(npairs_out)
+        *npairs_out = 0;
+    if(nq == 0)
+        return SHQ_OK;
+    SHQ_CHECK(kernel_type == 1 || kernel_type == 2 || kernel_type == 4, SHQ_ERR_INVALID, "unknown DensityKernelType %d", kernel_type);
+    hipStream_t st = ctx->stream;
+    const long long nl = ctx->ntreeparts + SHQ_NMAXCHILD;
+    SHQ_TRY(ctx->flag_leaf.reserve(nl));
+    /* GASMASK, not garbage; wind particles take metals like any other gas */
+    bh_gather_leaf_kernel<<<dim3(nblk(nl)), dim3(256), 0, st>>>(nl, ctx->leaf_pidx.ptr, ctx->pflags.ptr, ctx->flag_leaf.ptr);
+    SHQ_HIP(hipGetLastError());
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    SHQ_TRY(ctx->wind_cnt.reserve(4));
+    SphDev a = make_dev(ctx);
+    a.Box = BoxSize;
+    a.invBox = 1.0 / BoxSize;
+    const long long ntasks = (nq + 255) / 256;
+    const unsigned grid = (unsigned) (ntasks < NL_REDO_BLOCKS ? ntasks : NL_REDO_BLOCKS);
+    w->cursor = ctx->wind_cnt.ptr;
+    w->leaf_pidx = ctx->leaf_pidx.ptr;
+    unsigned long long np = 0;
+    for(int pass = 0; pass < 2; pass++) {
+        SHQ_HIP(hipMemsetAsync(ctx->wind_cnt.ptr, 0, sizeof(unsigned long long), st));
+        if(pass == 0) {
+            switch(kernel_type) {
+            case 1: metal_emit_kernel<1, false><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, ctx->s_nlist2.ptr, ntasks); break;
+            case 2: metal_emit_kernel<2, false><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, ctx->s_nlist2.ptr, ntasks); break;
+            default: metal_emit_kernel<4, false><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, ctx->s_nlist2.ptr, ntasks); break;
+            }
+        } else {
+            switch(kernel_type) {
+            case 1: metal_emit_kernel<1, true><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, ctx->s_nlist2.ptr, ntasks); break;
+            case 2: metal_emit_kernel<2, true><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, ctx->s_nlist2.ptr, ntasks); break;
+            default: metal_emit_kernel<4, true><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, ctx->s_nlist2.ptr, ntasks); break;
+            }
+        }
+        SHQ_HIP(hipGetLastError());
+        unsigned long long h = 0;
+        SHQ_HIP(hipMemcpyAsync(&h, ctx->wind_cnt.ptr, sizeof(h), hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipStreamSynchronize(st));
+        if(pass == 0) {
+            np = h;
+            if(np == 0)
+                break;
+            SHQ_TRY(ctx->metal_keys[0].reserve((size_t) np));
+            SHQ_TRY(ctx->metal_keys[1].reserve((size_t) np));
+            SHQ_TRY(ctx->metal_val[0].reserve((size_t) np));
+            SHQ_TRY(ctx->metal_val[1].reserve((size_t) np));
+            w->keys = ctx->metal_keys[0].ptr;
+            w->wk = ctx->metal_val[0].ptr;
+            w->capacity = np;
+        } else
+            SHQ_CHECK(h == np, SHQ_ERR_STATE, "metal_return: the two walks disagree on the number of pairs (%llu, %llu)", np, h);
+    }
+    if(npairs_out)
+        *npairs_out = (int64_t) np;
+    SHQ_HIP(hipMemsetAsync(d_massreturn, 0, sizeof(double) * (size_t) nq, st));
+    if(np == 0)
+        return SHQ_OK;
+    size_t tmp = 0;
+    SHQ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, ctx->metal_keys[0].ptr, ctx->metal_keys[1].ptr, ctx->metal_val[0].ptr, ctx->metal_val[1].ptr, (size_t) np, 0, 64, st));
+    SHQ_TRY(ctx->wind_kicks.reserve(tmp + 16));
+    SHQ_HIP(rocprim::radix_sort_pairs(ctx->wind_kicks.ptr, tmp, ctx->metal_keys[0].ptr, ctx->metal_keys[1].ptr, ctx->metal_val[0].ptr, ctx->metal_val[1].ptr, (size_t) np, 0, 64,
+                                      st));
+    /* thismass per pair, in (particle, star) order, into metal_val[0] */
+    metal_apply_kernel<<<dim3(nblk((long long) np)), dim3(256), 0, st>>>((long long) np, ctx->metal_keys[1].ptr, ctx->metal_val[1].ptr, *w, ctx->metal_val[0].ptr);
+    SHQ_HIP(hipGetLastError());
+    metal_rekey_kernel<<<dim3(nblk((long long) np)), dim3(256), 0, st>>>((long long) np, ctx->metal_keys[1].ptr, ctx->metal_keys[0].ptr);
+    SHQ_HIP(hipGetLastError());
+    SHQ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, ctx->metal_keys[0].ptr, ctx->metal_keys[1].ptr, ctx->metal_val[0].ptr, ctx->metal_val[1].ptr, (size_t) np, 0, 64, st));
+    SHQ_TRY(ctx->wind_kicks.reserve(tmp + 16));
+    SHQ_HIP(rocprim::radix_sort_pairs(ctx->wind_kicks.ptr, tmp, ctx->metal_keys[0].ptr, ctx->metal_keys[1].ptr, ctx->metal_val[0].ptr, ctx->metal_val[1].ptr, (size_t) np, 0, 64,
+                                      st));
+    metal_sum_kernel<<<dim3(nblk((long long) np)), dim3(256), 0, st>>>((long long) np, ctx->metal_keys[1].ptr, ctx->metal_val[1].ptr, d_massreturn);
     SHQ_HIP(hipGetLastError());
     return SHQ_OK;
 }

@@ -1399,3 +1399,94 @@ extern "C" int shq_winds_and_feedback(shq_context *ctx, const shq_tree_view *tre
         *nkicked = applied;
     return SHQ_OK;
 }
+
+/* ---- metal_return's treewalk (metal_return.cpp:513-530, 573-667) ---------------------------------------------------------------- */
+extern "C" int shq_metal_return(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_gas_metal_view *gas, const int32_t *queue,
+                                int64_t nqueue, const double *StarVolumeSPH, const double *MassGenerated, const double *MetalGenerated,
+                                const double *MetalSpeciesGenerated, double MaxGasMass, int SPHWeighting, int DensityKernelType, double *MassReturn, int64_t *npairs)
+{
+    SHQ_CHECK(ctx && tree && parts && gas && (nqueue == 0 || (queue && StarVolumeSPH && MassGenerated && MetalGenerated && MetalSpeciesGenerated && MassReturn)),
+              SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->sphrun.phase == 0, SHQ_ERR_STATE, "metal_return: an SPH walk is open");
+    SHQ_CHECK(gas->nmetals == SHQ_NMETALS, SHQ_ERR_INVALID, "metal_return: NMETALS = %d, the library was built for %d", gas->nmetals, SHQ_NMETALS);
+    SHQ_CHECK(parts->off_hsml != SHQ_NOFIELD && parts->off_pi != SHQ_NOFIELD && parts->off_type != SHQ_NOFIELD && parts->off_flags != SHQ_NOFIELD, SHQ_ERR_INVALID,
+              "metal_return: the particle view needs Hsml, PI, Type and the flag byte");
+    if(npairs)
+        *npairs = 0;
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t n = parts->numpart, nq = nqueue;
+    for(int64_t k = 0; k < nq; k++) {
+        const int32_t i = queue[k];
+        SHQ_CHECK(i >= 0 && i < n, SHQ_ERR_INVALID, "metal_return: queue[%ld] = %d out of range", (long) k, i);
+        SHQ_CHECK(*pfield<uint8_t>(parts, i, parts->off_type) == 4 && !(*pfield<uint8_t>(parts, i, parts->off_flags) & 1u), SHQ_ERR_INVALID,
+                  "metal_return: particle %d in the queue is not a live star", i);
+        /* "StarVolumeSPH %g hsml %g" (:619): the reference ends the run at the first neighbour of such a star */
+        SHQ_CHECK(StarVolumeSPH[k] != 0, SHQ_ERR_INVALID, "metal_return: StarVolumeSPH = 0 for star %d (hsml %g)", i, *pfield<double>(parts, i, parts->off_hsml));
+    }
+    SHQ_TRY(shq_particles_upload(ctx, parts));
+    SHQ_TRY(shq_dynamics_upload(ctx, parts));
+    SHQ_TRY(shq_tree_upload(ctx, tree));
+    if(nq == 0)
+        return SHQ_OK;
+    hipStream_t st = ctx->stream;
+    const size_t cap = (size_t) std::max<int64_t>(n, 1);
+    std::vector<float> gf(cap * (1 + SHQ_NMETALS), 0.f);
+    std::vector<double> gd(cap * 2, 1.0);
+    float *hm = gf.data(), *hz = gf.data() + cap;
+    double *hd = gd.data(), *hy = gd.data() + cap;
+    auto slot = [&](int64_t i) { return static_cast<char *>(gas->base) + (size_t) *pfield<int32_t>(parts, i, parts->off_pi) * gas->elsize; };
+    for(int64_t i = 0; i < n; i++) {
+        hm[i] = *pfield<float>(parts, i, parts->off_mass);
+        if(*pfield<uint8_t>(parts, i, parts->off_type) != 0 || (*pfield<uint8_t>(parts, i, parts->off_flags) & 1u))
+            continue;
+        const int32_t pi = *pfield<int32_t>(parts, i, parts->off_pi);
+        SHQ_CHECK(pi >= 0 && pi < gas->numslots, SHQ_ERR_INVALID, "metal_return: gas particle %ld has PI %d outside the slot array", (long) i, pi);
+        const char *s = slot(i);
+        hd[i] = *reinterpret_cast<const double *>(s + gas->off_density);
+        hy[i] = *reinterpret_cast<const double *>(s + gas->off_metallicity);
+        for(int m = 0; m < SHQ_NMETALS; m++)
+            hz[(size_t) i * SHQ_NMETALS + m] = reinterpret_cast<const float *>(s + gas->off_metals)[m];
+    }
+    SHQ_TRY(ctx->metal_gf.reserve(gf.size()));
+    SHQ_TRY(ctx->metal_gd.reserve(gd.size()));
+    SHQ_TRY(ctx->metal_star.reserve((size_t) nq * (4 + SHQ_NMETALS)));
+    SHQ_TRY(ctx->bhw_queue.reserve((size_t) nq));
+    SHQ_HIP(hipMemcpyAsync(ctx->metal_gf.ptr, gf.data(), sizeof(float) * gf.size(), hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemcpyAsync(ctx->metal_gd.ptr, gd.data(), sizeof(double) * gd.size(), hipMemcpyHostToDevice, st));
+    double *ds = ctx->metal_star.ptr;
+    SHQ_HIP(hipMemcpyAsync(ds, StarVolumeSPH, sizeof(double) * (size_t) nq, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemcpyAsync(ds + nq, MassGenerated, sizeof(double) * (size_t) nq, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemcpyAsync(ds + 2 * nq, MetalGenerated, sizeof(double) * (size_t) nq, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemcpyAsync(ds + 4 * nq, MetalSpeciesGenerated, sizeof(double) * (size_t) nq * SHQ_NMETALS, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemcpyAsync(ctx->bhw_queue.ptr, queue, sizeof(int32_t) * (size_t) nq, hipMemcpyHostToDevice, st));
+    MetalWalkArgs w;
+    memset(&w, 0, sizeof(w));
+    w.SPHWeighting = SPHWeighting;
+    w.MaxGasMass = MaxGasMass;
+    w.starvolume = ds;
+    w.massgenerated = ds + nq;
+    w.metalgenerated = ds + 2 * nq;
+    w.speciesgenerated = ds + 4 * nq;
+    w.gmass = ctx->metal_gf.ptr;
+    w.gmetals = ctx->metal_gf.ptr + cap;
+    w.gdensity = ctx->metal_gd.ptr;
+    w.gmetallicity = ctx->metal_gd.ptr + cap;
+    SHQ_TRY(shq_metal_return_device(ctx, &w, DensityKernelType, tree->BoxSize, ctx->bhw_queue.ptr, nq, ds + 3 * nq, npairs));
+    std::vector<float> gf1(gf.size());
+    std::vector<double> gd1(gd.size());
+    SHQ_HIP(hipMemcpyAsync(MassReturn, ds + 3 * nq, sizeof(double) * (size_t) nq, hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipMemcpyAsync(gf1.data(), ctx->metal_gf.ptr, sizeof(float) * gf.size(), hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipMemcpyAsync(gd1.data(), ctx->metal_gd.ptr, sizeof(double) * gd.size(), hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    for(int64_t i = 0; i < n; i++) {
+        if(*pfield<uint8_t>(parts, i, parts->off_type) != 0 || (*pfield<uint8_t>(parts, i, parts->off_flags) & 1u))
+            continue;
+        char *s = slot(i);
+        *pfield_w<float>(parts, i, parts->off_mass) = gf1[i];
+        *reinterpret_cast<double *>(s + gas->off_density) = gd1[i];
+        *reinterpret_cast<double *>(s + gas->off_metallicity) = gd1[cap + i];
+        for(int m = 0; m < SHQ_NMETALS; m++)
+            reinterpret_cast<float *>(s + gas->off_metals)[m] = gf1[cap + (size_t) i * SHQ_NMETALS + m];
+    }
+    return SHQ_OK;
+}
