@@ -273,6 +273,14 @@ int shq_tree_build_domain(shq_context *ctx, double BoxSize, int mask, const int3
                           const shq_topnode_geo *topnodes, int ntopnodes, shq_topleaf *topleaves, int ntopleaves, int ThisTask,
                           int64_t firstnode, shq_topleaf_moments *local_moments, shq_tree_build_stats *stats);
 int shq_tree_set_topleaf_moments(shq_context *ctx, const shq_topleaf_moments *moments, int ntopleaves);
+/* The particle loop of domain_maintain() (libgadget/domain.cpp:296-330, 347-368) after shq_drift, on the domain of the last
+ * shq_tree_build_domain (its top tree and the cells of its top-level nodes): a live particle that is still inside the cell of its
+ * top leaf keeps it (inside_topleaf, bounds included), any other gets TopLeaf = domain_get_topleaf(PEANO(Pos)) (domain.h:68-76,
+ * utils/peano.h:15-21: the descent through the daughter table on PEANO()'s integer coordinates finds the same leaf); d_target
+ * (may be NULL) = layoutfunc: the leaf's task, -1 for garbage and, when dmtree == 0, for dark matter whose gravity bin is not
+ * active at Ti_Current (it stays and keeps its leaf).  d_topleaf / d_target are DEVICE arrays of one int per resident particle —
+ * d_target is what shq_exchange_plan takes.  *nchanged = particles that left their leaf. */
+int shq_domain_maintain_topleaf(shq_context *ctx, int dmtree, int64_t Ti_Current, int32_t *d_topleaf, int32_t *d_target, int64_t *nchanged);
 
 /* Resident drift and kick: with the particles, their velocities and the force
  * arrays in HBM a step is  shq_drift -> shq_tree_build -> shq_pm_run / shq_grav_short_run -> kicks,

@@ -1182,3 +1182,97 @@ extern "C" int shq_tree_download(shq_context *ctx, int64_t firstnode, shq_node *
     SHQ_HIP(hipStreamSynchronize(st));
     return SHQ_OK;
 }
+
+/* ---- domain_maintain's particle loop (libgadget/domain.cpp:296-330, 347-368) --------------------------------------------------------
+ * After the drift: a particle that is still inside the cell of its top leaf keeps it (inside_topleaf: |2 (Pos - center)| <= len on
+ * every axis), otherwise TopLeaf = domain_get_topleaf(PEANO(Pos)) — here the descent through the daughter-per-octant table on the
+ * integer coordinates PEANO() forms (utils/peano.h:15-21), which is the same leaf; then layoutfunc: the leaf's task, or -1 (stay) for
+ * an invalid leaf and for inactive dark matter when no dark-matter tree is wanted.  Garbage is left alone. */
+namespace {
+__global__ void dom_topleaf_kernel(long long n, const double4 *__restrict__ posm, const uint8_t *__restrict__ pflags, const uint8_t *__restrict__ bin_grav, TbGeo geo,
+                                   const double4 *__restrict__ leafbox, const int32_t *__restrict__ leaftask, int ntopleaves, double Box, int dmtree, long long Ti,
+                                   int32_t *topleaf, int32_t *target, unsigned long long *nchanged)
+{
+#pragma clang fp contract(off)
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    const unsigned f = pflags[i];
+    if(f & 1u) {
+        if(target)
+            target[i] = -1;
+        return;
+    }
+    const int type = f >> 4;
+    if(!dmtree && type == 1) {
+        const int bin = bin_grav[i];
+        const bool active = bin <= 0 || Ti <= 0 || (Ti % (1ll << bin)) == 0; /* is_timebin_active, timestep.cpp:132-139 */
+        if(!active) {
+            if(target)
+                target[i] = -1;
+            return;
+        }
+    }
+    const double4 p = posm[i];
+    int tl = topleaf[i];
+    bool inside = false;
+    if(tl >= 0 && tl < ntopleaves) {
+        const double4 b = leafbox[tl];
+        inside = (fabs(2 * (p.x - b.x)) <= b.w) && (fabs(2 * (p.y - b.y)) <= b.w) && (fabs(2 * (p.z - b.z)) <= b.w);
+    }
+    if(!inside) {
+        const double DomainFac = 1.0 / (Box * 1.001) * 2097152.0;
+        const int ix = (int) ((p.x + Box / 2000) * DomainFac), iy = (int) ((p.y + Box / 2000) * DomainFac), iz = (int) ((p.z + Box / 2000) * DomainFac);
+        int t = 0;
+        for(int l = 0; l < 21 && geo.kind[t].x == TOPK_INTERNAL; l++) {
+            const int s = ((ix >> (20 - l)) & 1) + 2 * ((iy >> (20 - l)) & 1) + 4 * ((iz >> (20 - l)) & 1);
+            t = geo.child(t, s);
+        }
+        tl = geo.kind[t].y;
+        topleaf[i] = tl;
+        atomicAdd(nchanged, 1ull);
+    }
+    if(target)
+        target[i] = (tl >= 0 && tl < ntopleaves) ? leaftask[tl] : -1;
+}
+} // namespace
+
+extern "C" int shq_domain_maintain_topleaf(shq_context *ctx, int dmtree, int64_t Ti_Current, int32_t *d_topleaf, int32_t *d_target, int64_t *nchanged)
+{
+    SHQ_CHECK(ctx && d_topleaf, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts && ctx->tb_domain && !ctx->dom_geo.empty() && ctx->dom_rec.size() == 9 * ctx->dom_geo.size(), SHQ_ERR_STATE,
+              "domain_maintain_topleaf: needs the domain of a shq_tree_build_domain call");
+    SHQ_CHECK(dmtree || ctx->have_dyn || ctx->have_sph, SHQ_ERR_STATE, "domain_maintain_topleaf: the gravity time bins must be resident (shq_dynamics_upload)");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int ntl = (int) ctx->dom_leaf_task.size(), ntn = (int) ctx->dom_geo.size();
+    std::vector<double4> box((size_t) ntl);
+    for(int t = 0; t < ntn; t++) {
+        const int l = ctx->dom_geo[t].leaf;
+        if(ctx->dom_geo[t].daughter[0] < 0 && l >= 0 && l < ntl) {
+            const double *r = &ctx->dom_rec[9 * (size_t) t];
+            box[l] = make_double4(r[5], r[6], r[7], r[8]);
+        }
+    }
+    TreeBuildBufs &b = ctx->tb;
+    hipStream_t st = ctx->stream;
+    SHQ_TRY(b.topbuf.reserve(4 * (size_t) ntl + (size_t) ntl + 8));
+    double4 *d_box = reinterpret_cast<double4 *>(b.topbuf.ptr);
+    int32_t *d_task = reinterpret_cast<int32_t *>(b.topbuf.ptr + 4 * (size_t) ntl);
+    SHQ_TRY(b.counters.reserve(4));
+    SHQ_HIP(hipMemcpyAsync(d_box, box.data(), sizeof(double4) * (size_t) ntl, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemcpyAsync(d_task, ctx->dom_leaf_task.data(), sizeof(int32_t) * (size_t) ntl, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemsetAsync(b.counters.ptr, 0, sizeof(unsigned long long), st));
+    const long long n = ctx->numpart;
+    if(n > 0) {
+        const TbGeo geo{b.geo_child[0].ptr, b.geo_child[1].ptr, b.geo_kind.ptr};
+        dom_topleaf_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, ctx->posm.ptr, ctx->pflags.ptr, ctx->bin_grav.ptr, geo, d_box, d_task, ntl, ctx->treeBox, dmtree,
+                                                               (long long) Ti_Current, d_topleaf, d_target, b.counters.ptr);
+        SHQ_HIP(hipGetLastError());
+    }
+    unsigned long long h = 0;
+    SHQ_HIP(hipMemcpyAsync(&h, b.counters.ptr, sizeof(h), hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st)); /* box / task staging live on this frame */
+    if(nchanged)
+        *nchanged = (int64_t) h;
+    return SHQ_OK;
+}

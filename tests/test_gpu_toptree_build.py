@@ -217,3 +217,68 @@ def test_domain_tree_walks_and_exports_like_the_uploaded_tree(ctx):
     for f in ("Task", "Index"):
         assert np.array_equal(got[f], otable[f]), f
     assert np.array_equal(got["NodeList"], otable["NodeList"])
+
+
+def test_domain_maintain_topleaf_equals_reference_keys(ctx):
+    """shq_domain_maintain_topleaf after a drift: every live particle's top leaf is domain_get_topleaf(PEANO(pos)) on a top tree cut
+    in Peano-Hilbert key space, with the reference's own peano.cpp (compiled in place, pinned by its golden keys) as the judge;
+    layoutfunc's targets; inactive dark matter stays when no dark-matter tree is wanted; garbage is left alone"""
+    import ctypes
+    import os
+    import torch
+    import test_peano_ref_cpu as tp
+    if not os.path.exists(tp.LIB):
+        pytest.skip("no prebuilt reference peano library")
+    lib = ctypes.CDLL(tp.LIB)
+    lib.ref_peano_hilbert_key.restype = ctypes.c_uint64
+    lib.ref_peano_hilbert_key.argtypes = [ctypes.c_int] * 4
+    lib.ref_PEANO.restype = ctypes.c_uint64
+    lib.ref_PEANO.argtypes = [ctypes.c_void_p, ctypes.c_double]
+    rng = np.random.default_rng(77)
+    nodes = tp.key_space_topnodes(rng, maxdepth=3, psplit=0.6)
+    geo = tp.geo_from_topnodes(nodes, lib)
+    ntl = sum(1 for nd in nodes if nd["Daughter"] < 0)
+    ntask, me = 4, 1
+    tl = np.zeros(ntl, dtype=capi.TOPLEAF_DTYPE)
+    tl["Task"] = np.arange(ntl) % ntask
+
+    def ref_leaf(p):
+        return np.array([tp.domain_get_topleaf(lib.ref_PEANO(np.ascontiguousarray(x).ctypes.data, cm.BOX), nodes) for x in p], dtype=np.int32)
+    pos = rng.random((20000, 3)) * cm.BOX
+    leaf0 = ref_leaf(pos)
+    mine = np.flatnonzero(tl["Task"][leaf0] == me)
+    n = len(mine)
+    pman = cm.make_partmanager(np.ascontiguousarray(pos[mine]))
+    P = pman.Base
+    P["Type"] = rng.choice([0, 1, 4], size=n, p=[0.2, 0.6, 0.2])
+    P["Hsml"] = 0.01 * cm.BOX
+    P["Vel"] = rng.normal(size=(n, 3)) * 1.0
+    P["TimeBinGravity"] = rng.integers(19, 23, n)
+    P["Flags"][::97] |= 1
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    sq.dynamics_upload(ctx, pman)
+    sq.tree_build_domain(ctx, cm.BOX, geo, tl.copy(), me, n + 5)
+    sq.drift(ctx, 0.12 * cm.BOX, cm.BOX)                      # a long drift: a good part of the particles leaves its leaf
+    sq.dynamics_download(ctx, pman)
+    want = ref_leaf(P["Pos"])
+    old = leaf0[mine].copy()
+    old[5], old[6] = -1, 10**6                                # invalid entries (the FOF exchange overwrites TopLeaf): looked up afresh
+    garbage = (P["Flags"] & 1) != 0
+    for dmtree in (1, 0):
+        d_tl = torch.from_numpy(old.copy()).to("cuda:0")
+        d_tg = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
+        nch = C.c_int64()
+        Ti = 1 << 20                                          # bins 19 and 20 are active, 21 and 22 are not
+        capi.check(capi.hip.shq_domain_maintain_topleaf(ctx.h, dmtree, Ti, d_tl.data_ptr(), d_tg.data_ptr(), C.byref(nch)))
+        ctx.synchronize()
+        got, tgt = d_tl.cpu().numpy(), d_tg.cpu().numpy()
+        stays = garbage.copy()
+        if not dmtree:
+            stays |= (P["Type"] == 1) & (P["TimeBinGravity"] > 20)
+        assert np.array_equal(got[~stays], want[~stays]) and np.array_equal(got[stays], old[stays])
+        assert np.array_equal(tgt[~stays], tl["Task"][want[~stays]]) and (tgt[stays] == -1).all()
+        assert nch.value == int((want[~stays] != old[~stays]).sum()) and 0.1 * n < nch.value < 0.95 * n
+        assert (tgt[~stays] != me).sum() > 0.05 * n           # these are what shq_exchange_plan would send away
+    with pytest.raises(sq.ShqError):
+        capi.check(capi.hip.shq_domain_maintain_topleaf(ctx.h, 1, 0, None, None, None))
