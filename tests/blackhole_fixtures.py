@@ -23,7 +23,7 @@ def params(**kw):
     return p, SimpleNamespace(**d)
 
 
-def setup(seed, ngrid=14, nbh=36, ndm=300):
+def setup(seed, ngrid=14, nbh=36, ndm=300, bh_hsml=1.0):
     """gas on a jittered grid, some dark matter the walks must ignore, black holes: single ones, close pairs (mergers) and a triple"""
     rng = np.random.default_rng(seed)
     ngas = ngrid**3
@@ -59,7 +59,7 @@ def setup(seed, ngrid=14, nbh=36, ndm=300):
             P["FullTreeGravAccel"][i] + 5000.0 * ((P["Pos"][i] - P["Pos"][j] + cm.BOX / 2) % cm.BOX - cm.BOX / 2)
     isgas, isbh = types == 0, types == 5
     P["Hsml"] = sp * rng.uniform(1.2, 1.8, n)
-    P["Hsml"][isbh] = sp * rng.uniform(1.8, 2.6, nbh)
+    P["Hsml"][isbh] = sp * rng.uniform(1.8, 2.6, nbh) * bh_hsml
     P["PI"][isgas] = rng.permutation(ngas)
     P["PI"][isbh] = np.arange(nbh)[::-1]
     gi = np.flatnonzero(isgas)

@@ -27,9 +27,9 @@ def close(a, b, rtol=1e-11):
     return a.shape == b.shape and np.abs(a - b).max(initial=0.0) <= rtol * scale
 
 
-def run_both(ctx, seed, queue_stride=1, **kw):
+def run_both(ctx, seed, queue_stride=1, bh_hsml=1.0, **kw):
     cp, prm = params(**kw)
-    pman, S, B, kf, rnd, bi = setup(seed)
+    pman, S, B, kf, rnd, bi = setup(seed, bh_hsml=bh_hsml)
     P = pman.Base
     n, ngas, nbh = len(P), len(S), len(B)
     ids = np.ascontiguousarray(P["ID"])
@@ -138,6 +138,14 @@ def test_kinetic_feedback(ctx):
     assert kicked.sum() > 20
     rel = f["B"]["KineticFdbkEnergy"][(ke == 2) & (a["ow"]["BH_SwallowID"] == 0)]
     assert len(rel) > 0 and (rel == 0).all()
+
+
+def test_large_kernels_overflow_the_lane_lists(ctx):
+    """black holes with ~400-700 neighbours: the per-lane neighbour lists (256 entries) are flushed in the middle of the walk"""
+    a, f = run_both(ctx, 8, bh_hsml=2.0, BH_DRAG=1)
+    check_accretion(a)
+    check_feedback(f)
+    assert (a["ow"]["MgasEnc"] == 0).all() and (a["ow"]["SPH_SwallowID"] != 0).sum() > 50
 
 
 def test_bh_walk_argument_errors(ctx):

@@ -19,7 +19,7 @@ import metal_return as omr  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def setup(seed, ngrid=14, nstar=300, nq=120):
+def setup(seed, ngrid=14, nstar=300, nq=120, hscale=1.0):
     rng = np.random.default_rng(seed)
     ngas = ngrid**3
     sp = cm.BOX / ngrid
@@ -39,7 +39,7 @@ def setup(seed, ngrid=14, nstar=300, nq=120):
     P["Pos"], P["Type"] = pos, types
     P["Mass"] = rng.uniform(0.8, 1.2, n).astype(np.float32)
     P["ID"] = np.arange(n) + 1
-    P["Hsml"] = sp * rng.uniform(1.0, 2.0, n)
+    P["Hsml"] = sp * rng.uniform(1.0, 2.0, n) * hscale
     isgas, isstar = types == 0, types == 4
     P["PI"][isgas] = rng.permutation(ngas)
     P["PI"][isstar] = rng.permutation(nstar)
@@ -59,9 +59,11 @@ def setup(seed, ngrid=14, nstar=300, nq=120):
     return pman, S, queue, starvol, massgen, metalgen, species
 
 
-@pytest.mark.parametrize("sphw,kt", [(1, 1), (0, 1), (1, 2), (1, 4)])
-def test_metal_return_equals_serial_loop(ctx, sphw, kt):
-    pman, S, queue, starvol, massgen, metalgen, species = setup(5 + kt + sphw)
+@pytest.mark.parametrize("sphw,kt,hscale", [(1, 1, 1.0), (0, 1, 1.0), (1, 2, 1.0), (1, 4, 1.0), (0, 1, 2.4)])
+def test_metal_return_equals_serial_loop(ctx, sphw, kt, hscale):
+    pman, S, queue, starvol, massgen, metalgen, species = setup(5 + kt + sphw, hscale=hscale)
+    if hscale > 1:
+        starvol = starvol * hscale**3                         # more neighbours share the same return
     P = pman.Base
     tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
     oP, oS = P.copy(), S.copy()
@@ -98,7 +100,9 @@ def test_metal_return_equals_serial_loop(ctx, sphw, kt):
     vol1 = P["Mass"][gas] / S["Density"][pi]
     assert np.abs(vol1 / vol0 - 1).max() < 5e-7
     heavy = gas & (P0["Mass"] == np.float32(3.9))
-    assert (P["Mass"][heavy] <= 4.0).all() and (P["Mass"][heavy] == P0["Mass"][heavy]).any() and (P["Mass"][heavy] > P0["Mass"][heavy]).any()
+    assert (P["Mass"][heavy] <= 4.0).all() and (P["Mass"][heavy] > P0["Mass"][heavy]).any()
+    if hscale == 1:
+        assert (P["Mass"][heavy] == P0["Mass"][heavy]).any()      # some refused a return that would have lifted them over MaxGasMass
     # untouched: everything that is not gas
     assert np.array_equal(P["Mass"][~gas], P0["Mass"][~gas])
 

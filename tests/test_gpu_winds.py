@@ -32,7 +32,7 @@ def params(**kw):
     return p, SimpleNamespace(**d)
 
 
-def setup(seed, ngrid=16, nstar=400, nnew=60):
+def setup(seed, ngrid=16, nstar=400, nnew=60, hscale=1.0):
     rng = np.random.default_rng(seed)
     ngas = ngrid**3
     sp = cm.BOX / ngrid
@@ -53,7 +53,7 @@ def setup(seed, ngrid=16, nstar=400, nnew=60):
     P["Mass"] = rng.uniform(0.8, 1.2, n).astype(np.float32)
     P["ID"] = rng.permutation(n).astype(np.uint64) + 7
     P["Vel"] = rng.normal(size=(n, 3)) * 30
-    P["Hsml"] = sp * rng.uniform(1.0, 2.2, n)
+    P["Hsml"] = sp * rng.uniform(1.0, 2.2, n) * hscale
     isgas, isstar = types == 0, types == 4
     P["PI"][isgas] = rng.permutation(ngas)
     P["PI"][isstar] = rng.permutation(nstar)
@@ -74,9 +74,9 @@ def setup(seed, ngrid=16, nstar=400, nnew=60):
     return pman, S, ST, rnd, np.ascontiguousarray(rng.permutation(new))
 
 
-def run_both(ctx, seed, **kw):
+def run_both(ctx, seed, hscale=1.0, **kw):
     cp, prm = params(**kw)
-    pman, S, ST, rnd, new = setup(seed)
+    pman, S, ST, rnd, new = setup(seed, hscale=hscale)
     P = pman.Base
     ids = np.ascontiguousarray(P["ID"])
     tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
@@ -122,6 +122,12 @@ def test_fixed_efficiency_winds_with_thermal_energy(ctx):
     assert r.applied > 20 and (r.S["Entropy"][pi] > r.S0["Entropy"][pi]).all() and np.array_equal(r.S["DelayTime"], r.S0["DelayTime"])
     dv = np.sqrt(((r.P["Vel"][kicked] - r.P0["Vel"][kicked]) ** 2).sum(axis=1))
     assert np.allclose(dv, 350.0 * 0.2, rtol=1e-12)
+
+
+def test_large_kernels_overflow_the_lane_lists(ctx):
+    """stars with up to ~700 gas neighbours: the per-lane lists are flushed in the middle of both walks"""
+    r = run_both(ctx, 4, hscale=2.6, WindEfficiency=30.0, WindModel=ow.WIND_FIXED_EFFICIENCY + ow.WIND_DECOUPLE_SPH)
+    assert r.tw[r.P["PI"][r.new]].max() > 300 and r.applied > 20
 
 
 def test_subgrid_model_and_errors(ctx):
