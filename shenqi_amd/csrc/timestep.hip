@@ -200,10 +200,37 @@ __device__ double dynfric_dloga(long long i, long long k, const TsArgs &a)
     return dt * p.hubble;
 }
 
+/* Tallies of the lanes that are active here, into the workgroup's LDS copy of the result slots.  One atomic per distinct slot and
+ * wave instead of one per lane: 64 lanes adding to the same LDS word serialise (that was 2 of the kernel's 2.3 ms at 256^3). */
+__device__ __forceinline__ void tally_add1(unsigned long long *out, int slot)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(1);
+    while(todo) {
+        const int leader = __ffsll((long long) todo) - 1;
+        const int ls = __shfl(slot, leader);
+        const unsigned long long same = __ballot(slot == ls);
+        if(lane == leader)
+            atomicAdd(&out[ls], (unsigned long long) __popcll(same));
+        todo &= ~same;
+    }
+}
+/* most lanes find the slot already at or beyond their value: a plain read first */
+__device__ __forceinline__ void tally_min(unsigned long long *out, int slot, long long v)
+{
+    if(v < (long long) ((volatile unsigned long long *) out)[slot])
+        atomicMin((long long *) &out[slot], v);
+}
+__device__ __forceinline__ void tally_max(unsigned long long *out, int slot, long long v)
+{
+    if(v > (long long) ((volatile unsigned long long *) out)[slot])
+        atomicMax((long long *) &out[slot], v);
+}
+
 __device__ __forceinline__ void count_titype(int titype, unsigned long long *out)
 {
     const int slot = titype == TI_ACCEL ? O_ACCEL : titype == TI_COURANT ? O_COURANT : titype == TI_ACCRETE ? O_ACCRETE : titype == TI_NEIGH ? O_NEIGH : O_HSML;
-    atomicAdd(&out[slot], 1ull);
+    tally_add1(out, slot);
 }
 
 /* MODE 0 find_timesteps, 1 find_hydro_timesteps, 2 hierarchical first loop, 3 hierarchical refinement, 4 find_global_timestep.
@@ -246,7 +273,7 @@ __device__ void timestep_body(const TsArgs &a, const long long t)
                 if(dloga_hydro < dloga)
                     dloga = dloga_hydro;
                 dti = convert_timestep_to_ti(dloga, p.dti_max, p);
-                atomicMin((long long *) &a.out[O_DTIMIN], dti);
+                tally_min(a.out, O_DTIMIN, dti);
             }
             if(dti <= 1 || dti > TIMEBASE)
                 atomicAdd(&a.out[O_NBADBIN], 1ull);
@@ -262,8 +289,8 @@ __device__ void timestep_body(const TsArgs &a, const long long t)
             a.bin_hydro[i] = (uint8_t) bin;
             a.bin_grav[i] = (uint8_t) bin;
         }
-        atomicMin((long long *) &a.out[O_MIN], (long long) bin);
-        atomicMax((long long *) &a.out[O_MAX], (long long) bin);
+        tally_min(a.out, O_MIN, (long long) bin);
+        tally_max(a.out, O_MAX, (long long) bin);
     } else if(MODE == 1) {
         if(type != 0 && type != 5)
             return;
@@ -283,7 +310,7 @@ __device__ void timestep_body(const TsArgs &a, const long long t)
         count_titype(titype, a.out);
         if(timebin_active(a.bin_hydro[i], Ti) && timebin_active(bin_hydro, Ti))
             a.bin_hydro[i] = (uint8_t) bin_hydro;
-        atomicMin((long long *) &a.out[O_MIN], (long long) bin_hydro);
+        tally_min(a.out, O_MIN, (long long) bin_hydro);
         if(type == 5 && a.bh_pidx) {
             const long long k = shq_bh_ordinal(a.bh_pidx, a.nbh, (int32_t) i);
             if(k >= 0) {
@@ -310,7 +337,7 @@ __device__ void timestep_body(const TsArgs &a, const long long t)
         int bin = timestep_bin(dti_gravity);
         if(bin > a.largest_active)
             bin = a.largest_active;
-        atomicAdd(&a.out[O_COUNTS + bin], 1ull);
+        tally_add1(a.out, O_COUNTS + bin);
         a.bin_grav[i] = (uint8_t) bin;
     } else if(MODE == 3) {
         const double dloga_gravity = gravity_dloga(a.accel + 3 * i, a.gravpm + 3 * i, p);
@@ -331,6 +358,8 @@ __device__ void timestep_body(const TsArgs &a, const long long t)
 __device__ __forceinline__ bool slot_is_min(int k) { return k == O_MIN || k == O_DTIMIN; }
 __device__ __forceinline__ bool slot_is_max(int k) { return k == O_MAX || k == O_MAXDYN; }
 
+inline unsigned ts_grid(long long nt) { const unsigned b = nblk(nt); return b < 2048u ? b : 2048u; }
+
 template <int MODE>
 __global__ __launch_bounds__(256) void timestep_kernel(TsArgs a)
 {
@@ -340,8 +369,9 @@ __global__ __launch_bounds__(256) void timestep_kernel(TsArgs a)
     __syncthreads();
     unsigned long long *const gout = a.out;
     a.out = sh;
-    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if(t < a.nt)
+    /* a few thousand workgroups stride over the targets: every workgroup ends with a handful of atomics on the same few global
+     * words, and 65 536 workgroups' worth of those serialise in the L2 (that, not the loop, was the kernel's 2.3 ms at 256^3) */
+    for(long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x; t < a.nt; t += (long long) gridDim.x * blockDim.x)
         timestep_body<MODE>(a, t);
     __syncthreads();
     for(int k = threadIdx.x; k < O_END; k += blockDim.x) {
@@ -546,7 +576,7 @@ extern "C" int shq_find_timesteps(shq_context *ctx, const shq_timestep_params *p
     SHQ_TRY(fill_args(ctx, p, active, nactive, 0, a, "find_timesteps"));
     a.dti_min_global = dti_min_global;
     if(a.nt > 0) {
-        timestep_kernel<0><<<dim3(nblk(a.nt)), dim3(256), 0, ctx->stream>>>(a);
+        timestep_kernel<0><<<dim3(ts_grid(a.nt)), dim3(256), 0, ctx->stream>>>(a);
         SHQ_HIP(hipGetLastError());
     }
     shq_timestep_result r;
@@ -565,7 +595,7 @@ extern "C" int shq_find_global_timestep(shq_context *ctx, const shq_timestep_par
     TsArgs a;
     SHQ_TRY(fill_args(ctx, p, nullptr, 0, 0, a, "find_global_timestep"));
     if(a.nt > 0) {
-        timestep_kernel<4><<<dim3(nblk(a.nt)), dim3(256), 0, ctx->stream>>>(a);
+        timestep_kernel<4><<<dim3(ts_grid(a.nt)), dim3(256), 0, ctx->stream>>>(a);
         SHQ_HIP(hipGetLastError());
     }
     return fetch(ctx, res);
@@ -577,7 +607,7 @@ extern "C" int shq_find_hydro_timesteps(shq_context *ctx, const shq_timestep_par
     TsArgs a;
     SHQ_TRY(fill_args(ctx, p, active, nactive, 0, a, "find_hydro_timesteps"));
     if(a.nt > 0) {
-        timestep_kernel<1><<<dim3(nblk(a.nt)), dim3(256), 0, ctx->stream>>>(a);
+        timestep_kernel<1><<<dim3(ts_grid(a.nt)), dim3(256), 0, ctx->stream>>>(a);
         SHQ_HIP(hipGetLastError());
     }
     shq_timestep_result r;
@@ -612,7 +642,7 @@ extern "C" int shq_hier_gravity_bins(shq_context *ctx, const shq_timestep_params
     SHQ_TRY(fill_args(ctx, p, active, nactive, from_accel_store, a, "hier_gravity_bins"));
     a.largest_active = largest_active;
     if(a.nt > 0) {
-        timestep_kernel<2><<<dim3(nblk(a.nt)), dim3(256), 0, ctx->stream>>>(a);
+        timestep_kernel<2><<<dim3(ts_grid(a.nt)), dim3(256), 0, ctx->stream>>>(a);
         SHQ_HIP(hipGetLastError());
     }
     return fetch(ctx, res);
@@ -642,7 +672,7 @@ extern "C" int shq_hier_refine(shq_context *ctx, const shq_timestep_params *p, c
     SHQ_TRY(fill_args(ctx, p, active, nactive, from_accel_store, a, "hier_refine"));
     a.ti = ti;
     if(a.nt > 0) {
-        timestep_kernel<3><<<dim3(nblk(a.nt)), dim3(256), 0, ctx->stream>>>(a);
+        timestep_kernel<3><<<dim3(ts_grid(a.nt)), dim3(256), 0, ctx->stream>>>(a);
         SHQ_HIP(hipGetLastError());
     }
     return fetch(ctx, res);

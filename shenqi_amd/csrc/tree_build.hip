@@ -1230,7 +1230,9 @@ __global__ void dom_topleaf_kernel(long long n, const double4 *__restrict__ posm
         }
         tl = geo.kind[t].y;
         topleaf[i] = tl;
-        atomicAdd(nchanged, 1ull);
+        const unsigned long long movers = __ballot(1); /* one atomic per wave: millions of adds to one word serialise in the L2 */
+        if((int) (threadIdx.x & 63) == __ffsll((long long) movers) - 1)
+            atomicAdd(nchanged, (unsigned long long) __popcll(movers));
     }
     if(target)
         target[i] = (tl >= 0 && tl < ntopleaves) ? leaftask[tl] : -1;
