@@ -942,9 +942,9 @@ int shq_bh_feedback(shq_context *ctx, const shq_tree_view *tree, const shq_part_
 /* winds_and_feedback() (libgadget/winds.cpp:295-369): the two asymmetric walks over the gas tree for the new
  * stars of the step — sfr_wind_weight_ngbiter (:411-447: mass of the gas inside the star's Hsml that is not already a wind particle,
  * into TotalWeight[star slot]) and sfr_wind_feedback_ngbiter (:510-565: a gas particle becomes a kick candidate when
- * Table[(star ID + gas ID) % size] < windeff Mass / TotalWeight, with get_wind_params, :489-507) — then the reference's own resolution on
- * the host: the candidates sorted by (particle, distance, star ID), the first of every particle kicks (wind_do_kick, :449-471: Vel along
- * get_wind_dir, Entropy += therm / enttou, DelayTime when winds decouple), in the caller's arrays.  WindModel carries the reference's
+ * Table[(star ID + gas ID) % size] < windeff Mass / TotalWeight, with get_wind_params, :489-507) — then the reference's resolution:
+ * the candidates sorted by (particle, distance, star ID), the first of every particle kicks (wind_do_kick, :449-471: Vel along
+ * get_wind_dir, Entropy += therm / enttou, DelayTime when winds decouple); the results go into the caller's arrays.  WindModel carries the reference's
  * flag bits (WIND_DECOUPLE_SPH 2, WIND_USE_HALO 4, WIND_FIXED_EFFICIENCY 8); the subgrid model (bit 1) does nothing here, as there.
  * `tree` is the gas tree; the star view gives STARP.VDisp (float).  `kicks` (may be NULL) receives the sorted candidate list. */
 typedef struct shq_wind_params {

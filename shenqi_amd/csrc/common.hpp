@@ -505,6 +505,7 @@ struct WindWalkArgs {
     shq_wind_params P;
 };
 int shq_wind_walk_device(shq_context *ctx, const WindWalkArgs *w, const int32_t *d_queue, int64_t nq, bool kick);
+int shq_wind_resolve_device(shq_context *ctx, const WindWalkArgs *w, long long nk, shq_wind_kick *d_sorted, unsigned long long *d_napplied, int *d_odd);
 /* metal return (sph.hip) */
 #define SHQ_NMETALS 9
 struct MetalWalkArgs {

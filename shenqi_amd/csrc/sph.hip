@@ -3132,6 +3132,39 @@ __global__ __launch_bounds__(256) void bh_feedback_kernel(const SphDev a, const 
     } /* task loop */
 }
 
+/* blackhole_feedback_postprocess (:929-965), one thread per hole of the feedback queue; out[t] = accreted mass, accreted black-hole
+ * mass, momentum[3], progenitors, minTimeBin from the walk */
+__global__ void bh_feedback_post_kernel(long long nq, const int32_t *queue, const BhWalkArgs w, double4 *posm)
+{
+#pragma clang fp contract(off)
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= nq)
+        return;
+    const long long n = queue[t];
+    const long long b = shq_bh_ordinal(w.bhp, w.nbh, (int32_t) n);
+    BhRec &B = w.bh[b];
+    const double *o = w.out + BH_FB_NOUT * t;
+    B.CountProgs += (int32_t) o[5];
+    if(o[1] > 0)
+        B.Mass += o[1];
+    if(o[0] > 0) {
+        const double accmass = o[0];
+        const float pm = (float) posm[n].w;
+        for(int k = 0; k < 3; k++)
+            w.velw[3 * n + k] = (w.velw[3 * n + k] * pm + o[2 + k]) / (pm + accmass);
+        const double SeedBHDynMass = w.P.SeedBHDynMass;
+        if(SeedBHDynMass > 0 && B.Mtrack + accmass < SeedBHDynMass)
+            B.Mtrack += accmass;
+        else if(B.Mtrack < SeedBHDynMass) {
+            posm[n].w = (double) (float) (B.Mtrack + accmass);
+            B.Mtrack = SeedBHDynMass;
+        } else
+            posm[n].w = (double) (float) (pm + accmass);
+    }
+    if(B.KEflag == 2)
+        B.KineticFdbkEnergy = 0;
+}
+
 static int bh_launch_prep(shq_context *ctx, const shq_kick_factors *kf)
 {
     SHQ_TRY(shq_sph_prepare(ctx, kf, nullptr, nullptr)); /* SPH_VelPred of every gas particle, Hsml in leaf order */
@@ -3184,6 +3217,8 @@ int shq_bh_feedback_device(shq_context *ctx, const shq_kick_factors *kf, const B
     case 2: bh_feedback_kernel<2><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, *kf, ctx->s_nlist2.ptr, ntasks); break;
     default: bh_feedback_kernel<4><<<dim3(grid), dim3(256), 0, st>>>(a, d_queue, nq, *w, *kf, ctx->s_nlist2.ptr, ntasks); break;
     }
+    SHQ_HIP(hipGetLastError());
+    bh_feedback_post_kernel<<<dim3(nblk(nq)), dim3(256), 0, st>>>(nq, d_queue, *w, ctx->posm.ptr);
     SHQ_HIP(hipGetLastError());
     return SHQ_OK;
 }
@@ -3292,6 +3327,88 @@ __global__ __launch_bounds__(256) void wind_walk_kernel(const SphDev a, const in
             atomicAdd(w.nvisited, (unsigned long long) visited);
     }
     } /* task loop */
+}
+
+/* the StarKick resolution (winds.cpp:330-350) on the device: the candidates sorted by (particle, distance, star ID) — three stable
+ * radix sorts, least significant key first — then the first candidate of every particle kicks: wind_do_kick + get_wind_dir, :449-487 */
+__global__ void wind_kick_keys_kernel(long long n, const shq_wind_kick *k, int which, unsigned long long *keys, int32_t *idx, const int32_t *order)
+{
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= n)
+        return;
+    const int32_t j = order ? order[t] : (int32_t) t;
+    const shq_wind_kick &K = k[j];
+    keys[t] = which == 0 ? K.StarID : (which == 1 ? (unsigned long long) __double_as_longlong(K.StarDistance) /* >= 0: bits order like values */
+                                                   : (unsigned long long) (unsigned) K.part_index);
+    idx[t] = j;
+}
+
+__global__ void wind_kick_gather_kernel(long long n, const shq_wind_kick *k, const int32_t *order, shq_wind_kick *out)
+{
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t < n)
+        out[t] = k[order[t]];
+}
+
+__global__ void wind_do_kick_kernel(long long n, const shq_wind_kick *k, const WindWalkArgs w, double *vel, double *entropy, const double *density, double *delay,
+                                    unsigned long long *napplied, int *odd)
+{
+#pragma clang fp contract(off)
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= n)
+        return;
+    const shq_wind_kick K = k[t];
+    if(t > 0 && k[t - 1].part_index == K.part_index)
+        return; /* "Only do the kick for the first particle, which is the closest" */
+    const long long other = K.part_index;
+    const unsigned long long id = w.ids[other];
+    const double theta = acos(2 * w.rnd[(id + 3) % w.rndsize] - 1);
+    const double phi = 2 * M_PI * w.rnd[(id + 4) % w.rndsize];
+    const double dir[3] = {sin(theta) * cos(phi), sin(theta) * sin(phi), cos(theta)};
+    const double v = K.StarKickVelocity, atime = w.P.Time;
+    if(v > 0 && atime > 0) {
+        for(int j = 0; j < 3; j++)
+            vel[3 * other + j] += v * dir[j];
+        const double enttou = pow(density[other] / pow(atime, 3), SPH_GAMMA_MINUS1) / SPH_GAMMA_MINUS1;
+        entropy[other] += K.StarTherm / enttou;
+        if((w.P.WindModel & 2) && w.P.MaxWindFreeTravelTime > 0) { /* winds_ever_decouple */
+            double d = w.P.WindFreeTravelLength / (v / atime);
+            if(d > w.P.MaxWindFreeTravelTime)
+                d = w.P.MaxWindFreeTravelTime;
+            delay[other] = d;
+        }
+    }
+    if(!(v > 0) || !isfinite(v) || !isfinite(delay[other]))
+        *odd = 1; /* "Odd v", winds.cpp:344 */
+    atomicAdd(napplied, 1ull);
+}
+
+int shq_wind_resolve_device(shq_context *ctx, const WindWalkArgs *w, long long nk, shq_wind_kick *d_sorted, unsigned long long *d_napplied, int *d_odd)
+{
+    if(nk == 0)
+        return SHQ_OK;
+    hipStream_t st = ctx->stream;
+    SHQ_TRY(ctx->metal_keys[0].reserve((size_t) nk));
+    SHQ_TRY(ctx->metal_keys[1].reserve((size_t) nk));
+    SHQ_TRY(ctx->s_queue2.reserve((size_t) nk));
+    SHQ_TRY(ctx->s_queue3.reserve((size_t) nk));
+    int32_t *ord[2] = {ctx->s_queue2.ptr, ctx->s_queue3.ptr};
+    const int32_t *cur = nullptr;
+    for(int which = 0; which < 3; which++) {
+        wind_kick_keys_kernel<<<dim3(nblk(nk)), dim3(256), 0, st>>>(nk, w->kicks, which, ctx->metal_keys[0].ptr, ord[0], cur);
+        SHQ_HIP(hipGetLastError());
+        size_t tmp = 0;
+        SHQ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, ctx->metal_keys[0].ptr, ctx->metal_keys[1].ptr, ord[0], ord[1], (size_t) nk, 0, 64, st));
+        SHQ_TRY(ctx->hydrec_leaf.reserve(tmp + 16));
+        SHQ_HIP(rocprim::radix_sort_pairs(ctx->hydrec_leaf.ptr, tmp, ctx->metal_keys[0].ptr, ctx->metal_keys[1].ptr, ord[0], ord[1], (size_t) nk, 0, 64, st));
+        cur = ord[1];
+        std::swap(ord[0], ord[1]); /* the next pass writes its identity-permuted indices over the old input */
+    }
+    wind_kick_gather_kernel<<<dim3(nblk(nk)), dim3(256), 0, st>>>(nk, w->kicks, cur, d_sorted);
+    SHQ_HIP(hipGetLastError());
+    wind_do_kick_kernel<<<dim3(nblk(nk)), dim3(256), 0, st>>>(nk, d_sorted, *w, ctx->vel.ptr, ctx->g_entropy.ptr, ctx->g_density.ptr, ctx->g_delaytime.ptr, d_napplied, d_odd);
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
 }
 
 int shq_wind_walk_device(shq_context *ctx, const WindWalkArgs *w, const int32_t *d_queue, int64_t nq, bool kick)

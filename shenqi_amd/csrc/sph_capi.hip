@@ -1229,38 +1229,32 @@ extern "C" int shq_bh_feedback(shq_context *ctx, const shq_tree_view *tree, cons
             nbhs++;
         }
     }
-    /* blackhole_feedback_reduce (PRIMARY) + blackhole_feedback_postprocess (:912-965) */
+    /* blackhole_feedback_reduce (PRIMARY); blackhole_feedback_postprocess (:929-965) ran on the device: its results come back */
+    std::vector<double4> hposm((size_t) std::max<int64_t>(n, 1));
+    if(nq) {
+        SHQ_HIP(hipMemcpyAsync(S.rec.data(), ctx->bhw_rec.ptr, sizeof(BhRec) * nbh, hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipMemcpyAsync(hposm.data(), ctx->posm.ptr, sizeof(double4) * (size_t) n, hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipStreamSynchronize(st));
+    }
     for(int64_t t = 0; t < nq; t++) {
         const int32_t i = q[t];
         const size_t b = (size_t) (std::lower_bound(S.bhp.begin(), S.bhp.end(), i) - S.bhp.begin());
         const int32_t pi = S.pi[b];
         const double *o = &out[8 * (size_t) t];
+        const BhRec &R = S.rec[b];
         work->BH_accreted_Mass[pi] = o[0];
         work->BH_accreted_BHMass[pi] = o[1];
         for(int d = 0; d < 3; d++)
             work->BH_accreted_momentum[pi][d] = o[2 + d];
         *bhfield<uint8_t>(bh, pi, bh->off_mintimebin) = (uint8_t) o[6];
-        *bhfield<int32_t>(bh, pi, bh->off_countprogs) += (int32_t) o[5];
-        if(o[1] > 0)
-            *bhfield<double>(bh, pi, bh->off_mass) += o[1];
-        if(o[0] > 0) {
-            const double accmass = o[0];
-            double *v = pfield_w<double>(parts, i, parts->off_vel);
-            float *pm = pfield_w<float>(parts, i, parts->off_mass);
-            double *mtrack = bhfield<double>(bh, pi, bh->off_mtrack);
-            for(int d = 0; d < 3; d++)
-                v[d] = (v[d] * *pm + o[2 + d]) / (*pm + accmass);
-            const double SeedBHDynMass = params->SeedBHDynMass;
-            if(SeedBHDynMass > 0 && *mtrack + accmass < SeedBHDynMass)
-                *mtrack += accmass;
-            else if(*mtrack < SeedBHDynMass) {
-                *pm = (float) (*mtrack + accmass);
-                *mtrack = SeedBHDynMass;
-            } else
-                *pm = (float) (*pm + accmass);
-        }
-        if(work->KEflag && work->KEflag[pi] == 2)
-            *bhfield<double>(bh, pi, bh->off_kineticfdbkenergy) = 0;
+        *bhfield<int32_t>(bh, pi, bh->off_countprogs) = R.CountProgs;
+        *bhfield<double>(bh, pi, bh->off_mass) = R.Mass;
+        *bhfield<double>(bh, pi, bh->off_mtrack) = R.Mtrack;
+        *bhfield<double>(bh, pi, bh->off_kineticfdbkenergy) = R.KineticFdbkEnergy;
+        double *v = pfield_w<double>(parts, i, parts->off_vel);
+        for(int d = 0; d < 3; d++)
+            v[d] = vel[3 * (size_t) i + d];
+        *pfield_w<float>(parts, i, parts->off_mass) = (float) hposm[(size_t) i].w;
     }
     if(n_sph_swallowed)
         *n_sph_swallowed = nsph;
@@ -1345,55 +1339,44 @@ extern "C" int shq_winds_and_feedback(shq_context *ctx, const shq_tree_view *tre
     SHQ_HIP(hipMemcpyAsync(cnt, ctx->wind_cnt.ptr, sizeof(cnt), hipMemcpyDeviceToHost, st));
     SHQ_HIP(hipStreamSynchronize(st));
     SHQ_CHECK(cnt[1] <= maxkicks, SHQ_ERR_STATE, "Not enough room in kick queue: %llu > %llu (winds.cpp:552)", cnt[1], maxkicks);
-    std::vector<shq_wind_kick> K((size_t) cnt[1]);
-    if(cnt[1])
-        SHQ_HIP(hipMemcpy(K.data(), ctx->wind_kicks.ptr, sizeof(shq_wind_kick) * K.size(), hipMemcpyDeviceToHost));
-    /* StarKick::operator< (:189-207): by particle, then distance, then star ID */
-    std::sort(K.begin(), K.end(), [](const shq_wind_kick &a, const shq_wind_kick &b) {
-        if(a.part_index != b.part_index)
-            return a.part_index < b.part_index;
-        if(a.StarDistance != b.StarDistance)
-            return a.StarDistance < b.StarDistance;
-        return a.StarID < b.StarID;
-    });
+    const long long nk = (long long) cnt[1];
     if(nkicks)
-        *nkicks = (int64_t) K.size();
-    if(kicks) {
-        SHQ_CHECK(kicks_capacity >= (int64_t) K.size(), SHQ_ERR_INVALID, "winds_and_feedback: room for %ld kicks, %ld found", (long) kicks_capacity, (long) K.size());
-        if(!K.empty())
-            memcpy(kicks, K.data(), sizeof(shq_wind_kick) * K.size());
-    }
-    const bool decouple = (params->WindModel & 2) && params->MaxWindFreeTravelTime > 0; /* winds_ever_decouple */
-    int64_t last = -1, applied = 0;
-    for(const shq_wind_kick &k : K) {
-        if(k.part_index == last)
-            continue;
-        const int32_t other = k.part_index;
-        last = other;
-        applied++;
-        /* wind_do_kick, :449-471 */
-        const uint64_t id = ids[other];
-        const double theta = acos(2 * rnd_table[(id + 3) % (uint64_t) rnd_size] - 1);
-        const double phi = 2 * M_PI * rnd_table[(id + 4) % (uint64_t) rnd_size];
-        const double dir[3] = {sin(theta) * cos(phi), sin(theta) * sin(phi), cos(theta)};
-        const double vel = k.StarKickVelocity, atime = params->Time;
-        const int32_t pi = *pfield<int32_t>(parts, other, parts->off_pi);
-        if(vel > 0 && atime > 0) {
+        *nkicks = nk;
+    if(kicks)
+        SHQ_CHECK(kicks_capacity >= nk, SHQ_ERR_INVALID, "winds_and_feedback: room for %ld kicks, %ld found", (long) kicks_capacity, (long) nk);
+    int64_t applied = 0;
+    if(nk > 0) {
+        /* the candidates sorted with StarKick's comparison, the first of every particle kicks: on the device, into the resident
+         * Vel / Entropy / DelayTime, which then go back into the caller's arrays */
+        SHQ_TRY(ctx->bhw_rec.reserve((size_t) nk * sizeof(shq_wind_kick)));
+        shq_wind_kick *d_sorted = reinterpret_cast<shq_wind_kick *>(ctx->bhw_rec.ptr);
+        SHQ_HIP(hipMemsetAsync(ctx->wind_cnt.ptr + 2, 0, sizeof(unsigned long long) * 2, st));
+        SHQ_TRY(shq_wind_resolve_device(ctx, &w, nk, d_sorted, ctx->wind_cnt.ptr + 2, reinterpret_cast<int *>(ctx->wind_cnt.ptr + 3)));
+        unsigned long long res[2] = {0, 0};
+        SHQ_HIP(hipMemcpyAsync(res, ctx->wind_cnt.ptr + 2, sizeof(res), hipMemcpyDeviceToHost, st));
+        std::vector<shq_wind_kick> K((size_t) nk);
+        SHQ_HIP(hipMemcpyAsync(K.data(), d_sorted, sizeof(shq_wind_kick) * (size_t) nk, hipMemcpyDeviceToHost, st));
+        std::vector<double> hv(3 * (size_t) n), he((size_t) n), hdl((size_t) n);
+        SHQ_HIP(hipMemcpyAsync(hv.data(), ctx->vel.ptr, sizeof(double) * 3 * (size_t) n, hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipMemcpyAsync(he.data(), ctx->g_entropy.ptr, sizeof(double) * (size_t) n, hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipMemcpyAsync(hdl.data(), ctx->g_delaytime.ptr, sizeof(double) * (size_t) n, hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipStreamSynchronize(st));
+        applied = (int64_t) res[0];
+        if(kicks)
+            memcpy(kicks, K.data(), sizeof(shq_wind_kick) * (size_t) nk);
+        int32_t last = -1;
+        for(const shq_wind_kick &k : K) { /* only the kicked particles changed */
+            if(k.part_index == last)
+                continue;
+            const int32_t other = last = k.part_index;
+            const int32_t pi = *pfield<int32_t>(parts, other, parts->off_pi);
             double *v = pfield_w<double>(parts, other, parts->off_vel);
             for(int j = 0; j < 3; j++)
-                v[j] += vel * dir[j];
-            const double gm1 = 5.0 / 3 - 1; /* GAMMA_MINUS1, physconst.h */
-            const double enttou = pow(*sfield(sph, pi, sph->off_density) / pow(atime, 3), gm1) / gm1;
-            *sfield(sph, pi, sph->off_entropy) += k.StarTherm / enttou;
-            if(decouple) {
-                double delay = params->WindFreeTravelLength / (vel / atime);
-                if(delay > params->MaxWindFreeTravelTime)
-                    delay = params->MaxWindFreeTravelTime;
-                *sfield(sph, pi, sph->off_delaytime) = delay;
-            }
+                v[j] = hv[3 * (size_t) other + j];
+            *sfield(sph, pi, sph->off_entropy) = he[(size_t) other];
+            *sfield(sph, pi, sph->off_delaytime) = hdl[(size_t) other];
         }
-        SHQ_CHECK(vel > 0 && std::isfinite(vel) && std::isfinite(*sfield(sph, pi, sph->off_delaytime)), SHQ_ERR_STATE, "Odd v: other = %d, v = %g (winds.cpp:344)", other,
-                  vel);
+        SHQ_CHECK((int) (res[1] & 0xffffffffull) == 0, SHQ_ERR_STATE, "Odd v in a wind kick (winds.cpp:344)");
     }
     if(nkicked)
         *nkicked = applied;
