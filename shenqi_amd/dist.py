@@ -933,3 +933,118 @@ class GpuFofOps:
         ng = C.c_int64()
         capi.check(capi.hip.shq_fof(self.ctx.h, C.byref(fp), capi.ptr(idarr), capi.ptr(out), None, C.byref(ng)))
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Particle exchange between ranks on full records: ExchangePlan::domain_exchange
+# (libgadget/exchange.hpp:242-333) with the loops on the device (shq_exchange_plan / _pack / _unpack, shq_slots_gc) and the
+# collectives through Comm — RCCL when the group is nccl, so the payloads cross xGMI from device buffer to device buffer.
+class DistExchange:
+    """One rank of a domain exchange.  parts: device uint8 tensor of MaxPart records (layout.part_elsize bytes each), slots: per type a
+    device uint8 tensor of slot records or None; layoutfn(parts, numpart) -> device int32 tensor with one target task per particle
+    (ExchangePlan::layoutfunc; under shenqi's decomposition what shq_domain_maintain_topleaf writes), evaluated every round as the
+    reference does.  maxlast caps the list entries sent per round (find_iter_space's role); a capped or memory-short round runs the
+    garbage collection between pack and receive (exchange_once, exchange.hpp:398-406, with shall_we_compact_slots)."""
+
+    def __init__(self, comm, ctx, layout):
+        self.comm, self.ctx, self.L = comm, ctx, layout
+        self.rounds = 0
+
+    @staticmethod
+    def _entries(arr):
+        e = (capi.ExchangeEntry * len(arr))()
+        for k, row in enumerate(arr):
+            e[k].base = int(row[0])
+            for t in range(6):
+                e[k].slots[t] = int(row[1 + t])
+        return e
+
+    @staticmethod
+    def _offsets(c):
+        o = np.zeros_like(c)
+        o[1:] = np.cumsum(c[:-1], axis=0)
+        return o
+
+    def _allsum(self, v):
+        """element-wise sum of a small int64 vector over the ranks"""
+        if not self.comm.multi:
+            return np.asarray(v, dtype=np.int64)
+        t = torch.tensor(np.asarray(v, dtype=np.int64))
+        if self.comm.backend == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, group=self.comm.group)
+        return t.cpu().numpy()
+
+    def exchange(self, parts, numpart, slots, slot_size, layoutfn, maxlast=0, maxrounds=10000):
+        comm, L, h = self.comm, self.L, self.ctx.h
+        esz = int(L.part_elsize)
+        maxpart = parts.numel() // esz
+        ssz = [int(L.slot_elsize[t]) for t in range(6)]
+        cap = [0 if slots[t] is None else slots[t].numel() // ssz[t] for t in range(6)]
+        slot_size = [int(x) for x in slot_size]
+        dev = parts.device
+        ntask = comm.size
+        self.rounds = 0
+        sp = (C.c_void_p * 6)(*[None if s is None else s.data_ptr() for s in slots])
+        while True:
+            if self.rounds >= maxrounds:
+                raise RuntimeError("DistExchange: no end after %d rounds" % maxrounds)
+            target = layoutfn(parts, numpart).to(torch.int32).contiguous()
+            tg = (capi.ExchangeEntry * ntask)()
+            nex, last = C.c_int64(), C.c_int64()
+            torch.cuda.current_stream(dev).synchronize()
+            capi.check(capi.hip.shq_exchange_plan(h, C.byref(L), parts.data_ptr(), numpart, target.data_ptr(), comm.rank, ntask, int(maxlast), C.byref(nex),
+                                                  C.byref(last), tg))
+            togo = np.array([[tg[t].base] + list(tg[t].slots) for t in range(ntask)], dtype=np.int64)
+            if int(self._allsum([nex.value])[0]) == 0:          # nobody has anything to send
+                break
+            self.rounds += 1
+            # MPI_Alltoall of the plan (exchange.hpp:217-219)
+            if comm.multi:
+                toget = comm.all_to_all_equal(torch.from_numpy(togo.copy()).to(dev if comm.backend == "nccl" else "cpu")).cpu().numpy()
+            else:
+                toget = togo.copy()
+            soff, goff = self._offsets(togo), self._offsets(toget)
+            nsend, nrecv = togo.sum(axis=0), toget.sum(axis=0)
+            partbuf = torch.empty(max(int(nsend[0]), 1) * esz, dtype=torch.uint8, device=dev)
+            slotbuf = [None if slots[t] is None else torch.empty(max(int(nsend[1 + t]), 1) * ssz[t], dtype=torch.uint8, device=dev) for t in range(6)]
+            bp = (C.c_void_p * 6)(*[None if b is None else b.data_ptr() for b in slotbuf])
+            capi.check(capi.hip.shq_exchange_pack(h, C.byref(L), parts.data_ptr(), sp, maxpart, self._entries(soff), ntask, partbuf.data_ptr(), bp))
+            # shall_we_gc on any task (:398-402), the slot types to compact on any task (shall_we_compact_slots, :300-317)
+            mine = [int(last.value < nex.value or numpart + int(nrecv[0]) > maxpart)]
+            for t in range(6):
+                c = 0
+                if slots[t] is not None and (slot_size[t] + int(nrecv[1 + t]) > 0.95 * cap[t] or int(nsend[1 + t]) > 0.1 * slot_size[t]):
+                    c = 1
+                mine.append(c)
+            glob = self._allsum(mine)
+            if glob[0] > 0:
+                n = C.c_int64(numpart)
+                sz = (C.c_int64 * 6)(*slot_size)
+                compact = (C.c_int * 6)(*[int(glob[1 + t] > 0) for t in range(6)])
+                capi.check(capi.hip.shq_slots_gc(h, C.byref(L), parts.data_ptr(), C.byref(n), maxpart, sp, sz, compact))
+                numpart, slot_size = int(n.value), [int(x) for x in sz]
+            self.ctx.synchronize()
+            if numpart + int(nrecv[0]) > maxpart:
+                raise MemoryError("DistExchange: %d + %d particles do not fit MaxPart %d" % (numpart, int(nrecv[0]), maxpart))
+            # the alltoallv of the base records and of every slot type (:409-480): device buffers, over RCCL when the group is nccl
+            rows, _ = comm.all_to_all_rows(partbuf[:int(nsend[0]) * esz].view(-1, esz), [int(x) for x in togo[:, 0]])
+            parts[numpart * esz:(numpart + int(nrecv[0])) * esz] = rows.reshape(-1)
+            for t in range(6):
+                if slots[t] is None:
+                    continue
+                if slot_size[t] + int(nrecv[1 + t]) > cap[t]:
+                    raise MemoryError("DistExchange: slot array of type %d is full" % t)
+                rows, _ = comm.all_to_all_rows(slotbuf[t][:int(nsend[1 + t]) * ssz[t]].view(-1, ssz[t]), [int(x) for x in togo[:, 1 + t]])
+                slots[t][slot_size[t] * ssz[t]:(slot_size[t] + int(nrecv[1 + t])) * ssz[t]] = rows.reshape(-1)
+            torch.cuda.current_stream(dev).synchronize()
+            so = (C.c_int64 * 6)(*slot_size)
+            capi.check(capi.hip.shq_exchange_unpack(h, C.byref(L), parts.data_ptr(), numpart, so, self._entries(toget), self._entries(goff), ntask))
+            numpart += int(nrecv[0])
+            for t in range(6):
+                if slots[t] is not None:
+                    slot_size[t] += int(nrecv[1 + t])
+            self.ctx.synchronize()
+            if int(self._allsum([int(last.value < nex.value)])[0]) == 0:
+                break
+        return numpart, slot_size

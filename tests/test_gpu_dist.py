@@ -284,3 +284,70 @@ def test_dist_fof_two_gloo_ranks_one_gpu():
                 results.append(pickle.load(f))
         tf.check(results, P, ref)
         assert max(res["rounds"] for res in results) >= 2
+
+
+def _exchange_worker(rank, world, initfile, outdir, maxlast):
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        import pickle
+        import shenqi_amd as sq
+        from shenqi_amd import capi, dist as sd
+        import exchange_fixtures as fx
+        P, numpart, slots, slot_size = fx.setup_task(rank, world, [40, 13, 0, 7, 25, 3], maxpart=256)
+        f = capi.PARTICLE_DTYPE.fields
+        L = capi.ExchangeLayout()
+        L.part_elsize, L.off_flags, L.off_type, L.off_pi = capi.PARTICLE_DTYPE.itemsize, f["Flags"][1], f["Type"][1], f["PI"][1]
+        for t in range(6):
+            L.slot_elsize[t] = 0 if fx.SLOT_DTYPES[t] is None else fx.SLOT_DTYPES[t].itemsize
+        L.off_reverselink = 0
+        esz, idoff = int(L.part_elsize), f["ID"][1]
+        dev = "cuda:0"
+        d_parts = torch.from_numpy(P.view(np.uint8).reshape(-1).copy()).to(dev)
+        d_slots = [None if s is None else torch.from_numpy(s.view(np.uint8).reshape(-1).copy()).to(dev) for s in slots]
+
+        def layoutfn(parts, n):                              # TestExchangePlan::layoutfunc: ID % NTask, on the device records
+            ids = parts.view(-1, esz)[:, idoff:idoff + 8].contiguous().view(torch.int64).reshape(-1)
+            return (ids % world).to(torch.int32)
+        comm = sd.Comm()
+        with sq.Context(0) as ctx:
+            ex = sd.DistExchange(comm, ctx, L)
+            n, sz = ex.exchange(d_parts, numpart, d_slots, slot_size, layoutfn, maxlast=maxlast)
+        with open(os.path.join(outdir, "x%d.pkl" % rank), "wb") as fh:
+            pickle.dump(dict(P=d_parts.cpu().numpy().view(capi.PARTICLE_DTYPE), n=n, sz=sz, rounds=ex.rounds,
+                             S=[None if s is None else s.cpu().numpy().view(fx.SLOT_DTYPES[t]) for t, s in enumerate(d_slots)]), fh)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("maxlast", [0, 9])
+def test_dist_exchange_two_gloo_ranks_one_gpu(maxlast):
+    """DistExchange: the device exchange loops (plan / pack / gc / unpack) with the collectives over a real process group — two ranks
+    sharing the GPU — end in the same particle and slot arrays as the restatement of ExchangePlan::domain_exchange; with a cap of 9
+    list entries per round the same number of rounds, a collection in each"""
+    import pickle
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import exchange as oex
+    import exchange_fixtures as fx
+    world = 2
+    otasks = []
+    for r in range(world):
+        P, numpart, slots, slot_size = fx.setup_task(r, world, [40, 13, 0, 7, 25, 3], maxpart=256)
+        otasks.append(oex.Task(P, numpart, slots, slot_size))
+    lay = [lambda P, n: fx.layout_id_mod(P, n, world)] * world
+    oit = oex.domain_exchange_batched(otasks, lay, maxlast if maxlast else 10**9)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_exchange_worker, args=(world, os.path.join(tmp, "init"), tmp, maxlast), nprocs=world, join=True)
+        out = []
+        for r in range(world):
+            with open(os.path.join(tmp, "x%d.pkl" % r), "rb") as fh:
+                d = pickle.load(fh)
+            o = otasks[r]
+            assert d["n"] == o.numpart and d["sz"] == o.slot_size and d["rounds"] == oit
+            assert all(np.array_equal(d["P"][k][:d["n"]], o.parts[k][:o.numpart]) for k in o.parts.dtype.names)
+            for t in range(6):
+                if o.slots[t] is not None:
+                    assert all(np.array_equal(d["S"][t][k][:d["sz"][t]], o.slots[t][k][:o.slot_size[t]]) for k in o.slots[t].dtype.names), (r, t)
+            out.append((d["P"], d["n"], d["S"], d["sz"]))
+        fx.check_after(out, world, world * 88)
+        assert oit == (1 if maxlast == 0 else oit) and (maxlast == 0 or oit >= 4)
