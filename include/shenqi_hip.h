@@ -968,6 +968,19 @@ int shq_winds_and_feedback(shq_context *ctx, const shq_tree_view *tree, const sh
                            const uint64_t *ids, const int32_t *NewStars, int64_t NumNewStars, const shq_wind_params *params, const double *rnd_table,
                            int64_t rnd_size, double *TotalWeight, shq_wind_kick *kicks, int64_t kicks_capacity, int64_t *nkicks, int64_t *nkicked);
 
+/* The wind model's two particle loops, on the caller's arrays (gas particles of `list`; NULL: all particles, non-gas skipped):
+ *   shq_winds_evolve    winds_evolve (winds.cpp:370-387) as cooling_and_starformation calls it per star-forming gas particle: a wind
+ *                       particle recouples when its physical density has dropped below WindFreeTravelDensThresh, otherwise its
+ *                       DelayTime (capped at MaxWindFreeTravelTime) shrinks by the particle's hydro step dloga_for_bin / hubble.
+ *   shq_winds_subgrid   winds_subgrid + winds_make_after_sf (:272-292, 567-585), the subgrid model (WindModel bit 1; a no-op without
+ *                       it): gas particle list[k] with stellar mass StellarMasses[k] formed this step is kicked (wind_do_kick) when
+ *                       Table[(ID + 2) % size] < 1 - exp(-windeff sm / Mass), with get_wind_params on its SphP.VDisp.  *nkicked counts them.
+ * StellarMasses is indexed like the list here (the reference indexes it by slot). */
+int shq_winds_evolve(shq_context *ctx, const shq_part_view *parts, const shq_sph_view *sph, const int32_t *list, int64_t nlist, double a3inv, double hubble,
+                     double WindFreeTravelDensThresh, double MaxWindFreeTravelTime, const shq_kick_factors *kf);
+int shq_winds_subgrid(shq_context *ctx, const shq_part_view *parts, const shq_sph_view *sph, size_t sph_off_vdisp, const uint64_t *ids, const int32_t *list,
+                      int64_t nlist, const double *StellarMasses, const shq_wind_params *params, const double *rnd_table, int64_t rnd_size, int64_t *nkicked);
+
 /* The treewalk of metal_return() (libgadget/metal_return.cpp:513-530, 573-667), after stellar_density
  * (shq_stellar_density) and with the per-star yields of metal_return_copy (:540-571: the IMF / yield-table integrals stay with the
  * caller): every gas particle inside the kernel of a star of `queue` (r2 > 0, r2 < H^2) receives

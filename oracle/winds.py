@@ -98,3 +98,47 @@ def winds_and_feedback(P, S, ST, ids, newstars, prm, rnd):
                     delay = prm.MaxWindFreeTravelTime
                 S["DelayTime"][pi] = delay
     return totalweight, kicks, applied
+
+
+def winds_evolve(P, S, lst, a3inv, hubble, dens_thresh, max_travel, kf):
+    """winds_evolve, winds.cpp:370-387, for the gas particles of lst"""
+    for i in lst:
+        if P["Type"][i] != 0 or (P["Flags"][i] & 1):
+            continue
+        pi = P["PI"][i]
+        if S["DelayTime"][pi] > 0 and S["Density"][pi] * a3inv < dens_thresh:
+            S["DelayTime"][pi] = 0
+        if S["DelayTime"][pi] > 0:
+            if S["DelayTime"][pi] > max_travel:
+                S["DelayTime"][pi] = max_travel
+            dtime = kf.dloga_for_bin[int(P["TimeBinHydro"][i])] / hubble
+            S["DelayTime"][pi] = max(S["DelayTime"][pi] - dtime, 0)
+
+
+def winds_subgrid(P, S, ids, lst, stellarmass, prm, rnd):
+    """winds_subgrid + winds_make_after_sf, winds.cpp:272-292, 567-585; stellarmass is indexed like lst.  Returns the number kicked."""
+    if not (prm.WindModel & WIND_SUBGRID):
+        return 0
+    n = 0
+    decouple = (prm.WindModel & WIND_DECOUPLE_SPH) and prm.MaxWindFreeTravelTime > 0
+    for k, i in enumerate(lst):
+        pi = P["PI"][i]
+        vel, windeff, utherm = get_wind_params(float(S["VDisp"][pi]), prm.Time, prm)
+        pw = windeff * stellarmass[k] / float(P["Mass"][i])
+        prob = 1 - np.exp(-pw)
+        if not (rnd[(int(ids[i]) + 2) % len(rnd)] < prob):
+            continue
+        if vel > 0 and prm.Time > 0:
+            theta = np.arccos(2 * rnd[(int(ids[i]) + 3) % len(rnd)] - 1)
+            phi = 2 * np.pi * rnd[(int(ids[i]) + 4) % len(rnd)]
+            direc = np.array([np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)])
+            P["Vel"][i] += vel * direc
+            enttou = (S["Density"][pi] / prm.Time ** 3) ** GAMMA_MINUS1 / GAMMA_MINUS1
+            S["Entropy"][pi] += utherm / enttou
+            if decouple:
+                delay = prm.WindFreeTravelLength / (vel / prm.Time)
+                if delay > prm.MaxWindFreeTravelTime:
+                    delay = prm.MaxWindFreeTravelTime
+                S["DelayTime"][pi] = delay
+            n += 1
+    return n

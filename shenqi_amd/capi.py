@@ -447,6 +447,10 @@ hip.shq_metal_return.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), 
 hip.shq_metal_return.restype = C.c_int
 hip.shq_domain_maintain_topleaf.argtypes = [_vp, C.c_int, C.c_int64, _vp, _vp, C.POINTER(C.c_int64)]
 hip.shq_domain_maintain_topleaf.restype = C.c_int
+hip.shq_winds_evolve.argtypes = [_vp, C.POINTER(PartView), C.POINTER(SphView), _vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(KickFactors)]
+hip.shq_winds_subgrid.argtypes = [_vp, C.POINTER(PartView), C.POINTER(SphView), C.c_size_t, _vp, _vp, C.c_int64, _vp, C.POINTER(WindParams), _vp, C.c_int64,
+                                  C.POINTER(C.c_int64)]
+hip.shq_winds_evolve.restype = hip.shq_winds_subgrid.restype = C.c_int
 hip.shq_sph_state_upload.argtypes = [_vp, C.POINTER(PartView), C.POINTER(SphView)]
 hip.shq_sph_state_upload.restype = C.c_int
 hip.shq_fof_seed_select.argtypes = [_vp, C.c_double, C.c_double, _vp, C.c_int64, C.POINTER(C.c_int64)]

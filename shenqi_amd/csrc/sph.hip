@@ -3636,3 +3636,93 @@ int shq_metal_return_device(shq_context *ctx, MetalWalkArgs *w, int kernel_type,
     SHQ_HIP(hipGetLastError());
     return SHQ_OK;
 }
+
+/* ---- the wind model's particle loops: winds_evolve (winds.cpp:370-387) and winds_subgrid / winds_make_after_sf (:272-292, 567-585) -- */
+__global__ void winds_evolve_kernel(long long n, const int32_t *list, const uint8_t *pflags, const uint8_t *bin_hydro, const double *density, double *delay,
+                                    double a3inv, double hubble, double DensThresh, double MaxTravelTime, shq_kick_factors kf)
+{
+#pragma clang fp contract(off)
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= n)
+        return;
+    const long long i = list ? (long long) list[t] : t;
+    const unsigned f = pflags[i];
+    if((f >> 4) != 0 || (f & 1u))
+        return;
+    double d = delay[i];
+    if(d > 0 && density[i] * a3inv < DensThresh)
+        d = 0;
+    if(d > 0) {
+        if(d > MaxTravelTime)
+            d = MaxTravelTime;
+        const double dtime = kf.dloga_for_bin[bin_hydro[i]] / hubble;
+        d = fmax(d - dtime, 0);
+    }
+    delay[i] = d;
+}
+
+__global__ void winds_subgrid_kernel(long long n, const int32_t *list, const double *stellarmass, const double *vdisp, const double4 *posm, const WindWalkArgs w, double *vel,
+                                     double *entropy, const double *density, double *delay, unsigned long long *nkicked)
+{
+#pragma clang fp contract(off)
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= n)
+        return;
+    const long long i = list ? (long long) list[t] : t;
+    /* get_wind_params, :489-507 */
+    const double time = w.P.Time;
+    const double vphys = vdisp[t] / time;
+    const double utherm = w.P.WindThermalFactor * 1.5 * vphys * vphys;
+    double windeff, v;
+    if(w.P.WindModel & 8) {
+        windeff = w.P.WindEfficiency;
+        v = w.P.WindSpeed * time;
+    } else {
+        windeff = (w.P.WindSigma0 * w.P.WindSigma0) / (vphys * vphys + 2 * utherm);
+        v = w.P.WindSpeedFactor * vdisp[t];
+    }
+    if(v < w.P.MinWindVelocity * time)
+        v = w.P.MinWindVelocity * time;
+    /* winds_make_after_sf: the Springel & Hernquist 03 probability */
+    const double pw = windeff * stellarmass[t] / posm[i].w;
+    const double prob = 1 - exp(-pw);
+    const unsigned long long id = w.ids[i];
+    if(!(w.rnd[(id + 2) % w.rndsize] < prob))
+        return;
+    if(v > 0 && time > 0) { /* wind_do_kick */
+        const double theta = acos(2 * w.rnd[(id + 3) % w.rndsize] - 1);
+        const double phi = 2 * M_PI * w.rnd[(id + 4) % w.rndsize];
+        const double dir[3] = {sin(theta) * cos(phi), sin(theta) * sin(phi), cos(theta)};
+        for(int j = 0; j < 3; j++)
+            vel[3 * i + j] += v * dir[j];
+        const double enttou = pow(density[i] / pow(time, 3), SPH_GAMMA_MINUS1) / SPH_GAMMA_MINUS1;
+        entropy[i] += utherm / enttou;
+        if((w.P.WindModel & 2) && w.P.MaxWindFreeTravelTime > 0) {
+            double d = w.P.WindFreeTravelLength / (v / time);
+            if(d > w.P.MaxWindFreeTravelTime)
+                d = w.P.MaxWindFreeTravelTime;
+            delay[i] = d;
+        }
+        atomicAdd(nkicked, 1ull);
+    }
+}
+
+int shq_winds_evolve_device(shq_context *ctx, const int32_t *d_list, int64_t n, double a3inv, double hubble, double DensThresh, double MaxTravelTime,
+                            const shq_kick_factors *kf)
+{
+    if(n > 0)
+        winds_evolve_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(n, d_list, ctx->pflags.ptr, ctx->bin_hydro.ptr, ctx->g_density.ptr, ctx->g_delaytime.ptr, a3inv,
+                                                                         hubble, DensThresh, MaxTravelTime, *kf);
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}
+
+int shq_winds_subgrid_device(shq_context *ctx, const WindWalkArgs *w, const int32_t *d_list, int64_t n, const double *d_stellarmass, const double *d_vdisp,
+                             unsigned long long *d_nkicked)
+{
+    if(n > 0)
+        winds_subgrid_kernel<<<dim3(nblk(n)), dim3(256), 0, ctx->stream>>>(n, d_list, d_stellarmass, d_vdisp, ctx->posm.ptr, *w, ctx->vel.ptr, ctx->g_entropy.ptr,
+                                                                          ctx->g_density.ptr, ctx->g_delaytime.ptr, d_nkicked);
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}

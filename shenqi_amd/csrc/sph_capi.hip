@@ -1473,3 +1473,116 @@ extern "C" int shq_metal_return(shq_context *ctx, const shq_tree_view *tree, con
     }
     return SHQ_OK;
 }
+
+/* ---- winds_evolve / winds_subgrid (winds.cpp:272-292, 370-387, 567-585) ----------------------------------------------------------- */
+namespace {
+/* Vel, Entropy and DelayTime of the listed gas particles back into the caller's arrays */
+int winds_writeback(shq_context *ctx, const shq_part_view *parts, const shq_sph_view *sph, const int32_t *list, int64_t nlist, bool vel_entropy)
+{
+    const int64_t n = parts->numpart;
+    std::vector<double> hv(vel_entropy ? 3 * (size_t) n : 1), he(vel_entropy ? (size_t) n : 1), hdl((size_t) std::max<int64_t>(n, 1));
+    hipStream_t st = ctx->stream;
+    if(n > 0) {
+        if(vel_entropy) {
+            SHQ_HIP(hipMemcpyAsync(hv.data(), ctx->vel.ptr, sizeof(double) * 3 * (size_t) n, hipMemcpyDeviceToHost, st));
+            SHQ_HIP(hipMemcpyAsync(he.data(), ctx->g_entropy.ptr, sizeof(double) * (size_t) n, hipMemcpyDeviceToHost, st));
+        }
+        SHQ_HIP(hipMemcpyAsync(hdl.data(), ctx->g_delaytime.ptr, sizeof(double) * (size_t) n, hipMemcpyDeviceToHost, st));
+    }
+    SHQ_HIP(hipStreamSynchronize(st));
+    const int64_t cnt = list ? nlist : n;
+    for(int64_t k = 0; k < cnt; k++) {
+        const int64_t i = list ? list[k] : k;
+        if(*pfield<uint8_t>(parts, i, parts->off_type) != 0 || (*pfield<uint8_t>(parts, i, parts->off_flags) & 1u))
+            continue;
+        const int32_t pi = *pfield<int32_t>(parts, i, parts->off_pi);
+        *sfield(sph, pi, sph->off_delaytime) = hdl[(size_t) i];
+        if(vel_entropy) {
+            double *v = pfield_w<double>(parts, i, parts->off_vel);
+            for(int j = 0; j < 3; j++)
+                v[j] = hv[3 * (size_t) i + j];
+            *sfield(sph, pi, sph->off_entropy) = he[(size_t) i];
+        }
+    }
+    return SHQ_OK;
+}
+
+int winds_list_check(const shq_part_view *parts, const int32_t *list, int64_t nlist, bool must_be_gas, const char *who)
+{
+    const int64_t n = parts->numpart;
+    for(int64_t k = 0; list && k < nlist; k++) {
+        SHQ_CHECK(list[k] >= 0 && list[k] < n, SHQ_ERR_INVALID, "%s: list[%ld] = %d out of range", who, (long) k, list[k]);
+        if(must_be_gas)
+            SHQ_CHECK(*pfield<uint8_t>(parts, list[k], parts->off_type) == 0, SHQ_ERR_INVALID, "%s: particle %d is not gas", who, list[k]);
+    }
+    return SHQ_OK;
+}
+} // namespace
+
+extern "C" int shq_winds_evolve(shq_context *ctx, const shq_part_view *parts, const shq_sph_view *sph, const int32_t *list, int64_t nlist, double a3inv, double hubble,
+                                double WindFreeTravelDensThresh, double MaxWindFreeTravelTime, const shq_kick_factors *kf)
+{
+    SHQ_CHECK(ctx && parts && sph && kf && (nlist == 0 || list || nlist == parts->numpart), SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(sph->off_delaytime != SHQ_NOFIELD && parts->off_timebin_hydro != SHQ_NOFIELD && parts->off_flags != SHQ_NOFIELD, SHQ_ERR_INVALID,
+              "winds_evolve: needs DelayTime, the hydro time bin and the flag byte");
+    SHQ_TRY(winds_list_check(parts, list, nlist, false, "winds_evolve"));
+    SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_particles_upload(ctx, parts));
+    SHQ_TRY(sph_upload(ctx, parts, sph));
+    const int64_t cnt = list ? nlist : parts->numpart;
+    const int32_t *d_list = nullptr;
+    if(list && cnt > 0) {
+        SHQ_TRY(ctx->bhw_queue.reserve((size_t) cnt));
+        SHQ_HIP(hipMemcpyAsync(ctx->bhw_queue.ptr, list, sizeof(int32_t) * (size_t) cnt, hipMemcpyHostToDevice, ctx->stream));
+        d_list = ctx->bhw_queue.ptr;
+    }
+    SHQ_TRY(shq_winds_evolve_device(ctx, d_list, cnt, a3inv, hubble, WindFreeTravelDensThresh, MaxWindFreeTravelTime, kf));
+    return winds_writeback(ctx, parts, sph, list, nlist, false);
+}
+
+extern "C" int shq_winds_subgrid(shq_context *ctx, const shq_part_view *parts, const shq_sph_view *sph, size_t sph_off_vdisp, const uint64_t *ids, const int32_t *list,
+                                 int64_t nlist, const double *StellarMasses, const shq_wind_params *params, const double *rnd_table, int64_t rnd_size, int64_t *nkicked)
+{
+    SHQ_CHECK(ctx && parts && sph && ids && params && rnd_table && (nlist == 0 || (list && StellarMasses)), SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(rnd_size > 0, SHQ_ERR_INVALID, "winds_subgrid: empty random table");
+    if(nkicked)
+        *nkicked = 0;
+    if(!(params->WindModel & 1) || nlist == 0) /* "The non-subgrid model does nothing here" */
+        return SHQ_OK;
+    SHQ_CHECK((params->WindModel & 8) || (params->WindModel & 4), SHQ_ERR_INVALID, "WindModel = 0x%X is strange (winds.cpp:503)", params->WindModel);
+    SHQ_CHECK(sph->off_delaytime != SHQ_NOFIELD && sph_off_vdisp + 8 <= sph->elsize, SHQ_ERR_INVALID, "winds_subgrid: needs DelayTime and VDisp of the gas slots");
+    SHQ_TRY(winds_list_check(parts, list, nlist, true, "winds_subgrid"));
+    SHQ_HIP(hipSetDevice(ctx->device));
+    const int64_t n = parts->numpart;
+    SHQ_TRY(shq_particles_upload(ctx, parts));
+    SHQ_TRY(sph_upload(ctx, parts, sph));
+    hipStream_t st = ctx->stream;
+    std::vector<double> hd(2 * (size_t) nlist);
+    for(int64_t k = 0; k < nlist; k++) {
+        hd[(size_t) k] = StellarMasses[k];
+        hd[(size_t) (nlist + k)] = *sfield(sph, *pfield<int32_t>(parts, list[k], parts->off_pi), sph_off_vdisp);
+    }
+    SHQ_TRY(ctx->bhw_ids.reserve((size_t) std::max<int64_t>(n, 1)));
+    SHQ_TRY(ctx->bhw_rnd.reserve((size_t) rnd_size));
+    SHQ_TRY(ctx->bhw_queue.reserve((size_t) nlist));
+    SHQ_TRY(ctx->wind_d.reserve(2 * (size_t) nlist));
+    SHQ_TRY(ctx->wind_cnt.reserve(4));
+    SHQ_HIP(hipMemcpyAsync(ctx->bhw_ids.ptr, ids, sizeof(uint64_t) * (size_t) n, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemcpyAsync(ctx->bhw_rnd.ptr, rnd_table, sizeof(double) * (size_t) rnd_size, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemcpyAsync(ctx->bhw_queue.ptr, list, sizeof(int32_t) * (size_t) nlist, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemcpyAsync(ctx->wind_d.ptr, hd.data(), sizeof(double) * hd.size(), hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemsetAsync(ctx->wind_cnt.ptr, 0, sizeof(unsigned long long) * 4, st));
+    WindWalkArgs w;
+    memset(&w, 0, sizeof(w));
+    w.ids = ctx->bhw_ids.ptr;
+    w.rnd = ctx->bhw_rnd.ptr;
+    w.rndsize = (unsigned long long) rnd_size;
+    w.P = *params;
+    SHQ_TRY(shq_winds_subgrid_device(ctx, &w, ctx->bhw_queue.ptr, nlist, ctx->wind_d.ptr, ctx->wind_d.ptr + nlist, ctx->wind_cnt.ptr));
+    unsigned long long h = 0;
+    SHQ_HIP(hipMemcpyAsync(&h, ctx->wind_cnt.ptr, sizeof(h), hipMemcpyDeviceToHost, st));
+    SHQ_TRY(winds_writeback(ctx, parts, sph, list, nlist, true));
+    if(nkicked)
+        *nkicked = (int64_t) h;
+    return SHQ_OK;
+}

@@ -155,3 +155,56 @@ def test_subgrid_model_and_errors(ctx):
         capi.check(call(cp3, gas))
     capi.check(call(cp3, new[:0].copy()))
     assert nk.value == 0
+
+
+def test_winds_evolve_and_subgrid_winds(ctx):
+    """the wind model's two particle loops: DelayTime ageing / recoupling (winds_evolve) and the subgrid kicks of freshly star-forming
+    gas (winds_subgrid, winds_make_after_sf) against their restatements"""
+    cp, prm = params(WindModel=ow.WIND_SUBGRID + ow.WIND_USE_HALO + ow.WIND_DECOUPLE_SPH)
+    pman, S, ST, rnd, new = setup(6, ngrid=12, nstar=50, nnew=10)
+    P = pman.Base
+    rng = np.random.default_rng(9)
+    ids = np.ascontiguousarray(P["ID"])
+    gas = np.flatnonzero((P["Type"] == 0) & ((P["Flags"] & 1) == 0)).astype(np.int32)
+    S["VDisp"] = rng.uniform(5, 60, len(S))
+    S["DelayTime"] = np.where(rng.random(len(S)) < 0.5, rng.uniform(0.0, 1.0, len(S)), 0.0)       # some above MaxWindFreeTravelTime 0.6
+    P["TimeBinHydro"] = rng.integers(16, 22, len(P))
+    kf = sq.KickFactors()
+    for b in range(47):
+        kf.dloga_for_bin[b] = 1e-3 * 2.0 ** (b - 16) if b > 0 else 0.0
+    pv, sv = pman.view(), capi.sph_view(S)
+    # ---- winds_evolve on a list and on everything
+    lst = np.ascontiguousarray(rng.permutation(gas)[:len(gas) // 2])
+    for which in (lst, None):
+        oP, oS = P.copy(), S.copy()
+        thresh = float(np.median(S["Density"])) * 8.0
+        ow.winds_evolve(oP, oS, range(len(P)) if which is None else which, 8.0, 0.3, thresh, 0.6, kf)
+        capi.check(capi.hip.shq_winds_evolve(ctx.h, C.byref(pv), C.byref(sv), None if which is None else capi.ptr(which), len(P) if which is None else len(which),
+                                             8.0, 0.3, thresh, 0.6, C.byref(kf)))
+        assert np.array_equal(S["DelayTime"], oS["DelayTime"])
+        if which is None:
+            assert (S["DelayTime"][P["PI"][gas]] <= 0.6).all()
+    assert (S["DelayTime"] == 0).sum() > (len(S) // 2) and (S["DelayTime"] > 0).any()
+    # ---- subgrid winds for a list of star-forming gas
+    maybe = np.ascontiguousarray(rng.permutation(gas)[:400])
+    sm = rng.uniform(0.0, 0.2, len(maybe))
+    oP, oS = P.copy(), S.copy()
+    P0 = P.copy()
+    on = ow.winds_subgrid(oP, oS, ids, maybe, sm, prm, rnd)
+    nk = C.c_int64()
+    off_vdisp = capi.SPH_DTYPE.fields["VDisp"][1]
+    capi.check(capi.hip.shq_winds_subgrid(ctx.h, C.byref(pv), C.byref(sv), off_vdisp, capi.ptr(ids), capi.ptr(maybe), len(maybe), capi.ptr(sm), C.byref(cp),
+                                          capi.ptr(rnd), len(rnd), C.byref(nk)))
+    assert nk.value == on and 10 < on < len(maybe)
+    assert np.array_equal(np.any(P["Vel"] != P0["Vel"], axis=1), np.any(oP["Vel"] != P0["Vel"], axis=1))
+    assert np.abs(P["Vel"] - oP["Vel"]).max() < 1e-11 and np.abs(S["Entropy"] / oS["Entropy"] - 1).max() < 1e-14 and np.array_equal(S["DelayTime"], oS["DelayTime"])
+    # without the subgrid bit the call does nothing
+    cp2, _ = params()
+    before = P["Vel"].copy()
+    capi.check(capi.hip.shq_winds_subgrid(ctx.h, C.byref(pv), C.byref(sv), off_vdisp, capi.ptr(ids), capi.ptr(maybe), len(maybe), capi.ptr(sm), C.byref(cp2),
+                                          capi.ptr(rnd), len(rnd), C.byref(nk)))
+    assert nk.value == 0 and np.array_equal(P["Vel"], before)
+    stars = np.flatnonzero(P["Type"] == 4)[:2].astype(np.int32)
+    with pytest.raises(sq.ShqError):
+        capi.check(capi.hip.shq_winds_subgrid(ctx.h, C.byref(pv), C.byref(sv), off_vdisp, capi.ptr(ids), capi.ptr(stars), 2, capi.ptr(sm), C.byref(cp),
+                                              capi.ptr(rnd), len(rnd), C.byref(nk)))
