@@ -108,7 +108,6 @@ timed("shq_bh_feedback", fb, 1)
 tree_g = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
 tvg = tree_g.view()
 # ---- winds
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 wp = capi.WindParams(BOX, 0.2, 20.0, 0.6, 2.0, 350.0, 353.0, 3.7, 100.0, 0.0, 4 + 2, 0)
 stv = capi.StarView(ST.ctypes.data, ST.dtype.itemsize, len(ST), ST.dtype.fields["VDisp"][1])
 new = np.ascontiguousarray(np.arange(ngas, ngas + nstar, dtype=np.int32))
