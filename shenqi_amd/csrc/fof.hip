@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void fof_link_kernel(long long nt, FofTree t, 
     const double4 p = t.posm_leaf[k];
     const double h2 = linkl * linkl;
     int no = 0;
+    int myroot = i; /* some member of the target's set, as close to its root as the last look found */
     int cend = -1, cskip = -1; /* inside a clique node: pool records [.., cend) are its sub-tree, cskip is where the walk goes on after it */
     while(no >= 0) {
         if(no >= cend)
@@ -138,6 +139,14 @@ __global__ __launch_bounds__(256) void fof_link_kernel(long long nt, FofTree t, 
             continue;
         }
         if(cend < 0 && b.len <= t.clique_len) { /* a clique: ONE friend inside is enough; its sub-tree is searched, not listed */
+            /* ... and none is needed when the target already sits in the clique's set: sets only ever merge, so the sub-tree can be
+             * passed over (in the caustic of the S-cluster nearly every clique a particle meets is in its group already: two or three
+             * dependent loads instead of leaf records, positions and a unite) */
+            myroot = uf_find(parent, myroot);
+            if(uf_find(parent, t.leaf_pidx[t.lo[t.order[no]]]) == myroot) {
+                no = c.sibling;
+                continue;
+            }
             cend = c.sibling >= 0 ? c.sibling : nn;
             cskip = c.sibling;
         }
