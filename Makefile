@@ -16,7 +16,7 @@ $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp include/shenqi_hip.h
 $(LIBDIR)/libshenqi_hip.so: $(HIPOBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIPOBJ) -L/opt/rocm/lib -lhipfft -Wl,-rpath,/opt/rocm/lib
 
-host:
+host: $(LIBDIR)/libshenqi_hip.so
 	$(MAKE) -C shenqi_amd/host
 
 oracle:
