@@ -250,6 +250,7 @@ struct shq_context {
     bool act_all = false;                /* PM step: the list is NULL, every particle is active */
     DevBuf<GravStatsDev> gstats;
     bool have_parts = false;
+    bool allow_padding = false; /* SHQ_WALK_PADDING=1: -1 entries of a gravity target list are idle lanes (tools/walk_cell_probe.py) */
 
     /* ---- node pool */
     int64_t numnodes = 0;

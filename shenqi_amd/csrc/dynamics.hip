@@ -347,7 +347,7 @@ int shq_resolve_active(shq_context *ctx, const int32_t *active, int64_t nactive,
     }
     SHQ_CHECK(nactive >= 0, SHQ_ERR_INVALID, "bad active list length %ld", (long) nactive);
     for(int64_t k = 0; k < nactive; k++)
-        SHQ_CHECK(active[k] >= 0 && active[k] < ctx->numpart, SHQ_ERR_INVALID, "active[%ld] = %d out of range", (long) k, active[k]);
+        SHQ_CHECK(active[k] >= (ctx->allow_padding ? -1 : 0) && active[k] < ctx->numpart, SHQ_ERR_INVALID, "active[%ld] = %d out of range", (long) k, active[k]);
     SHQ_TRY(ctx->active.reserve((size_t) std::max<int64_t>(nactive, 1)));
     if(nactive > 0)
         SHQ_HIP(hipMemcpyAsync(ctx->active.ptr, active, sizeof(int32_t) * nactive, hipMemcpyHostToDevice, ctx->stream));

@@ -157,11 +157,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void grav
     const int lane = threadIdx.x & 63;
     const long long wave = (long long) xcd_block(blockIdx.x, gridDim.x, a.xcdK) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long t = wave * 64 + lane;
-    const bool valid = t < a.ntargets;
+    bool valid = t < a.ntargets;
     long long pi = 0;
     double px = 0, py = 0, pz = 0, aold = 0;
     if(valid) {
         pi = a.targets ? (long long) a.targets[t] : t;
+        valid = pi >= 0; /* a negative list entry is an idle lane (padding of cell-aligned target groups) */
+    }
+    if(valid) {
         const double4 p = a.posm[pi];
         px = p.x;
         py = p.y;
@@ -382,6 +385,8 @@ __global__ void grav_postprocess_kernel(const int32_t *targets, long long ntarge
     if(t >= ntargets)
         return;
     const long long i = targets ? (long long) targets[t] : t;
+    if(i < 0)
+        return;
     const double a0 = acc[3 * i + 0] * G, a1 = acc[3 * i + 1] * G, a2 = acc[3 * i + 2] * G;
     acc[3 * i + 0] = a0;
     acc[3 * i + 1] = a1;
@@ -557,12 +562,12 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
 {
     if(walk_mode == SHQ_WALK_GROUP)
         return shq_launch_grav_walk_group(ctx, p, d_active, ntargets, update_potential, first);
-    SHQ_CHECK(first >= 0 && (first == 0 || !d_active) && first + ntargets <= ctx->numpart, SHQ_ERR_INVALID,
+    SHQ_CHECK(first >= 0 && (first == 0 || !d_active) && (first + ntargets <= ctx->numpart || (d_active && ctx->allow_padding)), SHQ_ERR_INVALID,
               "grav walk: bad target range [%ld, +%ld)", (long) first, (long) ntargets);
     SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "grav walk: particles and tree must be uploaded first");
     SHQ_CHECK(walk_mode == SHQ_WALK_EXACT, SHQ_ERR_INVALID, "unknown walk_mode %d", walk_mode);
     SHQ_CHECK(p->ForceSoftening > 0 && p->cellsize > 0 && p->dx > 0, SHQ_ERR_INVALID, "grav params: softening/cellsize/dx must be > 0");
-    SHQ_CHECK(ntargets >= 0 && ntargets <= ctx->numpart, SHQ_ERR_INVALID, "grav walk: ntargets %ld out of range", (long) ntargets);
+    SHQ_CHECK(ntargets >= 0 && (ntargets <= ctx->numpart || (d_active && ctx->allow_padding)), SHQ_ERR_INVALID, "grav walk: ntargets %ld out of range", (long) ntargets);
     SHQ_TRY(ctx->gravtab.reserve(2 * SHQ_NGRAVTAB));
     SHQ_TRY(ctx->gstats.reserve(1));
     SHQ_HIP(hipMemcpyAsync(ctx->gravtab.ptr, p->shortrange_table, sizeof(float) * SHQ_NGRAVTAB, hipMemcpyHostToDevice, ctx->stream));
