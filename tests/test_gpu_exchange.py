@@ -102,8 +102,8 @@ def gpu_exchange(ctx, tasks, targets, ntask, maxlast=0):
     return out, togo, last, partbuf, slotbuf
 
 
-def both(ctx, ntask, ntype, layout, garbage=False, swallowed=False):
-    tasks = [list(fx.setup_task(r, ntask, ntype)) for r in range(ntask)]
+def both(ctx, ntask, ntype, layout, garbage=False, swallowed=False, maxpart=1024):
+    tasks = [list(fx.setup_task(r, ntask, ntype, maxpart=maxpart)) for r in range(ntask)]
     tot = ntask * sum(ntype)
     if garbage:
         for T in tasks:
@@ -135,6 +135,14 @@ def both(ctx, ntask, ntype, layout, garbage=False, swallowed=False):
 def test_exchange_equals_reference_loop(ctx, ntask, ntype):
     gout, tot = both(ctx, ntask, ntype, fx.layout_id_mod)
     fx.check_after(gout, ntask, tot)
+
+
+def test_exchange_at_scale(ctx):
+    """44 000 particles per task, four tasks: the sorts and the word-wise copies beyond toy sizes (several workgroups per task and
+    type, slot records of 72 / 176 / 248 bytes), still field for field against the serial loop"""
+    gout, tot = both(ctx, 4, [20000, 6500, 0, 3500, 12500, 1500], fx.layout_id_mod, garbage=True, maxpart=100000)
+    fx.check_after(gout, 4, tot)
+    assert all(g[1] > 40000 for g in gout)
 
 
 def test_exchange_with_garbage_and_swallowed(ctx):
