@@ -27,9 +27,9 @@ def close(a, b, rtol=1e-11):
     return a.shape == b.shape and np.abs(a - b).max(initial=0.0) <= rtol * scale
 
 
-def run_both(ctx, seed, queue_stride=1, bh_hsml=1.0, **kw):
+def run_both(ctx, seed, queue_stride=1, bh_hsml=1.0, size=None, **kw):
     cp, prm = params(**kw)
-    pman, S, B, kf, rnd, bi = setup(seed, bh_hsml=bh_hsml)
+    pman, S, B, kf, rnd, bi = setup(seed, bh_hsml=bh_hsml, **(size or {}))
     P = pman.Base
     n, ngas, nbh = len(P), len(S), len(B)
     ids = np.ascontiguousarray(P["ID"])
@@ -146,6 +146,14 @@ def test_large_kernels_overflow_the_lane_lists(ctx):
     check_accretion(a)
     check_feedback(f)
     assert (a["ow"]["MgasEnc"] == 0).all() and (a["ow"]["SPH_SwallowID"] != 0).sum() > 50
+
+
+def test_many_black_holes_span_several_workgroups(ctx):
+    """700 black holes in 27 000 gas particles: 11 waves in 3 workgroups of the walk kernels (the other cases fit one wave)"""
+    a, f = run_both(ctx, 12, size=dict(ngrid=30, nbh=700, ndm=500), BH_DRAG=2, SeedBHDynMass=1.5)
+    check_accretion(a)
+    check_feedback(f)
+    assert (a["ow"]["SPH_SwallowID"] != 0).sum() > 500 and f["counts"][0] > 400
 
 
 def test_bh_walk_argument_errors(ctx):

@@ -107,6 +107,26 @@ def test_metal_return_equals_serial_loop(ctx, sphw, kt, hscale):
     assert np.array_equal(P["Mass"][~gas], P0["Mass"][~gas])
 
 
+def test_many_stars_span_several_workgroups(ctx):
+    """1000 stars: 16 waves in 4 workgroups of the emit kernel, ~16 000 triples through the sorts"""
+    pman, S, queue, starvol, massgen, metalgen, species = setup(21, ngrid=24, nstar=1500, nq=1000)
+    P = pman.Base
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+    oP, oS = P.copy(), S.copy()
+    omass = omr.metal_return(oP, oS, queue, starvol, massgen, metalgen, species, 4.0, 0, 1, cm.BOX)
+    f = capi.SPH_DTYPE.fields
+    gv = capi.GasMetalView(S.ctypes.data, S.dtype.itemsize, len(S), f["Density"][1], f["Metallicity"][1], f["Metals"][1], 9, 0)
+    pv, tv = pman.view(), tree.view()
+    mret = np.zeros(len(queue))
+    npairs = C.c_int64()
+    capi.check(capi.hip.shq_metal_return(ctx.h, C.byref(tv), C.byref(pv), C.byref(gv), capi.ptr(queue), len(queue), capi.ptr(starvol), capi.ptr(massgen),
+                                         capi.ptr(metalgen), capi.ptr(species), 4.0, 0, 1, capi.ptr(mret), C.byref(npairs)))
+    assert npairs.value > 10000
+    assert np.array_equal(P["Mass"], oP["Mass"]) and np.array_equal(S["Density"], oS["Density"])
+    assert np.array_equal(S["Metallicity"], oS["Metallicity"]) and np.array_equal(S["Metals"], oS["Metals"])
+    assert np.abs(mret - omass).max() <= 1e-14 * omass.max()
+
+
 def test_metal_return_errors_and_empty(ctx):
     pman, S, queue, starvol, massgen, metalgen, species = setup(9, ngrid=8, nstar=60, nq=10)
     P = pman.Base

@@ -74,9 +74,9 @@ def setup(seed, ngrid=16, nstar=400, nnew=60, hscale=1.0):
     return pman, S, ST, rnd, np.ascontiguousarray(rng.permutation(new))
 
 
-def run_both(ctx, seed, hscale=1.0, **kw):
+def run_both(ctx, seed, hscale=1.0, size=None, **kw):
     cp, prm = params(**kw)
-    pman, S, ST, rnd, new = setup(seed, hscale=hscale)
+    pman, S, ST, rnd, new = setup(seed, hscale=hscale, **(size or {}))
     P = pman.Base
     ids = np.ascontiguousarray(P["ID"])
     tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
@@ -128,6 +128,12 @@ def test_large_kernels_overflow_the_lane_lists(ctx):
     """stars with up to ~700 gas neighbours: the per-lane lists are flushed in the middle of both walks"""
     r = run_both(ctx, 4, hscale=2.6, WindEfficiency=30.0, WindModel=ow.WIND_FIXED_EFFICIENCY + ow.WIND_DECOUPLE_SPH)
     assert r.tw[r.P["PI"][r.new]].max() > 300 and r.applied > 20
+
+
+def test_many_new_stars_span_several_workgroups(ctx):
+    """900 new stars: 15 waves in 4 workgroups of the walk kernels"""
+    r = run_both(ctx, 7, size=dict(ngrid=24, nstar=1200, nnew=900))
+    assert r.applied > 300 and len(r.kicks) > r.applied
 
 
 def test_subgrid_model_and_errors(ctx):
