@@ -173,6 +173,8 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
         ctx->pm_overlap = atoi(v) != 0;
     if(const char *v = getenv("SHQ_WALK_VARIANT"))
         ctx->walk_variant = atoi(v);
+    if(const char *v = getenv("SHQ_WALK_STATS_GUARD"))
+        ctx->stats_guard = atoi(v);
     if(const char *v = getenv("SHQ_WALK_PADDING"))
         ctx->allow_padding = atoi(v) != 0;
     if(const char *v = getenv("SHQ_WALK_STATS"))

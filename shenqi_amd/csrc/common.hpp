@@ -250,6 +250,7 @@ struct shq_context {
     bool act_all = false;                /* PM step: the list is NULL, every particle is active */
     DevBuf<GravStatsDev> gstats;
     bool have_parts = false;
+    int stats_guard = 0;       /* SHQ_WALK_STATS_GUARD (A/B knob): 1 reads before atomicMin / atomicMax (slower), 2 drops the wave tallies */
     bool allow_padding = false; /* SHQ_WALK_PADDING=1: -1 entries of a gravity target list are idle lanes (tools/walk_cell_probe.py) */
 
     /* ---- node pool */
