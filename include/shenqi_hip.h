@@ -566,6 +566,11 @@ typedef struct shq_fof_group {
 int shq_fof(shq_context *ctx, const shq_fof_params *params, const uint64_t *ids, uint64_t *minid_by_particle, int32_t *grnr_by_particle,
             int64_t *ngroups);
 int shq_fof_groups_download(shq_context *ctx, shq_fof_group *groups, int64_t capacity);
+/* The slot-resident sums of add_particle_to_group (fof.cpp:599-618: MassHeIonized, Sfr, GasMetalMass, GasMetalElemMass[],
+ * StellarMetalMass, StellarMetalElemMass[], BH_Mdot, BH_Mass): per group and column the sum of values_by_particle[i][col] over the
+ * group's members, in member (particle index) order.  The caller fills the columns from its slots (zero where a type does not
+ * contribute); sums_by_group is [ngroups][ncol] in catalogue order.  Groups of more than 256 members are summed in 256 slices. */
+int shq_fof_group_sums(shq_context *ctx, const double *values_by_particle, int ncol, double *sums_by_group);
 /* The marking loop of fof_seed (fof.cpp:1290-1302) on the resident catalogue: the seed_index (densest gas particle) of every group
  * with Mass >= MinFoFMassForNewSeed, MassType[4] >= MinMStarForNewSeed, no black hole yet and a seed candidate, in catalogue order,
  * into the DEVICE array d_seed_index (NULL: count only) — the list shq_blackhole_make_seeds takes.  One task: seed_task is this task. */

@@ -453,6 +453,8 @@ hip.shq_winds_subgrid.argtypes = [_vp, C.POINTER(PartView), C.POINTER(SphView), 
 hip.shq_winds_evolve.restype = hip.shq_winds_subgrid.restype = C.c_int
 hip.shq_sph_state_upload.argtypes = [_vp, C.POINTER(PartView), C.POINTER(SphView)]
 hip.shq_sph_state_upload.restype = C.c_int
+hip.shq_fof_group_sums.argtypes = [_vp, _vp, C.c_int, _vp]
+hip.shq_fof_group_sums.restype = C.c_int
 hip.shq_fof_seed_select.argtypes = [_vp, C.c_double, C.c_double, _vp, C.c_int64, C.POINTER(C.c_int64)]
 for _f in ("shq_make_particle_stars", "shq_blackhole_make_seeds", "shq_fof_seed_select"):
     getattr(hip, _f).restype = C.c_int

@@ -822,4 +822,56 @@ extern "C" int shq_fof_seed_select(shq_context *ctx, double MinFoFMassForNewSeed
     return SHQ_OK;
 }
 
+namespace {
+/* one workgroup per (group, column): 256 contiguous slices of the member list, each summed in member order by one thread, the slice
+ * sums added in slice order by thread 0.  A group of up to 256 members is the plain serial sum of add_particle_to_group. */
+__global__ __launch_bounds__(256) void fof_colsum_kernel(const shq_fof_group *g, const int32_t *members, const double *values, int ncol, double *sums)
+{
+#pragma clang fp contract(off)
+    __shared__ double part[256];
+    const long long grp = blockIdx.x / ncol;
+    const int col = (int) (blockIdx.x % ncol);
+    const long long first = g[grp].first_member, len = g[grp].Length;
+    const long long per = (len + 255) / 256;
+    const long long a = first + (long long) threadIdx.x * per, e = a + per < first + len ? a + per : first + len;
+    double s = 0;
+    for(long long k = a; k < e; k++)
+        s += values[(size_t) members[k] * ncol + col];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if(threadIdx.x == 0) {
+        double t = 0;
+        for(int j = 0; j < 256; j++)
+            t += part[j];
+        sums[(size_t) grp * ncol + col] = t;
+    }
+}
+} // namespace
+
+extern "C" int shq_fof_group_sums(shq_context *ctx, const double *values_by_particle, int ncol, double *sums_by_group)
+{
+    SHQ_CHECK(ctx && (ncol == 0 || (values_by_particle && sums_by_group)), SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->fof_ngroups >= 0, SHQ_ERR_STATE, "fof_group_sums: run shq_fof first");
+    SHQ_CHECK(ncol >= 0 && ncol <= 1024, SHQ_ERR_INVALID, "fof_group_sums: %d columns", ncol);
+    const long long ng = ctx->fof_ngroups, n = ctx->numpart;
+    if(ng == 0 || ncol == 0)
+        return SHQ_OK;
+    SHQ_CHECK(ctx->have_parts && ctx->fof_i32[1].ptr, SHQ_ERR_STATE, "fof_group_sums: the particle set changed since shq_fof");
+    SHQ_CHECK(ng * ncol < (1ll << 31), SHQ_ERR_INVALID, "fof_group_sums: %ld groups x %d columns is too many for one launch", (long) ng, ncol);
+    SHQ_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    SHQ_TRY(ctx->fof_members.reserve((size_t) std::max<int64_t>(ctx->fof_nmembers, 1)));
+    fof_members_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, ctx->fof_i32[1].ptr, ctx->fof_i32[2].ptr, ctx->fof_i32[4].ptr, ctx->fof_i32[5].ptr, ctx->fof_i32[3].ptr,
+                                                           ctx->fof_goff[1].ptr, ctx->fof_members.ptr);
+    SHQ_HIP(hipGetLastError());
+    SHQ_TRY(ctx->ex_u64.reserve((size_t) n * ncol + (size_t) ng * ncol));
+    double *d_val = reinterpret_cast<double *>(ctx->ex_u64.ptr), *d_sum = d_val + (size_t) n * ncol;
+    SHQ_HIP(hipMemcpyAsync(d_val, values_by_particle, sizeof(double) * (size_t) n * ncol, hipMemcpyHostToDevice, st));
+    fof_colsum_kernel<<<dim3((unsigned) (ng * ncol)), dim3(256), 0, st>>>(ctx->fof_groups.ptr, ctx->fof_members.ptr, d_val, ncol, d_sum);
+    SHQ_HIP(hipGetLastError());
+    SHQ_HIP(hipMemcpyAsync(sums_by_group, d_sum, sizeof(double) * (size_t) ng * ncol, hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    return SHQ_OK;
+}
+
 static_assert(sizeof(shq_fof_group) == 272, "shq_fof_group layout (shenqi_amd/capi.py FOF_GROUP_DTYPE)");

@@ -229,3 +229,40 @@ def test_fof_seed_candidates_and_seed_select(ctx):
                 with pytest.raises(sq.ShqError):
                     capi.check(capi.hip.shq_fof_seed_select(ctx.h, minmass, minstar, out.data_ptr(), 1, C.byref(ns)))
         assert 0 < len(ofof.seed_marks(ogroups, 60.0, 8.0)) < len(ofof.seed_marks(ogroups, 0.0, 0.0))
+
+
+def test_fof_group_sums_of_slot_quantities(ctx):
+    """shq_fof_group_sums: per-group sums of caller-supplied per-particle columns (Sfr, metal masses, BH_Mass ... of
+    add_particle_to_group, fof.cpp:599-618) in member order: small groups exactly the serial sum, the long one to rounding"""
+    rng = np.random.default_rng(33)
+    box = 300.0
+    centres = rng.random((30, 3)) * box
+    sizes = rng.integers(5, 200, size=30)
+    sizes[0] = 3000                                         # one group beyond 256 members per slice... and beyond 256 members
+    pos = np.mod(np.concatenate([c + rng.normal(size=(s, 3)) * 1.2 for c, s in zip(centres, sizes)] + [rng.random((2000, 3)) * box]), box)
+    n = len(pos)
+    perm = rng.permutation(n)
+    pos = pos[perm]
+    types = np.ones(n, dtype=np.uint8)
+    ids = rng.permutation(n).astype(np.uint64) + 1
+    vel = np.zeros((n, 3))
+    mass = np.ones(n)
+    minid, grnr, groups, members, _ = gpu_fof(ctx, pos, vel, mass, types, ids, box, 1.5, 8)
+    ncol = 5
+    vals = np.ascontiguousarray(rng.normal(size=(n, ncol)) * np.array([1.0, 1e3, 1e-3, 5.0, 0.0]))
+    sums = np.full((len(groups), ncol), np.nan)
+    capi.check(capi.hip.shq_fof_group_sums(ctx.h, capi.ptr(vals), ncol, capi.ptr(sums)))
+    assert len(groups) > 15 and groups["Length"].max() > 2500
+    for g, G in enumerate(groups):
+        mem = members[G["first_member"]:G["first_member"] + G["Length"]]
+        if G["Length"] <= 256:
+            want = np.zeros(ncol)
+            for i in mem:                                    # the serial loop of fof_compile_catalogue over the sorted members
+                want += vals[i]
+            assert np.array_equal(sums[g], want), g
+        else:
+            want = vals[mem].sum(axis=0)
+            assert np.abs(sums[g] - want).max() <= 1e-12 * np.abs(vals[mem]).sum(axis=0).max()
+    assert (sums[:, 4] == 0).all()
+    with pytest.raises(sq.ShqError):
+        capi.check(capi.hip.shq_fof_group_sums(ctx.h, None, 3, capi.ptr(sums)))
