@@ -972,6 +972,14 @@ typedef struct shq_star_view {
 int shq_winds_and_feedback(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph, const shq_star_view *stars,
                            const uint64_t *ids, const int32_t *NewStars, int64_t NumNewStars, const shq_wind_params *params, const double *rnd_table,
                            int64_t rnd_size, double *TotalWeight, shq_wind_kick *kicks, int64_t kicks_capacity, int64_t *nkicks, int64_t *nkicked);
+/* The two halves of the call above for a multi-rank driver (shenqi_amd/dist.py:DistWinds): the walks alone — TotalWeight and the sorted
+ * candidate list, nothing applied; a candidate's particle may be an imported ghost — and the resolution + kicks for a candidate list
+ * gathered from all ranks on the particles' owner (any order: it is sorted again). */
+int shq_winds_candidates(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph, const shq_star_view *stars,
+                         const uint64_t *ids, const int32_t *NewStars, int64_t NumNewStars, const shq_wind_params *params, const double *rnd_table,
+                         int64_t rnd_size, double *TotalWeight, shq_wind_kick *kicks, int64_t kicks_capacity, int64_t *nkicks);
+int shq_winds_apply(shq_context *ctx, const shq_part_view *parts, const shq_sph_view *sph, const uint64_t *ids, const shq_wind_kick *kicks, int64_t nk,
+                    const shq_wind_params *params, const double *rnd_table, int64_t rnd_size, int64_t *nkicked);
 
 /* The wind model's two particle loops, on the caller's arrays (gas particles of `list`; NULL: all particles, non-gas skipped):
  *   shq_winds_evolve    winds_evolve (winds.cpp:370-387) as cooling_and_starformation calls it per star-forming gas particle: a wind

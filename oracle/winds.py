@@ -42,11 +42,11 @@ def get_wind_params(vdisp, time, prm):
     return vel, windeff, utherm
 
 
-def winds_and_feedback(P, S, ST, ids, newstars, prm, rnd):
-    """returns (TotalWeight by star slot, sorted kick list, number applied); P["Vel"], S["Entropy"], S["DelayTime"] are modified"""
+def candidates(P, S, ST, ids, newstars, prm, rnd):
+    """the two walks: (TotalWeight by star slot, candidate kicks sorted with StarKick's comparison); nothing is applied"""
     totalweight = np.zeros(len(ST))
     if prm.WindModel & WIND_SUBGRID:
-        return totalweight, [], 0
+        return totalweight, []
     for i in newstars:
         assert P["Type"][i] == 4
         idx, r = gas_neighbours(P, S, i, prm.BoxSize)
@@ -77,6 +77,12 @@ def winds_and_feedback(P, S, ST, ids, newstars, prm, rnd):
             if rnd[(int(ids[i]) + int(ids[other])) % len(rnd)] < p and v > 0:
                 kicks.append((int(other), float(rr), int(ids[i]), v, utherm))
     kicks.sort(key=lambda k: (k[0], k[1], k[2]))
+    return totalweight, kicks
+
+
+def apply(P, S, ids, kicks, prm, rnd):
+    """the resolution after the walk (winds.cpp:330-350) and wind_do_kick: kicks in any order; returns the number applied"""
+    kicks = sorted(kicks, key=lambda k: (k[0], k[1], k[2]))
     last, applied = -1, 0
     decouple = (prm.WindModel & WIND_DECOUPLE_SPH) and prm.MaxWindFreeTravelTime > 0
     for other, _, _, vel, therm in kicks:
@@ -97,7 +103,13 @@ def winds_and_feedback(P, S, ST, ids, newstars, prm, rnd):
                 if delay > prm.MaxWindFreeTravelTime:
                     delay = prm.MaxWindFreeTravelTime
                 S["DelayTime"][pi] = delay
-    return totalweight, kicks, applied
+    return applied
+
+
+def winds_and_feedback(P, S, ST, ids, newstars, prm, rnd):
+    """returns (TotalWeight by star slot, sorted kick list, number applied); P["Vel"], S["Entropy"], S["DelayTime"] are modified"""
+    totalweight, kicks = candidates(P, S, ST, ids, newstars, prm, rnd)
+    return totalweight, kicks, apply(P, S, ids, kicks, prm, rnd)
 
 
 def winds_evolve(P, S, lst, a3inv, hubble, dens_thresh, max_travel, kf):

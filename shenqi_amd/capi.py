@@ -442,6 +442,10 @@ hip.shq_bh_accretion.restype = hip.shq_bh_feedback.restype = C.c_int
 hip.shq_winds_and_feedback.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(SphView), C.POINTER(StarView), _vp, _vp, C.c_int64, C.POINTER(WindParams),
                                        _vp, C.c_int64, _vp, _vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
 hip.shq_winds_and_feedback.restype = C.c_int
+hip.shq_winds_candidates.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(SphView), C.POINTER(StarView), _vp, _vp, C.c_int64, C.POINTER(WindParams),
+                                     _vp, C.c_int64, _vp, _vp, C.c_int64, C.POINTER(C.c_int64)]
+hip.shq_winds_apply.argtypes = [_vp, C.POINTER(PartView), C.POINTER(SphView), _vp, _vp, C.c_int64, C.POINTER(WindParams), _vp, C.c_int64, C.POINTER(C.c_int64)]
+hip.shq_winds_candidates.restype = hip.shq_winds_apply.restype = C.c_int
 hip.shq_metal_return.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView), C.POINTER(GasMetalView), _vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp,
                                  C.POINTER(C.c_int64)]
 hip.shq_metal_return.restype = C.c_int

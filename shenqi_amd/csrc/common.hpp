@@ -511,7 +511,7 @@ int shq_winds_evolve_device(shq_context *ctx, const int32_t *d_list, int64_t n, 
                             const shq_kick_factors *kf);
 int shq_winds_subgrid_device(shq_context *ctx, const WindWalkArgs *w, const int32_t *d_list, int64_t n, const double *d_stellarmass, const double *d_vdisp,
                              unsigned long long *d_nkicked);
-int shq_wind_resolve_device(shq_context *ctx, const WindWalkArgs *w, long long nk, shq_wind_kick *d_sorted, unsigned long long *d_napplied, int *d_odd);
+int shq_wind_resolve_device(shq_context *ctx, const WindWalkArgs *w, long long nk, shq_wind_kick *d_sorted, unsigned long long *d_napplied, int *d_odd, bool apply);
 /* metal return (sph.hip) */
 #define SHQ_NMETALS 9
 struct MetalWalkArgs {

@@ -3383,7 +3383,7 @@ __global__ void wind_do_kick_kernel(long long n, const shq_wind_kick *k, const W
     atomicAdd(napplied, 1ull);
 }
 
-int shq_wind_resolve_device(shq_context *ctx, const WindWalkArgs *w, long long nk, shq_wind_kick *d_sorted, unsigned long long *d_napplied, int *d_odd)
+int shq_wind_resolve_device(shq_context *ctx, const WindWalkArgs *w, long long nk, shq_wind_kick *d_sorted, unsigned long long *d_napplied, int *d_odd, bool apply)
 {
     if(nk == 0)
         return SHQ_OK;
@@ -3406,8 +3406,11 @@ int shq_wind_resolve_device(shq_context *ctx, const WindWalkArgs *w, long long n
     }
     wind_kick_gather_kernel<<<dim3(nblk(nk)), dim3(256), 0, st>>>(nk, w->kicks, cur, d_sorted);
     SHQ_HIP(hipGetLastError());
-    wind_do_kick_kernel<<<dim3(nblk(nk)), dim3(256), 0, st>>>(nk, d_sorted, *w, ctx->vel.ptr, ctx->g_entropy.ptr, ctx->g_density.ptr, ctx->g_delaytime.ptr, d_napplied, d_odd);
-    SHQ_HIP(hipGetLastError());
+    if(apply) {
+        wind_do_kick_kernel<<<dim3(nblk(nk)), dim3(256), 0, st>>>(nk, d_sorted, *w, ctx->vel.ptr, ctx->g_entropy.ptr, ctx->g_density.ptr, ctx->g_delaytime.ptr, d_napplied,
+                                                                  d_odd);
+        SHQ_HIP(hipGetLastError());
+    }
     return SHQ_OK;
 }
 

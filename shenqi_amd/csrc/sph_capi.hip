@@ -1264,9 +1264,35 @@ extern "C" int shq_bh_feedback(shq_context *ctx, const shq_tree_view *tree, cons
 }
 
 /* ---- winds_and_feedback (winds.cpp:295-369) ------------------------------------------------------------------------------------ */
-extern "C" int shq_winds_and_feedback(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph, const shq_star_view *stars,
+namespace {
+/* Vel, Entropy, DelayTime of the kicked particles (the first of every run of the sorted list) back into the caller's arrays */
+int winds_kicked_back(shq_context *ctx, const shq_part_view *parts, const shq_sph_view *sph, const std::vector<shq_wind_kick> &K)
+{
+    const int64_t n = parts->numpart;
+    hipStream_t st = ctx->stream;
+    std::vector<double> hv(3 * (size_t) n), he((size_t) n), hdl((size_t) n);
+    SHQ_HIP(hipMemcpyAsync(hv.data(), ctx->vel.ptr, sizeof(double) * 3 * (size_t) n, hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipMemcpyAsync(he.data(), ctx->g_entropy.ptr, sizeof(double) * (size_t) n, hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipMemcpyAsync(hdl.data(), ctx->g_delaytime.ptr, sizeof(double) * (size_t) n, hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    int32_t last = -1;
+    for(const shq_wind_kick &k : K) {
+        if(k.part_index == last)
+            continue;
+        const int32_t other = last = k.part_index;
+        const int32_t pi = *pfield<int32_t>(parts, other, parts->off_pi);
+        double *v = pfield_w<double>(parts, other, parts->off_vel);
+        for(int j = 0; j < 3; j++)
+            v[j] = hv[3 * (size_t) other + j];
+        *sfield(sph, pi, sph->off_entropy) = he[(size_t) other];
+        *sfield(sph, pi, sph->off_delaytime) = hdl[(size_t) other];
+    }
+    return SHQ_OK;
+}
+
+int winds_impl(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph, const shq_star_view *stars,
                                       const uint64_t *ids, const int32_t *NewStars, int64_t NumNewStars, const shq_wind_params *params, const double *rnd_table,
-                                      int64_t rnd_size, double *TotalWeight, shq_wind_kick *kicks, int64_t kicks_capacity, int64_t *nkicks, int64_t *nkicked)
+                                      int64_t rnd_size, double *TotalWeight, shq_wind_kick *kicks, int64_t kicks_capacity, int64_t *nkicks, int64_t *nkicked, bool apply)
 {
     SHQ_CHECK(ctx && tree && parts && sph && stars && ids && params && rnd_table && (NumNewStars == 0 || NewStars), SHQ_ERR_INVALID, "null argument");
     SHQ_CHECK(ctx->sphrun.phase == 0, SHQ_ERR_STATE, "winds_and_feedback: an SPH walk is open");
@@ -1351,35 +1377,87 @@ extern "C" int shq_winds_and_feedback(shq_context *ctx, const shq_tree_view *tre
         SHQ_TRY(ctx->bhw_rec.reserve((size_t) nk * sizeof(shq_wind_kick)));
         shq_wind_kick *d_sorted = reinterpret_cast<shq_wind_kick *>(ctx->bhw_rec.ptr);
         SHQ_HIP(hipMemsetAsync(ctx->wind_cnt.ptr + 2, 0, sizeof(unsigned long long) * 2, st));
-        SHQ_TRY(shq_wind_resolve_device(ctx, &w, nk, d_sorted, ctx->wind_cnt.ptr + 2, reinterpret_cast<int *>(ctx->wind_cnt.ptr + 3)));
+        SHQ_TRY(shq_wind_resolve_device(ctx, &w, nk, d_sorted, ctx->wind_cnt.ptr + 2, reinterpret_cast<int *>(ctx->wind_cnt.ptr + 3), apply));
         unsigned long long res[2] = {0, 0};
         SHQ_HIP(hipMemcpyAsync(res, ctx->wind_cnt.ptr + 2, sizeof(res), hipMemcpyDeviceToHost, st));
         std::vector<shq_wind_kick> K((size_t) nk);
         SHQ_HIP(hipMemcpyAsync(K.data(), d_sorted, sizeof(shq_wind_kick) * (size_t) nk, hipMemcpyDeviceToHost, st));
-        std::vector<double> hv(3 * (size_t) n), he((size_t) n), hdl((size_t) n);
-        SHQ_HIP(hipMemcpyAsync(hv.data(), ctx->vel.ptr, sizeof(double) * 3 * (size_t) n, hipMemcpyDeviceToHost, st));
-        SHQ_HIP(hipMemcpyAsync(he.data(), ctx->g_entropy.ptr, sizeof(double) * (size_t) n, hipMemcpyDeviceToHost, st));
-        SHQ_HIP(hipMemcpyAsync(hdl.data(), ctx->g_delaytime.ptr, sizeof(double) * (size_t) n, hipMemcpyDeviceToHost, st));
         SHQ_HIP(hipStreamSynchronize(st));
         applied = (int64_t) res[0];
         if(kicks)
             memcpy(kicks, K.data(), sizeof(shq_wind_kick) * (size_t) nk);
-        int32_t last = -1;
-        for(const shq_wind_kick &k : K) { /* only the kicked particles changed */
-            if(k.part_index == last)
-                continue;
-            const int32_t other = last = k.part_index;
-            const int32_t pi = *pfield<int32_t>(parts, other, parts->off_pi);
-            double *v = pfield_w<double>(parts, other, parts->off_vel);
-            for(int j = 0; j < 3; j++)
-                v[j] = hv[3 * (size_t) other + j];
-            *sfield(sph, pi, sph->off_entropy) = he[(size_t) other];
-            *sfield(sph, pi, sph->off_delaytime) = hdl[(size_t) other];
-        }
+        if(apply)
+            SHQ_TRY(winds_kicked_back(ctx, parts, sph, K));
         SHQ_CHECK((int) (res[1] & 0xffffffffull) == 0, SHQ_ERR_STATE, "Odd v in a wind kick (winds.cpp:344)");
     }
     if(nkicked)
         *nkicked = applied;
+    return SHQ_OK;
+}
+} // namespace
+
+extern "C" int shq_winds_and_feedback(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph, const shq_star_view *stars,
+                                      const uint64_t *ids, const int32_t *NewStars, int64_t NumNewStars, const shq_wind_params *params, const double *rnd_table,
+                                      int64_t rnd_size, double *TotalWeight, shq_wind_kick *kicks, int64_t kicks_capacity, int64_t *nkicks, int64_t *nkicked)
+{
+    return winds_impl(ctx, tree, parts, sph, stars, ids, NewStars, NumNewStars, params, rnd_table, rnd_size, TotalWeight, kicks, kicks_capacity, nkicks, nkicked, true);
+}
+
+extern "C" int shq_winds_candidates(shq_context *ctx, const shq_tree_view *tree, const shq_part_view *parts, const shq_sph_view *sph, const shq_star_view *stars,
+                                    const uint64_t *ids, const int32_t *NewStars, int64_t NumNewStars, const shq_wind_params *params, const double *rnd_table,
+                                    int64_t rnd_size, double *TotalWeight, shq_wind_kick *kicks, int64_t kicks_capacity, int64_t *nkicks)
+{
+    return winds_impl(ctx, tree, parts, sph, stars, ids, NewStars, NumNewStars, params, rnd_table, rnd_size, TotalWeight, kicks, kicks_capacity, nkicks, nullptr, false);
+}
+
+extern "C" int shq_winds_apply(shq_context *ctx, const shq_part_view *parts, const shq_sph_view *sph, const uint64_t *ids, const shq_wind_kick *kicks, int64_t nk,
+                               const shq_wind_params *params, const double *rnd_table, int64_t rnd_size, int64_t *nkicked)
+{
+    SHQ_CHECK(ctx && parts && sph && ids && params && rnd_table && (nk == 0 || kicks), SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(rnd_size > 0 && nk >= 0, SHQ_ERR_INVALID, "winds_apply: empty random table or bad list length");
+    SHQ_CHECK(sph->off_delaytime != SHQ_NOFIELD && parts->off_vel != SHQ_NOFIELD && parts->off_pi != SHQ_NOFIELD && parts->off_type != SHQ_NOFIELD, SHQ_ERR_INVALID,
+              "winds_apply: needs Vel, PI, Type and DelayTime");
+    if(nkicked)
+        *nkicked = 0;
+    const int64_t n = parts->numpart;
+    for(int64_t k = 0; k < nk; k++) {
+        SHQ_CHECK(kicks[k].part_index >= 0 && kicks[k].part_index < n && *pfield<uint8_t>(parts, kicks[k].part_index, parts->off_type) == 0, SHQ_ERR_INVALID,
+                  "winds_apply: kick %ld names particle %d, which is not a gas particle of this set", (long) k, kicks[k].part_index);
+        SHQ_CHECK(kicks[k].StarDistance >= 0, SHQ_ERR_INVALID, "winds_apply: negative distance in kick %ld", (long) k);
+    }
+    if(nk == 0)
+        return SHQ_OK;
+    SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_particles_upload(ctx, parts));
+    SHQ_TRY(sph_upload(ctx, parts, sph));
+    hipStream_t st = ctx->stream;
+    SHQ_TRY(ctx->bhw_ids.reserve((size_t) n));
+    SHQ_TRY(ctx->bhw_rnd.reserve((size_t) rnd_size));
+    SHQ_TRY(ctx->wind_cnt.reserve(4));
+    SHQ_TRY(ctx->wind_kicks.reserve((size_t) nk * sizeof(shq_wind_kick)));
+    SHQ_TRY(ctx->bhw_rec.reserve((size_t) nk * sizeof(shq_wind_kick)));
+    SHQ_HIP(hipMemcpyAsync(ctx->bhw_ids.ptr, ids, sizeof(uint64_t) * (size_t) n, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemcpyAsync(ctx->bhw_rnd.ptr, rnd_table, sizeof(double) * (size_t) rnd_size, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemcpyAsync(ctx->wind_kicks.ptr, kicks, sizeof(shq_wind_kick) * (size_t) nk, hipMemcpyHostToDevice, st));
+    SHQ_HIP(hipMemsetAsync(ctx->wind_cnt.ptr, 0, sizeof(unsigned long long) * 4, st));
+    WindWalkArgs w;
+    memset(&w, 0, sizeof(w));
+    w.ids = ctx->bhw_ids.ptr;
+    w.rnd = ctx->bhw_rnd.ptr;
+    w.rndsize = (unsigned long long) rnd_size;
+    w.kicks = reinterpret_cast<shq_wind_kick *>(ctx->wind_kicks.ptr);
+    w.P = *params;
+    shq_wind_kick *d_sorted = reinterpret_cast<shq_wind_kick *>(ctx->bhw_rec.ptr);
+    SHQ_TRY(shq_wind_resolve_device(ctx, &w, nk, d_sorted, ctx->wind_cnt.ptr + 2, reinterpret_cast<int *>(ctx->wind_cnt.ptr + 3), true));
+    unsigned long long res[2] = {0, 0};
+    SHQ_HIP(hipMemcpyAsync(res, ctx->wind_cnt.ptr + 2, sizeof(res), hipMemcpyDeviceToHost, st));
+    std::vector<shq_wind_kick> K((size_t) nk);
+    SHQ_HIP(hipMemcpyAsync(K.data(), d_sorted, sizeof(shq_wind_kick) * (size_t) nk, hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    SHQ_TRY(winds_kicked_back(ctx, parts, sph, K));
+    SHQ_CHECK((int) (res[1] & 0xffffffffull) == 0, SHQ_ERR_STATE, "Odd v in a wind kick (winds.cpp:344)");
+    if(nkicked)
+        *nkicked = (int64_t) res[0];
     return SHQ_OK;
 }
 

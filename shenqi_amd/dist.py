@@ -1048,3 +1048,117 @@ class DistExchange:
             if int(self._allsum([int(last.value < nex.value)])[0]) == 0:
                 break
         return numpart, slot_size
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Winds from new stars across ranks (libgadget/winds.cpp:295-369).  The reference exports every new star's query to the ranks whose
+# top leaves its Hsml touches and merges the StarKick queues afterwards; here, as for the SPH operators, every rank imports the gas
+# records within reach of its slab, runs the two walks for its own new stars on local + ghost gas, and sends the kick candidates
+# that fell on ghosts to the ghosts' owners, who resolve all candidates of their own particles (nearest star, then smaller star
+# ID: the same outcome whatever the decomposition) and kick.
+class DistWinds:
+    """P: numpy PARTICLE_DTYPE array of everything this rank owns (gas PI -> SphP, star PI -> StarP), IDs in P["ID"].
+    ops.candidates(Pall, Sall, StarP, newstars, prm, rnd) -> (TotalWeight by star slot, kicks: numpy array of capi.WIND_KICK_DTYPE),
+    ops.apply(P, SphP, kicks, prm, rnd) -> number kicked (GpuWindOps below; the CPU tests use the restatement)."""
+
+    def __init__(self, comm, decomp, ops):
+        self.comm, self.d, self.ops = comm, decomp, ops
+        self.nghost = self.nkicks = 0
+
+    def run(self, P, SphP, StarP, newstars, prm, rnd):
+        comm = self.comm
+        nloc = len(P)
+        newstars = np.asarray(newstars, dtype=np.int32)
+        reach = float(P["Hsml"][newstars].max()) if len(newstars) else 0.0
+        if comm.multi:
+            t = torch.tensor([reach], dtype=torch.float64)
+            if comm.backend == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=comm.group)
+            reach = float(t.item())
+        gas = np.flatnonzero((P["Type"] == 0) & ((P["Flags"] & 1) == 0))
+        # ghost gas: the record carries its owner and its index there in fields the walks do not read
+        G = P[gas].copy()
+        G["TopLeaf"] = comm.rank
+        G["GrNr"] = gas
+        rec = np.concatenate([G.view(np.uint8).reshape(len(G), -1), SphP[P["PI"][gas]].view(np.uint8).reshape(len(G), -1)], axis=1)
+        got = ghost_records(comm, self.d, torch.from_numpy(np.ascontiguousarray(G["Pos"][:, 0])), torch.zeros(len(G), dtype=torch.float64),
+                            torch.from_numpy(rec), [reach] * max(1, comm.size)).numpy()
+        ng = self.nghost = len(got)
+        psz = P.dtype.itemsize
+        Pall = np.empty(nloc + ng, dtype=P.dtype)
+        Pall[:nloc] = P
+        Pall[nloc:] = np.ascontiguousarray(got[:, :psz]).view(P.dtype).reshape(ng)
+        Sall = np.empty(len(SphP) + ng, dtype=SphP.dtype)
+        Sall[:len(SphP)] = SphP
+        Sall[len(SphP):] = np.ascontiguousarray(got[:, psz:]).view(SphP.dtype).reshape(ng)
+        Pall["PI"][nloc:] = len(SphP) + np.arange(ng)
+        tw, kicks = self.ops.candidates(Pall, Sall, StarP, newstars, prm, rnd)
+        # a candidate goes to the owner of its particle, with the particle's index there
+        part = kicks["part_index"].astype(np.int64)
+        ghost = part >= nloc
+        owner = np.full(len(kicks), comm.rank, dtype=np.int64)
+        owner[ghost] = Pall["TopLeaf"][part[ghost]]
+        kicks = kicks.copy()
+        kicks["part_index"][ghost] = Pall["GrNr"][part[ghost]]
+        if comm.multi:
+            order = np.argsort(owner, kind="stable")
+            counts = np.bincount(owner, minlength=comm.size).tolist()
+            rows = np.ascontiguousarray(kicks[order]).view(np.int64).reshape(len(kicks), -1)      # 40-byte records as five int64 words
+            recv, _ = comm.all_to_all_rows(torch.from_numpy(rows), counts)
+            kicks = np.ascontiguousarray(recv.numpy()).view(kicks.dtype).reshape(-1)
+        self.nkicks = len(kicks)
+        applied = self.ops.apply(P, SphP, kicks, prm, rnd)
+        return tw, applied
+
+
+class GpuWindOps:
+    """DistWinds' two steps on the device library (shq_winds_candidates / shq_winds_apply) through the host mirror's tree builder."""
+
+    def __init__(self, ctx, BoxSize):
+        import shenqi_amd as sq
+        self.sq, self.ctx, self.L = sq, ctx, BoxSize
+
+    def _pman(self, Pall):
+        pman = self.sq.PartManager(len(Pall), self.L)
+        pman.Base[:] = Pall
+        return pman
+
+    def _params(self, prm):
+        p = capi.WindParams()
+        for k, _ in capi.WindParams._fields_:
+            if k != "pad_":
+                setattr(p, k, getattr(prm, k))
+        return p
+
+    def candidates(self, Pall, Sall, StarP, newstars, prm, rnd):
+        sq = self.sq
+        pman = self._pman(Pall)
+        tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
+        ids = np.ascontiguousarray(Pall["ID"])
+        new = np.ascontiguousarray(newstars, dtype=np.int32)
+        rnd = np.ascontiguousarray(rnd, dtype=np.float64)
+        tw = np.zeros(len(StarP))
+        pv, tv, sv = pman.view(), tree.view(), capi.sph_view(Sall)
+        stv = capi.StarView(StarP.ctypes.data, StarP.dtype.itemsize, len(StarP), StarP.dtype.fields["VDisp"][1])
+        cp = self._params(prm)
+        nk = C.c_int64()
+        capi.check(capi.hip.shq_winds_candidates(self.ctx.h, C.byref(tv), C.byref(pv), C.byref(sv), C.byref(stv), capi.ptr(ids), capi.ptr(new), len(new), C.byref(cp),
+                                                 capi.ptr(rnd), len(rnd), capi.ptr(tw), None, 0, C.byref(nk)))
+        kicks = np.zeros(max(nk.value, 1), dtype=capi.WIND_KICK_DTYPE)
+        capi.check(capi.hip.shq_winds_candidates(self.ctx.h, C.byref(tv), C.byref(pv), C.byref(sv), C.byref(stv), capi.ptr(ids), capi.ptr(new), len(new), C.byref(cp),
+                                                 capi.ptr(rnd), len(rnd), capi.ptr(tw), capi.ptr(kicks), len(kicks), C.byref(nk)))
+        return tw, kicks[:nk.value]
+
+    def apply(self, P, SphP, kicks, prm, rnd):
+        pman = self._pman(P)
+        ids = np.ascontiguousarray(P["ID"])
+        rnd = np.ascontiguousarray(rnd, dtype=np.float64)
+        kicks = np.ascontiguousarray(kicks, dtype=capi.WIND_KICK_DTYPE)
+        pv, sv = pman.view(), capi.sph_view(SphP)
+        cp = self._params(prm)
+        na = C.c_int64()
+        capi.check(capi.hip.shq_winds_apply(self.ctx.h, C.byref(pv), C.byref(sv), capi.ptr(ids), capi.ptr(kicks), len(kicks), C.byref(cp), capi.ptr(rnd), len(rnd),
+                                            C.byref(na)))
+        P["Vel"] = pman.Base["Vel"]
+        return na.value

@@ -351,3 +351,34 @@ def test_dist_exchange_two_gloo_ranks_one_gpu(maxlast):
             out.append((d["P"], d["n"], d["S"], d["sz"]))
         fx.check_after(out, world, world * 88)
         assert oit == (1 if maxlast == 0 else oit) and (maxlast == 0 or oit >= 4)
+
+
+def _winds_worker(rank, world, initfile, outdir):
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        import pickle
+        import shenqi_amd as sq
+        from shenqi_amd import dist as sd
+        import test_dist_winds_cpu as tdw
+        with sq.Context(0) as ctx:
+            res = tdw.run_rank(sd.Comm(), rank, sd.GpuWindOps(ctx, tdw.global_set()[5].BoxSize))
+        with open(os.path.join(outdir, "r%d.pkl" % rank), "wb") as f:
+            pickle.dump(res, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dist_winds_two_gloo_ranks_one_gpu():
+    """DistWinds with the DEVICE walks and kicks (shq_winds_candidates / shq_winds_apply) on two ranks sharing the GPU: the kick
+    candidates that fall on imported ghosts travel to their owners; same kicks as the undivided restatement"""
+    import pickle
+    import test_dist_winds_cpu as tdw
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_winds_worker, args=(2, os.path.join(tmp, "init"), tmp), nprocs=2, join=True)
+        results = []
+        for r in range(2):
+            with open(os.path.join(tmp, "r%d.pkl" % r), "rb") as f:
+                results.append(pickle.load(f))
+        tdw.check(results, exact=False)
+        assert all(r["nghost"] > 0 for r in results)
