@@ -219,11 +219,18 @@ extern "C" void shq_shutdown(shq_context *ctx)
     for(auto &b : ctx->fof_u64) b.release();
     for(auto &b : ctx->fof_gkey) b.release();
     for(auto &b : ctx->fof_goff) b.release();
+    ctx->hilb_iota.release();
+    ctx->bhw_bhp.release(); ctx->bhw_queue.release(); ctx->bhw_rec.release(); ctx->bhw_ids.release(); ctx->bhw_sphsw.release(); ctx->bhw_bhsw.release();
+    ctx->bhw_swid.release(); ctx->bhw_rnd.release(); ctx->bhw_out.release(); ctx->bhw_eeqos.release(); ctx->bhw_heated.release();
+    ctx->wind_kicks.release(); ctx->wind_d.release(); ctx->wind_cnt.release();
+    for(auto &b : ctx->metal_keys) b.release();
+    for(auto &b : ctx->metal_val) b.release();
+    ctx->metal_star.release(); ctx->metal_gd.release(); ctx->metal_gf.release();
     ctx->velp.release(); ctx->hydC.release(); ctx->hydD.release(); ctx->velp_leaf.release(); ctx->hydrec_leaf.release();
     ctx->hsml_leaf.release(); ctx->flag_leaf.release();
     ctx->s_numngb.release(); ctx->s_dhsmldens.release(); ctx->s_left.release(); ctx->s_right.release(); ctx->s_rot.release();
     ctx->s_gradrho.release(); ctx->s_evp_in.release(); ctx->s_todo.release(); ctx->s_queue2.release(); ctx->s_queue3.release();
-    ctx->tb.release(); ctx->tree_targets.release(); ctx->ps_sums.release(); ctx->ps_bintab.release(); ctx->s_blockcount.release(); ctx->s_nlist.release(); ctx->s_ncount.release(); ctx->s_redo.release(); ctx->s_counters.release(); ctx->pm_oob.release(); ctx->fft_tw.release();
+    ctx->tb.release(); ctx->tree_targets.release(); ctx->ps_sums.release(); ctx->ps_bintab.release(); ctx->s_blockcount.release(); ctx->s_nlist.release(); ctx->s_ncount.release(); ctx->s_redo.release(); ctx->s_redo2.release(); ctx->s_counters.release(); ctx->pm_oob.release(); ctx->fft_tw.release();
     for(int i = 0; i < SHQ_NTIMERS; i++) {
         (void) hipEventDestroy(ctx->ev_begin[i]);
         (void) hipEventDestroy(ctx->ev_end[i]);
