@@ -266,3 +266,58 @@ def test_fof_group_sums_of_slot_quantities(ctx):
     assert (sums[:, 4] == 0).all()
     with pytest.raises(sq.ShqError):
         capi.check(capi.hip.shq_fof_group_sums(ctx.h, None, 3, capi.ptr(sums)))
+
+
+def test_fof_properties_at_scale_on_the_cluster(ctx):
+    """128^3 particles of the bench's S-cluster (two groups of ~10^6 members around a caustic, cliques many levels deep): what a
+    friends-of-friends catalogue must satisfy whatever its size — friends share a label (a sample of particles against a k-d tree of
+    all), small groups are connected and complete, lengths add up, the label is the smallest member ID"""
+    from scipy.spatial import cKDTree
+    n1 = 128
+    n = n1**3
+    L = 1.0
+    pos = sq.synth_positions("cluster", n, L=L)
+    rng = np.random.default_rng(2)
+    ids = rng.permutation(n).astype(np.uint64) + 1
+    types = np.ones(n, dtype=np.uint8)
+    linkl = 0.2 * L / n1
+    minid, grnr, groups, members, _ = gpu_fof(ctx, pos, np.zeros((n, 3)), np.ones(n), types, ids, L, linkl, 2)
+    assert len(groups) >= 2 and groups["Length"].max() > n // 20
+    # lengths, numbering and labels
+    assert int(groups["Length"].sum()) == len(members) == int((grnr > 0).sum())
+    assert np.array_equal(np.sort(groups["GrNr"]), np.arange(1, len(groups) + 1))
+    order = np.argsort(groups["GrNr"])
+    assert (np.diff(groups["Length"][order]) <= 0).all()
+    low = np.full(len(groups), np.iinfo(np.uint64).max, dtype=np.uint64)
+    gi = np.repeat(np.arange(len(groups)), groups["Length"])
+    np.minimum.at(low, gi, ids[members])
+    assert np.array_equal(low, groups["MinID"]) and np.array_equal(minid[members], groups["MinID"][gi])
+    # friends share a label: a sample from the dense core, the outskirts and the field
+    tree = cKDTree(np.mod(pos, L), boxsize=L)
+    sample = np.concatenate([rng.choice(n, 1500, replace=False), members[rng.choice(len(members), 1500, replace=False)]])
+    for i in sample:
+        nb = tree.query_ball_point(np.mod(pos[i], L), linkl * (1 - 1e-12))
+        assert (minid[nb] == minid[i]).all()
+    # small groups: connected through links <= linkl, and nothing within linkl of a member is left outside
+    small = np.flatnonzero(groups["Length"] <= 64)[:40]
+    assert len(small) >= 5
+    for g in small:
+        mem = members[groups["first_member"][g]:groups["first_member"][g] + groups["Length"][g]]
+        sub = cKDTree(np.mod(pos[mem], L), boxsize=L)
+        pairs = sub.query_pairs(linkl * (1 + 1e-12), output_type="ndarray")
+        reach = {0}
+        frontier = [0]
+        adj = {}
+        for a, b in pairs:
+            adj.setdefault(int(a), []).append(int(b))
+            adj.setdefault(int(b), []).append(int(a))
+        while frontier:
+            x = frontier.pop()
+            for y in adj.get(x, []):
+                if y not in reach:
+                    reach.add(y)
+                    frontier.append(y)
+        assert len(reach) == len(mem)
+        for i in mem:
+            nb = tree.query_ball_point(np.mod(pos[i], L), linkl * (1 - 1e-12))
+            assert np.isin(nb, mem).all()
