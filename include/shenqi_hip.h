@@ -1093,6 +1093,10 @@ int shq_pm_slab_pitch(int Nmesh);
 int shq_pm_slab2_deposit(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, int xoff, int nalloc,
                          void *d_mesh_i64);
 int shq_pm_slab2_fft_yz(shq_context *ctx, int Nmesh, void *d_planes, int nplanes, int direction);
+/* the same with the pack / unpack of the mesh transposes fused into the Y pass: direction 0 stores the (y, z) spectrum of the planes
+ * into d_packed = [nranks][nplanes][Nmesh / nranks][pitch / 2] complex (rows [destination rank][x plane]: the send buffer of the
+ * all-to-all), direction 1 starts from d_packed in that layout (what the return all-to-all delivers: rows [source rank][x plane]) */
+int shq_pm_slab2_fft_yz_packed(shq_context *ctx, int Nmesh, void *d_planes, int nplanes, int direction, void *d_packed, int nranks);
 int shq_pm_slab2_xgreen(shq_context *ctx, const shq_pm_params *pm, void *d_spec, int y0, int nyl);
 int shq_pm_slab2_readout(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, int xoff, int nalloc,
                          const void *d_phi);

@@ -436,6 +436,8 @@ int shq_fft3d_run(shq_context *ctx, double *d_mesh, int N, int zp, int stage, bo
                   const double *d_sinctab, double asmth2, double pot_factor);
 int shq_fft3d_run_slab(shq_context *ctx, double *d_mesh, int N, int zp, int stage, bool from_i64, double inv_scale,
                        const double *d_sinctab, double asmth2, double pot_factor, int nslab, int y0);
+int shq_fft3d_run_slab_packed(shq_context *ctx, double *d_mesh, int N, int zp, int stage, bool from_i64, double inv_scale,
+                              const double *d_sinctab, double asmth2, double pot_factor, int nslab, int y0, double *d_packed, int nranks);
 /* sph.hip */
 int shq_sph_prepare(shq_context *ctx, const shq_kick_factors *kf, const shq_hydro_params *hp, const double *d_evp_in);
 int shq_sph_density_device(shq_context *ctx, const shq_density_params *p, const int32_t *d_queue, int64_t nq,

@@ -369,9 +369,15 @@ struct GreenArgs {
     const double *sinctab; /* 1 / sinc^2(pi k / N) per mesh index */
     double asmth2, pot_factor;
     int y0;                /* mesh index of outer = 0 in the X pass (y-slab of a distributed mesh) */
+    /* PK != 0 (Y pass of a distributed mesh): the transposed side of the pass lives in `alt`, laid out as the all-to-all wants it,
+     * [dest rank q][x plane][y inside q's slab][z']: line element y sits at alt + (y / nyl) qstride + outer alt_outer + (y % nyl) es */
+    double2 *alt;
+    int nyl;
+    long long qstride, alt_outer;
 };
 
-template <int N, int MODE>
+/* PK 0: in place.  PK 1: results stored into ga.alt in the packed (send) layout.  PK 2: input loaded from ga.alt in that layout. */
+template <int N, int MODE, int PK = 0>
 __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const long long es, const long long outer_stride,
                                                           const int ntiles, const int ntot, const double2 *__restrict__ W,
                                                           const GreenArgs ga, const unsigned xcdk)
@@ -392,12 +398,14 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
      * bytes), so they should run on the same XCD at about the same time and find the other half in its L2. */
     const unsigned vb = xcd_block(blockIdx.x, gridDim.x, xcdk);
     double prx[E], pry[E];
-#define FFT_FETCH(BASE)                                                                          \
+#define FFT_FETCH(BASE, ABASE)                                                                   \
     _Pragma("unroll") for(int i = 0; i < E; i++)                                                 \
     {                                                                                            \
         const int e = threadIdx.x + i * FFT_T;                                                   \
         if(EXACT || e < FFT_C * N) {                                                             \
-            const double2 t_ = (BASE)[(long long) (e / FFT_C) * es + (e % FFT_C)];               \
+            const int r_ = e / FFT_C, c_ = e % FFT_C;                                            \
+            const double2 t_ = PK == 2 ? (ABASE)[(long long) (r_ / ga.nyl) * ga.qstride + (long long) (r_ % ga.nyl) * es + c_] \
+                                       : (BASE)[(long long) r_ * es + c_];                       \
             prx[i] = t_.x;                                                                       \
             pry[i] = t_.y;                                                                       \
         }                                                                                        \
@@ -407,7 +415,8 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
         return;
     int outer = t / ntiles, tile = t - outer * ntiles;
     double2 *base = cm + (long long) outer * outer_stride + (long long) tile * FFT_C;
-    FFT_FETCH(base)
+    double2 *abase = PK ? ga.alt + (long long) outer * ga.alt_outer + (long long) tile * FFT_C : nullptr;
+    FFT_FETCH(base, abase)
     while(true) {
 #pragma unroll
         for(int i = 0; i < E; i++) {
@@ -420,7 +429,8 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
         const bool more = tn < ntot;
         const int outer_n = more ? tn / ntiles : outer, tile_n = more ? tn - outer_n * ntiles : tile;
         double2 *base_n = cm + (long long) outer_n * outer_stride + (long long) tile_n * FFT_C;
-        FFT_FETCH(base_n)
+        double2 *abase_n = PK ? ga.alt + (long long) outer_n * ga.alt_outer + (long long) tile_n * FFT_C : nullptr;
+        FFT_FETCH(base_n, abase_n)
         if(MODE == 0)
             fft_lines<N, -1>(buf, Wl);
         if(MODE == 2) {
@@ -444,7 +454,10 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
             fft_lines<N, +1>(buf, Wl);
         for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T) {
             const int row = e / FFT_C, col = e - row * FFT_C;
-            base[(long long) row * es + col] = buf[col * LS + row];
+            if(PK == 1)
+                abase[(long long) (row / ga.nyl) * ga.qstride + (long long) (row % ga.nyl) * es + col] = buf[col * LS + row];
+            else
+                base[(long long) row * es + col] = buf[col * LS + row];
         }
         if(!more)
             break;
@@ -453,6 +466,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
         outer = outer_n;
         tile = tile_n;
         base = base_n;
+        abase = abase_n;
     }
 #undef FFT_FETCH
 }
@@ -478,14 +492,15 @@ int run_n(shq_context *ctx, double *d_mesh, int zp, int stage, bool from_i64, do
     /* persistent grids: as many workgroups as are resident on the chip at once (LDS-limited) */
     static unsigned res_zf = 0, res_zi = 0, res_s = 0;
     if(res_s == 0) {
-        const void *fns[6] = {(const void *) fft_pass_z_fwd<N, true>, (const void *) fft_pass_z_fwd<N, false>,
+        const void *fns[8] = {(const void *) fft_pass_z_fwd<N, true>, (const void *) fft_pass_z_fwd<N, false>,
                               (const void *) fft_pass_z_inv<N>,       (const void *) fft_pass_strided<N, 0>,
-                              (const void *) fft_pass_strided<N, 1>,  (const void *) fft_pass_strided<N, 2>};
+                              (const void *) fft_pass_strided<N, 1>,  (const void *) fft_pass_strided<N, 2>,
+                              (const void *) fft_pass_strided<N, 0, 1>, (const void *) fft_pass_strided<N, 1, 2>};
         int ncu = 0;
         if(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || ncu < 1)
             ncu = 256;
-        unsigned occ[6];
-        for(int i = 0; i < 6; i++) {
+        unsigned occ[8];
+        for(int i = 0; i < 8; i++) {
             if(lds > 48 * 1024) /* allow > 48 KB of dynamic LDS */
                 SHQ_HIP(hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
             int per_cu = 0;
@@ -497,6 +512,8 @@ int run_n(shq_context *ctx, double *d_mesh, int zp, int stage, bool from_i64, do
         res_zi = occ[2];
         res_s = occ[3] < occ[4] ? occ[3] : occ[4];
         res_s = res_s < occ[5] ? res_s : occ[5];
+        res_s = res_s < occ[6] ? res_s : occ[6];
+        res_s = res_s < occ[7] ? res_s : occ[7];
     }
     const unsigned gmul = getenv("SHQ_FFT_GRID_MUL") ? (unsigned) atoi(getenv("SHQ_FFT_GRID_MUL")) : 8u;
     auto grid = [&](int tot, unsigned resident) {
@@ -507,6 +524,20 @@ int run_n(shq_context *ctx, double *d_mesh, int zp, int stage, bool from_i64, do
     const unsigned xcdk = getenv("SHQ_FFT_XCD_K") ? (unsigned) atoi(getenv("SHQ_FFT_XCD_K")) : 8u;
     if(stage == 12) { /* lines along x of a y-slab: element stride nslab * zpc, outer = local y */
         fft_pass_strided<N, 2><<<gs, dim3(FFT_T), lds, s>>>(cm, (long long) nslab * zpc, zpc, ntiles, stot, W, ga, xcdk);
+        SHQ_HIP(hipGetLastError());
+        return SHQ_OK;
+    }
+    if(stage == 13 || stage == 14) { /* stages 10 / 11 with the Y pass writing / reading the all-to-all layout in ga.alt */
+        if(stage == 13) {
+            if(from_i64)
+                fft_pass_z_fwd<N, true><<<gzf, dim3(FFT_T), lds, s>>>(d_mesh, ztot, zp, W, inv_scale);
+            else
+                fft_pass_z_fwd<N, false><<<gzf, dim3(FFT_T), lds, s>>>(d_mesh, ztot, zp, W, 1.0);
+            fft_pass_strided<N, 0, 1><<<gs, dim3(FFT_T), lds, s>>>(cm, zpc, (long long) N * zpc, ntiles, stot, W, ga, xcdk);
+        } else {
+            fft_pass_strided<N, 1, 2><<<gs, dim3(FFT_T), lds, s>>>(cm, zpc, (long long) N * zpc, ntiles, stot, W, ga, xcdk);
+            fft_pass_z_inv<N><<<gzi, dim3(FFT_T), lds, s>>>(d_mesh, ztot, zp, W);
+        }
         SHQ_HIP(hipGetLastError());
         return SHQ_OK;
     }
@@ -590,6 +621,13 @@ int shq_fft3d_run(shq_context *ctx, double *d_mesh, int N, int zp, int stage, bo
 int shq_fft3d_run_slab(shq_context *ctx, double *d_mesh, int N, int zp, int stage, bool from_i64, double inv_scale,
                        const double *d_sinctab, double asmth2, double pot_factor, int nslab, int y0)
 {
+    return shq_fft3d_run_slab_packed(ctx, d_mesh, N, zp, stage, from_i64, inv_scale, d_sinctab, asmth2, pot_factor, nslab, y0, nullptr, 1);
+}
+
+/* stages 13 / 14: as 10 / 11, the spectrum's transposed side in d_packed = [nranks][nslab][N / nranks][zp / 2] complex */
+int shq_fft3d_run_slab_packed(shq_context *ctx, double *d_mesh, int N, int zp, int stage, bool from_i64, double inv_scale,
+                              const double *d_sinctab, double asmth2, double pot_factor, int nslab, int y0, double *d_packed, int nranks)
+{
     SHQ_CHECK(shq_fft3d_supported(N), SHQ_ERR_INVALID, "fft3d: unsupported mesh size %d", N);
     SHQ_CHECK(nslab > 0 && nslab <= N && y0 >= 0 && y0 + (stage == 12 ? nslab : 0) <= N, SHQ_ERR_INVALID, "fft3d: bad slab geometry");
     SHQ_CHECK(zp >= N + 2 && zp % 8 == 0, SHQ_ERR_INVALID, "fft3d: pitch %d must be a multiple of 8 doubles and >= N+2", zp);
@@ -599,6 +637,15 @@ int shq_fft3d_run_slab(shq_context *ctx, double *d_mesh, int N, int zp, int stag
     ga.asmth2 = asmth2;
     ga.pot_factor = pot_factor;
     ga.y0 = y0;
+    ga.alt = reinterpret_cast<double2 *>(d_packed);
+    ga.nyl = 1;
+    ga.qstride = ga.alt_outer = 0;
+    if(stage == 13 || stage == 14) {
+        SHQ_CHECK(d_packed && nranks >= 1 && N % nranks == 0, SHQ_ERR_INVALID, "fft3d: packed stages need a buffer and a rank count that divides the mesh");
+        ga.nyl = N / nranks;
+        ga.alt_outer = (long long) ga.nyl * (zp / 2);
+        ga.qstride = (long long) nslab * ga.alt_outer;
+    }
 #define SHQ_FFT_CASE(NN) case NN: return run_n<NN>(ctx, d_mesh, zp, stage, from_i64, inv_scale, ga, nslab)
     switch(N) {
         SHQ_FFT_CASE(16); SHQ_FFT_CASE(24); SHQ_FFT_CASE(32); SHQ_FFT_CASE(40); SHQ_FFT_CASE(48); SHQ_FFT_CASE(64);

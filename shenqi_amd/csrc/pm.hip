@@ -886,6 +886,21 @@ extern "C" int shq_pm_slab2_fft_yz(shq_context *ctx, int Nmesh, void *d_planes, 
                               ldexp(1.0, -ctx->pm_log2scale), ctx->sinctab.ptr, 0, 0, nplanes, 0);
 }
 
+/* the same two stages with the pack / unpack of the transposes fused into the Y pass: direction 0 leaves the (y, z) spectrum of the
+ * planes in d_packed = [nranks][nplanes][N / nranks][zp / 2] (complex) — rows [destination rank][x plane], what the all-to-all sends —
+ * and direction 1 starts from d_packed in that layout (what the return all-to-all delivers) */
+extern "C" int shq_pm_slab2_fft_yz_packed(shq_context *ctx, int Nmesh, void *d_planes, int nplanes, int direction, void *d_packed, int nranks)
+{
+    SHQ_CHECK(ctx && d_planes && d_packed, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(nranks >= 1 && Nmesh % nranks == 0, SHQ_ERR_INVALID, "pm_slab2_fft_yz_packed: %d ranks do not divide the mesh", nranks);
+    SHQ_TRY(shq_join_pm(ctx));
+    SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(slab_sinctab(ctx, Nmesh));
+    const int zp = shq_fft3d_pitch(Nmesh);
+    return shq_fft3d_run_slab_packed(ctx, (double *) d_planes, Nmesh, zp, direction == 0 ? 13 : 14, direction == 0, ldexp(1.0, -ctx->pm_log2scale), ctx->sinctab.ptr, 0,
+                                     0, nplanes, 0, (double *) d_packed, nranks);
+}
+
 /* X forward + potential_transfer + X inverse on the y-slab [N][nyl][zp / 2] (complex) received by the transpose */
 extern "C" int shq_pm_slab2_xgreen(shq_context *ctx, const shq_pm_params *pm, void *d_spec, int y0, int nyl)
 {

@@ -323,12 +323,19 @@ class SlabPM:
             ghost = c.shift(buf[xoff + nxl:xoff + nxl + 1].contiguous(), +1)
             buf[xoff:xoff + 1] += ghost
         own = buf[xoff:xoff + nxl]
-        ops.fft_yz(own, nxl, 0)
-        spec = own.view(torch.float64).view(torch.complex128)               # [nxl, N, zpc]
         nyl = N // P
+        # the pack / unpack around the transposes: fused into the Y pass of the FFT (SHQ_DIST_FUSED_PACK=0: torch permute copies)
+        fused = multi and hasattr(ops, "fft_yz_packed") and os.environ.get("SHQ_DIST_FUSED_PACK", "1") != "0"
+        if fused:
+            send = torch.empty((P * nxl, nyl, zpc), dtype=torch.complex128, device=buf.device)      # rows [dest q][x_l]
+            ops.fft_yz_packed(own, nxl, 0, send, P)
+        else:
+            ops.fft_yz(own, nxl, 0)
+        spec = own.view(torch.float64).view(torch.complex128)               # [nxl, N, zpc]
         hooks = list(hooks) + [None, None]
         if multi:
-            send = spec.reshape(nxl, P, nyl, zpc).permute(1, 0, 2, 3).reshape(P * nxl, nyl, zpc)   # rows [dest q][x_l]
+            if not fused:
+                send = spec.reshape(nxl, P, nyl, zpc).permute(1, 0, 2, 3).reshape(P * nxl, nyl, zpc)   # rows [dest q][x_l]
             pend = c.all_to_all_rows_start(send, [nxl] * P, self.d.widths)                         # [x (all)][y_l][z']
             del send
             if hooks[0]:
@@ -343,12 +350,16 @@ class SlabPM:
             pend = c.all_to_all_rows_start(spec_t, self.d.widths, [nxl] * P)                       # rows [src q][x_l]
             if hooks[1]:
                 hooks[1]()
-            recv = pend.wait()
-            spec.copy_(recv.reshape(P, nxl, nyl, zpc).permute(1, 0, 2, 3).reshape(nxl, N, zpc))
+            recv = pend.wait()                                                                     # rows [src q][x_l]
+            if fused:
+                ops.fft_yz_packed(own, nxl, 1, recv.contiguous(), P)
+            else:
+                spec.copy_(recv.reshape(P, nxl, nyl, zpc).permute(1, 0, 2, 3).reshape(nxl, N, zpc))
             del recv, pend
         elif hooks[1]:
             hooks[1]()
-        ops.fft_yz(own, nxl, 1)
+        if not fused:
+            ops.fft_yz(own, nxl, 1)
         phi = buf.view(torch.float64)
         if P > 1:
             phi[0:2] = c.shift(phi[xoff + nxl - 2:xoff + nxl].contiguous(), +1)    # my last 2 -> right rank's left ghosts
@@ -453,6 +464,12 @@ class GpuOps:
     def fft_yz(self, planes, nplanes, direction):
         assert planes.is_contiguous()
         self._call(capi.hip.shq_pm_slab2_fft_yz, self.N, C.c_void_p(planes.data_ptr()), nplanes, direction)
+
+    def fft_yz_packed(self, planes, nplanes, direction, packed, nranks):
+        """fft_yz with the pack (direction 0) / unpack (direction 1) of the transposes fused into the Y pass: `packed` is the
+        all-to-all buffer [nranks * nplanes, N / nranks, zpc] complex"""
+        assert planes.is_contiguous() and packed.is_contiguous() and packed.dtype == torch.complex128
+        self._call(capi.hip.shq_pm_slab2_fft_yz_packed, self.N, C.c_void_p(planes.data_ptr()), nplanes, direction, C.c_void_p(packed.data_ptr()), nranks)
 
     def xgreen(self, spec_t, y0, nyl):
         assert spec_t.is_contiguous() and spec_t.dtype == torch.complex128
