@@ -538,7 +538,9 @@ int shq_blackhole_make_seeds(shq_context *ctx, const shq_exchange_layout *layout
  * there; here the member with the lowest particle index comes first and sums run in index order (one thread per group: deterministic).
  * The slot-resident sums (Sfr, metal masses, BH_Mass / BH_Mdot) stay with the caller: shq_fof_members hands it every group's member
  * list.  Several tasks (ghost labels through the export walk, fof_reduce_groups) are not covered.
- * shq_fof rebuilds the context's tree over the primary types (force_tree_rebuild_mask(&dmtree, ..., FOFPrimaryLinkTypes)).
+ * shq_fof builds its own tree over the primary types (force_tree_rebuild_mask(&dmtree, ..., FOFPrimaryLinkTypes)) in the context's
+ * tree storage and leaves the context WITHOUT a resident tree, as fof_fof frees its tree (fof.cpp:254): the next gravity / SPH /
+ * export call needs shq_tree_build or shq_tree_upload first and returns SHQ_ERR_STATE otherwise.
  * ids: Part[].ID by particle index (host).  minid_by_particle / grnr_by_particle (host, may be NULL): HaloLabel[].MinID and Part[].GrNr
  * (-1 outside groups).  WindsDecoupleSph: winds_is_particle_decoupled applies (DelayTime > 0 gas never seeds). */
 typedef struct shq_fof_params {

@@ -181,6 +181,13 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
         ctx->walk_stats = atoi(v);
     if(const char *v = getenv("SHQ_XCD_K"))
         ctx->xcd_k = atoi(v);
+    if(const char *v = getenv("SHQ_WALK_PERSIST"))
+        ctx->walk_persist = atoi(v);
+    {
+        int ncu = 0;
+        if(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0)
+            ctx->num_cus = ncu;
+    }
     *out = ctx;
     return SHQ_OK;
 }
@@ -197,7 +204,7 @@ extern "C" void shq_shutdown(shq_context *ctx)
     (void) hipStreamSynchronize(ctx->stream);
     shq_pm_destroy_plans(ctx);
     ctx->posm.release(); ctx->oldacc.release(); ctx->treeacc.release(); ctx->gravpm.release();
-    ctx->pmpot.release(); ctx->acc.release(); ctx->pot.release(); ctx->nint.release();
+    ctx->pmpot.release(); ctx->acc.release(); ctx->pot.release(); ctx->nint.release(); ctx->walk_tasks.release();
     ctx->pflags.release(); ctx->active.release(); ctx->act_list.release(); ctx->act_sub.release(); ctx->act_counts.release(); ctx->act_temp.release(); ctx->act_flag.release();
     ctx->gq_res.release(); ctx->s_queue0.release(); ctx->s_nlist2.release(); ctx->topnodes.release(); ctx->topleaves.release(); ctx->top_counts.release(); ctx->top_table.release(); ctx->gstats.release(); ctx->nodeF.release(); ctx->walk_counters.release(); ctx->walk_pool_idx.release(); ctx->walk_pool_msk.release(); ctx->walk_chunk_cnt.release(); ctx->walk_chunk_next.release(); ctx->walk_group_head.release();
     ctx->nodeA.release(); ctx->nodeB.release(); ctx->nodeC.release(); ctx->nodeG.release();

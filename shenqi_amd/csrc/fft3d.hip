@@ -380,7 +380,7 @@ struct GreenArgs {
 template <int N, int MODE, int PK = 0>
 __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const long long es, const long long outer_stride,
                                                           const int ntiles, const int ntot, const double2 *__restrict__ W,
-                                                          const GreenArgs ga, const unsigned xcdk)
+                                                          const GreenArgs ga, const unsigned xcdk, const int tile0 = 0)
 {
     extern __shared__ double2 buf[];
     constexpr int LS = N + 1;
@@ -413,7 +413,9 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
     int t = (int) vb;
     if(t >= ntot)
         return;
-    int outer = t / ntiles, tile = t - outer * ntiles;
+    /* a launch covers the column tiles [tile0, tile0 + ntiles) of every outer index (all of them, or one z' chunk of the chained
+     * Y -> X -> Y sequence below) */
+    int outer = t / ntiles, tile = tile0 + (t - outer * ntiles);
     double2 *base = cm + (long long) outer * outer_stride + (long long) tile * FFT_C;
     double2 *abase = PK ? ga.alt + (long long) outer * ga.alt_outer + (long long) tile * FFT_C : nullptr;
     FFT_FETCH(base, abase)
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
         __syncthreads();
         const int tn = t + (int) gridDim.x;
         const bool more = tn < ntot;
-        const int outer_n = more ? tn / ntiles : outer, tile_n = more ? tn - outer_n * ntiles : tile;
+        const int outer_n = more ? tn / ntiles : outer, tile_n = more ? tile0 + (tn - outer_n * ntiles) : tile;
         double2 *base_n = cm + (long long) outer_n * outer_stride + (long long) tile_n * FFT_C;
         double2 *abase_n = PK ? ga.alt + (long long) outer_n * ga.alt_outer + (long long) tile_n * FFT_C : nullptr;
         FFT_FETCH(base_n, abase_n)
@@ -552,6 +554,31 @@ int run_n(shq_context *ctx, double *d_mesh, int zp, int stage, bool from_i64, do
             fft_pass_strided<N, 1><<<gs, dim3(FFT_T), lds, s>>>(cm, zpc, (long long) N * zpc, ntiles, stot, W, ga, xcdk);
             fft_pass_z_inv<N><<<gzi, dim3(FFT_T), lds, s>>>(d_mesh, ztot, zp, W);
         }
+        SHQ_HIP(hipGetLastError());
+        return SHQ_OK;
+    }
+    /* Chained middle passes (stage 2, full cube): Y forward, the fused X pass and Y inverse all work on lines inside one plane
+     * of constant z', so they can run chunk by chunk over z' — `chain` column tiles (chain x 64 bytes of every (x, y) row) at a
+     * time, about chain x 38 MB at 768^3 — and the chunk written by one pass is still in the 256 MB Infinity Cache when the next
+     * pass reads it: the mesh crosses the HBM interface three times (Z forward, the chain, Z inverse) instead of five. */
+    static const int chain_env = getenv("SHQ_FFT_CHAIN") ? atoi(getenv("SHQ_FFT_CHAIN")) : -1;
+    int chain = chain_env;
+    if(chain < 0) /* default: chunks of about 100 MB */
+        chain = (int) ((100.0e6) / ((double) N * N * FFT_C * sizeof(double2)) + 0.5);
+    if(stage == 2 && nslab == N && chain > 0 && chain < ntiles) {
+        if(from_i64)
+            fft_pass_z_fwd<N, true><<<gzf, dim3(FFT_T), lds, s>>>(d_mesh, ztot, zp, W, inv_scale);
+        else
+            fft_pass_z_fwd<N, false><<<gzf, dim3(FFT_T), lds, s>>>(d_mesh, ztot, zp, W, 1.0);
+        for(int t0 = 0; t0 < ntiles; t0 += chain) {
+            const int tw = t0 + chain <= ntiles ? chain : ntiles - t0;
+            const int ctot = N * tw;
+            const dim3 gc = grid(ctot, res_s);
+            fft_pass_strided<N, 0><<<gc, dim3(FFT_T), lds, s>>>(cm, zpc, (long long) N * zpc, tw, ctot, W, ga, xcdk, t0);
+            fft_pass_strided<N, 2><<<gc, dim3(FFT_T), lds, s>>>(cm, (long long) N * zpc, zpc, tw, ctot, W, ga, xcdk, t0);
+            fft_pass_strided<N, 1><<<gc, dim3(FFT_T), lds, s>>>(cm, zpc, (long long) N * zpc, tw, ctot, W, ga, xcdk, t0);
+        }
+        fft_pass_z_inv<N><<<gzi, dim3(FFT_T), lds, s>>>(d_mesh, ztot, zp, W);
         SHQ_HIP(hipGetLastError());
         return SHQ_OK;
     }

@@ -604,6 +604,13 @@ extern "C" int shq_fof(shq_context *ctx, const shq_fof_params *fp, const uint64_
     SHQ_CHECK(n < (1ll << 31) - 64, SHQ_ERR_INVALID, "fof: too many particles");
     /* the tree of the primary types (fof.cpp:176-178) */
     SHQ_TRY(shq_tree_build(ctx, fp->BoxSize, fp->PrimaryLinkTypes, nullptr, 0, nullptr));
+    /* That tree is fof's own, as in the reference (fof_fof builds and frees it, fof.cpp:176-178 and :254): the context's resident
+     * tree is gone from the caller's point of view, whatever happens below.  A later walk must rebuild or upload one — it fails
+     * with SHQ_ERR_STATE instead of walking a tree that holds the primary link types only. */
+    ctx->have_tree = false;
+    ctx->tb_built = false;
+    ctx->have_tree_targets = false;
+    ctx->have_toptree = false;
     const long long nt = ctx->ntreeparts;
     FofTree t = {ctx->nodeB.ptr, ctx->nodeC.ptr, ctx->posm_leaf.ptr, ctx->leaf_pidx.ptr, fp->BoxSize, ctx->tb.order[1].ptr, ctx->tb.lo.ptr, ctx->tb.hi.ptr,
                  ctx->tb.parent.ptr, fp->LinkingLength / 1.7320508075688774 * (1 - 1e-12)};

@@ -52,6 +52,9 @@ struct WalkArgs {
     int stats_guard;
     const float *tab_f;
     const float *tab_p;
+    unsigned int *task_counters; /* PERSIST: 8 counters, one per XCD region, 64 B apart */
+    long long nwaves;            /* PERSIST: number of 64-target tasks */
+    int task_run_log2;           /* PERSIST: log2 of the run of consecutive tasks a region owns */
 };
 
 /* NEAREST (partmanager.h:99) as d - L*rint(d/L): one multiply, one round, one fma. For
@@ -144,8 +147,52 @@ __device__ __forceinline__ void leaf_particle(const double4 *__restrict__ tab, c
  * particles fetched per batch (2 or 4).  STATS: wave-level counters for the bench.
  * amdgpu_num_sgpr(96): the kernel wants 106 SGPRs, which allocates 112 and caps a SIMD at 7 waves; held to 96 (ten values
  * parked in lanes of a spare VGPR, still 64 VGPRs) it runs 8: walk 44.45 -> 43.6 ms in a same-box A/B. */
-template <bool POT, bool PREFETCH, int LEAFB, int STATS, bool BH, bool GHOSTS = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void grav_walk_exact_kernel(const WalkArgs a)
+/* PERSIST: the grid is as many workgroups as the chip holds at once and every wave takes 64-target tasks from a counter until
+ * none is left, instead of one task per wave: a finished wave's slot is refilled at once rather than when the slowest of its
+ * workgroup's four waves ends (measured before: 6.5 of 8 wave slots per SIMD occupied on average), and the window table is
+ * staged once per resident workgroup, not once per 256 targets.  Tasks keep the XCD-chunked order of the one-shot grid: region x
+ * (= the XCD a workgroup most likely runs on, blockIdx % 8) owns every eighth run of 4 K tasks; a wave whose region is exhausted
+ * takes from the next one, so the clustered part of the box cannot leave seven XCDs idle. */
+/* The fields a task needs only before and after its walk (list, particle and output pointers, counters) must not stay in
+ * registers across the walk: hoisted out of the task loop they cost ~20 SGPRs, which under the 96-SGPR cap spill into VGPR lanes
+ * and from there to scratch.  They are re-read from the kernel argument segment through a pointer the optimiser cannot see
+ * through, at the points of use. */
+/* constant address space on the device pass; the host pass only parses the kernels */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SHQ_CONSTANT_AS __attribute__((address_space(4)))
+#else
+#define SHQ_CONSTANT_AS
+#endif
+typedef const SHQ_CONSTANT_AS WalkArgs *WalkArgsK;
+__device__ __forceinline__ WalkArgsK walk_cold_args()
+{
+    WalkArgsK kp = (WalkArgsK) __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+}
+
+/* returns the next task of this wave (wave-uniform), or -1 when all eight regions are exhausted */
+__device__ __forceinline__ int walk_next_task(WalkArgsK c, int &region, int &tried)
+{
+    const int lg = c->task_run_log2;
+    const int nwaves = (int) c->nwaves;
+    unsigned int *counters = c->task_counters;
+    while(tried < 8) {
+        unsigned k = 0;
+        if((threadIdx.x & 63) == 0)
+            k = atomicAdd(&counters[16 * region], 1u);
+        k = (unsigned) __builtin_amdgcn_readfirstlane((int) k);
+        const unsigned t = ((((k >> lg) << 3) + (unsigned) region) << lg) | (k & ((1u << lg) - 1u));
+        if(k < 0x40000000u && t < (unsigned) nwaves)
+            return (int) t;
+        region = (region + 1) & 7;
+        tried++;
+    }
+    return -1;
+}
+
+template <bool POT, bool PREFETCH, int LEAFB, int STATS, bool BH, bool GHOSTS = false, bool PERSIST = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(8, 8))) void grav_walk_exact_kernel(const WalkArgs a)
 {
     __shared__ double4 tab[SHQ_NGRAVTAB];
     for(int i = threadIdx.x; i < SHQ_NGRAVTAB; i += blockDim.x) {
@@ -155,22 +202,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void grav
     }
     __syncthreads();
 
+    /* the node pool and the leaf-ordered particle copy are read-only for the whole launch: read through the constant address
+     * space, so that the loads stay scalar (s_load) although the task loop puts a task's result stores before the next task's
+     * node loads (the scalar cache is not coherent with vector stores, and the compiler must assume they may alias) */
+    typedef const SHQ_CONSTANT_AS NodeG *NodeGK;
+    typedef const SHQ_CONSTANT_AS double4 *Double4K;
+    const NodeGK nodeG = (NodeGK) (size_t) a.nodeG;
+    const Double4K posm_leaf = (Double4K) (size_t) a.posm_leaf;
     const int lane = threadIdx.x & 63;
-    const long long wave = (long long) xcd_block(blockIdx.x, gridDim.x, a.xcdK) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int region = blockIdx.x & 7, tried = 0;
+    long long wave = PERSIST ? (long long) walk_next_task(walk_cold_args(), region, tried)
+                             : (long long) xcd_block(blockIdx.x, gridDim.x, a.xcdK) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    while(wave >= 0) {
     const long long t = wave * 64 + lane;
-    bool valid = t < a.ntargets;
     long long pi = 0;
     double px = 0, py = 0, pz = 0, aold = 0;
-    if(valid) {
-        pi = a.targets ? (long long) a.targets[t] : t;
-        valid = pi >= 0; /* a negative list entry is an idle lane (padding of cell-aligned target groups) */
-    }
-    if(valid) {
-        const double4 p = a.posm[pi];
-        px = p.x;
-        py = p.y;
-        pz = p.z;
-        aold = a.errtol * a.oldacc[pi];
+    bool valid;
+    {
+        const WalkArgs c = PERSIST ? *walk_cold_args() : a;
+        valid = t < c.ntargets;
+        if(valid) {
+            pi = c.targets ? (long long) c.targets[t] : t;
+            valid = pi >= 0; /* a negative list entry is an idle lane (padding of cell-aligned target groups) */
+        }
+        if(valid) {
+            const double4 p = c.posm[pi];
+            px = p.x;
+            py = p.y;
+            pz = p.z;
+            aold = c.errtol * c.oldacc[pi];
+        }
     }
     double ax = 0, ay = 0, az = 0, pot = 0;
     int nint = 0;
@@ -189,19 +250,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void grav
             mynext = st.x >= 0 ? st.x : -2;
             seg1 = st.y; seg2 = st.z; seg3 = st.w;
             if(mynext >= 0)
-                myend = a.nodeG[mynext].sibling;
+                myend = a.nodeG[mynext].sibling; /* per-lane (vector) load */
         }
     }
     unsigned int visited = 0, wave_applies = 0, wave_node_applies = 0;
     unsigned int hv[8] = {}, hn[8] = {}, hl[8] = {};
     unsigned int lonely8 = 0, lonely16 = 0; /* STATS == 2: this lane's interactions in rounds of <= 8 / <= 16 lanes */
 
-    NodeG nd = a.nodeG[cur];
+    NodeG nd = nodeG[cur];
 
     while(cur >= 0) {
         NodeG nd1;
         if(PREFETCH) /* pool is padded by one record */
-            nd1 = a.nodeG[cur + 1];
+            nd1 = nodeG[cur + 1];
         if(STATS)
             visited++;
         const bool act = (mynext == cur);
@@ -266,7 +327,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void grav
         if(nd.type == SHQ_PARTICLE_NODE_TYPE) {
             /* gravshort2.hpp:290-304: every particle of an opened leaf is evaluated */
             if(doopenm != 0ull) {
-                const double4 *__restrict__ lp = a.posm_leaf + nd.child;
+                const Double4K lp = posm_leaf + nd.child;
                 const int cnt = nd.count;
                 if(STATS)
                     wave_applies += cnt;
@@ -324,17 +385,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void grav
         if(PREFETCH && next == cur + 1)
             nd = nd1;
         else if(next >= 0)
-            nd = a.nodeG[next];
+            nd = nodeG[next];
         cur = next;
     }
 
+    {
+    const WalkArgs c = PERSIST ? *walk_cold_args() : a;
     if(valid) {
-        a.acc[3 * pi + 0] = ax;
-        a.acc[3 * pi + 1] = ay;
-        a.acc[3 * pi + 2] = az;
+        c.acc[3 * pi + 0] = ax;
+        c.acc[3 * pi + 1] = ay;
+        c.acc[3 * pi + 2] = az;
         if(POT)
-            a.pot[pi] = pot;
-        a.nint[pi] = nint;
+            c.pot[pi] = pot;
+        c.nint[pi] = nint;
     }
     /* statistics (treewalk2.h:446-448 interaction min/max) */
     long long mn = valid ? nint : 0x7fffffffffffll, mx = valid ? nint : 0, sm = valid ? nint : 0;
@@ -352,34 +415,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void grav
             l8m = max(l8m, (unsigned int) __shfl_xor(l8m, off));
             l16m = max(l16m, (unsigned int) __shfl_xor(l16m, off));
         }
-    if(lane == 0 && a.stats && a.stats_guard != 2) {
-        atomicAdd(&a.stats->ninteractions, (unsigned long long) sm);
+    if(lane == 0 && c.stats && c.stats_guard != 2) {
+        atomicAdd(&c.stats->ninteractions, (unsigned long long) sm);
         /* 262 144 waves end here with three no-return atomics on one cache line.  Measured at 256^3 (same box, SHQ_WALK_STATS_GUARD):
          * as they are 39.3 ms, without any of them 39.3 ms, with a read first so that only improvements reach atomicMin / atomicMax
          * 40.9 ms — the read has to come back through the line the atomics are queued on, and the wave holds its slot meanwhile. */
-        if(a.stats_guard != 1 || mn < ((volatile long long *) &a.stats->min_int)[0])
-            atomicMin(&a.stats->min_int, mn);
-        if(a.stats_guard != 1 || mx > ((volatile long long *) &a.stats->max_int)[0])
-            atomicMax(&a.stats->max_int, mx);
+        if(c.stats_guard != 1 || mn < ((volatile long long *) &c.stats->min_int)[0])
+            atomicMin(&c.stats->min_int, mn);
+        if(c.stats_guard != 1 || mx > ((volatile long long *) &c.stats->max_int)[0])
+            atomicMax(&c.stats->max_int, mx);
         if(STATS) {
-            atomicAdd(&a.stats->nvisited, (unsigned long long) visited);
-            atomicAdd(&a.stats->nwave_applies, (unsigned long long) wave_applies);
-            atomicAdd(&a.stats->nwave_node_applies, (unsigned long long) wave_node_applies);
-            atomicAdd(&a.stats->nnode_interactions, (unsigned long long) node_int_wave);
+            atomicAdd(&c.stats->nvisited, (unsigned long long) visited);
+            atomicAdd(&c.stats->nwave_applies, (unsigned long long) wave_applies);
+            atomicAdd(&c.stats->nwave_node_applies, (unsigned long long) wave_node_applies);
+            atomicAdd(&c.stats->nnode_interactions, (unsigned long long) node_int_wave);
         }
         if(STATS == 2)
             for(int b = 0; b < 8; b++) {
-                atomicAdd(&a.stats->hist_visit[b], (unsigned long long) hv[b]);
-                atomicAdd(&a.stats->hist_node[b], (unsigned long long) hn[b]);
-                atomicAdd(&a.stats->hist_leaf[b], (unsigned long long) hl[b]);
+                atomicAdd(&c.stats->hist_visit[b], (unsigned long long) hv[b]);
+                atomicAdd(&c.stats->hist_node[b], (unsigned long long) hn[b]);
+                atomicAdd(&c.stats->hist_leaf[b], (unsigned long long) hl[b]);
             }
         if(STATS == 2) {
-            atomicAdd(&a.stats->lonely[0], (unsigned long long) l8s);
-            atomicAdd(&a.stats->lonely[1], (unsigned long long) l8m);
-            atomicAdd(&a.stats->lonely[2], (unsigned long long) l16s);
-            atomicAdd(&a.stats->lonely[3], (unsigned long long) l16m);
+            atomicAdd(&c.stats->lonely[0], (unsigned long long) l8s);
+            atomicAdd(&c.stats->lonely[1], (unsigned long long) l8m);
+            atomicAdd(&c.stats->lonely[2], (unsigned long long) l16s);
+            atomicAdd(&c.stats->lonely[3], (unsigned long long) l16m);
         }
     }
+    }
+    wave = PERSIST ? (long long) walk_next_task(walk_cold_args(), region, tried) : -1;
+    } /* task loop */
 }
 
 /* GravTreeOutput::postprocess, gravshort2.hpp:88-107 */
@@ -455,23 +521,25 @@ __global__ void stats_init_kernel(GravStatsDev *s)
  * own instantiation: the relative criterion drops out at compile time, and a profile lists the seeding
  * walk and the production walk as two kernels. */
 template <bool POT, bool PREFETCH, int LEAFB, bool BH>
-void launch_variant_bh(int stats, dim3 grid, dim3 block, hipStream_t stream, const WalkArgs &a)
+void launch_variant_bh(int stats, bool persist, dim3 grid, dim3 block, hipStream_t stream, const WalkArgs &a, size_t dyn_lds = 0)
 {
     if(stats == 2 && POT && !PREFETCH && LEAFB == 2)
         grav_walk_exact_kernel<POT, PREFETCH, LEAFB, (POT && !PREFETCH && LEAFB == 2) ? 2 : 1, BH><<<grid, block, 0, stream>>>(a);
     else if(stats)
         grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 1, BH><<<grid, block, 0, stream>>>(a);
+    else if(persist && !PREFETCH && LEAFB == 2)
+        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 0, BH, false, (!PREFETCH && LEAFB == 2)><<<grid, block, dyn_lds, stream>>>(a);
     else
         grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 0, BH><<<grid, block, 0, stream>>>(a);
 }
 
 template <bool POT, bool PREFETCH, int LEAFB>
-void launch_variant(int stats, dim3 grid, dim3 block, hipStream_t stream, const WalkArgs &a)
+void launch_variant(int stats, bool persist, dim3 grid, dim3 block, hipStream_t stream, const WalkArgs &a, size_t dyn_lds = 0)
 {
     if(a.useBH)
-        launch_variant_bh<POT, PREFETCH, LEAFB, true>(stats, grid, block, stream, a);
+        launch_variant_bh<POT, PREFETCH, LEAFB, true>(stats, persist, grid, block, stream, a, dyn_lds);
     else
-        launch_variant_bh<POT, PREFETCH, LEAFB, false>(stats, grid, block, stream, a);
+        launch_variant_bh<POT, PREFETCH, LEAFB, false>(stats, persist, grid, block, stream, a, dyn_lds);
 }
 
 } // namespace
@@ -521,6 +589,9 @@ static void fill_walk_args(shq_context *ctx, const shq_grav_params *p, WalkArgs 
     a.stats_guard = ctx->stats_guard;
     a.tab_f = ctx->gravtab.ptr;
     a.tab_p = ctx->gravtab.ptr + SHQ_NGRAVTAB;
+    a.task_counters = nullptr;
+    a.nwaves = 0;
+    a.task_run_log2 = 7;
 }
 
 /* secondary (GHOSTS) walk over query arrays already on the device: a carries the query positions as posm, the
@@ -602,25 +673,44 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     const long long nwaves = (ntargets + 63) / 64;
     const long long blocks = (nwaves + (threads / 64) - 1) / (threads / 64);
     SHQ_CHECK(blocks < (1ll << 31), SHQ_ERR_INVALID, "grav walk: too many targets for one launch");
-    const dim3 grid((unsigned) blocks), block(threads);
     /* tuning knobs (diagnostic): SHQ_WALK_VARIANT = 0..3 selects prefetch/leaf-batch; the
      * default is the measured-fastest one. */
     const int variant = ctx->walk_variant;
     const int stats = ctx->walk_stats;
+    /* persistent waves (the default for the production variant without counters): as many workgroups as fit the chip at
+     * 8 per CU, tasks from eight per-XCD counters */
+    static const int bpc_env = getenv("SHQ_WALK_BLOCKS_PER_CU") ? atoi(getenv("SHQ_WALK_BLOCKS_PER_CU")) : 8;
+    const int bpc = bpc_env >= 1 && bpc_env <= 8 ? bpc_env : 8; /* resident workgroups per CU (diagnostic: fewer leave room for other streams) */
+    const bool persist = ctx->walk_persist && !stats && variant == 3 && blocks > (long long) ctx->num_cus * bpc;
+    long long launch_blocks = blocks;
+    if(persist) {
+        SHQ_TRY(ctx->walk_tasks.reserve(8 * 16));
+        SHQ_HIP(hipMemsetAsync(ctx->walk_tasks.ptr, 0, sizeof(unsigned int) * 8 * 16, ctx->stream));
+        a.task_counters = ctx->walk_tasks.ptr;
+        a.nwaves = nwaves;
+        int lg = 0;
+        while((1u << lg) < 4u * (a.xcdK ? a.xcdK : 1u))
+            lg++;
+        a.task_run_log2 = lg;
+        launch_blocks = (long long) ctx->num_cus * bpc;
+    }
+    /* fewer than 8 resident workgroups per CU are enforced through the LDS allocation (160 KB per CU), not left to the dispatcher */
+    const size_t dyn_lds = persist && bpc < 8 ? (size_t) ((160 * 1024 / bpc - 16384) / 1024 * 1024 - 1024) : 0;
+    const dim3 grid((unsigned) launch_blocks), block(threads);
     SHQ_HIP(hipEventRecord(ctx->ev_begin[SHQ_NTIMERS - 1], ctx->stream));
     if(update_potential) {
         switch(variant) {
-        case 0: launch_variant<true, true, 4>(stats, grid, block, ctx->stream, a); break;
-        case 1: launch_variant<true, true, 2>(stats, grid, block, ctx->stream, a); break;
-        case 2: launch_variant<true, false, 4>(stats, grid, block, ctx->stream, a); break;
-        default: launch_variant<true, false, 2>(stats, grid, block, ctx->stream, a); break;
+        case 0: launch_variant<true, true, 4>(stats, persist, grid, block, ctx->stream, a); break;
+        case 1: launch_variant<true, true, 2>(stats, persist, grid, block, ctx->stream, a); break;
+        case 2: launch_variant<true, false, 4>(stats, persist, grid, block, ctx->stream, a); break;
+        default: launch_variant<true, false, 2>(stats, persist, grid, block, ctx->stream, a, dyn_lds); break;
         }
     } else {
         switch(variant) {
-        case 0: launch_variant<false, true, 4>(stats, grid, block, ctx->stream, a); break;
-        case 1: launch_variant<false, true, 2>(stats, grid, block, ctx->stream, a); break;
-        case 2: launch_variant<false, false, 4>(stats, grid, block, ctx->stream, a); break;
-        default: launch_variant<false, false, 2>(stats, grid, block, ctx->stream, a); break;
+        case 0: launch_variant<false, true, 4>(stats, persist, grid, block, ctx->stream, a); break;
+        case 1: launch_variant<false, true, 2>(stats, persist, grid, block, ctx->stream, a); break;
+        case 2: launch_variant<false, false, 4>(stats, persist, grid, block, ctx->stream, a); break;
+        default: launch_variant<false, false, 2>(stats, persist, grid, block, ctx->stream, a, dyn_lds); break;
         }
     }
     SHQ_HIP(hipGetLastError());

@@ -165,6 +165,29 @@ def test_fof_requires_run_and_handles_empty_and_no_groups(ctx):
         c2.close()
 
 
+def test_fof_leaves_no_resident_tree_behind(ctx):
+    """shq_fof builds its tree over the primary link types only (fof.cpp:176-178) and, like fof_fof (:254), keeps none: a gravity walk
+    of a mixed-type set right after it must fail loudly (SHQ_ERR_STATE) rather than walk a tree without the gas, star and BH particles,
+    and work again once the caller has built its own tree."""
+    rng = np.random.default_rng(11)
+    n = 4000
+    pos = rng.random((n, 3)) * cm.BOX
+    types = rng.integers(0, 6, n).astype(np.uint8)
+    types[types == 2] = 1
+    types[types == 3] = 1
+    gpu_fof(ctx, pos, np.zeros((n, 3)), np.ones(n), types, np.arange(1, n + 1, dtype=np.uint64), cm.BOX, 0.2, 5)
+    sq.set_gravshort_treepar(ErrTolForceAcc=0.005, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=1, Rcut=6.0)
+    sq.gravshort_set_softenings(cm.BOX / 16)
+    gp = sq.make_grav_params(cm.BOX, 1.5, 48, cm.G, cm.RHO0)
+    rc = capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, 0)
+    assert rc == 4 and b"tree" in capi.hip.shq_last_error()      # SHQ_ERR_STATE
+    sq.tree_build_device(ctx, cm.BOX)
+    capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, 0))
+    nint = np.zeros(n, dtype=np.int32)
+    capi.check(capi.hip.shq_grav_short_download(ctx.h, None, None, capi.ptr(nint), None))
+    assert (nint > 0).all()                                       # every type is back in the tree
+
+
 def test_fof_seed_candidates_and_seed_select(ctx):
     """the gas state resident (shq_sph_state_upload): MaxDens / seed_index per group as add_particle_to_group finds them (densest gas
     member that is not a decoupled wind particle, fof.cpp:619-628), then fof_seed's marking loop (fof.cpp:1290-1302) against the
