@@ -183,6 +183,8 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
         ctx->xcd_k = atoi(v);
     if(const char *v = getenv("SHQ_WALK_PERSIST"))
         ctx->walk_persist = atoi(v);
+    if(const char *v = getenv("SHQ_WALK_RING"))
+        ctx->walk_ring = atoi(v);
     {
         int ncu = 0;
         if(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0)

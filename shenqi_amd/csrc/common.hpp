@@ -383,6 +383,7 @@ struct shq_context {
     int walk_variant = 3;      /* SHQ_WALK_VARIANT: 0 prefetch+leaf4, 1 prefetch+leaf2, 2 leaf4, 3 leaf2 (fastest: no SGPR spills) */
     int walk_stats = 0;        /* SHQ_WALK_STATS / shq_set_walk_stats: wave-level counters (1), + histograms (2); off by default: 4 % */
     int walk_persist = 1;      /* SHQ_WALK_PERSIST: persistent waves taking 64-target tasks from per-XCD counters (0: one task per wave) */
+    int walk_ring = 1;         /* SHQ_WALK_RING: leaf particles through the wave-private LDS ring (persistent walk only) */
     int num_cus = 256;         /* compute units of the device */
     DevBuf<unsigned int> walk_tasks; /* the task counters of the persistent walk */
     int xcd_k = 32;            /* SHQ_XCD_K: blocks per XCD chunk in the remap (0 = off); 32 measured best (2 %) */

@@ -557,14 +557,14 @@ int run_n(shq_context *ctx, double *d_mesh, int zp, int stage, bool from_i64, do
         SHQ_HIP(hipGetLastError());
         return SHQ_OK;
     }
-    /* Chained middle passes (stage 2, full cube): Y forward, the fused X pass and Y inverse all work on lines inside one plane
-     * of constant z', so they can run chunk by chunk over z' — `chain` column tiles (chain x 64 bytes of every (x, y) row) at a
-     * time, about chain x 38 MB at 768^3 — and the chunk written by one pass is still in the 256 MB Infinity Cache when the next
-     * pass reads it: the mesh crosses the HBM interface three times (Z forward, the chain, Z inverse) instead of five. */
-    static const int chain_env = getenv("SHQ_FFT_CHAIN") ? atoi(getenv("SHQ_FFT_CHAIN")) : -1;
-    int chain = chain_env;
-    if(chain < 0) /* default: chunks of about 100 MB */
-        chain = (int) ((100.0e6) / ((double) N * N * FFT_C * sizeof(double2)) + 0.5);
+    /* Chained middle passes (stage 2, full cube; SHQ_FFT_CHAIN = column tiles per chunk, off by default): Y forward, the fused X
+     * pass and Y inverse all work on lines inside one plane of constant z', so they can run chunk by chunk over z' (a chunk of c
+     * tiles is c x 38 MB at 768^3) in the hope that a chunk written by one pass is still in the 256 MB Infinity Cache when the next
+     * pass reads it.  Measured at 768^3 (one box, FFT pipeline in ms): unchained 9.83; chunks of 2 / 3 / 4 / 6 / 8 tiles 11.85 /
+     * 11.20 / 11.03 / 10.59 / 10.56 — the cache does not absorb the write-then-read traffic of these passes, and every chunk pays
+     * the start and the tail of three more launches.  Kept as a diagnostic knob only. */
+    static const int chain_env = getenv("SHQ_FFT_CHAIN") ? atoi(getenv("SHQ_FFT_CHAIN")) : 0;
+    const int chain = chain_env;
     if(stage == 2 && nslab == N && chain > 0 && chain < ntiles) {
         if(from_i64)
             fft_pass_z_fwd<N, true><<<gzf, dim3(FFT_T), lds, s>>>(d_mesh, ztot, zp, W, inv_scale);

@@ -191,9 +191,35 @@ __device__ __forceinline__ int walk_next_task(WalkArgsK c, int &region, int &tri
     return -1;
 }
 
-template <bool POT, bool PREFETCH, int LEAFB, int STATS, bool BH, bool GHOSTS = false, bool PERSIST = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(8, 8))) void grav_walk_exact_kernel(const WalkArgs a)
+/* RING (leaf ring): the particles of an opened leaf are not evaluated at once — a round per particle in which only the lanes that
+ * opened this leaf work, < 10 % of the lanes on average — but copied (LDS-DMA, no registers) into a wave-private ring of SHQ_LEAF_RING
+ * sources in LDS, every lane noting in a bit mask which slots are its own.  When the ring is full, and at the end of the task, the
+ * wave drains it: in every round each lane pops ITS oldest slot, so lanes that opened different leaves work side by side.  A lane's
+ * particles are still evaluated in the order its walk met them; only their position relative to the node interactions changes (the
+ * last bits of the sums).  tools/walk_defer_sim.py: leaf rounds 340 -> 219 per wave (64^3 S-cluster) at 32 slots. */
+#define SHQ_LEAF_RING 32
+
+template <bool POT>
+__device__ __forceinline__ void leaf_ring_drain(const double4 *__restrict__ tab, const double4 *ring, unsigned &mymask, double px, double py,
+                                                double pz, const WalkArgs &a, double &ax, double &ay, double &az, double &pot,
+                                                const unsigned long long wrapm)
 {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the LDS-DMA copies into the ring have landed */
+    while(shq_ballot(mymask != 0u) != 0ull) {
+        if(mymask != 0u) {
+            const int b = __builtin_ctz(mymask);
+            mymask &= mymask - 1u;
+            const double4 q = ring[b];
+            leaf_particle<POT>(tab, q, px, py, pz, a, ax, ay, az, pot, wrapm);
+        }
+    }
+}
+
+template <bool POT, bool PREFETCH, int LEAFB, int STATS, bool BH, bool GHOSTS = false, bool PERSIST = false, bool RING = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(8, 8))) void grav_walk_exact_kernel(const WalkArgs a)
+{
+    extern __shared__ double4 ring_all[]; /* RING: SHQ_LEAF_RING slots per wave */
+    double4 *const ring = ring_all + (threadIdx.x >> 6) * SHQ_LEAF_RING;
     __shared__ double4 tab[SHQ_NGRAVTAB];
     for(int i = threadIdx.x; i < SHQ_NGRAVTAB; i += blockDim.x) {
         const int j = (i + 1 < SHQ_NGRAVTAB) ? i + 1 : i;
@@ -235,6 +261,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96), amdgpu_wav
     }
     double ax = 0, ay = 0, az = 0, pot = 0;
     int nint = 0;
+    unsigned ringmask = 0;             /* RING: this lane's pending slots */
+    int ringfill = 0;                  /* RING: slots in use (wave-uniform) */
+    unsigned long long ringwrap = 0;   /* RING: some pending leaf needs the periodic wrap (wave-uniform) */
     unsigned int node_int_wave = 0; /* STATS: monopole interactions of the whole wave (wave-uniform: no VGPR) */
     int mynext = valid ? a.root : -2;
     int cur = a.root;
@@ -326,7 +355,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96), amdgpu_wav
         int next;
         if(nd.type == SHQ_PARTICLE_NODE_TYPE) {
             /* gravshort2.hpp:290-304: every particle of an opened leaf is evaluated */
-            if(doopenm != 0ull) {
+            if(RING && doopenm != 0ull) {
+                const int cnt = nd.count;
+                if(ringfill + cnt > SHQ_LEAF_RING) {
+                    leaf_ring_drain<POT>(tab, ring, ringmask, px, py, pz, a, ax, ay, az, pot, ringwrap);
+                    ringfill = 0;
+                    ringwrap = 0;
+                }
+                /* cnt x 32 bytes of the leaf-ordered copy -> ring slots [ringfill, ringfill + cnt): lane l moves 16 bytes */
+                if(lane < 2 * cnt)
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const double2 *>(a.posm_leaf + nd.child) + lane,
+                                                     (__attribute__((address_space(3))) void *) (ring + ringfill), 16, 0, 0);
+                if(doopen) {
+                    ringmask |= ((1u << cnt) - 1u) << ringfill;
+                    nint += cnt;
+                }
+                ringfill += cnt;
+                ringwrap |= wrapm;
+            }
+            if(!RING && doopenm != 0ull) {
                 const Double4K lp = posm_leaf + nd.child;
                 const int cnt = nd.count;
                 if(STATS)
@@ -389,6 +436,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96), amdgpu_wav
         cur = next;
     }
 
+    if(RING)
+        leaf_ring_drain<POT>(tab, ring, ringmask, px, py, pz, a, ax, ay, az, pot, ringwrap);
     {
     const WalkArgs c = PERSIST ? *walk_cold_args() : a;
     if(valid) {
@@ -527,6 +576,8 @@ void launch_variant_bh(int stats, bool persist, dim3 grid, dim3 block, hipStream
         grav_walk_exact_kernel<POT, PREFETCH, LEAFB, (POT && !PREFETCH && LEAFB == 2) ? 2 : 1, BH><<<grid, block, 0, stream>>>(a);
     else if(stats)
         grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 1, BH><<<grid, block, 0, stream>>>(a);
+    else if(persist && !PREFETCH && LEAFB == 2 && block.x == 512)
+        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 0, BH, false, (!PREFETCH && LEAFB == 2), (!PREFETCH && LEAFB == 2)><<<grid, block, dyn_lds, stream>>>(a);
     else if(persist && !PREFETCH && LEAFB == 2)
         grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 0, BH, false, (!PREFETCH && LEAFB == 2)><<<grid, block, dyn_lds, stream>>>(a);
     else
@@ -695,8 +746,14 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
         launch_blocks = (long long) ctx->num_cus * bpc;
     }
     /* fewer than 8 resident workgroups per CU are enforced through the LDS allocation (160 KB per CU), not left to the dispatcher */
-    const size_t dyn_lds = persist && bpc < 8 ? (size_t) ((160 * 1024 / bpc - 16384) / 1024 * 1024 - 1024) : 0;
-    const dim3 grid((unsigned) launch_blocks), block(threads);
+    size_t dyn_lds = persist && bpc < 8 ? (size_t) ((160 * 1024 / bpc - 16384) / 1024 * 1024 - 1024) : 0;
+    /* leaf ring: workgroups of 8 waves (4 per CU: one window table per 8 waves leaves the LDS room for the rings) */
+    const bool ring = persist && ctx->walk_ring && bpc == 8;
+    if(ring) {
+        launch_blocks = (long long) ctx->num_cus * 4;
+        dyn_lds = sizeof(double4) * SHQ_LEAF_RING * 8;
+    }
+    const dim3 grid((unsigned) launch_blocks), block(ring ? 512 : threads);
     SHQ_HIP(hipEventRecord(ctx->ev_begin[SHQ_NTIMERS - 1], ctx->stream));
     if(update_potential) {
         switch(variant) {

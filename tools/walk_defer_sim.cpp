@@ -82,7 +82,7 @@ struct RingSim {
  * [4] max interactions of a lane, [5 + 3 c .. ] for config c: rounds, drains, idle lane-rounds */
 extern "C" void walk_defer_sim(const shq_node *nodes, int64_t firstnode, const double *pos, const double *oldacc, int64_t ntargets,
                                const shq_grav_params *p, int64_t wave_stride, int nconf, const int32_t *confR, const int32_t *confG,
-                               int64_t *out, int nout)
+                               const int32_t *confT, int64_t *out, int nout)
 {
     const shq_node *N = nodes - firstnode;
     const double rcut = p->Rcut, rcut2 = rcut * rcut, L = p->BoxSize;
@@ -104,6 +104,7 @@ extern "C" void walk_defer_sim(const shq_node *nodes, int64_t firstnode, const d
         }
         std::vector<RingSim> sims;
         std::vector<char> leafonly;
+        std::vector<int64_t> immediate(nconf, 0);
         for(int c = 0; c < nconf; c++) {
             leafonly.push_back(confG[c] < 0);
             sims.emplace_back(confR[c], confG[c] < 0 ? -confG[c] - 1 : confG[c]);
@@ -139,9 +140,10 @@ extern "C" void walk_defer_sim(const shq_node *nodes, int64_t firstnode, const d
                     if(accm >> l & 1)
                         nint[l]++;
                 for(size_t c = 0; c < sims.size(); c++) {
-                    if(leafonly[c])
+                    if(leafonly[c] || __builtin_popcountll(accm) >= confT[c]) {
                         sims[c].rounds++; /* nodes evaluated at once */
-                    else
+                        immediate[c]++;
+                    } else
                         sims[c].push(accm, 1);
                 }
             }
@@ -181,7 +183,7 @@ extern "C" void walk_defer_sim(const shq_node *nodes, int64_t firstnode, const d
             sims[c].finish();
             o[5 + 3 * c] = sims[c].rounds;
             o[6 + 3 * c] = sims[c].drains;
-            o[7 + 3 * c] = sims[c].idle;
+            o[7 + 3 * c] = immediate[c];
         }
     }
 }

@@ -56,9 +56,12 @@ def main():
         oldacc = np.linalg.norm(acc * G + gpm, axis=1) / G
         np.savez(cache, oldacc=oldacc)
     lib = C.CDLL(os.path.join(ROOT, "build", "libwalk_defer_sim.so"))
-    confs = [(16, -1), (32, -1), (64, -1), (32, -17), (64, -33), (64, -2), (128, -1), (32, 0), (64, 0), (128, 0), (256, 0), (32, 16), (64, 32), (64, 16), (64, 1), (128, 64), (128, 32), (128, 1), (256, 1), (1 << 20, 1)]
+    confs = [(32, -1, 65), (64, -1, 65), (64, -33, 65), (32, 0, 65), (64, 0, 65), (64, 32, 65), (128, 64, 65), (1 << 20, 1, 65)]
+    for T in (8, 16, 24, 32, 48):
+        confs += [(32, 0, T), (64, 0, T), (64, 32, T), (128, 64, T)]
     R = np.array([c[0] for c in confs], dtype=np.int32)
     Gn = np.array([c[1] for c in confs], dtype=np.int32)
+    Tn = np.array([c[2] for c in confs], dtype=np.int32)
     nw = (n + 63) // 64
     ns = (nw + stride - 1) // stride
     nout = 5 + 3 * len(confs)
@@ -67,15 +70,22 @@ def main():
     t0 = time.time()
     lib.walk_defer_sim(C.c_void_p(tree.Nodes_base.ctypes.data), C.c_int64(tree.firstnode), C.c_void_p(posc.ctypes.data),
                        C.c_void_p(oldacc.ctypes.data), C.c_int64(n), C.byref(gp_rel), C.c_int64(stride), C.c_int(len(confs)),
-                       C.c_void_p(R.ctypes.data), C.c_void_p(Gn.ctypes.data), C.c_void_p(out.ctypes.data), C.c_int(nout))
+                       C.c_void_p(R.ctypes.data), C.c_void_p(Gn.ctypes.data), C.c_void_p(Tn.ctypes.data), C.c_void_p(out.ctypes.data), C.c_int(nout))
     print("sim %.1f s, %d waves sampled" % (time.time() - t0, ns))
     m = out.mean(axis=0)
     print("per wave: visits %.0f  accepting visits %.0f  leaf rounds %.0f  => rounds now %.0f" % (m[0], m[1], m[2], m[1] + m[2]))
     print("interactions per target %.1f  (ideal rounds %.0f)  fullest lane %.0f" % (m[3] / 64, m[3] / 64, m[4]))
-    for c, (r, g) in enumerate(confs):
+    now = m[0] * 84 + m[1] * 118 + m[2] * 140
+    print("cost model (cycles per wave): visit 84, immediate node round 118, immediate leaf round 140, drained round 176 (leaf-only ring: 156)")
+    print("now: %.0f cycles" % now)
+    for c, (r, g, T) in enumerate(confs):
         kind = "leaf-only" if g < 0 else "all      "
         gg = -g - 1 if g < 0 else g
-        print("%s ring %7d gran %3d: rounds %.0f  (leaf part %.0f)  drains %.0f  lane use %.2f" % (kind, r, gg, m[5 + 3 * c], m[5 + 3 * c] - (m[1] if g < 0 else 0), m[6 + 3 * c], m[3] / (64 * m[5 + 3 * c])))
+        rounds, imm = m[5 + 3 * c], m[7 + 3 * c]
+        drained = rounds - imm
+        cost = m[0] * 84 + imm * 118 + drained * (156 if g < 0 else 176)
+        print("%s ring %7d gran %3d defer-below %2d: rounds %.0f = %.0f immediate + %.0f drained  drains %.0f  lane use %.2f  cost %.0f (%.3f of now)"
+              % (kind, r, gg, T, rounds, imm, drained, m[6 + 3 * c], m[3] / (64 * rounds), cost, cost / now))
 
 
 if __name__ == "__main__":
