@@ -611,6 +611,17 @@ int shq_grav_short_run_range(shq_context *ctx, const shq_grav_params *params, in
  * zero; the counters cost the walk ~4 %, they press on its scalar register budget), 1 on, 2 plus per-lane-participation
  * histograms printed to stderr.  ninteractions, min / max and kernel_ms are always filled. */
 int shq_set_walk_stats(shq_context *ctx, int level);
+/* How shq_grav_short_run launches the exact primary walk (a tuning / test knob; results are the same interaction sets either way).
+ * persist: 0 one 64-target task per wave; 1 (default) persistent waves taking tasks from per-XCD counters once the launch exceeds
+ * what the chip holds at once; 2 persistent waves for every launch.  leaf_ring: 1 (default) leaf particles go through the
+ * wave-private LDS ring of the persistent walk, 0 they are evaluated as the leaf is opened (the reference's summation order). */
+int shq_set_walk_launch(shq_context *ctx, int persist, int leaf_ring);
+/* Checker utility: direct summation as the reference's own gravity test does it (force_direct / grav_force,
+ * libgadget/tests/test_gravity.cpp:41-76,121-143): accel[ns][3] (host) = acceleration at the ns sample positions (host, [ns][3]) from
+ * the first nsrc resident particles and their (2 repeat + 1)^3 periodic images, spline-softened below h.  Partial sums over a
+ * rank's local particles add up across ranks (bench.py's sampled force check of the sharded TreePM step). */
+int shq_direct_force_sample(shq_context *ctx, const double *sample_pos, int64_t ns, int64_t nsrc, double BoxSize, double G, double h,
+                            int repeat, double *accel);
 int shq_grav_short_download(shq_context *ctx, double (*accel)[3], double *potential,
                             int64_t *ninteractions, shq_walk_stats *stats);
 /* Secondary walk: TreeWalk::ev_secondary (libgadget/treewalk2.h:618-700) with GravLocalTreeWalk::visit

@@ -334,6 +334,14 @@ def synth_positions(kind, n, seed=20240601, L=1.0):
     return pos
 
 
+def synth_positions_range(kind, nglobal, first, count, seed=20240601, L=1.0):
+    """particles [first, first + count) of one global synthetic set of nglobal particles, the same for any split over ranks"""
+    k = {"grid": 0, "uniform": 1, "cluster": 2}[kind]
+    pos = np.empty((int(count), 3), dtype=np.float64)
+    capi.host.shqh_synth_positions_range(k, int(nglobal), int(first), int(count), seed, L, capi.ptr(pos))
+    return pos
+
+
 def morton_order(pos, L):
     pos = np.ascontiguousarray(pos, dtype=np.float64)
     order = np.empty(len(pos), dtype=np.int32)

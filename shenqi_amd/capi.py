@@ -424,6 +424,10 @@ hip.shq_ngb_toptree_exports.argtypes = [_vp, C.c_int, C.c_double, _vp, C.c_int64
 hip.shq_ngb_toptree_exports.restype = C.c_int
 hip.shq_set_walk_stats.argtypes = [_vp, C.c_int]
 hip.shq_set_walk_stats.restype = C.c_int
+hip.shq_set_walk_launch.argtypes = [_vp, C.c_int, C.c_int]
+hip.shq_set_walk_launch.restype = C.c_int
+hip.shq_direct_force_sample.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int, _vp]
+hip.shq_direct_force_sample.restype = C.c_int
 hip.shq_exchange_plan.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.c_int64, _vp, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _vp]
 hip.shq_exchange_pack.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, _vp, C.c_int64, _vp, C.c_int, _vp, _vp]
 hip.shq_exchange_unpack.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.c_int64, _vp, _vp, _vp, C.c_int]
@@ -614,6 +618,8 @@ host.shqh_grav_short_tree.argtypes = [_vp, _vp, _vp, C.c_double, C.c_int, C.c_do
 host.shqh_gravpm_force.argtypes = [_vp, _vp, C.c_double, C.c_int, C.c_double, C.c_int]
 host.shqh_synth_positions.argtypes = [C.c_int, C.c_int64, C.c_uint64, C.c_double, _vp]
 host.shqh_synth_positions.restype = None
+host.shqh_synth_positions_range.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_double, _vp]
+host.shqh_synth_positions_range.restype = None
 host.shqh_morton_order.argtypes = [_vp, C.c_int64, C.c_double, _vp]
 host.shqh_morton_order.restype = None
 host.shqh_hilbert_order.argtypes = [_vp, C.c_int64, C.c_double, _vp]

@@ -257,6 +257,14 @@ extern "C" void shq_shutdown(shq_context *ctx)
     delete ctx;
 }
 
+extern "C" int shq_set_walk_launch(shq_context *ctx, int persist, int leaf_ring)
+{
+    SHQ_CHECK(ctx && persist >= 0 && persist <= 2 && (leaf_ring == 0 || leaf_ring == 1), SHQ_ERR_INVALID, "walk launch: persist 0..2, leaf_ring 0 or 1");
+    ctx->walk_persist = persist;
+    ctx->walk_ring = leaf_ring;
+    return SHQ_OK;
+}
+
 extern "C" int shq_set_walk_stats(shq_context *ctx, int level)
 {
     SHQ_CHECK(ctx && level >= 0 && level <= 2, SHQ_ERR_INVALID, "walk stats level must be 0, 1 or 2");
@@ -643,8 +651,8 @@ extern "C" int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree)
                 g.bhlim = 0; /* filled per walk, like rcuthl */
                 g.mlen2 = g.mass * g.len * g.len; /* (mass * len) * len, as shall_we_open_node evaluates it */
                 g.inside = 0.6 * g.len;
-                g.halflen = 0.5 * g.len;
-                g.wraplim = 0.5 * tree->BoxSize - g.halflen;
+                g.rcut2 = 0;
+                g.wraplim = 0.5 * tree->BoxSize - 0.5 * g.len;
                 hG[k] = g;
                 hH[k] = sn.hmax;
             }

@@ -111,7 +111,9 @@ struct alignas(128) NodeG {
     double bhlim;    /* len * len / BHOpeningAngle^2 of the current walk parameters: the Barnes-Hut test is r2 < bhlim */
     double mlen2;    /* mass * len * len */
     double inside;   /* 0.6 * len */
-    double halflen;  /* 0.5 * len */
+    double rcut2;    /* Rcut^2 of the current walk parameters (the same in every record): arrives with the node instead of
+                        occupying a scalar register pair for the whole walk, which under the 96-SGPR cap the compiler re-read
+                        from the kernel arguments at every visit */
     double wraplim;  /* Box / 2 - len / 2: while every |center - pos| stays below it, neither the centre nor the
                         centre of mass (inside the cell) needs the periodic wrap */
     double rcuthl;   /* Rcut + len / 2 of the discard test, filled for the Rcut of the current walk parameters */

@@ -525,7 +525,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
                     nd.sibling = nd.child = -1;
                     nd.type = SHQ_PSEUDO_NODE_TYPE;
                     nd.count = 0;
-                    nd.bhlim = nd.mlen2 = nd.inside = nd.halflen = nd.wraplim = nd.rcuthl = 0;
+                    nd.bhlim = nd.mlen2 = nd.inside = nd.rcut2 = nd.wraplim = nd.rcuthl = 0;
                 }
                 const bool anywrap = shq_ballot(on && (fmax(fmax(fabs(nd.center[0] - cx) + hx, fabs(nd.center[1] - cy) + hy),
                                                               fabs(nd.center[2] - cz) + hz) > nd.wraplim)) != 0ull;

@@ -74,6 +74,17 @@ __device__ __forceinline__ double rsqrt_fast(double x)
     return fma(y0 * e, fma(e, 0.375, 0.5), y0);
 }
 
+/* A double constant materialised in scalar registers AT THE POINT OF USE.  The softened branch of apply_accn needs ten constants
+ * that are no inline literals; left to itself the compiler keeps them in twenty VGPRs for the whole kernel (hoisted out of the walk
+ * and, in the persistent variant, out of the task loop), which is the difference between 8 and 6 waves per SIMD.  The volatile asm
+ * pins the two s_mov_b32 inside the (rare) branch. */
+__device__ __forceinline__ double sconst(double c)
+{
+    unsigned lo = (unsigned) (unsigned long long) __double_as_longlong(c), hi = (unsigned) ((unsigned long long) __double_as_longlong(c) >> 32);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
+}
+
 /* apply_accn (gravshort2.hpp:326-358) + apply_short_range_window (gravity.h:48-60).
  * mass/(r2*r) is formed as mass*rinv^3 (a few ulp from the reference's sqrt + divide); a
  * coincident source (r2 == 0, the target itself) is clamped to a tiny r2 so that it falls in
@@ -91,39 +102,39 @@ __device__ __forceinline__ void apply_accn(const double4 *__restrict__ tab, doub
     const double r = r2c * rinv;
     const double mr = mass * rinv;
     double fac = mr * rinv * rinv;
-    double facpot = -mr;
+    double npot = mr; /* minus the potential factor: the Newtonian -m/r enters the sum through the negated-operand form of the fma below */
     if(r2 < a.h2) {
         const double u = r * a.h_inv;
         double wp;
         if(u < 0.5) {
-            fac = mass * a.h3_inv * (10.666666666667 + u * u * (32.0 * u - 38.4));
-            wp = -2.8 + u * u * (5.333333333333 + u * u * (6.4 * u - 9.6));
-            facpot = mass * a.h_inv * wp;
+            fac = mass * a.h3_inv * (sconst(10.666666666667) + u * u * (32.0 * u - sconst(38.4)));
+            wp = sconst(-2.8) + u * u * (sconst(5.333333333333) + u * u * (sconst(6.4) * u - sconst(9.6)));
+            npot = -(mass * a.h_inv * wp);
         } else {
             /* the reference's 0.0667 / u^3 and 0.0667 / u terms are the Newtonian force and potential themselves
              * (mass h^-3 / u^3 = mass / r^3, mass h^-1 / u = mass / r), already formed above from 1/r: no divisions */
-            fac = fma(mass * a.h3_inv, 21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u, -0.066666666667 * fac);
-            wp = -3.2 + u * u * (10.666666666667 + u * (-16.0 + u * (9.6 - 2.133333333333 * u)));
-            facpot = fma(mass * a.h_inv, wp, 0.066666666667 * mr);
+            fac = fma(mass * a.h3_inv, sconst(21.333333333333) - 48.0 * u + sconst(38.4) * u * u - sconst(10.666666666667) * u * u * u,
+                      sconst(-0.066666666667) * fac);
+            wp = sconst(-3.2) + u * u * (sconst(10.666666666667) + u * (-16.0 + u * (sconst(9.6) - sconst(2.133333333333) * u)));
+            npot = -fma(mass * a.h_inv, wp, sconst(0.066666666667) * mr);
         }
     }
-    const double fi = r * a.inv_celldx;
-    if(fi < (double) (SHQ_NGRAVTAB - 1)) {
-        const int ti = (int) fi;                     /* fi >= 0: truncation == floor */
-        const double w1 = __builtin_amdgcn_fract(fi); /* fi - floor(fi) */
-        if(POT) {
-            const double4 t = tab[ti];
-            fac *= fma(w1, t.y, t.x);
-            facpot *= fma(w1, t.w, t.z);
-            pot += facpot;
-        } else {
-            const double2 t = *reinterpret_cast<const double2 *>(&tab[ti]);
-            fac *= fma(w1, t.y, t.x);
-        }
-        ax = fma(dx, fac, ax);
-        ay = fma(dy, fac, ay);
-        az = fma(dz, fac, az);
+    /* apply_short_range_window (gravity.h:48-60): beyond the table (index >= NTAB - 1) the source contributes nothing.  No branch:
+     * the index is clamped to the last row, which the LDS copy of the table holds as zeros (row NTAB - 2 keeps its own differences). */
+    const double fi = fmin(r * a.inv_celldx, (double) (SHQ_NGRAVTAB - 1));
+    const int ti = (int) fi;                     /* fi >= 0: truncation == floor */
+    const double w1 = __builtin_amdgcn_fract(fi); /* fi - floor(fi) */
+    if(POT) {
+        const double4 t = tab[ti];
+        fac *= fma(w1, t.y, t.x);
+        pot = fma(-npot, fma(w1, t.w, t.z), pot);
+    } else {
+        const double2 t = *reinterpret_cast<const double2 *>(&tab[ti]);
+        fac *= fma(w1, t.y, t.x);
     }
+    ax = fma(dx, fac, ax);
+    ay = fma(dy, fac, ay);
+    az = fma(dz, fac, az);
 }
 
 /* wrapm: wave-uniform, zero when the leaf's own visit found every awake lane further than len/2 from the L/2 limit:
@@ -216,7 +227,7 @@ __device__ __forceinline__ void leaf_ring_drain(const double4 *__restrict__ tab,
 }
 
 template <bool POT, bool PREFETCH, int LEAFB, int STATS, bool BH, bool GHOSTS = false, bool PERSIST = false, bool RING = false>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(8, 8))) void grav_walk_exact_kernel(const WalkArgs a)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num_vgpr(64))) void grav_walk_exact_kernel(const WalkArgs a)
 {
     extern __shared__ double4 ring_all[]; /* RING: SHQ_LEAF_RING slots per wave */
     double4 *const ring = ring_all + (threadIdx.x >> 6) * SHQ_LEAF_RING;
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_wav
     for(int i = threadIdx.x; i < SHQ_NGRAVTAB; i += blockDim.x) {
         const int j = (i + 1 < SHQ_NGRAVTAB) ? i + 1 : i;
         const double f0 = a.tab_f[i], f1 = a.tab_f[j], p0 = a.tab_p[i], p1 = a.tab_p[j];
-        tab[i] = make_double4(f0, f1 - f0, p0, p1 - p0);
+        tab[i] = i + 1 < SHQ_NGRAVTAB ? make_double4(f0, f1 - f0, p0, p1 - p0) : make_double4(0, 0, 0, 0); /* last row: see apply_accn */
     }
     __syncthreads();
 
@@ -322,13 +333,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_wav
         }
         const double r2 = dx * dx + dy * dy + dz * dz;
         /* shall_we_discard_node, gravshort2.hpp:152-167 */
-        const bool discard = (r2 > a.rcut2) && (cmax > nd.rcuthl); /* rcuthl = Rcut + len / 2, per node */
+        const bool discard = (r2 > nd.rcut2) && (cmax > nd.rcuthl); /* rcuthl = Rcut + len / 2, per node */
         /* shall_we_open_node, gravshort2.hpp:172-193 (len*len/r2 > theta2 written without the divide;
          * mass*len*len and 0.6*len come precomputed with the node) */
         const bool open = (!BH && (nd.mlen2 > r2 * r2 * aold)) || (r2 < nd.bhlim) || (cmax < nd.inside);
         const bool accept = act && !discard && !open;
         const bool doopen = act && !discard && open;
-        const unsigned long long discardm = shq_ballot(r2 > a.rcut2) & shq_ballot(cmax > nd.rcuthl);
+        const unsigned long long discardm = shq_ballot(r2 > nd.rcut2) & shq_ballot(cmax > nd.rcuthl);
         const unsigned long long openm = (BH ? 0ull : shq_ballot(nd.mlen2 > r2 * r2 * aold)) | shq_ballot(r2 < nd.bhlim) |
                                          shq_ballot(cmax < nd.inside);
         const unsigned long long acceptm = actm & ~discardm & ~openm, doopenm = actm & ~discardm & openm;
@@ -405,20 +416,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_wav
                 if(doopen)
                     nint += cnt;
             }
-            if(act)
-                mynext = nd.sibling;
-            next = nd.sibling;
-        } else if(nd.type == SHQ_PSEUDO_NODE_TYPE) {
-            /* gravshort2.hpp:305-315: pseudo nodes are skipped by the local walk */
-            if(act)
-                mynext = nd.sibling;
-            next = nd.sibling;
-        } else {
-            bool anyopen = doopenm != 0ull;
+        }
+        /* Links.  A leaf or a pseudo node (gravshort2.hpp:305-315: skipped by the local walk) is left through its sibling whatever
+         * the lane decided; an internal node is entered by the lanes that open it.  Written as one select on a wave-uniform
+         * "is internal" flag rather than three branches on the node type: the compiler lowered those to a dozen scalar flag
+         * moves and branches per visit. */
+        {
+            const bool internal = nd.type == SHQ_NODE_NODE_TYPE;
+            bool anyopen = internal && doopenm != 0ull;
             if(GHOSTS) /* a lane waits at a branch below this node: go down even if nobody opens it */
-                anyopen = anyopen || shq_ballot(mynext > cur && (nd.sibling < 0 || mynext < nd.sibling)) != 0ull;
+                anyopen = anyopen || (internal && shq_ballot(mynext > cur && (nd.sibling < 0 || mynext < nd.sibling)) != 0ull);
+            const int down = internal ? nd.child : nd.sibling;
             if(act)
-                mynext = doopen ? nd.child : nd.sibling;
+                mynext = doopen ? down : nd.sibling;
             next = anyopen ? nd.child : nd.sibling;
         }
         if(GHOSTS && act && mynext == myend) { /* branch done: wait at the next one of the NodeList */
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_wav
         c.nint[pi] = nint;
     }
     /* statistics (treewalk2.h:446-448 interaction min/max) */
-    long long mn = valid ? nint : 0x7fffffffffffll, mx = valid ? nint : 0, sm = valid ? nint : 0;
+    long long mn = valid ? (long long) nint : __double_as_longlong(sconst(__longlong_as_double(0x7fffffffffffll))), mx = valid ? nint : 0, sm = valid ? nint : 0;
     for(int off = 32; off > 0; off >>= 1) {
         long long o1 = __shfl_xor(mn, off), o2 = __shfl_xor(mx, off), o3 = __shfl_xor(sm, off);
         mn = o1 < mn ? o1 : mn;
@@ -546,7 +556,8 @@ __global__ void fill_rcuthl_kernel(NodeG *g, long long n, double rcut, double bh
 {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if(i < n) {
-        g[i].rcuthl = rcut + g[i].halflen;
+        g[i].rcuthl = rcut + 0.5 * g[i].len;
+        g[i].rcut2 = rcut * rcut;
         g[i].bhlim = g[i].len * g[i].len / bh2; /* len^2 / r2 > theta^2 (gravshort2.hpp:179-182) as r2 < len^2 / theta^2 */
     }
 }
@@ -732,8 +743,11 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
      * 8 per CU, tasks from eight per-XCD counters */
     static const int bpc_env = getenv("SHQ_WALK_BLOCKS_PER_CU") ? atoi(getenv("SHQ_WALK_BLOCKS_PER_CU")) : 8;
     const int bpc = bpc_env >= 1 && bpc_env <= 8 ? bpc_env : 8; /* resident workgroups per CU (diagnostic: fewer leave room for other streams) */
-    const bool persist = ctx->walk_persist && !stats && variant == 3 && blocks > (long long) ctx->num_cus * bpc;
+    const bool persist = ctx->walk_persist && !stats && variant == 3 && (ctx->walk_persist == 2 || blocks > (long long) ctx->num_cus * bpc);
+    /* leaf ring: workgroups of 8 waves (4 per CU: one window table per 8 waves leaves the LDS room for the rings) */
+    const bool ring = persist && ctx->walk_ring && bpc == 8;
     long long launch_blocks = blocks;
+    size_t dyn_lds = 0;
     if(persist) {
         SHQ_TRY(ctx->walk_tasks.reserve(8 * 16));
         SHQ_HIP(hipMemsetAsync(ctx->walk_tasks.ptr, 0, sizeof(unsigned int) * 8 * 16, ctx->stream));
@@ -743,15 +757,14 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
         while((1u << lg) < 4u * (a.xcdK ? a.xcdK : 1u))
             lg++;
         a.task_run_log2 = lg;
-        launch_blocks = (long long) ctx->num_cus * bpc;
-    }
-    /* fewer than 8 resident workgroups per CU are enforced through the LDS allocation (160 KB per CU), not left to the dispatcher */
-    size_t dyn_lds = persist && bpc < 8 ? (size_t) ((160 * 1024 / bpc - 16384) / 1024 * 1024 - 1024) : 0;
-    /* leaf ring: workgroups of 8 waves (4 per CU: one window table per 8 waves leaves the LDS room for the rings) */
-    const bool ring = persist && ctx->walk_ring && bpc == 8;
-    if(ring) {
-        launch_blocks = (long long) ctx->num_cus * 4;
-        dyn_lds = sizeof(double4) * SHQ_LEAF_RING * 8;
+        const long long wpb = ring ? 8 : 4;                                   /* waves per workgroup */
+        const long long need = (nwaves + wpb - 1) / wpb, resident = (long long) ctx->num_cus * (ring ? 4 : bpc);
+        launch_blocks = need < resident ? need : resident;
+        /* fewer than 8 resident workgroups per CU are enforced through the LDS allocation (160 KB per CU), not left to the dispatcher */
+        if(bpc < 8)
+            dyn_lds = (size_t) ((160 * 1024 / bpc - 16384) / 1024 * 1024 - 1024);
+        if(ring)
+            dyn_lds = sizeof(double4) * SHQ_LEAF_RING * 8;
     }
     const dim3 grid((unsigned) launch_blocks), block(ring ? 512 : threads);
     SHQ_HIP(hipEventRecord(ctx->ev_begin[SHQ_NTIMERS - 1], ctx->stream));
@@ -786,6 +799,88 @@ int shq_launch_grav_postprocess(shq_context *ctx, const shq_grav_params *p, cons
         d_active, ntargets, ctx->posm.ptr + first, ctx->acc.ptr + 3 * first, ctx->pot.ptr + first, ctx->treeacc.ptr + 3 * first, p->G,
         p->ForceSoftening, p->cbrtrho0, update_potential);
     SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}
+
+/* ---- sampled direct summation (a checker utility: force_direct / grav_force of the reference's own gravity test,
+ * tests/test_gravity.cpp:41-76,121-143): the acceleration at `ns` sample positions from the first `nsrc` resident particles and
+ * their (2 repeat + 1)^3 periodic images, spline-softened below h.  One workgroup per (sample, source chunk). */
+namespace {
+__global__ __launch_bounds__(256) void direct_sample_kernel(const double *__restrict__ tpos, int ns, const double4 *__restrict__ posm,
+                                                            long long nsrc, long long chunk, double Box, double G, double h, int repeat,
+                                                            double *__restrict__ out)
+{
+    const int t = blockIdx.x;
+    const long long j0 = (long long) blockIdx.y * chunk, j1 = j0 + chunk < nsrc ? j0 + chunk : nsrc;
+    const double px = tpos[3 * t], py = tpos[3 * t + 1], pz = tpos[3 * t + 2];
+    const double h_inv = 1.0 / h, h3_inv = h_inv * h_inv * h_inv;
+    double ax = 0, ay = 0, az = 0;
+    for(long long j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+        const double4 q = posm[j];
+        for(int xx = -repeat; xx <= repeat; xx++)
+            for(int yy = -repeat; yy <= repeat; yy++)
+                for(int zz = -repeat; zz <= repeat; zz++) {
+                    const double dx = Box * xx + px - q.x, dy = Box * yy + py - q.y, dz = Box * zz + pz - q.z;
+                    const double r2 = dx * dx + dy * dy + dz * dz;
+                    if(r2 == 0)
+                        continue;
+                    const double r = sqrt(r2);
+                    double fac = 1 / (r2 * r);
+                    if(r < h) {
+                        const double u = r * h_inv;
+                        if(u < 0.5)
+                            fac = h3_inv * (10.666666666667 + u * u * (32.0 * u - 38.4));
+                        else
+                            fac = h3_inv * (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u - 0.066666666667 / (u * u * u));
+                    }
+                    const double f = -fac * G * q.w;
+                    ax += dx * f;
+                    ay += dy * f;
+                    az += dz * f;
+                }
+    }
+    __shared__ double red[3][4];
+    for(int off = 32; off > 0; off >>= 1) {
+        ax += __shfl_xor(ax, off);
+        ay += __shfl_xor(ay, off);
+        az += __shfl_xor(az, off);
+    }
+    if((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = ax;
+        red[1][threadIdx.x >> 6] = ay;
+        red[2][threadIdx.x >> 6] = az;
+    }
+    __syncthreads();
+    if(threadIdx.x < 3)
+        atomicAdd(&out[3 * t + threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+} // namespace
+
+extern "C" int shq_direct_force_sample(shq_context *ctx, const double *sample_pos, int64_t ns, int64_t nsrc, double BoxSize, double G, double h,
+                                       int repeat, double *accel)
+{
+    SHQ_CHECK(ctx && sample_pos && accel, SHQ_ERR_INVALID, "direct_force_sample: null argument");
+    SHQ_CHECK(ctx->have_parts && nsrc >= 0 && nsrc <= ctx->numpart, SHQ_ERR_STATE, "direct_force_sample: %ld sources but %ld resident particles", (long) nsrc,
+              (long) ctx->numpart);
+    SHQ_CHECK(ns >= 0 && ns <= 65535 && BoxSize > 0 && h > 0 && repeat >= 0 && repeat <= 2, SHQ_ERR_INVALID, "direct_force_sample: bad arguments");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    for(int64_t i = 0; i < 3 * ns; i++)
+        accel[i] = 0;
+    if(ns == 0 || nsrc == 0)
+        return SHQ_OK;
+    DevBuf<double> d_t, d_o;
+    SHQ_TRY(d_t.reserve((size_t) (3 * ns)));
+    SHQ_TRY(d_o.reserve((size_t) (3 * ns)));
+    SHQ_HIP(hipMemcpyAsync(d_t.ptr, sample_pos, sizeof(double) * 3 * ns, hipMemcpyHostToDevice, ctx->stream));
+    SHQ_HIP(hipMemsetAsync(d_o.ptr, 0, sizeof(double) * 3 * ns, ctx->stream));
+    const long long chunk = 1 << 16;
+    const unsigned nchunks = (unsigned) ((nsrc + chunk - 1) / chunk);
+    direct_sample_kernel<<<dim3((unsigned) ns, nchunks), dim3(256), 0, ctx->stream>>>(d_t.ptr, (int) ns, ctx->posm.ptr, nsrc, chunk, BoxSize, G, h, repeat, d_o.ptr);
+    SHQ_HIP(hipGetLastError());
+    SHQ_HIP(hipMemcpyAsync(accel, d_o.ptr, sizeof(double) * 3 * ns, hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    d_t.release();
+    d_o.release();
     return SHQ_OK;
 }
 

@@ -434,8 +434,8 @@ __global__ void tb_pack_kernel(int nn, const int32_t *__restrict__ order, const 
     g.bhlim = 0; /* filled per walk, like rcuthl */
     g.mlen2 = g.mass * g.len * g.len; /* (mass * len) * len, as shall_we_open_node evaluates it */
     g.inside = 0.6 * g.len;
-    g.halflen = 0.5 * g.len;
-    g.wraplim = 0.5 * Box - g.halflen;
+    g.rcut2 = 0;
+    g.wraplim = 0.5 * Box - 0.5 * g.len;
     G[r] = g;
 }
 

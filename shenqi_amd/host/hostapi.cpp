@@ -147,6 +147,44 @@ void shqh_synth_positions(int kind, int64_t n, uint64_t seed, double L, double *
     }
 }
 
+/* Particles [first, first + count) of ONE global synthetic set of n particles (same kinds as above): the set is made of blocks of
+ * 65536 particles, each with its own engine seeded from (seed, block), so any rank can generate any range of it and the union over
+ * ranks does not depend on how many ranks there are (bench.py --gpus N: one S-cluster cut across the ranks, not N of them). */
+void shqh_synth_positions_range(int kind, int64_t n, int64_t first, int64_t count, uint64_t seed, double L, double *pos)
+{
+    const int64_t B = 65536;
+    if(kind == 0) {
+        const int64_t nc = (int64_t) llround(cbrt((double) n));
+        for(int64_t k = 0; k < count; k++) {
+            const int64_t i = first + k;
+            pos[3 * k] = (L / nc) * (i / nc / nc);
+            pos[3 * k + 1] = (L / nc) * ((i / nc) % nc);
+            pos[3 * k + 2] = (L / nc) * (i % nc);
+        }
+        return;
+    }
+    const int64_t b0 = first / B, b1 = (first + count + B - 1) / B;
+#pragma omp parallel for schedule(dynamic, 1)
+    for(int64_t b = b0; b < b1; b++) {
+        std::mt19937_64 gen(seed ^ ((uint64_t) (b + 1) * 0x9E3779B97F4A7C15ull));
+        auto u01 = [&]() { return (double) (gen() >> 11) * (1.0 / 9007199254740992.0); };
+        for(int64_t i = b * B; i < (b + 1) * B && i < n; i++)
+            for(int j = 0; j < 3; j++) {
+                const double u = u01();
+                if(i < first || i >= first + count)
+                    continue;
+                double v;
+                if(kind == 1 || i < n / 4)
+                    v = L * u;
+                else if(i < 3 * n / 4)
+                    v = L / 2 + L / 8 * exp(pow(u - 0.5, 2));
+                else
+                    v = L * 0.1 + L / 32 * exp(pow(u - 0.5, 2));
+                pos[3 * (i - first) + j] = v;
+            }
+    }
+}
+
 /* Sort particle indices along a Morton (Z-order) key of `bits` bits per dimension so that
  * consecutive particles are spatially close (the reference keeps particles in Peano-Hilbert
  * order, domain.cpp:268; any space-filling order gives compact target groups). */

@@ -382,3 +382,29 @@ def test_dist_winds_two_gloo_ranks_one_gpu():
                 results.append(pickle.load(f))
         tdw.check(results, exact=False)
         assert all(r["nghost"] > 0 for r in results)
+
+
+def test_bench_driver_command_two_gloo_ranks():
+    """The driver's own multi-GPU command — `python bench.py --gpus 2`, which starts its ranks through torch.distributed.run
+    (bench.launch_ranks) — rehearsed on the one-GPU box with SHQ_BENCH_BACKEND=gloo (both ranks share device 0, exchanges staged
+    through the host): one JSON line on stdout, whole-job value, weak scaling, the sharded walk's roofline, and the sampled
+    force check of the global particle set against direct summation."""
+    import json
+    import subprocess
+    env = dict(os.environ, SHQ_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--ngrid", "32", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "particle-steps/s" and out["value"] > 0
+    assert out["config"]["particles_total"] == 40**3          # 32^3 per GPU, rounded to a multiple of 2 x ranks per dimension
+    assert out["roofline"]["bound"] == "valu-f64" and 0 < out["roofline"]["frac"] < 1
+    fe = out["force_error"]
+    assert "mean" in fe, fe
+    # the reference's own limits for PM + tree against the +-1 image sum (tests/test_gravity.cpp:294-355): mean < 0.8 x, max < 3 x ErrTol
+    # hold at its 16^3 size; at this size and ErrTolForceAcc 0.005 the check is a guard against gross errors (wrong ghosts, a missing slab)
+    assert fe["mean"] < 0.02 and fe["max"] < 0.1, fe

@@ -183,7 +183,7 @@ def test_fof_leaves_no_resident_tree_behind(ctx):
     assert rc == 4 and b"tree" in capi.hip.shq_last_error()      # SHQ_ERR_STATE
     sq.tree_build_device(ctx, cm.BOX)
     capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, 0))
-    nint = np.zeros(n, dtype=np.int32)
+    nint = np.zeros(n, dtype=np.int64)
     capi.check(capi.hip.shq_grav_short_download(ctx.h, None, None, capi.ptr(nint), None))
     assert (nint > 0).all()                                       # every type is back in the tree
 

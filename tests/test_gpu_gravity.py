@@ -71,6 +71,48 @@ def test_walk_exact_parity_16(ctx, kind, usebh):
     assert np.allclose(pot, opot, rtol=1e-10, atol=1e-10 * np.abs(opot).max())
 
 
+@pytest.mark.parametrize("kind", ["random", "cluster"])
+@pytest.mark.parametrize("usebh", [1, 0])
+def test_walk_launch_modes_agree_and_match_the_oracle(ctx, kind, usebh):
+    """The persistent launch (waves taking 64-target tasks from per-XCD counters) and its leaf ring (leaf particles evaluated out of a
+    wave-private LDS ring, shq_set_walk_launch) against the one-task-per-wave launch and the oracle: interaction counts identical as
+    integers in every mode; persistent without the ring is bit-identical to the plain launch (same order of the same operations);
+    with the ring a target's leaf particles are summed after, not between, its node interactions: forces to 1e-13 of the largest,
+    and within the same 1e-11 of the oracle as every other mode.  Ragged sizes: a last wave with idle lanes, fewer tasks than waves."""
+    n = 20**3 + 37
+    pos = _positions(kind, 20**3 + 37) if kind == "cluster" else cm.random_positions(orc.boost_mt19937_uniform(1, 3 * n), n)
+    pman = cm.make_partmanager(pos)
+    tree = sq.force_tree_full(pman)
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, TreeUseBH=usebh)
+    sq.gravshort_set_softenings(cm.BOX / 20)
+    gp = sq.make_grav_params(cm.BOX, 1.5, 60, cm.G, cm.RHO0)
+    rng = np.random.default_rng(9)
+    told, pold = rng.normal(size=(n, 3)) * 500.0, rng.normal(size=(n, 3)) * 50.0
+    mass = pman.Base["Mass"]
+    oacc, opot, onint = orc.grav_walk(tree.Nodes_base, tree.firstnode, pos, mass, np.linalg.norm(told + pold, axis=1) / cm.G, gp)
+    orc.grav_postprocess(mass, gp, oacc, opot, True)
+    res = {}
+    try:
+        for mode in ((0, 0), (2, 0), (2, 1)):
+            capi.check(capi.hip.shq_set_walk_launch(ctx.h, *mode))
+            res[mode] = _gpu_walk(ctx, pman, tree, gp, (told, pold))
+        sub = np.arange(5, n, 7, dtype=np.int32)        # an active list through the ring launch, no potential
+        capi.check(capi.hip.shq_set_walk_launch(ctx.h, 2, 1))
+        asub = _gpu_walk(ctx, pman, tree, gp, (told, pold), active=sub, update_potential=False)
+    finally:
+        capi.check(capi.hip.shq_set_walk_launch(ctx.h, 1, 1))
+    scale = np.abs(oacc).max()
+    for mode, (acc, pot, nint, st) in res.items():
+        assert np.array_equal(nint, onint), mode
+        assert st.ninteractions == onint.sum() and st.min_interactions == onint.min() and st.max_interactions == onint.max()
+        assert np.abs(acc - oacc).max() < 1e-11 * scale, mode
+        assert np.allclose(pot, opot, rtol=1e-10, atol=1e-10 * np.abs(opot).max()), mode
+    assert np.array_equal(res[(0, 0)][0], res[(2, 0)][0]) and np.array_equal(res[(0, 0)][1], res[(2, 0)][1])
+    assert np.abs(res[(2, 1)][0] - res[(0, 0)][0]).max() < 1e-13 * scale
+    assert np.array_equal(asub[2][sub], onint[sub])
+    assert np.abs(asub[0][sub] - oacc[sub]).max() < 1e-11 * scale
+
+
 def test_walk_exact_parity_64_cluster(ctx):
     """S-cluster 64^3, Nmesh 192, relative criterion at ErrTolForceAcc 0.005 (north-star setting)."""
     n = 64**3
