@@ -4,7 +4,7 @@ ARCH ?= gfx950
 CSRC := shenqi_amd/csrc
 LIBDIR := shenqi_amd/lib
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -Iinclude
-HIPSRC := $(CSRC)/capi.hip $(CSRC)/grav_walk.hip $(CSRC)/grav_group.hip $(CSRC)/pm.hip $(CSRC)/sph.hip $(CSRC)/sph_capi.hip $(CSRC)/fft3d.hip $(CSRC)/tree_build.hip $(CSRC)/dynamics.hip $(CSRC)/timestep.hip $(CSRC)/fof.hip $(CSRC)/exchange.hip $(CSRC)/toptree.hip
+HIPSRC := $(CSRC)/capi.hip $(CSRC)/grav_walk.hip $(CSRC)/grav_group.hip $(CSRC)/pm.hip $(CSRC)/sph.hip $(CSRC)/sph_capi.hip $(CSRC)/sph_resident.hip $(CSRC)/fft3d.hip $(CSRC)/tree_build.hip $(CSRC)/dynamics.hip $(CSRC)/timestep.hip $(CSRC)/fof.hip $(CSRC)/exchange.hip $(CSRC)/toptree.hip
 HIPOBJ := $(patsubst $(CSRC)/%.hip,$(LIBDIR)/%.o,$(HIPSRC))
 
 all: $(LIBDIR)/libshenqi_hip.so host oracle

@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sph", action="store_true", help="skip the SPH operator figures (kernels.sph_*)")
     ap.add_argument("--walk-mode", type=int, default=0)
+    ap.add_argument("--workload", default="dm", choices=["dm", "c5"],
+                    help="N > 1 only: dm = dm-only TreePM (the metric's configuration, default); c5 = BASELINE configs[4]-shaped step, "
+                         "n^3 gas + n^3 dark matter: sharded TreePM over all + device-resident sharded SPH density and hydro of the gas")
     return ap.parse_args()
 
 
@@ -156,7 +159,21 @@ def distributed_walk_figures(ctx, sq, capi, tree, pos, oldacc, gp_rel, n):
     ctx.synchronize()
     t0 = time.perf_counter()
     counts, table = sq.grav_toptree_exports(ctx, gp_rel, len(act), act)
+    t_top_host = time.perf_counter() - t0
+    # the resident form: target list and table stay in HBM, send counts per task come back, queries are packed on the device
+    import torch
+    d_act = torch.from_numpy(act).cuda()
+    nexp, tc = C.c_int64(0), np.zeros(8, dtype=np.int64)
+    d_q = torch.empty(max(1, len(table)) * capi.GRAV_QUERY_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    d_place = torch.empty(max(1, len(table)), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    capi.check(capi.hip.shq_grav_toptree_exports_resident(ctx.h, C.byref(gp_rel), d_act.data_ptr(), len(act), 1, 8, C.byref(nexp), capi.ptr(tc)))
+    capi.check(capi.hip.shq_grav_export_pack(ctx.h, d_q.data_ptr(), d_place.data_ptr()))
+    ctx.synchronize()
     t_top = time.perf_counter() - t0
+    assert nexp.value == len(table)
     # the owners' side: restore the undivided tree (flags only) and walk the exported queries
     nodes["flags"][:] = keep_flags | (nodes["flags"] & 3)
     nodes["suns"][:] = keep_suns
@@ -171,7 +188,10 @@ def distributed_walk_figures(ctx, sq, capi, tree, pos, oldacc, gp_rel, n):
     t_sec = time.perf_counter() - t0
     nodes["flags"][:] = keep_flags
     return {"dist_workload": "rank 0 of a fabricated 8-rank domain (512 top leaves) over the bench's tree", "dist_local_targets": int(len(act)),
-            "dist_exports": int(len(table)), "dist_export_detection_ms": 1e3 * t_top, "dist_secondary_queries": int(len(q)),
+            "dist_exports": int(len(table)), "dist_export_detection_ms": 1e3 * t_top,
+            "dist_export_detection_note": "resident: count + scan + fill + per-task send counts + query packing on the device (wall time); "
+                                          "with the list up and the counts and the table down over PCIe: dist_export_detection_host_table_ms",
+            "dist_export_detection_host_table_ms": 1e3 * t_top_host, "dist_secondary_queries": int(len(q)),
             "dist_secondary_walk_ms": 1e3 * t_sec, "dist_secondary_interactions_per_query": float(nint.mean()) if len(q) else 0.0}
 
 
@@ -317,6 +337,139 @@ def c3_step(ctx, gas_pos, n1, density_ms, hydro_ms):
             "c3_particle_steps_per_s": 2 * n / (1e-3 * total)}
 
 
+def run_sharded_c5(args, rank, world, backend, dev, cdev, json_fd, sq, capi, sd, dist, torch):
+    """BASELINE configs[4]-shaped step on N ranks (examples/hydro: 2 x n^3, gas + dark matter): sharded TreePM over all particles +
+    sharded SPH density (Hsml loop) and hydro force of the gas with the gas resident on the device (dist.DistSPHDevice).  Positions as
+    SURVEY 8(d) prescribes for gas configurations: dark matter uniform (the z = 99 initial conditions nearly are), gas = dark matter
+    shifted by (L / 2n)(1, 1, 1), m_gas / m_dm = 0.0464 / 0.2350, Vel ~ N(0, 0.01 L), Entropy 1, Hsml 1.5 L / n, quintic kernel.
+    Sub-grid physics (cooling, star formation) is out of scope; time bins all zero (every particle active)."""
+    n1 = int(round(args.n * world ** (1.0 / 3.0) / (2 * world))) * 2 * world if args.n != 256 else {2: 320, 4: 400, 8: 512}.get(world, 256)
+    n1 = max(n1, 2 * world)
+    nmesh = 3 * n1
+    L = 1.0
+    ndm = n1**3
+    mine = ndm // world + (1 if rank < ndm % world else 0)
+    first = rank * (ndm // world) + min(rank, ndm % world)
+    comm = sd.Comm()
+    t0 = time.perf_counter()
+    dm = sq.synth_positions_range("uniform", ndm, first, mine, seed=20240601, L=L)
+    gas = np.mod(dm + 0.5 * L / n1, L)
+    mg, md = 0.0464 / 0.2814, 0.2350 / 0.2814
+    posm = np.concatenate([np.concatenate([gas, np.full((mine, 1), mg)], axis=1), np.concatenate([dm, np.full((mine, 1), md)], axis=1)], axis=0)
+    rows = np.zeros((mine, capi.GAS_NCOL))
+    rows[:, 0:3], rows[:, 3] = gas, mg
+    rows[:, 4:7] = np.random.default_rng(100 + rank).normal(size=(mine, 3)) * 0.01 * L
+    rows[:, 7], rows[:, 17], rows[:, 20] = 1.5 * L / n1, 1.0, 1.0
+    posm = torch.from_numpy(posm).to(dev)
+    rows = torch.from_numpy(rows).to(dev)
+    bounds = sd.balanced_bounds(comm, nmesh, L, posm[:, 0])
+    work_stream = torch.cuda.Stream(device=dev)
+    work_stream.wait_stream(torch.cuda.current_stream(dev))
+    torch.cuda.set_stream(work_stream)
+    ctx = sq.Context(dev.index, stream=work_stream.cuda_stream)
+    ctx_sph = sq.Context(dev.index, stream=work_stream.cuda_stream)   # the gas set and its tree live beside the gravity set
+    sq.set_gravshort_treepar(ErrTolForceAcc=args.errtol, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=1, Rcut=6.0)
+    sq.gravshort_set_softenings(L / n1)
+    gp_bh = sq.make_grav_params(L, 1.5, nmesh, G, RHO0)
+    sq.set_gravshort_treepar(ErrTolForceAcc=args.errtol, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=0, Rcut=6.0)
+    gp_rel = sq.make_grav_params(L, 1.5, nmesh, G, RHO0)
+    drv = sd.DistTreePM(comm, ctx, nmesh, L, 1.5, G, dev, halo_factor=1.5, bounds=bounds)
+    local = sd.exchange_to_owner(comm, drv.decomp, posm)
+    rows = sd.exchange_to_owner(comm, drv.decomp, rows).contiguous()
+    del posm
+    drv.setup(local, gp_rel.Rcut)
+    drv.step(gp_bh)
+    sph = sd.DistSPHDevice(comm, drv.decomp, ctx_sph, L)
+    dp = sq.make_density_params(L, kernel=2, MinGasHsml=1e-6)
+    hp = sq.make_hydro_params(L, kernel=2)
+    rounds0 = sph.density(rows, dp)            # converges Hsml from the initial guess; the timed steps start from the converged values
+    sph.hydro(rows, hp)
+    t_setup = time.perf_counter() - t0
+
+    def step():
+        drv.step(gp_rel)
+        sph.density(rows, dp)
+        sph.hydro(rows, hp)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    ctx_sph.synchronize()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    # per-operator figures of one more, untimed step (walk as a single launch)
+    t1 = time.perf_counter()
+    drv.step(gp_rel, overlap=False)
+    ctx.synchronize()
+    t_grav = time.perf_counter() - t1
+    st = sq.WalkStats()
+    capi.check(capi.hip.shq_grav_short_download(ctx.h, None, None, None, C.byref(st)))
+    t1 = time.perf_counter()
+    sph.density(rows, dp)
+    ctx_sph.synchronize()
+    t_dens = time.perf_counter() - t1
+    dstat = dict(sph.stats["density"])
+    t1 = time.perf_counter()
+    sph.hydro(rows, hp)
+    ctx_sph.synchronize()
+    t_hyd = time.perf_counter() - t1
+    hstat = dict(sph.stats["hydro"])
+    ngas = int(rows.shape[0])
+    ngb = float(dp.DesNumNgb)
+    dens_s = 1e-3 * dstat["kernel_ms"] / max(1, dstat["iterations"])
+    cand = dstat["ninteractions"] / max(1, ngas) / max(1, dstat["iterations"])
+    dens_bytes = ngas * (cand * 32.0 + ngb * 114.0)
+    hyd_bytes = ngas * ngb * 200.0
+    hyd_s = 1e-3 * hstat["kernel_ms"]
+    walk_s = max(st.kernel_ms * 1e-3, 1e-12)
+    nglobal = 2 * ndm
+    note = "gather / VALU bound: SURVEY 8(d)'s neighbour stream (served from L2 / LDS) over the HBM peak; rank 0"
+    out = {
+        "metric": "particle-steps/sec (grav+PM+SPH) at 256^3; rms force error vs ref",
+        "metric_note": "C5-shaped extra mode (--workload c5): n^3 gas + n^3 dark matter, TreePM over all + SPH density and hydro of the gas",
+        "value": nglobal * args.steps / elapsed, "unit": "particle-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "2 x %d^3 gas + dark matter (uniform + shifted copy), Nmesh %d, sharded over %d x-slabs: TreePM over all, "
+                               "density (quintic kernel, Hsml loop) + hydro of the gas resident on the device" % (n1, nmesh, world),
+                   "particles_total": nglobal, "nmesh": nmesh, "parallelism": "x-slabs x%d, RCCL all-to-all + ghost particles + ghost gas rows" % world},
+        "roofline": {"bound": "valu-f64", "kernel": "grav_walk_exact_kernel (rank 0)", "achieved": 45.0 * st.ninteractions / walk_s / 1e12,
+                     "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": 45.0 * st.ninteractions / walk_s / 1e12 / FP64_VECTOR_PEAK_TF,
+                     "traffic": None, "algorithmic_flops": 45.0 * st.ninteractions},
+        "roofline_sph_density": {"bound": "gather-valu (stream from L2/LDS)", "kernel": "sph_density_kernel, one Hsml iteration (rank 0)",
+                                 "achieved": dens_bytes / max(dens_s, 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": dens_bytes / max(dens_s, 1e-12) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": dens_bytes,
+                                 "note": note},
+        "roofline_sph_hydro": {"bound": "gather-valu (stream from L2/LDS)", "kernel": "sph_hydro_kernel (rank 0)",
+                               "achieved": hyd_bytes / max(hyd_s, 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": hyd_bytes / max(hyd_s, 1e-12) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": hyd_bytes,
+                               "note": note},
+        "kernels": {"treepm_step_ms": 1e3 * t_grav, "tree_walk_ms": float(st.kernel_ms), "tree_interactions_per_target": st.ninteractions / max(1, st.ntargets),
+                    "density_call_ms": 1e3 * t_dens, "density_kernels_ms": dstat["kernel_ms"], "density_iterations": dstat["iterations"],
+                    "density_first_call_import_rounds": rounds0, "hydro_call_ms": 1e3 * t_hyd, "hydro_kernels_ms": hstat["kernel_ms"],
+                    "gas_local": ngas, "gas_ghosts_density": dstat["nghost"], "gas_ghosts_hydro": hstat["nghost"],
+                    "grav_local": int(drv.nloc), "grav_ghosts": int(drv.nghost)},
+        "setup_s": {"generate_exchange_tree_first_density": t_setup},
+    }
+    ctx_sph.close()
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
+
+
 def run_sharded(args, rank, local_rank, world):
     """N > 1: one rank per GPU over RCCL; x-slab sharded TreePM (shenqi_amd/dist.py)."""
     # torchrun exports OMP_NUM_THREADS=1 when the variable is unset; the host side (Hilbert order, tree hand-over) is threaded:
@@ -346,6 +499,8 @@ def run_sharded(args, rank, local_rank, world):
     import shenqi_amd as sq
     from shenqi_amd import capi, dist as sd
 
+    if args.workload == "c5":
+        return run_sharded_c5(args, rank, world, backend, dev, cdev, json_fd, sq, capi, sd, dist, torch)
     # 256^3 particles per GPU (weak scaling); meshes 3 n1 = 960, 1200, 1536 all have a bespoke FFT
     n1 = {2: 320, 4: 400, 8: 512}.get(world)
     if n1 is None:
@@ -777,6 +932,49 @@ def main():
             capi.check(capi.hip.shq_find_timesteps(ctx.h, C.byref(tp), None, 0, 0, -1, C.byref(tr)))
         out["kernels"]["find_timesteps_ms"] = 1e3 * (time.perf_counter() - t0) / 3
         out["kernels"]["find_timesteps_bins"] = [int(tr.mTimeBin), int(tr.maxTimeBin)]
+        # A hierarchical step (BASELINE configs[4] "hierarchical timestepping"; timestep.cpp:305-480) on the resident
+        # set, as a PM step runs it: gravity bins of all particles from the stored accelerations (shq_hier_gravity_bins), the
+        # push-down rule, then the sub-step levels inside the library (shq_hier_gravity_levels: sub-list -> tree of the sub-list ->
+        # walk -> bin refinement -> kick per level, SHQ_WALK_AUTO).  The top level of such a step is the full TreePM force of `value`.
+        try:
+            sq.tree_build_device(ctx, L)
+            capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp_rel), None, 0, 1, 0))
+            capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, G))
+            top = 40
+            tp.dti_max = 1 << top
+            capi.check(capi.hip.shq_hier_gravity_bins(ctx.h, C.byref(tp), None, 0, 0, top, C.byref(tr)))
+            counts = [int(c) for c in tr.timebincounts]
+            largest = next((b for b in range(top, 0, -1) if counts[b] > 0), top)
+            push = largest
+            for b in range(largest, 0, -1):          # the push-down of a PM step (timestep.cpp:393-414)
+                if counts[b] // 3 > counts[b - 1]:
+                    break
+                push = b - 1
+                counts[b - 1] += counts[b]
+            if 0 < push < largest:
+                capi.check(capi.hip.shq_hier_push_down(ctx.h, None, 0, push))
+                largest = push
+            gkl = np.full(capi.TIMEBINS + 1, 1e-24)
+            levels = (capi.HierLevel * capi.TIMEBINS)()
+            nlev, mingrav, bad = C.c_int(0), C.c_int(0), C.c_int64(0)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            capi.check(capi.hip.shq_hier_gravity_levels(ctx.h, C.byref(tp), C.byref(gp_rel), L, 0x3f, 0, largest, capi.ptr(gkl), sq.WALK_AUTO,
+                                                        C.byref(mingrav), C.byref(bad), levels, C.byref(nlev)))
+            ctx.synchronize()
+            t_lev = time.perf_counter() - t0
+            lv = [{"bin": int(levels[i].timebin), "particles": int(levels[i].nparticles), "tree_nodes": int(levels[i].tree_nodes),
+                   "tree_build_ms": float(levels[i].tree_build_ms), "walk_ms": float(levels[i].walk_ms),
+                   "walk": "group" if levels[i].walk_mode == sq.WALK_GROUP else "exact"} for i in range(nlev.value)]
+            out["kernels"]["hier_sublevels_ms"] = 1e3 * t_lev
+            out["kernels"]["hier_step_ms"] = out["ms_per_step"] + 1e3 * t_lev
+            out["kernels"]["hier_levels"] = lv
+            out["kernels"]["hier_note"] = ("PM step of the hierarchical integrator: top level = the TreePM force of `value` (ms_per_step) + %d sub-step "
+                                           "levels below bin %d run by shq_hier_gravity_levels on the resident set (wall time, host-inclusive); "
+                                           "substeps of the particles in a level = sum of the deeper levels' lists" % (nlev.value, largest))
+            out["kernels"]["hier_particle_substeps_per_s"] = (n + sum(x["particles"] for x in lv)) / (1e-3 * out["kernels"]["hier_step_ms"])
+        except sq.ShqError as e:
+            out["kernels"]["hier_note"] = "skipped: %s" % e
         fp = capi.FofParams(L, 0.2 * L / n1, 2, 1 + 16 + 32, 32, 0)
         ids = np.arange(1, n + 1, dtype=np.uint64)
         ng = C.c_int64()

@@ -175,9 +175,13 @@ typedef struct shq_walk_stats {
  * GROUP: one SOURCE per lane; the wave takes its 64 targets as 8 groups of 8, every pending node carries the mask of the
  *   members whose own walk reaches it, node tests run 64 nodes at a time and each accepted source is applied to exactly the
  *   members that accept it.  Same interaction set per target, summed in a different order (forces agree to ~1e-15
- *   relative).  The faster of the two for primary walks. */
+ *   relative).  Measured at 256^3 (S-cluster): 73 ms against 39.5 ms for all particles, but 3.9 against 7.2 ms for every 64th and
+ *   3.2 against 11.3 ms for every 512th particle of the same tree: the walk of choice for SPARSE active lists over a full tree.
+ * AUTO: GROUP when an active list holds fewer than a tenth of the tree's particles (where the two lines above cross), EXACT
+ *   otherwise — what the hierarchical integrator's levels should pass (timestep.cpp:437-446 walks ever shorter lists). */
 #define SHQ_WALK_EXACT 0
 #define SHQ_WALK_GROUP 1
+#define SHQ_WALK_AUTO 2
 /* flag, or-ed into walk_mode: with active == NULL, take the targets of the tree's particles sorted along a
  * Peano-Hilbert curve of their CURRENT positions (keys + radix sort on the device, ~2 ms for 1.7e7) instead of
  * particle-index order — same results per particle; keeps target groups compact when the particle
@@ -344,7 +348,7 @@ int shq_dynamics_download(shq_context *ctx, const shq_part_view *parts);
 
 /* The integer time line on the device (libgadget/timestep.cpp:157-194, 307-446, 584-822, 1012-1110):
  * new time bins for the resident particles from the accelerations, smoothing lengths and signal velocities that are in HBM
- * already.  The sync-point table, the cosmology and DriftKickTimes stay with the host (shenqi_amd/host/timestep.cpp mirrors
+ * already.  The sync-point table, the cosmology and DriftKickTimes stay with the host (integration/reference_side/timestep.cpp mirrors
  * find_timesteps / find_hydro_timesteps / hierarchical_gravity_and_timesteps over these calls); the per-particle loops and
  * their reductions run here.  IEEE sqrt and divide, no fma contraction: the bins equal the host loop's as integers.
  *
@@ -413,6 +417,19 @@ int shq_hier_gravity_bins(shq_context *ctx, const shq_timestep_params *p, const 
 int shq_hier_push_down(shq_context *ctx, const int32_t *active, int64_t nactive, int push_down_bin);
 int shq_hier_refine(shq_context *ctx, const shq_timestep_params *p, const int32_t *active, int64_t nactive, int from_accel_store, int ti,
                     shq_timestep_result *res);
+/* The sub-step levels of hierarchical_gravity_and_timesteps (timestep.cpp:417-476) in one call, resident: for ti = largest_active - 1
+ * ... 1: sub-list (gravity bin <= ti) -> tree of the sub-list -> walk without potential -> shq_hier_refine -> hierarchical kick
+ * Vel += Accel * gravkick_level[ti] (the caller's apply_hierarchical_grav_kick factor of level ti, :247-287, the lower level's kick
+ * already subtracted).  Stops at the first empty sub-list (*mingravtimebin = ti + 1, :427-431; unchanged otherwise).
+ * walk_mode: SHQ_WALK_EXACT / _GROUP / _AUTO for the level walks.  levels (may be NULL, capacity SHQ_TIMEBINS): what each level did. */
+typedef struct shq_hier_level {
+    int32_t timebin, walk_mode;       /* the level's bin; the walk it ran (what SHQ_WALK_AUTO resolved to) */
+    int64_t nparticles, tree_nodes;   /* sub-list length = particles of the level's tree; its nodes */
+    double tree_build_ms, walk_ms;    /* HIP-event times of the device tree build and of the walk kernel(s) */
+} shq_hier_level;
+int shq_hier_gravity_levels(shq_context *ctx, const shq_timestep_params *p, const shq_grav_params *gp, double BoxSize, int treemask,
+                            int64_t Ti_Current, int largest_active, const double gravkick_level[SHQ_TIMEBINS + 1], int walk_mode,
+                            int *mingravtimebin, int64_t *badstepsizecount, shq_hier_level *levels, int *nlevels);
 /* get_long_range_timestep_dloga's particle loop (timestep.cpp:1153-1166): per type, sum of |Vel|^2, smallest positive mass and
  * count over the live particles.  The sum runs in a fixed order (blocks of 256 in index order, then the block sums in order),
  * so it is reproducible; the reference's OpenMP reduction has no fixed order. */
@@ -496,7 +513,11 @@ int shq_slots_split_particles(shq_context *ctx, const shq_exchange_layout *layou
 int shq_slots_convert(shq_context *ctx, const shq_exchange_layout *layout, void *d_parts, int64_t numpart, int64_t MaxPart, void *const d_slots[6],
                       int64_t slot_size[6], const int64_t slot_maxsize[6], const int32_t *d_index, int64_t n, int ptype);
 
-/* make_particle_star (libgadget/sfr_eff.cpp:604-630) for the lists of the star-formation merge step (:344-372): entry k converts
+/* Scope note: star formation itself (the sfr_eff.cpp criteria, cooling, the random draws) is OUT of scope; this entry is
+ * kept only as the slot-manager side of it — the one place where slots_convert / slots_split_particle (the
+ * row these belong to) have to fill a freshly converted slot from another slot array while both stay in HBM.  The caller decides
+ * who forms a star; nothing here evaluates star-formation physics.
+ * make_particle_star (libgadget/sfr_eff.cpp:604-630) for the lists of the star-formation merge step (:344-372): entry k converts
  * children[k] (the parent itself, or the particle split off it) to a star at slot firststarslot + k and fills the slot from the
  * PARENT's gas slot as it was before the conversion: FormationTime = Time, LastEnrichmentMyr = TotalMassReturned = 0, BirthDensity,
  * VDisp, Metallicity, Metals[nmetals].  A parent that is not gas is SHQ_ERR_INVALID ("Only gas forms stars"), nothing touched.
@@ -669,6 +690,16 @@ int shq_grav_toptree_exports(shq_context *ctx, const shq_grav_params *params, co
                              int32_t *exportcounts, shq_data_index *table, int64_t capacity, int64_t *nexport);
 int shq_ngb_toptree_exports(shq_context *ctx, int symmetric, double BoxSize, const int32_t *active, int64_t nactive,
                             int32_t *exportcounts, shq_data_index *table, int64_t capacity, int64_t *nexport);
+/* The same export detection with everything left in HBM (what ev_count_exports + ev_toptree do on managed memory,
+ * treewalk2.cuh:243-334): active = NULL (all own particles), a resident handle, or — active_on_device != 0 — a DEVICE list.  Back
+ * come the number of exports and task_counts[ntask], the entries per destination task (the send counts of
+ * ev_send_recv_export_import, treewalk2.h:618-700); the table stays resident.  shq_grav_export_pack then writes, on the device,
+ * the GravTreeQuery records of the table in task order (entries of one task in table order) into d_queries and the particle
+ * index of every record into d_place (the `place` argument of shq_grav_reduce_export_results): the send buffer of the caller's
+ * all-to-all, never on the host. */
+int shq_grav_toptree_exports_resident(shq_context *ctx, const shq_grav_params *params, const int32_t *active, int64_t nactive,
+                                      int active_on_device, int ntask, int64_t *nexport, int64_t *task_counts);
+int shq_grav_export_pack(shq_context *ctx, shq_grav_query *d_queries, int32_t *d_place);
 /* GravTreeResult::reduce<TREEWALK_GHOSTS> (gravshort2.hpp:136-146) for n returned results: Accel[place[k]] += results[k].Acc
  * and, with update_potential, Potential likewise, in the order k = 0..n-1 (the reference's loop over its export table, so
  * a target's partial sums are added in the same order).  Needs a preceding shq_grav_short_run with
@@ -840,6 +871,26 @@ int shq_hydro_ev_secondary(shq_context *ctx, const shq_hydro_params *params, con
 int shq_hydro_ev_reduce(shq_context *ctx, const int32_t *place, const shq_hydro_result *results, int64_t n);
 int shq_hydro_ev_postprocess(shq_context *ctx);
 int shq_hydro_close(shq_context *ctx, const shq_part_view *parts, const shq_sph_view *sph, shq_sph_stats *stats);
+
+/* ---- the SPH operators on a gas set that is already in HBM (sharded runs: local + imported ghost gas as rows of a device buffer
+ * that came out of the all-to-all; shenqi_amd/dist.py DistSPHDevice) -----------------------------------------------------------
+ * A row holds what density() / hydro_force() read of a neighbour and write of a target, SHQ_GAS_NCOL doubles:
+ *    0-2 Pos   3 Mass   4-6 Vel   7 Hsml   8-10 FullTreeGravAccel   11-13 GravPM   14-16 HydroAccel   17 Entropy   18 DtEntropy
+ *    19 DelayTime   20 Density   21 EgyWtDensity   22 DhsmlEgyDensityFactor   23 DivVel   24 CurlVel   25 MaxSignalVel   26 DtHsml
+ *    27 TimeBinGravity + 256 TimeBinHydro (as a double)
+ * shq_gas_set_device : the n rows become the resident particle set (all Type 0; the first nlocal are this rank's own = the
+ *                      targets); any tree is dropped: shq_tree_build(ctx, BoxSize, GASMASK, NULL, 0, ...) comes next.
+ * shq_density_resident / shq_hydro_resident : density() with its Hsml loop (densitytree2.hpp:117-257, treewalk2.h:480-557) and
+ *                      hydro_force() (hydratree2.hpp:127-379) for the nlocal targets over the tree of all n; EntVarPred is evaluated
+ *                      per particle.  Same kernels as shq_density / shq_hydro_force.
+ * shq_gas_get_device : results back into the first n rows of d_rows: which & 1: Hsml, DtHsml, Density, EgyWtDensity,
+ *                      DhsmlEgyDensityFactor, DivVel, CurlVel; which & 2: HydroAccel, DtEntropy, MaxSignalVel.
+ * Only statistics cross PCIe. */
+#define SHQ_GAS_NCOL 28
+int shq_gas_set_device(shq_context *ctx, const double *d_rows, int64_t n, int64_t nlocal);
+int shq_gas_get_device(shq_context *ctx, double *d_rows, int64_t n, int which);
+int shq_density_resident(shq_context *ctx, const shq_density_params *params, shq_sph_stats *stats);
+int shq_hydro_resident(shq_context *ctx, const shq_hydro_params *params, shq_sph_stats *stats);
 
 /* For the walk that is open: the export table of its current queue (TopTreeWalk::toptree_visit with cull_node, symmetric
  * for hydro; outputs as shq_ngb_toptree_exports, exportcounts indexed by queue position) and the query records of a
@@ -1122,7 +1173,12 @@ int shq_pm_set_deposit_log2scale(shq_context *ctx, int e);
 /* Drop-ins for petapm_fft_r2c / petapm_fft_c2r (libgadget/petapm.cpp:49-71) on one rank: unscaled 3-D transforms of an
  * Nmesh^3 real array ([x][y][z], z fastest: real_space_region, petapm.cpp:256-260) to / from its half spectrum in the
  * reference's Fourier layout [y][z'][x], x fastest, z' <= Nmesh / 2 (fourier_space_region, petapm.cpp:262-270: what
- * pm_apply_transfer_function, :1258-1298, enumerates).  Host pointers.  The _xyz pair keeps the spectrum as [x][y][z']. */
+ * pm_apply_transfer_function, :1258-1298, enumerates).  Host pointers.  The _xyz pair keeps the spectrum as [x][y][z'].
+ * ONE RANK ONLY (NTask == 1, the 1 x 1 rank grid of petapm.cpp:220-226): for NTask > 1 the reference's 2-D np0 x np1 pencil
+ * layouts (petapm.cpp:217-282) are neither produced nor consumed by this library; a multi-rank run replaces petapm_force as a
+ * whole with the x-slab pipeline (shq_pm_slab2_* + the caller's all-to-all, INTEGRATION.md "PM on several ranks") — an
+ * MI355X-first choice for 8 GPUs on point-to-point xGMI (one transpose pair per PM step instead of ten), not a drop-in for
+ * petapm_fft_r2c / c2r there.  The other petapm clients (plane.cpp:326-341, uvbg.cpp:575) get these two calls and nothing more. */
 int shq_fft_r2c(shq_context *ctx, int Nmesh, const double *real, double *complx);
 int shq_fft_c2r(shq_context *ctx, int Nmesh, const double *complx, double *real);
 int shq_fft_r2c_xyz(shq_context *ctx, int Nmesh, const double *real, double *complx);

@@ -295,8 +295,7 @@ int find_hydro_timesteps(shq_context *ctx, const ActiveParticles *act, DriftKick
 }
 
 /* apply_hierarchical_grav_kick, timestep.cpp:247-287 */
-static int hierarchical_grav_kick(shq_context *ctx, const int32_t *list, const DriftKickTimes *times, const TimeBinMgr *tbm, int from_accel_store,
-                                  int ti, int largest_active)
+static double hierarchical_gravkick_factor(const DriftKickTimes *times, const TimeBinMgr *tbm, int ti, int largest_active)
 {
     const inttime_t dti = dti_from_timebin(ti);
     double gravkick = tbm->get_exact_gravkick_factor(times->Ti_kick[ti], times->Ti_kick[ti] + dti / 2);
@@ -305,6 +304,13 @@ static int hierarchical_grav_kick(shq_context *ctx, const int32_t *list, const D
         const double lowerkick = tbm->get_exact_gravkick_factor(times->Ti_kick[ti + 1], times->Ti_kick[ti + 1] + lowerdti / 2);
         gravkick -= lowerkick;
     }
+    return gravkick;
+}
+
+static int hierarchical_grav_kick(shq_context *ctx, const int32_t *list, const DriftKickTimes *times, const TimeBinMgr *tbm, int from_accel_store,
+                                  int ti, int largest_active)
+{
+    const double gravkick = hierarchical_gravkick_factor(times, tbm, ti, largest_active);
     double tab[TIMEBINS + 1];
     for(int b = 0; b <= TIMEBINS; b++)
         tab[b] = gravkick; /* one factor for the whole sub-list, whatever bin a particle has moved to */
@@ -381,26 +387,15 @@ int hierarchical_gravity_and_timesteps(shq_context *ctx, const ActiveParticles *
     if(int rc = shq_grav_refresh_oldacc(ctx, gp.G)) /* grav_get_abs_accel of FullTreeGravAccel + GravPM, unchanged by the sub-steps */
         return fail(rc);
     int64_t badstepsizecount = 0;
-    for(ti = largest_active - 1; ti > 0; ti--) {
-        int64_t nsub = 0;
-        /* build_active_sublist(lastact, ti): the predicate is monotone in ti and bins only change inside the previous
-         * sub-list, so selecting from the full resident list gives the same particles in the same order */
-        if(int rc = shq_build_active_sublist(ctx, ti, times->Ti_Current, &nsub))
-            return fail(rc);
-        if(nsub == 0) {
-            times->mingravtimebin = ti + 1;
-            break;
-        }
-        if(int rc = shq_tree_build(ctx, pm->BoxSize, treemask, SHQ_SUBLIST_RESIDENT, 0, nullptr))
-            return fail(rc);
-        if(int rc = shq_grav_short_run(ctx, &gp, SHQ_SUBLIST_RESIDENT, 0, 0, walk_mode))
-            return fail(rc);
-        if(int rc = shq_hier_refine(ctx, &p, SHQ_SUBLIST_RESIDENT, 0, 1, ti, &r))
-            return fail(rc);
-        badstepsizecount += r.badstepsizecount;
-        if(int rc = hierarchical_grav_kick(ctx, SHQ_SUBLIST_RESIDENT, times, timebinmgr, 1, ti, largest_active))
-            return rc;
-    }
+    /* the levels run inside the library (shq_hier_gravity_levels); the kick factors are the host's (cosmology integrals) */
+    double kick_level[TIMEBINS + 1] = {};
+    for(ti = largest_active - 1; ti > 0; ti--)
+        kick_level[ti] = hierarchical_gravkick_factor(times, timebinmgr, ti, largest_active);
+    int mingrav = times->mingravtimebin;
+    if(int rc = shq_hier_gravity_levels(ctx, &p, &gp, pm->BoxSize, treemask, times->Ti_Current, largest_active, kick_level, walk_mode, &mingrav,
+                                        &badstepsizecount, nullptr, nullptr))
+        return fail(rc);
+    times->mingravtimebin = mingrav;
     times->mintimebin = times->mingravtimebin;
     if(badstepsizecount_out)
         *badstepsizecount_out = badstepsizecount;

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import (PARTICLE_DTYPE, SPH_DTYPE, NODE_DTYPE, WALK_EXACT, WALK_GROUP, WALK_TREE_ORDER, WALK_DEFER_POSTPROCESS, GravParams, PMParams,
+from .capi import (PARTICLE_DTYPE, SPH_DTYPE, NODE_DTYPE, WALK_EXACT, WALK_GROUP, WALK_AUTO, WALK_TREE_ORDER, WALK_DEFER_POSTPROCESS, GravParams, PMParams,
                    WalkStats, ShqError)
 
 GASMASK, DMMASK, NUMASK, STARMASK, BHMASK = 1, 2, 4, 16, 32
@@ -340,6 +340,32 @@ def synth_positions_range(kind, nglobal, first, count, seed=20240601, L=1.0):
     pos = np.empty((int(count), 3), dtype=np.float64)
     capi.host.shqh_synth_positions_range(k, int(nglobal), int(first), int(count), seed, L, capi.ptr(pos))
     return pos
+
+
+def make_density_params(BoxSize, kernel=1, eta=1.0, MaxNumNgbDeviation=0.5, BlackHoleNgbFactor=2.0, update_hsml=1, DoEgyDensity=1, BlackHoleOn=0, MinGasHsml=0.006):
+    """POD mirror of DensityPriv (densitytree2.hpp:10-52) for the C-ABI: DesNumNgb from DensityKrnl::desnumngb (densitykernel.hpp:36-41);
+    kick factors all zero"""
+    support = {1: 4, 2: 6, 4: 5}[kernel]
+    des = 4.0 / 3 * np.pi * (support / 2.0 * eta) ** 3
+    dp = capi.DensityParams()
+    dp.BoxSize, dp.DesNumNgb, dp.DesNumNgbBH, dp.MinGasHsml = BoxSize, des, des * BlackHoleNgbFactor, MinGasHsml
+    dp.MaxNumNgbDeviation = MaxNumNgbDeviation
+    dp.update_hsml, dp.BlackHoleOn, dp.DoEgyDensity, dp.WindsDecouple = update_hsml, BlackHoleOn, DoEgyDensity, 0
+    dp.DensityKernelType = kernel
+    return dp
+
+
+def make_hydro_params(BoxSize, atime=0.1, hubble=0.1, kernel=1, DensityIndependentSphOn=1, DensityContrastLimit=100.0, ArtBulkViscConst=0.75):
+    """POD mirror of HydroPriv (hydratree2.hpp:83-119) for the C-ABI; kick factors and drifts all zero"""
+    g = 5.0 / 3.0
+    hp = capi.HydroParams()
+    hp.BoxSize, hp.atime = BoxSize, atime
+    hp.fac_mu = atime ** (3 * (g - 1) / 2) / atime
+    hp.fac_vsic_fix = hubble * atime ** (3 * (g - 1))
+    hp.hubble_a2 = hubble * atime * atime
+    hp.ArtBulkViscConst, hp.DensityContrastLimit = ArtBulkViscConst, DensityContrastLimit
+    hp.DensityIndependentSphOn, hp.DensityKernelType = DensityIndependentSphOn, kernel
+    return hp
 
 
 def morton_order(pos, L):

@@ -18,6 +18,7 @@ NOFIELD = C.c_size_t(-1).value
 
 WALK_EXACT = 0
 WALK_GROUP = 1
+WALK_AUTO = 2
 WALK_TREE_ORDER = 0x100
 WALK_DEFER_POSTPROCESS = 0x200
 
@@ -322,6 +323,12 @@ class TimestepResult(C.Structure):
                 ("timebincounts", C.c_int64 * (TIMEBINS + 1))]
 
 
+class HierLevel(C.Structure):
+    """shq_hier_level"""
+    _fields_ = [("timebin", C.c_int32), ("walk_mode", C.c_int32), ("nparticles", C.c_int64), ("tree_nodes", C.c_int64),
+                ("tree_build_ms", C.c_double), ("walk_ms", C.c_double)]
+
+
 class DriftKickTimes(C.Structure):
     """DriftKickTimes, libgadget/timestep.h:10-26"""
     _fields_ = [("mintimebin", C.c_int), ("maxtimebin", C.c_int), ("mingravtimebin", C.c_int), ("Ti_kick", C.c_int64 * (TIMEBINS + 1)),
@@ -422,6 +429,17 @@ hip.shq_grav_toptree_exports.argtypes = [_vp, C.POINTER(GravParams), _vp, C.c_in
 hip.shq_grav_toptree_exports.restype = C.c_int
 hip.shq_ngb_toptree_exports.argtypes = [_vp, C.c_int, C.c_double, _vp, C.c_int64, _vp, _vp, C.c_int64, C.POINTER(C.c_int64)]
 hip.shq_ngb_toptree_exports.restype = C.c_int
+hip.shq_grav_toptree_exports_resident.argtypes = [_vp, C.POINTER(GravParams), _vp, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), _vp]
+hip.shq_grav_toptree_exports_resident.restype = C.c_int
+hip.shq_grav_export_pack.argtypes = [_vp, _vp, _vp]
+hip.shq_grav_export_pack.restype = C.c_int
+GAS_NCOL = 28
+hip.shq_gas_set_device.argtypes = [_vp, _vp, C.c_int64, C.c_int64]
+hip.shq_gas_get_device.argtypes = [_vp, _vp, C.c_int64, C.c_int]
+hip.shq_density_resident.argtypes = [_vp, C.POINTER(DensityParams), C.POINTER(SphStats)]
+hip.shq_hydro_resident.argtypes = [_vp, C.POINTER(HydroParams), C.POINTER(SphStats)]
+for _f in ("shq_gas_set_device", "shq_gas_get_device", "shq_density_resident", "shq_hydro_resident"):
+    getattr(hip, _f).restype = C.c_int
 hip.shq_set_walk_stats.argtypes = [_vp, C.c_int]
 hip.shq_set_walk_stats.restype = C.c_int
 hip.shq_set_walk_launch.argtypes = [_vp, C.c_int, C.c_int]
@@ -525,6 +543,9 @@ hip.shq_build_active_particles.argtypes = [_vp, C.c_int64, C.c_int, C.POINTER(Ac
 hip.shq_build_active_particles.restype = C.c_int
 hip.shq_build_active_sublist.argtypes = [_vp, C.c_int, C.c_int64, C.POINTER(C.c_int64)]
 hip.shq_build_active_sublist.restype = C.c_int
+hip.shq_hier_gravity_levels.argtypes = [_vp, _tsp, C.POINTER(GravParams), C.c_double, C.c_int, C.c_int64, C.c_int, _vp, C.c_int, C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int64), C.POINTER(HierLevel), C.POINTER(C.c_int)]
+hip.shq_hier_gravity_levels.restype = C.c_int
 hip.shq_active_download.argtypes = [_vp, C.c_int, _vp, C.c_int64, C.POINTER(C.c_int64)]
 hip.shq_active_download.restype = C.c_int
 hip.shq_kick_hydro.argtypes = [_vp, _vp, _vp, C.c_double, C.c_double, _vp, C.c_int64, C.c_int, C.POINTER(C.c_int64)]

@@ -417,6 +417,7 @@ extern "C" int shq_particles_upload(shq_context *ctx, const shq_part_view *parts
     ctx->have_tree_targets = false;
     ctx->tb_built = false;
     ctx->have_sph = false;  /* Hsml / Vel / slot data of the previous particle set */
+    ctx->gas_resident = false;
     ctx->have_dyn = false;
     ctx->have_bh_dyn = false;
     ctx->nbh = 0;
@@ -753,6 +754,7 @@ extern "C" int shq_particles_set_device(shq_context *ctx, const void *d_posm, in
     }
     ctx->have_tree_targets = false; /* nlocal may have changed */
     ctx->have_sph = false;
+    ctx->gas_resident = false;
     ctx->have_dyn = false;
     ctx->have_bh_dyn = false;
     ctx->nbh = 0;

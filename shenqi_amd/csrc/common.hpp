@@ -230,6 +230,10 @@ struct shq_context {
     DevBuf<int32_t> nint;      /* [N] interactions */
     DevBuf<uint8_t> pflags;    /* bit0 garbage, bit1 swallowed; bits 4-7 type */
     DevBuf<int32_t> active;    /* uploaded active list */
+    DevBuf<unsigned long long> top_task; /* resident export detection: entries per destination task */
+    DevBuf<int32_t> top_sort;            /* (task, entry) pairs before / after the stable sort */
+    DevBuf<long long> top_slot;          /* entry -> slot in the task-ordered send buffer */
+    long long top_ntargets = 0, top_nexport = -1;
     DevBuf<TopNodeG> topnodes;
     DevBuf<int2> topleaves;
     DevBuf<int32_t> top_counts;
@@ -311,6 +315,8 @@ struct shq_context {
     DevBuf<double> g_entropy, g_dtentropy, g_hydroaccel, g_delaytime;
     DevBuf<double> g_density, g_egywt, g_dhsmlegy, g_divvel, g_curlvel;
     DevBuf<double> g_hydroaccel_out, g_dtentropy_out, g_maxsignalvel;
+    bool gas_resident = false; /* the particle set came from shq_gas_set_device (rows of SHQ_GAS_NCOL doubles) */
+    DevBuf<int> gas_bad;
     /* particle exchange (exchange.hip) */
     DevBuf<int32_t> ex_list, ex_val[3];
     DevBuf<unsigned int> ex_key[4];
@@ -390,6 +396,7 @@ struct shq_context {
     DevBuf<unsigned int> walk_tasks; /* the task counters of the persistent walk */
     int xcd_k = 32;            /* SHQ_XCD_K: blocks per XCD chunk in the remap (0 = off); 32 measured best (2 %) */
     float last_walk_ms = 0;
+    int last_walk_mode = 0;    /* what SHQ_WALK_AUTO resolved to in the last launch */
 
     /* host staging */
     PinBuf<char> stage;

@@ -297,12 +297,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
     unsigned int hv[8] = {}, hn[8] = {}, hl[8] = {};
     unsigned int lonely8 = 0, lonely16 = 0; /* STATS == 2: this lane's interactions in rounds of <= 8 / <= 16 lanes */
 
-    NodeG nd = nodeG[cur];
-
-    while(cur >= 0) {
-        NodeG nd1;
-        if(PREFETCH) /* pool is padded by one record */
-            nd1 = nodeG[cur + 1];
+    do { /* cur >= 0: the root on entry, then every node the union walk reaches */
+        const NodeG nd = nodeG[cur];
         if(STATS)
             visited++;
         const bool act = (mynext == cur);
@@ -317,9 +313,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
         double dx = nd.cofm[0] - px, dy = nd.cofm[1] - py, dz = nd.cofm[2] - pz;
         double ux = nd.center[0] - px, uy = nd.center[1] - py, uz = nd.center[2] - pz;
         double cmax = fmax(fmax(fabs(ux), fabs(uy)), fabs(uz));
-        /* Wave votes are formed from the lane masks of the single comparisons (shq_ballot of one compare is that
-         * compare's own result) and combined with scalar logic; a vote on a compound boolean would cost two
-         * extra VALU instructions each, three times per node. */
+        /* Wave votes are formed from the lane masks of the single comparisons (shq_ballot of one compare is that compare's own
+         * result) and combined with scalar logic; the per-lane decisions are those masks read back as lane conditions
+         * (inverse ballot: no instruction).  A vote on a compound boolean would cost two VALU instructions, and lane booleans
+         * computed beside the masks would repeat the whole scalar algebra: every scalar instruction holds the SIMD's scalar pipe
+         * for four cycles, as long as an f64 instruction holds the vector pipe, and the walk issues nearly as many of the one as
+         * of the other (SQ_INSTS_SALU 61 k, SQ_INSTS_VALU 66 k per task). */
         const unsigned long long actm = shq_ballot(mynext == cur);
         const unsigned long long wrapm = shq_ballot(cmax > nd.wraplim) & actm;
         if(wrapm != 0ull) {
@@ -332,25 +331,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
             cmax = fmax(fmax(fabs(ux), fabs(uy)), fabs(uz));
         }
         const double r2 = dx * dx + dy * dy + dz * dz;
-        /* shall_we_discard_node, gravshort2.hpp:152-167 */
-        const bool discard = (r2 > nd.rcut2) && (cmax > nd.rcuthl); /* rcuthl = Rcut + len / 2, per node */
+        /* shall_we_discard_node, gravshort2.hpp:152-167 (rcuthl = Rcut + len / 2, per node) */
+        const unsigned long long keepm = actm & ~(shq_ballot(r2 > nd.rcut2) & shq_ballot(cmax > nd.rcuthl));
         /* shall_we_open_node, gravshort2.hpp:172-193 (len*len/r2 > theta2 written without the divide;
          * mass*len*len and 0.6*len come precomputed with the node) */
-        const bool open = (!BH && (nd.mlen2 > r2 * r2 * aold)) || (r2 < nd.bhlim) || (cmax < nd.inside);
-        const bool accept = act && !discard && !open;
-        const bool doopen = act && !discard && open;
-        const unsigned long long discardm = shq_ballot(r2 > nd.rcut2) & shq_ballot(cmax > nd.rcuthl);
         const unsigned long long openm = (BH ? 0ull : shq_ballot(nd.mlen2 > r2 * r2 * aold)) | shq_ballot(r2 < nd.bhlim) |
                                          shq_ballot(cmax < nd.inside);
-        const unsigned long long acceptm = actm & ~discardm & ~openm, doopenm = actm & ~discardm & openm;
+        const unsigned long long acceptm = keepm & ~openm, doopenm = keepm & openm;
+        const bool accept = __builtin_amdgcn_inverse_ballot_w64(acceptm), doopen = __builtin_amdgcn_inverse_ballot_w64(doopenm);
 
-        if(acceptm != 0ull) {
-            if(STATS) {
+        {
+            if(STATS && acceptm != 0ull) {
                 wave_applies++;
                 wave_node_applies++;
                 node_int_wave += (unsigned int) __popcll(acceptm);
             }
-            if(STATS == 2) {
+            if(STATS == 2 && acceptm != 0ull) {
                 const int pc = __popcll(acceptm);
                 hn[(pc - 1) >> 3 & 7]++;
                 if(accept && pc <= 8)
@@ -366,6 +362,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
         int next;
         if(nd.type == SHQ_PARTICLE_NODE_TYPE) {
             /* gravshort2.hpp:290-304: every particle of an opened leaf is evaluated */
+            asm volatile("" ::: "memory"); /* two scalar compare-and-branch pairs, not a merged boolean (five more scalar instructions) */
             if(RING && doopenm != 0ull) {
                 const int cnt = nd.count;
                 if(ringfill + cnt > SHQ_LEAF_RING) {
@@ -422,14 +419,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
          * "is internal" flag rather than three branches on the node type: the compiler lowered those to a dozen scalar flag
          * moves and branches per visit. */
         {
-            const bool internal = nd.type == SHQ_NODE_NODE_TYPE;
-            bool anyopen = internal && doopenm != 0ull;
-            if(GHOSTS) /* a lane waits at a branch below this node: go down even if nobody opens it */
-                anyopen = anyopen || (internal && shq_ballot(mynext > cur && (nd.sibling < 0 || mynext < nd.sibling)) != 0ull);
-            const int down = internal ? nd.child : nd.sibling;
+            /* the lanes that descend: those that open an internal node (a wave-uniform select on the node type, not a branch) */
+            unsigned long long descendm = nd.type == SHQ_NODE_NODE_TYPE ? doopenm : 0ull;
+            const bool descend = __builtin_amdgcn_inverse_ballot_w64(descendm);
+            if(GHOSTS && nd.type == SHQ_NODE_NODE_TYPE) /* a lane waits at a branch below this node: go down even if nobody opens it */
+                descendm |= shq_ballot(mynext > cur && (nd.sibling < 0 || mynext < nd.sibling));
             if(act)
-                mynext = doopen ? down : nd.sibling;
-            next = anyopen ? nd.child : nd.sibling;
+                mynext = descend ? nd.child : nd.sibling;
+            next = descendm != 0ull ? nd.child : nd.sibling;
         }
         if(GHOSTS && act && mynext == myend) { /* branch done: wait at the next one of the NodeList */
             mynext = seg1 >= 0 ? seg1 : -2;
@@ -438,13 +435,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
             seg3 = -1;
             myend = mynext >= 0 ? a.nodeG[mynext].sibling : -1;
         }
-        next = __builtin_amdgcn_readfirstlane(next);
-        if(PREFETCH && next == cur + 1)
-            nd = nd1;
-        else if(next >= 0)
-            nd = nodeG[next];
-        cur = next;
-    }
+        cur = __builtin_amdgcn_readfirstlane(next);
+    } while(cur >= 0);
 
     if(RING)
         leaf_ring_drain<POT>(tab, ring, ringmask, px, py, pz, a, ax, ay, az, pot, ringwrap);
@@ -700,6 +692,9 @@ int shq_launch_grav_walk_ghosts(shq_context *ctx, const shq_grav_params *p, cons
 int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets,
                          int update_potential, int walk_mode, int64_t first)
 {
+    if(walk_mode == SHQ_WALK_AUTO)
+        walk_mode = (d_active && ntargets * 10 < ctx->ntreeparts) ? SHQ_WALK_GROUP : SHQ_WALK_EXACT;
+    ctx->last_walk_mode = walk_mode;
     if(walk_mode == SHQ_WALK_GROUP)
         return shq_launch_grav_walk_group(ctx, p, d_active, ntargets, update_potential, first);
     SHQ_CHECK(first >= 0 && (first == 0 || !d_active) && (first + ntargets <= ctx->numpart || (d_active && ctx->allow_padding)), SHQ_ERR_INVALID,
@@ -770,15 +765,15 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     SHQ_HIP(hipEventRecord(ctx->ev_begin[SHQ_NTIMERS - 1], ctx->stream));
     if(update_potential) {
         switch(variant) {
-        case 0: launch_variant<true, true, 4>(stats, persist, grid, block, ctx->stream, a); break;
-        case 1: launch_variant<true, true, 2>(stats, persist, grid, block, ctx->stream, a); break;
+        case 0: launch_variant<true, false, 4>(stats, persist, grid, block, ctx->stream, a); break;
+        case 1: launch_variant<true, false, 2>(stats, persist, grid, block, ctx->stream, a); break;
         case 2: launch_variant<true, false, 4>(stats, persist, grid, block, ctx->stream, a); break;
         default: launch_variant<true, false, 2>(stats, persist, grid, block, ctx->stream, a, dyn_lds); break;
         }
     } else {
         switch(variant) {
-        case 0: launch_variant<false, true, 4>(stats, persist, grid, block, ctx->stream, a); break;
-        case 1: launch_variant<false, true, 2>(stats, persist, grid, block, ctx->stream, a); break;
+        case 0: launch_variant<false, false, 4>(stats, persist, grid, block, ctx->stream, a); break;
+        case 1: launch_variant<false, false, 2>(stats, persist, grid, block, ctx->stream, a); break;
         case 2: launch_variant<false, false, 4>(stats, persist, grid, block, ctx->stream, a); break;
         default: launch_variant<false, false, 2>(stats, persist, grid, block, ctx->stream, a, dyn_lds); break;
         }

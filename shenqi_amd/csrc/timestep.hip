@@ -9,7 +9,7 @@
  *   hierarchical_gravity_and_timesteps (three loops)              libgadget/timestep.cpp:356-380, 407-414, 449-464
  *   get_long_range_timestep_dloga (particle loop)                 libgadget/timestep.cpp:1153-1166
  *   black-hole half of do_hydro_kick, repositioning of the drift  libgadget/timestep.cpp:973-979, drift.cpp:32-53
- * The sync-point table, cosmology and DriftKickTimes stay on the host (shenqi_amd/host/timestep.cpp). */
+ * The sync-point table, cosmology and DriftKickTimes stay on the host (integration/reference_side/timestep.cpp). */
 #include "common.hpp"
 #include <string.h>
 #include <vector>
@@ -676,6 +676,57 @@ extern "C" int shq_hier_refine(shq_context *ctx, const shq_timestep_params *p, c
         SHQ_HIP(hipGetLastError());
     }
     return fetch(ctx, res);
+}
+
+/* The sub-step levels of hierarchical_gravity_and_timesteps (timestep.cpp:417-476) as one resident loop: for ti = largest_active - 1
+ * down to 1: the sub-list of the particles whose gravity bin is <= ti (build_active_sublist, :1373-1399), a tree of just those
+ * (force_tree_rebuild_mask over the sub-list, :437-441), their short-range walk without potential into AccelStore (:446), the bin
+ * refinement from that acceleration (:449-464) and the hierarchical kick of the level (:469).  Nothing but the sub-list length and
+ * the refinement tallies crosses PCIe.  The walk of a level is launched with `walk_mode` (SHQ_WALK_AUTO picks the sparse-list walk
+ * where a list is short against its tree). */
+extern "C" int shq_hier_gravity_levels(shq_context *ctx, const shq_timestep_params *p, const shq_grav_params *gp, double BoxSize, int treemask,
+                                       int64_t Ti_Current, int largest_active, const double gravkick_level[SHQ_TIMEBINS + 1], int walk_mode,
+                                       int *mingravtimebin, int64_t *badstepsizecount, shq_hier_level *levels, int *nlevels)
+{
+    SHQ_CHECK(ctx && p && gp && gravkick_level && mingravtimebin && badstepsizecount, SHQ_ERR_INVALID, "hier_gravity_levels: null argument");
+    SHQ_CHECK(largest_active >= 1 && largest_active <= TB, SHQ_ERR_INVALID, "hier_gravity_levels: largest_active %d out of range", largest_active);
+    int64_t bad = 0;
+    int nl = 0;
+    for(int ti = largest_active - 1; ti > 0; ti--) {
+        int64_t nsub = 0;
+        /* build_active_sublist(lastact, ti): the predicate is monotone in ti and bins only change inside the previous sub-list,
+         * so selecting from the full resident list gives the same particles in the same order */
+        SHQ_TRY(shq_build_active_sublist(ctx, ti, Ti_Current, &nsub));
+        if(nsub == 0) {
+            *mingravtimebin = ti + 1;
+            break;
+        }
+        shq_tree_build_stats ts;
+        SHQ_TRY(shq_tree_build(ctx, BoxSize, treemask, SHQ_SUBLIST_RESIDENT, 0, &ts));
+        SHQ_TRY(shq_grav_short_run(ctx, gp, SHQ_SUBLIST_RESIDENT, 0, 0, walk_mode));
+        shq_timestep_result r;
+        SHQ_TRY(shq_hier_refine(ctx, p, SHQ_SUBLIST_RESIDENT, 0, 1, ti, &r)); /* synchronises: the walk's events are readable */
+        bad += r.badstepsizecount;
+        double tab[SHQ_TIMEBINS + 1];
+        for(int b = 0; b <= SHQ_TIMEBINS; b++)
+            tab[b] = gravkick_level[ti]; /* one factor for the whole sub-list, whatever bin a particle has moved to */
+        SHQ_TRY(shq_kick_short(ctx, tab, SHQ_SUBLIST_RESIDENT, 0, 1));
+        if(levels) {
+            float wms = 0;
+            (void) hipEventElapsedTime(&wms, ctx->ev_begin[SHQ_NTIMERS - 1], ctx->ev_end[SHQ_NTIMERS - 1]);
+            levels[nl].timebin = ti;
+            levels[nl].walk_mode = ctx->last_walk_mode;
+            levels[nl].nparticles = nsub;
+            levels[nl].tree_nodes = ts.numnodes;
+            levels[nl].tree_build_ms = ts.build_ms;
+            levels[nl].walk_ms = wms;
+        }
+        nl++;
+    }
+    *badstepsizecount = bad;
+    if(nlevels)
+        *nlevels = nl;
+    return SHQ_OK;
 }
 
 extern "C" int shq_velocity_moments(shq_context *ctx, double v2sum[6], double min_mass[6], int64_t count[6])

@@ -16,6 +16,7 @@
 #include <vector>
 #include "common.hpp"
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
@@ -136,13 +137,53 @@ __global__ __launch_bounds__(256) void toptree_kernel(long long nt, const int32_
         counts[t] = nexp;
 }
 
+/* entries per destination task, and (second use) each entry's slot in the task-ordered send buffer */
+__global__ void top_task_count_kernel(long long n, const shq_data_index *__restrict__ table, int ntask, unsigned long long *counts)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k < n) {
+        const int t = table[k].Task;
+        if(t >= 0 && t < ntask)
+            atomicAdd(&counts[t], 1ull);
+    }
+}
+
+/* GravTreeQuery records (gravshort2.hpp:123-128) of the table's entries, written at their place in task order:
+ * slot[k] = offset of entry k's task + rank of k among that task's entries (table order kept: a stable counting sort) */
+__global__ void top_pack_queries_kernel(long long n, const shq_data_index *__restrict__ table, const long long *__restrict__ slot,
+                                        const double4 *__restrict__ posm, const double *__restrict__ oldacc, shq_grav_query *q, int32_t *place)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    const shq_data_index e = table[k];
+    const long long s = slot[k];
+    const double4 p = posm[e.Index];
+    shq_grav_query o;
+    o.Pos[0] = p.x;
+    o.Pos[1] = p.y;
+    o.Pos[2] = p.z;
+    for(int j = 0; j < 4; j++)
+        o.NodeList[j] = e.NodeList[j];
+    o.OldAcc = oldacc[e.Index];
+    q[s] = o;
+    place[s] = e.Index;
+}
+
 template <bool GRAV>
 int run_toptree(shq_context *ctx, const GravTopArgs &ga, const NgbTopArgs &na, const int32_t *active, int64_t nactive,
-                int32_t *exportcounts, shq_data_index *table, int64_t capacity, int64_t *nexport)
+                int32_t *exportcounts, shq_data_index *table, int64_t capacity, int64_t *nexport, bool resident = false,
+                bool active_on_device = false)
 {
     const int32_t *d_act = nullptr;
     int64_t nt = 0;
-    SHQ_TRY(shq_resolve_active(ctx, active, nactive, ctx->nlocal, &d_act, &nt));
+    if(active_on_device && active) {
+        d_act = active;
+        nt = nactive;
+    } else
+        SHQ_TRY(shq_resolve_active(ctx, active, nactive, ctx->nlocal, &d_act, &nt));
+    ctx->top_ntargets = nt;
+    ctx->top_nexport = 0;
     if(nexport)
         *nexport = 0;
     if(nt == 0)
@@ -165,15 +206,18 @@ int run_toptree(shq_context *ctx, const GravTopArgs &ga, const NgbTopArgs &na, c
     SHQ_CHECK(total >= 0, SHQ_ERR_INVALID, "toptree: more than 2^31 exports");
     if(nexport)
         *nexport = total;
-    if(!table || total == 0)
+    if((!table && !resident) || total == 0)
         return SHQ_OK;
-    SHQ_CHECK(capacity >= total, SHQ_ERR_NOMEM, "toptree: export table holds %ld entries, %d needed", (long) capacity, total);
+    SHQ_CHECK(resident || capacity >= total, SHQ_ERR_NOMEM, "toptree: export table holds %ld entries, %d needed", (long) capacity, total);
     SHQ_TRY(ctx->top_table.reserve((size_t) total));
     toptree_kernel<GRAV, true><<<dim3(nblk(nt)), dim3(256), 0, st>>>(nt, d_act, ctx->posm.ptr, ctx->topnodes.ptr, ctx->topleaves.ptr, ga, na,
                                                                     ctx->top_counts.ptr, ctx->top_table.ptr);
     SHQ_HIP(hipGetLastError());
-    SHQ_HIP(hipMemcpyAsync(table, ctx->top_table.ptr, sizeof(shq_data_index) * (size_t) total, hipMemcpyDeviceToHost, st));
-    SHQ_HIP(hipStreamSynchronize(st));
+    ctx->top_nexport = total;
+    if(table) {
+        SHQ_HIP(hipMemcpyAsync(table, ctx->top_table.ptr, sizeof(shq_data_index) * (size_t) total, hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipStreamSynchronize(st));
+    }
     return SHQ_OK;
 }
 
@@ -269,6 +313,89 @@ extern "C" int shq_grav_toptree_exports(shq_context *ctx, const shq_grav_params 
     ga.oldacc = ctx->oldacc.ptr;
     NgbTopArgs na = {};
     return run_toptree<true>(ctx, ga, na, active, nactive, exportcounts, table, capacity, nexport);
+}
+
+/* Export detection that stays in HBM (treewalk2.cuh:243-334 keeps its table in managed memory for the same reason): count, scan
+ * and fill as above for the targets `active` (NULL = all own particles, the resident handles, or with active_on_device a device
+ * list), the table and the scanned counts left resident; back come only the total and, per destination task, how many entries go
+ * there (the Send counts of ev_send_recv_export_import, treewalk2.h:618-700).  shq_grav_export_pack then writes the GravTreeQuery
+ * records in task order, and the matching `place` list for shq_grav_reduce_export_results, into DEVICE buffers of the caller
+ * (the payload of its all-to-all). */
+extern "C" int shq_grav_toptree_exports_resident(shq_context *ctx, const shq_grav_params *params, const int32_t *active, int64_t nactive,
+                                                 int active_on_device, int ntask, int64_t *nexport, int64_t *task_counts)
+{
+    SHQ_CHECK(ctx && params && nexport && (task_counts || ntask == 0) && ntask >= 0, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts && ctx->have_toptree, SHQ_ERR_STATE, "grav_toptree_exports: upload particles and the top tree first");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    GravTopArgs ga;
+    ga.Box = params->BoxSize;
+    ga.rcut = params->Rcut;
+    ga.rcut2 = params->Rcut * params->Rcut;
+    ga.errtol = params->ErrTolForceAcc;
+    ga.theta2 = params->BHOpeningAngle2;
+    ga.useBH = params->TreeUseBH;
+    ga.oldacc = ctx->oldacc.ptr;
+    NgbTopArgs na = {};
+    SHQ_TRY(run_toptree<true>(ctx, ga, na, active, nactive, nullptr, nullptr, 0, nexport, true, active_on_device != 0));
+    for(int t = 0; t < ntask; t++)
+        task_counts[t] = 0;
+    if(*nexport == 0 || ntask == 0)
+        return SHQ_OK;
+    SHQ_TRY(ctx->top_task.reserve((size_t) ntask));
+    SHQ_HIP(hipMemsetAsync(ctx->top_task.ptr, 0, sizeof(unsigned long long) * ntask, ctx->stream));
+    top_task_count_kernel<<<dim3(nblk(*nexport)), dim3(256), 0, ctx->stream>>>(*nexport, ctx->top_table.ptr, ntask, ctx->top_task.ptr);
+    SHQ_HIP(hipGetLastError());
+    std::vector<unsigned long long> h((size_t) ntask);
+    SHQ_HIP(hipMemcpyAsync(h.data(), ctx->top_task.ptr, sizeof(unsigned long long) * ntask, hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    for(int t = 0; t < ntask; t++)
+        task_counts[t] = (int64_t) h[t];
+    return SHQ_OK;
+}
+
+namespace {
+struct TaskOf {
+    __device__ int operator()(const shq_data_index &e) const { return e.Task; }
+};
+/* slot of entry k = start of its task + number of earlier entries of the same task: per task a flag scan would cost ntask passes;
+ * one stable radix sort of (task, k) pairs gives the same order */
+__global__ void top_keys_kernel(long long n, const shq_data_index *__restrict__ table, int32_t *key, int32_t *val)
+{
+    const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(k < n) {
+        key[k] = table[k].Task;
+        val[k] = (int32_t) k;
+    }
+}
+__global__ void top_slots_kernel(long long n, const int32_t *__restrict__ sorted_val, long long *slot)
+{
+    const long long s = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(s < n)
+        slot[sorted_val[s]] = s;
+}
+} // namespace
+
+extern "C" int shq_grav_export_pack(shq_context *ctx, shq_grav_query *d_queries, int32_t *d_place)
+{
+    SHQ_CHECK(ctx && d_queries && d_place, SHQ_ERR_INVALID, "null argument");
+    const long long n = ctx->top_nexport;
+    SHQ_CHECK(n >= 0 && ctx->have_toptree, SHQ_ERR_STATE, "grav_export_pack: run shq_grav_toptree_exports_resident first");
+    if(n == 0)
+        return SHQ_OK;
+    SHQ_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    SHQ_TRY(ctx->top_sort.reserve((size_t) (4 * n)));
+    SHQ_TRY(ctx->top_slot.reserve((size_t) n));
+    int32_t *key = ctx->top_sort.ptr, *val = key + n, *key2 = val + n, *val2 = key2 + n;
+    top_keys_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, ctx->top_table.ptr, key, val);
+    size_t tmp = 0;
+    SHQ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, key, key2, val, val2, (size_t) n, 0, 32, st));
+    SHQ_TRY(ctx->act_temp.reserve(tmp + 16));
+    SHQ_HIP(rocprim::radix_sort_pairs((void *) ctx->act_temp.ptr, tmp, key, key2, val, val2, (size_t) n, 0, 32, st)); /* stable */
+    top_slots_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, val2, ctx->top_slot.ptr);
+    top_pack_queries_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(n, ctx->top_table.ptr, ctx->top_slot.ptr, ctx->posm.ptr, ctx->oldacc.ptr, d_queries, d_place);
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
 }
 
 extern "C" int shq_ngb_toptree_exports(shq_context *ctx, int symmetric, double BoxSize, const int32_t *active, int64_t nactive,

@@ -710,6 +710,99 @@ class DistSPH:
             SphP[k][P["PI"]] = Sall[k][:nloc]
 
 
+def gas_rows_from_records(P, SphP):
+    """[n, capi.GAS_NCOL] float64 rows (the layout of shq_gas_set_device, include/shenqi_hip.h) of gas records
+    (capi.PARTICLE_DTYPE / capi.SPH_DTYPE, slot = PI)"""
+    n = len(P)
+    S = SphP[P["PI"]]
+    r = np.zeros((n, capi.GAS_NCOL))
+    r[:, 0:3], r[:, 3], r[:, 4:7], r[:, 7] = P["Pos"], P["Mass"], P["Vel"], P["Hsml"]
+    r[:, 8:11], r[:, 11:14], r[:, 14:17] = P["FullTreeGravAccel"], P["GravPM"], S["HydroAccel"]
+    r[:, 17], r[:, 18], r[:, 19] = S["Entropy"], S["DtEntropy"], S["DelayTime"]
+    r[:, 20], r[:, 21], r[:, 22], r[:, 23], r[:, 24] = S["Density"], S["EgyWtDensity"], S["DhsmlEgyDensityFactor"], S["DivVel"], S["CurlVel"]
+    r[:, 25], r[:, 26] = S["MaxSignalVel"], P["DtHsml"]
+    r[:, 27] = P["TimeBinGravity"].astype(np.float64) + 256.0 * P["TimeBinHydro"].astype(np.float64)
+    return r
+
+
+def gas_rows_to_records(rows, P, SphP):
+    """the result columns of rows (density and hydro) back into the records"""
+    pi = P["PI"]
+    P["Hsml"], P["DtHsml"] = rows[:, 7], rows[:, 26]
+    for c, k in ((20, "Density"), (21, "EgyWtDensity"), (22, "DhsmlEgyDensityFactor"), (23, "DivVel"), (24, "CurlVel"), (18, "DtEntropy"),
+                 (25, "MaxSignalVel")):
+        SphP[k][pi] = rows[:, c]
+    SphP["HydroAccel"][pi] = rows[:, 14:17]
+
+
+class DistSPHDevice:
+    """One rank of the sharded SPH operators with the gas RESIDENT on the device: `rows` is a float64 device tensor
+    [nloc, capi.GAS_NCOL] of the gas this rank owns (layout: shq_gas_set_device).  Ghost rows travel as device tensors through the
+    all-to-all (RCCL; gloo stages them through the host inside Comm), local + ghost rows become the context's particle set by one
+    scatter kernel, the tree of that set is built on the device (shq_tree_build over the gas), density / hydro run on the first
+    nloc rows (shq_density_resident / shq_hydro_resident) and one gather kernel writes the results back into the rows: no host
+    numpy and no PCIe copy of particle data inside an operator (the import rule is DistSPH's, see above)."""
+
+    def __init__(self, comm, decomp, ctx, BoxSize, hfac=1.3):
+        import shenqi_amd as sq
+        self.sq, self.comm, self.d, self.ctx, self.L, self.hfac = sq, comm, decomp, ctx, BoxSize, hfac
+        self.nghost = 0
+        self.stats = {}
+
+    def _allmax(self, v):
+        if not self.comm.multi:
+            return [float(v)] * max(1, self.comm.size)
+        t = torch.zeros(self.comm.size, dtype=torch.float64)
+        t[self.comm.rank] = float(v)
+        if self.comm.backend == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, group=self.comm.group)
+        return [float(x) for x in t.cpu()]
+
+    def _load(self, rows, reach, reach_of_rank):
+        """import the ghosts, make local + ghost rows the resident set, build their tree"""
+        ghosts = ghost_records(self.comm, self.d, rows[:, 0], reach, rows, reach_of_rank)
+        allrows = torch.cat([rows, ghosts.to(rows.device)], dim=0).contiguous()
+        self.nghost = int(ghosts.shape[0])
+        capi.check(capi.hip.shq_gas_set_device(self.ctx.h, allrows.data_ptr(), int(allrows.shape[0]), int(rows.shape[0])), "shq_gas_set_device")
+        self.sq.tree_build_device(self.ctx, self.L, mask=self.sq.GASMASK)
+        return allrows
+
+    def density(self, rows, dp):
+        """density() for the local gas (Hsml loop included); rows are updated in place.  Returns the number of import rounds."""
+        nloc = int(rows.shape[0])
+        h0 = rows[:, 7].clone()
+        halo = self.hfac * (float(h0.max().item()) if nloc else 0.0)
+        rounds = 0
+        st = capi.SphStats()
+        while True:
+            rounds += 1
+            halos = self._allmax(halo)
+            rows[:, 7] = h0
+            allrows = self._load(rows, torch.zeros(nloc, dtype=torch.float64, device=rows.device), halos)
+            capi.check(capi.hip.shq_density_resident(self.ctx.h, C.byref(dp), C.byref(st)), "shq_density_resident")
+            capi.check(capi.hip.shq_gas_get_device(self.ctx.h, allrows.data_ptr(), nloc, 1), "shq_gas_get_device")
+            hmax = float(allrows[:nloc, 7].max().item()) if nloc else 0.0
+            worst = max(h / max(hl, 1e-300) for h, hl in zip(self._allmax(hmax), halos)) if self.comm.multi else 0.0
+            if worst <= 1.0 or not self.comm.multi:
+                break
+            halo = self.hfac * max(hmax, halo)
+        rows.copy_(allrows[:nloc])
+        self.stats["density"] = dict(kernel_ms=float(st.kernel_ms), iterations=int(st.niterations), ninteractions=int(st.ninteractions), nghost=self.nghost)
+        return rounds
+
+    def hydro(self, rows, hp):
+        """hydro_force() for the local gas; needs the density fields of density() above on every rank"""
+        nloc = int(rows.shape[0])
+        hmax = self._allmax(float(rows[:, 7].max().item()) if nloc else 0.0)
+        allrows = self._load(rows, rows[:, 7].contiguous(), hmax)
+        st = capi.SphStats()
+        capi.check(capi.hip.shq_hydro_resident(self.ctx.h, C.byref(hp), C.byref(st)), "shq_hydro_resident")
+        capi.check(capi.hip.shq_gas_get_device(self.ctx.h, allrows.data_ptr(), nloc, 2), "shq_gas_get_device")
+        rows.copy_(allrows[:nloc])
+        self.stats["hydro"] = dict(kernel_ms=float(st.kernel_ms), ninteractions=int(st.ninteractions), nghost=self.nghost)
+
+
 class GpuSphOps:
     """DistSPH's operators on the device library, through the host mirror of the reference API (one-shot calls: the records
     cross PCIe once per operator)."""

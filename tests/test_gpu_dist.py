@@ -408,3 +408,80 @@ def test_bench_driver_command_two_gloo_ranks():
     # the reference's own limits for PM + tree against the +-1 image sum (tests/test_gravity.cpp:294-355): mean < 0.8 x, max < 3 x ErrTol
     # hold at its 16^3 size; at this size and ErrTolForceAcc 0.005 the check is a guard against gross errors (wrong ghosts, a missing slab)
     assert fe["mean"] < 0.02 and fe["max"] < 0.1, fe
+
+
+def _sph_device_worker(rank, world, initfile, outdir):
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        import shenqi_amd as sq
+        from shenqi_amd import dist as sd
+        import common as cm
+        from test_dist_sph_cpu import global_gas
+        comm = sd.Comm()
+        decomp = sd.SlabDecomp(comm, NMESH, BOX)
+        Pg, Sg = global_gas()
+        mine = (decomp.owner_of(torch.from_numpy(np.ascontiguousarray(Pg["Pos"][:, 0]))) == rank).numpy()
+        P = Pg[mine].copy()
+        SphP = Sg[Pg["PI"][mine]].copy()
+        P["PI"] = np.arange(len(P))
+        rows = torch.from_numpy(sd.gas_rows_from_records(P, SphP)).cuda()
+        with sq.Context(0) as ctx:
+            drv = sd.DistSPHDevice(comm, decomp, ctx, BOX)
+            rounds = drv.density(rows, cm.density_params(update_hsml=1, DoEgyDensity=1))
+            drv.hydro(rows, cm.hydro_params())
+            ctx.synchronize()
+        sd.gas_rows_to_records(rows.cpu().numpy(), P, SphP)
+        np.save(os.path.join(outdir, "p%d.npy" % rank), P)
+        np.save(os.path.join(outdir, "s%d.npy" % rank), SphP)
+        np.save(os.path.join(outdir, "r%d.npy" % rank), np.array([rounds, drv.nghost]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_dist_sph_device_resident(world):
+    """sharded density (Hsml loop) + hydro with the gas RESIDENT on the device (DistSPHDevice: ghost rows as device tensors, tree built on
+    the device, shq_density_resident / shq_hydro_resident, results gathered into the rows) on one rank and on two gloo ranks sharing the
+    GPU, against the oracle on the undivided gas — the same bar as the host-staged DistSPH above"""
+    from test_dist_sph_cpu import monolithic
+    Pm, Sm, _ = monolithic(1.5)
+    key = {int(i): k for k, i in enumerate(Pm["ID"])}
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_sph_device_worker, args=(world, os.path.join(tmp, "init"), tmp), nprocs=world, join=True)
+        seen = 0
+        for r in range(world):
+            P = np.load(os.path.join(tmp, "p%d.npy" % r))
+            S = np.load(os.path.join(tmp, "s%d.npy" % r))
+            rounds, nghost = np.load(os.path.join(tmp, "r%d.npy" % r))
+            assert rounds >= 1 and (nghost > 0) == (world > 1)
+            idx = np.array([key[int(i)] for i in P["ID"]])
+            seen += len(idx)
+            assert np.abs(P["Hsml"] / Pm["Hsml"][idx] - 1).max() < 1e-9
+            for name in ("Density", "EgyWtDensity", "DivVel", "CurlVel"):
+                assert np.abs(S[name] - Sm[name][idx]).max() < 1e-8 * np.abs(Sm[name]).max(), name
+            assert np.abs(S["HydroAccel"] - Sm["HydroAccel"][idx]).max() < 1e-7 * np.abs(Sm["HydroAccel"]).max()
+            assert np.abs(S["MaxSignalVel"] / Sm["MaxSignalVel"][idx] - 1).max() < 1e-8
+        assert seen == 16**3
+
+
+def test_bench_c5_mode_two_gloo_ranks():
+    """`bench.py --gpus 2 --workload c5`: the C5-shaped step (gas + dark matter: sharded TreePM + device-resident sharded density and
+    hydro) through the driver's launch path, rehearsed over gloo on one GPU: one JSON line with the three operators' rooflines"""
+    import json
+    import subprocess
+    env = dict(os.environ, SHQ_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--ngrid", "16", "--steps", "1", "--warmup", "0",
+                        "--workload", "c5"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["particles_total"] == 2 * 20**3
+    k = out["kernels"]
+    assert k["gas_ghosts_density"] > 0 and k["gas_ghosts_hydro"] > 0 and k["grav_ghosts"] > 0
+    assert 1 <= k["density_iterations"] <= 3          # steady state: Hsml converged by the set-up call
+    for r in ("roofline", "roofline_sph_density", "roofline_sph_hydro"):
+        assert out[r]["achieved"] > 0, r

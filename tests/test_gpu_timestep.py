@@ -1,5 +1,5 @@
 """GPU parity tests of the integer time line on the device (csrc/timestep.hip) and of its host mirror
-(shenqi_amd/host/timestep.cpp: find_timesteps, find_hydro_timesteps, hierarchical_gravity_and_timesteps) against the
+(integration/reference_side/timestep.cpp: find_timesteps, find_hydro_timesteps, hierarchical_gravity_and_timesteps) against the
 restatement of libgadget/timestep.cpp in oracle/timeline.py.  Time bins and tallies are integers: they must be equal."""
 import ctypes as C
 import math

@@ -75,6 +75,48 @@ def test_ngb_export_table_equals_oracle(ctx, symmetric):
     assert np.array_equal(table, otable)
 
 
+def test_resident_export_detection_and_device_query_packing(ctx):
+    """shq_grav_toptree_exports_resident + shq_grav_export_pack: the table stays in HBM; only the total and the per-task send counts
+    come back, and the GravTreeQuery records are written on the device in task order (entries of one task in table order) together
+    with the `place` list of the reduce step — against the host-table path of the same walk, for all targets and for a device list."""
+    import torch
+    pman, pos, rng = _setup()
+    n = len(pos)
+    dom = sq.force_tree_full(pman)
+    ntask = 6
+    tl = cm.make_domain(dom, ntask=ntask, me=1, depth=3)
+    cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=0)
+    sq.gravshort_set_softenings(cm.BOX / 20)
+    gp = sq.make_grav_params(cm.BOX, 1.5, 60, cm.G, cm.RHO0)
+    pv = pman.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, cm.G))
+    sq.toptree_upload(ctx, dom, tl)
+    oldacc = pman.Base["FullTreeGravAccel"][:, 0] / cm.G
+    act = np.sort(rng.choice(n, size=n // 5, replace=False)).astype(np.int32)
+    for active in (None, act):
+        nt = n if active is None else len(active)
+        _, table = sq.grav_toptree_exports(ctx, gp, nt, active)
+        nexp = C.c_int64(-1)
+        tc = np.zeros(ntask, dtype=np.int64)
+        d_act = None if active is None else torch.from_numpy(active).cuda()
+        capi.check(capi.hip.shq_grav_toptree_exports_resident(ctx.h, C.byref(gp), None if d_act is None else d_act.data_ptr(), nt,
+                                                              0 if d_act is None else 1, ntask, C.byref(nexp), capi.ptr(tc)))
+        assert nexp.value == len(table) > 0
+        assert np.array_equal(tc, np.bincount(table["Task"], minlength=ntask)) and tc[1] == 0
+        d_q = torch.zeros(nexp.value * capi.GRAV_QUERY_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        d_place = torch.zeros(nexp.value, dtype=torch.int32, device="cuda")
+        capi.check(capi.hip.shq_grav_export_pack(ctx.h, d_q.data_ptr(), d_place.data_ptr()))
+        ctx.synchronize()
+        q = d_q.cpu().numpy().view(capi.GRAV_QUERY_DTYPE)
+        place = d_place.cpu().numpy()
+        order = np.argsort(table["Task"], kind="stable")
+        want = table[order]
+        assert np.array_equal(place, want["Index"])
+        assert np.array_equal(q["NodeList"], want["NodeList"])
+        assert np.array_equal(q["Pos"], pos[want["Index"]]) and np.array_equal(q["OldAcc"], oldacc[want["Index"]])
+
+
 def test_primary_plus_secondary_equals_single_domain_walk(ctx):
     """The reference's distributed walk, assembled from this library's three pieces: primary walk on the tree
     with pseudo nodes, export table from the top-tree walk, secondary walks (on the owner's tree) of the

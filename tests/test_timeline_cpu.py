@@ -1,6 +1,6 @@
 """The integer time line on the CPU: the numpy / Python restatement (oracle/timeline.py) against the values the reference's own
 test holds (libgadget/tests/test_timebinmgr.cpp:23-146, sync points {0.1, 0.2, 0.8, 1.0}), and the C++ host mirror
-(shenqi_amd/host/timestep.cpp) against the restatement."""
+(integration/reference_side/timestep.cpp) against the restatement."""
 import ctypes as C
 import math
 import os
