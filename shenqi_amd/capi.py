@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBDIR = os.path.join(_HERE, "lib")
+LIBDIR = os.environ.get("SHQ_LIBDIR") or os.path.join(_HERE, "lib")   # SHQ_LIBDIR: an alternative build of the two libraries (tuning experiments)
 DATADIR = os.path.join(_HERE, "data")
 
 NGRAVTAB = 512

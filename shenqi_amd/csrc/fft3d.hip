@@ -618,8 +618,8 @@ bool shq_fft3d_supported(int N)
     return false;
 }
 
-/* z pitch (in doubles) the bespoke pipeline wants: N/2+1 complex rounded up to a multiple of 4. */
-int shq_fft3d_pitch(int N) { return 2 * (((N / 2 + 1) + 3) / 4 * 4); }
+/* z pitch (in doubles) the bespoke pipeline wants: N/2+1 complex rounded up to a multiple of the tile width FFT_C (4). */
+int shq_fft3d_pitch(int N) { return 2 * (((N / 2 + 1) + FFT_C - 1) / FFT_C * FFT_C); }
 
 static int ensure_twiddles(shq_context *ctx, int N)
 {

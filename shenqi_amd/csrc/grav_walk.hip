@@ -103,20 +103,25 @@ __device__ __forceinline__ void apply_accn(const double4 *__restrict__ tab, doub
     const double mr = mass * rinv;
     double fac = mr * rinv * rinv;
     double npot = mr; /* minus the potential factor: the Newtonian -m/r enters the sum through the negated-operand form of the fma below */
-    if(r2 < a.h2) {
-        const double u = r * a.h_inv;
-        double wp;
-        if(u < 0.5) {
-            fac = mass * a.h3_inv * (sconst(10.666666666667) + u * u * (32.0 * u - sconst(38.4)));
-            wp = sconst(-2.8) + u * u * (sconst(5.333333333333) + u * u * (sconst(6.4) * u - sconst(9.6)));
-            npot = -(mass * a.h_inv * wp);
-        } else {
-            /* the reference's 0.0667 / u^3 and 0.0667 / u terms are the Newtonian force and potential themselves
-             * (mass h^-3 / u^3 = mass / r^3, mass h^-1 / u = mass / r), already formed above from 1/r: no divisions */
-            fac = fma(mass * a.h3_inv, sconst(21.333333333333) - 48.0 * u + sconst(38.4) * u * u - sconst(10.666666666667) * u * u * u,
-                      sconst(-0.066666666667) * fac);
-            wp = sconst(-3.2) + u * u * (sconst(10.666666666667) + u * (-16.0 + u * (sconst(9.6) - sconst(2.133333333333) * u)));
-            npot = -fma(mass * a.h_inv, wp, sconst(0.066666666667) * mr);
+    /* a wave-uniform test first: no lane inside the softening length is the common case, and a scalar compare-and-branch is one
+     * scalar instruction less than saving, masking and restoring exec around an empty branch */
+    if(shq_ballot(r2 < a.h2) != 0ull) {
+        asm volatile("" ::: "memory"); /* keeps the scalar branch apart from the lane mask below */
+        if(r2 < a.h2) {
+            const double u = r * a.h_inv;
+            double wp;
+            if(u < 0.5) {
+                fac = mass * a.h3_inv * (sconst(10.666666666667) + u * u * (32.0 * u - sconst(38.4)));
+                wp = sconst(-2.8) + u * u * (sconst(5.333333333333) + u * u * (sconst(6.4) * u - sconst(9.6)));
+                npot = -(mass * a.h_inv * wp);
+            } else {
+                /* the reference's 0.0667 / u^3 and 0.0667 / u terms are the Newtonian force and potential themselves
+                 * (mass h^-3 / u^3 = mass / r^3, mass h^-1 / u = mass / r), already formed above from 1/r: no divisions */
+                fac = fma(mass * a.h3_inv, sconst(21.333333333333) - 48.0 * u + sconst(38.4) * u * u - sconst(10.666666666667) * u * u * u,
+                          sconst(-0.066666666667) * fac);
+                wp = sconst(-3.2) + u * u * (sconst(10.666666666667) + u * (-16.0 + u * (sconst(9.6) - sconst(2.133333333333) * u)));
+                npot = -fma(mass * a.h_inv, wp, sconst(0.066666666667) * mr);
+            }
         }
     }
     /* apply_short_range_window (gravity.h:48-60): beyond the table (index >= NTAB - 1) the source contributes nothing.  No branch:
@@ -298,6 +303,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
     unsigned int lonely8 = 0, lonely16 = 0; /* STATS == 2: this lane's interactions in rounds of <= 8 / <= 16 lanes */
 
     do { /* cur >= 0: the root on entry, then every node the union walk reaches */
+        /* the compiler fetches the record with four scalar loads (x16, x4, x8, x4).  Two s_load_dwordx16 of the two 64-byte halves
+         * were measured instead: 39.6 against 33.9 ms in a same-box A/B — not worth the two issue slots */
         const NodeG nd = nodeG[cur];
         if(STATS)
             visited++;
@@ -421,11 +428,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
         {
             /* the lanes that descend: those that open an internal node (a wave-uniform select on the node type, not a branch) */
             unsigned long long descendm = nd.type == SHQ_NODE_NODE_TYPE ? doopenm : 0ull;
-            const bool descend = __builtin_amdgcn_inverse_ballot_w64(descendm);
+            const unsigned long long descendm_lanes = descendm;
             if(GHOSTS && nd.type == SHQ_NODE_NODE_TYPE) /* a lane waits at a branch below this node: go down even if nobody opens it */
                 descendm |= shq_ballot(mynext > cur && (nd.sibling < 0 || mynext < nd.sibling));
-            if(act)
-                mynext = descend ? nd.child : nd.sibling;
+            /* Two moves of a scalar operand under the two lane masks, written out: as a select the compiler moves both values into
+             * vector registers first (2 v_mov + 2 v_cndmask, 12 vector-pipe cycles per visit against 4 here), and the vector pipe
+             * is the busier one (SQ_ACTIVE_INST_VALU 0.90, SQ_ACTIVE_INST_SCA 0.52 of the cycles).  exec is the whole wave here
+             * (top level of the visit loop) and is restored. */
+            {
+                const unsigned long long staym = actm & ~descendm_lanes;
+                unsigned long long saved;
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "s_mov_b64 exec, %[m1]\n\t"
+                             "v_mov_b32 %[dst], %[sib]\n\t"
+                             "s_mov_b64 exec, %[m2]\n\t"
+                             "v_mov_b32 %[dst], %[chd]\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [dst] "+v"(mynext), [sv] "=&s"(saved)
+                             : [m1] "s"(staym), [m2] "s"(descendm_lanes), [sib] "s"(nd.sibling), [chd] "s"(nd.child));
+            }
             next = descendm != 0ull ? nd.child : nd.sibling;
         }
         if(GHOSTS && act && mynext == myend) { /* branch done: wait at the next one of the NodeList */

@@ -759,14 +759,33 @@ class DistSPHDevice:
         dist.all_reduce(t, group=self.comm.group)
         return [float(x) for x in t.cpu()]
 
+    def _shared(self, device):
+        """the context runs on torch's current stream (then the stream orders library kernels and torch operators); with a stream of
+        its own (the tests) every hand-over between torch and the library is a synchronisation of the producing stream"""
+        s = getattr(self.ctx, "stream", None)
+        return bool(s) and int(s) == int(torch.cuda.current_stream(device).cuda_stream)
+
+    def _before(self, device):
+        if not self._shared(device):
+            torch.cuda.current_stream(device).synchronize()
+
+    def _after(self, device):
+        if not self._shared(device):
+            self.ctx.synchronize()
+
     def _load(self, rows, reach, reach_of_rank):
         """import the ghosts, make local + ghost rows the resident set, build their tree"""
         ghosts = ghost_records(self.comm, self.d, rows[:, 0], reach, rows, reach_of_rank)
         allrows = torch.cat([rows, ghosts.to(rows.device)], dim=0).contiguous()
         self.nghost = int(ghosts.shape[0])
+        self._before(rows.device)        # torch produced allrows on its stream
         capi.check(capi.hip.shq_gas_set_device(self.ctx.h, allrows.data_ptr(), int(allrows.shape[0]), int(rows.shape[0])), "shq_gas_set_device")
         self.sq.tree_build_device(self.ctx, self.L, mask=self.sq.GASMASK)
         return allrows
+
+    def _results(self, allrows, nloc, which):
+        capi.check(capi.hip.shq_gas_get_device(self.ctx.h, allrows.data_ptr(), nloc, which), "shq_gas_get_device")
+        self._after(allrows.device)      # the library wrote allrows on its stream
 
     def density(self, rows, dp):
         """density() for the local gas (Hsml loop included); rows are updated in place.  Returns the number of import rounds."""
@@ -781,7 +800,7 @@ class DistSPHDevice:
             rows[:, 7] = h0
             allrows = self._load(rows, torch.zeros(nloc, dtype=torch.float64, device=rows.device), halos)
             capi.check(capi.hip.shq_density_resident(self.ctx.h, C.byref(dp), C.byref(st)), "shq_density_resident")
-            capi.check(capi.hip.shq_gas_get_device(self.ctx.h, allrows.data_ptr(), nloc, 1), "shq_gas_get_device")
+            self._results(allrows, nloc, 1)
             hmax = float(allrows[:nloc, 7].max().item()) if nloc else 0.0
             worst = max(h / max(hl, 1e-300) for h, hl in zip(self._allmax(hmax), halos)) if self.comm.multi else 0.0
             if worst <= 1.0 or not self.comm.multi:
@@ -798,7 +817,7 @@ class DistSPHDevice:
         allrows = self._load(rows, rows[:, 7].contiguous(), hmax)
         st = capi.SphStats()
         capi.check(capi.hip.shq_hydro_resident(self.ctx.h, C.byref(hp), C.byref(st)), "shq_hydro_resident")
-        capi.check(capi.hip.shq_gas_get_device(self.ctx.h, allrows.data_ptr(), nloc, 2), "shq_gas_get_device")
+        self._results(allrows, nloc, 2)
         rows.copy_(allrows[:nloc])
         self.stats["hydro"] = dict(kernel_ms=float(st.kernel_ms), ninteractions=int(st.ninteractions), nghost=self.nghost)
 
