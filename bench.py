@@ -954,6 +954,7 @@ def main():
             if 0 < push < largest:
                 capi.check(capi.hip.shq_hier_push_down(ctx.h, None, 0, push))
                 largest = push
+            sq.build_active_particles(ctx, 0, True)      # a PM step: every particle is active (build_active_particles, timestep.cpp:1286-1349)
             gkl = np.full(capi.TIMEBINS + 1, 1e-24)
             levels = (capi.HierLevel * capi.TIMEBINS)()
             nlev, mingrav, bad = C.c_int(0), C.c_int(0), C.c_int64(0)

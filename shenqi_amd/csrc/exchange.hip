@@ -409,8 +409,10 @@ extern "C" int shq_exchange_pack(shq_context *ctx, const shq_exchange_layout *la
     const long long nthreads = last * (long long) (layout->part_elsize / 16);
     ex_copy_base_kernel<<<dim3(nblk(nthreads)), dim3(256), 0, st>>>(last, ctx->ex_val[1].ptr, ctx->ex_list.ptr, (const char *) d_parts, layout->part_elsize,
                                                                    (char *) d_partbuf);
+    SHQ_HIP(hipGetLastError());
     ex_copy_slot_kernel<<<dim3(nblk(last)), dim3(256), 0, st>>>(last, ctx->ex_val[2].ptr, ctx->ex_key[3].ptr, ctx->ex_i64.ptr, ctx->ex_i64.ptr + (size_t) NTask * 6,
                                                                ctx->ex_list.ptr, (const char *) d_parts, layout->part_elsize, layout->off_pi, tab);
+    SHQ_HIP(hipGetLastError()); /* a failed copy launch must not be followed by the marks that destroy its source */
     /* the copies read what the marks overwrite: same stream, in order */
     ex_mark_kernel<<<dim3(nblk(last)), dim3(256), 0, st>>>(last, ctx->ex_list.ptr, (char *) d_parts, layout->part_elsize, layout->off_flags, layout->off_type,
                                                           layout->off_pi, tab, layout->off_reverselink, (int) (MaxPart + 100));
@@ -480,12 +482,16 @@ extern "C" int shq_slots_gc(shq_context *ctx, const shq_exchange_layout *layout,
             SHQ_TRY(ctx->ex_bytes.reserve((size_t) std::max<int64_t>(nkeep, 1) * esz));
             if(nkeep > 0) {
                 gc_gather_kernel<<<dim3(nblk(nkeep * (long long) (esz / 4))), dim3(256), 0, st>>>(nkeep, ctx->ex_list.ptr, (const char *) d_parts, esz, ctx->ex_bytes.ptr);
+                SHQ_HIP(hipGetLastError()); /* before the copy back: a failed gather would hand d_parts stale bytes */
                 SHQ_HIP(hipMemcpyAsync(d_parts, ctx->ex_bytes.ptr, (size_t) nkeep * esz, hipMemcpyDeviceToDevice, st));
             }
             n = nkeep;
         }
     }
-    *numpart = n;
+    /* the caller's counts are published only after everything queued here has completed */
+    int64_t new_slot_size[6];
+    for(int ty = 0; ty < 6; ty++)
+        new_slot_size[ty] = slot_size[ty];
     bool any = false;
     SlotTab tab;
     memset(&tab, 0, sizeof(tab));
@@ -495,8 +501,11 @@ extern "C" int shq_slots_gc(shq_context *ctx, const shq_exchange_layout *layout,
         tab.ptr[ty] = (tab.elsize[ty] && d_slots) ? (char *) d_slots[ty] : nullptr;
         SHQ_CHECK(!tab.elsize[ty] || slot_size[ty] == 0 || tab.ptr[ty], SHQ_ERR_INVALID, "slots_gc: slot type %d enabled but no array", ty);
     }
-    if(!any)
+    if(!any) {
+        SHQ_HIP(hipStreamSynchronize(st));
+        *numpart = n;
         return SHQ_OK;
+    }
     /* slots_gc_mark */
     SHQ_TRY(ctx->ex_i64.reserve(16));
     long long h_sz[6];
@@ -513,6 +522,8 @@ extern "C" int shq_slots_gc(shq_context *ctx, const shq_exchange_layout *layout,
     int h_err = 0;
     SHQ_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
     SHQ_HIP(hipStreamSynchronize(st));
+    if(h_err != 0)
+        *numpart = n; /* the particle array has been compacted and that has completed: its count is the new one even on this error */
     SHQ_CHECK(h_err == 0, SHQ_ERR_INVALID, "slots_gc: a particle's PI lies outside its slot array (slotsmanager.cpp:276)");
     for(int ty = 0; ty < 6; ty++) {
         if(!compact[ty] || !tab.elsize[ty] || slot_size[ty] == 0)
@@ -525,15 +536,19 @@ extern "C" int shq_slots_gc(shq_context *ctx, const shq_exchange_layout *layout,
         if(nkeep < used && nkeep > 0) {
             SHQ_TRY(ctx->ex_bytes.reserve((size_t) nkeep * tab.elsize[ty]));
             gc_gather_kernel<<<dim3(nblk(nkeep * (long long) (tab.elsize[ty] / 4))), dim3(256), 0, st>>>(nkeep, ctx->ex_list.ptr, tab.ptr[ty], tab.elsize[ty], ctx->ex_bytes.ptr);
+            SHQ_HIP(hipGetLastError());
             SHQ_HIP(hipMemcpyAsync(tab.ptr[ty], ctx->ex_bytes.ptr, (size_t) nkeep * tab.elsize[ty], hipMemcpyDeviceToDevice, st));
         }
-        slot_size[ty] = nkeep;
+        new_slot_size[ty] = nkeep;
         if(nkeep > 0) {
             gc_collect_kernel<<<dim3(nblk(nkeep)), dim3(256), 0, st>>>(nkeep, tab.ptr[ty], tab.elsize[ty], layout->off_reverselink, (char *) d_parts, esz, layout->off_pi);
             SHQ_HIP(hipGetLastError());
         }
     }
     SHQ_HIP(hipStreamSynchronize(st));
+    *numpart = n;
+    for(int ty = 0; ty < 6; ty++)
+        slot_size[ty] = new_slot_size[ty];
     return SHQ_OK;
 }
 

@@ -677,7 +677,12 @@ class DistSPH:
         return Pall, Sall
 
     def density(self, P, SphP, **kw):
-        """density() for the local gas (Hsml loop included).  Returns the number of import rounds it took."""
+        """density() for the local gas (Hsml loop included).  Returns the number of import rounds it took.
+        The repeat decision looks at the FINAL Hsml of the targets: an intermediate guess of the Hsml loop may reach past the halo
+        (its NumNgb is then undercounted, which changes the next guess) and come back inside.  Such a target converges to an Hsml
+        within the same NumNgb tolerance (MaxNumNgbDeviation) as the undivided run, not necessarily the same one; with the default
+        hfac = 1.3 the first guess (at most 1.26 x the start value, densitytree2.hpp:233-246) cannot leave the halo, later ones only
+        after the bracket has closed from below.  The sharded tests assert Hsml against the undivided result to 1e-9."""
         nloc = len(P)
         rounds = 0
         halo = self.hfac * (float(P["Hsml"].max()) if nloc else 0.0)
@@ -1135,6 +1140,15 @@ class DistExchange:
                 toget = togo.copy()
             soff, goff = self._offsets(togo), self._offsets(toget)
             nsend, nrecv = togo.sum(axis=0), toget.sum(axis=0)
+            # Capacity first, before anything is packed or marked (the pack turns the leavers into garbage, and a rank that raised
+            # alone would leave the others blocked in the next collective): what cannot fit even once every leaver's record has been
+            # collected fails here, on every rank together, as the reference's endrun ends the whole job (exchange.hpp:286-296).
+            short = [int(numpart - int(nsend[0]) + int(nrecv[0]) > maxpart)]
+            short += [int(slots[t] is not None and slot_size[t] - int(nsend[1 + t]) + int(nrecv[1 + t]) > cap[t]) for t in range(6)]
+            gshort = self._allsum(short)
+            if gshort.sum() > 0:
+                what = "MaxPart %d" % maxpart if gshort[0] else "the slot array of type %d" % int(np.flatnonzero(gshort[1:])[0])
+                raise MemoryError("DistExchange: the arrivals of this round do not fit %s on %d rank(s); nothing was packed" % (what, int(gshort.max())))
             partbuf = torch.empty(max(int(nsend[0]), 1) * esz, dtype=torch.uint8, device=dev)
             slotbuf = [None if slots[t] is None else torch.empty(max(int(nsend[1 + t]), 1) * ssz[t], dtype=torch.uint8, device=dev) for t in range(6)]
             bp = (C.c_void_p * 6)(*[None if b is None else b.data_ptr() for b in slotbuf])
@@ -1154,16 +1168,17 @@ class DistExchange:
                 capi.check(capi.hip.shq_slots_gc(h, C.byref(L), parts.data_ptr(), C.byref(n), maxpart, sp, sz, compact))
                 numpart, slot_size = int(n.value), [int(x) for x in sz]
             self.ctx.synchronize()
-            if numpart + int(nrecv[0]) > maxpart:
-                raise MemoryError("DistExchange: %d + %d particles do not fit MaxPart %d" % (numpart, int(nrecv[0]), maxpart))
+            # second line (garbage that was there before this round may or may not have been collected): still collective
+            if int(self._allsum([int(numpart + int(nrecv[0]) > maxpart)])[0]) > 0:
+                raise MemoryError("DistExchange: %d + %d particles do not fit MaxPart %d on some rank" % (numpart, int(nrecv[0]), maxpart))
             # the alltoallv of the base records and of every slot type (:409-480): device buffers, over RCCL when the group is nccl
             rows, _ = comm.all_to_all_rows(partbuf[:int(nsend[0]) * esz].view(-1, esz), [int(x) for x in togo[:, 0]])
             parts[numpart * esz:(numpart + int(nrecv[0])) * esz] = rows.reshape(-1)
             for t in range(6):
                 if slots[t] is None:
                     continue
-                if slot_size[t] + int(nrecv[1 + t]) > cap[t]:
-                    raise MemoryError("DistExchange: slot array of type %d is full" % t)
+                if int(self._allsum([int(slot_size[t] + int(nrecv[1 + t]) > cap[t])])[0]) > 0:
+                    raise MemoryError("DistExchange: slot array of type %d is full on some rank" % t)
                 rows, _ = comm.all_to_all_rows(slotbuf[t][:int(nsend[1 + t]) * ssz[t]].view(-1, ssz[t]), [int(x) for x in togo[:, 1 + t]])
                 slots[t][slot_size[t] * ssz[t]:(slot_size[t] + int(nrecv[1 + t])) * ssz[t]] = rows.reshape(-1)
             torch.cuda.current_stream(dev).synchronize()
