@@ -1,9 +1,9 @@
 #!/bin/bash
 # Refresh the rocprofv3 summaries kept under profiles/ (run on the GPU box from the repo root):
-#   tools/refresh_profiles.sh r02   ->  gpurun_out/profiles_r02/r02_*.{csv,json}, to be copied into profiles/
+#   tools/refresh_profiles.sh r03   ->  gpurun_out/profiles_r03/r03_*.{csv,json}, to be copied into profiles/
 # Kernel trace and every counter group are separate runs (--pmc is never combined with a trace domain).
 set -e -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
@@ -27,7 +27,10 @@ python3 $ROOT/tools/pmc_summary.py pmc $OUT/hbm.csv > $OUT/${TAG}_bench256_pmc_h
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU \
           --output-format csv -d $OUT/p_sq -o q -- $B --steps 3 --warmup 1 --no-cpu-baseline --no-sph > $OUT/sq.log 2>&1
 python3 $ROOT/tools/pmc_summary.py pmc "$(one $OUT/p_sq counter_collection.csv)" > $OUT/${TAG}_bench256_pmc_sq.json
-echo "sq pass done"
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INST_CYCLES_SMEM \
+          --output-format csv -d $OUT/p_sq2 -o q -- $B --steps 3 --warmup 1 --no-cpu-baseline --no-sph > $OUT/sq2.log 2>&1
+python3 $ROOT/tools/pmc_summary.py pmc "$(one $OUT/p_sq2 counter_collection.csv)" > $OUT/${TAG}_bench256_pmc_sq2.json
+echo "sq passes done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p_sphs -o s -- $S > $OUT/sph_stats.log 2>&1
 cp "$(one $OUT/p_sphs kernel_stats.csv)" $OUT/${TAG}_sph128_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/p_sphf -o f -- $S > $OUT/sph_fetch.log 2>&1
