@@ -1116,6 +1116,15 @@ int shq_pm_phase_ms(shq_context *ctx, double ms[6]);
 int shq_pm_measure_power(shq_context *ctx, int enable);
 int shq_pm_download_power(shq_context *ctx, int size, double *kk, double *power, int64_t *nmodes, double *norm);
 int shq_pm_set_debug(shq_context *ctx, int keep_meshes);
+/* The deposit mesh of the NEXT shq_pm_run is cleared in the shadow of the tree walk: the first production-size shq_grav_short_run
+ * (exact walk, no diagnostic counters, a task's share <= 64 KB) after a PM run writes the zeros from inside the walk kernel — 3.7 GB
+ * at Nmesh 768, spread over the walk's 34 ms on a memory system the walk leaves idle — and that shq_pm_run skips its 0.63 ms
+ * clearing kernel (petapm.cpp:1304-1310 deposits into a zeroed mesh either way: results are bit-identical).  The mesh is the
+ * library's own buffer and nothing reads it after the readout (shq_pm_set_debug(1) keeps COPIES); any other writer of it
+ * (shq_fft_r2c / c2r, a different Nmesh) resets the state.  On by default (SHQ_PM_SCRUB=0 or shq_pm_set_mesh_scrub(ctx, 0) turn it
+ * off); shq_pm_mesh_prezeroed reports whether the next shq_pm_run will skip the clearing. */
+int shq_pm_set_mesh_scrub(shq_context *ctx, int enable);
+int shq_pm_mesh_prezeroed(shq_context *ctx, int *zeroed);
 int shq_pm_download_mesh(shq_context *ctx, int which /*0 density,1 potential*/, double *mesh);
 
 /* ---- slab-sharded PM for multi-GPU runs (one rank per GPU, x-slabs of the mesh) ------------------

@@ -568,6 +568,8 @@ hip.shq_pm_run.argtypes = [_vp, C.POINTER(PMParams)]
 hip.shq_pm_download.argtypes = [_vp, _vp, _vp]
 hip.shq_pm_phase_ms.argtypes = [_vp, C.POINTER(C.c_double * 6)]
 hip.shq_pm_set_debug.argtypes = [_vp, C.c_int]
+hip.shq_pm_set_mesh_scrub.argtypes = [_vp, C.c_int]
+hip.shq_pm_mesh_prezeroed.argtypes = [_vp, C.POINTER(C.c_int)]
 hip.shq_pm_download_mesh.argtypes = [_vp, C.c_int, _vp]
 hip.shq_fft_r2c.argtypes = [_vp, C.c_int, _vp, _vp]
 hip.shq_fft_r2c_xyz.argtypes = [_vp, C.c_int, _vp, _vp]

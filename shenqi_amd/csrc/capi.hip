@@ -171,6 +171,8 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
     }
     if(const char *v = getenv("SHQ_PM_OVERLAP"))
         ctx->pm_overlap = atoi(v) != 0;
+    if(const char *v = getenv("SHQ_PM_SCRUB"))
+        ctx->pm_scrub = atoi(v) != 0;
     if(const char *v = getenv("SHQ_WALK_VARIANT"))
         ctx->walk_variant = atoi(v);
     if(const char *v = getenv("SHQ_WALK_STATS_GUARD"))
@@ -212,6 +214,7 @@ extern "C" void shq_shutdown(shq_context *ctx)
     ctx->nodeA.release(); ctx->nodeB.release(); ctx->nodeC.release(); ctx->nodeG.release();
     ctx->posm_leaf.release(); ctx->leaf_pidx.release();
     ctx->mesh.release(); ctx->sinctab.release(); ctx->dbg_rho.release(); ctx->dbg_pot.release();
+    ctx->mesh_words = 0; ctx->mesh_zeroed = false;
     ctx->gravtab.release(); ctx->stage.release();
     ctx->node_hmax.release(); ctx->pfather.release();
     ctx->hsml.release(); ctx->dthsml.release(); ctx->vel.release(); ctx->bin_grav.release(); ctx->bin_hydro.release();
@@ -1229,6 +1232,20 @@ extern "C" int shq_pm_set_debug(shq_context *ctx, int keep_meshes)
 {
     SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
     ctx->pm_keep = keep_meshes;
+    return SHQ_OK;
+}
+
+extern "C" int shq_pm_set_mesh_scrub(shq_context *ctx, int enable)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    ctx->pm_scrub = enable != 0;
+    return SHQ_OK;
+}
+
+extern "C" int shq_pm_mesh_prezeroed(shq_context *ctx, int *zeroed)
+{
+    SHQ_CHECK(ctx && zeroed, SHQ_ERR_INVALID, "null argument");
+    *zeroed = ctx->mesh_zeroed ? 1 : 0;
     return SHQ_OK;
 }
 

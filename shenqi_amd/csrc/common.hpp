@@ -213,6 +213,9 @@ struct shq_context {
     hipEvent_t ev_pm_ready = nullptr, ev_pm_done = nullptr;
     bool pm_pending = false;
     bool pm_overlap = false;
+    bool pm_scrub = true;      /* SHQ_PM_SCRUB: the first full tree walk after a PM run clears the PM mesh for the next deposit */
+    bool mesh_zeroed = false;  /* ctx->mesh is all zero (set by that walk, reset by pm_prepare) */
+    size_t mesh_words = 0;     /* 8-byte words of ctx->mesh in use (pm_prepare) */
     hipEvent_t ev_begin[SHQ_NTIMERS] = {};
     hipEvent_t ev_end[SHQ_NTIMERS] = {};
 

@@ -528,7 +528,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
                     nd.bhlim = nd.mlen2 = nd.inside = nd.rcut2 = nd.wraplim = nd.rcuthl = 0;
                 }
                 const bool anywrap = shq_ballot(on && (fmax(fmax(fabs(nd.center[0] - cx) + hx, fabs(nd.center[1] - cy) + hy),
-                                                              fabs(nd.center[2] - cz) + hz) > nd.wraplim)) != 0ull;
+                                                              fabs(nd.center[2] - cz) + hz) > fabs(nd.wraplim))) != 0ull; /* sign bit: interior flag of the exact walk */
 #pragma unroll
                 for(int i = 0; i < GS; i++) {
                     double dx = nd.cofm[0] - tx[i], dy = nd.cofm[1] - ty[i], dz = nd.cofm[2] - tz[i];

@@ -55,6 +55,9 @@ struct WalkArgs {
     unsigned int *task_counters; /* PERSIST: 8 counters, one per XCD region, 64 B apart */
     long long nwaves;            /* PERSIST: number of 64-target tasks */
     int task_run_log2;           /* PERSIST: log2 of the run of consecutive tasks a region owns */
+    uint4 *scrub;                /* PM mesh to clear in the shadow of the walk (null: none): task w zeroes the 16-byte units */
+    long long scrub_n16;         /*   [w * scrub_per_task, (w + 1) * scrub_per_task) below scrub_n16 */
+    int scrub_per_task;          /*   (a multiple of 64) */
 };
 
 /* NEAREST (partmanager.h:99) as d - L*rint(d/L): one multiply, one round, one fma. For
@@ -274,6 +277,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
             pz = p.z;
             aold = c.errtol * c.oldacc[pi];
         }
+        /* The PM's next deposit mesh is cleared here: 3.7 GB of stores spread over the walk's 34 ms (0.1 TB/s of a memory system
+         * the walk leaves idle, a dozen store instructions per task beside 64 k arithmetic ones) instead of a 0.63 ms kernel of
+         * their own.  shq_grav_short_run decides (pm.hip: mesh_zeroed). */
+        if(c.scrub_per_task > 0) {
+            const long long u0 = wave * c.scrub_per_task + lane;
+            for(int k = 0; k < c.scrub_per_task; k += 64)
+                if(u0 + k < c.scrub_n16)
+                    c.scrub[u0 + k] = make_uint4(0u, 0u, 0u, 0u);
+        }
     }
     double ax = 0, ay = 0, az = 0, pot = 0;
     int nint = 0;
@@ -327,18 +339,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
          * for four cycles, as long as an f64 instruction holds the vector pipe, and the walk issues nearly as many of the one as
          * of the other (SQ_INSTS_SALU 61 k, SQ_INSTS_VALU 66 k per task). */
         const unsigned long long actm = shq_ballot(mynext == cur);
-        const unsigned long long wrapm = shq_ballot(cmax > nd.wraplim) & actm;
-        if(wrapm != 0ull) {
-            dx = wrapd(dx, a.Box, a.invBox);
-            dy = wrapd(dy, a.Box, a.invBox);
-            dz = wrapd(dz, a.Box, a.invBox);
-            ux = wrapd(ux, a.Box, a.invBox);
-            uy = wrapd(uy, a.Box, a.invBox);
-            uz = wrapd(uz, a.Box, a.invBox);
-            cmax = fmax(fmax(fabs(ux), fabs(uy)), fabs(uz));
+        unsigned long long wrapm = 0ull;
+        int wl_hi = __double2hiint(nd.wraplim);
+        asm volatile("" : "+s"(wl_hi)); /* a 32-bit scalar compare (left alone the compiler widens it to a 64-bit VECTOR compare) */
+        if(wl_hi >= 0) { /* not an interior node (fill_rcuthl_kernel): the wrap may matter */
+            asm volatile("" ::: "memory");
+            wrapm = shq_ballot(cmax > nd.wraplim) & actm;
+            if(wrapm != 0ull) {
+                dx = wrapd(dx, a.Box, a.invBox);
+                dy = wrapd(dy, a.Box, a.invBox);
+                dz = wrapd(dz, a.Box, a.invBox);
+                ux = wrapd(ux, a.Box, a.invBox);
+                uy = wrapd(uy, a.Box, a.invBox);
+                uz = wrapd(uz, a.Box, a.invBox);
+                cmax = fmax(fmax(fabs(ux), fabs(uy)), fabs(uz));
+            }
         }
         const double r2 = dx * dx + dy * dy + dz * dz;
-        /* shall_we_discard_node, gravshort2.hpp:152-167 (rcuthl = Rcut + len / 2, per node) */
+        /* shall_we_discard_node, gravshort2.hpp:152-167 (rcuthl = Rcut + len / 2, per node).  (Making the second compare conditional
+         * on some lane being beyond Rcut at all — a scalar branch for a vector compare — measured 34.1 against 33.6 ms.) */
         const unsigned long long keepm = actm & ~(shq_ballot(r2 > nd.rcut2) & shq_ballot(cmax > nd.rcuthl));
         /* shall_we_open_node, gravshort2.hpp:172-193 (len*len/r2 > theta2 written without the divide;
          * mass*len*len and 0.6*len come precomputed with the node) */
@@ -565,13 +584,26 @@ __global__ void oldacc_kernel(long long n, const double *treeacc, const double *
 /* the discard test compares with Rcut + len / 2 and the Barnes-Hut test with len^2 / theta^2: wave-uniform
  * expressions that would cost every visit VALU instructions (there is no scalar f64 ALU); they are stored with the
  * node whenever the walk parameters or the tree change */
-__global__ void fill_rcuthl_kernel(NodeG *g, long long n, double rcut, double bh2)
+/* INTERIOR nodes carry wraplim with the sign bit set (the walk reads the sign on the scalar pipe and skips the wrap vote, the group
+ * walk takes |wraplim|).  A node is interior when its cell keeps M >= Rcut + 1.5 len from every face of the box.  Then for a target
+ * inside the box and a coordinate k with |center_k - pos_k| > Box/2 - len/2 — the only case in which the periodic wrap is not the
+ * identity on both displacement vectors — the lane is discarded with and without the wrap: without it |center_k - pos_k| > Box/2 - len/2
+ * >= Rcut + len/2 and |cofm_k - pos_k| > Box/2 - len >= Rcut (Box >= 2 M + len); with it the wrapped displacement crosses a face, so
+ * it is >= M + len/2 for the centre and >= M for the centre of mass, both beyond the same limits (shall_we_discard_node,
+ * gravshort2.hpp:152-167).  Every other lane's arithmetic is untouched. */
+__global__ void fill_rcuthl_kernel(NodeG *g, long long n, double rcut, double bh2, double Box)
 {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if(i < n) {
-        g[i].rcuthl = rcut + 0.5 * g[i].len;
+        const double len = g[i].len, hl = 0.5 * len;
+        g[i].rcuthl = rcut + hl;
         g[i].rcut2 = rcut * rcut;
-        g[i].bhlim = g[i].len * g[i].len / bh2; /* len^2 / r2 > theta^2 (gravshort2.hpp:179-182) as r2 < len^2 / theta^2 */
+        g[i].bhlim = len * len / bh2; /* len^2 / r2 > theta^2 (gravshort2.hpp:179-182) as r2 < len^2 / theta^2 */
+        double M = Box;
+        for(int k = 0; k < 3; k++)
+            M = fmin(M, fmin(g[i].center[k] - hl, Box - (g[i].center[k] + hl)));
+        const double wl = 0.5 * Box - hl;
+        g[i].wraplim = (len > 0 && wl > 0 && M >= rcut + 1.5 * len) ? -wl : wl;
     }
 }
 
@@ -626,7 +658,7 @@ void shq_fill_node_walk_params(shq_context *ctx, const shq_grav_params *p)
 {
     if((ctx->node_rcut != p->Rcut || ctx->node_bh2 != p->BHOpeningAngle2) && ctx->numnodes > 0) {
         const long long n = ctx->numnodes + 1;
-        fill_rcuthl_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->nodeG.ptr, n, p->Rcut, p->BHOpeningAngle2);
+        fill_rcuthl_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->nodeG.ptr, n, p->Rcut, p->BHOpeningAngle2, p->BoxSize);
         ctx->node_rcut = p->Rcut;
         ctx->node_bh2 = p->BHOpeningAngle2;
     }
@@ -665,6 +697,9 @@ static void fill_walk_args(shq_context *ctx, const shq_grav_params *p, WalkArgs 
     a.tab_f = ctx->gravtab.ptr;
     a.tab_p = ctx->gravtab.ptr + SHQ_NGRAVTAB;
     a.task_counters = nullptr;
+    a.scrub = nullptr;
+    a.scrub_n16 = 0;
+    a.scrub_per_task = 0;
     a.nwaves = 0;
     a.task_run_log2 = 7;
 }
@@ -782,6 +817,19 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
         if(ring)
             dyn_lds = sizeof(double4) * SHQ_LEAF_RING * 8;
     }
+    /* clear the PM mesh for the next deposit in this walk's shadow: the last shq_pm_run is through with it (same stream), nothing
+     * else is known to want it (pm_keep copies what it keeps), and the walk is large enough for a task's share to be a few stores */
+    bool scrubbed = false;
+    if(ctx->pm_scrub && !stats && variant == 3 && ctx->mesh.ptr && ctx->mesh_words > 0 && !ctx->mesh_zeroed && !ctx->pm_overlap) {
+        const long long n16 = (long long) (ctx->mesh_words / 2);
+        const long long per = ((n16 + nwaves - 1) / nwaves + 63) / 64 * 64;
+        if(ctx->mesh_words % 2 == 0 && per <= 4096) {
+            a.scrub = (uint4 *) ctx->mesh.ptr;
+            a.scrub_n16 = n16;
+            a.scrub_per_task = (int) per;
+            scrubbed = true;
+        }
+    }
     const dim3 grid((unsigned) launch_blocks), block(ring ? 512 : threads);
     SHQ_HIP(hipEventRecord(ctx->ev_begin[SHQ_NTIMERS - 1], ctx->stream));
     if(update_potential) {
@@ -801,6 +849,8 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     }
     SHQ_HIP(hipGetLastError());
     SHQ_HIP(hipEventRecord(ctx->ev_end[SHQ_NTIMERS - 1], ctx->stream));
+    if(scrubbed)
+        ctx->mesh_zeroed = true;
     return SHQ_OK;
 }
 

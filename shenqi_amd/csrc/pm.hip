@@ -47,6 +47,14 @@ __device__ __forceinline__ void cic_setup(double p, double cell, int N, int &ic,
     ic = i;
 }
 
+/* SHQ_PM_XCD_K / SHQ_PM_DEP_XCD_K: workgroups per XCD chunk of the readout / deposit block order (xcd_block; 0 = round robin) */
+static unsigned pm_xcdk(int deposit)
+{
+    static const unsigned kr = getenv("SHQ_PM_XCD_K") ? (unsigned) atoi(getenv("SHQ_PM_XCD_K")) : 64u;
+    static const unsigned kd = getenv("SHQ_PM_DEP_XCD_K") ? (unsigned) atoi(getenv("SHQ_PM_DEP_XCD_K")) : 0u;
+    return deposit ? kd : kr;
+}
+
 __global__ void pm_zero_kernel(unsigned long long *mesh, size_t n)
 {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,12 +78,12 @@ __global__ void pm_zero_kernel(unsigned long long *mesh, size_t n)
 
 __global__ __launch_bounds__(256) void pm_deposit_kernel(const double4 *__restrict__ posm, const uint8_t *__restrict__ pflags,
                                                          long long n, unsigned long long *mesh, int N, int zp, double cell,
-                                                         double scale, int xshift, int nxalloc, int *oob)
+                                                         double scale, int xshift, int nxalloc, int *oob, unsigned xcdk)
 {
     __shared__ unsigned long long tile[DEP_T * DEP_T * DEP_T];
     __shared__ int s_min[3], s_max[3];
     const int tid = threadIdx.x;
-    const long long base = (long long) blockIdx.x * DEP_CHUNK;
+    const long long base = (long long) xcd_block(blockIdx.x, gridDim.x, xcdk) * DEP_CHUNK;
     if(tid < 3) {
         s_min[tid] = 0x7fffffff;
         s_max[tid] = -0x7fffffff;
@@ -236,9 +244,10 @@ struct __attribute__((aligned(8))) pair8 { double x, y; }; /* two z-adjacent cel
 __global__ __launch_bounds__(256) void pm_readout_kernel(const double4 *__restrict__ posm, const uint8_t *__restrict__ pflags,
                                                          long long n, const double *__restrict__ mesh, int N, int zp,
                                                          double cell, double ffac, double *gravpm, double *pmpot, int xshift,
-                                                         int nxalloc, int *oob)
+                                                         int nxalloc, int *oob, unsigned xcdk)
 {
-    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    /* consecutive workgroups (consecutive runs of the space-filling curve: neighbouring mesh lines) share an XCD's L2 */
+    const long long i = (long long) xcd_block(blockIdx.x, gridDim.x, xcdk) * blockDim.x + threadIdx.x;
     if(i >= n)
         return;
     double g0 = 0, g1 = 0, g2 = 0, gp = 0;
@@ -364,6 +373,7 @@ void shq_pm_destroy_plans(shq_context *ctx)
 static int pm_prepare(shq_context *ctx, int N)
 {
     SHQ_CHECK(N >= 4 && N % 2 == 0, SHQ_ERR_INVALID, "Nmesh must be even and >= 4 (got %d)", N);
+    ctx->mesh_zeroed = false; /* every caller is about to write the mesh (shq_pm_run reads the flag first) */
     if(ctx->pm_nmesh == N && (ctx->have_plans || ctx->pm_custom_fft))
         return SHQ_OK;
     shq_pm_destroy_plans(ctx);
@@ -371,6 +381,7 @@ static int pm_prepare(shq_context *ctx, int N)
     ctx->pm_zp = ctx->pm_custom_fft ? shq_fft3d_pitch(N) : N + 2;
     const size_t padded = (size_t) N * N * ctx->pm_zp;
     SHQ_TRY(ctx->mesh.reserve(padded));
+    ctx->mesh_words = padded;
     SHQ_TRY(ctx->sinctab.reserve(N));
     SHQ_TRY(ctx->pm_oob.reserve(1));
     SHQ_HIP(hipMemset(ctx->pm_oob.ptr, 0, sizeof(int)));
@@ -486,6 +497,8 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
     SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "pm: particles must be uploaded first");
     SHQ_CHECK(pm->BoxSize > 0 && pm->Asmth > 0, SHQ_ERR_INVALID, "pm params: BoxSize and Asmth must be > 0");
     const int N = pm->Nmesh;
+    /* the mesh may have been cleared in the shadow of the last tree walk (grav_walk.hip, `scrub`) */
+    const bool prezeroed = ctx->mesh_zeroed && ctx->pm_nmesh == N;
     SHQ_TRY(pm_prepare(ctx, N));
     const int zp = ctx->pm_zp;
     const size_t padded = (size_t) N * N * zp;
@@ -501,10 +514,11 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
     const double pot_factor = -pm->G / (M_PI * pm->BoxSize);
 
     SHQ_HIP(hipEventRecord(ctx->ev_begin[8], ctx->stream));
-    pm_zero_kernel<<<dim3(2048), dim3(threads), 0, ctx->stream>>>((unsigned long long *) ctx->mesh.ptr, padded);
+    if(!(prezeroed && ctx->mesh_words == padded))
+        pm_zero_kernel<<<dim3(2048), dim3(threads), 0, ctx->stream>>>((unsigned long long *) ctx->mesh.ptr, padded);
     if(n > 0)
         pm_deposit_kernel<<<dim3((unsigned) ((n + DEP_CHUNK - 1) / DEP_CHUNK)), dim3(256), 0, ctx->stream>>>(
-            ctx->posm.ptr, ctx->pflags.ptr, n, (unsigned long long *) ctx->mesh.ptr, N, zp, cell, scale, 0, N, ctx->pm_oob.ptr);
+            ctx->posm.ptr, ctx->pflags.ptr, n, (unsigned long long *) ctx->mesh.ptr, N, zp, cell, scale, 0, N, ctx->pm_oob.ptr, pm_xcdk(1));
     if(ctx->pm_keep) {
         SHQ_TRY(ctx->dbg_rho.reserve(dense));
         pm_repitch_kernel<<<dim3((unsigned) ((dense + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
@@ -559,7 +573,7 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
     if(n > 0) {
         const double ffac = -(N / pm->BoxSize);
         pm_readout_kernel<<<dim3((unsigned) ((n + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-            ctx->posm.ptr, ctx->pflags.ptr, n, ctx->mesh.ptr, N, zp, cell, ffac, ctx->gravpm.ptr, ctx->pmpot.ptr, 0, N, ctx->pm_oob.ptr);
+            ctx->posm.ptr, ctx->pflags.ptr, n, ctx->mesh.ptr, N, zp, cell, ffac, ctx->gravpm.ptr, ctx->pmpot.ptr, 0, N, ctx->pm_oob.ptr, pm_xcdk(0));
     }
     SHQ_HIP(hipGetLastError());
     SHQ_HIP(hipEventRecord(ctx->ev_begin[13], ctx->stream));
@@ -759,7 +773,7 @@ extern "C" int shq_pm_slab_deposit(shq_context *ctx, const shq_pm_params *pm, in
     if(n > 0)
         pm_deposit_kernel<<<dim3((unsigned) ((n + DEP_CHUNK - 1) / DEP_CHUNK)), dim3(256), 0, ctx->stream>>>(
             ctx->posm.ptr, ctx->pflags.ptr, n, (unsigned long long *) d_mesh_i64, N, N + 2, pm->BoxSize / N, ldexp(1.0, ctx->pm_log2scale),
-            plane0, nalloc, ctx->pm_oob.ptr);
+            plane0, nalloc, ctx->pm_oob.ptr, pm_xcdk(1));
     SHQ_HIP(hipGetLastError());
     return check_oob(ctx, "pm_slab_deposit");
 }
@@ -781,7 +795,7 @@ extern "C" int shq_pm_slab_readout(shq_context *ctx, const shq_pm_params *pm, in
     if(n > 0)
         pm_readout_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(
             ctx->posm.ptr, ctx->pflags.ptr, n, (const double *) d_phi_ext, N, N + 2, pm->BoxSize / N, -(N / pm->BoxSize), ctx->gravpm.ptr,
-            ctx->pmpot.ptr, xshift, nalloc, ctx->pm_oob.ptr);
+            ctx->pmpot.ptr, xshift, nalloc, ctx->pm_oob.ptr, pm_xcdk(0));
     SHQ_HIP(hipGetLastError());
     ctx->have_pm_result = true;
     return check_oob(ctx, "pm_slab_readout");
@@ -868,7 +882,7 @@ extern "C" int shq_pm_slab2_deposit(shq_context *ctx, const shq_pm_params *pm, i
     if(n > 0)
         pm_deposit_kernel<<<dim3((unsigned) ((n + DEP_CHUNK - 1) / DEP_CHUNK)), dim3(256), 0, ctx->stream>>>(
             ctx->posm.ptr, ctx->pflags.ptr, n, (unsigned long long *) d_mesh_i64, N, zp, pm->BoxSize / N, ldexp(1.0, ctx->pm_log2scale),
-            plane0 - xoff, nfit, ctx->pm_oob.ptr);
+            plane0 - xoff, nfit, ctx->pm_oob.ptr, pm_xcdk(1));
     SHQ_HIP(hipGetLastError());
     return check_oob(ctx, "pm_slab2_deposit");
 }
@@ -931,7 +945,7 @@ extern "C" int shq_pm_slab2_readout(shq_context *ctx, const shq_pm_params *pm, i
     if(n > 0)
         pm_readout_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(
             ctx->posm.ptr, ctx->pflags.ptr, n, (const double *) d_phi, N, zp, pm->BoxSize / N, -(N / pm->BoxSize), ctx->gravpm.ptr,
-            ctx->pmpot.ptr, plane0 - xoff, nalloc, ctx->pm_oob.ptr);
+            ctx->pmpot.ptr, plane0 - xoff, nalloc, ctx->pm_oob.ptr, pm_xcdk(0));
     SHQ_HIP(hipGetLastError());
     ctx->have_pm_result = true;
     return check_oob(ctx, "pm_slab2_readout");

@@ -105,6 +105,16 @@ def _treepm_properties(ctx, pman, n1, nmesh, L, stride):
     assert np.abs(acc[targets] - oacc).max() < 1e-10 * scale
     assert np.allclose(pot[targets], opot, rtol=1e-9, atol=1e-10 * np.abs(opot).max())
 
+    # ---- the walks above cleared the PM mesh in their shadow (persistent launch at this size): a third PM run, without its
+    #      clearing kernel, reproduces the first two bit for bit
+    z = C.c_int(-1)
+    capi.check(capi.hip.shq_pm_mesh_prezeroed(ctx.h, C.byref(z)))
+    assert z.value == 1
+    g3 = np.zeros((n, 3)); p3 = np.zeros(n)
+    capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
+    capi.check(capi.hip.shq_pm_download(ctx.h, capi.ptr(g3), capi.ptr(p3)))
+    assert np.array_equal(g3, gpm[0]) and np.array_equal(p3, ppot[0])
+
 
 def test_c3_sph_128_properties(ctx):
     """BASELINE.json configs[2] at its gas size (128^3 gas particles, quintic kernel, pressure-entropy SPH): properties that

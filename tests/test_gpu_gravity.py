@@ -539,3 +539,74 @@ def test_walk_erfc_window(ctx, usebh):
     assert np.abs(acc - oacc).max() < 1e-11 * np.abs(oacc).max()
     assert np.allclose(pot, opot, rtol=1e-10, atol=1e-10 * np.abs(opot).max())
     cm.reference_treepar()                                  # back to the exact window for the tests that follow
+
+
+def test_pm_mesh_cleared_in_the_shadow_of_the_walk(ctx):
+    """The first production-size walk after a PM run zeroes the PM mesh from inside the walk kernel and the next shq_pm_run skips its
+    clearing kernel: GravPM / potential stay bit-identical, with the scrub on or off, after an intervening FFT seam call (another
+    writer of the mesh) and for a walk too small to carry the scrub."""
+    n, L, nmesh = 64**3, 1.0, 96
+    pos = sq.synth_positions("cluster", n, L=L)
+    pos = pos[sq.morton_order(pos, L)]
+    pman = cm.make_partmanager(pos, box=L)
+    tree = sq.force_tree_full(pman)
+    sq.set_gravshort_treepar(ErrTolForceAcc=0.005, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=1, Rcut=6.0)
+    sq.gravshort_set_softenings(L / 64)
+    gp = sq.make_grav_params(L, 1.5, nmesh, cm.G, cm.RHO0)
+    pmp = sq.PMParams(nmesh, 0, L, 1.5, cm.G)
+    pv, tv = pman.view(), tree.view()
+    capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+    capi.check(capi.hip.shq_tree_upload(ctx.h, C.byref(tv)))
+    capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, gp.G))
+
+    def pm():
+        capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
+        g = np.zeros((n, 3)); p = np.zeros(n)
+        capi.check(capi.hip.shq_pm_download(ctx.h, capi.ptr(g), capi.ptr(p)))
+        return g, p
+
+    def walk(active=None):
+        a = None if active is None else np.ascontiguousarray(active, dtype=np.int32)
+        capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), capi.ptr(a), 0 if a is None else len(a), 1, sq.WALK_EXACT))
+        acc = np.zeros((n, 3)); pot = np.zeros(n); nint = np.zeros(n, dtype=np.int64)
+        capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), capi.ptr(pot), capi.ptr(nint), C.byref(sq.WalkStats())))
+        return acc
+
+    def prezeroed():
+        z = C.c_int(-1)
+        capi.check(capi.hip.shq_pm_mesh_prezeroed(ctx.h, C.byref(z)))
+        return z.value
+
+    capi.check(capi.hip.shq_pm_set_mesh_scrub(ctx.h, 0))
+    g0, p0 = pm()
+    a0 = walk()
+    assert prezeroed() == 0
+    capi.check(capi.hip.shq_pm_set_mesh_scrub(ctx.h, 1))
+    g1, p1 = pm()
+    assert np.array_equal(g1, g0) and np.array_equal(p1, p0)
+    a1 = walk()
+    assert prezeroed() == 1                       # this walk carried the scrub ...
+    assert np.array_equal(a1, a0)                 # ... and its forces are what they were
+    g2, p2 = pm()                                 # no clearing kernel in this run
+    assert prezeroed() == 0
+    assert np.array_equal(g2, g0) and np.array_equal(p2, p0)
+    # a second walk before the next PM run has nothing left to do; a walk on 1/64 of the targets would have too large a share per task
+    walk()
+    assert prezeroed() == 1
+    walk()
+    assert prezeroed() == 1
+    g3, p3 = pm()
+    assert np.array_equal(g3, g0) and np.array_equal(p3, p0)
+    walk(np.arange(0, n, 64))
+    assert prezeroed() == 0
+    g4, p4 = pm()
+    assert np.array_equal(g4, g0) and np.array_equal(p4, p0)
+    # another writer of the mesh between the scrub and the PM run: the FFT seam
+    walk()
+    assert prezeroed() == 1
+    real = np.random.default_rng(5).standard_normal((nmesh, nmesh, nmesh))
+    comp = np.zeros((nmesh, nmesh, nmesh // 2 + 1, 2))
+    capi.check(capi.hip.shq_fft_r2c(ctx.h, nmesh, capi.ptr(real), capi.ptr(comp)))
+    assert prezeroed() == 0
+    g5, p5 = pm()
+    assert np.array_equal(g5, g0) and np.array_equal(p5, p0)
