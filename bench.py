@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sph", action="store_true", help="skip the SPH operator figures (kernels.sph_*)")
     ap.add_argument("--walk-mode", type=int, default=0)
+    ap.add_argument("--separate-calls", action="store_true",
+                    help="time shq_pm_run + shq_grav_refresh_oldacc + shq_grav_short_run instead of the one-call shq_treepm_step")
     ap.add_argument("--workload", default="dm", choices=["dm", "c5"],
                     help="N > 1 only: dm = dm-only TreePM (the metric's configuration, default); c5 = BASELINE configs[4]-shaped step, "
                          "n^3 gas + n^3 dark matter: sharded TreePM over all + device-resident sharded SPH density and hydro of the gas")
@@ -130,6 +132,13 @@ def load_profile(name):
             return json.load(f)
     except (OSError, ValueError):
         return None
+
+
+def production_walk_key(prof):
+    """the profile row of the production walk (potential on, no prefetch, leaf batch 2, no counters, relative criterion, primary
+    walk; whatever launch form the round used: the row with the most dispatches)"""
+    keys = [k for k in prof if k.startswith("grav_walk_exact_kernel<true, false, 2, 0, false, false")]
+    return max(keys, key=lambda k: prof[k].get("dispatches", 0)) if keys else None
 
 
 def hbm_bytes(e):
@@ -710,10 +719,19 @@ def main():
         numnodes = int(host_tree.numnodes)
         tb = capi.TreeBuildStats(n, numnodes, 0, 0.0)
 
-    def step(gp):
-        capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
-        capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, args.walk_mode))
-        capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, G))
+    def step(gp, one_call=None):
+        """gravpm_force, then grav_short_tree for every particle with OldAcc = |FullTreeGravAccel of the last step + the new
+        GravPM| / G (the reference's order on a PM step, run.cpp:518-563): as the library's one call (readout and OldAcc refresh
+        ride in the walk's prologue) or, with --separate-calls, as its three separate ones.  Same results bit for bit
+        (tests/test_gpu_gravity.py::test_treepm_step_equals_the_three_separate_calls)."""
+        if one_call is None:
+            one_call = not args.separate_calls and args.walk_mode == 0
+        if one_call:
+            capi.check(capi.hip.shq_treepm_step(ctx.h, C.byref(pmp), C.byref(gp), 1))
+        else:
+            capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
+            capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, G))
+            capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, args.walk_mode))
 
     # the timed steps run the production walk (no diagnostic counters); the wave-level figures under kernels.tree_* come from
     # one more, untimed step with the counters on (a separate kernel instantiation: its own row in a profile)
@@ -755,8 +773,13 @@ def main():
     ph = (C.c_double * 6)()
     capi.check(capi.hip.shq_pm_phase_ms(ctx.h, C.byref(ph)))
     ph = list(ph)
+    fused = C.c_int(0)
+    capi.check(capi.hip.shq_treepm_last_fused(ctx.h, C.byref(fused)))
+    step_route = ("shq_treepm_step: PM readout + OldAcc refresh in the walk's task prologue" if fused.value and not args.separate_calls and args.walk_mode == 0
+                  else "shq_pm_run + shq_grav_refresh_oldacc + shq_grav_short_run")
     capi.check(capi.hip.shq_set_walk_stats(ctx.h, 1))
-    step(gp_rel)
+    step(gp_rel, one_call=False)
+    capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, G))   # the OldAcc of the NEXT step, for the checks below
     stw = sq.WalkStats()
     capi.check(capi.hip.shq_grav_short_download(ctx.h, None, None, None, C.byref(stw)))
     for k in ("nnodes_visited", "nwave_interactions", "nwave_node_interactions", "nnode_interactions"):
@@ -789,17 +812,17 @@ def main():
     pj = load_profile("bench256_pmc_hbm.json")
     if pj and n1 == 256 and world == 1:
         # the production walk: potential on, no prefetch, leaf batch 2, no counters, relative criterion, primary walk
-        key = [k for k in pj if k.startswith("grav_walk_exact_kernel<true, false, 2, 0, false, false>")]
+        key = production_walk_key(pj)
         if key:
-            traffic = hbm_bytes(pj[key[0]])
+            traffic = hbm_bytes(pj[key])
         fk = [k for k in pj if k.startswith("fft_pass_")]
         if len(fk) == 5:
             traffic_fft = sum(hbm_bytes(pj[k]) for k in fk)
     sj = load_profile("bench256_pmc_sq.json")
     if sj:
-        key = [k for k in sj if k.startswith("grav_walk_exact_kernel<true, false, 2, 0, false, false>")]
-        if key and sj[key[0]].get("SQ_BUSY_CYCLES"):
-            e = sj[key[0]]
+        key = production_walk_key(sj)
+        if key and sj[key].get("SQ_BUSY_CYCLES"):
+            e = sj[key]
             # SQ_INSTS_VALU x 4 cycles per wave instruction over the SIMD cycles the kernel was resident (SQ_BUSY_CYCLES counts per
             # shader engine: / 32 engines x 1024 SIMDs)
             valu_busy = e.get("SQ_INSTS_VALU", 0.0) * 4.0 / (e["SQ_BUSY_CYCLES"] / 32.0 * 1024.0)
@@ -829,7 +852,7 @@ def main():
         "config": {"workload": "dm-only %d^3 TreePM (S-%s, Nmesh %d, Asmth 1.5, Rcut 6, ErrTolForceAcc %g, exact window)"
                                % (n1, args.kind, nmesh, args.errtol),
                    "particles_per_gpu": n, "nmesh": nmesh, "parallelism": "replicas x%d" % world if world > 1 else "1 GPU",
-                   "walk": "exact (per-target reference opening decisions)"},
+                   "walk": "exact (per-target reference opening decisions)", "step_calls": step_route},
         "roofline": walk_roofline if walk_s >= pm_s else
                     {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": pm_bytes},
@@ -849,7 +872,9 @@ def main():
             "tree_algorithmic_GBs": tree_bytes / max(walk_s, 1e-12) / 1e9,
             # the bespoke pipeline runs forward FFT, Green's function and inverse FFT as five fused passes: one phase
             "pm_ms": {"zero_and_deposit": ph[0], "fft_pipeline_5_passes_incl_greens_function": ph[1] + ph[2] + ph[3], "readout": ph[4],
-                      "total": ph[5]},
+                      "total": ph[5],
+                      "note": "zero: the mesh is cleared in the shadow of the previous walk; readout: 0 when the walk's prologue does it (config.step_calls)"},
+            "tree_wave_figures_from": "the counter launch (one task per wave, no leaf ring): lane efficiency and rounds per wave describe the union walk, not the ring's drain",
             "pm_algorithmic_GBs": pm_bytes / max(pm_s, 1e-12) / 1e9,
             "pm_frac_of_hbm_peak": pm_bytes / max(pm_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
             "pm_reference_structure_GBs": pm_bytes_reference_structure / max(pm_s, 1e-12) / 1e9,

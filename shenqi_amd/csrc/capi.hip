@@ -173,6 +173,8 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
         ctx->pm_overlap = atoi(v) != 0;
     if(const char *v = getenv("SHQ_PM_SCRUB"))
         ctx->pm_scrub = atoi(v) != 0;
+    if(const char *v = getenv("SHQ_TREEPM_FUSE"))
+        ctx->treepm_fuse = atoi(v) != 0;
     if(const char *v = getenv("SHQ_WALK_VARIANT"))
         ctx->walk_variant = atoi(v);
     if(const char *v = getenv("SHQ_WALK_STATS_GUARD"))
@@ -214,7 +216,7 @@ extern "C" void shq_shutdown(shq_context *ctx)
     ctx->nodeA.release(); ctx->nodeB.release(); ctx->nodeC.release(); ctx->nodeG.release();
     ctx->posm_leaf.release(); ctx->leaf_pidx.release();
     ctx->mesh.release(); ctx->sinctab.release(); ctx->dbg_rho.release(); ctx->dbg_pot.release();
-    ctx->mesh_words = 0; ctx->mesh_zeroed = false;
+    ctx->mesh_words = 0; ctx->mesh_zeroed = false; ctx->mesh_alt.release();
     ctx->gravtab.release(); ctx->stage.release();
     ctx->node_hmax.release(); ctx->pfather.release();
     ctx->hsml.release(); ctx->dthsml.release(); ctx->vel.release(); ctx->bin_grav.release(); ctx->bin_hydro.release();
@@ -1146,6 +1148,53 @@ extern "C" int shq_pm_run(shq_context *ctx, const shq_pm_params *pm)
     }
     SHQ_HIP(hipEventRecord(ctx->ev_pm_done, ctx->stream_pm));
     ctx->pm_pending = true;
+    return SHQ_OK;
+}
+
+/* gravpm_force followed by grav_short_tree for every particle — the force part of a PM step in the reference's own order
+ * (run.cpp:518-563: "gravpm_force() needs to be run first", because the walk's opening criterion reads the new GravPM through
+ * grav_get_abs_accel).  Deposit and transforms run as in shq_pm_run; the readout of GravPM / the PM potential and the OldAcc
+ * refresh happen in the prologue of the walk's tasks, target by target, where their scattered loads hide behind the arithmetic
+ * of the other waves (the walk leaves the memory system idle).  Falls back to the three separate launches when the walk at hand
+ * cannot carry them (Barnes-Hut seeding walk, diagnostic counters, a mesh beyond 2^32 cells, ...).  Same bits either way. */
+extern "C" int shq_treepm_step(shq_context *ctx, const shq_pm_params *pm, const shq_grav_params *params, int update_potential)
+{
+    SHQ_CHECK(ctx && pm && params, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "treepm_step: upload particles and tree first");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_join_pm(ctx));
+    const int64_t n = ctx->nlocal;
+    const bool fuse = !ctx->pm_overlap && ctx->treepm_fuse && pm->Nmesh >= 4 &&
+                      (size_t) pm->Nmesh * pm->Nmesh * (size_t) (pm->Nmesh + 10) < (1ull << 29) &&
+                      shq_walk_can_fuse_readout_pre(ctx, params, n);
+    SHQ_TRY(shq_pm_execute(ctx, pm, !fuse));
+    if(!fuse)
+        SHQ_TRY(shq_grav_refresh_oldacc(ctx, params->G));
+    else {
+        ctx->fuse_G = params->G;
+        ctx->fuse_readout = true;
+    }
+    const int rc = shq_launch_grav_walk(ctx, params, nullptr, n, update_potential, SHQ_WALK_EXACT);
+    ctx->fuse_readout = false;
+    SHQ_TRY(rc);
+    SHQ_TRY(shq_launch_grav_postprocess(ctx, params, nullptr, n, update_potential));
+    ctx->grav_raw = false;
+    ctx->last_stats.ntargets = n;
+    ctx->last_step_fused = fuse;
+    return SHQ_OK;
+}
+
+extern "C" int shq_treepm_set_fuse(shq_context *ctx, int enable)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    ctx->treepm_fuse = enable != 0;
+    return SHQ_OK;
+}
+
+extern "C" int shq_treepm_last_fused(shq_context *ctx, int *fused)
+{
+    SHQ_CHECK(ctx && fused, SHQ_ERR_INVALID, "null argument");
+    *fused = ctx->last_step_fused ? 1 : 0;
     return SHQ_OK;
 }
 

@@ -213,6 +213,11 @@ struct shq_context {
     hipEvent_t ev_pm_ready = nullptr, ev_pm_done = nullptr;
     bool pm_pending = false;
     bool pm_overlap = false;
+    bool treepm_fuse = true;   /* SHQ_TREEPM_FUSE: shq_treepm_step may fuse the readout into the walk */
+    bool last_step_fused = false;
+    bool fuse_readout = false; /* shq_treepm_step: the next exact walk carries the PM readout + OldAcc refresh in its prologue */
+    double fuse_cell = 0, fuse_ffac = 0, fuse_G = 0;
+    DevBuf<double> mesh_alt;   /* shq_treepm_step: the walk reads one mesh and clears the other (they change places per step) */
     bool pm_scrub = true;      /* SHQ_PM_SCRUB: the first full tree walk after a PM run clears the PM mesh for the next deposit */
     bool mesh_zeroed = false;  /* ctx->mesh is all zero (set by that walk, reset by pm_prepare) */
     size_t mesh_words = 0;     /* 8-byte words of ctx->mesh in use (pm_prepare) */
@@ -439,7 +444,9 @@ int shq_launch_grav_walk_group(shq_context *ctx, const shq_grav_params *p, const
 int shq_launch_grav_walk_ghosts(shq_context *ctx, const shq_grav_params *p, const double4 *d_qpos, const double *d_qoldacc,
                                 const int32_t *d_qstart, int64_t nq, double *d_acc, double *d_pot, int32_t *d_nint, int update_potential);
 /* pm.hip */
-int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm);
+int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm, bool readout = true);
+bool shq_walk_can_fuse_readout(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets, int64_t first);
+bool shq_walk_can_fuse_readout_pre(shq_context *ctx, const shq_grav_params *p, int64_t ntargets);
 void shq_pm_destroy_plans(shq_context *ctx);
 int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *complx, bool ref_layout);
 int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double *real, bool ref_layout);

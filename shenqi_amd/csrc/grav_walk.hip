@@ -25,6 +25,8 @@
  * the per-visit instruction count down.
  */
 #include "common.hpp"
+#include "pm_readout.hpp"
+#include <utility>
 #include <stdlib.h>
 
 namespace {
@@ -58,6 +60,14 @@ struct WalkArgs {
     uint4 *scrub;                /* PM mesh to clear in the shadow of the walk (null: none): task w zeroes the 16-byte units */
     long long scrub_n16;         /*   [w * scrub_per_task, (w + 1) * scrub_per_task) below scrub_n16 */
     int scrub_per_task;          /*   (a multiple of 64) */
+    /* READOUT (shq_treepm_step): the task prologue reads GravPM and the PM potential of its targets off the potential mesh and forms
+     * OldAcc from them, as gravpm_force -> grav_get_abs_accel do in the reference's order (run.cpp:518-538, gravshort2.hpp:111-121) */
+    const double *pm_mesh;       /* [N][N][zp] potential */
+    int pmN, pmzp;
+    double pmcell, pmffac, G;
+    const double *treeacc;       /* FullTreeGravAccel of the previous step, [N][3] */
+    const uint8_t *pflags;
+    double *gravpm, *pmpot, *oldacc_out;
 };
 
 /* NEAREST (partmanager.h:99) as d - L*rint(d/L): one multiply, one round, one fma. For
@@ -234,7 +244,7 @@ __device__ __forceinline__ void leaf_ring_drain(const double4 *__restrict__ tab,
     }
 }
 
-template <bool POT, bool PREFETCH, int LEAFB, int STATS, bool BH, bool GHOSTS = false, bool PERSIST = false, bool RING = false>
+template <bool POT, bool PREFETCH, int LEAFB, int STATS, bool BH, bool GHOSTS = false, bool PERSIST = false, bool RING = false, bool READOUT = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num_vgpr(64))) void grav_walk_exact_kernel(const WalkArgs a)
 {
     extern __shared__ double4 ring_all[]; /* RING: SHQ_LEAF_RING slots per wave */
@@ -275,7 +285,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
             px = p.x;
             py = p.y;
             pz = p.z;
-            aold = c.errtol * c.oldacc[pi];
+            if(READOUT) {
+                /* readout_potential / readout_force_{x,y,z} (gravpm.cpp:489-500) for this target, then grav_get_abs_accel
+                 * (gravshort2.hpp:111-121) with the NEW GravPM: 104 scattered loads and ~500 instructions per lane and task,
+                 * hidden behind the walks of the SIMD's other waves.  Same operations as pm_readout_kernel + oldacc_kernel. */
+                double g0 = 0, g1 = 0, g2 = 0, gp = 0;
+                pm_readout_lean(c.pm_mesh, c.pmN, c.pmzp, c.pmcell, c.pmffac, px, py, pz, !(c.pflags && (c.pflags[pi] & 2)), g0, g1, g2, gp);
+                c.gravpm[3 * pi + 0] = g0;
+                c.gravpm[3 * pi + 1] = g1;
+                c.gravpm[3 * pi + 2] = g2;
+                c.pmpot[pi] = gp;
+                const double gv[3] = {g0, g1, g2};
+                double s = 0;
+                for(int j = 0; j < 3; j++) {
+                    const double ax = c.treeacc[3 * pi + j] + gv[j];
+                    s += ax * ax;
+                }
+                const double oa = sqrt(s) / c.G;
+                c.oldacc_out[pi] = oa;
+                aold = c.errtol * oa;
+            } else
+                aold = c.errtol * c.oldacc[pi];
         }
         /* The PM's next deposit mesh is cleared here: 3.7 GB of stores spread over the walk's 34 ms (0.1 TB/s of a memory system
          * the walk leaves idle, a dozen store instructions per task beside 64 k arithmetic ones) instead of a 0.63 ms kernel of
@@ -283,8 +313,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
         if(c.scrub_per_task > 0) {
             const long long u0 = wave * c.scrub_per_task + lane;
             for(int k = 0; k < c.scrub_per_task; k += 64)
-                if(u0 + k < c.scrub_n16)
-                    c.scrub[u0 + k] = make_uint4(0u, 0u, 0u, 0u);
+                if(u0 + k < c.scrub_n16) {
+                    unsigned z = 0;
+                    asm volatile("" : "+v"(z)); /* the zeros are made here: hoisted out of the task loop they hold four registers for good */
+                    c.scrub[u0 + k] = make_uint4(z, z, z, z);
+                }
         }
     }
     double ax = 0, ay = 0, az = 0, pot = 0;
@@ -628,7 +661,12 @@ __global__ void stats_init_kernel(GravStatsDev *s)
 template <bool POT, bool PREFETCH, int LEAFB, bool BH>
 void launch_variant_bh(int stats, bool persist, dim3 grid, dim3 block, hipStream_t stream, const WalkArgs &a, size_t dyn_lds = 0)
 {
-    if(stats == 2 && POT && !PREFETCH && LEAFB == 2)
+    constexpr bool RO = !PREFETCH && LEAFB == 2 && !BH; /* the fused readout exists for the production variant only */
+    if(a.pm_mesh && RO && !stats && persist && block.x == 512)
+        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 0, BH, false, RO, RO, RO><<<grid, block, dyn_lds, stream>>>(a);
+    else if(a.pm_mesh && RO && !stats && !persist)
+        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 0, BH, false, false, false, RO><<<grid, block, 0, stream>>>(a);
+    else if(stats == 2 && POT && !PREFETCH && LEAFB == 2)
         grav_walk_exact_kernel<POT, PREFETCH, LEAFB, (POT && !PREFETCH && LEAFB == 2) ? 2 : 1, BH><<<grid, block, 0, stream>>>(a);
     else if(stats)
         grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 1, BH><<<grid, block, 0, stream>>>(a);
@@ -700,6 +738,12 @@ static void fill_walk_args(shq_context *ctx, const shq_grav_params *p, WalkArgs 
     a.scrub = nullptr;
     a.scrub_n16 = 0;
     a.scrub_per_task = 0;
+    a.pm_mesh = nullptr;
+    a.pmN = a.pmzp = 0;
+    a.pmcell = a.pmffac = a.G = 0;
+    a.treeacc = nullptr;
+    a.pflags = nullptr;
+    a.gravpm = a.pmpot = a.oldacc_out = nullptr;
     a.nwaves = 0;
     a.task_run_log2 = 7;
 }
@@ -743,6 +787,23 @@ int shq_launch_grav_walk_ghosts(shq_context *ctx, const shq_grav_params *p, cons
     }
     SHQ_HIP(hipGetLastError());
     return SHQ_OK;
+}
+
+/* Can the exact walk over these targets carry the PM readout in its prologue?  Every particle must be a target exactly once (a PM step:
+ * all time bins active), the walk must be the production instantiation with the relative criterion, and the mesh must be 32-bit
+ * addressable. */
+bool shq_walk_can_fuse_readout_pre(shq_context *ctx, const shq_grav_params *p, int64_t ntargets)
+{ /* what can be known before the PM has allocated its mesh */
+    const long long nwaves = (ntargets + 63) / 64, blocks = (nwaves + 3) / 4;
+    const bool persist = ctx->walk_persist && (ctx->walk_persist == 2 || blocks > (long long) ctx->num_cus * 8);
+    return ntargets > 0 && ntargets == ctx->numpart && ctx->numpart == ctx->nlocal && !ctx->walk_stats && ctx->walk_variant == 3 && !p->TreeUseBH &&
+           (!persist || ctx->walk_ring) && !getenv("SHQ_WALK_BLOCKS_PER_CU") && ctx->treeacc.ptr && ctx->have_tree;
+}
+
+bool shq_walk_can_fuse_readout(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets, int64_t first)
+{
+    return !d_active && first == 0 && shq_walk_can_fuse_readout_pre(ctx, p, ntargets) && ctx->mesh.ptr && ctx->mesh_words > 0 &&
+           ctx->mesh_words < (1ull << 29); /* 32-bit byte offsets */
 }
 
 int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets,
@@ -808,6 +869,10 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
         while((1u << lg) < 4u * (a.xcdK ? a.xcdK : 1u))
             lg++;
         a.task_run_log2 = lg;
+        /* (Handing the runs out longest-first, by the interaction counts of the previous walk — list scheduling on the measured task
+         * costs promises 1.002 x the ideal makespan against 1.026 x in launch order, tools/walk_task_costs.py — was built and
+         * measured: 34.3 against 34.0 ms run by run, 35.2 task by task.  Runs that follow each other in the box share their
+         * nodes in the scalar cache, and the tail is short anyway: the last waves have their SIMD to themselves.) */
         const long long wpb = ring ? 8 : 4;                                   /* waves per workgroup */
         const long long need = (nwaves + wpb - 1) / wpb, resident = (long long) ctx->num_cus * (ring ? 4 : bpc);
         launch_blocks = need < resident ? need : resident;
@@ -819,7 +884,7 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     }
     /* clear the PM mesh for the next deposit in this walk's shadow: the last shq_pm_run is through with it (same stream), nothing
      * else is known to want it (pm_keep copies what it keeps), and the walk is large enough for a task's share to be a few stores */
-    bool scrubbed = false;
+    bool scrubbed = false, swap_meshes = false;
     if(ctx->pm_scrub && !stats && variant == 3 && ctx->mesh.ptr && ctx->mesh_words > 0 && !ctx->mesh_zeroed && !ctx->pm_overlap) {
         const long long n16 = (long long) (ctx->mesh_words / 2);
         const long long per = ((n16 + nwaves - 1) / nwaves + 63) / 64 * 64;
@@ -828,6 +893,30 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
             a.scrub_n16 = n16;
             a.scrub_per_task = (int) per;
             scrubbed = true;
+        }
+    }
+    /* shq_treepm_step: the PM's readout and the OldAcc refresh ride in the task prologue (it checked that this launch can carry them) */
+    if(ctx->fuse_readout) {
+        SHQ_CHECK(shq_walk_can_fuse_readout(ctx, p, d_active, ntargets, first), SHQ_ERR_STATE, "fused readout requested for a launch that cannot carry it");
+        a.pm_mesh = ctx->mesh.ptr;
+        a.pmN = ctx->pm_nmesh;
+        a.pmzp = ctx->pm_zp;
+        a.pmcell = ctx->fuse_cell;
+        a.pmffac = ctx->fuse_ffac;
+        a.G = ctx->fuse_G;
+        a.treeacc = ctx->treeacc.ptr;
+        a.pflags = ctx->pflags.ptr;
+        a.gravpm = ctx->gravpm.ptr;
+        a.pmpot = ctx->pmpot.ptr;
+        a.oldacc_out = ctx->oldacc.ptr;
+        /* the mesh is being read: the zeros go to the second mesh, and the two change places after the launch */
+        if(scrubbed && ctx->mesh_alt.reserve(ctx->mesh_words) == SHQ_OK) {
+            a.scrub = (uint4 *) ctx->mesh_alt.ptr;
+            swap_meshes = true;
+        } else {
+            a.scrub = nullptr;
+            a.scrub_per_task = 0;
+            scrubbed = false;
         }
     }
     const dim3 grid((unsigned) launch_blocks), block(ring ? 512 : threads);
@@ -849,6 +938,10 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     }
     SHQ_HIP(hipGetLastError());
     SHQ_HIP(hipEventRecord(ctx->ev_end[SHQ_NTIMERS - 1], ctx->stream));
+    if(swap_meshes) {
+        std::swap(ctx->mesh.ptr, ctx->mesh_alt.ptr);
+        std::swap(ctx->mesh.cap, ctx->mesh_alt.cap);
+    }
     if(scrubbed)
         ctx->mesh_zeroed = true;
     return SHQ_OK;

@@ -19,33 +19,12 @@
  * All arithmetic is f64.
  */
 #include "common.hpp"
+#include "pm_readout.hpp"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
 namespace {
-
-__device__ __forceinline__ int wrapi(int i, int N) { return i >= N ? i - N : (i < 0 ? i + N : i); }
-/* x-plane index into the (possibly slab-local) mesh: global plane gx -> (gx - xshift) mod N.
- * xshift = 0 for the full periodic mesh; for a slab it is the global index of local plane 0. */
-__device__ __forceinline__ int xloc(int gx, int xshift, int N)
-{
-    int v = (gx - xshift) % N;
-    return v < 0 ? v + N : v;
-}
-
-/* CIC cell + residual: petapm.cpp:1147-1160 */
-__device__ __forceinline__ void cic_setup(double p, double cell, int N, int &ic, double &res)
-{
-    const double tmp = p / cell; /* a true divide, as petapm.cpp:1148, so cells/weights match bit for bit */
-    const double fl = floor(tmp);
-    res = tmp - fl;
-    int i = (int) fl;
-    i %= N;
-    if(i < 0)
-        i += N;
-    ic = i;
-}
 
 /* SHQ_PM_XCD_K / SHQ_PM_DEP_XCD_K: workgroups per XCD chunk of the readout / deposit block order (xcd_block; 0 = round robin) */
 static unsigned pm_xcdk(int deposit)
@@ -316,23 +295,10 @@ __global__ __launch_bounds__(256) void pm_readout_kernel(const double4 *__restri
                 g2 += w * fz;
             }
         } else {
+            auto M = [&](int dx, int dy, int dz) { return mesh[ox[2 + dx] + oy[2 + dy] + oz[2 + dz]]; };
 #pragma unroll
-            for(int c = 0; c < 8; c++) {
-                const int a = c & 1, b = (c >> 1) & 1, e = (c >> 2) & 1;
-                const double w = (a ? res[0] : 1 - res[0]) * (b ? res[1] : 1 - res[1]) * (e ? res[2] : 1 - res[2]);
-                const int X = 2 + a, Y = 2 + b, Z = 2 + e;
-                const double phi = mesh[ox[X] + oy[Y] + oz[Z]];
-                const double fx = ffac * (c1 * (mesh[ox[X + 1] + oy[Y] + oz[Z]] - mesh[ox[X - 1] + oy[Y] + oz[Z]]) -
-                                          c2 * (mesh[ox[X + 2] + oy[Y] + oz[Z]] - mesh[ox[X - 2] + oy[Y] + oz[Z]]));
-                const double fy = ffac * (c1 * (mesh[ox[X] + oy[Y + 1] + oz[Z]] - mesh[ox[X] + oy[Y - 1] + oz[Z]]) -
-                                          c2 * (mesh[ox[X] + oy[Y + 2] + oz[Z]] - mesh[ox[X] + oy[Y - 2] + oz[Z]]));
-                const double fz = ffac * (c1 * (mesh[ox[X] + oy[Y] + oz[Z + 1]] - mesh[ox[X] + oy[Y] + oz[Z - 1]]) -
-                                          c2 * (mesh[ox[X] + oy[Y] + oz[Z + 2]] - mesh[ox[X] + oy[Y] + oz[Z - 2]]));
-                gp += w * phi;
-                g0 += w * fx;
-                g1 += w * fy;
-                g2 += w * fz;
-            }
+            for(int c = 0; c < 8; c++)
+                pm_readout_corner<false>(c, res, ffac, M, g0, g1, g2, gp);
         }
     }
     gravpm[3 * i + 0] = g0;
@@ -492,7 +458,7 @@ int pm_measure_power(shq_context *ctx, int N, int zpc)
 
 } // namespace
 
-int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
+int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm, bool readout)
 {
     SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "pm: particles must be uploaded first");
     SHQ_CHECK(pm->BoxSize > 0 && pm->Asmth > 0, SHQ_ERR_INVALID, "pm params: BoxSize and Asmth must be > 0");
@@ -570,7 +536,9 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm)
         pm_repitch_kernel<<<dim3((unsigned) ((dense + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
             ctx->mesh.ptr, ctx->dbg_pot.ptr, (size_t) N * N, N, zp, N, 0, 1.0);
     }
-    if(n > 0) {
+    ctx->fuse_cell = cell;
+    ctx->fuse_ffac = -(N / pm->BoxSize);
+    if(n > 0 && readout) { /* !readout: shq_treepm_step, the tree walk's prologue reads the potential mesh */
         const double ffac = -(N / pm->BoxSize);
         pm_readout_kernel<<<dim3((unsigned) ((n + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
             ctx->posm.ptr, ctx->pflags.ptr, n, ctx->mesh.ptr, N, zp, cell, ffac, ctx->gravpm.ptr, ctx->pmpot.ptr, 0, N, ctx->pm_oob.ptr, pm_xcdk(0));

@@ -610,3 +610,59 @@ def test_pm_mesh_cleared_in_the_shadow_of_the_walk(ctx):
     assert prezeroed() == 0
     g5, p5 = pm()
     assert np.array_equal(g5, g0) and np.array_equal(p5, p0)
+
+
+def test_treepm_step_equals_the_three_separate_calls(ctx):
+    """shq_treepm_step (gravpm_force then grav_short_tree in the reference's order, run.cpp:518-563) against shq_pm_run +
+    shq_grav_refresh_oldacc + shq_grav_short_run from the same state: GravPM, PM potential, OldAcc-driven interaction counts, forces
+    and potentials bit for bit, with the readout fused into the walk's prologue and with the fusion switched off; and the walk's
+    result equals the oracle's walk from OldAcc = |FullTreeGravAccel_old + GravPM_new| / G."""
+    n, L, nmesh = 64**3, 1.0, 96
+    pos = sq.synth_positions("cluster", n, L=L)
+    pos = pos[sq.morton_order(pos, L)]
+    pman = cm.make_partmanager(pos, box=L)
+    tree = sq.force_tree_full(pman)
+    sq.set_gravshort_treepar(ErrTolForceAcc=0.005, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=0, Rcut=6.0)
+    sq.gravshort_set_softenings(L / 64)
+    gp = sq.make_grav_params(L, 1.5, nmesh, cm.G, cm.RHO0)
+    pmp = sq.PMParams(nmesh, 0, L, 1.5, cm.G)
+    rng = np.random.default_rng(11)
+    P = pman.Base
+    P["FullTreeGravAccel"] = rng.standard_normal((n, 3)) * 50.0       # "last step's" tree force
+    P["GravPM"] = rng.standard_normal((n, 3))                         # stale: must not enter OldAcc
+    pv, tv = pman.view(), tree.view()
+
+    def start():
+        capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+        capi.check(capi.hip.shq_tree_upload(ctx.h, C.byref(tv)))
+
+    def results():
+        g = np.zeros((n, 3)); pp = np.zeros(n)
+        capi.check(capi.hip.shq_pm_download(ctx.h, capi.ptr(g), capi.ptr(pp)))
+        acc = np.zeros((n, 3)); pot = np.zeros(n); nint = np.zeros(n, dtype=np.int64)
+        capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), capi.ptr(pot), capi.ptr(nint), C.byref(sq.WalkStats())))
+        return g, pp, acc, pot, nint
+
+    start()
+    capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
+    capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, gp.G))
+    capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, sq.WALK_EXACT))
+    ref = results()
+    fused = C.c_int(-1)
+    for want in (1, 0):
+        start()
+        capi.check(capi.hip.shq_treepm_set_fuse(ctx.h, want))
+        capi.check(capi.hip.shq_treepm_step(ctx.h, C.byref(pmp), C.byref(gp), 1))
+        capi.check(capi.hip.shq_treepm_last_fused(ctx.h, C.byref(fused)))
+        assert fused.value == want
+        got = results()
+        for a, b, name in zip(got, ref, ("GravPM", "PM potential", "acc", "pot", "ninteractions")):
+            assert np.array_equal(a, b), (want, name, float(np.abs(a - b).max()))
+    capi.check(capi.hip.shq_treepm_set_fuse(ctx.h, 1))
+    # the walk's opening criterion saw the NEW GravPM
+    g, _, acc, pot, nint = ref
+    oldacc = np.linalg.norm(P["FullTreeGravAccel"] + g, axis=1) / cm.G
+    o, op, on = orc.grav_walk(tree.Nodes_base, tree.firstnode, pos, P["Mass"], oldacc, gp)
+    orc.grav_postprocess(P["Mass"], gp, o, op, True)
+    assert np.array_equal(nint, on)
+    assert cm.force_err(acc, o).max() < 1e-5

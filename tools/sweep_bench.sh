@@ -9,7 +9,7 @@ for v in "$@"; do
 import json
 try:
     d=json.load(open("gpurun_out/sweep_${var}_$tag.json")); k=d["kernels"]
-    print("$var=$v step %.2f walk %.2f pm %s" % (d["ms_per_step"], k["tree_walk_ms"], {a: round(b,2) for a,b in k["pm_ms"].items()}), flush=True)
+    print("$var=$v step %.2f walk %.2f pm %s" % (d["ms_per_step"], k["tree_walk_ms"], {a: round(b,2) for a,b in k["pm_ms"].items() if not isinstance(b, str)}), flush=True)
 except Exception as e:
     print("$var=$v failed", e, flush=True)
 PY
