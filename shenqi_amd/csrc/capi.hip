@@ -658,7 +658,7 @@ extern "C" int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree)
                 g.mlen2 = g.mass * g.len * g.len; /* (mass * len) * len, as shall_we_open_node evaluates it */
                 g.inside = 0.6 * g.len;
                 g.rcut2 = 0;
-                g.wraplim = 0.5 * tree->BoxSize - 0.5 * g.len;
+                g.wraplim = std::max(0.5 * tree->BoxSize - 0.5 * g.len, 0.0);
                 hG[k] = g;
                 hH[k] = sn.hmax;
             }

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
         asm volatile("" : "+s"(wl_hi)); /* a 32-bit scalar compare (left alone the compiler widens it to a 64-bit VECTOR compare) */
         if(wl_hi >= 0) { /* not an interior node (fill_rcuthl_kernel): the wrap may matter */
             asm volatile("" ::: "memory");
-            wrapm = shq_ballot(cmax > nd.wraplim) & actm;
+            wrapm = shq_ballot(cmax >= nd.wraplim) & actm; /* >=: a zero limit (the root) means always; wrapping at equality is the identity */
             if(wrapm != 0ull) {
                 dx = wrapd(dx, a.Box, a.invBox);
                 dy = wrapd(dy, a.Box, a.invBox);
@@ -635,7 +635,9 @@ __global__ void fill_rcuthl_kernel(NodeG *g, long long n, double rcut, double bh
         double M = Box;
         for(int k = 0; k < 3; k++)
             M = fmin(M, fmin(g[i].center[k] - hl, Box - (g[i].center[k] + hl)));
-        const double wl = 0.5 * Box - hl;
+        /* the root's side is 1.001 Box (forcetree.cpp): its limit would be negative — "always wrap" — and must not read as the
+         * interior flag: zero says the same (the vote below is cmax >= wraplim) */
+        const double wl = fmax(0.5 * Box - hl, 0.0);
         g[i].wraplim = (len > 0 && wl > 0 && M >= rcut + 1.5 * len) ? -wl : wl;
     }
 }

@@ -435,7 +435,7 @@ __global__ void tb_pack_kernel(int nn, const int32_t *__restrict__ order, const 
     g.mlen2 = g.mass * g.len * g.len; /* (mass * len) * len, as shall_we_open_node evaluates it */
     g.inside = 0.6 * g.len;
     g.rcut2 = 0;
-    g.wraplim = 0.5 * Box - 0.5 * g.len;
+    g.wraplim = fmax(0.5 * Box - 0.5 * g.len, 0.0); /* the root (1.001 Box): zero = always wrap; fill_rcuthl_kernel adds the interior flag */
     G[r] = g;
 }
 
