@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void pm_readout_kernel(const double4 *__restri
             auto M = [&](int dx, int dy, int dz) { return mesh[ox[2 + dx] + oy[2 + dy] + oz[2 + dz]]; };
 #pragma unroll
             for(int c = 0; c < 8; c++)
-                pm_readout_corner<false>(c, res, ffac, M, g0, g1, g2, gp);
+                pm_readout_corner<0>(c, res, ffac, M, g0, g1, g2, gp);
         }
     }
     gravpm[3 * i + 0] = g0;

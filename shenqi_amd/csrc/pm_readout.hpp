@@ -3,6 +3,9 @@
  * tree walk's task prologue (grav_walk.hip, shq_treepm_step), so that both produce the same bits. */
 #pragma once
 #include "common.hpp"
+#ifndef SHQ_READOUT_FENCE
+#define SHQ_READOUT_FENCE 1 /* load grouping of the lean readout's common path, see pm_readout_corner: 2 (a stencil at a time, 64 VGPRs) measured no faster than 1 (62) */
+#endif
 
 __device__ __forceinline__ int wrapi(int i, int N) { return i >= N ? i - N : (i < 0 ? i + N : i); }
 /* x-plane index into the (possibly slab-local) mesh: global plane gx -> (gx - xshift) mod N.
@@ -29,9 +32,9 @@ __device__ __forceinline__ void cic_setup(double p, double cell, int N, int &ic,
 /* One corner c = (a, b, e) of the CIC cube: weight, potential and the three differenced force components, accumulated in the
  * order c = 0..7 — THE operation order of the readout (pm_readout_kernel's paired-load path fetches the same values and applies
  * the same operations).  M(dx, dy, dz) returns the mesh value at cell offsets (dx, dy, dz) in -2..3 from the particle's base cell.
- * FENCE: the loads are kept apart (two in flight instead of thirteen) for callers on a register budget; the arithmetic is the
- * same. */
-template <bool FENCE, typename MeshAt>
+ * FENCE: the loads are kept apart for callers on a register budget (1: two in flight; 2: a stencil's four — with the potential,
+ * five — instead of thirteen); the arithmetic is the same. */
+template <int FENCE, typename MeshAt>
 __device__ __forceinline__ void pm_readout_corner(int c, const double res[3], double ffac, MeshAt M, double &g0, double &g1, double &g2,
                                                   double &gp)
 {
@@ -45,15 +48,15 @@ __device__ __forceinline__ void pm_readout_corner(int c, const double res[3], do
 #define SHQ_PM_DIFF(P1, M1, P2, M2)                                \
     [&]() {                                                        \
         double d1 = (P1) - (M1);                                   \
-        if(FENCE)                                                  \
+        if(FENCE == 1)                                             \
             asm volatile("" : "+v"(d1)::"memory");                 \
         double d2 = (P2) - (M2);                                   \
         if(FENCE)                                                  \
-            asm volatile("" : "+v"(d2)::"memory");                 \
+            asm volatile("" : "+v"(d1), "+v"(d2)::"memory");       \
         return ffac * (c1 * d1 - c2 * d2);                         \
     }()
     double phi = M(a, b, e);
-    if(FENCE)
+    if(FENCE == 1)
         asm volatile("" : "+v"(phi)::"memory");
     const double fz = SHQ_PM_DIFF(M(a, b, e + 1), M(a, b, e - 1), M(a, b, e + 2), M(a, b, e - 2));
     const double fx = SHQ_PM_DIFF(M(a + 1, b, e), M(a - 1, b, e), M(a + 2, b, e), M(a - 2, b, e));
@@ -101,7 +104,7 @@ __device__ __forceinline__ void pm_readout_lean(const double *__restrict__ mesh,
                     asm volatile("" : "+s"(sb)); /* pinned in scalar registers: otherwise the offsets are re-associated into vector registers */
                     return *reinterpret_cast<const __attribute__((address_space(1))) double *>(sb + vb);
                 };
-                pm_readout_corner<true>(c, res, ffac, M, g0, g1, g2, gp);
+                pm_readout_corner<SHQ_READOUT_FENCE>(c, res, ffac, M, g0, g1, g2, gp);
             }
         }
     } else if(live) {
@@ -112,7 +115,7 @@ __device__ __forceinline__ void pm_readout_lean(const double *__restrict__ mesh,
                 const unsigned o = (unsigned) wrapi(ic[0] + dx, N) * sx + (unsigned) wrapi(ic[1] + dy, N) * sy + (unsigned) wrapi(ic[2] + dz, N);
                 return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(mesh) + (o << 3));
             };
-            pm_readout_corner<true>(c, res, ffac, M, g0, g1, g2, gp);
+            pm_readout_corner<1>(c, res, ffac, M, g0, g1, g2, gp);
         }
     }
 }
