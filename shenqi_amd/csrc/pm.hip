@@ -51,8 +51,12 @@ __global__ void pm_zero_kernel(unsigned long long *mesh, size_t n)
  * particles per cell) this removes almost all global atomics and all same-address contention;
  * sparse chunks whose footprint does not fit fall back to direct global atomics.  Integer adds
  * commute, so both routes give bit-identical meshes. */
+#ifndef DEP_T
 #define DEP_T 16
+#endif
+#ifndef DEP_PPT
 #define DEP_PPT 2
+#endif
 #define DEP_CHUNK (256 * DEP_PPT)
 
 __global__ __launch_bounds__(256) void pm_deposit_kernel(const double4 *__restrict__ posm, const uint8_t *__restrict__ pflags,
@@ -108,7 +112,10 @@ __global__ __launch_bounds__(256) void pm_deposit_kernel(const double4 *__restri
     const bool fits = (s_max[0] - m0 + 2 <= DEP_T) && (s_max[1] - m1 + 2 <= DEP_T) && (s_max[2] - m2 + 2 <= DEP_T);
     const size_t sy = (size_t) zp, sx = (size_t) N * zp;
     if(fits) {
-        for(int c = tid; c < DEP_T * DEP_T * DEP_T; c += 256)
+        /* the tile is the chunk's own footprint, ey x ez x ex cells (a dense clump covers a few dozen cells: clearing and flushing
+         * all DEP_T^3 slots for it was most of the kernel's LDS traffic) */
+        const int ey = s_max[1] - m1 + 2, ez = s_max[2] - m2 + 2, vol = (s_max[0] - m0 + 2) * ey * ez;
+        for(int c = tid; c < vol; c += 256)
             tile[c] = 0ull;
         __syncthreads();
 #pragma unroll
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(256) void pm_deposit_kernel(const double4 *__restri
                 for(int k = 0; k < 3; k++) {
                     const int off = (c >> k) & 1;
                     const int t = ic[j][k] - (k == 0 ? m0 : (k == 1 ? m1 : m2)) + off;
-                    lin = lin * DEP_T + t;
+                    lin = lin * (k == 0 ? 1 : (k == 1 ? ey : ez)) + t;
                     w *= off ? res[j][k] : (1 - res[j][k]);
                 }
                 const long long q = __double2ll_rn(w * mass[j] * scale);
@@ -131,10 +138,10 @@ __global__ __launch_bounds__(256) void pm_deposit_kernel(const double4 *__restri
             }
         }
         __syncthreads();
-        for(int c = tid; c < DEP_T * DEP_T * DEP_T; c += 256) {
+        for(int c = tid; c < vol; c += 256) {
             const unsigned long long v = tile[c];
             if(v != 0ull) {
-                const int tz = c % DEP_T, ty = (c / DEP_T) % DEP_T, tx = c / (DEP_T * DEP_T);
+                const int tz = c % ez, ty = (c / ez) % ey, tx = c / (ez * ey);
                 const int lx = xloc(m0 + tx, xshift, N);
                 if(lx >= nxalloc) {
                     *oob = 1; /* a particle outside this rank's slab: refuse to write out of bounds */
@@ -145,10 +152,17 @@ __global__ __launch_bounds__(256) void pm_deposit_kernel(const double4 *__restri
             }
         }
     } else {
+        /* Direct global atomics — but a global atomic is one 64-byte request to the memory side whatever it carries (the chip
+         * completes ~24 G of them per second: this path, the sparse background of the box, is what the kernel's time is made of),
+         * and two lanes of one instruction whose cells share 64 bytes share the request.  The cells z and z + 1 of a CIC column are
+         * neighbours in memory, so lane pairs take them: every lane forms its particle's eight (cell, value) entries, the wave
+         * trades them through LDS (the tile is idle on this path), and instruction k hands the pair (2 p, 2 p + 1) the two z cells
+         * of column k & 3 of particle p + 32 (k >> 2).  8 requests per particle become ~4.5.  Integer adds: the mesh does not care. */
+        static_assert(DEP_T * DEP_T * DEP_T >= 4 * 8 * 64 * 2, "the staging area is the LDS tile");
+        ulonglong2 *const stg = reinterpret_cast<ulonglong2 *>(tile) + (tid >> 6) * (8 * 64);
+        const int lane = tid & 63;
 #pragma unroll
         for(int j = 0; j < DEP_PPT; j++) {
-            if(!ok[j])
-                continue;
 #pragma unroll
             for(int c = 0; c < 8; c++) {
                 double w = 1.0;
@@ -164,11 +178,23 @@ __global__ __launch_bounds__(256) void pm_deposit_kernel(const double4 *__restri
                     w *= off ? res[j][k] : (1 - res[j][k]);
                 }
                 const long long q = __double2ll_rn(w * mass[j] * scale);
-                if(inb)
-                    atomicAdd(&mesh[lin], (unsigned long long) q);
-                else
+                if(ok[j] && !inb)
                     *oob = 1;
+                /* slot = column (x, y offsets) * 2 + z offset */
+                stg[((c & 3) * 2 + (c >> 2)) * 64 + lane] = make_ulonglong2(ok[j] && inb ? (unsigned long long) lin : ~0ull, (unsigned long long) q);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for(int k = 0; k < 8; k++) {
+                const ulonglong2 e = stg[((k & 3) * 2 + (lane & 1)) * 64 + (lane >> 1) + 32 * (k >> 2)];
+                if(e.x != ~0ull)
+                    atomicAdd(&mesh[e.x], e.y);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }
