@@ -727,7 +727,7 @@ def main():
         if one_call is None:
             one_call = not args.separate_calls and args.walk_mode == 0
         if one_call:
-            capi.check(capi.hip.shq_treepm_step(ctx.h, C.byref(pmp), C.byref(gp), 1))
+            capi.check(capi.hip.shq_treepm_step(ctx.h, C.byref(pmp), C.byref(gp), 1, sq.WALK_EXACT))
         else:
             capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
             capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, G))
@@ -924,10 +924,13 @@ def main():
                 t0 = time.perf_counter()
             sq.drift(ctx, 1e-4 * L / n1, L)
             sq.tree_build_device(ctx, L)
-            capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
             # targets in tree order: the particle index order goes stale as the particles move
-            capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp_rel), None, 0, 0, args.walk_mode | sq.WALK_TREE_ORDER))
-            capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, G))
+            if args.separate_calls or args.walk_mode != 0:
+                capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
+                capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, G))
+                capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp_rel), None, 0, 0, args.walk_mode | sq.WALK_TREE_ORDER))
+            else:
+                capi.check(capi.hip.shq_treepm_step(ctx.h, C.byref(pmp), C.byref(gp_rel), 0, sq.WALK_EXACT | sq.WALK_TREE_ORDER))
             sq.kick_short(ctx, gk, from_accel_store=True)
             sq.kick_pm(ctx, 1e-24)
         ctx.synchronize()

@@ -566,7 +566,7 @@ hip.shq_grav_short_tree.argtypes = [_vp, C.POINTER(TreeView), C.POINTER(PartView
 hip.shq_pm_force.argtypes = [_vp, C.POINTER(PMParams), C.POINTER(PartView), _vp, _vp]
 hip.shq_pm_run.argtypes = [_vp, C.POINTER(PMParams)]
 hip.shq_pm_download.argtypes = [_vp, _vp, _vp]
-hip.shq_treepm_step.argtypes = [_vp, C.POINTER(PMParams), C.POINTER(GravParams), C.c_int]
+hip.shq_treepm_step.argtypes = [_vp, C.POINTER(PMParams), C.POINTER(GravParams), C.c_int, C.c_int]
 hip.shq_treepm_last_fused.argtypes = [_vp, C.POINTER(C.c_int)]
 hip.shq_treepm_set_fuse.argtypes = [_vp, C.c_int]
 hip.shq_pm_phase_ms.argtypes = [_vp, C.POINTER(C.c_double * 6)]

@@ -1157,13 +1157,20 @@ extern "C" int shq_pm_run(shq_context *ctx, const shq_pm_params *pm)
  * refresh happen in the prologue of the walk's tasks, target by target, where their scattered loads hide behind the arithmetic
  * of the other waves (the walk leaves the memory system idle).  Falls back to the three separate launches when the walk at hand
  * cannot carry them (Barnes-Hut seeding walk, diagnostic counters, a mesh beyond 2^32 cells, ...).  Same bits either way. */
-extern "C" int shq_treepm_step(shq_context *ctx, const shq_pm_params *pm, const shq_grav_params *params, int update_potential)
+extern "C" int shq_treepm_step(shq_context *ctx, const shq_pm_params *pm, const shq_grav_params *params, int update_potential, int walk_mode)
 {
     SHQ_CHECK(ctx && pm && params, SHQ_ERR_INVALID, "null argument");
     SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "treepm_step: upload particles and tree first");
+    SHQ_CHECK((walk_mode & ~SHQ_WALK_TREE_ORDER) == SHQ_WALK_EXACT, SHQ_ERR_INVALID, "treepm_step: walk_mode is SHQ_WALK_EXACT, optionally | SHQ_WALK_TREE_ORDER");
     SHQ_HIP(hipSetDevice(ctx->device));
     SHQ_TRY(shq_join_pm(ctx));
-    const int64_t n = ctx->nlocal;
+    int64_t n = ctx->nlocal;
+    const int32_t *d_targets = nullptr;
+    if(walk_mode & SHQ_WALK_TREE_ORDER) { /* every own particle of the tree, in leaf order */
+        SHQ_TRY(shq_build_tree_targets(ctx));
+        d_targets = ctx->tree_targets.ptr;
+        n = ctx->ntree_targets;
+    }
     const bool fuse = !ctx->pm_overlap && ctx->treepm_fuse && pm->Nmesh >= 4 &&
                       (size_t) pm->Nmesh * pm->Nmesh * (size_t) (pm->Nmesh + 10) < (1ull << 29) &&
                       shq_walk_can_fuse_readout_pre(ctx, params, n);
@@ -1174,10 +1181,10 @@ extern "C" int shq_treepm_step(shq_context *ctx, const shq_pm_params *pm, const 
         ctx->fuse_G = params->G;
         ctx->fuse_readout = true;
     }
-    const int rc = shq_launch_grav_walk(ctx, params, nullptr, n, update_potential, SHQ_WALK_EXACT);
+    const int rc = shq_launch_grav_walk(ctx, params, d_targets, n, update_potential, SHQ_WALK_EXACT);
     ctx->fuse_readout = false;
     SHQ_TRY(rc);
-    SHQ_TRY(shq_launch_grav_postprocess(ctx, params, nullptr, n, update_potential));
+    SHQ_TRY(shq_launch_grav_postprocess(ctx, params, d_targets, n, update_potential));
     ctx->grav_raw = false;
     ctx->last_stats.ntargets = n;
     ctx->last_step_fused = fuse;

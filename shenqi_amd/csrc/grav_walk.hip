@@ -804,7 +804,8 @@ bool shq_walk_can_fuse_readout_pre(shq_context *ctx, const shq_grav_params *p, i
 
 bool shq_walk_can_fuse_readout(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets, int64_t first)
 {
-    return !d_active && first == 0 && shq_walk_can_fuse_readout_pre(ctx, p, ntargets) && ctx->mesh.ptr && ctx->mesh_words > 0 &&
+    /* targets: every particle once — no list, or the library's own list of all the tree's particles in leaf order */
+    return (!d_active || d_active == ctx->tree_targets.ptr) && first == 0 && shq_walk_can_fuse_readout_pre(ctx, p, ntargets) && ctx->mesh.ptr && ctx->mesh_words > 0 &&
            ctx->mesh_words < (1ull << 29); /* 32-bit byte offsets */
 }
 

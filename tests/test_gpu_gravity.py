@@ -652,13 +652,26 @@ def test_treepm_step_equals_the_three_separate_calls(ctx):
     for want in (1, 0):
         start()
         capi.check(capi.hip.shq_treepm_set_fuse(ctx.h, want))
-        capi.check(capi.hip.shq_treepm_step(ctx.h, C.byref(pmp), C.byref(gp), 1))
+        capi.check(capi.hip.shq_treepm_step(ctx.h, C.byref(pmp), C.byref(gp), 1, sq.WALK_EXACT))
         capi.check(capi.hip.shq_treepm_last_fused(ctx.h, C.byref(fused)))
         assert fused.value == want
         got = results()
         for a, b, name in zip(got, ref, ("GravPM", "PM potential", "acc", "pot", "ninteractions")):
             assert np.array_equal(a, b), (want, name, float(np.abs(a - b).max()))
     capi.check(capi.hip.shq_treepm_set_fuse(ctx.h, 1))
+    # the same with the targets taken in tree (leaf) order, as a moving-particle step does
+    start()
+    capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
+    capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, gp.G))
+    capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, sq.WALK_EXACT | sq.WALK_TREE_ORDER))
+    ref_t = results()
+    start()
+    capi.check(capi.hip.shq_treepm_step(ctx.h, C.byref(pmp), C.byref(gp), 1, sq.WALK_EXACT | sq.WALK_TREE_ORDER))
+    capi.check(capi.hip.shq_treepm_last_fused(ctx.h, C.byref(fused)))
+    assert fused.value == 1
+    for a, b, name in zip(results(), ref_t, ("GravPM", "PM potential", "acc", "pot", "ninteractions")):
+        assert np.array_equal(a, b), ("tree order", name, float(np.abs(a - b).max()))
+    assert np.array_equal(ref_t[0], ref[0]) and np.array_equal(ref_t[4], ref[4])
     # the walk's opening criterion saw the NEW GravPM
     g, _, acc, pot, nint = ref
     oldacc = np.linalg.norm(P["FullTreeGravAccel"] + g, axis=1) / cm.G
