@@ -34,6 +34,18 @@ namespace {
 #ifndef FFT_T
 #define FFT_T 256      /* threads per workgroup */
 #endif
+/* Element i of a line sits at LDS slot lx(i) = i + i / 16 (SHQ_FFT_PAD): the first radix-16 stage writes its outputs 16 elements
+ * apart — 256 bytes, two full sweeps of the 32 store banks, so the eight lanes a ds_write_b128 serves per cycle all meet in the same
+ * banks.  With one slot of padding per 16 elements consecutive lanes land 272 bytes apart, 16 bytes further along the banks each.
+ * (SQ_LDS_BANK_CONFLICT was 60 % of SQ_LDS_IDX_ACTIVE.)  The stages split every index into a per-thread part and a compile-time
+ * part without a carry between them, so that lx(t + c) = lx(t) + lx(c) and the sixteen accesses of a butterfly stay base register +
+ * immediate offset (with lx(t + c) computed per access the passes need 244-269 VGPRs and lose a workgroup per CU).  The line stride
+ * stays = 1 (mod 8) slots, which keeps the tile's transposed landing and leaving as they were. */
+#ifndef SHQ_FFT_PAD
+#define SHQ_FFT_PAD 1
+#endif
+__host__ __device__ constexpr int lx(int i) { return SHQ_FFT_PAD ? i + (i >> 4) : i; }
+__host__ __device__ constexpr int fft_ls(int N) { return lx(N - 1) + 1 + (9 - (lx(N - 1) + 1) % 8) % 8; }
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
@@ -112,7 +124,7 @@ struct NoLoadOp {
 template <int N, int n, int s, int R, int DIR, typename StoreOp = NoLoadOp>
 __device__ __forceinline__ void fft_stage(double2 *buf, const double2 *__restrict__ W, const StoreOp op = StoreOp())
 {
-    constexpr int LS = N + 1;
+    constexpr int LS = fft_ls(N);
     constexpr int m = n / R;
     constexpr int nb = N / R;               /* butterflies per line */
     constexpr int total = FFT_C * nb;
@@ -124,10 +136,11 @@ __device__ __forceinline__ void fft_stage(double2 *buf, const double2 *__restric
         if(i < total) {
             const int line = i / nb, b = i - line * nb;
             const int p = b / s, q = b - p * s;
-            const double2 *x = buf + line * LS + q + s * p;
+            /* s m j is a multiple of 16 in every stage of the 16 16 3 / 16 16 ... sequences: no carry into the padding term */
+            const double2 *x = buf + line * LS + ((s * m) % 16 == 0 ? lx(q + s * p) : 0);
 #pragma unroll
             for(int j = 0; j < R; j++)
-                v[kk][j] = x[s * m * j];
+                v[kk][j] = x[(s * m) % 16 == 0 ? lx(s * m * j) : lx(q + s * p + s * m * j)];
             if(R == 2) {
                 const double2 a0 = v[kk][0], a1 = v[kk][1];
                 v[kk][0] = cadd(a0, a1);
@@ -179,10 +192,12 @@ __device__ __forceinline__ void fft_stage(double2 *buf, const double2 *__restric
         if(i < total) {
             const int line = i / nb, b = i - line * nb;
             const int p = b / s, q = b - p * s;
-            double2 *y = buf + line * LS + q + s * R * p;
+            /* s k is a multiple of 16 (s % 16 == 0), or q + s k stays below 16 under a thread part that is a multiple of 16 */
+            constexpr bool SPLIT = s % 16 == 0 || ((s * R) % 16 == 0 && s * R <= 16);
+            double2 *y = buf + line * LS + (SPLIT ? lx(s % 16 == 0 ? q + s * R * p : s * R * p) : 0);
 #pragma unroll
             for(int k = 0; k < R; k++)
-                y[s * k] = op(line, q + s * R * p + s * k, v[kk][k]);
+                y[SPLIT ? (s % 16 == 0 ? lx(s * k) : q + s * k) : lx(q + s * R * p + s * k)] = op(line, q + s * R * p + s * k, v[kk][k]);
         }
     }
     __syncthreads();
@@ -219,7 +234,7 @@ __device__ __forceinline__ void fft_lines(double2 *buf, const double2 *__restric
  * the loads, which keeps the loop-carried registers free of copies (and of an early s_waitcnt). */
 template <int N> __device__ __forceinline__ double2 *lds_twiddles(double2 *buf, const double2 *__restrict__ W)
 {
-    double2 *Wl = buf + FFT_C * (N + 1);
+    double2 *Wl = buf + FFT_C * fft_ls(N);
     for(int i = threadIdx.x; i < N; i += FFT_T)
         Wl[i] = W[i];
     return Wl;
@@ -232,7 +247,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_fwd(double *mesh, const int 
                                                         const double2 *__restrict__ W, const double inv_scale)
 {
     extern __shared__ double2 buf[];
-    constexpr int LS = N + 1, H = N / 2, Nc = N / 2 + 1;
+    constexpr int LS = fft_ls(N), H = N / 2, Nc = N / 2 + 1;
     constexpr int E = (FFT_C * N + FFT_T - 1) / FFT_T; /* 16-byte pairs per thread: 2 FFT_C rows of N/2 pairs */
     constexpr bool EXACT = E * FFT_T == FFT_C * N;
     double2 *Wl = lds_twiddles<N>(buf, W);
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_fwd(double *mesh, const int 
                     a = (double) __double_as_longlong(a) * inv_scale;
                     b = (double) __double_as_longlong(b) * inv_scale;
                 }
-                double *dst = reinterpret_cast<double *>(buf + (r >> 1) * LS + z) + (r & 1);
+                double *dst = reinterpret_cast<double *>(buf + (r >> 1) * LS + lx(z)) + (r & 1); /* z even: lx(z + 1) = lx(z) + 1 */
                 dst[0] = a;
                 dst[2] = b;
             }
@@ -280,8 +295,8 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_fwd(double *mesh, const int 
         const long long row0 = (long long) t * (2 * FFT_C);
         for(int e = threadIdx.x; e < FFT_C * Nc; e += FFT_T) {
             const int l = e / Nc, k = e - l * Nc;
-            const double2 zk = buf[l * LS + k];
-            const double2 zn = conj2(buf[l * LS + (k == 0 ? 0 : N - k)]);
+            const double2 zk = buf[l * LS + lx(k)];
+            const double2 zn = conj2(buf[l * LS + lx(k == 0 ? 0 : N - k)]);
             const double2 xa = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y + zn.y));
             const double2 d = make_double2(0.5 * (zk.x - zn.x), 0.5 * (zk.y - zn.y));
             const double2 xb = make_double2(d.y, -d.x);
@@ -302,7 +317,7 @@ template <int N>
 __global__ __launch_bounds__(FFT_T) void fft_pass_z_inv(double *mesh, const int ntot, const int zp, const double2 *__restrict__ W)
 {
     extern __shared__ double2 buf[];
-    constexpr int LS = N + 1, H = N / 2, Nc = N / 2 + 1;
+    constexpr int LS = fft_ls(N), H = N / 2, Nc = N / 2 + 1;
     constexpr int E = (FFT_C * Nc + FFT_T - 1) / FFT_T;
     double2 *Wl = lds_twiddles<N>(buf, W);
     double2 *cm = reinterpret_cast<double2 *>(mesh);
@@ -338,9 +353,9 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_inv(double *mesh, const int 
                     xb.y = 0;
                 }
                 /* Z[k] = XA[k] + i XB[k];  Z[N-k] = conj(XA[k]) + i conj(XB[k]) */
-                buf[l * LS + k] = make_double2(xa.x - xb.y, xa.y + xb.x);
+                buf[l * LS + lx(k)] = make_double2(xa.x - xb.y, xa.y + xb.x);
                 if(k > 0 && 2 * k < N)
-                    buf[l * LS + N - k] = make_double2(xa.x + xb.y, -xa.y + xb.x);
+                    buf[l * LS + lx(N - k)] = make_double2(xa.x + xb.y, -xa.y + xb.x);
             }
         }
         __syncthreads();
@@ -352,7 +367,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_inv(double *mesh, const int 
         const long long row0 = (long long) t * (2 * FFT_C);
         for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T) {
             const int r = e / H, z = 2 * (e % H);
-            const double *src = reinterpret_cast<const double *>(buf + (r >> 1) * LS + z) + (r & 1);
+            const double *src = reinterpret_cast<const double *>(buf + (r >> 1) * LS + lx(z)) + (r & 1);
             cm[(row0 + r) * zpc + (z >> 1)] = make_double2(src[0], src[2]);
         }
         if(!more)
@@ -383,7 +398,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
                                                           const GreenArgs ga, const unsigned xcdk, const int tile0 = 0)
 {
     extern __shared__ double2 buf[];
-    constexpr int LS = N + 1;
+    constexpr int LS = fft_ls(N);
     constexpr int E = (FFT_C * N + FFT_T - 1) / FFT_T; /* tile elements per thread */
     constexpr bool EXACT = E * FFT_T == FFT_C * N;
     double2 *Wl = lds_twiddles<N>(buf, W);
@@ -424,7 +439,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
         for(int i = 0; i < E; i++) {
             const int e = threadIdx.x + i * FFT_T;
             if(EXACT || e < FFT_C * N)
-                buf[(e % FFT_C) * LS + e / FFT_C] = make_double2(prx[i], pry[i]);
+                buf[(e % FFT_C) * LS + lx(e / FFT_C)] = make_double2(prx[i], pry[i]);
         }
         __syncthreads();
         const int tn = t + (int) gridDim.x;
@@ -457,9 +472,9 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
         for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T) {
             const int row = e / FFT_C, col = e - row * FFT_C;
             if(PK == 1)
-                abase[(long long) (row / ga.nyl) * ga.qstride + (long long) (row % ga.nyl) * es + col] = buf[col * LS + row];
+                abase[(long long) (row / ga.nyl) * ga.qstride + (long long) (row % ga.nyl) * es + col] = buf[col * LS + lx(row)];
             else
-                base[(long long) row * es + col] = buf[col * LS + row];
+                base[(long long) row * es + col] = buf[col * LS + lx(row)];
         }
         if(!more)
             break;
@@ -481,7 +496,7 @@ int run_n(shq_context *ctx, double *d_mesh, int zp, int stage, bool from_i64, do
 {
     const double2 *W = reinterpret_cast<const double2 *>(ctx->fft_tw.ptr);
     /* FFT_C padded lines + the twiddle table + (X pass) the sinc table */
-    constexpr size_t lds = sizeof(double2) * (FFT_C * (N + 1) + N) + sizeof(double) * N;
+    constexpr size_t lds = sizeof(double2) * (FFT_C * fft_ls(N) + N) + sizeof(double) * N;
 #ifndef SHQ_FFT_RELAX /* tile-shape experiments on one mesh size */
     static_assert(N % (2 * FFT_C) == 0, "rows must tile evenly");
 #endif
