@@ -679,3 +679,49 @@ def test_treepm_step_equals_the_three_separate_calls(ctx):
     orc.grav_postprocess(P["Mass"], gp, o, op, True)
     assert np.array_equal(nint, on)
     assert cm.force_err(acc, o).max() < 1e-5
+
+
+def test_treepm_step_ragged_boundary_and_swallowed(ctx):
+    """The one-call step on a set whose size is no multiple of 64, spread over the whole box (waves with particles next to the faces
+    take the readout's wrapped path) and holding swallowed black holes (no deposit, no readout: GravPM = 0, gravpm.cpp:176-178):
+    bit-identical to the separate calls."""
+    n = 5003
+    pos = cm.random_positions(orc.boost_mt19937_uniform(9, 3 * n), n)
+    pos[:40] *= 1e-3                                       # a few particles in the corner cell and on the faces
+    pos[40:80, 0] = cm.BOX * (1 - 1e-9)
+    pman = cm.make_partmanager(pos)
+    P = pman.Base
+    rng = np.random.default_rng(3)
+    bh = rng.choice(n, size=50, replace=False)
+    P["Type"][bh] = 5
+    P["Flags"][bh[::2]] |= 2
+    P["FullTreeGravAccel"] = rng.standard_normal((n, 3)) * 5.0
+    tree = sq.force_tree_full(pman)
+    cm.reference_treepar(ErrTolForceAcc=0.002, MaxBHOpeningAngle=0.9, TreeUseBH=0)
+    sq.gravshort_set_softenings(cm.BOX / 17)
+    gp = sq.make_grav_params(cm.BOX, 1.5, 48, cm.G, cm.RHO0)
+    pmp = sq.PMParams(48, 0, cm.BOX, 1.5, cm.G)
+    pv, tv = pman.view(), tree.view()
+
+    def run(one_call):
+        capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+        capi.check(capi.hip.shq_tree_upload(ctx.h, C.byref(tv)))
+        if one_call:
+            capi.check(capi.hip.shq_treepm_step(ctx.h, C.byref(pmp), C.byref(gp), 1, sq.WALK_EXACT))
+            f = C.c_int(0)
+            capi.check(capi.hip.shq_treepm_last_fused(ctx.h, C.byref(f)))
+            assert f.value == 1
+        else:
+            capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
+            capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, gp.G))
+            capi.check(capi.hip.shq_grav_short_run(ctx.h, C.byref(gp), None, 0, 1, sq.WALK_EXACT))
+        g = np.zeros((n, 3)); pp = np.zeros(n)
+        capi.check(capi.hip.shq_pm_download(ctx.h, capi.ptr(g), capi.ptr(pp)))
+        acc = np.zeros((n, 3)); pot = np.zeros(n); nint = np.zeros(n, dtype=np.int64)
+        capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), capi.ptr(pot), capi.ptr(nint), C.byref(sq.WalkStats())))
+        return g, pp, acc, pot, nint
+
+    ref, got = run(False), run(True)
+    for a, b, name in zip(got, ref, ("GravPM", "PM potential", "acc", "pot", "ninteractions")):
+        assert np.array_equal(a, b), (name, float(np.abs(a - b).max()))
+    assert np.all(ref[0][bh[::2]] == 0) and np.abs(ref[0]).max() > 0
