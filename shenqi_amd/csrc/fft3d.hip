@@ -44,8 +44,29 @@ namespace {
 #ifndef SHQ_FFT_PAD
 #define SHQ_FFT_PAD 1
 #endif
-__host__ __device__ constexpr int lx(int i) { return SHQ_FFT_PAD ? i + (i >> 4) : i; }
-__host__ __device__ constexpr int fft_ls(int N) { return lx(N - 1) + 1 + (9 - (lx(N - 1) + 1) % 8) % 8; }
+/* the padding is used for the mesh sizes whose every stage splits that way (768 = 16 16 3, 1024 = 16 16 4, 1536 = 16 16 2 3, ...); the
+ * others (384 = 16 4 2 3, 960 = 16 4 3 5, ...) keep the plain layout */
+__host__ __device__ constexpr int fft_radix(int n) { return n % 16 == 0 ? 16 : (n % 4 == 0 ? 4 : (n % 2 == 0 ? 2 : (n % 3 == 0 ? 3 : 5))); }
+__host__ __device__ constexpr bool fft_pad_ok(int N)
+{
+    if(!SHQ_FFT_PAD)
+        return false;
+    int n = N, s = 1;
+    while(n > 1) {
+        const int R = fft_radix(n), m = n / R;
+        if((s * m) % 16 != 0 || !(s % 16 == 0 || ((s * R) % 16 == 0 && s * R <= 16)))
+            return false;
+        n = m;
+        s *= R;
+    }
+    return true;
+}
+template <int N> __host__ __device__ constexpr int lx(int i) { return fft_pad_ok(N) ? i + (i >> 4) : i; }
+__host__ __device__ constexpr int fft_ls(int N)
+{
+    const int last = fft_pad_ok(N) ? (N - 1) + ((N - 1) >> 4) : N - 1;
+    return last + 1 + (9 - (last + 1) % 8) % 8;
+}
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
@@ -137,10 +158,10 @@ __device__ __forceinline__ void fft_stage(double2 *buf, const double2 *__restric
             const int line = i / nb, b = i - line * nb;
             const int p = b / s, q = b - p * s;
             /* s m j is a multiple of 16 in every stage of the 16 16 3 / 16 16 ... sequences: no carry into the padding term */
-            const double2 *x = buf + line * LS + ((s * m) % 16 == 0 ? lx(q + s * p) : 0);
+            const double2 *x = buf + line * LS + ((s * m) % 16 == 0 ? lx<N>(q + s * p) : 0);
 #pragma unroll
             for(int j = 0; j < R; j++)
-                v[kk][j] = x[(s * m) % 16 == 0 ? lx(s * m * j) : lx(q + s * p + s * m * j)];
+                v[kk][j] = x[(s * m) % 16 == 0 ? lx<N>(s * m * j) : lx<N>(q + s * p + s * m * j)];
             if(R == 2) {
                 const double2 a0 = v[kk][0], a1 = v[kk][1];
                 v[kk][0] = cadd(a0, a1);
@@ -194,10 +215,10 @@ __device__ __forceinline__ void fft_stage(double2 *buf, const double2 *__restric
             const int p = b / s, q = b - p * s;
             /* s k is a multiple of 16 (s % 16 == 0), or q + s k stays below 16 under a thread part that is a multiple of 16 */
             constexpr bool SPLIT = s % 16 == 0 || ((s * R) % 16 == 0 && s * R <= 16);
-            double2 *y = buf + line * LS + (SPLIT ? lx(s % 16 == 0 ? q + s * R * p : s * R * p) : 0);
+            double2 *y = buf + line * LS + (SPLIT ? lx<N>(s % 16 == 0 ? q + s * R * p : s * R * p) : 0);
 #pragma unroll
             for(int k = 0; k < R; k++)
-                y[SPLIT ? (s % 16 == 0 ? lx(s * k) : q + s * k) : lx(q + s * R * p + s * k)] = op(line, q + s * R * p + s * k, v[kk][k]);
+                y[SPLIT ? (s % 16 == 0 ? lx<N>(s * k) : q + s * k) : lx<N>(q + s * R * p + s * k)] = op(line, q + s * R * p + s * k, v[kk][k]);
         }
     }
     __syncthreads();
@@ -280,7 +301,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_fwd(double *mesh, const int 
                     a = (double) __double_as_longlong(a) * inv_scale;
                     b = (double) __double_as_longlong(b) * inv_scale;
                 }
-                double *dst = reinterpret_cast<double *>(buf + (r >> 1) * LS + lx(z)) + (r & 1); /* z even: lx(z + 1) = lx(z) + 1 */
+                double *dst = reinterpret_cast<double *>(buf + (r >> 1) * LS + lx<N>(z)) + (r & 1); /* z even: the slot of z + 1 is the next one */
                 dst[0] = a;
                 dst[2] = b;
             }
@@ -295,8 +316,8 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_fwd(double *mesh, const int 
         const long long row0 = (long long) t * (2 * FFT_C);
         for(int e = threadIdx.x; e < FFT_C * Nc; e += FFT_T) {
             const int l = e / Nc, k = e - l * Nc;
-            const double2 zk = buf[l * LS + lx(k)];
-            const double2 zn = conj2(buf[l * LS + lx(k == 0 ? 0 : N - k)]);
+            const double2 zk = buf[l * LS + lx<N>(k)];
+            const double2 zn = conj2(buf[l * LS + lx<N>(k == 0 ? 0 : N - k)]);
             const double2 xa = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y + zn.y));
             const double2 d = make_double2(0.5 * (zk.x - zn.x), 0.5 * (zk.y - zn.y));
             const double2 xb = make_double2(d.y, -d.x);
@@ -353,9 +374,9 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_inv(double *mesh, const int 
                     xb.y = 0;
                 }
                 /* Z[k] = XA[k] + i XB[k];  Z[N-k] = conj(XA[k]) + i conj(XB[k]) */
-                buf[l * LS + lx(k)] = make_double2(xa.x - xb.y, xa.y + xb.x);
+                buf[l * LS + lx<N>(k)] = make_double2(xa.x - xb.y, xa.y + xb.x);
                 if(k > 0 && 2 * k < N)
-                    buf[l * LS + lx(N - k)] = make_double2(xa.x + xb.y, -xa.y + xb.x);
+                    buf[l * LS + lx<N>(N - k)] = make_double2(xa.x + xb.y, -xa.y + xb.x);
             }
         }
         __syncthreads();
@@ -367,7 +388,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_inv(double *mesh, const int 
         const long long row0 = (long long) t * (2 * FFT_C);
         for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T) {
             const int r = e / H, z = 2 * (e % H);
-            const double *src = reinterpret_cast<const double *>(buf + (r >> 1) * LS + lx(z)) + (r & 1);
+            const double *src = reinterpret_cast<const double *>(buf + (r >> 1) * LS + lx<N>(z)) + (r & 1);
             cm[(row0 + r) * zpc + (z >> 1)] = make_double2(src[0], src[2]);
         }
         if(!more)
@@ -439,7 +460,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
         for(int i = 0; i < E; i++) {
             const int e = threadIdx.x + i * FFT_T;
             if(EXACT || e < FFT_C * N)
-                buf[(e % FFT_C) * LS + lx(e / FFT_C)] = make_double2(prx[i], pry[i]);
+                buf[(e % FFT_C) * LS + lx<N>(e / FFT_C)] = make_double2(prx[i], pry[i]);
         }
         __syncthreads();
         const int tn = t + (int) gridDim.x;
@@ -472,9 +493,9 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
         for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T) {
             const int row = e / FFT_C, col = e - row * FFT_C;
             if(PK == 1)
-                abase[(long long) (row / ga.nyl) * ga.qstride + (long long) (row % ga.nyl) * es + col] = buf[col * LS + lx(row)];
+                abase[(long long) (row / ga.nyl) * ga.qstride + (long long) (row % ga.nyl) * es + col] = buf[col * LS + lx<N>(row)];
             else
-                base[(long long) row * es + col] = buf[col * LS + lx(row)];
+                base[(long long) row * es + col] = buf[col * LS + lx<N>(row)];
         }
         if(!more)
             break;
