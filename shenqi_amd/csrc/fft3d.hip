@@ -31,8 +31,12 @@ namespace {
 #ifndef FFT_C
 #define FFT_C 4        /* complex lines per workgroup */
 #endif
+/* threads per workgroup: 256, two workgroups per CU, up to Nmesh 768; above that one tile + tables no longer fit the LDS twice, and a
+ * 256-thread workgroup would be one wave per SIMD holding 250-500 registers: 512 threads (the same two waves per SIMD, half the tile
+ * elements per thread).  N is the mesh size wherever the macro is used. */
+__host__ __device__ constexpr int fft_threads(int N) { return N > 768 ? 512 : 256; }
 #ifndef FFT_T
-#define FFT_T 256      /* threads per workgroup */
+#define FFT_T fft_threads(N)
 #endif
 /* Element i of a line sits at LDS slot lx(i) = i + i / 16 (SHQ_FFT_PAD): the first radix-16 stage writes its outputs 16 elements
  * apart — 256 bytes, two full sweeps of the 32 store banks, so the eight lanes a ds_write_b128 serves per cycle all meet in the same
