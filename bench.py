@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--kind", default="cluster", choices=["cluster", "uniform", "grid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sph", action="store_true", help="skip the SPH operator figures (kernels.sph_*)")
+    ap.add_argument("--sph-ngrid", type=int, default=128,
+                    help="gas particles per dimension of the SPH / C3 figures (128 = BASELINE configs[2]; 256 = the particle set of configs[4])")
     ap.add_argument("--walk-mode", type=int, default=0)
     ap.add_argument("--separate-calls", action="store_true",
                     help="time shq_pm_run + shq_grav_refresh_oldacc + shq_grav_short_run instead of the one-call shq_treepm_step")
@@ -1018,7 +1020,7 @@ def main():
     except sq.ShqError as e:
         out["kernels"]["fof_note"] = "skipped: %s" % e
     if not args.no_sph:
-        figs = sph_figures(ctx)
+        figs = sph_figures(ctx, n1=args.sph_ngrid)
         for k in ("roofline_sph_density", "roofline_sph_hydro"):
             out[k] = figs.pop(k)
         out["kernels"].update(figs)
