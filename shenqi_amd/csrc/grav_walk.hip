@@ -287,8 +287,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
             pz = p.z;
             if(READOUT) {
                 /* readout_potential / readout_force_{x,y,z} (gravpm.cpp:489-500) for this target, then grav_get_abs_accel
-                 * (gravshort2.hpp:111-121) with the NEW GravPM: 104 scattered loads and ~500 instructions per lane and task,
-                 * hidden behind the walks of the SIMD's other waves.  Same operations as pm_readout_kernel + oldacc_kernel. */
+                 * (gravshort2.hpp:111-121) with the NEW GravPM: 104 loads and ~330 vector instructions per lane and task (of 63 k),
+                 * the loads' latency hidden behind the walks of the SIMD's other waves.  Same operations as pm_readout_kernel +
+                 * oldacc_kernel, so the same bits. */
                 double g0 = 0, g1 = 0, g2 = 0, gp = 0;
                 pm_readout_lean(c.pm_mesh, c.pmN, c.pmzp, c.pmcell, c.pmffac, px, py, pz, !(c.pflags && (c.pflags[pi] & 2)), g0, g1, g2, gp);
                 c.gravpm[3 * pi + 0] = g0;
