@@ -173,6 +173,8 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
         ctx->pm_overlap = atoi(v) != 0;
     if(const char *v = getenv("SHQ_PM_SCRUB"))
         ctx->pm_scrub = atoi(v) != 0;
+    if(const char *v = getenv("SHQ_WALK_SPARSE"))
+        ctx->walk_sparse = atoi(v);
     if(const char *v = getenv("SHQ_TREEPM_FUSE"))
         ctx->treepm_fuse = atoi(v) != 0;
     if(const char *v = getenv("SHQ_WALK_VARIANT"))
@@ -924,6 +926,13 @@ extern "C" int shq_grav_short_download(shq_context *ctx, double (*accel)[3], dou
     SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
     SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "nothing to download");
     SHQ_HIP(hipSetDevice(ctx->device));
+    if(ctx->sp_check_pending) { /* the pair kernel's stacks are sized for any tree the build accepts; a full one must not pass silently */
+        int flag = 0;
+        SHQ_HIP(hipMemcpyAsync(&flag, ctx->sp_flags.ptr, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->sp_check_pending = false;
+        SHQ_CHECK(flag == 0, SHQ_ERR_DEVICE, "grav walk: a pair stack of the sparse-subtree kernel overflowed (SHQ_WALK_SPARSE=0 avoids the kernel)");
+    }
     const int64_t n = ctx->numpart;
     if(accel && n > 0)
         SHQ_HIP(hipMemcpyAsync(accel, ctx->acc.ptr, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));

@@ -402,6 +402,11 @@ struct shq_context {
     int walk_ring = 1;         /* SHQ_WALK_RING: leaf particles through the wave-private LDS ring (persistent walk only) */
     int num_cus = 256;         /* compute units of the device */
     DevBuf<unsigned int> walk_tasks; /* the task counters of the persistent walk */
+    DevBuf<int4> sp_items, sp_stack;  /* SHQ_WALK_SPARSE: noted subtrees per task, pair stacks of the pair kernel's waves */
+    DevBuf<int32_t> sp_count;
+    DevBuf<int> sp_flags;             /* [0] stack overflow, [16] the pair kernel's task counter */
+    int walk_sparse = 0;              /* SHQ_WALK_SPARSE */
+    bool sp_check_pending = false;
     int xcd_k = 32;            /* SHQ_XCD_K: blocks per XCD chunk in the remap (0 = off); 32 measured best (2 %) */
     float last_walk_ms = 0;
     int last_walk_mode = 0;    /* what SHQ_WALK_AUTO resolved to in the last launch */

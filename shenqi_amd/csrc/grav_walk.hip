@@ -68,6 +68,13 @@ struct WalkArgs {
     const double *treeacc;       /* FullTreeGravAccel of the previous step, [N][3] */
     const uint8_t *pflags;
     double *gravpm, *pmpot, *oldacc_out;
+    /* SPARSE: subtrees that at most SHQ_SPARSE_LANES lanes of a task enter are not walked by the task's wave; it notes them here
+     * (slot k of task w: {first node, end node, lane mask}) and grav_pair_kernel walks them with one lane per (target, node) pair */
+    int4 *sp_items;
+    int32_t *sp_count;
+    int4 *sp_stack;              /* pair kernel: SHQ_SPARSE_STACK pairs per resident wave */
+    int *sp_overflow;
+    unsigned int *sp_task;       /* pair kernel: task counter */
 };
 
 /* NEAREST (partmanager.h:99) as d - L*rint(d/L): one multiply, one round, one fma. For
@@ -227,6 +234,9 @@ __device__ __forceinline__ int walk_next_task(WalkArgsK c, int &region, int &tri
  * particles are still evaluated in the order its walk met them; only their position relative to the node interactions changes (the
  * last bits of the sums).  tools/walk_defer_sim.py: leaf rounds 340 -> 219 per wave (64^3 S-cluster) at 32 slots. */
 #define SHQ_LEAF_RING 32
+#define SHQ_SPARSE_LANES 8     /* a subtree entered by at most this many lanes goes to the pair kernel */
+#define SHQ_SPARSE_CAP 96      /* ... while the task has a free slot (31.7 per task on average at 256^3) */
+#define SHQ_SPARSE_STACK 16384 /* pairs per resident wave of the pair kernel */
 
 template <bool POT>
 __device__ __forceinline__ void leaf_ring_drain(const double4 *__restrict__ tab, const double4 *ring, unsigned &mymask, double px, double py,
@@ -244,7 +254,8 @@ __device__ __forceinline__ void leaf_ring_drain(const double4 *__restrict__ tab,
     }
 }
 
-template <bool POT, bool PREFETCH, int LEAFB, int STATS, bool BH, bool GHOSTS = false, bool PERSIST = false, bool RING = false, bool READOUT = false>
+template <bool POT, bool PREFETCH, int LEAFB, int STATS, bool BH, bool GHOSTS = false, bool PERSIST = false, bool RING = false, bool READOUT = false,
+          bool SPARSE = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num_vgpr(64))) void grav_walk_exact_kernel(const WalkArgs a)
 {
     extern __shared__ double4 ring_all[]; /* RING: SHQ_LEAF_RING slots per wave */
@@ -323,6 +334,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
     }
     double ax = 0, ay = 0, az = 0, pot = 0;
     int nint = 0;
+    int sp_n = 0;                      /* SPARSE: subtrees this task has handed to the pair kernel (wave-uniform) */
     unsigned ringmask = 0;             /* RING: this lane's pending slots */
     int ringfill = 0;                  /* RING: slots in use (wave-uniform) */
     unsigned long long ringwrap = 0;   /* RING: some pending leaf needs the periodic wrap (wave-uniform) */
@@ -481,6 +493,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
         {
             /* the lanes that descend: those that open an internal node (a wave-uniform select on the node type, not a branch) */
             unsigned long long descendm = nd.type == SHQ_NODE_NODE_TYPE ? doopenm : 0ull;
+            if(SPARSE && descendm != 0ull) {
+                asm volatile("" ::: "memory");
+                if(__popcll(descendm) <= SHQ_SPARSE_LANES && sp_n < SHQ_SPARSE_CAP) {
+                    /* few lanes want this subtree: note it and pass on, as if they had accepted the node (its own monopole was
+                     * evaluated above for the lanes that accept it; the lanes in the mask OPEN it: the pair kernel starts at its
+                     * first child) */
+                    if(lane == 0)
+                        walk_cold_args()->sp_items[wave * SHQ_SPARSE_CAP + sp_n] =
+                            make_int4(nd.child, nd.sibling, (int) (unsigned) descendm, (int) (unsigned) (descendm >> 32));
+                    sp_n++;
+                    descendm = 0ull;
+                }
+                descendm = ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (descendm >> 32)) << 32) |
+                           (unsigned) __builtin_amdgcn_readfirstlane((int) descendm);
+            }
             const unsigned long long descendm_lanes = descendm;
             if(GHOSTS && nd.type == SHQ_NODE_NODE_TYPE) /* a lane waits at a branch below this node: go down even if nobody opens it */
                 descendm |= shq_ballot(mynext > cur && (nd.sibling < 0 || mynext < nd.sibling));
@@ -524,6 +551,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
             c.pot[pi] = pot;
         c.nint[pi] = nint;
     }
+    if(SPARSE && lane == 0)
+        c.sp_count[wave] = sp_n;
     /* statistics (treewalk2.h:446-448 interaction min/max) */
     long long mn = valid ? (long long) nint : __double_as_longlong(sconst(__longlong_as_double(0x7fffffffffffll))), mx = valid ? nint : 0, sm = valid ? nint : 0;
     for(int off = 32; off > 0; off >>= 1) {
@@ -540,7 +569,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
             l8m = max(l8m, (unsigned int) __shfl_xor(l8m, off));
             l16m = max(l16m, (unsigned int) __shfl_xor(l16m, off));
         }
-    if(lane == 0 && c.stats && c.stats_guard != 2) {
+    if(!SPARSE && lane == 0 && c.stats && c.stats_guard != 2) { /* SPARSE: the pair kernel tallies, once the counts are complete */
         atomicAdd(&c.stats->ninteractions, (unsigned long long) sm);
         /* 262 144 waves end here with three no-return atomics on one cache line.  Measured at 256^3 (same box, SHQ_WALK_STATS_GUARD):
          * as they are 39.3 ms, without any of them 39.3 ms, with a read first so that only improvements reach atomicMin / atomicMax
@@ -571,6 +600,201 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
     }
     wave = PERSIST ? (long long) walk_next_task(walk_cold_args(), region, tried) : -1;
     } /* task loop */
+}
+
+/* ---- the sparse subtrees: one lane per (target, node) pair ---------------------------------------------------------------
+ * A wave of the main walk spends a node visit's ~45 vector instructions whether 64 or 3 of its lanes are awake, and the subtrees
+ * that at most eight lanes enter are 21 % of its visits and 27 % of its monopole rounds for 2.4 % of the interactions.  Here a wave
+ * takes ONE task's noted subtrees (same 64 targets, target slot = lane of the main walk) and keeps a stack of pairs {node, end,
+ * slot}: it pops 64, every lane loads ITS node's record, tests it against ITS target with the reference's expressions
+ * (gravshort2.hpp:152-193, the same code path as the main walk: identical decisions), evaluates it on accept into the target's LDS
+ * accumulator, walks a leaf's particles on open, pushes the first child on open of an internal node, and pushes the sibling while
+ * the end of the subtree is not reached.  All lanes run the same code whatever their pair is.  The sums are added to what the main
+ * walk stored for the task's targets (this wave alone touches them: no atomics, fixed order), and the wave tallies the
+ * interaction statistics the main walk left to it.  Per-target interaction sets are the reference's; the order of the sum is not. */
+template <bool POT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void grav_pair_kernel(const WalkArgs a)
+{
+    /* 8 waves share one window table: 52 KB per workgroup, three of them (24 waves) per CU */
+    __shared__ double4 tab[SHQ_NGRAVTAB];
+    __shared__ double4 tgt_all[8][64];   /* px, py, pz, errtol * OldAcc of the task's targets */
+    __shared__ double acc_all[8][5][64]; /* ax, ay, az, pot, interaction count per target */
+    for(int i = threadIdx.x; i < SHQ_NGRAVTAB; i += blockDim.x) {
+        const int j = (i + 1 < SHQ_NGRAVTAB) ? i + 1 : i;
+        const double f0 = a.tab_f[i], f1 = a.tab_f[j], p0 = a.tab_p[i], p1 = a.tab_p[j];
+        tab[i] = i + 1 < SHQ_NGRAVTAB ? make_double4(f0, f1 - f0, p0, p1 - p0) : make_double4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double4 *const tgt = tgt_all[wv];
+    double(*const acc)[64] = acc_all[wv];
+    int4 *const stack = a.sp_stack + ((size_t) blockIdx.x * 8 + wv) * SHQ_SPARSE_STACK;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    /* tasks in a fixed stride over the resident waves, and ONE set of tallies per wave at the end: a returning atomic on one word
+     * completes ~88 times per microsecond chip-wide and three no-return ones on one line take ~12 ns each (MI355X_MICROARCH.md) —
+     * per task that was 10 ms for this kernel, whatever it did in between */
+    long long w_sum = 0, w_min = 0x7fffffffffffll, w_max = 0;
+    for(long long task = (long long) blockIdx.x * 8 + wv; task < a.nwaves; task += (long long) gridDim.x * 8) {
+        const long long t = task * 64 + lane;
+        const bool valid = t < a.ntargets;
+        const long long pi = valid ? (a.targets ? (long long) a.targets[t] : t) : -1;
+        const bool have = pi >= 0;
+        const int cnt = a.sp_count[task];
+        int sp = 0;
+        if(cnt > 0) {
+            double4 me = make_double4(0, 0, 0, 0);
+            if(have) {
+                const double4 p = a.posm[pi];
+                me = make_double4(p.x, p.y, p.z, a.errtol * a.oldacc[pi]);
+            }
+            tgt[lane] = me;
+            for(int k = 0; k < 5; k++)
+                acc[k][lane] = 0.0;
+            /* the noted subtrees as pairs (first node, end, slot), in the order the task noted them: the items are fetched 64 at a
+             * time, one per lane (one trip to memory, not one per item), and handed round with readlane */
+            for(int k0 = 0; k0 < cnt; k0 += 64) {
+                int4 mine = make_int4(0, 0, 0, 0);
+                if(k0 + lane < cnt)
+                    mine = a.sp_items[task * SHQ_SPARSE_CAP + k0 + lane];
+                const int kn = cnt - k0 < 64 ? cnt - k0 : 64;
+                for(int k = 0; k < kn; k++) {
+                    const int ix = __builtin_amdgcn_readlane(mine.x, k), iy = __builtin_amdgcn_readlane(mine.y, k);
+                    const unsigned long long m = ((unsigned long long) (unsigned) __builtin_amdgcn_readlane(mine.w, k) << 32) |
+                                                 (unsigned) __builtin_amdgcn_readlane(mine.z, k);
+                    if((m >> lane) & 1ull)
+                        stack[sp + __popcll(m & below)] = make_int4(ix, iy, lane, 0);
+                    sp += __popcll(m);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        while(sp > 0) {
+            const int np = sp < 64 ? sp : 64;
+            sp -= np;
+            int node = -1, end = -1, slot = 0, kind = 0;
+            if(lane < np) {
+                const int4 pr = stack[sp + lane];
+                node = pr.x;
+                end = pr.y;
+                slot = pr.z;
+                kind = pr.w;
+            }
+            int push_sib = -1, push_child = -1, child_end = -1, leaf0 = 0, leafn = 0;
+            double ax = 0, ay = 0, az = 0, pot = 0;
+            int ni = 0;
+            if(node >= 0 && kind == 1) { /* a particle of an opened leaf (gravshort2.hpp:290-304) */
+                const double4 tg = tgt[slot];
+                leaf_particle<POT>(tab, a.posm_leaf[node], tg.x, tg.y, tg.z, a, ax, ay, az, pot, ~0ull);
+                ni = 1;
+            }
+            if(node >= 0 && kind == 0) {
+                const NodeG nd = a.nodeG[node];
+                const double4 tg = tgt[slot];
+                const double px = tg.x, py = tg.y, pz = tg.z, aold = tg.w;
+                double dx = nd.cofm[0] - px, dy = nd.cofm[1] - py, dz = nd.cofm[2] - pz;
+                double ux = nd.center[0] - px, uy = nd.center[1] - py, uz = nd.center[2] - pz;
+                double cmax = fmax(fmax(fabs(ux), fabs(uy)), fabs(uz));
+                /* the wrap is the identity on every component it is not needed for: applying it per lane gives the main walk's bits */
+                const bool wrap = __double2hiint(nd.wraplim) >= 0 && cmax >= nd.wraplim; /* sign bit: interior node, never wraps */
+                if(wrap) {
+                    dx = wrapd(dx, a.Box, a.invBox);
+                    dy = wrapd(dy, a.Box, a.invBox);
+                    dz = wrapd(dz, a.Box, a.invBox);
+                    ux = wrapd(ux, a.Box, a.invBox);
+                    uy = wrapd(uy, a.Box, a.invBox);
+                    uz = wrapd(uz, a.Box, a.invBox);
+                    cmax = fmax(fmax(fabs(ux), fabs(uy)), fabs(uz));
+                }
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                const bool keep = !(r2 > nd.rcut2 && cmax > nd.rcuthl);
+                const bool open = (!a.useBH && nd.mlen2 > r2 * r2 * aold) || r2 < nd.bhlim || cmax < nd.inside;
+                if(keep && !open) {
+                    apply_accn<POT, false>(tab, dx, dy, dz, r2, nd.mass, a, ax, ay, az, pot);
+                    ni = 1;
+                }
+                if(keep && open) {
+                    if(nd.type == SHQ_NODE_NODE_TYPE) {
+                        push_child = nd.child;
+                        child_end = nd.sibling;
+                    } else if(nd.type == SHQ_PARTICLE_NODE_TYPE) { /* its particles become pairs of their own: one per lane and batch */
+                        leaf0 = nd.child;
+                        leafn = nd.count;
+                    }
+                }
+                if(nd.sibling != end && nd.sibling >= 0)
+                    push_sib = nd.sibling;
+            }
+            if(ni > 0) {
+                atomicAdd(&acc[0][slot], ax);
+                atomicAdd(&acc[1][slot], ay);
+                atomicAdd(&acc[2][slot], az);
+                if(POT)
+                    atomicAdd(&acc[3][slot], pot);
+                atomicAdd(&acc[4][slot], 1.0);
+            }
+            /* siblings first, then children, leaf particles on top: the stack stays depth-bounded */
+            {
+                const unsigned long long m = shq_ballot(push_sib >= 0);
+                if(push_sib >= 0)
+                    stack[sp + __popcll(m & below)] = make_int4(push_sib, end, slot, 0);
+                sp += __popcll(m);
+            }
+            {
+                const unsigned long long m = shq_ballot(push_child >= 0);
+                if(push_child >= 0)
+                    stack[sp + __popcll(m & below)] = make_int4(push_child, child_end, slot, 0);
+                sp += __popcll(m);
+            }
+            if(shq_ballot(leafn > 0) != 0ull)
+                for(int k = 0; k < SHQ_NMAXCHILD; k++) {
+                    const unsigned long long m = shq_ballot(k < leafn);
+                    if(m == 0ull)
+                        break;
+                    if(k < leafn)
+                        stack[sp + __popcll(m & below)] = make_int4(leaf0 + k, -1, slot, 1);
+                    sp += __popcll(m);
+                }
+            if(sp > SHQ_SPARSE_STACK - 640) { /* cannot happen for trees of <= 21 levels and <= SHQ_SPARSE_CAP x 8 starting pairs; loud if it does */
+                if(lane == 0)
+                    *a.sp_overflow = 1;
+                sp = 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        /* add to what the main walk stored, and tally */
+        long long nint = 0;
+        if(have) {
+            nint = a.nint[pi];
+            if(cnt > 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                a.acc[3 * pi + 0] += acc[0][lane];
+                a.acc[3 * pi + 1] += acc[1][lane];
+                a.acc[3 * pi + 2] += acc[2][lane];
+                if(POT)
+                    a.pot[pi] += acc[3][lane];
+                nint += (long long) acc[4][lane];
+                a.nint[pi] = (int32_t) nint;
+            }
+        }
+        long long mn = have ? nint : 0x7fffffffffffll, mx = have ? nint : 0, sm = have ? nint : 0;
+        for(int off = 32; off > 0; off >>= 1) {
+            const long long o1 = __shfl_xor(mn, off), o2 = __shfl_xor(mx, off), o3 = __shfl_xor(sm, off);
+            mn = o1 < mn ? o1 : mn;
+            mx = o2 > mx ? o2 : mx;
+            sm += o3;
+        }
+        w_sum += sm;
+        w_min = mn < w_min ? mn : w_min;
+        w_max = mx > w_max ? mx : w_max;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if(lane == 0 && a.stats) {
+        atomicAdd(&a.stats->ninteractions, (unsigned long long) w_sum);
+        atomicMin(&a.stats->min_int, w_min);
+        atomicMax(&a.stats->max_int, w_max);
+    }
 }
 
 /* GravTreeOutput::postprocess, gravshort2.hpp:88-107 */
@@ -664,8 +888,12 @@ __global__ void stats_init_kernel(GravStatsDev *s)
 template <bool POT, bool PREFETCH, int LEAFB, bool BH>
 void launch_variant_bh(int stats, bool persist, dim3 grid, dim3 block, hipStream_t stream, const WalkArgs &a, size_t dyn_lds = 0)
 {
-    constexpr bool RO = !PREFETCH && LEAFB == 2 && !BH; /* the fused readout exists for the production variant only */
-    if(a.pm_mesh && RO && !stats && persist && block.x == 512)
+    constexpr bool RO = !PREFETCH && LEAFB == 2 && !BH; /* the fused readout and the sparse-subtree hand-over exist for the production variant only */
+    if(a.pm_mesh && a.sp_items && RO && !stats && persist && block.x == 512)
+        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 0, BH, false, RO, RO, RO, RO><<<grid, block, dyn_lds, stream>>>(a);
+    else if(a.sp_items && RO && !stats && persist && block.x == 512)
+        grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 0, BH, false, RO, RO, false, RO><<<grid, block, dyn_lds, stream>>>(a);
+    else if(a.pm_mesh && RO && !stats && persist && block.x == 512)
         grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 0, BH, false, RO, RO, RO><<<grid, block, dyn_lds, stream>>>(a);
     else if(a.pm_mesh && RO && !stats && !persist)
         grav_walk_exact_kernel<POT, PREFETCH, LEAFB, 0, BH, false, false, false, RO><<<grid, block, 0, stream>>>(a);
@@ -747,6 +975,11 @@ static void fill_walk_args(shq_context *ctx, const shq_grav_params *p, WalkArgs 
     a.treeacc = nullptr;
     a.pflags = nullptr;
     a.gravpm = a.pmpot = a.oldacc_out = nullptr;
+    a.sp_items = nullptr;
+    a.sp_count = nullptr;
+    a.sp_stack = nullptr;
+    a.sp_overflow = nullptr;
+    a.sp_task = nullptr;
     a.nwaves = 0;
     a.task_run_log2 = 7;
 }
@@ -862,6 +1095,22 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     const bool persist = ctx->walk_persist && !stats && variant == 3 && (ctx->walk_persist == 2 || blocks > (long long) ctx->num_cus * bpc);
     /* leaf ring: workgroups of 8 waves (4 per CU: one window table per 8 waves leaves the LDS room for the rings) */
     const bool ring = persist && ctx->walk_ring && bpc == 8;
+    /* sparse subtrees to the pair kernel (SHQ_WALK_SPARSE): the production launch with the relative criterion only */
+    const bool sparse = ring && ctx->walk_sparse && !p->TreeUseBH;
+    const long long pair_blocks = (long long) ctx->num_cus * 3; /* of 8 waves */
+    if(sparse) {
+        SHQ_TRY(ctx->sp_items.reserve((size_t) nwaves * SHQ_SPARSE_CAP));
+        SHQ_TRY(ctx->sp_count.reserve((size_t) nwaves));
+        SHQ_TRY(ctx->sp_stack.reserve((size_t) pair_blocks * 8 * SHQ_SPARSE_STACK));
+        SHQ_TRY(ctx->sp_flags.reserve(32));
+        SHQ_HIP(hipMemsetAsync(ctx->sp_flags.ptr, 0, sizeof(int) * 32, ctx->stream));
+        a.sp_items = ctx->sp_items.ptr;
+        a.sp_count = ctx->sp_count.ptr;
+        a.sp_stack = ctx->sp_stack.ptr;
+        a.sp_overflow = ctx->sp_flags.ptr;
+        a.sp_task = reinterpret_cast<unsigned int *>(ctx->sp_flags.ptr + 16);
+        a.nwaves = nwaves;
+    }
     long long launch_blocks = blocks;
     size_t dyn_lds = 0;
     if(persist) {
@@ -941,6 +1190,14 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
         }
     }
     SHQ_HIP(hipGetLastError());
+    if(sparse) { /* the noted subtrees, one lane per (target, node) pair; inside the walk's timer */
+        if(update_potential)
+            grav_pair_kernel<true><<<dim3((unsigned) pair_blocks), dim3(512), 0, ctx->stream>>>(a);
+        else
+            grav_pair_kernel<false><<<dim3((unsigned) pair_blocks), dim3(512), 0, ctx->stream>>>(a);
+        SHQ_HIP(hipGetLastError());
+        ctx->sp_check_pending = true;
+    }
     SHQ_HIP(hipEventRecord(ctx->ev_end[SHQ_NTIMERS - 1], ctx->stream));
     if(swap_meshes) {
         std::swap(ctx->mesh.ptr, ctx->mesh_alt.ptr);
