@@ -234,7 +234,9 @@ __device__ __forceinline__ int walk_next_task(WalkArgsK c, int &region, int &tri
  * particles are still evaluated in the order its walk met them; only their position relative to the node interactions changes (the
  * last bits of the sums).  tools/walk_defer_sim.py: leaf rounds 340 -> 219 per wave (64^3 S-cluster) at 32 slots. */
 #define SHQ_LEAF_RING 32
+#ifndef SHQ_SPARSE_LANES
 #define SHQ_SPARSE_LANES 8     /* a subtree entered by at most this many lanes goes to the pair kernel */
+#endif
 #define SHQ_SPARSE_CAP 96      /* ... while the task has a free slot (31.7 per task on average at 256^3) */
 #define SHQ_SPARSE_STACK 16384 /* pairs per resident wave of the pair kernel */
 
@@ -618,7 +620,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     /* 8 waves share one window table: 52 KB per workgroup, three of them (24 waves) per CU */
     __shared__ double4 tab[SHQ_NGRAVTAB];
     __shared__ double4 tgt_all[8][64];   /* px, py, pz, errtol * OldAcc of the task's targets */
-    __shared__ double acc_all[8][5][64]; /* ax, ay, az, pot, interaction count per target */
+    __shared__ double acc_all[8][4][64]; /* ax, ay, az, pot per target */
+    __shared__ int cnt_all[8][64];       /* interaction count per target */
     for(int i = threadIdx.x; i < SHQ_NGRAVTAB; i += blockDim.x) {
         const int j = (i + 1 < SHQ_NGRAVTAB) ? i + 1 : i;
         const double f0 = a.tab_f[i], f1 = a.tab_f[j], p0 = a.tab_p[i], p1 = a.tab_p[j];
@@ -628,6 +631,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double4 *const tgt = tgt_all[wv];
     double(*const acc)[64] = acc_all[wv];
+    int *const cntl = cnt_all[wv];
     int4 *const stack = a.sp_stack + ((size_t) blockIdx.x * 8 + wv) * SHQ_SPARSE_STACK;
     const unsigned long long below = (1ull << lane) - 1ull;
     /* tasks in a fixed stride over the resident waves, and ONE set of tallies per wave at the end: a returning atomic on one word
@@ -648,8 +652,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 me = make_double4(p.x, p.y, p.z, a.errtol * a.oldacc[pi]);
             }
             tgt[lane] = me;
-            for(int k = 0; k < 5; k++)
+            for(int k = 0; k < 4; k++)
                 acc[k][lane] = 0.0;
+            cntl[lane] = 0;
             /* the noted subtrees as pairs (first node, end, slot), in the order the task noted them: the items are fetched 64 at a
              * time, one per lane (one trip to memory, not one per item), and handed round with readlane */
             for(int k0 = 0; k0 < cnt; k0 += 64) {
@@ -731,7 +736,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 atomicAdd(&acc[2][slot], az);
                 if(POT)
                     atomicAdd(&acc[3][slot], pot);
-                atomicAdd(&acc[4][slot], 1.0);
+                atomicAdd(&cntl[slot], 1);
             }
             /* siblings first, then children, leaf particles on top: the stack stays depth-bounded */
             {
@@ -774,7 +779,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 a.acc[3 * pi + 2] += acc[2][lane];
                 if(POT)
                     a.pot[pi] += acc[3][lane];
-                nint += (long long) acc[4][lane];
+                nint += (long long) cntl[lane];
                 a.nint[pi] = (int32_t) nint;
             }
         }
