@@ -637,6 +637,11 @@ int shq_set_walk_stats(shq_context *ctx, int level);
  * what the chip holds at once; 2 persistent waves for every launch.  leaf_ring: 1 (default) leaf particles go through the
  * wave-private LDS ring of the persistent walk, 0 they are evaluated as the leaf is opened (the reference's summation order). */
 int shq_set_walk_launch(shq_context *ctx, int persist, int leaf_ring);
+/* The production launch (persistent waves + leaf ring, relative criterion) does not enter a subtree that at most eight of a wave's 64
+ * lanes open: it notes it, and a second kernel walks the noted subtrees with one lane per (target, node) pair: the
+ * same interaction sets, a different order of the sum (forces to 1e-13 of the largest).  On by default; 0 (or SHQ_WALK_SPARSE=0)
+ * makes the main walk enter every subtree itself.  A test / tuning knob like shq_set_walk_launch. */
+int shq_set_walk_sparse(shq_context *ctx, int enable);
 /* Checker utility: direct summation as the reference's own gravity test does it (force_direct / grav_force,
  * libgadget/tests/test_gravity.cpp:41-76,121-143): accel[ns][3] (host) = acceleration at the ns sample positions (host, [ns][3]) from
  * the first nsrc resident particles and their (2 repeat + 1)^3 periodic images, spline-softened below h.  Partial sums over a

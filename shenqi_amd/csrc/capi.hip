@@ -264,6 +264,13 @@ extern "C" void shq_shutdown(shq_context *ctx)
     delete ctx;
 }
 
+extern "C" int shq_set_walk_sparse(shq_context *ctx, int enable)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    ctx->walk_sparse = enable != 0;
+    return SHQ_OK;
+}
+
 extern "C" int shq_set_walk_launch(shq_context *ctx, int persist, int leaf_ring)
 {
     SHQ_CHECK(ctx && persist >= 0 && persist <= 2 && (leaf_ring == 0 || leaf_ring == 1), SHQ_ERR_INVALID, "walk launch: persist 0..2, leaf_ring 0 or 1");

@@ -99,8 +99,12 @@ def test_walk_launch_modes_agree_and_match_the_oracle(ctx, kind, usebh):
         sub = np.arange(5, n, 7, dtype=np.int32)        # an active list through the ring launch, no potential
         capi.check(capi.hip.shq_set_walk_launch(ctx.h, 2, 1))
         asub = _gpu_walk(ctx, pman, tree, gp, (told, pold), active=sub, update_potential=False)
+        # the ring launch hands sparse subtrees to the pair kernel by default: the same launch entering every subtree itself
+        capi.check(capi.hip.shq_set_walk_sparse(ctx.h, 0))
+        res[(2, 1, "no pair kernel")] = _gpu_walk(ctx, pman, tree, gp, (told, pold))
     finally:
         capi.check(capi.hip.shq_set_walk_launch(ctx.h, 1, 1))
+        capi.check(capi.hip.shq_set_walk_sparse(ctx.h, 1))
     scale = np.abs(oacc).max()
     for mode, (acc, pot, nint, st) in res.items():
         assert np.array_equal(nint, onint), mode
@@ -109,6 +113,7 @@ def test_walk_launch_modes_agree_and_match_the_oracle(ctx, kind, usebh):
         assert np.allclose(pot, opot, rtol=1e-10, atol=1e-10 * np.abs(opot).max()), mode
     assert np.array_equal(res[(0, 0)][0], res[(2, 0)][0]) and np.array_equal(res[(0, 0)][1], res[(2, 0)][1])
     assert np.abs(res[(2, 1)][0] - res[(0, 0)][0]).max() < 1e-13 * scale
+    assert np.abs(res[(2, 1, "no pair kernel")][0] - res[(0, 0)][0]).max() < 1e-13 * scale
     assert np.array_equal(asub[2][sub], onint[sub])
     assert np.abs(asub[0][sub] - oacc[sub]).max() < 1e-11 * scale
 
