@@ -865,7 +865,8 @@ def main():
                             "note": "a plain copy of the same 3.66 GB mesh (tools/copy_rate.py, torch copy_) reaches 4.5 TB/s on this card: "
                                     "five passes at that rate would take 8.1 ms"},
         "kernels": {
-            "tree_walk_ms": st.kernel_ms, "tree_walk_with_counters_ms": counted_walk_ms, "tree_interactions_per_target": st.ninteractions / max(1, st.ntargets),
+            "tree_walk_ms": st.kernel_ms, "tree_walk_with_counters_ms": counted_walk_ms,
+            "pair_kernel_lean_records": bool(capi.hip.shq_walk_pair_lean(ctx.h) == 1), "tree_interactions_per_target": st.ninteractions / max(1, st.ntargets),
             "tree_interactions_per_s": st.ninteractions / max(walk_s, 1e-12),
             "tree_fp64_frac_of_vector_peak": 45.0 * st.ninteractions / max(walk_s, 1e-12) / 1e12 / FP64_VECTOR_PEAK_TF,
             "tree_nodes_visited_per_wave": st.nnodes_visited / max(1.0, st.ntargets / 64.0),

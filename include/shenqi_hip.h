@@ -640,8 +640,13 @@ int shq_set_walk_launch(shq_context *ctx, int persist, int leaf_ring);
 /* The production launch (persistent waves + leaf ring, relative criterion) does not enter a subtree that at most eight of a wave's 64
  * lanes open: it notes it, and a second kernel walks the noted subtrees with one lane per (target, node) pair: the
  * same interaction sets, a different order of the sum (forces to 1e-13 of the largest).  On by default; 0 (or SHQ_WALK_SPARSE=0)
- * makes the main walk enter every subtree itself.  A test / tuning knob like shq_set_walk_launch. */
+ * makes the main walk enter every subtree itself.  A test / tuning knob like shq_set_walk_launch.
+ * The pair kernel fetches the first 80 bytes of a node's record and recomputes the products of {mass, len} and the walk parameters that
+ * fill the rest (same expressions, same bits) whenever the device found that true of every record of the pool when it last filled
+ * them; 2 makes it fetch whole records regardless.  shq_walk_pair_lean: 1 if the current pool passed that check, 0 if not (or not
+ * checked yet), < 0 on error. */
 int shq_set_walk_sparse(shq_context *ctx, int enable);
+int shq_walk_pair_lean(shq_context *ctx);
 /* Checker utility: direct summation as the reference's own gravity test does it (force_direct / grav_force,
  * libgadget/tests/test_gravity.cpp:41-76,121-143): accel[ns][3] (host) = acceleration at the ns sample positions (host, [ns][3]) from
  * the first nsrc resident particles and their (2 repeat + 1)^3 periodic images, spline-softened below h.  Partial sums over a

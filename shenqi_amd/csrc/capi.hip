@@ -267,8 +267,20 @@ extern "C" void shq_shutdown(shq_context *ctx)
 extern "C" int shq_set_walk_sparse(shq_context *ctx, int enable)
 {
     SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
-    ctx->walk_sparse = enable != 0;
+    ctx->walk_sparse = enable == 2 ? 2 : enable != 0;
     return SHQ_OK;
+}
+
+extern "C" int shq_walk_pair_lean(shq_context *ctx)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    if(!ctx->node_lean_checked || !ctx->node_lean_bad.ptr)
+        return 0;
+    SHQ_HIP(hipSetDevice(ctx->device));
+    int bad = 1;
+    SHQ_HIP(hipMemcpyAsync(&bad, ctx->node_lean_bad.ptr, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    return bad == 0 ? 1 : 0;
 }
 
 extern "C" int shq_set_walk_launch(shq_context *ctx, int persist, int leaf_ring)

@@ -405,7 +405,9 @@ struct shq_context {
     DevBuf<int4> sp_items, sp_stack;  /* SHQ_WALK_SPARSE: noted subtrees per task, pair stacks of the pair kernel's waves */
     DevBuf<int32_t> sp_count;
     DevBuf<int> sp_flags;             /* [0] stack overflow, [16] the pair kernel's task counter */
-    int walk_sparse = 1;              /* SHQ_WALK_SPARSE (0: the main walk enters every subtree itself) */
+    int walk_sparse = 1;              /* SHQ_WALK_SPARSE (0: the main walk enters every subtree itself; 2: pair kernel on full records) */
+    DevBuf<int> node_lean_bad;        /* [0] != 0: some record's second half is not reproducible from {mass, len} (fill_rcuthl_kernel) */
+    bool node_lean_checked = false;
     bool sp_check_pending = false;
     int xcd_k = 32;            /* SHQ_XCD_K: blocks per XCD chunk in the remap (0 = off); 32 measured best (2 %) */
     float last_walk_ms = 0;

@@ -75,6 +75,8 @@ struct WalkArgs {
     int4 *sp_stack;              /* pair kernel: SHQ_SPARSE_STACK pairs per resident wave */
     int *sp_overflow;
     unsigned int *sp_task;       /* pair kernel: task counter */
+    const int *sp_lean_bad;      /* pair kernel: *sp_lean_bad == 0 says fill_rcuthl_kernel found every record's products reproducible from
+                                    {mass, len} by lean_products() below (null: not checked) */
 };
 
 /* NEAREST (partmanager.h:99) as d - L*rint(d/L): one multiply, one round, one fma. For
@@ -239,6 +241,12 @@ __device__ __forceinline__ int walk_next_task(WalkArgsK c, int &region, int &tri
 #endif
 #define SHQ_SPARSE_CAP 96      /* ... while the task has a free slot (31.7 per task on average at 256^3) */
 #define SHQ_SPARSE_STACK 16384 /* pairs per resident wave of the pair kernel */
+/* the pair kernel's workgroups: waves per workgroup (one window table each), workgroups per CU, waves per SIMD */
+#ifndef SHQ_PAIR_WAVES
+#define SHQ_PAIR_WAVES 8
+#define SHQ_PAIR_WG_PER_CU 3
+#define SHQ_PAIR_EU 6
+#endif
 
 template <bool POT>
 __device__ __forceinline__ void leaf_ring_drain(const double4 *__restrict__ tab, const double4 *ring, unsigned &mymask, double px, double py,
@@ -614,14 +622,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
  * the end of the subtree is not reached.  All lanes run the same code whatever their pair is.  The sums are added to what the main
  * walk stored for the task's targets (this wave alone touches them: no atomics, fixed order), and the wave tallies the
  * interaction statistics the main walk left to it.  Per-target interaction sets are the reference's; the order of the sum is not. */
+/* The per-node products of a NodeG record that follow from {mass, len} and the walk parameters, in the expressions that fill them
+ * (tree_build.hip pack kernel / capi.hip upload: mlen2, inside, wraplim; fill_rcuthl_kernel: rcuthl).  0.5 * len and 0.5 * Box are exact,
+ * so each sum is one rounding whether or not the compiler contracts it, and the products have no additions to contract. */
+struct LeanProducts { double rcuthl, mlen2, inside, wraplim; };
+__device__ __forceinline__ LeanProducts lean_products(double mass, double len, double rcut, double Box)
+{
+    LeanProducts r;
+    const double hl = 0.5 * len;
+    r.rcuthl = rcut + hl;
+    r.mlen2 = mass * len * len;
+    r.inside = 0.6 * len;
+    r.wraplim = fmax(0.5 * Box - hl, 0.0);
+    return r;
+}
+/* level of a node whose side is rootlen 2^-level: same mantissa, so the high words differ by level << 20 */
+__device__ __forceinline__ int lean_level(double rootlen, double len) { return (__double2hiint(rootlen) - __double2hiint(len)) >> 20; }
+
 template <bool POT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void grav_pair_kernel(const WalkArgs a)
+__global__ __launch_bounds__(64 * SHQ_PAIR_WAVES) __attribute__((amdgpu_waves_per_eu(SHQ_PAIR_EU, SHQ_PAIR_EU))) void grav_pair_kernel(const WalkArgs a)
 {
     /* 8 waves share one window table: 52 KB per workgroup, three of them (24 waves) per CU */
     __shared__ double4 tab[SHQ_NGRAVTAB];
-    __shared__ double4 tgt_all[8][64];   /* px, py, pz, errtol * OldAcc of the task's targets */
-    __shared__ double acc_all[8][4][64]; /* ax, ay, az, pot per target */
-    __shared__ int cnt_all[8][64];       /* interaction count per target */
+    __shared__ double4 tgt_all[SHQ_PAIR_WAVES][64];   /* px, py, pz, errtol * OldAcc of the task's targets */
+    __shared__ double acc_all[SHQ_PAIR_WAVES][4][64]; /* ax, ay, az, pot per target */
+    __shared__ int cnt_all[SHQ_PAIR_WAVES][64];       /* interaction count per target */
+    __shared__ double bh_lvl[32];                     /* len^2 / theta^2 by tree level */
+    const double rootlen = a.Box * 1.001;             /* forcetree.cpp:661 */
+    if(threadIdx.x < 32) {
+        const double l = ldexp(rootlen, -(int) threadIdx.x);
+        bh_lvl[threadIdx.x] = l * l / a.bh2; /* fill_rcuthl_kernel's expression on the same len */
+    }
+    const bool lean = __builtin_amdgcn_readfirstlane(a.sp_lean_bad ? (*a.sp_lean_bad == 0) : 0) != 0;
     for(int i = threadIdx.x; i < SHQ_NGRAVTAB; i += blockDim.x) {
         const int j = (i + 1 < SHQ_NGRAVTAB) ? i + 1 : i;
         const double f0 = a.tab_f[i], f1 = a.tab_f[j], p0 = a.tab_p[i], p1 = a.tab_p[j];
@@ -632,13 +664,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     double4 *const tgt = tgt_all[wv];
     double(*const acc)[64] = acc_all[wv];
     int *const cntl = cnt_all[wv];
-    int4 *const stack = a.sp_stack + ((size_t) blockIdx.x * 8 + wv) * SHQ_SPARSE_STACK;
+    int4 *const stack = a.sp_stack + ((size_t) blockIdx.x * SHQ_PAIR_WAVES + wv) * SHQ_SPARSE_STACK;
     const unsigned long long below = (1ull << lane) - 1ull;
     /* tasks in a fixed stride over the resident waves, and ONE set of tallies per wave at the end: a returning atomic on one word
      * completes ~88 times per microsecond chip-wide and three no-return ones on one line take ~12 ns each (MI355X_MICROARCH.md) —
      * per task that was 10 ms for this kernel, whatever it did in between */
     long long w_sum = 0, w_min = 0x7fffffffffffll, w_max = 0;
-    for(long long task = (long long) blockIdx.x * 8 + wv; task < a.nwaves; task += (long long) gridDim.x * 8) {
+    for(long long task = (long long) blockIdx.x * SHQ_PAIR_WAVES + wv; task < a.nwaves; task += (long long) gridDim.x * SHQ_PAIR_WAVES) {
         const long long t = task * 64 + lane;
         const bool valid = t < a.ntargets;
         const long long pi = valid ? (a.targets ? (long long) a.targets[t] : t) : -1;
@@ -687,50 +719,72 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             }
             int push_sib = -1, push_child = -1, child_end = -1, leaf0 = 0, leafn = 0;
             double ax = 0, ay = 0, az = 0, pot = 0;
-            int ni = 0;
-            if(node >= 0 && kind == 1) { /* a particle of an opened leaf (gravshort2.hpp:290-304) */
-                const double4 tg = tgt[slot];
-                leaf_particle<POT>(tab, a.posm_leaf[node], tg.x, tg.y, tg.z, a, ax, ay, az, pot, ~0ull);
-                ni = 1;
+            /* ONE body for both kinds of pair: a node record begins with {cofm, mass}, which is what a leaf particle's record is, so the
+             * source is one load from either array, the rest of a node's record is requested right behind it (one trip to memory per
+             * batch, not one per kind), and displacement, wrap, r^2 and the evaluation are issued once for the whole wave */
+            const bool live = node >= 0, isnode = live && kind == 0;
+            double4 src = make_double4(0, 0, 0, 0);
+            double cx = 0, cy = 0, cz = 0, wraplim = 0, rcut2 = 0, rcuthl = 0, mlen2 = 0, bhlim = 0, inside = 0;
+            int nsib = -1, nchild = -1, ntype = 0, ncount = 0;
+            if(live) {
+                const double4 *const sp4 = kind == 1 ? a.posm_leaf + node : reinterpret_cast<const double4 *>(a.nodeG + node);
+                src = *sp4;
             }
-            if(node >= 0 && kind == 0) {
-                const NodeG nd = a.nodeG[node];
-                const double4 tg = tgt[slot];
-                const double px = tg.x, py = tg.y, pz = tg.z, aold = tg.w;
-                double dx = nd.cofm[0] - px, dy = nd.cofm[1] - py, dz = nd.cofm[2] - pz;
-                double ux = nd.center[0] - px, uy = nd.center[1] - py, uz = nd.center[2] - pz;
-                double cmax = fmax(fmax(fabs(ux), fabs(uy)), fabs(uz));
-                /* the wrap is the identity on every component it is not needed for: applying it per lane gives the main walk's bits */
-                const bool wrap = __double2hiint(nd.wraplim) >= 0 && cmax >= nd.wraplim; /* sign bit: interior node, never wraps */
-                if(wrap) {
-                    dx = wrapd(dx, a.Box, a.invBox);
-                    dy = wrapd(dy, a.Box, a.invBox);
-                    dz = wrapd(dz, a.Box, a.invBox);
-                    ux = wrapd(ux, a.Box, a.invBox);
-                    uy = wrapd(uy, a.Box, a.invBox);
-                    uz = wrapd(uz, a.Box, a.invBox);
-                    cmax = fmax(fmax(fabs(ux), fabs(uy)), fabs(uz));
-                }
-                const double r2 = dx * dx + dy * dy + dz * dz;
-                const bool keep = !(r2 > nd.rcut2 && cmax > nd.rcuthl);
-                const bool open = (!a.useBH && nd.mlen2 > r2 * r2 * aold) || r2 < nd.bhlim || cmax < nd.inside;
-                if(keep && !open) {
-                    apply_accn<POT, false>(tab, dx, dy, dz, r2, nd.mass, a, ax, ay, az, pot);
-                    ni = 1;
-                }
+            if(isnode) {
+                const NodeG *const nd = a.nodeG + node;
+                const double len = nd->len;
+                cx = nd->center[0], cy = nd->center[1], cz = nd->center[2];
+                nsib = nd->sibling, nchild = nd->child, ntype = nd->type, ncount = nd->count;
+                if(lean) {
+                    /* this kernel is bound by the 16-byte pieces its lanes fetch from 64 different lines (a second record's worth of
+                     * loads per pair: 3.5 -> 5.8 ms), not by arithmetic: the second half of the record — products of {mass, len} and
+                     * the walk parameters — is recomputed with the expressions that filled it (checked record by record by
+                     * fill_rcuthl_kernel), five pieces per pair instead of eight.  Without the interior flag: such a node's wrap
+                     * only ever changes lanes that are discarded either way (the comment of fill_rcuthl_kernel) */
+                    const LeanProducts lp = lean_products(src.w, len, a.rcut, a.Box);
+                    rcuthl = lp.rcuthl, mlen2 = lp.mlen2, inside = lp.inside, wraplim = lp.wraplim, rcut2 = a.rcut2;
+                    bhlim = bh_lvl[lean_level(rootlen, len) & 31];
+                } else
+                    bhlim = nd->bhlim, mlen2 = nd->mlen2, inside = nd->inside, rcut2 = nd->rcut2, wraplim = nd->wraplim, rcuthl = nd->rcuthl;
+            }
+            const double4 tg = tgt[slot];
+            double dx = src.x - tg.x, dy = src.y - tg.y, dz = src.z - tg.z;
+            double ux = cx - tg.x, uy = cy - tg.y, uz = cz - tg.z;
+            double cmax = fmax(fmax(fabs(ux), fabs(uy)), fabs(uz));
+            /* the wrap is the identity on every component it is not needed for: applying it per lane gives the main walk's bits.  A
+             * leaf particle is always wrapped (gravshort2.hpp:290-304), a node unless it is interior (sign bit of wraplim) */
+            const bool nwrap = isnode && __double2hiint(wraplim) >= 0 && cmax >= wraplim;
+            if(nwrap || (live && !isnode)) {
+                dx = wrapd(dx, a.Box, a.invBox);
+                dy = wrapd(dy, a.Box, a.invBox);
+                dz = wrapd(dz, a.Box, a.invBox);
+            }
+            if(nwrap) {
+                ux = wrapd(ux, a.Box, a.invBox);
+                uy = wrapd(uy, a.Box, a.invBox);
+                uz = wrapd(uz, a.Box, a.invBox);
+                cmax = fmax(fmax(fabs(ux), fabs(uy)), fabs(uz));
+            }
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            bool ev = live && !isnode;
+            if(isnode) {
+                const bool keep = !(r2 > rcut2 && cmax > rcuthl);
+                const bool open = (!a.useBH && mlen2 > r2 * r2 * tg.w) || r2 < bhlim || cmax < inside;
+                ev = keep && !open;
                 if(keep && open) {
-                    if(nd.type == SHQ_NODE_NODE_TYPE) {
-                        push_child = nd.child;
-                        child_end = nd.sibling;
-                    } else if(nd.type == SHQ_PARTICLE_NODE_TYPE) { /* its particles become pairs of their own: one per lane and batch */
-                        leaf0 = nd.child;
-                        leafn = nd.count;
+                    if(ntype == SHQ_NODE_NODE_TYPE) {
+                        push_child = nchild;
+                        child_end = nsib;
+                    } else if(ntype == SHQ_PARTICLE_NODE_TYPE) { /* its particles become pairs of their own: one per lane and batch */
+                        leaf0 = nchild;
+                        leafn = ncount;
                     }
                 }
-                if(nd.sibling != end && nd.sibling >= 0)
-                    push_sib = nd.sibling;
+                if(nsib != end && nsib >= 0)
+                    push_sib = nsib;
             }
-            if(ni > 0) {
+            if(ev) { /* CLAMP for the particle that is the target itself; a no-op on an accepted node's r^2 */
+                apply_accn<POT, true>(tab, dx, dy, dz, r2, src.w, a, ax, ay, az, pot);
                 atomicAdd(&acc[0][slot], ax);
                 atomicAdd(&acc[1][slot], ay);
                 atomicAdd(&acc[2][slot], az);
@@ -751,15 +805,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                     stack[sp + __popcll(m & below)] = make_int4(push_child, child_end, slot, 0);
                 sp += __popcll(m);
             }
-            if(shq_ballot(leafn > 0) != 0ull)
+            /* a leaf's particles: the lane's first slot is the prefix sum of the counts below it, formed from the votes on the four
+             * bits of the count (count <= 8) instead of one vote per particle */
+            if(shq_ballot(leafn > 0) != 0ull) {
+                const unsigned long long b0 = shq_ballot((leafn & 1) != 0), b1 = shq_ballot((leafn & 2) != 0),
+                                         b2 = shq_ballot((leafn & 4) != 0), b3 = shq_ballot((leafn & 8) != 0);
+                const int off = __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below) + 8 * __popcll(b3 & below);
                 for(int k = 0; k < SHQ_NMAXCHILD; k++) {
-                    const unsigned long long m = shq_ballot(k < leafn);
-                    if(m == 0ull)
+                    if(shq_ballot(k < leafn) == 0ull)
                         break;
                     if(k < leafn)
-                        stack[sp + __popcll(m & below)] = make_int4(leaf0 + k, -1, slot, 1);
-                    sp += __popcll(m);
+                        stack[sp + off + k] = make_int4(leaf0 + k, -1, slot, 1);
                 }
+                sp += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3);
+            }
             if(sp > SHQ_SPARSE_STACK - 640) { /* cannot happen for trees of <= 21 levels and <= SHQ_SPARSE_CAP x 8 starting pairs; loud if it does */
                 if(lane == 0)
                     *a.sp_overflow = 1;
@@ -854,7 +913,7 @@ __global__ void oldacc_kernel(long long n, const double *treeacc, const double *
  * >= Rcut + len/2 and |cofm_k - pos_k| > Box/2 - len >= Rcut (Box >= 2 M + len); with it the wrapped displacement crosses a face, so
  * it is >= M + len/2 for the centre and >= M for the centre of mass, both beyond the same limits (shall_we_discard_node,
  * gravshort2.hpp:152-167).  Every other lane's arithmetic is untouched. */
-__global__ void fill_rcuthl_kernel(NodeG *g, long long n, double rcut, double bh2, double Box)
+__global__ void fill_rcuthl_kernel(NodeG *g, long long n, double rcut, double bh2, double Box, int *lean_bad)
 {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if(i < n) {
@@ -869,6 +928,18 @@ __global__ void fill_rcuthl_kernel(NodeG *g, long long n, double rcut, double bh
          * interior flag: zero says the same (the vote below is cmax >= wraplim) */
         const double wl = fmax(0.5 * Box - hl, 0.0);
         g[i].wraplim = (len > 0 && wl > 0 && M >= rcut + 1.5 * len) ? -wl : wl;
+        /* may the pair kernel recompute this record's second half from {mass, len}?  Yes when len is rootlen 2^-level to the bit (the
+         * Barnes-Hut limit then comes from a table by level, the expression above on the same number) and lean_products() returns
+         * what is stored.  The record behind the pool is never visited. */
+        if(lean_bad && i < n - 1) {
+            const double rootlen = Box * 1.001;
+            const int k = lean_level(rootlen, len);
+            const LeanProducts lp = lean_products(g[i].mass, len, rcut, Box);
+            const bool ok = len > 0 && k >= 0 && k < 32 && ldexp(rootlen, -k) == len && lp.rcuthl == g[i].rcuthl &&
+                            lp.mlen2 == g[i].mlen2 && lp.inside == g[i].inside && lp.wraplim == wl;
+            if(!ok)
+                *lean_bad = 1;
+        }
     }
 }
 
@@ -932,7 +1003,11 @@ void shq_fill_node_walk_params(shq_context *ctx, const shq_grav_params *p)
 {
     if((ctx->node_rcut != p->Rcut || ctx->node_bh2 != p->BHOpeningAngle2) && ctx->numnodes > 0) {
         const long long n = ctx->numnodes + 1;
-        fill_rcuthl_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->nodeG.ptr, n, p->Rcut, p->BHOpeningAngle2, p->BoxSize);
+        int *lean_bad = nullptr;
+        if(ctx->node_lean_bad.reserve(16) == SHQ_OK && hipMemsetAsync(ctx->node_lean_bad.ptr, 0, sizeof(int) * 16, ctx->stream) == hipSuccess)
+            lean_bad = ctx->node_lean_bad.ptr;
+        ctx->node_lean_checked = lean_bad != nullptr;
+        fill_rcuthl_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->nodeG.ptr, n, p->Rcut, p->BHOpeningAngle2, p->BoxSize, lean_bad);
         ctx->node_rcut = p->Rcut;
         ctx->node_bh2 = p->BHOpeningAngle2;
     }
@@ -984,6 +1059,7 @@ static void fill_walk_args(shq_context *ctx, const shq_grav_params *p, WalkArgs 
     a.sp_count = nullptr;
     a.sp_stack = nullptr;
     a.sp_overflow = nullptr;
+    a.sp_lean_bad = nullptr;
     a.sp_task = nullptr;
     a.nwaves = 0;
     a.task_run_log2 = 7;
@@ -1102,17 +1178,18 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     const bool ring = persist && ctx->walk_ring && bpc == 8;
     /* sparse subtrees to the pair kernel (SHQ_WALK_SPARSE): the production launch with the relative criterion only */
     const bool sparse = ring && ctx->walk_sparse && !p->TreeUseBH;
-    const long long pair_blocks = (long long) ctx->num_cus * 3; /* of 8 waves */
+    const long long pair_blocks = (long long) ctx->num_cus * SHQ_PAIR_WG_PER_CU;
     if(sparse) {
         SHQ_TRY(ctx->sp_items.reserve((size_t) nwaves * SHQ_SPARSE_CAP));
         SHQ_TRY(ctx->sp_count.reserve((size_t) nwaves));
-        SHQ_TRY(ctx->sp_stack.reserve((size_t) pair_blocks * 8 * SHQ_SPARSE_STACK));
+        SHQ_TRY(ctx->sp_stack.reserve((size_t) pair_blocks * SHQ_PAIR_WAVES * SHQ_SPARSE_STACK));
         SHQ_TRY(ctx->sp_flags.reserve(32));
         SHQ_HIP(hipMemsetAsync(ctx->sp_flags.ptr, 0, sizeof(int) * 32, ctx->stream));
         a.sp_items = ctx->sp_items.ptr;
         a.sp_count = ctx->sp_count.ptr;
         a.sp_stack = ctx->sp_stack.ptr;
         a.sp_overflow = ctx->sp_flags.ptr;
+        a.sp_lean_bad = ctx->node_lean_checked && ctx->walk_sparse != 2 ? ctx->node_lean_bad.ptr : nullptr;
         a.sp_task = reinterpret_cast<unsigned int *>(ctx->sp_flags.ptr + 16);
         a.nwaves = nwaves;
     }
@@ -1197,9 +1274,9 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     SHQ_HIP(hipGetLastError());
     if(sparse) { /* the noted subtrees, one lane per (target, node) pair; inside the walk's timer */
         if(update_potential)
-            grav_pair_kernel<true><<<dim3((unsigned) pair_blocks), dim3(512), 0, ctx->stream>>>(a);
+            grav_pair_kernel<true><<<dim3((unsigned) pair_blocks), dim3(64 * SHQ_PAIR_WAVES), 0, ctx->stream>>>(a);
         else
-            grav_pair_kernel<false><<<dim3((unsigned) pair_blocks), dim3(512), 0, ctx->stream>>>(a);
+            grav_pair_kernel<false><<<dim3((unsigned) pair_blocks), dim3(64 * SHQ_PAIR_WAVES), 0, ctx->stream>>>(a);
         SHQ_HIP(hipGetLastError());
         ctx->sp_check_pending = true;
     }

@@ -102,6 +102,11 @@ def test_walk_launch_modes_agree_and_match_the_oracle(ctx, kind, usebh):
         # the ring launch hands sparse subtrees to the pair kernel by default: the same launch entering every subtree itself
         capi.check(capi.hip.shq_set_walk_sparse(ctx.h, 0))
         res[(2, 1, "no pair kernel")] = _gpu_walk(ctx, pman, tree, gp, (told, pold))
+        # the pair kernel fetches 80 of a record's 128 bytes and recomputes the rest (the pool passed the device's check that this
+        # reproduces every record); 2 = whole records: the same decisions and the same bits
+        lean = capi.hip.shq_walk_pair_lean(ctx.h)
+        capi.check(capi.hip.shq_set_walk_sparse(ctx.h, 2))
+        res[(2, 1, "whole records")] = _gpu_walk(ctx, pman, tree, gp, (told, pold))
     finally:
         capi.check(capi.hip.shq_set_walk_launch(ctx.h, 1, 1))
         capi.check(capi.hip.shq_set_walk_sparse(ctx.h, 1))
@@ -114,6 +119,9 @@ def test_walk_launch_modes_agree_and_match_the_oracle(ctx, kind, usebh):
     assert np.array_equal(res[(0, 0)][0], res[(2, 0)][0]) and np.array_equal(res[(0, 0)][1], res[(2, 0)][1])
     assert np.abs(res[(2, 1)][0] - res[(0, 0)][0]).max() < 1e-13 * scale
     assert np.abs(res[(2, 1, "no pair kernel")][0] - res[(0, 0)][0]).max() < 1e-13 * scale
+    assert lean == 1
+    for k in range(3):
+        assert np.array_equal(res[(2, 1)][k], res[(2, 1, "whole records")][k]), k
     assert np.array_equal(asub[2][sub], onint[sub])
     assert np.abs(asub[0][sub] - oacc[sub]).max() < 1e-11 * scale
 
