@@ -647,6 +647,11 @@ int shq_set_walk_launch(shq_context *ctx, int persist, int leaf_ring);
  * checked yet), < 0 on error. */
 int shq_set_walk_sparse(shq_context *ctx, int enable);
 int shq_walk_pair_lean(shq_context *ctx);
+/* Where the pair kernel runs: 1 (default; SHQ_WALK_OVERLAP) beside the main walk on the context's second stream once a launch has
+ * at least 128 tasks per CU — three workgroups of the main walk and one of the pair kernel per CU, the pair kernel taking a task when
+ * the main walk has raised its flag (results, noted subtrees and OldAcc cross at the device's coherence point); 0 behind it on the
+ * same stream; 2 beside it whatever the size of the launch (tests).  Same interaction sets and the same sums in every mode. */
+int shq_set_walk_overlap(shq_context *ctx, int mode);
 /* Checker utility: direct summation as the reference's own gravity test does it (force_direct / grav_force,
  * libgadget/tests/test_gravity.cpp:41-76,121-143): accel[ns][3] (host) = acceleration at the ns sample positions (host, [ns][3]) from
  * the first nsrc resident particles and their (2 repeat + 1)^3 periodic images, spline-softened below h.  Partial sums over a

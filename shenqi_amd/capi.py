@@ -448,6 +448,8 @@ hip.shq_set_walk_sparse.argtypes = [_vp, C.c_int]
 hip.shq_set_walk_sparse.restype = C.c_int
 hip.shq_walk_pair_lean.argtypes = [_vp]
 hip.shq_walk_pair_lean.restype = C.c_int
+hip.shq_set_walk_overlap.argtypes = [_vp, C.c_int]
+hip.shq_set_walk_overlap.restype = C.c_int
 hip.shq_direct_force_sample.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int, _vp]
 hip.shq_direct_force_sample.restype = C.c_int
 hip.shq_exchange_plan.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.c_int64, _vp, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _vp]

@@ -149,6 +149,13 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
         delete ctx;
         return SHQ_ERR_DEVICE;
     }
+    if(hipStreamCreateWithPriority(&ctx->stream_pair, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+       hipEventCreateWithFlags(&ctx->ev_pair_fork, hipEventDisableTiming) != hipSuccess ||
+       hipEventCreateWithFlags(&ctx->ev_pair_join, hipEventDisableTiming) != hipSuccess) {
+        shq_set_error("creating the pair kernel's stream failed");
+        delete ctx;
+        return SHQ_ERR_DEVICE;
+    }
     if(const char *v = getenv("SHQ_WALK_FREE_CUS")) {
         const int k = atoi(v);
         if(k > 0 && k <= 16) {
@@ -175,6 +182,8 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
         ctx->pm_scrub = atoi(v) != 0;
     if(const char *v = getenv("SHQ_WALK_SPARSE"))
         ctx->walk_sparse = atoi(v);
+    if(const char *v = getenv("SHQ_WALK_OVERLAP"))
+        ctx->walk_overlap = atoi(v);
     if(const char *v = getenv("SHQ_TREEPM_FUSE"))
         ctx->treepm_fuse = atoi(v) != 0;
     if(const char *v = getenv("SHQ_WALK_VARIANT"))
@@ -257,6 +266,12 @@ extern "C" void shq_shutdown(shq_context *ctx)
         (void) hipStreamDestroy(ctx->stream_walk);
     if(ctx->stream_pm)
         (void) hipStreamDestroy(ctx->stream_pm);
+    if(ctx->stream_pair)
+        (void) hipStreamDestroy(ctx->stream_pair);
+    if(ctx->ev_pair_fork)
+        (void) hipEventDestroy(ctx->ev_pair_fork);
+    if(ctx->ev_pair_join)
+        (void) hipEventDestroy(ctx->ev_pair_join);
     if(ctx->ev_pm_ready)
         (void) hipEventDestroy(ctx->ev_pm_ready);
     if(ctx->ev_pm_done)
@@ -268,6 +283,14 @@ extern "C" int shq_set_walk_sparse(shq_context *ctx, int enable)
 {
     SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
     ctx->walk_sparse = enable == 2 ? 2 : enable != 0;
+    return SHQ_OK;
+}
+
+extern "C" int shq_set_walk_overlap(shq_context *ctx, int mode)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_CHECK(mode >= 0 && mode <= 2, SHQ_ERR_INVALID, "walk overlap mode %d", mode);
+    ctx->walk_overlap = mode;
     return SHQ_OK;
 }
 

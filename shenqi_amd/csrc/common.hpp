@@ -211,6 +211,10 @@ struct shq_context {
     hipEvent_t ev_walk_in = nullptr, ev_walk_out = nullptr;
     hipStream_t stream_pm = nullptr;
     hipEvent_t ev_pm_ready = nullptr, ev_pm_done = nullptr;
+    /* the pair kernel of the sparse subtrees runs beside the main walk on this stream (lowest priority: when both have workgroups
+     * pending, the main walk's go first) */
+    hipStream_t stream_pair = nullptr;
+    hipEvent_t ev_pair_fork = nullptr, ev_pair_join = nullptr;
     bool pm_pending = false;
     bool pm_overlap = false;
     bool treepm_fuse = true;   /* SHQ_TREEPM_FUSE: shq_treepm_step may fuse the readout into the walk */
@@ -408,6 +412,7 @@ struct shq_context {
     int walk_sparse = 1;              /* SHQ_WALK_SPARSE (0: the main walk enters every subtree itself; 2: pair kernel on full records) */
     DevBuf<int> node_lean_bad;        /* [0] != 0: some record's second half is not reproducible from {mass, len} (fill_rcuthl_kernel) */
     bool node_lean_checked = false;
+    int walk_overlap = 1;             /* SHQ_WALK_OVERLAP: the pair kernel beside the main walk (second stream) instead of behind it */
     bool sp_check_pending = false;
     int xcd_k = 32;            /* SHQ_XCD_K: blocks per XCD chunk in the remap (0 = off); 32 measured best (2 %) */
     float last_walk_ms = 0;

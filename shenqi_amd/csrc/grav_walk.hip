@@ -75,6 +75,7 @@ struct WalkArgs {
     int4 *sp_stack;              /* pair kernel: SHQ_SPARSE_STACK pairs per resident wave */
     int *sp_overflow;
     unsigned int *sp_task;       /* pair kernel: task counter */
+    int sp_live;                 /* the pair kernel runs BESIDE the main walk (second stream) and takes a task once sp_count[task] >= 0 */
     const int *sp_lean_bad;      /* pair kernel: *sp_lean_bad == 0 says fill_rcuthl_kernel found every record's products reproducible from
                                     {mass, len} by lean_products() below (null: not checked) */
 };
@@ -209,6 +210,12 @@ __device__ __forceinline__ WalkArgsK walk_cold_args()
     return kp;
 }
 
+/* What the main walk hands to the pair kernel while both run (results of a task, its noted subtrees, OldAcc) crosses XCDs, whose L2s
+ * are not coherent with each other inside a launch: those few stores and loads go to the device's coherence point (agent-scope
+ * relaxed atomics: sc1), ordered by the wave's own s_waitcnt and the task's flag; everything else stays cached as before */
+template <typename T> __device__ __forceinline__ void agent_store(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ T agent_load(const T *p) { return __hip_atomic_load(const_cast<T *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 /* returns the next task of this wave (wave-uniform), or -1 when all eight regions are exhausted */
 __device__ __forceinline__ int walk_next_task(WalkArgsK c, int &region, int &tried)
 {
@@ -324,7 +331,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
                     s += ax * ax;
                 }
                 const double oa = sqrt(s) / c.G;
-                c.oldacc_out[pi] = oa;
+                if(SPARSE)
+                    agent_store(&c.oldacc_out[pi], oa);
+                else
+                    c.oldacc_out[pi] = oa;
                 aold = c.errtol * oa;
             } else
                 aold = c.errtol * c.oldacc[pi];
@@ -509,9 +519,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
                     /* few lanes want this subtree: note it and pass on, as if they had accepted the node (its own monopole was
                      * evaluated above for the lanes that accept it; the lanes in the mask OPEN it: the pair kernel starts at its
                      * first child) */
-                    if(lane == 0)
-                        walk_cold_args()->sp_items[wave * SHQ_SPARSE_CAP + sp_n] =
-                            make_int4(nd.child, nd.sibling, (int) (unsigned) descendm, (int) (unsigned) (descendm >> 32));
+                    if(lane == 0) {
+                        unsigned long long *const it = reinterpret_cast<unsigned long long *>(walk_cold_args()->sp_items + (wave * SHQ_SPARSE_CAP + sp_n));
+                        agent_store(it, ((unsigned long long) (unsigned) nd.sibling << 32) | (unsigned) nd.child);
+                        agent_store(it + 1, descendm);
+                    }
                     sp_n++;
                     descendm = 0ull;
                 }
@@ -554,15 +566,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
     {
     const WalkArgs c = PERSIST ? *walk_cold_args() : a;
     if(valid) {
-        c.acc[3 * pi + 0] = ax;
-        c.acc[3 * pi + 1] = ay;
-        c.acc[3 * pi + 2] = az;
-        if(POT)
-            c.pot[pi] = pot;
-        c.nint[pi] = nint;
+        if(SPARSE) {
+            agent_store(&c.acc[3 * pi + 0], ax);
+            agent_store(&c.acc[3 * pi + 1], ay);
+            agent_store(&c.acc[3 * pi + 2], az);
+            if(POT)
+                agent_store(&c.pot[pi], pot);
+            agent_store(&c.nint[pi], (int32_t) nint);
+        } else {
+            c.acc[3 * pi + 0] = ax;
+            c.acc[3 * pi + 1] = ay;
+            c.acc[3 * pi + 2] = az;
+            if(POT)
+                c.pot[pi] = pot;
+            c.nint[pi] = nint;
+        }
     }
-    if(SPARSE && lane == 0)
-        c.sp_count[wave] = sp_n;
+    if(SPARSE) { /* the task's flag, behind everything the pair kernel reads of it */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if(lane == 0)
+            agent_store(&c.sp_count[wave], (int32_t) sp_n);
+    }
     /* statistics (treewalk2.h:446-448 interaction min/max) */
     long long mn = valid ? (long long) nint : __double_as_longlong(sconst(__longlong_as_double(0x7fffffffffffll))), mx = valid ? nint : 0, sm = valid ? nint : 0;
     for(int off = 32; off > 0; off >>= 1) {
@@ -639,14 +663,18 @@ __device__ __forceinline__ LeanProducts lean_products(double mass, double len, d
 /* level of a node whose side is rootlen 2^-level: same mantissa, so the high words differ by level << 20 */
 __device__ __forceinline__ int lean_level(double rootlen, double len) { return (__double2hiint(rootlen) - __double2hiint(len)) >> 20; }
 
-template <bool POT>
-__global__ __launch_bounds__(64 * SHQ_PAIR_WAVES) __attribute__((amdgpu_waves_per_eu(SHQ_PAIR_EU, SHQ_PAIR_EU))) void grav_pair_kernel(const WalkArgs a)
+/* waves_per_eu(6, 6) is there for the register budget it implies (80): the four-wave build, which shares its SIMDs with the main walk,
+ * cannot reach six waves by itself (its LDS), which the compiler remarks on */
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"
+template <bool POT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SHQ_PAIR_EU, SHQ_PAIR_EU))) void grav_pair_kernel(const WalkArgs a)
 {
     /* 8 waves share one window table: 52 KB per workgroup, three of them (24 waves) per CU */
     __shared__ double4 tab[SHQ_NGRAVTAB];
-    __shared__ double4 tgt_all[SHQ_PAIR_WAVES][64];   /* px, py, pz, errtol * OldAcc of the task's targets */
-    __shared__ double acc_all[SHQ_PAIR_WAVES][4][64]; /* ax, ay, az, pot per target */
-    __shared__ int cnt_all[SHQ_PAIR_WAVES][64];       /* interaction count per target */
+    __shared__ double4 tgt_all[WAVES][64];   /* px, py, pz, errtol * OldAcc of the task's targets */
+    __shared__ double acc_all[WAVES][4][64]; /* ax, ay, az, pot per target */
+    __shared__ int cnt_all[WAVES][64];       /* interaction count per target */
     __shared__ double bh_lvl[32];                     /* len^2 / theta^2 by tree level */
     const double rootlen = a.Box * 1.001;             /* forcetree.cpp:661 */
     if(threadIdx.x < 32) {
@@ -664,24 +692,49 @@ __global__ __launch_bounds__(64 * SHQ_PAIR_WAVES) __attribute__((amdgpu_waves_pe
     double4 *const tgt = tgt_all[wv];
     double(*const acc)[64] = acc_all[wv];
     int *const cntl = cnt_all[wv];
-    int4 *const stack = a.sp_stack + ((size_t) blockIdx.x * SHQ_PAIR_WAVES + wv) * SHQ_SPARSE_STACK;
+    int4 *const stack = a.sp_stack + ((size_t) blockIdx.x * WAVES + wv) * SHQ_SPARSE_STACK;
     const unsigned long long below = (1ull << lane) - 1ull;
     /* tasks in a fixed stride over the resident waves, and ONE set of tallies per wave at the end: a returning atomic on one word
      * completes ~88 times per microsecond chip-wide and three no-return ones on one line take ~12 ns each (MI355X_MICROARCH.md) —
      * per task that was 10 ms for this kernel, whatever it did in between */
     long long w_sum = 0, w_min = 0x7fffffffffffll, w_max = 0;
-    for(long long task = (long long) blockIdx.x * SHQ_PAIR_WAVES + wv; task < a.nwaves; task += (long long) gridDim.x * SHQ_PAIR_WAVES) {
+    /* live (beside the main walk): the next task in order from one counter — the main walk finishes its tasks roughly in order, 9 per
+     * microsecond, and only one of this kernel's workgroups fits a CU beside it: the others start when it ends and share what is left */
+    auto next_task = [&](long long prev) -> long long {
+        if(a.sp_live) {
+            unsigned k = 0;
+            if(lane == 0)
+                k = atomicAdd(a.sp_task, 1u);
+            return (long long) (unsigned) __builtin_amdgcn_readfirstlane((int) k);
+        }
+        return prev < 0 ? (long long) blockIdx.x * WAVES + wv : prev + (long long) gridDim.x * WAVES;
+    };
+    for(long long task = next_task(-1); task < a.nwaves; task = next_task(task)) {
         const long long t = task * 64 + lane;
         const bool valid = t < a.ntargets;
         const long long pi = valid ? (a.targets ? (long long) a.targets[t] : t) : -1;
         const bool have = pi >= 0;
-        const int cnt = a.sp_count[task];
+        int cnt = agent_load(&a.sp_count[task]);
+        if(a.sp_live) {
+            /* beside the main walk: wait for the task (the main walk never waits for this kernel, and every task below nwaves gets its
+             * flag; the bound only keeps a broken launch from hanging the card: ~4 s, then the error flag) */
+            for(unsigned spin = 0; cnt < 0 && spin < (1u << 22); spin++) {
+                __builtin_amdgcn_s_sleep(32);
+                cnt = agent_load(&a.sp_count[task]);
+            }
+            cnt = __builtin_amdgcn_readfirstlane(cnt);
+            if(cnt < 0) {
+                if(lane == 0)
+                    agent_store(a.sp_overflow, 3);
+                break;
+            }
+        }
         int sp = 0;
         if(cnt > 0) {
             double4 me = make_double4(0, 0, 0, 0);
             if(have) {
                 const double4 p = a.posm[pi];
-                me = make_double4(p.x, p.y, p.z, a.errtol * a.oldacc[pi]);
+                me = make_double4(p.x, p.y, p.z, a.errtol * agent_load(&a.oldacc[pi]));
             }
             tgt[lane] = me;
             for(int k = 0; k < 4; k++)
@@ -691,8 +744,11 @@ __global__ __launch_bounds__(64 * SHQ_PAIR_WAVES) __attribute__((amdgpu_waves_pe
              * time, one per lane (one trip to memory, not one per item), and handed round with readlane */
             for(int k0 = 0; k0 < cnt; k0 += 64) {
                 int4 mine = make_int4(0, 0, 0, 0);
-                if(k0 + lane < cnt)
-                    mine = a.sp_items[task * SHQ_SPARSE_CAP + k0 + lane];
+                if(k0 + lane < cnt) {
+                    const unsigned long long *const it = reinterpret_cast<const unsigned long long *>(a.sp_items + (task * SHQ_SPARSE_CAP + k0 + lane));
+                    const unsigned long long lo = agent_load(it), hi = agent_load(it + 1);
+                    mine = make_int4((int) (unsigned) lo, (int) (unsigned) (lo >> 32), (int) (unsigned) hi, (int) (unsigned) (hi >> 32));
+                }
                 const int kn = cnt - k0 < 64 ? cnt - k0 : 64;
                 for(int k = 0; k < kn; k++) {
                     const int ix = __builtin_amdgcn_readlane(mine.x, k), iy = __builtin_amdgcn_readlane(mine.y, k);
@@ -830,14 +886,14 @@ __global__ __launch_bounds__(64 * SHQ_PAIR_WAVES) __attribute__((amdgpu_waves_pe
         /* add to what the main walk stored, and tally */
         long long nint = 0;
         if(have) {
-            nint = a.nint[pi];
+            nint = agent_load(&a.nint[pi]);
             if(cnt > 0) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                a.acc[3 * pi + 0] += acc[0][lane];
-                a.acc[3 * pi + 1] += acc[1][lane];
-                a.acc[3 * pi + 2] += acc[2][lane];
+                a.acc[3 * pi + 0] = agent_load(&a.acc[3 * pi + 0]) + acc[0][lane];
+                a.acc[3 * pi + 1] = agent_load(&a.acc[3 * pi + 1]) + acc[1][lane];
+                a.acc[3 * pi + 2] = agent_load(&a.acc[3 * pi + 2]) + acc[2][lane];
                 if(POT)
-                    a.pot[pi] += acc[3][lane];
+                    a.pot[pi] = agent_load(&a.pot[pi]) + acc[3][lane];
                 nint += (long long) cntl[lane];
                 a.nint[pi] = (int32_t) nint;
             }
@@ -860,6 +916,8 @@ __global__ __launch_bounds__(64 * SHQ_PAIR_WAVES) __attribute__((amdgpu_waves_pe
         atomicMax(&a.stats->max_int, w_max);
     }
 }
+
+#pragma clang diagnostic pop
 
 /* GravTreeOutput::postprocess, gravshort2.hpp:88-107 */
 __global__ void grav_postprocess_kernel(const int32_t *targets, long long ntargets, const double4 *posm, double *acc,
@@ -1060,6 +1118,7 @@ static void fill_walk_args(shq_context *ctx, const shq_grav_params *p, WalkArgs 
     a.sp_stack = nullptr;
     a.sp_overflow = nullptr;
     a.sp_lean_bad = nullptr;
+    a.sp_live = 0;
     a.sp_task = nullptr;
     a.nwaves = 0;
     a.task_run_log2 = 7;
@@ -1178,11 +1237,16 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     const bool ring = persist && ctx->walk_ring && bpc == 8;
     /* sparse subtrees to the pair kernel (SHQ_WALK_SPARSE): the production launch with the relative criterion only */
     const bool sparse = ring && ctx->walk_sparse && !p->TreeUseBH;
-    const long long pair_blocks = (long long) ctx->num_cus * SHQ_PAIR_WG_PER_CU;
+    /* SHQ_WALK_OVERLAP: the pair kernel beside the main walk instead of behind it — the main walk saturates the vector ALUs with six
+     * waves per SIMD as well as with eight (29.6 against 29.9 ms), the pair kernel waits for memory: three workgroups of the main walk
+     * and one of the pair kernel per CU, the pair kernel on the second stream taking a task when its flag is up */
+    const bool live = sparse && ctx->walk_overlap && !ctx->pm_overlap && ctx->stream_pair && ctx->ev_pair_fork && ctx->ev_pair_join && !stats &&
+                      (ctx->walk_overlap == 2 || nwaves >= (long long) ctx->num_cus * 32 * 4); /* 2: whatever the size (tests) */
+    const long long pair_blocks = (long long) ctx->num_cus * (live ? 4 : SHQ_PAIR_WG_PER_CU); /* live: of four waves */
     if(sparse) {
         SHQ_TRY(ctx->sp_items.reserve((size_t) nwaves * SHQ_SPARSE_CAP));
         SHQ_TRY(ctx->sp_count.reserve((size_t) nwaves));
-        SHQ_TRY(ctx->sp_stack.reserve((size_t) pair_blocks * SHQ_PAIR_WAVES * SHQ_SPARSE_STACK));
+        SHQ_TRY(ctx->sp_stack.reserve((size_t) pair_blocks * (live ? 4 : SHQ_PAIR_WAVES) * SHQ_SPARSE_STACK));
         SHQ_TRY(ctx->sp_flags.reserve(32));
         SHQ_HIP(hipMemsetAsync(ctx->sp_flags.ptr, 0, sizeof(int) * 32, ctx->stream));
         a.sp_items = ctx->sp_items.ptr;
@@ -1190,6 +1254,10 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
         a.sp_stack = ctx->sp_stack.ptr;
         a.sp_overflow = ctx->sp_flags.ptr;
         a.sp_lean_bad = ctx->node_lean_checked && ctx->walk_sparse != 2 ? ctx->node_lean_bad.ptr : nullptr;
+        if(live) {
+            SHQ_HIP(hipMemsetAsync(ctx->sp_count.ptr, 0xff, sizeof(int32_t) * (size_t) nwaves, ctx->stream));
+            a.sp_live = 1;
+        }
         a.sp_task = reinterpret_cast<unsigned int *>(ctx->sp_flags.ptr + 16);
         a.nwaves = nwaves;
     }
@@ -1209,7 +1277,7 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
          * measured: 34.3 against 34.0 ms run by run, 35.2 task by task.  Runs that follow each other in the box share their
          * nodes in the scalar cache, and the tail is short anyway: the last waves have their SIMD to themselves.) */
         const long long wpb = ring ? 8 : 4;                                   /* waves per workgroup */
-        const long long need = (nwaves + wpb - 1) / wpb, resident = (long long) ctx->num_cus * (ring ? 4 : bpc);
+        const long long need = (nwaves + wpb - 1) / wpb, resident = (long long) ctx->num_cus * (ring ? (live ? 3 : 4) : bpc);
         launch_blocks = need < resident ? need : resident;
         /* fewer than 8 resident workgroups per CU are enforced through the LDS allocation (160 KB per CU), not left to the dispatcher */
         if(bpc < 8)
@@ -1256,6 +1324,8 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     }
     const dim3 grid((unsigned) launch_blocks), block(ring ? 512 : threads);
     SHQ_HIP(hipEventRecord(ctx->ev_begin[SHQ_NTIMERS - 1], ctx->stream));
+    if(live) /* what precedes the walk on this stream (the PM, the flags' reset) also precedes the pair kernel on the other */
+        SHQ_HIP(hipEventRecord(ctx->ev_pair_fork, ctx->stream));
     if(update_potential) {
         switch(variant) {
         case 0: launch_variant<true, false, 4>(stats, persist, grid, block, ctx->stream, a); break;
@@ -1273,11 +1343,26 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     }
     SHQ_HIP(hipGetLastError());
     if(sparse) { /* the noted subtrees, one lane per (target, node) pair; inside the walk's timer */
-        if(update_potential)
-            grav_pair_kernel<true><<<dim3((unsigned) pair_blocks), dim3(64 * SHQ_PAIR_WAVES), 0, ctx->stream>>>(a);
+        /* live: submitted AFTER the main walk, which never waits for it — if the two are run one after the other after all (a
+         * profiler collecting counters serialises dispatches) the pair kernel finds every flag up */
+        hipStream_t ps = live ? ctx->stream_pair : ctx->stream;
+        if(live)
+            SHQ_HIP(hipStreamWaitEvent(ps, ctx->ev_pair_fork, 0));
+        const dim3 pg((unsigned) pair_blocks);
+        if(live) { /* workgroups of four waves, one per SIMD: 6 x 64 registers of the main walk + 80 */
+            if(update_potential)
+                grav_pair_kernel<true, 4><<<pg, dim3(256), 0, ps>>>(a);
+            else
+                grav_pair_kernel<false, 4><<<pg, dim3(256), 0, ps>>>(a);
+        } else if(update_potential)
+            grav_pair_kernel<true, SHQ_PAIR_WAVES><<<pg, dim3(64 * SHQ_PAIR_WAVES), 0, ps>>>(a);
         else
-            grav_pair_kernel<false><<<dim3((unsigned) pair_blocks), dim3(64 * SHQ_PAIR_WAVES), 0, ctx->stream>>>(a);
+            grav_pair_kernel<false, SHQ_PAIR_WAVES><<<pg, dim3(64 * SHQ_PAIR_WAVES), 0, ps>>>(a);
         SHQ_HIP(hipGetLastError());
+        if(live) {
+            SHQ_HIP(hipEventRecord(ctx->ev_pair_join, ps));
+            SHQ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_pair_join, 0));
+        }
         ctx->sp_check_pending = true;
     }
     SHQ_HIP(hipEventRecord(ctx->ev_end[SHQ_NTIMERS - 1], ctx->stream));

@@ -107,7 +107,14 @@ def test_walk_launch_modes_agree_and_match_the_oracle(ctx, kind, usebh):
         lean = capi.hip.shq_walk_pair_lean(ctx.h)
         capi.check(capi.hip.shq_set_walk_sparse(ctx.h, 2))
         res[(2, 1, "whole records")] = _gpu_walk(ctx, pman, tree, gp, (told, pold))
+        # the pair kernel beside the main walk (second stream, a flag per task) and behind it: the same sums in the same order
+        capi.check(capi.hip.shq_set_walk_sparse(ctx.h, 1))
+        capi.check(capi.hip.shq_set_walk_overlap(ctx.h, 2))
+        res[(2, 1, "beside")] = _gpu_walk(ctx, pman, tree, gp, (told, pold))
+        capi.check(capi.hip.shq_set_walk_overlap(ctx.h, 0))
+        res[(2, 1, "behind")] = _gpu_walk(ctx, pman, tree, gp, (told, pold))
     finally:
+        capi.check(capi.hip.shq_set_walk_overlap(ctx.h, 1))
         capi.check(capi.hip.shq_set_walk_launch(ctx.h, 1, 1))
         capi.check(capi.hip.shq_set_walk_sparse(ctx.h, 1))
     scale = np.abs(oacc).max()
@@ -122,6 +129,7 @@ def test_walk_launch_modes_agree_and_match_the_oracle(ctx, kind, usebh):
     assert lean == 1
     for k in range(3):
         assert np.array_equal(res[(2, 1)][k], res[(2, 1, "whole records")][k]), k
+        assert np.array_equal(res[(2, 1, "beside")][k], res[(2, 1, "behind")][k]), k
     assert np.array_equal(asub[2][sub], onint[sub])
     assert np.abs(asub[0][sub] - oacc[sub]).max() < 1e-11 * scale
 

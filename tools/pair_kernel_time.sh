@@ -8,5 +8,11 @@ rm -rf $OUT/ps
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ps -o s -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sph > $OUT/ps.log 2>&1
 f=$(find $OUT/ps -name "*kernel_stats.csv" | head -1)
 echo "== ${1:-tree}"
-grep "grav_pair_kernel\|grav_walk_exact_kernel<true, false, 2, 0, false, false, true, true, true, true" "$f" | cut -d, -f1-4 | sed 's/(anonymous namespace):://; s/(.*)"/"/' | cut -c1-150
+python3 - "$f" <<PY
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+    if n.startswith("grav_pair_kernel") or n.startswith("grav_walk_exact_kernel"):
+        print("%-95s %3s calls  %.3f ms" % (n[:n.find("(")] if "(" in n else n, r["Calls"], float(r["AverageNs"]) / 1e6))
+PY
 rm -rf $OUT/ps
