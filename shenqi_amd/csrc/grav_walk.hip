@@ -246,7 +246,9 @@ __device__ __forceinline__ int walk_next_task(WalkArgsK c, int &region, int &tri
 #ifndef SHQ_SPARSE_LANES
 #define SHQ_SPARSE_LANES 8     /* a subtree entered by at most this many lanes goes to the pair kernel */
 #endif
+#ifndef SHQ_SPARSE_CAP
 #define SHQ_SPARSE_CAP 96      /* ... while the task has a free slot (31.7 per task on average at 256^3) */
+#endif
 #define SHQ_SPARSE_STACK 16384 /* pairs per resident wave of the pair kernel */
 /* the pair kernel's workgroups: waves per workgroup (one window table each), workgroups per CU, waves per SIMD */
 #ifndef SHQ_PAIR_WAVES
