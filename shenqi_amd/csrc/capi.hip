@@ -973,6 +973,7 @@ extern "C" int shq_grav_short_download(shq_context *ctx, double (*accel)[3], dou
         SHQ_HIP(hipMemcpyAsync(&flag, ctx->sp_flags.ptr, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         SHQ_HIP(hipStreamSynchronize(ctx->stream));
         ctx->sp_check_pending = false;
+        SHQ_CHECK(flag != 3, SHQ_ERR_DEVICE, "grav walk: the pair kernel gave up waiting for a task of the main walk beside it (SHQ_WALK_OVERLAP=0 runs it behind the walk)");
         SHQ_CHECK(flag == 0, SHQ_ERR_DEVICE, "grav walk: a pair stack of the sparse-subtree kernel overflowed (SHQ_WALK_SPARSE=0 avoids the kernel)");
     }
     const int64_t n = ctx->numpart;
