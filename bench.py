@@ -842,7 +842,10 @@ def main():
                              "peak; valu_busy = SQ_INSTS_VALU x 4 / resident SIMD cycles from the committed SQ pass; `traffic` = HBM "
                              "bytes per launch of the production walk from the committed FETCH_SIZE / WRITE_SIZE passes (several "
                              "times the compulsory bytes, still a fraction of a TB/s: not a bandwidth problem).  The HBM-bound part "
-                             "of the step is the PM: roofline_pm_fft"}
+                             "of the step is the PM: roofline_pm_fft.  Kernel time = one HIP-event bracket on the walk's stream around "
+                             "grav_walk_exact_kernel and grav_pair_kernel, which runs beside it on a second stream and is waited for "
+                             "before the closing event (both start within 10 us, the pair kernel ends ~0.3 ms after the walk: "
+                             "profiles/README.md); the interactions counted are those of both"}
     out = {
         "metric": "particle-steps/sec (grav+PM+SPH) at 256^3; rms force error vs ref",
         "value": n * world * args.steps / elapsed,
