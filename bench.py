@@ -779,6 +779,10 @@ def main():
     capi.check(capi.hip.shq_treepm_last_fused(ctx.h, C.byref(fused)))
     step_route = ("shq_treepm_step: PM readout + OldAcc refresh in the walk's task prologue" if fused.value and not args.separate_calls and args.walk_mode == 0
                   else "shq_pm_run + shq_grav_refresh_oldacc + shq_grav_short_run")
+    # the pair kernel's sticky status after the timed loop (no download inside it): launches the mop-up pass had to finish, the
+    # deepest pair stack; an overflow in any of the timed steps comes back here as an error
+    pair_rec, pair_high, pair_mop = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    capi.check(capi.hip.shq_walk_pair_status(ctx.h, C.byref(pair_rec), C.byref(pair_high), C.byref(pair_mop)))
     capi.check(capi.hip.shq_set_walk_stats(ctx.h, 1))
     step(gp_rel, one_call=False)
     capi.check(capi.hip.shq_grav_refresh_oldacc(ctx.h, G))   # the OldAcc of the NEXT step, for the checks below
@@ -869,6 +873,7 @@ def main():
                                     "five passes at that rate would take 8.1 ms"},
         "kernels": {
             "tree_walk_ms": st.kernel_ms, "tree_walk_with_counters_ms": counted_walk_ms,
+            "pair_kernel_recovered_launches": int(pair_rec.value), "pair_kernel_stack_high_water": int(pair_high.value),
             "pair_kernel_lean_records": bool(capi.hip.shq_walk_pair_lean(ctx.h) == 1), "tree_interactions_per_target": st.ninteractions / max(1, st.ntargets),
             "tree_interactions_per_s": st.ninteractions / max(walk_s, 1e-12),
             "tree_fp64_frac_of_vector_peak": 45.0 * st.ninteractions / max(walk_s, 1e-12) / 1e12 / FP64_VECTOR_PEAK_TF,

@@ -652,6 +652,20 @@ int shq_walk_pair_lean(shq_context *ctx);
  * the main walk has raised its flag (results, noted subtrees and OldAcc cross at the device's coherence point); 0 behind it on the
  * same stream; 2 beside it whatever the size of the launch (tests).  Same interaction sets and the same sums in every mode. */
 int shq_set_walk_overlap(shq_context *ctx, int mode);
+/* The pair kernel's failures are STICKY and loud (the reference checks every launch and ends the run, treewalk2.cuh:351-353).
+ *  - A pair stack that ran full dropped pairs: the accelerations of that launch are incomplete.  The error word stays up on the device
+ *    whatever is launched afterwards; a copy follows every launch to pinned host memory, and shq_synchronize, every *_download,
+ *    shq_kick_short, shq_hier_refine, shq_walk_pair_status (which wait for the stream) and the next shq_treepm_step /
+ *    shq_grav_short_run (which do not: they see the launches completed by then) return SHQ_ERR_DEVICE once; the report clears it.
+ *  - A wave of the pair kernel running BESIDE the main walk that gave up waiting for a task (the two kernels were not co-resident:
+ *    nothing in HIP promises they are) is not an error any more: a mop-up pass behind both kernels walks every task not marked done,
+ *    in the order of the pair kernel run behind the walk (same sums, same bits).  It returns at once when nobody gave up.
+ * shq_walk_pair_status: launches since shq_init that needed the mop-up pass, the deepest pair stack seen (entries, of SHQ_SPARSE_STACK
+ * = 4096 per wave), the tasks the last launch's mop-up walked; waits for the stream and returns the sticky error like the others.
+ * shq_set_walk_debug (tests): pair_spin_max > 0 = polls of a task's flag before a live pair wave gives up (default 2^22; 1 starves
+ * it: every task goes to the mop-up pass); pair_stack_cap > 0 = pairs per wave stack (704 .. 4096; small values force the overflow). */
+int shq_walk_pair_status(shq_context *ctx, int64_t *recovered_launches, int64_t *stack_high_water, int64_t *last_mopped_tasks);
+int shq_set_walk_debug(shq_context *ctx, int pair_spin_max, int pair_stack_cap);
 /* Checker utility: direct summation as the reference's own gravity test does it (force_direct / grav_force,
  * libgadget/tests/test_gravity.cpp:41-76,121-143): accel[ns][3] (host) = acceleration at the ns sample positions (host, [ns][3]) from
  * the first nsrc resident particles and their (2 repeat + 1)^3 periodic images, spline-softened below h.  Partial sums over a

@@ -450,6 +450,10 @@ hip.shq_walk_pair_lean.argtypes = [_vp]
 hip.shq_walk_pair_lean.restype = C.c_int
 hip.shq_set_walk_overlap.argtypes = [_vp, C.c_int]
 hip.shq_set_walk_overlap.restype = C.c_int
+hip.shq_walk_pair_status.argtypes = [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+hip.shq_walk_pair_status.restype = C.c_int
+hip.shq_set_walk_debug.argtypes = [_vp, C.c_int, C.c_int]
+hip.shq_set_walk_debug.restype = C.c_int
 hip.shq_direct_force_sample.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int, _vp]
 hip.shq_direct_force_sample.restype = C.c_int
 hip.shq_exchange_plan.argtypes = [_vp, C.POINTER(ExchangeLayout), _vp, C.c_int64, _vp, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _vp]

@@ -222,6 +222,7 @@ extern "C" void shq_shutdown(shq_context *ctx)
     shq_pm_destroy_plans(ctx);
     ctx->posm.release(); ctx->oldacc.release(); ctx->treeacc.release(); ctx->gravpm.release();
     ctx->pmpot.release(); ctx->acc.release(); ctx->pot.release(); ctx->nint.release(); ctx->walk_tasks.release();
+    ctx->sp_items.release(); ctx->sp_stack.release(); ctx->sp_count.release(); ctx->sp_flags.release(); ctx->sp_host.release(); ctx->node_lean_bad.release();
     ctx->pflags.release(); ctx->active.release(); ctx->act_list.release(); ctx->act_sub.release(); ctx->act_counts.release(); ctx->act_temp.release(); ctx->act_flag.release();
     ctx->gq_res.release(); ctx->s_queue0.release(); ctx->s_nlist2.release(); ctx->topnodes.release(); ctx->topleaves.release(); ctx->top_counts.release(); ctx->top_table.release(); ctx->gstats.release(); ctx->nodeF.release(); ctx->walk_counters.release(); ctx->walk_pool_idx.release(); ctx->walk_pool_msk.release(); ctx->walk_chunk_cnt.release(); ctx->walk_chunk_next.release(); ctx->walk_group_head.release();
     ctx->nodeA.release(); ctx->nodeB.release(); ctx->nodeC.release(); ctx->nodeG.release();
@@ -335,7 +336,8 @@ extern "C" int shq_synchronize(shq_context *ctx)
     SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
     SHQ_TRY(shq_join_pm(ctx));
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
-    return SHQ_OK;
+    ctx->sp_check_pending = false;
+    return shq_walk_check_status(ctx, false);
 }
 
 extern "C" void *shq_stream(shq_context *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
@@ -752,6 +754,7 @@ extern "C" int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree)
     ctx->node_rcut = -1;
     ctx->have_group_aux = false;
     ctx->tb_built = false;
+    SHQ_TRY(shq_walk_prereserve(ctx));
     ctx->have_tree_targets = false;
     return SHQ_OK;
 }
@@ -825,6 +828,7 @@ extern "C" int shq_grav_short_run(shq_context *ctx, const shq_grav_params *param
     SHQ_CHECK(ctx && params, SHQ_ERR_INVALID, "null argument");
     SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "grav_short_run: upload particles and tree first");
     SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_walk_check_status(ctx, false));
     const int32_t *d_active = nullptr;
     int64_t nt = 0;
     if((walk_mode & SHQ_WALK_TREE_ORDER) && !active) {
@@ -968,14 +972,7 @@ extern "C" int shq_grav_short_download(shq_context *ctx, double (*accel)[3], dou
     SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
     SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "nothing to download");
     SHQ_HIP(hipSetDevice(ctx->device));
-    if(ctx->sp_check_pending) { /* the pair kernel's stacks are sized for any tree the build accepts; a full one must not pass silently */
-        int flag = 0;
-        SHQ_HIP(hipMemcpyAsync(&flag, ctx->sp_flags.ptr, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        SHQ_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->sp_check_pending = false;
-        SHQ_CHECK(flag != 3, SHQ_ERR_DEVICE, "grav walk: the pair kernel gave up waiting for a task of the main walk beside it (SHQ_WALK_OVERLAP=0 runs it behind the walk)");
-        SHQ_CHECK(flag == 0, SHQ_ERR_DEVICE, "grav walk: a pair stack of the sparse-subtree kernel overflowed (SHQ_WALK_SPARSE=0 avoids the kernel)");
-    }
+    SHQ_TRY(shq_walk_check_status(ctx, true)); /* a pair stack that ran full in ANY launch since the last report, not just the last one */
     const int64_t n = ctx->numpart;
     if(accel && n > 0)
         SHQ_HIP(hipMemcpyAsync(accel, ctx->acc.ptr, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1215,6 +1212,7 @@ extern "C" int shq_treepm_step(shq_context *ctx, const shq_pm_params *pm, const 
     SHQ_CHECK(ctx->have_parts && ctx->have_tree, SHQ_ERR_STATE, "treepm_step: upload particles and tree first");
     SHQ_CHECK((walk_mode & ~SHQ_WALK_TREE_ORDER) == SHQ_WALK_EXACT, SHQ_ERR_INVALID, "treepm_step: walk_mode is SHQ_WALK_EXACT, optionally | SHQ_WALK_TREE_ORDER");
     SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_walk_check_status(ctx, false)); /* an earlier step of a resident loop whose pair kernel failed: no new step on its forces */
     SHQ_TRY(shq_join_pm(ctx));
     int64_t n = ctx->nlocal;
     const int32_t *d_targets = nullptr;

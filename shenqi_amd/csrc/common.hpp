@@ -408,7 +408,10 @@ struct shq_context {
     DevBuf<unsigned int> walk_tasks; /* the task counters of the persistent walk */
     DevBuf<int4> sp_items, sp_stack;  /* SHQ_WALK_SPARSE: noted subtrees per task, pair stacks of the pair kernel's waves */
     DevBuf<int32_t> sp_count;
-    DevBuf<int> sp_flags;             /* [0] stack overflow, [16] the pair kernel's task counter */
+    DevBuf<int> sp_flags;             /* SpFlag (grav_walk.hip): [0, 8) per launch, [8, 16) sticky, [16] the pair kernel's task counter */
+    PinBuf<int> sp_host;              /* the sticky words as the last completed launch left them */
+    int sp_stack_cap = 0;             /* pairs per pair-kernel wave (0: SHQ_SPARSE_STACK); shq_set_walk_debug */
+    unsigned sp_spin_max = 0;         /* polls before a live pair wave gives up (0: default) */
     int walk_sparse = 1;              /* SHQ_WALK_SPARSE (0: the main walk enters every subtree itself; 2: pair kernel on full records) */
     DevBuf<int> node_lean_bad;        /* [0] != 0: some record's second half is not reproducible from {mass, len} (fill_rcuthl_kernel) */
     bool node_lean_checked = false;
@@ -450,6 +453,9 @@ int shq_launch_grav_postprocess(shq_context *ctx, const shq_grav_params *p, cons
 int shq_launch_oldacc(shq_context *ctx, double G);
 void shq_launch_stats_init(shq_context *ctx);
 void shq_fill_node_walk_params(shq_context *ctx, const shq_grav_params *p);
+int shq_walk_reserve_sparse(shq_context *ctx, long long nwaves);
+int shq_walk_check_status(shq_context *ctx, bool sync);
+int shq_walk_prereserve(shq_context *ctx);
 /* grav_group.hip */
 int shq_launch_grav_walk_group(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets, int update_potential,
                                int64_t first);

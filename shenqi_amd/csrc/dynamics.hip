@@ -512,6 +512,9 @@ extern "C" int shq_kick_short(shq_context *ctx, const double gravkick[SHQ_TIMEBI
     SHQ_HIP(hipSetDevice(ctx->device));
     const double *acc = from_accel_store ? ctx->acc.ptr : ctx->treeacc.ptr;
     SHQ_CHECK(acc, SHQ_ERR_STATE, "kick_short: no accelerations on the device yet");
+    /* no kick on the accelerations of a walk whose pair kernel dropped pairs: waits for a walk still in flight (this call ends with a
+     * synchronisation anyway), free otherwise */
+    SHQ_TRY(shq_walk_check_status(ctx, true));
     KickTab tab;
     memcpy(tab.k, gravkick, sizeof(tab.k));
     const int32_t *d_act = nullptr;

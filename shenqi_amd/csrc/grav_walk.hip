@@ -72,8 +72,11 @@ struct WalkArgs {
      * (slot k of task w: {first node, end node, lane mask}) and grav_pair_kernel walks them with one lane per (target, node) pair */
     int4 *sp_items;
     int32_t *sp_count;
-    int4 *sp_stack;              /* pair kernel: SHQ_SPARSE_STACK pairs per resident wave */
-    int *sp_overflow;
+    int4 *sp_stack;              /* pair kernel: sp_stack_cap pairs per resident wave */
+    int *sp_flags;               /* pair kernel: the status words of SpFlag below */
+    int sp_stack_cap;            /* pairs per resident wave (SHQ_SPARSE_STACK unless a test shrank it) */
+    unsigned sp_spin_max;        /* live: polls of a task's flag before the wave gives up (a test knob starves it) */
+    int sp_mop;                  /* this launch is the mop-up pass behind a live pair kernel (see grav_pair_kernel) */
     unsigned int *sp_task;       /* pair kernel: task counter */
     int sp_live;                 /* the pair kernel runs BESIDE the main walk (second stream) and takes a task once sp_count[task] >= 0 */
     const int *sp_lean_bad;      /* pair kernel: *sp_lean_bad == 0 says fill_rcuthl_kernel found every record's products reproducible from
@@ -249,7 +252,22 @@ __device__ __forceinline__ int walk_next_task(WalkArgsK c, int &region, int &tri
 #ifndef SHQ_SPARSE_CAP
 #define SHQ_SPARSE_CAP 96      /* ... while the task has a free slot (31.7 per task on average at 256^3) */
 #endif
-#define SHQ_SPARSE_STACK 16384 /* pairs per resident wave of the pair kernel */
+#define SHQ_SPARSE_STACK 4096  /* pairs per resident wave of the pair kernel: 9 x the deepest stack seen (443 at 256^3 S-cluster, shq_walk_pair_status) */
+#define SHQ_SPARSE_SPIN (1u << 22)
+/* The pair kernel's status words (ctx->sp_flags).  [0, 8) belong to one launch and are cleared by the next; [8, 16) are STICKY: no
+ * launch clears them, a copy travels to pinned host memory behind every launch, and the library's entry points return SHQ_ERR_DEVICE
+ * once the error word is up (shq_walk_check_status) - the reference checks every launch and ends the run (treewalk2.cuh:351-353). */
+enum SpFlag {
+    SP_OVERFLOW = 0,   /* a wave's pair stack ran full: it dropped pairs (sums incomplete) */
+    SP_GAVEUP = 1,     /* live: a wave gave up waiting for a task's flag; the mop-up pass behind the walk takes what it left */
+    SP_MOPPED = 2,     /* tasks the mop-up pass walked */
+    SP_HIGHWATER = 3,  /* deepest pair stack of the launch */
+    SP_STICKY_ERROR = 8,     /* bit 0: some launch since the last report overflowed a pair stack */
+    SP_STICKY_RECOVERED = 9, /* launches in which the mop-up pass had to finish the live pair kernel's work */
+    SP_STICKY_HIGHWATER = 10,
+    SP_TASK_COUNTER = 16
+};
+#define SP_TASK_DONE (-2)      /* sp_count[task] once the pair kernel has added the task's sums back: a second pass skips it */
 /* the pair kernel's workgroups: waves per workgroup (one window table each), workgroups per CU, waves per SIMD */
 #ifndef SHQ_PAIR_WAVES
 #define SHQ_PAIR_WAVES 8
@@ -678,6 +696,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SHQ_
     __shared__ double acc_all[WAVES][4][64]; /* ax, ay, az, pot per target */
     __shared__ int cnt_all[WAVES][64];       /* interaction count per target */
     __shared__ double bh_lvl[32];                     /* len^2 / theta^2 by tree level */
+    /* The mop-up pass: launched behind every live pair kernel, on the main stream (the main walk and the live pair kernel are through:
+     * every task's flag is up).  Nothing to do unless a live wave gave up waiting (SP_GAVEUP) - then the tasks not marked SP_TASK_DONE
+     * are walked here, in the stride order of the pair kernel run behind the walk: same sums, same order per task. */
+    if(a.sp_mop && agent_load(a.sp_flags + SP_GAVEUP) == 0)
+        return;
     const double rootlen = a.Box * 1.001;             /* forcetree.cpp:661 */
     if(threadIdx.x < 32) {
         const double l = ldexp(rootlen, -(int) threadIdx.x);
@@ -694,7 +717,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SHQ_
     double4 *const tgt = tgt_all[wv];
     double(*const acc)[64] = acc_all[wv];
     int *const cntl = cnt_all[wv];
-    int4 *const stack = a.sp_stack + ((size_t) blockIdx.x * WAVES + wv) * SHQ_SPARSE_STACK;
+    int4 *const stack = a.sp_stack + ((size_t) blockIdx.x * WAVES + wv) * (size_t) a.sp_stack_cap;
+    int sp_high = 0;
+    int mopped = 0;
     const unsigned long long below = (1ull << lane) - 1ull;
     /* tasks in a fixed stride over the resident waves, and ONE set of tallies per wave at the end: a returning atomic on one word
      * completes ~88 times per microsecond chip-wide and three no-return ones on one line take ~12 ns each (MI355X_MICROARCH.md) —
@@ -717,17 +742,22 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SHQ_
         const long long pi = valid ? (a.targets ? (long long) a.targets[t] : t) : -1;
         const bool have = pi >= 0;
         int cnt = agent_load(&a.sp_count[task]);
+        if(a.sp_mop) {
+            if(__builtin_amdgcn_readfirstlane(cnt) == SP_TASK_DONE)
+                continue;
+            mopped++;
+        }
         if(a.sp_live) {
             /* beside the main walk: wait for the task (the main walk never waits for this kernel, and every task below nwaves gets its
              * flag; the bound only keeps a broken launch from hanging the card: ~4 s, then the error flag) */
-            for(unsigned spin = 0; cnt < 0 && spin < (1u << 22); spin++) {
+            for(unsigned spin = 0; cnt < 0 && spin < a.sp_spin_max; spin++) {
                 __builtin_amdgcn_s_sleep(32);
                 cnt = agent_load(&a.sp_count[task]);
             }
             cnt = __builtin_amdgcn_readfirstlane(cnt);
             if(cnt < 0) {
                 if(lane == 0)
-                    agent_store(a.sp_overflow, 3);
+                    agent_store(a.sp_flags + SP_GAVEUP, 1);
                 break;
             }
         }
@@ -877,9 +907,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SHQ_
                 }
                 sp += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3);
             }
-            if(sp > SHQ_SPARSE_STACK - 640) { /* cannot happen for trees of <= 21 levels and <= SHQ_SPARSE_CAP x 8 starting pairs; loud if it does */
-                if(lane == 0)
-                    *a.sp_overflow = 1;
+            sp_high = sp > sp_high ? sp : sp_high;
+            if(sp > a.sp_stack_cap - 640) { /* never seen (SP_HIGHWATER is reported); loud and sticky if it happens: the pairs are dropped */
+                if(lane == 0) {
+                    agent_store(a.sp_flags + SP_OVERFLOW, 1);
+                    atomicOr(a.sp_flags + SP_STICKY_ERROR, 1);
+                }
                 sp = 0;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -910,6 +943,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SHQ_
         w_sum += sm;
         w_min = mn < w_min ? mn : w_min;
         w_max = mx > w_max ? mx : w_max;
+        /* the task is through: a second pass (the mop-up behind a live kernel that gave up somewhere) must not add its sums again */
+        if(lane == 0)
+            agent_store(&a.sp_count[task], (int32_t) SP_TASK_DONE);
         __builtin_amdgcn_wave_barrier();
     }
     if(lane == 0 && a.stats) {
@@ -917,6 +953,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SHQ_
         atomicMin(&a.stats->min_int, w_min);
         atomicMax(&a.stats->max_int, w_max);
     }
+    if(lane == 0 && sp_high > 0) {
+        atomicMax(a.sp_flags + SP_HIGHWATER, sp_high);
+        atomicMax(a.sp_flags + SP_STICKY_HIGHWATER, sp_high);
+    }
+    if(lane == 0 && mopped > 0)
+        atomicAdd(a.sp_flags + SP_MOPPED, mopped);
+    if(a.sp_mop && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicAdd(a.sp_flags + SP_STICKY_RECOVERED, 1);
 }
 
 #pragma clang diagnostic pop
@@ -1118,7 +1162,10 @@ static void fill_walk_args(shq_context *ctx, const shq_grav_params *p, WalkArgs 
     a.sp_items = nullptr;
     a.sp_count = nullptr;
     a.sp_stack = nullptr;
-    a.sp_overflow = nullptr;
+    a.sp_flags = nullptr;
+    a.sp_stack_cap = SHQ_SPARSE_STACK;
+    a.sp_spin_max = SHQ_SPARSE_SPIN;
+    a.sp_mop = 0;
     a.sp_lean_bad = nullptr;
     a.sp_live = 0;
     a.sp_task = nullptr;
@@ -1185,6 +1232,97 @@ bool shq_walk_can_fuse_readout(shq_context *ctx, const shq_grav_params *p, const
            ctx->mesh_words < (1ull << 29); /* 32-bit byte offsets */
 }
 
+/* The sparse-subtree buffers for launches of up to nwaves 64-target tasks: the noted subtrees and flags per task, the pair stacks
+ * of as many waves as the larger of the two pair-kernel grids holds, the status words and their pinned host copy.  Called when a tree
+ * is installed (for the tree's own particles), so that the walk's launch path neither allocates nor - hipFree is a device-wide
+ * synchronisation - waits; a launch over more targets than that grows them once. */
+int shq_walk_reserve_sparse(shq_context *ctx, long long nwaves)
+{
+    if(nwaves < 1)
+        nwaves = 1;
+    const long long stack_waves = (long long) ctx->num_cus * (SHQ_PAIR_WG_PER_CU * SHQ_PAIR_WAVES > 16 ? SHQ_PAIR_WG_PER_CU * SHQ_PAIR_WAVES : 16);
+    SHQ_TRY(ctx->sp_items.reserve((size_t) nwaves * SHQ_SPARSE_CAP));
+    SHQ_TRY(ctx->sp_count.reserve((size_t) nwaves));
+    if(ctx->sp_stack_cap <= 0)
+        ctx->sp_stack_cap = SHQ_SPARSE_STACK;
+    if(ctx->sp_spin_max == 0)
+        ctx->sp_spin_max = SHQ_SPARSE_SPIN;
+    SHQ_TRY(ctx->sp_stack.reserve((size_t) stack_waves * (size_t) ctx->sp_stack_cap));
+    if(!ctx->sp_flags.ptr) {
+        SHQ_TRY(ctx->sp_flags.reserve(32));
+        SHQ_HIP(hipMemsetAsync(ctx->sp_flags.ptr, 0, sizeof(int) * 32, ctx->stream));
+    }
+    if(!ctx->sp_host.ptr) {
+        SHQ_TRY(ctx->sp_host.reserve(8));
+        for(int k = 0; k < 8; k++)
+            ctx->sp_host.ptr[k] = 0;
+    }
+    return SHQ_OK;
+}
+
+/* at tree installation: the buffers of a walk over all of the context's particles, if such a walk would take the sparse path */
+int shq_walk_prereserve(shq_context *ctx)
+{
+    const long long nwaves = (ctx->numpart + 63) / 64;
+    const bool persist = ctx->walk_persist == 2 || (ctx->walk_persist && (nwaves + 3) / 4 > (long long) ctx->num_cus * 8);
+    if(persist && ctx->walk_ring && ctx->walk_sparse && ctx->walk_variant == 3)
+        return shq_walk_reserve_sparse(ctx, nwaves);
+    return SHQ_OK;
+}
+
+/* The pair kernel's sticky error word, as the last completed launch left it in pinned host memory.  sync: wait for everything queued
+ * on the stream first (the calls that synchronise anyway); without it the check costs nothing and sees the launches that have
+ * completed so far - a resident loop learns of a failed step at a later step's entry, and at its final synchronisation at the latest.
+ * The report clears the word: the caller has been told (the shenqi-side shim turns the code into endrun, treewalk2.cuh:351-353). */
+int shq_walk_check_status(shq_context *ctx, bool sync)
+{
+    if(!ctx->sp_host.ptr)
+        return SHQ_OK;
+    if(sync && ctx->sp_check_pending) {
+        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->sp_check_pending = false;
+    }
+    const volatile int *h = ctx->sp_host.ptr;
+    if(h[0] != 0) {
+        SHQ_HIP(hipStreamSynchronize(ctx->stream)); /* copies of later launches still in flight would put the word back */
+        SHQ_HIP(hipMemsetAsync(ctx->sp_flags.ptr + SP_STICKY_ERROR, 0, sizeof(int), ctx->stream));
+        ctx->sp_host.ptr[0] = 0;
+        ctx->sp_check_pending = false;
+        shq_set_error("grav walk: a pair stack of the sparse-subtree kernel overflowed in an earlier launch and its pairs were dropped: the accelerations "
+                      "of that launch are incomplete (SHQ_WALK_SPARSE=0 avoids the kernel)");
+        return SHQ_ERR_DEVICE;
+    }
+    return SHQ_OK;
+}
+
+extern "C" int shq_set_walk_debug(shq_context *ctx, int pair_spin_max, int pair_stack_cap)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    SHQ_CHECK(pair_spin_max >= 0 && (pair_stack_cap == 0 || (pair_stack_cap >= 704 && pair_stack_cap <= SHQ_SPARSE_STACK)), SHQ_ERR_INVALID,
+              "walk debug: pair_spin_max >= 0 (0: default), pair_stack_cap 0 (default) or 704..%d", SHQ_SPARSE_STACK);
+    ctx->sp_spin_max = pair_spin_max > 0 ? (unsigned) pair_spin_max : SHQ_SPARSE_SPIN;
+    ctx->sp_stack_cap = pair_stack_cap > 0 ? pair_stack_cap : SHQ_SPARSE_STACK; /* never above what was reserved */
+    return SHQ_OK;
+}
+
+extern "C" int shq_walk_pair_status(shq_context *ctx, int64_t *recovered_launches, int64_t *stack_high_water, int64_t *last_mopped_tasks)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    int w[16] = {};
+    if(ctx->sp_flags.ptr) {
+        SHQ_HIP(hipSetDevice(ctx->device));
+        SHQ_HIP(hipMemcpyAsync(w, ctx->sp_flags.ptr, sizeof(w), hipMemcpyDeviceToHost, ctx->stream));
+        SHQ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if(recovered_launches)
+        *recovered_launches = w[SP_STICKY_RECOVERED];
+    if(stack_high_water)
+        *stack_high_water = w[SP_STICKY_HIGHWATER];
+    if(last_mopped_tasks)
+        *last_mopped_tasks = w[SP_MOPPED];
+    return shq_walk_check_status(ctx, true);
+}
+
 int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets,
                          int update_potential, int walk_mode, int64_t first)
 {
@@ -1245,22 +1383,24 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
     const bool live = sparse && ctx->walk_overlap && !ctx->pm_overlap && ctx->stream_pair && ctx->ev_pair_fork && ctx->ev_pair_join && !stats &&
                       (ctx->walk_overlap == 2 || nwaves >= (long long) ctx->num_cus * 32 * 4); /* 2: whatever the size (tests) */
     const long long pair_blocks = (long long) ctx->num_cus * (live ? 4 : SHQ_PAIR_WG_PER_CU); /* live: of four waves */
+    const long long mop_blocks = (long long) ctx->num_cus * SHQ_PAIR_WG_PER_CU;                /* the pass behind a live pair kernel */
     if(sparse) {
-        SHQ_TRY(ctx->sp_items.reserve((size_t) nwaves * SHQ_SPARSE_CAP));
-        SHQ_TRY(ctx->sp_count.reserve((size_t) nwaves));
-        SHQ_TRY(ctx->sp_stack.reserve((size_t) pair_blocks * (live ? 4 : SHQ_PAIR_WAVES) * SHQ_SPARSE_STACK));
-        SHQ_TRY(ctx->sp_flags.reserve(32));
-        SHQ_HIP(hipMemsetAsync(ctx->sp_flags.ptr, 0, sizeof(int) * 32, ctx->stream));
+        /* no-ops after shq_walk_reserve_sparse (tree installation) unless the launch is larger than the tree's own particles */
+        SHQ_TRY(shq_walk_reserve_sparse(ctx, nwaves));
+        SHQ_HIP(hipMemsetAsync(ctx->sp_flags.ptr, 0, sizeof(int) * SP_STICKY_ERROR, ctx->stream));
+        SHQ_HIP(hipMemsetAsync(ctx->sp_flags.ptr + SP_TASK_COUNTER, 0, sizeof(int) * 16, ctx->stream));
         a.sp_items = ctx->sp_items.ptr;
         a.sp_count = ctx->sp_count.ptr;
         a.sp_stack = ctx->sp_stack.ptr;
-        a.sp_overflow = ctx->sp_flags.ptr;
+        a.sp_flags = ctx->sp_flags.ptr;
+        a.sp_stack_cap = ctx->sp_stack_cap;
+        a.sp_spin_max = ctx->sp_spin_max;
         a.sp_lean_bad = ctx->node_lean_checked && ctx->walk_sparse != 2 ? ctx->node_lean_bad.ptr : nullptr;
         if(live) {
             SHQ_HIP(hipMemsetAsync(ctx->sp_count.ptr, 0xff, sizeof(int32_t) * (size_t) nwaves, ctx->stream));
             a.sp_live = 1;
         }
-        a.sp_task = reinterpret_cast<unsigned int *>(ctx->sp_flags.ptr + 16);
+        a.sp_task = reinterpret_cast<unsigned int *>(ctx->sp_flags.ptr + SP_TASK_COUNTER);
         a.nwaves = nwaves;
     }
     long long launch_blocks = blocks;
@@ -1364,7 +1504,21 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
         if(live) {
             SHQ_HIP(hipEventRecord(ctx->ev_pair_join, ps));
             SHQ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_pair_join, 0));
+            /* co-residency of the two kernels is what HIP does not promise (a tool that serialises queues, the pair stream dispatched
+             * first): a live wave that gave up waiting leaves its tasks to this pass behind both kernels - it returns at once when no
+             * wave gave up, and otherwise walks every task not marked done in the order of the pair kernel run behind the walk */
+            WalkArgs m = a;
+            m.sp_live = 0;
+            m.sp_mop = 1;
+            const dim3 mg((unsigned) mop_blocks);
+            if(update_potential)
+                grav_pair_kernel<true, SHQ_PAIR_WAVES><<<mg, dim3(64 * SHQ_PAIR_WAVES), 0, ctx->stream>>>(m);
+            else
+                grav_pair_kernel<false, SHQ_PAIR_WAVES><<<mg, dim3(64 * SHQ_PAIR_WAVES), 0, ctx->stream>>>(m);
+            SHQ_HIP(hipGetLastError());
         }
+        /* the sticky words follow every launch to pinned host memory: the entry points read them there without a round trip */
+        SHQ_HIP(hipMemcpyAsync(ctx->sp_host.ptr, ctx->sp_flags.ptr + SP_STICKY_ERROR, sizeof(int) * 8, hipMemcpyDeviceToHost, ctx->stream));
         ctx->sp_check_pending = true;
     }
     SHQ_HIP(hipEventRecord(ctx->ev_end[SHQ_NTIMERS - 1], ctx->stream));

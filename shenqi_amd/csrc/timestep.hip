@@ -675,7 +675,11 @@ extern "C" int shq_hier_refine(shq_context *ctx, const shq_timestep_params *p, c
         timestep_kernel<3><<<dim3(ts_grid(a.nt)), dim3(256), 0, ctx->stream>>>(a);
         SHQ_HIP(hipGetLastError());
     }
-    return fetch(ctx, res);
+    SHQ_TRY(fetch(ctx, res));
+    /* the accelerations this refinement read (and the level's kick is about to use) came from a walk queued before it: fetch() has
+     * waited for the stream, so the pair kernel's status of that walk is on the host */
+    ctx->sp_check_pending = false;
+    return shq_walk_check_status(ctx, false);
 }
 
 /* The sub-step levels of hierarchical_gravity_and_timesteps (timestep.cpp:417-476) as one resident loop: for ti = largest_active - 1

@@ -868,6 +868,7 @@ static int tree_build_impl(shq_context *ctx, double BoxSize, int mask, const int
     ctx->have_father = true;
     ctx->tb_built = true;
     ctx->tb_domain = dom;
+    SHQ_TRY(shq_walk_prereserve(ctx));
     ctx->have_toptree = false;
     if(stats) {
         stats->nparticles = n;

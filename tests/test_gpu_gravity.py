@@ -702,6 +702,92 @@ def test_treepm_step_equals_the_three_separate_calls(ctx):
     assert cm.force_err(acc, o).max() < 1e-5
 
 
+def test_pair_kernel_failures_in_a_resident_loop(ctx):
+    """The sparse-subtree pair kernel's two failure modes inside a resident loop of three shq_treepm_step calls WITHOUT a download
+    in between (every launch checked, treewalk2.cuh:351-353).  (1) A live pair kernel whose waves give up waiting for the main walk
+    (shq_set_walk_debug starves them: one poll) is finished by the mop-up pass behind the walk: forces, potentials and interaction
+    counts of all three steps' end state equal the undisturbed loop's bit for bit, and the status says three launches were recovered.
+    (2) A pair stack that runs full (shrunk to its minimum) drops pairs: the sticky error survives the launches that follow and comes
+    back as SHQ_ERR_DEVICE from a later step's entry or, at the latest, from shq_synchronize; the report clears it."""
+    n, L, nmesh = 64**3, 1.0, 96
+    pos = sq.synth_positions("cluster", n, L=L)
+    pos = pos[sq.morton_order(pos, L)]
+    pman = cm.make_partmanager(pos, box=L)
+    tree = sq.force_tree_full(pman)
+    sq.set_gravshort_treepar(ErrTolForceAcc=0.005, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=0, Rcut=6.0)
+    sq.gravshort_set_softenings(L / 64)
+    gp = sq.make_grav_params(L, 1.5, nmesh, cm.G, cm.RHO0)
+    pmp = sq.PMParams(nmesh, 0, L, 1.5, cm.G)
+    P = pman.Base
+    P["FullTreeGravAccel"] = np.random.default_rng(12).standard_normal((n, 3)) * 50.0
+    pv, tv = pman.view(), tree.view()
+    ERR_DEVICE = 2
+
+    def start():
+        capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+        capi.check(capi.hip.shq_tree_upload(ctx.h, C.byref(tv)))
+
+    def status():
+        rec, high, mop = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        rc = capi.hip.shq_walk_pair_status(ctx.h, C.byref(rec), C.byref(high), C.byref(mop))
+        return rc, rec.value, high.value, mop.value
+
+    def results():
+        acc = np.zeros((n, 3)); pot = np.zeros(n); nint = np.zeros(n, dtype=np.int64)
+        capi.check(capi.hip.shq_grav_short_download(ctx.h, capi.ptr(acc), capi.ptr(pot), capi.ptr(nint), C.byref(sq.WalkStats())))
+        return acc, pot, nint
+
+    def step():
+        return capi.hip.shq_treepm_step(ctx.h, C.byref(pmp), C.byref(gp), 1, sq.WALK_EXACT)
+
+    try:
+        capi.check(capi.hip.shq_set_walk_launch(ctx.h, 2, 1))   # the production launch at this size: persistent waves, leaf ring,
+        capi.check(capi.hip.shq_set_walk_overlap(ctx.h, 2))     # the pair kernel beside the main walk
+        start()
+        for _ in range(3):                                      # every step's OldAcc comes from the step before: a resident loop
+            capi.check(step())
+        ref = results()
+        rc, rec0, high, mop = status()
+        assert rc == 0 and mop == 0 and 0 < high <= 4096, (rc, high, mop)
+        # (1) starved live pair kernel: the mop-up pass walks what the live waves left
+        capi.check(capi.hip.shq_set_walk_debug(ctx.h, 1, 0))
+        start()
+        for _ in range(3):
+            capi.check(step())
+        rc, rec1, _, mop = status()
+        got = results()
+        assert rc == 0 and rec1 == rec0 + 3 and mop > 0, (rc, rec0, rec1, mop)
+        for a, b, name in zip(got, ref, ("acc", "pot", "ninteractions")):
+            assert np.array_equal(a, b), name
+        # (2) pair stacks of 704 entries overflow in the cluster: sticky, reported although two more launches follow the first failure
+        capi.check(capi.hip.shq_set_walk_debug(ctx.h, 0, 704))
+        start()
+        capi.check(step())                                      # queued; its failure is not known yet
+        rcs = [step()]
+        if rcs[-1] == 0:
+            rcs.append(step())
+        if rcs[-1] == 0:
+            rcs.append(capi.hip.shq_synchronize(ctx.h))
+        assert rcs[-1] == ERR_DEVICE and "pair stack" in capi.hip.shq_last_error().decode(), rcs
+        # drained and cleared: the same loop with the stacks restored is the reference loop again
+        capi.check(capi.hip.shq_set_walk_debug(ctx.h, 0, 0))
+        while capi.hip.shq_synchronize(ctx.h) != 0:
+            pass
+        start()
+        for _ in range(3):
+            capi.check(step())
+        got = results()
+        for a, b, name in zip(got, ref, ("acc", "pot", "ninteractions")):
+            assert np.array_equal(a, b), name
+    finally:
+        capi.hip.shq_set_walk_debug(ctx.h, 0, 0)
+        capi.hip.shq_synchronize(ctx.h)
+        capi.hip.shq_synchronize(ctx.h)
+        capi.check(capi.hip.shq_set_walk_overlap(ctx.h, 1))
+        capi.check(capi.hip.shq_set_walk_launch(ctx.h, 1, 1))
+    assert np.isfinite(ref[0]).all() and ref[2].min() > 0
+
+
 def test_treepm_step_ragged_boundary_and_swallowed(ctx):
     """The one-call step on a set whose size is no multiple of 64, spread over the whole box (waves with particles next to the faces
     take the readout's wrapped path) and holding swallowed black holes (no deposit, no readout: GravPM = 0, gravpm.cpp:176-178):
