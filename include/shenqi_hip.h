@@ -1146,6 +1146,11 @@ int shq_treepm_last_fused(shq_context *ctx, int *fused);
 /* HIP-event durations (ms) of the last shq_pm_run's phases: [0] zero+deposit+convert, [1] r2c,
  * [2] potential transfer, [3] c2r, [4] readout, [5] total. Synchronises. */
 int shq_pm_phase_ms(shq_context *ctx, double ms[6]);
+/* How the undivided PM runs its five FFT passes (a test / tuning knob; the potential mesh is the same to the bit either way): 1 (default;
+ * SHQ_FFT_TRANSPOSED) the mesh changes layout from pass to pass between the mesh and a scratch mesh of the same size, so that one side
+ * of every pass moves contiguous 48 KB tiles; 0 in place, column tiles of 64-byte pieces on both sides. */
+int shq_pm_set_fft_transposed(shq_context *ctx, int enable);
+
 /* Power spectrum of the PM density, the side product of potential_transfer (measure_power_spectrum /
  * powerspectrum_add_mode, libgadget/gravpm.cpp:323-376, :430).  After shq_pm_measure_power(ctx, 1) every PM
  * run (shq_pm_run / shq_pm_force) also accumulates, per logarithmic k bin (size = Nmesh bins, bin =

@@ -450,6 +450,8 @@ hip.shq_walk_pair_lean.argtypes = [_vp]
 hip.shq_walk_pair_lean.restype = C.c_int
 hip.shq_set_walk_overlap.argtypes = [_vp, C.c_int]
 hip.shq_set_walk_overlap.restype = C.c_int
+hip.shq_pm_set_fft_transposed.argtypes = [_vp, C.c_int]
+hip.shq_pm_set_fft_transposed.restype = C.c_int
 hip.shq_walk_pair_status.argtypes = [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
 hip.shq_walk_pair_status.restype = C.c_int
 hip.shq_set_walk_debug.argtypes = [_vp, C.c_int, C.c_int]

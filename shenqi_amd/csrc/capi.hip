@@ -184,6 +184,8 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
         ctx->walk_sparse = atoi(v);
     if(const char *v = getenv("SHQ_WALK_OVERLAP"))
         ctx->walk_overlap = atoi(v);
+    if(const char *v = getenv("SHQ_FFT_TRANSPOSED"))
+        ctx->fft_transposed = atoi(v) != 0;
     if(const char *v = getenv("SHQ_TREEPM_FUSE"))
         ctx->treepm_fuse = atoi(v) != 0;
     if(const char *v = getenv("SHQ_WALK_VARIANT"))

@@ -379,6 +379,8 @@ struct shq_context {
     hipfftHandle plan_r2c = 0, plan_c2r = 0;
     bool have_plans = false;
     bool pm_custom_fft = false; /* bespoke 5-pass FFT pipeline (fft3d.hip) instead of rocFFT */
+    bool fft_transposed = true; /* SHQ_FFT_TRANSPOSED / shq_pm_set_fft_transposed: the undivided PM's five passes change the mesh layout
+                                   between the mesh and a scratch mesh (mesh_alt) instead of working in place (fft3d.hip) */
     int pm_zp = 0;             /* z pitch of the mesh in doubles */
     DevBuf<double> fft_tw;     /* twiddles exp(-2 pi i k / N) */
     int fft_tw_n = 0;
@@ -475,6 +477,8 @@ bool shq_fft3d_supported(int N);
 int shq_fft3d_pitch(int N);
 int shq_fft3d_run(shq_context *ctx, double *d_mesh, int N, int zp, int stage, bool from_i64, double inv_scale,
                   const double *d_sinctab, double asmth2, double pot_factor);
+int shq_fft3d_run_transposed(shq_context *ctx, double *d_mesh, double *d_scratch, int N, int zp, bool from_i64, double inv_scale,
+                             const double *d_sinctab, double asmth2, double pot_factor);
 int shq_fft3d_run_slab(shq_context *ctx, double *d_mesh, int N, int zp, int stage, bool from_i64, double inv_scale,
                        const double *d_sinctab, double asmth2, double pot_factor, int nslab, int y0);
 int shq_fft3d_run_slab_packed(shq_context *ctx, double *d_mesh, int N, int zp, int stage, bool from_i64, double inv_scale,

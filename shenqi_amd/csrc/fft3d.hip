@@ -513,6 +513,309 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
 #undef FFT_FETCH
 }
 
+/* ---- the transposing pipeline (round 4; the undivided PM of shq_pm_run / shq_treepm_step) ------------------------------------
+ * tools/copy_probe.hip moves the 768^3 mesh in the access shapes of the passes with nothing but 16-byte loads and stores:
+ * contiguous 48 KB tiles both sides 1.25 ms (5.8 TB/s); one side in pieces of 512 / 256 / 128 / 64 B 1.27 / 1.38 / 1.50 / 1.57 ms;
+ * BOTH sides in 64-byte pieces 6208 B apart (the Y passes above) 1.83-1.91 ms, 37 MB apart (the X pass) 2.2-2.4 ms - the passes above run
+ * at those rates already (1.65 / 2.38 ms): what bounds them is the DRAM's row activations, one per 64-byte piece, not the FFT.
+ * So the mesh changes its layout from pass to pass, between the mesh A and a scratch mesh B of the same size, such that one side of
+ * every pass is a contiguous tile and only two of the ten sides are left with 64-byte pieces:
+ *
+ *   LY = [x][zb][y][4]   tile (x, zb) = the four z' columns 4 zb .. 4 zb + 3 of plane x, all y: N x 64 B contiguous
+ *   LX = [y][zb][x][4]   tile (y, zb) likewise with the lines along x
+ *
+ *   Z fwd   A (real rows [x][y][z], int64 deposit)  -> B in LY: 8 rows in, per z' block one 512-byte piece (8 y x 4 z') out
+ *   Y fwd   B tile (x, zb) contiguous               -> A in LX: row ky of the tile is a 64-byte piece
+ *   X       A tile (ky, zb) contiguous: forward, potential_transfer, inverse  -> B in LY: row x is a 64-byte piece
+ *   Y inv   B tile (x, zb) contiguous               -> the same tile of B, in place
+ *   Z inv   B in LY, gathered in 512-byte pieces    -> A (real rows): the potential, where the deposit was
+ *
+ * The arithmetic - stages, twiddles, the two-for-one separation, the Green's function - is the functions above applied to the same
+ * values in the same order: the potential mesh is bit-identical to the in-place pipeline's (a test compares the two). */
+template <int N, bool FROM_I64>
+__global__ __launch_bounds__(FFT_T) void fft_t_z_fwd(const double *mesh, double2 *__restrict__ out, const int ntot, const int zp,
+                                                     const double2 *__restrict__ W, const double inv_scale)
+{
+    extern __shared__ double2 buf[];
+    constexpr int LS = fft_ls(N), H = N / 2, Nc = N / 2 + 1;
+    constexpr int E = (FFT_C * N + FFT_T - 1) / FFT_T;
+    constexpr bool EXACT = E * FFT_T == FFT_C * N;
+    static_assert(FFT_C == 4, "the layouts are written for tiles of 4 lines");
+    double2 *Wl = lds_twiddles<N>(buf, W);
+    const double2 *cm = reinterpret_cast<const double2 *>(mesh);
+    const int zpc = zp / 2, nzb = zpc / 4;
+    double pa[E], pb[E];
+#define FFT_FETCH(T_)                                                                            \
+    _Pragma("unroll") for(int i = 0; i < E; i++)                                                 \
+    {                                                                                            \
+        const int e = threadIdx.x + i * FFT_T;                                                   \
+        if(EXACT || e < FFT_C * N) {                                                             \
+            const long long row = (long long) (T_) * (2 * FFT_C) + e / H;                        \
+            const double2 v_ = cm[row * zpc + (e % H)];                                          \
+            pa[i] = v_.x;                                                                        \
+            pb[i] = v_.y;                                                                        \
+        }                                                                                        \
+    }
+    int t = blockIdx.x;
+    if(t >= ntot)
+        return;
+    FFT_FETCH(t)
+    while(true) {
+#pragma unroll
+        for(int i = 0; i < E; i++) {
+            const int e = threadIdx.x + i * FFT_T;
+            if(EXACT || e < FFT_C * N) {
+                const int r = e / H, z = 2 * (e % H);
+                double a = pa[i], b = pb[i];
+                if(FROM_I64) {
+                    a = (double) __double_as_longlong(a) * inv_scale;
+                    b = (double) __double_as_longlong(b) * inv_scale;
+                }
+                double *dst = reinterpret_cast<double *>(buf + (r >> 1) * LS + lx<N>(z)) + (r & 1);
+                dst[0] = a;
+                dst[2] = b;
+            }
+        }
+        __syncthreads();
+        const int tn = t + (int) gridDim.x;
+        const bool more = tn < ntot;
+        const int tf = more ? tn : t;
+        FFT_FETCH(tf)
+        fft_lines<N, -1>(buf, Wl);
+        /* rows 8 t .. 8 t + 7 = plane x, rows y0 .. y0 + 7 (8 divides N).  Thread -> (zb, line pair l, column c): sixteen threads fill
+         * one 512-byte piece [zb][y0 .. y0 + 7][4] with two stores each (rows y0 + 2 l and y0 + 2 l + 1) */
+        const long long row0 = (long long) t * (2 * FFT_C);
+        const int x = (int) (row0 / N), y0 = (int) (row0 - (long long) x * N);
+        for(int e = threadIdx.x; e < 16 * nzb; e += FFT_T) {
+            const int zb = e >> 4, l = (e >> 2) & 3, c = e & 3, k = 4 * zb + c;
+            double2 xa = make_double2(0, 0), xb = make_double2(0, 0); /* the pad columns k >= Nc hold zeros */
+            if(k < Nc) {
+                const double2 zk = buf[l * LS + lx<N>(k)];
+                const double2 zn = conj2(buf[l * LS + lx<N>(k == 0 ? 0 : N - k)]);
+                xa = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y + zn.y));
+                const double2 d = make_double2(0.5 * (zk.x - zn.x), 0.5 * (zk.y - zn.y));
+                xb = make_double2(d.y, -d.x);
+            }
+            double2 *o = out + (((long long) x * nzb + zb) * N + (y0 + 2 * l)) * 4 + c;
+            o[0] = xa;
+            o[4] = xb;
+        }
+        if(!more)
+            break;
+        __syncthreads();
+        t = tn;
+    }
+#undef FFT_FETCH
+}
+
+template <int N>
+__global__ __launch_bounds__(FFT_T) void fft_t_z_inv(const double2 *__restrict__ in, double *mesh, const int ntot, const int zp, const double2 *__restrict__ W)
+{
+    extern __shared__ double2 buf[];
+    constexpr int LS = fft_ls(N), H = N / 2, Nc = N / 2 + 1;
+    double2 *Wl = lds_twiddles<N>(buf, W);
+    double2 *cm = reinterpret_cast<double2 *>(mesh);
+    const int zpc = zp / 2, nzb = zpc / 4;
+    constexpr int EMAX = (16 * ((N / 2 + 1 + 3) / 4) + FFT_T - 1) / FFT_T; /* 16 (zb, l, c) slots per z' block of the unpadded spectrum... */
+    const int nslots = 16 * nzb;                                           /* ...the pitch may hold more blocks: those are skipped */
+    double ax[EMAX], ay[EMAX], bx[EMAX], by[EMAX];
+#define FFT_FETCH(T_)                                                                            \
+    {                                                                                            \
+        const long long row0_ = (long long) (T_) * (2 * FFT_C);                                  \
+        const int x_ = (int) (row0_ / N), y0_ = (int) (row0_ - (long long) x_ * N);              \
+        _Pragma("unroll") for(int i = 0; i < EMAX; i++)                                          \
+        {                                                                                        \
+            const int e = threadIdx.x + i * FFT_T;                                               \
+            const int zb = e >> 4, l = (e >> 2) & 3, c = e & 3, k = 4 * zb + c;                  \
+            if(e < nslots && k < Nc) {                                                           \
+                const double2 *p_ = in + (((long long) x_ * nzb + zb) * N + (y0_ + 2 * l)) * 4 + c; \
+                const double2 xa_ = p_[0], xb_ = p_[4];                                          \
+                ax[i] = xa_.x;                                                                   \
+                ay[i] = xa_.y;                                                                   \
+                bx[i] = xb_.x;                                                                   \
+                by[i] = xb_.y;                                                                   \
+            }                                                                                    \
+        }                                                                                        \
+    }
+    int t = blockIdx.x;
+    if(t >= ntot)
+        return;
+    FFT_FETCH(t)
+    while(true) {
+#pragma unroll
+        for(int i = 0; i < EMAX; i++) {
+            const int e = threadIdx.x + i * FFT_T;
+            const int zb = e >> 4, l = (e >> 2) & 3, c = e & 3, k = 4 * zb + c;
+            if(e < nslots && k < Nc) {
+                double2 xa = make_double2(ax[i], ay[i]), xb = make_double2(bx[i], by[i]);
+                if(k == 0 || 2 * k == N) {
+                    xa.y = 0;
+                    xb.y = 0;
+                }
+                buf[l * LS + lx<N>(k)] = make_double2(xa.x - xb.y, xa.y + xb.x);
+                if(k > 0 && 2 * k < N)
+                    buf[l * LS + lx<N>(N - k)] = make_double2(xa.x + xb.y, -xa.y + xb.x);
+            }
+        }
+        __syncthreads();
+        const int tn = t + (int) gridDim.x;
+        const bool more = tn < ntot;
+        const int tf = more ? tn : t;
+        FFT_FETCH(tf)
+        fft_lines<N, +1>(buf, Wl);
+        const long long row0 = (long long) t * (2 * FFT_C);
+        for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T) {
+            const int r = e / H, z = 2 * (e % H);
+            const double *src = reinterpret_cast<const double *>(buf + (r >> 1) * LS + lx<N>(z)) + (r & 1);
+            cm[(row0 + r) * zpc + (z >> 1)] = make_double2(src[0], src[2]);
+        }
+        if(!more)
+            break;
+        __syncthreads();
+        t = tn;
+    }
+#undef FFT_FETCH
+}
+
+/* Y and X passes on contiguous tiles.  Tile t = (o, zb), o = t / nzb: N rows of 4 columns at src + t * 4 N.  MODE as in fft_pass_strided.
+ * SCATTER: row i of the result goes to dst + ((i * nzb + zb) * N + o) * 4 (the other layout: a 64-byte piece); otherwise the tile is
+ * written back where it came from (dst may be src). */
+template <int N, int MODE, bool SCATTER>
+__global__ __launch_bounds__(FFT_T) void fft_t_tile(const double2 *src, double2 *dst, const int nzb, const int ntot, const double2 *__restrict__ W,
+                                                    const GreenArgs ga, const unsigned xcdk)
+{
+    extern __shared__ double2 buf[];
+    constexpr int LS = fft_ls(N);
+    constexpr int E = (FFT_C * N + FFT_T - 1) / FFT_T;
+    constexpr bool EXACT = E * FFT_T == FFT_C * N;
+    double2 *Wl = lds_twiddles<N>(buf, W);
+    double *gax = reinterpret_cast<double *>(Wl + N);
+    if(MODE == 2)
+        for(int i = threadIdx.x; i < N; i += FFT_T) {
+            const int k = i <= N / 2 ? i : i - N;
+            const double sc = ga.sinctab[i];
+            gax[i] = exp(-(double) k * (double) k * ga.asmth2) * sc * sc;
+        }
+    const unsigned vb = xcd_block(blockIdx.x, gridDim.x, xcdk);
+    double prx[E], pry[E];
+#define FFT_FETCH(T_)                                                                            \
+    {                                                                                            \
+        const double2 *b_ = src + (long long) (T_) * (FFT_C * N);                                \
+        _Pragma("unroll") for(int i = 0; i < E; i++)                                             \
+        {                                                                                        \
+            const int e = threadIdx.x + i * FFT_T;                                               \
+            if(EXACT || e < FFT_C * N) {                                                         \
+                const double2 t_ = b_[e];                                                        \
+                prx[i] = t_.x;                                                                   \
+                pry[i] = t_.y;                                                                   \
+            }                                                                                    \
+        }                                                                                        \
+    }
+    int t = (int) vb;
+    if(t >= ntot)
+        return;
+    FFT_FETCH(t)
+    while(true) {
+#pragma unroll
+        for(int i = 0; i < E; i++) {
+            const int e = threadIdx.x + i * FFT_T;
+            if(EXACT || e < FFT_C * N)
+                buf[(e % FFT_C) * LS + lx<N>(e / FFT_C)] = make_double2(prx[i], pry[i]);
+        }
+        __syncthreads();
+        const int tn = t + (int) gridDim.x;
+        const bool more = tn < ntot;
+        const int tf = more ? tn : t;
+        FFT_FETCH(tf)
+        const int o = t / nzb, zb = t - o * nzb;
+        if(MODE == 0)
+            fft_lines<N, -1>(buf, Wl);
+        if(MODE == 2) { /* potential_transfer as in fft_pass_strided: line index = kx, o = ky, columns z' = 4 zb .. 4 zb + 3 */
+            const int y = ga.y0 + o, z0 = zb * FFT_C;
+            const int ky = y <= N / 2 ? y : y - N;
+            const double gy = gax[y] * ga.pot_factor, ky2 = (double) ky * (double) ky;
+            auto green = [=](int col, int x, double2 v) {
+                const int z = z0 + col;
+                const int kx = x <= N / 2 ? x : x - N;
+                const double k2 = (double) kx * (double) kx + (ky2 + (double) z * (double) z);
+                const double fac = (k2 == 0.0 || z > N / 2) ? 0.0 : gax[x] * gy * gax[z] / k2;
+                return make_double2(v.x * fac, v.y * fac);
+            };
+            fft_lines<N, -1>(buf, Wl, green);
+            fft_lines<N, +1>(buf, Wl);
+        }
+        if(MODE == 1)
+            fft_lines<N, +1>(buf, Wl);
+        if(SCATTER) {
+            double2 *ob = dst + ((long long) zb * N + o) * FFT_C;
+            const long long rs = (long long) nzb * N * FFT_C;
+            for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T) {
+                const int row = e / FFT_C, col = e - row * FFT_C;
+                ob[(long long) row * rs + col] = buf[col * LS + lx<N>(row)];
+            }
+        } else {
+            double2 *ob = dst + (long long) t * (FFT_C * N);
+            for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T)
+                ob[e] = buf[(e % FFT_C) * LS + lx<N>(e / FFT_C)];
+        }
+        if(!more)
+            break;
+        __syncthreads();
+        t = tn;
+    }
+#undef FFT_FETCH
+}
+
+template <int N>
+int run_t(shq_context *ctx, double *d_mesh, double *d_scratch, int zp, bool from_i64, double inv_scale, const GreenArgs &ga)
+{
+    const double2 *W = reinterpret_cast<const double2 *>(ctx->fft_tw.ptr);
+    constexpr size_t lds = sizeof(double2) * (FFT_C * fft_ls(N) + N) + sizeof(double) * N;
+    const int ztot = (int) (((long long) N * N) / (2 * FFT_C));
+    const int zpc = zp / 2, nzb = zpc / FFT_C;
+    const int stot = N * nzb;
+    double2 *A = reinterpret_cast<double2 *>(d_mesh), *B = reinterpret_cast<double2 *>(d_scratch);
+    hipStream_t s = ctx->stream;
+    static unsigned res_z = 0, res_s = 0;
+    if(res_s == 0) {
+        const void *fns[6] = {(const void *) fft_t_z_fwd<N, true>, (const void *) fft_t_z_fwd<N, false>, (const void *) fft_t_z_inv<N>,
+                              (const void *) fft_t_tile<N, 0, true>, (const void *) fft_t_tile<N, 2, true>, (const void *) fft_t_tile<N, 1, false>};
+        int ncu = 0;
+        if(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || ncu < 1)
+            ncu = 256;
+        unsigned occ[6];
+        for(int i = 0; i < 6; i++) {
+            if(lds > 48 * 1024)
+                SHQ_HIP(hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            int per_cu = 0;
+            if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fns[i], FFT_T, lds) != hipSuccess || per_cu < 1)
+                per_cu = 1;
+            occ[i] = (unsigned) per_cu * (unsigned) ncu;
+        }
+        res_z = occ[0] < occ[1] ? occ[0] : occ[1];
+        res_z = res_z < occ[2] ? res_z : occ[2];
+        unsigned r = occ[3] < occ[4] ? occ[3] : occ[4];
+        res_s = r < occ[5] ? r : occ[5];
+    }
+    const unsigned gmul = getenv("SHQ_FFT_GRID_MUL") ? (unsigned) atoi(getenv("SHQ_FFT_GRID_MUL")) : 8u;
+    auto grid = [&](int tot, unsigned resident) {
+        const unsigned cap = gmul == 0 ? (unsigned) tot : resident * gmul;
+        return dim3((unsigned) tot < cap ? (unsigned) tot : cap);
+    };
+    const dim3 gz = grid(ztot, res_z), gs = grid(stot, res_s);
+    const unsigned xcdk = getenv("SHQ_FFT_XCD_K") ? (unsigned) atoi(getenv("SHQ_FFT_XCD_K")) : 8u;
+    if(from_i64)
+        fft_t_z_fwd<N, true><<<gz, dim3(FFT_T), lds, s>>>(d_mesh, B, ztot, zp, W, inv_scale);
+    else
+        fft_t_z_fwd<N, false><<<gz, dim3(FFT_T), lds, s>>>(d_mesh, B, ztot, zp, W, 1.0);
+    fft_t_tile<N, 0, true><<<gs, dim3(FFT_T), lds, s>>>(B, A, nzb, stot, W, ga, xcdk);
+    fft_t_tile<N, 2, true><<<gs, dim3(FFT_T), lds, s>>>(A, B, nzb, stot, W, ga, xcdk);
+    fft_t_tile<N, 1, false><<<gs, dim3(FFT_T), lds, s>>>(B, B, nzb, stot, W, ga, xcdk);
+    fft_t_z_inv<N><<<gz, dim3(FFT_T), lds, s>>>(B, d_mesh, ztot, zp, W);
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}
+
 /* stage 0 / 1 / 2 as shq_fft3d_run on a full cube (nslab = N).  Slab stages for a distributed mesh:
  * 10: Z forward + Y forward on `nslab` x-planes [nslab][N][zp];  11: Y inverse + Z inverse on them;
  * 12: X forward + potential_transfer + X inverse on a y-slab [N][nslab][zpc] (lines along the slowest axis). */
@@ -674,6 +977,32 @@ static int ensure_twiddles(shq_context *ctx, int N)
     SHQ_HIP(hipMemcpy(ctx->fft_tw.ptr, h.data(), sizeof(double) * 2 * N, hipMemcpyHostToDevice));
     ctx->fft_tw_n = N;
     return SHQ_OK;
+}
+
+/* forward + potential_transfer + inverse of a full cube through the transposing pipeline: d_scratch is a second mesh of the same size */
+int shq_fft3d_run_transposed(shq_context *ctx, double *d_mesh, double *d_scratch, int N, int zp, bool from_i64, double inv_scale,
+                             const double *d_sinctab, double asmth2, double pot_factor)
+{
+    SHQ_CHECK(shq_fft3d_supported(N) && N % (2 * FFT_C) == 0, SHQ_ERR_INVALID, "fft3d: unsupported mesh size %d", N);
+    SHQ_CHECK(zp == shq_fft3d_pitch(N) && d_mesh && d_scratch && d_mesh != d_scratch, SHQ_ERR_INVALID, "fft3d: bad pitch or scratch mesh");
+    SHQ_TRY(ensure_twiddles(ctx, N));
+    GreenArgs ga;
+    ga.sinctab = d_sinctab;
+    ga.asmth2 = asmth2;
+    ga.pot_factor = pot_factor;
+    ga.y0 = 0;
+    ga.alt = nullptr;
+    ga.nyl = 1;
+    ga.qstride = ga.alt_outer = 0;
+#define SHQ_FFT_CASE(NN) case NN: return run_t<NN>(ctx, d_mesh, d_scratch, zp, from_i64, inv_scale, ga)
+    switch(N) {
+        SHQ_FFT_CASE(16); SHQ_FFT_CASE(24); SHQ_FFT_CASE(32); SHQ_FFT_CASE(40); SHQ_FFT_CASE(48); SHQ_FFT_CASE(64);
+        SHQ_FFT_CASE(80); SHQ_FFT_CASE(96); SHQ_FFT_CASE(128); SHQ_FFT_CASE(192); SHQ_FFT_CASE(256); SHQ_FFT_CASE(384);
+        SHQ_FFT_CASE(512); SHQ_FFT_CASE(768); SHQ_FFT_CASE(960); SHQ_FFT_CASE(1024); SHQ_FFT_CASE(1152); SHQ_FFT_CASE(1200);
+        SHQ_FFT_CASE(1536);
+    }
+#undef SHQ_FFT_CASE
+    return SHQ_ERR_INVALID;
 }
 
 /* stage: 0 forward only (r2c), 1 inverse only (c2r), 2 forward + potential_transfer + inverse.

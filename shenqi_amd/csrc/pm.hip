@@ -531,8 +531,16 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm, bool readout)
         SHQ_HIP(hipEventRecord(ctx->ev_begin[12], ctx->stream));
     } else if(ctx->pm_custom_fft) {
         /* five fused passes: Z fwd (+ int64 -> f64), Y fwd, X fwd + potential_transfer + X inv, Y inv, Z inv */
+        /* the transposing pipeline (fft3d.hip) wants a second mesh as scratch: the one shq_treepm_step keeps anyway (between two steps
+         * it holds the previous step's potential, which nothing reads any more once that step's walk has gone by on this stream) */
+        double *scratch = nullptr;
+        if(ctx->fft_transposed && zp == shq_fft3d_pitch(N) && ctx->mesh_alt.reserve(padded) == SHQ_OK)
+            scratch = ctx->mesh_alt.ptr;
         SHQ_HIP(hipEventRecord(ctx->ev_begin[9], ctx->stream));
-        SHQ_TRY(shq_fft3d_run(ctx, ctx->mesh.ptr, N, zp, 2, true, 1.0 / scale, ctx->sinctab.ptr, asmth2, pot_factor));
+        if(scratch)
+            SHQ_TRY(shq_fft3d_run_transposed(ctx, ctx->mesh.ptr, scratch, N, zp, true, 1.0 / scale, ctx->sinctab.ptr, asmth2, pot_factor));
+        else
+            SHQ_TRY(shq_fft3d_run(ctx, ctx->mesh.ptr, N, zp, 2, true, 1.0 / scale, ctx->sinctab.ptr, asmth2, pot_factor));
         SHQ_HIP(hipEventRecord(ctx->ev_begin[10], ctx->stream));
         SHQ_HIP(hipEventRecord(ctx->ev_begin[11], ctx->stream));
         SHQ_HIP(hipEventRecord(ctx->ev_begin[12], ctx->stream));
@@ -572,6 +580,13 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm, bool readout)
     SHQ_HIP(hipGetLastError());
     SHQ_HIP(hipEventRecord(ctx->ev_begin[13], ctx->stream));
     ctx->have_pm_result = true;
+    return SHQ_OK;
+}
+
+extern "C" int shq_pm_set_fft_transposed(shq_context *ctx, int enable)
+{
+    SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
+    ctx->fft_transposed = enable != 0;
     return SHQ_OK;
 }
 
