@@ -1132,12 +1132,13 @@ int shq_pm_download(shq_context *ctx, double (*gravpm)[3], double *pm_potential)
 /* The force part of a PM step as ONE call: gravpm_force, then grav_short_tree for every particle, in the reference's order
  * (libgadget/run.cpp:518-563 — the PM first, because the walk's opening criterion uses FullTreeGravAccel of the last step + the
  * NEW GravPM, gravshort2.hpp:111-121).  Equivalent to shq_pm_run; shq_grav_refresh_oldacc; shq_grav_short_run(all particles,
- * walk_mode = SHQ_WALK_EXACT, optionally | SHQ_WALK_TREE_ORDER) and bit-identical to that sequence; when the walk at hand can carry it (relative criterion, no diagnostic counters,
- * every resident particle a target, mesh below 2^32 cells) the CIC readout and the OldAcc refresh are done by the walk's tasks for
- * their own 64 targets before they walk, instead of by two kernels of their own: the readout is bound by scattered loads, the walk
- * by arithmetic, so the one hides behind the other (1.5 + 0.2 ms of 47 at 256^3).  Results land where the separate calls leave them
- * (shq_pm_download, shq_grav_short_download, the resident arrays the kicks read).  SHQ_TREEPM_FUSE=0 or shq_treepm_set_fuse(ctx, 0)
- * force the separate launches; shq_treepm_last_fused reports which route the last call took. */
+ * walk_mode = SHQ_WALK_EXACT, optionally | SHQ_WALK_TREE_ORDER) and bit-identical to that sequence.  By default the PM's readout kernel
+ * forms OldAcc as it stores GravPM (one pass over the particles instead of two).  With SHQ_TREEPM_FUSE=1 or shq_treepm_set_fuse(ctx, 1),
+ * when the walk at hand can carry it (relative criterion, no diagnostic counters, every resident particle a target, mesh below 2^32
+ * bytes), the CIC readout and the OldAcc refresh are done by the walk's tasks for their own 64 targets before they walk; that was the
+ * default in round 3 and is off since round 4: beside the pair kernel the prologue's loads cost the walk more (2.0 ms) than the two
+ * kernels they replace (1.6 ms).  Results land where the separate calls leave them (shq_pm_download, shq_grav_short_download, the
+ * resident arrays the kicks read) with the same bits on either route; shq_treepm_last_fused reports which one the last call took. */
 int shq_treepm_step(shq_context *ctx, const shq_pm_params *pm, const shq_grav_params *params, int update_potential, int walk_mode);
 int shq_treepm_set_fuse(shq_context *ctx, int enable);
 int shq_treepm_last_fused(shq_context *ctx, int *fused);

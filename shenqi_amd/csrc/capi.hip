@@ -1226,10 +1226,16 @@ extern "C" int shq_treepm_step(shq_context *ctx, const shq_pm_params *pm, const 
     const bool fuse = !ctx->pm_overlap && ctx->treepm_fuse && pm->Nmesh >= 4 &&
                       (size_t) pm->Nmesh * pm->Nmesh * (size_t) (pm->Nmesh + 10) < (1ull << 29) &&
                       shq_walk_can_fuse_readout_pre(ctx, params, n);
-    SHQ_TRY(shq_pm_execute(ctx, pm, !fuse));
-    if(!fuse)
-        SHQ_TRY(shq_grav_refresh_oldacc(ctx, params->G));
-    else {
+    /* not fused: the readout kernel forms OldAcc as it stores GravPM (the operations of shq_grav_refresh_oldacc, one pass less) */
+    ctx->readout_oldacc_G = (!fuse && ctx->numpart > 0 && ctx->treeacc.ptr && ctx->oldacc.ptr) ? params->G : 0.0;
+    const bool oldacc_done = ctx->readout_oldacc_G > 0;
+    const int rc_pm = shq_pm_execute(ctx, pm, !fuse);
+    ctx->readout_oldacc_G = 0;
+    SHQ_TRY(rc_pm);
+    if(!fuse) {
+        if(!oldacc_done)
+            SHQ_TRY(shq_grav_refresh_oldacc(ctx, params->G));
+    } else {
         ctx->fuse_G = params->G;
         ctx->fuse_readout = true;
     }

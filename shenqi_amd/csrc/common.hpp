@@ -217,7 +217,10 @@ struct shq_context {
     hipEvent_t ev_pair_fork = nullptr, ev_pair_join = nullptr;
     bool pm_pending = false;
     bool pm_overlap = false;
-    bool treepm_fuse = true;   /* SHQ_TREEPM_FUSE: shq_treepm_step may fuse the readout into the walk */
+    bool treepm_fuse = false;  /* SHQ_TREEPM_FUSE / shq_treepm_set_fuse: shq_treepm_step carries the readout in the walk's task prologue.  Off since
+                                  round 4: with the pair kernel beside the main walk the prologue's 104 eight-byte loads per lane cost the walk
+                                  2.0 ms (28.5 -> 30.5) where the readout kernel with its 28 sixteen-byte loads takes 1.44 (same-box A/B) */
+    double readout_oldacc_G = 0; /* > 0: the PM's readout kernel also forms OldAcc from FullTreeGravAccel and the new GravPM (shq_treepm_step) */
     bool last_step_fused = false;
     bool fuse_readout = false; /* shq_treepm_step: the next exact walk carries the PM readout + OldAcc refresh in its prologue */
     double fuse_cell = 0, fuse_ffac = 0, fuse_G = 0;

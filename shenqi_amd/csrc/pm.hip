@@ -249,7 +249,8 @@ struct __attribute__((aligned(8))) pair8 { double x, y; }; /* two z-adjacent cel
 __global__ __launch_bounds__(256) void pm_readout_kernel(const double4 *__restrict__ posm, const uint8_t *__restrict__ pflags,
                                                          long long n, const double *__restrict__ mesh, int N, int zp,
                                                          double cell, double ffac, double *gravpm, double *pmpot, int xshift,
-                                                         int nxalloc, int *oob, unsigned xcdk)
+                                                         int nxalloc, int *oob, unsigned xcdk, const double *__restrict__ treeacc = nullptr,
+                                                         double *oldacc = nullptr, double G = 0)
 {
     /* consecutive workgroups (consecutive runs of the space-filling curve: neighbouring mesh lines) share an XCD's L2 */
     const long long i = (long long) xcd_block(blockIdx.x, gridDim.x, xcdk) * blockDim.x + threadIdx.x;
@@ -331,6 +332,15 @@ __global__ __launch_bounds__(256) void pm_readout_kernel(const double4 *__restri
     gravpm[3 * i + 1] = g1;
     gravpm[3 * i + 2] = g2;
     pmpot[i] = gp;
+    if(oldacc) { /* shq_treepm_step: grav_get_abs_accel (gravshort2.hpp:111-121) with the new GravPM, the operations of oldacc_kernel */
+        const double gv[3] = {g0, g1, g2};
+        double s = 0;
+        for(int j = 0; j < 3; j++) {
+            const double ax = treeacc[3 * i + j] + gv[j];
+            s += ax * ax;
+        }
+        oldacc[i] = sqrt(s) / G;
+    }
 }
 
 /* copy rows of `len` doubles between pitches; as_i64: the source holds fixed-point integers */
@@ -575,7 +585,8 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm, bool readout)
     if(n > 0 && readout) { /* !readout: shq_treepm_step, the tree walk's prologue reads the potential mesh */
         const double ffac = -(N / pm->BoxSize);
         pm_readout_kernel<<<dim3((unsigned) ((n + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-            ctx->posm.ptr, ctx->pflags.ptr, n, ctx->mesh.ptr, N, zp, cell, ffac, ctx->gravpm.ptr, ctx->pmpot.ptr, 0, N, ctx->pm_oob.ptr, pm_xcdk(0));
+            ctx->posm.ptr, ctx->pflags.ptr, n, ctx->mesh.ptr, N, zp, cell, ffac, ctx->gravpm.ptr, ctx->pmpot.ptr, 0, N, ctx->pm_oob.ptr, pm_xcdk(0),
+            ctx->readout_oldacc_G > 0 ? ctx->treeacc.ptr : nullptr, ctx->readout_oldacc_G > 0 ? ctx->oldacc.ptr : nullptr, ctx->readout_oldacc_G);
     }
     SHQ_HIP(hipGetLastError());
     SHQ_HIP(hipEventRecord(ctx->ev_begin[13], ctx->stream));
