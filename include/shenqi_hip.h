@@ -663,7 +663,7 @@ int shq_set_walk_overlap(shq_context *ctx, int mode);
  * shq_walk_pair_status: launches since shq_init that needed the mop-up pass, the deepest pair stack seen (entries, of SHQ_SPARSE_STACK
  * = 4096 per wave), the tasks the last launch's mop-up walked; waits for the stream and returns the sticky error like the others.
  * shq_set_walk_debug (tests): pair_spin_max > 0 = polls of a task's flag before a live pair wave gives up (default 2^22; 1 starves
- * it: every task goes to the mop-up pass); pair_stack_cap > 0 = pairs per wave stack (704 .. 4096; small values force the overflow). */
+ * it: every task goes to the mop-up pass); pair_stack_cap > 0 = pairs per wave stack (1344 .. 4096; small values force the overflow). */
 int shq_walk_pair_status(shq_context *ctx, int64_t *recovered_launches, int64_t *stack_high_water, int64_t *last_mopped_tasks);
 int shq_set_walk_debug(shq_context *ctx, int pair_spin_max, int pair_stack_cap);
 /* Checker utility: direct summation as the reference's own gravity test does it (force_direct / grav_force,

@@ -254,6 +254,9 @@ __device__ __forceinline__ int walk_next_task(WalkArgsK c, int &region, int &tri
 #endif
 #define SHQ_SPARSE_STACK 4096  /* pairs per resident wave of the pair kernel: 9 x the deepest stack seen (443 at 256^3 S-cluster, shq_walk_pair_status) */
 #define SHQ_SPARSE_SPIN (1u << 22)
+#ifndef SHQ_PAIR_DEPTH2
+#define SHQ_PAIR_DEPTH2 1      /* the pair kernel takes two batches of 64 pairs per round (0: one) */
+#endif
 /* The pair kernel's status words (ctx->sp_flags).  [0, 8) belong to one launch and are cleared by the next; [8, 16) are STICKY: no
  * launch clears them, a copy travels to pinned host memory behind every launch, and the library's entry points return SHQ_ERR_DEVICE
  * once the error word is up (shq_walk_check_status) - the reference checks every launch and ends the run (treewalk2.cuh:351-353). */
@@ -271,8 +274,8 @@ enum SpFlag {
 /* the pair kernel's workgroups: waves per workgroup (one window table each), workgroups per CU, waves per SIMD */
 #ifndef SHQ_PAIR_WAVES
 #define SHQ_PAIR_WAVES 8
-#define SHQ_PAIR_WG_PER_CU 3
-#define SHQ_PAIR_EU 6
+#define SHQ_PAIR_WG_PER_CU 2
+#define SHQ_PAIR_EU 4
 #endif
 
 template <bool POT>
@@ -683,14 +686,13 @@ __device__ __forceinline__ LeanProducts lean_products(double mass, double len, d
 /* level of a node whose side is rootlen 2^-level: same mantissa, so the high words differ by level << 20 */
 __device__ __forceinline__ int lean_level(double rootlen, double len) { return (__double2hiint(rootlen) - __double2hiint(len)) >> 20; }
 
-/* waves_per_eu(6, 6) is there for the register budget it implies (80): the four-wave build, which shares its SIMDs with the main walk,
- * cannot reach six waves by itself (its LDS), which the compiler remarks on */
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wpass-failed"
 template <bool POT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SHQ_PAIR_EU, SHQ_PAIR_EU))) void grav_pair_kernel(const WalkArgs a)
+__device__ __forceinline__ void grav_pair_body(const WalkArgs &a)
 {
-    /* 8 waves share one window table: 52 KB per workgroup, three of them (24 waves) per CU */
+    /* the workgroup's waves share one window table: 52 KB per workgroup of eight waves, two of them per CU (behind the walk); 34 KB per
+     * workgroup of four (beside it) */
     __shared__ double4 tab[SHQ_NGRAVTAB];
     __shared__ double4 tgt_all[WAVES][64];   /* px, py, pz, errtol * OldAcc of the task's targets */
     __shared__ double acc_all[WAVES][4][64]; /* ax, ay, az, pot per target */
@@ -794,50 +796,66 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SHQ_
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        while(sp > 0) {
-            const int np = sp < 64 ? sp : 64;
-            sp -= np;
-            int node = -1, end = -1, slot = 0, kind = 0;
+        /* TWO batches of up to 64 pairs per round, the top 128 entries of the stack: both batches' pops are one trip to memory and both
+         * batches' records the next, where a batch at a time made them two trips per 64 pairs - the kernel waits for memory, not for
+         * arithmetic, and beside the main walk it has one wave per SIMD and registers to spare (128 fit behind the main walk's 6 x 64).
+         * Batch A's records are requested first, so its evaluation starts while B's are still on their way. */
+        struct PairLd {
+            int node, end, slot, kind;
+            double4 src;
+            double cx, cy, cz, len;
+            int nsib, nchild, ntype, ncount;
+        };
+        struct PairOut {
+            int push_sib, push_child, child_end, leaf0, leafn;
+        };
+        auto pair_pop = [&](int base, int np, PairLd &p) {
+            p.node = -1, p.end = -1, p.slot = 0, p.kind = 0;
             if(lane < np) {
-                const int4 pr = stack[sp + lane];
-                node = pr.x;
-                end = pr.y;
-                slot = pr.z;
-                kind = pr.w;
+                const int4 pr = stack[base + lane];
+                p.node = pr.x, p.end = pr.y, p.slot = pr.z, p.kind = pr.w;
             }
-            int push_sib = -1, push_child = -1, child_end = -1, leaf0 = 0, leafn = 0;
+        };
+        /* ONE body for both kinds of pair: a node record begins with {cofm, mass}, which is what a leaf particle's record is, so the
+         * source is one load from either array and the rest of a node's record is requested right behind it */
+        auto pair_fetch = [&](PairLd &p) {
+            p.src = make_double4(0, 0, 0, 0);
+            p.cx = p.cy = p.cz = p.len = 0;
+            p.nsib = -1, p.nchild = -1, p.ntype = 0, p.ncount = 0;
+            if(p.node >= 0) {
+                const double4 *const sp4 = p.kind == 1 ? a.posm_leaf + p.node : reinterpret_cast<const double4 *>(a.nodeG + p.node);
+                p.src = *sp4;
+                if(p.kind == 0) {
+                    const NodeG *const nd = a.nodeG + p.node;
+                    p.len = nd->len;
+                    p.cx = nd->center[0], p.cy = nd->center[1], p.cz = nd->center[2];
+                    p.nsib = nd->sibling, p.nchild = nd->child, p.ntype = nd->type, p.ncount = nd->count;
+                }
+            }
+        };
+        auto pair_eval = [&](const PairLd &p, PairOut &o) {
+            o.push_sib = -1, o.push_child = -1, o.child_end = -1, o.leaf0 = 0, o.leafn = 0;
             double ax = 0, ay = 0, az = 0, pot = 0;
-            /* ONE body for both kinds of pair: a node record begins with {cofm, mass}, which is what a leaf particle's record is, so the
-             * source is one load from either array, the rest of a node's record is requested right behind it (one trip to memory per
-             * batch, not one per kind), and displacement, wrap, r^2 and the evaluation are issued once for the whole wave */
-            const bool live = node >= 0, isnode = live && kind == 0;
-            double4 src = make_double4(0, 0, 0, 0);
-            double cx = 0, cy = 0, cz = 0, wraplim = 0, rcut2 = 0, rcuthl = 0, mlen2 = 0, bhlim = 0, inside = 0;
-            int nsib = -1, nchild = -1, ntype = 0, ncount = 0;
-            if(live) {
-                const double4 *const sp4 = kind == 1 ? a.posm_leaf + node : reinterpret_cast<const double4 *>(a.nodeG + node);
-                src = *sp4;
-            }
+            const bool live = p.node >= 0, isnode = live && p.kind == 0;
+            double wraplim = 0, rcut2 = 0, rcuthl = 0, mlen2 = 0, bhlim = 0, inside = 0;
             if(isnode) {
-                const NodeG *const nd = a.nodeG + node;
-                const double len = nd->len;
-                cx = nd->center[0], cy = nd->center[1], cz = nd->center[2];
-                nsib = nd->sibling, nchild = nd->child, ntype = nd->type, ncount = nd->count;
                 if(lean) {
                     /* this kernel is bound by the 16-byte pieces its lanes fetch from 64 different lines (a second record's worth of
-                     * loads per pair: 3.5 -> 5.8 ms), not by arithmetic: the second half of the record — products of {mass, len} and
-                     * the walk parameters — is recomputed with the expressions that filled it (checked record by record by
+                     * loads per pair: 3.5 -> 5.8 ms), not by arithmetic: the second half of the record - products of {mass, len} and
+                     * the walk parameters - is recomputed with the expressions that filled it (checked record by record by
                      * fill_rcuthl_kernel), five pieces per pair instead of eight.  Without the interior flag: such a node's wrap
                      * only ever changes lanes that are discarded either way (the comment of fill_rcuthl_kernel) */
-                    const LeanProducts lp = lean_products(src.w, len, a.rcut, a.Box);
+                    const LeanProducts lp = lean_products(p.src.w, p.len, a.rcut, a.Box);
                     rcuthl = lp.rcuthl, mlen2 = lp.mlen2, inside = lp.inside, wraplim = lp.wraplim, rcut2 = a.rcut2;
-                    bhlim = bh_lvl[lean_level(rootlen, len) & 31];
-                } else
+                    bhlim = bh_lvl[lean_level(rootlen, p.len) & 31];
+                } else {
+                    const NodeG *const nd = a.nodeG + p.node;
                     bhlim = nd->bhlim, mlen2 = nd->mlen2, inside = nd->inside, rcut2 = nd->rcut2, wraplim = nd->wraplim, rcuthl = nd->rcuthl;
+                }
             }
-            const double4 tg = tgt[slot];
-            double dx = src.x - tg.x, dy = src.y - tg.y, dz = src.z - tg.z;
-            double ux = cx - tg.x, uy = cy - tg.y, uz = cz - tg.z;
+            const double4 tg = tgt[p.slot];
+            double dx = p.src.x - tg.x, dy = p.src.y - tg.y, dz = p.src.z - tg.z;
+            double ux = p.cx - tg.x, uy = p.cy - tg.y, uz = p.cz - tg.z;
             double cmax = fmax(fmax(fabs(ux), fabs(uy)), fabs(uz));
             /* the wrap is the identity on every component it is not needed for: applying it per lane gives the main walk's bits.  A
              * leaf particle is always wrapped (gravshort2.hpp:290-304), a node unless it is interior (sign bit of wraplim) */
@@ -860,41 +878,36 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SHQ_
                 const bool open = (!a.useBH && mlen2 > r2 * r2 * tg.w) || r2 < bhlim || cmax < inside;
                 ev = keep && !open;
                 if(keep && open) {
-                    if(ntype == SHQ_NODE_NODE_TYPE) {
-                        push_child = nchild;
-                        child_end = nsib;
-                    } else if(ntype == SHQ_PARTICLE_NODE_TYPE) { /* its particles become pairs of their own: one per lane and batch */
-                        leaf0 = nchild;
-                        leafn = ncount;
+                    if(p.ntype == SHQ_NODE_NODE_TYPE) {
+                        o.push_child = p.nchild;
+                        o.child_end = p.nsib;
+                    } else if(p.ntype == SHQ_PARTICLE_NODE_TYPE) { /* its particles become pairs of their own: one per lane and batch */
+                        o.leaf0 = p.nchild;
+                        o.leafn = p.ncount;
                     }
                 }
-                if(nsib != end && nsib >= 0)
-                    push_sib = nsib;
+                if(p.nsib != p.end && p.nsib >= 0)
+                    o.push_sib = p.nsib;
             }
             if(ev) { /* CLAMP for the particle that is the target itself; a no-op on an accepted node's r^2 */
-                apply_accn<POT, true>(tab, dx, dy, dz, r2, src.w, a, ax, ay, az, pot);
-                atomicAdd(&acc[0][slot], ax);
-                atomicAdd(&acc[1][slot], ay);
-                atomicAdd(&acc[2][slot], az);
+                apply_accn<POT, true>(tab, dx, dy, dz, r2, p.src.w, a, ax, ay, az, pot);
+                atomicAdd(&acc[0][p.slot], ax);
+                atomicAdd(&acc[1][p.slot], ay);
+                atomicAdd(&acc[2][p.slot], az);
                 if(POT)
-                    atomicAdd(&acc[3][slot], pot);
-                atomicAdd(&cntl[slot], 1);
+                    atomicAdd(&acc[3][p.slot], pot);
+                atomicAdd(&cntl[p.slot], 1);
             }
-            /* siblings first, then children, leaf particles on top: the stack stays depth-bounded */
-            {
-                const unsigned long long m = shq_ballot(push_sib >= 0);
-                if(push_sib >= 0)
-                    stack[sp + __popcll(m & below)] = make_int4(push_sib, end, slot, 0);
-                sp += __popcll(m);
-            }
-            {
-                const unsigned long long m = shq_ballot(push_child >= 0);
-                if(push_child >= 0)
-                    stack[sp + __popcll(m & below)] = make_int4(push_child, child_end, slot, 0);
-                sp += __popcll(m);
-            }
-            /* a leaf's particles: the lane's first slot is the prefix sum of the counts below it, formed from the votes on the four
-             * bits of the count (count <= 8) instead of one vote per particle */
+        };
+        auto push_nodes = [&](int what, int what_end, int slot) {
+            const unsigned long long m = shq_ballot(what >= 0);
+            if(what >= 0)
+                stack[sp + __popcll(m & below)] = make_int4(what, what_end, slot, 0);
+            sp += __popcll(m);
+        };
+        /* a leaf's particles: the lane's first slot is the prefix sum of the counts below it, formed from the votes on the four
+         * bits of the count (count <= 8) instead of one vote per particle */
+        auto push_leaves = [&](int leaf0, int leafn, int slot) {
             if(shq_ballot(leafn > 0) != 0ull) {
                 const unsigned long long b0 = shq_ballot((leafn & 1) != 0), b1 = shq_ballot((leafn & 2) != 0),
                                          b2 = shq_ballot((leafn & 4) != 0), b3 = shq_ballot((leafn & 8) != 0);
@@ -907,8 +920,35 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SHQ_
                 }
                 sp += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3);
             }
+        };
+        while(sp > 0) {
+            const int npa = sp < 64 ? sp : 64;
+            sp -= npa;
+            const int npb = SHQ_PAIR_DEPTH2 ? (sp < 64 ? sp : 64) : 0;
+            sp -= npb;
+            PairLd pa, pb;
+            PairOut oa, ob;
+            pair_pop(sp + npb, npa, pa);
+            if(npb > 0)
+                pair_pop(sp, npb, pb);
+            pair_fetch(pa);
+            if(npb > 0)
+                pair_fetch(pb);
+            pair_eval(pa, oa);
+            if(npb > 0)
+                pair_eval(pb, ob);
+            /* siblings first, then children, leaf particles on top: the stack stays depth-bounded */
+            push_nodes(oa.push_sib, pa.end, pa.slot);
+            if(npb > 0)
+                push_nodes(ob.push_sib, pb.end, pb.slot);
+            push_nodes(oa.push_child, oa.child_end, pa.slot);
+            if(npb > 0)
+                push_nodes(ob.push_child, ob.child_end, pb.slot);
+            push_leaves(oa.leaf0, oa.leafn, pa.slot);
+            if(npb > 0)
+                push_leaves(ob.leaf0, ob.leafn, pb.slot);
             sp_high = sp > sp_high ? sp : sp_high;
-            if(sp > a.sp_stack_cap - 640) { /* never seen (SP_HIGHWATER is reported); loud and sticky if it happens: the pairs are dropped */
+            if(sp > a.sp_stack_cap - 1280) { /* never seen (SP_HIGHWATER is reported); loud and sticky if it happens: the pairs are dropped */
                 if(lane == 0) {
                     agent_store(a.sp_flags + SP_OVERFLOW, 1);
                     atomicOr(a.sp_flags + SP_STICKY_ERROR, 1);
@@ -961,6 +1001,15 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SHQ_
         atomicAdd(a.sp_flags + SP_MOPPED, mopped);
     if(a.sp_mop && blockIdx.x == 0 && threadIdx.x == 0)
         atomicAdd(a.sp_flags + SP_STICKY_RECOVERED, 1);
+}
+
+/* One register budget for both launch forms, 128 (waves_per_eu(4, 4) is there for the budget it implies): beside the main walk (workgroups
+ * of four waves, one per SIMD) that is what is left of a SIMD's 512 registers behind the main walk's six waves of 64; behind it (workgroups
+ * of eight waves, two per CU) the two batches per round need it as well.  The same code in both: the same sums in the same order. */
+template <bool POT> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void grav_pair_kernel_live(const WalkArgs a) { grav_pair_body<POT, 4>(a); }
+template <bool POT> __global__ __launch_bounds__(64 * SHQ_PAIR_WAVES) __attribute__((amdgpu_waves_per_eu(SHQ_PAIR_EU, SHQ_PAIR_EU))) void grav_pair_kernel(const WalkArgs a)
+{
+    grav_pair_body<POT, SHQ_PAIR_WAVES>(a);
 }
 
 #pragma clang diagnostic pop
@@ -1298,8 +1347,8 @@ int shq_walk_check_status(shq_context *ctx, bool sync)
 extern "C" int shq_set_walk_debug(shq_context *ctx, int pair_spin_max, int pair_stack_cap)
 {
     SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
-    SHQ_CHECK(pair_spin_max >= 0 && (pair_stack_cap == 0 || (pair_stack_cap >= 704 && pair_stack_cap <= SHQ_SPARSE_STACK)), SHQ_ERR_INVALID,
-              "walk debug: pair_spin_max >= 0 (0: default), pair_stack_cap 0 (default) or 704..%d", SHQ_SPARSE_STACK);
+    SHQ_CHECK(pair_spin_max >= 0 && (pair_stack_cap == 0 || (pair_stack_cap >= 1344 && pair_stack_cap <= SHQ_SPARSE_STACK)), SHQ_ERR_INVALID,
+              "walk debug: pair_spin_max >= 0 (0: default), pair_stack_cap 0 (default) or 1344..%d", SHQ_SPARSE_STACK);
     ctx->sp_spin_max = pair_spin_max > 0 ? (unsigned) pair_spin_max : SHQ_SPARSE_SPIN;
     ctx->sp_stack_cap = pair_stack_cap > 0 ? pair_stack_cap : SHQ_SPARSE_STACK; /* never above what was reserved */
     return SHQ_OK;
@@ -1493,13 +1542,13 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
         const dim3 pg((unsigned) pair_blocks);
         if(live) { /* workgroups of four waves, one per SIMD: 6 x 64 registers of the main walk + 80 */
             if(update_potential)
-                grav_pair_kernel<true, 4><<<pg, dim3(256), 0, ps>>>(a);
+                grav_pair_kernel_live<true><<<pg, dim3(256), 0, ps>>>(a);
             else
-                grav_pair_kernel<false, 4><<<pg, dim3(256), 0, ps>>>(a);
+                grav_pair_kernel_live<false><<<pg, dim3(256), 0, ps>>>(a);
         } else if(update_potential)
-            grav_pair_kernel<true, SHQ_PAIR_WAVES><<<pg, dim3(64 * SHQ_PAIR_WAVES), 0, ps>>>(a);
+            grav_pair_kernel<true><<<pg, dim3(64 * SHQ_PAIR_WAVES), 0, ps>>>(a);
         else
-            grav_pair_kernel<false, SHQ_PAIR_WAVES><<<pg, dim3(64 * SHQ_PAIR_WAVES), 0, ps>>>(a);
+            grav_pair_kernel<false><<<pg, dim3(64 * SHQ_PAIR_WAVES), 0, ps>>>(a);
         SHQ_HIP(hipGetLastError());
         if(live) {
             SHQ_HIP(hipEventRecord(ctx->ev_pair_join, ps));
@@ -1512,9 +1561,9 @@ int shq_launch_grav_walk(shq_context *ctx, const shq_grav_params *p, const int32
             m.sp_mop = 1;
             const dim3 mg((unsigned) mop_blocks);
             if(update_potential)
-                grav_pair_kernel<true, SHQ_PAIR_WAVES><<<mg, dim3(64 * SHQ_PAIR_WAVES), 0, ctx->stream>>>(m);
+                grav_pair_kernel<true><<<mg, dim3(64 * SHQ_PAIR_WAVES), 0, ctx->stream>>>(m);
             else
-                grav_pair_kernel<false, SHQ_PAIR_WAVES><<<mg, dim3(64 * SHQ_PAIR_WAVES), 0, ctx->stream>>>(m);
+                grav_pair_kernel<false><<<mg, dim3(64 * SHQ_PAIR_WAVES), 0, ctx->stream>>>(m);
             SHQ_HIP(hipGetLastError());
         }
         /* the sticky words follow every launch to pinned host memory: the entry points read them there without a round trip */

@@ -793,8 +793,8 @@ def test_pair_kernel_failures_in_a_resident_loop(ctx):
         assert rc == 0 and rec1 == rec0 + 3 and mop > 0, (rc, rec0, rec1, mop)
         for a, b, name in zip(got, ref, ("acc", "pot", "ninteractions")):
             assert np.array_equal(a, b), name
-        # (2) pair stacks of 704 entries overflow in the cluster: sticky, reported although two more launches follow the first failure
-        capi.check(capi.hip.shq_set_walk_debug(ctx.h, 0, 704))
+        # (2) pair stacks of 1344 entries overflow in the cluster: sticky, reported although two more launches follow the first failure
+        capi.check(capi.hip.shq_set_walk_debug(ctx.h, 0, 1344))
         start()
         capi.check(step())                                      # queued; its failure is not known yet
         rcs = [step()]

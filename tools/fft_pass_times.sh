@@ -28,4 +28,4 @@ PY
   rm -rf $OUT/p_$tag
 }
 run default
-for kv in "$@"; do run "$(echo $kv | tr '=' '_')" "$kv"; done
+for kv in "$@"; do run "$(echo $kv | tr '=/' '__')" "$kv"; done
