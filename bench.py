@@ -82,9 +82,18 @@ def cpu_baseline(pos, mass, tree, gp_rel, oldacc, L, acc_gpu=None):
                 "targets": int(len(targets)), "tolerance_north_star": 1e-3}
     nsub = min(n, 64**3)
     sub = pos[:: max(1, n // nsub)][:nsub]
+    # the PM leg: the oracle's deposit / transfer functions / readout around scipy's multi-threaded pocketfft (the oracle's own mixed-radix
+    # FFT is a checker, not a baseline; the reference runs FFTW / heffte, absent here)
+    fft_threads = orc.lib.orc_num_threads()
+    fft_name = "scipy.fft (pocketfft, %d threads)" % fft_threads
+    try:
+        orc.use_scipy_fft(fft_threads)
+    except Exception:
+        fft_name = "the oracle's own mixed-radix FFT (scipy.fft unavailable)"
     t0 = time.perf_counter()
     orc.pm_force(sub, np.ones(len(sub), dtype=np.float32), 192, L, 1.5, G)
     t_pm = time.perf_counter() - t0
+    orc.use_scipy_fft(0)
     frac_tree = len(targets) / n
     frac_pm = len(sub) / n
     est_full = t_tree / frac_tree + t_pm / frac_pm
@@ -92,12 +101,11 @@ def cpu_baseline(pos, mass, tree, gp_rel, oldacc, L, acc_gpu=None):
     return {
         "value": n / est_full, "unit": "particle-steps/s", "cores": orc.lib.orc_num_threads(), "kind": "port",
         "cpu_model": model, "physical_cores": phys,
-        # the two legs separately: the oracle's PM runs on its own mixed-radix FFT (the reference's FFTW / heffte is absent), which
-        # dominates the combined figure; the tree leg is the like-for-like part
+        # the two legs separately; the tree leg is the like-for-like part
         "tree_value": n / (t_tree / frac_tree), "pm_value": n / (t_pm / frac_pm),
         "sample": "oracle tree walk of %d of %d targets (every 64th 64-target group, same tree) in %.2f s + oracle PM step "
-                  "(reference structure, 5 FFTs) on a %d-particle/192^3-mesh sub-problem in %.2f s; each scaled by its "
-                  "fraction of the full job" % (len(targets), n, t_tree, len(sub), t_pm),
+                  "(reference structure, 5 FFTs through %s) on a %d-particle/192^3-mesh sub-problem in %.2f s; each scaled by its "
+                  "fraction of the full job" % (len(targets), n, t_tree, fft_name, len(sub), t_pm),
         "tree_s_sample": t_tree, "pm_s_sample": t_pm, "force_error": ferr,
     }
 
@@ -802,7 +810,10 @@ def main():
     zp = 2 * (((nmesh // 2 + 1) + 3) // 4 * 4)
     mesh_bytes = 8.0 * nmesh * nmesh * zp
     fft_bytes = 5 * 2 * mesh_bytes
-    pm_bytes = mesh_bytes + (32.0 + 128.0) * n + fft_bytes + (32.0 + 448.0 + 32.0) * n
+    deposit_bytes = (32.0 + 128.0) * n
+    readout_bytes = (32.0 + 448.0 + 32.0) * n
+    oldacc_bytes = (24.0 + 8.0) * n                       # the readout kernel also reads FullTreeGravAccel and writes OldAcc
+    pm_bytes = mesh_bytes + deposit_bytes + fft_bytes + readout_bytes
     # PM with the reference's structure (1 r2c + 4 c2r, separate transfer sweeps), for comparison only
     pm_bytes_reference_structure = 468.0 * n + 240.0 * ncells
     walk_s = st.kernel_ms * 1e-3
@@ -837,15 +848,23 @@ def main():
     # TFLOP/s on MI355X; no MFMA instruction is used or usable: bound "valu-f64").  The HBM view of the same launch
     # stays alongside: algorithmic bytes, measured traffic.
     walk_flops = 45.0 * st.ninteractions
+    # what one launch of the production walk moves by design: the walk's compulsory bytes, the PM mesh it clears for the next deposit
+    # (the `scrub` in the tasks' prologue), and - only on the fused route - the readout of its own targets (512 B each) + OldAcc
+    pm_cov_bytes = deposit_bytes + fft_bytes + (0.0 if fused.value else readout_bytes + oldacc_bytes)
+    walk_alg = {"tree_walk": tree_bytes, "pm_mesh_cleared_in_the_walk": mesh_bytes,
+                "pm_readout_in_the_prologue": (readout_bytes + oldacc_bytes) if fused.value else 0.0}
+    walk_alg_bytes = sum(walk_alg.values())
     walk_roofline = {"bound": "valu-f64", "kernel": "grav_walk_exact_kernel", "achieved": walk_flops / max(walk_s, 1e-12) / 1e12,
                      "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
                      "frac": walk_flops / max(walk_s, 1e-12) / 1e12 / FP64_VECTOR_PEAK_TF, "traffic": traffic,
-                     "algorithmic_flops": walk_flops, "algorithmic_bytes": tree_bytes, "hbm_algorithmic_GBs": tree_bytes / max(walk_s, 1e-12) / 1e9,
+                     "algorithmic_flops": walk_flops, "algorithmic_bytes": walk_alg_bytes, "algorithmic_bytes_parts": walk_alg,
+                     "hbm_algorithmic_GBs": walk_alg_bytes / max(walk_s, 1e-12) / 1e9,
                      "valu_busy": valu_busy,
                      "note": "FP64-issue bound: 45 flop per interaction (SURVEY 8(d)) x interactions / kernel time against the FP64 "
-                             "peak; valu_busy = SQ_INSTS_VALU x 4 / resident SIMD cycles from the committed SQ pass; `traffic` = HBM "
-                             "bytes per launch of the production walk from the committed FETCH_SIZE / WRITE_SIZE passes (several "
-                             "times the compulsory bytes, still a fraction of a TB/s: not a bandwidth problem).  The HBM-bound part "
+                             "peak; valu_busy = SQ_INSTS_VALU x 4 / resident SIMD cycles from the committed SQ pass, in which the profiler "
+                             "SERIALISES the main walk and the pair kernel (a counter pass cannot see them overlapped); `traffic` = HBM "
+                             "bytes per launch of the production walk (main walk row only) from the committed FETCH_SIZE / WRITE_SIZE "
+                             "passes, against algorithmic_bytes = the parts listed.  The HBM-bound part "
                              "of the step is the PM: roofline_pm_fft.  Kernel time = one HIP-event bracket on the walk's stream around "
                              "grav_walk_exact_kernel and grav_pair_kernel, which runs beside it on a second stream and is waited for "
                              "before the closing event (both start within 10 us, the pair kernel ends ~0.3 ms after the walk: "
@@ -869,8 +888,10 @@ def main():
                             "achieved": fft_bytes / max(fft_s, 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": fft_bytes / max(fft_s, 1e-12) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_fft,
                             "algorithmic_bytes": fft_bytes,
-                            "note": "a plain copy of the same 3.66 GB mesh (tools/copy_rate.py, torch copy_) reaches 4.5 TB/s on this card: "
-                                    "five passes at that rate would take 8.1 ms"},
+                            "note": "yardstick: tools/copy_probe.hip moves this mesh with 16-byte loads and stores at 5.8 TB/s in contiguous "
+                                    "48 KB tiles (6.4 TB/s for a plain nontemporal copy), 4.6 TB/s with one side in 64-byte pieces, 3.0-3.9 TB/s "
+                                    "with both sides in 64-byte pieces (the in-place passes of rounds 1-3); the transposing pipeline of round 4 "
+                                    "has contiguous tiles on eight of its ten sides: its five passes at the probe's rates would take 6.9 ms"},
         "kernels": {
             "tree_walk_ms": st.kernel_ms, "tree_walk_with_counters_ms": counted_walk_ms,
             "pair_kernel_recovered_launches": int(pair_rec.value), "pair_kernel_stack_high_water": int(pair_high.value),
@@ -888,8 +909,10 @@ def main():
                       "total": ph[5],
                       "note": "zero: the mesh is cleared in the shadow of the previous walk; readout: 0 when the walk's prologue does it (config.step_calls)"},
             "tree_wave_figures_from": "the counter launch (one task per wave, no leaf ring): lane efficiency and rounds per wave describe the union walk, not the ring's drain",
-            "pm_algorithmic_GBs": pm_bytes / max(pm_s, 1e-12) / 1e9,
-            "pm_frac_of_hbm_peak": pm_bytes / max(pm_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
+            # the bytes of what pm_ms.total covers: deposit + five passes + (unless the walk's prologue did it) readout and OldAcc; the
+            # clearing of the mesh rides in the walk and is counted there (roofline.algorithmic_bytes_parts)
+            "pm_algorithmic_GBs": pm_cov_bytes / max(pm_s, 1e-12) / 1e9,
+            "pm_frac_of_hbm_peak": pm_cov_bytes / max(pm_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
             "pm_reference_structure_GBs": pm_bytes_reference_structure / max(pm_s, 1e-12) / 1e9,
             "event_ms_per_step": ev_ms / args.steps,
         },
@@ -935,7 +958,12 @@ def main():
             if it == nwarm:
                 ctx.synchronize()
                 t0 = time.perf_counter()
+            if it == nres + nwarm - 1:
+                ctx.timer_begin(1)              # the last pass on one time line (kernels.resident_timeline_ms)
             sq.drift(ctx, 1e-4 * L / n1, L)
+            if not (args.separate_calls or args.walk_mode != 0):
+                # gravpm_force started early: the PM runs on the library's second stream while the tree is built; shq_treepm_step joins it
+                capi.check(capi.hip.shq_pm_start(ctx.h, C.byref(pmp), G))
             sq.tree_build_device(ctx, L)
             # targets in tree order: the particle index order goes stale as the particles move
             if args.separate_calls or args.walk_mode != 0:
@@ -946,8 +974,16 @@ def main():
                 capi.check(capi.hip.shq_treepm_step(ctx.h, C.byref(pmp), C.byref(gp_rel), 0, sq.WALK_EXACT | sq.WALK_TREE_ORDER))
             sq.kick_short(ctx, gk, from_accel_store=True)
             sq.kick_pm(ctx, 1e-24)
+        ctx.timer_end(1)
         ctx.synchronize()
         t_res = time.perf_counter() - t0
+        def at(slot, which=0):
+            ms = C.c_double(0)
+            capi.check(capi.hip.shq_timer_between_ms(ctx.h, 1, 0, slot, which, C.byref(ms)))
+            return round(ms.value, 3)
+        out["kernels"]["resident_timeline_ms"] = {"pm_begin": at(8), "fft_begin": at(9), "fft_end": at(10), "pm_end": at(13), "tree_build_begin": at(16),
+                                                  "tree_build_end": at(16, 1), "walk_begin": at(19), "walk_end": at(19, 1), "kicks_end": at(1, 1),
+                                                  "note": "the last pass of the resident loop from its drift on (HIP events across the two streams)"}
         out["kernels"]["resident_full_step_ms"] = 1e3 * t_res / nres
         out["kernels"]["resident_full_step_particle_steps_per_s"] = n * nres / t_res
         rst = sq.WalkStats()

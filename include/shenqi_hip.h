@@ -64,6 +64,10 @@ void *shq_stream(shq_context *ctx);
 int shq_timer_begin(shq_context *ctx, int slot);
 int shq_timer_end(shq_context *ctx, int slot);
 int shq_timer_elapsed_ms(shq_context *ctx, int slot, double *ms);
+/* elapsed time between two recorded timer events (which: 0 begin, 1 end), e.g. the caller's slot 1 begin -> the library's walk (slot 19)
+ * begin: where the phases of a resident step lie on one time line although they run on different streams.  Library slots: 8 PM begin,
+ * 9 / 10 FFT pipeline begin / end, 13 PM end (all as begin events), 16 tree build, 19 tree walk. */
+int shq_timer_between_ms(shq_context *ctx, int slot_a, int which_a, int slot_b, int which_b, double *ms);
 /* Library version string. */
 const char *shq_version(void);
 
@@ -1142,6 +1146,13 @@ int shq_pm_download(shq_context *ctx, double (*gravpm)[3], double *pm_potential)
 int shq_treepm_step(shq_context *ctx, const shq_pm_params *pm, const shq_grav_params *params, int update_potential, int walk_mode);
 int shq_treepm_set_fuse(shq_context *ctx, int enable);
 int shq_treepm_last_fused(shq_context *ctx, int *fused);
+/* gravpm_force started early, for a resident step: the PM of the CURRENT positions (deposit, transforms, readout) is queued on the
+ * library's second stream behind everything queued so far, and the call returns; the caller goes on with what needs the positions but
+ * not the PM - shq_tree_build - and then calls shq_treepm_step with the same Nmesh, which joins this PM instead of running its own
+ * (same results bit for bit).  G > 0: the readout forms OldAcc = |FullTreeGravAccel + GravPM| / G as shq_treepm_step's does.  The
+ * reference has no order between force_tree_full and gravpm_force either (run.cpp:476-538; the PM uses no tree).  Every other consumer
+ * of PM results (shq_pm_download, shq_kick_pm, ...) joins it too; shq_drift and a particle upload discard it. */
+int shq_pm_start(shq_context *ctx, const shq_pm_params *pm, double G);
 /* Debug / parity taps: copy the mesh after deposit (Nmesh^3 doubles, [x][y][z]) and the
  * potential mesh after c2r. Valid after shq_pm_run with keep_meshes set. */
 /* HIP-event durations (ms) of the last shq_pm_run's phases: [0] zero+deposit+convert, [1] r2c,

@@ -78,6 +78,8 @@ void orc_pm_force(const double *pos, const float *mass, const uint8_t *skip, int
                   double *gravpm, double *potential, double *mesh_rho, double *mesh_pot);
 /* Unscaled 3-D r2c / c2r on an N^3 mesh, layouts [x][y][z] <-> [x][y][z'<=N/2] complex. */
 void orc_fft_r2c(int N, const double *real, double *complx);
+/* install other transforms for orc_pm_force (NULL, NULL: the oracle's own again); same conventions as orc_fft_r2c / orc_fft_c2r */
+void orc_set_fft(void (*r2c)(int, const double *, double *), void (*c2r)(int, const double *, double *));
 void orc_fft_c2r(int N, const double *complx, double *real);
 
 /* ---- SPH (libgadget/densitytree2.hpp, hydratree2.hpp, density2.h, densitykernel.hpp) ---- */

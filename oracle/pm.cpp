@@ -195,6 +195,20 @@ static inline void cic_setup(const double *Pos, double CellSize, int N, int iCel
     }
 }
 
+/* The transforms orc_pm_force calls: the oracle's own (below) unless a caller has installed others.  bench.py's cpu_baseline installs
+ * scipy's multi-threaded pocketfft behind the same deposit / transfer-function / readout code, so that the reported CPU baseline is
+ * not priced on this file's plain mixed-radix FFT (the reference runs FFTW / heffte, absent here).  Same conventions: unscaled both
+ * ways, half spectrum [x][y][z'] of N / 2 + 1 complex. */
+typedef void (*orc_fft_fn)(int, const double *, double *);
+static orc_fft_fn g_r2c = nullptr, g_c2r = nullptr;
+extern "C" void orc_set_fft(orc_fft_fn r2c, orc_fft_fn c2r)
+{
+    g_r2c = r2c;
+    g_c2r = c2r;
+}
+static void pm_r2c(int N, const double *real, double *complx) { (g_r2c ? g_r2c : orc_fft_r2c)(N, real, complx); }
+static void pm_c2r(int N, const double *complx, double *real) { (g_c2r ? g_c2r : orc_fft_c2r)(N, complx, real); }
+
 extern "C" void orc_pm_force(const double *pos, const float *mass, const uint8_t *skip, int64_t n,
                              const shq_pm_params *pm, int fixed_point_log2scale, int use_stencil,
                              double *gravpm, double *potential, double *mesh_rho, double *mesh_pot)
@@ -243,7 +257,7 @@ extern "C" void orc_pm_force(const double *pos, const float *mass, const uint8_t
         memcpy(mesh_rho, real.data(), sizeof(double) * N3);
 
     std::vector<cplx> rho_k((size_t) N * N * Nc);
-    orc_fft_r2c(N, real.data(), reinterpret_cast<double *>(rho_k.data()));
+    pm_r2c(N, real.data(), reinterpret_cast<double *>(rho_k.data()));
 
     /* potential_transfer, gravpm.cpp:378-444 (no neutrinos, no P(k) side effect) */
     const double asmth2 = pow((2 * M_PI) * pm->Asmth / N, 2);
@@ -290,7 +304,7 @@ extern "C" void orc_pm_force(const double *pos, const float *mass, const uint8_t
                     }
                     work[ip] = v;
                 }
-        orc_fft_c2r(N, reinterpret_cast<double *>(work.data()), fmesh[out].data());
+        pm_c2r(N, reinterpret_cast<double *>(work.data()), fmesh[out].data());
     }
     if(mesh_pot)
         memcpy(mesh_pot, fmesh[0].data(), sizeof(double) * N3);

@@ -579,6 +579,10 @@ hip.shq_pm_force.argtypes = [_vp, C.POINTER(PMParams), C.POINTER(PartView), _vp,
 hip.shq_pm_run.argtypes = [_vp, C.POINTER(PMParams)]
 hip.shq_pm_download.argtypes = [_vp, _vp, _vp]
 hip.shq_treepm_step.argtypes = [_vp, C.POINTER(PMParams), C.POINTER(GravParams), C.c_int, C.c_int]
+hip.shq_timer_between_ms.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+hip.shq_timer_between_ms.restype = C.c_int
+hip.shq_pm_start.argtypes = [_vp, _vp, C.c_double]
+hip.shq_pm_start.restype = C.c_int
 hip.shq_treepm_last_fused.argtypes = [_vp, C.POINTER(C.c_int)]
 hip.shq_treepm_set_fuse.argtypes = [_vp, C.c_int]
 hip.shq_pm_phase_ms.argtypes = [_vp, C.POINTER(C.c_double * 6)]

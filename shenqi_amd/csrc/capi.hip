@@ -126,8 +126,12 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
         ctx->own_stream = false;
         pm_cus = 0;
     } else {
+        /* the library's own main stream runs at the highest priority: what it queues beside the work of the two side streams (the pair
+         * kernel beside the walk, an early PM beside the tree build) gets the free slots first */
+        int plo = 0, phi = 0;
+        (void) hipDeviceGetStreamPriorityRange(&plo, &phi);
         hipError_t e = pm_cus > 0 ? hipExtStreamCreateWithCUMask(&ctx->stream, 8, mask_main)
-                                  : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+                                  : hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, getenv("SHQ_MAIN_PRIO_DEFAULT") ? 0 : phi);
         if(e != hipSuccess) {
             shq_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
             delete ctx;
@@ -141,6 +145,8 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
     }
     int prio_lo = 0, prio_hi = 0;
     (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if(getenv("SHQ_DEBUG_PRIO"))
+        fprintf(stderr, "[shq] stream priorities: lowest %d, highest %d\n", prio_lo, prio_hi);
     if((pm_cus > 0 ? hipExtStreamCreateWithCUMask(&ctx->stream_pm, 8, mask_pm)
                    : hipStreamCreateWithPriority(&ctx->stream_pm, hipStreamNonBlocking, prio_hi)) != hipSuccess ||
        hipEventCreateWithFlags(&ctx->ev_pm_ready, hipEventDisableTiming) != hipSuccess ||
@@ -184,6 +190,8 @@ extern "C" int shq_init(int device, void *stream, shq_context **out)
         ctx->walk_sparse = atoi(v);
     if(const char *v = getenv("SHQ_WALK_OVERLAP"))
         ctx->walk_overlap = atoi(v);
+    if(const char *v = getenv("SHQ_TREE_TARGETS_REFRESH"))
+        ctx->tree_targets_refresh = atoi(v) > 0 ? atoi(v) : 1;
     if(const char *v = getenv("SHQ_FFT_TRANSPOSED"))
         ctx->fft_transposed = atoi(v) != 0;
     if(const char *v = getenv("SHQ_TREEPM_FUSE"))
@@ -220,6 +228,8 @@ extern "C" void shq_shutdown(shq_context *ctx)
         (void) hipStreamSynchronize(ctx->stream_walk);
     if(ctx->stream_pm)
         (void) hipStreamSynchronize(ctx->stream_pm);
+    if(ctx->stream_pair)
+        (void) hipStreamSynchronize(ctx->stream_pair);
     (void) hipStreamSynchronize(ctx->stream);
     shq_pm_destroy_plans(ctx);
     ctx->posm.release(); ctx->oldacc.release(); ctx->treeacc.release(); ctx->gravpm.release();
@@ -356,6 +366,20 @@ extern "C" int shq_timer_end(shq_context *ctx, int slot)
     SHQ_HIP(hipEventRecord(ctx->ev_end[slot], ctx->stream));
     return SHQ_OK;
 }
+/* elapsed time from one recorded timer event to another (which: 0 = the slot's begin event, 1 = its end event): the slots of the library's
+ * own phases (8-13 PM, 16 tree build, 19 walk) against the caller's (0-7), whatever streams they were recorded on.  Waits for event b. */
+extern "C" int shq_timer_between_ms(shq_context *ctx, int slot_a, int which_a, int slot_b, int which_b, double *ms)
+{
+    SHQ_CHECK(ctx && ms && slot_a >= 0 && slot_a < SHQ_NTIMERS && slot_b >= 0 && slot_b < SHQ_NTIMERS, SHQ_ERR_INVALID, "bad timer slot");
+    hipEvent_t a = which_a ? ctx->ev_end[slot_a] : ctx->ev_begin[slot_a], b = which_b ? ctx->ev_end[slot_b] : ctx->ev_begin[slot_b];
+    SHQ_HIP(hipEventSynchronize(a));
+    SHQ_HIP(hipEventSynchronize(b));
+    float f = 0;
+    SHQ_HIP(hipEventElapsedTime(&f, a, b));
+    *ms = f;
+    return SHQ_OK;
+}
+
 extern "C" int shq_timer_elapsed_ms(shq_context *ctx, int slot, double *ms)
 {
     SHQ_CHECK(ctx && ms && slot >= 0 && slot < SHQ_NTIMERS, SHQ_ERR_INVALID, "bad timer slot %d", slot);
@@ -819,6 +843,7 @@ extern "C" int shq_particles_set_device(shq_context *ctx, const void *d_posm, in
     ctx->nlocal = nlocal;
     ctx->have_parts = true;
     ctx->have_pm_result = false;
+    ctx->pm_prestarted = false;
     return SHQ_OK;
 }
 
@@ -1182,23 +1207,57 @@ extern "C" int shq_pm_run(shq_context *ctx, const shq_pm_params *pm)
     SHQ_CHECK(ctx && pm, SHQ_ERR_INVALID, "null argument");
     SHQ_HIP(hipSetDevice(ctx->device));
     SHQ_TRY(shq_join_pm(ctx));
+    ctx->pm_prestarted = false;
     if(!ctx->pm_overlap)
         return shq_pm_execute(ctx, pm);
-    /* The PM reads only the positions and writes only GravPM / the PM potential: it runs on its own stream
-     * behind everything queued so far, and the main stream goes on (typically with the tree walk, which is
-     * VALU bound while the PM is HBM bound).  Consumers of its results join it (shq_join_pm). */
+    return shq_pm_run_on_pm_stream(ctx, pm, false);
+}
+
+/* The PM reads only the positions (and, when its readout forms OldAcc, FullTreeGravAccel) and writes only the mesh, GravPM, the PM potential
+ * and OldAcc: it runs on its own stream behind everything queued so far, and the main stream goes on.  Consumers of its results join it
+ * (shq_join_pm). */
+int shq_pm_run_on_pm_stream(shq_context *ctx, const shq_pm_params *pm, bool low_priority)
+{
+    /* low_priority (shq_pm_start): the library's lowest-priority stream, the pair kernel's, idle between two walks.  An FFT pass holds
+     * 464 of a SIMD's 512 registers and 141 of a CU's 160 KB of LDS: nothing else starts on a CU while two of its workgroups are resident,
+     * and on the high-priority PM stream the next pass's workgroups take every slot that frees up - the tree build beside it took 17 ms
+     * instead of 5.5.  At the lowest priority the tree build's kernels get the freed slots first. */
+    hipStream_t ps = low_priority && ctx->stream_pair ? ctx->stream_pair : ctx->stream_pm;
     SHQ_HIP(hipEventRecord(ctx->ev_pm_ready, ctx->stream));
-    SHQ_HIP(hipStreamWaitEvent(ctx->stream_pm, ctx->ev_pm_ready, 0));
+    SHQ_HIP(hipStreamWaitEvent(ps, ctx->ev_pm_ready, 0));
     hipStream_t main_stream = ctx->stream;
-    ctx->stream = ctx->stream_pm;
+    ctx->stream = ps;
     const int rc = shq_pm_execute(ctx, pm);
     ctx->stream = main_stream;
     if(rc != SHQ_OK) {
-        (void) hipStreamSynchronize(ctx->stream_pm);
+        (void) hipStreamSynchronize(ps);
         return rc;
     }
-    SHQ_HIP(hipEventRecord(ctx->ev_pm_done, ctx->stream_pm));
+    SHQ_HIP(hipEventRecord(ctx->ev_pm_done, ps));
     ctx->pm_pending = true;
+    return SHQ_OK;
+}
+
+/* gravpm_force started EARLY: the PM needs the drifted positions and nothing of the tree, so a resident step queues it on the library's
+ * second stream and builds the tree meanwhile (force_tree_full and gravpm_force have no order between them in the reference either:
+ * run.cpp:476-538 builds the tree first only because the domain decomposition comes with it).  G > 0: the readout forms OldAcc from
+ * FullTreeGravAccel of the last step and the new GravPM, as shq_treepm_step does.  shq_treepm_step (same Nmesh) then joins this PM instead
+ * of running its own; every other consumer of PM results joins it as well.  A drift or a particle upload discards it. */
+extern "C" int shq_pm_start(shq_context *ctx, const shq_pm_params *pm, double G)
+{
+    SHQ_CHECK(ctx && pm, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "pm_start: particles must be uploaded first");
+    SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_join_pm(ctx));
+    SHQ_TRY(shq_walk_check_status(ctx, false));
+    ctx->readout_oldacc_G = (G > 0 && ctx->numpart > 0 && ctx->treeacc.ptr && ctx->oldacc.ptr) ? G : 0.0;
+    const bool oldacc_done = ctx->readout_oldacc_G > 0;
+    const int rc = shq_pm_run_on_pm_stream(ctx, pm, true);
+    ctx->readout_oldacc_G = 0;
+    SHQ_TRY(rc);
+    ctx->pm_prestarted = true;
+    ctx->pm_prestarted_oldacc = oldacc_done;
+    ctx->pm_prestarted_nmesh = pm->Nmesh;
     return SHQ_OK;
 }
 
@@ -1215,7 +1274,9 @@ extern "C" int shq_treepm_step(shq_context *ctx, const shq_pm_params *pm, const 
     SHQ_CHECK((walk_mode & ~SHQ_WALK_TREE_ORDER) == SHQ_WALK_EXACT, SHQ_ERR_INVALID, "treepm_step: walk_mode is SHQ_WALK_EXACT, optionally | SHQ_WALK_TREE_ORDER");
     SHQ_HIP(hipSetDevice(ctx->device));
     SHQ_TRY(shq_walk_check_status(ctx, false)); /* an earlier step of a resident loop whose pair kernel failed: no new step on its forces */
+    const bool prestarted = ctx->pm_prestarted && ctx->pm_pending && ctx->pm_prestarted_nmesh == pm->Nmesh;
     SHQ_TRY(shq_join_pm(ctx));
+    ctx->pm_prestarted = false;
     int64_t n = ctx->nlocal;
     const int32_t *d_targets = nullptr;
     if(walk_mode & SHQ_WALK_TREE_ORDER) { /* every own particle of the tree, in leaf order */
@@ -1223,15 +1284,18 @@ extern "C" int shq_treepm_step(shq_context *ctx, const shq_pm_params *pm, const 
         d_targets = ctx->tree_targets.ptr;
         n = ctx->ntree_targets;
     }
-    const bool fuse = !ctx->pm_overlap && ctx->treepm_fuse && pm->Nmesh >= 4 &&
+    const bool fuse = !prestarted && !ctx->pm_overlap && ctx->treepm_fuse && pm->Nmesh >= 4 &&
                       (size_t) pm->Nmesh * pm->Nmesh * (size_t) (pm->Nmesh + 10) < (1ull << 29) &&
                       shq_walk_can_fuse_readout_pre(ctx, params, n);
     /* not fused: the readout kernel forms OldAcc as it stores GravPM (the operations of shq_grav_refresh_oldacc, one pass less) */
-    ctx->readout_oldacc_G = (!fuse && ctx->numpart > 0 && ctx->treeacc.ptr && ctx->oldacc.ptr) ? params->G : 0.0;
-    const bool oldacc_done = ctx->readout_oldacc_G > 0;
-    const int rc_pm = shq_pm_execute(ctx, pm, !fuse);
-    ctx->readout_oldacc_G = 0;
-    SHQ_TRY(rc_pm);
+    bool oldacc_done = ctx->pm_prestarted_oldacc;
+    if(!prestarted) { /* (a PM started by shq_pm_start for these positions has just been joined: nothing to run) */
+        ctx->readout_oldacc_G = (!fuse && ctx->numpart > 0 && ctx->treeacc.ptr && ctx->oldacc.ptr) ? params->G : 0.0;
+        oldacc_done = ctx->readout_oldacc_G > 0;
+        const int rc_pm = shq_pm_execute(ctx, pm, !fuse);
+        ctx->readout_oldacc_G = 0;
+        SHQ_TRY(rc_pm);
+    }
     if(!fuse) {
         if(!oldacc_done)
             SHQ_TRY(shq_grav_refresh_oldacc(ctx, params->G));

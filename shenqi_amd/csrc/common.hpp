@@ -216,6 +216,9 @@ struct shq_context {
     hipStream_t stream_pair = nullptr;
     hipEvent_t ev_pair_fork = nullptr, ev_pair_join = nullptr;
     bool pm_pending = false;
+    bool pm_prestarted = false;          /* shq_pm_start: the PM of the current positions is queued on stream_pm; shq_treepm_step takes it over */
+    bool pm_prestarted_oldacc = false;   /* ... and its readout kernel formed OldAcc */
+    int pm_prestarted_nmesh = 0;
     bool pm_overlap = false;
     bool treepm_fuse = false;  /* SHQ_TREEPM_FUSE / shq_treepm_set_fuse: shq_treepm_step carries the readout in the walk's task prologue.  Off since
                                   round 4: with the pair kernel beside the main walk the prologue's 104 eight-byte loads per lane cost the walk
@@ -307,6 +310,9 @@ struct shq_context {
     DevBuf<int32_t> tree_targets; /* own particles in leaf order (SHQ_WALK_TREE_ORDER) */
     int64_t ntree_targets = 0;
     bool have_tree_targets = false;
+    int tree_targets_refresh = 8;  /* SHQ_TREE_TARGETS_REFRESH: rebuilds over the same particle set that keep the list (1: a new list per build) */
+    int tree_targets_age = 0, tree_targets_mask = -2;
+    long long tree_targets_np = -1, tree_targets_ntree = -1;
     DevBuf<long long> hilb_iota;  /* shq_hilbert_order: 0 .. n-1, the values of its sort */
     /* black-hole accretion / feedback walks: per-call uploads (sph_capi.hip) */
     DevBuf<int32_t> bhw_bhp, bhw_queue;
@@ -461,6 +467,7 @@ void shq_fill_node_walk_params(shq_context *ctx, const shq_grav_params *p);
 int shq_walk_reserve_sparse(shq_context *ctx, long long nwaves);
 int shq_walk_check_status(shq_context *ctx, bool sync);
 int shq_walk_prereserve(shq_context *ctx);
+const int *shq_walk_error_word(shq_context *ctx); /* device address of the pair kernel's sticky error word, or null before any sparse launch */
 /* grav_group.hip */
 int shq_launch_grav_walk_group(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets, int update_potential,
                                int64_t first);
@@ -468,6 +475,7 @@ int shq_launch_grav_walk_ghosts(shq_context *ctx, const shq_grav_params *p, cons
                                 const int32_t *d_qstart, int64_t nq, double *d_acc, double *d_pot, int32_t *d_nint, int update_potential);
 /* pm.hip */
 int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm, bool readout = true);
+int shq_pm_run_on_pm_stream(shq_context *ctx, const shq_pm_params *pm, bool low_priority);
 bool shq_walk_can_fuse_readout(shq_context *ctx, const shq_grav_params *p, const int32_t *d_active, int64_t ntargets, int64_t first);
 bool shq_walk_can_fuse_readout_pre(shq_context *ctx, const shq_grav_params *p, int64_t ntargets);
 void shq_pm_destroy_plans(shq_context *ctx);

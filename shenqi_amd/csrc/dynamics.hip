@@ -95,11 +95,15 @@ __global__ void drift_kernel(long long n, double4 *posm, double *vel, double *hs
 struct KickTab { double k[SHQ_TIMEBINS + 1]; };
 
 __global__ void kick_short_kernel(long long nt, const int32_t *__restrict__ targets, double *vel, const double *__restrict__ accel,
-                                  const uint8_t *__restrict__ pflags, const uint8_t *__restrict__ bin_grav, KickTab tab)
+                                  const uint8_t *__restrict__ pflags, const uint8_t *__restrict__ bin_grav, KickTab tab, const int *walk_error)
 {
 #pragma clang fp contract(off)
     const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if(t >= nt)
+        return;
+    /* the sticky error word of the tree walk's pair kernel (grav_walk.hip): a walk that dropped pairs left incomplete accelerations, and
+     * nothing is kicked with them - the host learns of it at its next synchronisation, the velocities stay as they were */
+    if(walk_error && *walk_error != 0)
         return;
     const long long i = targets ? (long long) targets[t] : t;
     if(pflags[i] & 3u)
@@ -495,8 +499,9 @@ extern "C" int shq_drift(shq_context *ctx, double ddrift, double BoxSize, const 
     ctx->have_tree = false;
     ctx->have_toptree = false;
     ctx->tb_built = false;
-    ctx->have_tree_targets = false;
+    /* (the tree-order target list survives a drift: it is an order of the same particles, refreshed by the tree builds every few steps) */
     ctx->have_pm_result = false;
+    ctx->pm_prestarted = false;
     SHQ_CHECK(h_err != 1, SHQ_ERR_INVALID, "drift: a gas particle reached Hsml <= 0 (drift.cpp:61-63)");
     SHQ_CHECK(h_err != 2, SHQ_ERR_INVALID, "drift: a particle position is not finite (drift.cpp:72-75)");
     SHQ_CHECK(h_err != 3, SHQ_ERR_INVALID, "drift: a black hole would jump further than 0.1 BoxSize to its potential minimum (drift.cpp:40-48)");
@@ -512,19 +517,20 @@ extern "C" int shq_kick_short(shq_context *ctx, const double gravkick[SHQ_TIMEBI
     SHQ_HIP(hipSetDevice(ctx->device));
     const double *acc = from_accel_store ? ctx->acc.ptr : ctx->treeacc.ptr;
     SHQ_CHECK(acc, SHQ_ERR_STATE, "kick_short: no accelerations on the device yet");
-    /* no kick on the accelerations of a walk whose pair kernel dropped pairs: waits for a walk still in flight (this call ends with a
-     * synchronisation anyway), free otherwise */
-    SHQ_TRY(shq_walk_check_status(ctx, true));
+    /* no kick on the accelerations of a walk whose pair kernel dropped pairs: the kernel below reads the sticky error word on the
+     * device and leaves the velocities alone when it is up (a walk still in flight on the stream is covered too); here, what is known
+     * on the host so far.  The call does not wait for the stream (round 4: a resident step has no host round trip between walk and kick). */
+    SHQ_TRY(shq_walk_check_status(ctx, false));
     KickTab tab;
     memcpy(tab.k, gravkick, sizeof(tab.k));
     const int32_t *d_act = nullptr;
     int64_t nt = 0;
     SHQ_TRY(shq_resolve_active(ctx, active, nactive, ctx->numpart, &d_act, &nt));
     if(nt > 0) {
-        kick_short_kernel<<<dim3(nblk(nt)), dim3(256), 0, ctx->stream>>>((long long) nt, d_act, ctx->vel.ptr, acc, ctx->pflags.ptr, ctx->bin_grav.ptr, tab);
+        kick_short_kernel<<<dim3(nblk(nt)), dim3(256), 0, ctx->stream>>>((long long) nt, d_act, ctx->vel.ptr, acc, ctx->pflags.ptr, ctx->bin_grav.ptr, tab,
+                                                                        shq_walk_error_word(ctx));
         SHQ_HIP(hipGetLastError());
     }
-    SHQ_HIP(hipStreamSynchronize(ctx->stream));
     return SHQ_OK;
 }
 

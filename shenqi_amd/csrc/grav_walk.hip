@@ -1309,6 +1309,8 @@ int shq_walk_reserve_sparse(shq_context *ctx, long long nwaves)
     return SHQ_OK;
 }
 
+const int *shq_walk_error_word(shq_context *ctx) { return ctx->sp_flags.ptr ? ctx->sp_flags.ptr + SP_STICKY_ERROR : nullptr; }
+
 /* at tree installation: the buffers of a walk over all of the context's particles, if such a walk would take the sparse path */
 int shq_walk_prereserve(shq_context *ctx)
 {

@@ -303,7 +303,7 @@ extern "C" int shq_density_close(shq_context *ctx, shq_node *nodes_rw, const shq
     }
     if(nodes_rw && params->update_hsml) { /* update_tree_hmax_father wrote leaf hmax on the device */
         for(int64_t j = 0; j < ctx->numnodes; j++) {
-            shq_node &nd = nodes_rw[ctx->node_order[j]];
+            shq_node &nd = nodes_rw[ctx->node_order.empty() ? j : (int64_t) ctx->node_order[j]];
             if(hmax[j] > nd.hmax)
                 nd.hmax = hmax[j];
         }

@@ -681,6 +681,8 @@ int shq_build_tree_targets(shq_context *ctx)
         }
     }
     ctx->have_tree_targets = true;
+    ctx->tree_targets_ntree = ctx->ntreeparts;
+    ctx->tree_targets_age = 0;
     return SHQ_OK;
 }
 
@@ -702,6 +704,13 @@ static int tree_build_impl(shq_context *ctx, double BoxSize, int mask, const int
     const long long ncand = ncand_;
     SHQ_CHECK(ncand < (1ll << 31) - 64, SHQ_ERR_INVALID, "tree_build: too many particles");
     ctx->have_tree = false;
+    /* The tree-order target list (SHQ_WALK_TREE_ORDER: the tree's own particles along the Peano-Hilbert curve of their positions when it
+     * was made) is an ORDER of targets, never a result: any order gives every particle the same bits.  The reference refreshes its
+     * particle order at domain decompositions, not every step (domain.cpp:268); a rebuild over the same particle set keeps the list for
+     * up to tree_targets_refresh builds (default 8; 1.8 ms per step at 256^3 otherwise), and drops it when the build is another set
+     * (active list, mask) or the number of tree particles changes (checked after the build, below). */
+    const bool keep_targets = ctx->have_tree_targets && !active && mask == ctx->tree_targets_mask && np == ctx->tree_targets_np &&
+                              ctx->tree_targets_age + 1 < ctx->tree_targets_refresh;
     ctx->have_tree_targets = false;
     SHQ_HIP(hipEventRecord(ctx->ev_begin[16], st));
 
@@ -853,9 +862,8 @@ static int tree_build_impl(shq_context *ctx, double BoxSize, int mask, const int
     SHQ_HIP(hipEventRecord(ctx->ev_end[16], st));
     SHQ_HIP(hipStreamSynchronize(st));
 
-    ctx->node_order.resize((size_t) nn);
-    for(int j = 0; j < nn; j++)
-        ctx->node_order[j] = j; /* a downloaded tree is numbered in pool order */
+    ctx->node_order.clear();    /* empty = identity: a downloaded tree is numbered in pool order (filling 7 M entries on the host cost a
+                                   resident step 2.9 ms between the build and the walk) */
     ctx->node_rank.clear();     /* identity */
     ctx->numnodes = nn;
     ctx->firstnode = np;
@@ -868,6 +876,13 @@ static int tree_build_impl(shq_context *ctx, double BoxSize, int mask, const int
     ctx->have_father = true;
     ctx->tb_built = true;
     ctx->tb_domain = dom;
+    if(keep_targets && ctx->ntreeparts == ctx->tree_targets_ntree) {
+        ctx->have_tree_targets = true;
+        ctx->tree_targets_age++;
+    } else
+        ctx->tree_targets_age = 0;
+    ctx->tree_targets_mask = active ? -1 : mask;
+    ctx->tree_targets_np = np;
     SHQ_TRY(shq_walk_prereserve(ctx));
     ctx->have_toptree = false;
     if(stats) {

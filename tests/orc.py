@@ -252,6 +252,37 @@ def pm_force(pos, mass, Nmesh, BoxSize, Asmth, G, skip=None, fixed_point_log2sca
     return g, pot, rho, phi
 
 
+_FFT_FN = C.CFUNCTYPE(None, C.c_int, C.c_void_p, C.c_void_p)
+_fft_keep = []
+
+
+def use_scipy_fft(workers):
+    """orc_pm_force's transforms through scipy.fft (pocketfft, `workers` threads) instead of the oracle's own mixed-radix FFT; workers = 0
+    restores the oracle's.  Same conventions (unscaled, half spectrum [x][y][z']).  For the CPU baseline of bench.py: the deposit,
+    transfer functions and readout stay the oracle's, the five transforms get a production FFT."""
+    lib.orc_set_fft.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_set_fft.restype = None
+    if not workers:
+        lib.orc_set_fft(None, None)
+        del _fft_keep[:]
+        return
+    import scipy.fft
+
+    def r2c(N, real, cplx):
+        a = np.ctypeslib.as_array(C.cast(real, C.POINTER(C.c_double)), shape=(N, N, N))
+        out = np.ctypeslib.as_array(C.cast(cplx, C.POINTER(C.c_double)), shape=(N, N, N // 2 + 1, 2)).view(np.complex128)[..., 0]
+        out[...] = scipy.fft.rfftn(a, workers=workers)
+
+    def c2r(N, cplx, real):
+        a = np.ctypeslib.as_array(C.cast(cplx, C.POINTER(C.c_double)), shape=(N, N, N // 2 + 1, 2)).view(np.complex128)[..., 0]
+        out = np.ctypeslib.as_array(C.cast(real, C.POINTER(C.c_double)), shape=(N, N, N))
+        out[...] = scipy.fft.irfftn(a, s=(N, N, N), workers=workers, norm="forward")   # "forward": no 1/N^3 on the inverse = unscaled
+
+    fr, fc = _FFT_FN(r2c), _FFT_FN(c2r)
+    _fft_keep[:] = [fr, fc]
+    lib.orc_set_fft(C.cast(fr, C.c_void_p), C.cast(fc, C.c_void_p))
+
+
 def fft_r2c(real):
     N = real.shape[0]
     real = np.ascontiguousarray(real, dtype=np.float64)

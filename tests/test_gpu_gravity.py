@@ -727,6 +727,15 @@ def test_treepm_step_equals_the_three_separate_calls(ctx):
     for a, b, name in zip(results(), ref_t, ("GravPM", "PM potential", "acc", "pot", "ninteractions")):
         assert np.array_equal(a, b), ("tree order", name, float(np.abs(a - b).max()))
     assert np.array_equal(ref_t[0], ref[0]) and np.array_equal(ref_t[4], ref[4])
+    # the PM started early on the second stream (shq_pm_start), the tree installed meanwhile, shq_treepm_step joining it: the same bits;
+    # with and without OldAcc formed by the early PM's readout
+    for G_early in (gp.G, 0.0):
+        capi.check(capi.hip.shq_particles_upload(ctx.h, C.byref(pv)))
+        capi.check(capi.hip.shq_pm_start(ctx.h, C.byref(pmp), G_early))
+        capi.check(capi.hip.shq_tree_upload(ctx.h, C.byref(tv)))
+        capi.check(capi.hip.shq_treepm_step(ctx.h, C.byref(pmp), C.byref(gp), 1, sq.WALK_EXACT))
+        for a, b, name in zip(results(), ref, ("GravPM", "PM potential", "acc", "pot", "ninteractions")):
+            assert np.array_equal(a, b), ("early PM", G_early, name, float(np.abs(a - b).max()))
     # the walk's opening criterion saw the NEW GravPM
     g, _, acc, pot, nint = ref
     oldacc = np.linalg.norm(P["FullTreeGravAccel"] + g, axis=1) / cm.G
