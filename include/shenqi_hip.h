@@ -810,6 +810,9 @@ typedef struct shq_sph_stats {
     int32_t niterations;     /* Hsml iterations (do_hsml_loop, treewalk2.h:480-557) */
     int32_t pad_;
     double kernel_ms;        /* HIP-event time of the walk kernels */
+    double hsml_max_tried;   /* density calls: the largest Hsml any walk of the loop searched with (0 for other operators).  A sharded
+                                caller sizes its ghost halo by this, not by the Hsml the loop ends with: an intermediate guess beyond the
+                                halo undercounts NumNgb and steers the iteration (treewalk2.h:480-557 runs every guess against all ranks) */
 } shq_sph_stats;
 
 /* One-shot replacement of density_cuda() *including* the host Hsml loop the reference keeps on

@@ -385,7 +385,7 @@ class StellarParams(C.Structure):
 
 class SphStats(C.Structure):
     _fields_ = [("ntargets", C.c_int64), ("ninteractions", C.c_int64), ("niterations", C.c_int32), ("pad_", C.c_int32),
-                ("kernel_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("hsml_max_tried", C.c_double)]
 
 
 class PMParams(C.Structure):

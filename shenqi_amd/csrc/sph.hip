@@ -918,6 +918,7 @@ __global__ __launch_bounds__(HB_THREADS) void sph_density_block_kernel(const Sph
 struct PostArgs {
     double Box, DesNumNgb, DesNumNgbBH, MinGasHsml, MaxDev;
     int update_hsml, BlackHoleOn, DoEgyDensity;
+    unsigned long long *hmax_tried; /* the largest Hsml any walk of this loop has run with, as the bits of a non-negative double */
 };
 
 __global__ void sph_density_post_kernel(const SphDev a, const int32_t *queue, long long nq, const PostArgs p, int32_t *todo)
@@ -930,6 +931,10 @@ __global__ void sph_density_post_kernel(const SphDev a, const int32_t *queue, lo
     int done = 0;
     const double density = a.rho[i];
     double hs = a.hsml[i];
+    /* the radius the walk behind this call searched: a sharded caller's halo must cover the largest one TRIED, not just the one the
+     * loop ends with (an intermediate guess that reaches past the imported ghosts undercounts NumNgb and steers the next guess) */
+    if(p.hmax_tried && (unsigned long long) __double_as_longlong(hs) > *(volatile unsigned long long *) p.hmax_tried)
+        atomicMax(p.hmax_tried, (unsigned long long) __double_as_longlong(hs));
     double DhsmlDens = a.dhsmldens[i];
     DhsmlDens *= hs / (3 * density);
     DhsmlDens = 1 / (1 + DhsmlDens);
@@ -1588,6 +1593,7 @@ int shq_sph_density_post(shq_context *ctx, int64_t *nredo)
         pa.update_hsml = p->update_hsml;
         pa.BlackHoleOn = p->BlackHoleOn;
         pa.DoEgyDensity = p->DoEgyDensity;
+        pa.hmax_tried = reinterpret_cast<unsigned long long *>(ctx->s_counters.ptr + 3);
         sph_density_post_kernel<<<dim3(nblk(r.size)), dim3(256), 0, ctx->stream>>>(a, r.cur, r.size, pa, ctx->s_todo.ptr);
         SHQ_HIP(hipGetLastError());
     }
@@ -1626,15 +1632,18 @@ int shq_sph_density_end(shq_context *ctx, shq_sph_stats *stats)
     r.phase = 0;
     SHQ_HIP(hipEventRecord(ctx->ev_end[14], ctx->stream));
     if(stats) {
-        unsigned long long h_nint = 0;
-        SHQ_HIP(hipMemcpyAsync(&h_nint, ctx->s_counters.ptr + 1, sizeof(h_nint), hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long h_c[3] = {0, 0, 0}; /* [0] interactions, [2] bits of the largest Hsml tried */
+        SHQ_HIP(hipMemcpyAsync(h_c, ctx->s_counters.ptr + 1, sizeof(h_c), hipMemcpyDeviceToHost, ctx->stream));
         SHQ_HIP(hipStreamSynchronize(ctx->stream));
         float ms = 0;
         (void) hipEventElapsedTime(&ms, ctx->ev_begin[14], ctx->ev_end[14]);
         stats->ntargets = r.nq0;
-        stats->ninteractions = (int64_t) h_nint;
+        stats->ninteractions = (int64_t) h_c[0];
         stats->niterations = r.niter;
         stats->kernel_ms = ms;
+        double hm;
+        memcpy(&hm, &h_c[2], sizeof(hm));
+        stats->hsml_max_tried = hm;
     }
     return SHQ_OK;
 }
@@ -1828,6 +1837,7 @@ int shq_sph_hydro_end(shq_context *ctx, shq_sph_stats *stats)
         stats->ninteractions = (int64_t) h_nint;
         stats->niterations = 1;
         stats->kernel_ms = ms;
+        stats->hsml_max_tried = 0;
         if(getenv("SHQ_SPH_DEBUG") && r.nq0 > 0) {
             unsigned long long d[5];
             SHQ_HIP(hipMemcpy(d, nint, sizeof(d), hipMemcpyDeviceToHost));
@@ -2255,6 +2265,7 @@ int shq_sph_stellar_density_device(shq_context *ctx, const shq_stellar_params *p
         stats->ninteractions = (int64_t) h_nint;
         stats->niterations = niter;
         stats->kernel_ms = ms;
+        stats->hsml_max_tried = 0;
     }
     return SHQ_OK;
 }
@@ -2625,6 +2636,7 @@ int shq_wind_veldisp_device(shq_context *ctx, const shq_kick_factors *kf, double
         stats->ninteractions = (int64_t) h_nint;
         stats->niterations = niter;
         stats->kernel_ms = ms;
+        stats->hsml_max_tried = 0;
     }
     return SHQ_OK;
 }

@@ -806,7 +806,10 @@ class DistSPHDevice:
             allrows = self._load(rows, torch.zeros(nloc, dtype=torch.float64, device=rows.device), halos)
             capi.check(capi.hip.shq_density_resident(self.ctx.h, C.byref(dp), C.byref(st)), "shq_density_resident")
             self._results(allrows, nloc, 1)
-            hmax = float(allrows[:nloc, 7].max().item()) if nloc else 0.0
+            # the halo must cover the largest Hsml the loop TRIED, not the one it ended with: a guess that reached past the imported
+            # ghosts undercounted NumNgb and steered the guesses after it (the reference runs every guess against all ranks,
+            # treewalk2.h:480-557)
+            hmax = max(float(st.hsml_max_tried), float(allrows[:nloc, 7].max().item())) if nloc else 0.0
             worst = max(h / max(hl, 1e-300) for h, hl in zip(self._allmax(hmax), halos)) if self.comm.multi else 0.0
             if worst <= 1.0 or not self.comm.multi:
                 break

@@ -52,6 +52,41 @@ def test_c3_gravity_2x128_properties(ctx):
     _treepm_properties(ctx, pman, n1, 3 * n1, L, stride=64)
 
 
+def test_c4_512_properties(ctx):
+    """BASELINE.json configs[3] (dm-50-512: 512^3 dark matter, Nmesh 1024 per benchmarks/dm-50-512/paramfile.gadget:8), the whole
+    particle set on ONE card - what the 8-GPU run shards: 1.34e8 particles, ~5.9e7 tree nodes, an 8.7 GB mesh (beyond 2^32 bytes:
+    64-bit mesh offsets everywhere, the 512-thread FFT workgroups of the transposing pipeline), 64-bit interaction totals.  Same
+    properties as the 256^3 case, the oracle on every 2048th 64-target group over the device-built tree."""
+    n1, L = 512, 1.0
+    n = n1**3
+    pos = sq.synth_positions("cluster", n, L=L)
+    pos = pos[sq.hilbert_order(pos, L)]
+    pman = sq.PartManager(n, L)
+    P = pman.Base
+    P["Pos"] = pos
+    del pos
+    P["Type"] = 1
+    P["Mass"] = 1.0
+    _treepm_properties(ctx, pman, n1, 1024, L, stride=2048)
+
+
+def test_c5_gravity_2x256_properties(ctx):
+    """BASELINE.json configs[4] (examples/hydro: 2 x 256^3 gas + dark matter, Nmesh 768), gravity half on one card: PM + short-range
+    walk over all 3.4e7 particles of both species (masses Omega_b : Omega_m - Omega_b), the properties and the sampled oracle of the
+    other sizes."""
+    n1, L = 256, 1.0
+    n = n1**3
+    pos = np.concatenate([sq.synth_positions("uniform", n, L=L), sq.synth_positions("uniform", n, seed=77, L=L)])
+    order = sq.hilbert_order(pos, L)
+    pman = sq.PartManager(2 * n, L)
+    P = pman.Base
+    P["Pos"] = pos[order]
+    P["Type"] = np.where(order < n, 0, 1).astype(np.uint8)
+    P["Mass"] = np.where(order < n, 0.16, 0.84)
+    del pos
+    _treepm_properties(ctx, pman, n1, 3 * n1, L, stride=512)
+
+
 def _treepm_properties(ctx, pman, n1, nmesh, L, stride):
     P = pman.Base
     n = pman.NumPart
@@ -123,8 +158,18 @@ def test_c3_sph_128_properties(ctx):
         beyond the reference's own re-run bound (tests/test_density.cpp:203);
       - hydro: pair antisymmetry makes the total momentum change vanish: |sum m a| << sum |m a|;
       - oracle (fixed Hsml, sampled targets): densities and hydro accelerations to rounding."""
+    _sph_properties(ctx, 128, 512)
+
+
+def test_c5_sph_256_properties(ctx):
+    """BASELINE.json configs[4] at its gas size on one card (256^3 = 1.7e7 gas particles): the properties of the 128^3 case and
+    the oracle on every 4096th target."""
+    _sph_properties(ctx, 256, 4096)
+
+
+def _sph_properties(ctx, n1, sample):
     import common as cm
-    n1, L = 128, cm.BOX
+    L = cm.BOX
     n = n1**3
     pos = sq.synth_positions("uniform", n, L=L)
     pos = pos[sq.hilbert_order(pos, L)]
@@ -149,8 +194,8 @@ def test_c3_sph_128_properties(ctx):
     a = SphP["HydroAccel"]
     assert np.all(np.isfinite(a)) and np.abs(a).max() > 0
     assert np.abs(a.sum(axis=0)).max() < 1e-9 * np.abs(a).sum()   # unit masses: sum m a
-    # oracle on every 512th target, same tree, Hsml fixed at the converged values
-    act = np.arange(0, n, 512, dtype=np.int32)
+    # oracle on every `sample`-th target, same tree, Hsml fixed at the converged values
+    act = np.arange(0, n, sample, dtype=np.int32)
     dp = cm.density_params(BoxSize=L, kernel=kernel, update_hsml=0, DoEgyDensity=1, MinGasHsml=1e-6)
     S2 = SphP.copy()
     st = orc.SphState(P, S2, BhP)

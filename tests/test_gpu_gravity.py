@@ -263,13 +263,14 @@ def test_pm_parity_16(ctx, kind):
     assert np.array_equal(g3, g[perm]) and np.array_equal(p3, ppot[perm])
 
 
-@pytest.mark.parametrize("nmesh", [16, 24, 40, 48, 96, 192, 384])
+@pytest.mark.parametrize("nmesh", [16, 24, 40, 48, 96, 192, 384, 512, 1024])
 def test_pm_transposing_fft_pipeline_gives_the_in_place_pipelines_bits(ctx, nmesh):
     """The five FFT passes of the undivided PM as the transposing pipeline (mesh <-> scratch mesh, contiguous tiles on one side of
     every pass: fft3d.hip) against the in-place pipeline on the same deposit: potential mesh, GravPM and the PM potential bit for bit
     ("bit-pattern-reproducible per FFT plan": the two are the same plan, addressed differently); radix 16 / 4 / 2 / 3 / 5 stage
     mixes, meshes whose z pitch holds pad columns (16: Nc = 9 in 12) and ones without (24: Nc = 13 in 16)."""
-    n = 20**3 + 11
+    big = nmesh > 400                  # 512: the largest mesh on 256-thread workgroups; 1024 (C4's): 512-thread workgroups, > 2^32 bytes
+    n = 64**3 + 11 if big else 20**3 + 11
     pos = cm.random_positions(orc.boost_mt19937_uniform(3, 3 * n), n)
     pman = cm.make_partmanager(pos)
     pv = pman.view()
@@ -277,13 +278,14 @@ def test_pm_transposing_fft_pipeline_gives_the_in_place_pipelines_bits(ctx, nmes
     pmp = sq.PMParams(nmesh, 0, cm.BOX, 1.5, cm.G)
     got = {}
     try:
-        capi.check(capi.hip.shq_pm_set_debug(ctx.h, 1))
+        capi.check(capi.hip.shq_pm_set_debug(ctx.h, 0 if big else 1))
         for mode in (0, 1, 1):                       # the second transposing run starts from the scratch mesh the first one left
             capi.check(capi.hip.shq_pm_set_fft_transposed(ctx.h, mode))
             capi.check(capi.hip.shq_pm_run(ctx.h, C.byref(pmp)))
-            g = np.zeros((n, 3)); pp = np.zeros(n); phi = np.zeros((nmesh,) * 3)
+            g = np.zeros((n, 3)); pp = np.zeros(n); phi = np.zeros((1 if big else nmesh,) * 3)
             capi.check(capi.hip.shq_pm_download(ctx.h, capi.ptr(g), capi.ptr(pp)))
-            capi.check(capi.hip.shq_pm_download_mesh(ctx.h, 1, capi.ptr(phi)))
+            if not big:                # (the dense mesh copy of a big mesh is gigabytes: there the 2.6e5 particles' readouts sample it)
+                capi.check(capi.hip.shq_pm_download_mesh(ctx.h, 1, capi.ptr(phi)))
             if mode in got:
                 for a, b in zip(got[mode], (g, pp, phi)):
                     assert np.array_equal(a, b)
@@ -293,8 +295,11 @@ def test_pm_transposing_fft_pipeline_gives_the_in_place_pipelines_bits(ctx, nmes
         capi.check(capi.hip.shq_pm_set_fft_transposed(ctx.h, 1))
     for a, b, name in zip(got[0], got[1], ("GravPM", "PM potential", "potential mesh")):
         assert np.array_equal(a, b), (name, float(np.abs(a - b).max()))
-    og, opot, _, _ = orc.pm_force(pos, pman.Base["Mass"], nmesh, cm.BOX, 1.5, cm.G)
-    assert np.abs(got[1][0] - og).max() < 1e-9 * np.abs(og).max()
+    if not big:
+        og, opot, _, _ = orc.pm_force(pos, pman.Base["Mass"], nmesh, cm.BOX, 1.5, cm.G)
+        assert np.abs(got[1][0] - og).max() < 1e-9 * np.abs(og).max()
+    else:
+        assert np.all(np.isfinite(got[1][0])) and np.abs(got[1][0]).max() > 0
 
 
 @pytest.mark.parametrize("N", [24, 40, 64, 80, 18])
