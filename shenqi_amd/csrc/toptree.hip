@@ -348,8 +348,16 @@ extern "C" int shq_grav_toptree_exports_resident(shq_context *ctx, const shq_gra
     std::vector<unsigned long long> h((size_t) ntask);
     SHQ_HIP(hipMemcpyAsync(h.data(), ctx->top_task.ptr, sizeof(unsigned long long) * ntask, hipMemcpyDeviceToHost, ctx->stream));
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
-    for(int t = 0; t < ntask; t++)
+    unsigned long long sum = 0;
+    for(int t = 0; t < ntask; t++) {
         task_counts[t] = (int64_t) h[t];
+        sum += h[t];
+    }
+    /* an entry whose Task lies outside [0, ntask) is counted for nobody, yet shq_grav_export_pack packs every entry: the all-to-all's split
+     * points would no longer match the packed buffer.  The TopLeaves table and ntask disagree: the caller's error, said out loud. */
+    SHQ_CHECK(sum == (unsigned long long) ctx->top_nexport, SHQ_ERR_INVALID,
+              "toptree exports: %llu of %lld entries carry a Task outside [0, %d): TopLeaves[].Task and ntask disagree",
+              (unsigned long long) ctx->top_nexport - sum, (long long) ctx->top_nexport, ntask);
     return SHQ_OK;
 }
 

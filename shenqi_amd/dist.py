@@ -678,11 +678,11 @@ class DistSPH:
 
     def density(self, P, SphP, **kw):
         """density() for the local gas (Hsml loop included).  Returns the number of import rounds it took.
-        The repeat decision looks at the FINAL Hsml of the targets: an intermediate guess of the Hsml loop may reach past the halo
-        (its NumNgb is then undercounted, which changes the next guess) and come back inside.  Such a target converges to an Hsml
-        within the same NumNgb tolerance (MaxNumNgbDeviation) as the undivided run, not necessarily the same one; with the default
-        hfac = 1.3 the first guess (at most 1.26 x the start value, densitytree2.hpp:233-246) cannot leave the halo, later ones only
-        after the bracket has closed from below.  The sharded tests assert Hsml against the undivided result to 1e-9."""
+        The repeat decision looks at the largest Hsml the loop TRIED (shq_sph_stats.hsml_max_tried; round 4): an intermediate guess
+        that reaches past the halo undercounts NumNgb, which changes the next guess, so a loop whose guesses left the halo is run
+        again on a wider one even if it came back inside.  (An operator that does not report it - the CPU stand-in of the tests -
+        falls back to the final Hsml: with hfac = 1.3 the first guess, at most 1.26 x the start value, densitytree2.hpp:233-246,
+        cannot leave the halo.)  The sharded tests assert Hsml against the undivided result to 1e-9."""
         nloc = len(P)
         rounds = 0
         halo = self.hfac * (float(P["Hsml"].max()) if nloc else 0.0)
@@ -692,8 +692,9 @@ class DistSPH:
             halos = self._allmax(halo)
             Pall, Sall = self._import(P, SphP, np.zeros(nloc), halos)
             Pall["Hsml"][:nloc] = h0
-            self.ops.density(Pall, Sall, nloc, **kw)
-            hmax = float(Pall["Hsml"][:nloc].max()) if nloc else 0.0
+            tried = self.ops.density(Pall, Sall, nloc, **kw)
+            # the largest Hsml the loop TRIED where the operator reports it (the device library does), else the one it ended with
+            hmax = max(float(Pall["Hsml"][:nloc].max()), float(tried or 0.0)) if nloc else 0.0
             # every rank must agree on repeating: a target whose sphere outgrew the halo may have missed neighbours
             worst = max(h / max(hl, 1e-300) for h, hl in zip(self._allmax(hmax), halos)) if self.comm.multi else 0.0
             if worst <= 1.0 or not self.comm.multi:
@@ -848,8 +849,9 @@ class GpuSphOps:
         pman = self._pman(Pall)
         tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
         BhP = np.zeros(2, dtype=sq.BH_SLOT_DTYPE)
-        sq.density(self.ctx, np.arange(nloc, dtype=np.int32), 1, DoEgyDensity, 0, kick, tree, pman, Sall, BhP)
+        _, st = sq.density(self.ctx, np.arange(nloc, dtype=np.int32), 1, DoEgyDensity, 0, kick, tree, pman, Sall, BhP)
         Pall[:] = pman.Base
+        return float(st.hsml_max_tried)     # the largest Hsml any walk of the loop searched with
 
     def hydro(self, Pall, Sall, nloc, atime=0.1, hubble=0.1, kick=None, **_):
         sq = self.sq

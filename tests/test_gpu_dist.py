@@ -485,3 +485,31 @@ def test_bench_c5_mode_two_gloo_ranks():
     assert 1 <= k["density_iterations"] <= 3          # steady state: Hsml converged by the set-up call
     for r in ("roofline", "roofline_sph_density", "roofline_sph_hydro"):
         assert out[r]["achieved"] > 0, r
+
+
+def test_bench_c5_mode_one_rank_rccl():
+    """`bench.py --workload c5` as a ONE-rank RCCL group (SHQ_COMM_FORCE=1: every exchange of the sharded TreePM and of the
+    device-resident sharded SPH is a real RCCL collective on the one GPU - self-copies, so no scaling figure, but the nccl code
+    paths of Comm, the device-tensor ghost rows and the stream hand-overs all run): one JSON line, the three operators'
+    rooflines, a force check of the global set against direct summation."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, SHQ_COMM_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SHQ_BENCH_BACKEND", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--ngrid", "32", "--steps", "1", "--warmup", "0",
+                        "--workload", "c5"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["particles_total"] == 2 * 32**3
+    k = out["kernels"]
+    assert 1 <= k["density_iterations"] <= 3
+    for r in ("roofline", "roofline_sph_density", "roofline_sph_hydro"):
+        assert out[r]["achieved"] > 0, r

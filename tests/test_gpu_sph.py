@@ -54,7 +54,11 @@ def test_reference_gate_density_close_gpu(ctx):
 def test_reference_gate_density_random_gpu(ctx):
     n = 32**3
     pos = cm.random_positions(orc.boost_mt19937_uniform(0, 3 * n), n)
-    _do_density_test(ctx, pos, np.full(n, cm.BOX / 32), 0.187515, 1e-3)
+    pman, SphP, tree, st = _do_density_test(ctx, pos, np.full(n, cm.BOX / 32), 0.187515, 1e-3)
+    # the loop starts from Hsml = BOX / 32, well above where most particles end: the stats report the largest radius any walk of the
+    # loop searched with (what a sharded caller's halo must cover), not the largest final one
+    assert st.hsml_max_tried >= cm.BOX / 32 and st.hsml_max_tried >= pman.Base["Hsml"].max()
+    assert pman.Base["Hsml"].mean() < 0.7 * st.hsml_max_tried
 
 
 @pytest.mark.parametrize("kernel", [1, 2, 4])
