@@ -1251,6 +1251,22 @@ int shq_pm_set_deposit_log2scale(shq_context *ctx, int e);
  * petapm_fft_r2c / c2r there.  The other petapm clients (plane.cpp:326-341, uvbg.cpp:575) get these two calls and nothing more. */
 int shq_fft_r2c(shq_context *ctx, int Nmesh, const double *real, double *complx);
 int shq_fft_c2r(shq_context *ctx, int Nmesh, const double *complx, double *real);
+/* The transfer functions of the other petapm clients: pm_apply_transfer_function (petapm.cpp:1258-1298) followed by
+ * petapm_fft_c2r, for one function per call.  Every transfer function of libgenic/zeldovich.cpp:271-321 (density, disp_x/y/z,
+ * vel_x/y/z), the lensing planes' neutrino correction (libgadget/plane.cpp:283-304) and the gravity PM's force_x/y/z (gravpm.cpp:464-488)
+ * multiplies a mode by  T(k2) x { 1 | i kpos[axis] | i diff_kernel(kpos[axis] 2 pi / Nmesh) }  with T a function of the INTEGER
+ * k2 = kx^2 + ky^2 + kz^2 (through |k| = sqrt(k2) 2 pi / BoxSize): the caller tabulates T by k2 with its own functions (DeltaSpec,
+ * dlogGrowth, its spline ...), which keeps the values the reference's.  table: host, 3 (Nmesh/2)^2 + 1 entries.
+ * zero_mode: what happens to k2 = 0 - 0 the mode is left as it is (the `if(k2)` of the zeldovich transfers), 1 it is set to zero
+ * (plane.cpp:286).  complx: [y][z'][x] as shq_fft_r2c returns it; real: [x][y][z], unscaled.  Host pointers; synchronous. */
+#define SHQ_TF_RADIAL 0
+#define SHQ_TF_GRADIENT 1
+#define SHQ_TF_DIFF 2
+typedef struct shq_pm_transfer {
+    int32_t kind, axis, zero_mode, pad_;
+    const double *table;
+} shq_pm_transfer;
+int shq_pm_apply(shq_context *ctx, int Nmesh, const double *complx, const shq_pm_transfer *tf, double *real);
 int shq_fft_r2c_xyz(shq_context *ctx, int Nmesh, const double *real, double *complx);
 int shq_fft_c2r_xyz(shq_context *ctx, int Nmesh, const double *complx, double *real);
 

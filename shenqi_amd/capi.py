@@ -579,6 +579,12 @@ hip.shq_pm_force.argtypes = [_vp, C.POINTER(PMParams), C.POINTER(PartView), _vp,
 hip.shq_pm_run.argtypes = [_vp, C.POINTER(PMParams)]
 hip.shq_pm_download.argtypes = [_vp, _vp, _vp]
 hip.shq_treepm_step.argtypes = [_vp, C.POINTER(PMParams), C.POINTER(GravParams), C.c_int, C.c_int]
+class PMTransfer(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("axis", C.c_int32), ("zero_mode", C.c_int32), ("pad_", C.c_int32), ("table", C.c_void_p)]
+
+
+hip.shq_pm_apply.argtypes = [_vp, C.c_int, _vp, C.POINTER(PMTransfer), _vp]
+hip.shq_pm_apply.restype = C.c_int
 hip.shq_timer_between_ms.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
 hip.shq_timer_between_ms.restype = C.c_int
 hip.shq_pm_start.argtypes = [_vp, _vp, C.c_double]

@@ -480,7 +480,7 @@ bool shq_walk_can_fuse_readout(shq_context *ctx, const shq_grav_params *p, const
 bool shq_walk_can_fuse_readout_pre(shq_context *ctx, const shq_grav_params *p, int64_t ntargets);
 void shq_pm_destroy_plans(shq_context *ctx);
 int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *complx, bool ref_layout);
-int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double *real, bool ref_layout);
+int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double *real, bool ref_layout, const shq_pm_transfer *tf = nullptr);
 /* tree_build.hip */
 int shq_build_tree_targets(shq_context *ctx);
 /* fft3d.hip */

@@ -703,7 +703,46 @@ int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *c
     return SHQ_OK;
 }
 
-int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double *real, bool ref_layout)
+/* pm_apply_transfer_function (petapm.cpp:1258-1298) for the transfer functions of the other petapm clients, on the dense half
+ * spectrum [x][y][z'] (kpos = mesh_to_k of each index, k2 their integer norm): the factor of a mode is a function of the integer k2 -
+ * tabulated by the caller with its own functions (DeltaSpec, dlogGrowth, the neutrino spline ...), so the values are the reference's -
+ * times 1, or i kpos[axis], or i diff_kernel(kpos[axis] 2 pi / N): libgenic/zeldovich.cpp:271-321, libgadget/plane.cpp:283-304,
+ * gravpm.cpp:464-488.  The k2 = 0 mode is left alone (`if(k2)` of the zeldovich transfers) or set to zero (plane.cpp:286). */
+__global__ void pm_transfer_kernel(double2 *spec, int N, int Nc, const double *__restrict__ table, int kind, int axis, int zero_mode)
+{
+#pragma clang fp contract(off)
+    const size_t total = (size_t) N * N * Nc;
+    const size_t ip = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if(ip >= total)
+        return;
+    const int z = (int) (ip % Nc), y = (int) ((ip / Nc) % N), x = (int) (ip / ((size_t) Nc * N));
+    const int kpos[3] = {x <= N / 2 ? x : x - N, y <= N / 2 ? y : y - N, z <= N / 2 ? z : z - N};
+    const long long k2 = (long long) kpos[0] * kpos[0] + (long long) kpos[1] * kpos[1] + (long long) kpos[2] * kpos[2];
+    double2 v = spec[ip];
+    if(k2 == 0) {
+        if(zero_mode)
+            spec[ip] = make_double2(0.0, 0.0);
+        return;
+    }
+    double fac = table[k2];
+    if(kind == SHQ_TF_RADIAL) {
+        v.x *= fac;
+        v.y *= fac;
+    } else {
+        if(kind == SHQ_TF_GRADIENT)
+            fac = fac * kpos[axis];
+        else { /* SHQ_TF_DIFF: diff_kernel, gravpm.cpp:448-456 */
+            const double w = kpos[axis] * (2 * M_PI / N);
+            fac = fac * (1 / 6.0 * (8 * sin(w) - sin(2 * w)));
+        }
+        const double tmp = v.x;
+        v.x = -v.y * fac;
+        v.y = tmp * fac;
+    }
+    spec[ip] = v;
+}
+
+int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double *real, bool ref_layout, const shq_pm_transfer *tf)
 {
     SHQ_TRY(pm_prepare(ctx, N));
     const int zp = ctx->pm_zp;
@@ -722,6 +761,16 @@ int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double 
         tr.release();
     } else
         SHQ_HIP(hipMemcpyAsync(dense.ptr, complx, ctot * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    DevBuf<double> dtab;
+    if(tf) {
+        const size_t nk2 = 3 * (size_t) (N / 2) * (N / 2) + 1;
+        SHQ_TRY(dtab.reserve(nk2));
+        SHQ_HIP(hipMemcpyAsync(dtab.ptr, tf->table, nk2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        const size_t modes = (size_t) N * N * (N / 2 + 1);
+        pm_transfer_kernel<<<dim3((unsigned) ((modes + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+            reinterpret_cast<double2 *>(dense.ptr), N, N / 2 + 1, dtab.ptr, tf->kind, tf->axis, tf->zero_mode);
+        SHQ_HIP(hipGetLastError());
+    }
     pm_repitch_kernel<<<dim3((unsigned) ((ctot + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
         dense.ptr, ctx->mesh.ptr, (size_t) N * N, N + 2, N + 2, zp, 0, 1.0);
     if(ctx->pm_custom_fft)
@@ -736,7 +785,25 @@ int shq_fft_roundtrip_c2r(shq_context *ctx, int N, const double *complx, double 
     SHQ_HIP(hipMemcpyAsync(real, dense.ptr, tot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     dense.release();
+    dtab.release();
     return SHQ_OK;
+}
+
+/* pm_apply_transfer_function + petapm_fft_c2r for one transfer function of a petapm client other than the gravity PM (the
+ * displacement / velocity / density fields of libgenic/zeldovich.cpp:215-227, 271-321; the neutrino correction of the lensing planes,
+ * libgadget/plane.cpp:326-341): complx is the half spectrum in the reference's Fourier layout [y][z'][x] (as shq_fft_r2c returns it),
+ * real receives the unscaled inverse transform [x][y][z].  One resident upload / transform / download per call. */
+extern "C" int shq_pm_apply(shq_context *ctx, int Nmesh, const double *complx, const shq_pm_transfer *tf, double *real)
+{
+    SHQ_CHECK(ctx && complx && tf && real && tf->table, SHQ_ERR_INVALID, "null argument");
+    SHQ_CHECK(Nmesh >= 4 && Nmesh % 2 == 0, SHQ_ERR_INVALID, "pm_apply: Nmesh must be even and >= 4");
+    SHQ_CHECK(tf->kind >= SHQ_TF_RADIAL && tf->kind <= SHQ_TF_DIFF && (tf->kind == SHQ_TF_RADIAL || (tf->axis >= 0 && tf->axis <= 2)), SHQ_ERR_INVALID,
+              "pm_apply: kind %d / axis %d", tf->kind, tf->axis);
+    SHQ_HIP(hipSetDevice(ctx->device));
+    SHQ_TRY(shq_join_pm(ctx));
+    ctx->have_pm_result = false; /* the context's mesh is used as work space */
+    ctx->mesh_zeroed = false;
+    return shq_fft_roundtrip_c2r(ctx, Nmesh, complx, real, true, tf);
 }
 
 /* ---- slab-sharded PM (multi-GPU): local phases on caller-provided device buffers ------------------

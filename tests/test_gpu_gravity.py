@@ -322,6 +322,57 @@ def test_fft_dropins(ctx, N):
     assert np.abs(back - a * N**3).max() < 1e-11 * N**3
 
 
+@pytest.mark.parametrize("N", [24, 48, 18])
+def test_pm_apply_other_petapm_clients(ctx, N):
+    """shq_pm_apply = pm_apply_transfer_function + petapm_fft_c2r for the transfer functions of the other petapm clients, against the
+    reference's mode enumeration restated in numpy on its Fourier layout [y][z'][x] (petapm.cpp:1258-1298: kpos = mesh_to_k of
+    (y, z, x), handed to the transfer function as (kx, ky, kz)) and the oracle's c2r: the density and displacement transfers of
+    libgenic/zeldovich.cpp:271-321 with a made-up DeltaSpec(k), the k2 = 0 mode left alone; the lensing planes' neutrino correction
+    (plane.cpp:283-304: a radial factor, k2 = 0 set to zero); force_y_transfer (gravpm.cpp:464-488).  24, 48: bespoke transforms;
+    18: rocFFT."""
+    L = 7.0
+    a = np.random.default_rng(4).normal(size=(N, N, N))
+    spec = np.zeros((N, N // 2 + 1, N), dtype=np.complex128)           # [y][z'][x]
+    capi.check(capi.hip.shq_fft_r2c(ctx.h, N, capi.ptr(a), capi.ptr(spec)))
+    k1 = np.where(np.arange(N) <= N // 2, np.arange(N), np.arange(N) - N)
+    ky, kz, kx = np.meshgrid(k1, k1[: N // 2 + 1], k1, indexing="ij")    # the enumeration's pos[] = (y, z, x) -> kpos = (kx, ky, kz)
+    k2 = (kx.astype(np.int64) ** 2 + ky.astype(np.int64) ** 2 + kz.astype(np.int64) ** 2)
+    nz = k2 > 0
+    k2i = np.arange(3 * (N // 2) ** 2 + 1)
+    kmag_i = np.sqrt(k2i) * 2 * np.pi / L
+    delta = lambda k: 3.0 * k / (1.0 + (k / 2.0) ** 3)                   # a stand-in for curpower->DeltaSpec
+
+    def check(tf_kind, axis, zero_mode, table, expect_spec, tol=1e-11):
+        tab = np.ascontiguousarray(table, dtype=np.float64)
+        tf = capi.PMTransfer(tf_kind, axis, zero_mode, 0, tab.ctypes.data)
+        out = np.zeros((N, N, N))
+        capi.check(capi.hip.shq_pm_apply(ctx.h, N, capi.ptr(spec), C.byref(tf), capi.ptr(out)))
+        ref = orc.fft_c2r(np.ascontiguousarray(expect_spec.transpose(2, 0, 1)))    # [y][z'][x] -> [x][y][z']
+        assert np.abs(out - ref).max() < tol * np.abs(ref).max(), (tf_kind, axis)
+
+    # density_transfer: exp(-k2 / N^2) DeltaSpec(kmag) / sqrt(V), k2 = 0 untouched
+    T = np.exp(-k2i / N**2) * delta(kmag_i) / np.sqrt(L**3)
+    e = spec.copy()
+    e[nz] *= T[k2[nz]]
+    check(0, 0, 0, T, e)
+    # disp_y_transfer: fac = 1 / (2 pi) / sqrt(L) * ky / k2 * DeltaSpec; value -> (-im fac, re fac) = i fac value
+    with np.errstate(divide="ignore", invalid="ignore"):
+        T = np.where(k2i > 0, 1.0 / (2 * np.pi) / np.sqrt(L) / np.maximum(k2i, 1) * delta(kmag_i), 0.0)
+    e = spec.copy()
+    e[nz] = 1j * (T[k2[nz]] * ky[nz]) * spec[nz]
+    check(1, 1, 0, T, e)
+    # plane_neutrino_correction_transfer: value *= nufac(log k), zero mode zeroed
+    T = 0.05 * np.tanh(np.log(np.maximum(kmag_i, 1e-30)))
+    e = spec * T[k2]
+    e[~nz] = 0
+    check(0, 0, 1, T, e)
+    # force_z_transfer: fac = -diff_kernel(kz 2 pi / N) N / L, value -> i fac value (every mode; k2 = 0 has kz = 0: fac = 0 either way)
+    T = np.full(len(k2i), -(N / L))
+    w = kz * (2 * np.pi / N)
+    e = 1j * (T[k2] * (1 / 6.0 * (8 * np.sin(w) - np.sin(2 * w)))) * spec
+    check(2, 2, 1, T, e)
+
+
 def test_fft_seam_feeds_the_reference_transfer_function(ctx):
     """what a shenqi build would do with the drop-ins (petapm.cpp:403-452): r2c of the density mesh, potential_transfer applied
     to the [y][z'][x] spectrum exactly as pm_apply_transfer_function enumerates it (:1258-1298; restated in numpy on that
