@@ -349,9 +349,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96), amdgpu_num
                 c.pmpot[pi] = gp;
                 const double gv[3] = {g0, g1, g2};
                 double s = 0;
-                for(int j = 0; j < 3; j++) {
-                    const double ax = c.treeacc[3 * pi + j] + gv[j];
-                    s += ax * ax;
+                {
+#pragma clang fp contract(off)
+                    for(int j = 0; j < 3; j++) {
+                        const double ax = c.treeacc[3 * pi + j] + gv[j];
+                        s += ax * ax;
+                    }
                 }
                 const double oa = sqrt(s) / c.G;
                 if(SPARSE)
@@ -1045,6 +1048,7 @@ __global__ void grav_postprocess_kernel(const int32_t *targets, long long ntarge
 /* grav_get_abs_accel, gravshort2.hpp:111-121 */
 __global__ void oldacc_kernel(long long n, const double *treeacc, const double *gravpm, double *oldacc, double G)
 {
+#pragma clang fp contract(off) /* the same roundings as the readout kernel's and the walk prologue's copy of this sum */
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= n)
         return;

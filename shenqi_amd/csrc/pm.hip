@@ -252,6 +252,7 @@ __global__ __launch_bounds__(256) void pm_readout_kernel(const double4 *__restri
                                                          int nxalloc, int *oob, unsigned xcdk, const double *__restrict__ treeacc = nullptr,
                                                          double *oldacc = nullptr, double G = 0)
 {
+#pragma clang fp contract(off) /* see pm_readout_corner: the routes of the readout agree to the bit by construction, not by luck */
     /* consecutive workgroups (consecutive runs of the space-filling curve: neighbouring mesh lines) share an XCD's L2 */
     const long long i = (long long) xcd_block(blockIdx.x, gridDim.x, xcdk) * blockDim.x + threadIdx.x;
     if(i >= n)

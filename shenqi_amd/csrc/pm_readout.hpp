@@ -38,6 +38,9 @@ template <int FENCE, typename MeshAt>
 __device__ __forceinline__ void pm_readout_corner(int c, const double res[3], double ffac, MeshAt M, double &g0, double &g1, double &g2,
                                                   double &gp)
 {
+    /* no fp contraction here, nor in pm_readout_kernel's paired-load path: the "same bits on every route" of the readout must not
+     * depend on which of ffac * (c1 d1 - c2 d2) and w * f the compiler happens to fuse in three differently shaped code paths */
+#pragma clang fp contract(off)
     const double c1 = 2.0 / 3.0, c2 = 1.0 / 12.0;
     const int a = c & 1, b = (c >> 1) & 1, e = (c >> 2) & 1;
     /* bit ? r : 1 - r as one fma with wave-uniform operands (exactly r, exactly 1 - r): with a run-time corner index the select form
