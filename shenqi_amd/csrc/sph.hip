@@ -264,6 +264,7 @@ __global__ void sph_gather_leaf_kernel(long long nleaf, const int32_t *pidx, con
  * resident wave of a persistent grid, [entry][lane] so appends and reads coalesce) and are long enough
  * to be drained once. */
 #define NL_CAP 256      /* list entries per lane; quintic-kernel neighbourhoods hold ~113, symmetric hydro lists up to ~200 */
+#define NL_ROWS (NL_CAP + 64) /* rows of a wave's list region: a lane's fill is checked against NL_CAP once per candidate tile (<= 64 appends) */
 #define NL_MAXBLOCKS 4096 /* persistent workgroups (4 waves each) that own a list region */
 
 template <class F> __device__ __forceinline__ void nl_flush(const int32_t *myl, int &fill, F &&pair)
@@ -297,9 +298,9 @@ template <class F> __device__ __forceinline__ void nl_flush(const int32_t *myl, 
 #endif
 #define NW_WIN 32 /* nodes per window: half a window costs a few more reloads and buys 1.8 KB of LDS per wave */
 /* per wave: node window (centre + len, links, hmax for the symmetric cull) and candidate tile (position, interested
- * lanes, slot with the two flag bits on top, Hsml for the symmetric test): 4.3 KB (density) / 5.1 KB (hydro), so
+ * lanes per queued leaf, leaf records, slot with the two flag bits on top, Hsml for the symmetric test): 4.5 KB (density) / 5.4 KB (hydro), so
  * that the walk kernels reach 7-8 waves per SIMD instead of 5 */
-#define NW_LDS_PER_WAVE(SYM) (NW_WIN * (32 + 16 + ((SYM) ? 8 : 0)) + 64 * (32 + 8 + 4 + ((SYM) ? 8 : 0)))
+#define NW_LDS_PER_WAVE(SYM) (NW_WIN * (32 + 16 + ((SYM) ? 8 : 0)) + 64 * (32 + 8 + 4 + 4 + ((SYM) ? 8 : 0)))
 
 /* KEEP: only build the lists (two-kernel path): nothing is evaluated, `fill` returns the list length, and a
  * lane whose list would overflow sets `ovf` (its wave is then redone by the fused kernel). */
@@ -317,18 +318,23 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
     double *winH = reinterpret_cast<double *>(lds_wave + NW_WIN * 48); /* SYM only */
     char *tl = lds_wave + NW_WIN * (SYM ? 56 : 48);
     double4 *tq = reinterpret_cast<double4 *>(tl);
-    unsigned long long *tmask = reinterpret_cast<unsigned long long *>(tl + 64 * 32);
+    unsigned long long *lqm = reinterpret_cast<unsigned long long *>(tl + 64 * 32); /* per queued LEAF: the lanes that want it */
     int *tsl = reinterpret_cast<int *>(tl + 64 * 40);                  /* leaf slot | flags << 30 once gathered */
-    double *th = reinterpret_cast<double *>(tl + 64 * 44);             /* SYM only */
+    int *lqi = reinterpret_cast<int *>(tl + 64 * 44);                  /* per queued leaf: first candidate | count << 8 | may-wrap << 16 */
+    double *th = reinterpret_cast<double *>(tl + 64 * 48);             /* SYM only */
     const int lane = threadIdx.x & 63;
     const double halfBox = 0.5 * a.Box;
     unsigned int nint = 0;
-    int ncand = 0;
+    int ncand = 0, nleafq = 0;
     fill = 0;
     ovf = false;
     int mynext = valid ? a.root : -2;
 
-    /* scan the queued candidates: one coalesced gather, then broadcast reads */
+    /* scan the queued candidates: one coalesced gather, then broadcast reads.  Leaf by leaf (round 4): what is the same for a leaf's
+     * particles - which lanes want it, whether a displacement to it can need the periodic wrap at all - is read once per leaf into
+     * scalar registers (the interested lanes become the lane condition through an inverse ballot: no vector instruction), and a lane's
+     * fill is checked against NL_CAP once per tile (the list region has 64 rows of slack) instead of once per candidate:
+     * 22 -> 13 vector instructions per candidate, the same candidates in the same order with the same accept decisions. */
     auto scan_tile = [&]() {
         if(lane < ncand) {
             const int s = tsl[lane];
@@ -338,43 +344,53 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
                 th[lane] = a.hsml_leaf[s];
         }
         __builtin_amdgcn_wave_barrier();
-        for(int j = 0; j < ncand; j++) {
-            const double4 q = tq[j];
-            const unsigned long long km = tmask[j];
-            const int sf = tsl[j], s = sf & 0x3fffffff, fl = (int) ((unsigned) sf >> 30);
-            const double hj = SYM ? th[j] : 0.0;
-            const bool keep = ((km >> lane) & 1ull) && !(fl & 1) && !(KEEP && ovf);
-            double d0 = px - q.x, d1 = py - q.y, d2 = pz - q.z;
-            if(shq_ballot(fmax(fmax(fabs(d0), fabs(d1)), fabs(d2)) > halfBox) != 0ull) { /* any lane: a rare, harmless over-trigger */
-                d0 = wrapd(d0, a.Box, a.invBox);
-                d1 = wrapd(d1, a.Box, a.invBox);
-                d2 = wrapd(d2, a.Box, a.invBox);
-            }
-            const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
-            if(keep) {
-                nint++;
-                if(accept(r2, hj, fl)) {
-                    myl[fill * 64] = s;
-                    fill++;
+        for(int L = 0; L < nleafq; L++) {
+            const int info = __builtin_amdgcn_readfirstlane(lqi[L]);
+            const unsigned long long kmv = lqm[L];
+            const unsigned long long kms = ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (kmv >> 32)) << 32) |
+                                           (unsigned) __builtin_amdgcn_readfirstlane((int) kmv);
+            const bool mine = __builtin_amdgcn_inverse_ballot_w64(kms);
+            const int c0 = info & 0xff, cn = (info >> 8) & 0xff;
+            const bool maywrap = (info >> 16) != 0;
+            for(int k = 0; k < cn; k++) {
+                const int j = c0 + k;
+                const double4 q = tq[j];
+                const int sf = tsl[j], s = sf & 0x3fffffff, fl = (int) ((unsigned) sf >> 30);
+                const double hj = SYM ? th[j] : 0.0;
+                const bool keep = mine && !(fl & 1) && !(KEEP && ovf);
+                double d0 = px - q.x, d1 = py - q.y, d2 = pz - q.z;
+                if(maywrap) { /* wave-uniform; wrapping a displacement that does not need it is the identity */
+                    d0 = wrapd(d0, a.Box, a.invBox);
+                    d1 = wrapd(d1, a.Box, a.invBox);
+                    d2 = wrapd(d2, a.Box, a.invBox);
+                }
+                const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+                if(keep) {
+                    nint++;
+                    if(accept(r2, hj, fl)) {
+                        myl[fill * 64] = s;
+                        fill++;
+                    }
                 }
             }
-            if(KEEP) {
-                if(fill == NL_CAP) { /* this target's list does not fit: it leaves the walk (the others' lists stay good) and is
-                                        walked on its own by a whole wave afterwards (heavy_walk) */
-                    ovf = true;
-                    fill = 0;
-                    mynext = -2;
-                }
-            } else if(shq_ballot(fill == NL_CAP) != 0ull) {
-                if(dbg)
-                    dbg[2] += NL_CAP;
-                nl_flush(myl, fill, pair);
+        }
+        if(KEEP) {
+            if(fill >= NL_CAP) { /* this target's list does not fit: it leaves the walk (the others' lists stay good) and is
+                                    walked on its own by a whole wave afterwards (heavy_walk) */
+                ovf = true;
+                fill = 0;
+                mynext = -2;
             }
+        } else if(shq_ballot(fill >= NL_CAP) != 0ull) {
+            if(dbg)
+                dbg[2] += NL_CAP;
+            nl_flush(myl, fill, pair);
         }
         if(dbg)
             dbg[1] += ncand;
         __builtin_amdgcn_wave_barrier();
         ncand = 0;
+        nleafq = 0;
     };
 
     int seg1 = -1, seg2 = -1, seg3 = -1, myend = -1;
@@ -414,7 +430,8 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
         double dist = (SYM ? fmax(winH[w], h) : h) + 0.5 * B.w;
         double dx = B.x - px, dy = B.y - py, dz = B.z - pz;
         double dmax = fmax(fmax(fabs(dx), fabs(dy)), fabs(dz));
-        if((shq_ballot(dmax > halfBox) & actm) != 0ull) {
+        const bool wrapped_node = (shq_ballot(dmax > halfBox) & actm) != 0ull;
+        if(wrapped_node) {
             dx = wrapd(dx, a.Box, a.invBox);
             dy = wrapd(dy, a.Box, a.invBox);
             dz = wrapd(dz, a.Box, a.invBox);
@@ -431,10 +448,17 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
             if(km != 0ull && Ccount > 0) {
                 if(ncand + Ccount > 64)
                     scan_tile();
-                if(lane < Ccount) {
+                /* can a displacement from an interested lane to a particle of this leaf need the periodic wrap?  The particles lie in
+                 * the leaf's cell: |p - pos| <= |centre - pos| + len / 2 per coordinate; no, unless the node test itself wrapped or
+                 * that bound comes near Box / 2 for some interested lane (a conservative yes costs three identity wraps) */
+                const bool maywrap = wrapped_node || (shq_ballot(dmax + 0.5 * B.w > 0.999 * halfBox) & km) != 0ull;
+                if(lane < Ccount)
                     tsl[ncand + lane] = Cchild + lane;
-                    tmask[ncand + lane] = km;
+                if(lane == 0) {
+                    lqm[nleafq] = km;
+                    lqi[nleafq] = ncand | (Ccount << 8) | ((maywrap ? 1 : 0) << 16);
                 }
+                nleafq++;
                 ncand += Ccount;
             }
             if(act && !(KEEP && ovf)) /* a target that left the walk inside scan_tile stays out */
@@ -779,7 +803,7 @@ __device__ __forceinline__ void sph_density_body(const SphDev &a, const int32_t 
     }
     for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
     const long long wave = MODE == 4 ? task : task * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    int32_t *myl = nlist + (MODE == 0 ? ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) : (size_t) wave) * (size_t) (NL_CAP * 64) + lane;
+    int32_t *myl = nlist + (MODE == 0 ? ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) : (size_t) wave) * (size_t) (NL_ROWS * 64) + lane;
     const long long t = MODE >= 3 ? wave : wave * 64 + lane; /* MODE 3 / 4: every lane of the wave / workgroup works for the same target */
     bool valid = t < nq;
     long long pi = 0;
@@ -1106,7 +1130,7 @@ __device__ __forceinline__ void sph_hydro_body(const SphDev &a, const int32_t *q
     }
     for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
     const long long wave = MODE == 4 ? task : task * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    int32_t *myl = nlist + (MODE == 0 ? ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) : (size_t) wave) * (size_t) (NL_CAP * 64) + lane;
+    int32_t *myl = nlist + (MODE == 0 ? ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) : (size_t) wave) * (size_t) (NL_ROWS * 64) + lane;
     const long long t = MODE >= 3 ? wave : wave * 64 + lane; /* MODE 3 / 4: every lane of the wave / workgroup works for the same target */
     bool valid = t < nq;
     long long pi = 0;
@@ -1434,7 +1458,7 @@ static long long nl_chunk_waves(long long nq)
 static int reserve_nlist(shq_context *ctx, long long nq)
 {
     const long long waves = nl_chunk_waves(nq) + NL_REDO_BLOCKS * 4;
-    SHQ_TRY(ctx->s_nlist.reserve((size_t) waves * NL_CAP * 64));
+    SHQ_TRY(ctx->s_nlist.reserve((size_t) waves * NL_ROWS * 64));
     SHQ_TRY(ctx->s_ncount.reserve((size_t) (nl_chunk_waves(nq) + 4) * 64));
     SHQ_TRY(ctx->s_redo.reserve((size_t) (nq > 0 ? nq : 1)));
     SHQ_TRY(ctx->s_redo2.reserve((size_t) (nq > 0 ? nq : 1)));
@@ -1450,7 +1474,7 @@ static int launch_two_kernel(shq_context *ctx, const int32_t *q, long long nq, l
     long long *d_nredo = ctx->s_counters.ptr + 6;
     SHQ_HIP(hipMemsetAsync(d_nredo, 0, 2 * sizeof(long long), ctx->stream)); /* [6] targets for a wave of their own, [7] for a workgroup */
     int32_t *lists = ctx->s_nlist.ptr;
-    int32_t *fused_lists = ctx->s_nlist.ptr + (size_t) nl_chunk_waves(nq_reserved) * NL_CAP * 64;
+    int32_t *fused_lists = ctx->s_nlist.ptr + (size_t) nl_chunk_waves(nq_reserved) * NL_ROWS * 64;
     SHQ_CHECK(q || nq <= NL_CHUNK, SHQ_ERR_INVALID, "SPH walk: more than %lld targets need an explicit queue", (long long) NL_CHUNK);
     for(long long off = 0; off < nq; off += NL_CHUNK) {
         const long long m = (nq - off < NL_CHUNK) ? nq - off : NL_CHUNK;
@@ -1716,7 +1740,7 @@ int shq_sph_density_secondary(shq_context *ctx, const shq_density_params *p, con
         return SHQ_OK;
     SHQ_CHECK(p->DensityKernelType == 1 || p->DensityKernelType == 2 || p->DensityKernelType == 4, SHQ_ERR_INVALID,
               "unknown DensityKernelType %d", p->DensityKernelType);
-    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_ROWS * 64));
     SphDev a = make_dev(ctx);
     a.Box = p->BoxSize;
     a.invBox = 1.0 / p->BoxSize;
@@ -1903,7 +1927,7 @@ int shq_sph_hydro_secondary(shq_context *ctx, const shq_hydro_params *p, const d
         return SHQ_OK;
     SHQ_CHECK(p->DensityKernelType == 1 || p->DensityKernelType == 2 || p->DensityKernelType == 4, SHQ_ERR_INVALID,
               "unknown DensityKernelType %d", p->DensityKernelType);
-    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_ROWS * 64));
     SphDev a = hydro_dev(ctx, p);
     a.posm = d_qposm;
     a.hsml = const_cast<double *>(d_qhsml);
@@ -2029,7 +2053,7 @@ __global__ __launch_bounds__(256) void sph_stellar_kernel(const SphDev a, const 
     const int lane = threadIdx.x & 63;
     for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
     const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_ROWS * 64) + lane;
     const long long t = wave * 64 + lane;
     const bool valid = t < nq;
     long long pi = 0;
@@ -2195,7 +2219,7 @@ int shq_sph_stellar_density_device(shq_context *ctx, const shq_stellar_params *p
     SHQ_TRY(ctx->s_queue3.reserve(cap));
     SHQ_TRY(ctx->s_blockcount.reserve(nblk(n) + 1));
     SHQ_TRY(ctx->s_counters.reserve(8));
-    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_ROWS * 64));
     const long long nl = ctx->ntreeparts + SHQ_NMAXCHILD;
     SHQ_TRY(ctx->hsml_leaf.reserve(nl));   /* reused as the density-by-slot array */
     SHQ_TRY(ctx->flag_leaf.reserve(nl));
@@ -2288,7 +2312,7 @@ __global__ __launch_bounds__(256) void bh_veldisp_kernel(const SphDev a, const i
     const int lane = threadIdx.x & 63;
     for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
     const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_ROWS * 64) + lane;
     const long long t = wave * 64 + lane;
     const bool valid = t < nq;
     double px = 0, py = 0, pz = 0, h = 1, vx = 0, vy = 0, vz = 0;
@@ -2349,7 +2373,7 @@ int shq_bh_veldisp_device(shq_context *ctx, const shq_kick_factors *kf, double B
     const long long nl = ctx->ntreeparts + SHQ_NMAXCHILD;
     SHQ_TRY(ctx->velp_leaf.reserve(nl));
     SHQ_TRY(ctx->flag_leaf.reserve(nl));
-    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_ROWS * 64));
     hipStream_t st = ctx->stream;
     bh_veldisp_gather_kernel<<<dim3(nblk(nl)), dim3(256), 0, st>>>(nl, ctx->leaf_pidx.ptr, ctx->vel.ptr, ctx->treeacc.ptr, ctx->gravpm.ptr,
                                                                   ctx->bin_grav.ptr, ctx->pflags.ptr, *kf, 1 << 1, ctx->velp_leaf.ptr,
@@ -2462,7 +2486,7 @@ __global__ __launch_bounds__(256) void wind_veldisp_kernel(const SphDev a, const
     const int lane = threadIdx.x & 63;
     for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
     const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_ROWS * 64) + lane;
     const long long t = wave * 64 + lane;
     const bool valid = t < nq;
     long long pi = 0;
@@ -2572,7 +2596,7 @@ int shq_wind_veldisp_device(shq_context *ctx, const shq_kick_factors *kf, double
     SHQ_TRY(ctx->s_queue3.reserve(cap));
     SHQ_TRY(ctx->s_blockcount.reserve(nblk(n) + 1));
     SHQ_TRY(ctx->s_counters.reserve(8));
-    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_ROWS * 64));
     const long long nl = ctx->ntreeparts + SHQ_NMAXCHILD;
     SHQ_TRY(ctx->velp_leaf.reserve(nl));
     SHQ_TRY(ctx->flag_leaf.reserve(nl));
@@ -2661,7 +2685,7 @@ __global__ __launch_bounds__(256) void bh_dynfric_kernel(const SphDev a, const i
     const int lane = threadIdx.x & 63;
     for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
     const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_ROWS * 64) + lane;
     const long long t = wave * 64 + lane;
     const bool valid = t < nq;
     double px = 0, py = 0, pz = 0, h = 1;
@@ -2739,7 +2763,7 @@ int shq_bh_dynfric_device(shq_context *ctx, const shq_kick_factors *kf, double B
     SHQ_TRY(ctx->velp_leaf.reserve(nl));
     SHQ_TRY(ctx->hydrec_leaf.reserve((size_t) nl * sizeof(double4) + 128)); /* reused for the raw velocity + potential stream */
     SHQ_TRY(ctx->flag_leaf.reserve(nl));
-    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_ROWS * 64));
     hipStream_t st = ctx->stream;
     double4 *rv_leaf = reinterpret_cast<double4 *>(ctx->hydrec_leaf.ptr);
     bh_dynfric_gather_kernel<<<dim3(nblk(nl)), dim3(256), 0, st>>>(nl, ctx->leaf_pidx.ptr, ctx->vel.ptr, ctx->treeacc.ptr, ctx->gravpm.ptr,
@@ -2801,7 +2825,7 @@ __global__ __launch_bounds__(256) void bh_accretion_kernel(const SphDev a, const
     const int lane = threadIdx.x & 63;
     for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
     const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_ROWS * 64) + lane;
     const long long t = wave * 64 + lane;
     const bool valid = t < nq;
     double px = 0, py = 0, pz = 0, h = 1, imass = 0, ibhmass = 0, idens = 0, imtrack = 0;
@@ -3018,7 +3042,7 @@ __global__ __launch_bounds__(256) void bh_feedback_kernel(const SphDev a, const 
     const int lane = threadIdx.x & 63;
     for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
     const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_ROWS * 64) + lane;
     const long long t = wave * 64 + lane;
     const bool valid = t < nq;
     double px = 0, py = 0, pz = 0, h = 1, idens = 0, imtrack = 0, fws = 0, fbenergy = 0, kefb = 0;
@@ -3183,7 +3207,7 @@ static int bh_launch_prep(shq_context *ctx, const shq_kick_factors *kf)
     const long long nl = ctx->ntreeparts + SHQ_NMAXCHILD;
     bh_gather_leaf_kernel<<<dim3(nblk(nl)), dim3(256), 0, ctx->stream>>>(nl, ctx->leaf_pidx.ptr, ctx->pflags.ptr, ctx->flag_leaf.ptr);
     SHQ_HIP(hipGetLastError());
-    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_ROWS * 64));
     return SHQ_OK;
 }
 
@@ -3261,7 +3285,7 @@ __global__ __launch_bounds__(256) void wind_walk_kernel(const SphDev a, const in
     const int lane = threadIdx.x & 63;
     for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
     const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_ROWS * 64) + lane;
     const long long t = wave * 64 + lane;
     const bool valid = t < nq;
     double px = 0, py = 0, pz = 0, h = 1, imass = 0, tw = 0, vdisp = 0;
@@ -3435,7 +3459,7 @@ int shq_wind_walk_device(shq_context *ctx, const WindWalkArgs *w, const int32_t 
     SHQ_TRY(ctx->flag_leaf.reserve(nl));
     wind_gather_leaf_kernel<<<dim3(nblk(nl)), dim3(256), 0, st>>>(nl, ctx->leaf_pidx.ptr, ctx->pflags.ptr, ctx->g_delaytime.ptr, ctx->flag_leaf.ptr);
     SHQ_HIP(hipGetLastError());
-    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_ROWS * 64));
     SphDev a = make_dev(ctx);
     a.Box = w->P.BoxSize;
     a.invBox = 1.0 / w->P.BoxSize;
@@ -3464,7 +3488,7 @@ __global__ __launch_bounds__(256) void metal_emit_kernel(const SphDev a, const i
     const int lane = threadIdx.x & 63;
     for(long long task = xcd_block(blockIdx.x, gridDim.x); task < ntasks; task += gridDim.x) {
     const long long wave = task * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_CAP * 64) + lane;
+    int32_t *myl = nlist + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t) (NL_ROWS * 64) + lane;
     const long long t = wave * 64 + lane;
     const bool valid = t < nq;
     double px = 0, py = 0, pz = 0, h = 1;
@@ -3585,7 +3609,7 @@ int shq_metal_return_device(shq_context *ctx, MetalWalkArgs *w, int kernel_type,
     /* GASMASK, not garbage; wind particles take metals like any other gas */
     bh_gather_leaf_kernel<<<dim3(nblk(nl)), dim3(256), 0, st>>>(nl, ctx->leaf_pidx.ptr, ctx->pflags.ptr, ctx->flag_leaf.ptr);
     SHQ_HIP(hipGetLastError());
-    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_CAP * 64));
+    SHQ_TRY(ctx->s_nlist2.reserve((size_t) NL_REDO_BLOCKS * 4 * NL_ROWS * 64));
     SHQ_TRY(ctx->wind_cnt.reserve(4));
     SphDev a = make_dev(ctx);
     a.Box = BoxSize;
