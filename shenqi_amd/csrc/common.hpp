@@ -392,6 +392,10 @@ struct shq_context {
                                    between the mesh and a scratch mesh (mesh_alt) instead of working in place (fft3d.hip) */
     int pm_zp = 0;             /* z pitch of the mesh in doubles */
     DevBuf<double> fft_tw;     /* twiddles exp(-2 pi i k / N) */
+    DevBuf<double> fft_gax;    /* per-axis Green's function factor of the transposing pipeline's X pass (fft3d.hip) */
+    int fft_gax_n = 0;
+    double fft_gax_asmth2 = -1;
+    const double *fft_gax_src = nullptr;
     int fft_tw_n = 0;
     DevBuf<double> mesh;       /* padded in-place real/complex mesh: N*N*(N+2) doubles */
     DevBuf<double> sinctab;    /* 1/sinc^2 per mesh index */

@@ -35,6 +35,11 @@ namespace {
  * 256-thread workgroup would be one wave per SIMD holding 250-500 registers: 512 threads (the same two waves per SIMD, half the tile
  * elements per thread).  N is the mesh size wherever the macro is used. */
 __host__ __device__ constexpr int fft_threads(int N) { return N > 768 ? 512 : 256; }
+/* waves per SIMD the tile passes of the transposing pipeline are compiled for: the Y passes run three workgroups of four waves per CU up
+ * to Nmesh 768 (a tile + its 48 twiddles take 53 KB of the CU's 160, and the passes fit 168 registers: 3-4 % faster than two in a
+ * same-box A/B); the X pass keeps its Green's function factors in LDS and two workgroups (with the factors read from global memory and
+ * three workgroups it ran 2.44 against 2.09 ms); above 768 two workgroups of eight waves */
+__host__ __device__ constexpr int fft_tile_waves(int N, int MODE) { return (MODE != 2 && N <= 768) ? 3 : (N > 768 ? 4 : 2); }
 #ifndef FFT_T
 #define FFT_T fft_threads(N)
 #endif
@@ -66,6 +71,23 @@ __host__ __device__ constexpr bool fft_pad_ok(int N)
     return true;
 }
 template <int N> __host__ __device__ constexpr int lx(int i) { return fft_pad_ok(N) ? i + (i >> 4) : i; }
+/* Twiddles (round 4).  A butterfly of the stage (n, s, R) at position p multiplies its output k by w_N^(k p s).  Only w_N^(p s) is read
+ * from the table, the powers follow by repeated multiplication (k <= 15: a dozen rounding errors of 1e-16 on factors of modulus one,
+ * far inside the transforms' own error; every transform in the library takes its twiddles this way, so the pipelines that are
+ * compared bit for bit still agree) - fifteen LDS reads and thirty registers less per radix-16 butterfly, and the table shrinks from
+ * N entries to max over the stages of (m - 1) s + 1 (48 at 768): with 12 KB less LDS a tile pass fits THREE workgroups per CU. */
+__host__ __device__ constexpr int fft_twn(int N)
+{
+    int n = N, s = 1, mx = 0;
+    while(n > 1) {
+        const int R = fft_radix(n), m = n / R;
+        if((m - 1) * s > mx)
+            mx = (m - 1) * s;
+        n = m;
+        s *= R;
+    }
+    return mx + 1;
+}
 __host__ __device__ constexpr int fft_ls(int N)
 {
     const int last = fft_pad_ok(N) ? (N - 1) + ((N - 1) >> 4) : N - 1;
@@ -204,9 +226,14 @@ __device__ __forceinline__ void fft_stage(double2 *buf, const double2 *__restric
                 bfly16<DIR>(reinterpret_cast<double2(&)[16]>(v[kk]));
             }
             if(m > 1) { /* w_n^(p k); the last stage (m == 1) has p == 0 */
+                const double2 w1 = tw<DIR>(W, p * s);
+                double2 wk = w1;
+                v[kk][1] = cmul(v[kk][1], wk);
 #pragma unroll
-                for(int k = 1; k < R; k++)
-                    v[kk][k] = cmul(v[kk][k], tw<DIR>(W, k * p * s));
+                for(int k = 2; k < R; k++) {
+                    wk = cmul(wk, w1);
+                    v[kk][k] = cmul(v[kk][k], wk);
+                }
             }
         }
     }
@@ -260,7 +287,7 @@ __device__ __forceinline__ void fft_lines(double2 *buf, const double2 *__restric
 template <int N> __device__ __forceinline__ double2 *lds_twiddles(double2 *buf, const double2 *__restrict__ W)
 {
     double2 *Wl = buf + FFT_C * fft_ls(N);
-    for(int i = threadIdx.x; i < N; i += FFT_T)
+    for(int i = threadIdx.x; i < fft_twn(N); i += FFT_T)
         Wl[i] = W[i];
     return Wl;
 }
@@ -407,6 +434,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_inv(double *mesh, const int 
  * MODE 0: forward only; 1: inverse only; 2: forward, Green's function, inverse (X pass of the PM). */
 struct GreenArgs {
     const double *sinctab; /* 1 / sinc^2(pi k / N) per mesh index */
+    const double *gaxg;    /* transposing pipeline: exp(-k_i^2 asmth2) sinctab[i]^2 per mesh index, in global memory (fft_gax_kernel) */
     double asmth2, pot_factor;
     int y0;                /* mesh index of outer = 0 in the X pass (y-slab of a distributed mesh) */
     /* PK != 0 (Y pass of a distributed mesh): the transposed side of the pass lives in `alt`, laid out as the all-to-all wants it,
@@ -427,7 +455,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
     constexpr int E = (FFT_C * N + FFT_T - 1) / FFT_T; /* tile elements per thread */
     constexpr bool EXACT = E * FFT_T == FFT_C * N;
     double2 *Wl = lds_twiddles<N>(buf, W);
-    double *gax = reinterpret_cast<double *>(Wl + N); /* MODE 2 only: per-axis factor of the Green's function */
+    double *gax = reinterpret_cast<double *>(Wl + fft_twn(N)); /* MODE 2 only: per-axis factor of the Green's function */
     if(MODE == 2)
         for(int i = threadIdx.x; i < N; i += FFT_T) {
             const int k = i <= N / 2 ? i : i - N;
@@ -681,21 +709,20 @@ __global__ __launch_bounds__(FFT_T) void fft_t_z_inv(const double2 *__restrict__
  * SCATTER: row i of the result goes to dst + ((i * nzb + zb) * N + o) * 4 (the other layout: a 64-byte piece); otherwise the tile is
  * written back where it came from (dst may be src). */
 template <int N, int MODE, bool SCATTER>
-__global__ __launch_bounds__(FFT_T) void fft_t_tile(const double2 *src, double2 *dst, const int nzb, const int ntot, const double2 *__restrict__ W,
-                                                    const GreenArgs ga, const unsigned xcdk)
+__global__ __launch_bounds__(FFT_T, fft_tile_waves(N, MODE)) void fft_t_tile(const double2 *src, double2 *dst, const int nzb, const int ntot,
+                                                                       const double2 *__restrict__ W, const GreenArgs ga, const unsigned xcdk)
 {
     extern __shared__ double2 buf[];
     constexpr int LS = fft_ls(N);
     constexpr int E = (FFT_C * N + FFT_T - 1) / FFT_T;
     constexpr bool EXACT = E * FFT_T == FFT_C * N;
     double2 *Wl = lds_twiddles<N>(buf, W);
-    double *gax = reinterpret_cast<double *>(Wl + N);
-    if(MODE == 2)
-        for(int i = threadIdx.x; i < N; i += FFT_T) {
-            const int k = i <= N / 2 ? i : i - N;
-            const double sc = ga.sinctab[i];
-            gax[i] = exp(-(double) k * (double) k * ga.asmth2) * sc * sc;
-        }
+    double *gax = reinterpret_cast<double *>(Wl + fft_twn(N)); /* MODE 2: the Green's function's per-axis factors (fft_gax_kernel) in LDS */
+    if(MODE == 2) {
+        for(int i = threadIdx.x; i < N; i += FFT_T)
+            gax[i] = ga.gaxg[i];
+        __syncthreads();
+    }
     const unsigned vb = xcd_block(blockIdx.x, gridDim.x, xcdk);
     double prx[E], pry[E];
 #define FFT_FETCH(T_)                                                                            \
@@ -766,17 +793,28 @@ __global__ __launch_bounds__(FFT_T) void fft_t_tile(const double2 *src, double2 
 #undef FFT_FETCH
 }
 
+/* exp(-k_i^2 asmth2) sinctab[i]^2 per mesh index: the expression the in-place X pass fills its LDS table with */
+__global__ void fft_gax_kernel(int N, const double *__restrict__ sinctab, double asmth2, double *gax)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < N) {
+        const int k = i <= N / 2 ? i : i - N;
+        const double sc = sinctab[i];
+        gax[i] = exp(-(double) k * (double) k * asmth2) * sc * sc;
+    }
+}
+
 template <int N>
 int run_t(shq_context *ctx, double *d_mesh, double *d_scratch, int zp, bool from_i64, double inv_scale, const GreenArgs &ga)
 {
     const double2 *W = reinterpret_cast<const double2 *>(ctx->fft_tw.ptr);
-    constexpr size_t lds = sizeof(double2) * (FFT_C * fft_ls(N) + N) + sizeof(double) * N;
+    constexpr size_t lds = sizeof(double2) * (FFT_C * fft_ls(N) + fft_twn(N)), lds_x = lds + sizeof(double) * N; /* X pass: + its factor table */
     const int ztot = (int) (((long long) N * N) / (2 * FFT_C));
     const int zpc = zp / 2, nzb = zpc / FFT_C;
     const int stot = N * nzb;
     double2 *A = reinterpret_cast<double2 *>(d_mesh), *B = reinterpret_cast<double2 *>(d_scratch);
     hipStream_t s = ctx->stream;
-    static unsigned res_z = 0, res_s = 0;
+    static unsigned res_z = 0, res_s = 0, res_x = 0;
     if(res_s == 0) {
         const void *fns[6] = {(const void *) fft_t_z_fwd<N, true>, (const void *) fft_t_z_fwd<N, false>, (const void *) fft_t_z_inv<N>,
                               (const void *) fft_t_tile<N, 0, true>, (const void *) fft_t_tile<N, 2, true>, (const void *) fft_t_tile<N, 1, false>};
@@ -785,31 +823,32 @@ int run_t(shq_context *ctx, double *d_mesh, double *d_scratch, int zp, bool from
             ncu = 256;
         unsigned occ[6];
         for(int i = 0; i < 6; i++) {
-            if(lds > 48 * 1024)
-                SHQ_HIP(hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            const size_t l = i == 4 ? lds_x : lds;
+            if(l > 48 * 1024)
+                SHQ_HIP(hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int) l));
             int per_cu = 0;
-            if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fns[i], FFT_T, lds) != hipSuccess || per_cu < 1)
+            if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fns[i], FFT_T, l) != hipSuccess || per_cu < 1)
                 per_cu = 1;
             occ[i] = (unsigned) per_cu * (unsigned) ncu;
         }
         res_z = occ[0] < occ[1] ? occ[0] : occ[1];
         res_z = res_z < occ[2] ? res_z : occ[2];
-        unsigned r = occ[3] < occ[4] ? occ[3] : occ[4];
-        res_s = r < occ[5] ? r : occ[5];
+        res_s = occ[3] < occ[5] ? occ[3] : occ[5];
+        res_x = occ[4];
     }
     const unsigned gmul = getenv("SHQ_FFT_GRID_MUL") ? (unsigned) atoi(getenv("SHQ_FFT_GRID_MUL")) : 8u;
     auto grid = [&](int tot, unsigned resident) {
         const unsigned cap = gmul == 0 ? (unsigned) tot : resident * gmul;
         return dim3((unsigned) tot < cap ? (unsigned) tot : cap);
     };
-    const dim3 gz = grid(ztot, res_z), gs = grid(stot, res_s);
+    const dim3 gz = grid(ztot, res_z), gs = grid(stot, res_s), gx = grid(stot, res_x);
     const unsigned xcdk = getenv("SHQ_FFT_XCD_K") ? (unsigned) atoi(getenv("SHQ_FFT_XCD_K")) : 8u;
     if(from_i64)
         fft_t_z_fwd<N, true><<<gz, dim3(FFT_T), lds, s>>>(d_mesh, B, ztot, zp, W, inv_scale);
     else
         fft_t_z_fwd<N, false><<<gz, dim3(FFT_T), lds, s>>>(d_mesh, B, ztot, zp, W, 1.0);
     fft_t_tile<N, 0, true><<<gs, dim3(FFT_T), lds, s>>>(B, A, nzb, stot, W, ga, xcdk);
-    fft_t_tile<N, 2, true><<<gs, dim3(FFT_T), lds, s>>>(A, B, nzb, stot, W, ga, xcdk);
+    fft_t_tile<N, 2, true><<<gx, dim3(FFT_T), lds_x, s>>>(A, B, nzb, stot, W, ga, xcdk);
     fft_t_tile<N, 1, false><<<gs, dim3(FFT_T), lds, s>>>(B, B, nzb, stot, W, ga, xcdk);
     fft_t_z_inv<N><<<gz, dim3(FFT_T), lds, s>>>(B, d_mesh, ztot, zp, W);
     SHQ_HIP(hipGetLastError());
@@ -824,7 +863,7 @@ int run_n(shq_context *ctx, double *d_mesh, int zp, int stage, bool from_i64, do
 {
     const double2 *W = reinterpret_cast<const double2 *>(ctx->fft_tw.ptr);
     /* FFT_C padded lines + the twiddle table + (X pass) the sinc table */
-    constexpr size_t lds = sizeof(double2) * (FFT_C * fft_ls(N) + N) + sizeof(double) * N;
+    constexpr size_t lds = sizeof(double2) * (FFT_C * fft_ls(N) + fft_twn(N)) + sizeof(double) * N;
 #ifndef SHQ_FFT_RELAX /* tile-shape experiments on one mesh size */
     static_assert(N % (2 * FFT_C) == 0, "rows must tile evenly");
 #endif
@@ -994,6 +1033,15 @@ int shq_fft3d_run_transposed(shq_context *ctx, double *d_mesh, double *d_scratch
     ga.alt = nullptr;
     ga.nyl = 1;
     ga.qstride = ga.alt_outer = 0;
+    if(ctx->fft_gax_n != N || ctx->fft_gax_asmth2 != asmth2 || ctx->fft_gax_src != d_sinctab) {
+        SHQ_TRY(ctx->fft_gax.reserve((size_t) N));
+        fft_gax_kernel<<<dim3((unsigned) ((N + 255) / 256)), dim3(256), 0, ctx->stream>>>(N, d_sinctab, asmth2, ctx->fft_gax.ptr);
+        SHQ_HIP(hipGetLastError());
+        ctx->fft_gax_n = N;
+        ctx->fft_gax_asmth2 = asmth2;
+        ctx->fft_gax_src = d_sinctab;
+    }
+    ga.gaxg = ctx->fft_gax.ptr;
 #define SHQ_FFT_CASE(NN) case NN: return run_t<NN>(ctx, d_mesh, d_scratch, zp, from_i64, inv_scale, ga)
     switch(N) {
         SHQ_FFT_CASE(16); SHQ_FFT_CASE(24); SHQ_FFT_CASE(32); SHQ_FFT_CASE(40); SHQ_FFT_CASE(48); SHQ_FFT_CASE(64);
@@ -1030,6 +1078,7 @@ int shq_fft3d_run_slab_packed(shq_context *ctx, double *d_mesh, int N, int zp, i
     SHQ_TRY(ensure_twiddles(ctx, N));
     GreenArgs ga;
     ga.sinctab = d_sinctab;
+    ga.gaxg = nullptr;
     ga.asmth2 = asmth2;
     ga.pot_factor = pot_factor;
     ga.y0 = y0;
