@@ -824,7 +824,7 @@ def main():
     # HBM traffic per launch from the committed PMC summary of this same command (profiles/, made with
     # tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), if present: a counter pass cannot
     # run inside this process, so these two numbers are the committed measurement of the same kernels on the same workload
-    traffic = traffic_fft = None
+    traffic = traffic_fft = traffic_pair = None
     valu_busy = None
     pj = load_profile("bench256_pmc_hbm.json")
     if pj and n1 == 256 and world == 1:
@@ -832,9 +832,11 @@ def main():
         key = production_walk_key(pj)
         if key:
             traffic = hbm_bytes(pj[key])
-        fk = [k for k in pj if k.startswith("fft_pass_")]
+        fk = [k for k in pj if k.startswith("fft_t_")] or [k for k in pj if k.startswith("fft_pass_")]   # transposing / in-place pipeline
         if len(fk) == 5:
             traffic_fft = sum(hbm_bytes(pj[k]) for k in fk)
+        pk = [k for k in pj if k.startswith("grav_pair_kernel_live<true>")]
+        traffic_pair = hbm_bytes(pj[pk[0]]) if pk else None
     sj = load_profile("bench256_pmc_sq.json")
     if sj:
         key = production_walk_key(sj)
@@ -856,7 +858,7 @@ def main():
     walk_alg_bytes = sum(walk_alg.values())
     walk_roofline = {"bound": "valu-f64", "kernel": "grav_walk_exact_kernel", "achieved": walk_flops / max(walk_s, 1e-12) / 1e12,
                      "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": walk_flops / max(walk_s, 1e-12) / 1e12 / FP64_VECTOR_PEAK_TF, "traffic": traffic,
+                     "frac": walk_flops / max(walk_s, 1e-12) / 1e12 / FP64_VECTOR_PEAK_TF, "traffic": traffic, "traffic_pair_kernel": traffic_pair,
                      "algorithmic_flops": walk_flops, "algorithmic_bytes": walk_alg_bytes, "algorithmic_bytes_parts": walk_alg,
                      "hbm_algorithmic_GBs": walk_alg_bytes / max(walk_s, 1e-12) / 1e9,
                      "valu_busy": valu_busy,

@@ -3,7 +3,7 @@
 #   tools/refresh_profiles.sh r03   ->  gpurun_out/profiles_r03/r03_*.{csv,json}, to be copied into profiles/
 # Kernel trace and every counter group are separate runs (--pmc is never combined with a trace domain).
 set -e -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
