@@ -575,3 +575,21 @@ def test_oracle_runtests_force_gates():
         return acc
 
     check_runtests_gates(*_runtests_sequence(walk, pmforce, n))
+
+
+def test_oracle_pm_with_scipy_fft_hook():
+    """orc_set_fft (what bench.py's cpu_baseline times its PM leg with): scipy's pocketfft behind the oracle's deposit, transfer
+    functions and readout gives the oracle's own forces and potentials to rounding, and the hook uninstalls cleanly"""
+    import common as cm
+    n = 12**3
+    pos = cm.random_positions(orc.boost_mt19937_uniform(5, 3 * n), n)
+    mass = np.ones(n, dtype=np.float32)
+    g0, p0, _, _ = orc.pm_force(pos, mass, 24, cm.BOX, 1.5, cm.G)
+    orc.use_scipy_fft(2)
+    try:
+        g1, p1, _, _ = orc.pm_force(pos, mass, 24, cm.BOX, 1.5, cm.G)
+    finally:
+        orc.use_scipy_fft(0)
+    g2, p2, _, _ = orc.pm_force(pos, mass, 24, cm.BOX, 1.5, cm.G)
+    assert np.abs(g1 - g0).max() < 1e-12 * np.abs(g0).max() and np.abs(p1 - p0).max() < 1e-12 * np.abs(p0).max()
+    assert np.array_equal(g2, g0) and np.array_equal(p2, p0)
