@@ -579,7 +579,7 @@ def test_oracle_runtests_force_gates():
 
 def test_oracle_pm_with_scipy_fft_hook():
     """orc_set_fft (what bench.py's cpu_baseline times its PM leg with): scipy's pocketfft behind the oracle's deposit, transfer
-    functions and readout gives the oracle's own forces and potentials to rounding, and the hook uninstalls cleanly"""
+    functions and readout gives the oracle's own forces and potentials to rounding, with the hook installed and after it is removed"""
     import common as cm
     n = 12**3
     pos = cm.random_positions(orc.boost_mt19937_uniform(5, 3 * n), n)
@@ -592,4 +592,5 @@ def test_oracle_pm_with_scipy_fft_hook():
         orc.use_scipy_fft(0)
     g2, p2, _, _ = orc.pm_force(pos, mass, 24, cm.BOX, 1.5, cm.G)
     assert np.abs(g1 - g0).max() < 1e-12 * np.abs(g0).max() and np.abs(p1 - p0).max() < 1e-12 * np.abs(p0).max()
-    assert np.array_equal(g2, g0) and np.array_equal(p2, p0)
+    # (not bit for bit: the oracle's deposit adds f64 values with omp atomic, as the reference does, in whatever order its threads arrive)
+    assert np.abs(g2 - g0).max() < 1e-12 * np.abs(g0).max() and np.abs(p2 - p0).max() < 1e-12 * np.abs(p0).max()
