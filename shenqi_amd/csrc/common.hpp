@@ -173,6 +173,7 @@ __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb, unsigned 
 /* scratch of the device tree build (tree_build.hip) */
 struct TreeBuildBufs {
     DevBuf<unsigned long long> keys[2], okeys[2], packed[2], counters;
+    DevBuf<int> state;                   /* TbState (tree_build.hip): the level loop's bookkeeping */
     DevBuf<int32_t> idx[2], order[2], rank, frontier[2], bounds;
     DevBuf<int32_t> lo, hi, parent, sibling, firstchild, nchild, level;
     DevBuf<int32_t> top;                 /* domain build: TopNodes index of a top-level node, -1 below the top tree */
@@ -191,7 +192,7 @@ struct TreeBuildBufs {
         }
         counters.release(); rank.release(); bounds.release(); lo.release(); hi.release(); parent.release(); sibling.release();
         firstchild.release(); nchild.release(); level.release(); cen.release(); mom.release(); hmax.release(); temp.release();
-        exportbuf.release(); top.release(); path.release(); geo_child[0].release(); geo_child[1].release(); geo_kind.release(); topbuf.release();
+        exportbuf.release(); top.release(); path.release(); geo_child[0].release(); geo_child[1].release(); geo_kind.release(); topbuf.release(); state.release();
     }
 };
 

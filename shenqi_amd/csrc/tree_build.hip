@@ -150,13 +150,44 @@ __global__ void tb_root_kernel(TbNodes nd, int n, double Box, int dom)
 
 /* octant boundaries of every internal node of the level: bounds[9 f + s] = first sorted position whose
  * digit is >= s; packed[f] = (#children << 32) | #children with more than NMAXCHILD particles */
+/* The level loop keeps its bookkeeping on the device (round 4): how many nodes exist, the frontier of the level at hand and of the next
+ * one, where every level starts in the pool.  The host queues all TB_LEVELS levels back to back - fixed grids, grid-stride loops over a
+ * frontier whose length the kernels read here - and looks at the result once: a build used to make one host round trip per level,
+ * which is what stretched it threefold beside the FFT passes of an early PM. */
+struct TbState {
+    int nn, nf, nf_next, maxdepth, overflow, pad_[3];
+    int level_start[TB_LEVELS + 3];
+};
+
+__global__ void tb_state_init_kernel(TbState *st, int nf0)
+{
+    st->nn = 1;
+    st->nf = nf0;
+    st->nf_next = 0;
+    st->maxdepth = 0;
+    st->overflow = 0;
+    st->level_start[0] = 0;
+    for(int l = 1; l < TB_LEVELS + 3; l++)
+        st->level_start[l] = 1;
+}
+
+/* the level is through: its children are the pool's newest nodes, its internal children the next frontier */
+__global__ void tb_advance_kernel(TbState *st, int level)
+{
+    if(st->nf > 0)
+        st->maxdepth = level + 1;
+    for(int l = level + 2; l < TB_LEVELS + 3; l++)
+        st->level_start[l] = st->nn;
+    st->nf = st->nf_next;
+    st->nf_next = 0;
+}
+
 template <bool DOM>
-__global__ void tb_split_kernel(int nf, const int32_t *__restrict__ frontier, TbNodes nd, const unsigned long long *__restrict__ keys,
+__global__ void tb_split_kernel(const TbState *st, const int32_t *__restrict__ frontier, TbNodes nd, const unsigned long long *__restrict__ keys,
                                 int level, int32_t *bounds, unsigned long long *packed, TbGeo geo)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if(f >= nf)
-        return;
+    const int nf = st->nf;
+    for(int f = blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += gridDim.x * blockDim.x) {
     const int no = frontier[f];
     const int lo = nd.lo[no], hi = nd.hi[no];
     int b[9];
@@ -192,18 +223,26 @@ __global__ void tb_split_kernel(int nf, const int32_t *__restrict__ frontier, Tb
     for(int s = 0; s < 9; s++)
         bounds[9 * f + s] = b[s];
     packed[f] = ((unsigned long long) nch << 32) | nint;
+    }
 }
 
+/* A node's children take the next packed[f] >> 32 pool slots, contiguous and in octant order, wherever the pool's end happens to be when
+ * the node gets there (one atomic per node): the numbering inside a level depends on the order the threads arrive in, the tree does not -
+ * the walk pool is laid out by the pre-order rank, which is a sort on (first particle, level) / the octant path, not on these numbers. */
 template <bool DOM>
-__global__ void tb_children_kernel(int nf, const int32_t *__restrict__ frontier, TbNodes nd, int level, const int32_t *__restrict__ bounds,
-                                   const unsigned long long *__restrict__ scan, int nnodes, int32_t *next_frontier, int *err, TbGeo geo)
+__global__ void tb_children_kernel(TbState *st, const int32_t *__restrict__ frontier, TbNodes nd, int level, const int32_t *__restrict__ bounds,
+                                   const unsigned long long *__restrict__ packed, int cap, int32_t *next_frontier, int *err, TbGeo geo)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if(f >= nf)
-        return;
+    const int nf = st->nf;
+    for(int f = blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += gridDim.x * blockDim.x) {
     const int no = frontier[f];
-    const int base = nnodes + (int) (scan[f] >> 32);
-    int qoff = (int) (scan[f] & 0xffffffffull);
+    const int want = (int) (packed[f] >> 32), wantq = (int) (packed[f] & 0xffffffffull);
+    const int base = atomicAdd(&st->nn, want);
+    int qoff = atomicAdd(&st->nf_next, wantq);
+    if((long long) base + want > (long long) cap) { /* the pool is too small: the host doubles it and builds again */
+        st->overflow = 1;
+        continue;
+    }
     const double4 pc = nd.cen[no];
     const int psib = nd.sibling[no];
     const double lenhalf = 0.25 * pc.w; /* init_internal_node, forcetree.cpp:302-328 */
@@ -250,6 +289,7 @@ __global__ void tb_children_kernel(int nf, const int32_t *__restrict__ frontier,
     }
     nd.firstchild[no] = base;
     nd.nchild[no] = nch;
+    }
 }
 
 /* leaves list their particles in candidate-sequence order (the sort ordered them by the deeper key
@@ -750,60 +790,52 @@ static int tree_build_impl(shq_context *ctx, double BoxSize, int mask, const int
     TbGeo geo = {nullptr, nullptr, nullptr};
     if(dom)
         geo = TbGeo{b.geo_child[0].ptr, b.geo_child[1].ptr, b.geo_kind.ptr};
-    int level_start[TB_LEVELS + 2];
+    int level_start[TB_LEVELS + 3];
     int nn = 0, maxdepth = 0;
     size_t cap = (size_t) (0.6 * (double) n) + 4096;
+    SHQ_TRY(b.state.reserve((sizeof(TbState) + sizeof(int) - 1) / sizeof(int)));
+    TbState *d_state = reinterpret_cast<TbState *>(b.state.ptr);
     for(int attempt = 0;; attempt++) {
         SHQ_CHECK(attempt < 5, SHQ_ERR_NOMEM, "tree_build: node pool overflow");
+        SHQ_CHECK(cap < (1ull << 31) - 64, SHQ_ERR_NOMEM, "tree_build: node pool beyond 2^31 nodes");
         SHQ_TRY(reserve_nodes(ctx, cap));
         SHQ_TRY(b.bounds.reserve(9 * cap));
         SHQ_TRY(b.packed[0].reserve(cap + 1));
-        SHQ_TRY(b.packed[1].reserve(cap + 1));
         TbNodes nd = node_view(ctx);
         tb_root_kernel<<<1, 1, 0, st>>>(nd, (int) n, BoxSize, dom ? 1 : 0);
-        nn = 1;
-        level_start[0] = 0;
-        level_start[1] = 1;
-        maxdepth = 0;
-        int nf = (n > SHQ_NMAXCHILD || (dom && ctx->dom_kind[0] == TOPK_INTERNAL)) ? 1 : 0, fsel = 0;
-        if(nf)
+        const int nf0 = (n > SHQ_NMAXCHILD || (dom && ctx->dom_kind[0] == TOPK_INTERNAL)) ? 1 : 0;
+        tb_state_init_kernel<<<1, 1, 0, st>>>(d_state, nf0);
+        if(nf0)
             SHQ_HIP(hipMemsetAsync(b.frontier[0].ptr, 0, sizeof(int32_t), st)); /* frontier = {root} */
-        bool overflow = false;
-        for(int level = 0; nf > 0; level++) {
-            SHQ_CHECK(level < TB_LEVELS, SHQ_ERR_INVALID, "tree_build: tree deeper than %d levels", TB_LEVELS);
-            if(dom)
-                tb_split_kernel<true><<<dim3(nblk(nf)), dim3(256), 0, st>>>(nf, b.frontier[fsel].ptr, nd, keys, level, b.bounds.ptr, b.packed[0].ptr, geo);
-            else
-                tb_split_kernel<false><<<dim3(nblk(nf)), dim3(256), 0, st>>>(nf, b.frontier[fsel].ptr, nd, keys, level, b.bounds.ptr, b.packed[0].ptr, geo);
-            SHQ_HIP(hipMemsetAsync(b.packed[0].ptr + nf, 0, sizeof(unsigned long long), st));
-            size_t tmp = 0;
-            SHQ_HIP(rocprim::exclusive_scan(nullptr, tmp, b.packed[0].ptr, b.packed[1].ptr, 0ull, (size_t) nf + 1, rocprim::plus<unsigned long long>(), st));
-            SHQ_TRY(b.temp.reserve(tmp + 16));
-            SHQ_HIP(rocprim::exclusive_scan(b.temp.ptr, tmp, b.packed[0].ptr, b.packed[1].ptr, 0ull, (size_t) nf + 1, rocprim::plus<unsigned long long>(), st));
-            unsigned long long tot = 0;
-            SHQ_HIP(hipMemcpyAsync(&tot, b.packed[1].ptr + nf, sizeof(tot), hipMemcpyDeviceToHost, st));
-            SHQ_HIP(hipStreamSynchronize(st));
-            const int nch = (int) (tot >> 32), nint = (int) (tot & 0xffffffffull);
-            if((size_t) nn + (size_t) nch > cap) {
-                overflow = true;
-                break;
+        /* every level queued, no host round trip: a level whose frontier is empty costs three launches that find nothing to do */
+        const dim3 lg(n > (1 << 20) ? 2048u : 256u), lb(256);
+        int fsel = 0;
+        for(int level = 0; nf0 && level < TB_LEVELS; level++) {
+            if(dom) {
+                tb_split_kernel<true><<<lg, lb, 0, st>>>(d_state, b.frontier[fsel].ptr, nd, keys, level, b.bounds.ptr, b.packed[0].ptr, geo);
+                tb_children_kernel<true><<<lg, lb, 0, st>>>(d_state, b.frontier[fsel].ptr, nd, level, b.bounds.ptr, b.packed[0].ptr, (int) cap,
+                                                            b.frontier[fsel ^ 1].ptr, reinterpret_cast<int *>(b.counters.ptr + 1), geo);
+            } else {
+                tb_split_kernel<false><<<lg, lb, 0, st>>>(d_state, b.frontier[fsel].ptr, nd, keys, level, b.bounds.ptr, b.packed[0].ptr, geo);
+                tb_children_kernel<false><<<lg, lb, 0, st>>>(d_state, b.frontier[fsel].ptr, nd, level, b.bounds.ptr, b.packed[0].ptr, (int) cap,
+                                                             b.frontier[fsel ^ 1].ptr, reinterpret_cast<int *>(b.counters.ptr + 1), geo);
             }
-            if(dom)
-                tb_children_kernel<true><<<dim3(nblk(nf)), dim3(256), 0, st>>>(nf, b.frontier[fsel].ptr, nd, level, b.bounds.ptr, b.packed[1].ptr, nn,
-                                                                               b.frontier[fsel ^ 1].ptr, reinterpret_cast<int *>(b.counters.ptr + 1), geo);
-            else
-                tb_children_kernel<false><<<dim3(nblk(nf)), dim3(256), 0, st>>>(nf, b.frontier[fsel].ptr, nd, level, b.bounds.ptr, b.packed[1].ptr, nn,
-                                                                                b.frontier[fsel ^ 1].ptr, reinterpret_cast<int *>(b.counters.ptr + 1), geo);
-            SHQ_HIP(hipGetLastError());
-            nn += nch;
-            maxdepth = level + 1;
-            level_start[level + 2] = nn;
-            nf = nint;
+            tb_advance_kernel<<<1, 1, 0, st>>>(d_state, level);
             fsel ^= 1;
         }
-        if(!overflow)
-            break;
-        cap *= 2;
+        SHQ_HIP(hipGetLastError());
+        TbState hs;
+        SHQ_HIP(hipMemcpyAsync(&hs, d_state, sizeof(hs), hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipStreamSynchronize(st));
+        if(hs.overflow) {
+            cap *= 2;
+            continue;
+        }
+        nn = hs.nn;
+        maxdepth = hs.maxdepth;
+        for(int l = 0; l < TB_LEVELS + 3; l++)
+            level_start[l] = hs.level_start[l];
+        break;
     }
     int h_err = 0;
     SHQ_HIP(hipMemcpyAsync(&h_err, b.counters.ptr + 1, sizeof(int), hipMemcpyDeviceToHost, st));
