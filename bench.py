@@ -886,7 +886,7 @@ def main():
         "roofline": walk_roofline if walk_s >= pm_s else
                     {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": pm_bytes},
-        "roofline_pm_fft": {"bound": "hbm", "kernel": "fft_pass_z_fwd/strided/z_inv (5 fused passes)",
+        "roofline_pm_fft": {"bound": "hbm", "kernel": "fft_t_z_fwd / fft_t_tile x3 / fft_t_z_inv (5 fused passes, transposing pipeline)",
                             "achieved": fft_bytes / max(fft_s, 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": fft_bytes / max(fft_s, 1e-12) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_fft,
                             "algorithmic_bytes": fft_bytes,
