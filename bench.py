@@ -785,7 +785,9 @@ def main():
     ph = list(ph)
     fused = C.c_int(0)
     capi.check(capi.hip.shq_treepm_last_fused(ctx.h, C.byref(fused)))
-    step_route = ("shq_treepm_step: PM readout + OldAcc refresh in the walk's task prologue" if fused.value and not args.separate_calls and args.walk_mode == 0
+    one_call_route = not args.separate_calls and args.walk_mode == 0
+    step_route = ("shq_treepm_step: PM readout + OldAcc refresh in the walk's task prologue" if fused.value and one_call_route
+                  else "shq_treepm_step: the PM's readout kernel forms OldAcc, then the walk" if one_call_route
                   else "shq_pm_run + shq_grav_refresh_oldacc + shq_grav_short_run")
     # the pair kernel's sticky status after the timed loop (no download inside it): launches the mop-up pass had to finish, the
     # deepest pair stack; an overflow in any of the timed steps comes back here as an error

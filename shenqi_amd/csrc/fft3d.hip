@@ -38,8 +38,9 @@ __host__ __device__ constexpr int fft_threads(int N) { return N > 768 ? 512 : 25
 /* waves per SIMD the tile passes of the transposing pipeline are compiled for: the Y passes run three workgroups of four waves per CU up
  * to Nmesh 768 (a tile + its 48 twiddles take 53 KB of the CU's 160, and the passes fit 168 registers: 3-4 % faster than two in a
  * same-box A/B); the X pass keeps its Green's function factors in LDS and two workgroups (with the factors read from global memory and
- * three workgroups it ran 2.44 against 2.09 ms); above 768 two workgroups of eight waves */
-__host__ __device__ constexpr int fft_tile_waves(int N, int MODE) { return (MODE != 2 && N <= 768) ? 3 : (N > 768 ? 4 : 2); }
+ * three workgroups it ran 2.44 against 2.09 ms); above 768 the workgroups have eight waves and the bound stays at two per SIMD
+ * (four - a 128-register budget - made the 1200 mesh spill: 208 ms for its five passes instead of 44) */
+__host__ __device__ constexpr int fft_tile_waves(int N, int MODE) { return (MODE != 2 && N <= 768) ? 3 : 2; }
 #ifndef FFT_T
 #define FFT_T fft_threads(N)
 #endif

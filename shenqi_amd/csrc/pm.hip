@@ -545,8 +545,9 @@ int shq_pm_execute(shq_context *ctx, const shq_pm_params *pm, bool readout)
         /* the transposing pipeline (fft3d.hip) wants a second mesh as scratch: the one shq_treepm_step keeps anyway (between two steps
          * it holds the previous step's potential, which nothing reads any more once that step's walk has gone by on this stream) */
         double *scratch = nullptr;
-        if(ctx->fft_transposed && zp == shq_fft3d_pitch(N) && ctx->mesh_alt.reserve(padded) == SHQ_OK)
-            scratch = ctx->mesh_alt.ptr;
+        static const size_t scratch_off = getenv("SHQ_FFT_SCRATCH_OFFSET") ? (size_t) atoll(getenv("SHQ_FFT_SCRATCH_OFFSET")) / 8 : 0; /* probe */
+        if(ctx->fft_transposed && zp == shq_fft3d_pitch(N) && ctx->mesh_alt.reserve(padded + scratch_off) == SHQ_OK)
+            scratch = ctx->mesh_alt.ptr + scratch_off;
         SHQ_HIP(hipEventRecord(ctx->ev_begin[9], ctx->stream));
         if(scratch)
             SHQ_TRY(shq_fft3d_run_transposed(ctx, ctx->mesh.ptr, scratch, N, zp, true, 1.0 / scale, ctx->sinctab.ptr, asmth2, pot_factor));
