@@ -349,15 +349,21 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
             const unsigned long long kmv = lqm[L];
             const unsigned long long kms = ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (kmv >> 32)) << 32) |
                                            (unsigned) __builtin_amdgcn_readfirstlane((int) kmv);
-            const bool mine = __builtin_amdgcn_inverse_ballot_w64(kms);
             const int c0 = info & 0xff, cn = (info >> 8) & 0xff;
             const bool maywrap = (info >> 16) != 0;
-            for(int k = 0; k < cn; k++) {
-                const int j = c0 + k;
-                const double4 q = tq[j];
-                const int sf = tsl[j], s = sf & 0x3fffffff, fl = (int) ((unsigned) sf >> 30);
-                const double hj = SYM ? th[j] : 0.0;
-                const bool keep = mine && !(fl & 1) && !(KEEP && ovf);
+            /* what holds for the whole leaf: the lane wants it and has not left the walk (a lane leaves at a tile's end only) */
+            const bool keepL = __builtin_amdgcn_inverse_ballot_w64(kms) && !(KEEP && ovf);
+            /* the candidate's slot and flags are the same in every lane: scalar registers, and a garbage particle (rare) is passed
+             * over by a scalar branch instead of a lane condition; eight copies of the body with compile-time LDS offsets */
+#pragma unroll
+            for(int k = 0; k < SHQ_NMAXCHILD; k++) {
+                if(k >= cn)
+                    break;
+                const int sf = __builtin_amdgcn_readfirstlane(tsl[c0 + k]), s = sf & 0x3fffffff, fl = (int) ((unsigned) sf >> 30);
+                if(fl & 1)
+                    continue;
+                const double4 q = tq[c0 + k];
+                const double hj = SYM ? th[c0 + k] : 0.0;
                 double d0 = px - q.x, d1 = py - q.y, d2 = pz - q.z;
                 if(maywrap) { /* wave-uniform; wrapping a displacement that does not need it is the identity */
                     d0 = wrapd(d0, a.Box, a.invBox);
@@ -365,7 +371,7 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
                     d2 = wrapd(d2, a.Box, a.invBox);
                 }
                 const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
-                if(keep) {
+                if(keepL) {
                     nint++;
                     if(accept(r2, hj, fl)) {
                         myl[fill * 64] = s;
