@@ -274,7 +274,11 @@ template <int N, int n, int s, int DIR> struct Stages {
 template <int N, int DIR, typename StoreOp = NoLoadOp>
 __device__ __forceinline__ void fft_lines(double2 *buf, const double2 *__restrict__ W, const StoreOp op = StoreOp())
 {
+#ifdef SHQ_FFT_PROBE_NOCOMPUTE /* timing probe only (wrong results): what a pass costs without its transforms */
+    __syncthreads();
+#else
     Stages<N, N, 1, DIR>::run(buf, W, op);
+#endif
 }
 
 /* ---- persistent workgroups -------------------------------------------------------------------------
