@@ -1258,7 +1258,8 @@ int shq_fft_c2r(shq_context *ctx, int Nmesh, const double *complx, double *real)
  * k2 = kx^2 + ky^2 + kz^2 (through |k| = sqrt(k2) 2 pi / BoxSize): the caller tabulates T by k2 with its own functions (DeltaSpec,
  * dlogGrowth, its spline ...), which keeps the values the reference's.  table: host, 3 (Nmesh/2)^2 + 1 entries.
  * zero_mode: what happens to k2 = 0 - 0 the mode is left as it is (the `if(k2)` of the zeldovich transfers), 1 it is set to zero
- * (plane.cpp:286).  complx: [y][z'][x] as shq_fft_r2c returns it; real: [x][y][z], unscaled.  Host pointers; synchronous. */
+ * (plane.cpp:286), 2 it is multiplied by T[0] like every other mode (uvbg.cpp:211-215 divide_by_ncell; the reionisation filters
+ * filter_pm, uvbg.cpp:218-250, are SHQ_TF_RADIAL tables in k R as well).  complx: [y][z'][x] as shq_fft_r2c returns it; real: [x][y][z], unscaled.  Host pointers; synchronous. */
 #define SHQ_TF_RADIAL 0
 #define SHQ_TF_GRADIENT 1
 #define SHQ_TF_DIFF 2

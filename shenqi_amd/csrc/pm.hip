@@ -709,7 +709,9 @@ int shq_fft_roundtrip_r2c(shq_context *ctx, int N, const double *real, double *c
  * spectrum [x][y][z'] (kpos = mesh_to_k of each index, k2 their integer norm): the factor of a mode is a function of the integer k2 -
  * tabulated by the caller with its own functions (DeltaSpec, dlogGrowth, the neutrino spline ...), so the values are the reference's -
  * times 1, or i kpos[axis], or i diff_kernel(kpos[axis] 2 pi / N): libgenic/zeldovich.cpp:271-321, libgadget/plane.cpp:283-304,
- * gravpm.cpp:464-488.  The k2 = 0 mode is left alone (`if(k2)` of the zeldovich transfers) or set to zero (plane.cpp:286). */
+ * gravpm.cpp:464-488; the reionisation filters of libgadget/uvbg.cpp:211-250 (top-hat, k-space top-hat, Gaussian in k R; divide_by_ncell) are
+ * radial factors too.  The k2 = 0 mode is left alone (`if(k2)` of the zeldovich transfers), set to zero (plane.cpp:286), or multiplied by
+ * T[0] like the others (divide_by_ncell). */
 __global__ void pm_transfer_kernel(double2 *spec, int N, int Nc, const double *__restrict__ table, int kind, int axis, int zero_mode)
 {
 #pragma clang fp contract(off)
@@ -721,8 +723,8 @@ __global__ void pm_transfer_kernel(double2 *spec, int N, int Nc, const double *_
     const int kpos[3] = {x <= N / 2 ? x : x - N, y <= N / 2 ? y : y - N, z <= N / 2 ? z : z - N};
     const long long k2 = (long long) kpos[0] * kpos[0] + (long long) kpos[1] * kpos[1] + (long long) kpos[2] * kpos[2];
     double2 v = spec[ip];
-    if(k2 == 0) {
-        if(zero_mode)
+    if(k2 == 0 && zero_mode != 2) { /* 2: the k2 = 0 mode takes its factor T[0] like every other (uvbg.cpp's divide_by_ncell) */
+        if(zero_mode == 1)
             spec[ip] = make_double2(0.0, 0.0);
         return;
     }

@@ -366,6 +366,12 @@ def test_pm_apply_other_petapm_clients(ctx, N):
     e = spec * T[k2]
     e[~nz] = 0
     check(0, 0, 1, T, e)
+    # uvbg.cpp:211-250: the real-space top-hat filter in k R (untouched below k R = 1e-4, so also at k2 = 0) times divide_by_ncell on EVERY mode
+    R = 0.9
+    kR = np.sqrt(k2i) * 2 * np.pi / L * R
+    with np.errstate(divide="ignore", invalid="ignore"):
+        T = np.where(kR > 1e-4, 3.0 * (np.sin(kR) / kR**3 - np.cos(kR) / kR**2), 1.0) / N**3
+    check(0, 0, 2, T, spec * T[k2])
     # force_z_transfer: fac = -diff_kernel(kz 2 pi / N) N / L, value -> i fac value (every mode; k2 = 0 has kz = 0: fac = 0 either way)
     T = np.full(len(k2i), -(N / L))
     w = kz * (2 * np.pi / N)
