@@ -515,7 +515,8 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
  * group walk; the sum runs in a different order (rounding-level differences). */
 #define HW_STACK 1024
 #define HW_SOFT 512   /* above this fill the walk goes depth-first, one node per round: at most 7 more per tree level */
-#define HW_CAND 640   /* < 64 pending + <= 64 x 8 queued per node round */
+#define HW_UNR 4      /* candidates per lane and candidate round (round 4): the round's gathers are independent loads in flight together */
+#define HW_CAND (64 * HW_UNR + 64 * 8 + 64) /* < 64 HW_UNR pending + <= 64 x 8 queued per node round */
 #define HW_LDS ((HW_STACK + HW_CAND) * 4)
 
 #define HW_ABORT 16384 /* candidates after which a wave gives its target up to a whole workgroup (heavy_block) */
@@ -535,21 +536,37 @@ __device__ __forceinline__ unsigned int heavy_walk(const SphDev &a, char *lds_wa
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for(;;) {
-        if(nc >= 64 || (S == 0 && nc > 0)) {
-            /* candidate round */
-            const int m = nc < 64 ? nc : 64;
-            if(lane < m) {
-                const int s = cq[(chead + lane) % HW_CAND];
-                const double4 q = a.posm_leaf[s];
-                const int fl = a.flag_leaf[s];
-                const double hj = SYM ? a.hsml_leaf[s] : 0.0;
-                if(!(fl & 1)) {
-                    nint++;
-                    const double d0 = wrapd(px - q.x, a.Box, a.invBox), d1 = wrapd(py - q.y, a.Box, a.invBox), d2 = wrapd(pz - q.z, a.Box, a.invBox);
-                    if(accept(d0 * d0 + d1 * d1 + d2 * d2, hj, fl))
-                        pair(s);
+        if(nc >= 64 * HW_UNR || (S == 0 && nc > 0)) {
+            /* candidate round: up to HW_UNR candidates per lane, their records requested together (a round used to be one dependent
+             * gather of 64 records: a target with 10^4 candidates spent its time waiting for 160 of them, one after the other) */
+            const int m = nc < 64 * HW_UNR ? nc : 64 * HW_UNR;
+            int sj[HW_UNR], flj[HW_UNR];
+            double4 qj[HW_UNR];
+            double hjj[HW_UNR];
+#pragma unroll
+            for(int j = 0; j < HW_UNR; j++) {
+                const int idx = lane + 64 * j;
+                sj[j] = -1;
+                flj[j] = 1;
+                qj[j] = make_double4(0, 0, 0, 0);
+                hjj[j] = 0.0;
+                if(idx < m) {
+                    const int s = cq[(chead + idx) % HW_CAND];
+                    sj[j] = s;
+                    qj[j] = a.posm_leaf[s];
+                    flj[j] = a.flag_leaf[s];
+                    hjj[j] = SYM ? a.hsml_leaf[s] : 0.0;
                 }
             }
+#pragma unroll
+            for(int j = 0; j < HW_UNR; j++)
+                if(sj[j] >= 0 && !(flj[j] & 1)) {
+                    nint++;
+                    const double4 q = qj[j];
+                    const double d0 = wrapd(px - q.x, a.Box, a.invBox), d1 = wrapd(py - q.y, a.Box, a.invBox), d2 = wrapd(pz - q.z, a.Box, a.invBox);
+                    if(accept(d0 * d0 + d1 * d1 + d2 * d2, hjj[j], flj[j]))
+                        pair(sj[j]);
+                }
             chead = (chead + m) % HW_CAND;
             nc -= m;
             done += m;
@@ -640,7 +657,8 @@ __device__ __forceinline__ double wave_sum(double v)
 #define HB_WAVES (HB_THREADS / 64)
 #define HB_STACK 8192
 #define HB_SOFT 4096
-#define HB_CAND (HB_THREADS * 9)
+#define HB_UNR 4 /* candidates per thread and candidate round, as HW_UNR */
+#define HB_CAND (HB_THREADS * (8 + HB_UNR) + HB_THREADS)
 
 struct HbShared {
     int stk[HB_STACK];
@@ -715,20 +733,35 @@ __device__ __forceinline__ unsigned int heavy_block(const SphDev &a, HbShared &s
         __syncthreads();
         const int S = sh.S, nc = sh.nc, chead = sh.chead;
         __syncthreads();
-        if(nc >= HB_THREADS || (S == 0 && nc > 0)) {
-            const int m = nc < HB_THREADS ? nc : HB_THREADS;
-            if(tid < m) {
-                const int s = sh.cq[(chead + tid) % HB_CAND];
-                const double4 q = a.posm_leaf[s];
-                const int fl = a.flag_leaf[s];
-                const double hj = SYM ? a.hsml_leaf[s] : 0.0;
-                if(!(fl & 1)) {
-                    nint++;
-                    const double d0 = wrapd(px - q.x, a.Box, a.invBox), d1 = wrapd(py - q.y, a.Box, a.invBox), d2 = wrapd(pz - q.z, a.Box, a.invBox);
-                    if(accept(d0 * d0 + d1 * d1 + d2 * d2, hj, fl))
-                        pair(s);
+        if(nc >= HB_THREADS * HB_UNR || (S == 0 && nc > 0)) {
+            const int m = nc < HB_THREADS * HB_UNR ? nc : HB_THREADS * HB_UNR;
+            int sj[HB_UNR], flj[HB_UNR];
+            double4 qj[HB_UNR];
+            double hjj[HB_UNR];
+#pragma unroll
+            for(int j = 0; j < HB_UNR; j++) {
+                const int idx = tid + HB_THREADS * j;
+                sj[j] = -1;
+                flj[j] = 1;
+                qj[j] = make_double4(0, 0, 0, 0);
+                hjj[j] = 0.0;
+                if(idx < m) {
+                    const int s = sh.cq[(chead + idx) % HB_CAND];
+                    sj[j] = s;
+                    qj[j] = a.posm_leaf[s];
+                    flj[j] = a.flag_leaf[s];
+                    hjj[j] = SYM ? a.hsml_leaf[s] : 0.0;
                 }
             }
+#pragma unroll
+            for(int j = 0; j < HB_UNR; j++)
+                if(sj[j] >= 0 && !(flj[j] & 1)) {
+                    nint++;
+                    const double4 q = qj[j];
+                    const double d0 = wrapd(px - q.x, a.Box, a.invBox), d1 = wrapd(py - q.y, a.Box, a.invBox), d2 = wrapd(pz - q.z, a.Box, a.invBox);
+                    if(accept(d0 * d0 + d1 * d1 + d2 * d2, hjj[j], flj[j]))
+                        pair(sj[j]);
+                }
             if(tid == 0) {
                 sh.chead = (chead + m) % HB_CAND;
                 sh.nc = nc - m;
