@@ -1226,6 +1226,12 @@ int shq_pm_slab_readout(shq_context *ctx, const shq_pm_params *pm, int plane0, i
 int shq_pm_slab_pitch(int Nmesh);
 int shq_pm_slab2_deposit(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, int xoff, int nalloc,
                          void *d_mesh_i64);
+/* slab2_deposit with `nghost` (1 or 2) planes behind the slab open to the deposit: 2 when the slab also holds the particles of part
+ * of its right-hand neighbour's first plane (slabs cut below the plane so that a plane through a cluster's core can be shared:
+ * the reference balances at top-leaf granularity, domain.cpp:620-700); slab2_readout then wants 2 + 4 ghost planes (nalloc =
+ * nplanes + 6), which its (xoff, nalloc) arguments already express. */
+int shq_pm_slab2_deposit_ghosts(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, int xoff, int nalloc, int nghost,
+                                void *d_mesh_i64);
 int shq_pm_slab2_fft_yz(shq_context *ctx, int Nmesh, void *d_planes, int nplanes, int direction);
 /* the same with the pack / unpack of the mesh transposes fused into the Y pass: direction 0 stores the (y, z) spectrum of the planes
  * into d_packed = [nranks][nplanes][Nmesh / nranks][pitch / 2] complex (rows [destination rank][x plane]: the send buffer of the

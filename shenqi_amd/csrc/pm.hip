@@ -949,8 +949,10 @@ extern "C" int shq_pm_slab_green(shq_context *ctx, const shq_pm_params *pm, int 
  * ghost plane and three potential ghost planes behind; 0 for a single rank, nalloc = N). */
 extern "C" int shq_pm_slab_pitch(int Nmesh) { return shq_fft3d_supported(Nmesh) ? shq_fft3d_pitch(Nmesh) : 0; }
 
-extern "C" int shq_pm_slab2_deposit(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, int xoff, int nalloc,
-                                    void *d_mesh_i64)
+/* nghost: planes behind the slab's own that its particles may deposit into — 1 (the CIC neighbour plane of the last own plane),
+ * or 2 when the slab also holds particles of the first plane of its right-hand neighbour (dist.py, slabs cut below the plane) */
+extern "C" int shq_pm_slab2_deposit_ghosts(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, int xoff, int nalloc,
+                                           int nghost, void *d_mesh_i64)
 {
     if(ctx)
         SHQ_TRY(shq_join_pm(ctx));
@@ -958,7 +960,8 @@ extern "C" int shq_pm_slab2_deposit(shq_context *ctx, const shq_pm_params *pm, i
     SHQ_CHECK(ctx->have_parts, SHQ_ERR_STATE, "pm_slab2_deposit: particles must be uploaded first");
     const int N = pm->Nmesh;
     SHQ_CHECK(shq_fft3d_supported(N), SHQ_ERR_INVALID, "pm_slab2: mesh size %d has no bespoke FFT", N);
-    SHQ_CHECK(nplanes > 0 && nplanes <= N && plane0 >= 0 && plane0 < N && xoff >= 0 && xoff + nplanes <= nalloc && nalloc <= N + 5,
+    SHQ_CHECK(nplanes > 0 && nplanes <= N && plane0 >= 0 && plane0 < N && xoff >= 0 && xoff + nplanes <= nalloc && nalloc <= N + 8 &&
+                  nghost >= 1 && nghost <= 2,
               SHQ_ERR_INVALID, "bad slab geometry");
     SHQ_HIP(hipSetDevice(ctx->device));
     SHQ_TRY(slab_sinctab(ctx, N));
@@ -967,8 +970,8 @@ extern "C" int shq_pm_slab2_deposit(shq_context *ctx, const shq_pm_params *pm, i
     const size_t cnt = (size_t) nalloc * N * zp;
     pm_zero_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>((unsigned long long *) d_mesh_i64, cnt);
     const long long n = ctx->nlocal;
-    /* buffer plane of mesh plane ix: (ix - (plane0 - xoff)) mod N; own planes and the right ghost must fit */
-    const int nfit = nplanes == N ? N : xoff + nplanes + 1;
+    /* buffer plane of mesh plane ix: (ix - (plane0 - xoff)) mod N; own planes and the right ghost(s) must fit */
+    const int nfit = nplanes == N ? N : xoff + nplanes + nghost;
     SHQ_CHECK(nfit <= nalloc, SHQ_ERR_INVALID, "pm_slab2_deposit: no room for the deposit ghost plane");
     if(n > 0)
         pm_deposit_kernel<<<dim3((unsigned) ((n + DEP_CHUNK - 1) / DEP_CHUNK)), dim3(256), 0, ctx->stream>>>(
@@ -976,6 +979,12 @@ extern "C" int shq_pm_slab2_deposit(shq_context *ctx, const shq_pm_params *pm, i
             plane0 - xoff, nfit, ctx->pm_oob.ptr, pm_xcdk(1));
     SHQ_HIP(hipGetLastError());
     return check_oob(ctx, "pm_slab2_deposit");
+}
+
+extern "C" int shq_pm_slab2_deposit(shq_context *ctx, const shq_pm_params *pm, int plane0, int nplanes, int xoff, int nalloc,
+                                    void *d_mesh_i64)
+{
+    return shq_pm_slab2_deposit_ghosts(ctx, pm, plane0, nplanes, xoff, nalloc, 1, d_mesh_i64);
 }
 
 /* direction 0: int64 deposit planes -> (y, z) half spectrum (Z forward, Y forward); 1: back to real space.

@@ -169,11 +169,16 @@ class Comm:
 class SlabDecomp:
     """x-slabs of the box = runs of mesh planes, one per rank.  `bounds` (P+1 plane indices, 0 ... Nmesh)
     may be unequal: balanced_bounds() picks them so that every rank owns about the same number of
-    particles (the reference balances work through its Peano top-leaf assignment, domain.cpp:620)."""
+    particles (the reference balances work through its Peano top-leaf assignment, domain.cpp:620).
+    `ycuts` (P+1 lengths, the first and last 0) refine a boundary below the plane: the particles of plane bounds[r] with
+    y < ycuts[r] belong to rank r - 1 (its walk targets, its deposit and readout) while the MESH plane stays rank r's —
+    a plane through the core of a cluster carries several per cent of all the work, more than the share of a rank at 64
+    ranks.  The left rank then deposits into two planes of its right neighbour instead of one and reads four of its
+    potential planes instead of three (dep_ghosts, pot_right)."""
 
     MIN_PLANES = 3   # the readout needs 3 planes from the right neighbour and 2 from the left
 
-    def __init__(self, comm, Nmesh, BoxSize, bounds=None):
+    def __init__(self, comm, Nmesh, BoxSize, bounds=None, ycuts=None):
         P = comm.size
         if bounds is None:
             if Nmesh % P != 0:
@@ -182,56 +187,101 @@ class SlabDecomp:
         bounds = [int(b) for b in bounds]
         if len(bounds) != P + 1 or bounds[0] != 0 or bounds[-1] != Nmesh:
             raise ValueError("bounds must run from 0 to Nmesh with one entry per rank + 1")
+        ycuts = [0.0] * (P + 1) if ycuts is None else [float(c) for c in ycuts]
+        if len(ycuts) != P + 1 or ycuts[0] != 0.0 or ycuts[-1] != 0.0 or min(ycuts) < 0.0 or max(ycuts) > BoxSize:
+            raise ValueError("ycuts must hold one length in [0, BoxSize] per boundary, none at the box's own edge")
+        self.split = max(ycuts) > 0.0
+        self.dep_ghosts, self.pot_right = (2, 4) if self.split else (1, 3)
+        self.min_planes = self.MIN_PLANES + (1 if self.split else 0)
         widths = [bounds[r + 1] - bounds[r] for r in range(P)]
-        if P > 1 and min(widths) < self.MIN_PLANES:
-            raise ValueError("every slab needs at least %d mesh planes (got %s)" % (self.MIN_PLANES, widths))
+        if P > 1 and min(widths) < self.min_planes:
+            raise ValueError("every slab needs at least %d mesh planes (got %s)" % (self.min_planes, widths))
         if Nmesh % P != 0:
             raise ValueError("Nmesh %d must be divisible by the number of ranks %d (equal y-slabs of the spectrum)" % (Nmesh, P))
-        self.comm, self.N, self.L, self.bounds, self.widths = comm, Nmesh, BoxSize, bounds, widths
+        self.comm, self.N, self.L, self.bounds, self.widths, self.ycuts = comm, Nmesh, BoxSize, bounds, widths, ycuts
         self.cell = BoxSize / Nmesh
         self.nxl = widths[comm.rank]
         self.plane0 = bounds[comm.rank]
-        self.x0 = self.plane0 * self.cell
-        self.x1 = bounds[comm.rank + 1] * self.cell
+        self.x0, self.x1 = self.slab_range(comm.rank)
 
-    def owner_of(self, x):
-        """rank owning positions x (tensor), by the mesh plane of the CIC base cell (floor(x / cell))."""
+    def owner_of(self, x, y=None):
+        """rank owning positions x (tensor), by the mesh plane of the CIC base cell (floor(x / cell)); with sub-plane cuts
+        the y coordinates decide inside a boundary plane."""
         plane = torch.floor(x / self.cell).to(torch.int64) % self.N
         inner = torch.tensor(self.bounds[1:-1], dtype=torch.int64, device=x.device)
-        return torch.searchsorted(inner, plane, right=True)
+        owner = torch.searchsorted(inner, plane, right=True)
+        if self.split:
+            if y is None:
+                raise ValueError("this decomposition cuts planes by y: owner_of needs the y coordinates")
+            first = torch.tensor(self.bounds[:-1], dtype=torch.int64, device=x.device)[owner]
+            cut = torch.tensor(self.ycuts[:-1], dtype=y.dtype, device=x.device)[owner]
+            owner = owner - ((plane == first) & (y < cut)).to(owner.dtype)
+        return owner
 
     def slab_range(self, r):
-        return self.bounds[r] * self.cell, self.bounds[r + 1] * self.cell
+        """x extent of what rank r owns: its planes, and the boundary plane behind them when part of that is its own too"""
+        return self.bounds[r] * self.cell, (self.bounds[r + 1] + (1 if self.ycuts[r + 1] > 0.0 else 0)) * self.cell
 
 
-def balanced_bounds(comm, Nmesh, BoxSize, x, weights=None, plane_cost=0.0):
+def balanced_bounds(comm, Nmesh, BoxSize, x, weights=None, plane_cost=0.0, y=None):
     """Plane boundaries giving every rank about the same share of the work (x: positions held by this rank, any
     distribution).  Work of a plane = the sum of `weights` over its particles (1 each when None: equal counts) +
     `plane_cost` (what a mesh plane costs whoever owns it, in the units of the weights).  One all-reduce of an
-    Nmesh-long histogram."""
+    Nmesh-long histogram.
+    With y (the same particles' y coordinates) the cut is refined below the plane and (bounds, ycuts) come back for
+    SlabDecomp: the plane in which a rank's share ends goes to the right-hand rank as a mesh plane, and its particles
+    with y < ycut — a whole number of mesh cells — to the left-hand one, so that the shares meet to within one row of
+    cells instead of one plane.  A second all-reduce, of the cut planes' y histograms."""
     P = comm.size
     cell = BoxSize / Nmesh
     plane = (torch.floor(x / cell).to(torch.int64) % Nmesh).cpu()
     w = None if weights is None else torch.as_tensor(weights).to(torch.float64).cpu()
-    hist = torch.bincount(plane, weights=w, minlength=Nmesh).to(torch.float64)
-    if P > 1:
-        h = hist.cuda() if comm.backend == "nccl" else hist
-        dist.all_reduce(h, group=comm.group)
-        hist = h.cpu()
+
+    def allsum(h):
+        if P > 1:
+            g = h.cuda() if comm.backend == "nccl" else h
+            dist.all_reduce(g, group=comm.group)
+            h = g.cpu()
+        return h
+
+    hist = allsum(torch.bincount(plane, weights=w, minlength=Nmesh).to(torch.float64))
     cum = torch.cumsum(hist + float(plane_cost), 0).numpy()
     total = cum[-1]
-    bounds = [0]
+    minp = SlabDecomp.MIN_PLANES + (0 if y is None else 1)
+    bounds, want = [0], [0.0]
     for r in range(1, P):
         target = total * r / P
         i = int(np.searchsorted(cum, target, side="left"))          # first plane whose cumulated work reaches the target
-        # cut before or after that plane, whichever leaves the left ranks closer to their share (a plane through the
-        # cluster's core carries several per cent of the work)
-        b = i if (i > 0 and target - cum[i - 1] < cum[min(i, Nmesh - 1)] - target) else i + 1
-        b = max(b, bounds[-1] + SlabDecomp.MIN_PLANES)
-        b = min(b, Nmesh - SlabDecomp.MIN_PLANES * (P - r))
-        bounds.append(b)
+        if y is None:
+            # cut before or after that plane, whichever leaves the left ranks closer to their share (a plane through the
+            # cluster's core carries several per cent of the work)
+            b = i if (i > 0 and target - cum[i - 1] < cum[min(i, Nmesh - 1)] - target) else i + 1
+        else:
+            b = min(i, Nmesh - 1)                                     # the share ends inside plane i: cut that plane
+        lo, hi = bounds[-1] + minp, Nmesh - minp * (P - r)
+        want.append(target - (cum[b - 1] if b > 0 else 0.0) if lo <= b <= hi and y is not None else 0.0)
+        bounds.append(min(max(b, lo), hi))
     bounds.append(Nmesh)
-    return bounds
+    if y is None:
+        return bounds
+    # the particles of the cut planes by their row of cells in y
+    row = (torch.floor(y / cell).to(torch.int64) % Nmesh).cpu()
+    yh = torch.zeros((P - 1, Nmesh), dtype=torch.float64)
+    for r in range(1, P):
+        sel = plane == bounds[r]
+        yh[r - 1] = torch.bincount(row[sel], weights=None if w is None else w[sel], minlength=Nmesh).to(torch.float64)
+    yh = allsum(yh).numpy() if P > 1 else yh.numpy()
+    ycuts = [0.0]
+    for r in range(1, P):
+        cy = np.cumsum(yh[r - 1])
+        k = int(np.searchsorted(cy, want[r], side="left"))            # rows 0 .. k reach the share
+        if want[r] <= 0.0:
+            k = 0
+        elif k < Nmesh and want[r] - (cy[k - 1] if k > 0 else 0.0) >= cy[k] - want[r]:
+            k = k + 1                                                 # with row k the left rank comes closer to its share
+        ycuts.append(k * cell)
+    ycuts.append(0.0)
+    return bounds, ycuts
 
 
 # Cost model of one force step on an MI355X, from the one-GPU bench (DESIGN §5): the walk takes 39.5 ms for 8.5e9 interactions,
@@ -241,22 +291,22 @@ COST_MS_PER_PARTICLE = 4.2 / 16777216
 COST_MS_PER_CELL = 7.9 / 768.0**3
 
 
-def cost_balanced_bounds(comm, drv):
+def cost_balanced_bounds(comm, drv, subplane=False):
     """Slab boundaries that even out the measured work instead of the particle count: every local particle weighs its
     interaction count of the last walk (plus its deposit / readout), every mesh plane its share of the (y, z) passes.
     The reference balances its domains the same way, by the work counted in the previous step (domain.cpp:620-700,
-    GravCost).  Call after a drv.step(); all ranks get the same list."""
+    GravCost).  Call after a drv.step(); all ranks get the same list — with subplane the pair (bounds, ycuts)."""
     n = int(drv.allp.shape[0])
     nint = np.zeros(n, dtype=np.int64)
     capi.check(capi.hip.shq_grav_short_download(drv.ctx.h, None, None, capi.ptr(nint), None))
     w = COST_MS_PER_INTERACTION * nint[: drv.nloc].astype(np.float64) + COST_MS_PER_PARTICLE
     return balanced_bounds(comm, drv.N, drv.L, drv.local[:, 0], weights=torch.from_numpy(w),
-                           plane_cost=COST_MS_PER_CELL * float(drv.N) ** 2)
+                           plane_cost=COST_MS_PER_CELL * float(drv.N) ** 2, y=drv.local[:, 1] if subplane else None)
 
 
 def exchange_to_owner(comm, decomp, posm):
     """Domain exchange: send every particle (rows x, y, z, m) to the rank owning its slab."""
-    owner = decomp.owner_of(posm[:, 0])
+    owner = decomp.owner_of(posm[:, 0], posm[:, 1])
     order = torch.argsort(owner, stable=True)
     counts = torch.bincount(owner, minlength=comm.size).tolist()
     recv, _ = comm.all_to_all_rows(posm[order], counts)
@@ -290,10 +340,10 @@ def ghost_exchange(comm, decomp, posm, halo):
 class SlabPM:
     """Distributed PM force for the particles this rank owns."""
 
-    def __init__(self, comm, Nmesh, BoxSize, Asmth, G, ops, bounds=None):
+    def __init__(self, comm, Nmesh, BoxSize, Asmth, G, ops, bounds=None, ycuts=None):
         self.comm, self.ops = comm, ops
         self.N, self.L, self.Asmth, self.G = Nmesh, BoxSize, Asmth, G
-        self.d = SlabDecomp(comm, Nmesh, BoxSize, bounds)
+        self.d = SlabDecomp(comm, Nmesh, BoxSize, bounds, ycuts)
 
     def force(self, hooks=()):
         """Runs one PM step for the particles loaded in `ops`; results stay in ops (gravpm, potential).
@@ -316,12 +366,13 @@ class SlabPM:
         zp = ops.pitch()
         zpc = zp // 2
         multi = c.multi   # SHQ_COMM_FORCE: one rank keeps its periodic geometry but still runs the transposes as collectives
-        xoff, nalloc = (0, N) if P == 1 else (2, nxl + 5)
+        dg, pr = self.d.dep_ghosts, self.d.pot_right     # deposit ghost planes behind the slab, potential planes read from there
+        xoff, nalloc = (0, N) if P == 1 else (2, nxl + 2 + pr)
         buf = ops.mesh_buffer(nalloc, N, zp)                               # int64 [nalloc, N, zp]
-        ops.deposit2(buf, self.d.plane0, nxl, xoff, nalloc)
+        ops.deposit2(buf, self.d.plane0, nxl, xoff, nalloc, dg)
         if P > 1:
-            ghost = c.shift(buf[xoff + nxl:xoff + nxl + 1].contiguous(), +1)
-            buf[xoff:xoff + 1] += ghost
+            ghost = c.shift(buf[xoff + nxl:xoff + nxl + dg].contiguous(), +1)
+            buf[xoff:xoff + dg] += ghost
         own = buf[xoff:xoff + nxl]
         nyl = N // P
         # the pack / unpack around the transposes: fused into the Y pass of the FFT (SHQ_DIST_FUSED_PACK=0: torch permute copies)
@@ -363,7 +414,7 @@ class SlabPM:
         phi = buf.view(torch.float64)
         if P > 1:
             phi[0:2] = c.shift(phi[xoff + nxl - 2:xoff + nxl].contiguous(), +1)    # my last 2 -> right rank's left ghosts
-            phi[xoff + nxl:xoff + nxl + 3] = c.shift(phi[xoff:xoff + 3].contiguous(), -1)  # my first 3 -> left rank's right ghosts
+            phi[xoff + nxl:xoff + nxl + pr] = c.shift(phi[xoff:xoff + pr].contiguous(), -1)  # my first 3 (4) -> left rank's right ghosts
         ops.readout2(phi, self.d.plane0, nxl, xoff, nalloc)
 
     def _force_torch(self):
@@ -373,10 +424,11 @@ class SlabPM:
         Nc = N // 2 + 1
         widths = self.d.widths
         # 1. deposit + ghost plane to the right neighbour (integer add)
-        mesh_i = self.ops.deposit(self.d.plane0, nxl)                 # int64 [nxl(+1), N, N+2]
+        dg, pr = self.d.dep_ghosts, self.d.pot_right
+        mesh_i = self.ops.deposit(self.d.plane0, nxl, dg)             # int64 [nxl(+dg), N, N+2]
         if P > 1:
-            ghost = c.shift(mesh_i[nxl:nxl + 1], +1)
-            mesh_i[0:1] += ghost
+            ghost = c.shift(mesh_i[nxl:nxl + dg].contiguous(), +1)
+            mesh_i[0:dg] += ghost
         real = self.ops.to_real(mesh_i[:nxl])                          # f64 [nxl, N, N+2]
         # 2. forward: 2-D r2c over (y, z), transpose (x-slabs -> equal y-slabs), 1-D along x
         spec = torch.fft.rfft2(real[..., :N], dim=(1, 2))              # [nxl, N, Nc], unscaled
@@ -395,14 +447,14 @@ class SlabPM:
         phi = torch.fft.irfft2(spec, s=(N, N), dim=(1, 2), norm="forward")                   # [nxl, N, N], unscaled
         # 5. potential ghost planes (2 from the left neighbour, 3 from the right) and readout
         if P > 1:
-            ext = self.ops.empty((nxl + 5, N, N + 2), torch.float64)
+            ext = self.ops.empty((nxl + 2 + pr, N, N + 2), torch.float64)
             ext[2:2 + nxl, :, :N] = phi
             ext[0:2, :, :N] = c.shift(phi[nxl - 2:nxl].contiguous(), +1)          # my last 2 -> right rank's left ghosts
-            ext[2 + nxl:, :, :N] = c.shift(phi[0:3].contiguous(), -1)             # my first 3 -> left rank's right ghosts
+            ext[2 + nxl:, :, :N] = c.shift(phi[0:pr].contiguous(), -1)            # my first 3 (4) -> left rank's right ghosts
         else:
             ext = self.ops.empty((N, N, N + 2), torch.float64)
             ext[:, :, :N] = phi
-        self.ops.readout(ext, self.d.plane0, nxl)
+        self.ops.readout(ext, self.d.plane0, nxl, pr)
 
 
 class GpuOps:
@@ -458,8 +510,8 @@ class GpuOps:
         capi.check(fn(self.ctx.h, *args))
         self._after()
 
-    def deposit2(self, buf, plane0, nxl, xoff, nalloc):
-        self._call(capi.hip.shq_pm_slab2_deposit, C.byref(self.pm), plane0, nxl, xoff, nalloc, C.c_void_p(buf.data_ptr()))
+    def deposit2(self, buf, plane0, nxl, xoff, nalloc, ghosts=1):
+        self._call(capi.hip.shq_pm_slab2_deposit_ghosts, C.byref(self.pm), plane0, nxl, xoff, nalloc, ghosts, C.c_void_p(buf.data_ptr()))
 
     def fft_yz(self, planes, nplanes, direction):
         assert planes.is_contiguous()
@@ -494,7 +546,9 @@ class GpuOps:
         capi.check(capi.hip.shq_pm_set_deposit_log2scale(self.ctx.h, e))
         self.log2scale = e
 
-    def deposit(self, plane0, nxl):
+    def deposit(self, plane0, nxl, ghosts=1):
+        if ghosts != 1:
+            raise NotImplementedError("slabs cut below the plane need a mesh size with a bespoke transform (shq_pm_slab2_*)")
         nalloc = nxl if nxl == self.N else nxl + 1
         mesh = torch.empty((nalloc, self.N, self.N + 2), dtype=torch.int64, device=self.device)
         self._call(capi.hip.shq_pm_slab_deposit, C.byref(self.pm), plane0, nxl, C.c_void_p(mesh.data_ptr()))
@@ -507,8 +561,8 @@ class GpuOps:
         assert spec_t.is_contiguous() and spec_t.dtype == torch.complex128
         self._call(capi.hip.shq_pm_slab_green, C.byref(self.pm), y0, nyl, C.c_void_p(spec_t.data_ptr()))
 
-    def readout(self, ext, plane0, nxl):
-        assert ext.is_contiguous()
+    def readout(self, ext, plane0, nxl, pot_right=3):
+        assert ext.is_contiguous() and pot_right == 3
         self._call(capi.hip.shq_pm_slab_readout, C.byref(self.pm), plane0, nxl, C.c_void_p(ext.data_ptr()))
 
     def results(self, nlocal):
@@ -521,13 +575,13 @@ class GpuOps:
 class DistTreePM:
     """One rank of the sharded TreePM force: PM over x-slabs + tree walk over local + ghost particles."""
 
-    def __init__(self, comm, ctx, Nmesh, BoxSize, Asmth, G, device, halo_factor=1.5, bounds=None):
+    def __init__(self, comm, ctx, Nmesh, BoxSize, Asmth, G, device, halo_factor=1.5, bounds=None, ycuts=None):
         import shenqi_amd as sq
         self.sq = sq
         self.comm, self.ctx, self.device = comm, ctx, device
         self.N, self.L, self.Asmth, self.G = Nmesh, BoxSize, Asmth, G
         self.ops = GpuOps(ctx, Nmesh, BoxSize, Asmth, G, device)
-        self.pm = SlabPM(comm, Nmesh, BoxSize, Asmth, G, self.ops, bounds)
+        self.pm = SlabPM(comm, Nmesh, BoxSize, Asmth, G, self.ops, bounds, ycuts)
         self.decomp = self.pm.d
         self.halo_factor = halo_factor
         self.tree = None

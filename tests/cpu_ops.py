@@ -30,9 +30,9 @@ class CpuOps:
         res = t - ic
         return ic % self.N, res, p[:, 3]
 
-    def deposit(self, plane0, nxl):
+    def deposit(self, plane0, nxl, ghosts=1):
         N = self.N
-        nalloc = nxl if nxl == N else nxl + 1
+        nalloc = nxl if nxl == N else nxl + ghosts
         mesh = np.zeros((nalloc, N, N + 2), dtype=np.int64)
         ic, res, m = self._cic()
         scale = 2.0 ** self.log2scale
@@ -71,9 +71,10 @@ class CpuOps:
         fac[k2 == 0] = 0.0
         a *= fac
 
-    def readout(self, ext, plane0, nxl):
+    def readout(self, ext, plane0, nxl, pot_right=3):
         N = self.N
         phi = ext.numpy()
+        assert nxl == N or phi.shape[0] == nxl + 2 + pot_right
         xshift = 0 if nxl == N else plane0 - 2
         ic, res, m = self._cic()
         ffac = -(N / self.L)

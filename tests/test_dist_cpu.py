@@ -43,21 +43,36 @@ def _worker(rank, world, initfile, outdir, balanced):
         comm = sd.Comm()
         posm_g = _global_particles()
         mine = torch.from_numpy(posm_g[rank::world].copy())          # any initial distribution
-        bounds = sd.balanced_bounds(comm, NMESH, BOX, mine[:, 0]) if balanced else None
-        decomp = sd.SlabDecomp(comm, NMESH, BOX, bounds)
+        bounds, ycuts = None, None
+        if balanced == "split":       # boundaries cut below the plane: a plane's particles shared by y, its mesh plane not
+            bounds, ycuts = sd.balanced_bounds(comm, NMESH, BOX, mine[:, 0], y=mine[:, 1])
+            assert max(ycuts) > 0
+        elif balanced:
+            bounds = sd.balanced_bounds(comm, NMESH, BOX, mine[:, 0])
+        decomp = sd.SlabDecomp(comm, NMESH, BOX, bounds, ycuts)
         local = sd.exchange_to_owner(comm, decomp, mine)
         nloc = local.shape[0]
         total = comm.allreduce_sum(float(nloc))
         assert int(total) == NPART
         x = local[:, 0].numpy()
-        assert np.all((np.floor(x / (BOX / NMESH)) % NMESH >= decomp.plane0) & (np.floor(x / (BOX / NMESH)) % NMESH < decomp.plane0 + decomp.nxl))
-        if balanced:
+        pl = np.floor(x / (BOX / NMESH)) % NMESH
+        if balanced == "split":
+            yy = local[:, 1].numpy()
+            nxt = decomp.bounds[rank + 1] % NMESH
+            assert np.all(((pl >= decomp.plane0) & (pl < decomp.plane0 + decomp.nxl)) | ((pl == nxt) & (yy < decomp.ycuts[rank + 1])))
+            assert not np.any((pl == decomp.plane0) & (yy < decomp.ycuts[rank]))
+            assert np.any(pl == nxt) or rank == world - 1
+            # (how much closer to equal shares the cut by rows of cells comes: test_balanced_bounds_weighted_gloo — this
+            # set's cluster sits inside one cell)
+        else:
+            assert np.all((pl >= decomp.plane0) & (pl < decomp.plane0 + decomp.nxl))
+        if balanced and balanced != "split":
             assert nloc < 0.6 * NPART, (nloc, bounds)      # plane granularity limits the balance on this tiny mesh
         # ---- PM ----
         ops = CpuOps(NMESH, BOX, 1.5, G)
         ops.set_deposit_scale(comm.allreduce_sum(float(local[:, 3].sum())))
         ops.set_particles(local, nloc)
-        pm = sd.SlabPM(comm, NMESH, BOX, 1.5, G, ops, bounds)
+        pm = sd.SlabPM(comm, NMESH, BOX, 1.5, G, ops, bounds, ycuts)
         pm.force()
         gpm, ppot = ops.results(nloc)
         # ---- tree with imported ghosts ----
@@ -75,7 +90,7 @@ def _worker(rank, world, initfile, outdir, balanced):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,balanced", [(2, False), (4, False), (3, True), (4, True)])
+@pytest.mark.parametrize("world,balanced", [(2, False), (4, False), (3, True), (4, True), (2, "split"), (3, "split")])
 def test_slab_pm_and_ghost_tree_gloo(world, balanced):
     import orc
     import common as cm
@@ -143,6 +158,25 @@ def _weights_worker(rank, world, initfile):
         assert abs(bw[1] - N // 3) <= 2, bw      # 3 t = (3 / 2 + 1 / 2) / 2 -> t = 1 / 3 of the box
         # a plane cost that dwarfs the particle work brings back equal widths
         assert sd.balanced_bounds(comm, N, L, x, weights=w, plane_cost=1e9) == [0, N // 2, N]
+        # a sheet thinner than a plane (what a cluster's core is to a 1024 mesh): three quarters of everything in plane 40.
+        # Cut by planes, a rank gets the sheet or does not; cut by rows of cells inside the sheet's plane the shares meet.
+        xs = torch.cat([x[:5000], torch.from_numpy((40.5 + 0.1 * rng.standard_normal(15000)) * (L / N))])
+        ys = torch.from_numpy(rng.random(20000) * L)
+        bp = sd.balanced_bounds(comm, N, L, xs)
+        bs, yc = sd.balanced_bounds(comm, N, L, xs, y=ys)
+        assert bs[1] == 40 and yc[0] == 0 and yc[2] == 0 and 0.2 * L < yc[1] < 0.8 * L, (bs, yc)
+
+        def share(decomp):
+            own = decomp.owner_of(xs, ys)
+            return comm.allreduce_sum(float((own == 0).sum())) / 40000.0
+        plain, cut = share(sd.SlabDecomp(comm, N, L, bp)), share(sd.SlabDecomp(comm, N, L, bs, yc))
+        assert abs(plain - 0.5) > 0.2 and abs(cut - 0.5) < 0.01, (plain, cut)
+        # weights move the cut inside the plane too
+        wy = torch.where(ys < 0.25 * L, 5.0, 1.0)
+        _, ycw = sd.balanced_bounds(comm, N, L, xs, weights=wy, y=ys)
+        assert ycw[1] < yc[1] - 0.1 * L, (ycw, yc)
+        with pytest.raises(ValueError):
+            sd.SlabDecomp(comm, N, L, bs, yc).owner_of(xs)
     finally:
         dist.destroy_process_group()
 

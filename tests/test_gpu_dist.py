@@ -28,7 +28,7 @@ def _global_particles():
     return np.concatenate([pos, np.ones((NPART, 1))], axis=1)
 
 
-def _run_rank(rank, world, outdir):
+def _run_rank(rank, world, outdir, split=False):
     import shenqi_amd as sq
     from shenqi_amd import capi, dist as sd
     import common as cm
@@ -43,8 +43,14 @@ def _run_rank(rank, world, outdir):
     cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=0)
     gp = sq.make_grav_params(BOX, 1.5, NMESH, G, cm.RHO0)
     bounds = sd.balanced_bounds(comm, NMESH, BOX, mine[:, 0]) if world > 1 else None
-    drv = sd.DistTreePM(comm, ctx, NMESH, BOX, 1.5, G, dev, halo_factor=1.3, bounds=bounds)
+    # split: the first plane of rank 1 (the plane through the cluster) shared by y — its particles below 0.6 BOX are rank 0's
+    ycuts = [0.0, 0.6 * BOX, 0.0] if split else None
+    drv = sd.DistTreePM(comm, ctx, NMESH, BOX, 1.5, G, dev, halo_factor=1.3, bounds=bounds, ycuts=ycuts)
     local = sd.exchange_to_owner(comm, drv.decomp, mine)
+    if split:
+        pl = torch.floor(local[:, 0] / (BOX / NMESH)).to(torch.int64) % NMESH
+        shared = int(((pl == bounds[1]) & (local[:, 1] < ycuts[1])).sum()) if rank == 0 else int((pl == bounds[1]).sum())
+        assert shared > 100, (rank, shared, bounds)       # both ranks hold a good part of that plane
     drv.setup(local, gp.Rcut)
     drv.step(gp_bh)
     drv.step(gp)
@@ -53,7 +59,7 @@ def _run_rank(rank, world, outdir):
     ctx.close()
 
 
-def _worker(rank, world, initfile, outdir, backend="gloo"):
+def _worker(rank, world, initfile, outdir, backend="gloo", split=False):
     os.environ["OMP_NUM_THREADS"] = "2"
     if backend == "nccl":
         os.environ["SHQ_COMM_FORCE"] = "1"
@@ -64,7 +70,7 @@ def _worker(rank, world, initfile, outdir, backend="gloo"):
     else:
         dist.init_process_group(backend, init_method="file://" + initfile, rank=rank, world_size=world)
     try:
-        _run_rank(rank, world, outdir)
+        _run_rank(rank, world, outdir, split)
     finally:
         dist.destroy_process_group()
 
@@ -118,6 +124,20 @@ def test_dist_driver_two_gloo_ranks_one_gpu():
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker, args=(2, os.path.join(tmp, "init"), tmp), nprocs=2, join=True)
         _check(tmp, 2)
+
+
+def test_dist_driver_two_ranks_sharing_a_plane():
+    """slabs cut below the plane (SlabDecomp ycuts): rank 0 deposits into two planes of rank 1 and reads four of its potential
+    planes (shq_pm_slab2_deposit_ghosts, [nxl + 6] buffers).  Same oracle bounds as the plane-aligned run, and the PM force of
+    every particle has the plane-aligned run's bits: the mesh is a fixed-point sum, whoever deposits."""
+    with tempfile.TemporaryDirectory() as tmp, tempfile.TemporaryDirectory() as tmp2:
+        mp.spawn(_worker, args=(2, os.path.join(tmp, "init"), tmp, "gloo", True), nprocs=2, join=True)
+        _check(tmp, 2)
+        mp.spawn(_worker, args=(2, os.path.join(tmp2, "init"), tmp2), nprocs=2, join=True)
+        rows = [np.concatenate([np.load(os.path.join(t, "g%d.npy" % r)) for r in range(2)]) for t in (tmp, tmp2)]
+        assert len(np.load(os.path.join(tmp, "g0.npy"))) != len(np.load(os.path.join(tmp2, "g0.npy")))
+        a, b = [r[np.lexsort(r[:, :3].T)] for r in rows]
+        assert np.array_equal(a[:, :3], b[:, :3]) and np.array_equal(a[:, 7:11], b[:, 7:11])
 
 
 def test_dist_driver_one_rccl_rank_collectives_forced():
