@@ -557,15 +557,20 @@ def run_sharded(args, rank, local_rank, world):
     del posm
     drv.setup(local, gp_rel.Rcut)
     drv.step(gp_bh)
-    bounds_count = bounds
+    bounds_count, ycuts = bounds, None
     if os.environ.get("SHQ_BENCH_REBALANCE", "1") == "1":
         # like the reference's domain decomposition (domain.cpp:620-700), balance the work counted in the previous force
         # evaluation rather than the particle count: one relative-criterion step, new boundaries, particles to their new owners
         drv.step(gp_rel)
-        bounds = sd.cost_balanced_bounds(comm, drv)
-        if bounds != bounds_count:
+        # SHQ_BENCH_SUBPLANE=0: boundaries on whole planes; otherwise the plane a rank's share ends in is shared by y
+        # (the shared plane needs the slab entry points of the bespoke transforms: shq_pm_slab2_deposit_ghosts)
+        if os.environ.get("SHQ_BENCH_SUBPLANE", "1") == "1" and world > 1 and int(capi.hip.shq_pm_slab_pitch(nmesh)) > 0:
+            bounds, ycuts = sd.cost_balanced_bounds(comm, drv, subplane=True)
+        else:
+            bounds = sd.cost_balanced_bounds(comm, drv)
+        if bounds != bounds_count or ycuts is not None:
             local = drv.local
-            drv = sd.DistTreePM(comm, ctx, nmesh, L, 1.5, G, dev, halo_factor=1.5, bounds=bounds)
+            drv = sd.DistTreePM(comm, ctx, nmesh, L, 1.5, G, dev, halo_factor=1.5, bounds=bounds, ycuts=ycuts)
             local = sd.exchange_to_owner(comm, drv.decomp, local)
             drv.setup(local, gp_rel.Rcut)
             drv.step(gp_bh)
@@ -607,7 +612,8 @@ def run_sharded(args, rank, local_rank, world):
         "config": {"workload": "dm-only %d^3 TreePM sharded over %d x-slabs (S-%s, Nmesh %d, Asmth 1.5, Rcut 6, ErrTolForceAcc %g, "
                                "exact window), %.3g particles per GPU" % (n1, world, args.kind, nmesh, args.errtol, nglobal / world),
                    "particles_total": nglobal, "nmesh": nmesh, "parallelism": "x-slabs x%d, RCCL all-to-all + ghost exchange" % world,
-                   "slab_bounds": bounds, "slab_bounds_by_count": bounds_count, "walk": "exact (per-target reference opening decisions)"},
+                   "slab_bounds": bounds, "slab_ycuts": ycuts,
+                   "slab_bounds_by_count": bounds_count, "walk": "exact (per-target reference opening decisions)"},
         "roofline": {"bound": "valu-f64", "kernel": "grav_walk_exact_kernel (rank 0)",
                      "achieved": 45.0 * st.ninteractions / max(st.kernel_ms * 1e-3, 1e-12) / 1e12, "peak": FP64_VECTOR_PEAK_TF,
                      "unit": "TFLOP/s", "frac": 45.0 * st.ninteractions / max(st.kernel_ms * 1e-3, 1e-12) / 1e12 / FP64_VECTOR_PEAK_TF,

@@ -265,7 +265,7 @@ extern "C" void shq_shutdown(shq_context *ctx)
     for(auto &b : ctx->metal_val) b.release();
     ctx->metal_star.release(); ctx->metal_gd.release(); ctx->metal_gf.release();
     ctx->velp.release(); ctx->hydC.release(); ctx->hydD.release(); ctx->velp_leaf.release(); ctx->hydrec_leaf.release();
-    ctx->hsml_leaf.release(); ctx->flag_leaf.release();
+    ctx->hsml_leaf.release(); ctx->flag_leaf.release(); ctx->posf_leaf.release(); ctx->ngarb_leaf.release();
     ctx->s_numngb.release(); ctx->s_dhsmldens.release(); ctx->s_left.release(); ctx->s_right.release(); ctx->s_rot.release();
     ctx->s_gradrho.release(); ctx->s_evp_in.release(); ctx->s_todo.release(); ctx->s_queue2.release(); ctx->s_queue3.release();
     ctx->tb.release(); ctx->tree_targets.release(); ctx->ps_sums.release(); ctx->ps_bintab.release(); ctx->s_blockcount.release(); ctx->s_nlist.release(); ctx->s_ncount.release(); ctx->s_redo.release(); ctx->s_redo2.release(); ctx->s_counters.release(); ctx->pm_oob.release(); ctx->fft_tw.release();

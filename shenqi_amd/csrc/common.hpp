@@ -365,6 +365,8 @@ struct shq_context {
     DevBuf<double4> velp, hydC, hydD, velp_leaf;
     DevBuf<char> hydrec_leaf;  /* HydRec[] (sph.hip): 128-byte neighbour records for the hydro evaluation */
     DevBuf<double> hsml_leaf;
+    DevBuf<int32_t> ngarb_leaf;
+    DevBuf<float4> posf_leaf; /* (x, y, z) rounded to f32 and the f32 pre-test bound of the particle's own Hsml: sph.hip, ngb_walk PRE32 */
     DevBuf<int32_t> flag_leaf;
     DevBuf<double> s_numngb, s_dhsmldens, s_left, s_right, s_rot, s_gradrho, s_evp_in;
     DevBuf<int32_t> s_todo, s_queue2, s_queue3, s_blockcount;

@@ -118,12 +118,14 @@ __device__ __forceinline__ double pressure_predict(double eom, double evp)
 /* Everything the hydro pair evaluation needs of neighbour j besides its position, in ONE cache line:
  * five separate leaf-ordered arrays cost five line fetches per (lane, pair), and the evaluation kernel
  * is bound by exactly that L2 -> L1 traffic. */
+/* everything the hydro pair evaluation reads of a neighbour, in ONE 128-byte line (round 4: position and mass moved in, in the place of
+ * the padding and of the EntVarPred copy next to the velocity: eight 16-byte gathers per pair instead of ten — the evaluation kernel is
+ * bound by the texture addresser's cycles per gather instruction, not by arithmetic) */
 struct alignas(128) HydRec {
-    double4 velp; /* predicted velocity, EntVarPred */
+    double4 posm; /* x, y, z, mass */
+    double4 velh; /* predicted velocity, Hsml */
     double4 C;    /* EntVarPred, density_j, soundspeed_j, p_over_rho2_j */
     double4 D;    /* Dhsml_j, rr2_j, f2_j, dloga_for_bin_j */
-    double hsml;
-    double pad_[3];
 };
 static_assert(sizeof(HydRec) == 128, "HydRec must be one 128-byte line");
 
@@ -141,6 +143,8 @@ struct SphDev {
     const HydRec *hydrec_leaf;  /* one 128-byte line per neighbour for the hydro pair evaluation */
     const double *hsml_leaf;
     const int32_t *flag_leaf;   /* bit0 skip (garbage / not gas), bit1 wind-decoupled */
+    const float4 *posf_leaf;    /* f32 pre-test copy: x, y, z rounded; w = pre32_bound(Hsml); x = NaN: skip, x = inf: never accepted */
+    const int32_t *ngarb_leaf;  /* at a leaf's first slot: how many of its particles are to be skipped (x = NaN above) */
     /* per particle */
     const double4 *posm;
     const uint8_t *pflags;
@@ -221,10 +225,27 @@ __global__ void sph_predict_kernel(const PredArgs a)
     }
 }
 
+/* ---- the f32 pre-test of the candidate scan (round 4) ----------------------------------------------------------------
+ * The scan of a candidate tile tests ~2500 candidates per wave, of which a lane is interested in a tenth and accepts a
+ * twentieth, in f64: 3 subtractions, 3 multiply-adds and a compare at four cycles each.  On gfx950 the f32 VOP2 forms issue at
+ * twice that rate, and the decision does not have to be exact THERE: the lists may hold a superset as long as the evaluation
+ * applies the reference's own test to every entry (it recomputes r2 in f64 anyway).  So the scan runs on coordinates rounded
+ * to f32 (error <= 2^-24 |x| each, <= 2^-22 Box on a displacement with room to spare) against the bound
+ * (h + 2^-20 Box)^2 (1 + 2^-20) rounded up: r < h in f64 implies the f32 test passes.  For h / Box = 3e-3 (1024^3) the lists
+ * grow by 0.1 %.  Leaves whose displacements may need the periodic wrap keep the f64 scan (their tile does). */
+__device__ __forceinline__ float pre32_bound(double h, double eps)
+{
+    const double b = (h + eps) * (h + eps) * (1.0 + 0x1p-20);
+    float f = (float) b;
+    if((double) f < b)
+        f = __uint_as_float(__float_as_uint(f) + 1u); /* b > 0 and finite: the next float up */
+    return f;
+}
+
 __global__ void sph_gather_leaf_kernel(long long nleaf, const int32_t *pidx, const double4 *velp, const double4 *hydC,
                                        const double4 *hydD, const double *hsml, const uint8_t *pflags, const double *delay,
                                        double4 *velp_leaf, HydRec *hydrec_leaf, double *hsml_leaf,
-                                       int32_t *flag_leaf)
+                                       int32_t *flag_leaf, const double4 *posm_leaf = nullptr, float4 *posf_leaf = nullptr, double pre_eps = 0)
 {
     const long long s = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if(s >= nleaf)
@@ -233,11 +254,11 @@ __global__ void sph_gather_leaf_kernel(long long nleaf, const int32_t *pidx, con
     velp_leaf[s] = velp[p];
     if(hydrec_leaf) {
         HydRec r;
-        r.velp = velp[p];
+        const double4 v = velp[p];
+        r.posm = posm_leaf[s];
+        r.velh = make_double4(v.x, v.y, v.z, hsml[p]);
         r.C = hydC[p];
         r.D = hydD[p];
-        r.hsml = hsml[p];
-        r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
         hydrec_leaf[s] = r;
     }
     hsml_leaf[s] = hsml[p];
@@ -248,6 +269,31 @@ __global__ void sph_gather_leaf_kernel(long long nleaf, const int32_t *pidx, con
     if(delay && delay[p] > 0)
         o |= 2;
     flag_leaf[s] = o;
+    if(posf_leaf) {
+        const double4 q = posm_leaf[s];
+        float4 f = make_float4((float) q.x, (float) q.y, (float) q.z, pre32_bound(hsml[p], pre_eps));
+        if(o & 1)
+            f.x = __builtin_nanf("");             /* not a candidate at all */
+        else if(hydrec_leaf && (o & 2))
+            f.x = __builtin_inff();               /* hydro never accepts a wind-decoupled particle (it still counts as a candidate) */
+        posf_leaf[s] = f;
+    }
+}
+
+/* per leaf node: how many of its particles the scans pass over (flag bit 0), kept at the leaf's first slot: the f32 scan takes a
+ * leaf's candidate count from its node and subtracts this */
+__global__ void sph_leaf_ngarb_kernel(int npool, const NodeC *__restrict__ nodeC, const int32_t *__restrict__ flag_leaf, int32_t *ngarb_leaf)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= npool)
+        return;
+    const NodeC nc = nodeC[i];
+    if(nc.type != SHQ_PARTICLE_NODE_TYPE || nc.count <= 0)
+        return;
+    int ng = 0;
+    for(int j = 0; j < nc.count; j++)
+        ng += flag_leaf[nc.child + j] & 1;
+    ngarb_leaf[nc.child] = ng;
 }
 
 /* ---- density walk ------------------------------------------------------------------------------ */
@@ -293,6 +339,9 @@ template <class F> __device__ __forceinline__ void nl_flush(const int32_t *myl, 
  *   - accepted candidates go to the lane's list (see above) and are evaluated lane by lane.
  * Leaves are queued and tiles are scanned in walk order, so each lane still meets its neighbours in
  * depth-first order. */
+#ifndef SPH_PROBE
+#define SPH_PROBE 0 /* timing probes of the walk kernels (tools/sph_ab.sh with build_variant.sh): never in a shipped build */
+#endif
 #ifndef SPH_WALK_WPB
 #define SPH_WALK_WPB 1 /* waves per block of the walk-only kernels (MODE 1) */
 #endif
@@ -308,10 +357,13 @@ template <class F> __device__ __forceinline__ void nl_flush(const int32_t *myl, 
  * under the top-level nodes of its NodeList = the pre-order index ranges [start, sibling(start)); `seg` holds the (sorted)
  * packed start indices.  As in the gravity walk a lane waits at the start of its next branch and the wave cursor, which
  * still begins at the root, also descends wherever a lane waits further down. */
-template <bool SYM, bool KEEP, bool GHOSTS, class Accept, class Pair>
+/* PRE32: tiles none of whose leaves may need the periodic wrap are scanned with the f32 pre-test (pre32_bound above; thri = the
+ * target's own bound); `pair` must then apply the exact test itself. */
+template <bool SYM, bool KEEP, bool GHOSTS, bool PRE32 = false, class Accept, class Pair>
 __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave, int32_t *myl, const bool valid, const double px,
                                                  const double py, const double pz, const double h, Accept &&accept, Pair &&pair,
-                                                 unsigned int *dbg, int &fill, bool &ovf, const int4 seg = make_int4(-1, -1, -1, -1))
+                                                 unsigned int *dbg, int &fill, bool &ovf, const int4 seg = make_int4(-1, -1, -1, -1),
+                                                 const float thri = 0.f)
 {
     double4 *winB = reinterpret_cast<double4 *>(lds_wave);
     int4 *winC = reinterpret_cast<int4 *>(lds_wave + NW_WIN * 32);
@@ -329,6 +381,25 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
     fill = 0;
     ovf = false;
     int mynext = valid ? a.root : -2;
+    /* PRE32: the leaf waiting for its f32 records (scalar loads: a leaf's records are consecutive and the same for every lane, so
+     * they travel through the scalar cache into scalar registers: no LDS tile, no gather, no vector register) */
+    typedef const float __attribute__((address_space(4))) *FloatK;
+    typedef const int32_t __attribute__((address_space(4))) *IntK;
+    typedef __attribute__((address_space(1))) char *GChar;
+    const FloatK posfK = (FloatK) (size_t) a.posf_leaf;
+    auto ldrec = [&](const int slot) { return make_float4(posfK[4 * slot], posfK[4 * slot + 1], posfK[4 * slot + 2], posfK[4 * slot + 3]); };
+    const IntK ngarbK = (IntK) (size_t) a.ngarb_leaf;
+    const float pfx = (float) px, pfy = (float) py, pfz = (float) pz;
+    GChar region = nullptr; /* the wave's list region as a scalar base: an append is one store with a 32-bit lane offset */
+    if(PRE32) {
+        const unsigned long long rb = (unsigned long long) (myl - lane);
+        region = (GChar) (size_t) (((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (rb >> 32)) << 32) |
+                                   (unsigned) __builtin_amdgcn_readfirstlane((int) rb));
+    }
+    int p_cn = 0, p_sb = 0, p_ng = 0;
+    unsigned long long p_km = 0ull;
+    float4 pd0, pd1, pd2, pd3, pd4, pd5, pd6, pd7;
+    pd0 = pd1 = pd2 = pd3 = pd4 = pd5 = pd6 = pd7 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     /* scan the queued candidates: one coalesced gather, then broadcast reads.  Leaf by leaf (round 4): what is the same for a leaf's
      * particles - which lanes want it, whether a displacement to it can need the periodic wrap at all - is read once per leaf into
@@ -399,6 +470,63 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
         nleafq = 0;
     };
 
+    /* PRE32: the f32 pre-test of the waiting leaf's candidates, straight-line code per leaf size; the candidates are scalar operands */
+    auto process_pending = [&]() {
+        if(p_cn == 0 || (SPH_PROBE == 1 && SYM)) /* probe 1: the hydro walk without its candidates */
+            return;
+        if(__builtin_amdgcn_inverse_ballot_w64(p_km) && !(KEEP && ovf)) { /* the lane mask of the whole leaf */
+            nint += p_cn - p_ng;
+            unsigned int off = ((unsigned int) fill * 64u + (unsigned int) lane) * 4u;
+#if SPH_PROBE == 2 /* timing probe: the hydro walk's tests without the list (the lists stay empty) */
+#define PRE32_STORE(k)                                                                                                                  \
+    if(SYM)                                                                                                                             \
+        nint++;                                                                                                                         \
+    else {                                                                                                                              \
+        *reinterpret_cast<__attribute__((address_space(1))) int32_t *>(region + off) = p_sb + (k);                                      \
+        off += 256u;                                                                                                                    \
+    }
+#else
+#define PRE32_STORE(k)                                                                                                                  \
+    *reinterpret_cast<__attribute__((address_space(1))) int32_t *>(region + off) = p_sb + (k);                                          \
+    off += 256u;
+#endif
+#define PRE32_BODY(k, Q)                                                                                                                \
+    {                                                                                                                                   \
+        const float e0 = pfx - Q.x, e1 = pfy - Q.y, e2 = pfz - Q.z;                                                                     \
+        const float rr = e0 * e0 + e1 * e1 + e2 * e2;                                                                                   \
+        if(rr < (SYM ? fmaxf(thri, Q.w) : thri)) {                                                                                      \
+            PRE32_STORE(k)                                                                                                              \
+        }                                                                                                                               \
+    }
+            switch(p_cn) {
+            case 1: PRE32_BODY(0, pd0) break;
+            case 2: PRE32_BODY(0, pd0) PRE32_BODY(1, pd1) break;
+            case 3: PRE32_BODY(0, pd0) PRE32_BODY(1, pd1) PRE32_BODY(2, pd2) break;
+            case 4: PRE32_BODY(0, pd0) PRE32_BODY(1, pd1) PRE32_BODY(2, pd2) PRE32_BODY(3, pd3) break;
+            case 5: PRE32_BODY(0, pd0) PRE32_BODY(1, pd1) PRE32_BODY(2, pd2) PRE32_BODY(3, pd3) PRE32_BODY(4, pd4) break;
+            case 6: PRE32_BODY(0, pd0) PRE32_BODY(1, pd1) PRE32_BODY(2, pd2) PRE32_BODY(3, pd3) PRE32_BODY(4, pd4) PRE32_BODY(5, pd5) break;
+            case 7: PRE32_BODY(0, pd0) PRE32_BODY(1, pd1) PRE32_BODY(2, pd2) PRE32_BODY(3, pd3) PRE32_BODY(4, pd4) PRE32_BODY(5, pd5) PRE32_BODY(6, pd6) break;
+            default: PRE32_BODY(0, pd0) PRE32_BODY(1, pd1) PRE32_BODY(2, pd2) PRE32_BODY(3, pd3) PRE32_BODY(4, pd4) PRE32_BODY(5, pd5) PRE32_BODY(6, pd6) PRE32_BODY(7, pd7) break;
+            }
+#undef PRE32_BODY
+            fill = (int) (off >> 8); /* lane * 4 < 256 */
+        }
+        if(dbg)
+            dbg[1] += p_cn;
+        p_cn = 0;
+        if(KEEP) {
+            if(fill >= NL_CAP) { /* as in scan_tile; checked per leaf here (<= 8 appends, the region has 64 rows of slack) */
+                ovf = true;
+                fill = 0;
+                mynext = -2;
+            }
+        } else if(shq_ballot(fill >= NL_CAP) != 0ull) {
+            if(dbg)
+                dbg[2] += NL_CAP;
+            nl_flush(myl, fill, pair);
+        }
+    };
+
     int seg1 = -1, seg2 = -1, seg3 = -1, myend = -1;
     if(GHOSTS) {
         mynext = (valid && seg.x >= 0) ? seg.x : -2;
@@ -407,8 +535,13 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
             myend = a.nodeC[mynext].sibling;
     }
     int cur = a.root, wbase = -(1 << 30);
+    /* The loop is written for the scalar pipe (round 4; the counter pass had 69 k scalar beside 56 k vector instructions per wave, and a
+     * scalar instruction holds its pipe for four cycles like an f64 one): lane conditions exist only as ballot masks, combined with
+     * 64-bit scalar algebra and read back through inverse ballots; wave-uniform decisions are compare-and-branch on those masks,
+     * never booleans the compiler would materialise as masks of their own; one window test; the lanes' links are set before the
+     * leaf is handed on, so that nothing after the hand-over depends on it. */
     while(cur >= 0) {
-        if(cur < wbase || cur >= wbase + NW_WIN) {
+        if((unsigned int) (cur - wbase) >= (unsigned int) NW_WIN) {
             wbase = cur;
             __builtin_amdgcn_wave_barrier();
             if(lane < NW_WIN) {
@@ -429,68 +562,80 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
         const int Ctype = __builtin_amdgcn_readfirstlane(Cv.z), Ccount = __builtin_amdgcn_readfirstlane(Cv.w);
         if(dbg)
             dbg[0]++;
-        const bool act = (mynext == cur);
-        /* cull_node<symmetric>, localtreewalk2.h:154-182.  The wave votes are formed from the lane masks of the single
-         * comparisons and combined with scalar logic (a vote on a compound boolean costs two extra VALU instructions). */
+        /* cull_node<symmetric>, localtreewalk2.h:154-182 */
         const unsigned long long actm = shq_ballot(mynext == cur);
-        double dist = (SYM ? fmax(winH[w], h) : h) + 0.5 * B.w;
+        const double dist = (SYM ? fmax(winH[w], h) : h) + 0.5 * B.w;
         double dx = B.x - px, dy = B.y - py, dz = B.z - pz;
         double dmax = fmax(fmax(fabs(dx), fabs(dy)), fabs(dz));
-        const bool wrapped_node = (shq_ballot(dmax > halfBox) & actm) != 0ull;
-        if(wrapped_node) {
+        const unsigned long long wrapm = shq_ballot(dmax > halfBox) & actm;
+        if(wrapm != 0ull) {
             dx = wrapd(dx, a.Box, a.invBox);
             dy = wrapd(dy, a.Box, a.invBox);
             dz = wrapd(dz, a.Box, a.invBox);
             dmax = fmax(fmax(fabs(dx), fabs(dy)), fabs(dz));
         }
+        asm volatile("" ::: "memory");
         const double r2 = dx * dx + dy * dy + dz * dz;
         const double dist2 = dist + (0.5 * (1.7320508075688772 - 1.0)) * B.w;
-        const bool far1 = dmax > dist, far2 = r2 > dist2 * dist2;
-        const bool keep = act && !far1 && !far2;
-        const unsigned long long keepm = actm & ~shq_ballot(dmax > dist) & ~shq_ballot(r2 > dist2 * dist2);
-        int next;
-        if(Ctype == SHQ_PARTICLE_NODE_TYPE) {
-            const unsigned long long km = keepm;
-            if(km != 0ull && Ccount > 0) {
-                if(ncand + Ccount > 64)
-                    scan_tile();
-                /* can a displacement from an interested lane to a particle of this leaf need the periodic wrap?  The particles lie in
-                 * the leaf's cell: |p - pos| <= |centre - pos| + len / 2 per coordinate; no, unless the node test itself wrapped or
-                 * that bound comes near Box / 2 for some interested lane (a conservative yes costs three identity wraps) */
-                const bool maywrap = wrapped_node || (shq_ballot(dmax + 0.5 * B.w > 0.999 * halfBox) & km) != 0ull;
+        const unsigned long long keepm = actm & ~(shq_ballot(dmax > dist) | shq_ballot(r2 > dist2 * dist2));
+        /* the node types without control flow: every awake lane passes on to the sibling; the lanes that keep an internal node go down
+         * instead, and the cursor with them; a kept leaf is the one branch */
+        unsigned long long openm = Ctype == SHQ_NODE_NODE_TYPE ? keepm : 0ull;
+        const unsigned long long leafm = (Ctype == SHQ_PARTICLE_NODE_TYPE && Ccount > 0) ? keepm : 0ull;
+        unsigned long long downm = openm;
+        if(GHOSTS) /* a lane waits at a branch below this node: go down even if nobody opens it */
+            downm |= Ctype == SHQ_NODE_NODE_TYPE ? shq_ballot(mynext > cur && (Csib < 0 || mynext < Csib)) : 0ull;
+        if(__builtin_amdgcn_inverse_ballot_w64(actm))
+            mynext = Csib;
+        if(__builtin_amdgcn_inverse_ballot_w64(openm))
+            mynext = Cchild;
+        const int next = downm != 0ull ? Cchild : Csib;
+        asm volatile("" ::: "memory");
+        if(leafm != 0ull) {
+            if(!PRE32 && ncand + Ccount > 64)
+                scan_tile();
+            /* can a displacement from an interested lane to a particle of this leaf need the periodic wrap?  The particles lie in
+             * the leaf's cell: |p - pos| <= |centre - pos| + len / 2 per coordinate; no, unless the node test itself wrapped or
+             * that bound comes near Box / 2 for some interested lane (a conservative yes costs three identity wraps) */
+            const unsigned long long nearm = wrapm | (shq_ballot(dmax + 0.5 * B.w > 0.999 * halfBox) & leafm);
+            if(PRE32)
+                process_pending(); /* leaves are scanned in walk order: the waiting one first */
+            if(PRE32 && nearm == 0ull) {
+                /* this leaf waits for its records while the walk goes on */
+                pd0 = ldrec(Cchild); pd1 = ldrec(Cchild + 1); pd2 = ldrec(Cchild + 2); pd3 = ldrec(Cchild + 3);
+                pd4 = ldrec(Cchild + 4); pd5 = ldrec(Cchild + 5); pd6 = ldrec(Cchild + 6); pd7 = ldrec(Cchild + 7);
+                p_ng = ngarbK[Cchild];
+                p_km = leafm;
+                p_sb = Cchild;
+                p_cn = Ccount;
+            } else {
                 if(lane < Ccount)
                     tsl[ncand + lane] = Cchild + lane;
                 if(lane == 0) {
-                    lqm[nleafq] = km;
-                    lqi[nleafq] = ncand | (Ccount << 8) | ((maywrap ? 1 : 0) << 16);
+                    lqm[nleafq] = leafm;
+                    lqi[nleafq] = ncand | (Ccount << 8) | ((nearm != 0ull ? 1 : 0) << 16);
                 }
                 nleafq++;
                 ncand += Ccount;
+                if(PRE32)
+                    scan_tile(); /* a leaf that may need the periodic wrap: the f64 scan, at once */
             }
-            if(act && !(KEEP && ovf)) /* a target that left the walk inside scan_tile stays out */
-                mynext = Csib;
-            next = Csib;
-        } else if(Ctype == SHQ_PSEUDO_NODE_TYPE) {
-            if(act && !(KEEP && ovf))
-                mynext = Csib;
-            next = Csib;
-        } else {
-            bool any = keepm != 0ull;
-            if(GHOSTS) /* a lane waits at a branch below this node: go down even if nobody opens it */
-                any = any || shq_ballot(mynext > cur && (Csib < 0 || mynext < Csib)) != 0ull;
-            if(act && !(KEEP && ovf))
-                mynext = keep ? Cchild : Csib;
-            next = any ? Cchild : Csib;
         }
-        if(GHOSTS && act && mynext == myend) { /* branch done: wait at the next one of the NodeList */
-            mynext = seg1 >= 0 ? seg1 : -2;
-            seg1 = seg2;
-            seg2 = seg3;
-            seg3 = -1;
-            myend = mynext >= 0 ? a.nodeC[mynext].sibling : -1;
+        if(GHOSTS) {
+            if(shq_ballot(mynext == myend) & actm) { /* rare: some lane's branch is done */
+                if(__builtin_amdgcn_inverse_ballot_w64(actm) && mynext == myend) { /* wait at the next one of the NodeList */
+                    mynext = seg1 >= 0 ? seg1 : -2;
+                    seg1 = seg2;
+                    seg2 = seg3;
+                    seg3 = -1;
+                    myend = mynext >= 0 ? a.nodeC[mynext].sibling : -1;
+                }
+            }
         }
         cur = next;
     }
+    if(PRE32)
+        process_pending();
     if(ncand > 0)
         scan_tile();
     if(dbg) {
@@ -871,6 +1016,9 @@ __device__ __forceinline__ void sph_density_body(const SphDev &a, const int32_t 
         const double d1 = wrapd(py - q.y, a.Box, a.invBox);
         const double d2 = wrapd(pz - q.z, a.Box, a.invBox);
         const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        /* the lists of the f32 pre-test hold a superset: the reference's test (densitytree2.hpp:362-375) decides here */
+        if(!(r2 < h2) || (nowind && (a.flag_leaf[s] & 2)))
+            return;
         const double r = sqrt(r2);
         const double u = r * Hinv;
         const double wk = kernel.wk(u);
@@ -918,9 +1066,10 @@ __device__ __forceinline__ void sph_density_body(const SphDev &a, const int32_t 
         Div = wave_sum(Div); R0 = wave_sum(R0); R1 = wave_sum(R1); R2 = wave_sum(R2); G0 = wave_sum(G0); G1 = wave_sum(G1); G2 = wave_sum(G2);
         valid = lane == 0;
     } else if(MODE != 2)
-        nint = ngb_walk<false, MODE == 1, GHOSTS>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(false), myl, valid, px, py, pz, h, accept, pair,
-                                                  (unsigned int *) nullptr, fill, ovf,
-                                                  (GHOSTS && valid) ? qseg[t] : make_int4(-1, -1, -1, -1));
+        nint = ngb_walk<false, MODE == 1, GHOSTS, true>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(false), myl, valid, px, py, pz, h, accept, pair,
+                                                        (unsigned int *) nullptr, fill, ovf,
+                                                        (GHOSTS && valid) ? qseg[t] : make_int4(-1, -1, -1, -1),
+                                                        valid ? pre32_bound(h, a.Box * 0x1p-20) : 0.f);
     if(MODE == 1) {
         counts[wave * 64 + lane] = ovf ? -1 : fill; /* -1: this target goes to the one-target-per-wave kernel */
         if(ovf)
@@ -1199,16 +1348,20 @@ __device__ __forceinline__ void sph_hydro_body(const SphDev &a, const int32_t *q
 
     /* HydroLocalTreeWalk::ngbiter, hydratree2.hpp:253-378, for one accepted neighbour (leaf slot s) */
     auto pair = [&](const int s) {
-        const double4 q = a.posm_leaf[s];
         const HydRec *rec = a.hydrec_leaf + s;
-        const double4 w = rec->velp;
+        const double4 q = rec->posm;
+        const double4 w = rec->velh;
         const double4 Cj = rec->C;
         const double4 Dj = rec->D;
-        const double hj = rec->hsml;
+        const double hj = w.w;
         const double d0 = wrapd(px - q.x, a.Box, a.invBox);
         const double d1 = wrapd(py - q.y, a.Box, a.invBox);
         const double d2 = wrapd(pz - q.z, a.Box, a.invBox);
         const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        /* the lists of the f32 pre-test hold a superset: the reference's test (hydratree2.hpp:253-262) decides here (a wind-decoupled
+         * particle never reaches a list: its f32 record is at infinity, and the f64 scan's accept() knows its flag) */
+        if(!(r2 > 0 && (r2 < hi2 || r2 < hj * hj)))
+            return;
         /* The reference divides by r, H and the entropy variables at every use; with ~10 f64 divisions
          * (a dozen instructions each) they were half of this function.  Here 1/r comes from v_rsq_f64 + a
          * Newton step and the kernel of j from one reciprocal of h_j: same formulas, results differ from
@@ -1281,9 +1434,10 @@ __device__ __forceinline__ void sph_hydro_body(const SphDev &a, const int32_t *q
             MaxSig = fmax(MaxSig, __shfl_xor(MaxSig, off));
         valid = lane == 0;
     } else if(MODE != 2)
-        nint = ngb_walk<true, MODE == 1, GHOSTS>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(true), myl, valid, px, py, pz, hi, accept, pair,
-                                                 (MODE == 0 && nint_total && !GHOSTS) ? dbgc : (unsigned int *) nullptr, fill, ovf,
-                                                 (GHOSTS && valid) ? qseg[t] : make_int4(-1, -1, -1, -1));
+        nint = ngb_walk<true, MODE == 1, GHOSTS, true>(a, lds + (threadIdx.x >> 6) * NW_LDS_PER_WAVE(true), myl, valid, px, py, pz, hi, accept, pair,
+                                                       (MODE == 0 && nint_total && !GHOSTS) ? dbgc : (unsigned int *) nullptr, fill, ovf,
+                                                       (GHOSTS && valid) ? qseg[t] : make_int4(-1, -1, -1, -1),
+                                                       valid ? pre32_bound(hi, a.Box * 0x1p-20) : 0.f);
     if(MODE == 1) {
         counts[wave * 64 + lane] = ovf ? -1 : fill; /* -1: this target goes to the one-target-per-wave kernel */
         if(ovf)
@@ -1388,6 +1542,8 @@ SphDev make_dev(shq_context *ctx)
     a.hydrec_leaf = reinterpret_cast<const HydRec *>(ctx->hydrec_leaf.ptr);
     a.hsml_leaf = ctx->hsml_leaf.ptr;
     a.flag_leaf = ctx->flag_leaf.ptr;
+    a.posf_leaf = ctx->posf_leaf.ptr;
+    a.ngarb_leaf = ctx->ngarb_leaf.ptr;
     a.posm = ctx->posm.ptr;
     a.pflags = ctx->pflags.ptr;
     a.hsml = ctx->hsml.ptr;
@@ -1431,6 +1587,8 @@ int shq_sph_prepare(shq_context *ctx, const shq_kick_factors *kf, const shq_hydr
     SHQ_TRY(ctx->hydrec_leaf.reserve(nl * sizeof(HydRec) + 128));
     SHQ_TRY(ctx->hsml_leaf.reserve(nl));
     SHQ_TRY(ctx->flag_leaf.reserve(nl));
+    SHQ_TRY(ctx->posf_leaf.reserve(nl));
+    SHQ_TRY(ctx->ngarb_leaf.reserve(nl));
     if(n == 0)
         return SHQ_OK;
     PredArgs a;
@@ -1465,7 +1623,10 @@ int shq_sph_prepare(shq_context *ctx, const shq_kick_factors *kf, const shq_hydr
     sph_gather_leaf_kernel<<<dim3(nblk(nl)), dim3(256), 0, ctx->stream>>>(
         nl, ctx->leaf_pidx.ptr, ctx->velp.ptr, hp ? ctx->hydC.ptr : nullptr, hp ? ctx->hydD.ptr : nullptr, ctx->hsml.ptr,
         ctx->pflags.ptr, ctx->g_delaytime.ptr, ctx->velp_leaf.ptr, hp ? reinterpret_cast<HydRec *>(ctx->hydrec_leaf.ptr) : nullptr,
-        ctx->hsml_leaf.ptr, ctx->flag_leaf.ptr);
+        ctx->hsml_leaf.ptr, ctx->flag_leaf.ptr, ctx->posm_leaf.ptr, ctx->posf_leaf.ptr, ldexp(ctx->treeBox, -20));
+    if(ctx->numnodes > 0)
+        sph_leaf_ngarb_kernel<<<dim3(nblk(ctx->numnodes)), dim3(256), 0, ctx->stream>>>((int) ctx->numnodes, ctx->nodeC.ptr, ctx->flag_leaf.ptr,
+                                                                                      ctx->ngarb_leaf.ptr);
     SHQ_HIP(hipGetLastError());
     return SHQ_OK;
 }

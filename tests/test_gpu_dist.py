@@ -43,8 +43,9 @@ def _run_rank(rank, world, outdir, split=False):
     cm.reference_treepar(ErrTolForceAcc=0.005, MaxBHOpeningAngle=0.9, Rcut=6.0, TreeUseBH=0)
     gp = sq.make_grav_params(BOX, 1.5, NMESH, G, cm.RHO0)
     bounds = sd.balanced_bounds(comm, NMESH, BOX, mine[:, 0]) if world > 1 else None
-    # split: the first plane of rank 1 (the plane through the cluster) shared by y — its particles below 0.6 BOX are rank 0's
-    ycuts = [0.0, 0.6 * BOX, 0.0] if split else None
+    # split: the first plane of rank 1 (the plane through the cluster, which sits at y = 5.0 ... 5.3) shared by y — its particles
+    # below y = 5.06 are rank 0's
+    ycuts = [0.0, 5.06, 0.0] if split else None
     drv = sd.DistTreePM(comm, ctx, NMESH, BOX, 1.5, G, dev, halo_factor=1.3, bounds=bounds, ycuts=ycuts)
     local = sd.exchange_to_owner(comm, drv.decomp, mine)
     if split:

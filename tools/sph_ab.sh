@@ -3,5 +3,5 @@
 # iteration and the hydro pass.  GPU box, repo root.
 for which in tree "$@" tree; do
   if [ "$which" = tree ]; then unset SHQ_LIBDIR; else export SHQ_LIBDIR=$PWD/$which; fi
-  python tools/bench_sph.py 128 uniform 2 2>&1 | grep -E "density: 1 iter|hydro:" | tail -2 | sed "s|^|$which  |"
+  python tools/bench_sph.py 128 uniform 2 2>&1 | grep -E "density:|hydro:" | tail -3 | sed "s|^|$which  |"
 done
