@@ -285,6 +285,9 @@ extern "C" void shq_shutdown(shq_context *ctx)
         (void) hipEventDestroy(ctx->ev_pair_fork);
     if(ctx->ev_pair_join)
         (void) hipEventDestroy(ctx->ev_pair_join);
+    for(int i = 0; i < 4; i++)
+        if(ctx->ev_sph[i])
+            (void) hipEventDestroy(ctx->ev_sph[i]);
     if(ctx->ev_pm_ready)
         (void) hipEventDestroy(ctx->ev_pm_ready);
     if(ctx->ev_pm_done)

@@ -216,6 +216,7 @@ struct shq_context {
      * pending, the main walk's go first) */
     hipStream_t stream_pair = nullptr;
     hipEvent_t ev_pair_fork = nullptr, ev_pair_join = nullptr;
+    hipEvent_t ev_sph[4] = {nullptr, nullptr, nullptr, nullptr}; /* sph.hip, launch_two_kernel: walk done / evaluation done, two list regions */
     bool pm_pending = false;
     bool pm_prestarted = false;          /* shq_pm_start: the PM of the current positions is queued on stream_pm; shq_treepm_step takes it over */
     bool pm_prestarted_oldacc = false;   /* ... and its readout kernel formed OldAcc */

@@ -1654,14 +1654,36 @@ static long long nl_chunk_waves(long long nq)
     return ((chunk + 255) / 256) * 4;
 }
 
-/* list scratch: one region per wave of a chunk, followed by one per wave of the fused redo kernel */
+/* Walk and evaluation in a pipeline (round 4).  The walk kernel is bound by the vector and scalar pipes (tools/sph_ab.sh with the
+ * SPH_PROBE builds: 3.2 ms of node tests + 1.5 ms of candidate tests for the 128^3 hydro pass), the evaluation kernel by the texture
+ * addresser (eight to ten 16-byte gathers per pair from 64 different lines, 37 % VALU busy): with the targets cut into NL_PIPE pieces, the
+ * evaluation of piece k runs on a second stream beside the walk of piece k + 1, two list regions in turn.  SHQ_SPH_PIPE=0: one after the
+ * other, as before (the same lists, the same sums). */
+#define NL_PIPE 4
+#define NL_PIPE_MIN (1ll << 19)
+static bool nl_pipelined(const int32_t *q, long long nq)
+{
+    static const bool on = getenv("SHQ_SPH_PIPE") && atoi(getenv("SHQ_SPH_PIPE")) != 0;
+    return on && q != nullptr && nq > NL_PIPE_MIN;
+}
+static long long nl_pipe_targets(long long nq)
+{
+    const long long c = (((nq + NL_PIPE - 1) / NL_PIPE) + 255) / 256 * 256;
+    return c < NL_CHUNK ? c : NL_CHUNK;
+}
+
+/* list scratch: one region per wave of a chunk (both layouts fit: two pieces of a quarter each, or the whole), followed by one per
+ * wave of the fused redo kernel */
 static int reserve_nlist(shq_context *ctx, long long nq)
 {
     const long long waves = nl_chunk_waves(nq) + NL_REDO_BLOCKS * 4;
     SHQ_TRY(ctx->s_nlist.reserve((size_t) waves * NL_ROWS * 64));
-    SHQ_TRY(ctx->s_ncount.reserve((size_t) (nl_chunk_waves(nq) + 4) * 64));
+    SHQ_TRY(ctx->s_ncount.reserve((size_t) (nl_chunk_waves(nq) + 8) * 64));
     SHQ_TRY(ctx->s_redo.reserve((size_t) (nq > 0 ? nq : 1)));
     SHQ_TRY(ctx->s_redo2.reserve((size_t) (nq > 0 ? nq : 1)));
+    for(int i = 0; i < 4; i++)
+        if(!ctx->ev_sph[i])
+            SHQ_HIP(hipEventCreateWithFlags(&ctx->ev_sph[i], hipEventDisableTiming));
     return SHQ_OK;
 }
 
@@ -1676,15 +1698,36 @@ static int launch_two_kernel(shq_context *ctx, const int32_t *q, long long nq, l
     int32_t *lists = ctx->s_nlist.ptr;
     int32_t *fused_lists = ctx->s_nlist.ptr + (size_t) nl_chunk_waves(nq_reserved) * NL_ROWS * 64;
     SHQ_CHECK(q || nq <= NL_CHUNK, SHQ_ERR_INVALID, "SPH walk: more than %lld targets need an explicit queue", (long long) NL_CHUNK);
-    for(long long off = 0; off < nq; off += NL_CHUNK) {
-        const long long m = (nq - off < NL_CHUNK) ? nq - off : NL_CHUNK;
+    const bool pipe = nl_pipelined(q, nq) && ctx->stream_pair;
+    const long long chunk = pipe ? nl_pipe_targets(nq) : NL_CHUNK;
+    /* pipelined: two regions of a piece's waves each (a piece is at most a quarter of what was reserved, rounded up to 256 targets) */
+    const size_t region = pipe ? (size_t) ((chunk + 255) / 256 * 4) * NL_ROWS * 64 : 0;
+    const size_t cregion = pipe ? (size_t) ((chunk + 255) / 256 * 4 + 4) * 64 : 0;
+    static const bool hi = getenv("SHQ_SPH_PIPE") && atoi(getenv("SHQ_SPH_PIPE")) == 2; /* the evaluation on the high-priority stream */
+    hipStream_t sw = ctx->stream, se = pipe ? (hi && ctx->stream_pm ? ctx->stream_pm : ctx->stream_pair) : ctx->stream;
+    int k = 0;
+    for(long long off = 0; off < nq; off += chunk, k++) {
+        const long long m = (nq - off < chunk) ? nq - off : chunk;
         const long long ntasks = (m + 255) / 256;
         const int32_t *qc = q ? q + off : nullptr;
         const long long wtasks = (m + 64 * SPH_WALK_WPB - 1) / (64 * SPH_WALK_WPB);
-        walk((unsigned) wtasks, qc, m, wtasks, lists, ctx->s_ncount.ptr);
-        eval((unsigned) ntasks, qc, m, ntasks, lists, ctx->s_ncount.ptr);
-        sph_collect_redo_kernel<<<dim3(nblk(m)), dim3(256), 0, ctx->stream>>>(ctx->s_ncount.ptr, qc, m, ctx->s_redo.ptr, d_nredo);
+        const int b = k & 1;
+        int32_t *lb = lists + b * region, *cb = ctx->s_ncount.ptr + b * cregion;
+        if(pipe && k >= 2)
+            SHQ_HIP(hipStreamWaitEvent(sw, ctx->ev_sph[2 + b], 0)); /* the evaluation of piece k - 2 is done with this region */
+        walk(sw, (unsigned) wtasks, qc, m, wtasks, lb, cb);
+        if(pipe) {
+            SHQ_HIP(hipEventRecord(ctx->ev_sph[b], sw));
+            SHQ_HIP(hipStreamWaitEvent(se, ctx->ev_sph[b], 0));
+        }
+        eval(se, (unsigned) ntasks, qc, m, ntasks, lb, cb);
+        sph_collect_redo_kernel<<<dim3(nblk(m)), dim3(256), 0, se>>>(cb, qc, m, ctx->s_redo.ptr, d_nredo);
+        if(pipe)
+            SHQ_HIP(hipEventRecord(ctx->ev_sph[2 + b], se));
     }
+    if(pipe)
+        for(int b = 0; b < 2 && b < k; b++)
+            SHQ_HIP(hipStreamWaitEvent(sw, ctx->ev_sph[2 + b], 0));
     fused((unsigned) NL_HEAVY_BLOCKS, ctx->s_redo.ptr, fused_lists, d_nredo);
     block((unsigned) NL_BLOCK_BLOCKS, ctx->s_redo2.ptr, d_nredo + 1);
     SHQ_HIP(hipGetLastError());
@@ -1698,11 +1741,11 @@ static int launch_density(shq_context *ctx, const SphDev &a, const int32_t *q, l
     hipStream_t st = ctx->stream;
     return launch_two_kernel(
         ctx, q, nq, nq_reserved,
-        [&](unsigned grid, const int32_t *qc, long long m, long long ntasks, int32_t *lists, int32_t *counts) {
-            sph_density_kernel<KT, 1><<<dim3(grid), dim3(64 * SPH_WALK_WPB), 0, st>>>(a, qc, m, wd, nint, lists, ntasks, counts, nullptr);
+        [&](hipStream_t s, unsigned grid, const int32_t *qc, long long m, long long ntasks, int32_t *lists, int32_t *counts) {
+            sph_density_kernel<KT, 1><<<dim3(grid), dim3(64 * SPH_WALK_WPB), 0, s>>>(a, qc, m, wd, nint, lists, ntasks, counts, nullptr);
         },
-        [&](unsigned grid, const int32_t *qc, long long m, long long ntasks, int32_t *lists, int32_t *counts) {
-            sph_density_kernel<KT, 2><<<dim3(grid), dim3(256), 0, st>>>(a, qc, m, wd, nint, lists, ntasks, counts, nullptr);
+        [&](hipStream_t s, unsigned grid, const int32_t *qc, long long m, long long ntasks, int32_t *lists, int32_t *counts) {
+            sph_density_kernel<KT, 2><<<dim3(grid), dim3(256), 0, s>>>(a, qc, m, wd, nint, lists, ntasks, counts, nullptr);
         },
         [&](unsigned grid, const int32_t *redo, int32_t *lists, const long long *d_nredo) {
             sph_density_kernel<KT, 3><<<dim3(grid), dim3(64), 0, st>>>(a, redo, 0, wd, nint, lists, 0, nullptr, d_nredo);
@@ -1717,11 +1760,11 @@ static int launch_hydro(shq_context *ctx, const SphDev &a, const int32_t *q, lon
     hipStream_t st = ctx->stream;
     return launch_two_kernel(
         ctx, q, nq, nq,
-        [&](unsigned grid, const int32_t *qc, long long m, long long ntasks, int32_t *lists, int32_t *counts) {
-            sph_hydro_kernel<KT, 1><<<dim3(grid), dim3(64 * SPH_WALK_WPB), 0, st>>>(a, qc, m, hc, nint, lists, ntasks, counts, nullptr);
+        [&](hipStream_t s, unsigned grid, const int32_t *qc, long long m, long long ntasks, int32_t *lists, int32_t *counts) {
+            sph_hydro_kernel<KT, 1><<<dim3(grid), dim3(64 * SPH_WALK_WPB), 0, s>>>(a, qc, m, hc, nint, lists, ntasks, counts, nullptr);
         },
-        [&](unsigned grid, const int32_t *qc, long long m, long long ntasks, int32_t *lists, int32_t *counts) {
-            sph_hydro_kernel<KT, 2><<<dim3(grid), dim3(256), 0, st>>>(a, qc, m, hc, nint, lists, ntasks, counts, nullptr);
+        [&](hipStream_t s, unsigned grid, const int32_t *qc, long long m, long long ntasks, int32_t *lists, int32_t *counts) {
+            sph_hydro_kernel<KT, 2><<<dim3(grid), dim3(256), 0, s>>>(a, qc, m, hc, nint, lists, ntasks, counts, nullptr);
         },
         [&](unsigned grid, const int32_t *redo, int32_t *lists, const long long *d_nredo) {
             sph_hydro_kernel<KT, 3><<<dim3(grid), dim3(64), 0, st>>>(a, redo, 0, hc, nint, lists, 0, nullptr, d_nredo);
