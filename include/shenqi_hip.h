@@ -215,6 +215,19 @@ int shq_grav_short_tree(shq_context *ctx, const shq_tree_view *tree, const shq_p
 
 /* Resident API. */
 int shq_particles_upload(shq_context *ctx, const shq_part_view *parts);
+/* One-shot operators upload the views they are handed — particles, SPH state, tree, and the ID array of the sub-grid walks: at 2 x 10^6
+ * particles 50-170 ms of packing and PCIe around 4-7 ms of kernels, and run.cpp:621-681 calls a handful of them per step on the same
+ * particles.  With a bit of `mask` set the caller vouches that the context's copy of that input IS the view it passes next: same base
+ * pointer and count, contents unchanged on the host since the copy was made or changed only by the library's own operators (which
+ * write what they change to the views and to the context alike; shq_metal_return, which changes masses and densities in the caller's
+ * records only, takes the particle and SPH bits back itself).  Those uploads are then skipped.  A drift, a kick, a device-side particle
+ * hand-over or mask = 0 ends it. */
+#define SHQ_CURRENT_PARTICLES 1
+#define SHQ_CURRENT_SPH 2
+#define SHQ_CURRENT_TREE 4
+#define SHQ_CURRENT_IDS 8
+int shq_set_inputs_current(shq_context *ctx, int mask);
+
 int shq_tree_upload(shq_context *ctx, const shq_tree_view *tree);
 
 /* Device tree build.  Replaces, for a single-domain tree, force_tree_rebuild / force_tree_create_nodes

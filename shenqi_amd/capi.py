@@ -533,6 +533,9 @@ hip.shq_pm_slab2_deposit.argtypes = [_vp, C.POINTER(PMParams), C.c_int, C.c_int,
 hip.shq_pm_slab2_deposit.restype = C.c_int
 hip.shq_pm_slab2_deposit_ghosts.argtypes = [_vp, C.POINTER(PMParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]
 hip.shq_pm_slab2_deposit_ghosts.restype = C.c_int
+hip.shq_set_inputs_current.argtypes = [_vp, C.c_int]
+hip.shq_set_inputs_current.restype = C.c_int
+CURRENT_PARTICLES, CURRENT_SPH, CURRENT_TREE, CURRENT_IDS = 1, 2, 4, 8
 hip.shq_pm_slab2_fft_yz.argtypes = [_vp, C.c_int, _vp, C.c_int, C.c_int]
 hip.shq_pm_slab2_fft_yz_packed.argtypes = [_vp, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
 hip.shq_pm_slab2_fft_yz_packed.restype = C.c_int

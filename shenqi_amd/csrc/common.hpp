@@ -216,6 +216,10 @@ struct shq_context {
      * pending, the main walk's go first) */
     hipStream_t stream_pair = nullptr;
     hipEvent_t ev_pair_fork = nullptr, ev_pair_join = nullptr;
+    /* shq_set_inputs_current: which of the context's copies the caller vouches for, and what they are copies of */
+    int inputs_current = 0;
+    const void *cur_parts = nullptr, *cur_sph = nullptr, *cur_tree = nullptr, *cur_ids = nullptr;
+    int64_t cur_parts_n = -1, cur_sph_n = -1, cur_tree_n = -1, cur_tree_first = -1, cur_ids_n = -1;
     hipEvent_t ev_sph[4] = {nullptr, nullptr, nullptr, nullptr}; /* sph.hip, launch_two_kernel: walk done / evaluation done, two list regions */
     bool pm_pending = false;
     bool pm_prestarted = false;          /* shq_pm_start: the PM of the current positions is queued on stream_pm; shq_treepm_step takes it over */

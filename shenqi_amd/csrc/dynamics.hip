@@ -473,6 +473,8 @@ extern "C" int shq_active_download(shq_context *ctx, int sublist, int32_t *list,
 
 extern "C" int shq_drift(shq_context *ctx, double ddrift, double BoxSize, const double random_shift[3])
 {
+    if(ctx)
+        ctx->inputs_current = 0; /* the resident set moves: shq_set_inputs_current ends here */
     SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
     SHQ_CHECK(ctx->have_parts && ctx->have_dyn, SHQ_ERR_STATE, "drift: shq_particles_upload and shq_dynamics_upload first");
     SHQ_CHECK(BoxSize > 0, SHQ_ERR_INVALID, "drift: BoxSize must be > 0");
@@ -511,6 +513,8 @@ extern "C" int shq_drift(shq_context *ctx, double ddrift, double BoxSize, const 
 extern "C" int shq_kick_short(shq_context *ctx, const double gravkick[SHQ_TIMEBINS + 1], const int32_t *active, int64_t nactive,
                               int from_accel_store)
 {
+    if(ctx)
+        ctx->inputs_current = 0; /* the resident set moves: shq_set_inputs_current ends here */
     SHQ_CHECK(ctx && gravkick, SHQ_ERR_INVALID, "null argument");
     SHQ_CHECK(ctx->have_parts && ctx->have_dyn, SHQ_ERR_STATE, "kick_short: shq_particles_upload and shq_dynamics_upload first");
     SHQ_CHECK(!active || nactive >= 0, SHQ_ERR_INVALID, "kick_short: bad active list");
@@ -537,6 +541,8 @@ extern "C" int shq_kick_short(shq_context *ctx, const double gravkick[SHQ_TIMEBI
 extern "C" int shq_kick_hydro(shq_context *ctx, const double hydrokick[SHQ_TIMEBINS + 1], const double dt_entr[SHQ_TIMEBINS + 1], double atime,
                               double MaxGasVel, const int32_t *active, int64_t nactive, int from_hydro_output, int64_t *nlimited)
 {
+    if(ctx)
+        ctx->inputs_current = 0; /* the resident set moves: shq_set_inputs_current ends here */
     SHQ_CHECK(ctx && hydrokick && dt_entr, SHQ_ERR_INVALID, "null argument");
     SHQ_CHECK(ctx->have_parts && ctx->have_sph && ctx->vel.ptr && ctx->g_entropy.ptr, SHQ_ERR_STATE,
               "kick_hydro: no SPH state on the device (shq_density / shq_hydro_force, or their phase calls, load it)");
@@ -580,6 +586,8 @@ extern "C" int shq_entropy_download(shq_context *ctx, double *entropy_by_particl
 
 extern "C" int shq_kick_pm(shq_context *ctx, double Fgravkick)
 {
+    if(ctx)
+        ctx->inputs_current = 0; /* the resident set moves: shq_set_inputs_current ends here */
     SHQ_CHECK(ctx, SHQ_ERR_INVALID, "null context");
     SHQ_CHECK(ctx->have_parts && ctx->have_dyn, SHQ_ERR_STATE, "kick_pm: shq_particles_upload and shq_dynamics_upload first");
     SHQ_HIP(hipSetDevice(ctx->device));

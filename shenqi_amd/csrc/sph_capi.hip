@@ -35,6 +35,19 @@ template <typename T> int down(shq_context *ctx, const DevBuf<T> &b, std::vector
     return SHQ_OK;
 }
 
+/* the particle IDs the sub-grid walks compare and record (bhw_ids); skipped when the caller vouches for the copy */
+int ids_upload(shq_context *ctx, const uint64_t *ids, int64_t n)
+{
+    SHQ_TRY(ctx->bhw_ids.reserve((size_t) std::max<int64_t>(n, 1)));
+    if((ctx->inputs_current & SHQ_CURRENT_IDS) && ctx->cur_ids == (const void *) ids && ctx->cur_ids_n == n)
+        return SHQ_OK;
+    if(n > 0)
+        SHQ_HIP(hipMemcpyAsync(ctx->bhw_ids.ptr, ids, sizeof(uint64_t) * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+    ctx->cur_ids = ids;
+    ctx->cur_ids_n = n;
+    return SHQ_OK;
+}
+
 /* Gather the SPH state into per-particle-index arrays (gas fields come from slot PI). */
 int sph_upload(shq_context *ctx, const shq_part_view *parts, const shq_sph_view *sph)
 {
@@ -42,6 +55,9 @@ int sph_upload(shq_context *ctx, const shq_part_view *parts, const shq_sph_view 
                   parts->off_type != SHQ_NOFIELD, SHQ_ERR_INVALID, "SPH needs Hsml, Vel, PI and Type in the particle view");
     SHQ_CHECK(sph && (sph->numslots == 0 || sph->base), SHQ_ERR_INVALID, "SPH slot view is NULL");
     const int64_t n = parts->numpart;
+    if((ctx->inputs_current & SHQ_CURRENT_SPH) && ctx->have_sph && ctx->cur_sph == sph->base && ctx->cur_sph_n == sph->numslots &&
+       ctx->cur_parts == parts->base && ctx->numpart == n)
+        return SHQ_OK; /* shq_set_inputs_current */
     /* one parallel pass into pinned staging (17 doubles + 2 bytes per particle), then one copy per array */
     const size_t cap = (size_t) std::max<int64_t>(n, 1);
     SHQ_TRY(ctx->stage.reserve(cap * (17 * sizeof(double) + 2) + 256));
@@ -135,6 +151,8 @@ int sph_upload(shq_context *ctx, const shq_part_view *parts, const shq_sph_view 
     SHQ_TRY(upd(ctx->g_maxsignalvel, msv, n));
     SHQ_HIP(hipStreamSynchronize(ctx->stream));
     ctx->have_sph = true;
+    ctx->cur_sph = sph->base;
+    ctx->cur_sph_n = sph->numslots;
     return SHQ_OK;
 }
 
@@ -1033,8 +1051,7 @@ int bh_upload_common(shq_context *ctx, const shq_tree_view *tree, const shq_part
         SHQ_HIP(hipMemcpyAsync(ctx->bhw_bhp.ptr, S.bhp.data(), sizeof(int32_t) * nbh, hipMemcpyHostToDevice, st));
         SHQ_HIP(hipMemcpyAsync(ctx->bhw_rec.ptr, S.rec.data(), sizeof(BhRec) * nbh, hipMemcpyHostToDevice, st));
     }
-    if(n)
-        SHQ_HIP(hipMemcpyAsync(ctx->bhw_ids.ptr, ids, sizeof(uint64_t) * n, hipMemcpyHostToDevice, st));
+    SHQ_TRY(ids_upload(ctx, ids, (int64_t) n));
     SHQ_HIP(hipMemcpyAsync(ctx->bhw_rnd.ptr, rnd_table, sizeof(double) * (size_t) rnd_size, hipMemcpyHostToDevice, st));
     if(!queue.empty())
         SHQ_HIP(hipMemcpyAsync(ctx->bhw_queue.ptr, queue.data(), sizeof(int32_t) * queue.size(), hipMemcpyHostToDevice, st));
@@ -1331,7 +1348,7 @@ int winds_impl(shq_context *ctx, const shq_tree_view *tree, const shq_part_view 
     SHQ_TRY(ctx->bhw_queue.reserve((size_t) nq));
     SHQ_TRY(ctx->wind_d.reserve(2 * (size_t) nq));
     SHQ_TRY(ctx->wind_cnt.reserve(4));
-    SHQ_HIP(hipMemcpyAsync(ctx->bhw_ids.ptr, ids, sizeof(uint64_t) * (size_t) n, hipMemcpyHostToDevice, st));
+    SHQ_TRY(ids_upload(ctx, ids, (int64_t) n));
     SHQ_HIP(hipMemcpyAsync(ctx->bhw_rnd.ptr, rnd_table, sizeof(double) * (size_t) rnd_size, hipMemcpyHostToDevice, st));
     SHQ_HIP(hipMemcpyAsync(ctx->bhw_queue.ptr, NewStars, sizeof(int32_t) * (size_t) nq, hipMemcpyHostToDevice, st));
     SHQ_HIP(hipMemcpyAsync(ctx->wind_d.ptr + nq, vdisp.data(), sizeof(double) * (size_t) nq, hipMemcpyHostToDevice, st));
@@ -1436,7 +1453,7 @@ extern "C" int shq_winds_apply(shq_context *ctx, const shq_part_view *parts, con
     SHQ_TRY(ctx->wind_cnt.reserve(4));
     SHQ_TRY(ctx->wind_kicks.reserve((size_t) nk * sizeof(shq_wind_kick)));
     SHQ_TRY(ctx->bhw_rec.reserve((size_t) nk * sizeof(shq_wind_kick)));
-    SHQ_HIP(hipMemcpyAsync(ctx->bhw_ids.ptr, ids, sizeof(uint64_t) * (size_t) n, hipMemcpyHostToDevice, st));
+    SHQ_TRY(ids_upload(ctx, ids, (int64_t) n));
     SHQ_HIP(hipMemcpyAsync(ctx->bhw_rnd.ptr, rnd_table, sizeof(double) * (size_t) rnd_size, hipMemcpyHostToDevice, st));
     SHQ_HIP(hipMemcpyAsync(ctx->wind_kicks.ptr, kicks, sizeof(shq_wind_kick) * (size_t) nk, hipMemcpyHostToDevice, st));
     SHQ_HIP(hipMemsetAsync(ctx->wind_cnt.ptr, 0, sizeof(unsigned long long) * 4, st));
@@ -1549,6 +1566,8 @@ extern "C" int shq_metal_return(shq_context *ctx, const shq_tree_view *tree, con
         for(int m = 0; m < SHQ_NMETALS; m++)
             reinterpret_cast<float *>(s + gas->off_metals)[m] = gf1[cap + (size_t) i * SHQ_NMETALS + m];
     }
+    /* the gas masses (and densities) changed in the caller's records only: the context's particle and SPH copies are no longer the views */
+    ctx->inputs_current &= ~(SHQ_CURRENT_PARTICLES | SHQ_CURRENT_SPH);
     return SHQ_OK;
 }
 
@@ -1645,7 +1664,7 @@ extern "C" int shq_winds_subgrid(shq_context *ctx, const shq_part_view *parts, c
     SHQ_TRY(ctx->bhw_queue.reserve((size_t) nlist));
     SHQ_TRY(ctx->wind_d.reserve(2 * (size_t) nlist));
     SHQ_TRY(ctx->wind_cnt.reserve(4));
-    SHQ_HIP(hipMemcpyAsync(ctx->bhw_ids.ptr, ids, sizeof(uint64_t) * (size_t) n, hipMemcpyHostToDevice, st));
+    SHQ_TRY(ids_upload(ctx, ids, (int64_t) n));
     SHQ_HIP(hipMemcpyAsync(ctx->bhw_rnd.ptr, rnd_table, sizeof(double) * (size_t) rnd_size, hipMemcpyHostToDevice, st));
     SHQ_HIP(hipMemcpyAsync(ctx->bhw_queue.ptr, list, sizeof(int32_t) * (size_t) nlist, hipMemcpyHostToDevice, st));
     SHQ_HIP(hipMemcpyAsync(ctx->wind_d.ptr, hd.data(), sizeof(double) * hd.size(), hipMemcpyHostToDevice, st));

@@ -103,6 +103,8 @@ int resident_queue(shq_context *ctx, const char *who)
 
 extern "C" int shq_gas_set_device(shq_context *ctx, const double *d_rows, int64_t n, int64_t nlocal)
 {
+    if(ctx)
+        ctx->inputs_current = 0; /* the resident set moves: shq_set_inputs_current ends here */
     SHQ_CHECK(ctx && (d_rows || n == 0), SHQ_ERR_INVALID, "null argument");
     SHQ_CHECK(n >= 0 && n < (1ll << 31) && nlocal >= 0 && nlocal <= n, SHQ_ERR_INVALID, "gas_set_device: bad particle counts");
     SHQ_HIP(hipSetDevice(ctx->device));

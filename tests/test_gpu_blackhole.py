@@ -177,3 +177,58 @@ def test_bh_walk_argument_errors(ctx):
     capi.check(capi.hip.shq_bh_accretion(ctx.h, C.byref(tv), C.byref(pv), C.byref(sv), C.byref(bv), capi.ptr(ids), None, 0, C.byref(kf), C.byref(cp), 0,
                                          capi.ptr(rnd), len(rnd), C.byref(cw)))
     assert (w["SPH_SwallowID"] == 0).all() and (w["BH_SwallowID"] == 0).all() and (B["encounter"] == 7).all()
+
+
+def _sequence(ctx, current):
+    """accretion -> feedback -> accretion on the same views; with `current` the second and third call take particles, SPH state, tree and
+    IDs from the context (shq_set_inputs_current) instead of uploading the views again"""
+    cp, prm = params()
+    pman, S, B, kf, rnd, bi = setup(3)
+    P = pman.Base
+    n, ngas, nbh = len(P), len(S), len(B)
+    ids = np.ascontiguousarray(P["ID"])
+    queue = np.ascontiguousarray(bi.astype(np.int32))
+    Ti = 1 << 18
+    tree = sq.force_tree_rebuild_mask(pman, sq.GASMASK + sq.BHMASK)
+    sq.force_tree_update_hmax(tree, pman)
+    w, cw = make_work(ngas, nbh)
+    pv, tv, sv, bv = pman.view(), tree.view(), capi.sph_view(S), capi.bh_slot_view(B)
+    eeqos = (np.arange(n) % 3 == 0).astype(np.uint8)
+    ns, nb = C.c_int64(), C.c_int64()
+    snaps = []
+
+    def snap():
+        snaps.append(dict(P=P.copy(), S=S.copy(), B=B.copy(), w={k: v.copy() for k, v in w.items()}, counts=(ns.value, nb.value)))
+
+    def accretion():
+        capi.check(capi.hip.shq_bh_accretion(ctx.h, C.byref(tv), C.byref(pv), C.byref(sv), C.byref(bv), capi.ptr(ids), capi.ptr(queue), len(queue), C.byref(kf),
+                                             C.byref(cp), Ti, capi.ptr(rnd), len(rnd), C.byref(cw)))
+        snap()
+
+    capi.check(capi.hip.shq_set_inputs_current(ctx.h, 0))
+    accretion()
+    if current:
+        capi.check(capi.hip.shq_set_inputs_current(ctx.h, capi.CURRENT_PARTICLES | capi.CURRENT_SPH | capi.CURRENT_TREE | capi.CURRENT_IDS))
+    capi.check(capi.hip.shq_bh_feedback(ctx.h, C.byref(tv), C.byref(pv), C.byref(sv), C.byref(bv), capi.ptr(ids), capi.ptr(queue), len(queue), C.byref(kf),
+                                        C.byref(cp), len(P) + 50, capi.ptr(rnd), len(rnd), capi.ptr(eeqos), C.byref(cw), C.byref(ns), C.byref(nb)))
+    snap()
+    # the holes that were swallowed are no targets any more (blackhole_haswork)
+    alive = np.ascontiguousarray(queue[(P["Flags"][queue] & 3) == 0])
+    queue = alive
+    accretion()
+    capi.check(capi.hip.shq_set_inputs_current(ctx.h, 0))
+    return snaps
+
+
+def test_inputs_current_gives_the_uploading_calls_bits(ctx):
+    """shq_set_inputs_current: a feedback walk and a second accretion walk that take their inputs from the context — the particles as the
+    first call uploaded them and the feedback walk changed them in place — end in the bits of the calls that upload the views every time"""
+    a, b = _sequence(ctx, False), _sequence(ctx, True)
+    assert len(a) == len(b) == 3 and a[1]["counts"] == b[1]["counts"] and a[1]["counts"][0] > 5
+    for x, y in zip(a, b):
+        for rec in ("P", "S", "B"):
+            for name in x[rec].dtype.names:                  # field by field: the records' padding is not initialised
+                assert np.array_equal(x[rec][name], y[rec][name], equal_nan=True), (rec, name)
+        for k in x["w"]:
+            assert np.array_equal(x["w"][k], y["w"][k]), k
+    assert capi.hip.shq_set_inputs_current(ctx.h, 16) != 0       # not a combination of SHQ_CURRENT_*

@@ -19,6 +19,7 @@ from shenqi_amd import capi  # noqa: E402
 n1 = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 nstar = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 nbh = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
+CURRENT = len(sys.argv) > 4 and sys.argv[4] == "current"      # shq_set_inputs_current after the first call: later calls skip the uploads
 BOX = 8.0
 rng = np.random.default_rng(1)
 ngas = n1 ** 3
@@ -103,6 +104,8 @@ def fb():
 
 
 timed("shq_bh_accretion", acc, 1)
+if CURRENT:
+    capi.check(capi.hip.shq_set_inputs_current(c.h, 15))
 timed("shq_bh_feedback", fb, 1)
 # the feedback changed the particle set (garbage): rebuild the gas tree
 tree_g = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
