@@ -959,7 +959,8 @@ def main():
         # with 1e-9 the core flew apart within a few passes and the loop timed another particle distribution (644 instead of 507
         # interactions per target)
         gk = np.full(capi.TIMEBINS + 1, 1e-24)
-        nres = 3
+        nres = 8                                # one refresh period of the tree-order target list (tree_targets_refresh builds): exactly one
+        #                                         of the timed passes rebuilds it, as one step in eight does in a run
         capi.check(capi.hip.shq_set_walk_stats(ctx.h, 0))
         # a sub-step of the hierarchical integrator: no potential update (update_potential = 0, its own kernel instantiation and
         # so its own row in a profile), kicks from the walk's Accel output (AccelStore, timestep.cpp:273)

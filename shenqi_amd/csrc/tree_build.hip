@@ -791,7 +791,7 @@ static int tree_build_impl(shq_context *ctx, double BoxSize, int mask, const int
     if(dom)
         geo = TbGeo{b.geo_child[0].ptr, b.geo_child[1].ptr, b.geo_kind.ptr};
     int level_start[TB_LEVELS + 3];
-    int nn = 0, maxdepth = 0;
+    int nn = 0, maxdepth = 0, h_err = 0;
     size_t cap = (size_t) (0.6 * (double) n) + 4096;
     SHQ_TRY(b.state.reserve((sizeof(TbState) + sizeof(int) - 1) / sizeof(int)));
     TbState *d_state = reinterpret_cast<TbState *>(b.state.ptr);
@@ -826,6 +826,7 @@ static int tree_build_impl(shq_context *ctx, double BoxSize, int mask, const int
         SHQ_HIP(hipGetLastError());
         TbState hs;
         SHQ_HIP(hipMemcpyAsync(&hs, d_state, sizeof(hs), hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipMemcpyAsync(&h_err, b.counters.ptr + 1, sizeof(int), hipMemcpyDeviceToHost, st)); /* one round trip for both */
         SHQ_HIP(hipStreamSynchronize(st));
         if(hs.overflow) {
             cap *= 2;
@@ -837,9 +838,6 @@ static int tree_build_impl(shq_context *ctx, double BoxSize, int mask, const int
             level_start[l] = hs.level_start[l];
         break;
     }
-    int h_err = 0;
-    SHQ_HIP(hipMemcpyAsync(&h_err, b.counters.ptr + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-    SHQ_HIP(hipStreamSynchronize(st));
     SHQ_CHECK(h_err != 3, SHQ_ERR_INVALID, "tree_build: a particle of this rank lies in a top leaf of another task (Bad topleaf, forcetree.cpp:807)");
     SHQ_CHECK(h_err == 0, SHQ_ERR_INVALID, "tree_build: more than %d particles closer than Box/2^%d: deeper than the device build supports",
               SHQ_NMAXCHILD, TB_LEVELS);
