@@ -325,7 +325,9 @@ struct shq_context {
     DevBuf<char> bhw_rec;
     DevBuf<unsigned long long> bhw_ids, bhw_sphsw, bhw_bhsw, bhw_swid;
     DevBuf<double> bhw_rnd, bhw_out;
-    DevBuf<uint8_t> bhw_eeqos, bhw_heated;
+    DevBuf<uint8_t> bhw_eeqos, bhw_heated, bhw_touched;
+    DevBuf<int32_t> bhw_tlist;
+    DevBuf<double> bhw_trows;
     DevBuf<unsigned long long> metal_keys[2];
     DevBuf<double> metal_val[2], metal_star, metal_gd;
     DevBuf<float> metal_gf;
@@ -554,6 +556,7 @@ struct BhWalkArgs {
     uint8_t *pflags;
     const uint8_t *eeqos;      /* sfreff_on_eeqos per particle, or NULL */
     uint8_t *heated;           /* BHHeated per particle (out) */
+    uint8_t *touched;          /* gas particles whose entropy, velocity or flags the feedback walk changed (out; may be NULL) */
     const int32_t *leaf_pidx;
     unsigned long long *sph_swallow; /* by particle index */
     unsigned long long *bh_swallow;  /* by black-hole ordinal */
@@ -602,6 +605,10 @@ int shq_metal_return_device(shq_context *ctx, MetalWalkArgs *w, int kernel_type,
                             int64_t *npairs_out);
 int shq_bh_accretion_device(shq_context *ctx, const shq_kick_factors *kf, const BhWalkArgs *w, const int32_t *d_queue, int64_t nq, double *d_post);
 int shq_bh_feedback_device(shq_context *ctx, const shq_kick_factors *kf, const BhWalkArgs *w, const int32_t *d_queue, int64_t nq);
+/* the particles marked in `mark` (one byte each), ascending, into d_list (room for n entries); *m = their number (one host round trip) */
+int shq_marked_list(shq_context *ctx, const uint8_t *d_mark, int64_t n, int32_t *d_list, int64_t *m);
+/* rows of eight doubles for the particles of d_list: vx, vy, vz, entropy, delay time, mass word of posm, flag byte, `extra` byte (or 0) */
+int shq_rows_gather(shq_context *ctx, const int32_t *d_list, int64_t m, const uint8_t *d_extra, double *d_rows);
 int shq_bh_veldisp_device(shq_context *ctx, const shq_kick_factors *kf, double BoxSize, const int32_t *d_queue, int64_t nq, double *d_out);
 int shq_sph_stellar_density_device(shq_context *ctx, const shq_stellar_params *p, const int32_t *d_queue, int64_t nq, double *d_starvol,
                                    shq_sph_stats *stats);

@@ -24,6 +24,8 @@
  */
 #include "common.hpp"
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <math.h>
 #include <stdlib.h>
 
@@ -3364,6 +3366,8 @@ __global__ __launch_bounds__(256) void bh_feedback_kernel(const SphDev a, const 
                 const double injected = fbenergy * mass_j * wk / fws;
                 if(w.eeqos && w.eeqos[p])
                     w.heated[p] = 1;
+                if(w.touched)
+                    w.touched[p] = 1;
                 const double enttou = pow(w.density[p] * w.P.a3inv, SPH_GAMMA - 1) / (SPH_GAMMA - 1);
                 unsigned long long *eptr = reinterpret_cast<unsigned long long *>(w.entropy + p);
                 unsigned long long oldb = atomicAdd(eptr, 0ull);
@@ -3388,9 +3392,13 @@ __global__ __launch_bounds__(256) void bh_feedback_kernel(const SphDev a, const 
                 const double dir[3] = {sin(theta) * cos(phi), sin(theta) * sin(phi), cos(theta)};
                 for(int j = 0; j < 3; j++)
                     atomicAdd(w.velw + 3 * p + j, dvel * dir[j]);
+                if(w.touched)
+                    w.touched[p] = 1;
             }
         }
         if(mark == myid + 1) {
+            if(w.touched)
+                w.touched[p] = 1;
             accmass += q.w;
             const double4 vp = a.velp[p];
             mom0 += (q.w * vp.x);
@@ -3474,6 +3482,61 @@ int shq_bh_accretion_device(shq_context *ctx, const shq_kick_factors *kf, const 
     }
     SHQ_HIP(hipGetLastError());
     bh_accretion_post_kernel<<<dim3(nblk(nq)), dim3(256), 0, st>>>(nq, d_queue, *w, *kf, ctx->posm.ptr, d_post);
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
+}
+
+namespace {
+struct Marked {
+    const uint8_t *mark;
+    __device__ bool operator()(const int32_t &i) const { return mark[i] != 0; }
+};
+__global__ void rows_gather_kernel(long long m, const int32_t *__restrict__ list, const double *__restrict__ vel, const double *__restrict__ entropy,
+                                   const double *__restrict__ delay, const double4 *__restrict__ posm, const uint8_t *__restrict__ pflags,
+                                   const uint8_t *__restrict__ extra, double *rows)
+{
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= m)
+        return;
+    const long long p = list[t];
+    double *r = rows + 8 * t;
+    r[0] = vel[3 * p];
+    r[1] = vel[3 * p + 1];
+    r[2] = vel[3 * p + 2];
+    r[3] = entropy ? entropy[p] : 0.0;
+    r[4] = delay ? delay[p] : 0.0;
+    r[5] = posm[p].w;
+    r[6] = (double) pflags[p];
+    r[7] = extra ? (double) extra[p] : 0.0;
+}
+} // namespace
+
+int shq_marked_list(shq_context *ctx, const uint8_t *d_mark, int64_t n, int32_t *d_list, int64_t *m)
+{
+    *m = 0;
+    if(n <= 0)
+        return SHQ_OK;
+    hipStream_t st = ctx->stream;
+    SHQ_TRY(ctx->s_counters.reserve(8));
+    unsigned long long *d_count = reinterpret_cast<unsigned long long *>(ctx->s_counters.ptr);
+    size_t tmp = 0;
+    const rocprim::counting_iterator<int32_t> all(0);
+    SHQ_HIP(rocprim::select(nullptr, tmp, all, d_list, d_count, (size_t) n, Marked{d_mark}, st));
+    SHQ_TRY(ctx->tb.temp.reserve(tmp + 16));
+    SHQ_HIP(rocprim::select(ctx->tb.temp.ptr, tmp, all, d_list, d_count, (size_t) n, Marked{d_mark}, st));
+    unsigned long long h = 0;
+    SHQ_HIP(hipMemcpyAsync(&h, d_count, sizeof(h), hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    *m = (int64_t) h;
+    return SHQ_OK;
+}
+
+int shq_rows_gather(shq_context *ctx, const int32_t *d_list, int64_t m, const uint8_t *d_extra, double *d_rows)
+{
+    if(m <= 0)
+        return SHQ_OK;
+    rows_gather_kernel<<<dim3(nblk(m)), dim3(256), 0, ctx->stream>>>(m, d_list, ctx->vel.ptr, ctx->g_entropy.ptr, ctx->g_delaytime.ptr, ctx->posm.ptr,
+                                                                      ctx->pflags.ptr, d_extra, d_rows);
     SHQ_HIP(hipGetLastError());
     return SHQ_OK;
 }

@@ -1175,7 +1175,6 @@ extern "C" int shq_bh_feedback(shq_context *ctx, const shq_tree_view *tree, cons
     SHQ_TRY(bh_upload_common(ctx, tree, parts, sph, ids, rnd_table, rnd_size, S, q));
     hipStream_t st = ctx->stream;
     std::vector<uint64_t> sphsw((size_t) std::max<int64_t>(n, 1), 0), bhsw(std::max<size_t>(nbh, 1), 0), swid(std::max<size_t>(nbh, 1));
-    std::vector<uint8_t> flags0((size_t) std::max<int64_t>(n, 1));
     for(int64_t i = 0; i < n; i++)
         if(*pfield<uint8_t>(parts, i, parts->off_type) == 0 && !(*pfield<uint8_t>(parts, i, parts->off_flags) & 1u)) {
             const int32_t pi = *pfield<int32_t>(parts, i, parts->off_pi);
@@ -1191,53 +1190,70 @@ extern "C" int shq_bh_feedback(shq_context *ctx, const shq_tree_view *tree, cons
     }
     SHQ_TRY(ctx->bhw_eeqos.reserve((size_t) std::max<int64_t>(n, 1)));
     SHQ_TRY(ctx->bhw_heated.reserve((size_t) std::max<int64_t>(n, 1)));
+    SHQ_TRY(ctx->bhw_touched.reserve((size_t) std::max<int64_t>(n, 1)));
+    SHQ_TRY(ctx->bhw_tlist.reserve((size_t) std::max<int64_t>(n, 1)));
+    /* what the walk changes on the neighbours' side comes back as rows of the particles it touched (and of the holes), not as whole
+     * arrays: at 2 x 10^6 particles the five array downloads and the loop over every gas particle were most of this call */
+    std::vector<double> bh0(8 * std::max<size_t>(nbh, 1));
     if(n) {
         if(eeqos)
             SHQ_HIP(hipMemcpyAsync(ctx->bhw_eeqos.ptr, eeqos, (size_t) n, hipMemcpyHostToDevice, st));
         SHQ_HIP(hipMemsetAsync(ctx->bhw_heated.ptr, 0, (size_t) n, st));
-        SHQ_HIP(hipMemcpyAsync(flags0.data(), ctx->pflags.ptr, (size_t) n, hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipMemsetAsync(ctx->bhw_touched.ptr, 0, (size_t) n, st));
+    }
+    SHQ_TRY(ctx->bhw_trows.reserve(8 * std::max<size_t>(nbh, 1)));
+    if(nbh) { /* the holes' flags before the walk */
+        SHQ_TRY(shq_rows_gather(ctx, ctx->bhw_bhp.ptr, (int64_t) nbh, nullptr, ctx->bhw_trows.ptr));
+        SHQ_HIP(hipMemcpyAsync(bh0.data(), ctx->bhw_trows.ptr, sizeof(double) * 8 * nbh, hipMemcpyDeviceToHost, st));
     }
     const int64_t nq = (int64_t) q.size();
     BhWalkArgs w;
     bh_fill_args(ctx, params, rnd_size, nbh, w);
     w.eeqos = eeqos ? ctx->bhw_eeqos.ptr : nullptr;
     w.heated = ctx->bhw_heated.ptr;
+    w.touched = ctx->bhw_touched.ptr;
     SHQ_TRY(shq_bh_feedback_device(ctx, kf, &w, ctx->bhw_queue.ptr, nq));
-    std::vector<double> out(8 * (size_t) std::max<int64_t>(nq, 1)), vel(3 * (size_t) std::max<int64_t>(n, 1)), ent((size_t) std::max<int64_t>(n, 1));
-    std::vector<uint8_t> flags1((size_t) std::max<int64_t>(n, 1)), heated((size_t) std::max<int64_t>(n, 1));
+    int64_t nt = 0;
+    SHQ_TRY(shq_marked_list(ctx, ctx->bhw_touched.ptr, n, ctx->bhw_tlist.ptr, &nt));
+    SHQ_TRY(ctx->bhw_trows.reserve(8 * (size_t) std::max<int64_t>(nt + (int64_t) nbh, 1)));
+    std::vector<double> out(8 * (size_t) std::max<int64_t>(nq, 1)), rows(8 * (size_t) std::max<int64_t>(nt, 1)), bh1(8 * std::max<size_t>(nbh, 1));
+    std::vector<int32_t> tl((size_t) std::max<int64_t>(nt, 1));
     if(nq)
         SHQ_HIP(hipMemcpyAsync(out.data(), ctx->bhw_out.ptr, sizeof(double) * 8 * (size_t) nq, hipMemcpyDeviceToHost, st));
-    if(n) {
-        SHQ_HIP(hipMemcpyAsync(vel.data(), ctx->vel.ptr, sizeof(double) * 3 * (size_t) n, hipMemcpyDeviceToHost, st));
-        SHQ_HIP(hipMemcpyAsync(ent.data(), ctx->g_entropy.ptr, sizeof(double) * (size_t) n, hipMemcpyDeviceToHost, st));
-        SHQ_HIP(hipMemcpyAsync(flags1.data(), ctx->pflags.ptr, (size_t) n, hipMemcpyDeviceToHost, st));
-        SHQ_HIP(hipMemcpyAsync(heated.data(), ctx->bhw_heated.ptr, (size_t) n, hipMemcpyDeviceToHost, st));
+    if(nt) {
+        SHQ_TRY(shq_rows_gather(ctx, ctx->bhw_tlist.ptr, nt, ctx->bhw_heated.ptr, ctx->bhw_trows.ptr));
+        SHQ_HIP(hipMemcpyAsync(rows.data(), ctx->bhw_trows.ptr, sizeof(double) * 8 * (size_t) nt, hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipMemcpyAsync(tl.data(), ctx->bhw_tlist.ptr, sizeof(int32_t) * (size_t) nt, hipMemcpyDeviceToHost, st));
     }
-    if(nbh)
+    if(nbh) {
+        SHQ_TRY(shq_rows_gather(ctx, ctx->bhw_bhp.ptr, (int64_t) nbh, nullptr, ctx->bhw_trows.ptr + 8 * (size_t) nt));
+        SHQ_HIP(hipMemcpyAsync(bh1.data(), ctx->bhw_trows.ptr + 8 * (size_t) nt, sizeof(double) * 8 * nbh, hipMemcpyDeviceToHost, st));
         SHQ_HIP(hipMemcpyAsync(swid.data(), ctx->bhw_swid.ptr, sizeof(uint64_t) * nbh, hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipMemcpyAsync(S.rec.data(), ctx->bhw_rec.ptr, sizeof(BhRec) * nbh, hipMemcpyDeviceToHost, st));
+    }
     SHQ_HIP(hipStreamSynchronize(st));
-    /* the neighbours' side of the walk, into the caller's arrays */
+    /* the neighbours' side of the walk, into the caller's arrays: only tree particles that were gas and no garbage are ever touched */
     int64_t nsph = 0, nbhs = 0;
-    for(int64_t i = 0; i < n; i++) {
-        const unsigned type = *pfield<uint8_t>(parts, i, parts->off_type);
-        if(type == 0 && !(flags0[i] & 1u)) {
-            const int32_t pi = *pfield<int32_t>(parts, i, parts->off_pi);
-            *sfield(sph, pi, sph->off_entropy) = ent[i];
-            double *v = pfield_w<double>(parts, i, parts->off_vel);
-            for(int d = 0; d < 3; d++)
-                v[d] = vel[3 * i + d];
-            if(heated[i])
-                *pfield_w<uint8_t>(parts, i, parts->off_flags) |= 8u; /* BHHeated: bit 3 of the flag byte */
-            if(flags1[i] & 1u) { /* slots_mark_garbage, slotsmanager.cpp:590-599 */
-                *pfield_w<uint8_t>(parts, i, parts->off_flags) |= 1u;
-                *reinterpret_cast<int32_t *>(static_cast<char *>(sph->base) + (size_t) pi * sph->elsize) = (int32_t) (MaxPart + 100);
-                nsph++;
-            }
+    for(int64_t t = 0; t < nt; t++) {
+        const int64_t i = tl[(size_t) t];
+        const double *r = &rows[8 * (size_t) t];
+        SHQ_CHECK(*pfield<uint8_t>(parts, i, parts->off_type) == 0, SHQ_ERR_STATE, "bh_feedback: the walk touched a particle that is not gas");
+        const int32_t pi = *pfield<int32_t>(parts, i, parts->off_pi);
+        *sfield(sph, pi, sph->off_entropy) = r[3];
+        double *v = pfield_w<double>(parts, i, parts->off_vel);
+        for(int d = 0; d < 3; d++)
+            v[d] = r[d];
+        if(r[7] != 0)
+            *pfield_w<uint8_t>(parts, i, parts->off_flags) |= 8u; /* BHHeated: bit 3 of the flag byte */
+        if(((unsigned) r[6] & 1u) && !(*pfield<uint8_t>(parts, i, parts->off_flags) & 1u)) { /* slots_mark_garbage, slotsmanager.cpp:590-599 */
+            *pfield_w<uint8_t>(parts, i, parts->off_flags) |= 1u;
+            *reinterpret_cast<int32_t *>(static_cast<char *>(sph->base) + (size_t) pi * sph->elsize) = (int32_t) (MaxPart + 100);
+            nsph++;
         }
     }
     for(size_t b = 0; b < nbh; b++) {
         const int64_t i = S.bhp[b];
-        if((flags1[i] & 2u) && !(flags0[i] & 2u)) {
+        if(((unsigned) bh1[8 * b + 6] & 2u) && !((unsigned) bh0[8 * b + 6] & 2u)) {
             const int32_t pi = S.pi[b];
             *pfield_w<uint8_t>(parts, i, parts->off_flags) |= 2u; /* Swallowed */
             *bhfield<uint64_t>(bh, pi, bh->off_swallowid) = swid[b];
@@ -1247,12 +1263,6 @@ extern "C" int shq_bh_feedback(shq_context *ctx, const shq_tree_view *tree, cons
         }
     }
     /* blackhole_feedback_reduce (PRIMARY); blackhole_feedback_postprocess (:929-965) ran on the device: its results come back */
-    std::vector<double4> hposm((size_t) std::max<int64_t>(n, 1));
-    if(nq) {
-        SHQ_HIP(hipMemcpyAsync(S.rec.data(), ctx->bhw_rec.ptr, sizeof(BhRec) * nbh, hipMemcpyDeviceToHost, st));
-        SHQ_HIP(hipMemcpyAsync(hposm.data(), ctx->posm.ptr, sizeof(double4) * (size_t) n, hipMemcpyDeviceToHost, st));
-        SHQ_HIP(hipStreamSynchronize(st));
-    }
     for(int64_t t = 0; t < nq; t++) {
         const int32_t i = q[t];
         const size_t b = (size_t) (std::lower_bound(S.bhp.begin(), S.bhp.end(), i) - S.bhp.begin());
@@ -1270,8 +1280,8 @@ extern "C" int shq_bh_feedback(shq_context *ctx, const shq_tree_view *tree, cons
         *bhfield<double>(bh, pi, bh->off_kineticfdbkenergy) = R.KineticFdbkEnergy;
         double *v = pfield_w<double>(parts, i, parts->off_vel);
         for(int d = 0; d < 3; d++)
-            v[d] = vel[3 * (size_t) i + d];
-        *pfield_w<float>(parts, i, parts->off_mass) = (float) hposm[(size_t) i].w;
+            v[d] = bh1[8 * b + d];
+        *pfield_w<float>(parts, i, parts->off_mass) = (float) bh1[8 * b + 5];
     }
     if(n_sph_swallowed)
         *n_sph_swallowed = nsph;
@@ -1285,24 +1295,32 @@ namespace {
 /* Vel, Entropy, DelayTime of the kicked particles (the first of every run of the sorted list) back into the caller's arrays */
 int winds_kicked_back(shq_context *ctx, const shq_part_view *parts, const shq_sph_view *sph, const std::vector<shq_wind_kick> &K)
 {
-    const int64_t n = parts->numpart;
     hipStream_t st = ctx->stream;
-    std::vector<double> hv(3 * (size_t) n), he((size_t) n), hdl((size_t) n);
-    SHQ_HIP(hipMemcpyAsync(hv.data(), ctx->vel.ptr, sizeof(double) * 3 * (size_t) n, hipMemcpyDeviceToHost, st));
-    SHQ_HIP(hipMemcpyAsync(he.data(), ctx->g_entropy.ptr, sizeof(double) * (size_t) n, hipMemcpyDeviceToHost, st));
-    SHQ_HIP(hipMemcpyAsync(hdl.data(), ctx->g_delaytime.ptr, sizeof(double) * (size_t) n, hipMemcpyDeviceToHost, st));
-    SHQ_HIP(hipStreamSynchronize(st));
+    /* rows of the kicked particles only (the arrays are N long, the kicked a few per cent of the gas) */
+    std::vector<int32_t> list;
     int32_t last = -1;
-    for(const shq_wind_kick &k : K) {
-        if(k.part_index == last)
-            continue;
-        const int32_t other = last = k.part_index;
+    for(const shq_wind_kick &k : K)
+        if(k.part_index != last)
+            list.push_back(last = k.part_index);
+    const size_t m = list.size();
+    if(m == 0)
+        return SHQ_OK;
+    SHQ_TRY(ctx->bhw_tlist.reserve(m));
+    SHQ_TRY(ctx->bhw_trows.reserve(8 * m));
+    std::vector<double> rows(8 * m);
+    SHQ_HIP(hipMemcpyAsync(ctx->bhw_tlist.ptr, list.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, st));
+    SHQ_TRY(shq_rows_gather(ctx, ctx->bhw_tlist.ptr, (int64_t) m, nullptr, ctx->bhw_trows.ptr));
+    SHQ_HIP(hipMemcpyAsync(rows.data(), ctx->bhw_trows.ptr, sizeof(double) * 8 * m, hipMemcpyDeviceToHost, st));
+    SHQ_HIP(hipStreamSynchronize(st));
+    for(size_t t = 0; t < m; t++) {
+        const int32_t other = list[t];
+        const double *r = &rows[8 * t];
         const int32_t pi = *pfield<int32_t>(parts, other, parts->off_pi);
         double *v = pfield_w<double>(parts, other, parts->off_vel);
         for(int j = 0; j < 3; j++)
-            v[j] = hv[3 * (size_t) other + j];
-        *sfield(sph, pi, sph->off_entropy) = he[(size_t) other];
-        *sfield(sph, pi, sph->off_delaytime) = hdl[(size_t) other];
+            v[j] = r[j];
+        *sfield(sph, pi, sph->off_entropy) = r[3];
+        *sfield(sph, pi, sph->off_delaytime) = r[4];
     }
     return SHQ_OK;
 }
