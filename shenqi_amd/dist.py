@@ -279,7 +279,7 @@ def balanced_bounds(comm, Nmesh, BoxSize, x, weights=None, plane_cost=0.0, y=Non
             k = 0
         elif k < Nmesh and want[r] - (cy[k - 1] if k > 0 else 0.0) >= cy[k] - want[r]:
             k = k + 1                                                 # with row k the left rank comes closer to its share
-        ycuts.append(k * cell)
+        ycuts.append(min(k * cell, float(BoxSize)))
     ycuts.append(0.0)
     return bounds, ycuts
 

@@ -405,24 +405,28 @@ def test_dist_winds_two_gloo_ranks_one_gpu():
         assert all(r["nghost"] > 0 for r in results)
 
 
-def test_bench_driver_command_two_gloo_ranks():
+@pytest.mark.parametrize("ngrid,total,shared", [(32, 40, False), (26, 32, True)])
+def test_bench_driver_command_two_gloo_ranks(ngrid, total, shared):
     """The driver's own multi-GPU command — `python bench.py --gpus 2`, which starts its ranks through torch.distributed.run
     (bench.launch_ranks) — rehearsed on the one-GPU box with SHQ_BENCH_BACKEND=gloo (both ranks share device 0, exchanges staged
     through the host): one JSON line on stdout, whole-job value, weak scaling, the sharded walk's roofline, and the sampled
-    force check of the global particle set against direct summation."""
+    force check of the global particle set against direct summation.  ngrid 26 -> 32^3 particles on a 96 mesh, which has the
+    library's own transforms: there the rebalanced slabs share the plane the cut falls in (config.slab_ycuts)."""
     import json
     import subprocess
     env = dict(os.environ, SHQ_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--ngrid", "32", "--steps", "1", "--warmup", "0"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--ngrid", str(ngrid), "--steps", "1", "--warmup", "0"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "particle-steps/s" and out["value"] > 0
-    assert out["config"]["particles_total"] == 40**3          # 32^3 per GPU, rounded to a multiple of 2 x ranks per dimension
+    assert out["config"]["particles_total"] == total**3       # ngrid^3 per GPU, rounded to a multiple of 2 x ranks per dimension
+    yc = out["config"]["slab_ycuts"]
+    assert (yc is not None and len(yc) == 3 and yc[0] == 0 and yc[2] == 0) if shared else yc is None, yc
     assert out["roofline"]["bound"] == "valu-f64" and 0 < out["roofline"]["frac"] < 1
     fe = out["force_error"]
     assert "mean" in fe, fe
