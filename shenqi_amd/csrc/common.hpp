@@ -609,6 +609,7 @@ int shq_bh_feedback_device(shq_context *ctx, const shq_kick_factors *kf, const B
 int shq_marked_list(shq_context *ctx, const uint8_t *d_mark, int64_t n, int32_t *d_list, int64_t *m);
 /* rows of eight doubles for the particles of d_list: vx, vy, vz, entropy, delay time, mass word of posm, flag byte, `extra` byte (or 0) */
 int shq_rows_gather(shq_context *ctx, const int32_t *d_list, int64_t m, const uint8_t *d_extra, double *d_rows);
+int shq_u64_gather(shq_context *ctx, const int32_t *d_list, int64_t m, const unsigned long long *d_src, unsigned long long *d_out);
 int shq_bh_veldisp_device(shq_context *ctx, const shq_kick_factors *kf, double BoxSize, const int32_t *d_queue, int64_t nq, double *d_out);
 int shq_sph_stellar_density_device(shq_context *ctx, const shq_stellar_params *p, const int32_t *d_queue, int64_t nq, double *d_starvol,
                                    shq_sph_stats *stats);

@@ -3170,6 +3170,8 @@ __global__ __launch_bounds__(256) void bh_accretion_kernel(const SphDev a, const
             const double rn = w.rnd[w.ids[p] % w.rndsize];
             if(rn < pacc)
                 atomicMax(w.sph_swallow + p, myid + 1); /* "prefer to be swallowed by a bigger ID" */
+                if(w.touched)
+                    w.touched[p] = 1;
             fws += (mass_j * wk);
             if(w.P.BlackHoleKineticOn == 1)
                 mgas += mass_j;
@@ -3528,6 +3530,24 @@ int shq_marked_list(shq_context *ctx, const uint8_t *d_mark, int64_t n, int32_t 
     SHQ_HIP(hipMemcpyAsync(&h, d_count, sizeof(h), hipMemcpyDeviceToHost, st));
     SHQ_HIP(hipStreamSynchronize(st));
     *m = (int64_t) h;
+    return SHQ_OK;
+}
+
+namespace {
+__global__ void u64_gather_kernel(long long m, const int32_t *__restrict__ list, const unsigned long long *__restrict__ src, unsigned long long *out)
+{
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t < m)
+        out[t] = src[list[t]];
+}
+} // namespace
+
+int shq_u64_gather(shq_context *ctx, const int32_t *d_list, int64_t m, const unsigned long long *d_src, unsigned long long *d_out)
+{
+    if(m <= 0)
+        return SHQ_OK;
+    u64_gather_kernel<<<dim3(nblk(m)), dim3(256), 0, ctx->stream>>>(m, d_list, d_src, d_out);
+    SHQ_HIP(hipGetLastError());
     return SHQ_OK;
 }
 

@@ -1112,20 +1112,34 @@ extern "C" int shq_bh_accretion(shq_context *ctx, const shq_tree_view *tree, con
     BhWalkArgs w;
     bh_fill_args(ctx, params, rnd_size, nbh, w);
     w.Ti_Current = Ti_Current;
+    /* the gas particles the walk marks come back as a list (a few thousand of N) */
+    SHQ_TRY(ctx->bhw_touched.reserve((size_t) std::max<int64_t>(n, 1)));
+    SHQ_TRY(ctx->bhw_tlist.reserve((size_t) std::max<int64_t>(n, 1)));
+    SHQ_HIP(hipMemsetAsync(ctx->bhw_touched.ptr, 0, (size_t) n, st));
+    w.touched = ctx->bhw_touched.ptr;
     double *d_post = ctx->bhw_out.ptr + 8 * (size_t) nqueue;
     SHQ_TRY(shq_bh_accretion_device(ctx, kf, &w, ctx->bhw_queue.ptr, nqueue, d_post));
+    int64_t nt = 0;
+    SHQ_TRY(shq_marked_list(ctx, ctx->bhw_touched.ptr, n, ctx->bhw_tlist.ptr, &nt));
+    SHQ_TRY(ctx->bhw_trows.reserve((size_t) std::max<int64_t>(nt, 1)));
+    unsigned long long *d_marks = reinterpret_cast<unsigned long long *>(ctx->bhw_trows.ptr);
     std::vector<double> out(16 * (size_t) nqueue);
-    std::vector<uint64_t> sphsw((size_t) std::max<int64_t>(n, 1)), bhsw(std::max<size_t>(nbh, 1));
+    std::vector<uint64_t> marks((size_t) std::max<int64_t>(nt, 1)), bhsw(std::max<size_t>(nbh, 1));
+    std::vector<int32_t> tl((size_t) std::max<int64_t>(nt, 1));
     SHQ_HIP(hipMemcpyAsync(out.data(), ctx->bhw_out.ptr, sizeof(double) * out.size(), hipMemcpyDeviceToHost, st));
     SHQ_HIP(hipMemcpyAsync(S.rec.data(), ctx->bhw_rec.ptr, sizeof(BhRec) * nbh, hipMemcpyDeviceToHost, st));
-    SHQ_HIP(hipMemcpyAsync(sphsw.data(), ctx->bhw_sphsw.ptr, sizeof(uint64_t) * (size_t) n, hipMemcpyDeviceToHost, st));
+    if(nt) {
+        SHQ_TRY(shq_u64_gather(ctx, ctx->bhw_tlist.ptr, nt, ctx->bhw_sphsw.ptr, d_marks));
+        SHQ_HIP(hipMemcpyAsync(marks.data(), d_marks, sizeof(uint64_t) * (size_t) nt, hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipMemcpyAsync(tl.data(), ctx->bhw_tlist.ptr, sizeof(int32_t) * (size_t) nt, hipMemcpyDeviceToHost, st));
+    }
     SHQ_HIP(hipMemcpyAsync(bhsw.data(), ctx->bhw_bhsw.ptr, sizeof(uint64_t) * nbh, hipMemcpyDeviceToHost, st));
     SHQ_HIP(hipStreamSynchronize(st));
-    for(int64_t i = 0; i < n; i++)
-        if(sphsw[i]) {
-            SHQ_CHECK(*pfield<uint8_t>(parts, i, parts->off_type) == 0, SHQ_ERR_STATE, "bh_accretion: a swallow mark on a particle that is not gas");
-            work->SPH_SwallowID[*pfield<int32_t>(parts, i, parts->off_pi)] = sphsw[i];
-        }
+    for(int64_t t = 0; t < nt; t++) {
+        const int64_t i = tl[(size_t) t];
+        SHQ_CHECK(*pfield<uint8_t>(parts, i, parts->off_type) == 0, SHQ_ERR_STATE, "bh_accretion: a swallow mark on a particle that is not gas");
+        work->SPH_SwallowID[*pfield<int32_t>(parts, i, parts->off_pi)] = marks[(size_t) t];
+    }
     for(size_t b = 0; b < nbh; b++)
         if(bhsw[b])
             work->BH_SwallowID[S.pi[b]] = bhsw[b];

@@ -106,6 +106,7 @@ def fb():
 timed("shq_bh_accretion", acc, 1)
 if CURRENT:
     capi.check(capi.hip.shq_set_inputs_current(c.h, 15))
+timed("shq_bh_accretion", acc, 1)          # the second call: no first-use allocations; with `current`, no uploads either
 timed("shq_bh_feedback", fb, 1)
 # the feedback changed the particle set (garbage): rebuild the gas tree
 tree_g = sq.force_tree_rebuild_mask(pman, sq.GASMASK)
