@@ -600,7 +600,10 @@ struct MetalWalkArgs {
     /* gas state by particle index */
     float *gmass, *gmetals;
     double *gdensity, *gmetallicity;
+    uint8_t *touched;              /* gas particles the return changed (out; may be NULL) */
 };
+/* rows of 3 + SHQ_NMETALS doubles for the gas particles of d_list: mass, density, metallicity, metals */
+int shq_metal_rows_gather(shq_context *ctx, const MetalWalkArgs *w, const int32_t *d_list, int64_t m, double *d_rows);
 int shq_metal_return_device(shq_context *ctx, MetalWalkArgs *w, int kernel_type, double BoxSize, const int32_t *d_queue, int64_t nq, double *d_massreturn,
                             int64_t *npairs_out);
 int shq_bh_accretion_device(shq_context *ctx, const shq_kick_factors *kf, const BhWalkArgs *w, const int32_t *d_queue, int64_t nq, double *d_post);

@@ -3897,6 +3897,22 @@ __global__ void metal_apply_kernel(long long npairs, const unsigned long long *_
     w.gmetallicity[p] = metallicity;
     for(int i = 0; i < SHQ_NMETALS; i++)
         w.gmetals[(size_t) p * SHQ_NMETALS + i] = metals[i];
+    if(w.touched)
+        w.touched[p] = 1;
+}
+
+__global__ void metal_rows_gather_kernel(long long m, const int32_t *__restrict__ list, const MetalWalkArgs w, double *rows)
+{
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= m)
+        return;
+    const size_t p = (size_t) list[t];
+    double *r = rows + (size_t) (3 + SHQ_NMETALS) * t;
+    r[0] = (double) w.gmass[p];
+    r[1] = w.gdensity[p];
+    r[2] = w.gmetallicity[p];
+    for(int i = 0; i < SHQ_NMETALS; i++)
+        r[3 + i] = (double) w.gmetals[p * SHQ_NMETALS + i];
 }
 
 __global__ void metal_rekey_kernel(long long npairs, const unsigned long long *keys, unsigned long long *out)
@@ -3920,6 +3936,15 @@ __global__ void metal_sum_kernel(long long npairs, const unsigned long long *__r
     for(long long k = k0; k < npairs && (unsigned) (keys_tp[k] >> 32) == t; k++)
         s += thismass[k];
     massreturn[t] = s;
+}
+
+int shq_metal_rows_gather(shq_context *ctx, const MetalWalkArgs *w, const int32_t *d_list, int64_t m, double *d_rows)
+{
+    if(m <= 0)
+        return SHQ_OK;
+    metal_rows_gather_kernel<<<dim3(nblk(m)), dim3(256), 0, ctx->stream>>>(m, d_list, *w, d_rows);
+    SHQ_HIP(hipGetLastError());
+    return SHQ_OK;
 }
 
 int shq_metal_return_device(shq_context *ctx, MetalWalkArgs *w, int kernel_type, double BoxSize, const int32_t *d_queue, int64_t nq, double *d_massreturn, int64_t *npairs_out)

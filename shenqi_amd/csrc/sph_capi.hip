@@ -1581,22 +1581,36 @@ extern "C" int shq_metal_return(shq_context *ctx, const shq_tree_view *tree, con
     w.gmetals = ctx->metal_gf.ptr + cap;
     w.gdensity = ctx->metal_gd.ptr;
     w.gmetallicity = ctx->metal_gd.ptr + cap;
+    /* the gas the return changes comes back as rows of the particles it touched */
+    SHQ_TRY(ctx->bhw_touched.reserve(cap));
+    SHQ_TRY(ctx->bhw_tlist.reserve(cap));
+    SHQ_HIP(hipMemsetAsync(ctx->bhw_touched.ptr, 0, cap, st));
+    w.touched = ctx->bhw_touched.ptr;
     SHQ_TRY(shq_metal_return_device(ctx, &w, DensityKernelType, tree->BoxSize, ctx->bhw_queue.ptr, nq, ds + 3 * nq, npairs));
-    std::vector<float> gf1(gf.size());
-    std::vector<double> gd1(gd.size());
+    int64_t nt = 0;
+    SHQ_TRY(shq_marked_list(ctx, ctx->bhw_touched.ptr, n, ctx->bhw_tlist.ptr, &nt));
+    const size_t W = 3 + SHQ_NMETALS;
+    SHQ_TRY(ctx->bhw_trows.reserve(W * (size_t) std::max<int64_t>(nt, 1)));
+    std::vector<double> rows(W * (size_t) std::max<int64_t>(nt, 1));
+    std::vector<int32_t> tl((size_t) std::max<int64_t>(nt, 1));
     SHQ_HIP(hipMemcpyAsync(MassReturn, ds + 3 * nq, sizeof(double) * (size_t) nq, hipMemcpyDeviceToHost, st));
-    SHQ_HIP(hipMemcpyAsync(gf1.data(), ctx->metal_gf.ptr, sizeof(float) * gf.size(), hipMemcpyDeviceToHost, st));
-    SHQ_HIP(hipMemcpyAsync(gd1.data(), ctx->metal_gd.ptr, sizeof(double) * gd.size(), hipMemcpyDeviceToHost, st));
+    if(nt) {
+        SHQ_TRY(shq_metal_rows_gather(ctx, &w, ctx->bhw_tlist.ptr, nt, ctx->bhw_trows.ptr));
+        SHQ_HIP(hipMemcpyAsync(rows.data(), ctx->bhw_trows.ptr, sizeof(double) * W * (size_t) nt, hipMemcpyDeviceToHost, st));
+        SHQ_HIP(hipMemcpyAsync(tl.data(), ctx->bhw_tlist.ptr, sizeof(int32_t) * (size_t) nt, hipMemcpyDeviceToHost, st));
+    }
     SHQ_HIP(hipStreamSynchronize(st));
-    for(int64_t i = 0; i < n; i++) {
-        if(*pfield<uint8_t>(parts, i, parts->off_type) != 0 || (*pfield<uint8_t>(parts, i, parts->off_flags) & 1u))
-            continue;
+    for(int64_t t = 0; t < nt; t++) {
+        const int64_t i = tl[(size_t) t];
+        const double *r = &rows[W * (size_t) t];
+        SHQ_CHECK(*pfield<uint8_t>(parts, i, parts->off_type) == 0 && !(*pfield<uint8_t>(parts, i, parts->off_flags) & 1u), SHQ_ERR_STATE,
+                  "metal_return: the walk touched a particle that is not live gas");
         char *s = slot(i);
-        *pfield_w<float>(parts, i, parts->off_mass) = gf1[i];
-        *reinterpret_cast<double *>(s + gas->off_density) = gd1[i];
-        *reinterpret_cast<double *>(s + gas->off_metallicity) = gd1[cap + i];
+        *pfield_w<float>(parts, i, parts->off_mass) = (float) r[0];
+        *reinterpret_cast<double *>(s + gas->off_density) = r[1];
+        *reinterpret_cast<double *>(s + gas->off_metallicity) = r[2];
         for(int m = 0; m < SHQ_NMETALS; m++)
-            reinterpret_cast<float *>(s + gas->off_metals)[m] = gf1[cap + (size_t) i * SHQ_NMETALS + m];
+            reinterpret_cast<float *>(s + gas->off_metals)[m] = (float) r[3 + m];
     }
     /* the gas masses (and densities) changed in the caller's records only: the context's particle and SPH copies are no longer the views */
     ctx->inputs_current &= ~(SHQ_CURRENT_PARTICLES | SHQ_CURRENT_SPH);
