@@ -341,6 +341,9 @@ template <class F> __device__ __forceinline__ void nl_flush(const int32_t *myl, 
  *   - accepted candidates go to the lane's list (see above) and are evaluated lane by lane.
  * Leaves are queued and tiles are scanned in walk order, so each lane still meets its neighbours in
  * depth-first order. */
+#ifndef SPH_NODE_SCALAR
+#define SPH_NODE_SCALAR 0 /* 1: the walk reads the node under its cursor with scalar loads instead of from an LDS window (A/B knob) */
+#endif
 #ifndef SPH_PROBE
 #define SPH_PROBE 0 /* timing probes of the walk kernels (tools/sph_ab.sh with build_variant.sh): never in a shipped build */
 #endif
@@ -388,6 +391,10 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
     typedef const float __attribute__((address_space(4))) *FloatK;
     typedef const int32_t __attribute__((address_space(4))) *IntK;
     typedef __attribute__((address_space(1))) char *GChar;
+    typedef const double __attribute__((address_space(4))) *DoubleK;
+    const DoubleK nodeBK = (DoubleK) (size_t) a.nodeB, hmaxK = (DoubleK) (size_t) a.hmax;
+    const IntK nodeCK = (IntK) (size_t) a.nodeC;
+    (void) nodeBK; (void) hmaxK; (void) nodeCK;
     const FloatK posfK = (FloatK) (size_t) a.posf_leaf;
     auto ldrec = [&](const int slot) { return make_float4(posfK[4 * slot], posfK[4 * slot + 1], posfK[4 * slot + 2], posfK[4 * slot + 3]); };
     const IntK ngarbK = (IntK) (size_t) a.ngarb_leaf;
@@ -543,6 +550,14 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
      * never booleans the compiler would materialise as masks of their own; one window test; the lanes' links are set before the
      * leaf is handed on, so that nothing after the hand-over depends on it. */
     while(cur >= 0) {
+#if SPH_NODE_SCALAR
+        /* the node under the cursor through the scalar cache into scalar registers (as the gravity walk reads its nodes): no LDS window,
+         * no refills, no read-first-lanes; the tests take the record's fields as scalar operands */
+        const double4 B = make_double4(nodeBK[4 * (size_t) cur], nodeBK[4 * (size_t) cur + 1], nodeBK[4 * (size_t) cur + 2], nodeBK[4 * (size_t) cur + 3]);
+        const int Csib = nodeCK[4 * (size_t) cur], Cchild = nodeCK[4 * (size_t) cur + 1];
+        const int Ctype = nodeCK[4 * (size_t) cur + 2], Ccount = nodeCK[4 * (size_t) cur + 3];
+        const double Hnode = SYM ? hmaxK[(size_t) cur] : 0.0;
+#else
         if((unsigned int) (cur - wbase) >= (unsigned int) NW_WIN) {
             wbase = cur;
             __builtin_amdgcn_wave_barrier();
@@ -562,11 +577,13 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
         const int4 Cv = winC[w];
         const int Csib = __builtin_amdgcn_readfirstlane(Cv.x), Cchild = __builtin_amdgcn_readfirstlane(Cv.y);
         const int Ctype = __builtin_amdgcn_readfirstlane(Cv.z), Ccount = __builtin_amdgcn_readfirstlane(Cv.w);
+        const double Hnode = SYM ? winH[w] : 0.0;
+#endif
         if(dbg)
             dbg[0]++;
         /* cull_node<symmetric>, localtreewalk2.h:154-182 */
         const unsigned long long actm = shq_ballot(mynext == cur);
-        const double dist = (SYM ? fmax(winH[w], h) : h) + 0.5 * B.w;
+        const double dist = (SYM ? fmax(Hnode, h) : h) + 0.5 * B.w;
         double dx = B.x - px, dy = B.y - py, dz = B.z - pz;
         double dmax = fmax(fmax(fabs(dx), fabs(dy)), fabs(dz));
         const unsigned long long wrapm = shq_ballot(dmax > halfBox) & actm;
