@@ -422,10 +422,13 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_inv(double *mesh, const int 
         FFT_FETCH(tf)
         fft_lines<N, +1>(buf, Wl);
         const long long row0 = (long long) t * (2 * FFT_C);
-        for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T) {
-            const int r = e / H, z = 2 * (e % H);
-            const double *src = reinterpret_cast<const double *>(buf + (r >> 1) * LS + lx<N>(z)) + (r & 1);
-            cm[(row0 + r) * zpc + (z >> 1)] = make_double2(src[0], src[2]);
+        /* a thread takes the elements z, z + 1 of one line (two 16-byte LDS reads, consecutive lanes 32 bytes apart: no bank conflicts;
+         * the 8-byte reads of one row's real parts, 32 bytes apart, met four to a bank) and stores them to the line's two real rows */
+        for(int e = threadIdx.x; e < FFT_C * H; e += FFT_T) {
+            const int l = e / H, zz = e - l * H;
+            const double2 u0 = buf[l * LS + lx<N>(2 * zz)], u1 = buf[l * LS + lx<N>(2 * zz + 1)];
+            cm[(row0 + 2 * l) * zpc + zz] = make_double2(u0.x, u1.x);
+            cm[(row0 + 2 * l + 1) * zpc + zz] = make_double2(u0.y, u1.y);
         }
         if(!more)
             break;
@@ -571,22 +574,25 @@ __global__ __launch_bounds__(FFT_T) void fft_t_z_fwd(const double *mesh, double2
 {
     extern __shared__ double2 buf[];
     constexpr int LS = fft_ls(N), H = N / 2, Nc = N / 2 + 1;
-    constexpr int E = (FFT_C * N + FFT_T - 1) / FFT_T;
-    constexpr bool EXACT = E * FFT_T == FFT_C * N;
-    static_assert(FFT_C == 4, "the layouts are written for tiles of 4 lines");
+    constexpr int E = (FFT_C * H + FFT_T - 1) / FFT_T; /* a thread takes the elements z, z + 1 of BOTH real rows of a line (the line's */
+    constexpr bool EXACT = E * FFT_T == FFT_C * H;     /* entries z, z + 1 are then two 16-byte LDS stores; 8-byte stores 32 bytes apart */
+    static_assert(FFT_C == 4, "the layouts are written for tiles of 4 lines"); /* met four to a bank) */
     double2 *Wl = lds_twiddles<N>(buf, W);
     const double2 *cm = reinterpret_cast<const double2 *>(mesh);
     const int zpc = zp / 2, nzb = zpc / 4;
-    double pa[E], pb[E];
+    double pa[E], pb[E], pc[E], pd[E];
 #define FFT_FETCH(T_)                                                                            \
     _Pragma("unroll") for(int i = 0; i < E; i++)                                                 \
     {                                                                                            \
         const int e = threadIdx.x + i * FFT_T;                                                   \
-        if(EXACT || e < FFT_C * N) {                                                             \
-            const long long row = (long long) (T_) * (2 * FFT_C) + e / H;                        \
-            const double2 v_ = cm[row * zpc + (e % H)];                                          \
+        if(EXACT || e < FFT_C * H) {                                                             \
+            const int l_ = e / H;                                                                \
+            const long long row = (long long) (T_) * (2 * FFT_C) + 2 * l_;                       \
+            const double2 v_ = cm[row * zpc + (e - l_ * H)], w_ = cm[(row + 1) * zpc + (e - l_ * H)]; \
             pa[i] = v_.x;                                                                        \
             pb[i] = v_.y;                                                                        \
+            pc[i] = w_.x;                                                                        \
+            pd[i] = w_.y;                                                                        \
         }                                                                                        \
     }
     int t = blockIdx.x;
@@ -597,16 +603,17 @@ __global__ __launch_bounds__(FFT_T) void fft_t_z_fwd(const double *mesh, double2
 #pragma unroll
         for(int i = 0; i < E; i++) {
             const int e = threadIdx.x + i * FFT_T;
-            if(EXACT || e < FFT_C * N) {
-                const int r = e / H, z = 2 * (e % H);
-                double a = pa[i], b = pb[i];
+            if(EXACT || e < FFT_C * H) {
+                const int l = e / H, z = 2 * (e - l * H);
+                double a = pa[i], b = pb[i], c = pc[i], d = pd[i];
                 if(FROM_I64) {
                     a = (double) __double_as_longlong(a) * inv_scale;
                     b = (double) __double_as_longlong(b) * inv_scale;
+                    c = (double) __double_as_longlong(c) * inv_scale;
+                    d = (double) __double_as_longlong(d) * inv_scale;
                 }
-                double *dst = reinterpret_cast<double *>(buf + (r >> 1) * LS + lx<N>(z)) + (r & 1);
-                dst[0] = a;
-                dst[2] = b;
+                buf[l * LS + lx<N>(z)] = make_double2(a, c);
+                buf[l * LS + lx<N>(z + 1)] = make_double2(b, d);
             }
         }
         __syncthreads();
@@ -697,10 +704,13 @@ __global__ __launch_bounds__(FFT_T) void fft_t_z_inv(const double2 *__restrict__
         FFT_FETCH(tf)
         fft_lines<N, +1>(buf, Wl);
         const long long row0 = (long long) t * (2 * FFT_C);
-        for(int e = threadIdx.x; e < FFT_C * N; e += FFT_T) {
-            const int r = e / H, z = 2 * (e % H);
-            const double *src = reinterpret_cast<const double *>(buf + (r >> 1) * LS + lx<N>(z)) + (r & 1);
-            cm[(row0 + r) * zpc + (z >> 1)] = make_double2(src[0], src[2]);
+        /* a thread takes the elements z, z + 1 of one line (two 16-byte LDS reads, consecutive lanes 32 bytes apart: no bank conflicts;
+         * the 8-byte reads of one row's real parts, 32 bytes apart, met four to a bank) and stores them to the line's two real rows */
+        for(int e = threadIdx.x; e < FFT_C * H; e += FFT_T) {
+            const int l = e / H, zz = e - l * H;
+            const double2 u0 = buf[l * LS + lx<N>(2 * zz)], u1 = buf[l * LS + lx<N>(2 * zz + 1)];
+            cm[(row0 + 2 * l) * zpc + zz] = make_double2(u0.x, u1.x);
+            cm[(row0 + 2 * l + 1) * zpc + zz] = make_double2(u0.y, u1.y);
         }
         if(!more)
             break;
