@@ -667,14 +667,16 @@ __global__ __launch_bounds__(FFT_T) void fft_t_z_inv(const double2 *__restrict__
         {                                                                                        \
             const int e = threadIdx.x + i * FFT_T;                                               \
             const int zb = e >> 4, l = (e >> 2) & 3, c = e & 3, k = 4 * zb + c;                  \
-            if(e < nslots && k < Nc) {                                                           \
-                const double2 *p_ = in + (((long long) x_ * nzb + zb) * N + (y0_ + 2 * l)) * 4 + c; \
-                const double2 xa_ = p_[0], xb_ = p_[4];                                          \
-                ax[i] = xa_.x;                                                                   \
-                ay[i] = xa_.y;                                                                   \
-                bx[i] = xb_.x;                                                                   \
-                by[i] = xb_.y;                                                                   \
-            }                                                                                    \
+            /* no branch around the loads: an unused slot reads the tile's first entry instead.  With the loads under the slot's  \
+             * condition the compiler ended every pair with s_waitcnt vmcnt(0) (the values pass into loop-carried registers at the \
+             * join) and the "prefetch" was seven round trips to memory one after the other */                                     \
+            const bool ok_ = e < nslots && k < Nc;                                               \
+            const double2 *p_ = in + (((long long) x_ * nzb + (ok_ ? zb : 0)) * N + (y0_ + 2 * l)) * 4 + (ok_ ? c : 0); \
+            const double2 xa_ = p_[0], xb_ = p_[4];                                              \
+            ax[i] = xa_.x;                                                                       \
+            ay[i] = xa_.y;                                                                       \
+            bx[i] = xb_.x;                                                                       \
+            by[i] = xb_.y;                                                                       \
         }                                                                                        \
     }
     int t = blockIdx.x;
@@ -686,6 +688,10 @@ __global__ __launch_bounds__(FFT_T) void fft_t_z_inv(const double2 *__restrict__
         for(int i = 0; i < EMAX; i++) {
             const int e = threadIdx.x + i * FFT_T;
             const int zb = e >> 4, l = (e >> 2) & 3, c = e & 3, k = 4 * zb + c;
+            /* all four components stay alive up to here: the last slot group's imaginary parts are never used (its only column is
+             * N / 2), and the compiler handed their halves of the in-flight 16-byte loads to the first stage's temporaries - a write
+             * after write that made the stage wait for the whole prefetch */
+            asm volatile("" ::"v"(ax[i]), "v"(ay[i]), "v"(bx[i]), "v"(by[i]));
             if(e < nslots && k < Nc) {
                 double2 xa = make_double2(ax[i], ay[i]), xb = make_double2(bx[i], by[i]);
                 if(k == 0 || 2 * k == N) {
