@@ -314,8 +314,8 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_fwd(double *mesh, const int 
 #define FFT_FETCH(T_)                                                                            \
     _Pragma("unroll") for(int i = 0; i < E; i++)                                                 \
     {                                                                                            \
-        const int e = threadIdx.x + i * FFT_T;                                                   \
-        if(EXACT || e < FFT_C * N) {                                                             \
+        const int e_ = threadIdx.x + i * FFT_T, e = (EXACT || e_ < FFT_C * N) ? e_ : 0; /* no branch around the loads: see fft_t_z_inv */ \
+        { \
             const long long row = (long long) (T_) * (2 * FFT_C) + e / H;                        \
             const double2 v_ = cm[row * zpc + (e % H)];                                          \
             pa[i] = v_.x;                                                                        \
@@ -383,16 +383,15 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_inv(double *mesh, const int 
 #define FFT_FETCH(T_)                                                                            \
     _Pragma("unroll") for(int i = 0; i < E; i++)                                                 \
     {                                                                                            \
-        const int e = threadIdx.x + i * FFT_T;                                                   \
-        if(e < FFT_C * Nc) {                                                                     \
-            const int l = e / Nc, k = e - l * Nc;                                                \
-            const long long ra = (long long) (T_) * (2 * FFT_C) + 2 * l;                         \
-            const double2 xa_ = cm[ra * zpc + k], xb_ = cm[(ra + 1) * zpc + k];                  \
-            ax[i] = xa_.x;                                                                       \
-            ay[i] = xa_.y;                                                                       \
-            bx[i] = xb_.x;                                                                       \
-            by[i] = xb_.y;                                                                       \
-        }                                                                                        \
+        /* no branch around the loads (an unused slot reads the tile's first entry): see fft_t_z_inv */ \
+        const int e_ = threadIdx.x + i * FFT_T, e = e_ < FFT_C * Nc ? e_ : 0;                    \
+        const int l = e / Nc, k = e - l * Nc;                                                    \
+        const long long ra = (long long) (T_) * (2 * FFT_C) + 2 * l;                             \
+        const double2 xa_ = cm[ra * zpc + k], xb_ = cm[(ra + 1) * zpc + k];                      \
+        ax[i] = xa_.x;                                                                           \
+        ay[i] = xa_.y;                                                                           \
+        bx[i] = xb_.x;                                                                           \
+        by[i] = xb_.y;                                                                           \
     }
     int t = blockIdx.x;
     if(t >= ntot)
@@ -402,6 +401,7 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_inv(double *mesh, const int 
 #pragma unroll
         for(int i = 0; i < E; i++) {
             const int e = threadIdx.x + i * FFT_T;
+            asm volatile("" ::"v"(ax[i]), "v"(ay[i]), "v"(bx[i]), "v"(by[i])); /* every loaded half stays alive up to here: see fft_t_z_inv */
             if(e < FFT_C * Nc) {
                 const int l = e / Nc, k = e - l * Nc;
                 double2 xa = make_double2(ax[i], ay[i]), xb = make_double2(bx[i], by[i]);
@@ -477,8 +477,8 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_strided(double2 *cm, const lon
 #define FFT_FETCH(BASE, ABASE)                                                                   \
     _Pragma("unroll") for(int i = 0; i < E; i++)                                                 \
     {                                                                                            \
-        const int e = threadIdx.x + i * FFT_T;                                                   \
-        if(EXACT || e < FFT_C * N) {                                                             \
+        const int e_ = threadIdx.x + i * FFT_T, e = (EXACT || e_ < FFT_C * N) ? e_ : 0; /* no branch around the loads: see fft_t_z_inv */ \
+        { \
             const int r_ = e / FFT_C, c_ = e % FFT_C;                                            \
             const double2 t_ = PK == 2 ? (ABASE)[(long long) (r_ / ga.nyl) * ga.qstride + (long long) (r_ % ga.nyl) * es + c_] \
                                        : (BASE)[(long long) r_ * es + c_];                       \
@@ -584,8 +584,8 @@ __global__ __launch_bounds__(FFT_T) void fft_t_z_fwd(const double *mesh, double2
 #define FFT_FETCH(T_)                                                                            \
     _Pragma("unroll") for(int i = 0; i < E; i++)                                                 \
     {                                                                                            \
-        const int e = threadIdx.x + i * FFT_T;                                                   \
-        if(EXACT || e < FFT_C * H) {                                                             \
+        const int e_ = threadIdx.x + i * FFT_T, e = (EXACT || e_ < FFT_C * H) ? e_ : 0; /* no branch around the loads: see fft_t_z_inv */ \
+        { \
             const int l_ = e / H;                                                                \
             const long long row = (long long) (T_) * (2 * FFT_C) + 2 * l_;                       \
             const double2 v_ = cm[row * zpc + (e - l_ * H)], w_ = cm[(row + 1) * zpc + (e - l_ * H)]; \
@@ -751,8 +751,8 @@ __global__ __launch_bounds__(FFT_T, fft_tile_waves(N, MODE)) void fft_t_tile(con
         const double2 *b_ = src + (long long) (T_) * (FFT_C * N);                                \
         _Pragma("unroll") for(int i = 0; i < E; i++)                                             \
         {                                                                                        \
-            const int e = threadIdx.x + i * FFT_T;                                               \
-            if(EXACT || e < FFT_C * N) {                                                         \
+            const int e_ = threadIdx.x + i * FFT_T, e = (EXACT || e_ < FFT_C * N) ? e_ : 0; /* no branch around the loads: see fft_t_z_inv */ \
+            { \
                 const double2 t_ = b_[e];                                                        \
                 prx[i] = t_.x;                                                                   \
                 pry[i] = t_.y;                                                                   \
