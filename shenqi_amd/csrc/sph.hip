@@ -347,6 +347,11 @@ template <class F> __device__ __forceinline__ void nl_flush(const int32_t *myl, 
 #ifndef SPH_PROBE
 #define SPH_PROBE 0 /* timing probes of the walk kernels (tools/sph_ab.sh with build_variant.sh): never in a shipped build */
 #endif
+#ifndef SPH_LEAF_ASM
+#define SPH_LEAF_ASM 1 /* the walk-only kernels (KEEP) fetch the PRE32 scan's leaf records by inline-asm scalar loads straight into the
+                          carried registers; 0: the compiler's loads everywhere (A/B knob).  tests/test_leaf_asm_isa_cpu.py reads the ISA
+                          of those kernels and fails if the compiler ever copies or spills the registers while the loads travel */
+#endif
 #ifndef SPH_WALK_WPB
 #define SPH_WALK_WPB 1 /* waves per block of the walk-only kernels (MODE 1) */
 #endif
@@ -407,8 +412,16 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
     }
     int p_cn = 0, p_sb = 0, p_ng = 0;
     unsigned long long p_km = 0ull;
-    float4 pd0, pd1, pd2, pd3, pd4, pd5, pd6, pd7;
-    pd0 = pd1 = pd2 = pd3 = pd4 = pd5 = pd6 = pd7 = make_float4(0.f, 0.f, 0.f, 0.f);
+    /* KEEP (the walk-only kernels of the two-kernel path): the waiting leaf's records by inline-asm scalar loads straight into the
+     * loop-carried registers, waited for in process_pending.  The compiler's own loads go through temporaries and are waited for and
+     * copied at the join (s_waitcnt lgkmcnt(0) + a column of s_mov right behind the loads): nothing travelled while the walk went on.
+     * The asm hides the loads from the compiler, so nothing may copy or spill those registers between the loads and the wait: true of
+     * the walk-only kernels (checked on their ISA by tests/test_leaf_asm_isa_cpu.py at every build of the test suite), not of the fused
+     * kernels, whose evaluation code makes the allocator spill scalars: those keep the compiler's loads. */
+    constexpr bool LEAF_ASM = SPH_LEAF_ASM && KEEP && !GHOSTS;
+    typedef float f4s __attribute__((ext_vector_type(4)));
+    f4s pd0, pd1, pd2, pd3, pd4, pd5, pd6, pd7;
+    pd0 = pd1 = pd2 = pd3 = pd4 = pd5 = pd6 = pd7 = (f4s) (0.f);
 
     /* scan the queued candidates: one coalesced gather, then broadcast reads.  Leaf by leaf (round 4): what is the same for a leaf's
      * particles - which lanes want it, whether a displacement to it can need the periodic wrap at all - is read once per leaf into
@@ -483,6 +496,8 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
     auto process_pending = [&]() {
         if(p_cn == 0 || (SPH_PROBE == 1 && SYM)) /* probe 1: the hydro walk without its candidates */
             return;
+        if(LEAF_ASM)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pd0), "+s"(pd1), "+s"(pd2), "+s"(pd3), "+s"(pd4), "+s"(pd5), "+s"(pd6), "+s"(pd7), "+s"(p_ng));
         if(__builtin_amdgcn_inverse_ballot_w64(p_km) && !(KEEP && ovf)) { /* the lane mask of the whole leaf */
             nint += p_cn - p_ng;
             unsigned int off = ((unsigned int) fill * 64u + (unsigned int) lane) * 4u;
@@ -621,9 +636,20 @@ __device__ __forceinline__ unsigned int ngb_walk(const SphDev &a, char *lds_wave
                 process_pending(); /* leaves are scanned in walk order: the waiting one first */
             if(PRE32 && nearm == 0ull) {
                 /* this leaf waits for its records while the walk goes on */
-                pd0 = ldrec(Cchild); pd1 = ldrec(Cchild + 1); pd2 = ldrec(Cchild + 2); pd3 = ldrec(Cchild + 3);
-                pd4 = ldrec(Cchild + 4); pd5 = ldrec(Cchild + 5); pd6 = ldrec(Cchild + 6); pd7 = ldrec(Cchild + 7);
-                p_ng = ngarbK[Cchild];
+                if(LEAF_ASM) {
+                    const FloatK rp = posfK + 4 * (size_t) Cchild;
+                    const IntK gp = ngarbK + (size_t) Cchild;
+                    asm volatile("s_load_dwordx4 %0, %9, 0x0\n\ts_load_dwordx4 %1, %9, 0x10\n\ts_load_dwordx4 %2, %9, 0x20\n\t"
+                                 "s_load_dwordx4 %3, %9, 0x30\n\ts_load_dwordx4 %4, %9, 0x40\n\ts_load_dwordx4 %5, %9, 0x50\n\t"
+                                 "s_load_dwordx4 %6, %9, 0x60\n\ts_load_dwordx4 %7, %9, 0x70\n\ts_load_dword %8, %10, 0x0"
+                                 : "=&s"(pd0), "=&s"(pd1), "=&s"(pd2), "=&s"(pd3), "=&s"(pd4), "=&s"(pd5), "=&s"(pd6), "=&s"(pd7), "=&s"(p_ng)
+                                 : "s"(rp), "s"(gp));
+                } else {
+                    auto ld4 = [&](const int slot) { const float4 r = ldrec(slot); f4s v; v.x = r.x; v.y = r.y; v.z = r.z; v.w = r.w; return v; };
+                    pd0 = ld4(Cchild); pd1 = ld4(Cchild + 1); pd2 = ld4(Cchild + 2); pd3 = ld4(Cchild + 3);
+                    pd4 = ld4(Cchild + 4); pd5 = ld4(Cchild + 5); pd6 = ld4(Cchild + 6); pd7 = ld4(Cchild + 7);
+                    p_ng = ngarbK[Cchild];
+                }
                 p_km = leafm;
                 p_sb = Cchild;
                 p_cn = Ccount;
