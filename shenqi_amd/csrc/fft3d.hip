@@ -305,21 +305,24 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_fwd(double *mesh, const int 
 {
     extern __shared__ double2 buf[];
     constexpr int LS = fft_ls(N), H = N / 2, Nc = N / 2 + 1;
-    constexpr int E = (FFT_C * N + FFT_T - 1) / FFT_T; /* 16-byte pairs per thread: 2 FFT_C rows of N/2 pairs */
-    constexpr bool EXACT = E * FFT_T == FFT_C * N;
+    constexpr int E = (FFT_C * H + FFT_T - 1) / FFT_T; /* a thread takes the elements z, z + 1 of BOTH real rows of a line: see fft_t_z_fwd */
+    constexpr bool EXACT = E * FFT_T == FFT_C * H;
     double2 *Wl = lds_twiddles<N>(buf, W);
     double2 *cm = reinterpret_cast<double2 *>(mesh);
     const int zpc = zp / 2;
-    double pa[E], pb[E];
+    double pa[E], pb[E], pc[E], pd[E];
 #define FFT_FETCH(T_)                                                                            \
     _Pragma("unroll") for(int i = 0; i < E; i++)                                                 \
     {                                                                                            \
-        const int e_ = threadIdx.x + i * FFT_T, e = (EXACT || e_ < FFT_C * N) ? e_ : 0; /* no branch around the loads: see fft_t_z_inv */ \
+        const int e_ = threadIdx.x + i * FFT_T, e = (EXACT || e_ < FFT_C * H) ? e_ : 0; /* no branch around the loads: see fft_t_z_inv */ \
         { \
-            const long long row = (long long) (T_) * (2 * FFT_C) + e / H;                        \
-            const double2 v_ = cm[row * zpc + (e % H)];                                          \
+            const int l_ = e / H;                                                                \
+            const long long row = (long long) (T_) * (2 * FFT_C) + 2 * l_;                       \
+            const double2 v_ = cm[row * zpc + (e - l_ * H)], w_ = cm[(row + 1) * zpc + (e - l_ * H)]; \
             pa[i] = v_.x;                                                                        \
             pb[i] = v_.y;                                                                        \
+            pc[i] = w_.x;                                                                        \
+            pd[i] = w_.y;                                                                        \
         }                                                                                        \
     }
     int t = blockIdx.x;
@@ -330,16 +333,17 @@ __global__ __launch_bounds__(FFT_T) void fft_pass_z_fwd(double *mesh, const int 
 #pragma unroll
         for(int i = 0; i < E; i++) {
             const int e = threadIdx.x + i * FFT_T;
-            if(EXACT || e < FFT_C * N) {
-                const int r = e / H, z = 2 * (e % H);
-                double a = pa[i], b = pb[i];
+            if(EXACT || e < FFT_C * H) {
+                const int l = e / H, z = 2 * (e - l * H);
+                double a = pa[i], b = pb[i], c = pc[i], d = pd[i];
                 if(FROM_I64) {
                     a = (double) __double_as_longlong(a) * inv_scale;
                     b = (double) __double_as_longlong(b) * inv_scale;
+                    c = (double) __double_as_longlong(c) * inv_scale;
+                    d = (double) __double_as_longlong(d) * inv_scale;
                 }
-                double *dst = reinterpret_cast<double *>(buf + (r >> 1) * LS + lx<N>(z)) + (r & 1); /* z even: the slot of z + 1 is the next one */
-                dst[0] = a;
-                dst[2] = b;
+                buf[l * LS + lx<N>(z)] = make_double2(a, c);
+                buf[l * LS + lx<N>(z + 1)] = make_double2(b, d);
             }
         }
         __syncthreads();
